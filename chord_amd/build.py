@@ -1,0 +1,74 @@
+"""In-tree build of libchordvis.so (HIP kernels + C-ABI + host mirror) for gfx950.
+
+hipcc cross-compiles without a GPU.  Parity kernels are built with
+-ffp-contract=off (no FMA contraction) and HIP's default correctly rounded
+fp32 divide/sqrt — the canonical arithmetic of SURVEY.md §8c.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+BUILD_DIR = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(OUT_DIR, "libchordvis.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+# HIP defaults kept on purpose: -fhip-fp32-correctly-rounded-divide-sqrt (IEEE / and sqrt), denormals preserved.
+DEVICE = ["--offload-arch=gfx950"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _headers_digest():
+    h = hashlib.sha1()
+    for d in (CSRC, os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".h", ".hpp", ".hip.h")):
+                with open(os.path.join(d, f), "rb") as fh:
+                    h.update(fh.read())
+    h.update(" ".join(COMMON + DEVICE).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    hd = _headers_digest()
+    objs, rebuilt = [], False
+    for src in _sources():
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(BUILD_DIR, src + ".o")
+        stamp = obj + ".stamp"
+        with open(path, "rb") as fh:
+            digest = hashlib.sha1(fh.read()).hexdigest() + hd
+        old = open(stamp).read() if os.path.exists(stamp) else ""
+        if force or old != digest or not os.path.exists(obj):
+            cmd = [HIPCC] + COMMON
+            if src.endswith(".hip"):
+                cmd += DEVICE + ["-x", "hip"]
+            cmd += ["-c", path, "-o", obj]
+            if verbose:
+                print("[chord_amd.build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            with open(stamp, "w") as fh:
+                fh.write(digest)
+            rebuilt = True
+        objs.append(obj)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, "-shared", "-fPIC", "-o", LIB] + objs + ["--offload-arch=gfx950"]
+        if verbose:
+            print("[chord_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,739 @@
+// C ABI entry points + the host-side mirror of the reference's pass surface.
+//
+//   chordvis_instance_culling      <- instanceCulling                 instance_culling.cpp:83-161
+//   chordvis_hzb_culling           <- detail::hzbCulling              instance_culling.cpp:286-351
+//   chordvis_render_mesh           <- renderMesh / renderMeshRasterPipe  mesh_raster.cpp:76-254
+//   chordvis_visibility_stage0/1   <- gltfVisibilityRenderingStage0/1 mesh_raster.cpp:269-329
+//   chordvis_build_hzb             <- buildHZB                        hzb.cpp:38-227
+//   chordvis_render_frame          <- DeferredRenderer::render hot segment  renderer.cpp:315-345,489
+//
+// Host code only records work on one HIP stream (the reference records Vulkan commands into one
+// command buffer); counts never come back to the CPU inside a frame.
+
+#include "device_layer.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+using namespace chord;
+
+namespace chord {
+
+int fail(ChordCtx* ctx, int code, const char* what, hipError_t e)
+{
+    if (ctx) {
+        char buf[512];
+        if (e != hipSuccess) std::snprintf(buf, sizeof(buf), "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+        else std::snprintf(buf, sizeof(buf), "%s", what);
+        ctx->lastError = buf;
+    }
+    return code;
+}
+
+} // namespace chord
+
+namespace {
+
+template <typename T>
+int dalloc(ChordCtx* c, T** p, size_t count)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (count == 0) count = 1;
+    CHORD_HIP(c, hipMalloc((void**)p, count * sizeof(T)));
+    return CHORDVIS_OK;
+}
+
+template <typename T>
+void dfree(T*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } }
+
+void record(ChordCtx* c, int id)
+{
+    if (!c->timers) return;
+    (void)hipEventRecord(c->ev[id], c->stream);
+    c->evRecorded[id] = true;
+}
+
+hipEvent_t raster_event(ChordCtx* c)
+{
+    if (c->rasterEvUsed >= c->rasterEv.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        c->rasterEv.push_back(e);
+    }
+    hipEvent_t e = c->rasterEv[c->rasterEvUsed++];
+    return e;
+}
+
+uint64_t stripes_per_rank(const ChordCtx* c)
+{
+    const uint32_t S = c->shard.stripeRows, N = c->shard.ranks;
+    const uint32_t stripes = (c->height + S - 1) / S;
+    return (stripes + N - 1) / N;
+}
+
+int alloc_hzb(ChordCtx* c, HzbBuffers& h)
+{
+    ChordHZBDesc d;
+    if (chordvis_hzb_desc(c->width, c->height, &d) != CHORDVIS_OK) return fail(c, CHORDVIS_E_INVALID, "render size unsupported for HZB");
+    h.desc = d;
+    h.valid = false;
+    int rc;
+    if ((rc = dalloc(c, &h.minTexels, d.totalTexels))) return rc;
+    if ((rc = dalloc(c, &h.maxTexels, d.totalTexels))) return rc;
+    if ((rc = dalloc(c, &h.validRange, 2))) return rc;
+    CHORD_HIP(c, hipMemsetAsync(h.minTexels, 0, sizeof(uint16_t) * d.totalTexels, c->stream));
+    CHORD_HIP(c, hipMemsetAsync(h.maxTexels, 0, sizeof(uint16_t) * d.totalTexels, c->stream));
+    return CHORDVIS_OK;
+}
+
+int configure_targets(ChordCtx* c, uint64_t* external)
+{
+    // visibility words (rank-major when sharded: ranks * stripesPerRank * stripeRows rows)
+    const uint32_t N = c->shard.ranks;
+    c->shard.stripesPerRank = (uint32_t)stripes_per_rank(c);
+    const uint64_t rows = N > 1 ? (uint64_t)N * c->shard.stripesPerRank * c->shard.stripeRows : c->height;
+    c->visWords = rows * c->width;
+    int rc;
+    if (external) {
+        dfree(c->dVisOwned);
+        c->dVis = external; c->visExternal = true;
+    } else {
+        if ((rc = dalloc(c, &c->dVisOwned, c->visWords))) return rc;
+        c->dVis = c->dVisOwned; c->visExternal = false;
+    }
+    if (N > 1) { if ((rc = dalloc(c, &c->dVisResolved, (uint64_t)c->width * c->height))) return rc; }
+    else dfree(c->dVisResolved);
+    for (int i = 0; i < 3; i++) if ((rc = alloc_hzb(c, c->hzb[i]))) return rc;
+    c->historySlot = 0;
+    // mid-frame HZB mip-0 exchange (sharded only)
+    if (N > 1) {
+        c->hzbExchangeChunkHalves = (uint64_t)c->shard.stripesPerRank * (c->shard.stripeRows / 2) * c->hzb[0].desc.width;
+        c->hzbExchangeHalves = c->hzbExchangeChunkHalves * N;
+        if ((rc = dalloc(c, &c->dHzbExchange, c->hzbExchangeHalves))) return rc;
+        CHORD_HIP(c, hipMemsetAsync(c->dHzbExchange, 0, c->hzbExchangeHalves * 2, c->stream));
+    } else {
+        dfree(c->dHzbExchange);
+        c->hzbExchangeHalves = c->hzbExchangeChunkHalves = 0;
+    }
+    return CHORDVIS_OK;
+}
+
+HzbBuffers from_handle(const ChordHZB* h)
+{
+    HzbBuffers b;
+    b.desc = h->desc; b.minTexels = h->minTexels; b.maxTexels = h->maxTexels; b.validRange = h->validRange;
+    b.valid = h->minTexels != nullptr;
+    return b;
+}
+
+CmdList from_handle(const ChordCountAndCmd& h)
+{
+    CmdList l; l.count = h.count; l.cmds = h.cmds; l.capacity = h.capacity; return l;
+}
+
+int ready(ChordCtx* c, const char* fn)
+{
+    if (!c) return CHORDVIS_E_INVALID;
+    if (!c->sceneLoaded || !c->viewSet || !c->dVis) {
+        char buf[160];
+        std::snprintf(buf, sizeof(buf), "%s: upload_scene, allocate_gbuffer and set_view must come first", fn);
+        return fail(c, CHORDVIS_E_INVALID, buf);
+    }
+    return CHORDVIS_OK;
+}
+
+int do_raster(ChordCtx* c, const CmdList& in)
+{
+    // renderMesh (mesh_raster.cpp:208-254): the four (alphaMode x twoSided) pipeline buckets and
+    // their filter passes collapse into one launch; the kernel reads bTwoSided per cluster.
+    launch_raster(c, in);
+    CHORD_HIP(c, hipGetLastError());
+    return CHORDVIS_OK;
+}
+
+} // namespace
+
+// launch_raster records the intermediate events itself when timers are on
+namespace chord {
+hipEvent_t next_raster_event(ChordCtx* c) { return c->timers ? raster_event(c) : nullptr; }
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------ context --
+
+int chordvis_create(int deviceOrdinal, void* hipStream, ChordCtx** outCtx)
+{
+    if (!outCtx) return CHORDVIS_E_INVALID;
+    *outCtx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || deviceOrdinal < 0 || deviceOrdinal >= n) return CHORDVIS_E_NO_DEVICE;
+    ChordCtx* c = new ChordCtx();
+    c->device = deviceOrdinal;
+    if (hipSetDevice(deviceOrdinal) != hipSuccess) { delete c; return CHORDVIS_E_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, deviceOrdinal) == hipSuccess) c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStream) { c->stream = (hipStream_t)hipStream; c->ownStream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CHORDVIS_E_HIP; }
+        c->ownStream = true;
+    }
+    for (int i = 0; i < T_COUNT; i++) (void)hipEventCreate(&c->ev[i]);
+    bool ok = hipMalloc((void**)&c->dView, sizeof(DView)) == hipSuccess &&
+              hipMalloc((void**)&c->dCounts, 4 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void**)&c->dCounters, sizeof(DeviceCounters)) == hipSuccess;
+    if (!ok) { chordvis_destroy(c); return CHORDVIS_E_HIP; }
+    (void)hipMemsetAsync(c->dCounts, 0, 4 * sizeof(uint32_t), c->stream);
+    (void)hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters), c->stream);
+    *outCtx = c;
+    return CHORDVIS_OK;
+}
+
+int chordvis_destroy(ChordCtx* c)
+{
+    if (!c) return CHORDVIS_E_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    dfree(c->dPrims); dfree(c->dGroups); dfree(c->dMeshlets); dfree(c->dGroupIndices); dfree(c->dMeshletData);
+    dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
+    dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
+    for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
+    dfree(c->dCounts); dfree(c->dVisOwned); dfree(c->dVisResolved);
+    for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
+    dfree(c->dHzbExchange); dfree(c->dBigTris); dfree(c->dBigChunks); dfree(c->dClipTris); dfree(c->dCounters);
+    for (int i = 0; i < T_COUNT; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (hipEvent_t e : c->rasterEv) (void)hipEventDestroy(e);
+    if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return CHORDVIS_OK;
+}
+
+const char* chordvis_last_error(ChordCtx* c) { return c ? c->lastError.c_str() : "null context"; }
+
+int chordvis_sync(ChordCtx* c)
+{
+    if (!c) return CHORDVIS_E_INVALID;
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    return CHORDVIS_OK;
+}
+
+// -------------------------------------------------------------------------------------- scene --
+
+int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
+{
+    if (!c || !s || !s->objects || !s->primitives || !s->materials || !s->assets || s->objectCount == 0)
+        return fail(c, CHORDVIS_E_INVALID, "upload_scene: null or empty scene");
+    CHORD_HIP(c, hipSetDevice(c->device));
+
+    // asset bases
+    std::vector<uint32_t> mB(s->assetCount + 1, 0), gB(s->assetCount + 1, 0), iB(s->assetCount + 1, 0), dB(s->assetCount + 1, 0), vB(s->assetCount + 1, 0);
+    for (uint32_t a = 0; a < s->assetCount; a++) {
+        const ChordAssetDesc& as = s->assets[a];
+        if (!as.meshlets || !as.meshletGroups || !as.meshletGroupIndices || !as.meshletData || !as.positions)
+            return fail(c, CHORDVIS_E_INVALID, "upload_scene: asset with null stream");
+        mB[a + 1] = mB[a] + as.meshletCount; gB[a + 1] = gB[a] + as.meshletGroupCount;
+        iB[a + 1] = iB[a] + as.meshletGroupIndexCount; dB[a + 1] = dB[a] + as.meshletDataCount; vB[a + 1] = vB[a] + as.vertexCount;
+    }
+    const uint32_t nM = mB.back(), nG = gB.back(), nI = iB.back(), nD = dB.back(), nV = vB.back();
+
+    std::vector<DMeshlet> meshlets(nM);
+    std::vector<DGroup> groups(nG);
+    std::vector<uint32_t> gidx(nI), mdata(nD);
+    std::vector<float> pos((size_t)nV * 3);
+    for (uint32_t a = 0; a < s->assetCount; a++) {
+        const ChordAssetDesc& as = s->assets[a];
+        for (uint32_t i = 0; i < as.meshletCount; i++) {
+            const ChordMeshlet& m = as.meshlets[i];
+            DMeshlet& d = meshlets[mB[a] + i];
+            std::memcpy(&d, &m, sizeof(ChordMeshlet));
+            const uint32_t V = m.vertexTriangleCount & 0xFFu, T = (m.vertexTriangleCount >> 8) & 0xFFu;
+            if (T > CHORD_MESHLET_MAX_TRIANGLES || m.dataOffset + V + T > as.meshletDataCount)
+                return fail(c, CHORDVIS_E_INVALID, "upload_scene: meshlet exceeds 255 vertices / 128 triangles or its data stream");
+            d.dataOffset = m.dataOffset + dB[a];
+            d.vertexBase = 0xFFFFFFFFu;
+        }
+        for (uint32_t i = 0; i < as.meshletGroupCount; i++) {
+            const ChordMeshletGroup& g = as.meshletGroups[i];
+            DGroup& d = groups[gB[a] + i];
+            std::memcpy(&d, &g, sizeof(ChordMeshletGroup));
+            d.pad0 = d.pad1 = 0;
+            if (g.meshletCount > CHORD_GROUP_MAX_MESHLETS) return fail(c, CHORDVIS_E_INVALID, "upload_scene: group with more than 4 meshlets (nanite_builder.cpp:411-415)");
+        }
+        std::memcpy(gidx.data() + iB[a], as.meshletGroupIndices, sizeof(uint32_t) * as.meshletGroupIndexCount);
+        std::memcpy(mdata.data() + dB[a], as.meshletData, sizeof(uint32_t) * as.meshletDataCount);
+        std::memcpy(pos.data() + (size_t)vB[a] * 3, as.positions, sizeof(float) * 3 * as.vertexCount);
+    }
+
+    // primitives
+    c->hPrims.assign(s->primitiveCount, DPrim{});
+    std::vector<uint32_t> primMeshlets(s->primitiveCount, 0);
+    for (uint32_t pi = 0; pi < s->primitiveCount; pi++) {
+        const ChordPrimitive& p = s->primitives[pi];
+        if (p.primitiveDatasBufferId >= s->assetCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: primitiveDatasBufferId out of range");
+        const uint32_t a = p.primitiveDatasBufferId;
+        const ChordAssetDesc& as = s->assets[a];
+        if (p.meshletGroupOffset + p.meshletGroupCount > as.meshletGroupCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: primitive group range out of bounds");
+        DPrim& d = c->hPrims[pi];
+        std::memcpy(d.posMin, p.posMin, 12); std::memcpy(d.posMax, p.posMax, 12);
+        d.meshletBase = mB[a] + p.meshletOffset;
+        d.groupBase = gB[a] + p.meshletGroupOffset;
+        d.groupIndicesBase = iB[a] + p.meshletGroupIndicesOffset;
+        d.groupCount = p.meshletGroupCount;
+        d.assetMeshletBase = mB[a];
+        for (uint32_t gi = 0; gi < p.meshletGroupCount; gi++) {
+            const ChordMeshletGroup& g = as.meshletGroups[p.meshletGroupOffset + gi];
+            for (uint32_t i = 0; i < g.meshletCount; i++) {
+                const uint32_t ii = p.meshletGroupIndicesOffset + g.meshletOffset + i;
+                if (ii >= as.meshletGroupIndexCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: group index out of bounds");
+                const uint32_t mi = p.meshletOffset + as.meshletGroupIndices[ii];
+                if (mi >= as.meshletCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: meshlet index out of bounds");
+                meshlets[mB[a] + mi].vertexBase = vB[a] + p.vertexOffset;
+                primMeshlets[pi]++;
+            }
+        }
+    }
+
+    // objects
+    c->hObjStatic.assign(s->objectCount, DObjStatic{});
+    uint64_t groupInst = 0, cmdCap = 0;
+    for (uint32_t o = 0; o < s->objectCount; o++) {
+        const ChordObject& ob = s->objects[o];
+        if (ob.GLTFPrimitiveDetail >= s->primitiveCount || ob.GLTFMaterialData >= s->materialCount)
+            return fail(c, CHORDVIS_E_INVALID, "upload_scene: object primitive/material id out of range");
+        DObjStatic& d = c->hObjStatic[o];
+        d.prim = ob.GLTFPrimitiveDetail;
+        d.twoSided = s->materials[ob.GLTFMaterialData].bTwoSided != 0 ? 1u : 0u;
+        d.groupBase = (uint32_t)groupInst;
+        groupInst += c->hPrims[d.prim].groupCount;
+        cmdCap += primMeshlets[d.prim];
+    }
+    if (cmdCap >= CHORD_MAX_INSTANCE_ID || groupInst > 0x7FFFFFFFull)
+        return fail(c, CHORDVIS_E_CAPACITY, "upload_scene: more than 2^24-2 cluster instances do not fit the 24-bit visibility id (base.h:412)");
+    std::vector<uint32_t> owner((size_t)groupInst);
+    for (uint32_t o = 0; o < s->objectCount; o++) {
+        const DObjStatic& d = c->hObjStatic[o];
+        std::fill(owner.begin() + d.groupBase, owner.begin() + d.groupBase + c->hPrims[d.prim].groupCount, o);
+    }
+
+    c->objectCount = s->objectCount; c->primCount = s->primitiveCount; c->materialCount = s->materialCount;
+    c->meshletCount = nM; c->groupCount = nG;
+    c->groupInstances = (uint32_t)groupInst; c->cmdCapacity = (uint32_t)std::max<uint64_t>(cmdCap, 1);
+    c->cullBlocks = std::max(1u, (c->groupInstances + 255u) / 256u);
+
+    int rc;
+#define UP(dst, vec)                                                                                          \
+    if ((rc = dalloc(c, &dst, vec.size()))) return rc;                                                        \
+    if (!vec.empty()) CHORD_HIP(c, hipMemcpy(dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
+    UP(c->dMeshlets, meshlets) UP(c->dGroups, groups) UP(c->dGroupIndices, gidx) UP(c->dMeshletData, mdata)
+    UP(c->dPositions, pos) UP(c->dPrims, c->hPrims) UP(c->dObjStatic, c->hObjStatic) UP(c->dGroupOwner, owner)
+#undef UP
+    if ((rc = dalloc(c, &c->dObjectsOwned, (size_t)s->objectCount))) return rc;
+    CHORD_HIP(c, hipMemcpy(c->dObjectsOwned, s->objects, sizeof(ChordObject) * s->objectCount, hipMemcpyHostToDevice));
+    c->dObjects = c->dObjectsOwned;
+    if ((rc = dalloc(c, &c->dObjFrame, (size_t)s->objectCount))) return rc;
+    if ((rc = dalloc(c, &c->dGroupMask, (size_t)c->groupInstances))) return rc;
+    if ((rc = dalloc(c, &c->dBlockCounts, (size_t)c->cullBlocks))) return rc;
+    for (int i = 0; i < 3; i++) {
+        if ((rc = dalloc(c, &c->lists[i].cmds, (size_t)c->cmdCapacity))) return rc;
+        c->lists[i].count = c->dCounts + i;
+        c->lists[i].capacity = c->cmdCapacity;
+    }
+    // deferred raster lists (fixed budgets; overflow is detected and reported by chordvis_stats)
+    c->bigTriCap = 2u << 20; c->bigChunkCap = 8u << 20; c->clipTriCap = 1u << 20;
+    if ((rc = dalloc(c, &c->dBigTris, (size_t)c->bigTriCap))) return rc;
+    if ((rc = dalloc(c, &c->dBigChunks, (size_t)c->bigChunkCap))) return rc;
+    if ((rc = dalloc(c, &c->dClipTris, (size_t)c->clipTriCap))) return rc;
+    c->sceneLoaded = true;
+    c->historySlot = 0;
+    return CHORDVIS_OK;
+}
+
+int chordvis_update_objects(ChordCtx* c, const ChordObject* hostObjects, uint32_t count)
+{
+    if (!c || !c->sceneLoaded || !hostObjects || count != c->objectCount) return fail(c, CHORDVIS_E_INVALID, "update_objects: count must equal the uploaded scene's objectCount");
+    CHORD_HIP(c, hipMemcpyAsync(c->dObjectsOwned, hostObjects, sizeof(ChordObject) * count, hipMemcpyHostToDevice, c->stream));
+    c->dObjects = c->dObjectsOwned;
+    return CHORDVIS_OK;
+}
+
+int chordvis_bind_objects(ChordCtx* c, const ChordObject* deviceObjects, uint32_t count)
+{
+    if (!c || !c->sceneLoaded || !deviceObjects || count != c->objectCount) return fail(c, CHORDVIS_E_INVALID, "bind_objects: count must equal the uploaded scene's objectCount");
+    c->dObjects = deviceObjects;
+    return CHORDVIS_OK;
+}
+
+int chordvis_set_view(ChordCtx* c, const ChordCameraView* view, const ChordInstanceCullingView* iv, uint32_t switchFlags)
+{
+    if (!c || !view || !iv) return fail(c, CHORDVIS_E_INVALID, "set_view: null argument");
+    c->hView.view = *view; c->hView.iv = *iv; c->hView.flags = switchFlags;
+    c->hView.width = (uint32_t)iv->renderDimension[0]; c->hView.height = (uint32_t)iv->renderDimension[1];
+    if (c->dVis && (c->hView.width != c->width || c->hView.height != c->height))
+        return fail(c, CHORDVIS_E_INVALID, "set_view: renderDimension differs from the allocated gbuffer");
+    // small constant block: stream-ordered copy from a context-owned staging copy
+    CHORD_HIP(c, hipMemcpyAsync(c->dView, &c->hView, sizeof(DView), hipMemcpyHostToDevice, c->stream));
+    c->viewSet = true;
+    return CHORDVIS_OK;
+}
+
+int chordvis_allocate_gbuffer(ChordCtx* c, uint32_t width, uint32_t height, uint64_t* deviceVisibility)
+{
+    if (!c || width < 64 || height < 64 || width > 4096 || height > 4096)      // renderer.h:52-53
+        return fail(c, CHORDVIS_E_INVALID, "allocate_gbuffer: render size must be 64..4096 per axis (renderer.h:52-53)");
+    CHORD_HIP(c, hipSetDevice(c->device));
+    c->width = width; c->height = height;
+    return configure_targets(c, deviceVisibility);
+}
+
+int chordvis_set_shard(ChordCtx* c, uint32_t stripeRows, uint32_t ranks, uint32_t rank)
+{
+    if (!c || ranks == 0 || rank >= ranks || stripeRows < 2 || (stripeRows & 1u)) return fail(c, CHORDVIS_E_INVALID, "set_shard: stripeRows must be even, rank < ranks");
+    c->shard.stripeRows = stripeRows; c->shard.ranks = ranks; c->shard.rank = rank;
+    if (c->width) {
+        if (c->visExternal) { c->dVis = nullptr; return fail(c, CHORDVIS_E_INVALID, "set_shard after allocate_gbuffer with an external buffer: call allocate_gbuffer again"); }
+        return configure_targets(c, nullptr);
+    }
+    return CHORDVIS_OK;
+}
+
+uint64_t chordvis_visibility_words(ChordCtx* c)
+{
+    if (!c) return 0;
+    if (c->width == 0) return 0;
+    const uint32_t N = c->shard.ranks;
+    const uint64_t rows = N > 1 ? (uint64_t)N * stripes_per_rank(c) * c->shard.stripeRows : c->height;
+    return rows * c->width;
+}
+uint64_t chordvis_visibility_chunk_words(ChordCtx* c) { return c ? chordvis_visibility_words(c) / c->shard.ranks : 0; }
+uint64_t* chordvis_visibility_ptr(ChordCtx* c) { return c ? c->dVis : nullptr; }
+uint64_t* chordvis_resolved_visibility_ptr(ChordCtx* c) { return c ? (c->shard.ranks > 1 ? c->dVisResolved : c->dVis) : nullptr; }
+uint16_t* chordvis_hzb_exchange_ptr(ChordCtx* c) { return c ? c->dHzbExchange : nullptr; }
+uint64_t chordvis_hzb_exchange_halves(ChordCtx* c) { return c ? c->hzbExchangeHalves : 0; }
+uint64_t chordvis_hzb_exchange_chunk_halves(ChordCtx* c) { return c ? c->hzbExchangeChunkHalves : 0; }
+
+// -------------------------------------------------------------------------------------- passes --
+
+int chordvis_clear_gbuffer(ChordCtx* c)
+{
+    int rc = ready(c, "clear_gbuffer");
+    if (rc) return rc;
+    // visibility = 0 / depth = 0.0 (render_textures.cpp:81-85,98-100).  Sharded: only the rank's own
+    // chunk needs clearing (the all-gather overwrites the rest).
+    if (c->shard.ranks > 1) {
+        const uint64_t chunk = c->visWords / c->shard.ranks;
+        CHORD_HIP(c, hipMemsetAsync(c->dVis + chunk * c->shard.rank, 0, chunk * 8, c->stream));
+    } else {
+        CHORD_HIP(c, hipMemsetAsync(c->dVis, 0, c->visWords * 8, c->stream));
+    }
+    CHORD_HIP(c, hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters), c->stream));
+    c->rasterEvUsed = 0;
+    return CHORDVIS_OK;
+}
+
+int chordvis_instance_culling(ChordCtx* c, ChordCountAndCmd* out)
+{
+    int rc = ready(c, "instance_culling");
+    if (rc) return rc;
+    launch_object_cull(c);                               // instanceCullingCS
+    launch_group_cull(c, c->lists[0]);                   // clusterGroupCullingCS (count + scatter)
+    CHORD_HIP(c, hipGetLastError());
+    if (out) *out = c->lists[0].handle();
+    return CHORDVIS_OK;
+}
+
+int chordvis_hzb_culling(ChordCtx* c, const ChordHZB* hzb, int bFirstStage, ChordCountAndCmd in,
+                         ChordCountAndCmd* outVisible, ChordCountAndCmd* outRejected)
+{
+    int rc = ready(c, "hzb_culling");
+    if (rc) return rc;
+    if (!hzb || !hzb->minTexels || !in.count || !in.cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling: invalid HZB or command list");
+    const HzbBuffers hb = from_handle(hzb);
+    const CmdList inL = from_handle(in);
+    if (bFirstStage) {
+        if (inL.cmds == c->lists[1].cmds || inL.cmds == c->lists[2].cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling: first stage input must be the instanceCulling list");
+        CHORD_HIP(c, hipMemsetAsync(c->dCounts + 1, 0, 8, c->stream));
+        launch_hzb_cull(c, hb, 0, inL, c->lists[1], &c->lists[2]);
+        if (outVisible) *outVisible = c->lists[1].handle();
+        if (outRejected) *outRejected = c->lists[2].handle();
+    } else {
+        if (inL.cmds == c->lists[1].cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling: second stage input aliases its output");
+        CmdList vis1 = c->lists[1];
+        vis1.count = c->dCounts + 3;
+        CHORD_HIP(c, hipMemsetAsync(c->dCounts + 3, 0, 4, c->stream));
+        launch_hzb_cull(c, hb, 1, inL, vis1, nullptr);
+        if (outVisible) *outVisible = vis1.handle();
+        if (outRejected) *outRejected = ChordCountAndCmd{nullptr, nullptr, 0};
+    }
+    CHORD_HIP(c, hipGetLastError());
+    return CHORDVIS_OK;
+}
+
+int chordvis_render_mesh(ChordCtx* c, ChordCountAndCmd in)
+{
+    int rc = ready(c, "render_mesh");
+    if (rc) return rc;
+    if (!in.count || !in.cmds) return CHORDVIS_OK;       // {nullptr, nullptr}: nothing to render (instance_culling.cpp:92-95)
+    return do_raster(c, from_handle(in));
+}
+
+int chordvis_visibility_stage0(ChordCtx* c, const ChordHZB* hzbPrev, ChordCountAndCmd in, ChordCountAndCmd* outRejected, int* shouldStage1)
+{
+    int rc = ready(c, "visibility_stage0");
+    if (rc) return rc;
+    if (shouldStage1) *shouldStage1 = 0;
+    if (outRejected) *outRejected = ChordCountAndCmd{nullptr, nullptr, 0};
+    const bool hzbOn = hzbPrev && hzbPrev->minTexels && (c->hView.flags & CHORD_FLAG_HZB_CULL);   // mesh_raster.cpp:293
+    if (hzbOn) {
+        ChordCountAndCmd vis, rej;
+        if ((rc = chordvis_hzb_culling(c, hzbPrev, 1, in, &vis, &rej))) return rc;
+        if ((rc = chordvis_render_mesh(c, vis))) return rc;
+        if (outRejected) *outRejected = rej;
+        if (shouldStage1) *shouldStage1 = 1;
+    } else {
+        if ((rc = chordvis_render_mesh(c, in))) return rc;
+    }
+    return CHORDVIS_OK;
+}
+
+int chordvis_visibility_stage1(ChordCtx* c, const ChordHZB* hzb, ChordCountAndCmd in)
+{
+    int rc = ready(c, "visibility_stage1");
+    if (rc) return rc;
+    ChordCountAndCmd vis;
+    if ((rc = chordvis_hzb_culling(c, hzb, 0, in, &vis, nullptr))) return rc;
+    return chordvis_render_mesh(c, vis);
+}
+
+int chordvis_build_hzb(ChordCtx* c, int bBuildMin, int bBuildMax, int bBuildValidRange, int slot, ChordHZB* out)
+{
+    int rc = ready(c, "build_hzb");
+    if (rc) return rc;
+    if (slot < 0 || slot > 2 || !(bBuildMin || bBuildMax) || (bBuildValidRange && !(bBuildMin && bBuildMax)))   // hzb.cpp:43-47
+        return fail(c, CHORDVIS_E_INVALID, "build_hzb: slot in 0..2, at least one channel, valid range needs min and max");
+    launch_hzb_build(c, c->hzb[slot], bBuildMin != 0, bBuildMax != 0, bBuildValidRange != 0, false);
+    CHORD_HIP(c, hipGetLastError());
+    if (out) {
+        *out = c->hzb[slot].handle();
+        if (!bBuildMax) out->maxTexels = nullptr;
+        if (!bBuildValidRange) out->validRange = nullptr;
+    }
+    return CHORDVIS_OK;
+}
+
+int chordvis_reset_history(ChordCtx* c)
+{
+    if (!c) return CHORDVIS_E_INVALID;
+    c->historySlot = 0;
+    return CHORDVIS_OK;
+}
+
+int chordvis_render_frame(ChordCtx* c)
+{
+    int rc = ready(c, "render_frame");
+    if (rc) return rc;
+    if (c->shard.ranks > 1) return fail(c, CHORDVIS_E_INVALID, "render_frame: sharded contexts use frame_phase_a/b/c");
+    for (int i = 0; i < T_COUNT; i++) c->evRecorded[i] = false;
+    record(c, T_FRAME_BEGIN);
+    if ((rc = chordvis_clear_gbuffer(c))) return rc;                                  // renderer.cpp:315
+    record(c, T_CLEAR);
+    ChordCountAndCmd post;
+    if ((rc = chordvis_instance_culling(c, &post))) return rc;                        // :321
+    record(c, T_CULL);
+    ChordHZB hist;
+    const bool haveHist = c->historySlot != 0;
+    if (haveHist) hist = c->hzb[c->historySlot].handle();
+    ChordCountAndCmd rejected;
+    int stage1 = 0;
+    if ((rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1))) return rc;   // :326
+    record(c, T_STAGE0);
+    c->shouldStage1 = stage1 != 0;
+    if (stage1) {
+        ChordHZB tmp;
+        if ((rc = chordvis_build_hzb(c, 1, 0, 0, 0, &tmp))) return rc;                // :334
+        record(c, T_HZB0);
+        if ((rc = chordvis_visibility_stage1(c, &tmp, rejected))) return rc;          // :337
+        record(c, T_STAGE1);
+    }
+    const int next = c->historySlot == 1 ? 2 : 1;
+    if ((rc = chordvis_build_hzb(c, 1, 1, 1, next, nullptr))) return rc;              // :343
+    record(c, T_HZBF);
+    c->historySlot = next;                                                            // :489
+    return CHORDVIS_OK;
+}
+
+// Sharded frame, phase a: everything up to the stage-0 raster + own-stripe HZB mip 0.
+int chordvis_frame_phase_a(ChordCtx* c)
+{
+    int rc = ready(c, "frame_phase_a");
+    if (rc) return rc;
+    for (int i = 0; i < T_COUNT; i++) c->evRecorded[i] = false;
+    record(c, T_FRAME_BEGIN);
+    if ((rc = chordvis_clear_gbuffer(c))) return rc;
+    record(c, T_CLEAR);
+    ChordCountAndCmd post;
+    if ((rc = chordvis_instance_culling(c, &post))) return rc;
+    record(c, T_CULL);
+    ChordHZB hist;
+    const bool haveHist = c->historySlot != 0;
+    if (haveHist) hist = c->hzb[c->historySlot].handle();
+    ChordCountAndCmd rejected;
+    int stage1 = 0;
+    if ((rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1))) return rc;
+    c->shouldStage1 = stage1 != 0;
+    c->lastRejected = from_handle(rejected);
+    if (stage1 && c->shard.ranks > 1) { launch_hzb_mip0_exchange(c); CHORD_HIP(c, hipGetLastError()); }
+    record(c, T_STAGE0);
+    return CHORDVIS_OK;
+}
+
+// phase b: [exchange buffer all-gathered by the caller] -> HZB chain -> stage 1.
+int chordvis_frame_phase_b(ChordCtx* c)
+{
+    int rc = ready(c, "frame_phase_b");
+    if (rc) return rc;
+    if (!c->shouldStage1) return CHORDVIS_OK;
+    if (c->shard.ranks > 1) launch_hzb_build(c, c->hzb[0], true, false, false, true);
+    else launch_hzb_build(c, c->hzb[0], true, false, false, false);
+    CHORD_HIP(c, hipGetLastError());
+    record(c, T_HZB0);
+    ChordHZB tmp = c->hzb[0].handle();
+    if ((rc = chordvis_visibility_stage1(c, &tmp, c->lastRejected.handle()))) return rc;
+    record(c, T_STAGE1);
+    return CHORDVIS_OK;
+}
+
+// phase c: [visibility buffer all-gathered in place by the caller] -> row-major copy + final HZB.
+int chordvis_frame_phase_c(ChordCtx* c)
+{
+    int rc = ready(c, "frame_phase_c");
+    if (rc) return rc;
+    if (c->shard.ranks > 1) { launch_detile(c); CHORD_HIP(c, hipGetLastError()); }
+    const int next = c->historySlot == 1 ? 2 : 1;
+    if ((rc = chordvis_build_hzb(c, 1, 1, 1, next, nullptr))) return rc;
+    record(c, T_HZBF);
+    c->historySlot = next;
+    return CHORDVIS_OK;
+}
+
+int chordvis_last_frame_cmds(ChordCtx* c, ChordCountAndCmd* out)
+{
+    if (!c || !out || !c->sceneLoaded) return fail(c, CHORDVIS_E_INVALID, "last_frame_cmds: no scene");
+    *out = c->lists[0].handle();
+    return CHORDVIS_OK;
+}
+
+int chordvis_history_hzb(ChordCtx* c, ChordHZB* out)
+{
+    if (!c || !out || c->historySlot == 0) return fail(c, CHORDVIS_E_INVALID, "history_hzb: no history yet");
+    *out = c->hzb[c->historySlot].handle();
+    return CHORDVIS_OK;
+}
+
+// ------------------------------------------------------------------------------ readback/stats --
+
+int chordvis_readback_visibility(ChordCtx* c, uint64_t* host)
+{
+    if (!c || !host || !c->dVis) return fail(c, CHORDVIS_E_INVALID, "readback_visibility: no gbuffer");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t* src = c->shard.ranks > 1 ? c->dVisResolved : c->dVis;
+    CHORD_HIP(c, hipMemcpy(host, src, (size_t)c->width * c->height * 8, hipMemcpyDeviceToHost));
+    return CHORDVIS_OK;
+}
+
+int chordvis_readback_cmds(ChordCtx* c, ChordCountAndCmd h, ChordDrawCmd* host, uint32_t cap, uint32_t* outCount)
+{
+    if (!c || !h.count || !h.cmds || !outCount) return fail(c, CHORDVIS_E_INVALID, "readback_cmds: invalid handle");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t n = 0;
+    CHORD_HIP(c, hipMemcpy(&n, h.count, 4, hipMemcpyDeviceToHost));
+    *outCount = n;
+    const uint32_t m = std::min(std::min(n, cap), h.capacity);
+    if (host && m) {
+        CHORD_HIP(c, hipMemcpy(host, h.cmds, sizeof(ChordDrawCmd) * m, hipMemcpyDeviceToHost));
+        // device meshlet ids are flattened over assets; hand back asset-relative ids (the reference's cmd.y)
+        for (uint32_t i = 0; i < m; i++) {
+            if (host[i].objectId < c->objectCount) host[i].meshletId -= c->hPrims[c->hObjStatic[host[i].objectId].prim].assetMeshletBase;
+        }
+    }
+    return CHORDVIS_OK;
+}
+
+int chordvis_readback_hzb(ChordCtx* c, const ChordHZB* hzb, uint16_t* hostMin, uint16_t* hostMax, uint32_t hostValidRange[2])
+{
+    if (!c || !hzb) return fail(c, CHORDVIS_E_INVALID, "readback_hzb: null handle");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t bytes = sizeof(uint16_t) * hzb->desc.totalTexels;
+    if (hostMin && hzb->minTexels) CHORD_HIP(c, hipMemcpy(hostMin, hzb->minTexels, bytes, hipMemcpyDeviceToHost));
+    if (hostMax && hzb->maxTexels) CHORD_HIP(c, hipMemcpy(hostMax, hzb->maxTexels, bytes, hipMemcpyDeviceToHost));
+    if (hostValidRange && hzb->validRange) CHORD_HIP(c, hipMemcpy(hostValidRange, hzb->validRange, 8, hipMemcpyDeviceToHost));
+    return CHORDVIS_OK;
+}
+
+int chordvis_upload_history_hzb(ChordCtx* c, const uint16_t* hostMin)
+{
+    if (!c || !hostMin || !c->dVis) return fail(c, CHORDVIS_E_INVALID, "upload_history_hzb: no gbuffer");
+    const int slot = c->historySlot == 1 ? 2 : 1;
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    CHORD_HIP(c, hipMemcpy(c->hzb[slot].minTexels, hostMin, sizeof(uint16_t) * c->hzb[slot].desc.totalTexels, hipMemcpyHostToDevice));
+    c->hzb[slot].valid = true;
+    c->historySlot = slot;
+    return CHORDVIS_OK;
+}
+
+int chordvis_enable_timers(ChordCtx* c, int enable)
+{
+    if (!c) return CHORDVIS_E_INVALID;
+    c->timers = enable != 0;
+    return CHORDVIS_OK;
+}
+
+int chordvis_stats(ChordCtx* c, ChordStats* out)
+{
+    if (!c || !out) return fail(c, CHORDVIS_E_INVALID, "stats: null argument");
+    std::memset(out, 0, sizeof(*out));
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t counts[4] = {0, 0, 0, 0};
+    CHORD_HIP(c, hipMemcpy(counts, c->dCounts, sizeof(counts), hipMemcpyDeviceToHost));
+    DeviceCounters dc;
+    CHORD_HIP(c, hipMemcpy(&dc, c->dCounters, sizeof(dc), hipMemcpyDeviceToHost));
+    out->countInstanceCulled = counts[0];
+    if (c->shouldStage1) {
+        out->countStage0Visible = counts[1]; out->countStage0Rejected = counts[2]; out->countStage1Visible = counts[3];
+        out->trianglesSubmitted = dc.trisHzbVisible0 + dc.trisHzbVisible1;
+    } else {
+        out->countStage0Visible = counts[0];
+        out->trianglesSubmitted = dc.trisInstanceCulled;
+    }
+    out->overflow = dc.overflow;
+    out->rasterLaunches = c->rasterEvUsed / 4;
+    if (c->timers) {
+        auto span = [&](int a, int b) -> float {
+            float ms = 0.0f;
+            if (c->evRecorded[a] && c->evRecorded[b] && hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) == hipSuccess) return ms;
+            return 0.0f;
+        };
+        out->msClear = span(T_FRAME_BEGIN, T_CLEAR);
+        out->msInstanceCulling = span(T_CLEAR, T_CULL);
+        out->msStage0 = span(T_CULL, T_STAGE0);
+        if (c->shouldStage1) {
+            out->msHzbStage0 = span(T_STAGE0, T_HZB0);
+            out->msStage1 = span(T_HZB0, T_STAGE1);
+            out->msHzbFinal = span(T_STAGE1, T_HZBF);
+        } else {
+            out->msHzbFinal = span(T_STAGE0, T_HZBF);
+        }
+        out->msFrame = span(T_FRAME_BEGIN, T_HZBF);
+        for (uint32_t i = 0; i + 3 < c->rasterEvUsed; i += 4) {
+            float a = 0, b = 0, d = 0;
+            (void)hipEventElapsedTime(&a, c->rasterEv[i], c->rasterEv[i + 1]);
+            (void)hipEventElapsedTime(&b, c->rasterEv[i + 1], c->rasterEv[i + 2]);
+            (void)hipEventElapsedTime(&d, c->rasterEv[i + 2], c->rasterEv[i + 3]);
+            out->msRasterCluster += a; out->msRasterClip += b; out->msRasterChunk += d;
+        }
+    }
+    if (dc.overflow) return fail(c, CHORDVIS_E_CAPACITY, "a deferred raster list overflowed this frame; the visibility buffer is incomplete");
+    return CHORDVIS_OK;
+}
+
+} // extern "C"

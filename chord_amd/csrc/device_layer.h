@@ -1,0 +1,211 @@
+// Thin HIP device layer under the pass surface: the counterpart of the reference's
+// Vulkan layer in source/graphics (Context graphics.h:88-345, buffer pool
+// buffer_pool.h:16-144, queue command_list.h:69-199, GPU timestamps query.cpp:5-127).
+//
+// One context = one device + one stream.  All buffers are plain hipMalloc
+// allocations sized from scene upper bounds at upload time (the reference sizes
+// its command buffers from lod0MeshletCount the same way, instance_culling.cpp:141).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "chordvis.h"
+
+namespace chord {
+
+// ---- flattened, pre-resolved scene records (bindless indirections removed at upload) ------
+
+struct DPrim {                 // per GLTFPrimitiveBuffer, 48 B
+    float    posMin[3]; uint32_t meshletBase;       // asset meshlet base + primitive.meshletOffset
+    float    posMax[3]; uint32_t groupBase;         // asset group base + primitive.meshletGroupOffset
+    uint32_t groupIndicesBase;                      // asset index base + primitive.meshletGroupIndicesOffset
+    uint32_t groupCount;
+    uint32_t assetMeshletBase;                      // to convert device meshlet ids back to asset-relative ones
+    uint32_t pad;
+};
+
+struct DGroup {                // GPUGLTFMeshletGroup padded to 48 B for 16-B loads
+    float    clusterPosCenter[3]; float parentError;
+    float    parentPosCenter[3];  float error;
+    uint32_t meshletOffset; uint32_t meshletCount; uint32_t pad0; uint32_t pad1;
+};
+
+struct DMeshlet {              // GPUGLTFMeshlet with dataOffset globalised and lod -> vertexBase
+    float    posMin[3]; uint32_t dataOffset;
+    float    posMax[3]; uint32_t vertexTriangleCount;
+    float    coneAxis[3]; float coneCutOff;
+    float    coneApex[3]; uint32_t vertexBase;      // asset vertex base + primitive.vertexOffset
+};
+
+struct DObjStatic {            // per object, derived once per upload, 16 B
+    uint32_t prim;
+    uint32_t twoSided;
+    uint32_t groupBase;        // first flattened (object, group) index
+    uint32_t pad;
+};
+
+struct DObjFrame {             // per object, per frame (written by the object-cull kernel), 208 B
+    float    mvp[16];          // row-major VP * M            (mesh_raster.hlsl:90-91)
+    float    mvpLast[16];      // row-major VP_last * M_last  (hzb_mainview_culling.hlsl:77-83)
+    float    localToView[12];  // rows 0..2 of V * M          (instance_culling.hlsl:170)
+    float    camLS[3];         // mul(translatedWorldToLocal, (0,0,0,1)).xyz (nanite_shared.hlsli:65)
+    float    maxScale;         // scaleExtractFromMatrix.w
+    uint32_t visible;
+    uint32_t isOrtho;          // mul(VP, M)[3][3] == 1 (base.hlsli:243-246)
+    uint32_t pad[2];
+};
+
+struct DView {                 // constants of one frame
+    ChordCameraView          view;
+    ChordInstanceCullingView iv;
+    uint32_t                 flags;
+    uint32_t                 width, height;
+    uint32_t                 pad;
+};
+
+struct ShardInfo {
+    uint32_t stripeRows, ranks, rank, stripesPerRank;
+};
+
+// Deferred work produced by the raster kernel (device lists, counts in DeviceCounters)
+struct BigTri {                // 48 B: a triangle too large for the per-cluster wave
+    int32_t  X[3]; int32_t Y[3];
+    float    d[3];
+    uint32_t payload;
+    uint32_t twoSided;
+    uint32_t pad;
+};
+struct BigChunk { uint32_t tri; uint32_t cxy; };            // 64x64-pixel chunk (cx | cy << 16)
+struct ClipTri { uint32_t cmdIndex; uint32_t tri; };       // needs the homogeneous clipper
+
+// The deferred lists are cut into LIST_SHARDS independent sub-lists (own counter, own region) so
+// that list allocation is not serialised on one memory-side atomic (one word sustains only
+// ~88 returning atomics/us on MI355X); a wave picks its shard from its global wave id.
+#define CHORD_LIST_SHARDS 64u
+struct DeviceCounters {
+    uint32_t bigTriCount[CHORD_LIST_SHARDS];
+    uint32_t bigChunkCount[CHORD_LIST_SHARDS];
+    uint32_t clipTriCount;
+    uint32_t overflow;                          // bit0 big lists, bit1 clip list
+    uint32_t pad[2];
+    // triangles (meshlet triangle counts) of the commands each list producer emitted this frame
+    unsigned long long trisInstanceCulled, trisHzbVisible0, trisHzbVisible1, pad2;
+};
+#define CHORD_COUNTERS_RESET_BYTES (CHORD_LIST_SHARDS * 8u + 4u)   // per raster launch: list counts only
+
+struct CmdList {
+    uint32_t*     count = nullptr;
+    ChordDrawCmd* cmds = nullptr;
+    uint32_t      capacity = 0;
+    ChordCountAndCmd handle() const { return ChordCountAndCmd{count, cmds, capacity}; }
+};
+
+struct HzbBuffers {
+    ChordHZBDesc desc{};
+    uint16_t* minTexels = nullptr;
+    uint16_t* maxTexels = nullptr;
+    uint32_t* validRange = nullptr;
+    bool valid = false;
+    ChordHZB handle() const { return ChordHZB{desc, minTexels, maxTexels, validRange}; }
+};
+
+enum TimerId { T_FRAME_BEGIN = 0, T_CLEAR, T_CULL, T_STAGE0, T_HZB0, T_STAGE1, T_HZBF, T_COUNT };
+
+} // namespace chord
+
+struct ChordCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    std::string lastError;
+    int numCUs = 256;
+
+    // scene
+    bool sceneLoaded = false;
+    uint32_t objectCount = 0, primCount = 0, materialCount = 0;
+    uint32_t meshletCount = 0, groupCount = 0;
+    uint32_t groupInstances = 0;      // sum over objects of their primitive's group count
+    uint32_t cmdCapacity = 0;         // sum over objects of their primitive's meshlet count (all LODs)
+    chord::DPrim* dPrims = nullptr;
+    chord::DGroup* dGroups = nullptr;
+    chord::DMeshlet* dMeshlets = nullptr;
+    uint32_t* dGroupIndices = nullptr;
+    uint32_t* dMeshletData = nullptr;
+    float* dPositions = nullptr;
+    chord::DObjStatic* dObjStatic = nullptr;
+    uint32_t* dGroupOwner = nullptr;  // object id per flattened (object, group)
+    ChordObject* dObjectsOwned = nullptr;
+    const ChordObject* dObjects = nullptr;
+    std::vector<chord::DPrim> hPrims;
+    std::vector<chord::DObjStatic> hObjStatic;
+
+    // frame
+    chord::DView hView{};
+    chord::DView* dView = nullptr;
+    bool viewSet = false;
+    chord::DObjFrame* dObjFrame = nullptr;
+    uint8_t* dGroupMask = nullptr;
+    uint32_t* dBlockCounts = nullptr;
+    uint32_t cullBlocks = 0;
+
+    // command lists: 0 = post instanceCulling, 1 = hzb visible, 2 = hzb rejected
+    chord::CmdList lists[3];
+    uint32_t* dCounts = nullptr;      // 4 x u32 backing the list counts
+
+    // gbuffer
+    uint32_t width = 0, height = 0;
+    chord::ShardInfo shard{64, 1, 0, 0};
+    uint64_t* dVis = nullptr;         // in use (owned or caller's)
+    uint64_t* dVisOwned = nullptr;
+    uint64_t* dVisResolved = nullptr; // row-major copy when ranks > 1
+    uint64_t visWords = 0;
+    bool visExternal = false;
+
+    // HZB: slot 0 temp, 1/2 history ping-pong
+    chord::HzbBuffers hzb[3];
+    int historySlot = 0;              // 0 = none, else 1 or 2
+    uint16_t* dHzbExchange = nullptr;
+    uint64_t hzbExchangeHalves = 0, hzbExchangeChunkHalves = 0;
+
+    // deferred raster work
+    chord::BigTri* dBigTris = nullptr;
+    chord::BigChunk* dBigChunks = nullptr;
+    chord::ClipTri* dClipTris = nullptr;
+    uint32_t bigTriCap = 0, bigChunkCap = 0, clipTriCap = 0;
+    chord::DeviceCounters* dCounters = nullptr;
+
+    // timers
+    bool timers = false;
+    hipEvent_t ev[chord::T_COUNT]{};
+    bool evRecorded[chord::T_COUNT]{};
+    std::vector<hipEvent_t> rasterEv;  // pairs
+    uint32_t rasterEvUsed = 0;
+    bool shouldStage1 = false;
+    chord::CmdList lastRejected;
+};
+
+namespace chord {
+
+int fail(ChordCtx* ctx, int code, const char* what, hipError_t e = hipSuccess);
+
+#define CHORD_HIP(ctx, call)                                                         \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess) return ::chord::fail((ctx), CHORDVIS_E_HIP, #call, e_); \
+    } while (0)
+
+// kernel launchers (implemented in the .hip translation units) ---------------------------------
+void launch_object_cull(ChordCtx* c);
+void launch_group_cull(ChordCtx* c, const CmdList& out);
+void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
+                     const CmdList* outRejected);
+void launch_raster(ChordCtx* c, const CmdList& in);
+void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange, bool fromExchange);
+void launch_hzb_mip0_exchange(ChordCtx* c);
+void launch_detile(ChordCtx* c);
+hipEvent_t next_raster_event(ChordCtx* c);      // nullptr when timers are off
+
+} // namespace chord

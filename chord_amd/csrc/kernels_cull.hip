@@ -1,0 +1,404 @@
+// Culling kernels of the visibility path, hand-written for gfx950 (wave64).
+//
+//   object_cull_kernel          <- instanceCullingCS          instance_culling.hlsl:47-131
+//   group_cull_count/scatter    <- clusterGroupCullingCS      instance_culling.hlsl:133-208
+//   hzb_cull_kernel<PHASE>      <- hzbMainViewCullingCS       hzb_mainview_culling.hlsl:35-213
+//
+// Design differences from the reference (results identical as sets; slots deterministic):
+//  * the reference spends a 64-thread group per object with 63 idle lanes and orders objects by
+//    an atomic; here one thread tests one object and the (object, group) expansion is a static
+//    prefix table built at upload, so the cluster list is produced in (object, group, meshlet)
+//    order by a two-kernel block scan (count -> scatter) instead of wave atomics.  That makes the
+//    visibility payload (slot + 1) reproducible run to run and identical on every rank.
+//  * one-thread "indirect args" kernels (indirect_cmd.hlsl, pipeline_filter.hlsl:27-38) vanish:
+//    count-driven kernels read the device-side count and grid-stride.
+//  * record fetches go through pre-resolved offsets (DPrim / DObjStatic) instead of 4 levels of
+//    bindless indirection; per-object matrices (VP*M, V*M) are computed once per object per frame.
+//
+// Memory-bound integer/fp32 VALU work: no MFMA.  Built with -ffp-contract=off.
+
+#include "device_layer.h"
+#include "device_math.h"
+
+namespace chord {
+
+// ------------------------------------------------------------------------------ object stage --
+
+__global__ __launch_bounds__(256) void object_cull_kernel(
+    const ChordObject* __restrict__ objects, const DObjStatic* __restrict__ objStatic,
+    const DPrim* __restrict__ prims, const DView* __restrict__ dview, DObjFrame* __restrict__ objFrame,
+    uint32_t objectCount)
+{
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= objectCount) return;
+    const ChordObject& obj = objects[o];
+    const DView& dv = *dview;
+
+    const Mat4 M = load_mat(obj.basicData.localToTranslatedWorld);
+    const Mat4 VP = load_mat(dv.iv.translatedWorldToClip);
+    const Mat4 mvp = mul_mm(VP, M);                                         // instance_culling.hlsl:71
+    const bool ortho = mvp.r[3][3] == 1.0f;                                 // base.hlsli:243-246
+
+    bool visible = true;
+    if (dv.flags & CHORD_FLAG_FRUSTUM_CULL) {                               // instance_culling.hlsl:79-89
+        const DPrim& prim = prims[objStatic[o].prim];
+        f3 c, e;
+        aabb_center_extent(prim.posMin, prim.posMax, c, e);
+        if (ortho) visible = !ortho_frustum_culling(c, e, mvp);
+        else       visible = !frustum_culling(&dv.iv.frustumPlanesRS[0][0], c, e, M);
+    }
+
+    DObjFrame& of = objFrame[o];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) of.mvp[r * 4 + c] = mvp.r[r][c];
+
+    {   // hzb_mainview_culling.hlsl:77-83 (phase 0 matrix)
+        const Mat4 Ml = load_mat(obj.basicData.localToTranslatedWorldLastFrame);
+        const Mat4 VPl = load_mat(dv.view.translatedWorldToClipLastFrame);
+        const Mat4 ml = mul_mm(VPl, Ml);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) of.mvpLast[r * 4 + c] = ml.r[r][c];
+    }
+    {   // instance_culling.hlsl:170 — always the main view
+        const Mat4 V = load_mat(dv.view.translatedWorldToView);
+        const Mat4 l2v = mul_mm(V, M);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) of.localToView[r * 4 + c] = l2v.r[r][c];
+    }
+    {   // nanite_shared.hlsli:65
+        const Mat4 W2L = load_mat(obj.basicData.translatedWorldToLocal);
+        const f4 cam = mul_mv(W2L, 0.0f, 0.0f, 0.0f, 1.0f);
+        of.camLS[0] = cam.x; of.camLS[1] = cam.y; of.camLS[2] = cam.z;
+    }
+    of.maxScale = obj.basicData.scaleExtractFromMatrix[3];
+    of.visible = visible ? 1u : 0u;
+    of.isOrtho = ortho ? 1u : 0u;
+}
+
+// ------------------------------------------------------------------------------- group stage --
+
+// projectSphereToScreen(transformSphere(...)) — base.hlsli:233-241, 503-518
+__device__ __forceinline__ float projected_error_px(float lodScale, const float* __restrict__ l2v, float maxScale,
+                                                    const float* center, float radius)
+{
+    f3 q;
+    q.x = ((l2v[0] * center[0] + l2v[1] * center[1]) + l2v[2] * center[2]) + l2v[3] * 1.0f;
+    q.y = ((l2v[4] * center[0] + l2v[5] * center[1]) + l2v[6] * center[2]) + l2v[7] * 1.0f;
+    q.z = ((l2v[8] * center[0] + l2v[9] * center[1]) + l2v[10] * center[2]) + l2v[11] * 1.0f;
+    const float R = maxScale * radius;
+    const float d2 = dot3(q, q);
+    const float r2 = R * R;
+    if (d2 <= r2) return -1.0f;
+    return lodScale * R / sqrtf(d2 - r2);
+}
+
+// isMeshletGroupVisibile — nanite_shared.hlsli:15-49
+__device__ __forceinline__ bool group_visible(float lodScale, const float* __restrict__ l2v, float maxScale, const DGroup& g)
+{
+    const bool finalLod = g.parentError > CHORD_ERROR_RADIUS_ROOT;
+    const bool firstLod = g.error < -0.5f;
+    if (!finalLod) {
+        const float pe = projected_error_px(lodScale, l2v, maxScale, g.parentPosCenter, g.parentError);
+        if (pe > 0.0f && pe <= CHORD_ERROR_PIXEL_THRESHOLD) return false;
+    }
+    if (!firstLod) {
+        const float er = projected_error_px(lodScale, l2v, maxScale, g.clusterPosCenter, g.error);
+        if (er < 0.0f || er > CHORD_ERROR_PIXEL_THRESHOLD) return false;
+    }
+    return true;
+}
+
+// isMeshletVisible — nanite_shared.hlsli:51-91
+__device__ __forceinline__ bool meshlet_visible(uint32_t flags, const float* __restrict__ planes, const DObjFrame& of,
+                                                const Mat4& M, bool twoSided, const DMeshlet& m)
+{
+    if (!twoSided && (flags & CHORD_FLAG_CONE_CULL)) {
+        const f3 v = {m.coneApex[0] - of.camLS[0], m.coneApex[1] - of.camLS[1], m.coneApex[2] - of.camLS[2]};
+        const float len = sqrtf(dot3(v, v));
+        const f3 n = {v.x / len, v.y / len, v.z / len};
+        const f3 axis = {m.coneAxis[0], m.coneAxis[1], m.coneAxis[2]};
+        if (dot3(n, axis) >= m.coneCutOff) return false;
+    }
+    if (flags & CHORD_FLAG_FRUSTUM_CULL) {
+        f3 c, e;
+        aabb_center_extent(m.posMin, m.posMax, c, e);
+        if (of.isOrtho) {
+            Mat4 mvp;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = of.mvp[r * 4 + cc];
+            return !ortho_frustum_culling(c, e, mvp);
+        }
+        return !frustum_culling(planes, c, e, M);
+    }
+    return true;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += n;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns (exclusive, blockTotal)
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* blockTotal)
+{
+    __shared__ uint32_t waveSums[4];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v, lane);
+    if (lane == 63) waveSums[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        const uint32_t s = waveSums[w];
+        if (w < wave) base += s;
+        total += s;
+    }
+    __syncthreads();
+    *blockTotal = total;
+    return base + incl - v;
+}
+
+struct GroupCullParams {
+    const ChordObject* objects; const DObjStatic* objStatic; const DObjFrame* objFrame; const DPrim* prims;
+    const DGroup* groups; const uint32_t* groupIndices; const DMeshlet* meshlets; const uint32_t* groupOwner;
+    const DView* dview; uint8_t* groupMask; uint32_t* blockCounts; uint32_t groupInstances;
+};
+
+__global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint32_t mask = 0;
+    if (t < p.groupInstances) {
+        const uint32_t o = p.groupOwner[t];
+        const DObjFrame& of = p.objFrame[o];
+        if (of.visible) {
+            const DObjStatic st = p.objStatic[o];
+            const DPrim& prim = p.prims[st.prim];
+            const DGroup g = p.groups[prim.groupBase + (t - st.groupBase)];
+            const DView& dv = *p.dview;
+            if (group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {     // instance_culling.hlsl:174
+                const Mat4 M = load_mat(p.objects[o].basicData.localToTranslatedWorld);
+                const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
+                for (uint32_t i = 0; i < g.meshletCount && i < CHORD_GROUP_MAX_MESHLETS; i++) {
+                    const uint32_t mi = prim.meshletBase + p.groupIndices[idxBase + i];  // :178-180
+                    if (meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, st.twoSided != 0, p.meshlets[mi]))
+                        mask |= 1u << i;
+                }
+            }
+        }
+        p.groupMask[t] = (uint8_t)mask;
+    }
+    uint32_t total;
+    (void)block_excl_scan(__popc(mask), &total);
+    if (threadIdx.x == 0) p.blockCounts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams p, ChordDrawCmd* __restrict__ outCmds,
+                                                                 uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters)
+{
+    // exclusive prefix of the preceding blocks' counts (B <= a few thousand: one strided pass)
+    __shared__ uint32_t red[256];
+    uint32_t part = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) part += p.blockCounts[b];
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const uint32_t blockBase = red[0];
+    __syncthreads();
+
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t mask = t < p.groupInstances ? p.groupMask[t] : 0u;
+    uint32_t total;
+    const uint32_t off = block_excl_scan(__popc(mask), &total);
+    uint32_t tris = 0;
+    if (mask) {
+        const uint32_t o = p.groupOwner[t];
+        const DObjStatic st = p.objStatic[o];
+        const DPrim& prim = p.prims[st.prim];
+        const DGroup& g = p.groups[prim.groupBase + (t - st.groupBase)];
+        const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
+        uint32_t slot = blockBase + off;
+        for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
+            if (mask & (1u << i)) {
+                ChordDrawCmd cmd;
+                cmd.objectId = o;
+                cmd.meshletId = prim.meshletBase + p.groupIndices[idxBase + i];
+                cmd.slot = slot;                                            // instance_culling.hlsl:203-206
+                outCmds[slot] = cmd;
+                tris += (p.meshlets[cmd.meshletId].vertexTriangleCount >> 8) & 0xFFu;
+                slot++;
+            }
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *outCount = blockBase + total;
+    // triangles this list submits (the Gtri/s unit): one fire-and-forget atomic per block
+    uint32_t blockTris;
+    (void)block_excl_scan(tris, &blockTris);
+    if (threadIdx.x == 0 && blockTris) atomicAdd(&counters->trisInstanceCulled, (unsigned long long)blockTris);
+}
+
+// -------------------------------------------------------------------------------- HZB stage --
+
+struct HzbCullParams {
+    const DObjFrame* objFrame; const DMeshlet* meshlets; const DView* dview;
+    const uint16_t* hzbMin; ChordHZBDesc desc;
+    const uint32_t* inCount; const ChordDrawCmd* inCmds;
+    uint32_t* visCount; ChordDrawCmd* visCmds;
+    uint32_t* rejCount; ChordDrawCmd* rejCmds;
+    DeviceCounters* counters;
+};
+
+template <int PHASE>
+__global__ __launch_bounds__(256) void hzb_cull_kernel(HzbCullParams p)
+{
+    const uint32_t count = *p.inCount;
+    const DView& dv = *p.dview;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t stride = gridDim.x * 256u;
+    // every lane of a wave runs the same number of iterations so the ballots below are complete
+    const uint32_t first = blockIdx.x * 256u + (threadIdx.x & ~63u);
+    for (uint32_t wbase = first; wbase < count; wbase += stride) {
+        const uint32_t i = wbase + lane;
+        const bool active = i < count;
+        bool visible = true;
+        ChordDrawCmd cmd = {0, 0, 0};
+        uint32_t tris = 0;
+        if (active) {
+            cmd = p.inCmds[i];
+            const DMeshlet& m = p.meshlets[cmd.meshletId];
+            tris = (m.vertexTriangleCount >> 8) & 0xFFu;
+            if (dv.flags & CHORD_FLAG_HZB_CULL) {
+                const DObjFrame& of = p.objFrame[cmd.objectId];
+                f3 c, e;
+                aabb_center_extent(m.posMin, m.posMax, c, e);
+                Mat4 mvp;
+                const float* src = PHASE == 0 ? of.mvpLast : of.mvp;         // hzb_mainview_culling.hlsl:77-83
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = src[r * 4 + cc];
+
+                f3 mx = {-10.0f, -10.0f, -10.0f}, mn = {10.0f, 10.0f, 10.0f};
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const f3 uvz = project_pos_to_uvz(extent_corner(c, e, k), mvp);
+                    mn.x = fminf(mn.x, uvz.x); mn.y = fminf(mn.y, uvz.y); mn.z = fminf(mn.z, uvz.z);
+                    mx.x = fmaxf(mx.x, uvz.x); mx.y = fmaxf(mx.y, uvz.y); mx.z = fmaxf(mx.z, uvz.z);
+                }
+                const bool zInRange = mx.z < 1.0f && mn.z > 0.0f;
+                if (zInRange) {
+                    if ((mn.x >= 1.0f || mn.y >= 1.0f) || (mx.x <= 0.0f || mx.y <= 0.0f)) visible = false;
+                }
+                if (visible && zInRange) {
+                    mn.x = saturatef(mn.x); mn.y = saturatef(mn.y);
+                    mx.x = saturatef(mx.x); mx.y = saturatef(mx.y);
+                    const float W = dv.view.renderDimension[0], H = dv.view.renderDimension[1];
+                    int rx = (int)(mn.x * W + 0.5f);
+                    int ry = (int)(mn.y * H + 0.5f);
+                    int rz = (int)(mx.x * W + -0.5f);
+                    int rw = (int)(mx.y * H + -0.5f);
+                    rx = max(0, rx); ry = max(0, ry);
+                    rz = (int)fminf(W - 1.0f, (float)rz);
+                    rw = (int)fminf(H - 1.0f, (float)rw);
+                    if (rz < rx || rw < ry) {
+                        visible = false;
+                    } else {
+                        const int mx0 = rx >> 1, my0 = ry >> 1, mz0 = rz >> 1, mw0 = rw >> 1;
+                        int lv = max(first_bit_high(mz0 - mx0), first_bit_high(mw0 - my0)) - 1;
+                        lv = max(0, lv);
+                        if (((mz0 >> lv) - (mx0 >> lv) >= 4) || ((mw0 >> lv) - (my0 >> lv) >= 4)) lv += 1;
+                        const int cx = mx0 >> lv, cy = my0 >> lv, cz = mz0 >> lv, cw = mw0 >> lv;
+                        const uint32_t mw = max(1u, p.desc.width >> lv);
+                        const uint16_t* mip = p.hzbMin + p.desc.mipOffset[lv];
+                        float zMin = 10.0f;
+#pragma unroll
+                        for (int x = 0; x < 4; x++)
+#pragma unroll
+                            for (int y = 0; y < 4; y++) {
+                                const int sx = min(cz, cx + x), sy = min(cw, cy + y);
+                                zMin = fminf(zMin, f16_to_f32(mip[(uint32_t)sy * mw + (uint32_t)sx]));
+                            }
+                        if (zMin > mx.z) visible = false;
+                    }
+                }
+            }
+        }
+        // wave64 ballot compaction, one atomic per wave per list (hzb_mainview_culling.hlsl:163-185)
+        const unsigned long long vmask = __ballot(active && visible);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        uint32_t vbase = 0;
+        if (lane == 0 && vmask) vbase = atomicAdd(p.visCount, (uint32_t)__popcll(vmask));
+        vbase = __shfl(vbase, 0, 64);
+        if (active && visible) p.visCmds[vbase + (uint32_t)__popcll(vmask & lt)] = cmd;
+        {   // triangles of the visible commands, one atomic per wave
+            uint32_t t = (active && visible) ? tris : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0 && t) atomicAdd(PHASE == 0 ? &p.counters->trisHzbVisible0 : &p.counters->trisHzbVisible1, (unsigned long long)t);
+        }
+        if (PHASE == 0) {
+            const unsigned long long rmask = __ballot(active && !visible);
+            uint32_t rbase = 0;
+            if (lane == 0 && rmask) rbase = atomicAdd(p.rejCount, (uint32_t)__popcll(rmask));
+            rbase = __shfl(rbase, 0, 64);
+            if (active && !visible) p.rejCmds[rbase + (uint32_t)__popcll(rmask & lt)] = cmd;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- launchers --
+
+void launch_object_cull(ChordCtx* c)
+{
+    const uint32_t blocks = (c->objectCount + 255u) / 256u;
+    hipLaunchKernelGGL(object_cull_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                       c->dObjects, c->dObjStatic, c->dPrims, c->dView, c->dObjFrame, c->objectCount);
+}
+
+void launch_group_cull(ChordCtx* c, const CmdList& out)
+{
+    GroupCullParams p;
+    p.objects = c->dObjects; p.objStatic = c->dObjStatic; p.objFrame = c->dObjFrame; p.prims = c->dPrims;
+    p.groups = c->dGroups; p.groupIndices = c->dGroupIndices; p.meshlets = c->dMeshlets; p.groupOwner = c->dGroupOwner;
+    p.dview = c->dView; p.groupMask = c->dGroupMask; p.blockCounts = c->dBlockCounts; p.groupInstances = c->groupInstances;
+    const uint32_t blocks = c->cullBlocks;
+    hipLaunchKernelGGL(group_cull_count_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(group_cull_scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+}
+
+void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
+                     const CmdList* outRejected)
+{
+    HzbCullParams p;
+    p.objFrame = c->dObjFrame; p.meshlets = c->dMeshlets; p.dview = c->dView;
+    p.hzbMin = hzb.minTexels; p.desc = hzb.desc;
+    p.inCount = in.count; p.inCmds = in.cmds;
+    p.visCount = outVisible.count; p.visCmds = outVisible.cmds;
+    p.rejCount = outRejected ? outRejected->count : nullptr;
+    p.rejCmds = outRejected ? outRejected->cmds : nullptr;
+    p.counters = c->dCounters;
+    uint32_t blocks = (in.capacity + 255u) / 256u;
+    const uint32_t maxBlocks = (uint32_t)c->numCUs * 8u;
+    if (blocks > maxBlocks) blocks = maxBlocks;
+    if (blocks < 1) blocks = 1;
+    if (phase == 0) hipLaunchKernelGGL(hzb_cull_kernel<0>, dim3(blocks), dim3(256), 0, c->stream, p);
+    else            hipLaunchKernelGGL(hzb_cull_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, p);
+}
+
+} // namespace chord

@@ -1,0 +1,274 @@
+// HZB build + de-stripe kernels, hand-written for gfx950.
+//
+// Replaces the single-dispatch HZB shaders (hzb_one.hlsl:126-372, hzb.hlsl:127-389) driven by
+// buildHZB (hzb.cpp:38-227).  The reference keeps everything in one dispatch with a
+// globallycoherent mip 5 + atomic ticket so the last workgroup can finish mips 6..11; on MI355X
+// an agent-scope release/acquire pair costs more (~3.5 us) than a kernel boundary (~1.5 us), so
+// the chain is built by three stream-ordered launches instead:
+//   hzb_mip0_kernel   depth (high half of the visibility words) -> mip 0 min[/max] (+ valid range)
+//                     HBM-bound: reads 8*W*H bytes once, 16 B per lane, fully coalesced
+//   hzb_mips_kernel   one block per 32x32 mip-0 tile -> mips 1..5 through LDS
+//   hzb_tail_kernel   one block -> mips 6..n
+// Texel semantics: mip l texel = min (max) over the 2^(l+1) square of
+// edge-clamped source depth, stored as binary16 (RNE); max chain carries +1 ulp from mip 5 up
+// (hzb.hlsl:67-71).  Only the sampled extent of each mip (x <= ((W-1)>>1)>>l) is defined.
+//
+// The sharded (multi-GPU) variant builds mip 0 for the rank's own stripes straight into the
+// rank-major exchange buffer; after the all-gather hzb_mips_kernel reads mip 0 through the
+// stripe map and also writes the canonical mip 0.
+
+#include "device_layer.h"
+#include "device_math.h"
+
+namespace chord {
+
+struct HzbParams {
+    const unsigned long long* vis; int32_t W, H;
+    ShardInfo shard;
+    ChordHZBDesc desc;
+    uint16_t* hzbMin; uint16_t* hzbMax; uint32_t* validRange;
+    uint16_t* exchange;           // rank-major mip-0 min rows (sharded only)
+    uint32_t exchangePitch;       // halves per exchange row
+};
+
+__device__ __forceinline__ uint32_t valid_w(const ChordHZBDesc& d, uint32_t l)
+{
+    const uint32_t w = max(1u, d.width >> l);
+    return min(w, (((d.srcWidth - 1u) >> 1) >> l) + 1u);
+}
+__device__ __forceinline__ uint32_t valid_h(const ChordHZBDesc& d, uint32_t l)
+{
+    const uint32_t h = max(1u, d.height >> l);
+    return min(h, (((d.srcHeight - 1u) >> 1) >> l) + 1u);
+}
+
+__device__ __forceinline__ size_t vis_row_base(const ShardInfo& s, bool sharded, uint32_t y, uint32_t W)
+{
+    if (!sharded) return (size_t)y * W;
+    const uint32_t stripe = y / s.stripeRows;
+    return ((size_t)((stripe % s.ranks) * s.stripesPerRank + stripe / s.ranks) * s.stripeRows + (y % s.stripeRows)) * (size_t)W;
+}
+
+// exchange-buffer row of mip-0 row y0 (pixel rows 2*y0, 2*y0+1 live in one stripe: stripeRows is even)
+__device__ __forceinline__ size_t exchange_row(const ShardInfo& s, uint32_t y0)
+{
+    const uint32_t half = s.stripeRows >> 1;
+    const uint32_t stripe = y0 / half;
+    return (size_t)((stripe % s.ranks) * s.stripesPerRank + stripe / s.ranks) * half + (y0 % half);
+}
+
+// MODE 0: full frame, row-major vis        -> canonical mip 0 (min, optional max, optional range)
+// MODE 1: own stripes of a rank-major vis  -> exchange buffer (min only)
+// MODE 2: full frame of a rank-major vis   -> canonical mip 0 (after the visibility all-gather)
+template <int MODE>
+__global__ __launch_bounds__(256) void hzb_mip0_kernel(HzbParams p, int wantMax, int wantRange)
+{
+    const uint32_t vw = valid_w(p.desc, 0), vh = valid_h(p.desc, 0);
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    float mn = 0.0f, mx = 0.0f;
+    uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
+    bool act = x < vw && y < vh;
+    if (MODE == 1 && act) act = (((2u * y) / p.shard.stripeRows) % p.shard.ranks) == p.shard.rank;
+    if (act) {
+        const uint32_t sx0 = min(2u * x, (uint32_t)p.W - 1u), sx1 = min(2u * x + 1u, (uint32_t)p.W - 1u);
+        const uint32_t sy0 = min(2u * y, (uint32_t)p.H - 1u), sy1 = min(2u * y + 1u, (uint32_t)p.H - 1u);
+        const size_t r0 = vis_row_base(p.shard, MODE != 0, sy0, (uint32_t)p.W);
+        const size_t r1 = vis_row_base(p.shard, MODE != 0, sy1, (uint32_t)p.W);
+        const float d00 = __uint_as_float((uint32_t)(p.vis[r0 + sx0] >> 32));
+        const float d10 = __uint_as_float((uint32_t)(p.vis[r0 + sx1] >> 32));
+        const float d01 = __uint_as_float((uint32_t)(p.vis[r1 + sx0] >> 32));
+        const float d11 = __uint_as_float((uint32_t)(p.vis[r1 + sx1] >> 32));
+        mn = fminf(fminf(fminf(d00, d10), d01), d11);
+        mx = fmaxf(fmaxf(fmaxf(d00, d10), d01), d11);
+        if (MODE == 1) {
+            p.exchange[exchange_row(p.shard, y) * p.exchangePitch + x] = f32_to_f16(mn);
+        } else {
+            const uint32_t mw = max(1u, p.desc.width);
+            p.hzbMin[p.desc.mipOffset[0] + y * mw + x] = f32_to_f16(mn);
+            if (wantMax) p.hzbMax[p.desc.mipOffset[0] + y * mw + x] = f32_to_f16(mx);
+        }
+        if (wantRange) {                                          // hzb.hlsl:163-176
+            const float dd[4] = {d00, d10, d01, d11};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (dd[i] > 0.0f) {
+                    const uint32_t b = __float_as_uint(dd[i]);
+                    if (dd[i] < 1.0f) rmin = min(rmin, b);
+                    rmax = max(rmax, b);
+                }
+            }
+        }
+    }
+    if (MODE != 1 && wantRange) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            rmin = min(rmin, (uint32_t)__shfl_down(rmin, off, 64));
+            rmax = max(rmax, (uint32_t)__shfl_down(rmax, off, 64));
+        }
+        if ((threadIdx.x & 63u) == 0u) {
+            if (rmin != 0xFFFFFFFFu) atomicMin(&p.validRange[0], rmin);
+            if (rmax != 0u) atomicMax(&p.validRange[1], rmax);
+        }
+    }
+}
+
+// One block per 32x32 mip-0 tile: mips 1..5.  FROM_EXCHANGE: read mip 0 (min) through the
+// stripe map and also emit the canonical mip 0.
+template <bool FROM_EXCHANGE>
+__global__ __launch_bounds__(256) void hzb_mips_kernel(HzbParams p, int wantMax)
+{
+    __shared__ float sMin[16][17], sMax[16][17];
+    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t bx = blockIdx.x, by = blockIdx.y;
+    const ChordHZBDesc& d = p.desc;
+
+    // level 1 from level 0
+    float mn = 0.0f, mx = 0.0f;
+    {
+        const uint32_t pw = valid_w(d, 0), ph = valid_h(d, 0), pmw = max(1u, d.width);
+        const uint32_t X = bx * 16u + tx, Y = by * 16u + ty;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const uint32_t cx = min(2u * X + i, pw - 1u), cy = min(2u * Y + j, ph - 1u);
+                float a, b = 0.0f;
+                if (FROM_EXCHANGE) {
+                    const uint16_t h = p.exchange[exchange_row(p.shard, cy) * p.exchangePitch + cx];
+                    a = f16_to_f32(h);
+                    if (2u * X + i == cx && 2u * Y + j == cy) p.hzbMin[d.mipOffset[0] + cy * pmw + cx] = h;
+                } else {
+                    a = f16_to_f32(p.hzbMin[d.mipOffset[0] + cy * pmw + cx]);
+                    if (wantMax) b = f16_to_f32(p.hzbMax[d.mipOffset[0] + cy * pmw + cx]);
+                }
+                if (i == 0 && j == 0) { mn = a; mx = b; } else { mn = fminf(mn, a); mx = fmaxf(mx, b); }
+            }
+        if (d.mipCount > 1 && X < valid_w(d, 1) && Y < valid_h(d, 1)) {
+            const uint32_t mw = max(1u, d.width >> 1);
+            p.hzbMin[d.mipOffset[1] + Y * mw + X] = f32_to_f16(mn);
+            if (wantMax) p.hzbMax[d.mipOffset[1] + Y * mw + X] = f32_to_f16(mx);
+        }
+        sMin[ty][tx] = mn; sMax[ty][tx] = mx;
+    }
+    // levels 2..5 through LDS: level l tile is (32 >> l) wide
+#pragma unroll
+    for (uint32_t l = 2; l <= 5; l++) {
+        __syncthreads();
+        const uint32_t side = 32u >> l;                     // 8, 4, 2, 1
+        const bool act = tx < side && ty < side && l < d.mipCount;
+        float rmn = 0.0f, rmx = 0.0f;
+        if (act) {
+            const uint32_t pw = valid_w(d, l - 1), ph = valid_h(d, l - 1);
+            const uint32_t originX = bx * (64u >> l), originY = by * (64u >> l);     // tile origin at level l-1
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    // children clamped to the valid extent of level l-1, in tile-local coordinates
+                    const uint32_t gx = min(originX + 2u * tx + i, pw - 1u), gy = min(originY + 2u * ty + j, ph - 1u);
+                    const uint32_t lx = gx >= originX ? gx - originX : 0u, ly = gy >= originY ? gy - originY : 0u;
+                    const float a = sMin[ly][lx], b = sMax[ly][lx];
+                    if (i == 0 && j == 0) { rmn = a; rmx = b; } else { rmn = fminf(rmn, a); rmx = fmaxf(rmx, b); }
+                }
+        }
+        __syncthreads();
+        if (act) {
+            const uint32_t X = bx * side + tx, Y = by * side + ty;
+            // keep what the stored halves hold (the max chain's +1 ulp at mip 5 is applied on store)
+            uint16_t hmn = f32_to_f16(rmn), hmx = f32_to_f16(rmx);
+            if (l == 5) hmx = (uint16_t)(hmx + 1u);                                  // storeHZBMip5
+            if (X < valid_w(d, l) && Y < valid_h(d, l)) {
+                const uint32_t mw = max(1u, d.width >> l);
+                p.hzbMin[d.mipOffset[l] + Y * mw + X] = hmn;
+                if (wantMax) p.hzbMax[d.mipOffset[l] + Y * mw + X] = hmx;
+            }
+            sMin[ty][tx] = rmn; sMax[ty][tx] = rmx;
+        }
+    }
+}
+
+// One block: mips 6..mipCount-1 from the stored mip 5.
+__global__ __launch_bounds__(256) void hzb_tail_kernel(HzbParams p, int wantMax)
+{
+    const ChordHZBDesc& d = p.desc;
+    for (uint32_t l = 6; l < d.mipCount; l++) {
+        const uint32_t vw = valid_w(d, l), vh = valid_h(d, l), mw = max(1u, d.width >> l);
+        const uint32_t pw = valid_w(d, l - 1), ph = valid_h(d, l - 1), pmw = max(1u, d.width >> (l - 1));
+        for (uint32_t i = threadIdx.x; i < vw * vh; i += 256u) {
+            const uint32_t x = i % vw, y = i / vw;
+            float mn = 0.0f, mx = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                for (int ii = 0; ii < 2; ii++) {
+                    const uint32_t cx = min(2u * x + ii, pw - 1u), cy = min(2u * y + jj, ph - 1u);
+                    const float a = f16_to_f32(p.hzbMin[d.mipOffset[l - 1] + cy * pmw + cx]);
+                    const float b = wantMax ? f16_to_f32(p.hzbMax[d.mipOffset[l - 1] + cy * pmw + cx]) : 0.0f;
+                    if (ii == 0 && jj == 0) { mn = a; mx = b; } else { mn = fminf(mn, a); mx = fmaxf(mx, b); }
+                }
+            p.hzbMin[d.mipOffset[l] + y * mw + x] = f32_to_f16(mn);
+            if (wantMax) p.hzbMax[d.mipOffset[l] + y * mw + x] = f32_to_f16(mx);
+        }
+        __syncthreads();       // level l complete and visible to this block before level l+1
+    }
+}
+
+// rank-major (striped) visibility -> row-major
+__global__ __launch_bounds__(256) void detile_kernel(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst,
+                                                     uint32_t W, uint32_t H, ShardInfo shard)
+{
+    const uint32_t y = blockIdx.y;
+    const size_t sb = vis_row_base(shard, true, y, W);
+    for (uint32_t x = blockIdx.x * 256u + threadIdx.x; x < W; x += gridDim.x * 256u)
+        dst[(size_t)y * W + x] = src[sb + x];
+}
+
+static HzbParams make_params(ChordCtx* c, HzbBuffers& out)
+{
+    HzbParams p;
+    p.vis = (const unsigned long long*)c->dVis; p.W = (int32_t)c->width; p.H = (int32_t)c->height;
+    p.shard = c->shard; p.desc = out.desc;
+    p.hzbMin = out.minTexels; p.hzbMax = out.maxTexels; p.validRange = out.validRange;
+    p.exchange = c->dHzbExchange; p.exchangePitch = out.desc.width;
+    return p;
+}
+
+void launch_hzb_mip0_exchange(ChordCtx* c)
+{
+    HzbParams p = make_params(c, c->hzb[0]);
+    const uint32_t vw = min(p.desc.width, (((uint32_t)p.W - 1u) >> 1) + 1u), vh = min(p.desc.height, (((uint32_t)p.H - 1u) >> 1) + 1u);
+    hipLaunchKernelGGL(hzb_mip0_kernel<1>, dim3((vw + 63u) / 64u, (vh + 3u) / 4u), dim3(256), 0, c->stream, p, 0, 0);
+}
+
+void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange, bool fromExchange)
+{
+    (void)bMin;
+    HzbParams p = make_params(c, out);
+    const int wantMax = bMax ? 1 : 0, wantRange = bValidRange ? 1 : 0;
+    const uint32_t vw = min(p.desc.width, (((uint32_t)p.W - 1u) >> 1) + 1u), vh = min(p.desc.height, (((uint32_t)p.H - 1u) >> 1) + 1u);
+    if (bValidRange) {
+        // clearRangeValue = { ~0u, 0u }  (hzb.cpp:108-109)
+        (void)hipMemsetD32Async((hipDeviceptr_t)out.validRange, (int)0xFFFFFFFFu, 1, c->stream);
+        (void)hipMemsetD32Async((hipDeviceptr_t)(out.validRange + 1), 0, 1, c->stream);
+    }
+    if (!fromExchange) {
+        const dim3 g0((vw + 63u) / 64u, (vh + 3u) / 4u);
+        if (c->shard.ranks > 1) hipLaunchKernelGGL(hzb_mip0_kernel<2>, g0, dim3(256), 0, c->stream, p, wantMax, wantRange);
+        else                    hipLaunchKernelGGL(hzb_mip0_kernel<0>, g0, dim3(256), 0, c->stream, p, wantMax, wantRange);
+    }
+    const dim3 g1((vw + 31u) / 32u, (vh + 31u) / 32u);
+    if (fromExchange) hipLaunchKernelGGL(hzb_mips_kernel<true>, g1, dim3(256), 0, c->stream, p, 0);
+    else              hipLaunchKernelGGL(hzb_mips_kernel<false>, g1, dim3(256), 0, c->stream, p, wantMax);
+    if (p.desc.mipCount > 6) hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, wantMax);
+    out.valid = true;
+}
+
+void launch_detile(ChordCtx* c)
+{
+    const dim3 g((c->width + 255u) / 256u > 8u ? 8u : (c->width + 255u) / 256u, c->height);
+    hipLaunchKernelGGL(detile_kernel, g, dim3(256), 0, c->stream, (const unsigned long long*)c->dVis,
+                       (unsigned long long*)c->dVisResolved, c->width, c->height, c->shard);
+}
+
+} // namespace chord

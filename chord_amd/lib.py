@@ -1,0 +1,159 @@
+"""ctypes binding of libchordvis.so (the C ABI declared in include/chordvis.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module
+raises at import, and every device entry point fails loudly without a GPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import records as R
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libchordvis.so")
+
+OK, E_INVALID, E_HIP, E_NO_DEVICE, E_CAPACITY = 0, -1, -2, -3, -4
+
+
+class ChordvisError(RuntimeError):
+    pass
+
+
+class CountAndCmd(C.Structure):
+    _fields_ = [("count", C.c_void_p), ("cmds", C.c_void_p), ("capacity", C.c_uint32)]
+
+
+class HZB(C.Structure):
+    _fields_ = [("desc", R.HZBDesc), ("minTexels", C.c_void_p), ("maxTexels", C.c_void_p), ("validRange", C.c_void_p)]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [
+        ("position", C.c_double * 3), ("front", C.c_double * 3), ("worldUp", C.c_double * 3),
+        ("fovy", C.c_float), ("jitter", C.c_float * 2),
+        ("zNear", C.c_double), ("zFar", C.c_double),
+        ("width", C.c_uint32), ("height", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("msClear", C.c_float), ("msInstanceCulling", C.c_float), ("msStage0", C.c_float), ("msHzbStage0", C.c_float),
+        ("msStage1", C.c_float), ("msHzbFinal", C.c_float), ("msFrame", C.c_float),
+        ("msRasterCluster", C.c_float), ("msRasterClip", C.c_float), ("msRasterChunk", C.c_float),
+        ("rasterLaunches", C.c_uint32), ("overflow", C.c_uint32), ("countInstanceCulled", C.c_uint32), ("countStage0Visible", C.c_uint32),
+        ("countStage0Rejected", C.c_uint32), ("countStage1Visible", C.c_uint32), ("trianglesSubmitted", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ChordvisError(
+            "libchordvis.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python chord_amd/build.py`; there is no CPU fallback for the product path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    P = C.POINTER
+    protos = {
+        "chordvis_version": (C.c_char_p, []),
+        "chordvis_hzb_desc": (i32, [u32, u32, P(R.HZBDesc)]),
+        "chordvis_camera_fill_view": (i32, [P(CameraDesc), vp, vp, vp]),
+        "chordvis_object_basic_data": (i32, [vp, vp, vp, vp, vp]),
+        "chordvis_object_basic_data_batch": (i32, [u32, vp, vp, vp, vp, vp]),
+        "chordvis_create": (i32, [i32, vp, P(vp)]),
+        "chordvis_destroy": (i32, [vp]),
+        "chordvis_last_error": (C.c_char_p, [vp]),
+        "chordvis_sync": (i32, [vp]),
+        "chordvis_upload_scene": (i32, [vp, P(R.SceneDesc)]),
+        "chordvis_update_objects": (i32, [vp, vp, u32]),
+        "chordvis_bind_objects": (i32, [vp, vp, u32]),
+        "chordvis_set_view": (i32, [vp, vp, vp, u32]),
+        "chordvis_allocate_gbuffer": (i32, [vp, u32, u32, vp]),
+        "chordvis_set_shard": (i32, [vp, u32, u32, u32]),
+        "chordvis_visibility_words": (u64, [vp]),
+        "chordvis_visibility_chunk_words": (u64, [vp]),
+        "chordvis_visibility_ptr": (vp, [vp]),
+        "chordvis_clear_gbuffer": (i32, [vp]),
+        "chordvis_instance_culling": (i32, [vp, P(CountAndCmd)]),
+        "chordvis_hzb_culling": (i32, [vp, P(HZB), i32, CountAndCmd, P(CountAndCmd), P(CountAndCmd)]),
+        "chordvis_render_mesh": (i32, [vp, CountAndCmd]),
+        "chordvis_visibility_stage0": (i32, [vp, P(HZB), CountAndCmd, P(CountAndCmd), P(i32)]),
+        "chordvis_visibility_stage1": (i32, [vp, P(HZB), CountAndCmd]),
+        "chordvis_build_hzb": (i32, [vp, i32, i32, i32, i32, P(HZB)]),
+        "chordvis_render_frame": (i32, [vp]),
+        "chordvis_frame_phase_a": (i32, [vp]),
+        "chordvis_frame_phase_b": (i32, [vp]),
+        "chordvis_frame_phase_c": (i32, [vp]),
+        "chordvis_reset_history": (i32, [vp]),
+        "chordvis_hzb_exchange_ptr": (vp, [vp]),
+        "chordvis_hzb_exchange_halves": (u64, [vp]),
+        "chordvis_hzb_exchange_chunk_halves": (u64, [vp]),
+        "chordvis_resolved_visibility_ptr": (vp, [vp]),
+        "chordvis_last_frame_cmds": (i32, [vp, P(CountAndCmd)]),
+        "chordvis_history_hzb": (i32, [vp, P(HZB)]),
+        "chordvis_readback_visibility": (i32, [vp, vp]),
+        "chordvis_readback_cmds": (i32, [vp, CountAndCmd, vp, u32, P(u32)]),
+        "chordvis_readback_hzb": (i32, [vp, P(HZB), vp, vp, vp]),
+        "chordvis_upload_history_hzb": (i32, [vp, vp]),
+        "chordvis_enable_timers": (i32, [vp, i32]),
+        "chordvis_stats": (i32, [vp, P(Stats)]),
+    }
+    missing = []
+    for name, (res, args) in protos.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype, fn.argtypes = res, args
+    if missing:
+        raise ChordvisError("libchordvis.so lacks symbols declared in include/chordvis.h: %s" % ", ".join(missing))
+    return lib, sorted(protos)
+
+
+lib, EXPORTED = _load()
+
+
+# ------------------------------------------------------------------------------- host helpers ---
+
+def hzb_desc(width, height):
+    d = R.HZBDesc()
+    rc = lib.chordvis_hzb_desc(width, height, C.byref(d))
+    if rc != OK:
+        raise ChordvisError("chordvis_hzb_desc(%d, %d) -> %d" % (width, height, rc))
+    return d
+
+
+def make_views(camera, last_view=None):
+    """(ChordCameraView, ChordInstanceCullingView) numpy records for a scenes.Camera."""
+    cd = CameraDesc()
+    cd.position[:] = camera.position
+    cd.front[:] = camera.front
+    cd.worldUp[:] = camera.world_up
+    cd.fovy = camera.fovy
+    cd.jitter[:] = camera.jitter
+    cd.zNear, cd.zFar = camera.z_near, camera.z_far
+    cd.width, cd.height = camera.width, camera.height
+    view = np.zeros(1, dtype=R.CAMERA_VIEW)
+    iv = np.zeros(1, dtype=R.INSTANCE_CULLING_VIEW)
+    lv = last_view.ctypes.data if last_view is not None else None
+    rc = lib.chordvis_camera_fill_view(C.byref(cd), lv, view.ctypes.data, iv.ctypes.data)
+    if rc != OK:
+        raise ChordvisError("chordvis_camera_fill_view -> %d" % rc)
+    return view, iv
+
+
+def fill_objects(scene, camera, camera_last=None):
+    """SceneNode::getObjectBasicData for every object of a scenes.Scene (static objects)."""
+    cam = (C.c_double * 3)(*camera.position)
+    cam_last = (C.c_double * 3)(*(camera_last or camera).position)
+    l2w = scene.local_to_world
+    rc = lib.chordvis_object_basic_data_batch(len(scene.objects), l2w.ctypes.data, None, cam, cam_last,
+                                              scene.objects.ctypes.data)
+    if rc != OK:
+        raise ChordvisError("chordvis_object_basic_data_batch -> %d" % rc)
+    return scene.objects

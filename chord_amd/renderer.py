@@ -1,0 +1,187 @@
+"""Host-side mirror of the reference's pass surface over the C ABI (libchordvis.so).
+
+Names follow source/renderer/mesh/gltf_rendering.h:37-108 and postprocessing.h:41-54:
+instance_culling, hzb_culling, render_mesh, visibility_stage0/1, build_hzb, and render_frame for
+the hot segment of DeferredRenderer::render (renderer.cpp:315-345).  Everything here only forwards
+to the HIP library; there is no CPU implementation of any pass in this package.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as L
+from . import records as R
+
+
+class VisibilityRenderer:
+    """One device context (graphics::Context + DeferredRenderer state for this path)."""
+
+    def __init__(self, device=0, stream=None):
+        self._ctx = C.c_void_p()
+        rc = L.lib.chordvis_create(device, stream, C.byref(self._ctx))
+        if rc != L.OK:
+            raise L.ChordvisError(
+                "chordvis_create(device=%d) failed with %d: no usable HIP device (the product path has no CPU fallback)" % (device, rc))
+        self.width = self.height = 0
+        self.scene = None
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != L.OK:
+            msg = L.lib.chordvis_last_error(self._ctx)
+            raise L.ChordvisError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def close(self):
+        if self._ctx:
+            L.lib.chordvis_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(L.lib.chordvis_sync(self._ctx), "sync")
+
+    # -- scene / view ---------------------------------------------------------------------------
+    def upload_scene(self, scene):
+        self.scene = scene
+        self._check(L.lib.chordvis_upload_scene(self._ctx, C.byref(scene.desc)), "upload_scene")
+
+    def update_objects(self, objects):
+        objects = np.ascontiguousarray(objects, dtype=R.OBJECT)
+        self._check(L.lib.chordvis_update_objects(self._ctx, objects.ctypes.data, len(objects)), "update_objects")
+
+    def bind_objects(self, device_ptr, count):
+        self._check(L.lib.chordvis_bind_objects(self._ctx, device_ptr, count), "bind_objects")
+
+    def allocate_gbuffer(self, width, height, device_visibility=None):
+        self._check(L.lib.chordvis_allocate_gbuffer(self._ctx, width, height, device_visibility), "allocate_gbuffer")
+        self.width, self.height = width, height
+
+    def set_shard(self, stripe_rows, ranks, rank):
+        self._check(L.lib.chordvis_set_shard(self._ctx, stripe_rows, ranks, rank), "set_shard")
+
+    def set_view(self, view, instance_view, flags):
+        self._views = (view, instance_view)       # keep alive
+        self._check(L.lib.chordvis_set_view(self._ctx, view.ctypes.data, instance_view.ctypes.data, flags), "set_view")
+
+    # -- buffers for collectives ------------------------------------------------------------------
+    def visibility_words(self):
+        return int(L.lib.chordvis_visibility_words(self._ctx))
+
+    def visibility_chunk_words(self):
+        return int(L.lib.chordvis_visibility_chunk_words(self._ctx))
+
+    def visibility_ptr(self):
+        return L.lib.chordvis_visibility_ptr(self._ctx)
+
+    def resolved_visibility_ptr(self):
+        return L.lib.chordvis_resolved_visibility_ptr(self._ctx)
+
+    def hzb_exchange(self):
+        return (L.lib.chordvis_hzb_exchange_ptr(self._ctx), int(L.lib.chordvis_hzb_exchange_halves(self._ctx)),
+                int(L.lib.chordvis_hzb_exchange_chunk_halves(self._ctx)))
+
+    # -- passes -------------------------------------------------------------------------------------
+    def clear_gbuffer(self):
+        self._check(L.lib.chordvis_clear_gbuffer(self._ctx), "clear_gbuffer")
+
+    def instance_culling(self):
+        out = L.CountAndCmd()
+        self._check(L.lib.chordvis_instance_culling(self._ctx, C.byref(out)), "instance_culling")
+        return out
+
+    def hzb_culling(self, hzb, first_stage, in_list):
+        vis, rej = L.CountAndCmd(), L.CountAndCmd()
+        self._check(L.lib.chordvis_hzb_culling(self._ctx, C.byref(hzb), int(first_stage), in_list, C.byref(vis), C.byref(rej)), "hzb_culling")
+        return vis, rej
+
+    def render_mesh(self, in_list):
+        self._check(L.lib.chordvis_render_mesh(self._ctx, in_list), "render_mesh")
+
+    def visibility_stage0(self, hzb_prev, in_list):
+        rej, flag = L.CountAndCmd(), C.c_int(0)
+        self._check(L.lib.chordvis_visibility_stage0(self._ctx, C.byref(hzb_prev) if hzb_prev is not None else None,
+                                                      in_list, C.byref(rej), C.byref(flag)), "visibility_stage0")
+        return bool(flag.value), rej
+
+    def visibility_stage1(self, hzb, in_list):
+        self._check(L.lib.chordvis_visibility_stage1(self._ctx, C.byref(hzb), in_list), "visibility_stage1")
+
+    def build_hzb(self, build_min=True, build_max=False, build_valid_range=False, slot=0):
+        out = L.HZB()
+        self._check(L.lib.chordvis_build_hzb(self._ctx, int(build_min), int(build_max), int(build_valid_range), slot, C.byref(out)), "build_hzb")
+        return out
+
+    def render_frame(self):
+        self._check(L.lib.chordvis_render_frame(self._ctx), "render_frame")
+
+    def frame_phase_a(self):
+        self._check(L.lib.chordvis_frame_phase_a(self._ctx), "frame_phase_a")
+
+    def frame_phase_b(self):
+        self._check(L.lib.chordvis_frame_phase_b(self._ctx), "frame_phase_b")
+
+    def frame_phase_c(self):
+        self._check(L.lib.chordvis_frame_phase_c(self._ctx), "frame_phase_c")
+
+    def reset_history(self):
+        self._check(L.lib.chordvis_reset_history(self._ctx), "reset_history")
+
+    def last_frame_cmds(self):
+        out = L.CountAndCmd()
+        self._check(L.lib.chordvis_last_frame_cmds(self._ctx, C.byref(out)), "last_frame_cmds")
+        return out
+
+    def history_hzb(self):
+        out = L.HZB()
+        self._check(L.lib.chordvis_history_hzb(self._ctx, C.byref(out)), "history_hzb")
+        return out
+
+    def upload_history_hzb(self, hzb_min):
+        hzb_min = np.ascontiguousarray(hzb_min, dtype=np.uint16)
+        self._check(L.lib.chordvis_upload_history_hzb(self._ctx, hzb_min.ctypes.data), "upload_history_hzb")
+
+    # -- readback -------------------------------------------------------------------------------------
+    def read_visibility(self):
+        out = np.empty(self.width * self.height, dtype=np.uint64)
+        self._check(L.lib.chordvis_readback_visibility(self._ctx, out.ctypes.data), "readback_visibility")
+        return out
+
+    def read_cmds(self, handle):
+        n = C.c_uint32(0)
+        self._check(L.lib.chordvis_readback_cmds(self._ctx, handle, None, 0, C.byref(n)), "readback_cmds")
+        out = np.zeros(max(1, n.value), dtype=R.DRAW_CMD)
+        self._check(L.lib.chordvis_readback_cmds(self._ctx, handle, out.ctypes.data, len(out), C.byref(n)), "readback_cmds")
+        return out[:n.value].copy()
+
+    def read_hzb(self, hzb):
+        n = hzb.desc.totalTexels
+        mn = np.zeros(n, dtype=np.uint16)
+        mx = np.zeros(n, dtype=np.uint16) if hzb.maxTexels else None
+        rng = np.zeros(2, dtype=np.uint32) if hzb.validRange else None
+        self._check(L.lib.chordvis_readback_hzb(self._ctx, C.byref(hzb), mn.ctypes.data,
+                                                mx.ctypes.data if mx is not None else None,
+                                                rng.ctypes.data if rng is not None else None), "readback_hzb")
+        return mn, mx, rng
+
+    def enable_timers(self, on=True):
+        self._check(L.lib.chordvis_enable_timers(self._ctx, int(on)), "enable_timers")
+
+    def stats(self):
+        st = L.Stats()
+        self._check(L.lib.chordvis_stats(self._ctx, C.byref(st)), "stats")
+        return st.as_dict()
+
+
+def decode_visibility(vis):
+    """(depth float32, slot int64 (-1 = empty), triangle uint8) from packed words — base.hlsli:437-447."""
+    vis = np.asarray(vis, dtype=np.uint64)
+    depth = (vis >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    low = (vis & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    tri = (low & 0xFF).astype(np.uint8)
+    slot = ((low >> 8) & 0xFFFFFF).astype(np.int64) - 1
+    return depth, slot, tri

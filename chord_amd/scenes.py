@@ -1,0 +1,492 @@
+"""Deterministic procedural meshlet scenes for BASELINE.json's configs.
+
+The reference ships no Sponza/Bistro assets (install/resource/mesh holds only
+low_sphere.glb) and its importer needs METIS (nanite_builder.cpp:692-716), so
+the inputs are synthesized here in the *output format* of the reference's
+importer: meshlets of <=255 vertices / <=128 triangles with AABB + normal cone
+(nanite_builder.cpp:1024-1044, meshopt_clusterizer.cpp:760-860), meshlet groups
+that share one (error sphere, parent error sphere) (nanite_builder.cpp:313-395),
+and the packed meshletData stream [V vertex ids][T tris i0|i1<<8|i2<<16]
+(asset_gltf_helper.cpp:522-548).
+
+Every surface is a grid of 9x9-vertex patches (81 vertices / 128 triangles per
+meshlet).  LOD levels follow a patch quadtree: the 4 LOD0 patches of a 2x2
+block are replaced by 2 LOD1 meshlets (half the triangles), the 8 LOD1 meshlets
+of a 4x4 block by 4 LOD2 meshlets.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import records as T
+
+FLT_MAX = np.float32(3.4028234663852886e38)
+
+
+def pcg_hash(v):
+    """Counter-based PCG (Jarzynski & Olano 2020) on uint32 arrays."""
+    v = np.asarray(v, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    state = (v * np.uint64(747796405) + np.uint64(2891336453)) & np.uint64(0xFFFFFFFF)
+    sh = ((state >> np.uint64(28)) + np.uint64(4))
+    word = (((state >> sh) ^ state) * np.uint64(277803737)) & np.uint64(0xFFFFFFFF)
+    return (((word >> np.uint64(22)) ^ word) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
+def pcg32(seed, i):
+    """i-th 32-bit value of stream `seed`."""
+    return pcg_hash((np.uint64(seed) * np.uint64(0x9E3779B9) + np.asarray(i, dtype=np.uint64)) & np.uint64(0xFFFFFFFF))
+
+
+def rand01(seed, i):
+    return (pcg32(seed, i).astype(np.float64) / 4294967295.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# 9x9 patch topology: vertex (i, j) -> j*9+i ; cell -> (v00, v10, v11), (v00, v11, v01): CCW
+# when the parameter plane is seen with u to the right and v up (normal = dS/du x dS/dv).
+
+def _patch_tri_table():
+    tris = []
+    for j in range(8):
+        for i in range(8):
+            v00 = j * 9 + i
+            v10 = v00 + 1
+            v01 = v00 + 9
+            v11 = v01 + 1
+            tris.append(v00 | (v10 << 8) | (v11 << 16))
+            tris.append(v00 | (v11 << 8) | (v01 << 16))
+    return np.array(tris, dtype=np.uint32)
+
+
+PATCH_TRIS = _patch_tri_table()
+PATCH_V, PATCH_T = 81, 128
+_TI = np.stack([PATCH_TRIS & 0xFF, (PATCH_TRIS >> 8) & 0xFF, (PATCH_TRIS >> 16) & 0xFF], axis=1).astype(np.int64)
+
+
+def _meshlet_bounds(pos):
+    """pos: (M, 81, 3) float32 -> AABB + meshopt-style normal cone per meshlet."""
+    pos64 = pos.astype(np.float64)
+    pmin = pos.min(axis=1)
+    pmax = pos.max(axis=1)
+    a, b, c = pos64[:, _TI[:, 0]], pos64[:, _TI[:, 1]], pos64[:, _TI[:, 2]]
+    n = np.cross(b - a, c - a)                                # (M, 128, 3)
+    ln = np.linalg.norm(n, axis=2, keepdims=True)
+    valid = ln[..., 0] > 0
+    n = np.where(ln > 0, n / np.maximum(ln, 1e-300), 0.0)
+    axis = n.sum(axis=1)
+    la = np.linalg.norm(axis, axis=1, keepdims=True)
+    axis = np.where(la > 0, axis / np.maximum(la, 1e-300), 0.0)
+    dp = (n * axis[:, None, :]).sum(axis=2)
+    dp = np.where(valid, dp, 1.0)
+    mindp = dp.min(axis=1)
+    center = 0.5 * (pmin.astype(np.float64) + pmax.astype(np.float64))
+    # apex = center - axis * maxt, t = dot(center - corner, n) / dot(axis, n)
+    dc = ((center[:, None, :] - a) * n).sum(axis=2)
+    dn = np.where(dp > 1e-6, dp, 1.0)
+    t = np.where(valid, dc / dn, 0.0)
+    maxt = np.maximum(t.max(axis=1), 0.0)
+    apex = center - axis * maxt[:, None]
+    cutoff = np.sqrt(np.maximum(0.0, 1.0 - mindp * mindp))
+    degenerate = mindp <= 0.1                                  # meshopt: cone wider than ~168 deg => never culls
+    axis = np.where(degenerate[:, None], 0.0, axis)
+    apex = np.where(degenerate[:, None], 0.0, apex)
+    cutoff = np.where(degenerate, 1.0, cutoff)
+    return pmin, pmax, axis.astype(np.float32), cutoff.astype(np.float32), apex.astype(np.float32)
+
+
+class PrimitiveBuilder:
+    """Accumulates parametric surfaces into one primitive (one GLTFPrimitiveBuffer)."""
+
+    def __init__(self):
+        self.positions = []        # list of (n,3) float32
+        self.nverts = 0
+        self.meshlets = []         # list of structured arrays (dataOffset relative to primitive)
+        self.meshlet_data = []     # list of uint32 arrays
+        self.ndata = 0
+        self.nmeshlets = 0
+        self.groups = []
+        self.group_indices = []
+        self.nindices = 0
+
+    def _add_meshlets(self, pos, lod):
+        """pos (M,81,3) float32. Returns meshlet ids (relative to this primitive)."""
+        M = pos.shape[0]
+        pmin, pmax, axis, cutoff, apex = _meshlet_bounds(pos)
+        ml = np.zeros(M, dtype=T.MESHLET)
+        ml["posMin"], ml["posMax"] = pmin, pmax
+        ml["coneAxis"], ml["coneCutOff"], ml["coneApex"] = axis, cutoff, apex
+        ml["lod"] = lod
+        ml["vertexTriangleCount"] = PATCH_V | (PATCH_T << 8)
+        stride = PATCH_V + PATCH_T
+        ml["dataOffset"] = self.ndata + np.arange(M, dtype=np.uint32) * stride
+        data = np.empty((M, stride), dtype=np.uint32)
+        data[:, :PATCH_V] = self.nverts + np.arange(M, dtype=np.uint32)[:, None] * PATCH_V + np.arange(PATCH_V, dtype=np.uint32)[None, :]
+        data[:, PATCH_V:] = PATCH_TRIS[None, :]
+        ids = self.nmeshlets + np.arange(M, dtype=np.uint32)
+        self.positions.append(pos.reshape(-1, 3))
+        self.nverts += M * PATCH_V
+        self.meshlets.append(ml)
+        self.meshlet_data.append(data.reshape(-1))
+        self.ndata += M * stride
+        self.nmeshlets += M
+        return ids
+
+    def _add_groups(self, member_ids, center, error, parent_center, parent_error):
+        """member_ids (G, k) meshlet ids; one group per row."""
+        G, k = member_ids.shape
+        g = np.zeros(G, dtype=T.MESHLET_GROUP)
+        g["clusterPosCenter"] = center
+        g["error"] = error
+        g["parentPosCenter"] = parent_center
+        g["parentError"] = parent_error
+        g["meshletOffset"] = self.nindices + np.arange(G, dtype=np.uint32) * k
+        g["meshletCount"] = k
+        self.groups.append(g)
+        self.group_indices.append(member_ids.reshape(-1).astype(np.uint32))
+        self.nindices += G * k
+
+    def add_surface(self, S, P, Q, lods=1, error_scale=0.06):
+        """S(u, v) -> (..., 3) float64 over [0,1]^2; P x Q LOD0 patches; lods in {1, 2, 3}."""
+        if lods > 1:
+            assert P % 4 == 0 and Q % 4 == 0, "LOD quadtree needs patch grids in multiples of 4"
+        k = np.arange(9) / 8.0
+
+        def sample(u0, v0, du, dv):
+            # u0,v0: (M,) patch origins; du,dv patch extents -> (M,81,3) float32 (row j = v, col i = u)
+            U = u0[:, None, None] + du * k[None, None, :]
+            V = v0[:, None, None] + dv * k[None, :, None]
+            U, V = np.broadcast_arrays(U, V)
+            return S(U, V).astype(np.float32).reshape(len(u0), 81, 3)
+
+        pi, pj = np.meshgrid(np.arange(P), np.arange(Q), indexing="xy")     # (Q,P)
+        pos0 = sample((pi / P).reshape(-1), (pj / Q).reshape(-1), 1.0 / P, 1.0 / Q)
+        ids0 = self._add_meshlets(pos0, 0).reshape(Q, P)
+        edge = float(np.mean(np.linalg.norm(pos0[:, 8].astype(np.float64) - pos0[:, 0].astype(np.float64), axis=1)))
+        e1, e2 = error_scale * edge, 2.0 * error_scale * edge
+
+        def block_centers(step):
+            # AABB centre of each step x step block of LOD0 patches -> (Q/step, P/step, 3)
+            bq, bp = Q // step, P // step
+            pm = pos0.reshape(Q, P, 81, 3)
+            pm = pm.reshape(bq, step, bp, step, 81, 3)
+            mn = pm.min(axis=(1, 3, 4))
+            mx = pm.max(axis=(1, 3, 4))
+            return (0.5 * (mn.astype(np.float64) + mx.astype(np.float64))).astype(np.float32)
+
+        if lods == 1:
+            # un-parented LOD0 groups: runs of up to 4 meshlets in id order (rootSphereGroupMap, nanite_builder.cpp:373-390)
+            flat = ids0.reshape(-1)
+            n4 = (len(flat) // 4) * 4
+            if n4:
+                self._add_groups(flat[:n4].reshape(-1, 4), 0.0, -1.0, 0.0, FLT_MAX)
+            if len(flat) - n4:
+                self._add_groups(flat[n4:].reshape(1, -1), 0.0, -1.0, 0.0, FLT_MAX)
+            return
+
+        c1 = block_centers(2)                                                 # (Q/2, P/2, 3)
+        blk0 = ids0.reshape(Q // 2, 2, P // 2, 2).transpose(0, 2, 1, 3).reshape(-1, 4)
+        self._add_groups(blk0, 0.0, -1.0, c1.reshape(-1, 3), e1)
+
+        # LOD1: two meshlets per 2x2 block, each spanning half the block in u
+        bi, bj = np.meshgrid(np.arange(P // 2), np.arange(Q // 2), indexing="xy")
+        u0 = np.stack([bi * 2 / P, bi * 2 / P + 1.0 / P], axis=-1).reshape(-1)
+        v0 = np.repeat((bj * 2 / Q).reshape(-1), 2)
+        pos1 = sample(u0, v0, 1.0 / P, 2.0 / Q)
+        ids1 = self._add_meshlets(pos1, 1).reshape(Q // 2, P // 2, 2)
+        if lods == 2:
+            self._add_groups(ids1.reshape(-1, 2), c1.reshape(-1, 3), e1, 0.0, FLT_MAX)
+            return
+        c2 = block_centers(4)                                                 # (Q/4, P/4, 3)
+        c2_for_b1 = np.repeat(np.repeat(c2, 2, axis=0), 2, axis=1)
+        self._add_groups(ids1.reshape(-1, 2), c1.reshape(-1, 3), e1, c2_for_b1.reshape(-1, 3), e2)
+
+        # LOD2: four meshlets per 4x4 block, each spanning a 2x2-patch quadrant
+        qi, qj = np.meshgrid(np.arange(P // 2), np.arange(Q // 2), indexing="xy")
+        pos2 = sample((qi * 2 / P).reshape(-1), (qj * 2 / Q).reshape(-1), 2.0 / P, 2.0 / Q)
+        ids2 = self._add_meshlets(pos2, 2).reshape(Q // 2, P // 2)
+        blk2 = ids2.reshape(Q // 4, 2, P // 4, 2).transpose(0, 2, 1, 3).reshape(-1, 4)
+        self._add_groups(blk2, c2.reshape(-1, 3), e2, 0.0, FLT_MAX)
+
+    def finish(self):
+        pos = np.concatenate(self.positions) if self.positions else np.zeros((0, 3), np.float32)
+        return dict(
+            positions=pos,
+            meshlets=np.concatenate(self.meshlets),
+            meshlet_data=np.concatenate(self.meshlet_data),
+            groups=np.concatenate(self.groups),
+            group_indices=np.concatenate(self.group_indices),
+        )
+
+
+class SceneBuilder:
+    def __init__(self, name):
+        self.name = name
+        self.prims = []
+        self.materials = [self._material(0)]
+        self.obj_prim = []
+        self.obj_mat = []
+        self.obj_l2w = []
+
+    @staticmethod
+    def _material(two_sided):
+        m = np.zeros(1, dtype=T.MATERIAL)
+        m["bTwoSided"] = two_sided
+        m["baseColorFactor"] = 1.0
+        m["materialType"] = 1
+        return m
+
+    def add_material(self, two_sided):
+        self.materials.append(self._material(two_sided))
+        return len(self.materials) - 1
+
+    def add_primitive(self, builder):
+        self.prims.append(builder.finish())
+        return len(self.prims) - 1
+
+    def add_object(self, prim, l2w=None, material=0):
+        self.obj_prim.append(prim)
+        self.obj_mat.append(material)
+        self.obj_l2w.append(np.eye(4) if l2w is None else np.asarray(l2w, dtype=np.float64))
+        return len(self.obj_prim) - 1
+
+    def build(self):
+        prims = np.zeros(len(self.prims), dtype=T.PRIMITIVE)
+        pos, ml, md, gr, gi = [], [], [], [], []
+        nv = nm = nd = ng = ni = 0
+        for i, p in enumerate(self.prims):
+            prims[i]["posMin"] = p["positions"].min(axis=0)
+            prims[i]["posMax"] = p["positions"].max(axis=0)
+            prims[i]["posAverage"] = p["positions"].mean(axis=0)
+            prims[i]["vertexOffset"], prims[i]["vertexCount"] = nv, len(p["positions"])
+            prims[i]["meshletOffset"] = nm
+            prims[i]["meshletGroupOffset"], prims[i]["meshletGroupCount"] = ng, len(p["groups"])
+            prims[i]["meshletGroupIndicesOffset"] = ni
+            m = p["meshlets"].copy()
+            m["dataOffset"] += nd
+            pos.append(p["positions"]); ml.append(m); md.append(p["meshlet_data"]); gr.append(p["groups"]); gi.append(p["group_indices"])
+            nv += len(p["positions"]); nm += len(m); nd += len(p["meshlet_data"]); ng += len(p["groups"]); ni += len(p["group_indices"])
+        objects = np.zeros(len(self.obj_prim), dtype=T.OBJECT)
+        objects["GLTFPrimitiveDetail"] = np.array(self.obj_prim, dtype=np.uint32)
+        objects["GLTFMaterialData"] = np.array(self.obj_mat, dtype=np.uint32)
+        scene = T.Scene(objects, prims, np.concatenate(self.materials), np.concatenate(ml), np.concatenate(gr),
+                        np.concatenate(gi), np.concatenate(md), np.concatenate(pos), name=self.name)
+        # glm column-major doubles
+        scene.local_to_world = np.ascontiguousarray(np.stack([m.T.reshape(16) for m in self.obj_l2w]), dtype=np.float64)
+        return scene
+
+
+def translate(x, y, z):
+    m = np.eye(4)
+    m[:3, 3] = (x, y, z)
+    return m
+
+
+def rotate_y(a):
+    c, s = math.cos(a), math.sin(a)
+    m = np.eye(4)
+    m[0, 0], m[0, 2], m[2, 0], m[2, 2] = c, s, -s, c
+    return m
+
+
+def scale(sx, sy=None, sz=None):
+    sy = sx if sy is None else sy
+    sz = sx if sz is None else sz
+    return np.diag([sx, sy, sz, 1.0])
+
+
+# --------------------------------------------------------------------------------- surfaces ---
+
+def _bumps(seed, amp, freq):
+    """Smooth deterministic displacement field d(a, b) (sum of 4 sinusoids)."""
+    ph = rand01(seed, np.arange(12))
+    ths = ph[0:4] * 2 * math.pi
+    fs = freq * (0.6 + 1.4 * ph[4:8])
+    ps = ph[8:12] * 2 * math.pi
+
+    def d(a, b):
+        r = 0.0
+        for k in range(4):
+            r = r + np.sin(fs[k] * (a * math.cos(ths[k]) + b * math.sin(ths[k])) + ps[k])
+        return amp * 0.25 * r
+    return d
+
+
+def plane_surface(origin, du, dv, seed=0, amp=0.0, freq=1.0):
+    """S(u,v) = origin + u*du + v*dv + n*d(u,v); normal n = normalize(du x dv)."""
+    origin, du, dv = (np.asarray(x, dtype=np.float64) for x in (origin, du, dv))
+    n = np.cross(du, dv)
+    n = n / np.linalg.norm(n)
+    lu, lv = np.linalg.norm(du), np.linalg.norm(dv)
+    d = _bumps(seed, amp, freq)
+
+    def S(U, V):
+        h = d(U * lu, V * lv) if amp else 0.0
+        return origin + U[..., None] * du + V[..., None] * dv + (np.zeros_like(U) + h)[..., None] * n
+    return S
+
+
+def cylinder_surface(base, radius, height, seed=0, amp=0.0):
+    """Outward-facing cylinder wall around +y; u = angle, v = height."""
+    base = np.asarray(base, dtype=np.float64)
+    d = _bumps(seed, amp, 3.0)
+
+    def S(U, V):
+        ang = -U * 2 * math.pi                    # dS/du x dS/dv points outward
+        r = radius + (d(U * 2 * math.pi * radius, V * height) if amp else 0.0)
+        return base + np.stack([r * np.cos(ang), V * height, r * np.sin(ang)], axis=-1)
+    return S
+
+
+# ------------------------------------------------------------------------------------ camera ---
+
+class Camera:
+    def __init__(self, position, front, width, height, fovy=math.radians(45.0), z_near=0.001, z_far=20000.0,
+                 world_up=(0.0, 1.0, 0.0), jitter=(0.0, 0.0)):
+        self.position = tuple(float(x) for x in position)
+        self.front = tuple(float(x) for x in front)
+        self.world_up = world_up
+        self.width, self.height = int(width), int(height)
+        self.fovy, self.z_near, self.z_far = float(fovy), float(z_near), float(z_far)
+        self.jitter = jitter
+
+    def moved(self, delta):
+        c = Camera(tuple(p + d for p, d in zip(self.position, delta)), self.front, self.width, self.height,
+                   self.fovy, self.z_near, self.z_far, self.world_up, self.jitter)
+        return c
+
+
+# ------------------------------------------------------------------------------------ configs ---
+
+def config1_single_meshlet():
+    """BASELINE config 1: one 128-triangle meshlet, 256x256, fixed camera."""
+    i = np.arange(81)
+    z = ((pcg32(1, i) & 0xFFFF).astype(np.float64) / 65535.0 - 0.5) * 0.2
+
+    def S(U, V):
+        # exact lattice: look the height up by vertex index
+        ii = np.rint(U * 8).astype(np.int64)
+        jj = np.rint(V * 8).astype(np.int64)
+        return np.stack([U * 2 - 1, V * 2 - 1, z[jj * 9 + ii]], axis=-1)
+
+    pb = PrimitiveBuilder()
+    pb.add_surface(S, 1, 1, lods=1)
+    sb = SceneBuilder("config1_single_meshlet")
+    sb.add_object(sb.add_primitive(pb))
+    cam = Camera((0.0, 0.0, 3.0), (0.0, 0.0, -1.0), 256, 256)
+    return sb.build(), cam
+
+
+def config2_atrium(width=1920, height=1080):
+    """BASELINE config 2 (Sponza-class): 2048 patches = 262 144 triangles, 22 objects, single LOD."""
+    sb = SceneBuilder("config2_atrium")
+    L, Wd, Hh = 32.0, 16.0, 8.0
+    seed = 2000
+
+    def obj(S, P, Q):
+        nonlocal seed
+        pb = PrimitiveBuilder()
+        pb.add_surface(S, P, Q, lods=1)
+        sb.add_object(sb.add_primitive(pb))
+        seed += 1
+
+    # floor (normal +y), ceiling (normal -y)
+    obj(plane_surface((-L / 2, 0, Wd / 2), (L, 0, 0), (0, 0, -Wd), seed, 0.03, 2.0), 32, 16)
+    obj(plane_surface((-L / 2, Hh, -Wd / 2), (L, 0, 0), (0, 0, Wd), seed, 0.05, 1.0), 32, 8)
+    # long walls (normals facing inward)
+    obj(plane_surface((-L / 2, 0, -Wd / 2), (L, 0, 0), (0, Hh, 0), seed, 0.04, 1.5), 32, 8)
+    obj(plane_surface((L / 2, 0, Wd / 2), (-L, 0, 0), (0, Hh, 0), seed, 0.04, 1.5), 32, 8)
+    # end walls
+    obj(plane_surface((-L / 2, 0, Wd / 2), (0, 0, -Wd), (0, Hh, 0), seed, 0.04, 1.5), 16, 8)
+    obj(plane_surface((L / 2, 0, -Wd / 2), (0, 0, Wd), (0, Hh, 0), seed, 0.04, 1.5), 16, 8)
+    # two colonnades of 8 columns
+    for side in (-1, 1):
+        for k in range(8):
+            x = -L / 2 + 2.0 + k * 4.0
+            obj(cylinder_surface((x, 0.0, side * 4.0), 0.45, Hh, seed, 0.02), 4, 8)
+    cam = Camera((-L / 2 + 1.0, 1.7, 0.3), (1.0, -0.02, -0.01), width, height)
+    return sb.build(), cam
+
+
+def _building(pb, w, d, h, seed, lods):
+    # 4 sides + roof, each 8x8 patches, normals outward
+    pb.add_surface(plane_surface((-w / 2, 0, d / 2), (w, 0, 0), (0, h, 0), seed + 0, 0.15, 0.8), 8, 8, lods)      # +z face
+    pb.add_surface(plane_surface((w / 2, 0, d / 2), (0, 0, -d), (0, h, 0), seed + 1, 0.15, 0.8), 8, 8, lods)     # +x face
+    pb.add_surface(plane_surface((w / 2, 0, -d / 2), (-w, 0, 0), (0, h, 0), seed + 2, 0.15, 0.8), 8, 8, lods)    # -z face
+    pb.add_surface(plane_surface((-w / 2, 0, -d / 2), (0, 0, d), (0, h, 0), seed + 3, 0.15, 0.8), 8, 8, lods)    # -x face
+    pb.add_surface(plane_surface((-w / 2, h, d / 2), (w, 0, 0), (0, 0, -d), seed + 4, 0.10, 0.5), 8, 8, lods)    # roof
+
+
+def _street_primitives(sb, lods=3):
+    """Unique geometry of one 'street' block: ground + 40 buildings + 311 props. Returns [(prim, l2w)]."""
+    out = []
+    pb = PrimitiveBuilder()
+    pb.add_surface(plane_surface((-64, 0, 64), (128, 0, 0), (0, 0, -128), 3000, 0.08, 0.9), 64, 64, lods)
+    out.append((sb.add_primitive(pb), np.eye(4)))
+    # 4 rows x 10 buildings along x; rows at z = -34, -14 | +14, +34 (street down the middle)
+    b = 0
+    for row, z in enumerate((-36.0, -15.0, 15.0, 36.0)):
+        for k in range(10):
+            r = rand01(3100, np.arange(b * 4, b * 4 + 4))
+            w, d, h = 9.0 + 2.0 * r[0], 9.0 + 2.0 * r[1], 10.0 + 14.0 * r[2]
+            pb = PrimitiveBuilder()
+            _building(pb, w, d, h, 3200 + b * 8, lods)
+            x = -58.0 + k * 12.8 + (r[3] - 0.5)
+            out.append((sb.add_primitive(pb), translate(x, 0.0, z) @ rotate_y((r[3] - 0.5) * 0.2)))
+            b += 1
+    # 311 props (lamp posts / bollards / planters): 4x4-patch cylinders scattered over the street and sidewalks
+    for p in range(311):
+        r = rand01(3900, np.arange(p * 5, p * 5 + 5))
+        rad, hgt = 0.15 + 0.5 * r[0], 0.8 + 3.5 * r[1]
+        pb = PrimitiveBuilder()
+        pb.add_surface(cylinder_surface((0, 0, 0), rad, hgt, 4000 + p, 0.02), 4, 4, lods)
+        x, z = -60.0 + 120.0 * r[2], -8.0 + 16.0 * r[3]
+        out.append((sb.add_primitive(pb), translate(x, 0.0, z)))
+    return out
+
+
+def config3_street(width=3840, height=2160, lods=3):
+    """BASELINE config 3 (Bistro-class): 21 872 LOD0 patches = 2 799 616 triangles, 352 objects, 3 LOD levels."""
+    sb = SceneBuilder("config3_street")
+    for prim, l2w in _street_primitives(sb, lods):
+        sb.add_object(prim, l2w)
+    cam = Camera((-57.0, 1.7, 0.4), (1.0, 0.03, 0.02), width, height)
+    return sb.build(), cam
+
+
+def config4_street_x64(width=3840, height=2160, grid=8, lods=3):
+    """BASELINE config 4: config 3 instanced on a grid x grid lattice (shared geometry), ~179 M triangles at 8x8."""
+    sb = SceneBuilder("config4_street_x%d" % (grid * grid))
+    prims = _street_primitives(sb, lods)
+    pitch = 132.0
+    for gz in range(grid):
+        for gx in range(grid):
+            off = translate((gx - (grid - 1) / 2) * pitch, 0.0, (gz - (grid - 1) / 2) * pitch)
+            for prim, l2w in prims:
+                sb.add_object(prim, off @ l2w)
+    half = (grid - 1) / 2 * pitch
+    cam = Camera((-half - 60.0, 45.0, -half - 20.0), (1.0, -0.28, 0.75), width, height)
+    return sb.build(), cam
+
+
+def small_test_scene(width=160, height=96, lods=3, seed=7, two_sided_every=3):
+    """A small multi-object scene with LODs for parity tests (a few hundred meshlets)."""
+    sb = SceneBuilder("small_test_scene")
+    two = sb.add_material(1)
+    pb = PrimitiveBuilder()
+    pb.add_surface(plane_surface((-8, 0, 8), (16, 0, 0), (0, 0, -16), seed, 0.2, 0.7), 8, 8, lods)
+    sb.add_object(sb.add_primitive(pb))
+    for k in range(6):
+        r = rand01(seed + 1, np.arange(k * 4, k * 4 + 4))
+        pb = PrimitiveBuilder()
+        if k % 2 == 0:
+            _building(pb, 1.5 + r[0], 1.5 + r[1], 1.0 + 2.5 * r[2], seed * 100 + k * 8, min(lods, 3))
+        else:
+            pb.add_surface(cylinder_surface((0, 0, 0), 0.3 + 0.4 * r[0], 1.0 + 2.0 * r[1], seed * 100 + k, 0.03), 4, 4, lods)
+        prim = sb.add_primitive(pb)
+        m = translate(-5.0 + 10.0 * r[2], 0.0, -5.0 + 10.0 * r[3]) @ rotate_y(r[0] * 3.0) @ scale(1.0 + 0.5 * r[1])
+        sb.add_object(prim, m, material=two if (k % two_sided_every == 1) else 0)
+        if k == 2:      # an instanced copy
+            sb.add_object(prim, translate(3.0, 0.0, 4.0) @ m)
+    cam = Camera((-7.0, 1.6, 6.5), (0.8, -0.12, -0.6), width, height)
+    return sb.build(), cam

@@ -1,0 +1,222 @@
+/*
+ * chordvis.h — C ABI of the MI355X-native visibility hot path (libchordvis.so).
+ *
+ * The reference has no plugin/FFI boundary for this path: its boundary is the
+ * free-function pass surface of source/renderer (gltf_rendering.h:37-108,
+ * postprocessing.h:41-54) called from DeferredRenderer::render
+ * (renderer.cpp:319-345), sitting on the Vulkan device layer of
+ * source/graphics.  Every entry point below names the reference interface it
+ * replaces.  Signatures carry plain pointers and sizes only; device memory is
+ * named by raw device pointers (the counterpart of the reference's bindless
+ * uint32 ids obtained from asSRV/asUAV, render_helper.h:290-359).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative CHORDVIS_E_* code otherwise;
+ *    chordvis_last_error(ctx) returns the message (reference: check()/
+ *    checkVkResult() assert + log, utils.h:57-72, graphics/common.h:337).
+ *  - one host thread per context; all passes are enqueued on the context's HIP
+ *    stream in call order and never synchronize the host (reference: one
+ *    graphics queue, one vkQueueSubmit per frame, command_list.cpp:107-153).
+ *  - handles (ChordCountAndCmd, ChordHZB) point into context-owned device
+ *    memory and stay valid until the next chordvis_instance_culling /
+ *    chordvis_build_hzb into the same slot (reference: pooled buffers recycled
+ *    after N frames, buffer_pool.cpp:71,122).
+ */
+#ifndef CHORDVIS_H
+#define CHORDVIS_H
+
+#include "chordvis_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHORDVIS_OK              0
+#define CHORDVIS_E_INVALID      -1   /* bad argument / call order            */
+#define CHORDVIS_E_HIP          -2   /* a HIP runtime call failed            */
+#define CHORDVIS_E_NO_DEVICE    -3   /* no usable gfx950 device              */
+#define CHORDVIS_E_CAPACITY     -4   /* scene exceeds a documented limit     */
+
+typedef struct ChordCtx ChordCtx;
+
+/* CountAndCmdBuffer — postprocessing.h:48.  Device pointers. */
+typedef struct ChordCountAndCmd {
+    uint32_t*     count;     /* device: number of valid commands           */
+    ChordDrawCmd* cmds;      /* device: uint3 commands                     */
+    uint32_t      capacity;  /* commands the buffer can hold               */
+} ChordCountAndCmd;
+
+/* HZBContext — render_helper.h:411-451.  Device pointers into one f16 chain per channel. */
+typedef struct ChordHZB {
+    ChordHZBDesc desc;
+    uint16_t*    minTexels;   /* device, desc.totalTexels halves, or NULL    */
+    uint16_t*    maxTexels;   /* device or NULL                              */
+    uint32_t*    validRange;  /* device uint2 {asuint(min), asuint(max)} or NULL */
+} ChordHZB;
+
+/* Camera inputs of ICamera (camera.h:22-139) + ViewportCamera::updateMatrixMisc (viewport.cpp:434-445). */
+typedef struct ChordCameraDesc {
+    double   position[3];
+    double   front[3];
+    double   worldUp[3];
+    float    fovy;          /* radians */
+    float    jitter[2];     /* PerframeCameraView::jitterData.xy, pixels in (-0.5, 0.5) */
+    double   zNear;
+    double   zFar;
+    uint32_t width, height;
+} ChordCameraDesc;
+
+/* GPU timestamps — the labels DeferredRenderer::render inserts (renderer.cpp:322-344). */
+typedef struct ChordStats {
+    float    msClear;              /* "Clear GBuffers"                   */
+    float    msInstanceCulling;    /* "GLTF Instance Culling"            */
+    float    msStage0;             /* "GLTF Visibility Stage0"           */
+    float    msHzbStage0;          /* "BuildHZB Post Prepass Stage0"     */
+    float    msStage1;             /* "GLTF Visibility Stage1"           */
+    float    msHzbFinal;           /* "BuildHZB"                         */
+    float    msFrame;              /* clear .. final HZB                 */
+    float    msRasterCluster;      /* sum over the frame's raster_cluster_kernel launches */
+    float    msRasterClip;         /* ... raster_clip_kernel                                */
+    float    msRasterChunk;        /* ... raster_chunk_kernel                               */
+    uint32_t rasterLaunches;       /* renderMesh calls this frame (1 or 2)                  */
+    uint32_t overflow;             /* non-zero: a deferred raster list overflowed (results invalid) */
+    uint32_t countInstanceCulled;  /* commands after instanceCulling     */
+    uint32_t countStage0Visible;
+    uint32_t countStage0Rejected;
+    uint32_t countStage1Visible;
+    uint64_t trianglesSubmitted;   /* sum of meshlet triangle counts of rastered commands */
+} ChordStats;
+
+/* ------------------------------------------------------------------ host-only (no device needed) */
+
+const char* chordvis_version(void);
+
+/* hzb.cpp:49-63 — extent / mip count / offsets of the HZB chain for a render size. */
+int chordvis_hzb_desc(uint32_t srcWidth, uint32_t srcHeight, ChordHZBDesc* out);
+
+/* ICamera::fillViewUniformParameter (camera.cpp:17-78), ICamera::computeRelativeWorldFrustum
+ * (camera.cpp:80-154), infiniteInvertZPerspectiveRH_ZO (utils.cpp:186-198) and the main-view
+ * InstanceCullingViewInfo fill of DeferredRenderer::render (renderer.cpp:175-263).
+ * lastFrame may be NULL (first frame: last-frame matrices = current). */
+int chordvis_camera_fill_view(const ChordCameraDesc* camera, const ChordCameraView* lastFrame,
+                              ChordCameraView* outView, ChordInstanceCullingView* outInstanceView);
+
+/* SceneNode::getObjectBasicData (scene_node.cpp:42-90): camera-relative f64 -> f32 transforms.
+ * Matrices are glm column-major doubles. */
+int chordvis_object_basic_data(const double localToWorld[16], const double prevLocalToWorld[16],
+                               const double cameraPos[3], const double cameraPosLast[3],
+                               ChordObjectBasicData* out);
+/* Batched form: fills objects[i].basicData for i < count (ids/pads untouched).
+ * prevLocalToWorld / cameraPosLast may be NULL (static object / camera). */
+int chordvis_object_basic_data_batch(uint32_t count, const double* localToWorld /*count*16*/,
+                                     const double* prevLocalToWorld, const double cameraPos[3],
+                                     const double cameraPosLast[3], ChordObject* objects);
+
+/* ------------------------------------------------------------------ context (graphics::Context, graphics.h:88-345) */
+
+/* hipStream: an existing hipStream_t to enqueue on (e.g. the caller's current stream), or NULL
+ * for a context-owned stream. */
+int chordvis_create(int deviceOrdinal, void* hipStream, ChordCtx** outCtx);
+int chordvis_destroy(ChordCtx* ctx);
+const char* chordvis_last_error(ChordCtx* ctx);
+int chordvis_sync(ChordCtx* ctx);
+
+/* GPUScene / asset upload (gpu_scene.h:20-165, asset_gltf.h:278): copies and flattens. */
+int chordvis_upload_scene(ChordCtx* ctx, const ChordSceneDesc* scene);
+/* uploadBufferToGPU("GLTFObjectInfo", ...) renderer.cpp:229 — per-frame object records
+ * (count must equal the uploaded scene's objectCount; primitive/material ids must not change). */
+int chordvis_update_objects(ChordCtx* ctx, const ChordObject* hostObjects, uint32_t count);
+/* Same, for a caller-owned DEVICE array (no copy; must stay valid while bound). */
+int chordvis_bind_objects(ChordCtx* ctx, const ChordObject* deviceObjects, uint32_t count);
+
+/* uploadBufferToGPU("PerViewCamera") + ("MainViewInstanceCullingInfo") renderer.cpp:246,262
+ * and the r.instanceculling.* cvars -> switchFlags (instance_culling.cpp:22-68). */
+int chordvis_set_view(ChordCtx* ctx, const ChordCameraView* view, const ChordInstanceCullingView* instanceView,
+                      uint32_t switchFlags);
+
+/* allocateGBufferTextures (render_textures.cpp:20-45): size the visibility target.  deviceVisibility
+ * may be a caller-owned device buffer of chordvis_visibility_words(ctx) uint64 (used for the
+ * multi-GPU all-gather), or NULL for a context-owned one. */
+int chordvis_allocate_gbuffer(ChordCtx* ctx, uint32_t width, uint32_t height, uint64_t* deviceVisibility);
+
+/* Multi-GPU screen ownership: rows are cut into stripes of stripeRows (even); stripe s belongs
+ * to rank (s % ranks).  The visibility buffer is stored rank-major (rank r's stripes
+ * contiguous) so one in-place all-gather reassembles it.  ranks == 1: plain row-major. */
+int chordvis_set_shard(ChordCtx* ctx, uint32_t stripeRows, uint32_t ranks, uint32_t rank);
+/* Number of uint64 words of the (possibly padded, rank-major) visibility buffer, and of one rank's chunk. */
+uint64_t chordvis_visibility_words(ChordCtx* ctx);
+uint64_t chordvis_visibility_chunk_words(ChordCtx* ctx);
+/* Device pointer of the visibility buffer in use (row-major when ranks == 1). */
+uint64_t* chordvis_visibility_ptr(ChordCtx* ctx);
+
+/* ------------------------------------------------------------------ passes (stream-ordered) */
+
+/* addClearGbufferPass — render_textures.cpp:74-102 (visibility = 0, depth = 0.0). */
+int chordvis_clear_gbuffer(ChordCtx* ctx);
+
+/* instanceCulling — instance_culling.cpp:83-161 (instanceCullingCS + clusterGroupCullingCS).
+ * Slots are assigned in deterministic (objectId, groupIdx, meshlet) order. */
+int chordvis_instance_culling(ChordCtx* ctx, ChordCountAndCmd* out);
+
+/* detail::hzbCulling — instance_culling.cpp:286-351 (hzbMainViewCullingCS).
+ * bFirstStage: project with last-frame matrices, also emit the rejected list. */
+int chordvis_hzb_culling(ChordCtx* ctx, const ChordHZB* hzb, int bFirstStage, ChordCountAndCmd in,
+                         ChordCountAndCmd* outVisible, ChordCountAndCmd* outRejected);
+
+/* renderMesh — mesh_raster.cpp:208-254: the 4 material buckets (filterPipeForVisibility +
+ * renderMeshRasterPipe) collapse into one software-raster launch that reads bTwoSided per
+ * cluster; masked materials are out of scope. */
+int chordvis_render_mesh(ChordCtx* ctx, ChordCountAndCmd in);
+
+/* gltfVisibilityRenderingStage0 — mesh_raster.cpp:269-311.  hzbPrev NULL/invalid or HZB culling
+ * disabled => draws `in`, *shouldStage1 = 0. */
+int chordvis_visibility_stage0(ChordCtx* ctx, const ChordHZB* hzbPrev, ChordCountAndCmd in,
+                               ChordCountAndCmd* outRejected, int* shouldStage1);
+
+/* gltfVisibilityRenderingStage1 — mesh_raster.cpp:313-329. */
+int chordvis_visibility_stage1(ChordCtx* ctx, const ChordHZB* hzb, ChordCountAndCmd in);
+
+/* buildHZB — hzb.cpp:38-227 from the depth half of the visibility words.
+ * slot 0 = temporary (post stage 0), slots 1/2 = history ping-pong. */
+int chordvis_build_hzb(ChordCtx* ctx, int bBuildMin, int bBuildMax, int bBuildValidRange, int slot, ChordHZB* out);
+
+/* DeferredRenderer::render hot segment (renderer.cpp:315-345,489): clear -> instanceCulling ->
+ * stage0 -> [buildHZB -> stage1] -> buildHZB(min,max,validRange); keeps the HZB as history for
+ * the next call.  Single-GPU (ranks == 1) only; sharded frames are driven in three phases so the
+ * host can run the collectives in between:
+ *   chordvis_frame_phase_a  clear .. stage 0 raster, own-stripe HZB mip 0 into the exchange buffer
+ *   [all-gather exchange buffer]
+ *   chordvis_frame_phase_b  assemble HZB, stage 1 cull + raster
+ *   [all-gather visibility buffer in place]
+ *   chordvis_frame_phase_c  de-stripe into row-major, final HZB, history swap            */
+int chordvis_render_frame(ChordCtx* ctx);
+int chordvis_frame_phase_a(ChordCtx* ctx);
+int chordvis_frame_phase_b(ChordCtx* ctx);
+int chordvis_frame_phase_c(ChordCtx* ctx);
+int chordvis_reset_history(ChordCtx* ctx);
+/* exchange buffer for the mid-frame HZB mip-0 all-gather (f16, rank-major) */
+uint16_t* chordvis_hzb_exchange_ptr(ChordCtx* ctx);
+uint64_t chordvis_hzb_exchange_halves(ChordCtx* ctx);        /* whole buffer */
+uint64_t chordvis_hzb_exchange_chunk_halves(ChordCtx* ctx);  /* one rank     */
+/* row-major visibility after phase_c (== chordvis_visibility_ptr when ranks == 1) */
+uint64_t* chordvis_resolved_visibility_ptr(ChordCtx* ctx);
+
+/* handles of the last frame (post-instanceCulling list: consumer contract, lighting.hlsl:318-345) */
+int chordvis_last_frame_cmds(ChordCtx* ctx, ChordCountAndCmd* out);
+int chordvis_history_hzb(ChordCtx* ctx, ChordHZB* out);
+
+/* ------------------------------------------------------------------ readback / stats (synchronize) */
+
+int chordvis_readback_visibility(ChordCtx* ctx, uint64_t* hostWords /* width*height, row-major */);
+int chordvis_readback_cmds(ChordCtx* ctx, ChordCountAndCmd handle, ChordDrawCmd* hostCmds, uint32_t cap, uint32_t* outCount);
+int chordvis_readback_hzb(ChordCtx* ctx, const ChordHZB* hzb, uint16_t* hostMin, uint16_t* hostMax, uint32_t hostValidRange[2]);
+/* upload an HZB min chain from the host (tests: feed a known history) into history */
+int chordvis_upload_history_hzb(ChordCtx* ctx, const uint16_t* hostMin);
+
+int chordvis_enable_timers(ChordCtx* ctx, int enable);
+int chordvis_stats(ChordCtx* ctx, ChordStats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHORDVIS_H */

@@ -1,0 +1,212 @@
+/*
+ * chordvis_types.h — the data contract of the visibility hot path.
+ *
+ * Plain-C restatement of the POD records the reference shares between its C++
+ * host code and its HLSL kernels.  Byte layouts are identical to the reference
+ * so a maintainer can hand the reference's own arrays across the C ABI:
+ *
+ *   ChordMeshlet              <- GPUGLTFMeshlet            install/resource/shader/gltf.h:38-51
+ *   ChordMeshletGroup         <- GPUGLTFMeshletGroup       install/resource/shader/gltf.h:26-36
+ *   ChordPrimitive            <- GLTFPrimitiveBuffer       install/resource/shader/gltf.h:65-91
+ *   ChordMaterial             <- GLTFMaterialGPUData       install/resource/shader/gltf.h:118-153
+ *   ChordObjectBasicData      <- GPUObjectBasicData        install/resource/shader/base.h:343-351
+ *   ChordObject               <- GPUObjectGLTFPrimitive    install/resource/shader/base.h:353-360
+ *   ChordInstanceCullingView  <- InstanceCullingViewInfo   install/resource/shader/base.h:121-135
+ *   ChordDrawCmd              <- uint3 draw command        install/resource/shader/instance_culling.hlsl:28-33
+ *
+ * Matrices are glm column-major in memory (element (row r, col c) at m[c*4+r]);
+ * the kernels read them with the HLSL convention M[r][c] == glm m[c][r]
+ * (install/resource/shader/hzb_culling_generic.hlsl:78-80).
+ *
+ * What changes versus the reference: bindless buffer ids
+ * (GLTFPrimitiveDatasBuffer, gltf.h:94-116) become plain pointers in
+ * ChordAssetDesc, and the slice of PerframeCameraView (base.h:292-340) that the
+ * path reads is restated as ChordCameraView.
+ */
+#ifndef CHORDVIS_TYPES_H
+#define CHORDVIS_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* switchFlags bits — gltf.h:10-12 */
+#define CHORD_FLAG_FRUSTUM_CULL   (1u << 0) /* kFrustumCullingEnableBit  */
+#define CHORD_FLAG_HZB_CULL       (1u << 1) /* kHZBCullingEnableBit      */
+#define CHORD_FLAG_CONE_CULL      (1u << 2) /* kMeshletConeCullEnableBit */
+
+/* base.h:428-436 */
+#define CHORD_MESHLET_MAX_VERTICES     255u
+#define CHORD_MESHLET_MAX_TRIANGLES    128u
+#define CHORD_GROUP_MAX_MESHLETS       4u
+#define CHORD_HZB_MAX_MIPS             12u
+#define CHORD_MAX_INSTANCE_ID          0xFFFFFFu /* kMaxInstanceIdCount, base.h:412 */
+
+/* nanite_shared.hlsli:11-12 */
+#define CHORD_ERROR_PIXEL_THRESHOLD    1.0f
+#define CHORD_ERROR_RADIUS_ROOT        3e38f
+
+/* base.h:442-444: sub-pixel precision of the raster the reference assumes */
+#define CHORD_SUBPIXEL_BITS            8
+
+typedef struct ChordMat4 { float m[16]; } ChordMat4;
+
+typedef struct ChordMeshlet {
+    float    posMin[3];
+    uint32_t dataOffset;           /* u32 index into meshletData           */
+    float    posMax[3];
+    uint32_t vertexTriangleCount;  /* V & 0xff | T << 8   (gltf.h:60-62)   */
+    float    coneAxis[3];
+    float    coneCutOff;
+    float    coneApex[3];
+    uint32_t lod;
+} ChordMeshlet;
+
+typedef struct ChordMeshletGroup {
+    float    clusterPosCenter[3];
+    float    parentError;          /* FLT_MAX when un-parented (root)      */
+    float    parentPosCenter[3];
+    float    error;                /* -1 at LOD0                           */
+    uint32_t meshletOffset;        /* into meshletGroupIndices             */
+    uint32_t meshletCount;         /* <= 4                                 */
+} ChordMeshletGroup;
+
+typedef struct ChordPrimitive {
+    float    posMin[3];
+    uint32_t primitiveDatasBufferId;   /* index into ChordSceneDesc.assets */
+    float    posMax[3];
+    uint32_t vertexOffset;
+    float    posAverage[3];
+    uint32_t vertexCount;
+    uint32_t meshletOffset;
+    uint32_t color0Offset;
+    uint32_t smoothNormalOffset;
+    uint32_t textureCoord1Offset;
+    uint32_t bvhNodeOffset;
+    uint32_t meshletGroupOffset;
+    uint32_t meshletGroupIndicesOffset;
+    uint32_t meshletGroupCount;
+    uint32_t lod0IndicesOffset;
+    uint32_t lod0IndicesCount;
+    uint32_t pad0;
+    uint32_t pad1;
+} ChordPrimitive;
+
+typedef struct ChordMaterial {
+    uint32_t alphaMode;
+    float    alphaCutOff;
+    uint32_t bTwoSided;
+    uint32_t baseColorId;
+    float    baseColorFactor[4];
+    float    emissiveFactor[3];
+    uint32_t emissiveTexture;
+    float    metallicFactor;
+    float    roughnessFactor;
+    uint32_t metallicRoughnessTexture;
+    uint32_t normalTexture;
+    uint32_t baseColorSampler;
+    uint32_t emissiveSampler;
+    uint32_t normalSampler;
+    uint32_t metallicRoughnessSampler;
+    float    normalFactorScale;
+    uint32_t bExistOcclusion;
+    float    occlusionTextureStrength;
+    uint32_t materialType;
+} ChordMaterial;
+
+typedef struct ChordObjectBasicData {
+    ChordMat4 localToTranslatedWorld;
+    ChordMat4 translatedWorldToLocal;
+    ChordMat4 localToTranslatedWorldLastFrame;
+    float     scaleExtractFromMatrix[4]; /* .w = max |scale| */
+} ChordObjectBasicData;
+
+typedef struct ChordObject {
+    ChordObjectBasicData basicData;
+    uint32_t GLTFPrimitiveDetail;  /* index into primitives */
+    uint32_t GLTFMaterialData;     /* index into materials  */
+    uint32_t pad1;
+    uint32_t pad2;
+} ChordObject;
+
+typedef struct ChordInstanceCullingView {
+    ChordMat4 translatedWorldToClip;
+    ChordMat4 clipToTranslatedWorld;
+    uint32_t  cameraWorldPos[8];          /* GPUStorageDouble4 */
+    float     orthoDepthConvertToView[4];
+    float     renderDimension[4];         /* w, h, 1/w, 1/h */
+    float     frustumPlanesRS[6][4];      /* left, down, right, top, front, back (camera.h:10-18) */
+} ChordInstanceCullingView;
+
+/* The slice of PerframeCameraView (base.h:292-340) the path reads, plus the
+ * one host-precomputed scalar the canonical arithmetic needs (lodScale). */
+typedef struct ChordCameraView {
+    ChordMat4 translatedWorldToView;
+    ChordMat4 translatedWorldToClip;
+    ChordMat4 translatedWorldToClipLastFrame;
+    float     renderDimension[4];         /* w, h, 1/w, 1/h */
+    float     cameraFovy;
+    float     zNear;
+    float     zFar;
+    float     lodScale;                   /* (h * 0.5f) / tanf(0.5f * fovy), base.hlsli:503-518 */
+} ChordCameraView;
+
+typedef struct ChordDrawCmd {
+    uint32_t objectId;
+    uint32_t meshletId;    /* index into the asset's meshlet array (primitive.meshletOffset applied) */
+    uint32_t slot;         /* index in the post-instanceCulling list; the visibility payload */
+} ChordDrawCmd;
+
+/* One GLTFPrimitiveDatasBuffer (gltf.h:94-116): bindless ids -> host pointers. */
+typedef struct ChordAssetDesc {
+    const ChordMeshlet*      meshlets;           uint32_t meshletCount;
+    const ChordMeshletGroup* meshletGroups;      uint32_t meshletGroupCount;
+    const uint32_t*          meshletGroupIndices;uint32_t meshletGroupIndexCount;
+    const uint32_t*          meshletData;        uint32_t meshletDataCount;  /* u32 words */
+    const float*             positions;          uint32_t vertexCount;       /* float3 tightly packed */
+} ChordAssetDesc;
+
+typedef struct ChordSceneDesc {
+    const ChordObject*    objects;    uint32_t objectCount;
+    const ChordPrimitive* primitives; uint32_t primitiveCount;
+    const ChordMaterial*  materials;  uint32_t materialCount;
+    const ChordAssetDesc* assets;     uint32_t assetCount;
+} ChordSceneDesc;
+
+/* Visibility texel — base.hlsli:437-447 (low 32 bits) under the depth bits
+ * (high 32 bits, D32 reverse-Z of render_textures.h:25). 0 == empty. */
+static inline uint32_t chord_encode_triangle_instance(uint32_t triangleId, uint32_t instanceId)
+{
+    return (((instanceId + 1u) & CHORD_MAX_INSTANCE_ID) << 8) | (triangleId & 0xFFu);
+}
+static inline void chord_decode_triangle_instance(uint32_t pack, uint32_t* triangleId, uint32_t* instanceId)
+{
+    *triangleId = pack & 0xFFu;
+    *instanceId = ((pack >> 8) & CHORD_MAX_INSTANCE_ID) - 1u;
+}
+
+/* HZB chain geometry — hzb.cpp:49-63.  mip l has (w0 >> l, h0 >> l) texels
+ * (min 1), stored as IEEE binary16, mips back to back, each row-major. */
+typedef struct ChordHZBDesc {
+    uint32_t srcWidth, srcHeight;
+    uint32_t width, height;        /* mip 0 extent */
+    uint32_t mipCount;
+    uint32_t mipOffset[CHORD_HZB_MAX_MIPS]; /* in texels from the chain base */
+    uint32_t totalTexels;
+} ChordHZBDesc;
+
+#ifdef __cplusplus
+}
+static_assert(sizeof(ChordMeshlet) == 64, "GPUGLTFMeshlet");
+static_assert(sizeof(ChordMeshletGroup) == 40, "GPUGLTFMeshletGroup");
+static_assert(sizeof(ChordPrimitive) == 96, "GLTFPrimitiveBuffer");
+static_assert(sizeof(ChordMaterial) == 96, "GLTFMaterialGPUData");
+static_assert(sizeof(ChordObjectBasicData) == 208, "GPUObjectBasicData");
+static_assert(sizeof(ChordObject) == 224, "GPUObjectGLTFPrimitive");
+static_assert(sizeof(ChordInstanceCullingView) == 288, "InstanceCullingViewInfo");
+static_assert(sizeof(ChordDrawCmd) == 12, "uint3 draw cmd");
+#endif
+
+#endif /* CHORDVIS_TYPES_H */

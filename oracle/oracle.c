@@ -1,0 +1,782 @@
+/*
+ * oracle.c — CPU restatement of chord's visibility hot path.  TEST INFRASTRUCTURE
+ * (see oracle.h).  PARITY UNPINNED by the reference's own tests; pinned by the
+ * analytic known-answer tests in tests/.
+ *
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -msse2 -mfpmath=sse
+ *
+ * Canonical arithmetic.  The reference leaves these to the
+ * shader compiler / driver / fixed-function rasterizer; this file fixes them:
+ *  (1) IEEE-754 binary32, round-to-nearest-even, every + - * / sqrt rounded
+ *      separately (no FMA contraction), evaluated in HLSL source order.
+ *      mul(M, v)[r]   = ((M[r][0]*v0 + M[r][1]*v1) + M[r][2]*v2) + M[r][3]*v3
+ *      mul(A, B)[r][c]= ((A[r][0]*B[0][c] + A[r][1]*B[1][c]) + A[r][2]*B[2][c]) + A[r][3]*B[3][c]
+ *      dot(a, b)      = (a.x*b.x + a.y*b.y) + a.z*b.z
+ *      normalize(v)   = v / sqrt(dot(v, v))
+ *      determinant(float3x3(r0,r1,r2)) = (r0.x*(r1.y*r2.z - r1.z*r2.y)
+ *                     - r0.y*(r1.x*r2.z - r1.z*r2.x)) + r0.z*(r1.x*r2.y - r1.y*r2.x)
+ *  (2) HLSL round() = round-half-to-even (rintf under the default FP env).
+ *  (3) int(float) truncates toward zero; firstbithigh(0) = -1.
+ *  (4) HZB texels are binary16, converted round-to-nearest-even.
+ *  (5) Raster: vertex (uv * dimension) snapped to 1/256 pixel with rintf, pixel
+ *      centres at +0.5, top-left fill rule, edge functions in 64-bit integers,
+ *      depth(px) = (d0 + l1*(d1-d0)) + l2*(d2-d0) with l_i = float(E_i) * (1.0f/float(2A)),
+ *      float(int64) := (float)(double)v (exact below 2^53, then one rounding),
+ *      d_i = clip.z_i / clip.w_i.  Triangles with a vertex outside
+ *      {0 <= z <= w, |x| <= G*w, |y| <= G*w} (G = 1024) go through a
+ *      Sutherland-Hodgman clipper in clip space (fixed plane order, intersections
+ *      always computed from the inside endpoint) and are fan-triangulated.
+ *  (6) Packed pixel = (asuint(depth) << 32) | encodeTriangleIdInstanceId(tri, slot); clear 0.
+ *  (7) Cluster slots are assigned in (objectId, groupIdx, meshlet-in-group) order.
+ *  (8) Depth test GREATER_OR_EQUAL + draw order  ==>  64-bit max of the packed word.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAT(mat, r, c) ((mat)->m[(c) * 4 + (r)])
+
+typedef struct { float x, y, z; } f3;
+typedef struct { float x, y, z, w; } f4;
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* ---------------------------------------------------------------- f16 ---- */
+
+uint16_t orc_f32_to_f16(float f)
+{
+    uint32_t x = f2u(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t mant = x & 0x007FFFFFu;
+    int32_t  exp  = (int32_t)((x >> 23) & 0xFF);
+    if (exp == 0xFF) return (uint16_t)(sign | 0x7C00u | (mant ? (0x0200u | (mant >> 13)) : 0u));
+    int32_t e = exp - 127 + 15;
+    if (e >= 0x1F) return (uint16_t)(sign | 0x7C00u);                 /* overflow -> inf */
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;                              /* underflow -> 0 */
+        mant |= 0x00800000u;
+        uint32_t shift = (uint32_t)(14 - e);                            /* 14..24 */
+        uint32_t h = mant >> shift;
+        uint32_t rem = mant & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (mant >> 13);
+    uint32_t rem = mant & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;             /* may carry into exp / inf: correct */
+    return (uint16_t)(sign | h);
+}
+
+float orc_f16_to_f32(uint16_t h)
+{
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t mant = h & 0x3FFu;
+    if (exp == 0) {
+        if (mant == 0) return u2f(sign);
+        int e = -1;
+        do { e++; mant <<= 1; } while (!(mant & 0x400u));
+        mant &= 0x3FFu;
+        return u2f(sign | ((uint32_t)(127 - 15 - e) << 23) | (mant << 13));
+    }
+    if (exp == 0x1F) return u2f(sign | 0x7F800000u | (mant << 13));
+    return u2f(sign | ((exp + 127 - 15) << 23) | (mant << 13));
+}
+
+/* --------------------------------------------------------- canonical ops -- */
+
+static inline f4 mul_mv(const ChordMat4* M, float v0, float v1, float v2, float v3)
+{
+    f4 r;
+    r.x = ((MAT(M,0,0) * v0 + MAT(M,0,1) * v1) + MAT(M,0,2) * v2) + MAT(M,0,3) * v3;
+    r.y = ((MAT(M,1,0) * v0 + MAT(M,1,1) * v1) + MAT(M,1,2) * v2) + MAT(M,1,3) * v3;
+    r.z = ((MAT(M,2,0) * v0 + MAT(M,2,1) * v1) + MAT(M,2,2) * v2) + MAT(M,2,3) * v3;
+    r.w = ((MAT(M,3,0) * v0 + MAT(M,3,1) * v1) + MAT(M,3,2) * v2) + MAT(M,3,3) * v3;
+    return r;
+}
+
+static inline void mul_mm(const ChordMat4* A, const ChordMat4* B, ChordMat4* C)
+{
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++)
+            MAT(C, r, c) = ((MAT(A,r,0) * MAT(B,0,c) + MAT(A,r,1) * MAT(B,1,c)) + MAT(A,r,2) * MAT(B,2,c)) + MAT(A,r,3) * MAT(B,3,c);
+}
+
+static inline float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
+/* base.hlsli:184-194 */
+static const float kExtentApplyFactor[8][3] = {
+    { 1,  1,  1}, {-1, -1, -1}, { 1,  1, -1}, { 1, -1,  1},
+    {-1,  1,  1}, { 1, -1, -1}, {-1, -1,  1}, {-1,  1, -1},
+};
+
+static inline f3 extent_corner(f3 c, f3 e, int k)
+{
+    f3 p;
+    p.x = c.x + e.x * kExtentApplyFactor[k][0];
+    p.y = c.y + e.y * kExtentApplyFactor[k][1];
+    p.z = c.z + e.z * kExtentApplyFactor[k][2];
+    return p;
+}
+
+/* base.hlsli:161-171 */
+static inline f3 project_pos_to_uvz(f3 pos, const ChordMat4* proj)
+{
+    f4 h = mul_mv(proj, pos.x, pos.y, pos.z, 1.0f);
+    f3 r;
+    r.x = h.x / h.w; r.y = h.y / h.w; r.z = h.z / h.w;
+    r.x = r.x * 0.5f + 0.5f;
+    r.y = r.y * -0.5f + 0.5f;
+    return r;
+}
+
+/* base.hlsli:243-246 */
+static inline int is_ortho_projection(const ChordMat4* M) { return MAT(M,3,3) == 1.0f; }
+
+/* base.hlsli:251-272 */
+static int ortho_frustum_culling(f3 c, f3 e, const ChordMat4* localToClip)
+{
+    f3 mn = {10.0f, 10.0f, 10.0f}, mx = {-10.0f, -10.0f, -10.0f};
+    for (int k = 0; k < 8; k++) {
+        f3 uvz = project_pos_to_uvz(extent_corner(c, e, k), localToClip);
+        mn.x = fminf(mn.x, uvz.x); mn.y = fminf(mn.y, uvz.y); mn.z = fminf(mn.z, uvz.z);
+        mx.x = fmaxf(mx.x, uvz.x); mx.y = fmaxf(mx.y, uvz.y); mx.z = fmaxf(mx.z, uvz.z);
+    }
+    return (mn.x >= 1.0f || mn.y >= 1.0f) || (mx.x <= 0.0f || mx.y <= 0.0f);
+}
+
+/* base.hlsli:275-305 */
+static int frustum_culling(const float planes[6][4], f3 c, f3 e, const ChordMat4* localToTranslatedWorld)
+{
+    f3 p[8];
+    for (int k = 0; k < 8; k++) {
+        f3 q = extent_corner(c, e, k);
+        f4 h = mul_mv(localToTranslatedWorld, q.x, q.y, q.z, 1.0f);
+        p[k].x = h.x; p[k].y = h.y; p[k].z = h.z;
+    }
+    for (int i = 0; i < 6; i++) {
+        f3 n = {planes[i][0], planes[i][1], planes[i][2]};
+        int allBack = 1;
+        for (int j = 0; j < 8; j++) {
+            if (dot3(n, p[j]) > -planes[i][3]) { allBack = 0; break; }
+        }
+        if (allBack) return 1;
+    }
+    return 0;
+}
+
+static inline void aabb_center_extent(const float mn[3], const float mx[3], int meshletOrder, f3* c, f3* e)
+{
+    /* instance_culling.hlsl:73-76 writes (posMin + posMax) * 0.5, nanite_shared.hlsli:74-77
+     * and hzb_mainview_culling.hlsl:65-68 write 0.5 * (...) / (...) * 0.5: same value. */
+    (void)meshletOrder;
+    c->x = (mn[0] + mx[0]) * 0.5f; c->y = (mn[1] + mx[1]) * 0.5f; c->z = (mn[2] + mx[2]) * 0.5f;
+    e->x = mx[0] - c->x; e->y = mx[1] - c->y; e->z = mx[2] - c->z;
+}
+
+/* ------------------------------------------------------------ object cull -- */
+
+static int object_visible(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, uint32_t flags, uint32_t o)
+{
+    /* instance_culling.hlsl:66-90 */
+    const ChordObject* obj = &scene->objects[o];
+    const ChordPrimitive* prim = &scene->primitives[obj->GLTFPrimitiveDetail];
+    if (!(flags & CHORD_FLAG_FRUSTUM_CULL)) return 1;
+    ChordMat4 localToClip;
+    mul_mm(&iv->translatedWorldToClip, &obj->basicData.localToTranslatedWorld, &localToClip);
+    f3 c, e;
+    aabb_center_extent(prim->posMin, prim->posMax, 0, &c, &e);
+    if (is_ortho_projection(&localToClip)) return !ortho_frustum_culling(c, e, &localToClip);
+    return !frustum_culling(iv->frustumPlanesRS, c, e, &obj->basicData.localToTranslatedWorld);
+}
+
+void orc_object_cull(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, uint32_t flags, uint8_t* visible)
+{
+    for (uint32_t o = 0; o < scene->objectCount; o++) visible[o] = (uint8_t)object_visible(scene, iv, flags, o);
+}
+
+/* -------------------------------------------------------- group LOD + cull -- */
+
+/* base.hlsli:233-241 + :503-518; K = (h * 0.5) / tan(fovy / 2) is host-precomputed (view->lodScale). */
+static float projected_error_px(const ChordCameraView* view, const ChordMat4* localToView, float maxScaleAbs,
+                                const float center[3], float radius)
+{
+    f4 q = mul_mv(localToView, center[0], center[1], center[2], 1.0f);
+    float R = maxScaleAbs * radius;
+    f3 q3 = {q.x, q.y, q.z};
+    float d2 = dot3(q3, q3);
+    float r2 = R * R;
+    if (d2 <= r2) return -1.0f;
+    return view->lodScale * R / sqrtf(d2 - r2);
+}
+
+int orc_group_visible(const ChordCameraView* view, const ChordObject* obj, const ChordMeshletGroup* g)
+{
+    /* nanite_shared.hlsli:15-49; localToView from instance_culling.hlsl:170 (always the main view) */
+    ChordMat4 localToView;
+    mul_mm(&view->translatedWorldToView, &obj->basicData.localToTranslatedWorld, &localToView);
+    float s = obj->basicData.scaleExtractFromMatrix[3];
+    int finalLod = g->parentError > CHORD_ERROR_RADIUS_ROOT;
+    int firstLod = g->error < -0.5f;
+    if (!finalLod) {
+        float pe = projected_error_px(view, &localToView, s, g->parentPosCenter, g->parentError);
+        if (pe > 0.0f && pe <= CHORD_ERROR_PIXEL_THRESHOLD) return 0;
+    }
+    if (!firstLod) {
+        float er = projected_error_px(view, &localToView, s, g->clusterPosCenter, g->error);
+        if (er < 0.0f || er > CHORD_ERROR_PIXEL_THRESHOLD) return 0;
+    }
+    return 1;
+}
+
+int orc_meshlet_visible(uint32_t flags, const ChordInstanceCullingView* iv, const ChordObject* obj,
+                        const ChordMeshlet* m, const ChordMaterial* mat)
+{
+    /* nanite_shared.hlsli:51-91 */
+    if (mat->bTwoSided == 0 && (flags & CHORD_FLAG_CONE_CULL)) {
+        f4 cam = mul_mv(&obj->basicData.translatedWorldToLocal, 0.0f, 0.0f, 0.0f, 1.0f);
+        f3 v = {m->coneApex[0] - cam.x, m->coneApex[1] - cam.y, m->coneApex[2] - cam.z};
+        float len = sqrtf(dot3(v, v));
+        f3 n = {v.x / len, v.y / len, v.z / len};
+        f3 axis = {m->coneAxis[0], m->coneAxis[1], m->coneAxis[2]};
+        if (dot3(n, axis) >= m->coneCutOff) return 0;
+    }
+    if (flags & CHORD_FLAG_FRUSTUM_CULL) {
+        f3 c, e;
+        aabb_center_extent(m->posMin, m->posMax, 1, &c, &e);
+        ChordMat4 localToClip;
+        mul_mm(&iv->translatedWorldToClip, &obj->basicData.localToTranslatedWorld, &localToClip);
+        if (is_ortho_projection(&localToClip)) return !ortho_frustum_culling(c, e, &localToClip);
+        return !frustum_culling(iv->frustumPlanesRS, c, e, &obj->basicData.localToTranslatedWorld);
+    }
+    return 1;
+}
+
+uint32_t orc_instance_culling(const ChordSceneDesc* scene, const ChordCameraView* view,
+                              const ChordInstanceCullingView* iv, uint32_t flags,
+                              ChordDrawCmd* outCmds, uint32_t cap)
+{
+    uint32_t n = 0;
+    for (uint32_t o = 0; o < scene->objectCount; o++) {
+        if (!object_visible(scene, iv, flags, o)) continue;
+        const ChordObject* obj = &scene->objects[o];
+        const ChordPrimitive* prim = &scene->primitives[obj->GLTFPrimitiveDetail];
+        const ChordMaterial* mat = &scene->materials[obj->GLTFMaterialData];
+        const ChordAssetDesc* as = &scene->assets[prim->primitiveDatasBufferId];
+        for (uint32_t gi = 0; gi < prim->meshletGroupCount; gi++) {
+            /* instance_culling.hlsl:163-164 */
+            const ChordMeshletGroup* g = &as->meshletGroups[prim->meshletGroupOffset + gi];
+            if (!orc_group_visible(view, obj, g)) continue;
+            for (uint32_t i = 0; i < g->meshletCount; i++) {
+                /* instance_culling.hlsl:178-180 */
+                uint32_t loadId = i + g->meshletOffset + prim->meshletGroupIndicesOffset;
+                uint32_t meshletIndex = prim->meshletOffset + as->meshletGroupIndices[loadId];
+                if (orc_meshlet_visible(flags, iv, obj, &as->meshlets[meshletIndex], mat)) {
+                    if (n < cap) { outCmds[n].objectId = o; outCmds[n].meshletId = meshletIndex; outCmds[n].slot = n; }
+                    n++;
+                }
+            }
+        }
+    }
+    return n;
+}
+
+/* -------------------------------------------------------------------- HZB -- */
+
+static uint32_t next_pot(uint32_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++; return v; }
+
+void orc_hzb_desc(uint32_t srcW, uint32_t srcH, ChordHZBDesc* out)
+{
+    /* hzb.cpp:49-63 */
+    uint32_t w = next_pot(srcW) / 2, h = next_pot(srcH) / 2;
+    if (w == srcW) w /= 2;
+    if (h == srcH) h /= 2;
+    if (w < 1) w = 1;
+    if (h < 1) h = 1;
+    uint32_t mx = w > h ? w : h, mips = 0;
+    while (mx) { mips++; mx >>= 1; }                 /* floor(log2(max)) + 1 */
+    if (mips > CHORD_HZB_MAX_MIPS) mips = CHORD_HZB_MAX_MIPS;
+    memset(out, 0, sizeof(*out));
+    out->srcWidth = srcW; out->srcHeight = srcH; out->width = w; out->height = h; out->mipCount = mips;
+    uint32_t off = 0;
+    for (uint32_t l = 0; l < mips; l++) {
+        uint32_t mw = w >> l, mh = h >> l;
+        if (mw < 1) mw = 1;
+        if (mh < 1) mh = 1;
+        out->mipOffset[l] = off;
+        off += mw * mh;
+    }
+    out->totalTexels = off;
+}
+
+static inline uint32_t mip_w(const ChordHZBDesc* d, uint32_t l) { uint32_t w = d->width >> l; return w ? w : 1; }
+static inline uint32_t mip_h(const ChordHZBDesc* d, uint32_t l) { uint32_t h = d->height >> l; return h ? h : 1; }
+
+uint32_t orc_hzb_valid_w(const ChordHZBDesc* d, uint32_t l)
+{
+    uint32_t v = (((d->srcWidth - 1) >> 1) >> l) + 1, w = mip_w(d, l);
+    return v < w ? v : w;
+}
+uint32_t orc_hzb_valid_h(const ChordHZBDesc* d, uint32_t l)
+{
+    uint32_t v = (((d->srcHeight - 1) >> 1) >> l) + 1, h = mip_h(d, l);
+    return v < h ? v : h;
+}
+
+void orc_hzb_build(const uint64_t* vis, uint32_t W, uint32_t H, const ChordHZBDesc* desc,
+                   uint16_t* hzbMin, uint16_t* hzbMax, uint32_t validRange[2])
+{
+    /* hzb_one.hlsl:126-372 / hzb.hlsl:127-389 restated per SURVEY Appendix A4:
+     * texel (x,y) of mip l = reduce over the 2^(l+1) square of edge-clamped
+     * source depth; converted to binary16 on store.  min/max commute with the
+     * monotone f32->f16 rounding, so reducing level by level from the stored
+     * halves (what the shader does from mip 5 up) gives the same bits.  Max
+     * variant: mips >= 5 carry +1 ulp (hzb.hlsl:67-71).  Only the sampled
+     * (valid) extent of each mip is defined; the rest is written as 0. */
+    memset(hzbMin, 0, sizeof(uint16_t) * desc->totalTexels);
+    if (hzbMax) memset(hzbMax, 0, sizeof(uint16_t) * desc->totalTexels);
+    uint32_t vmin = 0xFFFFFFFFu, vmax = 0u;
+    /* mip 0 from the source */
+    {
+        uint32_t vw = orc_hzb_valid_w(desc, 0), vh = orc_hzb_valid_h(desc, 0), mw = mip_w(desc, 0);
+        for (uint32_t y = 0; y < vh; y++) for (uint32_t x = 0; x < vw; x++) {
+            float mn = 0, mx = 0;
+            for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) {
+                uint32_t sx = 2 * x + i, sy = 2 * y + j;
+                if (sx > W - 1) sx = W - 1;
+                if (sy > H - 1) sy = H - 1;
+                float d = u2f((uint32_t)(vis[(size_t)sy * W + sx] >> 32));
+                if (i == 0 && j == 0) { mn = d; mx = d; } else { mn = fminf(mn, d); mx = fmaxf(mx, d); }
+                if (d > 0.0f) {                      /* hzb.hlsl:163-166 */
+                    uint32_t b = f2u(d);
+                    if (d < 1.0f && b < vmin) vmin = b;   /* :173 guard, see note in DESIGN.md */
+                    if (b > vmax) vmax = b;
+                }
+            }
+            hzbMin[desc->mipOffset[0] + y * mw + x] = orc_f32_to_f16(mn);
+            if (hzbMax) hzbMax[desc->mipOffset[0] + y * mw + x] = orc_f32_to_f16(mx);
+        }
+    }
+    for (uint32_t l = 1; l < desc->mipCount; l++) {
+        uint32_t vw = orc_hzb_valid_w(desc, l), vh = orc_hzb_valid_h(desc, l), mw = mip_w(desc, l);
+        uint32_t pw = orc_hzb_valid_w(desc, l - 1), ph = orc_hzb_valid_h(desc, l - 1), pmw = mip_w(desc, l - 1);
+        for (uint32_t y = 0; y < vh; y++) for (uint32_t x = 0; x < vw; x++) {
+            float mn = 0, mx = 0;
+            for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) {
+                uint32_t cx = 2 * x + i, cy = 2 * y + j;
+                if (cx > pw - 1) cx = pw - 1;        /* children past the valid edge are clamped duplicates */
+                if (cy > ph - 1) cy = ph - 1;
+                size_t idx = desc->mipOffset[l - 1] + (size_t)cy * pmw + cx;
+                float a = orc_f16_to_f32(hzbMin[idx]);
+                float b = hzbMax ? orc_f16_to_f32(hzbMax[idx]) : 0.0f;
+                if (i == 0 && j == 0) { mn = a; mx = b; } else { mn = fminf(mn, a); mx = fmaxf(mx, b); }
+            }
+            size_t o = desc->mipOffset[l] + (size_t)y * mw + x;
+            hzbMin[o] = orc_f32_to_f16(mn);
+            if (hzbMax) {
+                uint16_t h = orc_f32_to_f16(mx);
+                if (l == 5) h = (uint16_t)(h + 1);   /* storeHZBMip5: f32tof16(depth) + 1 */
+                hzbMax[o] = h;
+            }
+        }
+    }
+    if (validRange) { validRange[0] = vmin; validRange[1] = vmax; }
+}
+
+static inline int first_bit_high(int32_t v)
+{
+    if (v <= 0) return -1;     /* arguments here are >= 0; firstbithigh(0) = -1 */
+    int b = 31;
+    while (!((uint32_t)v >> b)) b--;
+    return b;
+}
+
+static inline float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+static int hzb_visible(const ChordSceneDesc* scene, const ChordCameraView* view, uint32_t flags, int phase,
+                       const ChordHZBDesc* hzb, const uint16_t* hzbMin, const ChordDrawCmd* cmd)
+{
+    /* hzb_mainview_culling.hlsl:56-161 */
+    const ChordObject* obj = &scene->objects[cmd->objectId];
+    const ChordPrimitive* prim = &scene->primitives[obj->GLTFPrimitiveDetail];
+    const ChordAssetDesc* as = &scene->assets[prim->primitiveDatasBufferId];
+    const ChordMeshlet* m = &as->meshlets[cmd->meshletId];
+    if (!(flags & CHORD_FLAG_HZB_CULL)) return 1;
+
+    f3 c, e;
+    aabb_center_extent(m->posMin, m->posMax, 1, &c, &e);
+    ChordMat4 mvp;
+    if (phase == 0) mul_mm(&view->translatedWorldToClipLastFrame, &obj->basicData.localToTranslatedWorldLastFrame, &mvp);
+    else            mul_mm(&view->translatedWorldToClip, &obj->basicData.localToTranslatedWorld, &mvp);
+
+    f3 mx = {-10.0f, -10.0f, -10.0f}, mn = {10.0f, 10.0f, 10.0f};
+    for (int i = 0; i < 8; i++) {
+        f3 uvz = project_pos_to_uvz(extent_corner(c, e, i), &mvp);
+        mn.x = fminf(mn.x, uvz.x); mn.y = fminf(mn.y, uvz.y); mn.z = fminf(mn.z, uvz.z);
+        mx.x = fmaxf(mx.x, uvz.x); mx.y = fmaxf(mx.y, uvz.y); mx.z = fmaxf(mx.z, uvz.z);
+    }
+    int zInRange = mx.z < 1.0f && mn.z > 0.0f;
+    int visible = 1;
+    if (zInRange) {
+        if ((mn.x >= 1.0f || mn.y >= 1.0f) || (mx.x <= 0.0f || mx.y <= 0.0f)) visible = 0;
+    }
+    if (visible && zInRange) {
+        mn.x = saturatef(mn.x); mn.y = saturatef(mn.y);
+        mx.x = saturatef(mx.x); mx.y = saturatef(mx.y);
+        const float W = view->renderDimension[0], H = view->renderDimension[1];
+        int32_t rx = (int32_t)(mn.x * W + 0.5f);
+        int32_t ry = (int32_t)(mn.y * H + 0.5f);
+        int32_t rz = (int32_t)(mx.x * W + -0.5f);
+        int32_t rw = (int32_t)(mx.y * H + -0.5f);
+        if (rx < 0) rx = 0;
+        if (ry < 0) ry = 0;
+        /* min(renderDimension.xy - 1, pixelRect.zw) in float, then truncated */
+        rz = (int32_t)fminf(W - 1.0f, (float)rz);
+        rw = (int32_t)fminf(H - 1.0f, (float)rw);
+        if (rz < rx || rw < ry) {
+            visible = 0;
+        } else {
+            int32_t mx0 = rx >> 1, my0 = ry >> 1, mz0 = rz >> 1, mw0 = rw >> 1;
+            int lx = first_bit_high(mz0 - mx0), ly = first_bit_high(mw0 - my0);
+            int lv = (lx > ly ? lx : ly) - 1;
+            if (lv < 0) lv = 0;
+            if (((mz0 >> lv) - (mx0 >> lv) >= 4) || ((mw0 >> lv) - (my0 >> lv) >= 4)) lv += 1;
+            int32_t cx = mx0 >> lv, cy = my0 >> lv, cz = mz0 >> lv, cw = mw0 >> lv;
+            float zMin = 10.0f;
+            uint32_t mw = mip_w(hzb, (uint32_t)lv);
+            for (int x = 0; x < 4; x++) for (int y = 0; y < 4; y++) {
+                int32_t sx = cx + x < cz ? cx + x : cz;
+                int32_t sy = cy + y < cw ? cy + y : cw;
+                zMin = fminf(zMin, orc_f16_to_f32(hzbMin[hzb->mipOffset[lv] + (size_t)sy * mw + (size_t)sx]));
+            }
+            if (zMin > mx.z) visible = 0;
+        }
+    }
+    return visible;
+}
+
+void orc_hzb_culling(const ChordSceneDesc* scene, const ChordCameraView* view, uint32_t flags, int phase,
+                     const ChordHZBDesc* hzb, const uint16_t* hzbMin,
+                     const ChordDrawCmd* inCmds, uint32_t inCount,
+                     ChordDrawCmd* outVisible, uint32_t* outVisibleCount,
+                     ChordDrawCmd* outRejected, uint32_t* outRejectedCount)
+{
+    uint32_t nv = 0, nr = 0;
+    for (uint32_t i = 0; i < inCount; i++) {
+        if (hzb_visible(scene, view, flags, phase, hzb, hzbMin, &inCmds[i])) outVisible[nv++] = inCmds[i];
+        else if (phase == 0 && outRejected) outRejected[nr++] = inCmds[i];
+    }
+    *outVisibleCount = nv;
+    if (outRejectedCount) *outRejectedCount = nr;
+}
+
+/* ----------------------------------------------------------------- raster -- */
+
+static inline int owns_row(const OrcShard* s, uint32_t y)
+{
+    if (!s || s->ranks <= 1) return 1;
+    return ((y / s->stripeRows) % s->ranks) == s->rank;
+}
+
+static inline void vis_max(uint64_t* p, uint64_t v, int atomic)
+{
+    if (!atomic) { if (v > *p) *p = v; return; }
+    uint64_t cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > cur) {
+        if (__atomic_compare_exchange_n(p, &cur, v, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+    }
+}
+
+static inline int64_t floor_shift8(int64_t v) { return v >= 0 ? (v >> 8) : -((-v + 255) >> 8); }
+
+typedef struct { int atomic; } RasterCtx;
+
+static void raster_snapped(const int32_t X[3], const int32_t Y[3], const float d[3], int twoSided, uint32_t payload,
+                           uint32_t W, uint32_t H, const OrcShard* shard, uint64_t* vis, OrcRasterStats* st, int atomic)
+{
+    /* signed doubled area in y-down screen space; reference front faces
+     * (det > 0 in clip (x,y,w), mesh_raster.hlsl:143-149; CCW front + Y-flipped
+     * viewport, helper.h:304-324,395-400) have area2 < 0 here. */
+    int64_t area2 = (int64_t)(X[1] - X[0]) * (int64_t)(Y[2] - Y[0]) - (int64_t)(X[2] - X[0]) * (int64_t)(Y[1] - Y[0]);
+    if (area2 == 0) return;
+    if (!twoSided && area2 > 0) return;             /* VK_CULL_MODE_BACK_BIT, mesh_raster.cpp:235 */
+    int64_t s = area2 < 0 ? -1 : 1;
+    int64_t A = area2 * s;
+
+    int32_t minX = X[0] < X[1] ? X[0] : X[1]; if (X[2] < minX) minX = X[2];
+    int32_t maxX = X[0] > X[1] ? X[0] : X[1]; if (X[2] > maxX) maxX = X[2];
+    int32_t minY = Y[0] < Y[1] ? Y[0] : Y[1]; if (Y[2] < minY) minY = Y[2];
+    int32_t maxY = Y[0] > Y[1] ? Y[0] : Y[1]; if (Y[2] > maxY) maxY = Y[2];
+    int64_t px0 = floor_shift8((int64_t)minX + 127), px1 = floor_shift8((int64_t)maxX - 128);
+    int64_t py0 = floor_shift8((int64_t)minY + 127), py1 = floor_shift8((int64_t)maxY - 128);
+    if (px0 < 0) px0 = 0;
+    if (py0 < 0) py0 = 0;
+    if (px1 > (int64_t)W - 1) px1 = (int64_t)W - 1;
+    if (py1 > (int64_t)H - 1) py1 = (int64_t)H - 1;
+    if (px1 < px0 || py1 < py0) return;
+    if (st) st->trianglesRastered++;
+
+    /* edge i is opposite vertex i: E0 = orient(V1,V2,P), E1 = orient(V2,V0,P), E2 = orient(V0,V1,P) */
+    static const int ea[3] = {1, 2, 0}, eb[3] = {2, 0, 1};
+    int64_t a[3], b[3], bias[3];
+    for (int i = 0; i < 3; i++) {
+        /* F(P) = s * ((B.x-A.x)*(P.y-A.y) - (B.y-A.y)*(P.x-A.x)); dF/dx = a, dF/dy = b */
+        a[i] = -s * (int64_t)(Y[eb[i]] - Y[ea[i]]);
+        b[i] =  s * (int64_t)(X[eb[i]] - X[ea[i]]);
+        int topLeft = (a[i] > 0) || (a[i] == 0 && b[i] > 0);
+        bias[i] = topLeft ? 0 : -1;
+    }
+    const float invA = 1.0f / (float)(double)A;
+    const float e1 = d[1] - d[0], e2 = d[2] - d[0];
+
+    for (int64_t py = py0; py <= py1; py++) {
+        if (!owns_row(shard, (uint32_t)py)) continue;
+        for (int64_t px = px0; px <= px1; px++) {
+            int64_t cx = px * 256 + 128, cy = py * 256 + 128;
+            int64_t E[3];
+            int inside = 1;
+            for (int i = 0; i < 3; i++) {
+                E[i] = s * ((int64_t)(X[eb[i]] - X[ea[i]]) * (cy - Y[ea[i]]) - (int64_t)(Y[eb[i]] - Y[ea[i]]) * (cx - X[ea[i]]));
+                if (E[i] + bias[i] < 0) { inside = 0; break; }
+            }
+            if (!inside) continue;
+            float l1 = (float)(double)E[1] * invA, l2 = (float)(double)E[2] * invA;
+            float z = (d[0] + l1 * e1) + l2 * e2;
+            uint64_t packed = ((uint64_t)f2u(z) << 32) | payload;
+            vis_max(&vis[(size_t)py * W + (size_t)px], packed, atomic);
+            if (st) st->fragments++;
+        }
+    }
+}
+
+void orc_raster_snapped_triangle(const int32_t X[3], const int32_t Y[3], const float d[3],
+                                 int twoSided, uint32_t payload, uint32_t W, uint32_t H,
+                                 const OrcShard* shard, uint64_t* vis, OrcRasterStats* stats)
+{
+    raster_snapped(X, Y, d, twoSided, payload, W, H, shard, vis, stats, 0);
+}
+
+#define ORC_GUARD 1024.0f
+
+/* signed distance of clip-space vertex to plane k (inside >= 0) */
+static inline float clip_dist(const f4* v, int k)
+{
+    switch (k) {
+    case 0: return v->w - v->z;                 /* near (reverse-Z: depth <= 1) */
+    case 1: return v->z;                        /* far  (depth >= 0)            */
+    case 2: return ORC_GUARD * v->w + v->x;
+    case 3: return ORC_GUARD * v->w - v->x;
+    case 4: return ORC_GUARD * v->w + v->y;
+    default: return ORC_GUARD * v->w - v->y;
+    }
+}
+
+static inline int vertex_in_fast_volume(const f4* v)
+{
+    if (!(v->w > 0.0f)) return 0;
+    for (int k = 0; k < 6; k++) if (!(clip_dist(v, k) >= 0.0f)) return 0;
+    return 1;
+}
+
+static inline f4 clip_intersect(const f4* in, const f4* out, float din, float dout)
+{
+    float t = din / (din - dout);
+    f4 r;
+    r.x = in->x + (out->x - in->x) * t;
+    r.y = in->y + (out->y - in->y) * t;
+    r.z = in->z + (out->z - in->z) * t;
+    r.w = in->w + (out->w - in->w) * t;
+    return r;
+}
+
+static inline void snap_vertex(const f4* h, float W, float H, int32_t* X, int32_t* Y, float* d)
+{
+    /* same expression the cull tests use (mesh_raster.hlsl:159-161) with w > 0 */
+    float u = h->x / fabsf(h->w) * 0.5f + 0.5f;
+    float v = h->y / fabsf(h->w) * -0.5f + 0.5f;
+    *X = (int32_t)rintf((u * W) * 256.0f);
+    *Y = (int32_t)rintf((v * H) * 256.0f);
+    *d = h->z / h->w;
+}
+
+static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, const ChordDrawCmd* cmd,
+                           const OrcShard* shard, uint64_t* vis, OrcRasterStats* st, int atomic)
+{
+    /* mesh_raster.hlsl:66-185 */
+    const ChordObject* obj = &scene->objects[cmd->objectId];
+    const ChordPrimitive* prim = &scene->primitives[obj->GLTFPrimitiveDetail];
+    const ChordMaterial* mat = &scene->materials[obj->GLTFMaterialData];
+    const ChordAssetDesc* as = &scene->assets[prim->primitiveDatasBufferId];
+    const ChordMeshlet* m = &as->meshlets[cmd->meshletId];
+    const uint32_t V = m->vertexTriangleCount & 0xFFu, T = (m->vertexTriangleCount >> 8) & 0xFFu;
+    const int twoSided = mat->bTwoSided != 0;       /* mesh_raster.cpp:224-235: DIM_TWO_SIDED bucket */
+    const float W = iv->renderDimension[0], H = iv->renderDimension[1];
+    const uint32_t Wi = (uint32_t)W, Hi = (uint32_t)H;
+
+    ChordMat4 mvp;
+    mul_mm(&iv->translatedWorldToClip, &obj->basicData.localToTranslatedWorld, &mvp);
+
+    f4 hs[CHORD_MESHLET_MAX_VERTICES + 1];
+    for (uint32_t i = 0; i < V; i++) {
+        uint32_t vi = prim->vertexOffset + as->meshletData[m->dataOffset + i];
+        const float* p = &as->positions[(size_t)vi * 3];
+        hs[i] = mul_mv(&mvp, p[0], p[1], p[2], 1.0f);
+    }
+    if (st) { st->clusters++; st->trianglesSubmitted += T; }
+
+    for (uint32_t t = 0; t < T; t++) {
+        uint32_t packedIdx = as->meshletData[m->dataOffset + V + t];
+        uint32_t idx[3] = {packedIdx & 0xFFu, (packedIdx >> 8) & 0xFFu, (packedIdx >> 16) & 0xFFu};
+        f4 h[3] = {hs[idx[0]], hs[idx[1]], hs[idx[2]]};
+
+        /* #0 back face (homogeneous determinant on x,y,w) */
+        if (!twoSided) {
+            float det = (h[0].x * (h[1].y * h[2].w - h[1].w * h[2].y)
+                       - h[0].y * (h[1].x * h[2].w - h[1].w * h[2].x))
+                       + h[0].w * (h[1].x * h[2].y - h[1].y * h[2].x);
+            if (det <= 0.0f) { if (st) st->trianglesBackface++; continue; }
+        }
+        /* #1 all behind */
+        if (h[0].w <= 0.0f && h[1].w <= 0.0f && h[2].w <= 0.0f) { if (st) st->trianglesNear++; continue; }
+        float u[3], v[3];
+        for (int i = 0; i < 3; i++) {
+            u[i] = h[i].x / fabsf(h[i].w) * 0.5f + 0.5f;
+            v[i] = h[i].y / fabsf(h[i].w) * -0.5f + 0.5f;
+        }
+        float maxU = fmaxf(u[0], fmaxf(u[1], u[2])), maxV = fmaxf(v[0], fmaxf(v[1], v[2]));
+        float minU = fminf(u[0], fminf(u[1], u[2])), minV = fminf(v[0], fminf(v[1], v[2]));
+        /* #2 off screen */
+        if ((minU >= 1.0f || minV >= 1.0f) || (maxU <= 0.0f || maxV <= 0.0f)) { if (st) st->trianglesOffscreen++; continue; }
+        /* #3 small primitive */
+        if (rintf(minU * W) == rintf(maxU * W) || rintf(minV * H) == rintf(maxV * H)) { if (st) st->trianglesSmall++; continue; }
+
+        uint32_t payload = chord_encode_triangle_instance(t, cmd->slot);
+        if (vertex_in_fast_volume(&h[0]) && vertex_in_fast_volume(&h[1]) && vertex_in_fast_volume(&h[2])) {
+            int32_t X[3], Y[3]; float d[3];
+            for (int i = 0; i < 3; i++) {
+                X[i] = (int32_t)rintf((u[i] * W) * 256.0f);
+                Y[i] = (int32_t)rintf((v[i] * H) * 256.0f);
+                d[i] = h[i].z / h[i].w;
+            }
+            raster_snapped(X, Y, d, twoSided, payload, Wi, Hi, shard, vis, st, atomic);
+        } else {
+            if (st) st->trianglesClipped++;
+            f4 poly[2][12];
+            int n = 3, cur = 0;
+            poly[0][0] = h[0]; poly[0][1] = h[1]; poly[0][2] = h[2];
+            for (int k = 0; k < 6 && n >= 3; k++) {
+                int m2 = 0;
+                f4* in = poly[cur]; f4* out = poly[cur ^ 1];
+                for (int i = 0; i < n; i++) {
+                    const f4* P = &in[i]; const f4* Q = &in[(i + 1) % n];
+                    float dp = clip_dist(P, k), dq = clip_dist(Q, k);
+                    int pin = dp >= 0.0f, qin = dq >= 0.0f;
+                    if (pin) out[m2++] = *P;
+                    if (pin && !qin) out[m2++] = clip_intersect(P, Q, dp, dq);
+                    else if (!pin && qin) out[m2++] = clip_intersect(Q, P, dq, dp);
+                }
+                n = m2; cur ^= 1;
+            }
+            if (n < 3) continue;
+            int ok = 1;
+            int32_t PX[12], PY[12]; float PD[12];
+            for (int i = 0; i < n; i++) {
+                if (!(poly[cur][i].w > 0.0f)) { ok = 0; break; }
+                snap_vertex(&poly[cur][i], W, H, &PX[i], &PY[i], &PD[i]);
+            }
+            if (!ok) continue;
+            for (int i = 1; i + 1 < n; i++) {
+                int32_t X[3] = {PX[0], PX[i], PX[i + 1]}, Y[3] = {PY[0], PY[i], PY[i + 1]};
+                float d[3] = {PD[0], PD[i], PD[i + 1]};
+                raster_snapped(X, Y, d, twoSided, payload, Wi, Hi, shard, vis, st, atomic);
+            }
+        }
+    }
+}
+
+void orc_raster(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv,
+                const ChordDrawCmd* cmds, uint32_t count, const OrcShard* shard,
+                uint64_t* vis, OrcRasterStats* stats)
+{
+    for (uint32_t i = 0; i < count; i++) raster_cluster(scene, iv, &cmds[i], shard, vis, stats, 0);
+}
+
+typedef struct {
+    const ChordSceneDesc* scene; const ChordInstanceCullingView* iv; const ChordDrawCmd* cmds;
+    uint32_t count; uint32_t* next; uint64_t* vis; OrcRasterStats stats;
+} MtJob;
+
+static void* mt_worker(void* p)
+{
+    MtJob* j = (MtJob*)p;
+    for (;;) {
+        uint32_t i = __atomic_fetch_add(j->next, 64u, __ATOMIC_RELAXED);
+        if (i >= j->count) break;
+        uint32_t e = i + 64u < j->count ? i + 64u : j->count;
+        for (; i < e; i++) raster_cluster(j->scene, j->iv, &j->cmds[i], NULL, j->vis, &j->stats, 1);
+    }
+    return NULL;
+}
+
+void orc_raster_mt(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv,
+                   const ChordDrawCmd* cmds, uint32_t count, uint32_t threads,
+                   uint64_t* vis, OrcRasterStats* stats)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256]; MtJob jobs[256]; uint32_t next = 0;
+    for (uint32_t t = 0; t < threads; t++) {
+        memset(&jobs[t], 0, sizeof(MtJob));
+        jobs[t].scene = scene; jobs[t].iv = iv; jobs[t].cmds = cmds; jobs[t].count = count; jobs[t].next = &next; jobs[t].vis = vis;
+        pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+    }
+    for (uint32_t t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        if (stats) {
+            uint64_t* a = (uint64_t*)stats; const uint64_t* b = (const uint64_t*)&jobs[t].stats;
+            for (size_t k = 0; k < sizeof(OrcRasterStats) / 8; k++) a[k] += b[k];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ frame -- */
+
+void orc_frame(const ChordSceneDesc* scene, const ChordCameraView* view, const ChordInstanceCullingView* iv,
+               uint32_t flags, const uint16_t* prevHzbMin, const OrcShard* shard,
+               uint64_t* vis, ChordDrawCmd* outCmds, uint32_t cmdCap, uint32_t counts[4],
+               uint16_t* outHzbMin, uint16_t* outHzbMax, uint32_t outValidRange[2],
+               OrcRasterStats* stats)
+{
+    const uint32_t W = (uint32_t)iv->renderDimension[0], H = (uint32_t)iv->renderDimension[1];
+    ChordHZBDesc hd;
+    orc_hzb_desc(W, H, &hd);
+    memset(vis, 0, sizeof(uint64_t) * (size_t)W * H);           /* render_textures.cpp:81-85,98-100 */
+    if (counts) memset(counts, 0, sizeof(uint32_t) * 4);
+
+    uint32_t n = orc_instance_culling(scene, view, iv, flags, outCmds, cmdCap);   /* renderer.cpp:321 */
+    if (n > cmdCap) n = cmdCap;
+    if (counts) counts[0] = n;
+
+    if (prevHzbMin && (flags & CHORD_FLAG_HZB_CULL)) {                           /* mesh_raster.cpp:293 */
+        ChordDrawCmd* visL = (ChordDrawCmd*)malloc(sizeof(ChordDrawCmd) * (n ? n : 1));
+        ChordDrawCmd* rejL = (ChordDrawCmd*)malloc(sizeof(ChordDrawCmd) * (n ? n : 1));
+        uint16_t* tmpHzb = (uint16_t*)malloc(sizeof(uint16_t) * hd.totalTexels);
+        uint32_t nv = 0, nr = 0, nv1 = 0;
+        orc_hzb_culling(scene, view, flags, 0, &hd, prevHzbMin, outCmds, n, visL, &nv, rejL, &nr);
+        orc_raster(scene, iv, visL, nv, shard, vis, stats);                       /* stage 0 */
+        orc_hzb_build(vis, W, H, &hd, tmpHzb, NULL, NULL);                        /* renderer.cpp:334 */
+        orc_hzb_culling(scene, view, flags, 1, &hd, tmpHzb, rejL, nr, visL, &nv1, NULL, NULL);
+        orc_raster(scene, iv, visL, nv1, shard, vis, stats);                      /* stage 1 */
+        if (counts) { counts[1] = nv; counts[2] = nr; counts[3] = nv1; }
+        free(visL); free(rejL); free(tmpHzb);
+    } else {
+        orc_raster(scene, iv, outCmds, n, shard, vis, stats);                     /* mesh_raster.cpp:307 */
+        if (counts) counts[1] = n;
+    }
+    if (outHzbMin) orc_hzb_build(vis, W, H, &hd, outHzbMin, outHzbMax, outValidRange);  /* renderer.cpp:343 */
+}

@@ -1,0 +1,120 @@
+/*
+ * oracle.h — CPU restatement of chord's visibility hot path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (chord_amd/, libchordvis.so) never does.
+ *
+ * PARITY UNPINNED: the reference has no golden vectors, known-answer tests or
+ * fixtures for this path (application/unit_test/main.cpp:6-26 tests only the
+ * job system) and cannot be built or run here (MSVC + Vulkan mesh shaders +
+ * DXC; CMakeLists.txt:94-96, source/shader_compiler/compiler.cpp:7-13).  This
+ * restatement therefore pins the implementation-defined choices the reference
+ * leaves to the driver / fixed-function hardware (see "Canonical arithmetic"
+ * in oracle.c) and is itself pinned by analytic known-answer tests under
+ * tests/ (raster rules, HZB brute force, LOD cut, frustum KATs).
+ *
+ * Each function cites the reference file:line whose algorithm it follows.
+ */
+#ifndef CHORD_ORACLE_H
+#define CHORD_ORACLE_H
+
+#include "../include/chordvis_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrcRasterStats {
+    uint64_t clusters;           /* draw commands rastered                                  */
+    uint64_t trianglesSubmitted; /* sum of meshlet triangle counts (the Gtri/s unit)        */
+    uint64_t trianglesBackface;  /* culled by mesh_raster.hlsl:143-149                      */
+    uint64_t trianglesNear;      /* :152-155                                                */
+    uint64_t trianglesOffscreen; /* :168-171                                                */
+    uint64_t trianglesSmall;     /* :174-179                                                */
+    uint64_t trianglesClipped;   /* survivors that needed the homogeneous clipper           */
+    uint64_t trianglesRastered;  /* survivors scan-converted (after snapped-area rejection) */
+    uint64_t fragments;          /* covered pixel centres (before the depth test)           */
+} OrcRasterStats;
+
+/* Screen ownership for the multi-GPU shard: rows are cut into stripes of
+ * `stripeRows`; stripe s belongs to rank (s % ranks).  ranks == 1 => all. */
+typedef struct OrcShard {
+    uint32_t stripeRows;
+    uint32_t ranks;
+    uint32_t rank;
+} OrcShard;
+
+uint16_t orc_f32_to_f16(float f);      /* round-to-nearest-even */
+float    orc_f16_to_f32(uint16_t h);
+
+/* hzb.cpp:49-63 */
+void orc_hzb_desc(uint32_t srcW, uint32_t srcH, ChordHZBDesc* out);
+/* valid (sampled) extent of mip l: texels x <= ((W-1)>>1)>>l */
+uint32_t orc_hzb_valid_w(const ChordHZBDesc* d, uint32_t l);
+uint32_t orc_hzb_valid_h(const ChordHZBDesc* d, uint32_t l);
+
+/* instance_culling.hlsl:47-131 (object stage only): visible[o] = 0/1 */
+void orc_object_cull(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv,
+                     uint32_t flags, uint8_t* visible);
+
+/* nanite_shared.hlsli:15-49 */
+int orc_group_visible(const ChordCameraView* view, const ChordObject* obj, const ChordMeshletGroup* g);
+
+/* nanite_shared.hlsli:51-91 */
+int orc_meshlet_visible(uint32_t flags, const ChordInstanceCullingView* iv, const ChordObject* obj,
+                        const ChordMeshlet* m, const ChordMaterial* mat);
+
+/* instance_culling.hlsl:47-208 — both stages, canonical (objectId, group, meshlet) order.
+ * Returns the number of commands (may exceed cap; only cap are written). */
+uint32_t orc_instance_culling(const ChordSceneDesc* scene, const ChordCameraView* view,
+                              const ChordInstanceCullingView* iv, uint32_t flags,
+                              ChordDrawCmd* outCmds, uint32_t cap);
+
+/* hzb_mainview_culling.hlsl:35-213.  phase 0 => last-frame matrices, emits
+ * visible + rejected; phase 1 => current matrices, emits visible only
+ * (outRejected may be NULL). Order of the input list is preserved. */
+void orc_hzb_culling(const ChordSceneDesc* scene, const ChordCameraView* view, uint32_t flags, int phase,
+                     const ChordHZBDesc* hzb, const uint16_t* hzbMin,
+                     const ChordDrawCmd* inCmds, uint32_t inCount,
+                     ChordDrawCmd* outVisible, uint32_t* outVisibleCount,
+                     ChordDrawCmd* outRejected, uint32_t* outRejectedCount);
+
+/* hzb_one.hlsl:126-372 / hzb.hlsl:127-389 — depth = high 32 bits of the
+ * visibility words.  hzbMax and validRange may be NULL. */
+void orc_hzb_build(const uint64_t* vis, uint32_t W, uint32_t H, const ChordHZBDesc* desc,
+                   uint16_t* hzbMin, uint16_t* hzbMax, uint32_t validRange[2]);
+
+/* mesh_raster.hlsl:51-210 + the fixed-function state it drives, canonical
+ * software scan conversion into the packed 64-bit visibility words. */
+void orc_raster(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv,
+                const ChordDrawCmd* cmds, uint32_t count, const OrcShard* shard,
+                uint64_t* vis, OrcRasterStats* stats);
+
+/* Scan-convert one screen-space triangle given snapped 24.8 coordinates
+ * (exposed for the raster-rule known-answer tests). */
+void orc_raster_snapped_triangle(const int32_t X[3], const int32_t Y[3], const float d[3],
+                                 int twoSided, uint32_t payload, uint32_t W, uint32_t H,
+                                 const OrcShard* shard, uint64_t* vis, OrcRasterStats* stats);
+
+/* Frame logic — mesh_raster.cpp:269-329, renderer.cpp:319-345,489.
+ * prevHzbMin == NULL => no history (first frame): whole list drawn, no stage 1.
+ * outCmds receives the post-instanceCulling list (consumer contract,
+ * lighting.hlsl:318-345). outHzbMin/outHzbMax/outValidRange = the HZB kept
+ * for the next frame. counts[0..3] = {instanceCulled, stage0Visible,
+ * stage0Rejected, stage1Visible}. */
+void orc_frame(const ChordSceneDesc* scene, const ChordCameraView* view, const ChordInstanceCullingView* iv,
+               uint32_t flags, const uint16_t* prevHzbMin, const OrcShard* shard,
+               uint64_t* vis, ChordDrawCmd* outCmds, uint32_t cmdCap, uint32_t counts[4],
+               uint16_t* outHzbMin, uint16_t* outHzbMax, uint32_t outValidRange[2],
+               OrcRasterStats* stats);
+
+/* OpenMP-free multi-threaded replay of orc_frame's raster legs (pthread,
+ * per-thread row bands merged by max) for the all-cores CPU baseline. */
+void orc_raster_mt(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv,
+                   const ChordDrawCmd* cmds, uint32_t count, uint32_t threads,
+                   uint64_t* vis, OrcRasterStats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
