@@ -62,7 +62,11 @@ def build(force=False, verbose=True):
             rebuilt = True
         objs.append(obj)
     if rebuilt or not os.path.exists(LIB):
-        cmd = [HIPCC, "-shared", "-fPIC", "-o", LIB] + objs + ["--offload-arch=gfx950"]
+        # -no-hip-rt: libchordvis.so carries NO DT_NEEDED on a particular libamdhip64.  A process must hold
+        # exactly one HIP/HSA runtime; PyTorch-ROCm wheels bundle their own (SONAME libamdhip64.so, not
+        # libamdhip64.so.7), so the host decides which runtime is live and loads it first (chord_amd/lib.py;
+        # a C++ host simply links -lamdhip64 itself).
+        cmd = [HIPCC, "-shared", "-fPIC", "-no-hip-rt", "-o", LIB] + objs + ["--offload-arch=gfx950"]
         if verbose:
             print("[chord_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

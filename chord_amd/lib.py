@@ -50,7 +50,30 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+def _preload_hip_runtime():
+    """Make exactly one HIP runtime live in this process, with global symbol visibility.
+
+    libchordvis.so is linked with -no-hip-rt (no DT_NEEDED on libamdhip64).  If PyTorch-ROCm is
+    installed its bundled runtime must be the one (two HSA runtimes in one process cannot both open
+    the device), otherwise the system ROCm runtime is used.
+    """
+    candidates = []
+    try:
+        import torch  # noqa: F401  (plumbing only: device memory, streams, torch.distributed)
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    candidates += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so"), "libamdhip64.so"]
+    for path in candidates:
+        try:
+            return C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            continue
+    raise ChordvisError("no HIP runtime (libamdhip64.so) found; tried: %s" % ", ".join(candidates))
+
+
 def _load():
+    _preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ChordvisError(
             "libchordvis.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
