@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — Gtri/s of the visibility hot path on N MI355X (one process per GPU).
+
+A "step" is one frame of the hot path (clear -> instanceCulling -> stage 0 [HZB phase 0 + raster]
+-> buildHZB -> stage 1 [HZB phase 1 + raster] -> buildHZB(min,max,range)) over a synthetic meshlet
+scene already resident in HBM.  Consecutive steps alternate between two camera positions 0.5 m
+apart so that every frame culls against the HZB of a *different* previous frame (BASELINE config 3:
+"two frames, camera advanced 0.5 m").
+
+  N = 1   workload "street_4k_hzb"      BASELINE config 3 (Bistro-class, 3840x2160, two-pass HZB)
+  N > 1   workload "street_x64_4k_hzb"  BASELINE config 4 (config 3 x 64 instances), rows sharded
+          in interleaved stripes across the ranks, HZB mip 0 + visibility reassembled with two
+          RCCL all-gathers per frame (torch.distributed, backend nccl == RCCL)
+
+value = triangles of the clusters submitted to the rasterizer per frame (post-cull, the unit of
+SURVEY §8d) x steps / wall time of the timed region, max over ranks.  Prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLUSTER_BYTES = 64 + 12   # meshlet header + draw command; + 4*(V+T) + 12*V per cluster
+
+
+def pick_stripe_rows(height, ranks):
+    """Even stripe height in [32, 96] with the least padding of ceil(H/S) to a multiple of ranks."""
+    best = None
+    for s in range(32, 97, 2):
+        stripes = -(-height // s)
+        per = -(-stripes // ranks)
+        pad = per * ranks * s - height
+        key = (pad, abs(s - 64))
+        if best is None or key < best[0]:
+            best = (key, s)
+    return best[1]
+
+
+def build_workload(name):
+    from chord_amd import scenes
+    if name == "street_4k_hzb":
+        return scenes.config3_street(3840, 2160)
+    if name == "street_x64_4k_hzb":
+        return scenes.config4_street_x64(3840, 2160, grid=8)
+    if name == "street_x16_4k_hzb":
+        return scenes.config4_street_x64(3840, 2160, grid=4)
+    if name == "atrium_1080p":
+        return scenes.config2_atrium(1920, 1080)
+    raise SystemExit("unknown workload %r" % name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="auto")
+    ap.add_argument("--cpu-baseline-frames", type=int, default=8, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
+    ap.add_argument("--no-hzb", action="store_true", help="disable HZB occlusion culling (frustum+cone only)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run --nproc-per-node %d bench.py ..." % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from chord_amd import lib as L, records as R
+    from chord_amd.renderer import VisibilityRenderer
+
+    wl = args.workload
+    if wl == "auto":
+        wl = "street_4k_hzb" if world == 1 else "street_x64_4k_hzb"
+    scene, cam_a = build_workload(wl)
+    f = np.array(cam_a.front, dtype=np.float64)
+    f /= np.linalg.norm(f)
+    cam_b = cam_a.moved(tuple(0.5 * f))
+    W, H = cam_a.width, cam_a.height
+    flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | (0 if args.no_hzb else R.FLAG_HZB_CULL)
+
+    # per-view inputs (host, once): frame at A follows a frame at B and vice versa
+    view_a0, _ = L.make_views(cam_a)
+    view_b0, _ = L.make_views(cam_b)
+    view_a, iv_a = L.make_views(cam_a, view_b0)
+    view_b, iv_b = L.make_views(cam_b, view_a0)
+    obj_a = L.fill_objects(scene, cam_a, cam_b).copy()
+    obj_b = L.fill_objects(scene, cam_b, cam_a).copy()
+    d_obj = [torch.from_numpy(o.view(np.uint8).reshape(-1)).to(dev) for o in (obj_a, obj_b)]
+    views = [(view_a, iv_a), (view_b, iv_b)]
+
+    stream = torch.cuda.current_stream(dev)
+    r = VisibilityRenderer(local_rank, stream.cuda_stream)
+    r.upload_scene(scene)
+    if world > 1:
+        r.set_shard(pick_stripe_rows(H, world), world, rank)
+    r.allocate_gbuffer(W, H)
+    words = r.visibility_words()
+    vis_t = torch.zeros(words, dtype=torch.int64, device=dev)      # caller-owned visibility (all-gather target)
+    r.allocate_gbuffer(W, H, vis_t.data_ptr())
+    chunk = r.visibility_chunk_words()
+    vis_mine = vis_t[rank * chunk:(rank + 1) * chunk]
+
+    def frame(i):
+        v, iv = views[i & 1]
+        r.bind_objects(d_obj[i & 1].data_ptr(), len(scene.objects))
+        r.set_view(v, iv, flags)
+        if world == 1:
+            r.render_frame()
+        else:
+            r.frame_phase_a()
+            ex.all_gather_hzb()
+            r.frame_phase_b()
+            dist.all_gather_into_tensor(vis_t, vis_mine)
+            r.frame_phase_c()
+
+    class Exchange:
+        """all-gather of the context-owned HZB mip-0 exchange buffer (f16, rank-major)."""
+        def __init__(self):
+            ptr, halves, chunk_h = r.hzb_exchange()
+            self.full = _tensor_from_ptr(ptr, halves, torch.int16, dev)
+            self.mine = self.full[rank * chunk_h:(rank + 1) * chunk_h]
+
+        def all_gather_hzb(self):
+            dist.all_gather_into_tensor(self.full, self.mine)
+
+    ex = Exchange() if world > 1 else None
+
+    # ---- warm-up (untimed): also collects the deterministic per-view counts ---------------------
+    r.enable_timers(0)
+    per_view = [None, None]
+    for i in range(max(args.warmup, 4)):
+        frame(i)
+        if i >= max(args.warmup, 4) - 2:
+            st = r.stats()
+            per_view[i & 1] = st
+    tris_per_pair = per_view[0]["trianglesSubmitted"] + per_view[1]["trianglesSubmitted"]
+    clusters_per_pair = sum(pv["countStage0Visible"] + pv["countStage1Visible"] for pv in per_view)
+
+    # ---- timed region --------------------------------------------------------------------------
+    r.enable_timers(2)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frame(i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    st = r.stats()                                  # per-frame GPU timestamps averaged over the timed steps
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tris_total = tris_per_pair * (args.steps // 2) + (per_view[0]["trianglesSubmitted"] if args.steps & 1 else 0)
+    value = tris_total / elapsed / 1e9
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream, inside the timed region)
+    pixels_touched = int((vis_t[:W * H] != 0).sum().item()) if world == 1 else None
+    V, T = 81, 128
+    cluster_bytes = CLUSTER_BYTES + 4 * (V + T) + 12 * V           # 1884 B per cluster
+    clusters_per_frame = clusters_per_pair / 2.0
+    kernels = {
+        "raster_cluster_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame),
+        "raster_chunk_kernel": (st["msRasterChunk"], 8.0 * (pixels_touched or 0)),
+    }
+    dom = max(kernels, key=lambda k: kernels[k][0])
+    dom_ms, dom_bytes = kernels[dom]
+    launches = max(1, st["rasterLaunches"])
+    achieved = (dom_bytes / launches) / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "avg_launch_us": round(dom_ms / launches * 1e3, 2), "launches_per_step": launches,
+                "algorithmic_bytes_per_launch": int(dom_bytes / launches)}
+
+    # ---- CPU baseline: the oracle replaying the same frame on the host (rank 0, N = 1) ----------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_baseline_frames > 0:
+        import orc
+        prev = orc.frame(scene_with(scene, obj_b), view_b0, L.make_views(cam_b)[1], flags)   # history for view A
+        sc_a = scene_with(scene, obj_a)
+        c0 = time.perf_counter()
+        tri = 0
+        for _ in range(args.cpu_baseline_frames):
+            out = orc.frame(sc_a, view_a, iv_a, flags, prev_hzb_min=prev["hzb_min"])
+            tri += out["stats"].trianglesSubmitted
+        c1 = time.perf_counter()
+        cpu = {"value": round(tri / (c1 - c0) / 1e9, 6), "unit": "Gtri/s", "cores": 1, "kind": "port",
+               "sample": "%d frames of %s (view A, history of view B), oracle/oracle.c single thread, %.1f s"
+                         % (args.cpu_baseline_frames, wl, c1 - c0)}
+
+    if rank == 0:
+        line = {
+            "metric": "Gtri/s into 4K 64-bit visbuffer", "value": round(value, 4), "unit": "Gtri/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "f32+u64", "data": "synthetic",
+            "config": {"workload": wl, "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(),
+                       "objects": len(scene.objects), "hzb": not args.no_hzb,
+                       "parallelism": "stripes%d" % world if world > 1 else "single"},
+            "triangles_submitted_per_step": tris_per_pair / 2.0,
+            "clusters_rastered_per_step": clusters_per_frame,
+            "gpu_ms": {k: round(st[k], 4) for k in ("msClear", "msInstanceCulling", "msStage0", "msHzbStage0", "msStage1",
+                                                     "msHzbFinal", "msFrame", "msRasterCluster", "msRasterClip", "msRasterChunk")},
+            "counts_view_a": {k: per_view[0][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible")},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def scene_with(scene, objects):
+    """A shallow scene whose object records are `objects` (the oracle reads host arrays)."""
+    from chord_amd import records as R
+    s = R.Scene(objects, scene.primitives, scene.materials, scene.meshlets, scene.groups, scene.group_indices,
+                scene.meshlet_data, scene.positions, name=scene.name)
+    return s
+
+
+class _CAI:
+    """Minimal __cuda_array_interface__ holder to view raw device memory as a torch tensor."""
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 3, "strides": None}
+
+
+def _tensor_from_ptr(ptr, n, dtype, dev):
+    typestr = {torch.int16: "<i2", torch.int64: "<i8", torch.uint8: "|u1"}[dtype]
+    return torch.as_tensor(_CAI(ptr, n, typestr), device=dev)
+
+
+if __name__ == "__main__":
+    main()

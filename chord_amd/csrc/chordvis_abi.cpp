@@ -47,22 +47,14 @@ int dalloc(ChordCtx* c, T** p, size_t count)
 template <typename T>
 void dfree(T*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } }
 
-void record(ChordCtx* c, int id)
+void record(ChordCtx* c, int tag) { chord::stamp(c, tag); }
+
+void begin_frame_stamps(ChordCtx* c)
 {
     if (!c->timers) return;
-    (void)hipEventRecord(c->ev[id], c->stream);
-    c->evRecorded[id] = true;
-}
-
-hipEvent_t raster_event(ChordCtx* c)
-{
-    if (c->rasterEvUsed >= c->rasterEv.size()) {
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
-        c->rasterEv.push_back(e);
-    }
-    hipEvent_t e = c->rasterEv[c->rasterEvUsed++];
-    return e;
+    if (c->timers == 1) { c->stampTags.clear(); c->framesStamped = 0; }
+    c->framesStamped++;
+    chord::stamp(c, S_FRAME_BEGIN);
 }
 
 uint64_t stripes_per_rank(const ChordCtx* c)
@@ -106,6 +98,10 @@ int configure_targets(ChordCtx* c, uint64_t* external)
     else dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) if ((rc = alloc_hzb(c, c->hzb[i]))) return rc;
     c->historySlot = 0;
+    {   // one {min, max} partial per block of the mip-0 kernel (64 x 4 texels per block)
+        const uint32_t vw = (c->width + 1) / 2, vh = (c->height + 1) / 2;
+        if ((rc = dalloc(c, &c->dRangePartials, (size_t)((vw + 63) / 64) * ((vh + 3) / 4) * 2))) return rc;
+    }
     // mid-frame HZB mip-0 exchange (sharded only)
     if (N > 1) {
         c->hzbExchangeChunkHalves = (uint64_t)c->shard.stripesPerRank * (c->shard.stripeRows / 2) * c->hzb[0].desc.width;
@@ -154,9 +150,19 @@ int do_raster(ChordCtx* c, const CmdList& in)
 
 } // namespace
 
-// launch_raster records the intermediate events itself when timers are on
 namespace chord {
-hipEvent_t next_raster_event(ChordCtx* c) { return c->timers ? raster_event(c) : nullptr; }
+void stamp(ChordCtx* c, int tag)
+{
+    if (!c->timers) return;
+    const size_t i = c->stampTags.size();
+    if (i >= c->evPool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->evPool.push_back(e);
+    }
+    (void)hipEventRecord(c->evPool[i], c->stream);
+    c->stampTags.push_back(tag);
+}
 }
 
 extern "C" {
@@ -179,7 +185,6 @@ int chordvis_create(int deviceOrdinal, void* hipStream, ChordCtx** outCtx)
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CHORDVIS_E_HIP; }
         c->ownStream = true;
     }
-    for (int i = 0; i < T_COUNT; i++) (void)hipEventCreate(&c->ev[i]);
     bool ok = hipMalloc((void**)&c->dView, sizeof(DView)) == hipSuccess &&
               hipMalloc((void**)&c->dCounts, 4 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void**)&c->dCounters, sizeof(DeviceCounters)) == hipSuccess;
@@ -201,9 +206,8 @@ int chordvis_destroy(ChordCtx* c)
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
     dfree(c->dCounts); dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
-    dfree(c->dHzbExchange); dfree(c->dBigTris); dfree(c->dBigChunks); dfree(c->dClipTris); dfree(c->dCounters);
-    for (int i = 0; i < T_COUNT; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (hipEvent_t e : c->rasterEv) (void)hipEventDestroy(e);
+    dfree(c->dRangePartials); dfree(c->dHzbExchange); dfree(c->dBigTris); dfree(c->dBigChunks); dfree(c->dClipTris); dfree(c->dCounters);
+    for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return CHORDVIS_OK;
@@ -427,7 +431,7 @@ int chordvis_clear_gbuffer(ChordCtx* c)
         CHORD_HIP(c, hipMemsetAsync(c->dVis, 0, c->visWords * 8, c->stream));
     }
     CHORD_HIP(c, hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters), c->stream));
-    c->rasterEvUsed = 0;
+    c->rasterCalls = 0;
     return CHORDVIS_OK;
 }
 
@@ -533,31 +537,30 @@ int chordvis_render_frame(ChordCtx* c)
     int rc = ready(c, "render_frame");
     if (rc) return rc;
     if (c->shard.ranks > 1) return fail(c, CHORDVIS_E_INVALID, "render_frame: sharded contexts use frame_phase_a/b/c");
-    for (int i = 0; i < T_COUNT; i++) c->evRecorded[i] = false;
-    record(c, T_FRAME_BEGIN);
+    begin_frame_stamps(c);
     if ((rc = chordvis_clear_gbuffer(c))) return rc;                                  // renderer.cpp:315
-    record(c, T_CLEAR);
+    record(c, S_CLEAR);
     ChordCountAndCmd post;
     if ((rc = chordvis_instance_culling(c, &post))) return rc;                        // :321
-    record(c, T_CULL);
+    record(c, S_CULL);
     ChordHZB hist;
     const bool haveHist = c->historySlot != 0;
     if (haveHist) hist = c->hzb[c->historySlot].handle();
     ChordCountAndCmd rejected;
     int stage1 = 0;
     if ((rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1))) return rc;   // :326
-    record(c, T_STAGE0);
+    record(c, S_STAGE0_END);
     c->shouldStage1 = stage1 != 0;
     if (stage1) {
         ChordHZB tmp;
         if ((rc = chordvis_build_hzb(c, 1, 0, 0, 0, &tmp))) return rc;                // :334
-        record(c, T_HZB0);
+        record(c, S_HZB0);
         if ((rc = chordvis_visibility_stage1(c, &tmp, rejected))) return rc;          // :337
-        record(c, T_STAGE1);
+        record(c, S_STAGE1_END);
     }
     const int next = c->historySlot == 1 ? 2 : 1;
     if ((rc = chordvis_build_hzb(c, 1, 1, 1, next, nullptr))) return rc;              // :343
-    record(c, T_HZBF);
+    record(c, S_HZBF);
     c->historySlot = next;                                                            // :489
     return CHORDVIS_OK;
 }
@@ -567,13 +570,12 @@ int chordvis_frame_phase_a(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_a");
     if (rc) return rc;
-    for (int i = 0; i < T_COUNT; i++) c->evRecorded[i] = false;
-    record(c, T_FRAME_BEGIN);
+    begin_frame_stamps(c);
     if ((rc = chordvis_clear_gbuffer(c))) return rc;
-    record(c, T_CLEAR);
+    record(c, S_CLEAR);
     ChordCountAndCmd post;
     if ((rc = chordvis_instance_culling(c, &post))) return rc;
-    record(c, T_CULL);
+    record(c, S_CULL);
     ChordHZB hist;
     const bool haveHist = c->historySlot != 0;
     if (haveHist) hist = c->hzb[c->historySlot].handle();
@@ -582,8 +584,8 @@ int chordvis_frame_phase_a(ChordCtx* c)
     if ((rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1))) return rc;
     c->shouldStage1 = stage1 != 0;
     c->lastRejected = from_handle(rejected);
-    if (stage1 && c->shard.ranks > 1) { launch_hzb_mip0_exchange(c); CHORD_HIP(c, hipGetLastError()); }
-    record(c, T_STAGE0);
+    record(c, S_STAGE0_END);
+    if (stage1 && c->shard.ranks > 1) { launch_hzb_mip0_exchange(c); CHORD_HIP(c, hipGetLastError()); record(c, S_HZB0); }
     return CHORDVIS_OK;
 }
 
@@ -593,13 +595,14 @@ int chordvis_frame_phase_b(ChordCtx* c)
     int rc = ready(c, "frame_phase_b");
     if (rc) return rc;
     if (!c->shouldStage1) return CHORDVIS_OK;
+    record(c, S_OTHER);          // time spent in the caller's all-gather
     if (c->shard.ranks > 1) launch_hzb_build(c, c->hzb[0], true, false, false, true);
     else launch_hzb_build(c, c->hzb[0], true, false, false, false);
     CHORD_HIP(c, hipGetLastError());
-    record(c, T_HZB0);
+    record(c, S_HZB0);
     ChordHZB tmp = c->hzb[0].handle();
     if ((rc = chordvis_visibility_stage1(c, &tmp, c->lastRejected.handle()))) return rc;
-    record(c, T_STAGE1);
+    record(c, S_STAGE1_END);
     return CHORDVIS_OK;
 }
 
@@ -608,10 +611,11 @@ int chordvis_frame_phase_c(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_c");
     if (rc) return rc;
+    record(c, S_OTHER);          // time spent in the caller's all-gather
     if (c->shard.ranks > 1) { launch_detile(c); CHORD_HIP(c, hipGetLastError()); }
     const int next = c->historySlot == 1 ? 2 : 1;
     if ((rc = chordvis_build_hzb(c, 1, 1, 1, next, nullptr))) return rc;
-    record(c, T_HZBF);
+    record(c, S_HZBF);
     c->historySlot = next;
     return CHORDVIS_OK;
 }
@@ -684,7 +688,9 @@ int chordvis_upload_history_hzb(ChordCtx* c, const uint16_t* hostMin)
 int chordvis_enable_timers(ChordCtx* c, int enable)
 {
     if (!c) return CHORDVIS_E_INVALID;
-    c->timers = enable != 0;
+    c->timers = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    c->stampTags.clear();
+    c->framesStamped = 0;
     return CHORDVIS_OK;
 }
 
@@ -706,32 +712,37 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
         out->trianglesSubmitted = dc.trisInstanceCulled;
     }
     out->overflow = dc.overflow;
-    out->rasterLaunches = c->rasterEvUsed / 4;
-    if (c->timers) {
-        auto span = [&](int a, int b) -> float {
+    out->rasterLaunches = c->rasterCalls;
+    if (c->timers && c->framesStamped && c->stampTags.size() > 1) {
+        // walk the stamps: the segment ending at stamp i is attributed by its tag and the current stage
+        float clear = 0, cull = 0, st0 = 0, hzb0 = 0, st1 = 0, hzbf = 0, rc_ = 0, rk = 0, rh = 0, other = 0;
+        int stage = 0;   // 0 = stage 0, 1 = stage 1
+        for (size_t i = 1; i < c->stampTags.size(); i++) {
+            const int tag = c->stampTags[i];
+            if (tag == S_FRAME_BEGIN) { stage = 0; continue; }           // gap between frames is not frame time
             float ms = 0.0f;
-            if (c->evRecorded[a] && c->evRecorded[b] && hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) == hipSuccess) return ms;
-            return 0.0f;
-        };
-        out->msClear = span(T_FRAME_BEGIN, T_CLEAR);
-        out->msInstanceCulling = span(T_CLEAR, T_CULL);
-        out->msStage0 = span(T_CULL, T_STAGE0);
-        if (c->shouldStage1) {
-            out->msHzbStage0 = span(T_STAGE0, T_HZB0);
-            out->msStage1 = span(T_HZB0, T_STAGE1);
-            out->msHzbFinal = span(T_STAGE1, T_HZBF);
-        } else {
-            out->msHzbFinal = span(T_STAGE0, T_HZBF);
+            if (hipEventElapsedTime(&ms, c->evPool[i - 1], c->evPool[i]) != hipSuccess) continue;
+            switch (tag) {
+            case S_CLEAR: clear += ms; break;
+            case S_CULL: cull += ms; break;
+            case S_HZBCULL: case S_STAGE0_END: case S_STAGE1_END: (stage == 0 ? st0 : st1) += ms; break;
+            case S_R_CLUSTER: rc_ += ms; (stage == 0 ? st0 : st1) += ms; break;
+            case S_R_CLIP: rk += ms; (stage == 0 ? st0 : st1) += ms; break;
+            case S_R_CHUNK: rh += ms; (stage == 0 ? st0 : st1) += ms; break;
+            case S_HZB0: hzb0 += ms; break;
+            case S_HZBF: hzbf += ms; break;
+            default: other += ms; break;
+            }
+            if (tag == S_STAGE0_END) stage = 1;
         }
-        out->msFrame = span(T_FRAME_BEGIN, T_HZBF);
-        for (uint32_t i = 0; i + 3 < c->rasterEvUsed; i += 4) {
-            float a = 0, b = 0, d = 0;
-            (void)hipEventElapsedTime(&a, c->rasterEv[i], c->rasterEv[i + 1]);
-            (void)hipEventElapsedTime(&b, c->rasterEv[i + 1], c->rasterEv[i + 2]);
-            (void)hipEventElapsedTime(&d, c->rasterEv[i + 2], c->rasterEv[i + 3]);
-            out->msRasterCluster += a; out->msRasterClip += b; out->msRasterChunk += d;
-        }
+        const float inv = 1.0f / (float)c->framesStamped;
+        out->msClear = clear * inv; out->msInstanceCulling = cull * inv; out->msStage0 = st0 * inv;
+        out->msHzbStage0 = hzb0 * inv; out->msStage1 = st1 * inv; out->msHzbFinal = hzbf * inv;
+        out->msRasterCluster = rc_ * inv; out->msRasterClip = rk * inv; out->msRasterChunk = rh * inv;
+        out->msFrame = (clear + cull + st0 + hzb0 + st1 + hzbf + other) * inv;
+        out->framesTimed = c->framesStamped;
     }
+    if (c->timers == 2) { c->stampTags.clear(); c->framesStamped = 0; }
     if (dc.overflow) return fail(c, CHORDVIS_E_CAPACITY, "a deferred raster list overflowed this frame; the visibility buffer is incomplete");
     return CHORDVIS_OK;
 }

@@ -112,7 +112,9 @@ struct HzbBuffers {
     ChordHZB handle() const { return ChordHZB{desc, minTexels, maxTexels, validRange}; }
 };
 
-enum TimerId { T_FRAME_BEGIN = 0, T_CLEAR, T_CULL, T_STAGE0, T_HZB0, T_STAGE1, T_HZBF, T_COUNT };
+// GPU timestamp tags: a stamp closes the segment that started at the previous stamp.
+enum StampTag { S_FRAME_BEGIN = 0, S_CLEAR, S_CULL, S_HZBCULL, S_R_CLUSTER, S_R_CLIP, S_R_CHUNK, S_STAGE0_END,
+                S_HZB0, S_STAGE1_END, S_HZBF, S_OTHER };
 
 } // namespace chord
 
@@ -167,6 +169,7 @@ struct ChordCtx {
     // HZB: slot 0 temp, 1/2 history ping-pong
     chord::HzbBuffers hzb[3];
     int historySlot = 0;              // 0 = none, else 1 or 2
+    uint32_t* dRangePartials = nullptr;   // per mip-0 block {min, max} of valid depth
     uint16_t* dHzbExchange = nullptr;
     uint64_t hzbExchangeHalves = 0, hzbExchangeChunkHalves = 0;
 
@@ -177,12 +180,12 @@ struct ChordCtx {
     uint32_t bigTriCap = 0, bigChunkCap = 0, clipTriCap = 0;
     chord::DeviceCounters* dCounters = nullptr;
 
-    // timers
-    bool timers = false;
-    hipEvent_t ev[chord::T_COUNT]{};
-    bool evRecorded[chord::T_COUNT]{};
-    std::vector<hipEvent_t> rasterEv;  // pairs
-    uint32_t rasterEvUsed = 0;
+    // timers: mode 0 off, 1 = last frame only, 2 = accumulate until chordvis_stats
+    int timers = 0;
+    std::vector<hipEvent_t> evPool;
+    std::vector<int> stampTags;        // tags of evPool[0 .. stampTags.size())
+    uint32_t framesStamped = 0;
+    uint32_t rasterCalls = 0;          // renderMesh calls since the last clear
     bool shouldStage1 = false;
     chord::CmdList lastRejected;
 };
@@ -206,6 +209,6 @@ void launch_raster(ChordCtx* c, const CmdList& in);
 void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange, bool fromExchange);
 void launch_hzb_mip0_exchange(ChordCtx* c);
 void launch_detile(ChordCtx* c);
-hipEvent_t next_raster_event(ChordCtx* c);      // nullptr when timers are off
+void stamp(ChordCtx* c, int tag);               // no-op when timers are off
 
 } // namespace chord

@@ -29,6 +29,8 @@ struct HzbParams {
     uint16_t* hzbMin; uint16_t* hzbMax; uint32_t* validRange;
     uint16_t* exchange;           // rank-major mip-0 min rows (sharded only)
     uint32_t exchangePitch;       // halves per exchange row
+    uint32_t* rangePartials;      // per mip-0 block {min bits, max bits}; reduced by the tail kernel
+    uint32_t rangePartialCount;
 };
 
 __device__ __forceinline__ uint32_t valid_w(const ChordHZBDesc& d, uint32_t l)
@@ -101,14 +103,21 @@ __global__ __launch_bounds__(256) void hzb_mip0_kernel(HzbParams p, int wantMax,
         }
     }
     if (MODE != 1 && wantRange) {
+        // The reference does one InterlockedMin/Max per wave on a single word (hzb.hlsl:168-176); on
+        // MI355X one word sustains only ~88 atomics/us (32k waves at 4K = 0.7 ms), so each block
+        // writes one partial instead and the single-block tail kernel reduces them.
+        __shared__ uint32_t sMn[4], sMx[4];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             rmin = min(rmin, (uint32_t)__shfl_down(rmin, off, 64));
             rmax = max(rmax, (uint32_t)__shfl_down(rmax, off, 64));
         }
-        if ((threadIdx.x & 63u) == 0u) {
-            if (rmin != 0xFFFFFFFFu) atomicMin(&p.validRange[0], rmin);
-            if (rmax != 0u) atomicMax(&p.validRange[1], rmax);
+        if ((threadIdx.x & 63u) == 0u) { sMn[threadIdx.x >> 6] = rmin; sMx[threadIdx.x >> 6] = rmax; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
+            p.rangePartials[2u * b] = min(min(sMn[0], sMn[1]), min(sMn[2], sMn[3]));
+            p.rangePartials[2u * b + 1u] = max(max(sMx[0], sMx[1]), max(sMx[2], sMx[3]));
         }
     }
 }
@@ -188,10 +197,25 @@ __global__ __launch_bounds__(256) void hzb_mips_kernel(HzbParams p, int wantMax)
     }
 }
 
-// One block: mips 6..mipCount-1 from the stored mip 5.
-__global__ __launch_bounds__(256) void hzb_tail_kernel(HzbParams p, int wantMax)
+// One block: mips 6..mipCount-1 from the stored mip 5, and the valid-range reduction.
+__global__ __launch_bounds__(256) void hzb_tail_kernel(HzbParams p, int wantMax, int wantRange)
 {
     const ChordHZBDesc& d = p.desc;
+    if (wantRange) {
+        __shared__ uint32_t sMn[256], sMx[256];
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        for (uint32_t i = threadIdx.x; i < p.rangePartialCount; i += 256u) {
+            mn = min(mn, p.rangePartials[2u * i]);
+            mx = max(mx, p.rangePartials[2u * i + 1u]);
+        }
+        sMn[threadIdx.x] = mn; sMx[threadIdx.x] = mx;
+        __syncthreads();
+        for (uint32_t s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) { sMn[threadIdx.x] = min(sMn[threadIdx.x], sMn[threadIdx.x + s]); sMx[threadIdx.x] = max(sMx[threadIdx.x], sMx[threadIdx.x + s]); }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { p.validRange[0] = sMn[0]; p.validRange[1] = sMx[0]; }   // init {~0u, 0u}: hzb.cpp:108-109
+    }
     for (uint32_t l = 6; l < d.mipCount; l++) {
         const uint32_t vw = valid_w(d, l), vh = valid_h(d, l), mw = max(1u, d.width >> l);
         const uint32_t pw = valid_w(d, l - 1), ph = valid_h(d, l - 1), pmw = max(1u, d.width >> (l - 1));
@@ -231,6 +255,7 @@ static HzbParams make_params(ChordCtx* c, HzbBuffers& out)
     p.shard = c->shard; p.desc = out.desc;
     p.hzbMin = out.minTexels; p.hzbMax = out.maxTexels; p.validRange = out.validRange;
     p.exchange = c->dHzbExchange; p.exchangePitch = out.desc.width;
+    p.rangePartials = c->dRangePartials; p.rangePartialCount = 0;
     return p;
 }
 
@@ -247,20 +272,16 @@ void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool b
     HzbParams p = make_params(c, out);
     const int wantMax = bMax ? 1 : 0, wantRange = bValidRange ? 1 : 0;
     const uint32_t vw = min(p.desc.width, (((uint32_t)p.W - 1u) >> 1) + 1u), vh = min(p.desc.height, (((uint32_t)p.H - 1u) >> 1) + 1u);
-    if (bValidRange) {
-        // clearRangeValue = { ~0u, 0u }  (hzb.cpp:108-109)
-        (void)hipMemsetD32Async((hipDeviceptr_t)out.validRange, (int)0xFFFFFFFFu, 1, c->stream);
-        (void)hipMemsetD32Async((hipDeviceptr_t)(out.validRange + 1), 0, 1, c->stream);
-    }
+    const dim3 g0((vw + 63u) / 64u, (vh + 3u) / 4u);
+    p.rangePartialCount = g0.x * g0.y;
     if (!fromExchange) {
-        const dim3 g0((vw + 63u) / 64u, (vh + 3u) / 4u);
         if (c->shard.ranks > 1) hipLaunchKernelGGL(hzb_mip0_kernel<2>, g0, dim3(256), 0, c->stream, p, wantMax, wantRange);
         else                    hipLaunchKernelGGL(hzb_mip0_kernel<0>, g0, dim3(256), 0, c->stream, p, wantMax, wantRange);
     }
     const dim3 g1((vw + 31u) / 32u, (vh + 31u) / 32u);
     if (fromExchange) hipLaunchKernelGGL(hzb_mips_kernel<true>, g1, dim3(256), 0, c->stream, p, 0);
     else              hipLaunchKernelGGL(hzb_mips_kernel<false>, g1, dim3(256), 0, c->stream, p, wantMax);
-    if (p.desc.mipCount > 6) hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, wantMax);
+    if (p.desc.mipCount > 6 || wantRange) hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, wantMax, wantRange);
     out.valid = true;
 }
 

@@ -4,10 +4,9 @@
 // (mesh_raster.hlsl:51-210; state mesh_raster.cpp:141-156, helper.h:7-13,304-324,395-407) with
 //   raster_cluster_kernel  one wave per visible meshlet: coalesced meshletData / position stream ->
 //                          clip-space transform -> LDS (SoA x,y,w,u,v,depth) -> per-triangle culls
-//                          (mesh_raster.hlsl:143-179) -> setup -> three size classes:
-//                            small  (bbox <= 4x4 px)    per-lane scan, 32-bit edge functions
-//                            medium (bbox <= 16x16 px)  the wave scans 8x8 tiles cooperatively
-//                            big                        appended to a device list as 64x64 chunks
+//                          (mesh_raster.hlsl:143-179) -> setup -> two size classes:
+//                            small (bbox <= 16x16 px)  per-lane scan, 32-bit edge functions
+//                            big                       appended to a device list as 64x64 chunks
 //                          triangles touching the near/guard planes -> clip list
 //   raster_clip_kernel     homogeneous Sutherland-Hodgman clipper (rare), one lane per triangle
 //   raster_chunk_kernel    one wave per 64x64 chunk of a big triangle: 64 lanes classify the 64
@@ -140,11 +139,15 @@ __device__ __forceinline__ void raster_small(const RasterParams& p, const TriSet
         if (owns_row<SH>(p.shard, py)) {
             unsigned long long* row = p.vis + row_base<SH>(p.shard, py, p.Wi);
             int32_t E0 = r0, E1 = r1, E2 = r2;
+            bool entered = false;
             for (int32_t px = ts.px0; px <= ts.px1; px++) {
                 if (((E0 + bias0) | (E1 + bias1) | (E2 + bias2)) >= 0) {
                     const float l1 = (float)E1 * ts.invA, l2 = (float)E2 * ts.invA;
                     const float z = (ts.d0 + l1 * d1m0) + l2 * d2m0;
                     vis_write(row + px, z, ts.payload);
+                    entered = true;
+                } else if (entered) {
+                    break;                       // convex: the span of this row is over
                 }
                 E0 += a0 * 256; E1 += a1 * 256; E2 += a2 * 256;
             }
@@ -249,7 +252,8 @@ __device__ __forceinline__ void emit_big_single(const RasterParams& p, uint32_t 
 }
 
 // ---- the per-cluster kernel -------------------------------------------------------------------
-enum { K_NONE = 0, K_SMALL = 1, K_MEDIUM = 2, K_BIG = 3, K_CLIP = 4 };
+enum { K_NONE = 0, K_SMALL = 1, K_BIG = 3, K_CLIP = 4 };
+#define SMALL_MAX 16     // per-lane scan up to 16x16 pixels; larger triangles go to the chunk kernel
 
 template <bool SH>
 __global__ __launch_bounds__(256) void raster_cluster_kernel(RasterParams p)
@@ -341,8 +345,7 @@ __global__ __launch_bounds__(256) void raster_cluster_kernel(RasterParams p)
                             const int32_t extX = max(ts.X[0], max(ts.X[1], ts.X[2])) - min(ts.X[0], min(ts.X[1], ts.X[2]));
                             const int32_t extY = max(ts.Y[0], max(ts.Y[1], ts.Y[2])) - min(ts.Y[0], min(ts.Y[1], ts.Y[2]));
                             const bool narrow = extX <= (1 << 14) && extY <= (1 << 14);   // 32-bit edge functions are exact
-                            if (bw <= 4 && bh <= 4 && narrow) kind = K_SMALL;
-                            else if (bw <= 16 && bh <= 16) kind = K_MEDIUM;
+                            if (bw <= SMALL_MAX && bh <= SMALL_MAX && narrow) kind = K_SMALL;
                             else kind = K_BIG;
                         }
                     }
@@ -381,24 +384,6 @@ __global__ __launch_bounds__(256) void raster_cluster_kernel(RasterParams p)
                     if (kind == K_BIG)
                         write_big(p, listShard, tbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull)), cbase + incl - n, ts, d, twoSided);
                 }
-            }
-
-            // medium: the whole wave scans each one
-            unsigned long long mm = __ballot(kind == K_MEDIUM);
-            while (mm) {
-                const int src = __ffsll((long long)mm) - 1;
-                mm &= mm - 1ull;
-                TriSetup bs;
-#pragma unroll
-                for (int i = 0; i < 3; i++) { bs.X[i] = bcast(ts.X[i], src); bs.Y[i] = bcast(ts.Y[i], src); }
-                bs.d0 = bcast(ts.d0, src); bs.e1 = bcast(ts.e1, src); bs.e2 = bcast(ts.e2, src);
-                bs.payload = bcast(ts.payload, src);
-                (void)tri_setup(bs, twoSided, p.Wi, p.Hi);
-                WideEdges we;
-                wide_edges(bs, we);
-                for (int32_t ty = bs.py0 & ~7; ty <= bs.py1; ty += 8)
-                    for (int32_t tx = bs.px0 & ~7; tx <= bs.px1; tx += 8)
-                        raster_tile<SH>(p, bs, we, bs.e1, bs.e2, tx, ty, lane);
             }
         }
         // LDS of this wave is rewritten by the next cluster: order the reads above before those writes
@@ -573,19 +558,19 @@ void launch_raster(ChordCtx* c, const CmdList& in)
     if (blocks < 1) blocks = 1;
     const uint32_t chunkBlocks = (uint32_t)c->numCUs * 8u;
     const uint32_t clipBlocks = (uint32_t)c->numCUs;
-    // optional GPU timestamps around each of the three kernels (4 events per renderMesh call)
-    auto stamp = [&]() { if (hipEvent_t e = next_raster_event(c)) (void)hipEventRecord(e, c->stream); };
+    // optional GPU timestamps after each of the three kernels
     const bool sh = c->shard.ranks > 1;
-    stamp();
+    stamp(c, S_HZBCULL);      // closes whatever preceded the raster (HZB cull / list reset)
     if (sh) hipLaunchKernelGGL(raster_cluster_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p);
     else    hipLaunchKernelGGL(raster_cluster_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p);
-    stamp();
+    stamp(c, S_R_CLUSTER);
     if (sh) hipLaunchKernelGGL(raster_clip_kernel<true>, dim3(clipBlocks), dim3(256), 0, c->stream, p);
     else    hipLaunchKernelGGL(raster_clip_kernel<false>, dim3(clipBlocks), dim3(256), 0, c->stream, p);
-    stamp();
+    stamp(c, S_R_CLIP);
     if (sh) hipLaunchKernelGGL(raster_chunk_kernel<true>, dim3(chunkBlocks), dim3(256), 0, c->stream, p);
     else    hipLaunchKernelGGL(raster_chunk_kernel<false>, dim3(chunkBlocks), dim3(256), 0, c->stream, p);
-    stamp();
+    stamp(c, S_R_CHUNK);
+    c->rasterCalls++;
 }
 
 } // namespace chord

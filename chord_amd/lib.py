@@ -42,7 +42,7 @@ class Stats(C.Structure):
         ("msClear", C.c_float), ("msInstanceCulling", C.c_float), ("msStage0", C.c_float), ("msHzbStage0", C.c_float),
         ("msStage1", C.c_float), ("msHzbFinal", C.c_float), ("msFrame", C.c_float),
         ("msRasterCluster", C.c_float), ("msRasterClip", C.c_float), ("msRasterChunk", C.c_float),
-        ("rasterLaunches", C.c_uint32), ("overflow", C.c_uint32), ("countInstanceCulled", C.c_uint32), ("countStage0Visible", C.c_uint32),
+        ("framesTimed", C.c_uint32), ("rasterLaunches", C.c_uint32), ("overflow", C.c_uint32), ("countInstanceCulled", C.c_uint32), ("countStage0Visible", C.c_uint32),
         ("countStage0Rejected", C.c_uint32), ("countStage1Visible", C.c_uint32), ("trianglesSubmitted", C.c_uint64),
     ]
 

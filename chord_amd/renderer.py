@@ -168,8 +168,9 @@ class VisibilityRenderer:
                                                 rng.ctypes.data if rng is not None else None), "readback_hzb")
         return mn, mx, rng
 
-    def enable_timers(self, on=True):
-        self._check(L.lib.chordvis_enable_timers(self._ctx, int(on)), "enable_timers")
+    def enable_timers(self, mode=1):
+        """0 off, 1 last frame, 2 accumulate until stats()."""
+        self._check(L.lib.chordvis_enable_timers(self._ctx, int(mode)), "enable_timers")
 
     def stats(self):
         st = L.Stats()

@@ -78,6 +78,7 @@ typedef struct ChordStats {
     float    msRasterCluster;      /* sum over the frame's raster_cluster_kernel launches */
     float    msRasterClip;         /* ... raster_clip_kernel                                */
     float    msRasterChunk;        /* ... raster_chunk_kernel                               */
+    uint32_t framesTimed;          /* frames the ms* fields are averaged over               */
     uint32_t rasterLaunches;       /* renderMesh calls this frame (1 or 2)                  */
     uint32_t overflow;             /* non-zero: a deferred raster list overflowed (results invalid) */
     uint32_t countInstanceCulled;  /* commands after instanceCulling     */
@@ -213,7 +214,9 @@ int chordvis_readback_hzb(ChordCtx* ctx, const ChordHZB* hzb, uint16_t* hostMin,
 /* upload an HZB min chain from the host (tests: feed a known history) into history */
 int chordvis_upload_history_hzb(ChordCtx* ctx, const uint16_t* hostMin);
 
-int chordvis_enable_timers(ChordCtx* ctx, int enable);
+/* mode 0: off.  1: GPU timestamps of the last frame.  2: accumulate over frames until the next
+ * chordvis_stats, which then reports per-frame averages (and restarts the accumulation). */
+int chordvis_enable_timers(ChordCtx* ctx, int mode);
 int chordvis_stats(ChordCtx* ctx, ChordStats* out);
 
 #ifdef __cplusplus
