@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--cpu-baseline-frames", type=int, default=8, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
     ap.add_argument("--no-hzb", action="store_true", help="disable HZB occlusion culling (frustum+cone only)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="raster ablation switches (measurement only; voids parity)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,6 +145,8 @@ def main():
             dist.all_gather_into_tensor(self.full, self.mine)
 
     ex = Exchange() if world > 1 else None
+    if args.debug_flags:
+        r.set_debug(args.debug_flags)
 
     # ---- warm-up (untimed): also collects the deterministic per-view counts ---------------------
     r.enable_timers(0)
@@ -219,7 +222,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32+u64", "data": "synthetic",
-            "config": {"workload": wl, "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(),
+            "config": {"workload": wl, **({"ABLATION_debug_flags": args.debug_flags} if args.debug_flags else {}), "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(),
                        "objects": len(scene.objects), "hzb": not args.no_hzb,
                        "parallelism": "stripes%d" % world if world > 1 else "single"},
             "triangles_submitted_per_step": tris_per_pair / 2.0,

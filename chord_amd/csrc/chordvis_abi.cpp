@@ -685,6 +685,13 @@ int chordvis_upload_history_hzb(ChordCtx* c, const uint16_t* hostMin)
     return CHORDVIS_OK;
 }
 
+int chordvis_set_debug(ChordCtx* c, uint32_t flags)
+{
+    if (!c) return CHORDVIS_E_INVALID;
+    c->debugFlags = flags;
+    return CHORDVIS_OK;
+}
+
 int chordvis_enable_timers(ChordCtx* c, int enable)
 {
     if (!c) return CHORDVIS_E_INVALID;

@@ -188,6 +188,7 @@ struct ChordCtx {
     uint32_t rasterCalls = 0;          // renderMesh calls since the last clear
     bool shouldStage1 = false;
     chord::CmdList lastRejected;
+    uint32_t debugFlags = 0;           // ablation switches for measurements (chordvis_set_debug)
 };
 
 namespace chord {

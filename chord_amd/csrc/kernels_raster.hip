@@ -37,7 +37,12 @@ struct RasterParams {
     BigTri* bigTris; BigChunk* bigChunks; ClipTri* clipTris;
     uint32_t bigTriCap, bigChunkCap, clipTriCap;       // big caps are PER SHARD
     DeviceCounters* counters;
+    uint32_t debug;                                    // ablation switches (chordvis_set_debug), 0 in production
 };
+#define DBG_NO_PIXELS   1u    // skip every visibility write
+#define DBG_PLAIN_STORE 2u    // plain store instead of atomicMax (wrong image; timing only)
+#define DBG_NO_BIG      4u    // drop big triangles instead of deferring them
+#define DBG_NO_EARLYZ   8u    // tile path: no read-before-atomic
 
 __device__ __forceinline__ int32_t bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
@@ -110,9 +115,13 @@ __device__ __forceinline__ bool tri_setup(TriSetup& ts, bool twoSided, int32_t W
     return true;
 }
 
-__device__ __forceinline__ void vis_write(unsigned long long* p, float z, uint32_t payload)
+__device__ __forceinline__ void vis_write(unsigned long long* p, float z, uint32_t payload, uint32_t debug = 0)
 {
     const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)payload;
+    if (debug) {
+        if (debug & DBG_NO_PIXELS) return;
+        if (debug & DBG_PLAIN_STORE) { *p = packed; return; }
+    }
     atomicMax(p, packed);
 }
 
@@ -144,7 +153,7 @@ __device__ __forceinline__ void raster_small(const RasterParams& p, const TriSet
                 if (((E0 + bias0) | (E1 + bias1) | (E2 + bias2)) >= 0) {
                     const float l1 = (float)E1 * ts.invA, l2 = (float)E2 * ts.invA;
                     const float z = (ts.d0 + l1 * d1m0) + l2 * d2m0;
-                    vis_write(row + px, z, ts.payload);
+                    vis_write(row + px, z, ts.payload, p.debug);
                     entered = true;
                 } else if (entered) {
                     break;                       // convex: the span of this row is over
@@ -200,6 +209,11 @@ __device__ __forceinline__ void raster_tile(const RasterParams& p, const TriSetu
     const float z = (ts.d0 + l1 * d1m0) + l2 * d2m0;
     unsigned long long* dst = p.vis + row_base<SH>(p.shard, py, p.Wi) + px;
     const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)ts.payload;
+    if (p.debug) {
+        if (p.debug & DBG_NO_PIXELS) return;
+        if (p.debug & DBG_PLAIN_STORE) { *dst = packed; return; }
+        if (p.debug & DBG_NO_EARLYZ) { atomicMax(dst, packed); return; }
+    }
     if (packed > *dst) atomicMax(dst, packed);        // stale read only costs a redundant atomic
 }
 
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(256) void raster_cluster_kernel(RasterParams p)
                         cbase = atomicAdd(&p.counters->bigChunkCount[listShard], total);
                     }
                     tbase = bcast(tbase, 0); cbase = bcast(cbase, 0);
-                    if (kind == K_BIG)
+                    if (kind == K_BIG && !(p.debug & DBG_NO_BIG))
                         write_big(p, listShard, tbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull)), cbase + incl - n, ts, d, twoSided);
                 }
             }
@@ -548,6 +562,7 @@ void launch_raster(ChordCtx* c, const CmdList& in)
     p.bigTris = c->dBigTris; p.bigChunks = c->dBigChunks; p.clipTris = c->dClipTris;
     p.bigTriCap = c->bigTriCap / CHORD_LIST_SHARDS; p.bigChunkCap = c->bigChunkCap / CHORD_LIST_SHARDS; p.clipTriCap = c->clipTriCap;
     p.counters = c->dCounters;
+    p.debug = c->debugFlags;
 
     // reset the deferred-list counts (leading bytes of DeviceCounters)
     (void)hipMemsetAsync(c->dCounters, 0, CHORD_COUNTERS_RESET_BYTES, c->stream);

@@ -124,6 +124,7 @@ def _load():
         "chordvis_upload_history_hzb": (i32, [vp, vp]),
         "chordvis_enable_timers": (i32, [vp, i32]),
         "chordvis_stats": (i32, [vp, P(Stats)]),
+        "chordvis_set_debug": (i32, [vp, u32]),
     }
     missing = []
     for name, (res, args) in protos.items():

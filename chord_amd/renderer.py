@@ -172,6 +172,10 @@ class VisibilityRenderer:
         """0 off, 1 last frame, 2 accumulate until stats()."""
         self._check(L.lib.chordvis_enable_timers(self._ctx, int(mode)), "enable_timers")
 
+    def set_debug(self, flags):
+        """Measurement-only ablation switches (0 = production)."""
+        self._check(L.lib.chordvis_set_debug(self._ctx, int(flags)), "set_debug")
+
     def stats(self):
         st = L.Stats()
         self._check(L.lib.chordvis_stats(self._ctx, C.byref(st)), "stats")

@@ -218,6 +218,9 @@ int chordvis_upload_history_hzb(ChordCtx* ctx, const uint16_t* hostMin);
  * chordvis_stats, which then reports per-frame averages (and restarts the accumulation). */
 int chordvis_enable_timers(ChordCtx* ctx, int mode);
 int chordvis_stats(ChordCtx* ctx, ChordStats* out);
+/* Measurement-only ablation switches of the raster kernels (bit0 no pixel writes, bit1 plain stores,
+ * bit2 drop big triangles, bit3 no early depth read).  0 = production; anything else voids parity. */
+int chordvis_set_debug(ChordCtx* ctx, uint32_t flags);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,374 @@
+"""Known-answer tests that pin the CPU oracle (the reference has no golden vectors for this path:
+SURVEY §4 / §8c).  Everything here is derivable from the Vulkan raster rules, IEEE-754 and the
+HLSL source without running the reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from chord_amd import records as R
+from chord_amd import scenes
+
+W = H = 64
+
+
+def px(v):
+    """pixel coordinate -> 24.8 fixed point"""
+    return int(round(v * 256))
+
+
+def coverage(X, Y, two_sided=True, w=W, h=H, d=(0.5, 0.5, 0.5), payload=0x101):
+    vis, st = orc.raster_snapped_triangle([px(x) for x in X], [px(y) for y in Y], d, two_sided, payload, w, h)
+    return (vis.reshape(h, w) != 0), st
+
+
+# ------------------------------------------------------------------------------- raster rules ---
+
+@pytest.mark.parametrize("n", [1, 2, 5, 17])
+def test_right_triangle_pixel_counts(n):
+    """Axis-aligned right triangle with legs n px: centres strictly inside + top-left edges.
+    Vertices on integer pixel corners; the hypotenuse passes through no pixel centre only when
+    counted with the fill rule: n(n-1)/2 + (diagonal centres are ON the hypotenuse)."""
+    # legs along the top and left edges: top edge (y=8) and left edge (x=8) are inclusive,
+    # the hypotenuse x + y = 16 + n passes exactly through the centres with (i + j) = n - 1.
+    cov, _ = coverage([8, 8 + n, 8], [8, 8, 8 + n])
+    ii, jj = np.meshgrid(np.arange(W), np.arange(H), indexing="xy")
+    cx, cy = ii + 0.5 - 8, jj + 0.5 - 8
+    inside = (cx > 0) & (cy > 0) & (cx + cy < n)          # no centre lies on the legs; diagonal centres: cx+cy == n
+    # hypotenuse goes from (8+n, 8) to (8, 8+n): neither top nor left => centres on it are excluded
+    assert np.array_equal(cov, inside)
+    assert cov.sum() == n * (n - 1) // 2
+
+
+def test_top_left_rule_shared_edge_covers_once():
+    """Two triangles sharing an edge cover every pixel of their union exactly once."""
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        p = rng.uniform(4, 60, size=(4, 2))
+        p = np.round(p * 256) / 256
+        a, b, c, d = p
+        # quad a-b-c-d split along a-c; orientation of both halves made consistent (two-sided raster)
+        v1, s1 = orc.raster_snapped_triangle([px(a[0]), px(b[0]), px(c[0])], [px(a[1]), px(b[1]), px(c[1])], (0.5,) * 3, 1, 1, W, H)
+        v2, s2 = orc.raster_snapped_triangle([px(a[0]), px(c[0]), px(d[0])], [px(a[1]), px(c[1]), px(d[1])], (0.5,) * 3, 1, 1, W, H)
+        # only test convex, consistently wound quads (b and d on opposite sides of a-c)
+        def side(p0, p1, q):
+            return (p1[0] - p0[0]) * (q[1] - p0[1]) - (p1[1] - p0[1]) * (q[0] - p0[0])
+        if side(a, c, b) * side(a, c, d) >= 0:
+            continue
+        both = (v1 != 0).astype(int) + (v2 != 0).astype(int)
+        assert both.max() <= 1, "a pixel on the shared edge was covered twice"
+        assert s1.fragments + s2.fragments == int((both > 0).sum())
+
+
+def test_pixel_centre_on_top_and_left_edges_is_inside():
+    # square [10,12]x[10,12] as two triangles: covers exactly centres 10.5, 11.5 in both axes
+    c1, _ = coverage([10, 12, 12], [10, 10, 12])
+    c2, _ = coverage([10, 12, 10], [10, 12, 12])
+    cov = c1 | c2
+    assert cov.sum() == 4 and cov[10:12, 10:12].all()
+    # half-pixel shifted: edges pass through centres; top/left inclusive, bottom/right exclusive
+    c1, _ = coverage([10.5, 12.5, 12.5], [10.5, 10.5, 12.5])
+    c2, _ = coverage([10.5, 12.5, 10.5], [10.5, 12.5, 12.5])
+    cov = c1 | c2
+    assert cov.sum() == 4 and cov[10:12, 10:12].all()
+    assert not (c1 & c2).any()
+
+
+def test_triangle_between_pixel_centres_has_no_coverage():
+    cov, st = coverage([10.55, 10.95, 10.75], [20.55, 20.6, 20.95])
+    assert cov.sum() == 0 and st.fragments == 0
+
+
+def test_back_face_culled_when_one_sided():
+    # reference front faces (CCW in NDC, y up) are clockwise in y-down screen space: area2 < 0
+    front = ([10, 10, 20], [10, 20, 10])      # (10,10)->(10,20)->(20,10): area2 = (0)(0)-(10)(10) < 0
+    cov_f, _ = coverage(*front, two_sided=False)
+    cov_b, _ = coverage(front[0][::-1], front[1][::-1], two_sided=False)
+    assert cov_f.sum() > 0 and cov_b.sum() == 0
+    cov_b2, _ = coverage(front[0][::-1], front[1][::-1], two_sided=True)
+    assert np.array_equal(cov_b2, cov_f)
+
+
+def test_depth_is_exact_at_vertices_and_affine():
+    # right triangle, depth = plane through the vertices: d(x, y) = 0.25 + x/64 + y/128 (exact binary fractions)
+    X, Y = [0, 32, 0], [0, 0, 32]
+    f = lambda x, y: 0.25 + x / 64.0 + y / 128.0
+    d = [f(x, y) for x, y in zip(X, Y)]
+    vis, _ = orc.raster_snapped_triangle([px(x) for x in X], [px(y) for y in Y], d, 1, 7, W, H)
+    vis = vis.reshape(H, W)
+    depth = (vis >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    ys, xs = np.nonzero(vis)
+    want = np.array([f(x + 0.5, y + 0.5) for x, y in zip(xs, ys)], dtype=np.float32)
+    # barycentrics of power-of-two triangles are exact binary fractions -> bit-exact plane values
+    assert np.array_equal(depth[ys, xs], want)
+    assert ((vis[ys, xs] & np.uint64(0xFFFFFFFF)) == 7).all()
+
+
+def test_larger_packed_word_wins():
+    """Depth test GREATER_OR_EQUAL (helper.h:7-13) == 64-bit max; ties go to the larger payload."""
+    X, Y = [px(2), px(30), px(2)], [px(2), px(2), px(30)]
+    vis, _ = orc.raster_snapped_triangle(X, Y, (0.25,) * 3, 1, 5, W, H)
+    vis, _ = orc.raster_snapped_triangle(X, Y, (0.5,) * 3, 1, 3, W, H, vis=vis)     # nearer (reverse-Z) wins
+    vis, _ = orc.raster_snapped_triangle(X, Y, (0.125,) * 3, 1, 9, W, H, vis=vis)   # farther loses
+    vis, _ = orc.raster_snapped_triangle(X, Y, (0.5,) * 3, 1, 4, W, H, vis=vis)     # tie: larger payload
+    nz = vis[vis != 0]
+    assert len(nz) and (nz == ((np.uint64(np.float32(0.5).view(np.uint32)) << np.uint64(32)) | np.uint64(4))).all()
+
+
+def test_row_sharding_partitions_the_pixels():
+    X, Y = [px(3.3), px(60.1), px(20.7)], [px(2.2), px(30.9), px(61.4)]
+    full, _ = orc.raster_snapped_triangle(X, Y, (0.3, 0.6, 0.9), 1, 11, W, H)
+    acc = np.zeros_like(full)
+    for r in range(4):
+        part, _ = orc.raster_snapped_triangle(X, Y, (0.3, 0.6, 0.9), 1, 11, W, H, shard=(6, 4, r))
+        assert not ((acc != 0) & (part != 0)).any()
+        rows = np.nonzero(part.reshape(H, W).any(axis=1))[0]
+        assert all((y // 6) % 4 == r for y in rows)
+        acc |= part
+    assert np.array_equal(acc, full)
+
+
+# ------------------------------------------------------------------------------- id encoding ---
+
+def test_encode_decode_round_trip():
+    from chord_amd.renderer import decode_visibility          # imports the product lib: symbols must load
+    for slot in (0, 1, 255, 256, 65535, (1 << 24) - 3):
+        for tri in (0, 1, 127):
+            word = (((slot + 1) & 0xFFFFFF) << 8) | (tri & 0xFF)
+            packed = np.array([(np.uint64(np.float32(0.75).view(np.uint32)) << np.uint64(32)) | np.uint64(word)], dtype=np.uint64)
+            d, s, t = decode_visibility(packed)
+            assert d[0] == np.float32(0.75) and s[0] == slot and t[0] == tri
+    d, s, t = decode_visibility(np.zeros(1, dtype=np.uint64))
+    assert s[0] == -1                                           # 0 == empty (sky)
+
+
+# --------------------------------------------------------------------------------------- f16 ---
+
+def test_f16_conversion_matches_ieee_rne():
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([
+        rng.uniform(0, 1, 4000).astype(np.float32),
+        (rng.uniform(0, 1, 2000) * 1e-5).astype(np.float32),      # half denormals
+        np.array([0.0, 1.0, 65504.0, 65520.0, 1e-8, 6.1e-5, 5.96e-8, 2.98e-8, 0.333333], dtype=np.float32),
+        np.arange(0, 2048, dtype=np.float32) / 2048.0 + np.float32(2.0 ** -12),   # exact ties
+    ])
+    want = vals.astype(np.float16).view(np.uint16)
+    got = np.array([orc.lib.orc_f32_to_f16(float(v)) for v in vals], dtype=np.uint16)
+    assert np.array_equal(got, want)
+    allh = np.arange(0, 0x7C00, dtype=np.uint16)
+    back = np.array([orc.lib.orc_f16_to_f32(int(h)) for h in allh], dtype=np.float32)
+    assert np.array_equal(back, allh.view(np.float16).astype(np.float32))
+
+
+# --------------------------------------------------------------------------------------- HZB ---
+
+def _depth_image(w, h, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.uniform(0.0005, 0.9, size=(h, w)).astype(np.float32)
+    d[rng.uniform(size=(h, w)) < 0.2] = 0.0                        # sky
+    return (d.view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.uint64(0x123), d
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (160, 96), (200, 120), (67, 131)])
+def test_hzb_equals_brute_force_min_max(w, h):
+    vis, depth = _depth_image(w, h, w * 1000 + h)
+    desc, mn, mx, rng = orc.hzb_build(vis.reshape(-1), w, h, want_max=True, want_range=True)
+    assert desc.width == orc.hzb_desc(w, h).width
+    for l in range(desc.mipCount):
+        mw, mh = desc.mip_dims(l)
+        vw, vh = desc.valid_dims(l)
+        size = 2 << l
+        lv_mn = mn[desc.mipOffset[l]: desc.mipOffset[l] + mw * mh].reshape(mh, mw)
+        lv_mx = mx[desc.mipOffset[l]: desc.mipOffset[l] + mw * mh].reshape(mh, mw)
+        for y in range(vh):
+            for x in range(vw):
+                ys = np.minimum(np.arange(y * size, (y + 1) * size), h - 1)
+                xs = np.minimum(np.arange(x * size, (x + 1) * size), w - 1)
+                block = depth[np.ix_(ys, xs)]
+                want_mn = np.float16(block.min()).view(np.uint16)
+                want_mx = np.float16(block.max()).view(np.uint16) + (1 if l >= 5 else 0)   # hzb.hlsl:67-71
+                assert lv_mn[y, x] == want_mn, (l, x, y)
+                assert lv_mx[y, x] == want_mx, (l, x, y)
+    valid = depth[depth > 0]
+    assert rng[1] == valid.max().view(np.uint32)
+    assert rng[0] == valid[valid < 1.0].min().view(np.uint32)
+
+
+def test_hzb_of_constant_image_is_constant():
+    w, h = 128, 96
+    c = np.float32(0.3125)
+    vis = np.full(w * h, (np.uint64(c.view(np.uint32)) << np.uint64(32)) | np.uint64(1), dtype=np.uint64)
+    desc, mn, _, _ = orc.hzb_build(vis, w, h)
+    for l in range(desc.mipCount):
+        mw, mh = desc.mip_dims(l)
+        vw, vh = desc.valid_dims(l)
+        lv = mn[desc.mipOffset[l]: desc.mipOffset[l] + mw * mh].reshape(mh, mw)
+        assert (lv[:vh, :vw] == np.float16(c).view(np.uint16)).all()
+
+
+def test_hzb_desc_matches_reference_sizes():
+    # hzb.cpp:49-63 worked examples
+    for (w, h), (ew, eh, mips) in {(3840, 2160): (2048, 2048, 12), (1920, 1080): (1024, 1024, 11), (256, 256): (128, 128, 8)}.items():
+        d = orc.hzb_desc(w, h)
+        assert (d.width, d.height, d.mipCount) == (ew, eh, mips)
+
+
+# ------------------------------------------------------------------------------------ culling ---
+
+def _scene(builder=scenes.small_test_scene, **kw):
+    import helpers as Hh
+    return Hh.setup_scene(lambda: builder(**kw))
+
+
+def test_frustum_known_boxes():
+    """Hand-placed boxes against each frustum plane (camera at origin looking down -z)."""
+    from chord_amd import lib as L
+    pb = scenes.PrimitiveBuilder()
+    pb.add_surface(scenes.plane_surface((-0.5, -0.5, 0.0), (1, 0, 0), (0, 1, 0)), 1, 1)
+    sb = scenes.SceneBuilder("boxes")
+    prim = sb.add_primitive(pb)
+    places = {
+        "centre": (0, 0, -10, True), "behind": (0, 0, 10, False), "left_out": (-30, 0, -10, False),
+        "right_out": (30, 0, -10, False), "up_out": (0, 30, -10, False), "down_out": (0, -30, -10, False),
+        "beyond_far": (0, 0, -20500, False), "straddle_left": (-4.3, 0, -10, True), "near": (0, 0, -0.01, True),
+    }
+    for x, y, z, _ in places.values():
+        sb.add_object(prim, scenes.translate(x, y, z))
+    scene = sb.build()
+    cam = scenes.Camera((0, 0, 0), (0, 0, -1), 256, 256)
+    L.fill_objects(scene, cam)
+    view, iv = L.make_views(cam)
+    vis = orc.object_cull(scene, iv, R.FLAG_FRUSTUM_CULL)
+    for (name, (_, _, _, want)), got in zip(places.items(), vis):
+        assert bool(got) == want, name
+    assert orc.object_cull(scene, iv, 0).all()            # flag off: nothing culled
+
+
+def _group_flags(scene, view, groups):
+    return np.array([orc.lib.orc_group_visible(view.ctypes.data, scene.objects[0:1].ctypes.data, groups[i:i + 1].ctypes.data)
+                     for i in range(len(groups))], dtype=bool)
+
+
+def test_lod_cut_selects_exactly_one_level_when_errors_are_monotone():
+    """Along every LOD0 -> LOD1 -> LOD2 chain (own error sphere == the child's parent sphere) exactly
+    one level passes isMeshletGroupVisibile when the projected errors grow up the chain."""
+    from chord_amd import lib as L
+    scene, _ = scenes.small_test_scene(320, 200, lods=3)
+    prim = scene.primitives[scene.objects[0]["GLTFPrimitiveDetail"]]
+    groups = scene.groups[prim["meshletGroupOffset"]: prim["meshletGroupOffset"] + prim["meshletGroupCount"]]
+    key = {(float(g["error"]),) + tuple(float(x) for x in g["clusterPosCenter"]): i for i, g in enumerate(groups)}
+    chains = []
+    for i, g in enumerate(groups):
+        if g["error"] >= 0:
+            continue
+        chain, cur = [i], g
+        while cur["parentError"] < 3e38:
+            j = key[(float(cur["parentError"]),) + tuple(float(x) for x in cur["parentPosCenter"])]
+            chain.append(j)
+            cur = groups[j]
+        chains.append(chain)
+    assert chains and all(len(c) == 3 for c in chains)
+
+    checked = 0
+    for dist in (6.0, 25.0, 60.0, 130.0, 300.0):
+        cam = scenes.Camera((0.0, dist * 0.6, dist), (0.0, -0.55, -1.0), 320, 200)
+        L.fill_objects(scene, cam)
+        view, _ = L.make_views(cam)
+        drawn = _group_flags(scene, view, groups)
+        # float64 replay of projectSphereToScreen to find the monotone chains
+        l2v = (view["translatedWorldToView"][0].reshape(4, 4).T.astype(np.float64) @
+               scene.objects[0]["localToTranslatedWorld"].reshape(4, 4).T.astype(np.float64))
+        k = float(view["lodScale"][0])
+
+        def px_err(center, r):
+            q = l2v[:3, :3] @ np.asarray(center, np.float64) + l2v[:3, 3]
+            d2 = q @ q
+            return -1.0 if d2 <= r * r else k * r / np.sqrt(d2 - r * r)
+        for c in chains:
+            e1 = px_err(groups[c[1]]["clusterPosCenter"], float(groups[c[1]]["error"]))
+            e2 = px_err(groups[c[2]]["clusterPosCenter"], float(groups[c[2]]["error"]))
+            if e1 < 0 or e2 < 0 or not (e1 * 1.001 < e2) or min(abs(e1 - 1), abs(e2 - 1)) < 1e-3:
+                continue
+            assert drawn[c].sum() == 1, (dist, c, e1, e2, drawn[c])
+            want = 0 if e1 > 1 else (1 if e2 > 1 else 2)
+            assert drawn[c][want]
+            checked += 1
+    assert checked > 50
+    # close up only LOD0 is drawn, from far away only the root level
+    cam = scenes.Camera((0.0, 1.0, 2.0), (0, -0.3, -1), 320, 200)
+    L.fill_objects(scene, cam)
+    assert np.array_equal(_group_flags(scene, L.make_views(cam)[0], groups), groups["error"] < 0)
+    cam = scenes.Camera((0.0, 1500.0, 4000.0), (0, -0.35, -1), 320, 200)
+    L.fill_objects(scene, cam)
+    assert np.array_equal(_group_flags(scene, L.make_views(cam)[0], groups), groups["parentError"] > 3e38)
+
+
+def test_instance_culling_invariants():
+    import helpers as Hh
+    scene, cam, view, iv = Hh.setup_scene(lambda: scenes.small_test_scene(200, 120))
+    cmds = orc.instance_culling(scene, view, iv, Hh.ALL_FLAGS)
+    assert np.array_equal(cmds["slot"], np.arange(len(cmds)))       # check(drawCmd.z == threadId), hzb_mainview_culling.hlsl:52-54
+    assert (np.diff(cmds["objectId"].astype(np.int64)) >= 0).all()  # canonical (object, group, meshlet) order
+    none = orc.instance_culling(scene, view, iv, 0)
+    assert len(none) >= len(cmds)
+    # with every test off the list is exactly the LOD cut of every object
+    keys = set(zip(none["objectId"].tolist(), none["meshletId"].tolist()))
+    assert all((o, m) in keys for o, m in zip(cmds["objectId"].tolist(), cmds["meshletId"].tolist()))
+
+
+def test_two_pass_hzb_partitions_and_preserves_the_image():
+    import helpers as Hh
+    scene, cam, view, iv = Hh.setup_scene(lambda: scenes.small_test_scene(320, 200, seed=3))
+    flags = Hh.ALL_FLAGS
+    f0 = orc.frame(scene, view, iv, flags)
+    f1 = orc.frame(scene, view, iv, flags, prev_hzb_min=f0["hzb_min"])
+    c = f1["counts"]
+    assert c[1] + c[2] == c[0] and c[3] <= c[2]                     # phase0 U rejected == input, phase 1 subset of rejected
+    assert c[2] > 0, "test scene should have occluded clusters"
+    assert np.array_equal(f1["vis"], f0["vis"])                     # static view: occlusion culling must not change the image
+    vis, rej = orc.hzb_culling(scene, view, flags, 0, f0["desc"], f0["hzb_min"], f0["cmds"])
+    both = np.sort(np.concatenate([vis["slot"], rej["slot"]]))
+    assert np.array_equal(both, np.arange(len(f0["cmds"])))
+    # HZB flag off: everything passes
+    vis2, rej2 = orc.hzb_culling(scene, view, R.FLAG_FRUSTUM_CULL, 0, f0["desc"], f0["hzb_min"], f0["cmds"])
+    assert len(vis2) == len(f0["cmds"]) and len(rej2) == 0
+
+
+def test_consumer_contract_slot_indexes_post_cull_list():
+    """lighting.hlsl:318-345 / visibility_tile.hlsl:47-54: texel -> slot -> cmd with cmd.z == slot."""
+    import helpers as Hh
+    from chord_amd.renderer import decode_visibility
+    scene, cam, view, iv = Hh.setup_scene(lambda: scenes.small_test_scene(200, 120))
+    f = orc.frame(scene, view, iv, Hh.ALL_FLAGS)
+    depth, slot, tri = decode_visibility(f["vis"])
+    hit = slot >= 0
+    assert hit.any() and slot[hit].max() < len(f["cmds"])
+    assert (f["cmds"]["slot"][slot[hit]] == slot[hit]).all()
+    tcount = (scene.meshlets["vertexTriangleCount"][f["cmds"]["meshletId"][slot[hit]]] >> 8) & 0xFF
+    assert (tri[hit] < tcount).all()
+    assert (depth[hit] > 0).all() and (depth[~hit] == 0).all()
+
+
+def test_multithreaded_raster_equals_scalar():
+    import helpers as Hh
+    scene, cam, view, iv = Hh.setup_scene(lambda: scenes.small_test_scene(320, 200, seed=21))
+    cmds = orc.instance_culling(scene, view, iv, Hh.ALL_FLAGS)
+    a, sa = orc.raster(scene, iv, cmds, 320, 200)
+    b, sb = orc.raster(scene, iv, cmds, 320, 200, threads=4)
+    assert np.array_equal(a, b) and sa.fragments == sb.fragments
+
+
+def test_near_plane_clipping_is_watertight_and_bounded():
+    """A coarse floor passing under the camera straddles w = 0 with triangles that stay on screen under the
+    reference's |w| projection (mesh_raster.hlsl:159-161), so they reach the clipper: the image must be
+    hole-free, covered exactly once, and nothing may be written outside the image."""
+    import helpers as Hh
+    for pos, front in (((0.3, 0.25, 0.2), (0.1, -0.6, -1.0)), ((0.3, 0.6, 0.2), (0.1, -1.0, -0.3))):
+        scene, cam, view, iv = Hh.setup_scene(lambda: scenes.floor_under_camera(pos, front, 128, 96))
+        cmds = orc.instance_culling(scene, view, iv, 0)
+        vis, st = orc.raster(scene, iv, cmds, 128, 96)
+        assert st.trianglesClipped > 0
+        cov = vis.reshape(96, 128) != 0
+        assert cov.all(), "hole in the clipped floor"
+        assert st.fragments == 128 * 96                       # single layer: every pixel hit exactly once
