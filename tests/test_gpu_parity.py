@@ -110,3 +110,142 @@ def test_hzb_culling_lists_match_oracle(gpu):
     # phase0 visible U rejected == input
     assert np.array_equal(H.sort_cmds(np.concatenate([gv, gr])), H.sort_cmds(f0["cmds"]))
     r.close()
+
+
+def test_golden_config1_on_gpu(gpu):
+    """The committed golden vector (tests/golden/config1.npz), through the C ABI."""
+    import test_golden as TG
+    g, scene, view, iv, flags = TG.load_gold()
+    r = _renderer(gpu, scene, view, iv, 256, 256, flags)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), g["vis"], 256, 256, "golden config1")
+    assert np.array_equal(r.read_cmds(r.last_frame_cmds()).view(np.uint8), g["cmds"])
+    mn, mx, rng = r.read_hzb(r.history_hzb())
+    assert np.array_equal(mn, g["hzb_min"]) and np.array_equal(mx, g["hzb_max"]) and np.array_equal(rng, g["valid_range"])
+    r.close()
+
+
+@pytest.mark.parametrize("pos,front", [((0.3, 0.25, 0.2), (0.1, -0.6, -1.0)), ((0.3, 0.6, 0.2), (0.1, -1.0, -0.3)),
+                                       ((0.0, 0.05, 0.0), (0.7, -0.1, -0.7))])
+def test_near_plane_clipper_matches_oracle(gpu, pos, front):
+    """Triangles straddling w = 0 / the guard band take the clip kernel, and are big on screen."""
+    scene, cam, view, iv = H.setup_scene(lambda: scenes.floor_under_camera(pos, front, 256, 192))
+    want = orc.frame(scene, view, iv, 0)
+    assert want["stats"].trianglesClipped > 0
+    r = _renderer(gpu, scene, view, iv, 256, 192, 0)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want["vis"], 256, 192, "clipper")
+    assert r.stats()["overflow"] == 0
+    r.close()
+
+
+def test_big_triangles_and_close_ups_match_oracle(gpu):
+    """Camera a few centimetres from a wall: every triangle is hundreds of pixels (chunk kernel)."""
+    def build():
+        scene, _ = scenes.small_test_scene(512, 384, seed=13)
+        return scene, scenes.Camera((-2.0, 0.35, 1.0), (0.9, -0.5, -0.4), 512, 384)
+    scene, cam, view, iv = H.setup_scene(build)
+    want = orc.frame(scene, view, iv, H.ALL_FLAGS)
+    assert want["stats"].fragments > 4 * want["stats"].trianglesRastered
+    r = _renderer(gpu, scene, view, iv, 512, 384, H.ALL_FLAGS)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want["vis"], 512, 384, "close-up")
+    r.close()
+
+
+def test_config2_atrium_1080p_matches_oracle(gpu):
+    """BASELINE config 2 at full size (frustum-only, no HZB): 2048 meshlets, 262 144 triangles."""
+    scene, cam, view, iv = H.setup_scene(scenes.config2_atrium)
+    flags = R.FLAG_FRUSTUM_CULL
+    want = orc.frame(scene, view, iv, flags)
+    r = _renderer(gpu, scene, view, iv, 1920, 1080, flags)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want["vis"], 1920, 1080, "config2")
+    st = r.stats()
+    assert st["trianglesSubmitted"] == want["stats"].trianglesSubmitted and st["overflow"] == 0
+    r.close()
+
+
+def test_config3_street_4k_two_pass_matches_oracle_and_properties(gpu):
+    """BASELINE config 3 at full size: frame 0 (no history) and frame 1 (two-pass HZB) bit-exact vs the
+    oracle; occlusion culling must not change a static image; a repeated frame is idempotent."""
+    from chord_amd import lib as L
+    scene, cam, view, iv = H.setup_scene(scenes.config3_street)
+    w, h = cam.width, cam.height
+    flags = H.ALL_FLAGS
+    want0 = orc.frame(scene, view, iv, flags)
+    r = _renderer(gpu, scene, view, iv, w, h, flags)
+    r.render_frame()
+    got0 = r.read_visibility()
+    H.assert_vis_equal(got0, want0["vis"], w, h, "config3 frame0")
+    r.render_frame()                                     # static camera, history from frame 0
+    got1 = r.read_visibility()
+    st1 = r.stats()
+    assert st1["countStage0Rejected"] > 0 and st1["overflow"] == 0
+    assert np.array_equal(got1, got0), "two-pass occlusion culling changed a static image"
+    want1 = orc.frame(scene, view, iv, flags, prev_hzb_min=want0["hzb_min"])
+    assert [st1["countInstanceCulled"], st1["countStage0Visible"], st1["countStage0Rejected"], st1["countStage1Visible"]] == list(want1["counts"])
+    assert st1["trianglesSubmitted"] == want1["stats"].trianglesSubmitted
+    r.render_frame()
+    assert np.array_equal(r.read_visibility(), got0)     # idempotent
+    # depth is in (0, 1] wherever something was drawn; the ids index the post-cull list
+    from chord_amd.renderer import decode_visibility
+    depth, slot, tri = decode_visibility(got0)
+    hit = slot >= 0
+    assert (depth[hit] > 0).all() and (depth[hit] <= 1.0).all() and slot[hit].max() < st1["countInstanceCulled"]
+    r.close()
+
+
+def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu):
+    """The multi-GPU path on one device: every rank's context runs its phases in turn, the two
+    all-gathers are replaced by device-to-device copies of the rank chunks, and each rank must end up
+    with exactly the single-GPU visibility buffer and HZB."""
+    import ctypes as C
+    import torch
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam, view, iv = H.setup_scene(lambda: scenes.small_test_scene(320, 200, seed=17))
+    w, h, flags = cam.width, cam.height, H.ALL_FLAGS
+    ref = _renderer(gpu, scene, view, iv, w, h, flags)
+    ranks, stripe = 3, 14
+    ctxs = []
+    for rk in range(ranks):
+        r = VisibilityRenderer(0)
+        r.upload_scene(scene)
+        r.set_shard(stripe, ranks, rk)
+        r.allocate_gbuffer(w, h)
+        r.set_view(view, iv, flags)
+        ctxs.append(r)
+    hip = L._preload_hip_runtime()
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def gather(ptrs, chunk_bytes):
+        for r in ctxs:
+            r.sync()
+        for dst in range(ranks):
+            for src in range(ranks):
+                if src != dst:
+                    assert hip.hipMemcpy(ptrs[dst] + src * chunk_bytes, ptrs[src] + src * chunk_bytes, chunk_bytes, 3) == 0
+
+    for frame in range(2):                               # frame 0: no history; frame 1: two-pass HZB
+        ref.render_frame()
+        want = ref.read_visibility()
+        wmn, wmx, wrng = ref.read_hzb(ref.history_hzb())
+        for r in ctxs:
+            r.frame_phase_a()
+        ex = [r.hzb_exchange() for r in ctxs]
+        gather([e[0] for e in ex], ex[0][2] * 2)
+        for r in ctxs:
+            r.frame_phase_b()
+        gather([r.visibility_ptr() for r in ctxs], ctxs[0].visibility_chunk_words() * 8)
+        for r in ctxs:
+            r.frame_phase_c()
+        for rk, r in enumerate(ctxs):
+            H.assert_vis_equal(r.read_visibility(), want, w, h, "frame %d rank %d" % (frame, rk))
+            mn, mx, rng = r.read_hzb(r.history_hzb())
+            assert np.array_equal(mn, wmn) and np.array_equal(mx, wmx) and np.array_equal(rng, wrng)
+            st, sr = r.stats(), ref.stats()
+            assert [st[k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible")] == \
+                   [sr[k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible")]
+    for r in ctxs + [ref]:
+        r.close()
