@@ -183,22 +183,29 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, inside the timed region)
-    pixels_touched = int((vis_t[:W * H] != 0).sum().item()) if world == 1 else None
+    # algorithmic bytes per frame (DESIGN.md "Roofline"): setup reads 1884 B per cluster (64 header + 12 cmd +
+    # 4(V+T) indices + 12V positions, V=81 T=128) and writes a 48 B record + 4 B per bin entry; the tile
+    # kernel reads 4 + 48 B per bin entry and moves 8 B per pixel out (and in, on the second pass).
+    pixels = W * H
     V, T = 81, 128
-    cluster_bytes = CLUSTER_BYTES + 4 * (V + T) + 12 * V           # 1884 B per cluster
+    cluster_bytes = CLUSTER_BYTES + 4 * (V + T) + 12 * V
     clusters_per_frame = clusters_per_pair / 2.0
+    recs = sum(pv["triangleRecords"] for pv in per_view) / 2.0
+    bins = sum(pv["binEntries"] for pv in per_view) / 2.0
+    launches = max(1, st["rasterLaunches"])
     kernels = {
-        "raster_cluster_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame),
-        "raster_chunk_kernel": (st["msRasterChunk"], 8.0 * (pixels_touched or 0)),
+        "raster_setup_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame + 48.0 * recs + 4.0 * bins),
+        "raster_tile_kernel": (st["msRasterChunk"], 52.0 * bins + 8.0 * pixels * (2 * launches - 1)),
     }
     dom = max(kernels, key=lambda k: kernels[k][0])
     dom_ms, dom_bytes = kernels[dom]
-    launches = max(1, st["rasterLaunches"])
     achieved = (dom_bytes / launches) / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                 "avg_launch_us": round(dom_ms / launches * 1e3, 2), "launches_per_step": launches,
-                "algorithmic_bytes_per_launch": int(dom_bytes / launches)}
+                "algorithmic_bytes_per_launch": int(dom_bytes / launches),
+                "other_kernel": {k: {"avg_launch_us": round(v[0] / launches * 1e3, 2), "algorithmic_bytes_per_launch": int(v[1] / launches)}
+                                 for k, v in kernels.items() if k != dom}}
 
     # ---- CPU baseline: the oracle replaying the same frame on the host (rank 0, N = 1) ----------
     cpu = None
@@ -226,7 +233,7 @@ def main():
                        "objects": len(scene.objects), "hzb": not args.no_hzb,
                        "parallelism": "stripes%d" % world if world > 1 else "single"},
             "triangles_submitted_per_step": tris_per_pair / 2.0,
-            "clusters_rastered_per_step": clusters_per_frame,
+            "clusters_rastered_per_step": clusters_per_frame, "triangle_records_per_step": recs, "bin_entries_per_step": bins,
             "gpu_ms": {k: round(st[k], 4) for k in ("msClear", "msInstanceCulling", "msStage0", "msHzbStage0", "msStage1",
                                                      "msHzbFinal", "msFrame", "msRasterCluster", "msRasterClip", "msRasterChunk")},
             "counts_view_a": {k: per_view[0][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible")},

@@ -13,6 +13,7 @@
 #include "device_layer.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 
@@ -98,6 +99,11 @@ int configure_targets(ChordCtx* c, uint64_t* external)
     else dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) if ((rc = alloc_hzb(c, c->hzb[i]))) return rc;
     c->historySlot = 0;
+    {   // per-tile triangle bins of the rasterizer: 64x64-pixel tiles, binCap entries each
+        c->tilesX = (c->width + 63) / 64; c->tilesY = (c->height + 63) / 64;
+        c->binCap = 16384;              // 4K: 2 passes x 2040 tiles x 16384 x 4 B = 267 MB
+        if ((rc = dalloc(c, &c->dTileBins, (size_t)2 * c->tilesX * c->tilesY * c->binCap))) return rc;
+    }
     {   // one {min, max} partial per block of the mip-0 kernel (64 x 4 texels per block)
         const uint32_t vw = (c->width + 1) / 2, vh = (c->height + 1) / 2;
         if ((rc = dalloc(c, &c->dRangePartials, (size_t)((vw + 63) / 64) * ((vh + 3) / 4) * 2))) return rc;
@@ -139,11 +145,25 @@ int ready(ChordCtx* c, const char* fn)
     return CHORDVIS_OK;
 }
 
+// addClearGbufferPass inside a frame: the visibility words are not memset; the first raster pass of the
+// frame starts every 64x64 tile from zero in LDS and writes every tile back, which is the clear.
+int begin_frame_clear(ChordCtx* c)
+{
+    // one memset: counters, the four command-list counts and both passes' tile bin counts
+    const size_t bytes = offsetof(FrameState, tileCount) + sizeof(uint32_t) * CHORD_TILECOUNT_STRIDE * (CHORD_MAX_TILES + (size_t)c->tilesX * c->tilesY);
+    CHORD_HIP(c, hipMemsetAsync(c->dFrameState, 0, bytes, c->stream));
+    c->rasterCalls = 0;
+    c->pendingClear = true;
+    c->inFrame = true;
+    return CHORDVIS_OK;
+}
+
 int do_raster(ChordCtx* c, const CmdList& in)
 {
     // renderMesh (mesh_raster.cpp:208-254): the four (alphaMode x twoSided) pipeline buckets and
     // their filter passes collapse into one launch; the kernel reads bTwoSided per cluster.
-    launch_raster(c, in);
+    launch_raster(c, in, c->pendingClear);
+    c->pendingClear = false;
     CHORD_HIP(c, hipGetLastError());
     return CHORDVIS_OK;
 }
@@ -185,12 +205,13 @@ int chordvis_create(int deviceOrdinal, void* hipStream, ChordCtx** outCtx)
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CHORDVIS_E_HIP; }
         c->ownStream = true;
     }
-    bool ok = hipMalloc((void**)&c->dView, sizeof(DView)) == hipSuccess &&
-              hipMalloc((void**)&c->dCounts, 4 * sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc((void**)&c->dCounters, sizeof(DeviceCounters)) == hipSuccess;
+    bool ok = hipMalloc((void**)&c->dTileClocks, sizeof(unsigned long long) * 2 * CHORD_MAX_TILES) == hipSuccess &&
+              hipMalloc((void**)&c->dView, sizeof(DView)) == hipSuccess &&
+              hipMalloc((void**)&c->dFrameState, sizeof(FrameState)) == hipSuccess;
     if (!ok) { chordvis_destroy(c); return CHORDVIS_E_HIP; }
-    (void)hipMemsetAsync(c->dCounts, 0, 4 * sizeof(uint32_t), c->stream);
-    (void)hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters), c->stream);
+    c->dCounters = &c->dFrameState->counters;
+    c->dCounts = c->dFrameState->listCounts;
+    (void)hipMemsetAsync(c->dFrameState, 0, sizeof(FrameState), c->stream);
     *outCtx = c;
     return CHORDVIS_OK;
 }
@@ -204,9 +225,11 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
-    dfree(c->dCounts); dfree(c->dVisOwned); dfree(c->dVisResolved);
+    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks);
+    dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
-    dfree(c->dRangePartials); dfree(c->dHzbExchange); dfree(c->dBigTris); dfree(c->dBigChunks); dfree(c->dClipTris); dfree(c->dCounters);
+    dfree(c->dRangePartials); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTileBins);
+    dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -343,11 +366,13 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         c->lists[i].count = c->dCounts + i;
         c->lists[i].capacity = c->cmdCapacity;
     }
-    // deferred raster lists (fixed budgets; overflow is detected and reported by chordvis_stats)
-    c->bigTriCap = 2u << 20; c->bigChunkCap = 8u << 20; c->clipTriCap = 1u << 20;
-    if ((rc = dalloc(c, &c->dBigTris, (size_t)c->bigTriCap))) return rc;
-    if ((rc = dalloc(c, &c->dBigChunks, (size_t)c->bigChunkCap))) return rc;
+    // raster work lists (fixed budgets sized for 288 GB of HBM; overflow is detected and reported by chordvis_stats)
+    c->triCap = 16u << 20;              // 16 M records x 48 B = 768 MB
+    c->clipTriCap = 1u << 20;
+    if ((rc = dalloc(c, &c->dTris, (size_t)c->triCap))) return rc;
     if ((rc = dalloc(c, &c->dClipTris, (size_t)c->clipTriCap))) return rc;
+    c->largeCap = 8u << 20;
+    if ((rc = dalloc(c, &c->dLargeList, (size_t)c->largeCap))) return rc;
     c->sceneLoaded = true;
     c->historySlot = 0;
     return CHORDVIS_OK;
@@ -432,6 +457,8 @@ int chordvis_clear_gbuffer(ChordCtx* c)
     }
     CHORD_HIP(c, hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters), c->stream));
     c->rasterCalls = 0;
+    c->pendingClear = false;
+    c->inFrame = false;
     return CHORDVIS_OK;
 }
 
@@ -456,7 +483,7 @@ int chordvis_hzb_culling(ChordCtx* c, const ChordHZB* hzb, int bFirstStage, Chor
     const CmdList inL = from_handle(in);
     if (bFirstStage) {
         if (inL.cmds == c->lists[1].cmds || inL.cmds == c->lists[2].cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling: first stage input must be the instanceCulling list");
-        CHORD_HIP(c, hipMemsetAsync(c->dCounts + 1, 0, 8, c->stream));
+        if (!c->inFrame) CHORD_HIP(c, hipMemsetAsync(c->dCounts + 1, 0, 8, c->stream));
         launch_hzb_cull(c, hb, 0, inL, c->lists[1], &c->lists[2]);
         if (outVisible) *outVisible = c->lists[1].handle();
         if (outRejected) *outRejected = c->lists[2].handle();
@@ -464,7 +491,7 @@ int chordvis_hzb_culling(ChordCtx* c, const ChordHZB* hzb, int bFirstStage, Chor
         if (inL.cmds == c->lists[1].cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling: second stage input aliases its output");
         CmdList vis1 = c->lists[1];
         vis1.count = c->dCounts + 3;
-        CHORD_HIP(c, hipMemsetAsync(c->dCounts + 3, 0, 4, c->stream));
+        if (!c->inFrame) CHORD_HIP(c, hipMemsetAsync(c->dCounts + 3, 0, 4, c->stream));
         launch_hzb_cull(c, hb, 1, inL, vis1, nullptr);
         if (outVisible) *outVisible = vis1.handle();
         if (outRejected) *outRejected = ChordCountAndCmd{nullptr, nullptr, 0};
@@ -538,7 +565,7 @@ int chordvis_render_frame(ChordCtx* c)
     if (rc) return rc;
     if (c->shard.ranks > 1) return fail(c, CHORDVIS_E_INVALID, "render_frame: sharded contexts use frame_phase_a/b/c");
     begin_frame_stamps(c);
-    if ((rc = chordvis_clear_gbuffer(c))) return rc;                                  // renderer.cpp:315
+    if ((rc = begin_frame_clear(c))) return rc;                                       // renderer.cpp:315
     record(c, S_CLEAR);
     ChordCountAndCmd post;
     if ((rc = chordvis_instance_culling(c, &post))) return rc;                        // :321
@@ -562,6 +589,7 @@ int chordvis_render_frame(ChordCtx* c)
     if ((rc = chordvis_build_hzb(c, 1, 1, 1, next, nullptr))) return rc;              // :343
     record(c, S_HZBF);
     c->historySlot = next;                                                            // :489
+    c->inFrame = false;
     return CHORDVIS_OK;
 }
 
@@ -571,7 +599,7 @@ int chordvis_frame_phase_a(ChordCtx* c)
     int rc = ready(c, "frame_phase_a");
     if (rc) return rc;
     begin_frame_stamps(c);
-    if ((rc = chordvis_clear_gbuffer(c))) return rc;
+    if ((rc = begin_frame_clear(c))) return rc;
     record(c, S_CLEAR);
     ChordCountAndCmd post;
     if ((rc = chordvis_instance_culling(c, &post))) return rc;
@@ -617,6 +645,7 @@ int chordvis_frame_phase_c(ChordCtx* c)
     if ((rc = chordvis_build_hzb(c, 1, 1, 1, next, nullptr))) return rc;
     record(c, S_HZBF);
     c->historySlot = next;
+    c->inFrame = false;
     return CHORDVIS_OK;
 }
 
@@ -692,6 +721,16 @@ int chordvis_set_debug(ChordCtx* c, uint32_t flags)
     return CHORDVIS_OK;
 }
 
+int chordvis_debug_tile_profile(ChordCtx* c, int pass, uint64_t* hostTicks, uint32_t* hostCounts, uint32_t capacity)
+{
+    if (!c || pass < 0 || pass > 1 || !hostTicks || !hostCounts || capacity < c->tilesX * c->tilesY) return fail(c, CHORDVIS_E_INVALID, "debug_tile_profile: bad arguments");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->tilesX * c->tilesY;
+    CHORD_HIP(c, hipMemcpy(hostTicks, c->dTileClocks + (size_t)pass * CHORD_MAX_TILES, n * 8, hipMemcpyDeviceToHost));
+    CHORD_HIP(c, hipMemcpy2D(hostCounts, 4, c->dFrameState->tileCount[pass], 4 * CHORD_TILECOUNT_STRIDE, 4, n, hipMemcpyDeviceToHost));
+    return CHORDVIS_OK;
+}
+
 int chordvis_enable_timers(ChordCtx* c, int enable)
 {
     if (!c) return CHORDVIS_E_INVALID;
@@ -720,6 +759,14 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
     }
     out->overflow = dc.overflow;
     out->rasterLaunches = c->rasterCalls;
+    for (uint32_t i = 0; i < CHORD_LIST_SHARDS; i++) out->triangleRecords += dc.triCount[i];
+    if (c->tilesX) {
+        std::vector<uint32_t> tc((size_t)c->tilesX * c->tilesY);
+        for (int pass = 0; pass < 2; pass++) {
+            CHORD_HIP(c, hipMemcpy2D(tc.data(), 4, c->dFrameState->tileCount[pass], 4 * CHORD_TILECOUNT_STRIDE, 4, tc.size(), hipMemcpyDeviceToHost));
+            for (uint32_t v : tc) out->binEntries += v;
+        }
+    }
     if (c->timers && c->framesStamped && c->stampTags.size() > 1) {
         // walk the stamps: the segment ending at stamp i is attributed by its tag and the current stage
         float clear = 0, cull = 0, st0 = 0, hzb0 = 0, st1 = 0, hzbf = 0, rc_ = 0, rk = 0, rh = 0, other = 0;

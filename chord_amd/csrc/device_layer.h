@@ -70,31 +70,39 @@ struct ShardInfo {
     uint32_t stripeRows, ranks, rank, stripesPerRank;
 };
 
-// Deferred work produced by the raster kernel (device lists, counts in DeviceCounters)
-struct BigTri {                // 48 B: a triangle too large for the per-cluster wave
+// Work lists between the raster kernels (device memory, counts in DeviceCounters)
+struct TriRec {                // 48 B: one set-up triangle (snapped 24.8 vertices, vertex depths, id)
     int32_t  X[3]; int32_t Y[3];
     float    d[3];
     uint32_t payload;
     uint32_t twoSided;
     uint32_t pad;
 };
-struct BigChunk { uint32_t tri; uint32_t cxy; };            // 64x64-pixel chunk (cx | cy << 16)
 struct ClipTri { uint32_t cmdIndex; uint32_t tri; };       // needs the homogeneous clipper
 
-// The deferred lists are cut into LIST_SHARDS independent sub-lists (own counter, own region) so
-// that list allocation is not serialised on one memory-side atomic (one word sustains only
-// ~88 returning atomics/us on MI355X); a wave picks its shard from its global wave id.
+// The record list is cut into LIST_SHARDS independent sub-lists (own counter, own region) so that
+// list allocation is not serialised on one memory-side atomic (one word sustains only ~88 returning
+// atomics/us on MI355X); a wave picks its shard from its global wave id.
 #define CHORD_LIST_SHARDS 64u
 struct DeviceCounters {
-    uint32_t bigTriCount[CHORD_LIST_SHARDS];
-    uint32_t bigChunkCount[CHORD_LIST_SHARDS];
-    uint32_t clipTriCount;
-    uint32_t overflow;                          // bit0 big lists, bit1 clip list
-    uint32_t pad[2];
+    uint32_t triCount[CHORD_LIST_SHARDS];       // records appended this frame (both raster passes)
+    uint32_t clipTriCount[2];                   // per raster pass
+    uint32_t largeCount[2];                     // per raster pass: records touching more than 2x2 tiles
+    uint32_t overflow;                          // bit0 record list / tile bin / large list, bit1 clip list
+    uint32_t pad[3];
     // triangles (meshlet triangle counts) of the commands each list producer emitted this frame
     unsigned long long trisInstanceCulled, trisHzbVisible0, trisHzbVisible1, pad2;
 };
-#define CHORD_COUNTERS_RESET_BYTES (CHORD_LIST_SHARDS * 8u + 4u)   // per raster launch: list counts only
+
+// Everything a frame zeroes lives in ONE allocation so the frame starts with one memset:
+// counters, the four command-list counts, and the per-pass tile bin counts (2 x tiles follow).
+#define CHORD_MAX_TILES 4096u                    // (4096 / 64)^2, renderer.h:52-53 caps the render size
+#define CHORD_TILECOUNT_STRIDE 16u               // one bin counter per 64-byte line
+struct FrameState {
+    DeviceCounters counters;
+    uint32_t listCounts[4];
+    uint32_t tileCount[2][CHORD_MAX_TILES * CHORD_TILECOUNT_STRIDE];
+};
 
 struct CmdList {
     uint32_t*     count = nullptr;
@@ -173,12 +181,19 @@ struct ChordCtx {
     uint16_t* dHzbExchange = nullptr;
     uint64_t hzbExchangeHalves = 0, hzbExchangeChunkHalves = 0;
 
-    // deferred raster work
-    chord::BigTri* dBigTris = nullptr;
-    chord::BigChunk* dBigChunks = nullptr;
+    // raster work lists: triangle records, per-tile bins, clip list
+    chord::TriRec* dTris = nullptr;
+    uint32_t triCap = 0;               // all shards together
+    chord::FrameState* dFrameState = nullptr;
+    uint32_t* dTileBins = nullptr;     // [2 passes][tiles][binCap]
+    bool inFrame = false;              // inside render_frame / frame_phase_*: per-pass counts were zeroed at frame begin
+    uint32_t binCap = 0, tilesX = 0, tilesY = 0;
     chord::ClipTri* dClipTris = nullptr;
-    uint32_t bigTriCap = 0, bigChunkCap = 0, clipTriCap = 0;
+    uint32_t clipTriCap = 0;
+    uint32_t* dLargeList = nullptr;    // [2 passes][largeCap / 2] record indices
+    uint32_t largeCap = 0;
     chord::DeviceCounters* dCounters = nullptr;
+    bool pendingClear = false;         // the next raster pass starts every tile from zero (fused clear)
 
     // timers: mode 0 off, 1 = last frame only, 2 = accumulate until chordvis_stats
     int timers = 0;
@@ -189,6 +204,7 @@ struct ChordCtx {
     bool shouldStage1 = false;
     chord::CmdList lastRejected;
     uint32_t debugFlags = 0;           // ablation switches for measurements (chordvis_set_debug)
+    unsigned long long* dTileClocks = nullptr;   // [2][CHORD_MAX_TILES] per-tile ticks when debug bit 4 is set
 };
 
 namespace chord {
@@ -206,7 +222,7 @@ void launch_object_cull(ChordCtx* c);
 void launch_group_cull(ChordCtx* c, const CmdList& out);
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
                      const CmdList* outRejected);
-void launch_raster(ChordCtx* c, const CmdList& in);
+void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles);
 void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange, bool fromExchange);
 void launch_hzb_mip0_exchange(ChordCtx* c);
 void launch_detile(ChordCtx* c);

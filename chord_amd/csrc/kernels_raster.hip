@@ -1,31 +1,45 @@
-// Software rasterizer of the visibility path, hand-written for gfx950 (wave64, LDS-staged).
+// Software rasterizer of the visibility path, hand-written for gfx950 (wave64, LDS tiles).
 //
 // Replaces meshRasterPassMS + the fixed-function rasterizer + depth test + meshRasterPassPS
-// (mesh_raster.hlsl:51-210; state mesh_raster.cpp:141-156, helper.h:7-13,304-324,395-407) with
-//   raster_cluster_kernel  one wave per visible meshlet: coalesced meshletData / position stream ->
-//                          clip-space transform -> LDS (SoA x,y,w,u,v,depth) -> per-triangle culls
-//                          (mesh_raster.hlsl:143-179) -> setup -> two size classes:
-//                            small (bbox <= 16x16 px)  per-lane scan, 32-bit edge functions
-//                            big                       appended to a device list as 64x64 chunks
-//                          triangles touching the near/guard planes -> clip list
-//   raster_clip_kernel     homogeneous Sutherland-Hodgman clipper (rare), one lane per triangle
-//   raster_chunk_kernel    one wave per 64x64 chunk of a big triangle: 64 lanes classify the 64
-//                          8x8 tiles, then scan the surviving tiles cooperatively
-// Every covered pixel does atomicMax(u64) of (asuint(depth) << 32 | ((slot+1)&0xFFFFFF)<<8 | tri):
-// reverse-Z "greater wins" + id in one global_atomic_umax_x2 (device scope, resolved at the
-// memory side so it is coherent across the 8 XCD L2s).
+// (mesh_raster.hlsl:51-210; state mesh_raster.cpp:141-156, helper.h:7-13,304-324,395-407).
+//
+// Measured on MI355X (tools/microbench/atomics.hip): a 64-bit global atomicMax costs one L2/fabric
+// request per 64-byte line touched — 26 Gop/s when every lane hits its own line (small triangles),
+// 214 Gop/s for an 8x8 footprint — while ds_max_u64 in LDS sustains ~1 050 Gop/s and plain coalesced
+// stores ~6.6 TB/s.  So fragments are resolved in LDS and the visibility words leave the CU once:
+//
+//   raster_setup_kernel   one wave per visible meshlet: coalesced meshletData / position stream ->
+//                         clip-space transform -> LDS (SoA x,y,w,u,v,depth) -> per-triangle culls
+//                         (mesh_raster.hlsl:143-179) -> snapped setup -> 48-byte triangle record
+//                         appended to a device list + one bin entry per 64x64 screen tile touched
+//   raster_clip_kernel    homogeneous Sutherland-Hodgman clipper for triangles touching the near /
+//                         guard planes (rare), emits records + bin entries the same way
+//   raster_bin_large_kernel  records touching more than 2x2 tiles: one wave per record, one lane per tile
+//   raster_tile_kernel    one workgroup per 64x64 tile: the tile's 4096 packed words live in LDS
+//                         (32 KB); every binned triangle is scan-converted with ds_max_u64
+//                         (small: one lane per triangle; larger: one pixel row per lane), then the
+//                         tile is written back with 16-byte coalesced stores (and, on the first pass
+//                         of a frame, this is also the clear).
+// The packed word is (asuint(depth) << 32) | ((slot+1)&0xFFFFFF)<<8 | tri: reverse-Z "greater wins"
+// and the id in one 64-bit max (GREATER_OR_EQUAL depth test + id write of the reference).
 //
 // Arithmetic is the canonical restatement of SURVEY.md §8c: snapped 24.8 coordinates, pixel
 // centres at +0.5, top-left rule, integer edge functions, depth = (d0 + l1*(d1-d0)) + l2*(d2-d0).
-// Integer / fp32 VALU + atomics; no MFMA.  Built with -ffp-contract=off.
+// Integer / fp32 VALU + LDS atomics; no MFMA.  Built with -ffp-contract=off.
 
 #include "device_layer.h"
 #include "device_math.h"
+
+#include <type_traits>
 
 namespace chord {
 
 #define GUARD_BAND 1024.0f
 #define LDS_VERTS 256
+#define TILE 64                 // pixels per tile side
+#define TILE_SHIFT 6
+#define SMALL_AREA 256          // clipped bbox pixels a single lane scans on its own
+#define TC_STRIDE CHORD_TILECOUNT_STRIDE   // one bin counter per 64-byte line (no false sharing between tiles)
 
 struct RasterParams {
     const uint32_t* count; const ChordDrawCmd* cmds;
@@ -34,29 +48,22 @@ struct RasterParams {
     unsigned long long* vis;
     float W, H; int32_t Wi, Hi;
     ShardInfo shard;
-    BigTri* bigTris; BigChunk* bigChunks; ClipTri* clipTris;
-    uint32_t bigTriCap, bigChunkCap, clipTriCap;       // big caps are PER SHARD
+    TriRec* tris; uint32_t triCap;                      // per list shard
+    uint32_t* tileCount; uint32_t* tileBins; uint32_t binCap; uint32_t tilesX, tilesY;
+    ClipTri* clipTris; uint32_t clipTriCap; uint32_t pass;   // raster pass of the frame (0 / 1): clip / large count slot
+    uint32_t* largeList; uint32_t largeCap;                  // records touching more than 2x2 tiles (binned by raster_bin_large_kernel)
     DeviceCounters* counters;
-    uint32_t debug;                                    // ablation switches (chordvis_set_debug), 0 in production
+    unsigned long long* tileClocks;                     // debug: per-tile elapsed wall clock ticks (DBG_TILE_CLOCKS)
+    uint32_t clearTiles;                                // first raster pass of a frame: tiles start from 0
+    uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
 #define DBG_NO_PIXELS   1u    // skip every visibility write
-#define DBG_PLAIN_STORE 2u    // plain store instead of atomicMax (wrong image; timing only)
-#define DBG_NO_BIG      4u    // drop big triangles instead of deferring them
-#define DBG_NO_EARLYZ   8u    // tile path: no read-before-atomic
+#define DBG_NO_BIN      2u    // setup only: no records, no bins
+#define DBG_TILE_CLOCKS 16u   // tile kernel writes its elapsed wall-clock ticks per tile
 
 __device__ __forceinline__ int32_t bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 __device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
-
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t n = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d) v += n;
-    }
-    return v;
-}
 
 template <bool SH>
 __device__ __forceinline__ bool owns_row(const ShardInfo& s, int32_t y)
@@ -75,6 +82,16 @@ __device__ __forceinline__ size_t row_base(const ShardInfo& s, int32_t y, int32_
     return ((size_t)(owner * s.stripesPerRank + local) * s.stripeRows + ((uint32_t)y % s.stripeRows)) * (size_t)Wi;
 }
 
+// does the rank own at least one pixel row in [y0, y1]?  (ranks == 1: always)
+__device__ __forceinline__ bool owns_any_row(const ShardInfo& s, int32_t y0, int32_t y1)
+{
+    if (s.ranks <= 1) return true;
+    const uint32_t s0 = (uint32_t)y0 / s.stripeRows, s1 = (uint32_t)y1 / s.stripeRows;
+    if (s1 - s0 + 1u >= s.ranks) return true;
+    for (uint32_t st = s0; st <= s1; st++) if (st % s.ranks == s.rank) return true;
+    return false;
+}
+
 __device__ __forceinline__ bool in_fast_volume(const f4& h)
 {
     return h.w > 0.0f && (h.w - h.z) >= 0.0f && h.z >= 0.0f &&
@@ -82,14 +99,12 @@ __device__ __forceinline__ bool in_fast_volume(const f4& h)
            (GUARD_BAND * h.w + h.y) >= 0.0f && (GUARD_BAND * h.w - h.y) >= 0.0f;
 }
 
-__device__ __forceinline__ int32_t floor_shift8(int32_t v) { return v >> 8; }   // arithmetic shift == floor
-
 // Per-triangle setup shared by every path.  Edge i is opposite vertex i:
 // E0 = orient(V1,V2,P), E1 = orient(V2,V0,P), E2 = orient(V0,V1,P), times s so the interior is positive.
 struct TriSetup {
     int32_t X[3], Y[3];
     float d0, e1, e2, invA;
-    int32_t px0, py0, px1, py1;       // clamped pixel bbox
+    int32_t px0, py0, px1, py1;       // pixel bbox clamped to the screen
     int64_t area;                     // |2A|
     int32_t s;                        // orientation sign
     uint32_t payload;
@@ -106,171 +121,84 @@ __device__ __forceinline__ bool tri_setup(TriSetup& ts, bool twoSided, int32_t W
     ts.area = area2 < 0 ? -area2 : area2;
     const int32_t minX = min(ts.X[0], min(ts.X[1], ts.X[2])), maxX = max(ts.X[0], max(ts.X[1], ts.X[2]));
     const int32_t minY = min(ts.Y[0], min(ts.Y[1], ts.Y[2])), maxY = max(ts.Y[0], max(ts.Y[1], ts.Y[2]));
-    ts.px0 = max(0, floor_shift8(minX + 127));
-    ts.py0 = max(0, floor_shift8(minY + 127));
-    ts.px1 = min(Wi - 1, floor_shift8(maxX - 128));
-    ts.py1 = min(Hi - 1, floor_shift8(maxY - 128));
+    ts.px0 = max(0, (minX + 127) >> 8);                  // arithmetic shift == floor
+    ts.py0 = max(0, (minY + 127) >> 8);
+    ts.px1 = min(Wi - 1, (maxX - 128) >> 8);
+    ts.py1 = min(Hi - 1, (maxY - 128) >> 8);
     if (ts.px1 < ts.px0 || ts.py1 < ts.py0) return false;
     ts.invA = 1.0f / (float)(double)ts.area;
     return true;
 }
 
-__device__ __forceinline__ void vis_write(unsigned long long* p, float z, uint32_t payload, uint32_t debug = 0)
+__device__ __forceinline__ bool narrow_extent(const TriSetup& ts)
 {
-    const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)payload;
-    if (debug) {
-        if (debug & DBG_NO_PIXELS) return;
-        if (debug & DBG_PLAIN_STORE) { *p = packed; return; }
-    }
-    atomicMax(p, packed);
+    const int32_t extX = max(ts.X[0], max(ts.X[1], ts.X[2])) - min(ts.X[0], min(ts.X[1], ts.X[2]));
+    const int32_t extY = max(ts.Y[0], max(ts.Y[1], ts.Y[2])) - min(ts.Y[0], min(ts.Y[1], ts.Y[2]));
+    return extX <= (1 << 14) && extY <= (1 << 14);       // 32-bit edge functions are exact
 }
 
-// ---- small triangles: one lane scans its own bbox with 32-bit edge functions ------------------
-template <bool SH>
-__device__ __forceinline__ void raster_small(const RasterParams& p, const TriSetup& ts, float d1m0, float d2m0)
+// ---- record + bin emission --------------------------------------------------------------------
+
+// One bin slot per lane, reserved with ONE atomic per distinct tile in the wave: lanes that target the
+// same tile elect a leader, all leaders issue their atomicAdd in a single wave instruction, and the
+// base is handed back through the lanes.  (64 lanes hitting one counter would serialise at the L2.)
+__device__ __forceinline__ uint32_t wave_bin_reserve(uint32_t* tileCount, bool has, uint32_t tile, uint32_t lane)
 {
-    // F_i(P) = s * (dx_i * (P.y - Ya) - dy_i * (P.x - Xa)),  a = dF/dx = -s*dy, b = dF/dy = s*dx
-    const int32_t s = ts.s;
-    const int32_t dx0 = ts.X[2] - ts.X[1], dy0 = ts.Y[2] - ts.Y[1];
-    const int32_t dx1 = ts.X[0] - ts.X[2], dy1 = ts.Y[0] - ts.Y[2];
-    const int32_t dx2 = ts.X[1] - ts.X[0], dy2 = ts.Y[1] - ts.Y[0];
-    const int32_t a0 = -s * dy0, b0 = s * dx0;
-    const int32_t a1 = -s * dy1, b1 = s * dx1;
-    const int32_t a2 = -s * dy2, b2 = s * dx2;
-    const int32_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? 0 : -1;
-    const int32_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 0 : -1;
-    const int32_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 0 : -1;
-    const int32_t cx0 = ts.px0 * 256 + 128, cy0 = ts.py0 * 256 + 128;
-    int32_t r0 = s * (dx0 * (cy0 - ts.Y[1]) - dy0 * (cx0 - ts.X[1]));
-    int32_t r1 = s * (dx1 * (cy0 - ts.Y[2]) - dy1 * (cx0 - ts.X[2]));
-    int32_t r2 = s * (dx2 * (cy0 - ts.Y[0]) - dy2 * (cx0 - ts.X[0]));
-    for (int32_t py = ts.py0; py <= ts.py1; py++) {
-        if (owns_row<SH>(p.shard, py)) {
-            unsigned long long* row = p.vis + row_base<SH>(p.shard, py, p.Wi);
-            int32_t E0 = r0, E1 = r1, E2 = r2;
-            bool entered = false;
-            for (int32_t px = ts.px0; px <= ts.px1; px++) {
-                if (((E0 + bias0) | (E1 + bias1) | (E2 + bias2)) >= 0) {
-                    const float l1 = (float)E1 * ts.invA, l2 = (float)E2 * ts.invA;
-                    const float z = (ts.d0 + l1 * d1m0) + l2 * d2m0;
-                    vis_write(row + px, z, ts.payload, p.debug);
-                    entered = true;
-                } else if (entered) {
-                    break;                       // convex: the span of this row is over
-                }
-                E0 += a0 * 256; E1 += a1 * 256; E2 += a2 * 256;
-            }
+    unsigned long long todo = __ballot(has);
+    int leader = 0;
+    uint32_t rank = 0, group = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        const uint32_t k = bcast(tile, l);
+        const unsigned long long same = __ballot(has && tile == k);
+        if (has && tile == k) { leader = l; rank = (uint32_t)__popcll(same & lt); group = (uint32_t)__popcll(same); }
+        todo &= ~same;
+    }
+    uint32_t base = 0;
+    if (has && (int)lane == leader) base = atomicAdd(&tileCount[(size_t)tile * TC_STRIDE], group);
+    base = __shfl(base, leader, 64);
+    return base + rank;
+}
+
+// Bins a record whose clamped bbox touches at most 2x2 tiles (all lanes of the wave call this).
+__device__ __forceinline__ void wave_bin_small(const RasterParams& p, bool emit, const TriSetup& ts, uint32_t gi, uint32_t lane)
+{
+    const int32_t tx0 = ts.px0 >> TILE_SHIFT, tx1 = ts.px1 >> TILE_SHIFT;
+    const int32_t ty0 = ts.py0 >> TILE_SHIFT, ty1 = ts.py1 >> TILE_SHIFT;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int32_t tx = (r & 1) ? tx1 : tx0, ty = (r & 2) ? ty1 : ty0;
+        bool has = emit && !((r & 1) && tx1 == tx0) && !((r & 2) && ty1 == ty0);
+        if (has) has = owns_any_row(p.shard, max(ts.py0, ty << TILE_SHIFT), min(ts.py1, (ty << TILE_SHIFT) + TILE - 1));
+        if (!__ballot(has)) continue;
+        const uint32_t tile = has ? (uint32_t)ty * p.tilesX + (uint32_t)tx : 0u;
+        const uint32_t slot = wave_bin_reserve(p.tileCount, has, tile, lane);
+        if (has) {
+            if (slot < p.binCap) p.tileBins[(size_t)tile * p.binCap + slot] = gi;
+            else atomicOr(&p.counters->overflow, 1u);
         }
-        r0 += b0 * 256; r1 += b1 * 256; r2 += b2 * 256;
     }
 }
 
-// ---- cooperative 8x8 tile scan (64-bit edge functions) ---------------------------------------
-struct WideEdges {
-    int64_t a[3], b[3];     // dF/dx, dF/dy per subpixel unit
-    int64_t bias[3];
-    int64_t dx[3], dy[3];
-    int32_t Xa[3], Ya[3];
-    int32_t s;
-};
-
-__device__ __forceinline__ void wide_edges(const TriSetup& ts, WideEdges& w)
+__device__ __forceinline__ bool touches_many_tiles(const TriSetup& ts)
 {
-    const int ea[3] = {1, 2, 0}, eb[3] = {2, 0, 1};
-    w.s = ts.s;
+    return ((ts.px1 >> TILE_SHIFT) - (ts.px0 >> TILE_SHIFT)) > 1 || ((ts.py1 >> TILE_SHIFT) - (ts.py0 >> TILE_SHIFT)) > 1;
+}
+
+__device__ __forceinline__ void write_record(TriRec* dst, const TriSetup& ts, const float d[3], bool twoSided)
+{
+    TriRec r;
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        w.dx[i] = (int64_t)(ts.X[eb[i]] - ts.X[ea[i]]);
-        w.dy[i] = (int64_t)(ts.Y[eb[i]] - ts.Y[ea[i]]);
-        w.Xa[i] = ts.X[ea[i]]; w.Ya[i] = ts.Y[ea[i]];
-        w.a[i] = -(int64_t)ts.s * w.dy[i];
-        w.b[i] = (int64_t)ts.s * w.dx[i];
-        w.bias[i] = (w.a[i] > 0 || (w.a[i] == 0 && w.b[i] > 0)) ? 0 : -1;
-    }
+    for (int i = 0; i < 3; i++) { r.X[i] = ts.X[i]; r.Y[i] = ts.Y[i]; r.d[i] = d[i]; }
+    r.payload = ts.payload; r.twoSided = twoSided ? 1u : 0u; r.pad = 0;
+    *dst = r;
 }
 
-__device__ __forceinline__ int64_t edge_at(const WideEdges& w, int i, int32_t px, int32_t py)
-{
-    const int64_t cx = (int64_t)px * 256 + 128, cy = (int64_t)py * 256 + 128;
-    return (int64_t)w.s * (w.dx[i] * (cy - w.Ya[i]) - w.dy[i] * (cx - w.Xa[i]));
-}
+// ---- the per-cluster setup kernel -------------------------------------------------------------
+enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
 
-// All 64 lanes: lane (lx, ly) handles pixel (tileX + lx, tileY + ly).
-template <bool SH>
-__device__ __forceinline__ void raster_tile(const RasterParams& p, const TriSetup& ts, const WideEdges& w,
-                                            float d1m0, float d2m0, int32_t tileX, int32_t tileY, uint32_t lane)
-{
-    const int32_t px = tileX + (int32_t)(lane & 7u), py = tileY + (int32_t)(lane >> 3);
-    if (px < ts.px0 || px > ts.px1 || py < ts.py0 || py > ts.py1) return;
-    if (!owns_row<SH>(p.shard, py)) return;
-    const int64_t E0 = edge_at(w, 0, px, py), E1 = edge_at(w, 1, px, py), E2 = edge_at(w, 2, px, py);
-    if (((E0 + w.bias[0]) | (E1 + w.bias[1]) | (E2 + w.bias[2])) < 0) return;
-    const float l1 = (float)(double)E1 * ts.invA, l2 = (float)(double)E2 * ts.invA;
-    const float z = (ts.d0 + l1 * d1m0) + l2 * d2m0;
-    unsigned long long* dst = p.vis + row_base<SH>(p.shard, py, p.Wi) + px;
-    const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)ts.payload;
-    if (p.debug) {
-        if (p.debug & DBG_NO_PIXELS) return;
-        if (p.debug & DBG_PLAIN_STORE) { *dst = packed; return; }
-        if (p.debug & DBG_NO_EARLYZ) { atomicMax(dst, packed); return; }
-    }
-    if (packed > *dst) atomicMax(dst, packed);        // stale read only costs a redundant atomic
-}
-
-// conservative: does the 8x8 tile at (tileX, tileY) touch the triangle (and its clamped bbox)?
-__device__ __forceinline__ bool tile_overlaps(const TriSetup& ts, const WideEdges& w, int32_t tileX, int32_t tileY)
-{
-    if (tileX > ts.px1 || tileX + 7 < ts.px0 || tileY > ts.py1 || tileY + 7 < ts.py0) return false;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int32_t cxp = w.a[i] > 0 ? tileX + 7 : tileX;
-        const int32_t cyp = w.b[i] > 0 ? tileY + 7 : tileY;
-        if (edge_at(w, i, cxp, cyp) + w.bias[i] < 0) return false;
-    }
-    return true;
-}
-
-// ---- deferred lists ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t chunk_count(const TriSetup& ts)
-{
-    return (uint32_t)(((ts.px1 >> 6) - (ts.px0 >> 6) + 1) * ((ts.py1 >> 6) - (ts.py0 >> 6) + 1));
-}
-
-__device__ __forceinline__ void write_big(const RasterParams& p, uint32_t shard, uint32_t ti, uint32_t ci,
-                                          const TriSetup& ts, const float d[3], bool twoSided)
-{
-    const uint32_t n = chunk_count(ts);
-    if (ti >= p.bigTriCap || ci + n > p.bigChunkCap) { atomicOr(&p.counters->overflow, 1u); return; }
-    const uint32_t gti = shard * p.bigTriCap + ti;
-    BigTri bt;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { bt.X[i] = ts.X[i]; bt.Y[i] = ts.Y[i]; bt.d[i] = d[i]; }
-    bt.payload = ts.payload; bt.twoSided = twoSided ? 1u : 0u; bt.pad = 0;
-    p.bigTris[gti] = bt;
-    BigChunk* dst = p.bigChunks + (size_t)shard * p.bigChunkCap + ci;
-    const int32_t cx0 = ts.px0 >> 6, cx1 = ts.px1 >> 6, cy0 = ts.py0 >> 6, cy1 = ts.py1 >> 6;
-    for (int32_t cy = cy0; cy <= cy1; cy++)
-        for (int32_t cx = cx0; cx <= cx1; cx++) {
-            BigChunk bc; bc.tri = gti; bc.cxy = (uint32_t)cx | ((uint32_t)cy << 16);
-            *dst++ = bc;
-        }
-}
-
-// one lane on its own (clip kernel, rare)
-__device__ __forceinline__ void emit_big_single(const RasterParams& p, uint32_t shard, const TriSetup& ts,
-                                                const float d[3], bool twoSided)
-{
-    const uint32_t ti = atomicAdd(&p.counters->bigTriCount[shard], 1u);
-    const uint32_t ci = atomicAdd(&p.counters->bigChunkCount[shard], chunk_count(ts));
-    write_big(p, shard, ti, ci, ts, d, twoSided);
-}
-
-// ---- the per-cluster kernel -------------------------------------------------------------------
-enum { K_NONE = 0, K_SMALL = 1, K_BIG = 3, K_CLIP = 4 };
-#define SMALL_MAX 16     // per-lane scan up to 16x16 pixels; larger triangles go to the chunk kernel
-
-template <bool SH>
-__global__ __launch_bounds__(256) void raster_cluster_kernel(RasterParams p)
+__global__ __launch_bounds__(256) void raster_setup_kernel(RasterParams p)
 {
     __shared__ float sX[4][LDS_VERTS], sY[4][LDS_VERTS], sW[4][LDS_VERTS];
     __shared__ float sU[4][LDS_VERTS], sV[4][LDS_VERTS], sD[4][LDS_VERTS];
@@ -353,27 +281,18 @@ __global__ __launch_bounds__(256) void raster_cluster_kernel(RasterParams p)
                         ts.X[0] = (int32_t)rintf((u0 * p.W) * 256.0f); ts.Y[0] = (int32_t)rintf((v0 * p.H) * 256.0f);
                         ts.X[1] = (int32_t)rintf((u1 * p.W) * 256.0f); ts.Y[1] = (int32_t)rintf((v1 * p.H) * 256.0f);
                         ts.X[2] = (int32_t)rintf((u2 * p.W) * 256.0f); ts.Y[2] = (int32_t)rintf((v2 * p.H) * 256.0f);
-                        if (tri_setup(ts, twoSided, p.Wi, p.Hi)) {
-                            ts.d0 = d[0]; ts.e1 = d[1] - d[0]; ts.e2 = d[2] - d[0];
-                            const int32_t bw = ts.px1 - ts.px0 + 1, bh = ts.py1 - ts.py0 + 1;
-                            const int32_t extX = max(ts.X[0], max(ts.X[1], ts.X[2])) - min(ts.X[0], min(ts.X[1], ts.X[2]));
-                            const int32_t extY = max(ts.Y[0], max(ts.Y[1], ts.Y[2])) - min(ts.Y[0], min(ts.Y[1], ts.Y[2]));
-                            const bool narrow = extX <= (1 << 14) && extY <= (1 << 14);   // 32-bit edge functions are exact
-                            if (bw <= SMALL_MAX && bh <= SMALL_MAX && narrow) kind = K_SMALL;
-                            else kind = K_BIG;
-                        }
+                        if (tri_setup(ts, twoSided, p.Wi, p.Hi) && owns_any_row(p.shard, ts.py0, ts.py1)) kind = K_EMIT;
                     }
                 }
             }
-
-            if (kind == K_SMALL) raster_small<SH>(p, ts, ts.e1, ts.e2);
+            if (p.debug & DBG_NO_BIN) kind = K_NONE;
 
             // clip list: wave-aggregated append
             {
                 const unsigned long long cm = __ballot(kind == K_CLIP);
                 if (cm) {
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&p.counters->clipTriCount, (uint32_t)__popcll(cm));
+                    if (lane == 0) base = atomicAdd(&p.counters->clipTriCount[p.pass], (uint32_t)__popcll(cm));
                     base = bcast(base, 0);
                     if (kind == K_CLIP) {
                         const uint32_t k = base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
@@ -382,21 +301,39 @@ __global__ __launch_bounds__(256) void raster_cluster_kernel(RasterParams p)
                     }
                 }
             }
-            // big list: one reservation per wave per sub-list (wave-aggregated)
+            // triangle records: one reservation per wave, contiguous 48-byte records, then the bins
             {
-                const unsigned long long bm = __ballot(kind == K_BIG);
-                if (bm) {
-                    const uint32_t n = kind == K_BIG ? chunk_count(ts) : 0u;
-                    const uint32_t incl = wave_incl_scan_u32(n, lane);
-                    const uint32_t total = bcast(incl, 63);
-                    uint32_t tbase = 0, cbase = 0;
-                    if (lane == 0) {
-                        tbase = atomicAdd(&p.counters->bigTriCount[listShard], (uint32_t)__popcll(bm));
-                        cbase = atomicAdd(&p.counters->bigChunkCount[listShard], total);
+                const unsigned long long em = __ballot(kind == K_EMIT);
+                if (em) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&p.counters->triCount[listShard], (uint32_t)__popcll(em));
+                    base = bcast(base, 0);
+                    uint32_t gi = 0;
+                    bool ok = false;
+                    if (kind == K_EMIT) {
+                        const uint32_t li = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+                        if (li < p.triCap) {
+                            gi = listShard * p.triCap + li;
+                            write_record(&p.tris[gi], ts, d, twoSided);
+                            ok = true;
+                        } else {
+                            atomicOr(&p.counters->overflow, 1u);
+                        }
                     }
-                    tbase = bcast(tbase, 0); cbase = bcast(cbase, 0);
-                    if (kind == K_BIG && !(p.debug & DBG_NO_BIG))
-                        write_big(p, listShard, tbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull)), cbase + incl - n, ts, d, twoSided);
+                    // <= 2x2 tiles: straight into the bins; more: the large list (one reservation per wave)
+                    const bool large = ok && touches_many_tiles(ts);
+                    wave_bin_small(p, ok && !large, ts, gi, lane);
+                    const unsigned long long lm = __ballot(large);
+                    if (lm) {
+                        uint32_t lbase = 0;
+                        if (lane == 0) lbase = atomicAdd(&p.counters->largeCount[p.pass], (uint32_t)__popcll(lm));
+                        lbase = bcast(lbase, 0);
+                        if (large) {
+                            const uint32_t k = lbase + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull));
+                            if (k < p.largeCap) p.largeList[k] = gi;
+                            else atomicOr(&p.counters->overflow, 1u);
+                        }
+                    }
                 }
             }
         }
@@ -430,28 +367,10 @@ __device__ __forceinline__ f4 clip_intersect(const f4& in, const f4& out, float 
     return r;
 }
 
-template <bool SH>
-__device__ void raster_serial_wide(const RasterParams& p, const TriSetup& ts)
-{
-    WideEdges w;
-    wide_edges(ts, w);
-    for (int32_t py = ts.py0; py <= ts.py1; py++) {
-        if (!owns_row<SH>(p.shard, py)) continue;
-        unsigned long long* row = p.vis + row_base<SH>(p.shard, py, p.Wi);
-        for (int32_t px = ts.px0; px <= ts.px1; px++) {
-            const int64_t E0 = edge_at(w, 0, px, py), E1 = edge_at(w, 1, px, py), E2 = edge_at(w, 2, px, py);
-            if (((E0 + w.bias[0]) | (E1 + w.bias[1]) | (E2 + w.bias[2])) < 0) continue;
-            const float l1 = (float)(double)E1 * ts.invA, l2 = (float)(double)E2 * ts.invA;
-            const float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
-            vis_write(row + px, z, ts.payload);
-        }
-    }
-}
-
-template <bool SH>
 __global__ __launch_bounds__(256) void raster_clip_kernel(RasterParams p)
 {
-    const uint32_t n = min(p.counters->clipTriCount, p.clipTriCap);
+    const uint32_t n = min(p.counters->clipTriCount[p.pass], p.clipTriCap);
+    const uint32_t listShard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % CHORD_LIST_SHARDS;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
         const ClipTri ct = p.clipTris[k];
         const ChordDrawCmd cmd = p.cmds[ct.cmdIndex];
@@ -502,55 +421,280 @@ __global__ __launch_bounds__(256) void raster_clip_kernel(RasterParams p)
             ts.Y[0] = PY[0]; ts.Y[1] = PY[i]; ts.Y[2] = PY[i + 1];
             const float d[3] = {PD[0], PD[i], PD[i + 1]};
             ts.payload = payload;
-            if (!tri_setup(ts, twoSided, p.Wi, p.Hi)) continue;
-            ts.d0 = d[0]; ts.e1 = d[1] - d[0]; ts.e2 = d[2] - d[0];
-            const int32_t bw = ts.px1 - ts.px0 + 1, bh = ts.py1 - ts.py0 + 1;
-            if (bw <= 16 && bh <= 16) raster_serial_wide<SH>(p, ts);
-            else emit_big_single(p, (blockIdx.x * 4u + (threadIdx.x >> 6)) % CHORD_LIST_SHARDS, ts, d, twoSided);
+            if (!tri_setup(ts, twoSided, p.Wi, p.Hi) || !owns_any_row(p.shard, ts.py0, ts.py1)) continue;
+            const uint32_t li = atomicAdd(&p.counters->triCount[listShard], 1u);
+            if (li >= p.triCap) { atomicOr(&p.counters->overflow, 1u); continue; }
+            const uint32_t gi = listShard * p.triCap + li;
+            write_record(&p.tris[gi], ts, d, twoSided);
+            // clipped pieces are rare and usually large: always through the large list
+            const uint32_t k2 = atomicAdd(&p.counters->largeCount[p.pass], 1u);
+            if (k2 < p.largeCap) p.largeList[k2] = gi;
+            else atomicOr(&p.counters->overflow, 1u);
         }
     }
 }
 
-// ---- big-triangle chunk kernel ----------------------------------------------------------------
-template <bool SH>
-__global__ __launch_bounds__(256) void raster_chunk_kernel(RasterParams p)
+// ---- large triangles: one wave per record, one lane per candidate tile -------------------------
+__global__ __launch_bounds__(256) void raster_bin_large_kernel(RasterParams p)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // lane s holds sub-list s: inclusive prefix of the 64 chunk counts
-    const uint32_t mine = min(p.counters->bigChunkCount[lane], p.bigChunkCap);
-    const uint32_t incl = wave_incl_scan_u32(mine, lane);
-    const uint32_t n = bcast(incl, 63);
+    const uint32_t n = min(p.counters->largeCount[p.pass], p.largeCap);
     for (uint32_t k = blockIdx.x * 4u + wave; k < n; k += gridDim.x * 4u) {
-        const uint32_t ku = __builtin_amdgcn_readfirstlane(k);
-        const uint32_t shard = (uint32_t)__popcll(__ballot(incl <= ku));          // first sub-list with incl > k
-        const uint32_t local = ku - (bcast(incl, (int)shard) - bcast(mine, (int)shard));
-        const BigChunk bc = p.bigChunks[(size_t)shard * p.bigChunkCap + local];
-        const uint32_t triIdx = __builtin_amdgcn_readfirstlane(bc.tri);
-        const uint32_t cxy = __builtin_amdgcn_readfirstlane(bc.cxy);
-        const BigTri* __restrict__ bt = &p.bigTris[triIdx];
+        const uint32_t gi = __builtin_amdgcn_readfirstlane(p.largeList[__builtin_amdgcn_readfirstlane(k)]);
+        const TriRec* __restrict__ r = &p.tris[gi];
         TriSetup ts;
 #pragma unroll
-        for (int i = 0; i < 3; i++) { ts.X[i] = bt->X[i]; ts.Y[i] = bt->Y[i]; }
-        ts.payload = bt->payload;
-        const bool twoSided = bt->twoSided != 0;
-        if (!tri_setup(ts, twoSided, p.Wi, p.Hi)) continue;
-        ts.d0 = bt->d[0]; ts.e1 = bt->d[1] - bt->d[0]; ts.e2 = bt->d[2] - bt->d[0];
-        WideEdges we;
-        wide_edges(ts, we);
-        const int32_t ox = (int32_t)(cxy & 0xFFFFu) * 64, oy = (int32_t)(cxy >> 16) * 64;
-        // 64 lanes classify the chunk's 64 tiles
-        const int32_t tX = ox + (int32_t)(lane & 7u) * 8, tY = oy + (int32_t)(lane >> 3) * 8;
-        unsigned long long tm = __ballot(tile_overlaps(ts, we, tX, tY));
-        while (tm) {
-            const int tile = __ffsll((long long)tm) - 1;
-            tm &= tm - 1ull;
-            raster_tile<SH>(p, ts, we, ts.e1, ts.e2, ox + (tile & 7) * 8, oy + (tile >> 3) * 8, lane);
+        for (int i = 0; i < 3; i++) { ts.X[i] = r->X[i]; ts.Y[i] = r->Y[i]; }
+        ts.payload = 0;
+        if (!tri_setup(ts, r->twoSided != 0, p.Wi, p.Hi)) continue;
+        const int ea[3] = {1, 2, 0}, eb[3] = {2, 0, 1};
+        int64_t a[3], b[3], bias[3], dxe[3], dye[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            dxe[i] = (int64_t)(ts.X[eb[i]] - ts.X[ea[i]]); dye[i] = (int64_t)(ts.Y[eb[i]] - ts.Y[ea[i]]);
+            a[i] = -(int64_t)ts.s * dye[i]; b[i] = (int64_t)ts.s * dxe[i];
+            bias[i] = (a[i] > 0 || (a[i] == 0 && b[i] > 0)) ? 0 : -1;
+        }
+        const int32_t tx0 = ts.px0 >> TILE_SHIFT, tx1 = ts.px1 >> TILE_SHIFT;
+        const int32_t ty0 = ts.py0 >> TILE_SHIFT, ty1 = ts.py1 >> TILE_SHIFT;
+        const uint32_t tw = (uint32_t)(tx1 - tx0 + 1), nt = tw * (uint32_t)(ty1 - ty0 + 1);
+        for (uint32_t tb = 0; tb < nt; tb += 64u) {
+            const uint32_t t = tb + lane;
+            if (t >= nt) continue;
+            const int32_t tx = tx0 + (int32_t)(t % tw), ty = ty0 + (int32_t)(t / tw);
+            // pixel rectangle of this tile clipped to the triangle's bbox; conservative edge test at its corners
+            const int32_t rx0 = max(ts.px0, tx << TILE_SHIFT), rx1 = min(ts.px1, (tx << TILE_SHIFT) + TILE - 1);
+            const int32_t ry0 = max(ts.py0, ty << TILE_SHIFT), ry1 = min(ts.py1, (ty << TILE_SHIFT) + TILE - 1);
+            bool hit = owns_any_row(p.shard, ry0, ry1);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int64_t cx = (int64_t)(a[i] > 0 ? rx1 : rx0) * 256 + 128, cy = (int64_t)(b[i] > 0 ? ry1 : ry0) * 256 + 128;
+                const int64_t E = (int64_t)ts.s * (dxe[i] * (cy - ts.Y[ea[i]]) - dye[i] * (cx - ts.X[ea[i]]));
+                hit = hit && !(E + bias[i] < 0);
+            }
+            if (hit) {
+                const uint32_t tile = (uint32_t)ty * p.tilesX + (uint32_t)tx;
+                const uint32_t slot = atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE], 1u);   // distinct tiles per lane
+                if (slot < p.binCap) p.tileBins[(size_t)tile * p.binCap + slot] = gi;
+                else atomicOr(&p.counters->overflow, 1u);
+            }
         }
     }
+}
+
+// ---- per-tile resolve kernel ------------------------------------------------------------------
+
+struct WideEdges {
+    int64_t a[3], b[3], bias[3], dx[3], dy[3];
+    int32_t Xa[3], Ya[3];
+    int32_t s;
+};
+
+__device__ __forceinline__ void wide_edges(const TriSetup& ts, WideEdges& w)
+{
+    const int ea[3] = {1, 2, 0}, eb[3] = {2, 0, 1};
+    w.s = ts.s;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        w.dx[i] = (int64_t)(ts.X[eb[i]] - ts.X[ea[i]]);
+        w.dy[i] = (int64_t)(ts.Y[eb[i]] - ts.Y[ea[i]]);
+        w.Xa[i] = ts.X[ea[i]]; w.Ya[i] = ts.Y[ea[i]];
+        w.a[i] = -(int64_t)ts.s * w.dy[i];
+        w.b[i] = (int64_t)ts.s * w.dx[i];
+        w.bias[i] = (w.a[i] > 0 || (w.a[i] == 0 && w.b[i] > 0)) ? 0 : -1;
+    }
+}
+
+__device__ __forceinline__ int64_t edge_at(const WideEdges& w, int i, int32_t px, int32_t py)
+{
+    const int64_t cx = (int64_t)px * 256 + 128, cy = (int64_t)py * 256 + 128;
+    return (int64_t)w.s * (w.dx[i] * (cy - w.Ya[i]) - w.dy[i] * (cx - w.Xa[i]));
+}
+
+__device__ __forceinline__ void lds_write(unsigned long long* tile, int32_t lx, int32_t ly, float z, uint32_t payload)
+{
+    const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)payload;
+    atomicMax(&tile[ly * TILE + lx], packed);              // ds_max_u64
+}
+
+// one lane scans its own (tile-clipped) bbox with 32-bit edge functions
+__device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
+                                                   int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels,
+                                                   unsigned long long rowMask)
+{
+    const int32_t s = ts.s;
+    const int32_t dx0 = ts.X[2] - ts.X[1], dy0 = ts.Y[2] - ts.Y[1];
+    const int32_t dx1 = ts.X[0] - ts.X[2], dy1 = ts.Y[0] - ts.Y[2];
+    const int32_t dx2 = ts.X[1] - ts.X[0], dy2 = ts.Y[1] - ts.Y[0];
+    const int32_t a0 = -s * dy0, b0 = s * dx0;
+    const int32_t a1 = -s * dy1, b1 = s * dx1;
+    const int32_t a2 = -s * dy2, b2 = s * dx2;
+    const int32_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? 0 : -1;
+    const int32_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 0 : -1;
+    const int32_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 0 : -1;
+    const int32_t cx0 = x0 * 256 + 128, cy0 = y0 * 256 + 128;
+    int32_t r0 = s * (dx0 * (cy0 - ts.Y[1]) - dy0 * (cx0 - ts.X[1]));
+    int32_t r1 = s * (dx1 * (cy0 - ts.Y[2]) - dy1 * (cx0 - ts.X[2]));
+    int32_t r2 = s * (dx2 * (cy0 - ts.Y[0]) - dy2 * (cx0 - ts.X[0]));
+    for (int32_t py = y0; py <= y1; py++) {
+        int32_t E0 = r0, E1 = r1, E2 = r2;
+        bool entered = false;
+        for (int32_t px = x0; px <= x1 && ((rowMask >> (py - oy)) & 1ull); px++) {
+            if (((E0 + bias0) | (E1 + bias1) | (E2 + bias2)) >= 0) {
+                const float l1 = (float)E1 * ts.invA, l2 = (float)E2 * ts.invA;
+                const float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
+                if (!noPixels) lds_write(tile, px - ox, py - oy, z, ts.payload);
+                entered = true;
+            } else if (entered) {
+                break;                                   // convex: the span of this row is over
+            }
+            E0 += a0 * 256; E1 += a1 * 256; E2 += a2 * 256;
+        }
+        r0 += b0 * 256; r1 += b1 * 256; r2 += b2 * 256;
+    }
+}
+
+// The whole wave scans one larger triangle inside the tile, one pixel ROW per lane (a 64x64 tile has 64
+// rows): every lane walks its row from the bbox's left edge with incremental edge functions — no
+// multiplies in the loop — and the wave leaves as soon as no lane can still enter its span.
+// WIDE = 64-bit edge functions (vertices more than 64 px apart); otherwise 32-bit is exact.
+template <bool WIDE>
+__device__ __forceinline__ void tile_raster_rows(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
+                                                 int32_t x0, int32_t y0, int32_t x1, int32_t y1, uint32_t lane, bool noPixels,
+                                                 unsigned long long rowMask)
+{
+    using E_t = typename std::conditional<WIDE, int64_t, int32_t>::type;
+    const int32_t py = oy + (int32_t)lane;
+    const bool rowActive = py >= y0 && py <= y1 && ((rowMask >> lane) & 1ull);
+    const E_t s = (E_t)ts.s;
+    const E_t dx0 = (E_t)(ts.X[2] - ts.X[1]), dy0 = (E_t)(ts.Y[2] - ts.Y[1]);
+    const E_t dx1 = (E_t)(ts.X[0] - ts.X[2]), dy1 = (E_t)(ts.Y[0] - ts.Y[2]);
+    const E_t dx2 = (E_t)(ts.X[1] - ts.X[0]), dy2 = (E_t)(ts.Y[1] - ts.Y[0]);
+    const E_t a0 = -s * dy0, b0 = s * dx0, a1 = -s * dy1, b1 = s * dx1, a2 = -s * dy2, b2 = s * dx2;
+    const E_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? 0 : -1;
+    const E_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 0 : -1;
+    const E_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 0 : -1;
+    const E_t cx = (E_t)x0 * 256 + 128, cy = (E_t)py * 256 + 128;
+    E_t E0 = s * (dx0 * (cy - ts.Y[1]) - dy0 * (cx - ts.X[1]));
+    E_t E1 = s * (dx1 * (cy - ts.Y[2]) - dy1 * (cx - ts.X[2]));
+    E_t E2 = s * (dx2 * (cy - ts.Y[0]) - dy2 * (cx - ts.X[0]));
+    const E_t st0 = a0 * 256, st1 = a1 * 256, st2 = a2 * 256;
+    unsigned long long* row = tile + lane * TILE - ox;
+    bool entered = false, done = !rowActive;
+    for (int32_t px = x0; px <= x1; px++) {
+        if (!done) {
+            if (((E0 + bias0) | (E1 + bias1) | (E2 + bias2)) >= 0) {
+                const float l1 = WIDE ? (float)(double)E1 * ts.invA : (float)(int32_t)E1 * ts.invA;
+                const float l2 = WIDE ? (float)(double)E2 * ts.invA : (float)(int32_t)E2 * ts.invA;
+                const float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
+                if (!noPixels) {
+                    const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)ts.payload;
+                    atomicMax(&row[px], packed);
+                }
+                entered = true;
+            } else if (entered) {
+                done = true;                             // convex: this row's span is over
+            }
+            E0 += st0; E1 += st1; E2 += st2;
+        }
+        if (__ballot(!done) == 0ull) break;
+    }
+}
+
+template <bool SH>
+__global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
+{
+    __shared__ unsigned long long tile[TILE * TILE];             // 32 KB
+    const uint32_t tileId = blockIdx.x;
+    const uint32_t n = min(p.tileCount[(size_t)tileId * TC_STRIDE], p.binCap);
+    const unsigned long long t0 = (p.debug & DBG_TILE_CLOCKS) ? wall_clock64() : 0ull;
+    if (n == 0 && !p.clearTiles) return;                          // untouched tile: global words stay as they are
+    const uint32_t lane = threadIdx.x & 63u;
+    const int32_t ox = (int32_t)(tileId % p.tilesX) * TILE, oy = (int32_t)(tileId / p.tilesX) * TILE;
+    const int32_t tw = min(TILE, p.Wi - ox), th = min(TILE, p.Hi - oy);
+    const bool noPixels = (p.debug & DBG_NO_PIXELS) != 0;
+    // bit ly set <=> this rank owns pixel row oy + ly (all ones when not sharded)
+    unsigned long long rowMask = ~0ull;
+    if (SH) {
+        rowMask = 0ull;
+        for (int32_t ly = 0; ly < th; ly++) if (owns_row<SH>(p.shard, oy + ly)) rowMask |= 1ull << ly;
+        if (rowMask == 0ull) return;                             // nothing of this tile belongs to the rank
+    }
+
+    // ---- tile in: zeros on the first pass of a frame, else the current words (16 B per lane) ---
+    for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += 256u) {
+        const int32_t ly = (int32_t)(i >> 5), lx = (int32_t)(i & 31u) * 2;
+        ulonglong2 v = make_ulonglong2(0ull, 0ull);
+        if (!p.clearTiles && ly < th && lx < tw && owns_row<SH>(p.shard, oy + ly)) {
+            const unsigned long long* src = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
+            if (lx + 1 < tw) v = *reinterpret_cast<const ulonglong2*>(src);
+            else v.x = src[0];
+        }
+        *reinterpret_cast<ulonglong2*>(&tile[ly * TILE + lx]) = v;
+    }
+    __syncthreads();
+
+    // ---- scan-convert the bin ------------------------------------------------------------------
+    const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
+    for (uint32_t base = 0; base < n; base += 256u) {
+        const uint32_t k = base + threadIdx.x;
+        bool big = false, wide = false;
+        TriSetup ts;
+        ts.s = 1; ts.invA = 0.0f; ts.d0 = ts.e1 = ts.e2 = 0.0f; ts.payload = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { ts.X[i] = 0; ts.Y[i] = 0; }
+        int32_t x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+        if (k < n) {
+            const TriRec* __restrict__ r = &p.tris[bin[k]];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { ts.X[i] = r->X[i]; ts.Y[i] = r->Y[i]; }
+            ts.payload = r->payload;
+            const float d0 = r->d[0], d1 = r->d[1], d2 = r->d[2];
+            if (tri_setup(ts, r->twoSided != 0, p.Wi, p.Hi)) {
+                ts.d0 = d0; ts.e1 = d1 - d0; ts.e2 = d2 - d0;
+                x0 = max(ts.px0, ox); y0 = max(ts.py0, oy);
+                x1 = min(ts.px1, ox + tw - 1); y1 = min(ts.py1, oy + th - 1);
+                if (x1 >= x0 && y1 >= y0) {
+                    const int32_t area = (x1 - x0 + 1) * (y1 - y0 + 1);
+                    wide = !narrow_extent(ts);
+                    if (area > SMALL_AREA || wide) big = true;
+                    else tile_raster_narrow(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask);
+                }
+            }
+        }
+        // large ones: each wave walks its own
+        unsigned long long bm = __ballot(big);
+        while (bm) {
+            const int src = __ffsll((long long)bm) - 1;
+            bm &= bm - 1ull;
+            TriSetup bs;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { bs.X[i] = bcast(ts.X[i], src); bs.Y[i] = bcast(ts.Y[i], src); }
+            bs.d0 = bcast(ts.d0, src); bs.e1 = bcast(ts.e1, src); bs.e2 = bcast(ts.e2, src);
+            bs.payload = bcast(ts.payload, src);
+            bs.s = bcast(ts.s, src); bs.invA = bcast(ts.invA, src);
+            const int32_t bx0 = bcast(x0, src), by0 = bcast(y0, src), bx1 = bcast(x1, src), by1 = bcast(y1, src);
+            const bool bwide = bcast((uint32_t)wide, src) != 0u;
+            if (bwide) tile_raster_rows<true>(tile, bs, ox, oy, bx0, by0, bx1, by1, lane, noPixels, rowMask);
+            else       tile_raster_rows<false>(tile, bs, ox, oy, bx0, by0, bx1, by1, lane, noPixels, rowMask);
+        }
+    }
+    __syncthreads();
+
+    // ---- tile out: 16-byte coalesced stores (owned rows only when sharded) ---------------------
+    for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += 256u) {
+        const int32_t ly = (int32_t)(i >> 5), lx = (int32_t)(i & 31u) * 2;
+        if (ly >= th || lx >= tw || !owns_row<SH>(p.shard, oy + ly)) continue;
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&tile[ly * TILE + lx]);
+        unsigned long long* dst = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
+        if (lx + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = v;
+        else dst[0] = v.x;
+    }
+    if ((p.debug & DBG_TILE_CLOCKS) && threadIdx.x == 0) p.tileClocks[tileId] = wall_clock64() - t0;
 }
 
 // ---- launcher ---------------------------------------------------------------------------------
-void launch_raster(ChordCtx* c, const CmdList& in)
+void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
 {
     RasterParams p;
     p.count = in.count; p.cmds = in.cmds;
@@ -559,31 +703,42 @@ void launch_raster(ChordCtx* c, const CmdList& in)
     p.vis = (unsigned long long*)c->dVis;
     p.W = (float)c->width; p.H = (float)c->height; p.Wi = (int32_t)c->width; p.Hi = (int32_t)c->height;
     p.shard = c->shard;
-    p.bigTris = c->dBigTris; p.bigChunks = c->dBigChunks; p.clipTris = c->dClipTris;
-    p.bigTriCap = c->bigTriCap / CHORD_LIST_SHARDS; p.bigChunkCap = c->bigChunkCap / CHORD_LIST_SHARDS; p.clipTriCap = c->clipTriCap;
+    p.tris = c->dTris; p.triCap = c->triCap / CHORD_LIST_SHARDS;
+    const uint32_t tiles = c->tilesX * c->tilesY;
+    const uint32_t pass = c->rasterCalls & 1u;
+    p.tileCount = c->dFrameState->tileCount[pass];
+    p.tileBins = c->dTileBins + (size_t)pass * tiles * c->binCap; p.binCap = c->binCap;
+    p.tilesX = c->tilesX; p.tilesY = c->tilesY;
+    p.clipTris = c->dClipTris + (size_t)pass * (c->clipTriCap / 2); p.clipTriCap = c->clipTriCap / 2; p.pass = pass;
+    p.largeList = c->dLargeList + (size_t)pass * (c->largeCap / 2); p.largeCap = c->largeCap / 2;
     p.counters = c->dCounters;
+    p.clearTiles = clearTiles ? 1u : 0u;
     p.debug = c->debugFlags;
+    p.tileClocks = c->dTileClocks + (size_t)pass * CHORD_MAX_TILES;
 
-    // reset the deferred-list counts (leading bytes of DeviceCounters)
-    (void)hipMemsetAsync(c->dCounters, 0, CHORD_COUNTERS_RESET_BYTES, c->stream);
+    // A frame zeroes every count once (begin_frame_clear); outside a frame, or from the third raster
+    // call of a frame on, the pass slot is recycled here.
+    if (!c->inFrame || c->rasterCalls >= 2) {
+        (void)hipMemsetAsync(p.tileCount, 0, sizeof(uint32_t) * TC_STRIDE * tiles, c->stream);
+        (void)hipMemsetAsync(&c->dCounters->clipTriCount[pass], 0, sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(&c->dCounters->largeCount[pass], 0, sizeof(uint32_t), c->stream);
+        if (!c->inFrame) (void)hipMemsetAsync(c->dCounters->triCount, 0, sizeof(uint32_t) * CHORD_LIST_SHARDS, c->stream);
+    }
 
     uint32_t blocks = (in.capacity + 3u) / 4u;
     const uint32_t maxBlocks = (uint32_t)c->numCUs * 6u;
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
-    const uint32_t chunkBlocks = (uint32_t)c->numCUs * 8u;
     const uint32_t clipBlocks = (uint32_t)c->numCUs;
-    // optional GPU timestamps after each of the three kernels
     const bool sh = c->shard.ranks > 1;
     stamp(c, S_HZBCULL);      // closes whatever preceded the raster (HZB cull / list reset)
-    if (sh) hipLaunchKernelGGL(raster_cluster_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p);
-    else    hipLaunchKernelGGL(raster_cluster_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(raster_setup_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
     stamp(c, S_R_CLUSTER);
-    if (sh) hipLaunchKernelGGL(raster_clip_kernel<true>, dim3(clipBlocks), dim3(256), 0, c->stream, p);
-    else    hipLaunchKernelGGL(raster_clip_kernel<false>, dim3(clipBlocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(raster_clip_kernel, dim3(clipBlocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(raster_bin_large_kernel, dim3((uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
     stamp(c, S_R_CLIP);
-    if (sh) hipLaunchKernelGGL(raster_chunk_kernel<true>, dim3(chunkBlocks), dim3(256), 0, c->stream, p);
-    else    hipLaunchKernelGGL(raster_chunk_kernel<false>, dim3(chunkBlocks), dim3(256), 0, c->stream, p);
+    if (sh) hipLaunchKernelGGL(raster_tile_kernel<true>, dim3(tiles), dim3(256), 0, c->stream, p);
+    else    hipLaunchKernelGGL(raster_tile_kernel<false>, dim3(tiles), dim3(256), 0, c->stream, p);
     stamp(c, S_R_CHUNK);
     c->rasterCalls++;
 }

@@ -44,6 +44,7 @@ class Stats(C.Structure):
         ("msRasterCluster", C.c_float), ("msRasterClip", C.c_float), ("msRasterChunk", C.c_float),
         ("framesTimed", C.c_uint32), ("rasterLaunches", C.c_uint32), ("overflow", C.c_uint32), ("countInstanceCulled", C.c_uint32), ("countStage0Visible", C.c_uint32),
         ("countStage0Rejected", C.c_uint32), ("countStage1Visible", C.c_uint32), ("trianglesSubmitted", C.c_uint64),
+        ("triangleRecords", C.c_uint64), ("binEntries", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -125,6 +126,7 @@ def _load():
         "chordvis_enable_timers": (i32, [vp, i32]),
         "chordvis_stats": (i32, [vp, P(Stats)]),
         "chordvis_set_debug": (i32, [vp, u32]),
+        "chordvis_debug_tile_profile": (i32, [vp, i32, vp, vp, u32]),
     }
     missing = []
     for name, (res, args) in protos.items():

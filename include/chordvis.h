@@ -86,6 +86,8 @@ typedef struct ChordStats {
     uint32_t countStage0Rejected;
     uint32_t countStage1Visible;
     uint64_t trianglesSubmitted;   /* sum of meshlet triangle counts of rastered commands */
+    uint64_t triangleRecords;      /* set-up triangles that survived the per-triangle culls (this frame)  */
+    uint64_t binEntries;           /* (triangle, 64x64 tile) pairs binned (this frame, both raster passes) */
 } ChordStats;
 
 /* ------------------------------------------------------------------ host-only (no device needed) */
@@ -221,6 +223,9 @@ int chordvis_stats(ChordCtx* ctx, ChordStats* out);
 /* Measurement-only ablation switches of the raster kernels (bit0 no pixel writes, bit1 plain stores,
  * bit2 drop big triangles, bit3 no early depth read).  0 = production; anything else voids parity. */
 int chordvis_set_debug(ChordCtx* ctx, uint32_t flags);
+/* Measurement only: with debug bit 4 set the tile kernel records its elapsed wall-clock ticks (100 MHz)
+ * per 64x64 tile; this reads them back with the tile's bin count for raster pass 0 / 1 of the last frame. */
+int chordvis_debug_tile_profile(ChordCtx* ctx, int pass, uint64_t* hostTicks, uint32_t* hostCounts, uint32_t capacity);
 
 #ifdef __cplusplus
 }

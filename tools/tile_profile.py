@@ -1,0 +1,21 @@
+"""Per-tile timing of the raster tile kernel (measurement aid)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from chord_amd import lib as L, records as R, scenes
+from chord_amd.renderer import VisibilityRenderer
+scene, cam = scenes.config3_street()
+L.fill_objects(scene, cam); view, iv = L.make_views(cam)
+flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | (R.FLAG_HZB_CULL if len(sys.argv) > 1 and sys.argv[1] == "hzb" else 0)
+r = VisibilityRenderer(0); r.upload_scene(scene); r.allocate_gbuffer(cam.width, cam.height); r.set_view(view, iv, flags)
+r.set_debug(16)
+for _ in range(3): r.render_frame()
+tx, ty = (cam.width + 63) // 64, (cam.height + 63) // 64
+for p in (0, 1):
+    ticks = np.zeros(tx * ty, np.uint64); cnt = np.zeros(tx * ty, np.uint32)
+    assert L.lib.chordvis_debug_tile_profile(r._ctx, p, ticks.ctypes.data, cnt.ctypes.data, tx * ty) == 0
+    us = ticks.astype(np.float64) / 100.0
+    order = np.argsort(-us)[:12]
+    print("pass", p, "entries", int(cnt.sum()), "max bin", int(cnt.max()), "tile us: sum %.0f mean %.1f max %.1f" % (us.sum(), us.mean(), us.max()))
+    for t in order: print("   tile (%2d,%2d) %7.1f us  bin %5d" % (t % tx, t // tx, us[t], cnt[t]))
+    print("   corr(us, bin) = %.3f" % np.corrcoef(us, cnt)[0, 1])
