@@ -17,7 +17,8 @@
 //   raster_bin_large_kernel  records touching more than 2x2 tiles: one wave per record, one lane per tile
 //   raster_tile_kernel    one workgroup per 64x64 tile: the tile's 4096 packed words live in LDS
 //                         (32 KB); every binned triangle is scan-converted with ds_max_u64
-//                         (small: one lane per triangle; larger: one pixel row per lane), then the
+//                         (tiny: one lane per triangle; others: cut into (triangle, row) units that a
+//                         block-wide prefix sum deals out one row per lane), then the
 //                         tile is written back with 16-byte coalesced stores (and, on the first pass
 //                         of a frame, this is also the clear).
 // The packed word is (asuint(depth) << 32) | ((slot+1)&0xFFFFFF)<<8 | tri: reverse-Z "greater wins"
@@ -554,62 +555,96 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
     }
 }
 
-// The whole wave scans one larger triangle inside the tile, one pixel ROW per lane (a 64x64 tile has 64
-// rows): every lane walks its row from the bbox's left edge with incremental edge functions — no
-// multiplies in the loop — and the wave leaves as soon as no lane can still enter its span.
-// WIDE = 64-bit edge functions (vertices more than 64 px apart); otherwise 32-bit is exact.
-template <bool WIDE>
-__device__ __forceinline__ void tile_raster_rows(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
-                                                 int32_t x0, int32_t y0, int32_t x1, int32_t y1, uint32_t lane, bool noPixels,
-                                                 unsigned long long rowMask)
+// ---- row units ------------------------------------------------------------------------------
+// Triangles are not equal: a tile may hold thousands of 1-pixel triangles or a few that cover it
+// completely.  Each batch of 256 bin entries is therefore cut into (triangle, pixel row) units; a
+// block-wide prefix sum over the row counts hands every thread one row at a time, so a lane's loop
+// length is one row span (<= 64 pixels) instead of one bbox area (<= 4096).  Tiny triangles (clipped
+// bbox <= TINY_AREA pixels) are scanned directly by the thread that set them up.
+//
+// Edge functions in the row loop are incremental (no multiplies).  Three exact representations:
+//   kind 0  int32   vertices at most 64 px apart (|E| < 2^30)
+//   kind 1  double  |coordinates| < 2^25 sub-pixels: every product and sum below 2^53, so fp64 is exact
+//                   and v_cvt_f32_f64 IS the canonical (float)(double)E
+//   kind 2  int64   anything else (guard-band monsters)
+#define TINY_AREA 16
+
+struct UnitParams {           // 64 B in LDS per batch entry
+    int32_t X[3], Y[3];
+    float d0, e1, e2, invA;
+    uint32_t payload;
+    uint32_t box;             // x0 | y0 << 8 | x1 << 16 | y1 << 24, tile-local
+    int32_t skind;            // s in bit 0 (1 = negative), kind << 1
+    uint32_t pad[3];
+};
+
+template <typename E_t>
+__device__ __forceinline__ void scan_row(unsigned long long* __restrict__ tileRow, const UnitParams& u, int32_t ox, int32_t py,
+                                         int32_t lx0, int32_t lx1, bool noPixels)
 {
-    using E_t = typename std::conditional<WIDE, int64_t, int32_t>::type;
-    const int32_t py = oy + (int32_t)lane;
-    const bool rowActive = py >= y0 && py <= y1 && ((rowMask >> lane) & 1ull);
-    const E_t s = (E_t)ts.s;
-    const E_t dx0 = (E_t)(ts.X[2] - ts.X[1]), dy0 = (E_t)(ts.Y[2] - ts.Y[1]);
-    const E_t dx1 = (E_t)(ts.X[0] - ts.X[2]), dy1 = (E_t)(ts.Y[0] - ts.Y[2]);
-    const E_t dx2 = (E_t)(ts.X[1] - ts.X[0]), dy2 = (E_t)(ts.Y[1] - ts.Y[0]);
+    const E_t s = (u.skind & 1) ? (E_t)-1 : (E_t)1;
+    const E_t dx0 = (E_t)(u.X[2] - u.X[1]), dy0 = (E_t)(u.Y[2] - u.Y[1]);
+    const E_t dx1 = (E_t)(u.X[0] - u.X[2]), dy1 = (E_t)(u.Y[0] - u.Y[2]);
+    const E_t dx2 = (E_t)(u.X[1] - u.X[0]), dy2 = (E_t)(u.Y[1] - u.Y[0]);
     const E_t a0 = -s * dy0, b0 = s * dx0, a1 = -s * dy1, b1 = s * dx1, a2 = -s * dy2, b2 = s * dx2;
-    const E_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? 0 : -1;
-    const E_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 0 : -1;
-    const E_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 0 : -1;
-    const E_t cx = (E_t)x0 * 256 + 128, cy = (E_t)py * 256 + 128;
-    E_t E0 = s * (dx0 * (cy - ts.Y[1]) - dy0 * (cx - ts.X[1]));
-    E_t E1 = s * (dx1 * (cy - ts.Y[2]) - dy1 * (cx - ts.X[2]));
-    E_t E2 = s * (dx2 * (cy - ts.Y[0]) - dy2 * (cx - ts.X[0]));
-    const E_t st0 = a0 * 256, st1 = a1 * 256, st2 = a2 * 256;
-    unsigned long long* row = tile + lane * TILE - ox;
-    bool entered = false, done = !rowActive;
-    for (int32_t px = x0; px <= x1; px++) {
-        if (!done) {
-            if (((E0 + bias0) | (E1 + bias1) | (E2 + bias2)) >= 0) {
-                const float l1 = WIDE ? (float)(double)E1 * ts.invA : (float)(int32_t)E1 * ts.invA;
-                const float l2 = WIDE ? (float)(double)E2 * ts.invA : (float)(int32_t)E2 * ts.invA;
-                const float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
-                if (!noPixels) {
-                    const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)ts.payload;
-                    atomicMax(&row[px], packed);
-                }
-                entered = true;
-            } else if (entered) {
-                done = true;                             // convex: this row's span is over
+    const E_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? (E_t)0 : (E_t)-1;
+    const E_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? (E_t)0 : (E_t)-1;
+    const E_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? (E_t)0 : (E_t)-1;
+    const E_t cx = (E_t)(ox + lx0) * (E_t)256 + (E_t)128, cy = (E_t)py * (E_t)256 + (E_t)128;
+    E_t E0 = s * (dx0 * (cy - (E_t)u.Y[1]) - dy0 * (cx - (E_t)u.X[1])) + bias0;     // bias folded in: inside <=> all >= 0
+    E_t E1 = s * (dx1 * (cy - (E_t)u.Y[2]) - dy1 * (cx - (E_t)u.X[2])) + bias1;
+    E_t E2 = s * (dx2 * (cy - (E_t)u.Y[0]) - dy2 * (cx - (E_t)u.X[0])) + bias2;
+    const E_t st0 = a0 * (E_t)256, st1 = a1 * (E_t)256, st2 = a2 * (E_t)256;
+    bool entered = false;
+    for (int32_t lx = lx0; lx <= lx1; lx++) {
+        const bool inside = std::is_floating_point<E_t>::value ? (E0 >= (E_t)0 && E1 >= (E_t)0 && E2 >= (E_t)0)
+                                                              : (((int64_t)E0 | (int64_t)E1 | (int64_t)E2) >= 0);
+        if (inside) {
+            // canonical l_i = float(E_i) * invA with E_i the unbiased integer
+            const float l1 = (float)(double)(E1 - bias1) * u.invA, l2 = (float)(double)(E2 - bias2) * u.invA;
+            const float z = (u.d0 + l1 * u.e1) + l2 * u.e2;
+            if (!noPixels) {
+                const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)u.payload;
+                atomicMax(&tileRow[lx], packed);             // ds_max_u64
             }
-            E0 += st0; E1 += st1; E2 += st2;
+            entered = true;
+        } else if (entered) {
+            break;                                           // convex: this row's span is over
         }
-        if (__ballot(!done) == 0ull) break;
+        E0 += st0; E1 += st1; E2 += st2;
     }
+}
+
+// exclusive scan of one value per thread over the 256-thread block
+__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t* waveSums, uint32_t* total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t nb = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += nb;
+    }
+    if (lane == 63u) waveSums[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) { const uint32_t sw = waveSums[w]; if (w < wave) base += sw; tot += sw; }
+    *total = tot;
+    return base + incl - v;
 }
 
 template <bool SH>
 __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
 {
     __shared__ unsigned long long tile[TILE * TILE];             // 32 KB
+    __shared__ UnitParams prm[256];                              // 16 KB
+    __shared__ uint32_t offs[257];
+    __shared__ uint32_t waveSums[4];
     const uint32_t tileId = blockIdx.x;
     const uint32_t n = min(p.tileCount[(size_t)tileId * TC_STRIDE], p.binCap);
     const unsigned long long t0 = (p.debug & DBG_TILE_CLOCKS) ? wall_clock64() : 0ull;
     if (n == 0 && !p.clearTiles) return;                          // untouched tile: global words stay as they are
-    const uint32_t lane = threadIdx.x & 63u;
     const int32_t ox = (int32_t)(tileId % p.tilesX) * TILE, oy = (int32_t)(tileId / p.tilesX) * TILE;
     const int32_t tw = min(TILE, p.Wi - ox), th = min(TILE, p.Hi - oy);
     const bool noPixels = (p.debug & DBG_NO_PIXELS) != 0;
@@ -634,50 +669,66 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
     }
     __syncthreads();
 
-    // ---- scan-convert the bin ------------------------------------------------------------------
+    // ---- scan-convert the bin, 256 entries per batch -------------------------------------------
     const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
     for (uint32_t base = 0; base < n; base += 256u) {
         const uint32_t k = base + threadIdx.x;
-        bool big = false, wide = false;
-        TriSetup ts;
-        ts.s = 1; ts.invA = 0.0f; ts.d0 = ts.e1 = ts.e2 = 0.0f; ts.payload = 0;
-#pragma unroll
-        for (int i = 0; i < 3; i++) { ts.X[i] = 0; ts.Y[i] = 0; }
-        int32_t x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+        uint32_t rows = 0;
         if (k < n) {
             const TriRec* __restrict__ r = &p.tris[bin[k]];
+            TriSetup ts;
 #pragma unroll
             for (int i = 0; i < 3; i++) { ts.X[i] = r->X[i]; ts.Y[i] = r->Y[i]; }
             ts.payload = r->payload;
             const float d0 = r->d[0], d1 = r->d[1], d2 = r->d[2];
             if (tri_setup(ts, r->twoSided != 0, p.Wi, p.Hi)) {
                 ts.d0 = d0; ts.e1 = d1 - d0; ts.e2 = d2 - d0;
-                x0 = max(ts.px0, ox); y0 = max(ts.py0, oy);
-                x1 = min(ts.px1, ox + tw - 1); y1 = min(ts.py1, oy + th - 1);
+                const int32_t x0 = max(ts.px0, ox), y0 = max(ts.py0, oy);
+                const int32_t x1 = min(ts.px1, ox + tw - 1), y1 = min(ts.py1, oy + th - 1);
                 if (x1 >= x0 && y1 >= y0) {
-                    const int32_t area = (x1 - x0 + 1) * (y1 - y0 + 1);
-                    wide = !narrow_extent(ts);
-                    if (area > SMALL_AREA || wide) big = true;
-                    else tile_raster_narrow(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask);
+                    const bool narrow = narrow_extent(ts);
+                    if (narrow && (x1 - x0 + 1) * (y1 - y0 + 1) <= TINY_AREA) {
+                        tile_raster_narrow(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask);
+                    } else {
+                        int32_t mag = 0;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) mag = max(mag, max(abs(ts.X[i]), abs(ts.Y[i])));
+                        const int32_t kind = narrow ? 0 : (mag < (1 << 25) ? 1 : 2);
+                        UnitParams& u = prm[threadIdx.x];
+#pragma unroll
+                        for (int i = 0; i < 3; i++) { u.X[i] = ts.X[i]; u.Y[i] = ts.Y[i]; }
+                        u.d0 = ts.d0; u.e1 = ts.e1; u.e2 = ts.e2; u.invA = ts.invA; u.payload = ts.payload;
+                        u.box = (uint32_t)(x0 - ox) | ((uint32_t)(y0 - oy) << 8) | ((uint32_t)(x1 - ox) << 16) | ((uint32_t)(y1 - oy) << 24);
+                        u.skind = (ts.s < 0 ? 1 : 0) | (kind << 1);
+                        rows = (uint32_t)(y1 - y0 + 1);
+                    }
                 }
             }
         }
-        // large ones: each wave walks its own
-        unsigned long long bm = __ballot(big);
-        while (bm) {
-            const int src = __ffsll((long long)bm) - 1;
-            bm &= bm - 1ull;
-            TriSetup bs;
+        uint32_t total;
+        const uint32_t off = block_scan_256(rows, waveSums, &total);
+        offs[threadIdx.x] = off;
+        if (threadIdx.x == 0) offs[256] = total;
+        __syncthreads();
+        for (uint32_t u0 = 0; u0 < total; u0 += 256u) {
+            const uint32_t ui = u0 + threadIdx.x;
+            if (ui < total) {
+                uint32_t e = 0;                                   // last entry with offs[e] <= ui
 #pragma unroll
-            for (int i = 0; i < 3; i++) { bs.X[i] = bcast(ts.X[i], src); bs.Y[i] = bcast(ts.Y[i], src); }
-            bs.d0 = bcast(ts.d0, src); bs.e1 = bcast(ts.e1, src); bs.e2 = bcast(ts.e2, src);
-            bs.payload = bcast(ts.payload, src);
-            bs.s = bcast(ts.s, src); bs.invA = bcast(ts.invA, src);
-            const int32_t bx0 = bcast(x0, src), by0 = bcast(y0, src), bx1 = bcast(x1, src), by1 = bcast(y1, src);
-            const bool bwide = bcast((uint32_t)wide, src) != 0u;
-            if (bwide) tile_raster_rows<true>(tile, bs, ox, oy, bx0, by0, bx1, by1, lane, noPixels, rowMask);
-            else       tile_raster_rows<false>(tile, bs, ox, oy, bx0, by0, bx1, by1, lane, noPixels, rowMask);
+                for (uint32_t st = 128; st > 0; st >>= 1) if (offs[e + st] <= ui) e += st;
+                const UnitParams& u = prm[e];
+                const int32_t ly = (int32_t)((u.box >> 8) & 0xFFu) + (int32_t)(ui - offs[e]);
+                if ((rowMask >> ly) & 1ull) {
+                    const int32_t lx0 = (int32_t)(u.box & 0xFFu), lx1 = (int32_t)((u.box >> 16) & 0xFFu);
+                    unsigned long long* tileRow = tile + ly * TILE;
+                    const int32_t kind = u.skind >> 1;
+                    if (kind == 0)      scan_row<int32_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
+                    else if (kind == 1) scan_row<double>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
+                    else                scan_row<int64_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
+                }
+            }
         }
+        __syncthreads();                                          // prm / offs are rewritten by the next batch
     }
     __syncthreads();
 
