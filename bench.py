@@ -35,19 +35,6 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CLUSTER_BYTES = 64 + 12   # meshlet header + draw command; + 4*(V+T) + 12*V per cluster
 
 
-def pick_stripe_rows(height, ranks):
-    """Even stripe height in [32, 96] with the least padding of ceil(H/S) to a multiple of ranks."""
-    best = None
-    for s in range(32, 97, 2):
-        stripes = -(-height // s)
-        per = -(-stripes // ranks)
-        pad = per * ranks * s - height
-        key = (pad, abs(s - 64))
-        if best is None or key < best[0]:
-            best = (key, s)
-    return best[1]
-
-
 def build_workload(name):
     from chord_amd import scenes
     if name == "street_4k_hzb":
@@ -113,6 +100,7 @@ def main():
     r = VisibilityRenderer(local_rank, stream.cuda_stream)
     r.upload_scene(scene)
     if world > 1:
+        from chord_amd.sharding import pick_stripe_rows
         r.set_shard(pick_stripe_rows(H, world), world, rank)
     r.allocate_gbuffer(W, H)
     words = r.visibility_words()
@@ -138,8 +126,9 @@ def main():
         """all-gather of the context-owned HZB mip-0 exchange buffer (f16, rank-major)."""
         def __init__(self):
             ptr, halves, chunk_h = r.hzb_exchange()
-            self.full = _tensor_from_ptr(ptr, halves, torch.int16, dev)
-            self.mine = self.full[rank * chunk_h:(rank + 1) * chunk_h]
+            # raw bytes: RCCL has no 16-bit integer type and the payload is opaque f16 bits anyway
+            self.full = _tensor_from_ptr(ptr, halves * 2, torch.uint8, dev)
+            self.mine = self.full[rank * chunk_h * 2:(rank + 1) * chunk_h * 2]
 
         def all_gather_hzb(self):
             dist.all_gather_into_tensor(self.full, self.mine)
@@ -160,7 +149,9 @@ def main():
     clusters_per_pair = sum(pv["countStage0Visible"] + pv["countStage1Visible"] for pv in per_view)
 
     # ---- timed region --------------------------------------------------------------------------
-    r.enable_timers(2)
+    # GPU timestamps (hipEvent on the launch stream) on every 8th step of the timed region: each event
+    # record costs ~5 us of stream idle time, 15 per frame would inflate the frame by ~20 %
+    r.enable_timers(2, period=8)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -185,17 +176,19 @@ def main():
     # ---- roofline of the dominant kernel (HIP events on the launch stream, inside the timed region)
     # algorithmic bytes per frame (DESIGN.md "Roofline"): setup reads 1884 B per cluster (64 header + 12 cmd +
     # 4(V+T) indices + 12V positions, V=81 T=128) and writes a 48 B record + 4 B per bin entry; the tile
-    # kernel reads 4 + 48 B per bin entry and moves 8 B per pixel out (and in, on the second pass).
+    # kernel reads 4 + 48 B per bin entry, writes every pixel once on the first pass of a frame (8 B x W x H, this
+    # is also the clear) and reads + writes the 64x64 tiles that have bin entries on the second pass.
     pixels = W * H
     V, T = 81, 128
     cluster_bytes = CLUSTER_BYTES + 4 * (V + T) + 12 * V
     clusters_per_frame = clusters_per_pair / 2.0
     recs = sum(pv["triangleRecords"] for pv in per_view) / 2.0
     bins = sum(pv["binEntries"] for pv in per_view) / 2.0
+    tiles1 = sum(pv["tilesTouched"][1] for pv in per_view) / 2.0
     launches = max(1, st["rasterLaunches"])
     kernels = {
         "raster_setup_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame + 48.0 * recs + 4.0 * bins),
-        "raster_tile_kernel": (st["msRasterChunk"], 52.0 * bins + 8.0 * pixels * (2 * launches - 1)),
+        "raster_tile_kernel": (st["msRasterChunk"], 52.0 * bins + 8.0 * pixels + (launches - 1) * 16.0 * 4096 * tiles1),
     }
     dom = max(kernels, key=lambda k: kernels[k][0])
     dom_ms, dom_bytes = kernels[dom]

@@ -52,7 +52,9 @@ void record(ChordCtx* c, int tag) { chord::stamp(c, tag); }
 
 void begin_frame_stamps(ChordCtx* c)
 {
-    if (!c->timers) return;
+    c->stampThisFrame = c->timers && (c->frameIndex % c->timerPeriod) == 0;
+    c->frameIndex++;
+    if (!c->stampThisFrame) return;
     if (c->timers == 1) { c->stampTags.clear(); c->framesStamped = 0; }
     c->framesStamped++;
     chord::stamp(c, S_FRAME_BEGIN);
@@ -173,7 +175,7 @@ int do_raster(ChordCtx* c, const CmdList& in)
 namespace chord {
 void stamp(ChordCtx* c, int tag)
 {
-    if (!c->timers) return;
+    if (!c->timers || !c->stampThisFrame) return;
     const size_t i = c->stampTags.size();
     if (i >= c->evPool.size()) {
         hipEvent_t e;
@@ -734,9 +736,12 @@ int chordvis_debug_tile_profile(ChordCtx* c, int pass, uint64_t* hostTicks, uint
 int chordvis_enable_timers(ChordCtx* c, int enable)
 {
     if (!c) return CHORDVIS_E_INVALID;
-    c->timers = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    c->timers = enable < 0 ? 0 : ((enable & 0xFF) > 2 ? 2 : (enable & 0xFF));
+    c->timerPeriod = (enable >> 8) > 0 ? (uint32_t)(enable >> 8) : 1u;
     c->stampTags.clear();
     c->framesStamped = 0;
+    c->frameIndex = 0;
+    c->stampThisFrame = false;
     return CHORDVIS_OK;
 }
 
@@ -764,7 +769,7 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
         std::vector<uint32_t> tc((size_t)c->tilesX * c->tilesY);
         for (int pass = 0; pass < 2; pass++) {
             CHORD_HIP(c, hipMemcpy2D(tc.data(), 4, c->dFrameState->tileCount[pass], 4 * CHORD_TILECOUNT_STRIDE, 4, tc.size(), hipMemcpyDeviceToHost));
-            for (uint32_t v : tc) out->binEntries += v;
+            for (uint32_t v : tc) { out->binEntries += v; out->tilesTouched[pass] += v ? 1u : 0u; }
         }
     }
     if (c->timers && c->framesStamped && c->stampTags.size() > 1) {

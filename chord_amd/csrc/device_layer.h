@@ -200,6 +200,9 @@ struct ChordCtx {
     std::vector<hipEvent_t> evPool;
     std::vector<int> stampTags;        // tags of evPool[0 .. stampTags.size())
     uint32_t framesStamped = 0;
+    uint32_t timerPeriod = 1;          // stamp every timerPeriod-th frame (an event record costs ~5 us of stream idle time)
+    uint32_t frameIndex = 0;
+    bool stampThisFrame = false;
     uint32_t rasterCalls = 0;          // renderMesh calls since the last clear
     bool shouldStage1 = false;
     chord::CmdList lastRejected;

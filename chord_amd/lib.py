@@ -44,11 +44,11 @@ class Stats(C.Structure):
         ("msRasterCluster", C.c_float), ("msRasterClip", C.c_float), ("msRasterChunk", C.c_float),
         ("framesTimed", C.c_uint32), ("rasterLaunches", C.c_uint32), ("overflow", C.c_uint32), ("countInstanceCulled", C.c_uint32), ("countStage0Visible", C.c_uint32),
         ("countStage0Rejected", C.c_uint32), ("countStage1Visible", C.c_uint32), ("trianglesSubmitted", C.c_uint64),
-        ("triangleRecords", C.c_uint64), ("binEntries", C.c_uint64),
+        ("triangleRecords", C.c_uint64), ("binEntries", C.c_uint64), ("tilesTouched", C.c_uint32 * 2),
     ]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n == "tilesTouched" else getattr(self, n)) for n, _ in self._fields_}
 
 
 def _preload_hip_runtime():

@@ -168,9 +168,9 @@ class VisibilityRenderer:
                                                 rng.ctypes.data if rng is not None else None), "readback_hzb")
         return mn, mx, rng
 
-    def enable_timers(self, mode=1):
-        """0 off, 1 last frame, 2 accumulate until stats()."""
-        self._check(L.lib.chordvis_enable_timers(self._ctx, int(mode)), "enable_timers")
+    def enable_timers(self, mode=1, period=1):
+        """0 off, 1 last frame, 2 accumulate until stats(); only every `period`-th frame is stamped."""
+        self._check(L.lib.chordvis_enable_timers(self._ctx, int(mode) | (int(period) << 8)), "enable_timers")
 
     def set_debug(self, flags):
         """Measurement-only ablation switches (0 = production)."""

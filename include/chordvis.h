@@ -88,6 +88,7 @@ typedef struct ChordStats {
     uint64_t trianglesSubmitted;   /* sum of meshlet triangle counts of rastered commands */
     uint64_t triangleRecords;      /* set-up triangles that survived the per-triangle culls (this frame)  */
     uint64_t binEntries;           /* (triangle, 64x64 tile) pairs binned (this frame, both raster passes) */
+    uint32_t tilesTouched[2];      /* 64x64 tiles with at least one bin entry, per raster pass            */
 } ChordStats;
 
 /* ------------------------------------------------------------------ host-only (no device needed) */
@@ -216,8 +217,10 @@ int chordvis_readback_hzb(ChordCtx* ctx, const ChordHZB* hzb, uint16_t* hostMin,
 /* upload an HZB min chain from the host (tests: feed a known history) into history */
 int chordvis_upload_history_hzb(ChordCtx* ctx, const uint16_t* hostMin);
 
-/* mode 0: off.  1: GPU timestamps of the last frame.  2: accumulate over frames until the next
- * chordvis_stats, which then reports per-frame averages (and restarts the accumulation). */
+/* mode (low 8 bits) 0: off.  1: GPU timestamps of the last frame.  2: accumulate over frames until the
+ * next chordvis_stats, which then reports per-frame averages (and restarts the accumulation).
+ * mode >> 8 = sampling period P (0/1 = every frame): only every P-th frame is stamped, because each
+ * hipEventRecord between two kernels costs ~5 us of stream idle time on MI355X. */
 int chordvis_enable_timers(ChordCtx* ctx, int mode);
 int chordvis_stats(ChordCtx* ctx, ChordStats* out);
 /* Measurement-only ablation switches of the raster kernels (bit0 no pixel writes, bit1 plain stores,

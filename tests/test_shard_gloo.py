@@ -1,0 +1,112 @@
+"""The N > 1 frame protocol on CPU: world_size-2 `gloo`, every rank renders its own stripes with the
+ORACLE (the checker stands in for the HIP kernels here), the two all-gathers of DESIGN.md §6 run through
+torch.distributed, and every rank must end with the single-rank frame."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_stripe_layout_round_trip_and_ownership():
+    from chord_amd.sharding import StripeLayout, pick_stripe_rows
+    for (w, h, ranks) in ((320, 200, 2), (3840, 2160, 8), (3840, 2160, 4), (1920, 1080, 2), (257, 131, 3)):
+        s = pick_stripe_rows(h, ranks)
+        assert s % 2 == 0 and 32 <= s <= 96
+        lay = StripeLayout(w, h, s, ranks)
+        assert lay.words % ranks == 0 and lay.rows_padded >= h and lay.rows_padded - h < ranks * s
+        rows = lay.rank_major_row(np.arange(h))
+        assert len(set(rows.tolist())) == h and rows.max() < lay.rows_padded
+        # a rank's rows all fall inside its chunk
+        for r in range(ranks):
+            mine = rows[lay.owner(np.arange(h)) == r]
+            assert ((mine >= r * lay.rows_padded // ranks) & (mine < (r + 1) * lay.rows_padded // ranks)).all()
+        img = (np.arange(h * w, dtype=np.uint64).reshape(h, w) * np.uint64(2654435761)) | np.uint64(1)
+        assert np.array_equal(lay.from_rank_major(lay.to_rank_major(img)), img)
+    # 4K on 8 ranks: padding stays under 2 %
+    lay = StripeLayout(3840, 2160, pick_stripe_rows(2160, 8), 8)
+    assert lay.rows_padded <= 2160 * 1.02
+
+
+def _worker(rank, world, port, tmp):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import helpers as H
+    import orc
+    from chord_amd import lib as L, scenes
+    from chord_amd.sharding import StripeLayout
+
+    scene, cam = scenes.small_test_scene(256, 160, seed=29)
+    w, h, flags = cam.width, cam.height, H.ALL_FLAGS
+    L.fill_objects(scene, cam)
+    view, iv = L.make_views(cam)
+    S = 16
+    lay = StripeLayout(w, h, S, world)
+    shard = (S, world, rank)
+    desc = orc.hzb_desc(w, h)
+    own_rows = np.nonzero(lay.owner(np.arange(h)) == rank)[0]
+    prev_hzb = None
+    for frame in range(2):
+        want = orc.frame(scene, view, iv, flags, prev_hzb_min=prev_hzb)       # the single-rank frame
+        # ---- phase a: cull (replicated, deterministic), phase-0 HZB cull, raster own stripes --------
+        cmds = orc.instance_culling(scene, view, iv, flags)
+        if prev_hzb is not None:
+            vis_list, rej = orc.hzb_culling(scene, view, flags, 0, desc, prev_hzb, cmds)
+        else:
+            vis_list, rej = cmds, cmds[:0]
+        mine, _ = orc.raster(scene, iv, vis_list, w, h, shard=shard)
+        mine = mine.reshape(h, w)
+        assert not mine[lay.owner(np.arange(h)) != rank].any()                 # only owned rows written
+        if prev_hzb is not None:
+            # ---- all-gather #1: HZB mip 0 (f16) of the own stripes, rank-major ---------------------
+            _, mn_local, _, _ = orc.hzb_build(mine.reshape(-1), w, h)
+            mw0, mh0 = desc.mip_dims(0)
+            vw0, vh0 = desc.valid_dims(0)
+            mip0_local = mn_local[desc.mipOffset[0]: desc.mipOffset[0] + mw0 * mh0].reshape(mh0, mw0)
+            ex = np.zeros((lay.exchange_rows(), mw0), dtype=np.int16)
+            own_half = np.nonzero(lay.owner(np.arange(vh0) * 2) == rank)[0]
+            ex[lay.exchange_row(own_half)] = mip0_local[own_half].view(np.int16)
+            chunk = lay.exchange_rows() // world
+            # exchanged as raw bytes: neither gloo nor NCCL/RCCL has a 16-bit integer type
+            parts = [torch.zeros((chunk, mw0 * 2), dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(ex[rank * chunk:(rank + 1) * chunk].copy().view(np.uint8)))
+            full_ex = torch.cat(parts).numpy().view(np.int16)
+            mip0 = np.zeros((mh0, mw0), dtype=np.uint16)
+            mip0[:vh0] = full_ex[lay.exchange_row(np.arange(vh0))].view(np.uint16)
+            # every rank reduces mips 1..n locally from the gathered mip 0: must equal the HZB of the full
+            # stage-0 image, which the single-rank oracle builds internally; rebuild it here to compare
+            full0, _ = orc.raster(scene, iv, vis_list, w, h)
+            _, want_mn, _, _ = orc.hzb_build(full0, w, h)
+            assert np.array_equal(mip0[:vh0, :vw0], want_mn[desc.mipOffset[0]: desc.mipOffset[0] + mw0 * mh0].reshape(mh0, mw0)[:vh0, :vw0])
+            # ---- phase b: phase-1 cull against the shared HZB, raster own stripes -------------------
+            vis1, _ = orc.hzb_culling(scene, view, flags, 1, desc, want_mn, rej)
+            mine = orc.raster(scene, iv, vis1, w, h, vis=mine.reshape(-1).copy(), shard=shard)[0].reshape(h, w)
+        # ---- all-gather #2: the visibility words, rank-major, then de-stripe -------------------------
+        rm = lay.to_rank_major(mine)
+        rows = lay.rows_padded // world
+        parts = [torch.zeros((rows, w), dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(rm[rank * rows:(rank + 1) * rows].view(np.int64).copy()))
+        full = lay.from_rank_major(torch.cat(parts).numpy().view(np.uint64))
+        assert np.array_equal(full.reshape(-1), want["vis"]), "rank %d frame %d differs from the single-rank frame" % (rank, frame)
+        prev_hzb = want["hzb_min"]
+        assert np.array_equal(orc.hzb_build(full.reshape(-1), w, h)[1], want["hzb_min"])
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+
+
+def test_two_rank_frame_over_gloo(tmp_path, built_lib):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turns a tools/profile.sh output directory (gpurun_out/<tag>) into tracked files under profiles/."""
+import collections
+import csv
+import os
+import shutil
+import sys
+
+src, name = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "stats", "r_kernel_stats.csv"), os.path.join(dst, name + "_kernel_stats.csv"))
+
+
+def pmc(kind):
+    path = os.path.join(src, kind, "r_counter_collection.csv")
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    if os.path.exists(path):
+        for r in csv.DictReader(open(path)):
+            agg[r["Kernel_Name"]][0] += 1
+            agg[r["Kernel_Name"]][1] += float(r["Counter_Value"])
+    return agg
+
+
+fetch, write = pmc("pmc_fetch"), pmc("pmc_write")
+stats = list(csv.DictReader(open(os.path.join(src, "stats", "r_kernel_stats.csv"))))
+bench = ""
+for line in open(os.path.join(src, "stats.log"), errors="ignore"):
+    if line.startswith('{"metric"'):
+        bench = line.strip()
+with open(os.path.join(dst, name + "_summary.md"), "w") as f:
+    f.write("# %s — rocprofv3 summary\n\n" % name)
+    f.write("Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 40 --warmup 4 --cpu-baseline-frames 0` "
+            "(+ separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of the same command; tools/profile.sh).\n\n")
+    f.write("FETCH_SIZE / WRITE_SIZE are KiB per launch as reported; per MI355X_MICROARCH.md §HBM, FETCH_SIZE on gfx950 "
+            "reports exactly half of the bytes of wide coalesced reads, so `fetch x2` is the corrected figure for streaming kernels.\n\n")
+    f.write("| kernel | calls | avg us | min us | max us | % | FETCH_SIZE KiB/launch | fetch x2 MB | WRITE_SIZE KiB/launch |\n|---|---|---|---|---|---|---|---|---|\n")
+    for r in stats:
+        k = r["Name"]
+        if not ("chord::" in k or "rocclr" in k):
+            continue
+        fe = fetch.get(k, [0, 0.0]); wr = write.get(k, [0, 0.0])
+        fa = fe[1] / fe[0] if fe[0] else float("nan")
+        wa = wr[1] / wr[0] if wr[0] else float("nan")
+        f.write("| `%s` | %s | %.1f | %.1f | %.1f | %s | %.0f | %.1f | %.0f |\n" % (
+            k.replace("void ", "").split("(")[0], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
+            float(r["MaxNs"]) / 1e3, r["Percentage"], fa, fa * 2 * 1024 / 1e6, wa))
+    if bench:
+        f.write("\nbench.py line of the `--stats` run (timing perturbed by the profiler):\n\n```json\n%s\n```\n" % bench)
+print("wrote", os.path.join(dst, name + "_summary.md"))
