@@ -149,11 +149,26 @@ int ready(ChordCtx* c, const char* fn)
 
 // addClearGbufferPass inside a frame: the visibility words are not memset; the first raster pass of the
 // frame starts every 64x64 tile from zero in LDS and writes every tile back, which is the clear.
+// passes other than instance_culling that run before it in a frame still need the constants on the device
+int flush_view(ChordCtx* c)
+{
+    if (c->viewDirty) {
+        CHORD_HIP(c, hipMemcpyAsync(c->dView, &c->hView, sizeof(DView), hipMemcpyHostToDevice, c->stream));
+        c->viewDirty = false;
+    }
+    if (c->zeroFrameStateInCull) {
+        CHORD_HIP(c, hipMemsetAsync(c->dFrameState, 0, c->frameStateZeroBytes, c->stream));
+        c->zeroFrameStateInCull = false;
+    }
+    return CHORDVIS_OK;
+}
+
 int begin_frame_clear(ChordCtx* c)
 {
-    // one memset: counters, the four command-list counts and both passes' tile bin counts
-    const size_t bytes = offsetof(FrameState, tileCount) + sizeof(uint32_t) * CHORD_TILECOUNT_STRIDE * (CHORD_MAX_TILES + (size_t)c->tilesX * c->tilesY);
-    CHORD_HIP(c, hipMemsetAsync(c->dFrameState, 0, bytes, c->stream));
+    // counters, the four command-list counts and both passes' tile bin counts: zeroed by the frame's first
+    // kernel (object_cull), not by a separate memset
+    c->frameStateZeroBytes = offsetof(FrameState, tileCount) + sizeof(uint32_t) * CHORD_TILECOUNT_STRIDE * (CHORD_MAX_TILES + (size_t)c->tilesX * c->tilesY);
+    c->zeroFrameStateInCull = true;
     c->rasterCalls = 0;
     c->pendingClear = true;
     c->inFrame = true;
@@ -207,7 +222,8 @@ int chordvis_create(int deviceOrdinal, void* hipStream, ChordCtx** outCtx)
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CHORDVIS_E_HIP; }
         c->ownStream = true;
     }
-    bool ok = hipMalloc((void**)&c->dTileClocks, sizeof(unsigned long long) * 2 * CHORD_MAX_TILES) == hipSuccess &&
+    bool ok = hipMalloc((void**)&c->dTileClocks, sizeof(unsigned long long) * 18 * CHORD_MAX_TILES) == hipSuccess &&
+              hipMalloc((void**)&c->dTileOrder, sizeof(uint32_t) * (1 + CHORD_MAX_TILES)) == hipSuccess &&
               hipMalloc((void**)&c->dView, sizeof(DView)) == hipSuccess &&
               hipMalloc((void**)&c->dFrameState, sizeof(FrameState)) == hipSuccess;
     if (!ok) { chordvis_destroy(c); return CHORDVIS_E_HIP; }
@@ -227,7 +243,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
-    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks);
+    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
     dfree(c->dRangePartials); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTileBins);
@@ -402,8 +418,9 @@ int chordvis_set_view(ChordCtx* c, const ChordCameraView* view, const ChordInsta
     c->hView.width = (uint32_t)iv->renderDimension[0]; c->hView.height = (uint32_t)iv->renderDimension[1];
     if (c->dVis && (c->hView.width != c->width || c->hView.height != c->height))
         return fail(c, CHORDVIS_E_INVALID, "set_view: renderDimension differs from the allocated gbuffer");
-    // small constant block: stream-ordered copy from a context-owned staging copy
-    CHORD_HIP(c, hipMemcpyAsync(c->dView, &c->hView, sizeof(DView), hipMemcpyHostToDevice, c->stream));
+    // the 600-byte constant block travels as a kernel argument of the frame's first kernel (object_cull),
+    // which publishes it for the later passes; see flush_view() for passes called out of frame order
+    c->viewDirty = true;
     c->viewSet = true;
     return CHORDVIS_OK;
 }
@@ -481,6 +498,7 @@ int chordvis_hzb_culling(ChordCtx* c, const ChordHZB* hzb, int bFirstStage, Chor
     int rc = ready(c, "hzb_culling");
     if (rc) return rc;
     if (!hzb || !hzb->minTexels || !in.count || !in.cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling: invalid HZB or command list");
+    if ((rc = flush_view(c))) return rc;
     const HzbBuffers hb = from_handle(hzb);
     const CmdList inL = from_handle(in);
     if (bFirstStage) {
@@ -507,6 +525,7 @@ int chordvis_render_mesh(ChordCtx* c, ChordCountAndCmd in)
     int rc = ready(c, "render_mesh");
     if (rc) return rc;
     if (!in.count || !in.cmds) return CHORDVIS_OK;       // {nullptr, nullptr}: nothing to render (instance_culling.cpp:92-95)
+    if ((rc = flush_view(c))) return rc;
     return do_raster(c, from_handle(in));
 }
 
@@ -730,6 +749,8 @@ int chordvis_debug_tile_profile(ChordCtx* c, int pass, uint64_t* hostTicks, uint
     const size_t n = (size_t)c->tilesX * c->tilesY;
     CHORD_HIP(c, hipMemcpy(hostTicks, c->dTileClocks + (size_t)pass * CHORD_MAX_TILES, n * 8, hipMemcpyDeviceToHost));
     CHORD_HIP(c, hipMemcpy2D(hostCounts, 4, c->dFrameState->tileCount[pass], 4 * CHORD_TILECOUNT_STRIDE, 4, n, hipMemcpyDeviceToHost));
+    if (capacity >= 9 * n)   // optional: 8 phase accumulators per tile follow the totals
+        CHORD_HIP(c, hipMemcpy(hostTicks + n, c->dTileClocks + (size_t)2 * CHORD_MAX_TILES + (size_t)pass * CHORD_MAX_TILES * 8, n * 64, hipMemcpyDeviceToHost));
     return CHORDVIS_OK;
 }
 

@@ -156,6 +156,9 @@ struct ChordCtx {
     chord::DView hView{};
     chord::DView* dView = nullptr;
     bool viewSet = false;
+    bool viewDirty = false;            // hView not yet on the device (object_cull publishes it from its kernel argument)
+    bool zeroFrameStateInCull = false; // object_cull zeroes the FrameState block instead of a memset
+    size_t frameStateZeroBytes = 0;
     chord::DObjFrame* dObjFrame = nullptr;
     uint8_t* dGroupMask = nullptr;
     uint32_t* dBlockCounts = nullptr;
@@ -190,6 +193,7 @@ struct ChordCtx {
     uint32_t binCap = 0, tilesX = 0, tilesY = 0;
     chord::ClipTri* dClipTris = nullptr;
     uint32_t clipTriCap = 0;
+    uint32_t* dTileOrder = nullptr;    // [1 + CHORD_MAX_TILES]: active count, then tile ids heaviest first
     uint32_t* dLargeList = nullptr;    // [2 passes][largeCap / 2] record indices
     uint32_t largeCap = 0;
     chord::DeviceCounters* dCounters = nullptr;

@@ -24,15 +24,23 @@ namespace chord {
 
 // ------------------------------------------------------------------------------ object stage --
 
+// The first kernel of a frame also (a) publishes the frame constants, which arrive as a 600-byte kernel
+// argument instead of a host-to-device copy, and (b) zeroes the FrameState block (counters, list counts,
+// tile-bin counts) — two launches (~5 us each on this GPU) that the frame no longer pays.
 __global__ __launch_bounds__(256) void object_cull_kernel(
     const ChordObject* __restrict__ objects, const DObjStatic* __restrict__ objStatic,
-    const DPrim* __restrict__ prims, const DView* __restrict__ dview, DObjFrame* __restrict__ objFrame,
-    uint32_t objectCount)
+    const DPrim* __restrict__ prims, const DView dv, DView* __restrict__ dviewOut, DObjFrame* __restrict__ objFrame,
+    uint32_t objectCount, uint4* __restrict__ zeroBase, uint32_t zeroVec4)
 {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dviewOut && blockIdx.x == 0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
+        for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += blockDim.x) dst[i] = src[i];
+    }
+    for (uint32_t i = o; i < zeroVec4; i += gridDim.x * blockDim.x) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
     if (o >= objectCount) return;
     const ChordObject& obj = objects[o];
-    const DView& dv = *dview;
 
     const Mat4 M = load_mat(obj.basicData.localToTranslatedWorld);
     const Mat4 VP = load_mat(dv.iv.translatedWorldToClip);
@@ -367,8 +375,17 @@ __global__ __launch_bounds__(256) void hzb_cull_kernel(HzbCullParams p)
 void launch_object_cull(ChordCtx* c)
 {
     const uint32_t blocks = (c->objectCount + 255u) / 256u;
+    uint4* zeroBase = nullptr;
+    uint32_t zeroVec4 = 0;
+    if (c->zeroFrameStateInCull) {
+        zeroBase = reinterpret_cast<uint4*>(c->dFrameState);
+        zeroVec4 = (uint32_t)((c->frameStateZeroBytes + 15u) / 16u);
+        c->zeroFrameStateInCull = false;
+    }
     hipLaunchKernelGGL(object_cull_kernel, dim3(blocks), dim3(256), 0, c->stream,
-                       c->dObjects, c->dObjStatic, c->dPrims, c->dView, c->dObjFrame, c->objectCount);
+                       c->dObjects, c->dObjStatic, c->dPrims, c->hView, c->viewDirty ? c->dView : (DView*)nullptr,
+                       c->dObjFrame, c->objectCount, zeroBase, zeroVec4);
+    c->viewDirty = false;
 }
 
 void launch_group_cull(ChordCtx* c, const CmdList& out)

@@ -54,13 +54,16 @@ struct RasterParams {
     ClipTri* clipTris; uint32_t clipTriCap; uint32_t pass;   // raster pass of the frame (0 / 1): clip / large count slot
     uint32_t* largeList; uint32_t largeCap;                  // records touching more than 2x2 tiles (binned by raster_bin_large_kernel)
     DeviceCounters* counters;
+    uint32_t* tileOrder;                                // [0] = active tile count, [1..] tile ids, heaviest first
     unsigned long long* tileClocks;                     // debug: per-tile elapsed wall clock ticks (DBG_TILE_CLOCKS)
+    unsigned long long* tilePhase;                      // debug: 8 phase accumulators per tile
     uint32_t clearTiles;                                // first raster pass of a frame: tiles start from 0
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
 #define DBG_NO_PIXELS   1u    // skip every visibility write
 #define DBG_NO_BIN      2u    // setup only: no records, no bins
 #define DBG_TILE_CLOCKS 16u   // tile kernel writes its elapsed wall-clock ticks per tile
+#define DBG_NO_TINY     32u   // tile kernel skips the per-lane scan of tiny triangles
 
 __device__ __forceinline__ int32_t bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
@@ -131,6 +134,24 @@ __device__ __forceinline__ bool tri_setup(TriSetup& ts, bool twoSided, int32_t W
     return true;
 }
 
+// Setup of a record that raster_setup_kernel / raster_clip_kernel already validated: bbox + stored sign / invA.
+__device__ __forceinline__ void tri_setup_from_record(TriSetup& ts, const TriRec& r, int32_t Wi, int32_t Hi)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) { ts.X[i] = r.X[i]; ts.Y[i] = r.Y[i]; }
+    ts.payload = r.payload;
+    ts.s = (r.twoSided & 2u) ? -1 : 1;
+    ts.invA = __uint_as_float(r.pad);
+    ts.d0 = r.d[0]; ts.e1 = r.d[1] - r.d[0]; ts.e2 = r.d[2] - r.d[0];
+    const int32_t minX = min(ts.X[0], min(ts.X[1], ts.X[2])), maxX = max(ts.X[0], max(ts.X[1], ts.X[2]));
+    const int32_t minY = min(ts.Y[0], min(ts.Y[1], ts.Y[2])), maxY = max(ts.Y[0], max(ts.Y[1], ts.Y[2]));
+    ts.px0 = max(0, (minX + 127) >> 8);
+    ts.py0 = max(0, (minY + 127) >> 8);
+    ts.px1 = min(Wi - 1, (maxX - 128) >> 8);
+    ts.py1 = min(Hi - 1, (maxY - 128) >> 8);
+    ts.area = 0;
+}
+
 __device__ __forceinline__ bool narrow_extent(const TriSetup& ts)
 {
     const int32_t extX = max(ts.X[0], max(ts.X[1], ts.X[2])) - min(ts.X[0], min(ts.X[1], ts.X[2]));
@@ -192,7 +213,9 @@ __device__ __forceinline__ void write_record(TriRec* dst, const TriSetup& ts, co
     TriRec r;
 #pragma unroll
     for (int i = 0; i < 3; i++) { r.X[i] = ts.X[i]; r.Y[i] = ts.Y[i]; r.d[i] = d[i]; }
-    r.payload = ts.payload; r.twoSided = twoSided ? 1u : 0u; r.pad = 0;
+    r.payload = ts.payload;
+    r.twoSided = (twoSided ? 1u : 0u) | (ts.s < 0 ? 2u : 0u);     // bit 1: orientation sign of the snapped triangle
+    r.pad = __float_as_uint(ts.invA);                             // 1 / float(2A): the tile kernel does not redo the division
     *dst = r;
 }
 
@@ -447,7 +470,7 @@ __global__ __launch_bounds__(256) void raster_bin_large_kernel(RasterParams p)
 #pragma unroll
         for (int i = 0; i < 3; i++) { ts.X[i] = r->X[i]; ts.Y[i] = r->Y[i]; }
         ts.payload = 0;
-        if (!tri_setup(ts, r->twoSided != 0, p.Wi, p.Hi)) continue;
+        if (!tri_setup(ts, (r->twoSided & 1u) != 0, p.Wi, p.Hi)) continue;
         const int ea[3] = {1, 2, 0}, eb[3] = {2, 0, 1};
         int64_t a[3], b[3], bias[3], dxe[3], dye[3];
 #pragma unroll
@@ -480,6 +503,43 @@ __global__ __launch_bounds__(256) void raster_bin_large_kernel(RasterParams p)
                 else atomicOr(&p.counters->overflow, 1u);
             }
         }
+    }
+}
+
+// ---- tile schedule: heaviest tiles first --------------------------------------------------------
+// The tile kernel's duration is its slowest tile plus whatever is still queued behind it, so tiles are
+// dispatched in descending order of their bin count (longest-processing-time first): one block
+// bucket-sorts the <= 4096 tile counts by floor(log2(count)).  Tiles without entries are listed last on
+// the first pass of a frame (they still have to be written: that is the clear) and dropped otherwise.
+__global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
+{
+    __shared__ uint32_t hist[20], base[20], cursor[20];
+    const uint32_t tiles = p.tilesX * p.tilesY;
+    if (threadIdx.x < 20u) { hist[threadIdx.x] = 0; cursor[threadIdx.x] = 0; }
+    __syncthreads();
+    uint32_t myBucket[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t t = threadIdx.x + k * 1024u;
+        myBucket[k] = 0xFFFFFFFFu;
+        if (t < tiles) {
+            const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], p.binCap);
+            // bucket 0 = heaviest (2^15..), bucket 16 = count 1, bucket 17 = empty
+            myBucket[k] = c ? 16u - (31u - (uint32_t)__clz(c)) : 17u;
+            atomicAdd(&hist[myBucket[k]], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int b = 0; b < 18; b++) { base[b] = acc; acc += hist[b]; }
+        p.tileOrder[0] = p.clearTiles ? tiles : tiles - hist[17];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t t = threadIdx.x + k * 1024u;
+        if (myBucket[k] != 0xFFFFFFFFu) p.tileOrder[1u + base[myBucket[k]] + atomicAdd(&cursor[myBucket[k]], 1u)] = t;
     }
 }
 
@@ -518,7 +578,9 @@ __device__ __forceinline__ void lds_write(unsigned long long* tile, int32_t lx, 
     atomicMax(&tile[ly * TILE + lx], packed);              // ds_max_u64
 }
 
-// one lane scans its own (tile-clipped) bbox with 32-bit edge functions
+// one lane scans its own (tile-clipped) tiny bbox with 32-bit edge functions.  ONE flattened loop over the
+// bbox pixels: with nested row/column loops a wave pays max(rows) x max(cols) over its lanes (a 1x16 and a
+// 16x1 box in the same wave = 256 trips); flattened it pays max(area) <= TINY_AREA.
 __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
                                                    int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels,
                                                    unsigned long long rowMask)
@@ -534,24 +596,25 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
     const int32_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 0 : -1;
     const int32_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 0 : -1;
     const int32_t cx0 = x0 * 256 + 128, cy0 = y0 * 256 + 128;
-    int32_t r0 = s * (dx0 * (cy0 - ts.Y[1]) - dy0 * (cx0 - ts.X[1]));
-    int32_t r1 = s * (dx1 * (cy0 - ts.Y[2]) - dy1 * (cx0 - ts.X[2]));
-    int32_t r2 = s * (dx2 * (cy0 - ts.Y[0]) - dy2 * (cx0 - ts.X[0]));
-    for (int32_t py = y0; py <= y1; py++) {
-        int32_t E0 = r0, E1 = r1, E2 = r2;
-        bool entered = false;
-        for (int32_t px = x0; px <= x1 && ((rowMask >> (py - oy)) & 1ull); px++) {
-            if (((E0 + bias0) | (E1 + bias1) | (E2 + bias2)) >= 0) {
-                const float l1 = (float)E1 * ts.invA, l2 = (float)E2 * ts.invA;
-                const float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
-                if (!noPixels) lds_write(tile, px - ox, py - oy, z, ts.payload);
-                entered = true;
-            } else if (entered) {
-                break;                                   // convex: the span of this row is over
-            }
-            E0 += a0 * 256; E1 += a1 * 256; E2 += a2 * 256;
+    int32_t r0 = s * (dx0 * (cy0 - ts.Y[1]) - dy0 * (cx0 - ts.X[1])) + bias0;   // bias folded in: inside <=> all >= 0
+    int32_t r1 = s * (dx1 * (cy0 - ts.Y[2]) - dy1 * (cx0 - ts.X[2])) + bias1;
+    int32_t r2 = s * (dx2 * (cy0 - ts.Y[0]) - dy2 * (cx0 - ts.X[0])) + bias2;
+    int32_t E0 = r0, E1 = r1, E2 = r2;
+    const int32_t w = x1 - x0 + 1, count = w * (y1 - y0 + 1);
+    int32_t lx = x0 - ox, ly = y0 - oy, col = 0;
+    for (int32_t i = 0; i < count; i++) {
+        if ((E0 | E1 | E2) >= 0 && ((rowMask >> ly) & 1ull)) {
+            const float l1 = (float)(E1 - bias1) * ts.invA, l2 = (float)(E2 - bias2) * ts.invA;
+            const float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
+            if (!noPixels) lds_write(tile, lx, ly, z, ts.payload);
         }
-        r0 += b0 * 256; r1 += b1 * 256; r2 += b2 * 256;
+        col++; lx++;
+        E0 += a0 * 256; E1 += a1 * 256; E2 += a2 * 256;
+        if (col == w) {
+            col = 0; lx = x0 - ox; ly++;
+            r0 += b0 * 256; r1 += b1 * 256; r2 += b2 * 256;
+            E0 = r0; E1 = r1; E2 = r2;
+        }
     }
 }
 
@@ -569,14 +632,35 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
 //   kind 2  int64   anything else (guard-band monsters)
 #define TINY_AREA 16
 
-struct UnitParams {           // 64 B in LDS per batch entry
+struct UnitParams {           // one batch entry, as the row loop wants it
     int32_t X[3], Y[3];
     float d0, e1, e2, invA;
     uint32_t payload;
     uint32_t box;             // x0 | y0 << 8 | x1 << 16 | y1 << 24, tile-local
     int32_t skind;            // s in bit 0 (1 = negative), kind << 1
-    uint32_t pad[3];
 };
+// LDS copy of the batch, structure-of-arrays: thread t writes word f at [f][t] (consecutive lanes ->
+// consecutive banks; the 64-byte-stride AoS form was a 32-way bank conflict on every store)
+#define UNIT_WORDS 13
+struct UnitParamsSoA { uint32_t w[UNIT_WORDS][256]; };
+
+__device__ __forceinline__ void unit_store(UnitParamsSoA& soa, uint32_t t, const UnitParams& u)
+{
+    soa.w[0][t] = (uint32_t)u.X[0]; soa.w[1][t] = (uint32_t)u.X[1]; soa.w[2][t] = (uint32_t)u.X[2];
+    soa.w[3][t] = (uint32_t)u.Y[0]; soa.w[4][t] = (uint32_t)u.Y[1]; soa.w[5][t] = (uint32_t)u.Y[2];
+    soa.w[6][t] = __float_as_uint(u.d0); soa.w[7][t] = __float_as_uint(u.e1); soa.w[8][t] = __float_as_uint(u.e2);
+    soa.w[9][t] = __float_as_uint(u.invA); soa.w[10][t] = u.payload; soa.w[11][t] = u.box; soa.w[12][t] = (uint32_t)u.skind;
+}
+
+__device__ __forceinline__ UnitParams unit_load(const UnitParamsSoA& soa, uint32_t t)
+{
+    UnitParams u;
+    u.X[0] = (int32_t)soa.w[0][t]; u.X[1] = (int32_t)soa.w[1][t]; u.X[2] = (int32_t)soa.w[2][t];
+    u.Y[0] = (int32_t)soa.w[3][t]; u.Y[1] = (int32_t)soa.w[4][t]; u.Y[2] = (int32_t)soa.w[5][t];
+    u.d0 = __uint_as_float(soa.w[6][t]); u.e1 = __uint_as_float(soa.w[7][t]); u.e2 = __uint_as_float(soa.w[8][t]);
+    u.invA = __uint_as_float(soa.w[9][t]); u.payload = soa.w[10][t]; u.box = soa.w[11][t]; u.skind = (int32_t)soa.w[12][t];
+    return u;
+}
 
 template <typename E_t>
 __device__ __forceinline__ void scan_row(unsigned long long* __restrict__ tileRow, const UnitParams& u, int32_t ox, int32_t py,
@@ -638,13 +722,17 @@ template <bool SH>
 __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
 {
     __shared__ unsigned long long tile[TILE * TILE];             // 32 KB
-    __shared__ UnitParams prm[256];                              // 16 KB
+    __shared__ UnitParamsSoA prm;                                // 13 KB
     __shared__ uint32_t offs[257];
     __shared__ uint32_t waveSums[4];
-    const uint32_t tileId = blockIdx.x;
+    const uint32_t active = p.tileOrder[0];
+    for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
+    const uint32_t tileId = p.tileOrder[1u + oi];
     const uint32_t n = min(p.tileCount[(size_t)tileId * TC_STRIDE], p.binCap);
-    const unsigned long long t0 = (p.debug & DBG_TILE_CLOCKS) ? wall_clock64() : 0ull;
-    if (n == 0 && !p.clearTiles) return;                          // untouched tile: global words stay as they are
+    const bool prof = (p.debug & DBG_TILE_CLOCKS) != 0;
+    const unsigned long long t0 = prof ? wall_clock64() : 0ull;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = t0;
+#define PHASE(i) do { if (prof) { __syncthreads(); const unsigned long long tn = wall_clock64(); ph[i] += tn - tp; tp = tn; } } while (0)
     const int32_t ox = (int32_t)(tileId % p.tilesX) * TILE, oy = (int32_t)(tileId / p.tilesX) * TILE;
     const int32_t tw = min(TILE, p.Wi - ox), th = min(TILE, p.Hi - oy);
     const bool noPixels = (p.debug & DBG_NO_PIXELS) != 0;
@@ -653,7 +741,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
     if (SH) {
         rowMask = 0ull;
         for (int32_t ly = 0; ly < th; ly++) if (owns_row<SH>(p.shard, oy + ly)) rowMask |= 1ull << ly;
-        if (rowMask == 0ull) return;                             // nothing of this tile belongs to the rank
+        if (rowMask == 0ull) continue;                           // nothing of this tile belongs to the rank
     }
 
     // ---- tile in: zeros on the first pass of a frame, else the current words (16 B per lane) ---
@@ -668,55 +756,65 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
         *reinterpret_cast<ulonglong2*>(&tile[ly * TILE + lx]) = v;
     }
     __syncthreads();
+    PHASE(0);
 
     // ---- scan-convert the bin, 256 entries per batch -------------------------------------------
+    // Software pipeline over the two dependent fetches of a batch (bin entry -> 48-byte record): the
+    // record of batch b+1 and the bin entry of batch b+2 are in flight while batch b is scan-converted.
     const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
+    uint32_t idxNext = threadIdx.x < n ? bin[threadIdx.x] : 0u;               // bin entry of batch 0
+    TriRec recNext;
+    if (threadIdx.x < n) recNext = p.tris[idxNext];                             // record of batch 0
+    idxNext = 256u + threadIdx.x < n ? bin[256u + threadIdx.x] : 0u;          // bin entry of batch 1
     for (uint32_t base = 0; base < n; base += 256u) {
         const uint32_t k = base + threadIdx.x;
+        const TriRec rec = recNext;
+        if (k + 256u < n) recNext = p.tris[idxNext];                            // record of the next batch
+        idxNext = k + 512u < n ? bin[k + 512u] : 0u;                            // bin entry of the batch after
+        if (prof) { volatile uint32_t sink = rec.payload; (void)sink; }
+        PHASE(1);
         uint32_t rows = 0;
         if (k < n) {
-            const TriRec* __restrict__ r = &p.tris[bin[k]];
             TriSetup ts;
-#pragma unroll
-            for (int i = 0; i < 3; i++) { ts.X[i] = r->X[i]; ts.Y[i] = r->Y[i]; }
-            ts.payload = r->payload;
-            const float d0 = r->d[0], d1 = r->d[1], d2 = r->d[2];
-            if (tri_setup(ts, r->twoSided != 0, p.Wi, p.Hi)) {
-                ts.d0 = d0; ts.e1 = d1 - d0; ts.e2 = d2 - d0;
+            tri_setup_from_record(ts, rec, p.Wi, p.Hi);
+            {
                 const int32_t x0 = max(ts.px0, ox), y0 = max(ts.py0, oy);
                 const int32_t x1 = min(ts.px1, ox + tw - 1), y1 = min(ts.py1, oy + th - 1);
                 if (x1 >= x0 && y1 >= y0) {
                     const bool narrow = narrow_extent(ts);
                     if (narrow && (x1 - x0 + 1) * (y1 - y0 + 1) <= TINY_AREA) {
-                        tile_raster_narrow(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask);
+                        if (!(p.debug & DBG_NO_TINY)) tile_raster_narrow(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask);
                     } else {
                         int32_t mag = 0;
 #pragma unroll
                         for (int i = 0; i < 3; i++) mag = max(mag, max(abs(ts.X[i]), abs(ts.Y[i])));
                         const int32_t kind = narrow ? 0 : (mag < (1 << 25) ? 1 : 2);
-                        UnitParams& u = prm[threadIdx.x];
+                        UnitParams u;
 #pragma unroll
                         for (int i = 0; i < 3; i++) { u.X[i] = ts.X[i]; u.Y[i] = ts.Y[i]; }
                         u.d0 = ts.d0; u.e1 = ts.e1; u.e2 = ts.e2; u.invA = ts.invA; u.payload = ts.payload;
                         u.box = (uint32_t)(x0 - ox) | ((uint32_t)(y0 - oy) << 8) | ((uint32_t)(x1 - ox) << 16) | ((uint32_t)(y1 - oy) << 24);
                         u.skind = (ts.s < 0 ? 1 : 0) | (kind << 1);
+                        unit_store(prm, threadIdx.x, u);
                         rows = (uint32_t)(y1 - y0 + 1);
                     }
                 }
             }
         }
+        PHASE(2);
         uint32_t total;
         const uint32_t off = block_scan_256(rows, waveSums, &total);
         offs[threadIdx.x] = off;
         if (threadIdx.x == 0) offs[256] = total;
         __syncthreads();
+        PHASE(3);
         for (uint32_t u0 = 0; u0 < total; u0 += 256u) {
             const uint32_t ui = u0 + threadIdx.x;
             if (ui < total) {
                 uint32_t e = 0;                                   // last entry with offs[e] <= ui
 #pragma unroll
                 for (uint32_t st = 128; st > 0; st >>= 1) if (offs[e + st] <= ui) e += st;
-                const UnitParams& u = prm[e];
+                const UnitParams u = unit_load(prm, e);
                 const int32_t ly = (int32_t)((u.box >> 8) & 0xFFu) + (int32_t)(ui - offs[e]);
                 if ((rowMask >> ly) & 1ull) {
                     const int32_t lx0 = (int32_t)(u.box & 0xFFu), lx1 = (int32_t)((u.box >> 16) & 0xFFu);
@@ -729,6 +827,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
             }
         }
         __syncthreads();                                          // prm / offs are rewritten by the next batch
+        PHASE(4);
     }
     __syncthreads();
 
@@ -741,7 +840,13 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
         if (lx + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = v;
         else dst[0] = v.x;
     }
-    if ((p.debug & DBG_TILE_CLOCKS) && threadIdx.x == 0) p.tileClocks[tileId] = wall_clock64() - t0;
+    PHASE(5);
+    if (prof && threadIdx.x == 0) {
+        p.tileClocks[tileId] = wall_clock64() - t0;
+        for (int i = 0; i < 6; i++) p.tilePhase[(size_t)tileId * 8 + i] = ph[i];
+    }
+    __syncthreads();                                              // the LDS tile is reused by the next iteration
+    }
 }
 
 // ---- launcher ---------------------------------------------------------------------------------
@@ -766,6 +871,8 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.clearTiles = clearTiles ? 1u : 0u;
     p.debug = c->debugFlags;
     p.tileClocks = c->dTileClocks + (size_t)pass * CHORD_MAX_TILES;
+    p.tileOrder = c->dTileOrder;
+    p.tilePhase = c->dTileClocks + (size_t)2 * CHORD_MAX_TILES + (size_t)pass * CHORD_MAX_TILES * 8;
 
     // A frame zeroes every count once (begin_frame_clear); outside a frame, or from the third raster
     // call of a frame on, the pass slot is recycled here.
@@ -787,9 +894,13 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     stamp(c, S_R_CLUSTER);
     hipLaunchKernelGGL(raster_clip_kernel, dim3(clipBlocks), dim3(256), 0, c->stream, p);
     hipLaunchKernelGGL(raster_bin_large_kernel, dim3((uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
     stamp(c, S_R_CLIP);
-    if (sh) hipLaunchKernelGGL(raster_tile_kernel<true>, dim3(tiles), dim3(256), 0, c->stream, p);
-    else    hipLaunchKernelGGL(raster_tile_kernel<false>, dim3(tiles), dim3(256), 0, c->stream, p);
+    // first pass of a frame: every tile is written, one block each, dispatched heaviest first; later passes touch
+    // few tiles: one resident wave of blocks strides over the (device-side) active list
+    const uint32_t tileBlocks = clearTiles ? tiles : min(tiles, (uint32_t)c->numCUs * 3u);
+    if (sh) hipLaunchKernelGGL(raster_tile_kernel<true>, dim3(tileBlocks), dim3(256), 0, c->stream, p);
+    else    hipLaunchKernelGGL(raster_tile_kernel<false>, dim3(tileBlocks), dim3(256), 0, c->stream, p);
     stamp(c, S_R_CHUNK);
     c->rasterCalls++;
 }

@@ -8,14 +8,17 @@ scene, cam = scenes.config3_street()
 L.fill_objects(scene, cam); view, iv = L.make_views(cam)
 flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | (R.FLAG_HZB_CULL if len(sys.argv) > 1 and sys.argv[1] == "hzb" else 0)
 r = VisibilityRenderer(0); r.upload_scene(scene); r.allocate_gbuffer(cam.width, cam.height); r.set_view(view, iv, flags)
-r.set_debug(16)
+r.set_debug(16 | (int(sys.argv[2]) if len(sys.argv) > 2 else 0))
 for _ in range(3): r.render_frame()
 tx, ty = (cam.width + 63) // 64, (cam.height + 63) // 64
 for p in (0, 1):
-    ticks = np.zeros(tx * ty, np.uint64); cnt = np.zeros(tx * ty, np.uint32)
-    assert L.lib.chordvis_debug_tile_profile(r._ctx, p, ticks.ctypes.data, cnt.ctypes.data, tx * ty) == 0
+    ticks = np.zeros(tx * ty * 9, np.uint64); cnt = np.zeros(tx * ty, np.uint32)
+    assert L.lib.chordvis_debug_tile_profile(r._ctx, p, ticks.ctypes.data, cnt.ctypes.data, tx * ty * 9) == 0
+    phase = ticks[tx * ty:].reshape(tx * ty, 8).astype(np.float64) / 100.0
+    ticks = ticks[:tx * ty]
     us = ticks.astype(np.float64) / 100.0
-    order = np.argsort(-us)[:12]
+    print("phase sums (us) in/load/setup/scan/units/out:", np.round(phase[:, :6].sum(axis=0), 0))
+    order = np.argsort(-us)[:4]
     print("pass", p, "entries", int(cnt.sum()), "max bin", int(cnt.max()), "tile us: sum %.0f mean %.1f max %.1f" % (us.sum(), us.mean(), us.max()))
-    for t in order: print("   tile (%2d,%2d) %7.1f us  bin %5d" % (t % tx, t // tx, us[t], cnt[t]))
+    for t in order: print("   tile (%2d,%2d) %7.1f us  bin %5d  phases" % (t % tx, t // tx, us[t], cnt[t]), np.round(phase[t, :6], 1))
     print("   corr(us, bin) = %.3f" % np.corrcoef(us, cnt)[0, 1])
