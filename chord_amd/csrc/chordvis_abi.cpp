@@ -106,6 +106,7 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         c->binCap = 16384;              // 4K: 2 passes x 2040 tiles x 16384 x 4 B = 267 MB
         if ((rc = dalloc(c, &c->dTileBins, (size_t)2 * c->tilesX * c->tilesY * c->binCap))) return rc;
     }
+    if ((rc = dalloc(c, &c->dTileRange, (size_t)2 * CHORD_MAX_TILES))) return rc;
     {   // one {min, max} partial per block of the mip-0 kernel (64 x 4 texels per block)
         const uint32_t vw = (c->width + 1) / 2, vh = (c->height + 1) / 2;
         if ((rc = dalloc(c, &c->dRangePartials, (size_t)((vw + 63) / 64) * ((vh + 3) / 4) * 2))) return rc;
@@ -246,7 +247,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
-    dfree(c->dRangePartials); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTileBins);
+    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTileBins);
     dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -594,20 +595,28 @@ int chordvis_render_frame(ChordCtx* c)
     ChordHZB hist;
     const bool haveHist = c->historySlot != 0;
     if (haveHist) hist = c->hzb[c->historySlot].handle();
+    const int next = c->historySlot == 1 ? 2 : 1;
+    // buildHZB is fused into the raster: the tile kernel reduces every finished 64x64 tile to mips 0..5 of the
+    // chain kept as history (and of the temporary chain stage 1 culls against); only the one-block tail remains.
+    c->fuseHzb = true;
+    c->fuseHzbSlot = next;
+    c->fuseHzbTemp = haveHist && (c->hView.flags & CHORD_FLAG_HZB_CULL);
     ChordCountAndCmd rejected;
     int stage1 = 0;
-    if ((rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1))) return rc;   // :326
+    rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1);   // :326
     record(c, S_STAGE0_END);
     c->shouldStage1 = stage1 != 0;
-    if (stage1) {
-        ChordHZB tmp;
-        if ((rc = chordvis_build_hzb(c, 1, 0, 0, 0, &tmp))) return rc;                // :334
+    if (!rc && stage1) {
+        launch_hzb_tail(c, c->hzb[0], false, false);                                  // buildHZB(min)  :334
         record(c, S_HZB0);
-        if ((rc = chordvis_visibility_stage1(c, &tmp, rejected))) return rc;          // :337
+        ChordHZB tmp = c->hzb[0].handle();
+        rc = chordvis_visibility_stage1(c, &tmp, rejected);                           // :337
         record(c, S_STAGE1_END);
     }
-    const int next = c->historySlot == 1 ? 2 : 1;
-    if ((rc = chordvis_build_hzb(c, 1, 1, 1, next, nullptr))) return rc;              // :343
+    c->fuseHzb = false;
+    if (rc) return rc;
+    launch_hzb_tail(c, c->hzb[next], true, true);                                     // buildHZB(min,max,range)  :343
+    CHORD_HIP(c, hipGetLastError());
     record(c, S_HZBF);
     c->historySlot = next;                                                            // :489
     c->inFrame = false;

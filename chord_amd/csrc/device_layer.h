@@ -181,6 +181,10 @@ struct ChordCtx {
     chord::HzbBuffers hzb[3];
     int historySlot = 0;              // 0 = none, else 1 or 2
     uint32_t* dRangePartials = nullptr;   // per mip-0 block {min, max} of valid depth
+    uint32_t* dTileRange = nullptr;       // per 64x64 tile {min, max} of valid depth (fused HZB)
+    bool fuseHzb = false;                 // inside render_frame: the tile kernel emits HZB mips 0..5
+    bool fuseHzbTemp = false;             // ... also into the temporary chain (slot 0) for stage 1
+    int fuseHzbSlot = 1;                  // history slot being produced this frame
     uint16_t* dHzbExchange = nullptr;
     uint64_t hzbExchangeHalves = 0, hzbExchangeChunkHalves = 0;
 
@@ -232,6 +236,7 @@ void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdLis
 void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles);
 void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange, bool fromExchange);
 void launch_hzb_mip0_exchange(ChordCtx* c);
+void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange);   // mips 6.. + range from per-tile partials
 void launch_detile(ChordCtx* c);
 void stamp(ChordCtx* c, int tag);               // no-op when timers are off
 

@@ -285,6 +285,17 @@ void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool b
     out.valid = true;
 }
 
+// After a raster pass with the fused reduction (mips 0..5 written by raster_tile_kernel): only the tail is left.
+void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange)
+{
+    HzbParams p = make_params(c, out);
+    p.rangePartials = c->dTileRange;
+    p.rangePartialCount = c->tilesX * c->tilesY;
+    if (p.desc.mipCount > 6 || bValidRange)
+        hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, bMax ? 1 : 0, bValidRange ? 1 : 0);
+    out.valid = true;
+}
+
 void launch_detile(ChordCtx* c)
 {
     const dim3 g((c->width + 255u) / 256u > 8u ? 8u : (c->width + 255u) / 256u, c->height);

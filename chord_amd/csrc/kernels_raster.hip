@@ -18,7 +18,7 @@
 //   raster_tile_kernel    one workgroup per 64x64 tile: the tile's 4096 packed words live in LDS
 //                         (32 KB); every binned triangle is scan-converted with ds_max_u64
 //                         (tiny: one lane per triangle; others: cut into (triangle, row) units that a
-//                         block-wide prefix sum deals out one row per lane), then the
+//                         block-wide prefix sum deals out one row per lane).  Tile-out: on the first pass
 //                         tile is written back with 16-byte coalesced stores (and, on the first pass
 //                         of a frame, this is also the clear).
 // The packed word is (asuint(depth) << 32) | ((slot+1)&0xFFFFFF)<<8 | tri: reverse-Z "greater wins"
@@ -55,6 +55,12 @@ struct RasterParams {
     uint32_t* largeList; uint32_t largeCap;                  // records touching more than 2x2 tiles (binned by raster_bin_large_kernel)
     DeviceCounters* counters;
     uint32_t* tileOrder;                                // [0] = active tile count, [1..] tile ids, heaviest first
+    // fused HZB (single-GPU frames): the tile kernel reduces its finished 64x64 tile to mips 0..5
+    uint32_t hzbFused;                                  // 0: off (later passes merge with global atomicMax)
+    ChordHZBDesc hzbDesc;
+    uint16_t* hzbMinA;                                  // temporary chain for stage 1 (first pass only) or NULL
+    uint16_t* hzbMinB; uint16_t* hzbMaxB;               // chain kept as history
+    uint32_t* tileRange;                                // per tile {min bits, max bits} of valid depth
     unsigned long long* tileClocks;                     // debug: per-tile elapsed wall clock ticks (DBG_TILE_CLOCKS)
     unsigned long long* tilePhase;                      // debug: 8 phase accumulators per tile
     uint32_t clearTiles;                                // first raster pass of a frame: tiles start from 0
@@ -64,6 +70,7 @@ struct RasterParams {
 #define DBG_NO_BIN      2u    // setup only: no records, no bins
 #define DBG_TILE_CLOCKS 16u   // tile kernel writes its elapsed wall-clock ticks per tile
 #define DBG_NO_TINY     32u   // tile kernel skips the per-lane scan of tiny triangles
+#define DBG_TILE_EXIT   64u   // tile kernel of passes >= 1 returns at once (launch-floor measurement)
 
 __device__ __forceinline__ int32_t bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
@@ -718,6 +725,99 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t* waveSum
     return base + incl - v;
 }
 
+// Reduces the finished tile (64x64 packed words in LDS) to HZB mips 0..5 — the 32x32 ... 1x1 texels this tile
+// owns — exactly as hzb_mip0_kernel + hzb_mips_kernel would from memory (edge-clamped source, binary16 RNE,
+// +1 ulp on the max chain at mip 5, hzb.hlsl:67-71), and to the tile's valid-depth range partial.
+__device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const unsigned long long* tile, float (*sMin)[17], float (*sMax)[17],
+                                                uint32_t* sRange, uint32_t tileId, int32_t tw, int32_t th)
+{
+    const ChordHZBDesc& d = p.hzbDesc;
+    const uint32_t tX = tileId % p.tilesX, tY = tileId / p.tilesX;
+    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(tile);        // depth = odd dwords
+    auto vw = [&](uint32_t l) { return min(max(1u, d.width >> l), (((d.srcWidth - 1u) >> 1) >> l) + 1u); };
+    auto vh = [&](uint32_t l) { return min(max(1u, d.height >> l), (((d.srcHeight - 1u) >> 1) >> l) + 1u); };
+    float mn1 = 0.0f, mx1 = 0.0f;
+    uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t lx0 = 2u * tx + i, ly0 = 2u * ty + j;           // mip-0 texel inside the tile (32x32)
+            float mn = 0.0f, mx = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const int32_t px = min((int32_t)(2u * lx0 + a), tw - 1), py = min((int32_t)(2u * ly0 + b), th - 1);
+                    const float dp = __uint_as_float(words[(py * TILE + px) * 2 + 1]);
+                    if (a == 0 && b == 0) { mn = dp; mx = dp; } else { mn = fminf(mn, dp); mx = fmaxf(mx, dp); }
+                    if (dp > 0.0f) {                                        // hzb.hlsl:163-176
+                        const uint32_t bits = __float_as_uint(dp);
+                        if (dp < 1.0f) rmin = min(rmin, bits);
+                        rmax = max(rmax, bits);
+                    }
+                }
+            const uint32_t gx = tX * 32u + lx0, gy = tY * 32u + ly0;
+            if (gx < vw(0) && gy < vh(0)) {
+                const size_t o = d.mipOffset[0] + (size_t)gy * max(1u, d.width) + gx;
+                const uint16_t hmn = f32_to_f16(mn);
+                if (p.hzbMinA) p.hzbMinA[o] = hmn;
+                p.hzbMinB[o] = hmn;
+                p.hzbMaxB[o] = f32_to_f16(mx);
+            }
+            if (i == 0 && j == 0) { mn1 = mn; mx1 = mx; } else { mn1 = fminf(mn1, mn); mx1 = fmaxf(mx1, mx); }
+        }
+    {
+        const uint32_t gx = tX * 16u + tx, gy = tY * 16u + ty;
+        if (d.mipCount > 1 && gx < vw(1) && gy < vh(1)) {
+            const size_t o = d.mipOffset[1] + (size_t)gy * max(1u, d.width >> 1) + gx;
+            const uint16_t hmn = f32_to_f16(mn1);
+            if (p.hzbMinA) p.hzbMinA[o] = hmn;
+            p.hzbMinB[o] = hmn;
+            p.hzbMaxB[o] = f32_to_f16(mx1);
+        }
+        sMin[ty][tx] = mn1; sMax[ty][tx] = mx1;
+    }
+#pragma unroll
+    for (uint32_t l = 2; l <= 5; l++) {
+        __syncthreads();
+        const uint32_t side = 32u >> l;                                     // 8, 4, 2, 1
+        const bool act = tx < side && ty < side && l < d.mipCount;
+        float rmn = 0.0f, rmx = 0.0f;
+        if (act) {
+            rmn = fminf(fminf(sMin[2 * ty][2 * tx], sMin[2 * ty][2 * tx + 1]), fminf(sMin[2 * ty + 1][2 * tx], sMin[2 * ty + 1][2 * tx + 1]));
+            rmx = fmaxf(fmaxf(sMax[2 * ty][2 * tx], sMax[2 * ty][2 * tx + 1]), fmaxf(sMax[2 * ty + 1][2 * tx], sMax[2 * ty + 1][2 * tx + 1]));
+        }
+        __syncthreads();
+        if (act) {
+            const uint32_t gx = tX * side + tx, gy = tY * side + ty;
+            uint16_t hmn = f32_to_f16(rmn), hmx = f32_to_f16(rmx);
+            if (l == 5) hmx = (uint16_t)(hmx + 1u);                         // storeHZBMip5
+            if (gx < vw(l) && gy < vh(l)) {
+                const size_t o = d.mipOffset[l] + (size_t)gy * max(1u, d.width >> l) + gx;
+                if (p.hzbMinA) p.hzbMinA[o] = hmn;
+                p.hzbMinB[o] = hmn;
+                p.hzbMaxB[o] = hmx;
+            }
+            sMin[ty][tx] = rmn; sMax[ty][tx] = rmx;
+        }
+    }
+    // valid-range partial of this tile (reduced over tiles by hzb_tail_kernel)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        rmin = min(rmin, (uint32_t)__shfl_down(rmin, off, 64));
+        rmax = max(rmax, (uint32_t)__shfl_down(rmax, off, 64));
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0u) { sRange[(threadIdx.x >> 6) * 2] = rmin; sRange[(threadIdx.x >> 6) * 2 + 1] = rmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p.tileRange[2u * tileId] = min(min(sRange[0], sRange[2]), min(sRange[4], sRange[6]));
+        p.tileRange[2u * tileId + 1u] = max(max(sRange[1], sRange[3]), max(sRange[5], sRange[7]));
+    }
+}
+
 template <bool SH>
 __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
 {
@@ -725,6 +825,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
     __shared__ UnitParamsSoA prm;                                // 13 KB
     __shared__ uint32_t offs[257];
     __shared__ uint32_t waveSums[4];
+    if ((p.debug & DBG_TILE_EXIT) && !p.clearTiles) return;
     const uint32_t active = p.tileOrder[0];
     for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
     const uint32_t tileId = p.tileOrder[1u + oi];
@@ -744,11 +845,13 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
         if (rowMask == 0ull) continue;                           // nothing of this tile belongs to the rank
     }
 
-    // ---- tile in: zeros on the first pass of a frame, else the current words (16 B per lane) ---
+    // ---- tile in: zero (first pass: this is the clear; un-fused later passes merge by max at tile-out), or the
+    //      current words when a later pass must leave the finished tile in LDS for the fused HZB reduction ----
+    const bool rmw = p.hzbFused && !p.clearTiles;
     for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += 256u) {
         const int32_t ly = (int32_t)(i >> 5), lx = (int32_t)(i & 31u) * 2;
         ulonglong2 v = make_ulonglong2(0ull, 0ull);
-        if (!p.clearTiles && ly < th && lx < tw && owns_row<SH>(p.shard, oy + ly)) {
+        if (rmw && ly < th && lx < tw) {
             const unsigned long long* src = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
             if (lx + 1 < tw) v = *reinterpret_cast<const ulonglong2*>(src);
             else v.x = src[0];
@@ -831,14 +934,33 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
     }
     __syncthreads();
 
-    // ---- tile out: 16-byte coalesced stores (owned rows only when sharded) ---------------------
-    for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += 256u) {
-        const int32_t ly = (int32_t)(i >> 5), lx = (int32_t)(i & 31u) * 2;
-        if (ly >= th || lx >= tw || !owns_row<SH>(p.shard, oy + ly)) continue;
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&tile[ly * TILE + lx]);
-        unsigned long long* dst = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
-        if (lx + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = v;
-        else dst[0] = v.x;
+    // ---- tile out ------------------------------------------------------------------------------------
+    if (p.clearTiles || rmw) {
+        // first pass of the frame: every word is written (16-byte coalesced stores); this is the clear.
+        // (fused-HZB later passes loaded the tile, so they store it back whole as well)
+        for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += 256u) {
+            const int32_t ly = (int32_t)(i >> 5), lx = (int32_t)(i & 31u) * 2;
+            if (ly >= th || lx >= tw || !owns_row<SH>(p.shard, oy + ly)) continue;
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&tile[ly * TILE + lx]);
+            unsigned long long* dst = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
+            if (lx + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = v;
+            else dst[0] = v.x;
+        }
+    } else {
+        // later passes: only the pixels this pass touched are merged, with a row-coalesced global atomicMax
+        // (8 lanes per 64-byte line) — no read-modify-write of the whole tile
+        for (uint32_t i = threadIdx.x; i < TILE * TILE; i += 256u) {
+            const int32_t ly = (int32_t)(i >> 6), lx = (int32_t)(i & 63u);
+            const unsigned long long v = tile[i];
+            if (v != 0ull && ly < th && lx < tw && owns_row<SH>(p.shard, oy + ly))
+                atomicMax(p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx, v);
+        }
+    }
+    if (p.hzbFused) {
+        // the batch buffers are free now: reuse them for the mip reduction
+        float (*sMin)[17] = reinterpret_cast<float (*)[17]>(&prm.w[0][0]);
+        float (*sMax)[17] = reinterpret_cast<float (*)[17]>(&prm.w[2][0]);
+        tile_hzb_reduce(p, tile, sMin, sMax, offs, tileId, tw, th);
     }
     PHASE(5);
     if (prof && threadIdx.x == 0) {
@@ -853,6 +975,13 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
 void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
 {
     RasterParams p;
+    p.hzbFused = 0; p.hzbMinA = nullptr; p.hzbMinB = nullptr; p.hzbMaxB = nullptr; p.tileRange = c->dTileRange;
+    p.hzbDesc = c->hzb[0].desc;
+    if (c->fuseHzb && c->shard.ranks == 1) {
+        p.hzbFused = 1;
+        p.hzbMinA = (clearTiles && c->fuseHzbTemp) ? c->hzb[0].minTexels : nullptr;
+        p.hzbMinB = c->hzb[c->fuseHzbSlot].minTexels; p.hzbMaxB = c->hzb[c->fuseHzbSlot].maxTexels;
+    }
     p.count = in.count; p.cmds = in.cmds;
     p.objFrame = c->dObjFrame; p.objStatic = c->dObjStatic;
     p.meshlets = c->dMeshlets; p.meshletData = c->dMeshletData; p.positions = c->dPositions;

@@ -5,11 +5,18 @@ import numpy as np
 from chord_amd import lib as L, records as R, scenes
 from chord_amd.renderer import VisibilityRenderer
 scene, cam = scenes.config3_street()
-L.fill_objects(scene, cam); view, iv = L.make_views(cam)
+import numpy as _np
+f = _np.array(cam.front); f = f / _np.linalg.norm(f)
+cam_b = cam.moved(tuple(0.5 * f))
+va0, _ = L.make_views(cam); vb0, _ = L.make_views(cam_b)
+views = [L.make_views(cam, vb0), L.make_views(cam_b, va0)]
+objs = [L.fill_objects(scene, cam, cam_b).copy(), L.fill_objects(scene, cam_b, cam).copy()]
+view, iv = views[0]
 flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | (R.FLAG_HZB_CULL if len(sys.argv) > 1 and sys.argv[1] == "hzb" else 0)
 r = VisibilityRenderer(0); r.upload_scene(scene); r.allocate_gbuffer(cam.width, cam.height); r.set_view(view, iv, flags)
 r.set_debug(16 | (int(sys.argv[2]) if len(sys.argv) > 2 else 0))
-for _ in range(3): r.render_frame()
+for i in range(5):      # alternate the two bench cameras; profile the last frame (view A after view B)
+    r.update_objects(objs[i & 1]); r.set_view(views[i & 1][0], views[i & 1][1], flags); r.render_frame()
 tx, ty = (cam.width + 63) // 64, (cam.height + 63) // 64
 for p in (0, 1):
     ticks = np.zeros(tx * ty * 9, np.uint64); cnt = np.zeros(tx * ty, np.uint32)
