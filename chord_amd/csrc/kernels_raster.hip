@@ -169,42 +169,65 @@ __device__ __forceinline__ bool narrow_extent(const TriSetup& ts)
 // ---- record + bin emission --------------------------------------------------------------------
 
 // One bin slot per lane, reserved with ONE atomic per distinct tile in the wave: lanes that target the
-// same tile elect a leader, all leaders issue their atomicAdd in a single wave instruction, and the
-// base is handed back through the lanes.  (64 lanes hitting one counter would serialise at the L2.)
-__device__ __forceinline__ uint32_t wave_bin_reserve(uint32_t* tileCount, bool has, uint32_t tile, uint32_t lane)
+// same tile elect a leader (pure ALU), all leaders issue their atomicAdd in a single wave instruction, and
+// the base is handed back through the lanes.  (64 lanes hitting one counter would serialise at the L2.)
+struct BinElect { int leader; uint32_t rank, group; };
+
+__device__ __forceinline__ BinElect wave_bin_elect(bool has, uint32_t tile, uint32_t lane)
 {
+    BinElect e; e.leader = 0; e.rank = 0; e.group = 0;
     unsigned long long todo = __ballot(has);
-    int leader = 0;
-    uint32_t rank = 0, group = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
     while (todo) {
         const int l = __ffsll((long long)todo) - 1;
         const uint32_t k = bcast(tile, l);
         const unsigned long long same = __ballot(has && tile == k);
-        if (has && tile == k) { leader = l; rank = (uint32_t)__popcll(same & lt); group = (uint32_t)__popcll(same); }
+        if (has && tile == k) { e.leader = l; e.rank = (uint32_t)__popcll(same & lt); e.group = (uint32_t)__popcll(same); }
         todo &= ~same;
     }
-    uint32_t base = 0;
-    if (has && (int)lane == leader) base = atomicAdd(&tileCount[(size_t)tile * TC_STRIDE], group);
-    base = __shfl(base, leader, 64);
-    return base + rank;
+    return e;
 }
 
-// Bins a record whose clamped bbox touches at most 2x2 tiles (all lanes of the wave call this).
-__device__ __forceinline__ void wave_bin_small(const RasterParams& p, bool emit, const TriSetup& ts, uint32_t gi, uint32_t lane)
+// Bins two records per lane (triangles lane and lane + 64 of the meshlet) whose clamped bboxes touch at most
+// 2x2 tiles each; the atomics of both are issued before either result is waited for.
+__device__ __forceinline__ void wave_bin_small2(const RasterParams& p, bool emitA, const TriSetup& tsA, uint32_t giA,
+                                                bool emitB, const TriSetup& tsB, uint32_t giB, uint32_t lane)
 {
-    const int32_t tx0 = ts.px0 >> TILE_SHIFT, tx1 = ts.px1 >> TILE_SHIFT;
-    const int32_t ty0 = ts.py0 >> TILE_SHIFT, ty1 = ts.py1 >> TILE_SHIFT;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int32_t tx = (r & 1) ? tx1 : tx0, ty = (r & 2) ? ty1 : ty0;
-        bool has = emit && !((r & 1) && tx1 == tx0) && !((r & 2) && ty1 == ty0);
-        if (has) has = owns_any_row(p.shard, max(ts.py0, ty << TILE_SHIFT), min(ts.py1, (ty << TILE_SHIFT) + TILE - 1));
-        if (!__ballot(has)) continue;
-        const uint32_t tile = has ? (uint32_t)ty * p.tilesX + (uint32_t)tx : 0u;
-        const uint32_t slot = wave_bin_reserve(p.tileCount, has, tile, lane);
-        if (has) {
-            if (slot < p.binCap) p.tileBins[(size_t)tile * p.binCap + slot] = gi;
+        bool hasA = emitA, hasB = emitB;
+        uint32_t tileA = 0, tileB = 0;
+        {
+            const int32_t tx0 = tsA.px0 >> TILE_SHIFT, tx1 = tsA.px1 >> TILE_SHIFT, ty0 = tsA.py0 >> TILE_SHIFT, ty1 = tsA.py1 >> TILE_SHIFT;
+            const int32_t tx = (r & 1) ? tx1 : tx0, ty = (r & 2) ? ty1 : ty0;
+            hasA = hasA && !((r & 1) && tx1 == tx0) && !((r & 2) && ty1 == ty0);
+            if (hasA) hasA = owns_any_row(p.shard, max(tsA.py0, ty << TILE_SHIFT), min(tsA.py1, (ty << TILE_SHIFT) + TILE - 1));
+            if (hasA) tileA = (uint32_t)ty * p.tilesX + (uint32_t)tx;
+        }
+        {
+            const int32_t tx0 = tsB.px0 >> TILE_SHIFT, tx1 = tsB.px1 >> TILE_SHIFT, ty0 = tsB.py0 >> TILE_SHIFT, ty1 = tsB.py1 >> TILE_SHIFT;
+            const int32_t tx = (r & 1) ? tx1 : tx0, ty = (r & 2) ? ty1 : ty0;
+            hasB = hasB && !((r & 1) && tx1 == tx0) && !((r & 2) && ty1 == ty0);
+            if (hasB) hasB = owns_any_row(p.shard, max(tsB.py0, ty << TILE_SHIFT), min(tsB.py1, (ty << TILE_SHIFT) + TILE - 1));
+            if (hasB) tileB = (uint32_t)ty * p.tilesX + (uint32_t)tx;
+        }
+        const unsigned long long anyA = __ballot(hasA), anyB = __ballot(hasB);
+        if (!(anyA | anyB)) continue;
+        const BinElect eA = wave_bin_elect(hasA, tileA, lane);
+        const BinElect eB = wave_bin_elect(hasB, tileB, lane);
+        uint32_t baseA = 0, baseB = 0;
+        if (hasA && (int)lane == eA.leader) baseA = atomicAdd(&p.tileCount[(size_t)tileA * TC_STRIDE], eA.group);
+        if (hasB && (int)lane == eB.leader) baseB = atomicAdd(&p.tileCount[(size_t)tileB * TC_STRIDE], eB.group);
+        baseA = __shfl(baseA, eA.leader, 64);
+        baseB = __shfl(baseB, eB.leader, 64);
+        if (hasA) {
+            const uint32_t slot = baseA + eA.rank;
+            if (slot < p.binCap) p.tileBins[(size_t)tileA * p.binCap + slot] = giA;
+            else atomicOr(&p.counters->overflow, 1u);
+        }
+        if (hasB) {
+            const uint32_t slot = baseB + eB.rank;
+            if (slot < p.binCap) p.tileBins[(size_t)tileB * p.binCap + slot] = giB;
             else atomicOr(&p.counters->overflow, 1u);
         }
     }
@@ -280,11 +303,18 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(RasterParams p)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- triangle phase -------------------------------------------------------------------
-        for (uint32_t tb = 0; tb < T; tb += 64u) {
-            const uint32_t t = tb + lane;
+        // ---- triangle phase: the (up to) two triangles of a lane are evaluated first, then emitted together so
+        //      that every round of list / bin reservations costs ONE atomic round trip for both ------------------
+        int kindA = K_NONE, kindB = K_NONE;
+        TriSetup tsA, tsB;
+        float dA[3] = {0.0f, 0.0f, 0.0f}, dB[3] = {0.0f, 0.0f, 0.0f};
+        tsA.px0 = tsA.py0 = tsA.px1 = tsA.py1 = 0; tsB.px0 = tsB.py0 = tsB.px1 = tsB.py1 = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const uint32_t t = (uint32_t)half * 64u + lane;
             int kind = K_NONE;
             TriSetup ts;
+            ts.px0 = ts.py0 = ts.px1 = ts.py1 = 0;
             float d[3] = {0.0f, 0.0f, 0.0f};
             if (t < T) {
                 const uint32_t packedIdx = p.meshletData[dataOffset + V + t];
@@ -317,55 +347,60 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(RasterParams p)
                 }
             }
             if (p.debug & DBG_NO_BIN) kind = K_NONE;
-
-            // clip list: wave-aggregated append
-            {
-                const unsigned long long cm = __ballot(kind == K_CLIP);
-                if (cm) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&p.counters->clipTriCount[p.pass], (uint32_t)__popcll(cm));
-                    base = bcast(base, 0);
-                    if (kind == K_CLIP) {
-                        const uint32_t k = base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
-                        if (k < p.clipTriCap) { ClipTri ct; ct.cmdIndex = cu; ct.tri = t; p.clipTris[k] = ct; }
-                        else atomicOr(&p.counters->overflow, 2u);
-                    }
-                }
+            if (half == 0) { kindA = kind; tsA = ts; dA[0] = d[0]; dA[1] = d[1]; dA[2] = d[2]; }
+            else           { kindB = kind; tsB = ts; dB[0] = d[0]; dB[1] = d[1]; dB[2] = d[2]; }
+        }
+        {
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long cmA = __ballot(kindA == K_CLIP), cmB = __ballot(kindB == K_CLIP);
+            const unsigned long long emA = __ballot(kindA == K_EMIT), emB = __ballot(kindB == K_EMIT);
+            const bool lgA = kindA == K_EMIT && touches_many_tiles(tsA), lgB = kindB == K_EMIT && touches_many_tiles(tsB);
+            const unsigned long long lmA = __ballot(lgA), lmB = __ballot(lgB);
+            const uint32_t nClip = (uint32_t)(__popcll(cmA) + __popcll(cmB)), nEm = (uint32_t)(__popcll(emA) + __popcll(emB));
+            const uint32_t nLg = (uint32_t)(__popcll(lmA) + __popcll(lmB));
+            // the three list reservations of the wave travel together: one atomic round trip
+            uint32_t cbase = 0, ebase = 0, lbase = 0;
+            if (lane == 0) {
+                if (nClip) cbase = atomicAdd(&p.counters->clipTriCount[p.pass], nClip);
+                if (nEm) ebase = atomicAdd(&p.counters->triCount[listShard], nEm);
+                if (nLg) lbase = atomicAdd(&p.counters->largeCount[p.pass], nLg);
             }
-            // triangle records: one reservation per wave, contiguous 48-byte records, then the bins
-            {
-                const unsigned long long em = __ballot(kind == K_EMIT);
-                if (em) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&p.counters->triCount[listShard], (uint32_t)__popcll(em));
-                    base = bcast(base, 0);
-                    uint32_t gi = 0;
-                    bool ok = false;
-                    if (kind == K_EMIT) {
-                        const uint32_t li = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-                        if (li < p.triCap) {
-                            gi = listShard * p.triCap + li;
-                            write_record(&p.tris[gi], ts, d, twoSided);
-                            ok = true;
-                        } else {
-                            atomicOr(&p.counters->overflow, 1u);
-                        }
-                    }
-                    // <= 2x2 tiles: straight into the bins; more: the large list (one reservation per wave)
-                    const bool large = ok && touches_many_tiles(ts);
-                    wave_bin_small(p, ok && !large, ts, gi, lane);
-                    const unsigned long long lm = __ballot(large);
-                    if (lm) {
-                        uint32_t lbase = 0;
-                        if (lane == 0) lbase = atomicAdd(&p.counters->largeCount[p.pass], (uint32_t)__popcll(lm));
-                        lbase = bcast(lbase, 0);
-                        if (large) {
-                            const uint32_t k = lbase + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull));
-                            if (k < p.largeCap) p.largeList[k] = gi;
-                            else atomicOr(&p.counters->overflow, 1u);
-                        }
-                    }
+            cbase = bcast(cbase, 0); ebase = bcast(ebase, 0); lbase = bcast(lbase, 0);
+            if (kindA == K_CLIP || kindB == K_CLIP) {
+                const bool isA = kindA == K_CLIP;     // at most one of the two is handled per statement below
+                if (kindA == K_CLIP) {
+                    const uint32_t k = cbase + (uint32_t)__popcll(cmA & lt);
+                    if (k < p.clipTriCap) { ClipTri ct; ct.cmdIndex = cu; ct.tri = lane; p.clipTris[k] = ct; }
+                    else atomicOr(&p.counters->overflow, 2u);
                 }
+                if (kindB == K_CLIP) {
+                    const uint32_t k = cbase + (uint32_t)__popcll(cmA) + (uint32_t)__popcll(cmB & lt);
+                    if (k < p.clipTriCap) { ClipTri ct; ct.cmdIndex = cu; ct.tri = lane + 64u; p.clipTris[k] = ct; }
+                    else atomicOr(&p.counters->overflow, 2u);
+                }
+                (void)isA;
+            }
+            uint32_t giA = 0, giB = 0;
+            bool okA = false, okB = false;
+            if (kindA == K_EMIT) {
+                const uint32_t li = ebase + (uint32_t)__popcll(emA & lt);
+                if (li < p.triCap) { giA = listShard * p.triCap + li; write_record(&p.tris[giA], tsA, dA, twoSided); okA = true; }
+                else atomicOr(&p.counters->overflow, 1u);
+            }
+            if (kindB == K_EMIT) {
+                const uint32_t li = ebase + (uint32_t)__popcll(emA) + (uint32_t)__popcll(emB & lt);
+                if (li < p.triCap) { giB = listShard * p.triCap + li; write_record(&p.tris[giB], tsB, dB, twoSided); okB = true; }
+                else atomicOr(&p.counters->overflow, 1u);
+            }
+            // <= 2x2 tiles: straight into the bins; more: the large list
+            if (emA | emB) wave_bin_small2(p, okA && !lgA, tsA, giA, okB && !lgB, tsB, giB, lane);
+            if (lgA && okA) {
+                const uint32_t k = lbase + (uint32_t)__popcll(lmA & lt);
+                if (k < p.largeCap) p.largeList[k] = giA; else atomicOr(&p.counters->overflow, 1u);
+            }
+            if (lgB && okB) {
+                const uint32_t k = lbase + (uint32_t)__popcll(lmA) + (uint32_t)__popcll(lmB & lt);
+                if (k < p.largeCap) p.largeList[k] = giB; else atomicOr(&p.counters->overflow, 1u);
             }
         }
         // LDS of this wave is rewritten by the next cluster: order the reads above before those writes
