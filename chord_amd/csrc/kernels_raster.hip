@@ -12,9 +12,9 @@
 //                         clip-space transform -> LDS (SoA x,y,w,u,v,depth) -> per-triangle culls
 //                         (mesh_raster.hlsl:143-179) -> snapped setup -> 48-byte triangle record
 //                         appended to a device list + one bin entry per 64x64 screen tile touched
-//   raster_clip_kernel    homogeneous Sutherland-Hodgman clipper for triangles touching the near /
-//                         guard planes (rare), emits records + bin entries the same way
-//   raster_bin_large_kernel  records touching more than 2x2 tiles: one wave per record, one lane per tile
+//   raster_clip_and_bin_large_kernel  one launch, two roles: (a) homogeneous Sutherland-Hodgman clipper for
+//                         triangles touching the near / guard planes (rare; emits + bins its pieces itself),
+//                         (b) records touching more than 2x2 tiles: one wave per record, one lane per tile
 //   raster_tile_kernel    one workgroup per 64x64 tile: the tile's 4096 packed words live in LDS
 //                         (32 KB); every binned triangle is scan-converted with ds_max_u64
 //                         (tiny: one lane per triangle; others: cut into (triangle, row) units that a
@@ -409,6 +409,33 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(RasterParams p)
     }
 }
 
+// One lane bins one record into every tile its clamped bbox may touch (conservative edge test at the tile
+// corners).  Only the clipper uses it; the hot paths go through wave_bin_small2 / raster_bin_large_kernel.
+__device__ void bin_record_tiles(const RasterParams& p, const TriSetup& ts, uint32_t gi)
+{
+    const int ea[3] = {1, 2, 0}, eb[3] = {2, 0, 1};
+    const int32_t tx0 = ts.px0 >> TILE_SHIFT, tx1 = ts.px1 >> TILE_SHIFT;
+    const int32_t ty0 = ts.py0 >> TILE_SHIFT, ty1 = ts.py1 >> TILE_SHIFT;
+    for (int32_t ty = ty0; ty <= ty1; ty++)
+        for (int32_t tx = tx0; tx <= tx1; tx++) {
+            const int32_t rx0 = max(ts.px0, tx << TILE_SHIFT), rx1 = min(ts.px1, (tx << TILE_SHIFT) + TILE - 1);
+            const int32_t ry0 = max(ts.py0, ty << TILE_SHIFT), ry1 = min(ts.py1, (ty << TILE_SHIFT) + TILE - 1);
+            bool hit = owns_any_row(p.shard, ry0, ry1);
+            for (int i = 0; i < 3 && hit; i++) {
+                const int64_t dxe = (int64_t)(ts.X[eb[i]] - ts.X[ea[i]]), dye = (int64_t)(ts.Y[eb[i]] - ts.Y[ea[i]]);
+                const int64_t a = -(int64_t)ts.s * dye, b = (int64_t)ts.s * dxe;
+                const int64_t bias = (a > 0 || (a == 0 && b > 0)) ? 0 : -1;
+                const int64_t cx = (int64_t)(a > 0 ? rx1 : rx0) * 256 + 128, cy = (int64_t)(b > 0 ? ry1 : ry0) * 256 + 128;
+                hit = !((int64_t)ts.s * (dxe * (cy - ts.Y[ea[i]]) - dye * (cx - ts.X[ea[i]])) + bias < 0);
+            }
+            if (!hit) continue;
+            const uint32_t tile = (uint32_t)ty * p.tilesX + (uint32_t)tx;
+            const uint32_t slot = atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE], 1u);
+            if (slot < p.binCap) p.tileBins[(size_t)tile * p.binCap + slot] = gi;
+            else atomicOr(&p.counters->overflow, 1u);
+        }
+}
+
 // ---- clipper kernel (rare path) ---------------------------------------------------------------
 __device__ __forceinline__ float clip_dist(const f4& v, int k)
 {
@@ -433,11 +460,11 @@ __device__ __forceinline__ f4 clip_intersect(const f4& in, const f4& out, float 
     return r;
 }
 
-__global__ __launch_bounds__(256) void raster_clip_kernel(RasterParams p)
+__device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t blocks)
 {
     const uint32_t n = min(p.counters->clipTriCount[p.pass], p.clipTriCap);
-    const uint32_t listShard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % CHORD_LIST_SHARDS;
-    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+    const uint32_t listShard = (block * 4u + (threadIdx.x >> 6)) % CHORD_LIST_SHARDS;
+    for (uint32_t k = block * 256u + threadIdx.x; k < n; k += blocks * 256u) {
         const ClipTri ct = p.clipTris[k];
         const ChordDrawCmd cmd = p.cmds[ct.cmdIndex];
         const DMeshlet& m = p.meshlets[cmd.meshletId];
@@ -492,20 +519,20 @@ __global__ __launch_bounds__(256) void raster_clip_kernel(RasterParams p)
             if (li >= p.triCap) { atomicOr(&p.counters->overflow, 1u); continue; }
             const uint32_t gi = listShard * p.triCap + li;
             write_record(&p.tris[gi], ts, d, twoSided);
-            // clipped pieces are rare and usually large: always through the large list
-            const uint32_t k2 = atomicAdd(&p.counters->largeCount[p.pass], 1u);
-            if (k2 < p.largeCap) p.largeList[k2] = gi;
-            else atomicOr(&p.counters->overflow, 1u);
+            // clipped pieces are rare: binned right here, one (scattered) atomic per tile they may touch
+            bin_record_tiles(p, ts, gi);
         }
     }
 }
 
 // ---- large triangles: one wave per record, one lane per candidate tile -------------------------
-__global__ __launch_bounds__(256) void raster_bin_large_kernel(RasterParams p)
+// One launch, two independent roles: the first CLIP_BLOCKS blocks run the clipper, the rest bin the large records.
+#define CLIP_BLOCKS 64u
+__device__ void raster_bin_large_part(const RasterParams& p, uint32_t block, uint32_t blocks)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t n = min(p.counters->largeCount[p.pass], p.largeCap);
-    for (uint32_t k = blockIdx.x * 4u + wave; k < n; k += gridDim.x * 4u) {
+    for (uint32_t k = block * 4u + wave; k < n; k += blocks * 4u) {
         const uint32_t gi = __builtin_amdgcn_readfirstlane(p.largeList[__builtin_amdgcn_readfirstlane(k)]);
         const TriRec* __restrict__ r = &p.tris[gi];
         TriSetup ts;
@@ -546,6 +573,12 @@ __global__ __launch_bounds__(256) void raster_bin_large_kernel(RasterParams p)
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterParams p)
+{
+    if (blockIdx.x < CLIP_BLOCKS) raster_clip_part(p, blockIdx.x, CLIP_BLOCKS);
+    else raster_bin_large_part(p, blockIdx.x - CLIP_BLOCKS, gridDim.x - CLIP_BLOCKS);
 }
 
 // ---- tile schedule: heaviest tiles first --------------------------------------------------------
@@ -1051,13 +1084,11 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     const uint32_t maxBlocks = (uint32_t)c->numCUs * 6u;
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
-    const uint32_t clipBlocks = (uint32_t)c->numCUs;
     const bool sh = c->shard.ranks > 1;
     stamp(c, S_HZBCULL);      // closes whatever preceded the raster (HZB cull / list reset)
     hipLaunchKernelGGL(raster_setup_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
     stamp(c, S_R_CLUSTER);
-    hipLaunchKernelGGL(raster_clip_kernel, dim3(clipBlocks), dim3(256), 0, c->stream, p);
-    hipLaunchKernelGGL(raster_bin_large_kernel, dim3((uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(raster_clip_and_bin_large_kernel, dim3(CLIP_BLOCKS + (uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
     hipLaunchKernelGGL(raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
     stamp(c, S_R_CLIP);
     // first pass of a frame: every tile is written, one block each, dispatched heaviest first; later passes touch
