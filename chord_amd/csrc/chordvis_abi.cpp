@@ -102,8 +102,8 @@ int configure_targets(ChordCtx* c, uint64_t* external)
     for (int i = 0; i < 3; i++) if ((rc = alloc_hzb(c, c->hzb[i]))) return rc;
     c->historySlot = 0;
     {   // per-tile triangle bins of the rasterizer: 64x64-pixel tiles, binCap entries each
-        c->tilesX = (c->width + 63) / 64; c->tilesY = (c->height + 63) / 64;
-        c->binCap = 16384;              // 4K: 2 passes x 2040 tiles x 16384 x 4 B = 267 MB
+        c->tilesX = (c->width + CHORD_TILE - 1) >> CHORD_TILE_SHIFT; c->tilesY = (c->height + CHORD_TILE - 1) >> CHORD_TILE_SHIFT;
+        c->binCap = CHORD_BIN_CAP;              // 4K: 2 passes x 2040 tiles x 16384 x 4 B = 267 MB
         if ((rc = dalloc(c, &c->dTileBins, (size_t)2 * c->tilesX * c->tilesY * c->binCap))) return rc;
     }
     if ((rc = dalloc(c, &c->dTileRange, (size_t)2 * CHORD_MAX_TILES))) return rc;
@@ -168,7 +168,7 @@ int begin_frame_clear(ChordCtx* c)
 {
     // counters, the four command-list counts and both passes' tile bin counts: zeroed by the frame's first
     // kernel (object_cull), not by a separate memset
-    c->frameStateZeroBytes = offsetof(FrameState, tileCount) + sizeof(uint32_t) * CHORD_TILECOUNT_STRIDE * (CHORD_MAX_TILES + (size_t)c->tilesX * c->tilesY);
+    c->frameStateZeroBytes = offsetof(FrameState, tileCount) + sizeof(uint32_t) * CHORD_TILECOUNT_STRIDE * ((size_t)2 * c->tilesX * c->tilesY);
     c->zeroFrameStateInCull = true;
     c->rasterCalls = 0;
     c->pendingClear = true;
@@ -757,7 +757,7 @@ int chordvis_debug_tile_profile(ChordCtx* c, int pass, uint64_t* hostTicks, uint
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
     const size_t n = (size_t)c->tilesX * c->tilesY;
     CHORD_HIP(c, hipMemcpy(hostTicks, c->dTileClocks + (size_t)pass * CHORD_MAX_TILES, n * 8, hipMemcpyDeviceToHost));
-    CHORD_HIP(c, hipMemcpy2D(hostCounts, 4, c->dFrameState->tileCount[pass], 4 * CHORD_TILECOUNT_STRIDE, 4, n, hipMemcpyDeviceToHost));
+    CHORD_HIP(c, hipMemcpy2D(hostCounts, 4, c->dFrameState->tileCount + (size_t)pass * c->tilesX * c->tilesY * CHORD_TILECOUNT_STRIDE, 4 * CHORD_TILECOUNT_STRIDE, 4, n, hipMemcpyDeviceToHost));
     if (capacity >= 9 * n)   // optional: 8 phase accumulators per tile follow the totals
         CHORD_HIP(c, hipMemcpy(hostTicks + n, c->dTileClocks + (size_t)2 * CHORD_MAX_TILES + (size_t)pass * CHORD_MAX_TILES * 8, n * 64, hipMemcpyDeviceToHost));
     return CHORDVIS_OK;
@@ -798,7 +798,7 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
     if (c->tilesX) {
         std::vector<uint32_t> tc((size_t)c->tilesX * c->tilesY);
         for (int pass = 0; pass < 2; pass++) {
-            CHORD_HIP(c, hipMemcpy2D(tc.data(), 4, c->dFrameState->tileCount[pass], 4 * CHORD_TILECOUNT_STRIDE, 4, tc.size(), hipMemcpyDeviceToHost));
+            CHORD_HIP(c, hipMemcpy2D(tc.data(), 4, c->dFrameState->tileCount + (size_t)pass * c->tilesX * c->tilesY * CHORD_TILECOUNT_STRIDE, 4 * CHORD_TILECOUNT_STRIDE, 4, tc.size(), hipMemcpyDeviceToHost));
             for (uint32_t v : tc) { out->binEntries += v; out->tilesTouched[pass] += v ? 1u : 0u; }
         }
     }

@@ -96,12 +96,22 @@ struct DeviceCounters {
 
 // Everything a frame zeroes lives in ONE allocation so the frame starts with one memset:
 // counters, the four command-list counts, and the per-pass tile bin counts (2 x tiles follow).
-#define CHORD_MAX_TILES 4096u                    // (4096 / 64)^2, renderer.h:52-53 caps the render size
+#ifndef CHORD_TILE_SHIFT
+#define CHORD_TILE_SHIFT 6                       // log2 of the raster tile side in pixels (5 or 6)
+#endif
+#define CHORD_TILE (1 << CHORD_TILE_SHIFT)
+#define CHORD_MAX_TILES ((4096u >> CHORD_TILE_SHIFT) * (4096u >> CHORD_TILE_SHIFT))   // renderer.h:52-53 caps the render size at 4096^2
+#if CHORD_TILE_SHIFT == 6
 #define CHORD_TILECOUNT_STRIDE 16u               // one bin counter per 64-byte line
+#define CHORD_BIN_CAP 16384u
+#else
+#define CHORD_TILECOUNT_STRIDE 4u                // four bin counters per 64-byte line
+#define CHORD_BIN_CAP 8192u
+#endif
 struct FrameState {
     DeviceCounters counters;
     uint32_t listCounts[4];
-    uint32_t tileCount[2][CHORD_MAX_TILES * CHORD_TILECOUNT_STRIDE];
+    uint32_t tileCount[2 * CHORD_MAX_TILES * CHORD_TILECOUNT_STRIDE];   // pass p starts at p * tiles * stride
 };
 
 struct CmdList {

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void hzb_mips_kernel(HzbParams p, int wantMax)
 }
 
 // One block: mips 6..mipCount-1 from the stored mip 5, and the valid-range reduction.
-__global__ __launch_bounds__(256) void hzb_tail_kernel(HzbParams p, int wantMax, int wantRange)
+__global__ __launch_bounds__(256) void hzb_tail_kernel(HzbParams p, int wantMax, int wantRange, uint32_t firstLevel)
 {
     const ChordHZBDesc& d = p.desc;
     if (wantRange) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void hzb_tail_kernel(HzbParams p, int wantMax,
         }
         if (threadIdx.x == 0) { p.validRange[0] = sMn[0]; p.validRange[1] = sMx[0]; }   // init {~0u, 0u}: hzb.cpp:108-109
     }
-    for (uint32_t l = 6; l < d.mipCount; l++) {
+    for (uint32_t l = firstLevel; l < d.mipCount; l++) {
         const uint32_t vw = valid_w(d, l), vh = valid_h(d, l), mw = max(1u, d.width >> l);
         const uint32_t pw = valid_w(d, l - 1), ph = valid_h(d, l - 1), pmw = max(1u, d.width >> (l - 1));
         for (uint32_t i = threadIdx.x; i < vw * vh; i += 256u) {
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void hzb_tail_kernel(HzbParams p, int wantMax,
                     if (ii == 0 && jj == 0) { mn = a; mx = b; } else { mn = fminf(mn, a); mx = fmaxf(mx, b); }
                 }
             p.hzbMin[d.mipOffset[l] + y * mw + x] = f32_to_f16(mn);
-            if (wantMax) p.hzbMax[d.mipOffset[l] + y * mw + x] = f32_to_f16(mx);
+            if (wantMax) p.hzbMax[d.mipOffset[l] + y * mw + x] = (uint16_t)(f32_to_f16(mx) + (l == 5u ? 1u : 0u));   // storeHZBMip5
         }
         __syncthreads();       // level l complete and visible to this block before level l+1
     }
@@ -281,7 +281,7 @@ void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool b
     const dim3 g1((vw + 31u) / 32u, (vh + 31u) / 32u);
     if (fromExchange) hipLaunchKernelGGL(hzb_mips_kernel<true>, g1, dim3(256), 0, c->stream, p, 0);
     else              hipLaunchKernelGGL(hzb_mips_kernel<false>, g1, dim3(256), 0, c->stream, p, wantMax);
-    if (p.desc.mipCount > 6 || wantRange) hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, wantMax, wantRange);
+    if (p.desc.mipCount > 6 || wantRange) hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, wantMax, wantRange, 6u);
     out.valid = true;
 }
 
@@ -291,8 +291,8 @@ void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange)
     HzbParams p = make_params(c, out);
     p.rangePartials = c->dTileRange;
     p.rangePartialCount = c->tilesX * c->tilesY;
-    if (p.desc.mipCount > 6 || bValidRange)
-        hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, bMax ? 1 : 0, bValidRange ? 1 : 0);
+    if (p.desc.mipCount > (uint32_t)CHORD_TILE_SHIFT || bValidRange)
+        hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, bMax ? 1 : 0, bValidRange ? 1 : 0, (uint32_t)CHORD_TILE_SHIFT);
     out.valid = true;
 }
 

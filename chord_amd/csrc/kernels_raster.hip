@@ -37,8 +37,8 @@ namespace chord {
 
 #define GUARD_BAND 1024.0f
 #define LDS_VERTS 256
-#define TILE 64                 // pixels per tile side
-#define TILE_SHIFT 6
+#define TILE CHORD_TILE         // pixels per tile side
+#define TILE_SHIFT CHORD_TILE_SHIFT
 #define SMALL_AREA 256          // clipped bbox pixels a single lane scans on its own
 #define TC_STRIDE CHORD_TILECOUNT_STRIDE   // one bin counter per 64-byte line (no false sharing between tiles)
 
@@ -592,9 +592,10 @@ __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
     const uint32_t tiles = p.tilesX * p.tilesY;
     if (threadIdx.x < 20u) { hist[threadIdx.x] = 0; cursor[threadIdx.x] = 0; }
     __syncthreads();
-    uint32_t myBucket[4];
+    constexpr uint32_t PER_THREAD = CHORD_MAX_TILES / 1024u;
+    uint32_t myBucket[PER_THREAD];
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
+    for (uint32_t k = 0; k < PER_THREAD; k++) {
         const uint32_t t = threadIdx.x + k * 1024u;
         myBucket[k] = 0xFFFFFFFFu;
         if (t < tiles) {
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
     }
     __syncthreads();
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
+    for (uint32_t k = 0; k < PER_THREAD; k++) {
         const uint32_t t = threadIdx.x + k * 1024u;
         if (myBucket[k] != 0xFFFFFFFFu) p.tileOrder[1u + base[myBucket[k]] + atomicAdd(&cursor[myBucket[k]], 1u)] = t;
     }
@@ -717,7 +718,8 @@ struct UnitParams {           // one batch entry, as the row loop wants it
 // LDS copy of the batch, structure-of-arrays: thread t writes word f at [f][t] (consecutive lanes ->
 // consecutive banks; the 64-byte-stride AoS form was a 32-way bank conflict on every store)
 #define UNIT_WORDS 13
-struct UnitParamsSoA { uint32_t w[UNIT_WORDS][256]; };
+#define TB 512                  // threads per tile workgroup = entries per batch
+struct UnitParamsSoA { uint32_t w[UNIT_WORDS][TB]; };
 
 __device__ __forceinline__ void unit_store(UnitParamsSoA& soa, uint32_t t, const UnitParams& u)
 {
@@ -774,8 +776,8 @@ __device__ __forceinline__ void scan_row(unsigned long long* __restrict__ tileRo
     }
 }
 
-// exclusive scan of one value per thread over the 256-thread block
-__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t* waveSums, uint32_t* total)
+// exclusive scan of one value per thread over the TB-thread block
+__device__ __forceinline__ uint32_t block_scan_tb(uint32_t v, uint32_t* waveSums, uint32_t* total)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = v;
@@ -788,12 +790,12 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t* waveSum
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < 4; w++) { const uint32_t sw = waveSums[w]; if (w < wave) base += sw; tot += sw; }
+    for (uint32_t w = 0; w < TB / 64u; w++) { const uint32_t sw = waveSums[w]; if (w < wave) base += sw; tot += sw; }
     *total = tot;
     return base + incl - v;
 }
 
-// Reduces the finished tile (64x64 packed words in LDS) to HZB mips 0..5 — the 32x32 ... 1x1 texels this tile
+// Reduces the finished tile (TILE^2 packed words in LDS) to HZB mips 0..log2(TILE)-1 — the (TILE/2)^2 ... 1x1 texels this tile
 // owns — exactly as hzb_mip0_kernel + hzb_mips_kernel would from memory (edge-clamped source, binary16 RNE,
 // +1 ulp on the max chain at mip 5, hzb.hlsl:67-71), and to the tile's valid-depth range partial.
 __device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const unsigned long long* tile, float (*sMin)[17], float (*sMax)[17],
@@ -801,17 +803,22 @@ __device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const uns
 {
     const ChordHZBDesc& d = p.hzbDesc;
     const uint32_t tX = tileId % p.tilesX, tY = tileId / p.tilesX;
-    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t tx = threadIdx.x & 15u, ty = (threadIdx.x >> 4) & 15u;
+    const bool hz = threadIdx.x < 256u;                                    // the reduction runs on a 16x16 thread grid
     const uint32_t* words = reinterpret_cast<const uint32_t*>(tile);        // depth = odd dwords
     auto vw = [&](uint32_t l) { return min(max(1u, d.width >> l), (((d.srcWidth - 1u) >> 1) >> l) + 1u); };
     auto vh = [&](uint32_t l) { return min(max(1u, d.height >> l), (((d.srcHeight - 1u) >> 1) >> l) + 1u); };
+    constexpr uint32_t M0 = TILE / 2;                  // mip-0 texels per tile side
+    constexpr int Q = (int)(M0 / 16u);                 // mip-0 texels per thread side (the block is 16x16 threads)
+    constexpr uint32_t L0 = Q == 2 ? 1u : 0u;          // level the 16x16 LDS grid holds after the per-thread part
     float mn1 = 0.0f, mx1 = 0.0f;
     uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
+    if (hz) {
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < Q; j++)
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t lx0 = 2u * tx + i, ly0 = 2u * ty + j;           // mip-0 texel inside the tile (32x32)
+        for (int i = 0; i < Q; i++) {
+            const uint32_t lx0 = (uint32_t)Q * tx + i, ly0 = (uint32_t)Q * ty + j;   // mip-0 texel inside the tile
             float mn = 0.0f, mx = 0.0f;
 #pragma unroll
             for (int b = 0; b < 2; b++)
@@ -826,7 +833,7 @@ __device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const uns
                         rmax = max(rmax, bits);
                     }
                 }
-            const uint32_t gx = tX * 32u + lx0, gy = tY * 32u + ly0;
+            const uint32_t gx = tX * M0 + lx0, gy = tY * M0 + ly0;
             if (gx < vw(0) && gy < vh(0)) {
                 const size_t o = d.mipOffset[0] + (size_t)gy * max(1u, d.width) + gx;
                 const uint16_t hmn = f32_to_f16(mn);
@@ -836,9 +843,10 @@ __device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const uns
             }
             if (i == 0 && j == 0) { mn1 = mn; mx1 = mx; } else { mn1 = fminf(mn1, mn); mx1 = fmaxf(mx1, mx); }
         }
-    {
+    }
+    if (hz) {
         const uint32_t gx = tX * 16u + tx, gy = tY * 16u + ty;
-        if (d.mipCount > 1 && gx < vw(1) && gy < vh(1)) {
+        if (Q == 2 && d.mipCount > 1 && gx < vw(1) && gy < vh(1)) {
             const size_t o = d.mipOffset[1] + (size_t)gy * max(1u, d.width >> 1) + gx;
             const uint16_t hmn = f32_to_f16(mn1);
             if (p.hzbMinA) p.hzbMinA[o] = hmn;
@@ -848,10 +856,10 @@ __device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const uns
         sMin[ty][tx] = mn1; sMax[ty][tx] = mx1;
     }
 #pragma unroll
-    for (uint32_t l = 2; l <= 5; l++) {
+    for (uint32_t l = L0 + 1u; l < (uint32_t)TILE_SHIFT; l++) {
         __syncthreads();
-        const uint32_t side = 32u >> l;                                     // 8, 4, 2, 1
-        const bool act = tx < side && ty < side && l < d.mipCount;
+        const uint32_t side = 16u >> (l - L0);                              // 8, 4, 2, 1
+        const bool act = hz && tx < side && ty < side && l < d.mipCount;
         float rmn = 0.0f, rmx = 0.0f;
         if (act) {
             rmn = fminf(fminf(sMin[2 * ty][2 * tx], sMin[2 * ty][2 * tx + 1]), fminf(sMin[2 * ty + 1][2 * tx], sMin[2 * ty + 1][2 * tx + 1]));
@@ -880,19 +888,19 @@ __device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const uns
     __syncthreads();
     if ((threadIdx.x & 63u) == 0u) { sRange[(threadIdx.x >> 6) * 2] = rmin; sRange[(threadIdx.x >> 6) * 2 + 1] = rmax; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {                                                // waves 0..3 hold the 16x16 grid
         p.tileRange[2u * tileId] = min(min(sRange[0], sRange[2]), min(sRange[4], sRange[6]));
         p.tileRange[2u * tileId + 1u] = max(max(sRange[1], sRange[3]), max(sRange[5], sRange[7]));
     }
 }
 
 template <bool SH>
-__global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
+__global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
 {
     __shared__ unsigned long long tile[TILE * TILE];             // 32 KB
     __shared__ UnitParamsSoA prm;                                // 13 KB
-    __shared__ uint32_t offs[257];
-    __shared__ uint32_t waveSums[4];
+    __shared__ uint32_t offs[TB + 1];
+    __shared__ uint32_t waveSums[TB / 64];
     if ((p.debug & DBG_TILE_EXIT) && !p.clearTiles) return;
     const uint32_t active = p.tileOrder[0];
     for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
@@ -916,8 +924,8 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
     // ---- tile in: zero (first pass: this is the clear; un-fused later passes merge by max at tile-out), or the
     //      current words when a later pass must leave the finished tile in LDS for the fused HZB reduction ----
     const bool rmw = p.hzbFused && !p.clearTiles;
-    for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += 256u) {
-        const int32_t ly = (int32_t)(i >> 5), lx = (int32_t)(i & 31u) * 2;
+    for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
+        const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
         ulonglong2 v = make_ulonglong2(0ull, 0ull);
         if (rmw && ly < th && lx < tw) {
             const unsigned long long* src = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
@@ -936,12 +944,12 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
     uint32_t idxNext = threadIdx.x < n ? bin[threadIdx.x] : 0u;               // bin entry of batch 0
     TriRec recNext;
     if (threadIdx.x < n) recNext = p.tris[idxNext];                             // record of batch 0
-    idxNext = 256u + threadIdx.x < n ? bin[256u + threadIdx.x] : 0u;          // bin entry of batch 1
-    for (uint32_t base = 0; base < n; base += 256u) {
+    idxNext = TB + threadIdx.x < n ? bin[TB + threadIdx.x] : 0u;          // bin entry of batch 1
+    for (uint32_t base = 0; base < n; base += TB) {
         const uint32_t k = base + threadIdx.x;
         const TriRec rec = recNext;
-        if (k + 256u < n) recNext = p.tris[idxNext];                            // record of the next batch
-        idxNext = k + 512u < n ? bin[k + 512u] : 0u;                            // bin entry of the batch after
+        if (k + TB < n) recNext = p.tris[idxNext];                            // record of the next batch
+        idxNext = k + 2u * TB < n ? bin[k + 2u * TB] : 0u;                            // bin entry of the batch after
         if (prof) { volatile uint32_t sink = rec.payload; (void)sink; }
         PHASE(1);
         uint32_t rows = 0;
@@ -974,17 +982,17 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
         }
         PHASE(2);
         uint32_t total;
-        const uint32_t off = block_scan_256(rows, waveSums, &total);
+        const uint32_t off = block_scan_tb(rows, waveSums, &total);
         offs[threadIdx.x] = off;
-        if (threadIdx.x == 0) offs[256] = total;
+        if (threadIdx.x == 0) offs[TB] = total;
         __syncthreads();
         PHASE(3);
-        for (uint32_t u0 = 0; u0 < total; u0 += 256u) {
+        for (uint32_t u0 = 0; u0 < total; u0 += TB) {
             const uint32_t ui = u0 + threadIdx.x;
             if (ui < total) {
                 uint32_t e = 0;                                   // last entry with offs[e] <= ui
 #pragma unroll
-                for (uint32_t st = 128; st > 0; st >>= 1) if (offs[e + st] <= ui) e += st;
+                for (uint32_t st = TB / 2; st > 0; st >>= 1) if (offs[e + st] <= ui) e += st;
                 const UnitParams u = unit_load(prm, e);
                 const int32_t ly = (int32_t)((u.box >> 8) & 0xFFu) + (int32_t)(ui - offs[e]);
                 if ((rowMask >> ly) & 1ull) {
@@ -1006,8 +1014,8 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
     if (p.clearTiles || rmw) {
         // first pass of the frame: every word is written (16-byte coalesced stores); this is the clear.
         // (fused-HZB later passes loaded the tile, so they store it back whole as well)
-        for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += 256u) {
-            const int32_t ly = (int32_t)(i >> 5), lx = (int32_t)(i & 31u) * 2;
+        for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
+            const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
             if (ly >= th || lx >= tw || !owns_row<SH>(p.shard, oy + ly)) continue;
             const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&tile[ly * TILE + lx]);
             unsigned long long* dst = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
@@ -1017,8 +1025,8 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(RasterParams p)
     } else {
         // later passes: only the pixels this pass touched are merged, with a row-coalesced global atomicMax
         // (8 lanes per 64-byte line) — no read-modify-write of the whole tile
-        for (uint32_t i = threadIdx.x; i < TILE * TILE; i += 256u) {
-            const int32_t ly = (int32_t)(i >> 6), lx = (int32_t)(i & 63u);
+        for (uint32_t i = threadIdx.x; i < TILE * TILE; i += TB) {
+            const int32_t ly = (int32_t)(i >> TILE_SHIFT), lx = (int32_t)(i & (TILE - 1));
             const unsigned long long v = tile[i];
             if (v != 0ull && ly < th && lx < tw && owns_row<SH>(p.shard, oy + ly))
                 atomicMax(p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx, v);
@@ -1059,7 +1067,7 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.tris = c->dTris; p.triCap = c->triCap / CHORD_LIST_SHARDS;
     const uint32_t tiles = c->tilesX * c->tilesY;
     const uint32_t pass = c->rasterCalls & 1u;
-    p.tileCount = c->dFrameState->tileCount[pass];
+    p.tileCount = c->dFrameState->tileCount + (size_t)pass * tiles * TC_STRIDE;
     p.tileBins = c->dTileBins + (size_t)pass * tiles * c->binCap; p.binCap = c->binCap;
     p.tilesX = c->tilesX; p.tilesY = c->tilesY;
     p.clipTris = c->dClipTris + (size_t)pass * (c->clipTriCap / 2); p.clipTriCap = c->clipTriCap / 2; p.pass = pass;
@@ -1093,9 +1101,9 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     stamp(c, S_R_CLIP);
     // first pass of a frame: every tile is written, one block each, dispatched heaviest first; later passes touch
     // few tiles: one resident wave of blocks strides over the (device-side) active list
-    const uint32_t tileBlocks = clearTiles ? tiles : min(tiles, (uint32_t)c->numCUs * 3u);
-    if (sh) hipLaunchKernelGGL(raster_tile_kernel<true>, dim3(tileBlocks), dim3(256), 0, c->stream, p);
-    else    hipLaunchKernelGGL(raster_tile_kernel<false>, dim3(tileBlocks), dim3(256), 0, c->stream, p);
+    const uint32_t tileBlocks = clearTiles ? tiles : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
+    if (sh) hipLaunchKernelGGL(raster_tile_kernel<true>, dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+    else    hipLaunchKernelGGL(raster_tile_kernel<false>, dim3(tileBlocks), dim3(TB), 0, c->stream, p);
     stamp(c, S_R_CHUNK);
     c->rasterCalls++;
 }
