@@ -39,6 +39,9 @@ namespace chord {
 #define LDS_VERTS 256
 #define TILE CHORD_TILE         // pixels per tile side
 #define TILE_SHIFT CHORD_TILE_SHIFT
+// LDS row pitch of the tile in 8-byte words: one word of padding rotates the banks by 2 per row, so lanes
+// that walk different rows at the same x (the row-unit loop) do not all hit the same bank pair
+#define TPITCH (TILE + 1)
 #define SMALL_AREA 256          // clipped bbox pixels a single lane scans on its own
 #define TC_STRIDE CHORD_TILECOUNT_STRIDE   // one bin counter per 64-byte line (no false sharing between tiles)
 
@@ -651,7 +654,7 @@ __device__ __forceinline__ int64_t edge_at(const WideEdges& w, int i, int32_t px
 __device__ __forceinline__ void lds_write(unsigned long long* tile, int32_t lx, int32_t ly, float z, uint32_t payload)
 {
     const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)payload;
-    atomicMax(&tile[ly * TILE + lx], packed);              // ds_max_u64
+    atomicMax(&tile[ly * TPITCH + lx], packed);            // ds_max_u64
 }
 
 // one lane scans its own (tile-clipped) tiny bbox with 32-bit edge functions.  ONE flattened loop over the
@@ -756,23 +759,34 @@ __device__ __forceinline__ void scan_row(unsigned long long* __restrict__ tileRo
     E_t E1 = s * (dx1 * (cy - (E_t)u.Y[2]) - dy1 * (cx - (E_t)u.X[2])) + bias1;
     E_t E2 = s * (dx2 * (cy - (E_t)u.Y[0]) - dy2 * (cx - (E_t)u.X[0])) + bias2;
     const E_t st0 = a0 * (E_t)256, st1 = a1 * (E_t)256, st2 = a2 * (E_t)256;
-    bool entered = false;
-    for (int32_t lx = lx0; lx <= lx1; lx++) {
+    // Span of the row in steps k from lx0: E_i + k * st_i >= 0 for all i.  The crossings are estimated in fp32
+    // (v_rcp_f32; error far below the +-1 step of slack taken on both sides) and only bound the
+    // loop; coverage itself is decided by the exact edge values inside it, so the loop has no data-dependent
+    // branch: a pixel outside merges the value 0, which ds_max ignores.
+    float klo = 0.0f, khi = (float)(lx1 - lx0);
+    {
+        const float e[3] = {(float)E0, (float)E1, (float)E2}, t[3] = {(float)st0, (float)st1, (float)st2};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float q = fminf(fmaxf(-e[i] * __builtin_amdgcn_rcpf(t[i]), -4.0f), 4096.0f);   // NaN (0 * inf) -> -4
+            if (t[i] > 0.0f) klo = fmaxf(klo, floorf(q) - 1.0f);
+            else if (t[i] < 0.0f) khi = fminf(khi, floorf(q) + 1.0f);
+            else if (e[i] < 0.0f) khi = -1.0f;                                                  // constant and outside
+        }
+    }
+    const int32_t k0 = (int32_t)klo, k1 = (int32_t)khi;
+    E0 += (E_t)k0 * st0; E1 += (E_t)k0 * st1; E2 += (E_t)k0 * st2;
+    unsigned long long* px = tileRow + lx0 + k0;
+    const unsigned long long payload = noPixels ? 0ull : (unsigned long long)u.payload;
+    for (int32_t k = k0; k <= k1; k++) {
         const bool inside = std::is_floating_point<E_t>::value ? (E0 >= (E_t)0 && E1 >= (E_t)0 && E2 >= (E_t)0)
                                                               : (((int64_t)E0 | (int64_t)E1 | (int64_t)E2) >= 0);
-        if (inside) {
-            // canonical l_i = float(E_i) * invA with E_i the unbiased integer
-            const float l1 = (float)(double)(E1 - bias1) * u.invA, l2 = (float)(double)(E2 - bias2) * u.invA;
-            const float z = (u.d0 + l1 * u.e1) + l2 * u.e2;
-            if (!noPixels) {
-                const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)u.payload;
-                atomicMax(&tileRow[lx], packed);             // ds_max_u64
-            }
-            entered = true;
-        } else if (entered) {
-            break;                                           // convex: this row's span is over
-        }
-        E0 += st0; E1 += st1; E2 += st2;
+        // canonical l_i = float(E_i) * invA with E_i the unbiased integer
+        const float l1 = (float)(double)(E1 - bias1) * u.invA, l2 = (float)(double)(E2 - bias2) * u.invA;
+        const float z = (u.d0 + l1 * u.e1) + l2 * u.e2;
+        const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | payload;
+        atomicMax(px, inside && !noPixels ? packed : 0ull);      // ds_max_u64
+        E0 += st0; E1 += st1; E2 += st2; px++;
     }
 }
 
@@ -825,7 +839,7 @@ __device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const uns
 #pragma unroll
                 for (int a = 0; a < 2; a++) {
                     const int32_t px = min((int32_t)(2u * lx0 + a), tw - 1), py = min((int32_t)(2u * ly0 + b), th - 1);
-                    const float dp = __uint_as_float(words[(py * TILE + px) * 2 + 1]);
+                    const float dp = __uint_as_float(words[(py * TPITCH + px) * 2 + 1]);
                     if (a == 0 && b == 0) { mn = dp; mx = dp; } else { mn = fminf(mn, dp); mx = fmaxf(mx, dp); }
                     if (dp > 0.0f) {                                        // hzb.hlsl:163-176
                         const uint32_t bits = __float_as_uint(dp);
@@ -897,7 +911,7 @@ __device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const uns
 template <bool SH>
 __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
 {
-    __shared__ unsigned long long tile[TILE * TILE];             // 32 KB
+    __shared__ unsigned long long tile[TILE * TPITCH];           // 32.5 KB
     __shared__ UnitParamsSoA prm;                                // 13 KB
     __shared__ uint32_t offs[TB + 1];
     __shared__ uint32_t waveSums[TB / 64];
@@ -932,7 +946,7 @@ __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
             if (lx + 1 < tw) v = *reinterpret_cast<const ulonglong2*>(src);
             else v.x = src[0];
         }
-        *reinterpret_cast<ulonglong2*>(&tile[ly * TILE + lx]) = v;
+        tile[ly * TPITCH + lx] = v.x; tile[ly * TPITCH + lx + 1] = v.y;
     }
     __syncthreads();
     PHASE(0);
@@ -997,7 +1011,7 @@ __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
                 const int32_t ly = (int32_t)((u.box >> 8) & 0xFFu) + (int32_t)(ui - offs[e]);
                 if ((rowMask >> ly) & 1ull) {
                     const int32_t lx0 = (int32_t)(u.box & 0xFFu), lx1 = (int32_t)((u.box >> 16) & 0xFFu);
-                    unsigned long long* tileRow = tile + ly * TILE;
+                    unsigned long long* tileRow = tile + ly * TPITCH;
                     const int32_t kind = u.skind >> 1;
                     if (kind == 0)      scan_row<int32_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
                     else if (kind == 1) scan_row<double>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
@@ -1017,7 +1031,7 @@ __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
         for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
             const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
             if (ly >= th || lx >= tw || !owns_row<SH>(p.shard, oy + ly)) continue;
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&tile[ly * TILE + lx]);
+            const ulonglong2 v = make_ulonglong2(tile[ly * TPITCH + lx], tile[ly * TPITCH + lx + 1]);
             unsigned long long* dst = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
             if (lx + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = v;
             else dst[0] = v.x;
@@ -1027,7 +1041,7 @@ __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
         // (8 lanes per 64-byte line) — no read-modify-write of the whole tile
         for (uint32_t i = threadIdx.x; i < TILE * TILE; i += TB) {
             const int32_t ly = (int32_t)(i >> TILE_SHIFT), lx = (int32_t)(i & (TILE - 1));
-            const unsigned long long v = tile[i];
+            const unsigned long long v = tile[ly * TPITCH + lx];
             if (v != 0ull && ly < th && lx < tw && owns_row<SH>(p.shard, oy + ly))
                 atomicMax(p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx, v);
         }

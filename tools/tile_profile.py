@@ -29,3 +29,11 @@ for p in (0, 1):
     print("pass", p, "entries", int(cnt.sum()), "max bin", int(cnt.max()), "tile us: sum %.0f mean %.1f max %.1f" % (us.sum(), us.mean(), us.max()))
     for t in order: print("   tile (%2d,%2d) %7.1f us  bin %5d  phases" % (t % tx, t // tx, us[t], cnt[t]), np.round(phase[t, :6], 1))
     print("   corr(us, bin) = %.3f" % np.corrcoef(us, cnt)[0, 1])
+    o2 = np.argsort(-phase[:, 4])[:6]
+    print("   by units phase:")
+    for t in o2: print("   tile (%2d,%2d) %7.1f us  bin %5d  phases" % (t % tx, t // tx, us[t], cnt[t]), np.round(phase[t, :6], 1))
+    h = np.histogram(us, bins=[0, 5, 10, 20, 30, 40, 50, 60, 80, 200])
+    print("   tile-time histogram (us):", list(zip(h[1][:-1].astype(int), h[0])))
+    for lo, hi in ((0, 1), (1, 64), (64, 256), (256, 1024), (1024, 100000)):
+        m = (cnt >= lo) & (cnt < hi)
+        print("   bins [%d,%d): %d tiles, time sum %.0f, phases" % (lo, hi, m.sum(), us[m].sum()), np.round(phase[m][:, :6].sum(axis=0), 0))
