@@ -680,20 +680,24 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
     int32_t r2 = s * (dx2 * (cy0 - ts.Y[0]) - dy2 * (cx0 - ts.X[0])) + bias2;
     int32_t E0 = r0, E1 = r1, E2 = r2;
     const int32_t w = x1 - x0 + 1, count = w * (y1 - y0 + 1);
-    int32_t lx = x0 - ox, ly = y0 - oy, col = 0;
+    // step to the next pixel / from the last pixel of a row to the first of the next; the body is branch-free:
+    // a pixel outside the triangle (or in a row another rank owns) merges 0, which ds_max ignores
+    const int32_t sx0 = a0 * 256, sx1 = a1 * 256, sx2 = a2 * 256;
+    const int32_t sw0 = b0 * 256 - (w - 1) * sx0, sw1 = b1 * 256 - (w - 1) * sx1, sw2 = b2 * 256 - (w - 1) * sx2;
+    int32_t ly = y0 - oy, col = 0;
+    unsigned long long* px = tile + ly * TPITCH + (x0 - ox);
+    const unsigned long long payload = (unsigned long long)ts.payload;
     for (int32_t i = 0; i < count; i++) {
-        if ((E0 | E1 | E2) >= 0 && ((rowMask >> ly) & 1ull)) {
-            const float l1 = (float)(E1 - bias1) * ts.invA, l2 = (float)(E2 - bias2) * ts.invA;
-            const float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
-            if (!noPixels) lds_write(tile, lx, ly, z, ts.payload);
-        }
-        col++; lx++;
-        E0 += a0 * 256; E1 += a1 * 256; E2 += a2 * 256;
-        if (col == w) {
-            col = 0; lx = x0 - ox; ly++;
-            r0 += b0 * 256; r1 += b1 * 256; r2 += b2 * 256;
-            E0 = r0; E1 = r1; E2 = r2;
-        }
+        const bool inside = (E0 | E1 | E2) >= 0 && ((rowMask >> ly) & 1ull) && !noPixels;
+        const float l1 = (float)(E1 - bias1) * ts.invA, l2 = (float)(E2 - bias2) * ts.invA;
+        const float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
+        atomicMax(px, inside ? (((unsigned long long)__float_as_uint(z) << 32) | payload) : 0ull);   // ds_max_u64
+        col++;
+        const bool wrap = col == w;
+        E0 += wrap ? sw0 : sx0; E1 += wrap ? sw1 : sx1; E2 += wrap ? sw2 : sx2;
+        px += wrap ? TPITCH - w + 1 : 1;
+        ly += wrap ? 1 : 0;
+        col = wrap ? 0 : col;
     }
 }
 
