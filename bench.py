@@ -67,11 +67,19 @@ def main():
             raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run --nproc-per-node %d bench.py ..." % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    # test hooks (a 1-GPU box cannot host two RCCL ranks): CHORDVIS_BENCH_BACKEND=gloo + CHORDVIS_BENCH_ONE_DEVICE=1
+    # run all ranks on device 0 with host-staged collectives, to exercise the N>1 control flow
+    backend = os.environ.get("CHORDVIS_BENCH_BACKEND", "nccl")
+    if os.environ.get("CHORDVIS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from chord_amd import lib as L, records as R
     from chord_amd.renderer import VisibilityRenderer

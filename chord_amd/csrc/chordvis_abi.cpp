@@ -105,6 +105,11 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         c->tilesX = (c->width + CHORD_TILE - 1) >> CHORD_TILE_SHIFT; c->tilesY = (c->height + CHORD_TILE - 1) >> CHORD_TILE_SHIFT;
         c->binCap = CHORD_BIN_CAP;              // 4K: 2 passes x 2040 tiles x 16384 x 4 B = 267 MB
         if ((rc = dalloc(c, &c->dTileBins, (size_t)2 * c->tilesX * c->tilesY * c->binCap))) return rc;
+        c->binPoolChunks = 32768;               // 2 passes x 32 Ki chunks x 1024 entries x 4 B = 256 MB
+        if ((rc = dalloc(c, &c->dBinPool, (size_t)2 * c->binPoolChunks * CHORD_BIN_CHUNK))) return rc;
+        const size_t tabWords = (size_t)2 * c->tilesX * c->tilesY * CHORD_BIN_MAX_CHUNKS;
+        if ((rc = dalloc(c, &c->dBinChunkTab, tabWords))) return rc;
+        CHORD_HIP(c, hipMemset(c->dBinChunkTab, 0, tabWords * sizeof(unsigned long long)));
     }
     if ((rc = dalloc(c, &c->dTileRange, (size_t)2 * CHORD_MAX_TILES))) return rc;
     {   // one {min, max} partial per block of the mip-0 kernel (64 x 4 texels per block)
@@ -247,7 +252,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
-    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTileBins);
+    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
     dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -386,7 +391,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         c->lists[i].capacity = c->cmdCapacity;
     }
     // raster work lists (fixed budgets sized for 288 GB of HBM; overflow is detected and reported by chordvis_stats)
-    c->triCap = 16u << 20;              // 16 M records x 48 B = 768 MB
+    c->triCap = 64u << 20;              // 64 M records x 48 B = 3 GB
     c->clipTriCap = 1u << 20;
     if ((rc = dalloc(c, &c->dTris, (size_t)c->triCap))) return rc;
     if ((rc = dalloc(c, &c->dClipTris, (size_t)c->clipTriCap))) return rc;

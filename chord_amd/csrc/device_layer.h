@@ -88,14 +88,19 @@ struct DeviceCounters {
     uint32_t triCount[CHORD_LIST_SHARDS];       // records appended this frame (both raster passes)
     uint32_t clipTriCount[2];                   // per raster pass
     uint32_t largeCount[2];                     // per raster pass: records touching more than 2x2 tiles
-    uint32_t overflow;                          // bit0 record list / tile bin / large list, bit1 clip list
-    uint32_t pad[3];
+    uint32_t overflow;                          // bit0 record list / tile bin / large list, bit1 clip list, bit2 bin chunk wait timed out
+    uint32_t binPoolCount[2];                   // per raster pass: overflow chunks handed out
+    uint32_t pad;
     // triangles (meshlet triangle counts) of the commands each list producer emitted this frame
     unsigned long long trisInstanceCulled, trisHzbVisible0, trisHzbVisible1, pad2;
 };
 
 // Everything a frame zeroes lives in ONE allocation so the frame starts with one memset:
 // counters, the four command-list counts, and the per-pass tile bin counts (2 x tiles follow).
+#define CHORD_BIN_CHUNK_SHIFT 10
+#define CHORD_BIN_CHUNK (1u << CHORD_BIN_CHUNK_SHIFT)   // entries per overflow chunk
+#define CHORD_BIN_MAX_CHUNKS 240u                    // overflow chunks per tile: bins hold up to binCap + 240 Ki entries
+#define CHORD_BIN_CHUNK_INVALID 0xFFFFFFFFu
 #ifndef CHORD_TILE_SHIFT
 #define CHORD_TILE_SHIFT 6                       // log2 of the raster tile side in pixels (5 or 6)
 #endif
@@ -202,7 +207,14 @@ struct ChordCtx {
     chord::TriRec* dTris = nullptr;
     uint32_t triCap = 0;               // all shards together
     chord::FrameState* dFrameState = nullptr;
-    uint32_t* dTileBins = nullptr;     // [2 passes][tiles][binCap]
+    uint32_t* dTileBins = nullptr;     // [2 passes][tiles][binCap]: the first binCap entries of every tile's bin
+    // entries beyond binCap live in CHORD_BIN_CHUNK-entry chunks handed out from a pool; the j-th overflow chunk of
+    // a tile is named by dBinChunkTab[pass][tile][j] = raster serial << 32 | chunk id (never zeroed: stale serials
+    // do not match)
+    uint32_t* dBinPool = nullptr;      // [2 passes][binPoolChunks][CHORD_BIN_CHUNK]
+    unsigned long long* dBinChunkTab = nullptr;
+    uint32_t binPoolChunks = 0;        // per pass
+    uint32_t rasterSerial = 0;
     bool inFrame = false;              // inside render_frame / frame_phase_*: per-pass counts were zeroed at frame begin
     uint32_t binCap = 0, tilesX = 0, tilesY = 0;
     chord::ClipTri* dClipTris = nullptr;

@@ -54,6 +54,8 @@ struct RasterParams {
     ShardInfo shard;
     TriRec* tris; uint32_t triCap;                      // per list shard
     uint32_t* tileCount; uint32_t* tileBins; uint32_t binCap; uint32_t tilesX, tilesY;
+    uint32_t* binPool; uint32_t binPoolChunks; uint32_t* binPoolCount;   // overflow chunks of this pass
+    unsigned long long* binChunkTab; uint32_t binStamp;                  // [tile][CHORD_BIN_MAX_CHUNKS] serial << 32 | chunk
     ClipTri* clipTris; uint32_t clipTriCap; uint32_t pass;   // raster pass of the frame (0 / 1): clip / large count slot
     uint32_t* largeList; uint32_t largeCap;                  // records touching more than 2x2 tiles (binned by raster_bin_large_kernel)
     DeviceCounters* counters;
@@ -191,6 +193,39 @@ __device__ __forceinline__ BinElect wave_bin_elect(bool has, uint32_t tile, uint
     return e;
 }
 
+// ---- tile bins ----------------------------------------------------------------------------------
+// Entry `slot` of a tile's bin: the first binCap entries have a fixed home; beyond that, entries live in
+// 1024-entry chunks from a pool.  The lane that drew the first slot of a chunk allocates it and publishes
+// `serial << 32 | id` in the tile's chunk table; lanes that drew other slots of that chunk wait for the entry
+// to carry this pass's serial.  Every allocation of a wave is issued before any of its lanes starts waiting
+// (two sequential phases, not an if/else), and an allocator never waits, so the wait always ends; it is
+// bounded anyway (overflow bit 2) so that a logic error cannot hang the device.
+__device__ __forceinline__ uint32_t bin_capacity(const RasterParams& p) { return p.binCap + CHORD_BIN_MAX_CHUNKS * CHORD_BIN_CHUNK; }
+
+__device__ __forceinline__ void bin_store(const RasterParams& p, uint32_t tile, uint32_t slot, uint32_t gi)
+{
+    if (slot < p.binCap) { p.tileBins[(size_t)tile * p.binCap + slot] = gi; return; }
+    const uint32_t o = slot - p.binCap, j = o >> CHORD_BIN_CHUNK_SHIFT;
+    if (j >= CHORD_BIN_MAX_CHUNKS) { atomicOr(&p.counters->overflow, 1u); return; }
+    unsigned long long* ent = p.binChunkTab + (size_t)tile * CHORD_BIN_MAX_CHUNKS + j;
+    const unsigned long long stamp = (unsigned long long)p.binStamp << 32;
+    if ((o & (CHORD_BIN_CHUNK - 1u)) == 0u) {
+        uint32_t id = atomicAdd(p.binPoolCount, 1u);
+        if (id >= p.binPoolChunks) { id = CHORD_BIN_CHUNK_INVALID; atomicOr(&p.counters->overflow, 1u); }
+        __hip_atomic_store(ent, stamp | id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned long long e = 0;
+    uint32_t spins = 0;
+    for (;;) {
+        e = __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((e & 0xFFFFFFFF00000000ull) == stamp) break;
+        if (++spins > (1u << 20)) { atomicOr(&p.counters->overflow, 4u); return; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    const uint32_t id = (uint32_t)e;
+    if (id != CHORD_BIN_CHUNK_INVALID) p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))] = gi;
+}
+
 // Bins two records per lane (triangles lane and lane + 64 of the meshlet) whose clamped bboxes touch at most
 // 2x2 tiles each; the atomics of both are issued before either result is waited for.
 __device__ __forceinline__ void wave_bin_small2(const RasterParams& p, bool emitA, const TriSetup& tsA, uint32_t giA,
@@ -225,13 +260,11 @@ __device__ __forceinline__ void wave_bin_small2(const RasterParams& p, bool emit
         baseB = __shfl(baseB, eB.leader, 64);
         if (hasA) {
             const uint32_t slot = baseA + eA.rank;
-            if (slot < p.binCap) p.tileBins[(size_t)tileA * p.binCap + slot] = giA;
-            else atomicOr(&p.counters->overflow, 1u);
+            bin_store(p, tileA, slot, giA);
         }
         if (hasB) {
             const uint32_t slot = baseB + eB.rank;
-            if (slot < p.binCap) p.tileBins[(size_t)tileB * p.binCap + slot] = giB;
-            else atomicOr(&p.counters->overflow, 1u);
+            bin_store(p, tileB, slot, giB);
         }
     }
 }
@@ -434,8 +467,7 @@ __device__ void bin_record_tiles(const RasterParams& p, const TriSetup& ts, uint
             if (!hit) continue;
             const uint32_t tile = (uint32_t)ty * p.tilesX + (uint32_t)tx;
             const uint32_t slot = atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE], 1u);
-            if (slot < p.binCap) p.tileBins[(size_t)tile * p.binCap + slot] = gi;
-            else atomicOr(&p.counters->overflow, 1u);
+            bin_store(p, tile, slot, gi);
         }
 }
 
@@ -571,8 +603,7 @@ __device__ void raster_bin_large_part(const RasterParams& p, uint32_t block, uin
             if (hit) {
                 const uint32_t tile = (uint32_t)ty * p.tilesX + (uint32_t)tx;
                 const uint32_t slot = atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE], 1u);   // distinct tiles per lane
-                if (slot < p.binCap) p.tileBins[(size_t)tile * p.binCap + slot] = gi;
-                else atomicOr(&p.counters->overflow, 1u);
+                bin_store(p, tile, slot, gi);
             }
         }
     }
@@ -602,9 +633,9 @@ __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
         const uint32_t t = threadIdx.x + k * 1024u;
         myBucket[k] = 0xFFFFFFFFu;
         if (t < tiles) {
-            const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], p.binCap);
-            // bucket 0 = heaviest (2^15..), bucket 16 = count 1, bucket 17 = empty
-            myBucket[k] = c ? 16u - (31u - (uint32_t)__clz(c)) : 17u;
+            const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], bin_capacity(p));
+            // bucket 0 = heaviest (2^16..), bucket 16 = count 1, bucket 17 = empty
+            myBucket[k] = c ? 16u - min(16u, 31u - (uint32_t)__clz(c)) : 17u;
             atomicAdd(&hist[myBucket[k]], 1u);
         }
     }
@@ -919,11 +950,12 @@ __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
     __shared__ UnitParamsSoA prm;                                // 13 KB
     __shared__ uint32_t offs[TB + 1];
     __shared__ uint32_t waveSums[TB / 64];
+    __shared__ uint32_t chunkTab[CHORD_BIN_MAX_CHUNKS];
     if ((p.debug & DBG_TILE_EXIT) && !p.clearTiles) return;
     const uint32_t active = p.tileOrder[0];
     for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
     const uint32_t tileId = p.tileOrder[1u + oi];
-    const uint32_t n = min(p.tileCount[(size_t)tileId * TC_STRIDE], p.binCap);
+    const uint32_t n = min(p.tileCount[(size_t)tileId * TC_STRIDE], bin_capacity(p));
     const bool prof = (p.debug & DBG_TILE_CLOCKS) != 0;
     const unsigned long long t0 = prof ? wall_clock64() : 0ull;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = t0;
@@ -959,19 +991,40 @@ __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
     // Software pipeline over the two dependent fetches of a batch (bin entry -> 48-byte record): the
     // record of batch b+1 and the bin entry of batch b+2 are in flight while batch b is scan-converted.
     const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
-    uint32_t idxNext = threadIdx.x < n ? bin[threadIdx.x] : 0u;               // bin entry of batch 0
+    if (n > p.binCap) {
+        // overflow chunks of this bin (chunk table -> LDS; an entry of another pass or a failed allocation reads
+        // as invalid and its entries are skipped)
+        const uint32_t chunks = (n - p.binCap + CHORD_BIN_CHUNK - 1u) >> CHORD_BIN_CHUNK_SHIFT;
+        for (uint32_t j = threadIdx.x; j < chunks; j += TB) {
+            const unsigned long long e = p.binChunkTab[(size_t)tileId * CHORD_BIN_MAX_CHUNKS + j];
+            chunkTab[j] = (uint32_t)(e >> 32) == p.binStamp ? (uint32_t)e : CHORD_BIN_CHUNK_INVALID;
+        }
+        __syncthreads();
+    }
+    const uint32_t recLimit = p.triCap * CHORD_LIST_SHARDS;
+    auto binEntry = [&](uint32_t k) -> uint32_t {              // record index of bin entry k, ~0u = none
+        if (k < p.binCap) return bin[k];
+        const uint32_t o = k - p.binCap, id = chunkTab[o >> CHORD_BIN_CHUNK_SHIFT];
+        if (id == CHORD_BIN_CHUNK_INVALID) return 0xFFFFFFFFu;
+        const uint32_t gi = p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))];
+        return gi < recLimit ? gi : 0xFFFFFFFFu;               // (only after a reported overflow)
+    };
+    uint32_t idxNext = threadIdx.x < n ? binEntry(threadIdx.x) : 0xFFFFFFFFu;   // bin entry of batch 0
     TriRec recNext;
-    if (threadIdx.x < n) recNext = p.tris[idxNext];                             // record of batch 0
-    idxNext = TB + threadIdx.x < n ? bin[TB + threadIdx.x] : 0u;          // bin entry of batch 1
+    bool haveNext = idxNext != 0xFFFFFFFFu;
+    if (haveNext) recNext = p.tris[idxNext];                                     // record of batch 0
+    idxNext = TB + threadIdx.x < n ? binEntry(TB + threadIdx.x) : 0xFFFFFFFFu;   // bin entry of batch 1
     for (uint32_t base = 0; base < n; base += TB) {
         const uint32_t k = base + threadIdx.x;
         const TriRec rec = recNext;
-        if (k + TB < n) recNext = p.tris[idxNext];                            // record of the next batch
-        idxNext = k + 2u * TB < n ? bin[k + 2u * TB] : 0u;                            // bin entry of the batch after
+        const bool have = haveNext;
+        haveNext = idxNext != 0xFFFFFFFFu;
+        if (haveNext) recNext = p.tris[idxNext];                                 // record of the next batch
+        idxNext = k + 2u * TB < n ? binEntry(k + 2u * TB) : 0xFFFFFFFFu;          // bin entry of the batch after
         if (prof) { volatile uint32_t sink = rec.payload; (void)sink; }
         PHASE(1);
         uint32_t rows = 0;
-        if (k < n) {
+        if (have) {
             TriSetup ts;
             tri_setup_from_record(ts, rec, p.Wi, p.Hi);
             {
@@ -1087,6 +1140,10 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     const uint32_t pass = c->rasterCalls & 1u;
     p.tileCount = c->dFrameState->tileCount + (size_t)pass * tiles * TC_STRIDE;
     p.tileBins = c->dTileBins + (size_t)pass * tiles * c->binCap; p.binCap = c->binCap;
+    p.binPool = c->dBinPool + (size_t)pass * c->binPoolChunks * CHORD_BIN_CHUNK; p.binPoolChunks = c->binPoolChunks;
+    p.binPoolCount = &c->dCounters->binPoolCount[pass];
+    p.binChunkTab = c->dBinChunkTab + (size_t)pass * tiles * CHORD_BIN_MAX_CHUNKS;
+    p.binStamp = ++c->rasterSerial;
     p.tilesX = c->tilesX; p.tilesY = c->tilesY;
     p.clipTris = c->dClipTris + (size_t)pass * (c->clipTriCap / 2); p.clipTriCap = c->clipTriCap / 2; p.pass = pass;
     p.largeList = c->dLargeList + (size_t)pass * (c->largeCap / 2); p.largeCap = c->largeCap / 2;
@@ -1103,6 +1160,7 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         (void)hipMemsetAsync(p.tileCount, 0, sizeof(uint32_t) * TC_STRIDE * tiles, c->stream);
         (void)hipMemsetAsync(&c->dCounters->clipTriCount[pass], 0, sizeof(uint32_t), c->stream);
         (void)hipMemsetAsync(&c->dCounters->largeCount[pass], 0, sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(&c->dCounters->binPoolCount[pass], 0, sizeof(uint32_t), c->stream);
         if (!c->inFrame) (void)hipMemsetAsync(c->dCounters->triCount, 0, sizeof(uint32_t) * CHORD_LIST_SHARDS, c->stream);
     }
 

@@ -166,6 +166,30 @@ def test_config2_atrium_1080p_matches_oracle(gpu):
     r.close()
 
 
+def test_bins_beyond_the_fixed_capacity_use_overflow_chunks(gpu):
+    """BASELINE config 4 (street x 64 instances) at 640x360: tens of thousands of triangles per 64x64 tile, so
+    bins run far past their fixed 16 384 entries and continue in pool chunks.  Frame 0 (no history) and
+    frame 1 (two-pass HZB; chunk-table entries of frame 0 are stale) must be exact, with no overflow."""
+    from chord_amd import lib as L
+    W, Hh = 640, 360
+    scene, cam, view, iv = H.setup_scene(scenes.config4_street_x64, W, Hh)
+    want0 = orc.frame(scene, view, iv, H.ALL_FLAGS)
+    want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want0["hzb_min"])
+    r = _renderer(gpu, scene, view, iv, W, Hh, H.ALL_FLAGS)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want0["vis"], W, Hh, "config4 frame 0")
+    tiles = ((W + 63) // 64) * ((Hh + 63) // 64)
+    ticks = np.zeros(tiles * 9, np.uint64); cnt = np.zeros(tiles, np.uint32)
+    assert L.lib.chordvis_debug_tile_profile(r._ctx, 0, ticks.ctypes.data, cnt.ctypes.data, tiles * 9) == 0
+    assert int(cnt.max()) > 16384 + 2 * 1024, "the scene no longer exercises the overflow chunks: max bin %d" % int(cnt.max())
+    assert r.stats()["overflow"] == 0
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want1["vis"], W, Hh, "config4 frame 1")
+    st = r.stats()
+    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want1["stats"].trianglesSubmitted
+    r.close()
+
+
 def test_config3_street_4k_two_pass_matches_oracle_and_properties(gpu):
     """BASELINE config 3 at full size: frame 0 (no history) and frame 1 (two-pass HZB) bit-exact vs the
     oracle; occlusion culling must not change a static image; a repeated frame is idempotent."""
