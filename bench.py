@@ -208,6 +208,35 @@ def main():
                 "other_kernel": {k: {"avg_launch_us": round(v[0] / launches * 1e3, 2), "algorithmic_bytes_per_launch": int(v[1] / launches)}
                                  for k, v in kernels.items() if k != dom}}
 
+    # ---- N > 1: the same workload unsharded on rank 0's GPU, measured live, so that the line carries its own
+    #      strong-scaling reference (the N = 1 default workload is BASELINE config 3, the N > 1 one config 4) ----
+    single_ref = None
+    if world > 1:
+        if rank == 0:
+            r1 = VisibilityRenderer(local_rank, stream.cuda_stream)
+            r1.upload_scene(scene)
+            r1.allocate_gbuffer(W, H)
+            r1.enable_timers(0)
+
+            def frame1(i):
+                v, iv = views[i & 1]
+                r1.bind_objects(d_obj[i & 1].data_ptr(), len(scene.objects))
+                r1.set_view(v, iv, flags)
+                r1.render_frame()
+            n1 = max(8, min(args.steps, 100)) & ~1
+            for i in range(8):
+                frame1(i)
+            torch.cuda.synchronize(dev)
+            s0 = time.perf_counter()
+            for i in range(n1):
+                frame1(i)
+            torch.cuda.synchronize(dev)
+            s1 = time.perf_counter()
+            single_ref = {"workload": wl, "n_gpus": 1, "steps": n1, "ms_per_step": round((s1 - s0) / n1 * 1e3, 4),
+                          "value": round(tris_per_pair * (n1 // 2) / (s1 - s0) / 1e9, 4), "unit": "Gtri/s"}
+            r1.close()
+        dist.barrier()
+
     # ---- CPU baseline: the oracle replaying the same frame on the host (rank 0, N = 1) ----------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline_frames > 0:
@@ -242,6 +271,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if single_ref is not None:
+            line["single_gpu_same_workload"] = single_ref
         print(json.dumps(line), flush=True)
     r.close()
     if world > 1:

@@ -320,6 +320,32 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(RasterParams p)
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = mv[r * 4 + cc];
 
+        // ---- sharded frames: a cluster whose projected bounds touch none of this rank's pixel rows is another
+        //      rank's work (conservative: 8 AABB corners, one pixel of slack; any corner at or behind the camera
+        //      plane keeps the cluster).  Skipping is invisible in the image: only triangles without an owned
+        //      row are dropped, exactly as the per-triangle ownership test below would. -----------------------
+        if (p.shard.ranks > 1) {
+            float ylo = 3.0e38f, yhi = -3.0e38f;
+            bool unbounded = false;
+            if (lane < 8u) {
+                const f4 h = mul_mv(mvp, (lane & 1u) ? m->posMax[0] : m->posMin[0], (lane & 2u) ? m->posMax[1] : m->posMin[1],
+                                    (lane & 4u) ? m->posMax[2] : m->posMin[2], 1.0f);
+                const float y = (h.y / h.w * -0.5f + 0.5f) * p.H;
+                if (!(h.w > 1.0e-6f) || !(fabsf(y) < 1.0e7f)) unbounded = true;
+                else { ylo = y; yhi = y; }
+            }
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) {
+                ylo = fminf(ylo, __shfl_xor(ylo, d, 64));
+                yhi = fmaxf(yhi, __shfl_xor(yhi, d, 64));
+            }
+            ylo = bcast(ylo, 0); yhi = bcast(yhi, 0);
+            if (__ballot(unbounded) == 0ull) {
+                const int32_t y0 = max((int32_t)floorf(ylo) - 1, 0), y1 = min((int32_t)ceilf(yhi) + 1, p.Hi - 1);
+                if (y1 < y0 || !owns_any_row(p.shard, y0, y1)) continue;
+            }
+        }
+
         // ---- vertex phase: coalesced index + position stream -> clip space -> LDS -------------
         bool notFast = false;
         for (uint32_t i = lane; i < V; i += 64u) {
