@@ -110,6 +110,14 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         const size_t tabWords = (size_t)2 * c->tilesX * c->tilesY * CHORD_BIN_MAX_CHUNKS;
         if ((rc = dalloc(c, &c->dBinChunkTab, tabWords))) return rc;
         CHORD_HIP(c, hipMemset(c->dBinChunkTab, 0, tabWords * sizeof(unsigned long long)));
+        // work items of the tile kernel: every tile once, plus the slices of split tiles (bounded by the entries
+        // a pass can hold)
+        const size_t tilesN = (size_t)c->tilesX * c->tilesY;
+        const size_t sliceBound = ((tilesN * c->binCap + (size_t)c->binPoolChunks * CHORD_BIN_CHUNK) >> CHORD_TILE_SLICE_SHIFT) + tilesN;
+        c->tileItemCap = (uint32_t)(sliceBound + tilesN);
+        if ((rc = dalloc(c, &c->dTileOrder, (size_t)1 + c->tileItemCap))) return rc;
+        if ((rc = dalloc(c, &c->dTileSlabs, tilesN * CHORD_TILE * CHORD_TILE))) return rc;
+        CHORD_HIP(c, hipMemset(c->dTileSlabs, 0, tilesN * CHORD_TILE * CHORD_TILE * sizeof(unsigned long long)));
     }
     if ((rc = dalloc(c, &c->dTileRange, (size_t)2 * CHORD_MAX_TILES))) return rc;
     {   // one {min, max} partial per block of the mip-0 kernel (64 x 4 texels per block)
@@ -229,7 +237,6 @@ int chordvis_create(int deviceOrdinal, void* hipStream, ChordCtx** outCtx)
         c->ownStream = true;
     }
     bool ok = hipMalloc((void**)&c->dTileClocks, sizeof(unsigned long long) * 18 * CHORD_MAX_TILES) == hipSuccess &&
-              hipMalloc((void**)&c->dTileOrder, sizeof(uint32_t) * (1 + CHORD_MAX_TILES)) == hipSuccess &&
               hipMalloc((void**)&c->dView, sizeof(DView)) == hipSuccess &&
               hipMalloc((void**)&c->dFrameState, sizeof(FrameState)) == hipSuccess;
     if (!ok) { chordvis_destroy(c); return CHORDVIS_E_HIP; }
@@ -249,7 +256,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
-    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder);
+    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
     dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);

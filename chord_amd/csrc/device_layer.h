@@ -101,6 +101,7 @@ struct DeviceCounters {
 #define CHORD_BIN_CHUNK (1u << CHORD_BIN_CHUNK_SHIFT)   // entries per overflow chunk
 #define CHORD_BIN_MAX_CHUNKS 240u                    // overflow chunks per tile: bins hold up to binCap + 240 Ki entries
 #define CHORD_BIN_CHUNK_INVALID 0xFFFFFFFFu
+#define CHORD_TILE_SLICE_SHIFT 11                    // long bins are scan-converted in slices of 2048 entries
 #ifndef CHORD_TILE_SHIFT
 #define CHORD_TILE_SHIFT 6                       // log2 of the raster tile side in pixels (5 or 6)
 #endif
@@ -219,7 +220,9 @@ struct ChordCtx {
     uint32_t binCap = 0, tilesX = 0, tilesY = 0;
     chord::ClipTri* dClipTris = nullptr;
     uint32_t clipTriCap = 0;
-    uint32_t* dTileOrder = nullptr;    // [1 + CHORD_MAX_TILES]: active count, then tile ids heaviest first
+    uint32_t* dTileOrder = nullptr;    // [1 + tileItemCap]: item count, then work items heaviest first
+    unsigned long long* dTileSlabs = nullptr;   // [tiles][TILE*TILE]: where the slices of a split tile meet (all zero between uses)
+    uint32_t tileItemCap = 0;
     uint32_t* dLargeList = nullptr;    // [2 passes][largeCap / 2] record indices
     uint32_t largeCap = 0;
     chord::DeviceCounters* dCounters = nullptr;

@@ -59,7 +59,8 @@ struct RasterParams {
     ClipTri* clipTris; uint32_t clipTriCap; uint32_t pass;   // raster pass of the frame (0 / 1): clip / large count slot
     uint32_t* largeList; uint32_t largeCap;                  // records touching more than 2x2 tiles (binned by raster_bin_large_kernel)
     DeviceCounters* counters;
-    uint32_t* tileOrder;                                // [0] = active tile count, [1..] tile ids, heaviest first
+    uint32_t* tileOrder;                                // [0] = work item count, [1..] items (tile | slice << 12 | (slices-1) << 22), heaviest first
+    unsigned long long* tileSlabs;                      // one TILE x TILE accumulation slab per tile (all zero between uses)
     // fused HZB (single-GPU frames): the tile kernel reduces its finished 64x64 tile to mips 0..5
     uint32_t hzbFused;                                  // 0: off (later passes merge with global atomicMax)
     ChordHZBDesc hzbDesc;
@@ -641,41 +642,59 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
     else raster_bin_large_part(p, blockIdx.x - CLIP_BLOCKS, gridDim.x - CLIP_BLOCKS);
 }
 
-// ---- tile schedule: heaviest tiles first --------------------------------------------------------
-// The tile kernel's duration is its slowest tile plus whatever is still queued behind it, so tiles are
-// dispatched in descending order of their bin count (longest-processing-time first): one block
-// bucket-sorts the <= 4096 tile counts by floor(log2(count)).  Tiles without entries are listed last on
-// the first pass of a frame (they still have to be written: that is the clear) and dropped otherwise.
+// ---- tile schedule: heaviest work first ---------------------------------------------------------
+// The tile kernel's duration is its slowest work item plus whatever is still queued behind it.  A tile
+// whose bin is long is cut into slices of TILE_SLICE entries that different workgroups scan-convert
+// concurrently (the last one to finish merges them, see raster_tile_kernel), and items are dispatched
+// in descending order of their entry count (longest-processing-time first): one block lists the slices
+// of split tiles first and bucket-sorts the other tiles by floor(log2(count)).  Tiles without entries
+// come last on the first pass of a frame (they still have to be written: that is the clear) and are
+// dropped otherwise.  Item = tile | slice << 12 | (slices - 1) << 22.
+#define TILE_SLICE_SHIFT CHORD_TILE_SLICE_SHIFT
+#define TILE_SLICE (1u << TILE_SLICE_SHIFT)
+#define TILE_SPLIT_MIN 6144u       // bins up to this many entries stay whole
 __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
 {
-    __shared__ uint32_t hist[20], base[20], cursor[20];
+    __shared__ uint32_t hist[20], base[20], cursor[20], splitItems;
     const uint32_t tiles = p.tilesX * p.tilesY;
     if (threadIdx.x < 20u) { hist[threadIdx.x] = 0; cursor[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) splitItems = 0;
     __syncthreads();
     constexpr uint32_t PER_THREAD = CHORD_MAX_TILES / 1024u;
-    uint32_t myBucket[PER_THREAD];
+    uint32_t myBucket[PER_THREAD], myPos[PER_THREAD], mySlices[PER_THREAD];
 #pragma unroll
     for (uint32_t k = 0; k < PER_THREAD; k++) {
         const uint32_t t = threadIdx.x + k * 1024u;
-        myBucket[k] = 0xFFFFFFFFu;
+        myBucket[k] = 0xFFFFFFFFu; myPos[k] = 0; mySlices[k] = 1;
         if (t < tiles) {
             const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], bin_capacity(p));
-            // bucket 0 = heaviest (2^16..), bucket 16 = count 1, bucket 17 = empty
-            myBucket[k] = c ? 16u - min(16u, 31u - (uint32_t)__clz(c)) : 17u;
+            if (c > TILE_SPLIT_MIN) {
+                mySlices[k] = (c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT;
+                myBucket[k] = 18u;
+                myPos[k] = atomicAdd(&splitItems, mySlices[k]);
+            } else {
+                // bucket 4 = 2^11.., bucket 16 = count 1, bucket 17 = empty
+                myBucket[k] = c ? 16u - (31u - (uint32_t)__clz(c)) : 17u;
+            }
             atomicAdd(&hist[myBucket[k]], 1u);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t acc = 0;
+        uint32_t acc = splitItems;
         for (int b = 0; b < 18; b++) { base[b] = acc; acc += hist[b]; }
-        p.tileOrder[0] = p.clearTiles ? tiles : tiles - hist[17];
+        p.tileOrder[0] = p.clearTiles ? acc : acc - hist[17];
     }
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < PER_THREAD; k++) {
         const uint32_t t = threadIdx.x + k * 1024u;
-        if (myBucket[k] != 0xFFFFFFFFu) p.tileOrder[1u + base[myBucket[k]] + atomicAdd(&cursor[myBucket[k]], 1u)] = t;
+        if (myBucket[k] == 0xFFFFFFFFu) continue;
+        if (myBucket[k] == 18u) {
+            for (uint32_t j = 0; j < mySlices[k]; j++) p.tileOrder[1u + myPos[k] + j] = t | (j << 12) | ((mySlices[k] - 1u) << 22);
+        } else {
+            p.tileOrder[1u + base[myBucket[k]] + atomicAdd(&cursor[myBucket[k]], 1u)] = t;
+        }
     }
 }
 
@@ -969,19 +988,57 @@ __device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const uns
     }
 }
 
+// Split tiles (see raster_tile_kernel): merges this slice's LDS tile into the tile's accumulation slab and draws a
+// ticket; the last slice to arrive takes the merged words back into LDS and returns true.  Kept out of line so
+// that its registers do not count against the scan-conversion loops (134 vs 109 VGPRs inlined).
+__device__ __noinline__ bool merge_slices(unsigned long long* tile, unsigned long long* slab, uint32_t* ticket, uint32_t slices,
+                                          uint32_t* sTicket, uint32_t* overflow)
+{
+    // all of a thread's atomics are in flight together (one round trip, not TILE*TILE/TB of them)
+    constexpr uint32_t PER = TILE * TILE / TB;
+    unsigned long long got[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t i = threadIdx.x + k * TB;
+        const unsigned long long v = tile[(i >> TILE_SHIFT) * TPITCH + (i & (TILE - 1))];
+        got[k] = v != 0ull ? atomicMax(slab + i, v) : 0ull;       // the returned value makes the wave wait for the atomic
+    }
+    unsigned long long seen = 0ull;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) seen |= got[k];
+    if (seen == 0xFFFFFFFFFFFFFFFFull) *overflow = 8u;            // (never true: keeps the returns live)
+    __syncthreads();
+    if (threadIdx.x == 0) *sTicket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    if (*sTicket != slices - 1u) return false;                    // (no thread touches LDS `tile` past this point)
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) got[k] = atomicExch(slab + threadIdx.x + k * TB, 0ull);
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t i = threadIdx.x + k * TB;
+        tile[(i >> TILE_SHIFT) * TPITCH + (i & (TILE - 1))] = got[k];
+    }
+    return true;
+}
+
 template <bool SH>
-__global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
+__global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
 {
     __shared__ unsigned long long tile[TILE * TPITCH];           // 32.5 KB
     __shared__ UnitParamsSoA prm;                                // 13 KB
     __shared__ uint32_t offs[TB + 1];
     __shared__ uint32_t waveSums[TB / 64];
     __shared__ uint32_t chunkTab[CHORD_BIN_MAX_CHUNKS];
+    __shared__ uint32_t sTicket;
     if ((p.debug & DBG_TILE_EXIT) && !p.clearTiles) return;
     const uint32_t active = p.tileOrder[0];
     for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
-    const uint32_t tileId = p.tileOrder[1u + oi];
-    const uint32_t n = min(p.tileCount[(size_t)tileId * TC_STRIDE], bin_capacity(p));
+    const uint32_t item = p.tileOrder[1u + oi];
+    const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
+    const uint32_t nAll = min(p.tileCount[(size_t)tileId * TC_STRIDE], bin_capacity(p));
+    // entries [lo, n) of the bin are this item's
+    const uint32_t lo = slices > 1u ? slice << TILE_SLICE_SHIFT : 0u;
+    const uint32_t n = slices > 1u ? min(nAll, lo + TILE_SLICE) : nAll;
     const bool prof = (p.debug & DBG_TILE_CLOCKS) != 0;
     const unsigned long long t0 = prof ? wall_clock64() : 0ull;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = t0;
@@ -1000,10 +1057,13 @@ __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
     // ---- tile in: zero (first pass: this is the clear; un-fused later passes merge by max at tile-out), or the
     //      current words when a later pass must leave the finished tile in LDS for the fused HZB reduction ----
     const bool rmw = p.hzbFused && !p.clearTiles;
+    // slices of a split tile start from zero; when the tile must leave this kernel complete (first pass, fused HZB)
+    // they meet in memory and the last one to arrive merges them (below)
+    const bool mergeSlices = slices > 1u && (p.clearTiles || rmw);
     for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
         const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
         ulonglong2 v = make_ulonglong2(0ull, 0ull);
-        if (rmw && ly < th && lx < tw) {
+        if (rmw && !mergeSlices && ly < th && lx < tw) {
             const unsigned long long* src = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
             if (lx + 1 < tw) v = *reinterpret_cast<const ulonglong2*>(src);
             else v.x = src[0];
@@ -1017,10 +1077,10 @@ __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
     // Software pipeline over the two dependent fetches of a batch (bin entry -> 48-byte record): the
     // record of batch b+1 and the bin entry of batch b+2 are in flight while batch b is scan-converted.
     const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
-    if (n > p.binCap) {
+    if (nAll > p.binCap) {
         // overflow chunks of this bin (chunk table -> LDS; an entry of another pass or a failed allocation reads
         // as invalid and its entries are skipped)
-        const uint32_t chunks = (n - p.binCap + CHORD_BIN_CHUNK - 1u) >> CHORD_BIN_CHUNK_SHIFT;
+        const uint32_t chunks = (nAll - p.binCap + CHORD_BIN_CHUNK - 1u) >> CHORD_BIN_CHUNK_SHIFT;
         for (uint32_t j = threadIdx.x; j < chunks; j += TB) {
             const unsigned long long e = p.binChunkTab[(size_t)tileId * CHORD_BIN_MAX_CHUNKS + j];
             chunkTab[j] = (uint32_t)(e >> 32) == p.binStamp ? (uint32_t)e : CHORD_BIN_CHUNK_INVALID;
@@ -1035,12 +1095,12 @@ __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
         const uint32_t gi = p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))];
         return gi < recLimit ? gi : 0xFFFFFFFFu;               // (only after a reported overflow)
     };
-    uint32_t idxNext = threadIdx.x < n ? binEntry(threadIdx.x) : 0xFFFFFFFFu;   // bin entry of batch 0
+    uint32_t idxNext = lo + threadIdx.x < n ? binEntry(lo + threadIdx.x) : 0xFFFFFFFFu;   // bin entry of batch 0
     TriRec recNext;
     bool haveNext = idxNext != 0xFFFFFFFFu;
     if (haveNext) recNext = p.tris[idxNext];                                     // record of batch 0
-    idxNext = TB + threadIdx.x < n ? binEntry(TB + threadIdx.x) : 0xFFFFFFFFu;   // bin entry of batch 1
-    for (uint32_t base = 0; base < n; base += TB) {
+    idxNext = lo + TB + threadIdx.x < n ? binEntry(lo + TB + threadIdx.x) : 0xFFFFFFFFu;   // bin entry of batch 1
+    for (uint32_t base = lo; base < n; base += TB) {
         const uint32_t k = base + threadIdx.x;
         const TriRec rec = recNext;
         const bool have = haveNext;
@@ -1106,6 +1166,26 @@ __global__ __launch_bounds__(TB) void raster_tile_kernel(RasterParams p)
         PHASE(4);
     }
     __syncthreads();
+
+    // ---- split tile: the slices meet in the tile's accumulation slab (device-scope atomic max of the pixels a
+    //      slice touched); the last slice to arrive takes the merged words back -- with an atomic exchange that
+    //      also restores the slab's invariant (all zero between uses).  Only atomics touch the slab, and a slice
+    //      draws its ticket after every one of its atomics has returned, so no cache-wide release/acquire is
+    //      needed (an agent-scope fence writes back the whole L2 of the XCD: measured 2x slower here). ----------
+    if (mergeSlices) {
+        if (!merge_slices(tile, p.tileSlabs + (size_t)tileId * (TILE * TILE), &p.tileCount[(size_t)tileId * TC_STRIDE + 1u],
+                          slices, &sTicket, &p.counters->overflow)) continue;   // not the last slice: done
+        if (rmw) {
+            for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
+                const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
+                if (ly >= th || lx >= tw) continue;
+                const unsigned long long* src = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
+                tile[ly * TPITCH + lx] = max(tile[ly * TPITCH + lx], src[0]);
+                if (lx + 1 < tw) tile[ly * TPITCH + lx + 1] = max(tile[ly * TPITCH + lx + 1], src[1]);
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- tile out ------------------------------------------------------------------------------------
     if (p.clearTiles || rmw) {
@@ -1177,7 +1257,7 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.clearTiles = clearTiles ? 1u : 0u;
     p.debug = c->debugFlags;
     p.tileClocks = c->dTileClocks + (size_t)pass * CHORD_MAX_TILES;
-    p.tileOrder = c->dTileOrder;
+    p.tileOrder = c->dTileOrder; p.tileSlabs = c->dTileSlabs;
     p.tilePhase = c->dTileClocks + (size_t)2 * CHORD_MAX_TILES + (size_t)pass * CHORD_MAX_TILES * 8;
 
     // A frame zeroes every count once (begin_frame_clear); outside a frame, or from the third raster
