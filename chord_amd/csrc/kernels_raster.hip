@@ -75,6 +75,8 @@ struct RasterParams {
 #define DBG_NO_PIXELS   1u    // skip every visibility write
 #define DBG_NO_BIN      2u    // setup only: no records, no bins
 #define DBG_TILE_CLOCKS 16u   // tile kernel writes its elapsed wall-clock ticks per tile
+#define DBG_NO_OUT      128u  // tile kernel skips tile-out and the HZB reduction
+#define DBG_NO_HZB      256u  // tile kernel writes the tile but skips the HZB reduction
 #define DBG_NO_TINY     32u   // tile kernel skips the per-lane scan of tiny triangles
 #define DBG_TILE_EXIT   64u   // tile kernel of passes >= 1 returns at once (launch-floor measurement)
 
@@ -889,102 +891,91 @@ __device__ __forceinline__ uint32_t block_scan_tb(uint32_t v, uint32_t* waveSums
     return base + incl - v;
 }
 
-// Reduces the finished tile (TILE^2 packed words in LDS) to HZB mips 0..log2(TILE)-1 — the (TILE/2)^2 ... 1x1 texels this tile
-// owns — exactly as hzb_mip0_kernel + hzb_mips_kernel would from memory (edge-clamped source, binary16 RNE,
-// +1 ulp on the max chain at mip 5, hzb.hlsl:67-71), and to the tile's valid-depth range partial.
-__device__ __forceinline__ void tile_hzb_reduce(const RasterParams& p, const unsigned long long* tile, float (*sMin)[17], float (*sMax)[17],
-                                                uint32_t* sRange, uint32_t tileId, int32_t tw, int32_t th)
+// Tile-out of a finished tile fused with its HZB reduction (single-GPU frames): every word goes to the visibility
+// buffer once (16-byte coalesced stores) and, from the same LDS reads, the tile is reduced to the HZB texels it owns
+// -- mips 0..5 = 32x32 ... 1x1 -- exactly as hzb_mip0_kernel + hzb_mips_kernel would from memory (edge-clamped
+// source, binary16 RNE, +1 ulp on the max chain at mip 5, hzb.hlsl:67-71), plus the tile's valid-depth range.
+// Wave w owns pixel rows 8w..8w+7: lanes 0-31 read two pixels of an even row, lanes 32-63 of the odd row below, so a
+// mip-0 texel is one cross-half shuffle away, mips 1-2 are shuffles + the running rows of the wave, and only mips
+// 3-5 (8x8 values per tile) cross waves through LDS: one barrier per tile.
+__device__ __forceinline__ void tile_out_and_hzb(const RasterParams& p, const unsigned long long* tile, float* sM2, uint32_t* sRange,
+                                                 uint32_t tileId, int32_t ox, int32_t oy, int32_t tw, int32_t th)
 {
+    static_assert(TILE == 64 && TB == 512, "wave w <-> pixel rows 8w..8w+7");
     const ChordHZBDesc& d = p.hzbDesc;
     const uint32_t tX = tileId % p.tilesX, tY = tileId / p.tilesX;
-    const uint32_t tx = threadIdx.x & 15u, ty = (threadIdx.x >> 4) & 15u;
-    const bool hz = threadIdx.x < 256u;                                    // the reduction runs on a 16x16 thread grid
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(tile);        // depth = odd dwords
-    auto vw = [&](uint32_t l) { return min(max(1u, d.width >> l), (((d.srcWidth - 1u) >> 1) >> l) + 1u); };
-    auto vh = [&](uint32_t l) { return min(max(1u, d.height >> l), (((d.srcHeight - 1u) >> 1) >> l) + 1u); };
-    constexpr uint32_t M0 = TILE / 2;                  // mip-0 texels per tile side
-    constexpr int Q = (int)(M0 / 16u);                 // mip-0 texels per thread side (the block is 16x16 threads)
-    constexpr uint32_t L0 = Q == 2 ? 1u : 0u;          // level the 16x16 LDS grid holds after the per-thread part
-    float mn1 = 0.0f, mx1 = 0.0f;
-    uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
-    if (hz) {
-#pragma unroll
-    for (int j = 0; j < Q; j++)
-#pragma unroll
-        for (int i = 0; i < Q; i++) {
-            const uint32_t lx0 = (uint32_t)Q * tx + i, ly0 = (uint32_t)Q * ty + j;   // mip-0 texel inside the tile
-            float mn = 0.0f, mx = 0.0f;
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const int32_t px = min((int32_t)(2u * lx0 + a), tw - 1), py = min((int32_t)(2u * ly0 + b), th - 1);
-                    const float dp = __uint_as_float(words[(py * TPITCH + px) * 2 + 1]);
-                    if (a == 0 && b == 0) { mn = dp; mx = dp; } else { mn = fminf(mn, dp); mx = fmaxf(mx, dp); }
-                    if (dp > 0.0f) {                                        // hzb.hlsl:163-176
-                        const uint32_t bits = __float_as_uint(dp);
-                        if (dp < 1.0f) rmin = min(rmin, bits);
-                        rmax = max(rmax, bits);
-                    }
-                }
-            const uint32_t gx = tX * M0 + lx0, gy = tY * M0 + ly0;
-            if (gx < vw(0) && gy < vh(0)) {
-                const size_t o = d.mipOffset[0] + (size_t)gy * max(1u, d.width) + gx;
-                const uint16_t hmn = f32_to_f16(mn);
-                if (p.hzbMinA) p.hzbMinA[o] = hmn;
-                p.hzbMinB[o] = hmn;
-                p.hzbMaxB[o] = f32_to_f16(mx);
-            }
-            if (i == 0 && j == 0) { mn1 = mn; mx1 = mx; } else { mn1 = fminf(mn1, mn); mx1 = fmaxf(mx1, mx); }
-        }
-    }
-    if (hz) {
-        const uint32_t gx = tX * 16u + tx, gy = tY * 16u + ty;
-        if (Q == 2 && d.mipCount > 1 && gx < vw(1) && gy < vh(1)) {
-            const size_t o = d.mipOffset[1] + (size_t)gy * max(1u, d.width >> 1) + gx;
-            const uint16_t hmn = f32_to_f16(mn1);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = lane >> 5, l = lane & 31u;
+    auto vw = [&](uint32_t lv) { return min(max(1u, d.width >> lv), (((d.srcWidth - 1u) >> 1) >> lv) + 1u); };
+    auto vh = [&](uint32_t lv) { return min(max(1u, d.height >> lv), (((d.srcHeight - 1u) >> 1) >> lv) + 1u); };
+    auto put = [&](uint32_t lv, uint32_t gx, uint32_t gy, float mn, float mx) {
+        if (lv < d.mipCount && gx < vw(lv) && gy < vh(lv)) {
+            const size_t o = d.mipOffset[lv] + (size_t)gy * max(1u, d.width >> lv) + gx;
+            const uint16_t hmn = f32_to_f16(mn);
+            uint16_t hmx = f32_to_f16(mx);
+            if (lv == 5u) hmx = (uint16_t)(hmx + 1u);                       // storeHZBMip5
             if (p.hzbMinA) p.hzbMinA[o] = hmn;
             p.hzbMinB[o] = hmn;
-            p.hzbMaxB[o] = f32_to_f16(mx1);
+            p.hzbMaxB[o] = hmx;
         }
-        sMin[ty][tx] = mn1; sMax[ty][tx] = mx1;
-    }
+    };
+    uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
+    float m1n = 0.0f, m1x = 0.0f, m2n = 0.0f, m2x = 0.0f;
 #pragma unroll
-    for (uint32_t l = L0 + 1u; l < (uint32_t)TILE_SHIFT; l++) {
-        __syncthreads();
-        const uint32_t side = 16u >> (l - L0);                              // 8, 4, 2, 1
-        const bool act = hz && tx < side && ty < side && l < d.mipCount;
-        float rmn = 0.0f, rmx = 0.0f;
-        if (act) {
-            rmn = fminf(fminf(sMin[2 * ty][2 * tx], sMin[2 * ty][2 * tx + 1]), fminf(sMin[2 * ty + 1][2 * tx], sMin[2 * ty + 1][2 * tx + 1]));
-            rmx = fmaxf(fmaxf(sMax[2 * ty][2 * tx], sMax[2 * ty][2 * tx + 1]), fmaxf(sMax[2 * ty + 1][2 * tx], sMax[2 * ty + 1][2 * tx + 1]));
+    for (uint32_t rp = 0; rp < 4u; rp++) {
+        const int32_t row = (int32_t)(8u * wave + 2u * rp + half), x2 = (int32_t)(2u * l);
+        const int32_t rc = min(row, th - 1), xa = min(x2, tw - 1), xb = min(x2 + 1, tw - 1);
+        const unsigned long long va = tile[rc * TPITCH + xa], vb = tile[rc * TPITCH + xb];
+        if (row < th && x2 < tw) {
+            unsigned long long* dst = p.vis + (size_t)(oy + row) * (size_t)p.Wi + ox + x2;
+            if (x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(va, vb);
+            else dst[0] = va;
         }
-        __syncthreads();
-        if (act) {
-            const uint32_t gx = tX * side + tx, gy = tY * side + ty;
-            uint16_t hmn = f32_to_f16(rmn), hmx = f32_to_f16(rmx);
-            if (l == 5) hmx = (uint16_t)(hmx + 1u);                         // storeHZBMip5
-            if (gx < vw(l) && gy < vh(l)) {
-                const size_t o = d.mipOffset[l] + (size_t)gy * max(1u, d.width >> l) + gx;
-                if (p.hzbMinA) p.hzbMinA[o] = hmn;
-                p.hzbMinB[o] = hmn;
-                p.hzbMaxB[o] = hmx;
+        const float da = __uint_as_float((uint32_t)(va >> 32)), db = __uint_as_float((uint32_t)(vb >> 32));
+        if (da > 0.0f) { const uint32_t bits = __float_as_uint(da); if (da < 1.0f) rmin = min(rmin, bits); rmax = max(rmax, bits); }   // hzb.hlsl:163-176
+        if (db > 0.0f) { const uint32_t bits = __float_as_uint(db); if (db < 1.0f) rmin = min(rmin, bits); rmax = max(rmax, bits); }
+        float mn = fminf(da, db), mx = fmaxf(da, db);
+        mn = fminf(mn, __shfl_xor(mn, 32, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));       // mip 0 texel (l, 4 wave + rp)
+        if (half == 0u) put(0u, tX * 32u + l, tY * 32u + 4u * wave + rp, mn, mx);
+        const float pn = fminf(mn, __shfl_xor(mn, 1, 64)), px = fmaxf(mx, __shfl_xor(mx, 1, 64));   // x pair
+        if (rp & 1u) {
+            m1n = fminf(m1n, pn); m1x = fmaxf(m1x, px);                                        // mip 1 texel (l/2, 2 wave + rp/2)
+            if (half == 0u && (l & 1u) == 0u) put(1u, tX * 16u + (l >> 1), tY * 16u + 2u * wave + (rp >> 1), m1n, m1x);
+            const float qn = fminf(m1n, __shfl_xor(m1n, 2, 64)), qx = fmaxf(m1x, __shfl_xor(m1x, 2, 64));
+            if (rp == 1u) { m2n = qn; m2x = qx; }
+            else {
+                m2n = fminf(m2n, qn); m2x = fmaxf(m2x, qx);                                    // mip 2 texel (l/4, wave)
+                if (half == 0u && (l & 3u) == 0u) {
+                    put(2u, tX * 8u + (l >> 2), tY * 8u + wave, m2n, m2x);
+                    sM2[wave * 8u + (l >> 2)] = m2n; sM2[64u + wave * 8u + (l >> 2)] = m2x;
+                }
             }
-            sMin[ty][tx] = rmn; sMax[ty][tx] = rmx;
-        }
+        } else { m1n = pn; m1x = px; }
     }
-    // valid-range partial of this tile (reduced over tiles by hzb_tail_kernel)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         rmin = min(rmin, (uint32_t)__shfl_down(rmin, off, 64));
         rmax = max(rmax, (uint32_t)__shfl_down(rmax, off, 64));
     }
+    if (lane == 0u) { sRange[wave * 2u] = rmin; sRange[wave * 2u + 1u] = rmax; }
     __syncthreads();
-    if ((threadIdx.x & 63u) == 0u) { sRange[(threadIdx.x >> 6) * 2] = rmin; sRange[(threadIdx.x >> 6) * 2 + 1] = rmax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {                                                // waves 0..3 hold the 16x16 grid
-        p.tileRange[2u * tileId] = min(min(sRange[0], sRange[2]), min(sRange[4], sRange[6]));
-        p.tileRange[2u * tileId + 1u] = max(max(sRange[1], sRange[3]), max(sRange[5], sRange[7]));
+    if (wave == 0u) {
+        const uint32_t x = lane & 7u, y = lane >> 3;                        // mip 2 texel (x, y) of the tile
+        float n3 = sM2[lane], x3 = sM2[64u + lane];
+        n3 = fminf(n3, __shfl_xor(n3, 1, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 1, 64));
+        n3 = fminf(n3, __shfl_xor(n3, 8, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 8, 64));
+        if (!(x & 1u) && !(y & 1u)) put(3u, tX * 4u + (x >> 1), tY * 4u + (y >> 1), n3, x3);
+        n3 = fminf(n3, __shfl_xor(n3, 2, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 2, 64));
+        n3 = fminf(n3, __shfl_xor(n3, 16, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 16, 64));
+        if (!(x & 3u) && !(y & 3u)) put(4u, tX * 2u + (x >> 2), tY * 2u + (y >> 2), n3, x3);
+        n3 = fminf(n3, __shfl_xor(n3, 4, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 4, 64));
+        n3 = fminf(n3, __shfl_xor(n3, 32, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 32, 64));
+        if (lane == 0u) {
+            put(5u, tX, tY, n3, x3);
+            uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+            for (uint32_t w = 0; w < TB / 64u; w++) { lo = min(lo, sRange[2u * w]); hi = max(hi, sRange[2u * w + 1u]); }
+            p.tileRange[2u * tileId] = lo; p.tileRange[2u * tileId + 1u] = hi;   // reduced over tiles by hzb_tail_kernel
+        }
     }
 }
 
@@ -1188,9 +1179,13 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     }
 
     // ---- tile out ------------------------------------------------------------------------------------
-    if (p.clearTiles || rmw) {
-        // first pass of the frame: every word is written (16-byte coalesced stores); this is the clear.
-        // (fused-HZB later passes loaded the tile, so they store it back whole as well)
+    if (p.debug & DBG_NO_OUT) {
+    } else if (p.hzbFused && !(p.debug & DBG_NO_HZB)) {
+        // single-GPU frame: the whole tile goes out (first pass: this is the clear; later passes loaded it), and its
+        // HZB texels with it; the batch buffers are free now and hold the cross-wave part of the reduction
+        tile_out_and_hzb(p, tile, reinterpret_cast<float*>(&prm.w[0][0]), offs, tileId, ox, oy, tw, th);
+    } else if (p.clearTiles || p.hzbFused) {
+        // first pass of the frame: every word is written (16-byte coalesced stores); this is the clear
         for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
             const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
             if (ly >= th || lx >= tw || !owns_row<SH>(p.shard, oy + ly)) continue;
@@ -1208,12 +1203,6 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
             if (v != 0ull && ly < th && lx < tw && owns_row<SH>(p.shard, oy + ly))
                 atomicMax(p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx, v);
         }
-    }
-    if (p.hzbFused) {
-        // the batch buffers are free now: reuse them for the mip reduction
-        float (*sMin)[17] = reinterpret_cast<float (*)[17]>(&prm.w[0][0]);
-        float (*sMax)[17] = reinterpret_cast<float (*)[17]>(&prm.w[2][0]);
-        tile_hzb_reduce(p, tile, sMin, sMax, offs, tileId, tw, th);
     }
     PHASE(5);
     if (prof && threadIdx.x == 0) {
