@@ -256,7 +256,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
-    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs);
+    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
     dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
@@ -362,6 +362,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         DObjStatic& d = c->hObjStatic[o];
         d.prim = ob.GLTFPrimitiveDetail;
         d.twoSided = s->materials[ob.GLTFMaterialData].bTwoSided != 0 ? 1u : 0u;
+        d.shadingType = s->materials[ob.GLTFMaterialData].materialType;
         d.groupBase = (uint32_t)groupInst;
         groupInst += c->hPrims[d.prim].groupCount;
         cmdCap += primMeshlets[d.prim];
@@ -444,6 +445,7 @@ int chordvis_allocate_gbuffer(ChordCtx* c, uint32_t width, uint32_t height, uint
         return fail(c, CHORDVIS_E_INVALID, "allocate_gbuffer: render size must be 64..4096 per axis (renderer.h:52-53)");
     CHORD_HIP(c, hipSetDevice(c->device));
     c->width = width; c->height = height;
+    dfree(c->dTileMarker); dfree(c->dShadingTiles);                             // sized by the render size; re-made on demand
     return configure_targets(c, deviceVisibility);
 }
 
@@ -702,6 +704,60 @@ int chordvis_history_hzb(ChordCtx* c, ChordHZB* out)
 {
     if (!c || !out || c->historySlot == 0) return fail(c, CHORDVIS_E_INVALID, "history_hzb: no history yet");
     *out = c->hzb[c->historySlot].handle();
+    return CHORDVIS_OK;
+}
+
+// ------------------------------------------------------------------------ tile marker (8f-1) --
+
+int chordvis_visibility_mark(ChordCtx* c, ChordCountAndCmd drawed, ChordTileMarker* out)
+{
+    if (!c || !out || !c->dVis || !c->sceneLoaded) return fail(c, CHORDVIS_E_INVALID, "visibility_mark: no scene / gbuffer");
+    if (!drawed.count || !drawed.cmds) return fail(c, CHORDVIS_E_INVALID, "visibility_mark: null command list");
+    const uint32_t mW = (c->width + 7u) / 8u, mH = (c->height + 7u) / 8u;
+    int rc;
+    if (!c->dTileMarker) {
+        if ((rc = dalloc(c, &c->dTileMarker, (size_t)mW * mH * 4))) return rc;
+        if ((rc = dalloc(c, &c->dShadingTiles, (size_t)mW * mH * 2 + 8))) return rc;
+    }
+    const unsigned long long* vis = (const unsigned long long*)(c->shard.ranks > 1 ? c->dVisResolved : c->dVis);
+    chord::launch_visibility_mark(c, vis, drawed.cmds, drawed.count, c->dTileMarker);
+    CHORD_HIP(c, hipGetLastError());
+    out->marker = c->dTileMarker;
+    out->visibilityDim[0] = c->width; out->visibilityDim[1] = c->height;
+    out->markerDim[0] = mW; out->markerDim[1] = mH;
+    return CHORDVIS_OK;
+}
+
+int chordvis_prepare_shading_tile_param(ChordCtx* c, uint32_t shadingType, const ChordTileMarker* marker, ChordShadingTiles* out)
+{
+    if (!c || !marker || !out || !marker->marker || marker->marker != c->dTileMarker)
+        return fail(c, CHORDVIS_E_INVALID, "prepare_shading_tile_param: marker is not this context's");
+    if (shadingType >= 128u) return fail(c, CHORDVIS_E_INVALID, "prepare_shading_tile_param: shading type does not fit the 128-bit marker");
+    const uint32_t total = marker->markerDim[0] * marker->markerDim[1];
+    uint32_t* count = c->dShadingTiles + (size_t)total * 2;
+    chord::launch_shading_tiles(c, c->dTileMarker, shadingType, c->dShadingTiles, count, count + 4);
+    CHORD_HIP(c, hipGetLastError());
+    out->tileCmd = c->dShadingTiles; out->count = count; out->dispatchIndirect = count + 4; out->capacity = total;
+    return CHORDVIS_OK;
+}
+
+int chordvis_readback_tile_marker(ChordCtx* c, const ChordTileMarker* marker, uint32_t* host)
+{
+    if (!c || !marker || !host || !marker->marker) return fail(c, CHORDVIS_E_INVALID, "readback_tile_marker: null argument");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    CHORD_HIP(c, hipMemcpy(host, marker->marker, (size_t)marker->markerDim[0] * marker->markerDim[1] * 16, hipMemcpyDeviceToHost));
+    return CHORDVIS_OK;
+}
+
+int chordvis_readback_shading_tiles(ChordCtx* c, const ChordShadingTiles* tiles, uint32_t* hostTiles, uint32_t hostCapacity,
+                                    uint32_t* hostCount, uint32_t hostArgs[4])
+{
+    if (!c || !tiles || !tiles->count || !hostCount) return fail(c, CHORDVIS_E_INVALID, "readback_shading_tiles: null argument");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    CHORD_HIP(c, hipMemcpy(hostCount, tiles->count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (hostArgs) CHORD_HIP(c, hipMemcpy(hostArgs, tiles->dispatchIndirect, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const uint32_t n = *hostCount < hostCapacity ? *hostCount : hostCapacity;
+    if (hostTiles && n) CHORD_HIP(c, hipMemcpy(hostTiles, tiles->tileCmd, (size_t)n * 8, hipMemcpyDeviceToHost));
     return CHORDVIS_OK;
 }
 

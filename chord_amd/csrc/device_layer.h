@@ -44,7 +44,7 @@ struct DObjStatic {            // per object, derived once per upload, 16 B
     uint32_t prim;
     uint32_t twoSided;
     uint32_t groupBase;        // first flattened (object, group) index
-    uint32_t pad;
+    uint32_t shadingType;      // materials[object.GLTFMaterialData].materialType (visibility_tile.hlsl:56-60)
 };
 
 struct DObjFrame {             // per object, per frame (written by the object-cull kernel), 208 B
@@ -220,6 +220,8 @@ struct ChordCtx {
     uint32_t binCap = 0, tilesX = 0, tilesY = 0;
     chord::ClipTri* dClipTris = nullptr;
     uint32_t clipTriCap = 0;
+    uint32_t* dTileMarker = nullptr;   // [markerDim.y][markerDim.x] uint4: shading types present per 8x8 pixels
+    uint32_t* dShadingTiles = nullptr; // [markerDim.x * markerDim.y] uint2 + {count, pad, uint4 dispatch args} behind them
     uint32_t* dTileOrder = nullptr;    // [1 + tileItemCap]: item count, then work items heaviest first
     unsigned long long* dTileSlabs = nullptr;   // [tiles][TILE*TILE]: where the slices of a split tile meet (all zero between uses)
     uint32_t tileItemCap = 0;
@@ -263,6 +265,8 @@ void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool b
 void launch_hzb_mip0_exchange(ChordCtx* c);
 void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange);   // mips 6.. + range from per-tile partials
 void launch_detile(ChordCtx* c);
+void launch_visibility_mark(ChordCtx* c, const unsigned long long* vis, const ChordDrawCmd* cmds, const uint32_t* cmdCount, uint32_t* marker);
+void launch_shading_tiles(ChordCtx* c, const uint32_t* marker, uint32_t shadingType, uint32_t* tiles, uint32_t* count, uint32_t* args);
 void stamp(ChordCtx* c, int tag);               // no-op when timers are off
 
 } // namespace chord

@@ -24,6 +24,14 @@ class CountAndCmd(C.Structure):
     _fields_ = [("count", C.c_void_p), ("cmds", C.c_void_p), ("capacity", C.c_uint32)]
 
 
+class TileMarker(C.Structure):
+    _fields_ = [("marker", C.c_void_p), ("visibilityDim", C.c_uint32 * 2), ("markerDim", C.c_uint32 * 2)]
+
+
+class ShadingTiles(C.Structure):
+    _fields_ = [("tileCmd", C.c_void_p), ("count", C.c_void_p), ("dispatchIndirect", C.c_void_p), ("capacity", C.c_uint32)]
+
+
 class HZB(C.Structure):
     _fields_ = [("desc", R.HZBDesc), ("minTexels", C.c_void_p), ("maxTexels", C.c_void_p), ("validRange", C.c_void_p)]
 
@@ -123,6 +131,10 @@ def _load():
         "chordvis_readback_cmds": (i32, [vp, CountAndCmd, vp, u32, P(u32)]),
         "chordvis_readback_hzb": (i32, [vp, P(HZB), vp, vp, vp]),
         "chordvis_upload_history_hzb": (i32, [vp, vp]),
+        "chordvis_visibility_mark": (i32, [vp, CountAndCmd, P(TileMarker)]),
+        "chordvis_prepare_shading_tile_param": (i32, [vp, u32, P(TileMarker), P(ShadingTiles)]),
+        "chordvis_readback_tile_marker": (i32, [vp, P(TileMarker), vp]),
+        "chordvis_readback_shading_tiles": (i32, [vp, P(ShadingTiles), vp, u32, P(u32), vp]),
         "chordvis_enable_timers": (i32, [vp, i32]),
         "chordvis_stats": (i32, [vp, P(Stats)]),
         "chordvis_set_debug": (i32, [vp, u32]),

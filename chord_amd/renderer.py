@@ -145,6 +145,34 @@ class VisibilityRenderer:
         hzb_min = np.ascontiguousarray(hzb_min, dtype=np.uint16)
         self._check(L.lib.chordvis_upload_history_hzb(self._ctx, hzb_min.ctypes.data), "upload_history_hzb")
 
+    # -- consumers' first step (visibility_tile.cpp) -------------------------------------------------------
+    def visibility_mark(self, drawed_meshlet_cmd=None):
+        """visibilityMark (visibility_tile.cpp:20-57); the command list defaults to last_frame_cmds()."""
+        out = L.TileMarker()
+        cmd = drawed_meshlet_cmd if drawed_meshlet_cmd is not None else self.last_frame_cmds()
+        self._check(L.lib.chordvis_visibility_mark(self._ctx, cmd, C.byref(out)), "visibility_mark")
+        return out
+
+    def prepare_shading_tile_param(self, shading_type, marker):
+        """prepareShadingTileParam (visibility_tile.cpp:59-110)."""
+        out = L.ShadingTiles()
+        self._check(L.lib.chordvis_prepare_shading_tile_param(self._ctx, int(shading_type), C.byref(marker), C.byref(out)),
+                    "prepare_shading_tile_param")
+        return out
+
+    def read_tile_marker(self, marker):
+        out = np.zeros((marker.markerDim[1], marker.markerDim[0], 4), dtype=np.uint32)
+        self._check(L.lib.chordvis_readback_tile_marker(self._ctx, C.byref(marker), out.ctypes.data), "readback_tile_marker")
+        return out
+
+    def read_shading_tiles(self, tiles):
+        out = np.zeros((max(1, tiles.capacity), 2), dtype=np.uint32)
+        n = C.c_uint32(0)
+        args = np.zeros(4, dtype=np.uint32)
+        self._check(L.lib.chordvis_readback_shading_tiles(self._ctx, C.byref(tiles), out.ctypes.data, tiles.capacity,
+                                                           C.byref(n), args.ctypes.data), "readback_shading_tiles")
+        return out[:n.value].copy(), args
+
     # -- readback -------------------------------------------------------------------------------------
     def read_visibility(self):
         out = np.empty(self.width * self.height, dtype=np.uint64)

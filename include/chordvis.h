@@ -54,6 +54,21 @@ typedef struct ChordHZB {
     uint32_t*    validRange;  /* device uint2 {asuint(min), asuint(max)} or NULL */
 } ChordHZB;
 
+/* VisibilityTileMarkerContext — visibility_tile.h:11-19.  One uint4 (128 shading-type bits) per 8x8 pixels. */
+typedef struct ChordTileMarker {
+    uint32_t* marker;            /* device, 4 words per texel, markerDim[0] x markerDim[1] texels, row-major */
+    uint32_t  visibilityDim[2];
+    uint32_t  markerDim[2];      /* ceil(visibilityDim / 8), visibility_tile.cpp:31 */
+} ChordTileMarker;
+
+/* VisibilityTileContxt — visibility_tile.h:29-33 */
+typedef struct ChordShadingTiles {
+    uint32_t* tileCmd;           /* device uint2 per tile: pixel origin of an 8x8 tile; order unspecified (as in the reference) */
+    uint32_t* count;             /* device: number of tiles */
+    uint32_t* dispatchIndirect;  /* device uint4 {(count + 3) / 4, 1, 1, 1} */
+    uint32_t  capacity;          /* markerDim[0] * markerDim[1] */
+} ChordShadingTiles;
+
 /* Camera inputs of ICamera (camera.h:22-139) + ViewportCamera::updateMatrixMisc (viewport.cpp:434-445). */
 typedef struct ChordCameraDesc {
     double   position[3];
@@ -209,11 +224,23 @@ uint64_t* chordvis_resolved_visibility_ptr(ChordCtx* ctx);
 int chordvis_last_frame_cmds(ChordCtx* ctx, ChordCountAndCmd* out);
 int chordvis_history_hzb(ChordCtx* ctx, ChordHZB* out);
 
+/* ------------------------------------------------------------------ consumers' first step */
+/* visibilityMark — visibility_tile.cpp:20-57 (tilerMarkerCS, visibility_tile.hlsl:65-134): marks, per 8x8 pixels of
+ * the (resolved, row-major) visibility buffer, which material shading types occur.  drawedMeshletCmd = the list
+ * the visibility ids index, i.e. chordvis_last_frame_cmds (renderer.cpp:354,359). */
+int chordvis_visibility_mark(ChordCtx* ctx, ChordCountAndCmd drawedMeshletCmd, ChordTileMarker* out);
+/* prepareShadingTileParam — visibility_tile.cpp:59-110 (tilePrepareCS + prepareTileParamCS, visibility_tile.hlsl:136-219) */
+int chordvis_prepare_shading_tile_param(ChordCtx* ctx, uint32_t shadingType, const ChordTileMarker* marker, ChordShadingTiles* out);
+
 /* ------------------------------------------------------------------ readback / stats (synchronize) */
 
 int chordvis_readback_visibility(ChordCtx* ctx, uint64_t* hostWords /* width*height, row-major */);
 int chordvis_readback_cmds(ChordCtx* ctx, ChordCountAndCmd handle, ChordDrawCmd* hostCmds, uint32_t cap, uint32_t* outCount);
 int chordvis_readback_hzb(ChordCtx* ctx, const ChordHZB* hzb, uint16_t* hostMin, uint16_t* hostMax, uint32_t hostValidRange[2]);
+/* host: 4 words per marker texel; tiles: 2 words per tile (at most hostCapacity tiles are copied) */
+int chordvis_readback_tile_marker(ChordCtx* ctx, const ChordTileMarker* marker, uint32_t* host);
+int chordvis_readback_shading_tiles(ChordCtx* ctx, const ChordShadingTiles* tiles, uint32_t* hostTiles, uint32_t hostCapacity,
+                                    uint32_t* hostCount, uint32_t hostDispatchArgs[4]);
 /* upload an HZB min chain from the host (tests: feed a known history) into history */
 int chordvis_upload_history_hzb(ChordCtx* ctx, const uint16_t* hostMin);
 

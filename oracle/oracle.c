@@ -780,3 +780,90 @@ void orc_frame(const ChordSceneDesc* scene, const ChordCameraView* view, const C
     }
     if (outHzbMin) orc_hzb_build(vis, W, H, &hd, outHzbMin, outHzbMax, outValidRange);  /* renderer.cpp:343 */
 }
+
+/* ================================================================================================
+ * Visibility tile marker and shading tile lists — visibility_tile.hlsl, visibility_tile.cpp
+ * ================================================================================================ */
+
+/* remap8x8 — base.hlsli:363-366 */
+static void remap8x8(uint32_t tid, uint32_t* x, uint32_t* y)
+{
+    *x = (((tid >> 2) & 0x7u) & 0xFFFEu) | (tid & 0x1u);
+    *y = ((tid >> 1) & 0x3u) | (((tid >> 3) & 0x7u) & 0xFFFCu);
+}
+
+/* getShadingType — visibility_tile.hlsl:39-63.  packID = the R32_UINT visibility texel = low word here. */
+static uint32_t shading_type(const ChordSceneDesc* scene, uint32_t packID, const ChordDrawCmd* cmds, uint32_t cmdCount)
+{
+    if (packID == 0u) return 0u;                                   /* kLightingType_None, base.h:422 */
+    const uint32_t instanceId = ((packID >> 8) & CHORD_MAX_INSTANCE_ID) - 1u;   /* base.hlsli:443-447 */
+    if (instanceId >= cmdCount) return 0u;                         /* (the shader would read out of bounds) */
+    const ChordDrawCmd cmd = cmds[instanceId];                     /* check(drawCmd.z == instanceId), :54 */
+    const ChordObject* obj = &scene->objects[cmd.objectId];
+    return scene->materials[obj->GLTFMaterialData].materialType;   /* :56-60 */
+}
+
+void orc_visibility_mark(const ChordSceneDesc* scene, const uint64_t* vis, uint32_t W, uint32_t H,
+                         const ChordDrawCmd* cmds, uint32_t cmdCount, uint32_t* marker)
+{
+    const uint32_t mW = (W + 7u) / 8u, mH = (H + 7u) / 8u;        /* visibility_tile.cpp:31 */
+    const uint32_t gW = (mW + 3u) / 4u, gH = (mH + 3u) / 4u;      /* dispatch, visibility_tile.cpp:54 */
+    for (uint32_t gy = 0; gy < gH; gy++)
+        for (uint32_t gx = 0; gx < gW; gx++) {
+            uint32_t s[8][8][4];                                   /* sTileMarkerR/G/B/A[x][y], :34-37 */
+            for (uint32_t tid = 0; tid < 64u; tid++) {
+                uint32_t rx, ry;
+                remap8x8(tid, &rx, &ry);
+                uint32_t m[4] = {0, 0, 0, 0};
+                for (uint32_t y = 0; y < 2u; y++)
+                    for (uint32_t x = 0; x < 2u; x++) {
+                        /* Gather at uv = (gatherPos + 1) * texelSize with a point/clamp-to-edge sampler: the 2x2
+                         * texels gatherPos + {0,1}^2, coordinates clamped to the image (:83-87) */
+                        const uint32_t px = gx * 32u + 4u * rx + 2u * x, py = gy * 32u + 4u * ry + 2u * y;
+                        for (uint32_t j = 0; j < 2u; j++)
+                            for (uint32_t i = 0; i < 2u; i++) {
+                                const uint32_t cx = px + i < W ? px + i : W - 1u, cy = py + j < H ? py + j : H - 1u;
+                                const uint32_t t = shading_type(scene, (uint32_t)(vis[(size_t)cy * W + cx] & 0xFFFFFFFFull), cmds, cmdCount);
+                                m[(t / 32u) & 3u] |= 1u << (t % 32u);            /* :92-93 (types < 128) */
+                            }
+                    }
+                for (int k = 0; k < 4; k++) s[rx][ry][k] = m[k];
+            }
+            for (uint32_t rx = 0; rx < 8u; rx += 2u)               /* :104-110 */
+                for (uint32_t ry = 0; ry < 8u; ry++)
+                    for (int k = 0; k < 4; k++) s[rx][ry][k] |= s[rx + 1u][ry][k];
+            for (uint32_t rx = 0; rx < 8u; rx += 2u)               /* :112-118 (only even x is read afterwards) */
+                for (uint32_t ry = 0; ry < 8u; ry += 2u)
+                    for (int k = 0; k < 4; k++) s[rx][ry][k] |= s[rx][ry + 1u][k];
+            for (uint32_t rx = 0; rx < 8u; rx += 2u)               /* :120-131 */
+                for (uint32_t ry = 0; ry < 8u; ry += 2u) {
+                    const uint32_t sx = gx * 4u + rx / 2u, sy = gy * 4u + ry / 2u;
+                    if (sx < mW && sy < mH)                        /* out-of-range image stores are dropped */
+                        for (int k = 0; k < 4; k++) marker[((size_t)sy * mW + sx) * 4u + (uint32_t)k] = s[rx][ry][k];
+                }
+        }
+}
+
+uint32_t orc_shading_tiles(const uint32_t* marker, uint32_t mW, uint32_t mH, uint32_t shadingType,
+                           uint32_t* tiles, uint32_t dispatchArgs[4])
+{
+    const uint32_t index = shadingType / 32u, bit = 1u << (shadingType % 32u);   /* visibility_tile.cpp:76-77 */
+    const uint32_t gW = (mW + 15u) / 16u, gH = (mH + 15u) / 16u;                 /* :83 */
+    uint32_t count = 0;
+    for (uint32_t gy = 0; gy < gH; gy++)
+        for (uint32_t gx = 0; gx < gW; gx++)
+            for (uint32_t tid = 0; tid < 64u; tid++) {
+                uint32_t rx, ry;
+                remap8x8(tid, &rx, &ry);
+                for (uint32_t y = 0; y < 2u; y++)
+                    for (uint32_t x = 0; x < 2u; x++) {
+                        const uint32_t sx = gx * 16u + rx + x * 8u, sy = gy * 16u + ry + y * 8u;   /* :141,152 */
+                        if (sx >= mW || sy >= mH) continue;                                  /* bAllInRange :170 */
+                        if (!(marker[((size_t)sy * mW + sx) * 4u + (index & 3u)] & bit)) continue;   /* :169 */
+                        tiles[2u * count] = sx * 8u; tiles[2u * count + 1u] = sy * 8u;       /* :174 */
+                        count++;
+                    }
+            }
+    dispatchArgs[0] = (count + 3u) / 4u; dispatchArgs[1] = 1u; dispatchArgs[2] = 1u; dispatchArgs[3] = 1u;   /* :211-216 */
+    return count;
+}

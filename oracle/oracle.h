@@ -114,6 +114,19 @@ void orc_raster_mt(const ChordSceneDesc* scene, const ChordInstanceCullingView* 
                    const ChordDrawCmd* cmds, uint32_t count, uint32_t threads,
                    uint64_t* vis, OrcRasterStats* stats);
 
+/* Visibility tile marker — visibility_tile.hlsl:39-134 (tilerMarkerCS): one uint4 (128 shading-type bits)
+ * per 8x8 pixels; marker holds 4 words per texel, markerDim = ceil(dim / 8) (visibility_tile.cpp:31).
+ * cmds = the post-instanceCulling list the visibility ids index (renderer.cpp:354,359). */
+void orc_visibility_mark(const ChordSceneDesc* scene, const uint64_t* vis, uint32_t W, uint32_t H,
+                         const ChordDrawCmd* cmds, uint32_t cmdCount, uint32_t* marker);
+
+/* Shading tile list — visibility_tile.hlsl:136-219 (tilePrepareCS, prepareTileParamCS): pixel origins of
+ * the 8x8 tiles whose marker has the bit of shadingType, their count and the indirect dispatch argument
+ * {(count+3)/4, 1, 1, 1}.  The reference's list order is scheduling-dependent (one atomic per wave); this
+ * restatement emits in workgroup / lane / sample order.  Returns the count. */
+uint32_t orc_shading_tiles(const uint32_t* marker, uint32_t markerW, uint32_t markerH, uint32_t shadingType,
+                           uint32_t* tiles, uint32_t dispatchArgs[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,3 +34,39 @@ def assert_vis_equal(got, want, w, h, what=""):
     y, x = bad[0]
     raise AssertionError("%s visibility mismatch at %d pixels; first (x=%d, y=%d): got %#018x want %#018x"
                          % (what, len(bad), x, y, int(got[y, x]), int(want[y, x])))
+
+
+def with_shading_types(scene, types=(1, 37, 100, 64, 127)):
+    """A copy of `scene` in which object i has its own material of shading type types[i % len(types)]
+    (the procedural scenes use type 1 throughout; the tile marker wants variety)."""
+    mats = scene.materials[scene.objects["GLTFMaterialData"]].copy()
+    mats["materialType"] = np.asarray(types, dtype=np.uint32)[np.arange(len(mats)) % len(types)]
+    objs = scene.objects.copy()
+    objs["GLTFMaterialData"] = np.arange(len(objs), dtype=np.uint32)
+    out = R.Scene(objs, scene.primitives, mats, scene.meshlets, scene.groups, scene.group_indices,
+                  scene.meshlet_data, scene.positions, name=scene.name + "+types")
+    if hasattr(scene, "local_to_world"):
+        out.local_to_world = scene.local_to_world
+    return out
+
+
+def brute_force_marker(scene, vis, w, h, cmds):
+    """Per 8x8 pixels the set of shading types present (empty pixel = type 0), straight from the definition."""
+    low = (np.asarray(vis, dtype=np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32).reshape(h, w)
+    slot = ((low >> 8) & 0xFFFFFF).astype(np.int64) - 1
+    obj = np.asarray(cmds["objectId"], dtype=np.int64)
+    typ = np.zeros((h, w), dtype=np.uint32)
+    hit = low != 0
+    typ[hit] = scene.materials["materialType"][scene.objects["GLTFMaterialData"][obj[slot[hit]]]]
+    mw, mh = (w + 7) // 8, (h + 7) // 8
+    marker = np.zeros((mh, mw, 4), dtype=np.uint32)
+    for y in range(h):
+        for x in range(w):
+            t = int(typ[y, x])
+            marker[y // 8, x // 8, t // 32] |= np.uint32(1 << (t % 32))
+    return marker
+
+
+def tiles_with_type(marker, t):
+    ys, xs = np.nonzero(marker[:, :, t // 32] & np.uint32(1 << (t % 32)))
+    return sorted((int(x) * 8, int(y) * 8) for x, y in zip(xs, ys))

@@ -52,6 +52,8 @@ def _load():
     lib.orc_raster_snapped_triangle.argtypes = [vp, vp, vp, i32, u32, u32, u32, P(Shard), vp, P(RasterStats)]
     lib.orc_frame.restype = None
     lib.orc_frame.argtypes = [P(R.SceneDesc), vp, vp, u32, vp, P(Shard), vp, vp, u32, vp, vp, vp, vp, P(RasterStats)]
+    lib.orc_visibility_mark.restype, lib.orc_visibility_mark.argtypes = None, [P(R.SceneDesc), vp, u32, u32, vp, u32, vp]
+    lib.orc_shading_tiles.restype, lib.orc_shading_tiles.argtypes = u32, [vp, u32, u32, u32, vp, vp]
     lib.orc_raster_mt.restype = None
     lib.orc_raster_mt.argtypes = [P(R.SceneDesc), vp, vp, u32, u32, vp, P(RasterStats)]
     return lib
@@ -147,3 +149,23 @@ def frame(scene, view, iv, flags, prev_hzb_min=None, shard=None):
                   hmin.ctypes.data, hmax.ctypes.data, rng.ctypes.data, C.byref(st))
     return dict(vis=vis, cmds=cmds[:counts[0]].copy(), counts=counts, desc=d, hzb_min=hmin, hzb_max=hmax,
                 valid_range=rng, stats=st)
+
+
+def visibility_mark(scene, vis, w, h, cmds):
+    """uint32[(mH, mW, 4)] marker of visibility_tile.hlsl:tilerMarkerCS."""
+    vis = np.ascontiguousarray(vis, dtype=np.uint64)
+    cmds = np.ascontiguousarray(cmds, dtype=R.DRAW_CMD)
+    mw, mh = (w + 7) // 8, (h + 7) // 8
+    marker = np.zeros((mh, mw, 4), dtype=np.uint32)
+    lib.orc_visibility_mark(C.byref(scene.desc), vis.ctypes.data, w, h, cmds.ctypes.data, len(cmds), marker.ctypes.data)
+    return marker
+
+
+def shading_tiles(marker, shading_type):
+    """(tiles uint32[(n, 2)] pixel origins, dispatch args uint32[4]) of tilePrepareCS + prepareTileParamCS."""
+    marker = np.ascontiguousarray(marker, dtype=np.uint32)
+    mh, mw = marker.shape[:2]
+    tiles = np.zeros((mh * mw, 2), dtype=np.uint32)
+    args = np.zeros(4, dtype=np.uint32)
+    n = lib.orc_shading_tiles(marker.ctypes.data, mw, mh, shading_type, tiles.ctypes.data, args.ctypes.data)
+    return tiles[:n].copy(), args

@@ -273,3 +273,51 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu):
                    [sr[k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible")]
     for r in ctxs + [ref]:
         r.close()
+
+
+def test_tile_marker_and_shading_tile_lists_match_oracle(gpu):
+    """visibilityMark + prepareShadingTileParam on a rendered frame whose objects carry five different
+    shading types; render size not a multiple of 8 or 32.  Marker bit-exact; tile lists equal as sets (the
+    reference's list order is scheduling-dependent), counts and dispatch arguments exact."""
+    W, Hh = 203, 117
+    scene, cam = scenes.small_test_scene(W, Hh, seed=21)
+    scene = H.with_shading_types(scene)
+    from chord_amd import lib as L
+    L.fill_objects(scene, cam)
+    view, iv = L.make_views(cam)
+    want = orc.frame(scene, view, iv, H.ALL_FLAGS)
+    r = _renderer(gpu, scene, view, iv, W, Hh, H.ALL_FLAGS)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want["vis"], W, Hh, "marker frame")
+    marker = r.visibility_mark()
+    got = r.read_tile_marker(marker)
+    ref = orc.visibility_mark(scene, want["vis"], W, Hh, want["cmds"])
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    assert np.array_equal(ref, H.brute_force_marker(scene, want["vis"], W, Hh, want["cmds"]))
+    types_seen = [t for t in (0, 1, 37, 100, 64, 127) if H.tiles_with_type(ref, t)]
+    assert len(types_seen) >= 4, types_seen
+    for t in (0, 1, 37, 100, 64, 127, 5):
+        tiles, args = r.read_shading_tiles(r.prepare_shading_tile_param(t, marker))
+        ref_tiles, ref_args = orc.shading_tiles(ref, t)
+        assert sorted(map(tuple, tiles.tolist())) == sorted(map(tuple, ref_tiles.tolist()))
+        assert args.tolist() == ref_args.tolist()
+    r.close()
+
+
+def test_tile_marker_config3_4k(gpu):
+    """The marker of the full-size config 3 frame (4K) against the oracle's."""
+    scene, cam = scenes.config3_street()
+    scene = H.with_shading_types(scene, (1, 2, 3, 66, 99))
+    from chord_amd import lib as L
+    L.fill_objects(scene, cam)
+    view, iv = L.make_views(cam)
+    want = orc.frame(scene, view, iv, H.ALL_FLAGS)
+    r = _renderer(gpu, scene, view, iv, cam.width, cam.height, H.ALL_FLAGS)
+    r.render_frame()
+    marker = r.visibility_mark()
+    got = r.read_tile_marker(marker)
+    ref = orc.visibility_mark(scene, want["vis"], cam.width, cam.height, want["cmds"])
+    assert np.array_equal(got, ref)
+    tiles, args = r.read_shading_tiles(r.prepare_shading_tile_param(66, marker))
+    assert sorted(map(tuple, tiles.tolist())) == H.tiles_with_type(ref, 66) and args[0] == (len(tiles) + 3) // 4
+    r.close()

@@ -6,6 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import helpers as HP
 import orc
 from chord_amd import records as R
 from chord_amd import scenes
@@ -372,3 +373,47 @@ def test_near_plane_clipping_is_watertight_and_bounded():
         cov = vis.reshape(96, 128) != 0
         assert cov.all(), "hole in the clipped floor"
         assert st.fragments == 128 * 96                       # single layer: every pixel hit exactly once
+
+
+# ---- visibility tile marker (visibility_tile.hlsl) -----------------------------------------
+
+def _marker_case(w, h, seed):
+    """A hand-made visibility buffer over a 3-object scene with shading types 1 / 37 / 100: random rectangles of
+    each cluster id, single pixels on the last column / row, the rest empty."""
+    scene, _ = scenes.small_test_scene(w, h)
+    scene = HP.with_shading_types(scene, (1, 37, 100))
+    n = 6
+    cmds = np.zeros(n, dtype=R.DRAW_CMD)
+    cmds["objectId"] = np.arange(n) % len(scene.objects); cmds["meshletId"] = 0; cmds["slot"] = np.arange(n)
+    rng = np.random.default_rng(seed)
+    vis = np.zeros((h, w), dtype=np.uint64)
+    for k in range(10):
+        x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+        x1, y1 = min(w, x0 + int(rng.integers(1, 20))), min(h, y0 + int(rng.integers(1, 12)))
+        slot = int(rng.integers(0, n))
+        vis[y0:y1, x0:x1] = (np.uint64(0x3F000000) << np.uint64(32)) | np.uint64(((slot + 1) << 8) | int(rng.integers(0, 128)))
+    vis[h - 1, 3] = np.uint64(((2 + 1) << 8) | 5)          # bottom row, top word (depth) zero on purpose: only the id counts
+    vis[1, w - 1] = np.uint64(((1 + 1) << 8) | 9)          # last column
+    return scene, vis.reshape(-1), cmds
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (104, 72), (67, 45), (129, 33)])
+def test_tile_marker_equals_the_set_of_types_per_8x8(w, h):
+    """Sizes that are not multiples of 8 / 32 exercise the clamp-to-edge Gather and the dropped out-of-range stores."""
+    scene, vis, cmds = _marker_case(w, h, seed=w * 1000 + h)
+    got = orc.visibility_mark(scene, vis, w, h, cmds)
+    want = HP.brute_force_marker(scene, vis, w, h, cmds)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert (got[:, :, 0] & 1).any() and (got[:, :, 1] & (1 << 5)).any() and (got[:, :, 3] & (1 << 4)).any()   # types 0, 37, 100 occur
+
+
+def test_shading_tile_lists_and_dispatch_args():
+    w, h = 104, 72
+    scene, vis, cmds = _marker_case(w, h, seed=5)
+    marker = orc.visibility_mark(scene, vis, w, h, cmds)
+    for t in (0, 1, 37, 100, 64):
+        tiles, args = orc.shading_tiles(marker, t)
+        want = HP.tiles_with_type(marker, t)
+        assert sorted(map(tuple, tiles.tolist())) == want and len(set(map(tuple, tiles.tolist()))) == len(tiles)
+        assert args.tolist() == [(len(want) + 3) // 4, 1, 1, 1]
+    assert len(orc.shading_tiles(marker, 64)[0]) == 0                      # a type nobody uses
