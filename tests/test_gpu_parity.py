@@ -220,7 +220,17 @@ def test_config3_street_4k_two_pass_matches_oracle_and_properties(gpu):
     r.close()
 
 
-def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu):
+SHARDED = [
+    ("small_3ranks", lambda: scenes.small_test_scene(320, 200, seed=17), 3, 14),
+    # many small clusters per stripe: exercises the cluster-level ownership filter of the setup kernel
+    ("street_720p_4ranks", lambda: scenes.config3_street(1280, 720), 4, None),
+    # config 4 (the N > 1 bench workload) at reduced size: overflow chunks and split tiles in sharded frames
+    ("street_x64_360p_8ranks", lambda: scenes.config4_street_x64(640, 360), 8, None),
+]
+
+
+@pytest.mark.parametrize("name,builder,ranks,stripe", SHARDED, ids=[s[0] for s in SHARDED])
+def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, ranks, stripe):
     """The multi-GPU path on one device: every rank's context runs its phases in turn, the two
     all-gathers are replaced by device-to-device copies of the rank chunks, and each rank must end up
     with exactly the single-GPU visibility buffer and HZB."""
@@ -228,10 +238,12 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu):
     import torch
     from chord_amd import lib as L
     from chord_amd.renderer import VisibilityRenderer
-    scene, cam, view, iv = H.setup_scene(lambda: scenes.small_test_scene(320, 200, seed=17))
+    from chord_amd.sharding import pick_stripe_rows
+    scene, cam, view, iv = H.setup_scene(builder)
     w, h, flags = cam.width, cam.height, H.ALL_FLAGS
     ref = _renderer(gpu, scene, view, iv, w, h, flags)
-    ranks, stripe = 3, 14
+    if stripe is None:
+        stripe = pick_stripe_rows(h, ranks)
     ctxs = []
     for rk in range(ranks):
         r = VisibilityRenderer(0)
