@@ -291,7 +291,7 @@ __device__ __forceinline__ void write_record(TriRec* dst, const TriSetup& ts, co
 // ---- the per-cluster setup kernel -------------------------------------------------------------
 enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
 
-__global__ __launch_bounds__(256) void raster_setup_kernel(RasterParams p)
+__global__ __launch_bounds__(256, 6) void raster_setup_kernel(RasterParams p)
 {
     __shared__ float sX[4][LDS_VERTS], sY[4][LDS_VERTS], sW[4][LDS_VERTS];
     __shared__ float sU[4][LDS_VERTS], sV[4][LDS_VERTS], sD[4][LDS_VERTS];
@@ -303,25 +303,45 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(RasterParams p)
     const uint32_t count = *p.count;
     const uint32_t listShard = (blockIdx.x * 4u + wave) % CHORD_LIST_SHARDS;
 
-    for (uint32_t c = blockIdx.x * 4u + wave; c < count; c += gridDim.x * 4u) {
-        // wave-uniform record fetches (scalarised by the compiler: addresses are uniform)
-        const uint32_t cu = __builtin_amdgcn_readfirstlane(c);
-        const ChordDrawCmd cmd = p.cmds[cu];
-        const uint32_t objectId = __builtin_amdgcn_readfirstlane(cmd.objectId);
-        const uint32_t meshletId = __builtin_amdgcn_readfirstlane(cmd.meshletId);
-        const uint32_t slot = __builtin_amdgcn_readfirstlane(cmd.slot);
-        const DMeshlet* __restrict__ m = &p.meshlets[meshletId];
-        const uint32_t vt = __builtin_amdgcn_readfirstlane(m->vertexTriangleCount);
-        const uint32_t V = vt & 0xFFu, T = (vt >> 8) & 0xFFu;
-        const uint32_t dataOffset = __builtin_amdgcn_readfirstlane(m->dataOffset);
-        const uint32_t vertexBase = __builtin_amdgcn_readfirstlane(m->vertexBase);
-        const bool twoSided = __builtin_amdgcn_readfirstlane(p.objStatic[objectId].twoSided) != 0;
-        const float* __restrict__ mv = p.objFrame[objectId].mvp;
+    // Wave-uniform header of a cluster (scalar loads: the addresses are uniform).  The chain command -> meshlet /
+    // object records -> index stream -> positions is four dependent memory round trips per cluster; the header of
+    // the NEXT cluster is fetched while the current one is processed (command at the top of the iteration, records
+    // after the vertex phase), which takes two of them off the critical path.
+    struct Header {
+        uint32_t objectId, meshletId, slot, V, T, dataOffset, vertexBase;
+        bool twoSided;
         Mat4 mvp;
+    };
+    auto load_header = [&](const ChordDrawCmd& cmd) -> Header {
+        Header h;
+        h.objectId = __builtin_amdgcn_readfirstlane(cmd.objectId);
+        h.meshletId = __builtin_amdgcn_readfirstlane(cmd.meshletId);
+        h.slot = __builtin_amdgcn_readfirstlane(cmd.slot);
+        const DMeshlet* __restrict__ mm = &p.meshlets[h.meshletId];
+        const uint32_t vt = __builtin_amdgcn_readfirstlane(mm->vertexTriangleCount);
+        h.V = vt & 0xFFu; h.T = (vt >> 8) & 0xFFu;
+        h.dataOffset = __builtin_amdgcn_readfirstlane(mm->dataOffset);
+        h.vertexBase = __builtin_amdgcn_readfirstlane(mm->vertexBase);
+        h.twoSided = __builtin_amdgcn_readfirstlane(p.objStatic[h.objectId].twoSided) != 0;
+        const float* __restrict__ mv = p.objFrame[h.objectId].mvp;
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = mv[r * 4 + cc];
+            for (int cc = 0; cc < 4; cc++) h.mvp.r[r][cc] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mv[r * 4 + cc])));
+        return h;
+    };
+    const uint32_t stride = gridDim.x * 4u;
+    uint32_t c = blockIdx.x * 4u + wave;
+    if (c >= count) return;
+    Header hdr = load_header(p.cmds[__builtin_amdgcn_readfirstlane(c)]);
+    for (; c < count; c += stride) {
+        const uint32_t cu = __builtin_amdgcn_readfirstlane(c);
+        const ChordDrawCmd cmdNext = p.cmds[__builtin_amdgcn_readfirstlane(min(c + stride, count - 1u))];
+        const uint32_t slot = hdr.slot, V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
+        const bool twoSided = hdr.twoSided;
+        const Mat4 mvp = hdr.mvp;
+        const DMeshlet* __restrict__ m = &p.meshlets[hdr.meshletId];
+        bool skip = false;
 
         // ---- sharded frames: a cluster whose projected bounds touch none of this rank's pixel rows is another
         //      rank's work (conservative: 8 AABB corners, one pixel of slack; any corner at or behind the camera
@@ -345,13 +365,19 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(RasterParams p)
             ylo = bcast(ylo, 0); yhi = bcast(yhi, 0);
             if (__ballot(unbounded) == 0ull) {
                 const int32_t y0 = max((int32_t)floorf(ylo) - 1, 0), y1 = min((int32_t)ceilf(yhi) + 1, p.Hi - 1);
-                if (y1 < y0 || !owns_any_row(p.shard, y0, y1)) continue;
+                skip = y1 < y0 || !owns_any_row(p.shard, y0, y1);
             }
         }
 
         // ---- vertex phase: coalesced index + position stream -> clip space -> LDS -------------
+        // (the triangle words of the lane travel with the vertex indices: one round trip less before the triangle phase)
+        uint32_t triWord[2] = {0u, 0u};
+        if (!skip) {
+            if (lane < T) triWord[0] = p.meshletData[dataOffset + V + lane];
+            if (lane + 64u < T) triWord[1] = p.meshletData[dataOffset + V + 64u + lane];
+        }
         bool notFast = false;
-        for (uint32_t i = lane; i < V; i += 64u) {
+        for (uint32_t i = lane; i < (skip ? 0u : V); i += 64u) {
             const uint32_t vi = p.meshletData[dataOffset + i] + vertexBase;
             const float* __restrict__ pos = p.positions + (size_t)vi * 3;
             const f4 h = mul_mv(mvp, pos[0], pos[1], pos[2], 1.0f);              // mesh_raster.hlsl:99
@@ -367,6 +393,8 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(RasterParams p)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        hdr = load_header(cmdNext);                                // in flight during the triangle phase
+        if (skip) continue;
 
         // ---- triangle phase: the (up to) two triangles of a lane are evaluated first, then emitted together so
         //      that every round of list / bin reservations costs ONE atomic round trip for both ------------------
@@ -382,7 +410,7 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(RasterParams p)
             ts.px0 = ts.py0 = ts.px1 = ts.py1 = 0;
             float d[3] = {0.0f, 0.0f, 0.0f};
             if (t < T) {
-                const uint32_t packedIdx = p.meshletData[dataOffset + V + t];
+                const uint32_t packedIdx = triWord[half];
                 const uint32_t i0 = packedIdx & 0xFFu, i1 = (packedIdx >> 8) & 0xFFu, i2 = (packedIdx >> 16) & 0xFFu;
                 const float x0 = lX[i0], y0 = lY[i0], w0 = lW[i0];
                 const float x1 = lX[i1], y1 = lY[i1], w1 = lW[i1];
