@@ -831,6 +831,20 @@ int chordvis_debug_tile_profile(ChordCtx* c, int pass, uint64_t* hostTicks, uint
     return CHORDVIS_OK;
 }
 
+int chordvis_debug_setup_profile(ChordCtx* c, int pass, uint64_t hostTicks[5], uint32_t* waves)
+{
+    if (!c || pass < 0 || pass > 1 || !hostTicks) return fail(c, CHORDVIS_E_INVALID, "debug_setup_profile: bad arguments");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)CHORD_MAX_TILES * 8;
+    std::vector<uint64_t> v(n);
+    CHORD_HIP(c, hipMemcpy(v.data(), c->dTileClocks + (size_t)2 * CHORD_MAX_TILES + (size_t)pass * CHORD_MAX_TILES * 8, n * 8, hipMemcpyDeviceToHost));
+    const uint32_t w = (uint32_t)std::min<size_t>((size_t)c->numCUs * 6 * 4, n / 5);
+    for (int i = 0; i < 5; i++) hostTicks[i] = 0;
+    for (uint32_t k = 0; k < w; k++) for (int i = 0; i < 5; i++) hostTicks[i] += v[(size_t)k * 5 + i];
+    if (waves) *waves = w;
+    return CHORDVIS_OK;
+}
+
 int chordvis_enable_timers(ChordCtx* c, int enable)
 {
     if (!c) return CHORDVIS_E_INVALID;
@@ -862,7 +876,7 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
     }
     out->overflow = dc.overflow;
     out->rasterLaunches = c->rasterCalls;
-    for (uint32_t i = 0; i < CHORD_LIST_SHARDS; i++) out->triangleRecords += dc.triCount[i];
+    for (uint32_t i = 0; i < CHORD_LIST_SHARDS; i++) out->triangleRecords += dc.triCount[i * CHORD_SHARD_STRIDE];
     if (c->tilesX) {
         std::vector<uint32_t> tc((size_t)c->tilesX * c->tilesY);
         for (int pass = 0; pass < 2; pass++) {

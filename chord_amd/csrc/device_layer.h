@@ -84,10 +84,13 @@ struct ClipTri { uint32_t cmdIndex; uint32_t tri; };       // needs the homogene
 // list allocation is not serialised on one memory-side atomic (one word sustains only ~88 returning
 // atomics/us on MI355X); a wave picks its shard from its global wave id.
 #define CHORD_LIST_SHARDS 64u
+#define CHORD_SHARD_STRIDE 16u
 struct DeviceCounters {
-    uint32_t triCount[CHORD_LIST_SHARDS];       // records appended this frame (both raster passes)
+    // shard counters sit one per 64-byte line (CHORD_SHARD_STRIDE words apart): atomics on different words of one
+    // line still serialise at the L2
+    uint32_t triCount[CHORD_LIST_SHARDS * CHORD_SHARD_STRIDE];   // records appended this frame (both raster passes)
     uint32_t clipTriCount[2];                   // per raster pass
-    uint32_t largeCount[2];                     // per raster pass: records touching more than 2x2 tiles
+    uint32_t largeCount[2][CHORD_LIST_SHARDS * CHORD_SHARD_STRIDE];  // per raster pass and list shard: records touching more than 2x2 tiles
     uint32_t overflow;                          // bit0 record list / tile bin / large list, bit1 clip list, bit2 bin chunk wait timed out
     uint32_t binPoolCount[2];                   // per raster pass: overflow chunks handed out
     uint32_t pad;
@@ -225,7 +228,7 @@ struct ChordCtx {
     uint32_t* dTileOrder = nullptr;    // [1 + tileItemCap]: item count, then work items heaviest first
     unsigned long long* dTileSlabs = nullptr;   // [tiles][TILE*TILE]: where the slices of a split tile meet (all zero between uses)
     uint32_t tileItemCap = 0;
-    uint32_t* dLargeList = nullptr;    // [2 passes][largeCap / 2] record indices
+    uint32_t* dLargeList = nullptr;    // [2 passes][CHORD_LIST_SHARDS][largeCap / 2 / CHORD_LIST_SHARDS] record indices
     uint32_t largeCap = 0;
     chord::DeviceCounters* dCounters = nullptr;
     bool pendingClear = false;         // the next raster pass starts every tile from zero (fused clear)

@@ -77,6 +77,7 @@ struct RasterParams {
 #define DBG_TILE_CLOCKS 16u   // tile kernel writes its elapsed wall-clock ticks per tile
 #define DBG_NO_OUT      128u  // tile kernel skips tile-out and the HZB reduction
 #define DBG_NO_HZB      256u  // tile kernel writes the tile but skips the HZB reduction
+#define DBG_SETUP_CLOCKS 512u // setup kernel accumulates per-wave phase ticks (header / vertex / triangle / reserve / emit)
 #define DBG_NO_TINY     32u   // tile kernel skips the per-lane scan of tiny triangles
 #define DBG_TILE_EXIT   64u   // tile kernel of passes >= 1 returns at once (launch-floor measurement)
 
@@ -229,46 +230,59 @@ __device__ __forceinline__ void bin_store(const RasterParams& p, uint32_t tile, 
     if (id != CHORD_BIN_CHUNK_INVALID) p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))] = gi;
 }
 
-// Bins two records per lane (triangles lane and lane + 64 of the meshlet) whose clamped bboxes touch at most
-// 2x2 tiles each; the atomics of both are issued before either result is waited for.
-__device__ __forceinline__ void wave_bin_small2(const RasterParams& p, bool emitA, const TriSetup& tsA, uint32_t giA,
-                                                bool emitB, const TriSetup& tsB, uint32_t giB, uint32_t lane)
+// Bin reservations of two records per lane (triangles lane and lane + 64 of the meshlet) whose clamped bboxes touch
+// at most 2x2 tiles each, split into ISSUE and COMMIT so that the caller can put every atomic of a cluster -- list
+// reservations and bin reservations -- into ONE memory round trip and do all its stores afterwards (returning
+// atomics and stores share the in-order vmcnt: a reservation issued behind the 48-byte record stores waits for
+// them; reserve + emit were 30 of 40 us per cluster in the profile of config 3):
+//   * the primary tile of every record (almost all entries) is reserved once per distinct tile of the wave;
+//   * the up to three further tiles of a record that straddles a tile boundary (few lanes) are reserved by the
+//     lane itself, one entry each.
+struct BinTicket {
+    uint32_t tileA[4], tileB[4], slotA[4], slotB[4];
+    uint32_t has;                 // bit r: A has tile r, bit 4 + r: B
+    BinElect eA, eB;
+};
+
+__device__ __forceinline__ void wave_bin_issue(const RasterParams& p, bool emitA, const TriSetup& tsA, bool emitB, const TriSetup& tsB,
+                                               uint32_t lane, BinTicket& k)
 {
+    auto tile_of = [&](const TriSetup& ts, int r, bool emit, uint32_t& tile) -> bool {
+        const int32_t tx0 = ts.px0 >> TILE_SHIFT, tx1 = ts.px1 >> TILE_SHIFT, ty0 = ts.py0 >> TILE_SHIFT, ty1 = ts.py1 >> TILE_SHIFT;
+        const int32_t tx = (r & 1) ? tx1 : tx0, ty = (r & 2) ? ty1 : ty0;
+        bool has = emit && !((r & 1) && tx1 == tx0) && !((r & 2) && ty1 == ty0);
+        if (has) has = owns_any_row(p.shard, max(ts.py0, ty << TILE_SHIFT), min(ts.py1, (ty << TILE_SHIFT) + TILE - 1));
+        tile = has ? (uint32_t)ty * p.tilesX + (uint32_t)tx : 0u;
+        return has;
+    };
+    k.has = 0u;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        bool hasA = emitA, hasB = emitB;
-        uint32_t tileA = 0, tileB = 0;
-        {
-            const int32_t tx0 = tsA.px0 >> TILE_SHIFT, tx1 = tsA.px1 >> TILE_SHIFT, ty0 = tsA.py0 >> TILE_SHIFT, ty1 = tsA.py1 >> TILE_SHIFT;
-            const int32_t tx = (r & 1) ? tx1 : tx0, ty = (r & 2) ? ty1 : ty0;
-            hasA = hasA && !((r & 1) && tx1 == tx0) && !((r & 2) && ty1 == ty0);
-            if (hasA) hasA = owns_any_row(p.shard, max(tsA.py0, ty << TILE_SHIFT), min(tsA.py1, (ty << TILE_SHIFT) + TILE - 1));
-            if (hasA) tileA = (uint32_t)ty * p.tilesX + (uint32_t)tx;
-        }
-        {
-            const int32_t tx0 = tsB.px0 >> TILE_SHIFT, tx1 = tsB.px1 >> TILE_SHIFT, ty0 = tsB.py0 >> TILE_SHIFT, ty1 = tsB.py1 >> TILE_SHIFT;
-            const int32_t tx = (r & 1) ? tx1 : tx0, ty = (r & 2) ? ty1 : ty0;
-            hasB = hasB && !((r & 1) && tx1 == tx0) && !((r & 2) && ty1 == ty0);
-            if (hasB) hasB = owns_any_row(p.shard, max(tsB.py0, ty << TILE_SHIFT), min(tsB.py1, (ty << TILE_SHIFT) + TILE - 1));
-            if (hasB) tileB = (uint32_t)ty * p.tilesX + (uint32_t)tx;
-        }
-        const unsigned long long anyA = __ballot(hasA), anyB = __ballot(hasB);
-        if (!(anyA | anyB)) continue;
-        const BinElect eA = wave_bin_elect(hasA, tileA, lane);
-        const BinElect eB = wave_bin_elect(hasB, tileB, lane);
-        uint32_t baseA = 0, baseB = 0;
-        if (hasA && (int)lane == eA.leader) baseA = atomicAdd(&p.tileCount[(size_t)tileA * TC_STRIDE], eA.group);
-        if (hasB && (int)lane == eB.leader) baseB = atomicAdd(&p.tileCount[(size_t)tileB * TC_STRIDE], eB.group);
-        baseA = __shfl(baseA, eA.leader, 64);
-        baseB = __shfl(baseB, eB.leader, 64);
-        if (hasA) {
-            const uint32_t slot = baseA + eA.rank;
-            bin_store(p, tileA, slot, giA);
-        }
-        if (hasB) {
-            const uint32_t slot = baseB + eB.rank;
-            bin_store(p, tileB, slot, giB);
-        }
+        k.slotA[r] = 0u; k.slotB[r] = 0u;
+        if (tile_of(tsA, r, emitA, k.tileA[r])) k.has |= 1u << r;
+        if (tile_of(tsB, r, emitB, k.tileB[r])) k.has |= 16u << r;
+    }
+    k.eA = wave_bin_elect((k.has & 1u) != 0u, k.tileA[0], lane);
+    k.eB = wave_bin_elect((k.has & 16u) != 0u, k.tileB[0], lane);
+    if ((k.has & 1u) && (int)lane == k.eA.leader) k.slotA[0] = atomicAdd(&p.tileCount[(size_t)k.tileA[0] * TC_STRIDE], k.eA.group);
+    if ((k.has & 16u) && (int)lane == k.eB.leader) k.slotB[0] = atomicAdd(&p.tileCount[(size_t)k.tileB[0] * TC_STRIDE], k.eB.group);
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+        if (k.has & (1u << r)) k.slotA[r] = atomicAdd(&p.tileCount[(size_t)k.tileA[r] * TC_STRIDE], 1u);
+        if (k.has & (16u << r)) k.slotB[r] = atomicAdd(&p.tileCount[(size_t)k.tileB[r] * TC_STRIDE], 1u);
+    }
+}
+
+// (a record that did not fit its list leaves its reserved bin slots unwritten: the frame is reported incomplete
+// anyway, and a stale entry of an earlier frame is a valid index)
+__device__ __forceinline__ void wave_bin_commit(const RasterParams& p, BinTicket& k, bool okA, uint32_t giA, bool okB, uint32_t giB)
+{
+    k.slotA[0] = __shfl(k.slotA[0], k.eA.leader, 64) + k.eA.rank;
+    k.slotB[0] = __shfl(k.slotB[0], k.eB.leader, 64) + k.eB.rank;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (okA && (k.has & (1u << r))) bin_store(p, k.tileA[r], k.slotA[r], giA);
+        if (okB && (k.has & (16u << r))) bin_store(p, k.tileB[r], k.slotB[r], giB);
     }
 }
 
@@ -291,7 +305,7 @@ __device__ __forceinline__ void write_record(TriRec* dst, const TriSetup& ts, co
 // ---- the per-cluster setup kernel -------------------------------------------------------------
 enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
 
-__global__ __launch_bounds__(256, 6) void raster_setup_kernel(RasterParams p)
+__global__ __launch_bounds__(256, 5) void raster_setup_kernel(RasterParams p)
 {
     __shared__ float sX[4][LDS_VERTS], sY[4][LDS_VERTS], sW[4][LDS_VERTS];
     __shared__ float sU[4][LDS_VERTS], sV[4][LDS_VERTS], sD[4][LDS_VERTS];
@@ -334,6 +348,9 @@ __global__ __launch_bounds__(256, 6) void raster_setup_kernel(RasterParams p)
     uint32_t c = blockIdx.x * 4u + wave;
     if (c >= count) return;
     Header hdr = load_header(p.cmds[__builtin_amdgcn_readfirstlane(c)]);
+    const bool sprof = (p.debug & DBG_SETUP_CLOCKS) != 0;
+    unsigned long long sph[5] = {0, 0, 0, 0, 0}, stp = sprof ? wall_clock64() : 0ull;
+#define SPHASE(i) do { if (sprof) { const unsigned long long tn = wall_clock64(); sph[i] += tn - stp; stp = tn; } } while (0)
     for (; c < count; c += stride) {
         const uint32_t cu = __builtin_amdgcn_readfirstlane(c);
         const ChordDrawCmd cmdNext = p.cmds[__builtin_amdgcn_readfirstlane(min(c + stride, count - 1u))];
@@ -369,6 +386,8 @@ __global__ __launch_bounds__(256, 6) void raster_setup_kernel(RasterParams p)
             }
         }
 
+        if (sprof) { volatile uint32_t sink = V + T; (void)sink; }
+        SPHASE(0);
         // ---- vertex phase: coalesced index + position stream -> clip space -> LDS -------------
         // (the triangle words of the lane travel with the vertex indices: one round trip less before the triangle phase)
         uint32_t triWord[2] = {0u, 0u};
@@ -377,22 +396,35 @@ __global__ __launch_bounds__(256, 6) void raster_setup_kernel(RasterParams p)
             if (lane + 64u < T) triWord[1] = p.meshletData[dataOffset + V + 64u + lane];
         }
         bool notFast = false;
-        for (uint32_t i = lane; i < (skip ? 0u : V); i += 64u) {
-            const uint32_t vi = p.meshletData[dataOffset + i] + vertexBase;
-            const float* __restrict__ pos = p.positions + (size_t)vi * 3;
-            const f4 h = mul_mv(mvp, pos[0], pos[1], pos[2], 1.0f);              // mesh_raster.hlsl:99
-            const float aw = fabsf(h.w);
-            lX[i] = h.x; lY[i] = h.y; lW[i] = h.w;
-            lU[i] = h.x / aw * 0.5f + 0.5f;                                      // :159-161
-            lV[i] = h.y / aw * -0.5f + 0.5f;
-            const bool fast = in_fast_volume(h);
-            lD[i] = fast ? h.z / h.w : __builtin_nanf("");
-            notFast = notFast || !fast;
+        // two vertices per lane and trip: both index loads, then both position loads, are in flight together
+        // (V = 81 is typical: one trip = two dependent round trips instead of four)
+        for (uint32_t i0 = lane; i0 < (skip ? 0u : V); i0 += 128u) {
+            const uint32_t i1 = i0 + 64u;
+            const bool second = i1 < V;
+            const uint32_t va = p.meshletData[dataOffset + i0] + vertexBase;
+            const uint32_t vb = second ? p.meshletData[dataOffset + i1] + vertexBase : va;
+            const float* __restrict__ pa = p.positions + (size_t)va * 3;
+            const float* __restrict__ pb = p.positions + (size_t)vb * 3;
+            const float ax = pa[0], ay = pa[1], az = pa[2], bx = pb[0], by = pb[1], bz = pb[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (k == 1 && !second) break;
+                const uint32_t i = k ? i1 : i0;
+                const f4 h = k ? mul_mv(mvp, bx, by, bz, 1.0f) : mul_mv(mvp, ax, ay, az, 1.0f);   // mesh_raster.hlsl:99
+                const float aw = fabsf(h.w);
+                lX[i] = h.x; lY[i] = h.y; lW[i] = h.w;
+                lU[i] = h.x / aw * 0.5f + 0.5f;                                  // :159-161
+                lV[i] = h.y / aw * -0.5f + 0.5f;
+                const bool fast = in_fast_volume(h);
+                lD[i] = fast ? h.z / h.w : __builtin_nanf("");
+                notFast = notFast || !fast;
+            }
         }
         const bool allFast = __ballot(notFast) == 0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        SPHASE(1);
         hdr = load_header(cmdNext);                                // in flight during the triangle phase
         if (skip) continue;
 
@@ -443,6 +475,7 @@ __global__ __launch_bounds__(256, 6) void raster_setup_kernel(RasterParams p)
             if (half == 0) { kindA = kind; tsA = ts; dA[0] = d[0]; dA[1] = d[1]; dA[2] = d[2]; }
             else           { kindB = kind; tsB = ts; dB[0] = d[0]; dB[1] = d[1]; dB[2] = d[2]; }
         }
+        SPHASE(2);
         {
             const unsigned long long lt = (1ull << lane) - 1ull;
             const unsigned long long cmA = __ballot(kindA == K_CLIP), cmB = __ballot(kindB == K_CLIP);
@@ -451,27 +484,27 @@ __global__ __launch_bounds__(256, 6) void raster_setup_kernel(RasterParams p)
             const unsigned long long lmA = __ballot(lgA), lmB = __ballot(lgB);
             const uint32_t nClip = (uint32_t)(__popcll(cmA) + __popcll(cmB)), nEm = (uint32_t)(__popcll(emA) + __popcll(emB));
             const uint32_t nLg = (uint32_t)(__popcll(lmA) + __popcll(lmB));
-            // the three list reservations of the wave travel together: one atomic round trip
+            // every reservation of the cluster travels together: the three list reservations (lane 0) and the bin
+            // reservations; nothing is stored before they are back
             uint32_t cbase = 0, ebase = 0, lbase = 0;
             if (lane == 0) {
                 if (nClip) cbase = atomicAdd(&p.counters->clipTriCount[p.pass], nClip);
-                if (nEm) ebase = atomicAdd(&p.counters->triCount[listShard], nEm);
-                if (nLg) lbase = atomicAdd(&p.counters->largeCount[p.pass], nLg);
+                if (nEm) ebase = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], nEm);
+                if (nLg) lbase = atomicAdd(&p.counters->largeCount[p.pass][listShard * CHORD_SHARD_STRIDE], nLg);
             }
+            BinTicket ticket;
+            if (emA | emB) wave_bin_issue(p, kindA == K_EMIT && !lgA, tsA, kindB == K_EMIT && !lgB, tsB, lane, ticket);
             cbase = bcast(cbase, 0); ebase = bcast(ebase, 0); lbase = bcast(lbase, 0);
-            if (kindA == K_CLIP || kindB == K_CLIP) {
-                const bool isA = kindA == K_CLIP;     // at most one of the two is handled per statement below
-                if (kindA == K_CLIP) {
-                    const uint32_t k = cbase + (uint32_t)__popcll(cmA & lt);
-                    if (k < p.clipTriCap) { ClipTri ct; ct.cmdIndex = cu; ct.tri = lane; p.clipTris[k] = ct; }
-                    else atomicOr(&p.counters->overflow, 2u);
-                }
-                if (kindB == K_CLIP) {
-                    const uint32_t k = cbase + (uint32_t)__popcll(cmA) + (uint32_t)__popcll(cmB & lt);
-                    if (k < p.clipTriCap) { ClipTri ct; ct.cmdIndex = cu; ct.tri = lane + 64u; p.clipTris[k] = ct; }
-                    else atomicOr(&p.counters->overflow, 2u);
-                }
-                (void)isA;
+            SPHASE(3);
+            if (kindA == K_CLIP) {
+                const uint32_t k = cbase + (uint32_t)__popcll(cmA & lt);
+                if (k < p.clipTriCap) { ClipTri ct; ct.cmdIndex = cu; ct.tri = lane; p.clipTris[k] = ct; }
+                else atomicOr(&p.counters->overflow, 2u);
+            }
+            if (kindB == K_CLIP) {
+                const uint32_t k = cbase + (uint32_t)__popcll(cmA) + (uint32_t)__popcll(cmB & lt);
+                if (k < p.clipTriCap) { ClipTri ct; ct.cmdIndex = cu; ct.tri = lane + 64u; p.clipTris[k] = ct; }
+                else atomicOr(&p.counters->overflow, 2u);
             }
             uint32_t giA = 0, giB = 0;
             bool okA = false, okB = false;
@@ -486,20 +519,26 @@ __global__ __launch_bounds__(256, 6) void raster_setup_kernel(RasterParams p)
                 else atomicOr(&p.counters->overflow, 1u);
             }
             // <= 2x2 tiles: straight into the bins; more: the large list
-            if (emA | emB) wave_bin_small2(p, okA && !lgA, tsA, giA, okB && !lgB, tsB, giB, lane);
+            if (emA | emB) wave_bin_commit(p, ticket, okA, giA, okB, giB);
             if (lgA && okA) {
                 const uint32_t k = lbase + (uint32_t)__popcll(lmA & lt);
-                if (k < p.largeCap) p.largeList[k] = giA; else atomicOr(&p.counters->overflow, 1u);
+                if (k < p.largeCap) p.largeList[(size_t)listShard * p.largeCap + k] = giA; else atomicOr(&p.counters->overflow, 1u);
             }
             if (lgB && okB) {
                 const uint32_t k = lbase + (uint32_t)__popcll(lmA) + (uint32_t)__popcll(lmB & lt);
-                if (k < p.largeCap) p.largeList[k] = giB; else atomicOr(&p.counters->overflow, 1u);
+                if (k < p.largeCap) p.largeList[(size_t)listShard * p.largeCap + k] = giB; else atomicOr(&p.counters->overflow, 1u);
             }
         }
         // LDS of this wave is rewritten by the next cluster: order the reads above before those writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        SPHASE(4);
     }
+    if (sprof && lane == 0u) {
+        const uint32_t w = blockIdx.x * 4u + wave;
+        if (w < CHORD_MAX_TILES * 8u / 5u) for (int i = 0; i < 5; i++) p.tilePhase[(size_t)w * 5u + i] = sph[i];
+    }
+#undef SPHASE
 }
 
 // One lane bins one record into every tile its clamped bbox may touch (conservative edge test at the tile
@@ -607,7 +646,7 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
             const float d[3] = {PD[0], PD[i], PD[i + 1]};
             ts.payload = payload;
             if (!tri_setup(ts, twoSided, p.Wi, p.Hi) || !owns_any_row(p.shard, ts.py0, ts.py1)) continue;
-            const uint32_t li = atomicAdd(&p.counters->triCount[listShard], 1u);
+            const uint32_t li = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], 1u);
             if (li >= p.triCap) { atomicOr(&p.counters->overflow, 1u); continue; }
             const uint32_t gi = listShard * p.triCap + li;
             write_record(&p.tris[gi], ts, d, twoSided);
@@ -623,9 +662,24 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
 __device__ void raster_bin_large_part(const RasterParams& p, uint32_t block, uint32_t blocks)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t n = min(p.counters->largeCount[p.pass], p.largeCap);
+    // the list is cut into CHORD_LIST_SHARDS sub-lists (one reservation counter each: a single word sustains only
+    // ~88 returning atomics per microsecond); a flat index is mapped to (shard, entry) through their prefix sums
+    __shared__ uint32_t sStart[CHORD_LIST_SHARDS + 1];
+    if (threadIdx.x < 64u) {
+        const uint32_t cnt = min(p.counters->largeCount[p.pass][threadIdx.x * CHORD_SHARD_STRIDE], p.largeCap);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t nb = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += nb; }
+        sStart[threadIdx.x + 1u] = incl;
+        if (threadIdx.x == 0u) sStart[0] = 0u;
+    }
+    __syncthreads();
+    const uint32_t n = sStart[CHORD_LIST_SHARDS];
     for (uint32_t k = block * 4u + wave; k < n; k += blocks * 4u) {
-        const uint32_t gi = __builtin_amdgcn_readfirstlane(p.largeList[__builtin_amdgcn_readfirstlane(k)]);
+        uint32_t sh = 0;
+#pragma unroll
+        for (uint32_t st = 32u; st > 0u; st >>= 1) if (sStart[sh + st] <= k) sh += st;
+        const uint32_t gi = __builtin_amdgcn_readfirstlane(p.largeList[(size_t)sh * p.largeCap + (k - sStart[sh])]);
         const TriRec* __restrict__ r = &p.tris[gi];
         TriSetup ts;
 #pragma unroll
@@ -1269,7 +1323,7 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.binStamp = ++c->rasterSerial;
     p.tilesX = c->tilesX; p.tilesY = c->tilesY;
     p.clipTris = c->dClipTris + (size_t)pass * (c->clipTriCap / 2); p.clipTriCap = c->clipTriCap / 2; p.pass = pass;
-    p.largeList = c->dLargeList + (size_t)pass * (c->largeCap / 2); p.largeCap = c->largeCap / 2;
+    p.largeList = c->dLargeList + (size_t)pass * (c->largeCap / 2); p.largeCap = c->largeCap / 2 / CHORD_LIST_SHARDS;   // per shard
     p.counters = c->dCounters;
     p.clearTiles = clearTiles ? 1u : 0u;
     p.debug = c->debugFlags;
@@ -1282,9 +1336,9 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     if (!c->inFrame || c->rasterCalls >= 2) {
         (void)hipMemsetAsync(p.tileCount, 0, sizeof(uint32_t) * TC_STRIDE * tiles, c->stream);
         (void)hipMemsetAsync(&c->dCounters->clipTriCount[pass], 0, sizeof(uint32_t), c->stream);
-        (void)hipMemsetAsync(&c->dCounters->largeCount[pass], 0, sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(c->dCounters->largeCount[pass], 0, sizeof(c->dCounters->largeCount[pass]), c->stream);
         (void)hipMemsetAsync(&c->dCounters->binPoolCount[pass], 0, sizeof(uint32_t), c->stream);
-        if (!c->inFrame) (void)hipMemsetAsync(c->dCounters->triCount, 0, sizeof(uint32_t) * CHORD_LIST_SHARDS, c->stream);
+        if (!c->inFrame) (void)hipMemsetAsync(c->dCounters->triCount, 0, sizeof(c->dCounters->triCount), c->stream);
     }
 
     uint32_t blocks = (in.capacity + 3u) / 4u;

@@ -139,6 +139,7 @@ def _load():
         "chordvis_stats": (i32, [vp, P(Stats)]),
         "chordvis_set_debug": (i32, [vp, u32]),
         "chordvis_debug_tile_profile": (i32, [vp, i32, vp, vp, u32]),
+        "chordvis_debug_setup_profile": (i32, [vp, i32, vp, P(u32)]),
     }
     missing = []
     for name, (res, args) in protos.items():
