@@ -305,7 +305,7 @@ __device__ __forceinline__ void write_record(TriRec* dst, const TriSetup& ts, co
 // ---- the per-cluster setup kernel -------------------------------------------------------------
 enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
 
-__global__ __launch_bounds__(256, 5) void raster_setup_kernel(RasterParams p)
+__global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
 {
     __shared__ float sX[4][LDS_VERTS], sY[4][LDS_VERTS], sW[4][LDS_VERTS];
     __shared__ float sU[4][LDS_VERTS], sV[4][LDS_VERTS], sD[4][LDS_VERTS];
@@ -1342,7 +1342,7 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     }
 
     uint32_t blocks = (in.capacity + 3u) / 4u;
-    const uint32_t maxBlocks = (uint32_t)c->numCUs * 6u;
+    const uint32_t maxBlocks = (uint32_t)c->numCUs * 4u;    // what is resident at 4 waves per SIMD
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
     const bool sh = c->shard.ranks > 1;
