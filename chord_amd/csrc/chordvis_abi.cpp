@@ -392,7 +392,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     c->dObjects = c->dObjectsOwned;
     if ((rc = dalloc(c, &c->dObjFrame, (size_t)s->objectCount))) return rc;
     if ((rc = dalloc(c, &c->dGroupMask, (size_t)c->groupInstances))) return rc;
-    if ((rc = dalloc(c, &c->dBlockCounts, (size_t)c->cullBlocks))) return rc;
+    if ((rc = dalloc(c, &c->dBlockCounts, (size_t)c->cullBlocks * 2))) return rc;   // counts, then triangles, per count block
     for (int i = 0; i < 3; i++) {
         if ((rc = dalloc(c, &c->lists[i].cmds, (size_t)c->cmdCapacity))) return rc;
         c->lists[i].count = c->dCounts + i;

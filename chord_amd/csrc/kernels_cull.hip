@@ -188,7 +188,7 @@ struct GroupCullParams {
 __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    uint32_t mask = 0;
+    uint32_t mask = 0, tris = 0;
     if (t < p.groupInstances) {
         const uint32_t o = p.groupOwner[t];
         const DObjFrame& of = p.objFrame[o];
@@ -202,33 +202,81 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
                 const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
                 for (uint32_t i = 0; i < g.meshletCount && i < CHORD_GROUP_MAX_MESHLETS; i++) {
                     const uint32_t mi = prim.meshletBase + p.groupIndices[idxBase + i];  // :178-180
-                    if (meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, st.twoSided != 0, p.meshlets[mi]))
+                    if (meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, st.twoSided != 0, p.meshlets[mi])) {
                         mask |= 1u << i;
+                        tris += (p.meshlets[mi].vertexTriangleCount >> 8) & 0xFFu;
+                    }
                 }
             }
         }
         p.groupMask[t] = (uint8_t)mask;
     }
-    uint32_t total;
+    uint32_t total, blockTris;
     (void)block_excl_scan(__popc(mask), &total);
-    if (threadIdx.x == 0) p.blockCounts[blockIdx.x] = total;
+    (void)block_excl_scan(tris, &blockTris);
+    if (threadIdx.x == 0) { p.blockCounts[blockIdx.x] = total; p.blockCounts[gridDim.x + blockIdx.x] = blockTris; }
 }
 
+// Long scenes (thousands of count blocks): one workgroup turns the per-block counts into exclusive offsets, so the
+// scatter kernel reads its base instead of summing all preceding counts itself (that is quadratic in the number of
+// blocks: 34 us at config 4), and adds up the triangles of the list (the Gtri/s unit).
+__global__ __launch_bounds__(1024) void group_cull_prefix_kernel(uint32_t* __restrict__ blockCounts, uint32_t blocks,
+                                                                 uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters)
+{
+    __shared__ uint32_t sWave[16];
+    __shared__ unsigned long long sTris[16];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    unsigned long long tris = 0;
+    for (uint32_t base = 0; base < blocks; base += 1024u) {
+        const uint32_t b = base + threadIdx.x;
+        const uint32_t v = b < blocks ? blockCounts[b] : 0u;
+        if (b < blocks) tris += blockCounts[blocks + b];
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t nb = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += nb; }
+        if (lane == 63u) sWave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16u; w++) { const uint32_t c = sWave[w]; if (w < wave) before += c; all += c; }
+        if (b < blocks) blockCounts[b] = carry + before + incl - v;
+        carry += all;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tris += __shfl_down(tris, off, 64);
+    if (lane == 0u) sTris[wave] = tris;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (uint32_t w = 0; w < 16u; w++) t += sTris[w];
+        *outCount = carry;
+        if (t) atomicAdd(&counters->trisInstanceCulled, t);
+    }
+}
+
+// PREFIXED: blockCounts already holds exclusive offsets (group_cull_prefix_kernel ran); otherwise every block sums the
+// preceding blocks' counts itself (a few hundred blocks: cheaper than one more launch).
+template <bool PREFIXED>
 __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams p, ChordDrawCmd* __restrict__ outCmds,
                                                                  uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters)
 {
-    // exclusive prefix of the preceding blocks' counts (B <= a few thousand: one strided pass)
     __shared__ uint32_t red[256];
-    uint32_t part = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) part += p.blockCounts[b];
-    red[threadIdx.x] = part;
-    __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    uint32_t blockBase;
+    if (PREFIXED) blockBase = p.blockCounts[blockIdx.x];
+    else {
+        uint32_t part = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) part += p.blockCounts[b];
+        red[threadIdx.x] = part;
+        __syncthreads();
+        for (uint32_t s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        blockBase = red[0];
         __syncthreads();
     }
-    const uint32_t blockBase = red[0];
-    __syncthreads();
 
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t mask = t < p.groupInstances ? p.groupMask[t] : 0u;
@@ -249,11 +297,12 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
                 cmd.meshletId = prim.meshletBase + p.groupIndices[idxBase + i];
                 cmd.slot = slot;                                            // instance_culling.hlsl:203-206
                 outCmds[slot] = cmd;
-                tris += (p.meshlets[cmd.meshletId].vertexTriangleCount >> 8) & 0xFFu;
+                if (!PREFIXED) tris += (p.meshlets[cmd.meshletId].vertexTriangleCount >> 8) & 0xFFu;
                 slot++;
             }
         }
     }
+    if (PREFIXED) return;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *outCount = blockBase + total;
     // triangles this list submits (the Gtri/s unit): one fire-and-forget atomic per block
     uint32_t blockTris;
@@ -428,7 +477,12 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     p.dview = c->dView; p.groupMask = c->dGroupMask; p.blockCounts = c->dBlockCounts; p.groupInstances = c->groupInstances;
     const uint32_t blocks = c->cullBlocks;
     hipLaunchKernelGGL(group_cull_count_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
-    hipLaunchKernelGGL(group_cull_scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+    if (blocks > 512u) {
+        hipLaunchKernelGGL(group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters);
+        hipLaunchKernelGGL(group_cull_scatter_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+    } else {
+        hipLaunchKernelGGL(group_cull_scatter_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+    }
 }
 
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
