@@ -115,7 +115,7 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         const size_t tilesN = (size_t)c->tilesX * c->tilesY;
         const size_t sliceBound = ((tilesN * c->binCap + (size_t)c->binPoolChunks * CHORD_BIN_CHUNK) >> CHORD_TILE_SLICE_SHIFT) + tilesN;
         c->tileItemCap = (uint32_t)(sliceBound + tilesN);
-        if ((rc = dalloc(c, &c->dTileOrder, (size_t)1 + c->tileItemCap))) return rc;
+        if ((rc = dalloc(c, &c->dTileOrder, ((size_t)1 + c->tileItemCap) * 2))) return rc;   // uint2 per item
         if ((rc = dalloc(c, &c->dTileSlabs, tilesN * CHORD_TILE * CHORD_TILE))) return rc;
         CHORD_HIP(c, hipMemset(c->dTileSlabs, 0, tilesN * CHORD_TILE * CHORD_TILE * sizeof(unsigned long long)));
     }

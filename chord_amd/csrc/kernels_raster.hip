@@ -59,7 +59,7 @@ struct RasterParams {
     ClipTri* clipTris; uint32_t clipTriCap; uint32_t pass;   // raster pass of the frame (0 / 1): clip / large count slot
     uint32_t* largeList; uint32_t largeCap;                  // records touching more than 2x2 tiles (binned by raster_bin_large_kernel)
     DeviceCounters* counters;
-    uint32_t* tileOrder;                                // [0] = work item count, [1..] items (tile | slice << 12 | (slices-1) << 22), heaviest first
+    uint2* tileOrder;                                   // [0].x = work item count, [1..] = {tile | slice << 12 | (slices-1) << 22, bin count}, heaviest first
     unsigned long long* tileSlabs;                      // one TILE x TILE accumulation slab per tile (all zero between uses)
     // fused HZB (single-GPU frames): the tile kernel reduces its finished 64x64 tile to mips 0..5
     uint32_t hzbFused;                                  // 0: off (later passes merge with global atomicMax)
@@ -745,13 +745,14 @@ __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
     if (threadIdx.x == 0) splitItems = 0;
     __syncthreads();
     constexpr uint32_t PER_THREAD = CHORD_MAX_TILES / 1024u;
-    uint32_t myBucket[PER_THREAD], myPos[PER_THREAD], mySlices[PER_THREAD];
+    uint32_t myBucket[PER_THREAD], myPos[PER_THREAD], mySlices[PER_THREAD], myCount[PER_THREAD];
 #pragma unroll
     for (uint32_t k = 0; k < PER_THREAD; k++) {
         const uint32_t t = threadIdx.x + k * 1024u;
-        myBucket[k] = 0xFFFFFFFFu; myPos[k] = 0; mySlices[k] = 1;
+        myBucket[k] = 0xFFFFFFFFu; myPos[k] = 0; mySlices[k] = 1; myCount[k] = 0;
         if (t < tiles) {
             const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], bin_capacity(p));
+            myCount[k] = c;
             if (c > TILE_SPLIT_MIN) {
                 mySlices[k] = (c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT;
                 myBucket[k] = 18u;
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
     if (threadIdx.x == 0) {
         uint32_t acc = splitItems;
         for (int b = 0; b < 18; b++) { base[b] = acc; acc += hist[b]; }
-        p.tileOrder[0] = p.clearTiles ? acc : acc - hist[17];
+        p.tileOrder[0] = make_uint2(p.clearTiles ? acc : acc - hist[17], 0u);
     }
     __syncthreads();
 #pragma unroll
@@ -775,9 +776,9 @@ __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
         const uint32_t t = threadIdx.x + k * 1024u;
         if (myBucket[k] == 0xFFFFFFFFu) continue;
         if (myBucket[k] == 18u) {
-            for (uint32_t j = 0; j < mySlices[k]; j++) p.tileOrder[1u + myPos[k] + j] = t | (j << 12) | ((mySlices[k] - 1u) << 22);
+            for (uint32_t j = 0; j < mySlices[k]; j++) p.tileOrder[1u + myPos[k] + j] = make_uint2(t | (j << 12) | ((mySlices[k] - 1u) << 22), myCount[k]);
         } else {
-            p.tileOrder[1u + base[myBucket[k]] + atomicAdd(&cursor[myBucket[k]], 1u)] = t;
+            p.tileOrder[1u + base[myBucket[k]] + atomicAdd(&cursor[myBucket[k]], 1u)] = make_uint2(t, myCount[k]);   // the count rides along: one round trip less per tile
         }
     }
 }
@@ -1104,11 +1105,12 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     __shared__ uint32_t chunkTab[CHORD_BIN_MAX_CHUNKS];
     __shared__ uint32_t sTicket;
     if ((p.debug & DBG_TILE_EXIT) && !p.clearTiles) return;
-    const uint32_t active = p.tileOrder[0];
+    const uint32_t active = p.tileOrder[0].x;
     for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
-    const uint32_t item = p.tileOrder[1u + oi];
+    const uint2 itemCount = p.tileOrder[1u + oi];
+    const uint32_t item = itemCount.x;
     const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
-    const uint32_t nAll = min(p.tileCount[(size_t)tileId * TC_STRIDE], bin_capacity(p));
+    const uint32_t nAll = itemCount.y;                            // (already clamped to the bin capacity)
     // entries [lo, n) of the bin are this item's
     const uint32_t lo = slices > 1u ? slice << TILE_SLICE_SHIFT : 0u;
     const uint32_t n = slices > 1u ? min(nAll, lo + TILE_SLICE) : nAll;
@@ -1328,7 +1330,7 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.clearTiles = clearTiles ? 1u : 0u;
     p.debug = c->debugFlags;
     p.tileClocks = c->dTileClocks + (size_t)pass * CHORD_MAX_TILES;
-    p.tileOrder = c->dTileOrder; p.tileSlabs = c->dTileSlabs;
+    p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrder); p.tileSlabs = c->dTileSlabs;
     p.tilePhase = c->dTileClocks + (size_t)2 * CHORD_MAX_TILES + (size_t)pass * CHORD_MAX_TILES * 8;
 
     // A frame zeroes every count once (begin_frame_clear); outside a frame, or from the third raster
