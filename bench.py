@@ -201,8 +201,20 @@ def main():
     dom = max(kernels, key=lambda k: kernels[k][0])
     dom_ms, dom_bytes = kernels[dom]
     achieved = (dom_bytes / launches) / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # HBM traffic of that kernel from the PMC counters: they need their own rocprofv3 passes, so the figure comes from
+    # the committed summary of those passes over this same command (profiles/, tools/profile.sh), per launch
+    traffic, traffic_src = None, None
+    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                      {"street_4k_hzb": "r01_config3_4k_hzb_traffic.json", "street_x64_4k_hzb": "r01_config4_x64_4k_hzb_traffic.json"}.get(wl, ""))
+    if world == 1 and not args.debug_flags and not args.no_hzb and os.path.isfile(tj):
+        try:
+            tk = json.load(open(tj))
+            traffic = int(tk["kernels"][dom]["hbm_bytes_per_launch"])
+            traffic_src = "profiles/" + os.path.basename(tj)
+        except (KeyError, ValueError):
+            traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(dom_ms / launches * 1e3, 2), "launches_per_step": launches,
                 "algorithmic_bytes_per_launch": int(dom_bytes / launches),
                 "other_kernel": {k: {"avg_launch_us": round(v[0] / launches * 1e3, 2), "algorithmic_bytes_per_launch": int(v[1] / launches)}

@@ -48,4 +48,28 @@ with open(os.path.join(dst, name + "_summary.md"), "w") as f:
             float(r["MaxNs"]) / 1e3, r["Percentage"], fa, fa * 2 * 1024 / 1e6, wa))
     if bench:
         f.write("\nbench.py line of the `--stats` run (timing perturbed by the profiler):\n\n```json\n%s\n```\n" % bench)
+# per-kernel HBM traffic for bench.py's roofline.traffic: 2 x FETCH_SIZE (gfx950 correction for wide reads,
+# MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KiB -> bytes, per launch
+import json
+traffic = {}
+for r in stats:
+    k = r["Name"]
+    if "chord::" not in k:
+        continue
+    fe = fetch.get(k, [0, 0.0]); wr = write.get(k, [0, 0.0])
+    if not fe[0] or not wr[0]:
+        continue
+    short = k.replace("void ", "").replace("chord::", "").split("(")[0].split("<")[0]
+    t = traffic.setdefault(short, {"fetch_kib_per_launch": 0.0, "write_kib_per_launch": 0.0, "launches": 0, "avg_us": 0.0})
+    calls = int(r["Calls"])
+    # template instances of one kernel are merged, weighted by their launches
+    t["fetch_kib_per_launch"] = (t["fetch_kib_per_launch"] * t["launches"] + fe[1] / fe[0] * calls) / (t["launches"] + calls)
+    t["write_kib_per_launch"] = (t["write_kib_per_launch"] * t["launches"] + wr[1] / wr[0] * calls) / (t["launches"] + calls)
+    t["avg_us"] = (t["avg_us"] * t["launches"] + float(r["AverageNs"]) / 1e3 * calls) / (t["launches"] + calls)
+    t["launches"] += calls
+for t in traffic.values():
+    t["hbm_bytes_per_launch"] = int((2.0 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024)
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --steps 40 --warmup 4` (tools/profile.sh); "
+                     "bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 per launch", "kernels": traffic},
+          open(os.path.join(dst, name + "_traffic.json"), "w"), indent=1)
 print("wrote", os.path.join(dst, name + "_summary.md"))
