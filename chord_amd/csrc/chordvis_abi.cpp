@@ -831,6 +831,43 @@ int chordvis_debug_tile_profile(ChordCtx* c, int pass, uint64_t* hostTicks, uint
     return CHORDVIS_OK;
 }
 
+// Measurement aid: captures two consecutive frames (the history slot alternates) into a hipGraph and replays it.
+int chordvis_debug_graph_frames(ChordCtx* c, uint32_t pairs, float* msPerFrameStream, float* msPerFrameGraph)
+{
+    if (!c || !pairs || !msPerFrameStream || !msPerFrameGraph) return fail(c, CHORDVIS_E_INVALID, "debug_graph_frames: bad arguments");
+    if (!c->ownStream) return fail(c, CHORDVIS_E_INVALID, "debug_graph_frames: needs a context-owned (capturable) stream");
+    int rc;
+    for (int i = 0; i < 4; i++) if ((rc = chordvis_render_frame(c))) return rc;
+    hipEvent_t e0, e1;
+    CHORD_HIP(c, hipEventCreate(&e0)); CHORD_HIP(c, hipEventCreate(&e1));
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    CHORD_HIP(c, hipEventRecord(e0, c->stream));
+    for (uint32_t i = 0; i < 2 * pairs; i++) if ((rc = chordvis_render_frame(c))) return rc;
+    CHORD_HIP(c, hipEventRecord(e1, c->stream));
+    CHORD_HIP(c, hipEventSynchronize(e1));
+    float ms = 0;
+    CHORD_HIP(c, hipEventElapsedTime(&ms, e0, e1));
+    *msPerFrameStream = ms / (2.0f * pairs);
+    hipGraph_t graph; hipGraphExec_t exec;
+    CHORD_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    rc = chordvis_render_frame(c);
+    if (!rc) rc = chordvis_render_frame(c);
+    hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+    if (rc) return rc;
+    CHORD_HIP(c, ce);
+    CHORD_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < 4; i++) CHORD_HIP(c, hipGraphLaunch(exec, c->stream));
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    CHORD_HIP(c, hipEventRecord(e0, c->stream));
+    for (uint32_t i = 0; i < pairs; i++) CHORD_HIP(c, hipGraphLaunch(exec, c->stream));
+    CHORD_HIP(c, hipEventRecord(e1, c->stream));
+    CHORD_HIP(c, hipEventSynchronize(e1));
+    CHORD_HIP(c, hipEventElapsedTime(&ms, e0, e1));
+    *msPerFrameGraph = ms / (2.0f * pairs);
+    (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return CHORDVIS_OK;
+}
+
 int chordvis_debug_setup_profile(ChordCtx* c, int pass, uint64_t hostTicks[5], uint32_t* waves)
 {
     if (!c || pass < 0 || pass > 1 || !hostTicks) return fail(c, CHORDVIS_E_INVALID, "debug_setup_profile: bad arguments");

@@ -255,6 +255,8 @@ int chordvis_stats(ChordCtx* ctx, ChordStats* out);
 int chordvis_set_debug(ChordCtx* ctx, uint32_t flags);
 /* Measurement only: with debug bit 4 set the tile kernel records its elapsed wall-clock ticks (100 MHz)
  * per 64x64 tile; this reads them back with the tile's bin count for raster pass 0 / 1 of the last frame. */
+/* measurement aid: ms per frame of 2*pairs stream-launched frames vs the same frames replayed from a hipGraph */
+int chordvis_debug_graph_frames(ChordCtx* ctx, uint32_t pairs, float* msPerFrameStream, float* msPerFrameGraph);
 /* debug bit 512: per-wave phase ticks (10 ns) of the setup kernel summed over waves: header wait / vertex / triangle / reserve / emit */
 int chordvis_debug_setup_profile(ChordCtx* ctx, int pass, uint64_t hostTicks[5], uint32_t* waves);
 int chordvis_debug_tile_profile(ChordCtx* ctx, int pass, uint64_t* hostTicks, uint32_t* hostCounts, uint32_t capacity);
