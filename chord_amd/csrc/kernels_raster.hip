@@ -78,6 +78,7 @@ struct RasterParams {
 #define DBG_NO_OUT      128u  // tile kernel skips tile-out and the HZB reduction
 #define DBG_NO_HZB      256u  // tile kernel writes the tile but skips the HZB reduction
 #define DBG_SETUP_CLOCKS 512u // setup kernel accumulates per-wave phase ticks (header / vertex / triangle / reserve / emit)
+#define DBG_NO_VIS_STORE 1024u // fused tile-out skips the visibility stores (HZB texels still written: culling unchanged)
 #define DBG_NO_TINY     32u   // tile kernel skips the per-lane scan of tiny triangles
 #define DBG_TILE_EXIT   64u   // tile kernel of passes >= 1 returns at once (launch-floor measurement)
 
@@ -1008,7 +1009,7 @@ __device__ __forceinline__ void tile_out_and_hzb(const RasterParams& p, const un
         const int32_t row = (int32_t)(8u * wave + 2u * rp + half), x2 = (int32_t)(2u * l);
         const int32_t rc = min(row, th - 1), xa = min(x2, tw - 1), xb = min(x2 + 1, tw - 1);
         const unsigned long long va = tile[rc * TPITCH + xa], vb = tile[rc * TPITCH + xb];
-        if (row < th && x2 < tw) {
+        if (row < th && x2 < tw && !(p.debug & DBG_NO_VIS_STORE)) {
             unsigned long long* dst = p.vis + (size_t)(oy + row) * (size_t)p.Wi + ox + x2;
             if (x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(va, vb);
             else dst[0] = va;

@@ -417,3 +417,108 @@ def test_shading_tile_lists_and_dispatch_args():
         assert sorted(map(tuple, tiles.tolist())) == want and len(set(map(tuple, tiles.tolist()))) == len(tiles)
         assert args.tolist() == [(len(want) + 3) // 4, 1, 1, 1]
     assert len(orc.shading_tiles(marker, 64)[0]) == 0                      # a type nobody uses
+
+
+# ---- independent restatement of the raster rule: exact rational geometry in Python -------------------------
+
+def _ref_raster_fraction(X, Y, d, two_sided, payload, w, h):
+    """Coverage from first principles with exact rationals, written independently of oracle.c: a pixel centre
+    (px + 1/2, py + 1/2) is covered iff it lies strictly inside the triangle, or on an edge that is a 'top' edge
+    (exactly horizontal, interior below it in y-down space) or a 'left' edge (interior to its right) -- the D3D/
+    Vulkan top-left rule.  Depth: barycentric weights as exact rationals rounded ONCE to float32 is NOT the
+    canonical value (the pinned formula rounds E_i and 1/2A separately), so depth is recomputed with numpy float32
+    ops in the pinned order; coverage is what this reference decides on its own."""
+    from fractions import Fraction as F
+    P = [(F(int(X[i]), 256), F(int(Y[i]), 256)) for i in range(3)]
+    area2 = (P[1][0] - P[0][0]) * (P[2][1] - P[0][1]) - (P[2][0] - P[0][0]) * (P[1][1] - P[0][1])
+    out = {}
+    if area2 == 0 or (area2 > 0 and not two_sided):
+        return out
+    # orient so that the interior is on the positive side of every directed edge
+    if area2 > 0:
+        P = [P[0], P[2], P[1]]
+        order = [0, 2, 1]
+    else:
+        order = [0, 1, 2]
+    # after this, walking P0->P1->P2 has negative doubled area in y-down coordinates (clockwise on screen)
+
+    def side(a, b, q):      # > 0: q on the interior side of directed edge a->b
+        return -((b[0] - a[0]) * (q[1] - a[1]) - (b[1] - a[1]) * (q[0] - a[0]))
+
+    edges = [(P[1], P[2]), (P[2], P[0]), (P[0], P[1])]      # edge i opposite vertex i
+    xs = [p[0] for p in P]; ys = [p[1] for p in P]
+    import math
+    x0 = max(0, math.floor(min(xs)) - 1); x1 = min(w - 1, math.ceil(max(xs)) + 1)
+    y0 = max(0, math.floor(min(ys)) - 1); y1 = min(h - 1, math.ceil(max(ys)) + 1)
+    A = abs(int(X[1] - X[0]) * int(Y[2] - Y[0]) - int(X[2] - X[0]) * int(Y[1] - Y[0]))
+    invA = np.float32(1.0) / np.float32(np.float64(A))
+    dd = [np.float32(v) for v in d]
+    e1, e2 = dd[1] - dd[0], dd[2] - dd[0]
+    for py in range(y0, y1 + 1):
+        for px in range(x0, x1 + 1):
+            q = (F(2 * px + 1, 2), F(2 * py + 1, 2))
+            ok = True
+            for (a, b) in edges:
+                sd = side(a, b, q)
+                if sd > 0:
+                    continue
+                if sd < 0:
+                    ok = False; break
+                # on the edge: top edge = horizontal with the interior below (larger y); left edge = interior to the right
+                ex, ey = b[0] - a[0], b[1] - a[1]
+                # interior direction n = gradient of side(): d(side)/dx = ey, d(side)/dy = -ex
+                nx, ny = ey, -ex
+                top = (ey == 0 and ny > 0)
+                left = (nx > 0)
+                if not (top or left):
+                    ok = False; break
+            if not ok:
+                continue
+            # pinned depth formula, float32 ops in the pinned order, weights of ORIGINAL vertices 1 and 2
+            E = [None] * 3
+            for k in range(3):
+                a, b = edges[k]
+                E[order[k]] = side(a, b, q) * 256 * 256            # exact integer (sub-pixel^2 units)
+            l1 = np.float32(np.float64(int(E[1]))) * invA
+            l2 = np.float32(np.float64(int(E[2]))) * invA
+            z = (dd[0] + l1 * e1) + l2 * e2
+            out[(px, py)] = (int(np.float32(z).view(np.uint32)) << 32) | payload
+    return out
+
+
+def test_raster_rule_against_exact_rational_reference():
+    """300 random triangles (slivers, sub-pixel, vertices exactly on pixel centres and on shared edges, both
+    windings, off-screen parts) through orc_raster_snapped_triangle and through an independent Python restatement
+    that decides coverage with exact rationals and the textbook wording of the top-left rule."""
+    rng = np.random.default_rng(20260927)
+    w, h = 24, 20
+    covered = 0
+    for it in range(300):
+        mode = it % 5
+        if mode == 0:      # general position
+            X = rng.integers(-4 * 256, (w + 4) * 256, 3); Y = rng.integers(-4 * 256, (h + 4) * 256, 3)
+        elif mode == 1:    # vertices on pixel centres / half-integers: edges through centres
+            X = rng.integers(-2, w + 2, 3) * 256 + 128; Y = rng.integers(-2, h + 2, 3) * 256 + 128
+        elif mode == 2:    # sub-pixel
+            cx, cy = rng.integers(0, w * 256), rng.integers(0, h * 256)
+            X = cx + rng.integers(-200, 200, 3); Y = cy + rng.integers(-200, 200, 3)
+        elif mode == 3:    # axis-aligned edges on pixel-centre lines
+            x0, y0 = rng.integers(0, w - 4) * 256 + 128, rng.integers(0, h - 4) * 256 + 128
+            s = int(rng.integers(1, 5)) * 256
+            X = np.array([x0, x0 + s, x0]); Y = np.array([y0, y0, y0 + s])
+            if rng.integers(0, 2): X, Y = X[::-1].copy(), Y[::-1].copy()
+        else:              # slivers
+            x0, y0 = rng.integers(0, w * 256), rng.integers(0, h * 256)
+            X = np.array([x0, x0 + rng.integers(500, 3000), x0 + rng.integers(500, 3000)])
+            Y = np.array([y0, y0 + rng.integers(-40, 40), y0 + rng.integers(-40, 40)])
+        X = np.asarray(X, dtype=np.int32); Y = np.asarray(Y, dtype=np.int32)
+        d = rng.random(3).astype(np.float32) * np.float32(0.9) + np.float32(0.05)
+        two_sided = bool(rng.integers(0, 2))
+        payload = int(rng.integers(1, 1 << 31))
+        vis, _ = orc.raster_snapped_triangle(X, Y, d, two_sided, payload, w, h)
+        want = _ref_raster_fraction(X, Y, d, two_sided, payload, w, h)
+        got = {(int(i % w), int(i // w)): int(v) for i, v in enumerate(vis) if v}
+        assert got == want, "triangle %d mode %d X=%s Y=%s two_sided=%s: %d vs %d pixels, diff %s" % (
+            it, mode, X.tolist(), Y.tolist(), two_sided, len(got), len(want), sorted(set(got.items()) ^ set(want.items()))[:4])
+        covered += len(want)
+    assert covered > 3000
