@@ -132,6 +132,28 @@ def raster_snapped_triangle(X, Y, d, two_sided, payload, w, h, vis=None, shard=N
     return vis, st
 
 
+def frame_mt(scene, view, iv, flags, prev_hzb_min, threads):
+    """orc_frame's sequence (mesh_raster.cpp:269-329, renderer.cpp:319-345) with the two raster legs spread over
+    `threads` host threads (orc_raster_mt); culling and HZB builds stay scalar.  For the all-cores CPU baseline."""
+    w, h = int(iv["renderDimension"][0][0]), int(iv["renderDimension"][0][1])
+    cmds = instance_culling(scene, view, iv, flags)
+    vis = np.zeros(w * h, dtype=np.uint64)
+    tris = 0
+    if prev_hzb_min is not None and (flags & R.FLAG_HZB_CULL):
+        d = hzb_desc(w, h)
+        visible, rejected = hzb_culling(scene, view, flags, 0, d, prev_hzb_min, cmds)
+        _, st0 = raster(scene, iv, visible, w, h, vis=vis, threads=threads)
+        _, mn, _, _ = hzb_build(vis, w, h)
+        visible1, _ = hzb_culling(scene, view, flags, 1, d, mn, rejected)
+        _, st1 = raster(scene, iv, visible1, w, h, vis=vis, threads=threads)
+        tris = int(st0.trianglesSubmitted + st1.trianglesSubmitted)
+    else:
+        _, st0 = raster(scene, iv, cmds, w, h, vis=vis, threads=threads)
+        tris = int(st0.trianglesSubmitted)
+    _, mn, mx, rng = hzb_build(vis, w, h, want_max=True, want_range=True)
+    return dict(vis=vis, cmds=cmds, hzb_min=mn, hzb_max=mx, valid_range=rng, triangles_submitted=tris)
+
+
 def frame(scene, view, iv, flags, prev_hzb_min=None, shard=None):
     w, h = int(iv["renderDimension"][0][0]), int(iv["renderDimension"][0][1])
     d = hzb_desc(w, h)

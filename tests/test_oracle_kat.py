@@ -522,3 +522,20 @@ def test_raster_rule_against_exact_rational_reference():
             it, mode, X.tolist(), Y.tolist(), two_sided, len(got), len(want), sorted(set(got.items()) ^ set(want.items()))[:4])
         covered += len(want)
     assert covered > 3000
+
+
+def test_multithreaded_frame_replay_equals_orc_frame():
+    """bench.py's all-cores CPU baseline (orc.frame_mt) is the same frame as orc_frame: image, HZB and counts."""
+    scene, cam = scenes.small_test_scene(320, 200, seed=3)
+    from chord_amd import lib as L
+    L.fill_objects(scene, cam)
+    view, iv = L.make_views(cam)
+    flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | R.FLAG_HZB_CULL
+    f0 = orc.frame(scene, view, iv, flags)
+    f1 = orc.frame(scene, view, iv, flags, prev_hzb_min=f0["hzb_min"])
+    m1 = orc.frame_mt(scene, view, iv, flags, f0["hzb_min"], threads=4)
+    assert np.array_equal(m1["vis"], f1["vis"]) and np.array_equal(m1["hzb_min"], f1["hzb_min"])
+    assert np.array_equal(m1["hzb_max"], f1["hzb_max"]) and np.array_equal(m1["valid_range"], f1["valid_range"])
+    assert m1["triangles_submitted"] == f1["stats"].trianglesSubmitted
+    m0 = orc.frame_mt(scene, view, iv, flags, None, threads=3)
+    assert np.array_equal(m0["vis"], f0["vis"]) and m0["triangles_submitted"] == f0["stats"].trianglesSubmitted
