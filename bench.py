@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="auto")
-    ap.add_argument("--cpu-baseline-frames", type=int, default=8, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
+    ap.add_argument("--cpu-baseline-frames", type=int, default=48, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
     ap.add_argument("--no-hzb", action="store_true", help="disable HZB occlusion culling (frustum+cone only)")
     ap.add_argument("--debug-flags", type=int, default=0, help="raster ablation switches (measurement only; voids parity)")
     args = ap.parse_args()
@@ -267,6 +267,7 @@ def main():
         # the same frames with the raster legs on every host core (culling and HZB builds stay scalar); the image
         # must equal the single-thread one
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = min(threads, 32)      # the scalar culling / HZB legs and the shared-buffer CAS stop paying beyond this
         if threads > 1:
             m0 = time.perf_counter()
             tri_mt = 0
