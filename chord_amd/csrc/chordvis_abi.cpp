@@ -105,16 +105,15 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         c->tilesX = (c->width + CHORD_TILE - 1) >> CHORD_TILE_SHIFT; c->tilesY = (c->height + CHORD_TILE - 1) >> CHORD_TILE_SHIFT;
         c->binCap = CHORD_BIN_CAP;              // 4K: 2 passes x 2040 tiles x 16384 x 4 B = 267 MB
         if ((rc = dalloc(c, &c->dTileBins, (size_t)2 * c->tilesX * c->tilesY * c->binCap))) return rc;
-        c->binPoolChunks = 32768;               // 2 passes x 32 Ki chunks x 1024 entries x 4 B = 256 MB
+        c->binPoolChunks = c->limitPoolChunks;  // default: 2 passes x 32 Ki chunks x 1024 entries x 4 B = 256 MB
         if ((rc = dalloc(c, &c->dBinPool, (size_t)2 * c->binPoolChunks * CHORD_BIN_CHUNK))) return rc;
-        const size_t tabWords = (size_t)2 * c->tilesX * c->tilesY * CHORD_BIN_MAX_CHUNKS;
+        const size_t tabWords = (size_t)2 * c->tilesX * c->tilesY * c->binMaxChunks;
         if ((rc = dalloc(c, &c->dBinChunkTab, tabWords))) return rc;
         CHORD_HIP(c, hipMemset(c->dBinChunkTab, 0, tabWords * sizeof(unsigned long long)));
         // work items of the tile kernel: every tile once, plus the slices of split tiles (bounded by the entries
         // a pass can hold)
         const size_t tilesN = (size_t)c->tilesX * c->tilesY;
-        const size_t sliceBound = ((tilesN * c->binCap + (size_t)c->binPoolChunks * CHORD_BIN_CHUNK) >> CHORD_TILE_SLICE_SHIFT) + tilesN;
-        c->tileItemCap = (uint32_t)(sliceBound + tilesN);
+        c->tileItemCap = (uint32_t)(tilesN * (CHORD_TILE_MAX_SLICES + 1u));
         if ((rc = dalloc(c, &c->dTileOrder, ((size_t)1 + c->tileItemCap) * 2))) return rc;   // uint2 per item
         if ((rc = dalloc(c, &c->dTileSlabs, tilesN * CHORD_TILE * CHORD_TILE))) return rc;
         CHORD_HIP(c, hipMemset(c->dTileSlabs, 0, tilesN * CHORD_TILE * CHORD_TILE * sizeof(unsigned long long)));
@@ -399,7 +398,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         c->lists[i].capacity = c->cmdCapacity;
     }
     // raster work lists (fixed budgets sized for 288 GB of HBM; overflow is detected and reported by chordvis_stats)
-    c->triCap = 64u << 20;              // 64 M records x 48 B = 3 GB
+    c->triCap = (uint32_t)c->limitRecords;   // default 64 M records x 48 B = 3 GB
     c->clipTriCap = 1u << 20;
     if ((rc = dalloc(c, &c->dTris, (size_t)c->triCap))) return rc;
     if ((rc = dalloc(c, &c->dClipTris, (size_t)c->clipTriCap))) return rc;
@@ -447,6 +446,23 @@ int chordvis_allocate_gbuffer(ChordCtx* c, uint32_t width, uint32_t height, uint
     c->width = width; c->height = height;
     dfree(c->dTileMarker); dfree(c->dShadingTiles);                             // sized by the render size; re-made on demand
     return configure_targets(c, deviceVisibility);
+}
+
+int chordvis_set_limits(ChordCtx* c, const ChordLimits* limits)
+{
+    if (!c || !limits) return fail(c, CHORDVIS_E_INVALID, "set_limits: null argument");
+    if (c->sceneLoaded || c->dVis) return fail(c, CHORDVIS_E_INVALID, "set_limits: call before upload_scene / allocate_gbuffer");
+    if (limits->maxTriangleRecords) {
+        if (limits->maxTriangleRecords < (1u << 16) || limits->maxTriangleRecords > 0xF0000000ull)
+            return fail(c, CHORDVIS_E_INVALID, "set_limits: maxTriangleRecords out of range (record indices are 32-bit)");
+        c->limitRecords = limits->maxTriangleRecords & ~(uint64_t)(CHORD_LIST_SHARDS - 1);
+    }
+    if (limits->binPoolChunks) c->limitPoolChunks = limits->binPoolChunks;
+    if (limits->binMaxChunksPerTile) {
+        if (limits->binMaxChunksPerTile > CHORD_BIN_MAX_CHUNKS_LIMIT) return fail(c, CHORDVIS_E_INVALID, "set_limits: at most 3072 overflow chunks per tile");
+        c->binMaxChunks = limits->binMaxChunksPerTile;
+    }
+    return CHORDVIS_OK;
 }
 
 int chordvis_set_shard(ChordCtx* c, uint32_t stripeRows, uint32_t ranks, uint32_t rank)

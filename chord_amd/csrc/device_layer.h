@@ -102,7 +102,9 @@ struct DeviceCounters {
 // counters, the four command-list counts, and the per-pass tile bin counts (2 x tiles follow).
 #define CHORD_BIN_CHUNK_SHIFT 10
 #define CHORD_BIN_CHUNK (1u << CHORD_BIN_CHUNK_SHIFT)   // entries per overflow chunk
-#define CHORD_BIN_MAX_CHUNKS 240u                    // overflow chunks per tile: bins hold up to binCap + 240 Ki entries
+#define CHORD_BIN_MAX_CHUNKS_DEFAULT 240u            // overflow chunks per tile: bins hold up to binCap + 240 Ki entries (chordvis_set_limits)
+#define CHORD_BIN_MAX_CHUNKS_LIMIT 3072u
+#define CHORD_TILE_MAX_SLICES 64u                    // a long bin is cut into at most this many slices
 #define CHORD_BIN_CHUNK_INVALID 0xFFFFFFFFu
 #define CHORD_TILE_SLICE_SHIFT 11                    // long bins are scan-converted in slices of 2048 entries
 #ifndef CHORD_TILE_SHIFT
@@ -218,6 +220,10 @@ struct ChordCtx {
     uint32_t* dBinPool = nullptr;      // [2 passes][binPoolChunks][CHORD_BIN_CHUNK]
     unsigned long long* dBinChunkTab = nullptr;
     uint32_t binPoolChunks = 0;        // per pass
+    uint32_t binMaxChunks = CHORD_BIN_MAX_CHUNKS_DEFAULT;   // per tile
+    // capacities a host may raise before upload_scene / allocate_gbuffer (chordvis_set_limits)
+    uint64_t limitRecords = 64ull << 20;
+    uint32_t limitPoolChunks = 32768;
     uint32_t rasterSerial = 0;
     bool inFrame = false;              // inside render_frame / frame_phase_*: per-pass counts were zeroed at frame begin
     uint32_t binCap = 0, tilesX = 0, tilesY = 0;

@@ -55,7 +55,7 @@ struct RasterParams {
     TriRec* tris; uint32_t triCap;                      // per list shard
     uint32_t* tileCount; uint32_t* tileBins; uint32_t binCap; uint32_t tilesX, tilesY;
     uint32_t* binPool; uint32_t binPoolChunks; uint32_t* binPoolCount;   // overflow chunks of this pass
-    unsigned long long* binChunkTab; uint32_t binStamp;                  // [tile][CHORD_BIN_MAX_CHUNKS] serial << 32 | chunk
+    unsigned long long* binChunkTab; uint32_t binStamp; uint32_t binMaxChunks;   // [tile][binMaxChunks] serial << 32 | chunk
     ClipTri* clipTris; uint32_t clipTriCap; uint32_t pass;   // raster pass of the frame (0 / 1): clip / large count slot
     uint32_t* largeList; uint32_t largeCap;                  // records touching more than 2x2 tiles (binned by raster_bin_large_kernel)
     DeviceCounters* counters;
@@ -205,14 +205,14 @@ __device__ __forceinline__ BinElect wave_bin_elect(bool has, uint32_t tile, uint
 // to carry this pass's serial.  Every allocation of a wave is issued before any of its lanes starts waiting
 // (two sequential phases, not an if/else), and an allocator never waits, so the wait always ends; it is
 // bounded anyway (overflow bit 2) so that a logic error cannot hang the device.
-__device__ __forceinline__ uint32_t bin_capacity(const RasterParams& p) { return p.binCap + CHORD_BIN_MAX_CHUNKS * CHORD_BIN_CHUNK; }
+__device__ __forceinline__ uint32_t bin_capacity(const RasterParams& p) { return p.binCap + p.binMaxChunks * CHORD_BIN_CHUNK; }
 
 __device__ __forceinline__ void bin_store(const RasterParams& p, uint32_t tile, uint32_t slot, uint32_t gi)
 {
     if (slot < p.binCap) { p.tileBins[(size_t)tile * p.binCap + slot] = gi; return; }
     const uint32_t o = slot - p.binCap, j = o >> CHORD_BIN_CHUNK_SHIFT;
-    if (j >= CHORD_BIN_MAX_CHUNKS) { atomicOr(&p.counters->overflow, 1u); return; }
-    unsigned long long* ent = p.binChunkTab + (size_t)tile * CHORD_BIN_MAX_CHUNKS + j;
+    if (j >= p.binMaxChunks) { atomicOr(&p.counters->overflow, 1u); return; }
+    unsigned long long* ent = p.binChunkTab + (size_t)tile * p.binMaxChunks + j;
     const unsigned long long stamp = (unsigned long long)p.binStamp << 32;
     if ((o & (CHORD_BIN_CHUNK - 1u)) == 0u) {
         uint32_t id = atomicAdd(p.binPoolCount, 1u);
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
             const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], bin_capacity(p));
             myCount[k] = c;
             if (c > TILE_SPLIT_MIN) {
-                mySlices[k] = (c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT;
+                mySlices[k] = min((c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT, CHORD_TILE_MAX_SLICES);
                 myBucket[k] = 18u;
                 myPos[k] = atomicAdd(&splitItems, mySlices[k]);
             } else {
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     __shared__ UnitParamsSoA prm;                                // 13 KB
     __shared__ uint32_t offs[TB + 1];
     __shared__ uint32_t waveSums[TB / 64];
-    __shared__ uint32_t chunkTab[CHORD_BIN_MAX_CHUNKS];
+    __shared__ uint32_t chunkTab[64];                            // the overflow chunks this item's entries live in
     __shared__ uint32_t sTicket;
     if ((p.debug & DBG_TILE_EXIT) && !p.clearTiles) return;
     const uint32_t active = p.tileOrder[0].x;
@@ -1113,8 +1113,11 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
     const uint32_t nAll = itemCount.y;                            // (already clamped to the bin capacity)
     // entries [lo, n) of the bin are this item's
-    const uint32_t lo = slices > 1u ? slice << TILE_SLICE_SHIFT : 0u;
-    const uint32_t n = slices > 1u ? min(nAll, lo + TILE_SLICE) : nAll;
+    // (slices of TILE_SLICE entries; a bin too long for CHORD_TILE_MAX_SLICES of them is cut into that many equal parts,
+    // rounded to whole batches)
+    const uint32_t per = slices > 1u ? max(TILE_SLICE, ((nAll + slices - 1u) / slices + TB - 1u) & ~(TB - 1u)) : nAll;
+    const uint32_t lo = slices > 1u ? min(nAll, slice * per) : 0u;
+    const uint32_t n = slices > 1u ? min(nAll, lo + per) : nAll;
     const bool prof = (p.debug & DBG_TILE_CLOCKS) != 0;
     const unsigned long long t0 = prof ? wall_clock64() : 0ull;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = t0;
@@ -1153,12 +1156,14 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     // Software pipeline over the two dependent fetches of a batch (bin entry -> 48-byte record): the
     // record of batch b+1 and the bin entry of batch b+2 are in flight while batch b is scan-converted.
     const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
-    if (nAll > p.binCap) {
-        // overflow chunks of this bin (chunk table -> LDS; an entry of another pass or a failed allocation reads
-        // as invalid and its entries are skipped)
-        const uint32_t chunks = (nAll - p.binCap + CHORD_BIN_CHUNK - 1u) >> CHORD_BIN_CHUNK_SHIFT;
+    uint32_t chunk0 = 0;                                          // first overflow chunk of this item's range
+    if (n > p.binCap) {
+        // overflow chunks the item's entries [lo, n) live in (chunk table -> LDS; an entry of another pass or a failed
+        // allocation reads as invalid and its entries are skipped)
+        chunk0 = lo > p.binCap ? (lo - p.binCap) >> CHORD_BIN_CHUNK_SHIFT : 0u;
+        const uint32_t chunks = min(64u, ((n - p.binCap + CHORD_BIN_CHUNK - 1u) >> CHORD_BIN_CHUNK_SHIFT) - chunk0);
         for (uint32_t j = threadIdx.x; j < chunks; j += TB) {
-            const unsigned long long e = p.binChunkTab[(size_t)tileId * CHORD_BIN_MAX_CHUNKS + j];
+            const unsigned long long e = p.binChunkTab[(size_t)tileId * p.binMaxChunks + chunk0 + j];
             chunkTab[j] = (uint32_t)(e >> 32) == p.binStamp ? (uint32_t)e : CHORD_BIN_CHUNK_INVALID;
         }
         __syncthreads();
@@ -1166,7 +1171,8 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     const uint32_t recLimit = p.triCap * CHORD_LIST_SHARDS;
     auto binEntry = [&](uint32_t k) -> uint32_t {              // record index of bin entry k, ~0u = none
         if (k < p.binCap) return bin[k];
-        const uint32_t o = k - p.binCap, id = chunkTab[o >> CHORD_BIN_CHUNK_SHIFT];
+        const uint32_t o = k - p.binCap, cj = (o >> CHORD_BIN_CHUNK_SHIFT) - chunk0;
+        const uint32_t id = cj < 64u ? chunkTab[cj] : CHORD_BIN_CHUNK_INVALID;
         if (id == CHORD_BIN_CHUNK_INVALID) return 0xFFFFFFFFu;
         const uint32_t gi = p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))];
         return gi < recLimit ? gi : 0xFFFFFFFFu;               // (only after a reported overflow)
@@ -1322,7 +1328,7 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.tileBins = c->dTileBins + (size_t)pass * tiles * c->binCap; p.binCap = c->binCap;
     p.binPool = c->dBinPool + (size_t)pass * c->binPoolChunks * CHORD_BIN_CHUNK; p.binPoolChunks = c->binPoolChunks;
     p.binPoolCount = &c->dCounters->binPoolCount[pass];
-    p.binChunkTab = c->dBinChunkTab + (size_t)pass * tiles * CHORD_BIN_MAX_CHUNKS;
+    p.binChunkTab = c->dBinChunkTab + (size_t)pass * tiles * c->binMaxChunks; p.binMaxChunks = c->binMaxChunks;
     p.binStamp = ++c->rasterSerial;
     p.tilesX = c->tilesX; p.tilesY = c->tilesY;
     p.clipTris = c->dClipTris + (size_t)pass * (c->clipTriCap / 2); p.clipTriCap = c->clipTriCap / 2; p.pass = pass;

@@ -24,6 +24,10 @@ class CountAndCmd(C.Structure):
     _fields_ = [("count", C.c_void_p), ("cmds", C.c_void_p), ("capacity", C.c_uint32)]
 
 
+class Limits(C.Structure):
+    _fields_ = [("maxTriangleRecords", C.c_uint64), ("binPoolChunks", C.c_uint32), ("binMaxChunksPerTile", C.c_uint32)]
+
+
 class TileMarker(C.Structure):
     _fields_ = [("marker", C.c_void_p), ("visibilityDim", C.c_uint32 * 2), ("markerDim", C.c_uint32 * 2)]
 
@@ -131,6 +135,7 @@ def _load():
         "chordvis_readback_cmds": (i32, [vp, CountAndCmd, vp, u32, P(u32)]),
         "chordvis_readback_hzb": (i32, [vp, P(HZB), vp, vp, vp]),
         "chordvis_upload_history_hzb": (i32, [vp, vp]),
+        "chordvis_set_limits": (i32, [vp, P(Limits)]),
         "chordvis_visibility_mark": (i32, [vp, CountAndCmd, P(TileMarker)]),
         "chordvis_prepare_shading_tile_param": (i32, [vp, u32, P(TileMarker), P(ShadingTiles)]),
         "chordvis_readback_tile_marker": (i32, [vp, P(TileMarker), vp]),

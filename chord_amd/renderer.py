@@ -145,6 +145,11 @@ class VisibilityRenderer:
         hzb_min = np.ascontiguousarray(hzb_min, dtype=np.uint16)
         self._check(L.lib.chordvis_upload_history_hzb(self._ctx, hzb_min.ctypes.data), "upload_history_hzb")
 
+    def set_limits(self, max_triangle_records=0, bin_pool_chunks=0, bin_max_chunks_per_tile=0):
+        """Work-list capacities (before upload_scene / allocate_gbuffer); 0 keeps a default."""
+        lim = L.Limits(int(max_triangle_records), int(bin_pool_chunks), int(bin_max_chunks_per_tile))
+        self._check(L.lib.chordvis_set_limits(self._ctx, C.byref(lim)), "set_limits")
+
     # -- consumers' first step (visibility_tile.cpp) -------------------------------------------------------
     def visibility_mark(self, drawed_meshlet_cmd=None):
         """visibilityMark (visibility_tile.cpp:20-57); the command list defaults to last_frame_cmds()."""

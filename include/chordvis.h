@@ -54,6 +54,15 @@ typedef struct ChordHZB {
     uint32_t*    validRange;  /* device uint2 {asuint(min), asuint(max)} or NULL */
 } ChordHZB;
 
+/* Work-list capacities (the counterpart of the reference's pool sizes); zero fields keep the default.  Call before
+ * chordvis_upload_scene / chordvis_allocate_gbuffer.  Defaults fit BASELINE configs 1-4; config 5 (1 G sub-pixel
+ * triangles in one pass) needs ~1.1 G records and ~1.1 M pool chunks per pass. */
+typedef struct ChordLimits {
+    uint64_t maxTriangleRecords;   /* 48 B each, per frame; default 64 Mi */
+    uint32_t binPoolChunks;        /* 1024-entry overflow chunks per raster pass; default 32 Ki */
+    uint32_t binMaxChunksPerTile;  /* default 240, at most 3072 */
+} ChordLimits;
+
 /* VisibilityTileMarkerContext — visibility_tile.h:11-19.  One uint4 (128 shading-type bits) per 8x8 pixels. */
 typedef struct ChordTileMarker {
     uint32_t* marker;            /* device, 4 words per texel, markerDim[0] x markerDim[1] texels, row-major */
@@ -161,6 +170,7 @@ int chordvis_allocate_gbuffer(ChordCtx* ctx, uint32_t width, uint32_t height, ui
 /* Multi-GPU screen ownership: rows are cut into stripes of stripeRows (even); stripe s belongs
  * to rank (s % ranks).  The visibility buffer is stored rank-major (rank r's stripes
  * contiguous) so one in-place all-gather reassembles it.  ranks == 1: plain row-major. */
+int chordvis_set_limits(ChordCtx* ctx, const ChordLimits* limits);
 int chordvis_set_shard(ChordCtx* ctx, uint32_t stripeRows, uint32_t ranks, uint32_t rank);
 /* Number of uint64 words of the (possibly padded, rank-major) visibility buffer, and of one rank's chunk. */
 uint64_t chordvis_visibility_words(ChordCtx* ctx);
