@@ -43,6 +43,10 @@ def build_workload(name):
         return scenes.config4_street_x64(3840, 2160, grid=8)
     if name == "street_x16_4k_hzb":
         return scenes.config4_street_x64(3840, 2160, grid=4)
+    if name == "subpixel_1g":            # BASELINE config 5: 1 Mi unique ~8x8 px patches x 8 instances = 1.07 G triangles
+        return scenes.config5_subpixel(3840, 2160)
+    if name == "subpixel_64m":           # the same at 1/16 size (64 Ki patches x 8): fits the default work-list limits
+        return scenes.config5_subpixel(3840, 2160, prims=64)
     if name == "atrium_1080p":
         return scenes.config2_atrium(1920, 1080)
     raise SystemExit("unknown workload %r" % name)
@@ -92,6 +96,8 @@ def main():
     f /= np.linalg.norm(f)
     cam_b = cam_a.moved(tuple(0.5 * f))
     W, H = cam_a.width, cam_a.height
+    if wl.startswith("subpixel"):
+        args.no_hzb = True               # config 5 is a single pass, frustum + cone only
     flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | (0 if args.no_hzb else R.FLAG_HZB_CULL)
 
     # per-view inputs (host, once): frame at A follows a frame at B and vice versa
@@ -106,6 +112,9 @@ def main():
 
     stream = torch.cuda.current_stream(dev)
     r = VisibilityRenderer(local_rank, stream.cuda_stream)
+    if wl == "subpixel_1g":              # ~1 G records of 48 B and as many bin entries in one pass (a rank holds 1/N of them)
+        share = max(1, world // 2) if world > 1 else 1
+        r.set_limits(max_triangle_records=(1152 << 20) // share, bin_pool_chunks=(1200 << 10) // share, bin_max_chunks_per_tile=2048)
     r.upload_scene(scene)
     if world > 1:
         from chord_amd.sharding import pick_stripe_rows
@@ -226,6 +235,8 @@ def main():
     if world > 1:
         if rank == 0:
             r1 = VisibilityRenderer(local_rank, stream.cuda_stream)
+            if wl == "subpixel_1g":
+                r1.set_limits(max_triangle_records=1152 << 20, bin_pool_chunks=1200 << 10, bin_max_chunks_per_tile=2048)
             r1.upload_scene(scene)
             r1.allocate_gbuffer(W, H)
             r1.enable_timers(0)

@@ -190,6 +190,35 @@ def test_bins_beyond_the_fixed_capacity_use_overflow_chunks(gpu):
     r.close()
 
 
+def test_config5_subpixel_reduced_matches_oracle(gpu):
+    """BASELINE config 5 at reduced size (16 k camera-facing patches of ~8x8 px = 2.1 M triangles of ~0.5 px^2 into
+    960x540): nearly every triangle survives the per-triangle culls and about half of them hit a pixel centre --
+    the sub-pixel stress case; with a raised per-tile chunk limit as the full-size workload uses."""
+    W, Hh = 960, 540
+    scene, cam, view, iv = H.setup_scene(scenes.config5_subpixel, W, Hh, prims=16, patches_per_prim=256, instances=4)
+    flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL
+    want = orc.frame(scene, view, iv, flags)
+    assert want["stats"].trianglesRastered > 0.8 * want["stats"].trianglesSubmitted
+    assert 0.3 * want["stats"].trianglesRastered < want["stats"].fragments < 0.8 * want["stats"].trianglesRastered
+    from chord_amd.renderer import VisibilityRenderer
+    r = VisibilityRenderer(0)
+    r.set_limits(max_triangle_records=8 << 20, bin_pool_chunks=16384, bin_max_chunks_per_tile=2048)
+    r.upload_scene(scene)
+    r.allocate_gbuffer(W, Hh)
+    r.set_view(view, iv, flags)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want["vis"], W, Hh, "config5 reduced")
+    st = r.stats()
+    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["stats"].trianglesSubmitted
+    assert st["triangleRecords"] == want["stats"].trianglesRastered
+    # two-pass HZB on the same scene (occlusion between the patch layers)
+    want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want["hzb_min"])
+    r.set_view(view, iv, H.ALL_FLAGS)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want1["vis"], W, Hh, "config5 reduced, HZB frame")
+    r.close()
+
+
 def test_config3_street_4k_two_pass_matches_oracle_and_properties(gpu):
     """BASELINE config 3 at full size: frame 0 (no history) and frame 1 (two-pass HZB) bit-exact vs the
     oracle; occlusion culling must not change a static image; a repeated frame is idempotent."""
