@@ -255,6 +255,8 @@ SHARDED = [
     ("street_720p_4ranks", lambda: scenes.config3_street(1280, 720), 4, None),
     # config 4 (the N > 1 bench workload) at reduced size: overflow chunks and split tiles in sharded frames
     ("street_x64_360p_8ranks", lambda: scenes.config4_street_x64(640, 360), 8, None),
+    # config 5 (sub-pixel patches, the other multi-GPU workload) at reduced size
+    ("subpixel_540p_8ranks", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4), 8, None),
 ]
 
 
