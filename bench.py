@@ -90,7 +90,11 @@ def main():
 
     wl = args.workload
     if wl == "auto":
-        wl = "street_4k_hzb" if world == 1 else "street_x64_4k_hzb"
+        # N = 1: BASELINE config 3 (the largest single-GPU configuration).  N > 1: config 5, the multi-GPU stress
+        # configuration (1 G sub-pixel triangles per frame): a frame long enough (40 ms on one GPU) for the
+        # fixed cost of the all-gathers to amortise.  Config 4 (0.5 ms per frame on one GPU: less than the 66 MB
+        # visibility all-gather alone) stays available as --workload street_x64_4k_hzb.  DESIGN.md 5 and 6.
+        wl = "street_4k_hzb" if world == 1 else "subpixel_1g"
     scene, cam_a = build_workload(wl)
     f = np.array(cam_a.front, dtype=np.float64)
     f /= np.linalg.norm(f)

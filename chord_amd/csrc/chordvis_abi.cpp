@@ -255,6 +255,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
+    dfree(c->dRankCmds);
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
@@ -374,6 +375,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         std::fill(owner.begin() + d.groupBase, owner.begin() + d.groupBase + c->hPrims[d.prim].groupCount, o);
     }
 
+    dfree(c->dRankCmds);                                   // sized by cmdCapacity; re-made by the first sharded raster pass
     c->objectCount = s->objectCount; c->primCount = s->primitiveCount; c->materialCount = s->materialCount;
     c->meshletCount = nM; c->groupCount = nG;
     c->groupInstances = (uint32_t)groupInst; c->cmdCapacity = (uint32_t)std::max<uint64_t>(cmdCap, 1);

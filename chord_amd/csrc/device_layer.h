@@ -121,7 +121,7 @@ struct DeviceCounters {
 #endif
 struct FrameState {
     DeviceCounters counters;
-    uint32_t listCounts[4];
+    uint32_t listCounts[8];        // [0..3] command lists of the frame, [4 + pass] this rank's clusters of a raster pass (sharded)
     uint32_t tileCount[2 * CHORD_MAX_TILES * CHORD_TILECOUNT_STRIDE];   // pass p starts at p * tiles * stride
 };
 
@@ -187,6 +187,7 @@ struct ChordCtx {
 
     // command lists: 0 = post instanceCulling, 1 = hzb visible, 2 = hzb rejected
     chord::CmdList lists[3];
+    ChordDrawCmd* dRankCmds = nullptr; // sharded frames: the commands of a raster pass whose clusters touch this rank's rows
     uint32_t* dCounts = nullptr;      // 4 x u32 backing the list counts
 
     // gbuffer
@@ -274,6 +275,7 @@ void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool b
 void launch_hzb_mip0_exchange(ChordCtx* c);
 void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange);   // mips 6.. + range from per-tile partials
 void launch_detile(ChordCtx* c);
+void launch_stripe_filter(ChordCtx* c, const CmdList& in, const CmdList& out);
 void launch_visibility_mark(ChordCtx* c, const unsigned long long* vis, const ChordDrawCmd* cmds, const uint32_t* cmdCount, uint32_t* marker);
 void launch_shading_tiles(ChordCtx* c, const uint32_t* marker, uint32_t shadingType, uint32_t* tiles, uint32_t* count, uint32_t* args);
 void stamp(ChordCtx* c, int tag);               // no-op when timers are off

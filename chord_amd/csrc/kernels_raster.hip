@@ -358,34 +358,7 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
         const uint32_t slot = hdr.slot, V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
         const bool twoSided = hdr.twoSided;
         const Mat4 mvp = hdr.mvp;
-        const DMeshlet* __restrict__ m = &p.meshlets[hdr.meshletId];
-        bool skip = false;
-
-        // ---- sharded frames: a cluster whose projected bounds touch none of this rank's pixel rows is another
-        //      rank's work (conservative: 8 AABB corners, one pixel of slack; any corner at or behind the camera
-        //      plane keeps the cluster).  Skipping is invisible in the image: only triangles without an owned
-        //      row are dropped, exactly as the per-triangle ownership test below would. -----------------------
-        if (p.shard.ranks > 1) {
-            float ylo = 3.0e38f, yhi = -3.0e38f;
-            bool unbounded = false;
-            if (lane < 8u) {
-                const f4 h = mul_mv(mvp, (lane & 1u) ? m->posMax[0] : m->posMin[0], (lane & 2u) ? m->posMax[1] : m->posMin[1],
-                                    (lane & 4u) ? m->posMax[2] : m->posMin[2], 1.0f);
-                const float y = (h.y / h.w * -0.5f + 0.5f) * p.H;
-                if (!(h.w > 1.0e-6f) || !(fabsf(y) < 1.0e7f)) unbounded = true;
-                else { ylo = y; yhi = y; }
-            }
-#pragma unroll
-            for (int d = 1; d < 8; d <<= 1) {
-                ylo = fminf(ylo, __shfl_xor(ylo, d, 64));
-                yhi = fmaxf(yhi, __shfl_xor(yhi, d, 64));
-            }
-            ylo = bcast(ylo, 0); yhi = bcast(yhi, 0);
-            if (__ballot(unbounded) == 0ull) {
-                const int32_t y0 = max((int32_t)floorf(ylo) - 1, 0), y1 = min((int32_t)ceilf(yhi) + 1, p.Hi - 1);
-                skip = y1 < y0 || !owns_any_row(p.shard, y0, y1);
-            }
-        }
+        const bool skip = false;                                  // (sharded frames filter their clusters before this kernel)
 
         if (sprof) { volatile uint32_t sink = V + T; (void)sink; }
         SPHASE(0);
@@ -1316,6 +1289,15 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         p.hzbMinB = c->hzb[c->fuseHzbSlot].minTexels; p.hzbMaxB = c->hzb[c->fuseHzbSlot].maxTexels;
     }
     p.count = in.count; p.cmds = in.cmds;
+    if (c->shard.ranks > 1 && !c->dRankCmds) (void)hipMalloc((void**)&c->dRankCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity);   // first sharded pass
+    if (c->shard.ranks > 1 && c->dRankCmds) {
+        // sharded frame: only the clusters that touch this rank's pixel rows reach the setup kernel
+        CmdList mine;
+        mine.count = c->dCounts + 4 + (c->rasterCalls & 1u); mine.cmds = c->dRankCmds; mine.capacity = in.capacity;
+        if (!c->inFrame || c->rasterCalls >= 2) (void)hipMemsetAsync(mine.count, 0, sizeof(uint32_t), c->stream);
+        launch_stripe_filter(c, in, mine);
+        p.count = mine.count; p.cmds = mine.cmds;
+    }
     p.objFrame = c->dObjFrame; p.objStatic = c->dObjStatic;
     p.meshlets = c->dMeshlets; p.meshletData = c->dMeshletData; p.positions = c->dPositions;
     p.vis = (unsigned long long*)c->dVis;

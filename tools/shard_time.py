@@ -1,0 +1,42 @@
+"""Compute-side time of ONE rank of an N-rank sharded frame, measured on one GPU (collectives skipped, so images are
+incomplete; valid for workloads whose culling does not depend on the exchanged HZB, i.e. config 5)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from chord_amd import lib as L, records as R
+from chord_amd.renderer import VisibilityRenderer
+from chord_amd.sharding import pick_stripe_rows
+wl = sys.argv[1] if len(sys.argv) > 1 else "subpixel_64m"
+scene, cam = bench.build_workload(wl)
+view, iv = L.make_views(cam)
+flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL
+objs = L.fill_objects(scene, cam, cam)
+for ranks in (1, 2, 4, 8):
+    r = VisibilityRenderer(0)
+    if wl == "subpixel_1g":
+        share = max(1, ranks // 2) if ranks > 1 else 1
+        r.set_limits(max_triangle_records=(1152 << 20) // share, bin_pool_chunks=(1200 << 10) // share, bin_max_chunks_per_tile=2048)
+    r.upload_scene(scene)
+    if ranks > 1:
+        r.set_shard(pick_stripe_rows(cam.height, ranks), ranks, 0)
+    r.allocate_gbuffer(cam.width, cam.height)
+    r.update_objects(objs); r.set_view(view, iv, flags)
+
+    def frame():
+        if ranks == 1:
+            r.render_frame()
+        else:
+            r.frame_phase_a(); r.frame_phase_b(); r.frame_phase_c()
+    for _ in range(3):
+        frame()
+    r.sync()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        frame()
+    r.sync()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    st = r.stats()
+    print("ranks %d: rank 0 compute %.3f ms/frame, records %d, overflow %d" % (ranks, ms, st["triangleRecords"], st["overflow"]))
+    r.close()
