@@ -196,7 +196,7 @@ def main():
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, inside the timed region)
     # algorithmic bytes per frame (DESIGN.md "Roofline"): setup reads 1884 B per cluster (64 header + 12 cmd +
-    # 4(V+T) indices + 12V positions, V=81 T=128) and writes a 48 B record + 4 B per bin entry; the tile
+    # 4(V+T) indices + 12V positions, V=81 T=128) and writes a 32 B (vertices <= 64 px apart) or 48 B record + 4 B per bin entry; the tile
     # kernel reads 4 + 48 B per bin entry, writes every pixel once on the first pass of a frame (8 B x W x H, this
     # is also the clear) and reads + writes the 64x64 tiles that have bin entries on the second pass.
     pixels = W * H
@@ -204,12 +204,15 @@ def main():
     cluster_bytes = CLUSTER_BYTES + 4 * (V + T) + 12 * V
     clusters_per_frame = clusters_per_pair / 2.0
     recs = sum(pv["triangleRecords"] for pv in per_view) / 2.0
+    recs_c = sum(pv["triangleRecordsCompact"] for pv in per_view) / 2.0
+    rec_bytes = 32.0 * recs_c + 48.0 * (recs - recs_c)            # what the setup kernel writes
+    rec_size = rec_bytes / recs if recs else 32.0                 # average record a bin entry leads to
     bins = sum(pv["binEntries"] for pv in per_view) / 2.0
     tiles1 = sum(pv["tilesTouched"][1] for pv in per_view) / 2.0
     launches = max(1, st["rasterLaunches"])
     kernels = {
-        "raster_setup_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame + 48.0 * recs + 4.0 * bins),
-        "raster_tile_kernel": (st["msRasterChunk"], 52.0 * bins + 8.0 * pixels + (launches - 1) * 16.0 * 4096 * tiles1),
+        "raster_setup_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame + rec_bytes + 4.0 * bins),
+        "raster_tile_kernel": (st["msRasterChunk"], (4.0 + rec_size) * bins + 8.0 * pixels + (launches - 1) * 16.0 * 4096 * tiles1),
     }
     dom = max(kernels, key=lambda k: kernels[k][0])
     dom_ms, dom_bytes = kernels[dom]

@@ -259,7 +259,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
-    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
+    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
     dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -400,9 +400,13 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         c->lists[i].capacity = c->cmdCapacity;
     }
     // raster work lists (fixed budgets sized for 288 GB of HBM; overflow is detected and reported by chordvis_stats)
-    c->triCap = (uint32_t)c->limitRecords;   // default 64 M records x 48 B = 3 GB
+    // records: nearly all triangles take the 32-byte form; the 48-byte list (triangles wider than 64 px, clipped
+    // pieces) gets a quarter of the limit.  Defaults: 64 M x 32 B + 16 M x 48 B = 2.8 GB
+    c->triCapC = (uint32_t)c->limitRecords;
+    c->triCap = (uint32_t)std::max<uint64_t>(c->limitRecords / 4, 1u << 20) & ~(CHORD_LIST_SHARDS - 1u);
     c->clipTriCap = 1u << 20;
     if ((rc = dalloc(c, &c->dTris, (size_t)c->triCap))) return rc;
+    if ((rc = dalloc(c, &c->dTrisC, (size_t)c->triCapC))) return rc;
     if ((rc = dalloc(c, &c->dClipTris, (size_t)c->clipTriCap))) return rc;
     c->largeCap = 8u << 20;
     if ((rc = dalloc(c, &c->dLargeList, (size_t)c->largeCap))) return rc;
@@ -455,7 +459,7 @@ int chordvis_set_limits(ChordCtx* c, const ChordLimits* limits)
     if (!c || !limits) return fail(c, CHORDVIS_E_INVALID, "set_limits: null argument");
     if (c->sceneLoaded || c->dVis) return fail(c, CHORDVIS_E_INVALID, "set_limits: call before upload_scene / allocate_gbuffer");
     if (limits->maxTriangleRecords) {
-        if (limits->maxTriangleRecords < (1u << 16) || limits->maxTriangleRecords > 0xF0000000ull)
+        if (limits->maxTriangleRecords < (1u << 16) || limits->maxTriangleRecords > 0x7FFFFFC0ull)
             return fail(c, CHORDVIS_E_INVALID, "set_limits: maxTriangleRecords out of range (record indices are 32-bit)");
         c->limitRecords = limits->maxTriangleRecords & ~(uint64_t)(CHORD_LIST_SHARDS - 1);
     }
@@ -931,7 +935,10 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
     }
     out->overflow = dc.overflow;
     out->rasterLaunches = c->rasterCalls;
-    for (uint32_t i = 0; i < CHORD_LIST_SHARDS; i++) out->triangleRecords += dc.triCount[i * CHORD_SHARD_STRIDE];
+    for (uint32_t i = 0; i < CHORD_LIST_SHARDS; i++) {
+        out->triangleRecords += dc.triCount[i * CHORD_SHARD_STRIDE] + dc.triCountC[i * CHORD_SHARD_STRIDE];
+        out->triangleRecordsCompact += dc.triCountC[i * CHORD_SHARD_STRIDE];
+    }
     if (c->tilesX) {
         std::vector<uint32_t> tc((size_t)c->tilesX * c->tilesY);
         for (int pass = 0; pass < 2; pass++) {

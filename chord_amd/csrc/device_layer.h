@@ -78,6 +78,16 @@ struct TriRec {                // 48 B: one set-up triangle (snapped 24.8 vertic
     uint32_t twoSided;
     uint32_t pad;
 };
+// 32 B: the same for a triangle whose vertices are at most 64 px apart (deltas fit 16 bits) -- nearly all of them.
+// Orientation sign and 1/2A are recomputed by the consumer from the deltas (the same expressions, exact integers).
+// A bin entry names a record by index; bit 31 set = the 48-byte list, clear = this one.
+struct TriRecC {
+    int32_t  X0, Y0;
+    int16_t  dX1, dY1, dX2, dY2;
+    float    d[3];
+    uint32_t payload;
+};
+#define CHORD_REC_WIDE 0x80000000u
 struct ClipTri { uint32_t cmdIndex; uint32_t tri; };       // needs the homogeneous clipper
 
 // The record list is cut into LIST_SHARDS independent sub-lists (own counter, own region) so that
@@ -88,7 +98,8 @@ struct ClipTri { uint32_t cmdIndex; uint32_t tri; };       // needs the homogene
 struct DeviceCounters {
     // shard counters sit one per 64-byte line (CHORD_SHARD_STRIDE words apart): atomics on different words of one
     // line still serialise at the L2
-    uint32_t triCount[CHORD_LIST_SHARDS * CHORD_SHARD_STRIDE];   // records appended this frame (both raster passes)
+    uint32_t triCount[CHORD_LIST_SHARDS * CHORD_SHARD_STRIDE];   // 48-byte records appended this frame (both raster passes)
+    uint32_t triCountC[CHORD_LIST_SHARDS * CHORD_SHARD_STRIDE];  // 32-byte records
     uint32_t clipTriCount[2];                   // per raster pass
     uint32_t largeCount[2][CHORD_LIST_SHARDS * CHORD_SHARD_STRIDE];  // per raster pass and list shard: records touching more than 2x2 tiles
     uint32_t overflow;                          // bit0 record list / tile bin / large list, bit1 clip list, bit2 bin chunk wait timed out
@@ -212,7 +223,9 @@ struct ChordCtx {
 
     // raster work lists: triangle records, per-tile bins, clip list
     chord::TriRec* dTris = nullptr;
-    uint32_t triCap = 0;               // all shards together
+    uint32_t triCap = 0;               // 48-byte records, all shards together
+    chord::TriRecC* dTrisC = nullptr;
+    uint32_t triCapC = 0;              // 32-byte records, all shards together
     chord::FrameState* dFrameState = nullptr;
     uint32_t* dTileBins = nullptr;     // [2 passes][tiles][binCap]: the first binCap entries of every tile's bin
     // entries beyond binCap live in CHORD_BIN_CHUNK-entry chunks handed out from a pool; the j-th overflow chunk of

@@ -52,7 +52,8 @@ struct RasterParams {
     unsigned long long* vis;
     float W, H; int32_t Wi, Hi;
     ShardInfo shard;
-    TriRec* tris; uint32_t triCap;                      // per list shard
+    TriRec* tris; uint32_t triCap;                      // 48-byte records, capacity per list shard
+    TriRecC* trisC; uint32_t triCapC;                   // 32-byte records
     uint32_t* tileCount; uint32_t* tileBins; uint32_t binCap; uint32_t tilesX, tilesY;
     uint32_t* binPool; uint32_t binPoolChunks; uint32_t* binPoolCount;   // overflow chunks of this pass
     unsigned long long* binChunkTab; uint32_t binStamp; uint32_t binMaxChunks;   // [tile][binMaxChunks] serial << 32 | chunk
@@ -132,6 +133,30 @@ struct TriSetup {
 };
 
 // Returns false when the triangle is rejected (zero area, back face after snapping, empty bbox).
+__device__ __forceinline__ bool narrow_extent(const TriSetup& ts)
+{
+    const int32_t extX = max(ts.X[0], max(ts.X[1], ts.X[2])) - min(ts.X[0], min(ts.X[1], ts.X[2]));
+    const int32_t extY = max(ts.Y[0], max(ts.Y[1], ts.Y[2])) - min(ts.Y[0], min(ts.Y[1], ts.Y[2]));
+    return extX <= (1 << 14) && extY <= (1 << 14);       // 32-bit edge functions are exact
+}
+
+// the 32-byte form holds a triangle iff its 16-bit deltas and 32-bit anchor are exact
+__device__ __forceinline__ bool fits_compact(const TriSetup& ts)
+{
+    return narrow_extent(ts);
+}
+
+__device__ __forceinline__ void write_record_c(TriRecC* dst, const TriSetup& ts, const float d[3])
+{
+    TriRecC r;
+    r.X0 = ts.X[0]; r.Y0 = ts.Y[0];
+    r.dX1 = (int16_t)(ts.X[1] - ts.X[0]); r.dY1 = (int16_t)(ts.Y[1] - ts.Y[0]);
+    r.dX2 = (int16_t)(ts.X[2] - ts.X[0]); r.dY2 = (int16_t)(ts.Y[2] - ts.Y[0]);
+    r.d[0] = d[0]; r.d[1] = d[1]; r.d[2] = d[2];
+    r.payload = ts.payload;
+    *dst = r;
+}
+
 __device__ __forceinline__ bool tri_setup(TriSetup& ts, bool twoSided, int32_t Wi, int32_t Hi)
 {
     const int64_t area2 = (int64_t)(ts.X[1] - ts.X[0]) * (int64_t)(ts.Y[2] - ts.Y[0]) -
@@ -152,6 +177,26 @@ __device__ __forceinline__ bool tri_setup(TriSetup& ts, bool twoSided, int32_t W
 }
 
 // Setup of a record that raster_setup_kernel / raster_clip_kernel already validated: bbox + stored sign / invA.
+__device__ __forceinline__ void tri_setup_from_compact(TriSetup& ts, const TriRecC& r, int32_t Wi, int32_t Hi)
+{
+    ts.X[0] = r.X0; ts.Y[0] = r.Y0;
+    ts.X[1] = r.X0 + r.dX1; ts.Y[1] = r.Y0 + r.dY1;
+    ts.X[2] = r.X0 + r.dX2; ts.Y[2] = r.Y0 + r.dY2;
+    ts.payload = r.payload;
+    // the same integers tri_setup reduced: |deltas| <= 2^14, so the 32-bit product is exact
+    const int32_t area2 = (int32_t)r.dX1 * (int32_t)r.dY2 - (int32_t)r.dX2 * (int32_t)r.dY1;
+    ts.s = area2 < 0 ? -1 : 1;
+    ts.invA = 1.0f / (float)(double)(area2 < 0 ? -(int64_t)area2 : (int64_t)area2);
+    ts.d0 = r.d[0]; ts.e1 = r.d[1] - r.d[0]; ts.e2 = r.d[2] - r.d[0];
+    const int32_t minX = min(ts.X[0], min(ts.X[1], ts.X[2])), maxX = max(ts.X[0], max(ts.X[1], ts.X[2]));
+    const int32_t minY = min(ts.Y[0], min(ts.Y[1], ts.Y[2])), maxY = max(ts.Y[0], max(ts.Y[1], ts.Y[2]));
+    ts.px0 = max(0, (minX + 127) >> 8);
+    ts.py0 = max(0, (minY + 127) >> 8);
+    ts.px1 = min(Wi - 1, (maxX - 128) >> 8);
+    ts.py1 = min(Hi - 1, (maxY - 128) >> 8);
+    ts.area = 0;
+}
+
 __device__ __forceinline__ void tri_setup_from_record(TriSetup& ts, const TriRec& r, int32_t Wi, int32_t Hi)
 {
 #pragma unroll
@@ -169,12 +214,6 @@ __device__ __forceinline__ void tri_setup_from_record(TriSetup& ts, const TriRec
     ts.area = 0;
 }
 
-__device__ __forceinline__ bool narrow_extent(const TriSetup& ts)
-{
-    const int32_t extX = max(ts.X[0], max(ts.X[1], ts.X[2])) - min(ts.X[0], min(ts.X[1], ts.X[2]));
-    const int32_t extY = max(ts.Y[0], max(ts.Y[1], ts.Y[2])) - min(ts.Y[0], min(ts.Y[1], ts.Y[2]));
-    return extX <= (1 << 14) && extY <= (1 << 14);       // 32-bit edge functions are exact
-}
 
 // ---- record + bin emission --------------------------------------------------------------------
 
@@ -454,21 +493,27 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
             const unsigned long long lt = (1ull << lane) - 1ull;
             const unsigned long long cmA = __ballot(kindA == K_CLIP), cmB = __ballot(kindB == K_CLIP);
             const unsigned long long emA = __ballot(kindA == K_EMIT), emB = __ballot(kindB == K_EMIT);
+            // the 32-byte record form takes every triangle whose vertices are at most 64 px apart; the rest go wide
+            const bool cpA = kindA == K_EMIT && fits_compact(tsA), cpB = kindB == K_EMIT && fits_compact(tsB);
+            const unsigned long long ecA = __ballot(cpA), ecB = __ballot(cpB);
+            const unsigned long long ewA = emA & ~ecA, ewB = emB & ~ecB;
             const bool lgA = kindA == K_EMIT && touches_many_tiles(tsA), lgB = kindB == K_EMIT && touches_many_tiles(tsB);
             const unsigned long long lmA = __ballot(lgA), lmB = __ballot(lgB);
-            const uint32_t nClip = (uint32_t)(__popcll(cmA) + __popcll(cmB)), nEm = (uint32_t)(__popcll(emA) + __popcll(emB));
+            const uint32_t nClip = (uint32_t)(__popcll(cmA) + __popcll(cmB));
+            const uint32_t nEc = (uint32_t)(__popcll(ecA) + __popcll(ecB)), nEw = (uint32_t)(__popcll(ewA) + __popcll(ewB));
             const uint32_t nLg = (uint32_t)(__popcll(lmA) + __popcll(lmB));
-            // every reservation of the cluster travels together: the three list reservations (lane 0) and the bin
+            // every reservation of the cluster travels together: the list reservations (lane 0) and the bin
             // reservations; nothing is stored before they are back
-            uint32_t cbase = 0, ebase = 0, lbase = 0;
+            uint32_t cbase = 0, ebaseC = 0, ebaseW = 0, lbase = 0;
             if (lane == 0) {
                 if (nClip) cbase = atomicAdd(&p.counters->clipTriCount[p.pass], nClip);
-                if (nEm) ebase = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], nEm);
+                if (nEc) ebaseC = atomicAdd(&p.counters->triCountC[listShard * CHORD_SHARD_STRIDE], nEc);
+                if (nEw) ebaseW = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], nEw);
                 if (nLg) lbase = atomicAdd(&p.counters->largeCount[p.pass][listShard * CHORD_SHARD_STRIDE], nLg);
             }
             BinTicket ticket;
             if (emA | emB) wave_bin_issue(p, kindA == K_EMIT && !lgA, tsA, kindB == K_EMIT && !lgB, tsB, lane, ticket);
-            cbase = bcast(cbase, 0); ebase = bcast(ebase, 0); lbase = bcast(lbase, 0);
+            cbase = bcast(cbase, 0); ebaseC = bcast(ebaseC, 0); ebaseW = bcast(ebaseW, 0); lbase = bcast(lbase, 0);
             SPHASE(3);
             if (kindA == K_CLIP) {
                 const uint32_t k = cbase + (uint32_t)__popcll(cmA & lt);
@@ -480,27 +525,36 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
                 if (k < p.clipTriCap) { ClipTri ct; ct.cmdIndex = cu; ct.tri = lane + 64u; p.clipTris[k] = ct; }
                 else atomicOr(&p.counters->overflow, 2u);
             }
+            // giX names the record in a bin: compact index, or CHORD_REC_WIDE | wide index
             uint32_t giA = 0, giB = 0;
             bool okA = false, okB = false;
-            if (kindA == K_EMIT) {
-                const uint32_t li = ebase + (uint32_t)__popcll(emA & lt);
-                if (li < p.triCap) { giA = listShard * p.triCap + li; write_record(&p.tris[giA], tsA, dA, twoSided); okA = true; }
+            if (cpA) {
+                const uint32_t li = ebaseC + (uint32_t)__popcll(ecA & lt);
+                if (li < p.triCapC) { giA = listShard * p.triCapC + li; write_record_c(&p.trisC[giA], tsA, dA); okA = true; }
+                else atomicOr(&p.counters->overflow, 1u);
+            } else if (kindA == K_EMIT) {
+                const uint32_t li = ebaseW + (uint32_t)__popcll(ewA & lt);
+                if (li < p.triCap) { giA = listShard * p.triCap + li; write_record(&p.tris[giA], tsA, dA, twoSided); giA |= CHORD_REC_WIDE; okA = true; }
                 else atomicOr(&p.counters->overflow, 1u);
             }
-            if (kindB == K_EMIT) {
-                const uint32_t li = ebase + (uint32_t)__popcll(emA) + (uint32_t)__popcll(emB & lt);
-                if (li < p.triCap) { giB = listShard * p.triCap + li; write_record(&p.tris[giB], tsB, dB, twoSided); okB = true; }
+            if (cpB) {
+                const uint32_t li = ebaseC + (uint32_t)__popcll(ecA) + (uint32_t)__popcll(ecB & lt);
+                if (li < p.triCapC) { giB = listShard * p.triCapC + li; write_record_c(&p.trisC[giB], tsB, dB); okB = true; }
+                else atomicOr(&p.counters->overflow, 1u);
+            } else if (kindB == K_EMIT) {
+                const uint32_t li = ebaseW + (uint32_t)__popcll(ewA) + (uint32_t)__popcll(ewB & lt);
+                if (li < p.triCap) { giB = listShard * p.triCap + li; write_record(&p.tris[giB], tsB, dB, twoSided); giB |= CHORD_REC_WIDE; okB = true; }
                 else atomicOr(&p.counters->overflow, 1u);
             }
             // <= 2x2 tiles: straight into the bins; more: the large list
             if (emA | emB) wave_bin_commit(p, ticket, okA, giA, okB, giB);
             if (lgA && okA) {
                 const uint32_t k = lbase + (uint32_t)__popcll(lmA & lt);
-                if (k < p.largeCap) p.largeList[(size_t)listShard * p.largeCap + k] = giA; else atomicOr(&p.counters->overflow, 1u);
+                if (k < p.largeCap) p.largeList[(size_t)listShard * p.largeCap + k] = giA & ~CHORD_REC_WIDE; else atomicOr(&p.counters->overflow, 1u);
             }
             if (lgB && okB) {
                 const uint32_t k = lbase + (uint32_t)__popcll(lmA) + (uint32_t)__popcll(lmB & lt);
-                if (k < p.largeCap) p.largeList[(size_t)listShard * p.largeCap + k] = giB; else atomicOr(&p.counters->overflow, 1u);
+                if (k < p.largeCap) p.largeList[(size_t)listShard * p.largeCap + k] = giB & ~CHORD_REC_WIDE; else atomicOr(&p.counters->overflow, 1u);
             }
         }
         // LDS of this wave is rewritten by the next cluster: order the reads above before those writes
@@ -625,7 +679,7 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
             const uint32_t gi = listShard * p.triCap + li;
             write_record(&p.tris[gi], ts, d, twoSided);
             // clipped pieces are rare: binned right here, one (scattered) atomic per tile they may touch
-            bin_record_tiles(p, ts, gi);
+            bin_record_tiles(p, ts, gi | CHORD_REC_WIDE);                // clipped pieces take the 48-byte form
         }
     }
 }
@@ -688,7 +742,7 @@ __device__ void raster_bin_large_part(const RasterParams& p, uint32_t block, uin
             if (hit) {
                 const uint32_t tile = (uint32_t)ty * p.tilesX + (uint32_t)tx;
                 const uint32_t slot = atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE], 1u);   // distinct tiles per lane
-                bin_store(p, tile, slot, gi);
+                bin_store(p, tile, slot, gi | CHORD_REC_WIDE);           // (the large list holds 48-byte records)
             }
         }
     }
@@ -1141,33 +1195,63 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         }
         __syncthreads();
     }
-    const uint32_t recLimit = p.triCap * CHORD_LIST_SHARDS;
-    auto binEntry = [&](uint32_t k) -> uint32_t {              // record index of bin entry k, ~0u = none
+    const uint32_t wideLimit = p.triCap * CHORD_LIST_SHARDS, compactLimit = p.triCapC * CHORD_LIST_SHARDS;
+    auto binEntry = [&](uint32_t k) -> uint32_t {              // record name of bin entry k, ~0u = none
         if (k < p.binCap) return bin[k];
         const uint32_t o = k - p.binCap, cj = (o >> CHORD_BIN_CHUNK_SHIFT) - chunk0;
         const uint32_t id = cj < 64u ? chunkTab[cj] : CHORD_BIN_CHUNK_INVALID;
         if (id == CHORD_BIN_CHUNK_INVALID) return 0xFFFFFFFFu;
         const uint32_t gi = p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))];
-        return gi < recLimit ? gi : 0xFFFFFFFFu;               // (only after a reported overflow)
+        const bool okIdx = (gi & CHORD_REC_WIDE) ? (gi & ~CHORD_REC_WIDE) < wideLimit : gi < compactLimit;
+        return okIdx ? gi : 0xFFFFFFFFu;                       // (only after a reported overflow)
     };
+    // a record in flight: 32 or 48 raw bytes (which, says bit 31 of its name) in three named registers quads (an
+    // array or a struct passed by reference ends up in scratch memory), expanded when its batch is processed
+#define FETCH_REC(gi, a, b, c)                                                                       \
+    do {                                                                                             \
+        if ((gi) & CHORD_REC_WIDE) {                                                                 \
+            const uint4* src_ = reinterpret_cast<const uint4*>(&p.tris[(gi) & ~CHORD_REC_WIDE]);     \
+            a = src_[0]; b = src_[1]; c = src_[2];                                                   \
+        } else {                                                                                     \
+            const uint4* src_ = reinterpret_cast<const uint4*>(&p.trisC[(gi)]);                      \
+            a = src_[0]; b = src_[1];                                                                \
+        }                                                                                            \
+    } while (0)
     uint32_t idxNext = lo + threadIdx.x < n ? binEntry(lo + threadIdx.x) : 0xFFFFFFFFu;   // bin entry of batch 0
-    TriRec recNext;
-    bool haveNext = idxNext != 0xFFFFFFFFu;
-    if (haveNext) recNext = p.tris[idxNext];                                     // record of batch 0
+    uint4 nq0 = make_uint4(0, 0, 0, 0), nq1 = nq0, nq2 = nq0;
+    uint32_t nameNext = idxNext;
+    if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);             // record of batch 0
     idxNext = lo + TB + threadIdx.x < n ? binEntry(lo + TB + threadIdx.x) : 0xFFFFFFFFu;   // bin entry of batch 1
     for (uint32_t base = lo; base < n; base += TB) {
         const uint32_t k = base + threadIdx.x;
-        const TriRec rec = recNext;
-        const bool have = haveNext;
-        haveNext = idxNext != 0xFFFFFFFFu;
-        if (haveNext) recNext = p.tris[idxNext];                                 // record of the next batch
+        const uint4 q0 = nq0, q1 = nq1, q2 = nq2;
+        const uint32_t name = nameNext;
+        const bool have = name != 0xFFFFFFFFu;
+        nameNext = idxNext;
+        if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);         // record of the next batch
         idxNext = k + 2u * TB < n ? binEntry(k + 2u * TB) : 0xFFFFFFFFu;          // bin entry of the batch after
-        if (prof) { volatile uint32_t sink = rec.payload; (void)sink; }
+        if (prof) { volatile uint32_t sink = q1.w; (void)sink; }
         PHASE(1);
         uint32_t rows = 0;
         if (have) {
             TriSetup ts;
-            tri_setup_from_record(ts, rec, p.Wi, p.Hi);
+            // (fields are picked out of the raw dwords by value: a pointer cast would put the record in scratch memory)
+            if (name & CHORD_REC_WIDE) {
+                TriRec w;
+                w.X[0] = (int32_t)q0.x; w.X[1] = (int32_t)q0.y; w.X[2] = (int32_t)q0.z; w.Y[0] = (int32_t)q0.w;
+                w.Y[1] = (int32_t)q1.x; w.Y[2] = (int32_t)q1.y;
+                w.d[0] = __uint_as_float(q1.z); w.d[1] = __uint_as_float(q1.w); w.d[2] = __uint_as_float(q2.x);
+                w.payload = q2.y; w.twoSided = q2.z; w.pad = q2.w;
+                tri_setup_from_record(ts, w, p.Wi, p.Hi);
+            } else {
+                TriRecC cr;
+                cr.X0 = (int32_t)q0.x; cr.Y0 = (int32_t)q0.y;
+                cr.dX1 = (int16_t)(q0.z & 0xFFFFu); cr.dY1 = (int16_t)(q0.z >> 16);
+                cr.dX2 = (int16_t)(q0.w & 0xFFFFu); cr.dY2 = (int16_t)(q0.w >> 16);
+                cr.d[0] = __uint_as_float(q1.x); cr.d[1] = __uint_as_float(q1.y); cr.d[2] = __uint_as_float(q1.z);
+                cr.payload = q1.w;
+                tri_setup_from_compact(ts, cr, p.Wi, p.Hi);
+            }
             {
                 const int32_t x0 = max(ts.px0, ox), y0 = max(ts.py0, oy);
                 const int32_t x1 = min(ts.px1, ox + tw - 1), y1 = min(ts.py1, oy + th - 1);
@@ -1304,6 +1388,7 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.W = (float)c->width; p.H = (float)c->height; p.Wi = (int32_t)c->width; p.Hi = (int32_t)c->height;
     p.shard = c->shard;
     p.tris = c->dTris; p.triCap = c->triCap / CHORD_LIST_SHARDS;
+    p.trisC = c->dTrisC; p.triCapC = c->triCapC / CHORD_LIST_SHARDS;
     const uint32_t tiles = c->tilesX * c->tilesY;
     const uint32_t pass = c->rasterCalls & 1u;
     p.tileCount = c->dFrameState->tileCount + (size_t)pass * tiles * TC_STRIDE;
@@ -1329,7 +1414,8 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         (void)hipMemsetAsync(&c->dCounters->clipTriCount[pass], 0, sizeof(uint32_t), c->stream);
         (void)hipMemsetAsync(c->dCounters->largeCount[pass], 0, sizeof(c->dCounters->largeCount[pass]), c->stream);
         (void)hipMemsetAsync(&c->dCounters->binPoolCount[pass], 0, sizeof(uint32_t), c->stream);
-        if (!c->inFrame) (void)hipMemsetAsync(c->dCounters->triCount, 0, sizeof(c->dCounters->triCount), c->stream);
+        if (!c->inFrame) { (void)hipMemsetAsync(c->dCounters->triCount, 0, sizeof(c->dCounters->triCount), c->stream);
+                           (void)hipMemsetAsync(c->dCounters->triCountC, 0, sizeof(c->dCounters->triCountC), c->stream); }
     }
 
     uint32_t blocks = (in.capacity + 3u) / 4u;

@@ -57,6 +57,7 @@ class Stats(C.Structure):
         ("framesTimed", C.c_uint32), ("rasterLaunches", C.c_uint32), ("overflow", C.c_uint32), ("countInstanceCulled", C.c_uint32), ("countStage0Visible", C.c_uint32),
         ("countStage0Rejected", C.c_uint32), ("countStage1Visible", C.c_uint32), ("trianglesSubmitted", C.c_uint64),
         ("triangleRecords", C.c_uint64), ("binEntries", C.c_uint64), ("tilesTouched", C.c_uint32 * 2),
+        ("triangleRecordsCompact", C.c_uint64),
     ]
 
     def as_dict(self):

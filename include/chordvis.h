@@ -113,6 +113,7 @@ typedef struct ChordStats {
     uint64_t triangleRecords;      /* set-up triangles that survived the per-triangle culls (this frame)  */
     uint64_t binEntries;           /* (triangle, 64x64 tile) pairs binned (this frame, both raster passes) */
     uint32_t tilesTouched[2];      /* 64x64 tiles with at least one bin entry, per raster pass            */
+    uint64_t triangleRecordsCompact; /* of triangleRecords, those in the 32-byte form (the rest take 48 bytes) */
 } ChordStats;
 
 /* ------------------------------------------------------------------ host-only (no device needed) */
