@@ -384,62 +384,69 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
             for (int cc = 0; cc < 4; cc++) h.mvp.r[r][cc] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mv[r * 4 + cc])));
         return h;
     };
+    // Software pipeline over clusters (a wave's clusters k, k+1, ... are `stride` apart in the list).  While cluster k is
+    // processed, k+1's header is resident, its vertex indices + triangle words are fetched after k's vertex phase, its
+    // positions after k's triangle arithmetic, and k+2's header at the end -- so that at the top of an iteration the
+    // positions of its first 128 vertices are already in registers (or on their way) and the chain of four dependent
+    // round trips command -> records -> indices -> positions is off the critical path.
     const uint32_t stride = gridDim.x * 4u;
     uint32_t c = blockIdx.x * 4u + wave;
     if (c >= count) return;
-    Header hdr = load_header(p.cmds[__builtin_amdgcn_readfirstlane(c)]);
+    auto cmd_at = [&](uint32_t i) -> ChordDrawCmd { return p.cmds[__builtin_amdgcn_readfirstlane(min(i, count - 1u))]; };
+    Header hdr = load_header(cmd_at(c));
+    Header hdrN = load_header(cmd_at(c + stride));
+    // geometry of the current cluster: vertices lane and lane + 64 (indices, then positions), triangle words
+    uint32_t t0 = 0, t1 = 0;
+    float pax, pay, paz, pbx, pby, pbz;
+    {
+        const uint32_t ia = p.meshletData[hdr.dataOffset + min(lane, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
+        const uint32_t ib = p.meshletData[hdr.dataOffset + min(lane + 64u, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
+        if (lane < hdr.T) t0 = p.meshletData[hdr.dataOffset + hdr.V + lane];
+        if (lane + 64u < hdr.T) t1 = p.meshletData[hdr.dataOffset + hdr.V + 64u + lane];
+        const float* __restrict__ pa = p.positions + (size_t)ia * 3;
+        const float* __restrict__ pb = p.positions + (size_t)ib * 3;
+        pax = pa[0]; pay = pa[1]; paz = pa[2]; pbx = pb[0]; pby = pb[1]; pbz = pb[2];
+    }
     const bool sprof = (p.debug & DBG_SETUP_CLOCKS) != 0;
     unsigned long long sph[5] = {0, 0, 0, 0, 0}, stp = sprof ? wall_clock64() : 0ull;
 #define SPHASE(i) do { if (sprof) { const unsigned long long tn = wall_clock64(); sph[i] += tn - stp; stp = tn; } } while (0)
     for (; c < count; c += stride) {
         const uint32_t cu = __builtin_amdgcn_readfirstlane(c);
-        const ChordDrawCmd cmdNext = p.cmds[__builtin_amdgcn_readfirstlane(min(c + stride, count - 1u))];
         const uint32_t slot = hdr.slot, V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
         const bool twoSided = hdr.twoSided;
         const Mat4 mvp = hdr.mvp;
-        const bool skip = false;                                  // (sharded frames filter their clusters before this kernel)
+        const uint32_t triWord[2] = {t0, t1};
 
         if (sprof) { volatile uint32_t sink = V + T; (void)sink; }
         SPHASE(0);
-        // ---- vertex phase: coalesced index + position stream -> clip space -> LDS -------------
-        // (the triangle words of the lane travel with the vertex indices: one round trip less before the triangle phase)
-        uint32_t triWord[2] = {0u, 0u};
-        if (!skip) {
-            if (lane < T) triWord[0] = p.meshletData[dataOffset + V + lane];
-            if (lane + 64u < T) triWord[1] = p.meshletData[dataOffset + V + 64u + lane];
-        }
+        // ---- vertex phase: position stream -> clip space -> LDS (mesh_raster.hlsl:84-105) ----------------
         bool notFast = false;
-        // two vertices per lane and trip: both index loads, then both position loads, are in flight together
-        // (V = 81 is typical: one trip = two dependent round trips instead of four)
-        for (uint32_t i0 = lane; i0 < (skip ? 0u : V); i0 += 128u) {
-            const uint32_t i1 = i0 + 64u;
-            const bool second = i1 < V;
-            const uint32_t va = p.meshletData[dataOffset + i0] + vertexBase;
-            const uint32_t vb = second ? p.meshletData[dataOffset + i1] + vertexBase : va;
-            const float* __restrict__ pa = p.positions + (size_t)va * 3;
-            const float* __restrict__ pb = p.positions + (size_t)vb * 3;
-            const float ax = pa[0], ay = pa[1], az = pa[2], bx = pb[0], by = pb[1], bz = pb[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (k == 1 && !second) break;
-                const uint32_t i = k ? i1 : i0;
-                const f4 h = k ? mul_mv(mvp, bx, by, bz, 1.0f) : mul_mv(mvp, ax, ay, az, 1.0f);   // mesh_raster.hlsl:99
-                const float aw = fabsf(h.w);
-                lX[i] = h.x; lY[i] = h.y; lW[i] = h.w;
-                lU[i] = h.x / aw * 0.5f + 0.5f;                                  // :159-161
-                lV[i] = h.y / aw * -0.5f + 0.5f;
-                const bool fast = in_fast_volume(h);
-                lD[i] = fast ? h.z / h.w : __builtin_nanf("");
-                notFast = notFast || !fast;
-            }
+        auto vertex = [&](uint32_t i, float x, float y, float z) {
+            const f4 h = mul_mv(mvp, x, y, z, 1.0f);                             // mesh_raster.hlsl:99
+            const float aw = fabsf(h.w);
+            lX[i] = h.x; lY[i] = h.y; lW[i] = h.w;
+            lU[i] = h.x / aw * 0.5f + 0.5f;                                      // :159-161
+            lV[i] = h.y / aw * -0.5f + 0.5f;
+            const bool fast = in_fast_volume(h);
+            lD[i] = fast ? h.z / h.w : __builtin_nanf("");
+            notFast = notFast || !fast;
+        };
+        if (lane < V) vertex(lane, pax, pay, paz);
+        if (lane + 64u < V) vertex(lane + 64u, pbx, pby, pbz);
+        for (uint32_t i = lane + 128u; i < V; i += 64u) {                        // (meshlets with more than 128 vertices)
+            const float* __restrict__ pp = p.positions + (size_t)(p.meshletData[dataOffset + i] + vertexBase) * 3;
+            vertex(i, pp[0], pp[1], pp[2]);
         }
         const bool allFast = __ballot(notFast) == 0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         SPHASE(1);
-        hdr = load_header(cmdNext);                                // in flight during the triangle phase
-        if (skip) continue;
+        // next cluster: indices and triangle words now (its header has been resident for an iteration)
+        const uint32_t nia = p.meshletData[hdrN.dataOffset + min(lane, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
+        const uint32_t nib = p.meshletData[hdrN.dataOffset + min(lane + 64u, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
+        const uint32_t nt0 = lane < hdrN.T ? p.meshletData[hdrN.dataOffset + hdrN.V + lane] : 0u;
+        const uint32_t nt1 = lane + 64u < hdrN.T ? p.meshletData[hdrN.dataOffset + hdrN.V + 64u + lane] : 0u;
 
         // ---- triangle phase: the (up to) two triangles of a lane are evaluated first, then emitted together so
         //      that every round of list / bin reservations costs ONE atomic round trip for both ------------------
@@ -489,6 +496,10 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
             else           { kindB = kind; tsB = ts; dB[0] = d[0]; dB[1] = d[1]; dB[2] = d[2]; }
         }
         SPHASE(2);
+        // next cluster: its positions now (the indices have arrived behind the triangle arithmetic)
+        const float* __restrict__ npa = p.positions + (size_t)nia * 3;
+        const float* __restrict__ npb = p.positions + (size_t)nib * 3;
+        const float nax = npa[0], nay = npa[1], naz = npa[2], nbx = npb[0], nby = npb[1], nbz = npb[2];
         {
             const unsigned long long lt = (1ull << lane) - 1ull;
             const unsigned long long cmA = __ballot(kindA == K_CLIP), cmB = __ballot(kindB == K_CLIP);
@@ -560,6 +571,11 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
         // LDS of this wave is rewritten by the next cluster: order the reads above before those writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // rotate the pipeline; the header after next is fetched now and first used after the next vertex phase
+        hdr = hdrN;
+        hdrN = load_header(cmd_at(c + 2u * stride));
+        t0 = nt0; t1 = nt1;
+        pax = nax; pay = nay; paz = naz; pbx = nbx; pby = nby; pbz = nbz;
         SPHASE(4);
     }
     if (sprof && lane == 0u) {
