@@ -36,8 +36,14 @@ def test_record_layouts_match_the_header():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
         for f in dt.names:
             lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, nested.get((cname, f), f)))
-    for cname, ct in (("ChordAssetDesc", R.AssetDesc), ("ChordSceneDesc", R.SceneDesc), ("ChordHZBDesc", R.HZBDesc)):
+    from chord_amd import lib as L
+    ctypes_mirrors = (("ChordAssetDesc", R.AssetDesc), ("ChordSceneDesc", R.SceneDesc), ("ChordHZBDesc", R.HZBDesc),
+                      ("ChordStats", L.Stats), ("ChordLimits", L.Limits), ("ChordTileMarker", L.TileMarker),
+                      ("ChordShadingTiles", L.ShadingTiles), ("ChordCountAndCmd", L.CountAndCmd), ("ChordHZB", L.HZB))
+    for cname, ct in ctypes_mirrors:
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in ct._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "chordvis.h"\nint main(void){\n%s\nreturn 0;}\n' % "\n".join(lines)
     with tempfile.TemporaryDirectory() as td:
         cpath, exe = os.path.join(td, "l.c"), os.path.join(td, "l")
@@ -49,9 +55,10 @@ def test_record_layouts_match_the_header():
         assert int(out[cname]) == dt.itemsize, cname
         for f in dt.names:
             assert int(out["%s.%s" % (cname, f)]) == dt.fields[f][1], (cname, f)
-    assert int(out["ChordAssetDesc"]) == C.sizeof(R.AssetDesc)
-    assert int(out["ChordSceneDesc"]) == C.sizeof(R.SceneDesc)
-    assert int(out["ChordHZBDesc"]) == C.sizeof(R.HZBDesc)
+    for cname, ct in ctypes_mirrors:
+        assert int(out[cname]) == C.sizeof(ct), cname
+        for f, _ in ct._fields_:
+            assert int(out["%s.%s" % (cname, f)]) == getattr(ct, f).offset, (cname, f)
     # reference sizes (gltf.h:26-153, base.h:121-135,343-360)
     assert [int(out[n]) for n in ("ChordMeshlet", "ChordMeshletGroup", "ChordPrimitive", "ChordMaterial", "ChordObject",
                                   "ChordInstanceCullingView", "ChordDrawCmd")] == [64, 40, 96, 96, 224, 288, 12]
