@@ -12,14 +12,14 @@ scene, cam = bench.build_workload(wl)
 view, iv = L.make_views(cam)
 flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL
 objs = L.fill_objects(scene, cam, cam)
-for ranks in (1, 2, 4, 8):
+for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
     r = VisibilityRenderer(0)
     if wl == "subpixel_1g":
         share = max(1, ranks // 2) if ranks > 1 else 1
         r.set_limits(max_triangle_records=(1152 << 20) // share, bin_pool_chunks=(1200 << 10) // share, bin_max_chunks_per_tile=2048)
     r.upload_scene(scene)
     if ranks > 1:
-        r.set_shard(pick_stripe_rows(cam.height, ranks), ranks, 0)
+        r.set_shard(int(os.environ.get("STRIPE", pick_stripe_rows(cam.height, ranks))), ranks, 0)
     r.allocate_gbuffer(cam.width, cam.height)
     r.update_objects(objs); r.set_view(view, iv, flags)
 
