@@ -475,6 +475,8 @@ int chordvis_set_shard(ChordCtx* c, uint32_t stripeRows, uint32_t ranks, uint32_
 {
     if (!c || ranks == 0 || rank >= ranks || stripeRows < 2 || (stripeRows & 1u)) return fail(c, CHORDVIS_E_INVALID, "set_shard: stripeRows must be even, rank < ranks");
     c->shard.stripeRows = stripeRows; c->shard.ranks = ranks; c->shard.rank = rank;
+    c->shard.stripeMagic = stripeRows > 1 ? (uint32_t)((0x100000000ull + stripeRows - 1) / stripeRows) : 0xFFFFFFFFu;
+    c->shard.rankMagic = ranks > 1 ? (uint32_t)((0x100000000ull + ranks - 1) / ranks) : 0xFFFFFFFFu;
     if (c->width) {
         if (c->visExternal) { c->dVis = nullptr; return fail(c, CHORDVIS_E_INVALID, "set_shard after allocate_gbuffer with an external buffer: call allocate_gbuffer again"); }
         return configure_targets(c, nullptr);

@@ -68,7 +68,15 @@ struct DView {                 // constants of one frame
 
 struct ShardInfo {
     uint32_t stripeRows, ranks, rank, stripesPerRank;
+    // ceil(2^32 / d): (x * magic) >> 32 == x / d for x < 2^16 (rows and stripes of a <= 4096-row frame) -- the GPU has no
+    // integer divide, and the ownership test runs several times per triangle
+    uint32_t stripeMagic, rankMagic;
 };
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t shard_stripe_of(const ShardInfo& s, uint32_t y) { return __umulhi(y, s.stripeMagic); }
+__device__ __forceinline__ uint32_t shard_div_ranks(const ShardInfo& s, uint32_t stripe) { return __umulhi(stripe, s.rankMagic); }
+__device__ __forceinline__ uint32_t shard_owner_of_stripe(const ShardInfo& s, uint32_t stripe) { return stripe - shard_div_ranks(s, stripe) * s.ranks; }
+#endif
 
 // Work lists between the raster kernels (device memory, counts in DeviceCounters)
 struct TriRec {                // 48 B: one set-up triangle (snapped 24.8 vertices, vertex depths, id)

@@ -502,10 +502,11 @@ struct StripeFilterParams {
 
 __device__ __forceinline__ bool shard_owns_any_row(const ShardInfo& s, int32_t y0, int32_t y1)
 {
-    const uint32_t s0 = (uint32_t)y0 / s.stripeRows, s1 = (uint32_t)y1 / s.stripeRows;
+    const uint32_t s0 = shard_stripe_of(s, (uint32_t)y0), s1 = shard_stripe_of(s, (uint32_t)y1);
     if (s1 - s0 + 1u >= s.ranks) return true;
-    for (uint32_t st = s0; st <= s1; st++) if (st % s.ranks == s.rank) return true;
-    return false;
+    const uint32_t o0 = shard_owner_of_stripe(s, s0);
+    const uint32_t ahead = s.rank >= o0 ? s.rank - o0 : s.rank + s.ranks - o0;
+    return s0 + ahead <= s1;
 }
 
 __global__ __launch_bounds__(256) void stripe_filter_kernel(StripeFilterParams p)

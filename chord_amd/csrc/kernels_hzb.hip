@@ -47,8 +47,8 @@ __device__ __forceinline__ uint32_t valid_h(const ChordHZBDesc& d, uint32_t l)
 __device__ __forceinline__ size_t vis_row_base(const ShardInfo& s, bool sharded, uint32_t y, uint32_t W)
 {
     if (!sharded) return (size_t)y * W;
-    const uint32_t stripe = y / s.stripeRows;
-    return ((size_t)((stripe % s.ranks) * s.stripesPerRank + stripe / s.ranks) * s.stripeRows + (y % s.stripeRows)) * (size_t)W;
+    const uint32_t stripe = shard_stripe_of(s, y), local = shard_div_ranks(s, stripe);
+    return ((size_t)((stripe - local * s.ranks) * s.stripesPerRank + local) * s.stripeRows + (y - stripe * s.stripeRows)) * (size_t)W;
 }
 
 // exchange-buffer row of mip-0 row y0 (pixel rows 2*y0, 2*y0+1 live in one stripe: stripeRows is even)
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void hzb_mip0_kernel(HzbParams p, int wantMax,
     float mn = 0.0f, mx = 0.0f;
     uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
     bool act = x < vw && y < vh;
-    if (MODE == 1 && act) act = (((2u * y) / p.shard.stripeRows) % p.shard.ranks) == p.shard.rank;
+    if (MODE == 1 && act) act = shard_owner_of_stripe(p.shard, shard_stripe_of(p.shard, 2u * y)) == p.shard.rank;
     if (act) {
         const uint32_t sx0 = min(2u * x, (uint32_t)p.W - 1u), sx1 = min(2u * x + 1u, (uint32_t)p.W - 1u);
         const uint32_t sy0 = min(2u * y, (uint32_t)p.H - 1u), sy1 = min(2u * y + 1u, (uint32_t)p.H - 1u);

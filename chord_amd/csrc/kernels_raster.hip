@@ -91,27 +91,29 @@ template <bool SH>
 __device__ __forceinline__ bool owns_row(const ShardInfo& s, int32_t y)
 {
     if (!SH) return true;
-    return (((uint32_t)y / s.stripeRows) % s.ranks) == s.rank;
+    return shard_owner_of_stripe(s, shard_stripe_of(s, (uint32_t)y)) == s.rank;
 }
 
 template <bool SH>
 __device__ __forceinline__ size_t row_base(const ShardInfo& s, int32_t y, int32_t Wi)
 {
     if (!SH) return (size_t)y * (size_t)Wi;
-    const uint32_t stripe = (uint32_t)y / s.stripeRows;
-    const uint32_t local = stripe / s.ranks;
-    const uint32_t owner = stripe % s.ranks;
-    return ((size_t)(owner * s.stripesPerRank + local) * s.stripeRows + ((uint32_t)y % s.stripeRows)) * (size_t)Wi;
+    const uint32_t stripe = shard_stripe_of(s, (uint32_t)y);
+    const uint32_t local = shard_div_ranks(s, stripe);
+    const uint32_t owner = stripe - local * s.ranks;
+    return ((size_t)(owner * s.stripesPerRank + local) * s.stripeRows + ((uint32_t)y - stripe * s.stripeRows)) * (size_t)Wi;
 }
 
 // does the rank own at least one pixel row in [y0, y1]?  (ranks == 1: always)
 __device__ __forceinline__ bool owns_any_row(const ShardInfo& s, int32_t y0, int32_t y1)
 {
     if (s.ranks <= 1) return true;
-    const uint32_t s0 = (uint32_t)y0 / s.stripeRows, s1 = (uint32_t)y1 / s.stripeRows;
+    const uint32_t s0 = shard_stripe_of(s, (uint32_t)y0), s1 = shard_stripe_of(s, (uint32_t)y1);
     if (s1 - s0 + 1u >= s.ranks) return true;
-    for (uint32_t st = s0; st <= s1; st++) if (st % s.ranks == s.rank) return true;
-    return false;
+    // the stripes s0..s1 (fewer than `ranks` of them) contain one of this rank's iff the first one at or after s0 is <= s1
+    const uint32_t o0 = shard_owner_of_stripe(s, s0);
+    const uint32_t ahead = s.rank >= o0 ? s.rank - o0 : s.rank + s.ranks - o0;
+    return s0 + ahead <= s1;
 }
 
 __device__ __forceinline__ bool in_fast_volume(const f4& h)
