@@ -8,19 +8,22 @@
 // 214 Gop/s for an 8x8 footprint — while ds_max_u64 in LDS sustains ~1 050 Gop/s and plain coalesced
 // stores ~6.6 TB/s.  So fragments are resolved in LDS and the visibility words leave the CU once:
 //
-//   raster_setup_kernel   one wave per visible meshlet: coalesced meshletData / position stream ->
-//                         clip-space transform -> LDS (SoA x,y,w,u,v,depth) -> per-triangle culls
-//                         (mesh_raster.hlsl:143-179) -> snapped setup -> 48-byte triangle record
-//                         appended to a device list + one bin entry per 64x64 screen tile touched
+//   raster_setup_kernel   one wave per visible meshlet, software-pipelined over the wave's meshlets: coalesced
+//                         meshletData / position stream -> clip-space transform -> LDS (SoA x,y,w,u,v,depth) ->
+//                         per-triangle culls (mesh_raster.hlsl:143-179) -> snapped setup -> a 32-byte (vertices
+//                         at most 64 px apart) or 48-byte triangle record + one bin entry per 64x64 screen tile
+//                         touched; every reservation of a meshlet in one memory round trip
 //   raster_clip_and_bin_large_kernel  one launch, two roles: (a) homogeneous Sutherland-Hodgman clipper for
 //                         triangles touching the near / guard planes (rare; emits + bins its pieces itself),
 //                         (b) records touching more than 2x2 tiles: one wave per record, one lane per tile
-//   raster_tile_kernel    one workgroup per 64x64 tile: the tile's 4096 packed words live in LDS
-//                         (32 KB); every binned triangle is scan-converted with ds_max_u64
-//                         (tiny: one lane per triangle; others: cut into (triangle, row) units that a
-//                         block-wide prefix sum deals out one row per lane).  Tile-out: on the first pass
-//                         tile is written back with 16-byte coalesced stores (and, on the first pass
-//                         of a frame, this is also the clear).
+//   raster_tile_order_kernel  work items of the tile kernel (tiles, or slices of tiles with long bins), heaviest first
+//   raster_tile_kernel    one 512-thread workgroup per work item: the tile's 4096 packed words live in LDS;
+//                         every binned triangle is scan-converted with ds_max_u64 (tiny: one lane per triangle;
+//                         others: cut into (triangle, row) units that a block-wide prefix sum deals out one row
+//                         per lane, each row a branch-free loop over an fp32-bounded span).  Tile-out: 16-byte
+//                         coalesced stores (on the first pass of a frame this is also the clear) fused with the
+//                         reduction of the tile to HZB mips 0..5; slices of a split tile meet in a per-tile slab.
+// Bins hold 16 384 entries per tile and continue in 1024-entry pool chunks (bin_store).
 // The packed word is (asuint(depth) << 32) | ((slot+1)&0xFFFFFF)<<8 | tri: reverse-Z "greater wins"
 // and the id in one 64-bit max (GREATER_OR_EQUAL depth test + id write of the reference).
 //
