@@ -309,6 +309,8 @@ def main():
                        "objects": len(scene.objects), "hzb": not args.no_hzb,
                        "parallelism": "stripes%d" % world if world > 1 else "single"},
             "triangles_submitted_per_step": tris_per_pair / 2.0,
+            # end to end over ALL scene triangles (LOD 0), i.e. including what culling removed
+            "scene_gtri_per_s": round(scene.triangle_count_lod0() / (ms_per_step * 1e-3) / 1e9, 3),
             "clusters_rastered_per_step": clusters_per_frame, "triangle_records_per_step": recs, "bin_entries_per_step": bins,
             "gpu_ms": {k: round(st[k], 4) for k in ("msClear", "msInstanceCulling", "msStage0", "msHzbStage0", "msStage1",
                                                      "msHzbFinal", "msFrame", "msRasterCluster", "msRasterClip", "msRasterChunk")},
