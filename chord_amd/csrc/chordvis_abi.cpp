@@ -892,6 +892,41 @@ int chordvis_debug_graph_frames(ChordCtx* c, uint32_t pairs, float* msPerFrameSt
     return CHORDVIS_OK;
 }
 
+// Debugging aid: raw read of an internal buffer.  which: 0 tile counts (FrameState::tileCount), 1 fixed bins, 2 chunk table,
+// 3 bin pool, 4 compact records, 5 wide records.  offset / bytes in bytes.
+int chordvis_debug_read(ChordCtx* c, int which, uint64_t offset, uint64_t bytes, void* host)
+{
+    if (!c || !host) return fail(c, CHORDVIS_E_INVALID, "debug_read: null argument");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    const char* base = nullptr;
+    switch (which) {
+    case 0: base = (const char*)c->dFrameState->tileCount; break;
+    case 1: base = (const char*)c->dTileBins; break;
+    case 2: base = (const char*)c->dBinChunkTab; break;
+    case 3: base = (const char*)c->dBinPool; break;
+    case 4: base = (const char*)c->dTrisC; break;
+    case 5: base = (const char*)c->dTris; break;
+    default: return fail(c, CHORDVIS_E_INVALID, "debug_read: unknown buffer");
+    }
+    CHORD_HIP(c, hipMemcpy(host, base + offset, bytes, hipMemcpyDeviceToHost));
+    return CHORDVIS_OK;
+}
+
+// Measurement / debugging aid: words of the split-tile accumulation slabs that are not zero (the invariant between
+// raster passes is: none).
+int chordvis_debug_slab_nonzero(ChordCtx* c, uint64_t* count)
+{
+    if (!c || !count || !c->dTileSlabs) return fail(c, CHORDVIS_E_INVALID, "debug_slab_nonzero: no gbuffer");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->tilesX * c->tilesY * CHORD_TILE * CHORD_TILE;
+    std::vector<unsigned long long> h(n);
+    CHORD_HIP(c, hipMemcpy(h.data(), c->dTileSlabs, n * 8, hipMemcpyDeviceToHost));
+    uint64_t k = 0;
+    for (size_t i = 0; i < n; i++) k += h[i] != 0ull;
+    *count = k;
+    return CHORDVIS_OK;
+}
+
 int chordvis_debug_setup_profile(ChordCtx* c, int pass, uint64_t hostTicks[5], uint32_t* waves)
 {
     if (!c || pass < 0 || pass > 1 || !hostTicks) return fail(c, CHORDVIS_E_INVALID, "debug_setup_profile: bad arguments");

@@ -83,6 +83,7 @@ struct RasterParams {
 #define DBG_NO_HZB      256u  // tile kernel writes the tile but skips the HZB reduction
 #define DBG_SETUP_CLOCKS 512u // setup kernel accumulates per-wave phase ticks (header / vertex / triangle / reserve / emit)
 #define DBG_NO_VIS_STORE 1024u // fused tile-out skips the visibility stores (HZB texels still written: culling unchanged)
+#define DBG_NO_SPLIT    2048u // tile order kernel never cuts a bin into slices
 #define DBG_NO_TINY     32u   // tile kernel skips the per-lane scan of tiny triangles
 #define DBG_TILE_EXIT   64u   // tile kernel of passes >= 1 returns at once (launch-floor measurement)
 
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
         if (t < tiles) {
             const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], bin_capacity(p));
             myCount[k] = c;
-            if (c > TILE_SPLIT_MIN) {
+            if (c > TILE_SPLIT_MIN && !(p.debug & DBG_NO_SPLIT)) {
                 mySlices[k] = min((c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT, CHORD_TILE_MAX_SLICES);
                 myBucket[k] = 18u;
                 myPos[k] = atomicAdd(&splitItems, mySlices[k]);
@@ -1141,6 +1142,7 @@ __device__ __noinline__ bool merge_slices(unsigned long long* tile, unsigned lon
         const uint32_t i = threadIdx.x + k * TB;
         tile[(i >> TILE_SHIFT) * TPITCH + (i & (TILE - 1))] = got[k];
     }
+    __syncthreads();                                              // the caller's next pass over `tile` maps words to threads differently
     return true;
 }
 

@@ -146,6 +146,8 @@ def _load():
         "chordvis_set_debug": (i32, [vp, u32]),
         "chordvis_debug_tile_profile": (i32, [vp, i32, vp, vp, u32]),
         "chordvis_debug_setup_profile": (i32, [vp, i32, vp, P(u32)]),
+        "chordvis_debug_read": (i32, [vp, i32, C.c_uint64, C.c_uint64, vp]),
+        "chordvis_debug_slab_nonzero": (i32, [vp, P(C.c_uint64)]),
         "chordvis_debug_graph_frames": (i32, [vp, u32, P(C.c_float), P(C.c_float)]),
     }
     missing = []

@@ -266,6 +266,10 @@ int chordvis_stats(ChordCtx* ctx, ChordStats* out);
 int chordvis_set_debug(ChordCtx* ctx, uint32_t flags);
 /* Measurement only: with debug bit 4 set the tile kernel records its elapsed wall-clock ticks (100 MHz)
  * per 64x64 tile; this reads them back with the tile's bin count for raster pass 0 / 1 of the last frame. */
+/* debugging aid: raw read of an internal buffer (0 tile counts, 1 fixed bins, 2 chunk table, 3 bin pool, 4 / 5 32- / 48-byte records) */
+int chordvis_debug_read(ChordCtx* ctx, int which, uint64_t offset, uint64_t bytes, void* host);
+/* debugging aid: non-zero words in the split-tile accumulation slabs (must be 0 between raster passes) */
+int chordvis_debug_slab_nonzero(ChordCtx* ctx, uint64_t* count);
 /* measurement aid: ms per frame of 2*pairs stream-launched frames vs the same frames replayed from a hipGraph */
 int chordvis_debug_graph_frames(ChordCtx* ctx, uint32_t pairs, float* msPerFrameStream, float* msPerFrameGraph);
 /* debug bit 512: per-wave phase ticks (10 ns) of the setup kernel summed over waves: header wait / vertex / triangle / reserve / emit */

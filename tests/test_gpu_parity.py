@@ -190,6 +190,27 @@ def test_bins_beyond_the_fixed_capacity_use_overflow_chunks(gpu):
     r.close()
 
 
+def test_config4_street_x64_4k_two_frames_match_oracle(gpu):
+    """BASELINE config 4 at full size (179 M scene triangles, 260 k clusters after culling, 4K): frame 0 (no history:
+    33 M triangles submitted, bins of 90 k entries) and frame 1 (two-pass HZB) bit-exact vs the oracle."""
+    scene, cam, view, iv = H.setup_scene(scenes.config4_street_x64)
+    W, Hh = cam.width, cam.height
+    want0 = orc.frame(scene, view, iv, H.ALL_FLAGS)
+    want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want0["hzb_min"])
+    r = _renderer(gpu, scene, view, iv, W, Hh, H.ALL_FLAGS)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want0["vis"], W, Hh, "config4 4K frame 0")
+    st = r.stats()
+    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want0["stats"].trianglesSubmitted
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want1["vis"], W, Hh, "config4 4K frame 1")
+    st = r.stats()
+    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want1["stats"].trianglesSubmitted
+    mn, mx, rng = r.read_hzb(r.history_hzb())
+    assert np.array_equal(mn, want1["hzb_min"]) and np.array_equal(mx, want1["hzb_max"]) and np.array_equal(rng, want1["valid_range"])
+    r.close()
+
+
 def test_config5_subpixel_reduced_matches_oracle(gpu):
     """BASELINE config 5 at reduced size (16 k camera-facing patches of ~8x8 px = 2.1 M triangles of ~0.5 px^2 into
     960x540): nearly every triangle survives the per-triangle culls and about half of them hit a pixel centre --
