@@ -240,6 +240,31 @@ def test_config5_subpixel_reduced_matches_oracle(gpu):
     r.close()
 
 
+def test_config5_subpixel_quarter_size_4k_matches_oracle(gpu):
+    """BASELINE config 5 at a quarter of its size and full resolution: 268 M sub-pixel triangles in one pass, 120 k
+    entries per 64x64 tile on average (up to 167 k: 64 equal-part slices per tile, bins deep into the pool chunks),
+    raised work-list limits -- against the multi-threaded oracle replay.  (tools/verify_config5.py runs the same check
+    at full size, 1.07 G triangles: also exact.)"""
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam = scenes.config5_subpixel(3840, 2160, prims=256)
+    L.fill_objects(scene, cam)
+    view, iv = L.make_views(cam)
+    flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL
+    r = VisibilityRenderer(0)
+    r.set_limits(max_triangle_records=296 << 20, bin_pool_chunks=332 << 10, bin_max_chunks_per_tile=2048)
+    r.upload_scene(scene)
+    r.allocate_gbuffer(cam.width, cam.height)
+    r.set_view(view, iv, flags)
+    r.render_frame()
+    got = r.read_visibility()
+    st = r.stats()
+    want = orc.frame_mt(scene, view, iv, flags, None, threads=16)
+    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["triangles_submitted"]
+    H.assert_vis_equal(got, want["vis"], cam.width, cam.height, "config5 quarter size")
+    r.close()
+
+
 def test_config3_street_4k_two_pass_matches_oracle_and_properties(gpu):
     """BASELINE config 3 at full size: frame 0 (no history) and frame 1 (two-pass HZB) bit-exact vs the
     oracle; occlusion culling must not change a static image; a repeated frame is idempotent."""
