@@ -25,6 +25,10 @@ SCENES = [
     ("small_nocone", lambda: scenes.small_test_scene(200, 120, seed=5), R.FLAG_FRUSTUM_CULL),
     ("small_nocull", lambda: scenes.small_test_scene(128, 128, seed=9, lods=2), 0),
     ("config1", scenes.config1_single_meshlet, R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL),
+    # the render-size limits of renderer.h:52-53: one tile, and 4096 tiles (the tile order kernel's full table)
+    ("small_64", lambda: scenes.small_test_scene(64, 64, seed=4), H.ALL_FLAGS),
+    ("small_4096", lambda: scenes.small_test_scene(4096, 4096, seed=6), H.ALL_FLAGS),
+    ("small_odd", lambda: scenes.small_test_scene(1237, 701, seed=8), H.ALL_FLAGS),
 ]
 
 
@@ -303,6 +307,8 @@ SHARDED = [
     ("street_x64_360p_8ranks", lambda: scenes.config4_street_x64(640, 360), 8, None),
     # config 5 (sub-pixel patches, the other multi-GPU workload) at reduced size
     ("subpixel_540p_8ranks", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4), 8, None),
+    # full size: long bins, pool chunks and split tiles in both raster passes of a sharded frame
+    ("street_x64_4k_2ranks", scenes.config4_street_x64, 2, None),
 ]
 
 
@@ -339,6 +345,8 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, r
             for src in range(ranks):
                 if src != dst:
                     assert hip.hipMemcpy(ptrs[dst] + src * chunk_bytes, ptrs[src] + src * chunk_bytes, chunk_bytes, 3) == 0
+        # a device-to-device hipMemcpy is ordered on the null stream only; the contexts run on non-blocking streams
+        assert hip.hipDeviceSynchronize() == 0
 
     for frame in range(2):                               # frame 0: no history; frame 1: two-pass HZB
         ref.render_frame()
