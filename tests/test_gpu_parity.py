@@ -418,3 +418,39 @@ def test_tile_marker_config3_4k(gpu):
     tiles, args = r.read_shading_tiles(r.prepare_shading_tile_param(66, marker))
     assert sorted(map(tuple, tiles.tolist())) == H.tiles_with_type(ref, 66) and args[0] == (len(tiles) + 3) // 4
     r.close()
+
+
+@pytest.mark.parametrize("name,builder", [("config3", scenes.config3_street), ("config4", scenes.config4_street_x64)])
+def test_moving_camera_sequence_matches_oracle(gpu, name, builder):
+    """What bench.py renders: frames alternating between two cameras 0.5 m apart, every frame culling against the HZB of
+    the previous (different) view through the objects' last-frame transforms.  Four frames B, A, B, A at full size,
+    each against the oracle fed with the oracle's own previous HZB."""
+    from chord_amd import lib as L
+    scene, cam_a = builder()
+    f = np.array(cam_a.front, dtype=np.float64); f /= np.linalg.norm(f)
+    cam_b = cam_a.moved(tuple(0.5 * f))
+    va0, _ = L.make_views(cam_a); vb0, _ = L.make_views(cam_b)
+    views = {"a": L.make_views(cam_a, vb0), "b": L.make_views(cam_b, va0)}
+    objs = {"a": L.fill_objects(scene, cam_a, cam_b).copy(), "b": L.fill_objects(scene, cam_b, cam_a).copy()}
+
+    def scene_with(o):
+        return R.Scene(o, scene.primitives, scene.materials, scene.meshlets, scene.groups, scene.group_indices,
+                       scene.meshlet_data, scene.positions, name=scene.name)
+    from chord_amd.renderer import VisibilityRenderer
+    r = VisibilityRenderer(0)
+    r.upload_scene(scene)
+    r.allocate_gbuffer(cam_a.width, cam_a.height)
+    prev = None
+    for i, k in enumerate("baba"):
+        view, iv = views[k]
+        want = orc.frame(scene_with(objs[k]), view, iv, H.ALL_FLAGS, prev_hzb_min=prev)
+        r.update_objects(objs[k])
+        r.set_view(view, iv, H.ALL_FLAGS)
+        r.render_frame()
+        H.assert_vis_equal(r.read_visibility(), want["vis"], cam_a.width, cam_a.height, "%s frame %d (view %s)" % (name, i, k))
+        st = r.stats()
+        assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["stats"].trianglesSubmitted
+        assert [st["countInstanceCulled"], st["countStage0Visible"], st["countStage0Rejected"], st["countStage1Visible"]] == want["counts"].tolist() \
+            or prev is None
+        prev = want["hzb_min"]
+    r.close()
