@@ -454,3 +454,44 @@ def test_moving_camera_sequence_matches_oracle(gpu, name, builder):
             or prev is None
         prev = want["hzb_min"]
     r.close()
+
+
+@pytest.mark.parametrize("name,builder", [("small", lambda: scenes.small_test_scene(400, 240, seed=31)),
+                                          ("config3_1080p", lambda: scenes.config3_street(1920, 1080)),
+                                          ("config4_4k", scenes.config4_street_x64)])
+def test_individual_passes_compose_to_the_frame(gpu, name, builder):
+    """the frame recorded pass by pass through the stand-alone entry points (clear, instance
+    culling, stage 0, buildHZB, stage 1, buildHZB -- renderer.cpp:315-345), with the caller carrying the history HZB,
+    gives the oracle's frames.  This is the path without the fused clear / fused HZB of chordvis_render_frame (a real
+    clear, the three-kernel HZB build, later raster passes merging with atomics); config 4 runs it with long bins."""
+    scene, cam, view, iv = H.setup_scene(builder)
+    W, Hh = cam.width, cam.height
+    want0 = orc.frame(scene, view, iv, H.ALL_FLAGS)
+    want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want0["hzb_min"])
+    r = _renderer(gpu, scene, view, iv, W, Hh, H.ALL_FLAGS)
+    hist = None
+    for frame, want in enumerate((want0, want1)):
+        r.clear_gbuffer()                                                   # addClearGbufferPass       renderer.cpp:315
+        post = r.instance_culling()                                         # instanceCulling           :321
+        stage1, rejected = r.visibility_stage0(hist, post)                  # :326
+        assert stage1 == (hist is not None)
+        if stage1:
+            tmp = r.build_hzb(True, False, False, slot=0)                   # buildHZB(min)             :334
+            r.visibility_stage1(tmp, rejected)                              # :337
+        hist = r.build_hzb(True, True, True, slot=1 + (frame & 1))          # buildHZB(min, max, range) :343
+        H.assert_vis_equal(r.read_visibility(), want["vis"], W, Hh, "%s pass-by-pass frame %d" % (name, frame))
+        mn, mx, rng = r.read_hzb(hist)
+        d = want["desc"]
+        for l in range(d.mipCount):                                         # only the sampled extent of a mip is defined
+            vw, vh = d.valid_dims(l)
+            mw, _ = d.mip_dims(l)
+            o = d.mipOffset[l]
+            for arr, ref in ((mn, want["hzb_min"]), (mx, want["hzb_max"])):
+                a = arr[o:o + mw * max(1, d.height >> l)].reshape(-1, mw)[:vh, :vw]
+                b = ref[o:o + mw * max(1, d.height >> l)].reshape(-1, mw)[:vh, :vw]
+                assert np.array_equal(a, b), (name, frame, l)
+        assert np.array_equal(rng, want["valid_range"])
+        got_cmds = r.read_cmds(post)
+        assert np.array_equal(H.sort_cmds(got_cmds), H.sort_cmds(want["cmds"]))
+    assert r.stats()["overflow"] == 0
+    r.close()
