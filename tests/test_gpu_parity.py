@@ -495,3 +495,28 @@ def test_individual_passes_compose_to_the_frame(gpu, name, builder):
         assert np.array_equal(H.sort_cmds(got_cmds), H.sort_cmds(want["cmds"]))
     assert r.stats()["overflow"] == 0
     r.close()
+
+
+def test_context_reuse_across_sizes_and_scenes(gpu):
+    """One context, re-targeted: a new render size (all per-size buffers are re-made, the HZB history is dropped), then a
+    new scene -- every frame must equal the oracle's first frame / two-pass frame for that state."""
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityRenderer
+    r = VisibilityRenderer(0)
+    for builder, w, h in ((lambda: scenes.small_test_scene(640, 360, seed=41), 640, 360),
+                          (lambda: scenes.small_test_scene(320, 200, seed=41), 320, 200),
+                          (lambda: scenes.config2_atrium(800, 448), 800, 448),
+                          (lambda: scenes.small_test_scene(1000, 600, seed=43), 1000, 600)):
+        scene, cam, view, iv = H.setup_scene(builder)
+        r.upload_scene(scene)
+        r.allocate_gbuffer(w, h)
+        r.set_view(view, iv, H.ALL_FLAGS)
+        r.reset_history()
+        want0 = orc.frame(scene, view, iv, H.ALL_FLAGS)
+        want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want0["hzb_min"])
+        r.render_frame()
+        H.assert_vis_equal(r.read_visibility(), want0["vis"], w, h, "%s %dx%d frame 0" % (scene.name, w, h))
+        r.render_frame()
+        H.assert_vis_equal(r.read_visibility(), want1["vis"], w, h, "%s %dx%d frame 1" % (scene.name, w, h))
+        assert r.stats()["overflow"] == 0
+    r.close()
