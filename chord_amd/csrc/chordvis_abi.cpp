@@ -524,8 +524,7 @@ int chordvis_instance_culling(ChordCtx* c, ChordCountAndCmd* out)
 {
     int rc = ready(c, "instance_culling");
     if (rc) return rc;
-    launch_object_cull(c);                               // instanceCullingCS
-    launch_group_cull(c, c->lists[0]);                   // clusterGroupCullingCS (count + scatter)
+    launch_group_cull(c, c->lists[0]);                   // instanceCullingCS + clusterGroupCullingCS (objects + count, scatter)
     CHORD_HIP(c, hipGetLastError());
     if (out) *out = c->lists[0].handle();
     return CHORDVIS_OK;

@@ -287,7 +287,6 @@ int fail(ChordCtx* ctx, int code, const char* what, hipError_t e = hipSuccess);
     } while (0)
 
 // kernel launchers (implemented in the .hip translation units) ---------------------------------
-void launch_object_cull(ChordCtx* c);
 void launch_group_cull(ChordCtx* c, const CmdList& out);
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
                      const CmdList* outRejected);

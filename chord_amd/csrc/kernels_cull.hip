@@ -1,6 +1,6 @@
 // Culling kernels of the visibility path, hand-written for gfx950 (wave64).
 //
-//   object_cull_kernel          <- instanceCullingCS          instance_culling.hlsl:47-131
+//   object_frame (device fn)    <- instanceCullingCS          instance_culling.hlsl:47-131 (runs inside group_cull_count_kernel)
 //   group_cull_count/scatter    <- clusterGroupCullingCS      instance_culling.hlsl:133-208
 //   hzb_cull_kernel<PHASE>      <- hzbMainViewCullingCS       hzb_mainview_culling.hlsl:35-213
 //
@@ -27,19 +27,12 @@ namespace chord {
 // The first kernel of a frame also (a) publishes the frame constants, which arrive as a 600-byte kernel
 // argument instead of a host-to-device copy, and (b) zeroes the FrameState block (counters, list counts,
 // tile-bin counts) — two launches (~5 us each on this GPU) that the frame no longer pays.
-__global__ __launch_bounds__(256) void object_cull_kernel(
-    const ChordObject* __restrict__ objects, const DObjStatic* __restrict__ objStatic,
-    const DPrim* __restrict__ prims, const DView dv, DView* __restrict__ dviewOut, DObjFrame* __restrict__ objFrame,
-    uint32_t objectCount, uint4* __restrict__ zeroBase, uint32_t zeroVec4)
+// instanceCullingCS (instance_culling.hlsl:47-131) for one object: OBB-vs-frustum and the per-object matrices every
+// later kernel of the frame reads.  Runs inside group_cull_count_kernel (below): a launch of its own cost 8 us of a
+// 216-us frame for 352 objects' worth of work.
+__device__ __forceinline__ void object_frame(const ChordObject* __restrict__ objects, const DObjStatic* __restrict__ objStatic,
+                                             const DPrim* __restrict__ prims, const DView& dv, DObjFrame* __restrict__ objFrame, uint32_t o)
 {
-    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (dviewOut && blockIdx.x == 0) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
-        for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += blockDim.x) dst[i] = src[i];
-    }
-    for (uint32_t i = o; i < zeroVec4; i += gridDim.x * blockDim.x) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (o >= objectCount) return;
     const ChordObject& obj = objects[o];
 
     const Mat4 M = load_mat(obj.basicData.localToTranslatedWorld);
@@ -185,9 +178,44 @@ struct GroupCullParams {
     const DView* dview; uint8_t* groupMask; uint32_t* blockCounts; uint32_t groupInstances;
 };
 
-__global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p)
+// The object pass as a kernel of its own: for long scenes (thousands of count blocks) the fused form below makes every count
+// block wait for its objects first, which costs more than the launch it saves (config 4: +4 us).
+__global__ __launch_bounds__(256) void object_cull_kernel(const ChordObject* __restrict__ objects, const DObjStatic* __restrict__ objStatic,
+                                                          const DPrim* __restrict__ prims, const DView dv, DView* __restrict__ dviewOut,
+                                                          DObjFrame* __restrict__ objFrame, uint32_t objectCount,
+                                                          uint4* __restrict__ zeroBase, uint32_t zeroVec4)
+{
+    const uint32_t o = blockIdx.x * 256u + threadIdx.x;
+    if (dviewOut && blockIdx.x == 0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
+        for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += 256u) dst[i] = src[i];
+    }
+    for (uint32_t i = o; i < zeroVec4; i += gridDim.x * 256u) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (o < objectCount) object_frame(objects, objStatic, prims, dv, objFrame, o);
+}
+
+// Short scenes: first the objects this block's group instances belong to (instanceCullingCS, one thread per object; an object whose
+// groups span several blocks is done by each of them -- same values), the frame's housekeeping that used to ride on the
+// object kernel (view block published for the later kernels, FrameState zeroed), then the groups.
+__global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p, const DView dv, DView* __restrict__ dviewOut,
+                                                               DObjFrame* __restrict__ objFrameOut, uint4* __restrict__ zeroBase, uint32_t zeroVec4)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (dviewOut && blockIdx.x == 0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
+        for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += 256u) dst[i] = src[i];
+    }
+    for (uint32_t i = t; i < zeroVec4; i += gridDim.x * 256u) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (p.groupInstances && objFrameOut) {
+        const uint32_t first = blockIdx.x * 256u;
+        if (first < p.groupInstances) {
+            const uint32_t oFirst = p.groupOwner[first], oLast = p.groupOwner[min(first + 255u, p.groupInstances - 1u)];
+            if (threadIdx.x <= oLast - oFirst) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, oFirst + threadIdx.x);
+        }
+    }
+    __syncthreads();                                       // the object records of this block are written (and visible to it)
     uint32_t mask = 0, tris = 0;
     if (t < p.groupInstances) {
         const uint32_t o = p.groupOwner[t];
@@ -196,7 +224,6 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
             const DObjStatic st = p.objStatic[o];
             const DPrim& prim = p.prims[st.prim];
             const DGroup g = p.groups[prim.groupBase + (t - st.groupBase)];
-            const DView& dv = *p.dview;
             if (group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {     // instance_culling.hlsl:174
                 const Mat4 M = load_mat(p.objects[o].basicData.localToTranslatedWorld);
                 const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
@@ -453,22 +480,6 @@ __global__ __launch_bounds__(256) void hzb_cull_kernel(HzbCullParams p)
 
 // ---------------------------------------------------------------------------------- launchers --
 
-void launch_object_cull(ChordCtx* c)
-{
-    const uint32_t blocks = (c->objectCount + 255u) / 256u;
-    uint4* zeroBase = nullptr;
-    uint32_t zeroVec4 = 0;
-    if (c->zeroFrameStateInCull) {
-        zeroBase = reinterpret_cast<uint4*>(c->dFrameState);
-        zeroVec4 = (uint32_t)((c->frameStateZeroBytes + 15u) / 16u);
-        c->zeroFrameStateInCull = false;
-    }
-    hipLaunchKernelGGL(object_cull_kernel, dim3(blocks), dim3(256), 0, c->stream,
-                       c->dObjects, c->dObjStatic, c->dPrims, c->hView, c->viewDirty ? c->dView : (DView*)nullptr,
-                       c->dObjFrame, c->objectCount, zeroBase, zeroVec4);
-    c->viewDirty = false;
-}
-
 void launch_group_cull(ChordCtx* c, const CmdList& out)
 {
     GroupCullParams p;
@@ -476,7 +487,23 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     p.groups = c->dGroups; p.groupIndices = c->dGroupIndices; p.meshlets = c->dMeshlets; p.groupOwner = c->dGroupOwner;
     p.dview = c->dView; p.groupMask = c->dGroupMask; p.blockCounts = c->dBlockCounts; p.groupInstances = c->groupInstances;
     const uint32_t blocks = c->cullBlocks;
-    hipLaunchKernelGGL(group_cull_count_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+    uint4* zeroBase = nullptr;
+    uint32_t zeroVec4 = 0;
+    if (c->zeroFrameStateInCull) {
+        zeroBase = reinterpret_cast<uint4*>(c->dFrameState);
+        zeroVec4 = (uint32_t)((c->frameStateZeroBytes + 15u) / 16u);
+        c->zeroFrameStateInCull = false;
+    }
+    DView* publish = c->viewDirty ? c->dView : (DView*)nullptr;
+    if (blocks > 512u) {
+        hipLaunchKernelGGL(object_cull_kernel, dim3((c->objectCount + 255u) / 256u), dim3(256), 0, c->stream, c->dObjects, c->dObjStatic,
+                           c->dPrims, c->hView, publish, c->dObjFrame, c->objectCount, zeroBase, zeroVec4);
+        hipLaunchKernelGGL(group_cull_count_kernel, dim3(blocks), dim3(256), 0, c->stream, p, c->hView, (DView*)nullptr,
+                           (DObjFrame*)nullptr, (uint4*)nullptr, 0u);
+    } else {
+        hipLaunchKernelGGL(group_cull_count_kernel, dim3(blocks), dim3(256), 0, c->stream, p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4);
+    }
+    c->viewDirty = false;
     if (blocks > 512u) {
         hipLaunchKernelGGL(group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters);
         hipLaunchKernelGGL(group_cull_scatter_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
