@@ -520,3 +520,26 @@ def test_context_reuse_across_sizes_and_scenes(gpu):
         H.assert_vis_equal(r.read_visibility(), want1["vis"], w, h, "%s %dx%d frame 1" % (scene.name, w, h))
         assert r.stats()["overflow"] == 0
     r.close()
+
+
+@pytest.mark.parametrize("pos,front", [((-62.0, 0.25, 3.0), (1.0, -0.02, -0.04)), ((-30.0, 0.6, 0.5), (0.3, -0.9, 0.2)),
+                                       ((-55.0, 1.2, 7.5), (0.9, 0.1, -0.4))])
+def test_config3_4k_ground_level_views_match_oracle(gpu, pos, front):
+    """Config 3 at 4K from cameras a hand above the ground / against a wall: thousands of triangles cross the near and
+    guard planes (homogeneous clipper at scale), many span dozens of tiles (large list, 48-byte records, int64 /
+    fp64 edge functions).  Two frames each (no history, then two-pass HZB)."""
+    def build():
+        scene, cam = scenes.config3_street()
+        return scene, scenes.Camera(pos, front, cam.width, cam.height)
+    scene, cam, view, iv = H.setup_scene(build)
+    W, Hh = cam.width, cam.height
+    want0 = orc.frame(scene, view, iv, H.ALL_FLAGS)
+    want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want0["hzb_min"])
+    r = _renderer(gpu, scene, view, iv, W, Hh, H.ALL_FLAGS)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want0["vis"], W, Hh, "ground view frame 0")
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want1["vis"], W, Hh, "ground view frame 1")
+    st = r.stats()
+    assert st["overflow"] == 0 and st["triangleRecords"] > st["triangleRecordsCompact"]      # wide records exist
+    r.close()
