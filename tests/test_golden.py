@@ -86,3 +86,17 @@ def test_host_camera_matches_glm_fixture():
             assert (planes[:, :3] @ (f * d) + planes[:, 3] > 0).all()
         assert planes[4, :3] @ f > 0.999 and planes[5, :3] @ f < -0.999       # front / back planes
         assert abs(view["lodScale"][0] - c["height"] * 0.5 / np.tan(0.5 * c["fovy"])) < 1e-2
+
+
+def test_oracle_reproduces_the_committed_digests():
+    """tests/golden/oracle_digests.json (make_digests.py): the oracle and the scene generators have not drifted on
+    reduced instances of configs 2, 3, 5 and the small test scene -- the anchor of every GPU parity test."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_digests", os.path.join(os.path.dirname(__file__), "golden", "make_digests.py"))
+    md = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(md)
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_digests.json")))
+    assert sorted(want) == sorted(md.CASES)
+    for name in md.CASES:
+        assert md.digests(name) == want[name], name
