@@ -50,9 +50,10 @@ def build(force=False, verbose=True):
             digest = hashlib.sha1(fh.read()).hexdigest() + hd
         old = open(stamp).read() if os.path.exists(stamp) else ""
         if force or old != digest or not os.path.exists(obj):
-            cmd = [HIPCC] + COMMON
+            # hipcc compiles .cpp as HIP too: name the one target for every file (no default-arch code objects)
+            cmd = [HIPCC] + COMMON + DEVICE
             if src.endswith(".hip"):
-                cmd += DEVICE + ["-x", "hip"]
+                cmd += ["-x", "hip"]
             cmd += ["-c", path, "-o", obj]
             if verbose:
                 print("[chord_amd.build]", " ".join(cmd), flush=True)
