@@ -3,7 +3,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'object_cull' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'group_cull_count' in r['Kernel_Name']]
 i0, i1 = idx[-3], idx[-2]
 t0 = int(rows[i0]['Start_Timestamp']); prev = None; tot = 0
 for r in rows[i0 - 2:i1 - 2]:
