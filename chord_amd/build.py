@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-OUT_DIR = os.path.join(HERE, "lib")
-BUILD_DIR = os.path.join(HERE, "lib", "obj")
+OUT_DIR = os.path.join(HERE, "_build")
+BUILD_DIR = os.path.join(HERE, "_build", "obj")
 LIB = os.path.join(OUT_DIR, "libchordvis.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

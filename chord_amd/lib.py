@@ -11,7 +11,7 @@ import numpy as np
 from . import records as R
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libchordvis.so")
+LIB_PATH = os.environ.get("CHORDVIS_LIB") or os.path.join(_HERE, "_build", "libchordvis.so")
 
 OK, E_INVALID, E_HIP, E_NO_DEVICE, E_CAPACITY = 0, -1, -2, -3, -4
 
