@@ -7,10 +7,14 @@ scene already resident in HBM.  Consecutive steps alternate between two camera p
 apart so that every frame culls against the HZB of a *different* previous frame (BASELINE config 3:
 "two frames, camera advanced 0.5 m").
 
-  N = 1   workload "street_4k_hzb"      BASELINE config 3 (Bistro-class, 3840x2160, two-pass HZB)
-  N > 1   workload "street_x64_4k_hzb"  BASELINE config 4 (config 3 x 64 instances), rows sharded
-          in interleaved stripes across the ranks, HZB mip 0 + visibility reassembled with two
-          RCCL all-gathers per frame (torch.distributed, backend nccl == RCCL)
+  N = 1   workload "street_4k_hzb"  BASELINE config 3 (Bistro-class, 3840x2160, two-pass HZB)
+  N > 1   workload "subpixel_1g"    BASELINE config 5 (1.07 G sub-pixel triangles per frame), rows sharded in
+          interleaved stripes across the ranks, HZB mip 0 (two-pass workloads) + visibility reassembled with RCCL
+          all-gathers issued by the library itself (chordvis_comm_init_rank: --exchange lib) or by torch.distributed
+          on the context's stream (--exchange torch); every N > 1 line carries the same workload rendered unsharded on
+          rank 0's GPU (single_gpu_same_workload) and speedup_vs_single.  --workload overrides either default, so the
+          N = 1 point of any curve can be re-run on the N > 1 workload.
+  `python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one process per GPU).
 
 value = triangles of the clusters submitted to the rasterizer per frame (post-cull, the unit of
 SURVEY §8d) x steps / wall time of the timed region, max over ranks.  Prints ONE JSON line.
@@ -47,6 +51,8 @@ def build_workload(name):
         return scenes.config5_subpixel(3840, 2160)
     if name == "subpixel_64m":           # the same at 1/16 size (64 Ki patches x 8): fits the default work-list limits
         return scenes.config5_subpixel(3840, 2160, prims=64)
+    if name == "street_720p_hzb":        # config 3 at 1280x720: the small two-pass workload of the N > 1 protocol tests
+        return scenes.config3_street(1280, 720)
     if name == "atrium_1080p":
         return scenes.config2_atrium(1920, 1080)
     raise SystemExit("unknown workload %r" % name)
@@ -57,19 +63,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="auto")
+    ap.add_argument("--workload", default="auto", help="street_4k_hzb | street_x64_4k_hzb | street_x16_4k_hzb | subpixel_1g | subpixel_64m | atrium_1080p")
+    ap.add_argument("--exchange", default="auto", choices=("auto", "lib", "torch"),
+                    help="N > 1: who issues the all-gathers -- the library (RCCL communicator on the context) or torch.distributed")
     ap.add_argument("--cpu-baseline-frames", type=int, default=48, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
     ap.add_argument("--no-hzb", action="store_true", help="disable HZB occlusion culling (frustum+cone only)")
     ap.add_argument("--debug-flags", type=int, default=0, help="raster ablation switches (measurement only; voids parity)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_spawn(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run --nproc-per-node %d bench.py ..." % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     # test hooks (a 1-GPU box cannot host two RCCL ranks): CHORDVIS_BENCH_BACKEND=gloo + CHORDVIS_BENCH_ONE_DEVICE=1
     # run all ranks on device 0 with host-staged collectives, to exercise the N>1 control flow
@@ -84,6 +91,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+    # Every kernel of the path AND every collective of the frame is enqueued on ONE explicit stream.  (PyTorch's
+    # default stream has handle 0; handed to chordvis_create that reads as "no stream given" and the context would run
+    # on a private non-blocking stream that nothing orders against the collectives.)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
 
     from chord_amd import lib as L, records as R
     from chord_amd.renderer import VisibilityRenderer
@@ -114,7 +126,7 @@ def main():
     d_obj = [torch.from_numpy(o.view(np.uint8).reshape(-1)).to(dev) for o in (obj_a, obj_b)]
     views = [(view_a, iv_a), (view_b, iv_b)]
 
-    stream = torch.cuda.current_stream(dev)
+    assert stream.cuda_stream != 0
     r = VisibilityRenderer(local_rank, stream.cuda_stream)
     if wl == "subpixel_1g":              # ~1 G records of 48 B and as many bin entries in one pass (a rank holds 1/N of them)
         share = max(1, world // 2) if world > 1 else 1
@@ -130,17 +142,57 @@ def main():
     chunk = r.visibility_chunk_words()
     vis_mine = vis_t[rank * chunk:(rank + 1) * chunk]
 
+    # ---- who issues the two all-gathers of a sharded frame -------------------------------------------------------
+    #   lib    the library (RCCL communicator attached to the context: ONE call per frame, like the reference's host)
+    #   torch  torch.distributed on the context's stream between chordvis_frame_phase_a/b/c
+    exchange = "none"
+    comm = None
+    if world > 1:
+        want = args.exchange if backend == "nccl" else "torch"
+        if want in ("auto", "lib"):
+            ok = 1
+            try:
+                from chord_amd.renderer import comm_unique_id
+                uid = [comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                r.comm_init_rank(world, rank, uid[0])
+                comm = r.comm_info()
+            except Exception as e:                       # noqa: BLE001  (no librccl / init failure: every rank falls back together)
+                ok = 0
+                if want == "lib":
+                    raise
+                print("[bench] rank %d: library-owned RCCL exchange unavailable (%s); using torch.distributed" % (rank, e), file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                exchange = "lib"
+            else:
+                if ok:
+                    r.comm_destroy()
+                exchange = "torch"
+        else:
+            exchange = "torch"
+
+    def all_gather(full, mine):
+        if backend == "nccl":
+            dist.all_gather_into_tensor(full, mine)      # ordered on the current stream (= the context's)
+        else:                                            # test hook (gloo has no device all-gather): staged through the host
+            torch.cuda.current_stream(dev).synchronize()
+            parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
+            dist.all_gather(parts, mine.cpu())
+            full.copy_(torch.cat(parts).to(dev))
+
     def frame(i):
         v, iv = views[i & 1]
         r.bind_objects(d_obj[i & 1].data_ptr(), len(scene.objects))
         r.set_view(v, iv, flags)
-        if world == 1:
+        if world == 1 or exchange == "lib":
             r.render_frame()
         else:
             r.frame_phase_a()
             ex.all_gather_hzb()
             r.frame_phase_b()
-            dist.all_gather_into_tensor(vis_t, vis_mine)
+            all_gather(vis_t, vis_mine)
             r.frame_phase_c()
 
     class Exchange:
@@ -152,7 +204,8 @@ def main():
             self.mine = self.full[rank * chunk_h * 2:(rank + 1) * chunk_h * 2]
 
         def all_gather_hzb(self):
-            dist.all_gather_into_tensor(self.full, self.mine)
+            if not args.no_hzb:                          # (a frame without stage 1 has nothing to exchange)
+                all_gather(self.full, self.mine)
 
     ex = Exchange() if world > 1 else None
     if args.debug_flags:
@@ -303,7 +356,7 @@ def main():
         line = {
             "metric": "Gtri/s into 4K 64-bit visbuffer", "value": round(value, 4), "unit": "Gtri/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32+u64", "data": "synthetic",
             "config": {"workload": wl, **({"ABLATION_debug_flags": args.debug_flags} if args.debug_flags else {}), "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(),
                        "objects": len(scene.objects), "hzb": not args.no_hzb,
@@ -319,12 +372,41 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if world > 1:
+            line["exchange"] = exchange
+            line["rccl_ranks"] = comm["ranks"] if (comm and exchange == "lib") else (dist.get_world_size() if backend == "nccl" else 0)
+            line["rccl_version"] = (comm["nccl_version_code"] if comm else (_torch_nccl_version() if backend == "nccl" else None))
+            line["collective_backend"] = backend
         if single_ref is not None:
             line["single_gpu_same_workload"] = single_ref
+            line["speedup_vs_single"] = round(single_ref["ms_per_step"] / ms_per_step, 4)
         print(json.dumps(line), flush=True)
     r.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def _torch_nccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return int(v[0]) * 10000 + int(v[1]) * 100 + int(v[2]) if isinstance(v, tuple) else int(v)
+    except Exception:                                    # noqa: BLE001
+        return None
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` without a launcher: one process per GPU under torch.distributed.run, same flags."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def scene_with(scene, objects):
@@ -347,4 +429,4 @@ def _tensor_from_ptr(ptr, n, dtype, dev):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

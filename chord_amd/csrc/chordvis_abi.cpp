@@ -192,8 +192,9 @@ int do_raster(ChordCtx* c, const CmdList& in)
 {
     // renderMesh (mesh_raster.cpp:208-254): the four (alphaMode x twoSided) pipeline buckets and
     // their filter passes collapse into one launch; the kernel reads bTwoSided per cluster.
-    launch_raster(c, in, c->pendingClear);
+    const hipError_t e = launch_raster(c, in, c->pendingClear);
     c->pendingClear = false;
+    if (e != hipSuccess) return fail(c, CHORDVIS_E_HIP, "launch_raster", e);
     CHORD_HIP(c, hipGetLastError());
     return CHORDVIS_OK;
 }
@@ -251,6 +252,7 @@ int chordvis_destroy(ChordCtx* c)
     if (!c) return CHORDVIS_E_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)chordvis_comm_destroy(c);
     dfree(c->dPrims); dfree(c->dGroups); dfree(c->dMeshlets); dfree(c->dGroupIndices); dfree(c->dMeshletData);
     dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
@@ -306,8 +308,13 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
             DMeshlet& d = meshlets[mB[a] + i];
             std::memcpy(&d, &m, sizeof(ChordMeshlet));
             const uint32_t V = m.vertexTriangleCount & 0xFFu, T = (m.vertexTriangleCount >> 8) & 0xFFu;
-            if (T > CHORD_MESHLET_MAX_TRIANGLES || m.dataOffset + V + T > as.meshletDataCount)
+            if (T > CHORD_MESHLET_MAX_TRIANGLES || (uint64_t)m.dataOffset + V + T > as.meshletDataCount)
                 return fail(c, CHORDVIS_E_INVALID, "upload_scene: meshlet exceeds 255 vertices / 128 triangles or its data stream");
+            for (uint32_t t = 0; t < T; t++) {                      // local vertex indices of every triangle word
+                const uint32_t w = as.meshletData[m.dataOffset + V + t];
+                if ((w & 0xFFu) >= V || ((w >> 8) & 0xFFu) >= V || ((w >> 16) & 0xFFu) >= V)
+                    return fail(c, CHORDVIS_E_INVALID, "upload_scene: triangle references a vertex beyond the meshlet's vertex count");
+            }
             d.dataOffset = m.dataOffset + dB[a];
             d.vertexBase = 0xFFFFFFFFu;
         }
@@ -326,6 +333,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     // primitives
     c->hPrims.assign(s->primitiveCount, DPrim{});
     std::vector<uint32_t> primMeshlets(s->primitiveCount, 0);
+    std::vector<uint64_t> primTriangles(s->primitiveCount, 0);
     for (uint32_t pi = 0; pi < s->primitiveCount; pi++) {
         const ChordPrimitive& p = s->primitives[pi];
         if (p.primitiveDatasBufferId >= s->assetCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: primitiveDatasBufferId out of range");
@@ -346,15 +354,24 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
                 if (ii >= as.meshletGroupIndexCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: group index out of bounds");
                 const uint32_t mi = p.meshletOffset + as.meshletGroupIndices[ii];
                 if (mi >= as.meshletCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: meshlet index out of bounds");
-                meshlets[mB[a] + mi].vertexBase = vB[a] + p.vertexOffset;
+                DMeshlet& dm = meshlets[mB[a] + mi];
+                if (dm.vertexBase == 0xFFFFFFFFu) {                  // first reference: check the vertex ids against the asset
+                    const ChordMeshlet& sm = as.meshlets[mi];
+                    const uint32_t V = sm.vertexTriangleCount & 0xFFu;
+                    for (uint32_t v = 0; v < V; v++)
+                        if ((uint64_t)p.vertexOffset + as.meshletData[sm.dataOffset + v] >= as.vertexCount)
+                            return fail(c, CHORDVIS_E_INVALID, "upload_scene: meshlet vertex id out of the asset's position stream");
+                }
+                dm.vertexBase = vB[a] + p.vertexOffset;
                 primMeshlets[pi]++;
+                primTriangles[pi] += (as.meshlets[mi].vertexTriangleCount >> 8) & 0xFFu;
             }
         }
     }
 
     // objects
     c->hObjStatic.assign(s->objectCount, DObjStatic{});
-    uint64_t groupInst = 0, cmdCap = 0;
+    uint64_t groupInst = 0, cmdCap = 0, instTriangles = 0;
     for (uint32_t o = 0; o < s->objectCount; o++) {
         const ChordObject& ob = s->objects[o];
         if (ob.GLTFPrimitiveDetail >= s->primitiveCount || ob.GLTFMaterialData >= s->materialCount)
@@ -366,6 +383,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         d.groupBase = (uint32_t)groupInst;
         groupInst += c->hPrims[d.prim].groupCount;
         cmdCap += primMeshlets[d.prim];
+        instTriangles += primTriangles[d.prim];
     }
     if (cmdCap >= CHORD_MAX_INSTANCE_ID || groupInst > 0x7FFFFFFFull)
         return fail(c, CHORDVIS_E_CAPACITY, "upload_scene: more than 2^24-2 cluster instances do not fit the 24-bit visibility id (base.h:412)");
@@ -399,11 +417,16 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         c->lists[i].count = c->dCounts + i;
         c->lists[i].capacity = c->cmdCapacity;
     }
-    // raster work lists (fixed budgets sized for 288 GB of HBM; overflow is detected and reported by chordvis_stats)
-    // records: nearly all triangles take the 32-byte form; the 48-byte list (triangles wider than 64 px, clipped
-    // pieces) gets a quarter of the limit.  Defaults: 64 M x 32 B + 16 M x 48 B = 2.8 GB
-    c->triCapC = (uint32_t)c->limitRecords;
-    c->triCap = (uint32_t)std::max<uint64_t>(c->limitRecords / 4, 1u << 20) & ~(CHORD_LIST_SHARDS - 1u);
+    // raster work lists, sized from the scene like the reference sizes its command buffers from lod0MeshletCount
+    // (instance_culling.cpp:141): a triangle instance is set up at most once per frame (stage 0 or stage 1), so the
+    // records of a frame never exceed the triangles of every meshlet instance (all LODs) plus the pieces the clipper
+    // adds; chordvis_set_limits caps (or, for scenes beyond the default cap, raises) the budget.  Exhaustion is
+    // detected on the device and reported by chordvis_stats.  Nearly all triangles take the 32-byte form; the 48-byte
+    // list (triangles wider than 64 px, clipped pieces) gets the same bound up to a quarter of the limit.
+    // (x2 + 256 Ki: the list is cut into 64 shards that fill unevenly, and a clipped triangle becomes several records)
+    const uint64_t need = (2 * instTriangles + (256u << 10) + CHORD_LIST_SHARDS - 1) & ~(uint64_t)(CHORD_LIST_SHARDS - 1);
+    c->triCapC = (uint32_t)std::min<uint64_t>(c->limitRecords, need);
+    c->triCap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->limitRecords / 4, 1u << 20), need) & ~(CHORD_LIST_SHARDS - 1u);
     c->clipTriCap = 1u << 20;
     if ((rc = dalloc(c, &c->dTris, (size_t)c->triCap))) return rc;
     if ((rc = dalloc(c, &c->dTrisC, (size_t)c->triCapC))) return rc;
@@ -463,7 +486,10 @@ int chordvis_set_limits(ChordCtx* c, const ChordLimits* limits)
             return fail(c, CHORDVIS_E_INVALID, "set_limits: maxTriangleRecords out of range (record indices are 32-bit)");
         c->limitRecords = limits->maxTriangleRecords & ~(uint64_t)(CHORD_LIST_SHARDS - 1);
     }
-    if (limits->binPoolChunks) c->limitPoolChunks = limits->binPoolChunks;
+    if (limits->binPoolChunks) {
+        if (limits->binPoolChunks > (16u << 20)) return fail(c, CHORDVIS_E_INVALID, "set_limits: at most 16 Mi pool chunks per pass (64 GB)");
+        c->limitPoolChunks = limits->binPoolChunks;
+    }
     if (limits->binMaxChunksPerTile) {
         if (limits->binMaxChunksPerTile > CHORD_BIN_MAX_CHUNKS_LIMIT) return fail(c, CHORDVIS_E_INVALID, "set_limits: at most 3072 overflow chunks per tile");
         c->binMaxChunks = limits->binMaxChunksPerTile;
@@ -618,11 +644,12 @@ int chordvis_reset_history(ChordCtx* c)
     return CHORDVIS_OK;
 }
 
-int chordvis_render_frame(ChordCtx* c)
+static int render_frame_impl(ChordCtx* c)
 {
     int rc = ready(c, "render_frame");
     if (rc) return rc;
-    if (c->shard.ranks > 1) return fail(c, CHORDVIS_E_INVALID, "render_frame: sharded contexts use frame_phase_a/b/c");
+    if (c->comm) return comm_render_frame(c);            // one process per GPU: the library runs the two all-gathers (RCCL)
+    if (c->shard.ranks > 1) return fail(c, CHORDVIS_E_INVALID, "render_frame: a sharded context needs a communicator (chordvis_comm_init_rank), a ChordGroup, or the host drives frame_phase_a/b/c");
     begin_frame_stamps(c);
     if ((rc = begin_frame_clear(c))) return rc;                                       // renderer.cpp:315
     record(c, S_CLEAR);
@@ -661,7 +688,7 @@ int chordvis_render_frame(ChordCtx* c)
 }
 
 // Sharded frame, phase a: everything up to the stage-0 raster + own-stripe HZB mip 0.
-int chordvis_frame_phase_a(ChordCtx* c)
+static int frame_phase_a_impl(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_a");
     if (rc) return rc;
@@ -685,7 +712,7 @@ int chordvis_frame_phase_a(ChordCtx* c)
 }
 
 // phase b: [exchange buffer all-gathered by the caller] -> HZB chain -> stage 1.
-int chordvis_frame_phase_b(ChordCtx* c)
+static int frame_phase_b_impl(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_b");
     if (rc) return rc;
@@ -702,7 +729,7 @@ int chordvis_frame_phase_b(ChordCtx* c)
 }
 
 // phase c: [visibility buffer all-gathered in place by the caller] -> row-major copy + final HZB.
-int chordvis_frame_phase_c(ChordCtx* c)
+static int frame_phase_c_impl(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_c");
     if (rc) return rc;
@@ -715,6 +742,21 @@ int chordvis_frame_phase_c(ChordCtx* c)
     c->inFrame = false;
     return CHORDVIS_OK;
 }
+
+// A failed frame must not leave frame-scoped state behind (the stand-alone passes that may follow would skip their
+// count resets, a later frame would inherit a fused-HZB request).
+static int end_failed_frame(ChordCtx* c, int rc)
+{
+    if (rc && c) {
+        if (c->zeroFrameStateInCull) { (void)hipMemsetAsync(c->dFrameState, 0, c->frameStateZeroBytes, c->stream); c->zeroFrameStateInCull = false; }
+        c->inFrame = false; c->fuseHzb = false; c->pendingClear = false; c->shouldStage1 = false;
+    }
+    return rc;
+}
+int chordvis_render_frame(ChordCtx* c) { return end_failed_frame(c, render_frame_impl(c)); }
+int chordvis_frame_phase_a(ChordCtx* c) { return end_failed_frame(c, frame_phase_a_impl(c)); }
+int chordvis_frame_phase_b(ChordCtx* c) { return end_failed_frame(c, frame_phase_b_impl(c)); }
+int chordvis_frame_phase_c(ChordCtx* c) { return end_failed_frame(c, frame_phase_c_impl(c)); }
 
 int chordvis_last_frame_cmds(ChordCtx* c, ChordCountAndCmd* out)
 {

@@ -212,6 +212,7 @@ struct ChordCtx {
     // gbuffer
     uint32_t width = 0, height = 0;
     chord::ShardInfo shard{64, 1, 0, 0};
+    void* comm = nullptr;             // ncclComm_t of a one-process-per-GPU host (chordvis_comm_init_rank), or null
     uint64_t* dVis = nullptr;         // in use (owned or caller's)
     uint64_t* dVisOwned = nullptr;
     uint64_t* dVisResolved = nullptr; // row-major copy when ranks > 1
@@ -290,7 +291,7 @@ int fail(ChordCtx* ctx, int code, const char* what, hipError_t e = hipSuccess);
 void launch_group_cull(ChordCtx* c, const CmdList& out);
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
                      const CmdList* outRejected);
-void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles);
+hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles);   // first failing HIP call, or hipSuccess
 void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange, bool fromExchange);
 void launch_hzb_mip0_exchange(ChordCtx* c);
 void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange);   // mips 6.. + range from per-tile partials
@@ -299,5 +300,6 @@ void launch_stripe_filter(ChordCtx* c, const CmdList& in, const CmdList& out);
 void launch_visibility_mark(ChordCtx* c, const unsigned long long* vis, const ChordDrawCmd* cmds, const uint32_t* cmdCount, uint32_t* marker);
 void launch_shading_tiles(ChordCtx* c, const uint32_t* marker, uint32_t shadingType, uint32_t* tiles, uint32_t* count, uint32_t* args);
 void stamp(ChordCtx* c, int tag);               // no-op when timers are off
+int comm_render_frame(ChordCtx* c);             // multi_gpu.cpp: phase a -> ncclAllGather -> phase b -> ncclAllGather -> phase c
 
 } // namespace chord

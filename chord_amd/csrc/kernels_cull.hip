@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
         const uint32_t first = blockIdx.x * 256u;
         if (first < p.groupInstances) {
             const uint32_t oFirst = p.groupOwner[first], oLast = p.groupOwner[min(first + 255u, p.groupInstances - 1u)];
-            if (threadIdx.x <= oLast - oFirst) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, oFirst + threadIdx.x);
+            // (256 group instances may span more than 256 objects when primitives without groups sit in between)
+            for (uint32_t k = threadIdx.x; k <= oLast - oFirst; k += 256u) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, oFirst + k);
         }
     }
     __syncthreads();                                       // the object records of this block are written (and visible to it)

@@ -247,23 +247,34 @@ __device__ __forceinline__ BinElect wave_bin_elect(bool has, uint32_t tile, uint
 // Entry `slot` of a tile's bin: the first binCap entries have a fixed home; beyond that, entries live in
 // 1024-entry chunks from a pool.  The lane that drew the first slot of a chunk allocates it and publishes
 // `serial << 32 | id` in the tile's chunk table; lanes that drew other slots of that chunk wait for the entry
-// to carry this pass's serial.  Every allocation of a wave is issued before any of its lanes starts waiting
-// (two sequential phases, not an if/else), and an allocator never waits, so the wait always ends; it is
-// bounded anyway (overflow bit 2) so that a logic error cannot hang the device.
+// to carry this pass's serial.  Every allocation for the slots a wave has drawn is issued before any of its lanes
+// starts waiting (bin_alloc for all of them, then bin_put), and an allocator never waits, so the wait always ends;
+// it is bounded anyway (overflow bit 2) so that a logic error cannot hang the device.
 __device__ __forceinline__ uint32_t bin_capacity(const RasterParams& p) { return p.binCap + p.binMaxChunks * CHORD_BIN_CHUNK; }
 
-__device__ __forceinline__ void bin_store(const RasterParams& p, uint32_t tile, uint32_t slot, uint32_t gi)
+// step 1 of a bin write: the lane that drew the first slot of an overflow chunk allocates it and publishes it.  Never waits.
+__device__ __forceinline__ void bin_alloc(const RasterParams& p, uint32_t tile, uint32_t slot)
+{
+    if (slot < p.binCap) return;
+    const uint32_t o = slot - p.binCap, j = o >> CHORD_BIN_CHUNK_SHIFT;
+    if (j >= p.binMaxChunks || (o & (CHORD_BIN_CHUNK - 1u)) != 0u) return;
+    uint32_t id = atomicAdd(p.binPoolCount, 1u);
+    if (id >= p.binPoolChunks) { id = CHORD_BIN_CHUNK_INVALID; atomicOr(&p.counters->overflow, 1u); }
+    __hip_atomic_store(p.binChunkTab + (size_t)tile * p.binMaxChunks + j, ((unsigned long long)p.binStamp << 32) | id,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// step 2: store the entry; a slot inside an overflow chunk waits for the chunk's allocator (the drawer of the chunk's
+// first slot, whose atomicAdd preceded this lane's: it has passed every wait of its own earlier writes and reaches its
+// bin_alloc without waiting -- PROVIDED every caller runs bin_alloc for ALL the slots it has drawn before its first
+// bin_put; wave_bin_commit draws eight slots per lane at once and therefore allocates for all eight first).
+__device__ __forceinline__ void bin_put(const RasterParams& p, uint32_t tile, uint32_t slot, uint32_t gi)
 {
     if (slot < p.binCap) { p.tileBins[(size_t)tile * p.binCap + slot] = gi; return; }
     const uint32_t o = slot - p.binCap, j = o >> CHORD_BIN_CHUNK_SHIFT;
     if (j >= p.binMaxChunks) { atomicOr(&p.counters->overflow, 1u); return; }
-    unsigned long long* ent = p.binChunkTab + (size_t)tile * p.binMaxChunks + j;
+    const unsigned long long* ent = p.binChunkTab + (size_t)tile * p.binMaxChunks + j;
     const unsigned long long stamp = (unsigned long long)p.binStamp << 32;
-    if ((o & (CHORD_BIN_CHUNK - 1u)) == 0u) {
-        uint32_t id = atomicAdd(p.binPoolCount, 1u);
-        if (id >= p.binPoolChunks) { id = CHORD_BIN_CHUNK_INVALID; atomicOr(&p.counters->overflow, 1u); }
-        __hip_atomic_store(ent, stamp | id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     unsigned long long e = 0;
     uint32_t spins = 0;
     for (;;) {
@@ -274,6 +285,13 @@ __device__ __forceinline__ void bin_store(const RasterParams& p, uint32_t tile, 
     }
     const uint32_t id = (uint32_t)e;
     if (id != CHORD_BIN_CHUNK_INVALID) p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))] = gi;
+}
+
+// one slot drawn, written at once (the looped binners: a slot is drawn, allocated for and stored within one iteration)
+__device__ __forceinline__ void bin_store(const RasterParams& p, uint32_t tile, uint32_t slot, uint32_t gi)
+{
+    bin_alloc(p, tile, slot);
+    bin_put(p, tile, slot, gi);
 }
 
 // Bin reservations of two records per lane (triangles lane and lane + 64 of the meshlet) whose clamped bboxes touch
@@ -325,10 +343,21 @@ __device__ __forceinline__ void wave_bin_commit(const RasterParams& p, BinTicket
 {
     k.slotA[0] = __shfl(k.slotA[0], k.eA.leader, 64) + k.eA.rank;
     k.slotB[0] = __shfl(k.slotB[0], k.eB.leader, 64) + k.eB.rank;
+    // all eight slots of a lane were drawn together (wave_bin_issue): every chunk allocation they owe comes before
+    // the first wait -- a wait ahead of a later allocation could close a cycle between two waves (each waiting for a
+    // chunk the other allocates in a later step), which costs 2^20 spins and drops entries.  A record that did not fit
+    // its list still allocates (its slots are drawn; other lanes may be waiting for the chunk).
+    if (k.has) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (k.has & (1u << r)) bin_alloc(p, k.tileA[r], k.slotA[r]);
+            if (k.has & (16u << r)) bin_alloc(p, k.tileB[r], k.slotB[r]);
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        if (okA && (k.has & (1u << r))) bin_store(p, k.tileA[r], k.slotA[r], giA);
-        if (okB && (k.has & (16u << r))) bin_store(p, k.tileB[r], k.slotB[r], giB);
+        if (okA && (k.has & (1u << r))) bin_put(p, k.tileA[r], k.slotA[r], giA);
+        if (okB && (k.has & (16u << r))) bin_put(p, k.tileB[r], k.slotB[r], giB);
     }
 }
 
@@ -1385,8 +1414,9 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
 }
 
 // ---- launcher ---------------------------------------------------------------------------------
-void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
+hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
 {
+#define LR_HIP(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
     RasterParams p;
     p.hzbFused = 0; p.hzbMinA = nullptr; p.hzbMinB = nullptr; p.hzbMaxB = nullptr; p.tileRange = c->dTileRange;
     p.hzbDesc = c->hzb[0].desc;
@@ -1396,12 +1426,12 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         p.hzbMinB = c->hzb[c->fuseHzbSlot].minTexels; p.hzbMaxB = c->hzb[c->fuseHzbSlot].maxTexels;
     }
     p.count = in.count; p.cmds = in.cmds;
-    if (c->shard.ranks > 1 && !c->dRankCmds) (void)hipMalloc((void**)&c->dRankCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity);   // first sharded pass
+    if (c->shard.ranks > 1 && !c->dRankCmds) LR_HIP(hipMalloc((void**)&c->dRankCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity));   // first sharded pass
     if (c->shard.ranks > 1 && c->dRankCmds) {
         // sharded frame: only the clusters that touch this rank's pixel rows reach the setup kernel
         CmdList mine;
         mine.count = c->dCounts + 4 + (c->rasterCalls & 1u); mine.cmds = c->dRankCmds; mine.capacity = in.capacity;
-        if (!c->inFrame || c->rasterCalls >= 2) (void)hipMemsetAsync(mine.count, 0, sizeof(uint32_t), c->stream);
+        if (!c->inFrame || c->rasterCalls >= 2) LR_HIP(hipMemsetAsync(mine.count, 0, sizeof(uint32_t), c->stream));
         launch_stripe_filter(c, in, mine);
         p.count = mine.count; p.cmds = mine.cmds;
     }
@@ -1433,12 +1463,12 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // A frame zeroes every count once (begin_frame_clear); outside a frame, or from the third raster
     // call of a frame on, the pass slot is recycled here.
     if (!c->inFrame || c->rasterCalls >= 2) {
-        (void)hipMemsetAsync(p.tileCount, 0, sizeof(uint32_t) * TC_STRIDE * tiles, c->stream);
-        (void)hipMemsetAsync(&c->dCounters->clipTriCount[pass], 0, sizeof(uint32_t), c->stream);
-        (void)hipMemsetAsync(c->dCounters->largeCount[pass], 0, sizeof(c->dCounters->largeCount[pass]), c->stream);
-        (void)hipMemsetAsync(&c->dCounters->binPoolCount[pass], 0, sizeof(uint32_t), c->stream);
-        if (!c->inFrame) { (void)hipMemsetAsync(c->dCounters->triCount, 0, sizeof(c->dCounters->triCount), c->stream);
-                           (void)hipMemsetAsync(c->dCounters->triCountC, 0, sizeof(c->dCounters->triCountC), c->stream); }
+        LR_HIP(hipMemsetAsync(p.tileCount, 0, sizeof(uint32_t) * TC_STRIDE * tiles, c->stream));
+        LR_HIP(hipMemsetAsync(&c->dCounters->clipTriCount[pass], 0, sizeof(uint32_t), c->stream));
+        LR_HIP(hipMemsetAsync(c->dCounters->largeCount[pass], 0, sizeof(c->dCounters->largeCount[pass]), c->stream));
+        LR_HIP(hipMemsetAsync(&c->dCounters->binPoolCount[pass], 0, sizeof(uint32_t), c->stream));
+        if (!c->inFrame) { LR_HIP(hipMemsetAsync(c->dCounters->triCount, 0, sizeof(c->dCounters->triCount), c->stream));
+                           LR_HIP(hipMemsetAsync(c->dCounters->triCountC, 0, sizeof(c->dCounters->triCountC), c->stream)); }
     }
 
     uint32_t blocks = (in.capacity + 3u) / 4u;
@@ -1459,6 +1489,8 @@ void launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     else    hipLaunchKernelGGL(raster_tile_kernel<false>, dim3(tileBlocks), dim3(TB), 0, c->stream, p);
     stamp(c, S_R_CHUNK);
     c->rasterCalls++;
+    return hipSuccess;
+#undef LR_HIP
 }
 
 } // namespace chord

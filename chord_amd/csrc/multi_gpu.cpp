@@ -1,0 +1,434 @@
+// Multi-GPU entry points of the C ABI: the frame sharded by interleaved row stripes, the two
+// exchanges of DESIGN.md 6 (own-stripe HZB mip 0 mid-frame, own-stripe visibility words at the end) issued by the
+// library itself, so that a C++ host calls ONE function per frame like DeferredRenderer::render does
+// (renderer.cpp:319-345).  The reference is single-device (graphics.cpp:524-548); nothing here has a counterpart in it.
+//
+// Two forms:
+//   ChordGroup            one process, n devices, one host thread per device.  The exchange is a DIRECT all-gather: every
+//                         rank pushes its chunk to each peer with its own hipMemcpyPeerAsync on a (source, destination)
+//                         stream -- n-1 concurrent copies per rank, one per xGMI link of the fully connected node; a
+//                         ring would serialise n-1 hops on one link.  Device ordinals may repeat, which is
+//                         how the protocol (events, ordering, buffer reuse) is exercised on a one-GPU box.
+//   chordvis_comm_*       one process per GPU (torch.distributed / MPI hosts): an RCCL communicator attached to a sharded
+//                         context; chordvis_render_frame then runs phase a -> ncclAllGather -> phase b -> ncclAllGather
+//                         -> phase c on the context's stream.  librccl is resolved at run time (dlopen), preferring the
+//                         copy already loaded in the process: a PyTorch-ROCm wheel bundles its own RCCL next to its own
+//                         HIP runtime, and a second HIP runtime in one process cannot open the device.
+
+#include "device_layer.h"
+
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+using namespace chord;
+
+// ------------------------------------------------------------------------------------------ RCCL, resolved at run time
+namespace {
+
+struct NcclUniqueId { char internal[CHORDVIS_UNIQUE_ID_BYTES]; };
+typedef struct ncclComm* NcclComm;
+enum { kNcclSuccess = 0 };
+enum { kNcclUint8 = 1, kNcclUint64 = 5 };                       // ncclDataType_t (rccl.h): ncclUint8 = 1, ncclUint64 = 5
+
+struct Rccl {
+    void* handle = nullptr;
+    std::string origin;
+    int (*GetVersion)(int*) = nullptr;
+    int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+    int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+std::mutex gRcclMutex;
+Rccl gRccl;
+std::string gRcclError;
+
+const Rccl* rccl()
+{
+    std::lock_guard<std::mutex> lk(gRcclMutex);
+    if (gRccl.handle) return &gRccl;
+    // a copy already mapped into the process wins (same HIP runtime as the host's); then the loader's search path
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    void* h = nullptr;
+    std::string origin;
+    if (const char* forced = getenv("CHORDVIS_RCCL")) { h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL); origin = forced; }
+    for (int pass = 0; pass < 2 && !h; pass++)
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+            if (h) { origin = std::string(n) + (pass == 0 ? " (already loaded)" : ""); break; }
+        }
+    if (!h) { gRcclError = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return nullptr; }
+    Rccl r;
+    r.handle = h; r.origin = origin;
+#define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name))
+    SYM(GetVersion, "ncclGetVersion"); SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy"); SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    if (!r.GetVersion || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) {
+        gRcclError = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather";
+        return nullptr;
+    }
+    gRccl = r;
+    return &gRccl;
+}
+
+int nccl_fail(ChordCtx* c, const Rccl* r, const char* what, int code)
+{
+    char buf[256];
+    std::snprintf(buf, sizeof(buf), "%s: %s (%d)", what, r && r->GetErrorString ? r->GetErrorString(code) : "RCCL error", code);
+    return fail(c, CHORDVIS_E_COMM, buf);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------- one process per GPU: RCCL comm
+extern "C" {
+
+uint32_t chordvis_pick_stripe_rows(uint32_t height, uint32_t ranks)
+{
+    // even stripe height in [32, 96] with the least padding of ceil(H / S) to a multiple of `ranks`, ties towards 64
+    if (ranks == 0) ranks = 1;
+    uint32_t best = 64; uint64_t bestKey = ~0ull;
+    for (uint32_t s = 32; s <= 96; s += 2) {
+        const uint32_t stripes = (height + s - 1) / s, per = (stripes + ranks - 1) / ranks;
+        const uint64_t pad = (uint64_t)per * ranks * s - height;
+        const uint64_t key = (pad << 8) | (uint64_t)(s > 64 ? s - 64 : 64 - s);
+        if (key < bestKey) { bestKey = key; best = s; }
+    }
+    return best;
+}
+
+int chordvis_comm_unique_id(void* out128)
+{
+    if (!out128) return CHORDVIS_E_INVALID;
+    const Rccl* r = rccl();
+    if (!r) return CHORDVIS_E_COMM;
+    NcclUniqueId id;
+    if (r->GetUniqueId(&id) != kNcclSuccess) return CHORDVIS_E_COMM;
+    std::memcpy(out128, &id, sizeof(id));
+    return CHORDVIS_OK;
+}
+
+int chordvis_comm_init_rank(ChordCtx* c, uint32_t nranks, uint32_t rank, const void* id128)
+{
+    if (!c || !id128 || nranks == 0 || rank >= nranks) return fail(c, CHORDVIS_E_INVALID, "comm_init_rank: bad arguments");
+    if (c->shard.ranks != nranks || c->shard.rank != rank)
+        return fail(c, CHORDVIS_E_INVALID, "comm_init_rank: call chordvis_set_shard(stripeRows, nranks, rank) first (same nranks / rank)");
+    const Rccl* r = rccl();
+    if (!r) return fail(c, CHORDVIS_E_COMM, gRcclError.c_str());
+    if (c->comm) { (void)r->CommDestroy((NcclComm)c->comm); c->comm = nullptr; }
+    CHORD_HIP(c, hipSetDevice(c->device));
+    NcclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    NcclComm comm = nullptr;
+    const int rc = r->CommInitRank(&comm, (int)nranks, id, (int)rank);
+    if (rc != kNcclSuccess) return nccl_fail(c, r, "ncclCommInitRank", rc);
+    c->comm = comm;
+    return CHORDVIS_OK;
+}
+
+int chordvis_comm_destroy(ChordCtx* c)
+{
+    if (!c) return CHORDVIS_E_INVALID;
+    if (c->comm) {
+        const Rccl* r = rccl();
+        (void)hipStreamSynchronize(c->stream);
+        if (r) (void)r->CommDestroy((NcclComm)c->comm);
+        c->comm = nullptr;
+    }
+    return CHORDVIS_OK;
+}
+
+int chordvis_comm_info(ChordCtx* c, int* ncclVersion, uint32_t* nranks, char* libraryOrigin, uint32_t originBytes)
+{
+    const Rccl* r = rccl();
+    if (!r) return c ? fail(c, CHORDVIS_E_COMM, gRcclError.c_str()) : CHORDVIS_E_COMM;
+    if (ncclVersion) { int v = 0; (void)r->GetVersion(&v); *ncclVersion = v; }
+    if (nranks) *nranks = (c && c->comm) ? c->shard.ranks : 0u;
+    if (libraryOrigin && originBytes) std::snprintf(libraryOrigin, originBytes, "%s", r->origin.c_str());
+    return CHORDVIS_OK;
+}
+
+} // extern "C"
+
+namespace chord {
+
+// The sharded frame of a context with a communicator: everything on the context's stream, no host synchronisation.
+int comm_render_frame(ChordCtx* c)
+{
+    const Rccl* r = rccl();
+    if (!r || !c->comm) return fail(c, CHORDVIS_E_COMM, "render_frame: sharded context without a communicator (chordvis_comm_init_rank, or drive chordvis_frame_phase_a/b/c)");
+    int rc;
+    if ((rc = chordvis_frame_phase_a(c))) return rc;
+    if (c->shouldStage1) {
+        // RCCL has no 16-bit integer type; the payload is opaque f16 bits
+        const size_t bytes = (size_t)c->hzbExchangeChunkHalves * 2;
+        char* base = reinterpret_cast<char*>(c->dHzbExchange);
+        const int e = r->AllGather(base + (size_t)c->shard.rank * bytes, base, bytes, kNcclUint8, (NcclComm)c->comm, c->stream);
+        if (e != kNcclSuccess) return nccl_fail(c, r, "ncclAllGather(hzb mip 0)", e);
+    }
+    if ((rc = chordvis_frame_phase_b(c))) return rc;
+    {
+        const size_t words = (size_t)(c->visWords / c->shard.ranks);
+        const int e = r->AllGather(c->dVis + (size_t)c->shard.rank * words, c->dVis, words, kNcclUint64, (NcclComm)c->comm, c->stream);
+        if (e != kNcclSuccess) return nccl_fail(c, r, "ncclAllGather(visibility)", e);
+    }
+    return chordvis_frame_phase_c(c);
+}
+
+} // namespace chord
+
+// ------------------------------------------------------------------------------------------ one process, n devices
+struct ChordGroup {
+    uint32_t n = 0;
+    std::vector<ChordCtx*> ctx;
+    std::vector<int> device;
+    std::string lastError;
+    uint32_t stripeRows = 0;
+    // copy streams and events: index [src * n + dst]
+    std::vector<hipStream_t> copyStream;
+    std::vector<hipEvent_t> evArrived[2];       // per exchange (0 = HZB mip 0, 1 = visibility)
+    std::vector<hipEvent_t> evReady[2];         // per rank
+    // worker threads: one per rank, parked on a condition variable between jobs
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cvJob, cvDone;
+    std::function<int(uint32_t)> job;
+    uint64_t jobSerial = 0;
+    uint32_t pending = 0;
+    std::vector<int> jobRc;
+    bool quit = false;
+    // host barrier between the steps of an exchange (an event must be RECORDED before another thread enqueues a wait on it)
+    std::mutex bm;
+    std::condition_variable bcv;
+    uint32_t bCount = 0; uint64_t bGen = 0;
+};
+
+namespace {
+
+void group_barrier(ChordGroup* g)
+{
+    std::unique_lock<std::mutex> lk(g->bm);
+    const uint64_t gen = g->bGen;
+    if (++g->bCount == g->n) { g->bCount = 0; g->bGen++; g->bcv.notify_all(); }
+    else g->bcv.wait(lk, [&] { return g->bGen != gen; });
+}
+
+void worker_main(ChordGroup* g, uint32_t rank)
+{
+    (void)hipSetDevice(g->device[rank]);
+    uint64_t seen = 0;
+    for (;;) {
+        std::function<int(uint32_t)> job;
+        {
+            std::unique_lock<std::mutex> lk(g->m);
+            g->cvJob.wait(lk, [&] { return g->quit || g->jobSerial != seen; });
+            if (g->quit) return;
+            seen = g->jobSerial;
+            job = g->job;
+        }
+        const int rc = job(rank);
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            g->jobRc[rank] = rc;
+            if (--g->pending == 0) g->cvDone.notify_all();
+        }
+    }
+}
+
+// runs fn(rank) on every rank's thread; returns the first failure (and keeps its message)
+int run_all(ChordGroup* g, const std::function<int(uint32_t)>& fn, const char* what)
+{
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        g->job = fn; g->pending = g->n; g->jobSerial++;
+        g->cvJob.notify_all();
+        g->cvDone.wait(lk, [&] { return g->pending == 0; });
+    }
+    for (uint32_t r = 0; r < g->n; r++)
+        if (g->jobRc[r]) {
+            char buf[640];
+            std::snprintf(buf, sizeof(buf), "%s: rank %u (device %d): %s", what, r, g->device[r], chordvis_last_error(g->ctx[r]));
+            g->lastError = buf;
+            return g->jobRc[r];
+        }
+    return CHORDVIS_OK;
+}
+
+// Direct all-gather of rank-major buffers, called by every rank's thread: rank r's chunk travels to each peer on the
+// (r, d) copy stream once both ends are ready -- r has produced it, d has finished with the region it lands in (d's
+// stream is past every earlier reader of its buffer when it records `ready`).  A compute stream then waits for every
+// copy that ends in its buffer AND every copy that leaves it (the source region is rewritten by the next frame).
+int group_all_gather(ChordGroup* g, uint32_t r, int which, const std::function<char*(uint32_t)>& base, size_t chunkBytes)
+{
+    ChordCtx* c = g->ctx[r];
+    const uint32_t n = g->n;
+    int rc = CHORDVIS_OK;
+    // a failing call is remembered, but the rank keeps walking through both host barriers: its peers wait there
+#define GG_HIP(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess && !rc) rc = fail(c, CHORDVIS_E_HIP, #call, e_); } while (0)
+    GG_HIP(hipEventRecord(g->evReady[which][r], c->stream));
+    group_barrier(g);                                             // every `ready` is recorded
+    for (uint32_t d = 0; d < n; d++) {
+        if (d == r) continue;
+        hipStream_t cs = g->copyStream[(size_t)r * n + d];
+        GG_HIP(hipStreamWaitEvent(cs, g->evReady[which][r], 0));
+        GG_HIP(hipStreamWaitEvent(cs, g->evReady[which][d], 0));
+        GG_HIP(hipMemcpyPeerAsync(base(d) + (size_t)r * chunkBytes, g->device[d], base(r) + (size_t)r * chunkBytes, g->device[r], chunkBytes, cs));
+        GG_HIP(hipEventRecord(g->evArrived[which][(size_t)r * n + d], cs));
+    }
+    group_barrier(g);                                             // every `arrived` is recorded
+    for (uint32_t o = 0; o < n; o++) {
+        if (o == r) continue;
+        GG_HIP(hipStreamWaitEvent(c->stream, g->evArrived[which][(size_t)o * n + r], 0));   // into my buffer
+        GG_HIP(hipStreamWaitEvent(c->stream, g->evArrived[which][(size_t)r * n + o], 0));   // out of my buffer
+    }
+#undef GG_HIP
+    return rc;
+}
+
+int gfail(ChordGroup* g, int code, const char* what) { if (g) g->lastError = what; return code; }
+
+} // namespace
+
+extern "C" {
+
+int chordvis_create_group(uint32_t n, const int* deviceOrdinals, ChordGroup** out)
+{
+    if (!out) return CHORDVIS_E_INVALID;
+    *out = nullptr;
+    if (n == 0 || n > 64 || !deviceOrdinals) return CHORDVIS_E_INVALID;
+    ChordGroup* g = new ChordGroup();
+    g->n = n;
+    g->device.assign(deviceOrdinals, deviceOrdinals + n);
+    g->ctx.assign(n, nullptr);
+    g->jobRc.assign(n, 0);
+    int rc = CHORDVIS_OK;
+    for (uint32_t r = 0; r < n && !rc; r++) rc = chordvis_create(g->device[r], nullptr, &g->ctx[r]);
+    g->copyStream.assign((size_t)n * n, nullptr);
+    for (int w = 0; w < 2; w++) { g->evArrived[w].assign((size_t)n * n, nullptr); g->evReady[w].assign(n, nullptr); }
+    for (uint32_t r = 0; r < n && !rc; r++) {
+        if (hipSetDevice(g->device[r]) != hipSuccess) { rc = CHORDVIS_E_NO_DEVICE; break; }
+        for (uint32_t d = 0; d < n; d++) {
+            if (d != r && g->device[d] != g->device[r]) {
+                int can = 0;
+                (void)hipDeviceCanAccessPeer(&can, g->device[r], g->device[d]);
+                if (can) { const hipError_t e = hipDeviceEnablePeerAccess(g->device[d], 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = CHORDVIS_E_HIP; (void)hipGetLastError(); }
+            }
+            if (d != r && hipStreamCreateWithFlags(&g->copyStream[(size_t)r * n + d], hipStreamNonBlocking) != hipSuccess) rc = CHORDVIS_E_HIP;
+            for (int w = 0; w < 2; w++)
+                if (d != r && hipEventCreateWithFlags(&g->evArrived[w][(size_t)r * n + d], hipEventDisableTiming) != hipSuccess) rc = CHORDVIS_E_HIP;
+        }
+        for (int w = 0; w < 2; w++) if (hipEventCreateWithFlags(&g->evReady[w][r], hipEventDisableTiming) != hipSuccess) rc = CHORDVIS_E_HIP;
+    }
+    if (rc) { chordvis_destroy_group(g); return rc; }
+    for (uint32_t r = 0; r < n; r++) g->workers.emplace_back(worker_main, g, r);
+    *out = g;
+    return CHORDVIS_OK;
+}
+
+int chordvis_destroy_group(ChordGroup* g)
+{
+    if (!g) return CHORDVIS_E_INVALID;
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        g->quit = true;
+        g->cvJob.notify_all();
+    }
+    for (std::thread& t : g->workers) t.join();
+    for (uint32_t r = 0; r < g->n; r++) if (g->ctx[r]) (void)hipStreamSynchronize(g->ctx[r]->stream);
+    for (hipStream_t s : g->copyStream) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (int w = 0; w < 2; w++) {
+        for (hipEvent_t e : g->evArrived[w]) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : g->evReady[w]) if (e) (void)hipEventDestroy(e);
+    }
+    for (ChordCtx* c : g->ctx) if (c) chordvis_destroy(c);
+    delete g;
+    return CHORDVIS_OK;
+}
+
+uint32_t chordvis_group_size(ChordGroup* g) { return g ? g->n : 0u; }
+ChordCtx* chordvis_group_ctx(ChordGroup* g, uint32_t rank) { return (g && rank < g->n) ? g->ctx[rank] : nullptr; }
+const char* chordvis_group_last_error(ChordGroup* g) { return g ? g->lastError.c_str() : "null group"; }
+
+int chordvis_group_set_limits(ChordGroup* g, const ChordLimits* limits)
+{
+    if (!g || !limits) return gfail(g, CHORDVIS_E_INVALID, "group_set_limits: null argument");
+    return run_all(g, [&](uint32_t r) { return chordvis_set_limits(g->ctx[r], limits); }, "group_set_limits");
+}
+
+int chordvis_group_upload_scene(ChordGroup* g, const ChordSceneDesc* scene)
+{
+    if (!g || !scene) return gfail(g, CHORDVIS_E_INVALID, "group_upload_scene: null argument");
+    return run_all(g, [&](uint32_t r) { return chordvis_upload_scene(g->ctx[r], scene); }, "group_upload_scene");   // replicated
+}
+
+int chordvis_group_allocate_gbuffer(ChordGroup* g, uint32_t width, uint32_t height, uint32_t stripeRows)
+{
+    if (!g) return CHORDVIS_E_INVALID;
+    if (stripeRows == 0) stripeRows = chordvis_pick_stripe_rows(height, g->n);
+    g->stripeRows = stripeRows;
+    return run_all(g, [&](uint32_t r) {
+        int rc = chordvis_set_shard(g->ctx[r], stripeRows, g->n, r);
+        if (!rc) rc = chordvis_allocate_gbuffer(g->ctx[r], width, height, nullptr);
+        return rc;
+    }, "group_allocate_gbuffer");
+}
+
+int chordvis_group_update_objects(ChordGroup* g, const ChordObject* hostObjects, uint32_t count)
+{
+    if (!g || !hostObjects) return gfail(g, CHORDVIS_E_INVALID, "group_update_objects: null argument");
+    return run_all(g, [&](uint32_t r) { return chordvis_update_objects(g->ctx[r], hostObjects, count); }, "group_update_objects");
+}
+
+int chordvis_group_set_view(ChordGroup* g, const ChordCameraView* view, const ChordInstanceCullingView* iv, uint32_t switchFlags)
+{
+    if (!g || !view || !iv) return gfail(g, CHORDVIS_E_INVALID, "group_set_view: null argument");
+    for (uint32_t r = 0; r < g->n; r++) {                      // host-only state: no thread hop needed
+        const int rc = chordvis_set_view(g->ctx[r], view, iv, switchFlags);
+        if (rc) { g->lastError = chordvis_last_error(g->ctx[r]); return rc; }
+    }
+    return CHORDVIS_OK;
+}
+
+int chordvis_group_render_frame(ChordGroup* g)
+{
+    if (!g) return CHORDVIS_E_INVALID;
+    if (g->n == 1) return run_all(g, [&](uint32_t r) { return chordvis_render_frame(g->ctx[r]); }, "group_render_frame");
+    // A rank that fails keeps walking through the host barriers (its peers would wait for it forever otherwise).
+    return run_all(g, [&](uint32_t r) {
+        ChordCtx* c = g->ctx[r];
+        // the same on every rank (they share the frame history), and taken BEFORE phase a so that a rank whose phase a
+        // fails still joins the exchange its peers are about to enter
+        const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
+        int rc = chordvis_frame_phase_a(c);
+        if (stage1) {
+            const int e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dHzbExchange); },
+                                           (size_t)c->hzbExchangeChunkHalves * 2);
+            if (!rc) rc = e;
+        }
+        if (!rc) rc = chordvis_frame_phase_b(c);
+        {
+            const int e = group_all_gather(g, r, 1, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dVis); },
+                                           (size_t)(c->visWords / g->n) * 8);
+            if (!rc) rc = e;
+        }
+        if (!rc) rc = chordvis_frame_phase_c(c);
+        return rc;
+    }, "group_render_frame");
+}
+
+int chordvis_group_sync(ChordGroup* g)
+{
+    if (!g) return CHORDVIS_E_INVALID;
+    return run_all(g, [&](uint32_t r) { return chordvis_sync(g->ctx[r]); }, "group_sync");
+}
+
+} // extern "C"

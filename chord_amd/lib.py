@@ -13,7 +13,7 @@ from . import records as R
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CHORDVIS_LIB") or os.path.join(_HERE, "_build", "libchordvis.so")
 
-OK, E_INVALID, E_HIP, E_NO_DEVICE, E_CAPACITY = 0, -1, -2, -3, -4
+OK, E_INVALID, E_HIP, E_NO_DEVICE, E_CAPACITY, E_COMM = 0, -1, -2, -3, -4, -5
 
 
 class ChordvisError(RuntimeError):
@@ -141,6 +141,23 @@ def _load():
         "chordvis_prepare_shading_tile_param": (i32, [vp, u32, P(TileMarker), P(ShadingTiles)]),
         "chordvis_readback_tile_marker": (i32, [vp, P(TileMarker), vp]),
         "chordvis_readback_shading_tiles": (i32, [vp, P(ShadingTiles), vp, u32, P(u32), vp]),
+        "chordvis_pick_stripe_rows": (u32, [u32, u32]),
+        "chordvis_comm_unique_id": (i32, [vp]),
+        "chordvis_comm_init_rank": (i32, [vp, u32, u32, vp]),
+        "chordvis_comm_destroy": (i32, [vp]),
+        "chordvis_comm_info": (i32, [vp, P(i32), P(u32), vp, u32]),
+        "chordvis_create_group": (i32, [u32, P(i32), P(vp)]),
+        "chordvis_destroy_group": (i32, [vp]),
+        "chordvis_group_size": (u32, [vp]),
+        "chordvis_group_ctx": (vp, [vp, u32]),
+        "chordvis_group_last_error": (C.c_char_p, [vp]),
+        "chordvis_group_set_limits": (i32, [vp, P(Limits)]),
+        "chordvis_group_upload_scene": (i32, [vp, P(R.SceneDesc)]),
+        "chordvis_group_allocate_gbuffer": (i32, [vp, u32, u32, u32]),
+        "chordvis_group_update_objects": (i32, [vp, vp, u32]),
+        "chordvis_group_set_view": (i32, [vp, vp, vp, u32]),
+        "chordvis_group_render_frame": (i32, [vp]),
+        "chordvis_group_sync": (i32, [vp]),
         "chordvis_enable_timers": (i32, [vp, i32]),
         "chordvis_stats": (i32, [vp, P(Stats)]),
         "chordvis_set_debug": (i32, [vp, u32]),

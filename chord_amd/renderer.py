@@ -16,12 +16,16 @@ from . import records as R
 class VisibilityRenderer:
     """One device context (graphics::Context + DeferredRenderer state for this path)."""
 
-    def __init__(self, device=0, stream=None):
-        self._ctx = C.c_void_p()
-        rc = L.lib.chordvis_create(device, stream, C.byref(self._ctx))
-        if rc != L.OK:
-            raise L.ChordvisError(
-                "chordvis_create(device=%d) failed with %d: no usable HIP device (the product path has no CPU fallback)" % (device, rc))
+    def __init__(self, device=0, stream=None, _borrowed_ctx=None):
+        self._borrowed = _borrowed_ctx is not None
+        if self._borrowed:
+            self._ctx = C.c_void_p(_borrowed_ctx)             # a rank of a VisibilityGroup: the group owns it
+        else:
+            self._ctx = C.c_void_p()
+            rc = L.lib.chordvis_create(device, stream, C.byref(self._ctx))
+            if rc != L.OK:
+                raise L.ChordvisError(
+                    "chordvis_create(device=%d) failed with %d: no usable HIP device (the product path has no CPU fallback)" % (device, rc))
         self.width = self.height = 0
         self.scene = None
 
@@ -32,9 +36,9 @@ class VisibilityRenderer:
             raise L.ChordvisError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
 
     def close(self):
-        if self._ctx:
+        if self._ctx and not self._borrowed:
             L.lib.chordvis_destroy(self._ctx)
-            self._ctx = C.c_void_p()
+        self._ctx = C.c_void_p()
 
     def __del__(self):
         try:
@@ -127,6 +131,18 @@ class VisibilityRenderer:
 
     def frame_phase_c(self):
         self._check(L.lib.chordvis_frame_phase_c(self._ctx), "frame_phase_c")
+
+    # -- one process per GPU: RCCL communicator owned by the library ---------------------------------
+    def comm_init_rank(self, nranks, rank, unique_id):
+        """Attach an RCCL communicator (after set_shard); render_frame() then runs the two all-gathers itself."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._check(L.lib.chordvis_comm_init_rank(self._ctx, nranks, rank, buf), "comm_init_rank")
+
+    def comm_destroy(self):
+        self._check(L.lib.chordvis_comm_destroy(self._ctx), "comm_destroy")
+
+    def comm_info(self):
+        return comm_info(self._ctx)
 
     def reset_history(self):
         self._check(L.lib.chordvis_reset_history(self._ctx), "reset_history")
@@ -223,3 +239,80 @@ def decode_visibility(vis):
     tri = (low & 0xFF).astype(np.uint8)
     slot = ((low >> 8) & 0xFFFFFF).astype(np.int64) - 1
     return depth, slot, tri
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0; the host distributes the 128 bytes)."""
+    buf = (C.c_char * 128)()
+    rc = L.lib.chordvis_comm_unique_id(buf)
+    if rc != L.OK:
+        raise L.ChordvisError("chordvis_comm_unique_id failed (%d): librccl not loadable" % rc)
+    return bytes(buf.raw)
+
+
+def comm_info(ctx=None):
+    ver, n = C.c_int(0), C.c_uint32(0)
+    origin = C.create_string_buffer(256)
+    rc = L.lib.chordvis_comm_info(ctx, C.byref(ver), C.byref(n), origin, 256)
+    if rc != L.OK:
+        raise L.ChordvisError("chordvis_comm_info failed (%d)" % rc)
+    return {"nccl_version_code": ver.value, "ranks": n.value, "library": origin.value.decode()}
+
+
+class VisibilityGroup:
+    """ChordGroup: one process, n devices, one call per frame; the library issues the exchanges (direct peer copies)."""
+
+    def __init__(self, devices):
+        devices = list(devices)
+        arr = (C.c_int * len(devices))(*devices)
+        self._g = C.c_void_p()
+        rc = L.lib.chordvis_create_group(len(devices), arr, C.byref(self._g))
+        if rc != L.OK:
+            raise L.ChordvisError("chordvis_create_group(%r) failed with %d" % (devices, rc))
+        self.size = len(devices)
+        self.ranks = [VisibilityRenderer(_borrowed_ctx=L.lib.chordvis_group_ctx(self._g, r)) for r in range(self.size)]
+
+    def _check(self, rc, what):
+        if rc != L.OK:
+            msg = L.lib.chordvis_group_last_error(self._g)
+            raise L.ChordvisError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def close(self):
+        if self._g:
+            for r in self.ranks:
+                r.close()
+            L.lib.chordvis_destroy_group(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_limits(self, max_triangle_records=0, bin_pool_chunks=0, bin_max_chunks_per_tile=0):
+        lim = L.Limits(int(max_triangle_records), int(bin_pool_chunks), int(bin_max_chunks_per_tile))
+        self._check(L.lib.chordvis_group_set_limits(self._g, C.byref(lim)), "group_set_limits")
+
+    def upload_scene(self, scene):
+        self.scene = scene
+        self._check(L.lib.chordvis_group_upload_scene(self._g, C.byref(scene.desc)), "group_upload_scene")
+
+    def allocate_gbuffer(self, width, height, stripe_rows=0):
+        self._check(L.lib.chordvis_group_allocate_gbuffer(self._g, width, height, stripe_rows), "group_allocate_gbuffer")
+        for r in self.ranks:
+            r.width, r.height = width, height
+
+    def update_objects(self, objects):
+        objects = np.ascontiguousarray(objects, dtype=R.OBJECT)
+        self._check(L.lib.chordvis_group_update_objects(self._g, objects.ctypes.data, len(objects)), "group_update_objects")
+
+    def set_view(self, view, instance_view, flags):
+        self._views = (view, instance_view)
+        self._check(L.lib.chordvis_group_set_view(self._g, view.ctypes.data, instance_view.ctypes.data, flags), "group_set_view")
+
+    def render_frame(self):
+        self._check(L.lib.chordvis_group_render_frame(self._g), "group_render_frame")
+
+    def sync(self):
+        self._check(L.lib.chordvis_group_sync(self._g), "group_sync")

@@ -36,6 +36,7 @@ extern "C" {
 #define CHORDVIS_E_HIP          -2   /* a HIP runtime call failed            */
 #define CHORDVIS_E_NO_DEVICE    -3   /* no usable gfx950 device              */
 #define CHORDVIS_E_CAPACITY     -4   /* scene exceeds a documented limit     */
+#define CHORDVIS_E_COMM         -5   /* RCCL missing / a collective failed   */
 
 typedef struct ChordCtx ChordCtx;
 
@@ -99,9 +100,9 @@ typedef struct ChordStats {
     float    msStage1;             /* "GLTF Visibility Stage1"           */
     float    msHzbFinal;           /* "BuildHZB"                         */
     float    msFrame;              /* clear .. final HZB                 */
-    float    msRasterCluster;      /* sum over the frame's raster_cluster_kernel launches */
-    float    msRasterClip;         /* ... raster_clip_kernel                                */
-    float    msRasterChunk;        /* ... raster_chunk_kernel                               */
+    float    msRasterCluster;      /* sum over the frame's raster_setup_kernel launches (per-meshlet setup + binning) */
+    float    msRasterClip;         /* ... raster_clip_and_bin_large_kernel + raster_tile_order_kernel                 */
+    float    msRasterChunk;        /* ... raster_tile_kernel (per-tile resolve in LDS, tile-out, fused HZB mips 0-5)  */
     uint32_t framesTimed;          /* frames the ms* fields are averaged over               */
     uint32_t rasterLaunches;       /* renderMesh calls this frame (1 or 2)                  */
     uint32_t overflow;             /* non-zero: a deferred raster list overflowed (results invalid) */
@@ -143,8 +144,11 @@ int chordvis_object_basic_data_batch(uint32_t count, const double* localToWorld 
 
 /* ------------------------------------------------------------------ context (graphics::Context, graphics.h:88-345) */
 
-/* hipStream: an existing hipStream_t to enqueue on (e.g. the caller's current stream), or NULL
- * for a context-owned stream. */
+/* hipStream: an existing hipStream_t to enqueue on (e.g. the caller's current stream), or NULL for a context-owned
+ * NON-BLOCKING stream.  NULL is "no stream given", not "the null stream": work the host enqueues on the legacy default
+ * stream is NOT ordered against a context-owned stream.  A host that issues its own collectives or copies between passes
+ * hands over the stream it issues them on (PyTorch: a torch.cuda.Stream made current; its default stream has handle 0,
+ * which arrives here as NULL), or passes hipStreamLegacy / hipStreamPerThread ((void*)1 / (void*)2), which go through. */
 int chordvis_create(int deviceOrdinal, void* hipStream, ChordCtx** outCtx);
 int chordvis_destroy(ChordCtx* ctx);
 const char* chordvis_last_error(ChordCtx* ctx);
@@ -212,8 +216,9 @@ int chordvis_build_hzb(ChordCtx* ctx, int bBuildMin, int bBuildMax, int bBuildVa
 
 /* DeferredRenderer::render hot segment (renderer.cpp:315-345,489): clear -> instanceCulling ->
  * stage0 -> [buildHZB -> stage1] -> buildHZB(min,max,validRange); keeps the HZB as history for
- * the next call.  Single-GPU (ranks == 1) only; sharded frames are driven in three phases so the
- * host can run the collectives in between:
+ * the next call.  On a sharded context (ranks > 1) this needs a communicator (chordvis_comm_init_rank below) and runs the
+ * three phases with the two all-gathers in between; a host that owns its collectives (e.g. torch.distributed) drives
+ * the phases itself -- on the context's stream, so that kernels and collectives are ordered:
  *   chordvis_frame_phase_a  clear .. stage 0 raster, own-stripe HZB mip 0 into the exchange buffer
  *   [all-gather exchange buffer]
  *   chordvis_frame_phase_b  assemble HZB, stage 1 cull + raster
@@ -230,6 +235,47 @@ uint64_t chordvis_hzb_exchange_halves(ChordCtx* ctx);        /* whole buffer */
 uint64_t chordvis_hzb_exchange_chunk_halves(ChordCtx* ctx);  /* one rank     */
 /* row-major visibility after phase_c (== chordvis_visibility_ptr when ranks == 1) */
 uint64_t* chordvis_resolved_visibility_ptr(ChordCtx* ctx);
+
+/* ------------------------------------------------------------------ multi-GPU (the reference is single-device,
+ * graphics.cpp:524-548).  The frame shards by interleaved row stripes (chordvis_set_shard); the two exchanges of a sharded
+ * frame -- own-stripe HZB mip 0 between the raster passes, own-stripe visibility words at the end -- are issued by the library,
+ * so the host keeps ONE call per frame, like DeferredRenderer::render (renderer.cpp:319-345). */
+
+/* even stripe height in [32, 96] with the least padding for `ranks` ranks */
+uint32_t chordvis_pick_stripe_rows(uint32_t height, uint32_t ranks);
+
+/* (a) one process per GPU (torch.distributed / MPI hosts): attach an RCCL communicator to a sharded context; from then on
+ * chordvis_render_frame(ctx) runs phase a -> ncclAllGather -> phase b -> ncclAllGather -> phase c on the context's stream.
+ * Rank 0 makes the id (ncclGetUniqueId), the host distributes the 128 bytes by its own means, every rank calls init_rank
+ * after chordvis_set_shard(stripeRows, nranks, rank).  librccl.so is resolved at run time, preferring a copy already loaded
+ * into the process (CHORDVIS_RCCL=<path> overrides). */
+#define CHORDVIS_UNIQUE_ID_BYTES 128
+int chordvis_comm_unique_id(void* out128);
+int chordvis_comm_init_rank(ChordCtx* ctx, uint32_t nranks, uint32_t rank, const void* id128);
+int chordvis_comm_destroy(ChordCtx* ctx);
+/* NCCL_VERSION_CODE of the loaded library, ranks of ctx's communicator (0 = none; ctx may be NULL), where librccl came from */
+int chordvis_comm_info(ChordCtx* ctx, int* ncclVersion, uint32_t* nranks, char* libraryOrigin, uint32_t originBytes);
+
+/* (b) one process, n devices: one context + one host thread per device; the exchanges are direct all-gathers -- every rank
+ * pushes its chunk to each peer with its own hipMemcpyPeerAsync (n-1 concurrent copies per rank, one per xGMI link).
+ * Ordinals may repeat (protocol tests on a one-GPU box).  The scene is replicated; per-rank readback and stats go through
+ * chordvis_group_ctx(group, rank) (borrowed; every rank ends a frame with the complete row-major image and HZB). */
+typedef struct ChordGroup ChordGroup;
+int chordvis_create_group(uint32_t n, const int* deviceOrdinals, ChordGroup** outGroup);
+int chordvis_destroy_group(ChordGroup* group);
+uint32_t chordvis_group_size(ChordGroup* group);
+ChordCtx* chordvis_group_ctx(ChordGroup* group, uint32_t rank);
+const char* chordvis_group_last_error(ChordGroup* group);
+int chordvis_group_set_limits(ChordGroup* group, const ChordLimits* limits);
+int chordvis_group_upload_scene(ChordGroup* group, const ChordSceneDesc* scene);
+/* stripeRows 0 = chordvis_pick_stripe_rows(height, n) */
+int chordvis_group_allocate_gbuffer(ChordGroup* group, uint32_t width, uint32_t height, uint32_t stripeRows);
+int chordvis_group_update_objects(ChordGroup* group, const ChordObject* hostObjects, uint32_t count);
+int chordvis_group_set_view(ChordGroup* group, const ChordCameraView* view, const ChordInstanceCullingView* instanceView, uint32_t switchFlags);
+/* DeferredRenderer::render hot segment (renderer.cpp:315-345,489) on n devices; returns when the frame is ENQUEUED on every
+ * device (no host synchronisation; chordvis_group_sync waits) */
+int chordvis_group_render_frame(ChordGroup* group);
+int chordvis_group_sync(ChordGroup* group);
 
 /* handles of the last frame (post-instanceCulling list: consumer contract, lighting.hlsl:318-345) */
 int chordvis_last_frame_cmds(ChordCtx* ctx, ChordCountAndCmd* out);
@@ -261,11 +307,12 @@ int chordvis_upload_history_hzb(ChordCtx* ctx, const uint16_t* hostMin);
  * hipEventRecord between two kernels costs ~5 us of stream idle time on MI355X. */
 int chordvis_enable_timers(ChordCtx* ctx, int mode);
 int chordvis_stats(ChordCtx* ctx, ChordStats* out);
-/* Measurement-only ablation switches of the raster kernels (bit0 no pixel writes, bit1 plain stores,
- * bit2 drop big triangles, bit3 no early depth read).  0 = production; anything else voids parity. */
+/* Measurement-only ablation switches of the raster kernels (kernels_raster.hip DBG_*): 1 no pixel writes, 2 setup
+ * emits no records / bins, 16 per-tile clocks (chordvis_debug_tile_profile), 32 skip the per-lane scan of tiny
+ * triangles, 64 tile kernel of later passes returns at once, 128 no tile-out, 256 tile-out without the HZB
+ * reduction, 512 setup-kernel phase clocks (chordvis_debug_setup_profile), 1024 fused tile-out skips the visibility
+ * stores, 2048 never split long bins.  0 = production; anything else voids parity. */
 int chordvis_set_debug(ChordCtx* ctx, uint32_t flags);
-/* Measurement only: with debug bit 4 set the tile kernel records its elapsed wall-clock ticks (100 MHz)
- * per 64x64 tile; this reads them back with the tile's bin count for raster pass 0 / 1 of the last frame. */
 /* debugging aid: raw read of an internal buffer (0 tile counts, 1 fixed bins, 2 chunk table, 3 bin pool, 4 / 5 32- / 48-byte records) */
 int chordvis_debug_read(ChordCtx* ctx, int which, uint64_t offset, uint64_t bytes, void* host);
 /* debugging aid: non-zero words in the split-tile accumulation slabs (must be 0 between raster passes) */

@@ -1,0 +1,152 @@
+"""The multi-GPU entry points on ONE device: ranks share device 0, so the protocol (stripes, two exchanges, event
+ordering, buffer reuse, one call per frame) is what is tested; xGMI bandwidth is not."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+from chord_amd import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+GROUPS = [
+    ("small_2", lambda: scenes.small_test_scene(320, 200, seed=17), 2, 14),
+    ("small_5", lambda: scenes.small_test_scene(320, 200, seed=23), 5, 0),
+    ("street_720p_8", lambda: scenes.config3_street(1280, 720), 8, 0),
+    ("street_x64_360p_4", lambda: scenes.config4_street_x64(640, 360), 4, 0),
+]
+
+
+@pytest.mark.parametrize("name,builder,ranks,stripe", GROUPS, ids=[g[0] for g in GROUPS])
+def test_group_frames_equal_the_single_gpu_frames(gpu, name, builder, ranks, stripe):
+    """chordvis_create_group / chordvis_group_render_frame: one call per frame, the library issues both exchanges
+    (direct peer copies ordered by events, no host synchronisation inside a frame); four frames with a moving camera so
+    that buffers are reused while copies of the previous frame may still be in flight."""
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityGroup, VisibilityRenderer
+    scene, cam0 = builder()
+    w, h, flags = cam0.width, cam0.height, H.ALL_FLAGS
+    f = np.array(cam0.front, dtype=np.float64)
+    f /= np.linalg.norm(f)
+    cams = [cam0.moved(tuple(0.25 * k * f)) for k in range(4)]
+    ref = VisibilityRenderer(0)
+    ref.upload_scene(scene)
+    ref.allocate_gbuffer(w, h)
+    g = VisibilityGroup([0] * ranks)
+    g.upload_scene(scene)
+    g.allocate_gbuffer(w, h, stripe)
+    wants = []
+    last_view = None
+    inputs = []
+    for k, cam in enumerate(cams):
+        objs = L.fill_objects(scene, cam, cams[k - 1] if k else None).copy()
+        view, iv = L.make_views(cam, last_view)
+        last_view = L.make_views(cam)[0]
+        inputs.append((objs, view, iv))
+    for objs, view, iv in inputs:                         # reference frames first
+        ref.update_objects(objs)
+        ref.set_view(view, iv, flags)
+        ref.render_frame()
+        wants.append((ref.read_visibility(), ref.read_hzb(ref.history_hzb()), ref.stats()))
+    for objs, view, iv in inputs[:2]:                     # two frames enqueued back to back, then checked ...
+        g.update_objects(objs)
+        g.set_view(view, iv, flags)
+        g.render_frame()
+    g.sync()
+    _check_ranks(g, wants[1], w, h, "frame 1")
+    for k, (objs, view, iv) in enumerate(inputs[2:], start=2):   # ... and frame by frame
+        g.update_objects(objs)
+        g.set_view(view, iv, flags)
+        g.render_frame()
+        _check_ranks(g, wants[k], w, h, "frame %d" % k)
+    g.close()
+    ref.close()
+
+
+def _check_ranks(g, want, w, h, what):
+    wvis, (wmn, wmx, wrng), wst = want
+    for rk, r in enumerate(g.ranks):
+        H.assert_vis_equal(r.read_visibility(), wvis, w, h, "%s rank %d" % (what, rk))
+        mn, mx, rng = r.read_hzb(r.history_hzb())
+        assert np.array_equal(mn, wmn) and np.array_equal(mx, wmx) and np.array_equal(rng, wrng), "%s rank %d HZB" % (what, rk)
+        st = r.stats()
+        keys = ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible")
+        assert [st[k] for k in keys] == [wst[k] for k in keys]
+
+
+def test_library_owned_rccl_exchange_world_size_1(gpu):
+    """chordvis_comm_*: librccl resolved at run time (the copy PyTorch already loaded), a communicator attached to the
+    context, chordvis_render_frame issuing ncclAllGather on the context's stream.  One rank is all a one-GPU box can
+    host; the frame (phases a/b/c around two in-place all-gathers) must equal the fused single-GPU frame."""
+    import torch  # noqa: F401  (loads PyTorch's librccl next to its HIP runtime)
+    from chord_amd.renderer import VisibilityRenderer, comm_unique_id
+    scene, cam, view, iv = H.setup_scene(lambda: scenes.small_test_scene(320, 200, seed=31))
+    w, h, flags = cam.width, cam.height, H.ALL_FLAGS
+    ref = VisibilityRenderer(0)
+    r = VisibilityRenderer(0)
+    for x in (ref, r):
+        x.upload_scene(scene)
+        x.allocate_gbuffer(w, h)
+        x.set_view(view, iv, flags)
+    r.comm_init_rank(1, 0, comm_unique_id())
+    info = r.comm_info()
+    assert info["ranks"] == 1 and info["nccl_version_code"] >= 20000, info
+    for frame in range(3):
+        ref.render_frame()
+        r.render_frame()
+        H.assert_vis_equal(r.read_visibility(), ref.read_visibility(), w, h, "frame %d" % frame)
+        a, b = r.read_hzb(r.history_hzb()), ref.read_hzb(ref.history_hzb())
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    r.comm_destroy()
+    r.close()
+    ref.close()
+
+
+def test_sharded_render_frame_without_a_communicator_is_refused(gpu):
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam, view, iv = H.setup_scene(lambda: scenes.small_test_scene(160, 96))
+    r = VisibilityRenderer(0)
+    r.upload_scene(scene)
+    r.set_shard(16, 2, 1)
+    r.allocate_gbuffer(cam.width, cam.height)
+    r.set_view(view, iv, H.ALL_FLAGS)
+    with pytest.raises(L.ChordvisError):
+        r.render_frame()
+    r.close()
+
+
+def _run_bench(extra, env_extra, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, "bench.py failed:\n%s\n%s" % (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_self_spawned_on_one_device(gpu):
+    """`python bench.py --gpus 2` with no launcher: re-executes itself under torch.distributed.run, two ranks on device 0
+    (gloo, host-staged all-gathers: a one-GPU box cannot host two RCCL ranks), the N > 1 control flow of the bench --
+    explicit stream, phases, both exchanges, the same-workload single-GPU reference and the speed-up field."""
+    line = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "4", "--workload", "street_720p_hzb"],
+                      {"CHORDVIS_BENCH_BACKEND": "gloo", "CHORDVIS_BENCH_ONE_DEVICE": "1"})
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["exchange"] == "torch"
+    assert line["config"]["workload"] == "street_720p_hzb" and line["single_gpu_same_workload"]["workload"] == "street_720p_hzb"
+    assert line["speedup_vs_single"] > 0 and line["value"] > 0
+    # the sharded frames submit exactly the triangles the single-GPU frames do
+    assert line["counts_view_a"]["countInstanceCulled"] > 0
+
+
+def test_bench_single_gpu_line_has_the_contract_fields(gpu):
+    line = _run_bench(["--steps", "6", "--warmup", "4", "--workload", "street_720p_hzb", "--cpu-baseline-frames", "2"], {})
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["roofline"]["frac"] < 1.0 and line["cpu_baseline"]["cores"] == 1
