@@ -151,17 +151,25 @@ def main():
         want = args.exchange if backend == "nccl" else "torch"
         if want in ("auto", "lib"):
             ok = 1
-            try:
-                from chord_amd.renderer import comm_unique_id
-                uid = [comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                r.comm_init_rank(world, rank, uid[0])
-                comm = r.comm_info()
-            except Exception as e:                       # noqa: BLE001  (no librccl / init failure: every rank falls back together)
+            from chord_amd.renderer import comm_unique_id
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid[0] = comm_unique_id()
+                except Exception as e:                   # noqa: BLE001  (no librccl: every rank falls back together)
+                    print("[bench] library-owned RCCL exchange unavailable (%s); using torch.distributed" % e, file=sys.stderr)
+            dist.broadcast_object_list(uid, src=0)
+            if uid[0] is None:
                 ok = 0
-                if want == "lib":
-                    raise
-                print("[bench] rank %d: library-owned RCCL exchange unavailable (%s); using torch.distributed" % (rank, e), file=sys.stderr)
+            else:
+                try:
+                    r.comm_init_rank(world, rank, uid[0])
+                    comm = r.comm_info()
+                except Exception as e:                   # noqa: BLE001
+                    ok = 0
+                    print("[bench] rank %d: chordvis_comm_init_rank failed (%s); using torch.distributed" % (rank, e), file=sys.stderr)
+            if want == "lib" and not ok:
+                raise SystemExit("--exchange lib: the library-owned RCCL communicator could not be set up")
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:

@@ -38,20 +38,24 @@ def _headers_digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
-    os.makedirs(BUILD_DIR, exist_ok=True)
-    hd = _headers_digest()
+def build(force=False, verbose=True, defines=(), tag=""):
+    """defines / tag: a measurement variant (e.g. defines=("-DCHORD_TILE_V=1",), tag="tile_v1") is built next to the
+    product library as _build/libchordvis_<tag>.so; chord_amd/lib.py loads it when CHORDVIS_LIB names it."""
+    build_dir = BUILD_DIR + ("_" + tag if tag else "")
+    lib_path = os.path.join(OUT_DIR, "libchordvis%s.so" % ("_" + tag if tag else ""))
+    os.makedirs(build_dir, exist_ok=True)
+    hd = _headers_digest() + " ".join(defines)
     objs, rebuilt = [], False
     for src in _sources():
         path = os.path.join(CSRC, src)
-        obj = os.path.join(BUILD_DIR, src + ".o")
+        obj = os.path.join(build_dir, src + ".o")
         stamp = obj + ".stamp"
         with open(path, "rb") as fh:
             digest = hashlib.sha1(fh.read()).hexdigest() + hd
         old = open(stamp).read() if os.path.exists(stamp) else ""
         if force or old != digest or not os.path.exists(obj):
             # hipcc compiles .cpp as HIP too: name the one target for every file (no default-arch code objects)
-            cmd = [HIPCC] + COMMON + DEVICE
+            cmd = [HIPCC] + COMMON + DEVICE + list(defines)
             if src.endswith(".hip"):
                 cmd += ["-x", "hip"]
             cmd += ["-c", path, "-o", obj]
@@ -62,18 +66,20 @@ def build(force=False, verbose=True):
                 fh.write(digest)
             rebuilt = True
         objs.append(obj)
-    if rebuilt or not os.path.exists(LIB):
+    if rebuilt or not os.path.exists(lib_path):
         # -no-hip-rt: libchordvis.so carries NO DT_NEEDED on a particular libamdhip64.  A process must hold
         # exactly one HIP/HSA runtime; PyTorch-ROCm wheels bundle their own (SONAME libamdhip64.so, not
         # libamdhip64.so.7), so the host decides which runtime is live and loads it first (chord_amd/lib.py;
         # a C++ host simply links -lamdhip64 itself).
-        cmd = [HIPCC, "-shared", "-fPIC", "-no-hip-rt", "-o", LIB] + objs + ["--offload-arch=gfx950"]
+        cmd = [HIPCC, "-shared", "-fPIC", "-no-hip-rt", "-o", lib_path] + objs + ["--offload-arch=gfx950"]
         if verbose:
             print("[chord_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    # python chord_amd/build.py [--force] [--tag NAME -DX=1 ...]
+    argv = sys.argv[1:]
+    tag = argv[argv.index("--tag") + 1] if "--tag" in argv else ""
+    print(build(force="--force" in argv, defines=tuple(a for a in argv if a.startswith("-D")), tag=tag))

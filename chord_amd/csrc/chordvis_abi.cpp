@@ -101,6 +101,7 @@ int configure_targets(ChordCtx* c, uint64_t* external)
     else dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) if ((rc = alloc_hzb(c, c->hzb[i]))) return rc;
     c->historySlot = 0;
+    c->pendingTailSlot = 0;
     {   // per-tile triangle bins of the rasterizer: 64x64-pixel tiles, binCap entries each
         c->tilesX = (c->width + CHORD_TILE - 1) >> CHORD_TILE_SHIFT; c->tilesY = (c->height + CHORD_TILE - 1) >> CHORD_TILE_SHIFT;
         c->binCap = CHORD_BIN_CAP;              // 4K: 2 passes x 2040 tiles x 16384 x 4 B = 267 MB
@@ -172,6 +173,18 @@ int flush_view(ChordCtx* c)
     if (c->zeroFrameStateInCull) {
         CHORD_HIP(c, hipMemsetAsync(c->dFrameState, 0, c->frameStateZeroBytes, c->stream));
         c->zeroFrameStateInCull = false;
+    }
+    return CHORDVIS_OK;
+}
+
+// The tail of the last fused frame's history HZB (mips 6.. + valid range) normally rides on the next frame's first
+// kernel; anything else that is about to read that chain launches it now.
+int flush_pending_tail(ChordCtx* c)
+{
+    if (c->pendingTailSlot) {
+        launch_hzb_tail(c, c->hzb[c->pendingTailSlot], true, true);
+        c->pendingTailSlot = 0;
+        CHORD_HIP(c, hipGetLastError());
     }
     return CHORDVIS_OK;
 }
@@ -274,6 +287,7 @@ const char* chordvis_last_error(ChordCtx* c) { return c ? c->lastError.c_str() :
 int chordvis_sync(ChordCtx* c)
 {
     if (!c) return CHORDVIS_E_INVALID;
+    { const int rc = flush_pending_tail(c); if (rc) return rc; }
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
     return CHORDVIS_OK;
 }
@@ -435,6 +449,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     if ((rc = dalloc(c, &c->dLargeList, (size_t)c->largeCap))) return rc;
     c->sceneLoaded = true;
     c->historySlot = 0;
+    c->pendingTailSlot = 0;
     return CHORDVIS_OK;
 }
 
@@ -562,6 +577,7 @@ int chordvis_hzb_culling(ChordCtx* c, const ChordHZB* hzb, int bFirstStage, Chor
     int rc = ready(c, "hzb_culling");
     if (rc) return rc;
     if (!hzb || !hzb->minTexels || !in.count || !in.cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling: invalid HZB or command list");
+    if ((rc = flush_pending_tail(c))) return rc;
     if ((rc = flush_view(c))) return rc;
     const HzbBuffers hb = from_handle(hzb);
     const CmdList inL = from_handle(in);
@@ -627,6 +643,7 @@ int chordvis_build_hzb(ChordCtx* c, int bBuildMin, int bBuildMax, int bBuildVali
     if (rc) return rc;
     if (slot < 0 || slot > 2 || !(bBuildMin || bBuildMax) || (bBuildValidRange && !(bBuildMin && bBuildMax)))   // hzb.cpp:43-47
         return fail(c, CHORDVIS_E_INVALID, "build_hzb: slot in 0..2, at least one channel, valid range needs min and max");
+    if ((rc = flush_pending_tail(c))) return rc;
     launch_hzb_build(c, c->hzb[slot], bBuildMin != 0, bBuildMax != 0, bBuildValidRange != 0, false);
     CHORD_HIP(c, hipGetLastError());
     if (out) {
@@ -640,6 +657,7 @@ int chordvis_build_hzb(ChordCtx* c, int bBuildMin, int bBuildMax, int bBuildVali
 int chordvis_reset_history(ChordCtx* c)
 {
     if (!c) return CHORDVIS_E_INVALID;
+    c->pendingTailSlot = 0;
     c->historySlot = 0;
     return CHORDVIS_OK;
 }
@@ -653,21 +671,31 @@ static int render_frame_impl(ChordCtx* c)
     begin_frame_stamps(c);
     if ((rc = begin_frame_clear(c))) return rc;                                       // renderer.cpp:315
     record(c, S_CLEAR);
-    ChordCountAndCmd post;
-    if ((rc = chordvis_instance_culling(c, &post))) return rc;                        // :321
-    record(c, S_CULL);
     ChordHZB hist;
     const bool haveHist = c->historySlot != 0;
     if (haveHist) hist = c->hzb[c->historySlot].handle();
     const int next = c->historySlot == 1 ? 2 : 1;
+    const bool hzbOn = haveHist && (c->hView.flags & CHORD_FLAG_HZB_CULL);           // mesh_raster.cpp:293
+    // instanceCulling :321 -- for short scenes the scatter kernel also runs HZB phase 0 of stage 0 (the test reads the
+    // history chain, whose tail the frame's first kernel has just completed)
+    const bool fusedPhase0 = launch_group_cull(c, c->lists[0], hzbOn ? &c->hzb[c->historySlot] : nullptr);
+    CHORD_HIP(c, hipGetLastError());
+    const ChordCountAndCmd post = c->lists[0].handle();
+    record(c, S_CULL);
     // buildHZB is fused into the raster: the tile kernel reduces every finished 64x64 tile to mips 0..5 of the
     // chain kept as history (and of the temporary chain stage 1 culls against); only the one-block tail remains.
     c->fuseHzb = true;
     c->fuseHzbSlot = next;
-    c->fuseHzbTemp = haveHist && (c->hView.flags & CHORD_FLAG_HZB_CULL);
+    c->fuseHzbTemp = hzbOn;
     ChordCountAndCmd rejected;
     int stage1 = 0;
-    rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1);   // :326
+    if (fusedPhase0) {                                                                // gltfVisibilityRenderingStage0 :326 with the cull already done
+        rc = chordvis_render_mesh(c, c->lists[1].handle());
+        rejected = c->lists[2].handle();
+        stage1 = 1;
+    } else {
+        rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1);   // :326
+    }
     record(c, S_STAGE0_END);
     c->shouldStage1 = stage1 != 0;
     if (!rc && stage1) {
@@ -679,8 +707,10 @@ static int render_frame_impl(ChordCtx* c)
     }
     c->fuseHzb = false;
     if (rc) return rc;
-    launch_hzb_tail(c, c->hzb[next], true, true);                                     // buildHZB(min,max,range)  :343
-    CHORD_HIP(c, hipGetLastError());
+    // buildHZB(min,max,range) :343 -- mips 0..5 are written; the one-block tail (mips 6.., range) is carried by the next
+    // frame's first kernel, or launched by whoever reads the chain first (flush_pending_tail)
+    c->hzb[next].valid = true;
+    c->pendingTailSlot = next;
     record(c, S_HZBF);
     c->historySlot = next;                                                            // :489
     c->inFrame = false;
@@ -692,6 +722,7 @@ static int frame_phase_a_impl(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_a");
     if (rc) return rc;
+    if ((rc = flush_pending_tail(c))) return rc;
     begin_frame_stamps(c);
     if ((rc = begin_frame_clear(c))) return rc;
     record(c, S_CLEAR);
@@ -768,6 +799,7 @@ int chordvis_last_frame_cmds(ChordCtx* c, ChordCountAndCmd* out)
 int chordvis_history_hzb(ChordCtx* c, ChordHZB* out)
 {
     if (!c || !out || c->historySlot == 0) return fail(c, CHORDVIS_E_INVALID, "history_hzb: no history yet");
+    { const int rc = flush_pending_tail(c); if (rc) return rc; }
     *out = c->hzb[c->historySlot].handle();
     return CHORDVIS_OK;
 }
@@ -858,6 +890,7 @@ int chordvis_readback_cmds(ChordCtx* c, ChordCountAndCmd h, ChordDrawCmd* host, 
 int chordvis_readback_hzb(ChordCtx* c, const ChordHZB* hzb, uint16_t* hostMin, uint16_t* hostMax, uint32_t hostValidRange[2])
 {
     if (!c || !hzb) return fail(c, CHORDVIS_E_INVALID, "readback_hzb: null handle");
+    { const int rc = flush_pending_tail(c); if (rc) return rc; }
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
     const size_t bytes = sizeof(uint16_t) * hzb->desc.totalTexels;
     if (hostMin && hzb->minTexels) CHORD_HIP(c, hipMemcpy(hostMin, hzb->minTexels, bytes, hipMemcpyDeviceToHost));
@@ -869,6 +902,7 @@ int chordvis_readback_hzb(ChordCtx* c, const ChordHZB* hzb, uint16_t* hostMin, u
 int chordvis_upload_history_hzb(ChordCtx* c, const uint16_t* hostMin)
 {
     if (!c || !hostMin || !c->dVis) return fail(c, CHORDVIS_E_INVALID, "upload_history_hzb: no gbuffer");
+    c->pendingTailSlot = 0;                              // the uploaded chain replaces whatever was pending
     const int slot = c->historySlot == 1 ? 2 : 1;
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
     CHORD_HIP(c, hipMemcpy(c->hzb[slot].minTexels, hostMin, sizeof(uint16_t) * c->hzb[slot].desc.totalTexels, hipMemcpyHostToDevice));
@@ -998,6 +1032,7 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
 {
     if (!c || !out) return fail(c, CHORDVIS_E_INVALID, "stats: null argument");
     std::memset(out, 0, sizeof(*out));
+    { const int rc = flush_pending_tail(c); if (rc) return rc; }
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
     uint32_t counts[4] = {0, 0, 0, 0};
     CHORD_HIP(c, hipMemcpy(counts, c->dCounts, sizeof(counts), hipMemcpyDeviceToHost));

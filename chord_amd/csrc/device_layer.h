@@ -115,6 +115,8 @@ struct DeviceCounters {
     uint32_t pad;
     // triangles (meshlet triangle counts) of the commands each list producer emitted this frame
     unsigned long long trisInstanceCulled, trisHzbVisible0, trisHzbVisible1, pad2;
+    uint32_t orderTicket[2];                    // per raster pass: workgroups of the merged clip / bin / order launch that are done
+    uint32_t pad3[2];
 };
 
 // Everything a frame zeroes lives in ONE allocation so the frame starts with one memset:
@@ -222,6 +224,7 @@ struct ChordCtx {
     // HZB: slot 0 temp, 1/2 history ping-pong
     chord::HzbBuffers hzb[3];
     int historySlot = 0;              // 0 = none, else 1 or 2
+    int pendingTailSlot = 0;          // history chain whose mips 6.. + valid range are still to be reduced (carried by the next frame's first kernel)
     uint32_t* dRangePartials = nullptr;   // per mip-0 block {min, max} of valid depth
     uint32_t* dTileRange = nullptr;       // per 64x64 tile {min, max} of valid depth (fused HZB)
     bool fuseHzb = false;                 // inside render_frame: the tile kernel emits HZB mips 0..5
@@ -288,7 +291,7 @@ int fail(ChordCtx* ctx, int code, const char* what, hipError_t e = hipSuccess);
     } while (0)
 
 // kernel launchers (implemented in the .hip translation units) ---------------------------------
-void launch_group_cull(ChordCtx* c, const CmdList& out);
+bool launch_group_cull(ChordCtx* c, const CmdList& out, const HzbBuffers* fusedHzb0 = nullptr);   // true: HZB phase 0 ran inside (lists 1 / 2 are filled)
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
                      const CmdList* outRejected);
 hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles);   // first failing HIP call, or hipSuccess

@@ -17,10 +17,17 @@
 //
 // Memory-bound integer/fp32 VALU work: no MFMA.  Built with -ffp-contract=off.
 
-#include "device_layer.h"
-#include "device_math.h"
+#include "hzb_device.h"
+
+#include <cstring>
 
 namespace chord {
+
+// The previous frame's HZB tail (mips 6.. of the chain kept as history + its valid range; renderer.cpp:343) rides on the
+// first kernel of the NEXT frame as one extra workgroup: it is a one-block, latency-bound job (9 us as a launch of its
+// own) whose result nothing needs before the next frame's HZB cull, two kernels later (chordvis_history_hzb and every
+// other reader launch it on demand).
+struct FrameTail { HzbParams p; uint32_t run; };
 
 // ------------------------------------------------------------------------------ object stage --
 
@@ -183,15 +190,16 @@ struct GroupCullParams {
 __global__ __launch_bounds__(256) void object_cull_kernel(const ChordObject* __restrict__ objects, const DObjStatic* __restrict__ objStatic,
                                                           const DPrim* __restrict__ prims, const DView dv, DView* __restrict__ dviewOut,
                                                           DObjFrame* __restrict__ objFrame, uint32_t objectCount,
-                                                          uint4* __restrict__ zeroBase, uint32_t zeroVec4)
+                                                          uint4* __restrict__ zeroBase, uint32_t zeroVec4, FrameTail tail)
 {
+    if (tail.run && blockIdx.x == gridDim.x - 1u) { hzb_tail_block(tail.p, 1, 1, (uint32_t)CHORD_TILE_SHIFT); return; }
     const uint32_t o = blockIdx.x * 256u + threadIdx.x;
     if (dviewOut && blockIdx.x == 0) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
         uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
         for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += 256u) dst[i] = src[i];
     }
-    for (uint32_t i = o; i < zeroVec4; i += gridDim.x * 256u) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t i = o; i < zeroVec4; i += (gridDim.x - tail.run) * 256u) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
     if (o < objectCount) object_frame(objects, objStatic, prims, dv, objFrame, o);
 }
 
@@ -199,15 +207,17 @@ __global__ __launch_bounds__(256) void object_cull_kernel(const ChordObject* __r
 // groups span several blocks is done by each of them -- same values), the frame's housekeeping that used to ride on the
 // object kernel (view block published for the later kernels, FrameState zeroed), then the groups.
 __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p, const DView dv, DView* __restrict__ dviewOut,
-                                                               DObjFrame* __restrict__ objFrameOut, uint4* __restrict__ zeroBase, uint32_t zeroVec4)
+                                                               DObjFrame* __restrict__ objFrameOut, uint4* __restrict__ zeroBase, uint32_t zeroVec4,
+                                                               uint32_t cullBlocks, FrameTail tail)
 {
+    if (tail.run && blockIdx.x == cullBlocks) { hzb_tail_block(tail.p, 1, 1, (uint32_t)CHORD_TILE_SHIFT); return; }
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (dviewOut && blockIdx.x == 0) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
         uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
         for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += 256u) dst[i] = src[i];
     }
-    for (uint32_t i = t; i < zeroVec4; i += gridDim.x * 256u) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t i = t; i < zeroVec4; i += cullBlocks * 256u) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
     if (p.groupInstances && objFrameOut) {
         const uint32_t first = blockIdx.x * 256u;
         if (first < p.groupInstances) {
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
     uint32_t total, blockTris;
     (void)block_excl_scan(__popc(mask), &total);
     (void)block_excl_scan(tris, &blockTris);
-    if (threadIdx.x == 0) { p.blockCounts[blockIdx.x] = total; p.blockCounts[gridDim.x + blockIdx.x] = blockTris; }
+    if (threadIdx.x == 0) { p.blockCounts[blockIdx.x] = total; p.blockCounts[cullBlocks + blockIdx.x] = blockTris; }
 }
 
 // Long scenes (thousands of count blocks): one workgroup turns the per-block counts into exclusive offsets, so the
@@ -282,60 +292,6 @@ __global__ __launch_bounds__(1024) void group_cull_prefix_kernel(uint32_t* __res
         *outCount = carry;
         if (t) atomicAdd(&counters->trisInstanceCulled, t);
     }
-}
-
-// PREFIXED: blockCounts already holds exclusive offsets (group_cull_prefix_kernel ran); otherwise every block sums the
-// preceding blocks' counts itself (a few hundred blocks: cheaper than one more launch).
-template <bool PREFIXED>
-__global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams p, ChordDrawCmd* __restrict__ outCmds,
-                                                                 uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters)
-{
-    __shared__ uint32_t red[256];
-    uint32_t blockBase;
-    if (PREFIXED) blockBase = p.blockCounts[blockIdx.x];
-    else {
-        uint32_t part = 0;
-        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) part += p.blockCounts[b];
-        red[threadIdx.x] = part;
-        __syncthreads();
-        for (uint32_t s = 128; s > 0; s >>= 1) {
-            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-            __syncthreads();
-        }
-        blockBase = red[0];
-        __syncthreads();
-    }
-
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t mask = t < p.groupInstances ? p.groupMask[t] : 0u;
-    uint32_t total;
-    const uint32_t off = block_excl_scan(__popc(mask), &total);
-    uint32_t tris = 0;
-    if (mask) {
-        const uint32_t o = p.groupOwner[t];
-        const DObjStatic st = p.objStatic[o];
-        const DPrim& prim = p.prims[st.prim];
-        const DGroup& g = p.groups[prim.groupBase + (t - st.groupBase)];
-        const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
-        uint32_t slot = blockBase + off;
-        for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
-            if (mask & (1u << i)) {
-                ChordDrawCmd cmd;
-                cmd.objectId = o;
-                cmd.meshletId = prim.meshletBase + p.groupIndices[idxBase + i];
-                cmd.slot = slot;                                            // instance_culling.hlsl:203-206
-                outCmds[slot] = cmd;
-                if (!PREFIXED) tris += (p.meshlets[cmd.meshletId].vertexTriangleCount >> 8) & 0xFFu;
-                slot++;
-            }
-        }
-    }
-    if (PREFIXED) return;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *outCount = blockBase + total;
-    // triangles this list submits (the Gtri/s unit): one fire-and-forget atomic per block
-    uint32_t blockTris;
-    (void)block_excl_scan(tris, &blockTris);
-    if (threadIdx.x == 0 && blockTris) atomicAdd(&counters->trisInstanceCulled, (unsigned long long)blockTris);
 }
 
 // -------------------------------------------------------------------------------- HZB stage --
@@ -418,6 +374,107 @@ __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DV
     return visible;
 }
 
+// PREFIXED: blockCounts already holds exclusive offsets (group_cull_prefix_kernel ran); otherwise every block sums the
+// preceding blocks' counts itself (a few hundred blocks: cheaper than one more launch).
+// HZB0: the phase-0 occlusion test of every command rides on the scatter (short scenes: hzbMainViewCullingCS as a launch of
+// its own costs ~7 us for a few thousand commands, nearly all of it launch + dependent-load latency); the visible /
+// rejected lists are reserved once per block like hzb_cull_kernel does.
+template <bool PREFIXED, bool HZB0>
+__global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams p, ChordDrawCmd* __restrict__ outCmds,
+                                                                 uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters,
+                                                                 HzbCullParams hp)
+{
+    __shared__ uint32_t red[256];
+    uint32_t blockBase;
+    if (PREFIXED) blockBase = p.blockCounts[blockIdx.x];
+    else {
+        uint32_t part = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) part += p.blockCounts[b];
+        red[threadIdx.x] = part;
+        __syncthreads();
+        for (uint32_t s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        blockBase = red[0];
+        __syncthreads();
+    }
+
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t mask = t < p.groupInstances ? p.groupMask[t] : 0u;
+    uint32_t total;
+    const uint32_t off = block_excl_scan(__popc(mask), &total);
+    uint32_t tris = 0;
+    uint32_t visBits = 0, rejBits = 0, visTris = 0;
+    ChordDrawCmd hcmd[CHORD_GROUP_MAX_MESHLETS];
+    if (mask) {
+        const uint32_t o = p.groupOwner[t];
+        const DObjStatic st = p.objStatic[o];
+        const DPrim& prim = p.prims[st.prim];
+        const DGroup& g = p.groups[prim.groupBase + (t - st.groupBase)];
+        const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
+        uint32_t slot = blockBase + off;
+        for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
+            if (mask & (1u << i)) {
+                ChordDrawCmd cmd;
+                cmd.objectId = o;
+                cmd.meshletId = prim.meshletBase + p.groupIndices[idxBase + i];
+                cmd.slot = slot;                                            // instance_culling.hlsl:203-206
+                outCmds[slot] = cmd;
+                if (!PREFIXED) tris += (p.meshlets[cmd.meshletId].vertexTriangleCount >> 8) & 0xFFu;
+                if (HZB0) {
+                    uint32_t t = 0;
+                    hcmd[i] = cmd;
+                    if (hzb_cmd_visible<0>(hp, *hp.dview, cmd, t)) { visBits |= 1u << i; visTris += t; }
+                    else rejBits |= 1u << i;
+                }
+                slot++;
+            }
+        }
+    }
+    if (HZB0) {
+        __shared__ uint32_t sWaveH[4], sBaseH[2];
+        __shared__ unsigned long long sTrisH[4];
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const uint32_t mine = (uint32_t)__popc(visBits) | ((uint32_t)__popc(rejBits) << 16);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t nb = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += nb; }
+        unsigned long long tsum = visTris;
+#pragma unroll
+        for (int offs = 32; offs > 0; offs >>= 1) tsum += __shfl_down(tsum, offs, 64);
+        if (lane == 63u) sWaveH[wave] = incl;
+        if (lane == 0u) sTrisH[wave] = tsum;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; w++) { const uint32_t cc = sWaveH[w]; if (w < wave) before += cc; all += cc; }
+        if (threadIdx.x == 0) {
+            const uint32_t nv = all & 0xFFFFu, nr = all >> 16;
+            sBaseH[0] = nv ? atomicAdd(hp.visCount, nv) : 0u;
+            sBaseH[1] = nr ? atomicAdd(hp.rejCount, nr) : 0u;
+            const unsigned long long tt = sTrisH[0] + sTrisH[1] + sTrisH[2] + sTrisH[3];
+            if (tt) atomicAdd(&hp.counters->trisHzbVisible0, tt);
+        }
+        __syncthreads();
+        const uint32_t excl = before + incl - mine;
+        uint32_t vslot = sBaseH[0] + (excl & 0xFFFFu), rslot = sBaseH[1] + (excl >> 16);
+#pragma unroll
+        for (uint32_t k = 0; k < CHORD_GROUP_MAX_MESHLETS; k++) {
+            if (visBits & (1u << k)) hp.visCmds[vslot++] = hcmd[k];
+            if (rejBits & (1u << k)) hp.rejCmds[rslot++] = hcmd[k];
+        }
+    }
+    if (PREFIXED) return;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *outCount = blockBase + total;
+    // triangles this list submits (the Gtri/s unit): one fire-and-forget atomic per block
+    uint32_t blockTris;
+    (void)block_excl_scan(tris, &blockTris);
+    if (threadIdx.x == 0 && blockTris) atomicAdd(&counters->trisInstanceCulled, (unsigned long long)blockTris);
+}
+
+// -------------------------------------------------------------------------------- HZB stage (kernels) --
+
 // One thread per 4 commands, block-wide scan of the per-thread counts, ONE reservation per list and 1024 commands:
 // the reference's one InterlockedAdd per wave and list (hzb_mainview_culling.hlsl:163-185) puts every wave of the
 // dispatch on the same two counter words -- 8 120 returning atomics on one 64-byte line at 260 k commands (config 4)
@@ -481,7 +538,22 @@ __global__ __launch_bounds__(256) void hzb_cull_kernel(HzbCullParams p)
 
 // ---------------------------------------------------------------------------------- launchers --
 
-void launch_group_cull(ChordCtx* c, const CmdList& out)
+static HzbCullParams make_hzb_cull_params(ChordCtx* c, const HzbBuffers& hzb, const CmdList& in, const CmdList& outVisible, const CmdList* outRejected)
+{
+    HzbCullParams p;
+    p.objFrame = c->dObjFrame; p.meshlets = c->dMeshlets; p.dview = c->dView;
+    p.hzbMin = hzb.minTexels; p.desc = hzb.desc;
+    p.inCount = in.count; p.inCmds = in.cmds;
+    p.visCount = outVisible.count; p.visCmds = outVisible.cmds;
+    p.rejCount = outRejected ? outRejected->count : nullptr;
+    p.rejCmds = outRejected ? outRejected->cmds : nullptr;
+    p.counters = c->dCounters;
+    return p;
+}
+
+// fusedHzb0: short scenes only -- the scatter also runs HZB phase 0 against `fusedHzb0` into lists 1 (visible) / 2 (rejected);
+// returns true when it did (the caller then skips its hzbCulling pass).
+bool launch_group_cull(ChordCtx* c, const CmdList& out, const HzbBuffers* fusedHzb0)
 {
     GroupCullParams p;
     p.objects = c->dObjects; p.objStatic = c->dObjStatic; p.objFrame = c->dObjFrame; p.prims = c->dPrims;
@@ -496,21 +568,39 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
         c->zeroFrameStateInCull = false;
     }
     DView* publish = c->viewDirty ? c->dView : (DView*)nullptr;
+    FrameTail tail;
+    std::memset(&tail, 0, sizeof(tail));
+    if (c->pendingTailSlot) {                              // the previous frame's buildHZB tail: one extra workgroup
+        tail.p = make_hzb_tail_params(c, c->hzb[c->pendingTailSlot]);
+        tail.run = 1u;
+        c->pendingTailSlot = 0;
+    }
+    FrameTail none;
+    std::memset(&none, 0, sizeof(none));
     if (blocks > 512u) {
-        hipLaunchKernelGGL(object_cull_kernel, dim3((c->objectCount + 255u) / 256u), dim3(256), 0, c->stream, c->dObjects, c->dObjStatic,
-                           c->dPrims, c->hView, publish, c->dObjFrame, c->objectCount, zeroBase, zeroVec4);
+        hipLaunchKernelGGL(object_cull_kernel, dim3((c->objectCount + 255u) / 256u + tail.run), dim3(256), 0, c->stream, c->dObjects, c->dObjStatic,
+                           c->dPrims, c->hView, publish, c->dObjFrame, c->objectCount, zeroBase, zeroVec4, tail);
         hipLaunchKernelGGL(group_cull_count_kernel, dim3(blocks), dim3(256), 0, c->stream, p, c->hView, (DView*)nullptr,
-                           (DObjFrame*)nullptr, (uint4*)nullptr, 0u);
+                           (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
     } else {
-        hipLaunchKernelGGL(group_cull_count_kernel, dim3(blocks), dim3(256), 0, c->stream, p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4);
+        hipLaunchKernelGGL(group_cull_count_kernel, dim3(blocks + tail.run), dim3(256), 0, c->stream, p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4,
+                           blocks, tail);
     }
     c->viewDirty = false;
+    HzbCullParams hp;
+    std::memset(&hp, 0, sizeof(hp));
     if (blocks > 512u) {
         hipLaunchKernelGGL(group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters);
-        hipLaunchKernelGGL(group_cull_scatter_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
-    } else {
-        hipLaunchKernelGGL(group_cull_scatter_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+        hipLaunchKernelGGL((group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, hp);
+        return false;
     }
+    if (fusedHzb0 && fusedHzb0->minTexels) {
+        hp = make_hzb_cull_params(c, *fusedHzb0, out, c->lists[1], &c->lists[2]);
+        hipLaunchKernelGGL((group_cull_scatter_kernel<false, true>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, hp);
+        return true;
+    }
+    hipLaunchKernelGGL((group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, hp);
+    return false;
 }
 
 // ---- sharded frames: this rank's clusters of a raster pass -----------------------------------------------------
@@ -610,14 +700,7 @@ void launch_stripe_filter(ChordCtx* c, const CmdList& in, const CmdList& out)
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
                      const CmdList* outRejected)
 {
-    HzbCullParams p;
-    p.objFrame = c->dObjFrame; p.meshlets = c->dMeshlets; p.dview = c->dView;
-    p.hzbMin = hzb.minTexels; p.desc = hzb.desc;
-    p.inCount = in.count; p.inCmds = in.cmds;
-    p.visCount = outVisible.count; p.visCmds = outVisible.cmds;
-    p.rejCount = outRejected ? outRejected->count : nullptr;
-    p.rejCmds = outRejected ? outRejected->cmds : nullptr;
-    p.counters = c->dCounters;
+    const HzbCullParams p = make_hzb_cull_params(c, hzb, in, outVisible, outRejected);
     const bool longList = in.capacity > 65536u;
     uint32_t blocks = (in.capacity + (longList ? 1023u : 255u)) / (longList ? 1024u : 256u);
     const uint32_t maxBlocks = (uint32_t)c->numCUs * 8u;

@@ -86,6 +86,9 @@ struct RasterParams {
 #define DBG_NO_SPLIT    2048u // tile order kernel never cuts a bin into slices
 #define DBG_NO_TINY     32u   // tile kernel skips the per-lane scan of tiny triangles
 #define DBG_TILE_EXIT   64u   // tile kernel of passes >= 1 returns at once (launch-floor measurement)
+#define DBG_NO_ENTRY    8192u // tile kernel fetches bin entries and records but does nothing with them
+#define DBG_NO_BATCH    16384u // tile kernel skips the bin altogether (tile in + tile out only)
+#define DBG_NO_UNITS    4096u // tile kernel skips the row units (entries are still fetched, set up, scanned and listed)
 
 __device__ __forceinline__ int32_t bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
@@ -816,21 +819,27 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 #define TILE_SLICE_SHIFT CHORD_TILE_SLICE_SHIFT
 #define TILE_SLICE (1u << TILE_SLICE_SHIFT)
 #define TILE_SPLIT_MIN 6144u       // bins up to this many entries stay whole
-__global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
+// NT threads of one workgroup.  COHERENT: the bin counts were written by other workgroups of THIS launch (returning
+// device-scope atomics, all performed before the caller drew its ticket): read them with device-scope atomic loads, a
+// plain load may be served from this XCD's L2.
+template <uint32_t NT, bool COHERENT>
+__device__ __forceinline__ void tile_order_part(const RasterParams& p)
 {
     __shared__ uint32_t hist[20], base[20], cursor[20], splitItems;
     const uint32_t tiles = p.tilesX * p.tilesY;
     if (threadIdx.x < 20u) { hist[threadIdx.x] = 0; cursor[threadIdx.x] = 0; }
     if (threadIdx.x == 0) splitItems = 0;
     __syncthreads();
-    constexpr uint32_t PER_THREAD = CHORD_MAX_TILES / 1024u;
+    constexpr uint32_t PER_THREAD = CHORD_MAX_TILES / NT;
     uint32_t myBucket[PER_THREAD], myPos[PER_THREAD], mySlices[PER_THREAD], myCount[PER_THREAD];
 #pragma unroll
     for (uint32_t k = 0; k < PER_THREAD; k++) {
-        const uint32_t t = threadIdx.x + k * 1024u;
+        const uint32_t t = threadIdx.x + k * NT;
         myBucket[k] = 0xFFFFFFFFu; myPos[k] = 0; mySlices[k] = 1; myCount[k] = 0;
         if (t < tiles) {
-            const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], bin_capacity(p));
+            const uint32_t raw = COHERENT ? __hip_atomic_load(&p.tileCount[(size_t)t * TC_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : p.tileCount[(size_t)t * TC_STRIDE];
+            const uint32_t c = min(raw, bin_capacity(p));
             myCount[k] = c;
             if (c > TILE_SPLIT_MIN && !(p.debug & DBG_NO_SPLIT)) {
                 mySlices[k] = min((c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT, CHORD_TILE_MAX_SLICES);
@@ -852,7 +861,7 @@ __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < PER_THREAD; k++) {
-        const uint32_t t = threadIdx.x + k * 1024u;
+        const uint32_t t = threadIdx.x + k * NT;
         if (myBucket[k] == 0xFFFFFFFFu) continue;
         if (myBucket[k] == 18u) {
             for (uint32_t j = 0; j < mySlices[k]; j++) p.tileOrder[1u + myPos[k] + j] = make_uint2(t | (j << 12) | ((mySlices[k] - 1u) << 22), myCount[k]);
@@ -860,6 +869,29 @@ __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
             p.tileOrder[1u + base[myBucket[k]] + atomicAdd(&cursor[myBucket[k]], 1u)] = make_uint2(t, myCount[k]);   // the count rides along: one round trip less per tile
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
+{
+    tile_order_part<1024u, false>(p);
+}
+
+// Short scenes: clipper, large-record binning and the tile schedule in ONE launch of a small grid.  Every workgroup
+// draws a ticket when its bin writes are done (their bin-count atomics return the slot, so they have been performed by
+// then); the last one orders the tiles.  (With the ~1100 workgroups a long scene wants, the tickets alone -- ~88
+// returning atomics per microsecond on one word -- cost more than the launch they save: tools/microbench/launch_floor.)
+#define MERGED_CLIP_BLOCKS 32u
+#define MERGED_BLOCKS 128u
+__global__ __launch_bounds__(256) void raster_clip_bin_order_kernel(RasterParams p, uint32_t* ticket)
+{
+    __shared__ uint32_t sLast;
+    if (blockIdx.x < MERGED_CLIP_BLOCKS) raster_clip_part(p, blockIdx.x, MERGED_CLIP_BLOCKS);
+    else raster_bin_large_part(p, blockIdx.x - MERGED_CLIP_BLOCKS, gridDim.x - MERGED_CLIP_BLOCKS);
+    __syncthreads();
+    if (threadIdx.x == 0) sLast = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!sLast) return;
+    tile_order_part<256u, true>(p);
 }
 
 // ---- per-tile resolve kernel ------------------------------------------------------------------
@@ -953,7 +985,9 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
 //   kind 1  double  |coordinates| < 2^25 sub-pixels: every product and sum below 2^53, so fp64 is exact
 //                   and v_cvt_f32_f64 IS the canonical (float)(double)E
 //   kind 2  int64   anything else (guard-band monsters)
+#ifndef TINY_AREA
 #define TINY_AREA 16
+#endif
 
 struct UnitParams {           // one batch entry, as the row loop wants it
     int32_t X[3], Y[3];
@@ -966,6 +1000,10 @@ struct UnitParams {           // one batch entry, as the row loop wants it
 // consecutive banks; the 64-byte-stride AoS form was a 32-way bank conflict on every store)
 #define UNIT_WORDS 13
 #define TB 512                  // threads per tile workgroup = entries per batch
+#ifndef CHORD_TILE_V
+#define CHORD_TILE_V 3          // 1: (triangle, row) units re-derived per unit; 2: pre-computed entries + row segments; 3: + unit lists
+#endif
+#define UNIT_CAP 4096           // units per round of a batch (CHORD_TILE_V 3)
 struct UnitParamsSoA { uint32_t w[UNIT_WORDS][TB]; };
 
 __device__ __forceinline__ void unit_store(UnitParamsSoA& soa, uint32_t t, const UnitParams& u)
@@ -1051,6 +1089,172 @@ __device__ __forceinline__ uint32_t block_scan_tb(uint32_t v, uint32_t* waveSums
     for (uint32_t w = 0; w < TB / 64u; w++) { const uint32_t sw = waveSums[w]; if (w < wave) base += sw; tot += sw; }
     *total = tot;
     return base + incl - v;
+}
+
+
+// ---- batch entries with pre-computed edge constants (CHORD_TILE_V >= 2) -------------------------------------------
+// The thread that fetches a bin entry also reduces it to what a pixel row needs, ONCE: for triangles whose vertices are
+// at most 64 px apart (nearly all) the three edge functions as  E_i(lx, ly) = C_i + ((a_i * lx + b_i * ly) << 8)  with
+// C_i the (top-left-biased) value at the tile's origin pixel and a_i, b_i the 16-bit pixel steps / 256 -- a row unit
+// then costs two multiply-adds per edge instead of re-deriving deltas, orientation, biases and the 24.8 products
+// (about 50 of the ~135 instructions a unit spent before its first pixel).  All values are exact 32-bit integers:
+// |a|, |b| <= 2^14 and a pixel of the tile is at most 2^15 + 128 sub-pixels from a vertex, so |E| < 2^31.
+// Rows wider than SEG pixels are cut into SEG-pixel segments, one unit each: a wave's row loops are at most SEG trips
+// long whatever mix of triangles the tile holds (62 % of the lanes were active before), and a tile covered by a few
+// huge triangles becomes hundreds of units instead of 64.
+// Wide triangles (kind 1: fp64 edges, kind 2: int64) keep their vertices and derive the edges per unit as before.
+#ifndef SEG_SHIFT
+#define SEG_SHIFT 6             // 64: one unit per row (16 / 32 were measured 3 % / 1 % slower on config 3: more units, same trips)
+#endif
+#define SEG (1 << SEG_SHIFT)
+#define ENTRY_WORDS 12
+struct EntrySoA { uint32_t w[ENTRY_WORDS][TB]; };
+#define EF_KIND_SHIFT 24          // box word: x0 | y0 << 6 | x1 << 12 | y1 << 18 | kind << 24 | bias1 << 26 | bias2 << 27 | sneg << 28
+
+template <typename E_t>
+__device__ __forceinline__ int32_t scan_span(unsigned long long* __restrict__ tileRow, E_t E0, E_t E1, E_t E2, E_t st0, E_t st1, E_t st2,
+                                          E_t bias1, E_t bias2, float d0, float e1, float e2, float invA, uint32_t payloadIn,
+                                          int32_t lx0, int32_t lx1, bool noPixels)
+{
+    // Span of the row in steps k from lx0 (see scan_row): fp32 estimates only BOUND the loop, coverage is exact inside.
+    float klo = 0.0f, khi = (float)(lx1 - lx0);
+    {
+        const float e[3] = {(float)E0, (float)E1, (float)E2}, t[3] = {(float)st0, (float)st1, (float)st2};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float q = fminf(fmaxf(-e[i] * __builtin_amdgcn_rcpf(t[i]), -4.0f), 4096.0f);   // NaN (0 * inf) -> -4
+            if (t[i] > 0.0f) klo = fmaxf(klo, floorf(q) - 1.0f);
+            else if (t[i] < 0.0f) khi = fminf(khi, floorf(q) + 1.0f);
+            else if (e[i] < 0.0f) khi = -1.0f;                                                  // constant and outside
+        }
+    }
+    const int32_t k0 = (int32_t)klo, k1 = (int32_t)khi;
+    E0 += (E_t)k0 * st0; E1 += (E_t)k0 * st1; E2 += (E_t)k0 * st2;
+    unsigned long long* px = tileRow + lx0 + k0;
+    const unsigned long long payload = noPixels ? 0ull : (unsigned long long)payloadIn;
+    for (int32_t k = k0; k <= k1; k++) {
+        const bool inside = std::is_floating_point<E_t>::value ? (E0 >= (E_t)0 && E1 >= (E_t)0 && E2 >= (E_t)0)
+                                                              : (((int64_t)E0 | (int64_t)E1 | (int64_t)E2) >= 0);
+        const float l1 = (float)(double)(E1 - bias1) * invA, l2 = (float)(double)(E2 - bias2) * invA;
+        const float z = (d0 + l1 * e1) + l2 * e2;
+        const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | payload;
+        atomicMax(px, inside && !noPixels ? packed : 0ull);      // ds_max_u64
+        E0 += st0; E1 += st1; E2 += st2; px++;
+    }
+    return max(k1 - k0 + 1, 0);
+}
+
+// int32 specialisation of the conversion (float)(double)E: exact for |E| < 2^31 either way, one instruction instead of two
+__device__ __forceinline__ int32_t scan_span_i32(unsigned long long* __restrict__ tileRow, int32_t E0, int32_t E1, int32_t E2,
+                                              int32_t st0, int32_t st1, int32_t st2, int32_t bias1, int32_t bias2,
+                                              float d0, float e1, float e2, float invA, uint32_t payloadIn,
+                                              int32_t lx0, int32_t lx1, bool noPixels)
+{
+    float klo = 0.0f, khi = (float)(lx1 - lx0);
+    {
+        const float e[3] = {(float)E0, (float)E1, (float)E2}, t[3] = {(float)st0, (float)st1, (float)st2};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float q = fminf(fmaxf(-e[i] * __builtin_amdgcn_rcpf(t[i]), -4.0f), 4096.0f);
+            if (t[i] > 0.0f) klo = fmaxf(klo, floorf(q) - 1.0f);
+            else if (t[i] < 0.0f) khi = fminf(khi, floorf(q) + 1.0f);
+            else if (e[i] < 0.0f) khi = -1.0f;
+        }
+    }
+    const int32_t k0 = (int32_t)klo, k1 = (int32_t)khi;
+    E0 += __mul24(k0, st0); E1 += __mul24(k0, st1); E2 += __mul24(k0, st2);     // |st| <= 2^22, 0 <= k0 < 2^12: 24-bit operands
+    int32_t U1 = E1 - bias1, U2 = E2 - bias2;                    // the unbiased values the canonical depth uses
+    unsigned long long* px = tileRow + lx0 + k0;
+    const unsigned long long payload = noPixels ? 0ull : (unsigned long long)payloadIn;
+    // two pixels per trip.  The second may lie one past the bound: coverage is decided by the exact edge values, and
+    // the word it would touch is at most the row's padding word (lx1 <= 63), a pixel right of the screen or a pixel of
+    // the next segment of the same row (which merges the same value) -- never another row.
+    for (int32_t k = k0; k <= k1; k += 2) {
+        const bool insideA = (E0 | E1 | E2) >= 0;
+        const bool insideB = ((E0 + st0) | (E1 + st1) | (E2 + st2)) >= 0;
+        const float l1a = (float)U1 * invA, l2a = (float)U2 * invA;   // (float)(double)E == (float)E: one rounding of an exact integer
+        const float l1b = (float)(U1 + st1) * invA, l2b = (float)(U2 + st2) * invA;
+        const float za = (d0 + l1a * e1) + l2a * e2;
+        const float zb = (d0 + l1b * e1) + l2b * e2;
+        atomicMax(px, insideA && !noPixels ? (((unsigned long long)__float_as_uint(za) << 32) | payload) : 0ull);      // ds_max_u64
+        atomicMax(px + 1, insideB && !noPixels ? (((unsigned long long)__float_as_uint(zb) << 32) | payload) : 0ull);
+        E0 += 2 * st0; E1 += 2 * st1; E2 += 2 * st2; U1 += 2 * st1; U2 += 2 * st2; px += 2;
+    }
+    return max(k1 - k0 + 1, 0);
+}
+
+// entry record of a triangle that needs row units; returns its unit count
+__device__ __forceinline__ uint32_t entry_store(EntrySoA& en, uint32_t t, const TriSetup& ts, bool narrow,
+                                                int32_t ox, int32_t oy, int32_t x0, int32_t y0, int32_t x1, int32_t y1)
+{
+    uint32_t box = (uint32_t)(x0 - ox) | ((uint32_t)(y0 - oy) << 6) | ((uint32_t)(x1 - ox) << 12) | ((uint32_t)(y1 - oy) << 18);
+    if (narrow) {
+        const int32_t s = ts.s;
+        const int32_t dx0 = ts.X[2] - ts.X[1], dy0 = ts.Y[2] - ts.Y[1];
+        const int32_t dx1 = ts.X[0] - ts.X[2], dy1 = ts.Y[0] - ts.Y[2];
+        const int32_t dx2 = ts.X[1] - ts.X[0], dy2 = ts.Y[1] - ts.Y[0];
+        const int32_t a0 = -s * dy0, b0 = s * dx0, a1 = -s * dy1, b1 = s * dx1, a2 = -s * dy2, b2 = s * dx2;
+        const int32_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? 0 : -1;
+        const int32_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 0 : -1;
+        const int32_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 0 : -1;
+        const int32_t cx = ox * 256 + 128, cy = oy * 256 + 128;
+        en.w[0][t] = ((uint32_t)a0 & 0xFFFFu) | ((uint32_t)b0 << 16);
+        en.w[1][t] = ((uint32_t)a1 & 0xFFFFu) | ((uint32_t)b1 << 16);
+        en.w[2][t] = ((uint32_t)a2 & 0xFFFFu) | ((uint32_t)b2 << 16);
+        // |deltas| <= 2^14 and the tile origin is at most 2^15 + 128 sub-pixels from a vertex: 24-bit operands, |E| < 2^31
+        en.w[3][t] = (uint32_t)(s * (__mul24(dx0, cy - ts.Y[1]) - __mul24(dy0, cx - ts.X[1])) + bias0);
+        en.w[4][t] = (uint32_t)(s * (__mul24(dx1, cy - ts.Y[2]) - __mul24(dy1, cx - ts.X[2])) + bias1);
+        en.w[5][t] = (uint32_t)(s * (__mul24(dx2, cy - ts.Y[0]) - __mul24(dy2, cx - ts.X[0])) + bias2);
+        box |= (bias1 ? 1u << 26 : 0u) | (bias2 ? 1u << 27 : 0u);
+    } else {
+        int32_t mag = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) mag = max(mag, max(abs(ts.X[i]), abs(ts.Y[i])));
+        en.w[0][t] = (uint32_t)ts.X[0]; en.w[1][t] = (uint32_t)ts.X[1]; en.w[2][t] = (uint32_t)ts.X[2];
+        en.w[3][t] = (uint32_t)ts.Y[0]; en.w[4][t] = (uint32_t)ts.Y[1]; en.w[5][t] = (uint32_t)ts.Y[2];
+        box |= (mag < (1 << 25) ? 1u : 2u) << EF_KIND_SHIFT;
+        box |= ts.s < 0 ? 1u << 28 : 0u;
+    }
+    en.w[6][t] = __float_as_uint(ts.d0); en.w[7][t] = __float_as_uint(ts.e1); en.w[8][t] = __float_as_uint(ts.e2);
+    en.w[9][t] = __float_as_uint(ts.invA); en.w[10][t] = ts.payload; en.w[11][t] = box;
+    return (uint32_t)(y1 - y0 + 1) * ((uint32_t)((x1 - x0) >> SEG_SHIFT) + 1u);
+}
+
+// one unit = (entry e, its j-th (row, segment))
+__device__ __forceinline__ int32_t entry_unit(const EntrySoA& en, unsigned long long* tile, uint32_t e, uint32_t row, uint32_t seg,
+                                           int32_t ox, int32_t oy, unsigned long long rowMask, bool noPixels)
+{
+    const uint32_t box = en.w[11][e];
+    const int32_t bx0 = (int32_t)(box & 63u), bx1 = (int32_t)((box >> 12) & 63u);
+    const int32_t ly = (int32_t)row;
+    if (!((rowMask >> ly) & 1ull)) return 0;
+    const int32_t lx0 = bx0 + (int32_t)(seg << SEG_SHIFT), lx1 = min(bx1, lx0 + SEG - 1);
+    unsigned long long* tileRow = tile + ly * TPITCH;
+    const float d0 = __uint_as_float(en.w[6][e]), e1 = __uint_as_float(en.w[7][e]), e2 = __uint_as_float(en.w[8][e]);
+    const float invA = __uint_as_float(en.w[9][e]);
+    const uint32_t payload = en.w[10][e];
+    const uint32_t kind = (box >> EF_KIND_SHIFT) & 3u;
+    if (kind == 0u) {
+        const uint32_t p0 = en.w[0][e], p1 = en.w[1][e], p2 = en.w[2][e];
+        const int32_t a0 = (int32_t)(int16_t)(p0 & 0xFFFFu), b0 = (int32_t)p0 >> 16;
+        const int32_t a1 = (int32_t)(int16_t)(p1 & 0xFFFFu), b1 = (int32_t)p1 >> 16;
+        const int32_t a2 = (int32_t)(int16_t)(p2 & 0xFFFFu), b2 = (int32_t)p2 >> 16;
+        // (16-bit steps times 6-bit pixel offsets: full-rate 24-bit multiplies)
+        const int32_t E0 = (int32_t)en.w[3][e] + (__mul24(a0, lx0) + __mul24(b0, ly)) * 256;
+        const int32_t E1 = (int32_t)en.w[4][e] + (__mul24(a1, lx0) + __mul24(b1, ly)) * 256;
+        const int32_t E2 = (int32_t)en.w[5][e] + (__mul24(a2, lx0) + __mul24(b2, ly)) * 256;
+        return scan_span_i32(tileRow, E0, E1, E2, a0 * 256, a1 * 256, a2 * 256, (box >> 26) & 1u ? -1 : 0, (box >> 27) & 1u ? -1 : 0,
+                             d0, e1, e2, invA, payload, lx0, lx1, noPixels);
+    } else {
+        UnitParams u;
+        u.X[0] = (int32_t)en.w[0][e]; u.X[1] = (int32_t)en.w[1][e]; u.X[2] = (int32_t)en.w[2][e];
+        u.Y[0] = (int32_t)en.w[3][e]; u.Y[1] = (int32_t)en.w[4][e]; u.Y[2] = (int32_t)en.w[5][e];
+        u.d0 = d0; u.e1 = e1; u.e2 = e2; u.invA = invA; u.payload = payload; u.box = 0;
+        u.skind = (int32_t)((box >> 28) & 1u) | (int32_t)(kind << 1);
+        if (kind == 1u) scan_row<double>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
+        else            scan_row<int64_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
+        return lx1 - lx0 + 1;
+    }
 }
 
 // Tile-out of a finished tile fused with its HZB reduction (single-GPU frames): every word goes to the visibility
@@ -1178,10 +1382,17 @@ __device__ __noinline__ bool merge_slices(unsigned long long* tile, unsigned lon
 template <bool SH>
 __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
 {
-    __shared__ unsigned long long tile[TILE * TPITCH];           // 32.5 KB
-    __shared__ UnitParamsSoA prm;                                // 13 KB
+    __shared__ __align__(16) unsigned long long tile[TILE * TPITCH];   // 32.5 KB
+#if CHORD_TILE_V >= 2
+    __shared__ EntrySoA prm;                                     // 24 KB: the batch's entries that need row units
+#if CHORD_TILE_V >= 3
+    __shared__ uint32_t unitList[UNIT_CAP];                      // 16 KB: (entry | row << 9 | segment << 15) of the units of a round
+#endif
+#else
+    __shared__ UnitParamsSoA prm;                                // 26 KB
+#endif
     __shared__ uint32_t offs[TB + 1];
-    __shared__ uint32_t waveSums[TB / 64];
+    __shared__ uint32_t waveSums[2][TB / 64];
     __shared__ uint32_t chunkTab[64];                            // the overflow chunks this item's entries live in
     __shared__ uint32_t sTicket;
     if ((p.debug & DBG_TILE_EXIT) && !p.clearTiles) return;
@@ -1196,10 +1407,11 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     // rounded to whole batches)
     const uint32_t per = slices > 1u ? max(TILE_SLICE, ((nAll + slices - 1u) / slices + TB - 1u) & ~(TB - 1u)) : nAll;
     const uint32_t lo = slices > 1u ? min(nAll, slice * per) : 0u;
-    const uint32_t n = slices > 1u ? min(nAll, lo + per) : nAll;
+    const uint32_t n = (p.debug & DBG_NO_BATCH) ? lo : (slices > 1u ? min(nAll, lo + per) : nAll);
     const bool prof = (p.debug & DBG_TILE_CLOCKS) != 0;
     const unsigned long long t0 = prof ? wall_clock64() : 0ull;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = t0;
+    uint32_t cUnits = 0, cUnitIters = 0, cTiny = 0, cTinyIters = 0;      // (profile only)
 #define PHASE(i) do { if (prof) { __syncthreads(); const unsigned long long tn = wall_clock64(); ph[i] += tn - tp; tp = tn; } } while (0)
     const int32_t ox = (int32_t)(tileId % p.tilesX) * TILE, oy = (int32_t)(tileId / p.tilesX) * TILE;
     const int32_t tw = min(TILE, p.Wi - ox), th = min(TILE, p.Hi - oy);
@@ -1218,10 +1430,15 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     // slices of a split tile start from zero; when the tile must leave this kernel complete (first pass, fused HZB)
     // they meet in memory and the last one to arrive merges them (below)
     const bool mergeSlices = slices > 1u && (p.clearTiles || rmw);
+    if (!(rmw && !mergeSlices)) {
+        // (the whole array incl. the padding words, 16 bytes per store)
+        static_assert((TILE * TPITCH) % 2 == 0, "whole 16-byte words");
+        for (uint32_t i = threadIdx.x; i < TILE * TPITCH / 2; i += TB) reinterpret_cast<ulonglong2*>(tile)[i] = make_ulonglong2(0ull, 0ull);
+    } else
     for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
         const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
         ulonglong2 v = make_ulonglong2(0ull, 0ull);
-        if (rmw && !mergeSlices && ly < th && lx < tw) {
+        if (ly < th && lx < tw) {
             const unsigned long long* src = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
             if (lx + 1 < tw) v = *reinterpret_cast<const ulonglong2*>(src);
             else v.x = src[0];
@@ -1278,7 +1495,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         const uint32_t k = base + threadIdx.x;
         const uint4 q0 = nq0, q1 = nq1, q2 = nq2;
         const uint32_t name = nameNext;
-        const bool have = name != 0xFFFFFFFFu;
+        const bool have = name != 0xFFFFFFFFu && !(p.debug & DBG_NO_ENTRY);
         nameNext = idxNext;
         if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);         // record of the next batch
         idxNext = k + 2u * TB < n ? binEntry(k + 2u * TB) : 0xFFFFFFFFu;          // bin entry of the batch after
@@ -1311,7 +1528,11 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                     const bool narrow = narrow_extent(ts);
                     if (narrow && (x1 - x0 + 1) * (y1 - y0 + 1) <= TINY_AREA) {
                         if (!(p.debug & DBG_NO_TINY)) tile_raster_narrow(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask);
+                        if (prof) { cTiny++; cTinyIters += (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1)); }
                     } else {
+#if CHORD_TILE_V >= 2
+                        rows = entry_store(prm, threadIdx.x, ts, narrow, ox, oy, x0, y0, x1, y1);      // (units, not rows)
+#else
                         int32_t mag = 0;
 #pragma unroll
                         for (int i = 0; i < 3; i++) mag = max(mag, max(abs(ts.X[i]), abs(ts.Y[i])));
@@ -1324,17 +1545,65 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                         u.skind = (ts.s < 0 ? 1 : 0) | (kind << 1);
                         unit_store(prm, threadIdx.x, u);
                         rows = (uint32_t)(y1 - y0 + 1);
+#endif
                     }
                 }
             }
         }
         PHASE(2);
         uint32_t total;
-        const uint32_t off = block_scan_tb(rows, waveSums, &total);
+        // (the wave sums alternate between two buffers: a batch without units then needs no barrier but the scan's own)
+        const uint32_t off = block_scan_tb(rows, waveSums[(base >> 9) & 1u], &total);
+#if CHORD_TILE_V < 3
         offs[threadIdx.x] = off;
         if (threadIdx.x == 0) offs[TB] = total;
         __syncthreads();
+#endif
         PHASE(3);
+#if CHORD_TILE_V >= 3
+        // rounds of UNIT_CAP units: every entry thread lists its units of the round (one LDS word each), then every
+        // thread takes units TB apart -- a unit finds its entry with ONE read instead of a 9-step binary search
+        for (uint32_t r0 = 0; r0 < total; r0 += UNIT_CAP) {
+            if (rows) {
+                const uint32_t box = prm.w[11][threadIdx.x];
+                const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> SEG_SHIFT) + 1u, y0l = (box >> 6) & 63u;
+                // my units [off, off + rows) cut to the round's window
+                const uint32_t lo2 = max(off, r0), hi2 = min(off + rows, r0 + UNIT_CAP);
+                if (lo2 < hi2) {
+                    uint32_t j = lo2 - off;
+                    uint32_t row = y0l + (nseg == 1u ? j : nseg == 2u ? j >> 1 : nseg == 4u ? j >> 2 : j / 3u);
+                    uint32_t seg = nseg == 1u ? 0u : nseg == 2u ? (j & 1u) : nseg == 4u ? (j & 3u) : j % 3u;
+                    for (uint32_t u = lo2; u < hi2; u++) {
+                        unitList[u - r0] = threadIdx.x | (row << 9) | (seg << 15);
+                        if (++seg == nseg) { seg = 0u; row++; }
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nr = min(total - r0, (uint32_t)UNIT_CAP);
+            for (uint32_t ui = threadIdx.x; ui < nr; ui += TB) {
+                const uint32_t d = unitList[ui];
+                if (p.debug & DBG_NO_UNITS) continue;
+                const int32_t trips = entry_unit(prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, rowMask, noPixels);
+                if (prof) { cUnits++; cUnitIters += (uint32_t)trips; }
+            }
+            if (r0 + UNIT_CAP < total) __syncthreads();           // the list is rewritten by the next round
+        }
+#elif CHORD_TILE_V == 2
+        for (uint32_t u0 = 0; u0 < total; u0 += TB) {
+            const uint32_t ui = u0 + threadIdx.x;
+            if (ui < total) {
+                uint32_t e = 0;                                   // last entry with offs[e] <= ui
+#pragma unroll
+                for (uint32_t st = TB / 2; st > 0; st >>= 1) if (offs[e + st] <= ui) e += st;
+                const uint32_t box = prm.w[11][e];
+                const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> SEG_SHIFT) + 1u, j = ui - offs[e];
+                const uint32_t rowj = nseg == 1u ? j : nseg == 2u ? j >> 1 : nseg == 4u ? j >> 2 : j / 3u;
+                const uint32_t seg = j - rowj * nseg;
+                entry_unit(prm, tile, e, ((box >> 6) & 63u) + rowj, seg, ox, oy, rowMask, noPixels);
+            }
+        }
+#else
         for (uint32_t u0 = 0; u0 < total; u0 += TB) {
             const uint32_t ui = u0 + threadIdx.x;
             if (ui < total) {
@@ -1353,7 +1622,12 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                 }
             }
         }
+#endif
+#if CHORD_TILE_V >= 3
+        if (total) __syncthreads();                               // prm / the unit list are rewritten by the next batch
+#else
         __syncthreads();                                          // prm / offs are rewritten by the next batch
+#endif
         PHASE(4);
     }
     __syncthreads();
@@ -1405,9 +1679,16 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         }
     }
     PHASE(5);
-    if (prof && threadIdx.x == 0) {
-        p.tileClocks[tileId] = wall_clock64() - t0;
-        for (int i = 0; i < 6; i++) p.tilePhase[(size_t)tileId * 8 + i] = ph[i];
+    if (prof) {
+        if (threadIdx.x == 0) {
+            p.tileClocks[tileId] = wall_clock64() - t0;
+            for (int i = 0; i < 6; i++) p.tilePhase[(size_t)tileId * 8 + i] = ph[i];
+            p.tilePhase[(size_t)tileId * 8 + 6] = 0ull; p.tilePhase[(size_t)tileId * 8 + 7] = 0ull;
+        }
+        __syncthreads();
+        // work counters of the tile: units << 32 | row-loop trips, tiny triangles << 32 | their bbox pixels
+        atomicAdd(&p.tilePhase[(size_t)tileId * 8 + 6], ((unsigned long long)cUnits << 32) | cUnitIters);
+        atomicAdd(&p.tilePhase[(size_t)tileId * 8 + 7], ((unsigned long long)cTiny << 32) | cTinyIters);
     }
     __syncthreads();                                              // the LDS tile is reused by the next iteration
     }
@@ -1467,6 +1748,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         LR_HIP(hipMemsetAsync(&c->dCounters->clipTriCount[pass], 0, sizeof(uint32_t), c->stream));
         LR_HIP(hipMemsetAsync(c->dCounters->largeCount[pass], 0, sizeof(c->dCounters->largeCount[pass]), c->stream));
         LR_HIP(hipMemsetAsync(&c->dCounters->binPoolCount[pass], 0, sizeof(uint32_t), c->stream));
+        LR_HIP(hipMemsetAsync(&c->dCounters->orderTicket[pass], 0, sizeof(uint32_t), c->stream));
         if (!c->inFrame) { LR_HIP(hipMemsetAsync(c->dCounters->triCount, 0, sizeof(c->dCounters->triCount), c->stream));
                            LR_HIP(hipMemsetAsync(c->dCounters->triCountC, 0, sizeof(c->dCounters->triCountC), c->stream)); }
     }
@@ -1479,8 +1761,12 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     stamp(c, S_HZBCULL);      // closes whatever preceded the raster (HZB cull / list reset)
     hipLaunchKernelGGL(raster_setup_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
     stamp(c, S_R_CLUSTER);
-    hipLaunchKernelGGL(raster_clip_and_bin_large_kernel, dim3(CLIP_BLOCKS + (uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
-    hipLaunchKernelGGL(raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
+    if (c->cullBlocks <= 512u) {
+        hipLaunchKernelGGL(raster_clip_bin_order_kernel, dim3(MERGED_BLOCKS), dim3(256), 0, c->stream, p, &c->dCounters->orderTicket[pass]);
+    } else {
+        hipLaunchKernelGGL(raster_clip_and_bin_large_kernel, dim3(CLIP_BLOCKS + (uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
+        hipLaunchKernelGGL(raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
+    }
     stamp(c, S_R_CLIP);
     // first pass of a frame: every tile is written, one block each, dispatched heaviest first; later passes touch
     // few tiles: one resident wave of blocks strides over the (device-side) active list

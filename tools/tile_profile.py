@@ -21,9 +21,13 @@ tx, ty = (cam.width + 63) // 64, (cam.height + 63) // 64
 for p in (0, 1):
     ticks = np.zeros(tx * ty * 9, np.uint64); cnt = np.zeros(tx * ty, np.uint32)
     assert L.lib.chordvis_debug_tile_profile(r._ctx, p, ticks.ctypes.data, cnt.ctypes.data, tx * ty * 9) == 0
-    phase = ticks[tx * ty:].reshape(tx * ty, 8).astype(np.float64) / 100.0
+    raw = ticks[tx * ty:].reshape(tx * ty, 8)
+    phase = raw.astype(np.float64) / 100.0
     ticks = ticks[:tx * ty]
     us = ticks.astype(np.float64) / 100.0
+    units, trips = (raw[:, 6] >> np.uint64(32)).astype(np.int64), (raw[:, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    tiny, tinypx = (raw[:, 7] >> np.uint64(32)).astype(np.int64), (raw[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    print("work: entries %d  tiny %d (bbox px %d)  units %d  row-loop trips %d (%.1f per unit)" % (cnt.sum(), tiny.sum(), tinypx.sum(), units.sum(), trips.sum(), trips.sum() / max(1, units.sum())))
     print("phase sums (us) in/load/setup/scan/units/out:", np.round(phase[:, :6].sum(axis=0), 0))
     order = np.argsort(-us)[:4]
     print("pass", p, "entries", int(cnt.sum()), "max bin", int(cnt.max()), "tile us: sum %.0f mean %.1f max %.1f" % (us.sum(), us.mean(), us.max()))
@@ -31,9 +35,9 @@ for p in (0, 1):
     print("   corr(us, bin) = %.3f" % np.corrcoef(us, cnt)[0, 1])
     o2 = np.argsort(-phase[:, 4])[:6]
     print("   by units phase:")
-    for t in o2: print("   tile (%2d,%2d) %7.1f us  bin %5d  phases" % (t % tx, t // tx, us[t], cnt[t]), np.round(phase[t, :6], 1))
+    for t in o2: print("   tile (%2d,%2d) %7.1f us  bin %5d  units %6d trips %7d tiny %5d  phases" % (t % tx, t // tx, us[t], cnt[t], units[t], trips[t], tiny[t]), np.round(phase[t, :6], 1))
     h = np.histogram(us, bins=[0, 5, 10, 20, 30, 40, 50, 60, 80, 200])
     print("   tile-time histogram (us):", list(zip(h[1][:-1].astype(int), h[0])))
     for lo, hi in ((0, 1), (1, 64), (64, 256), (256, 1024), (1024, 100000)):
         m = (cnt >= lo) & (cnt < hi)
-        print("   bins [%d,%d): %d tiles, time sum %.0f, phases" % (lo, hi, m.sum(), us[m].sum()), np.round(phase[m][:, :6].sum(axis=0), 0))
+        print("   bins [%d,%d): %d tiles, time sum %.0f, units %d trips %d tiny %d, phases" % (lo, hi, m.sum(), us[m].sum(), units[m].sum(), trips[m].sum(), tiny[m].sum()), np.round(phase[m][:, :6].sum(axis=0), 0))
