@@ -419,10 +419,7 @@ def self_spawn(n):
 
 def scene_with(scene, objects):
     """A shallow scene whose object records are `objects` (the oracle reads host arrays)."""
-    from chord_amd import records as R
-    s = R.Scene(objects, scene.primitives, scene.materials, scene.meshlets, scene.groups, scene.group_indices,
-                scene.meshlet_data, scene.positions, name=scene.name)
-    return s
+    return scene.with_objects(objects)
 
 
 class _CAI:

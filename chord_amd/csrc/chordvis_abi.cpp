@@ -204,7 +204,8 @@ int begin_frame_clear(ChordCtx* c)
 int do_raster(ChordCtx* c, const CmdList& in)
 {
     // renderMesh (mesh_raster.cpp:208-254): the four (alphaMode x twoSided) pipeline buckets and
-    // their filter passes collapse into one launch; the kernel reads bTwoSided per cluster.
+    // their filter passes collapse into one launch; the kernels read bTwoSided and alphaMode per cluster (masked
+    // triangles carry their texture coordinates and are alpha-tested per pixel; blended materials draw nothing).
     const hipError_t e = launch_raster(c, in, c->pendingClear);
     c->pendingClear = false;
     if (e != hipSuccess) return fail(c, CHORDVIS_E_HIP, "launch_raster", e);
@@ -267,7 +268,7 @@ int chordvis_destroy(ChordCtx* c)
     (void)hipStreamSynchronize(c->stream);
     (void)chordvis_comm_destroy(c);
     dfree(c->dPrims); dfree(c->dGroups); dfree(c->dMeshlets); dfree(c->dGroupIndices); dfree(c->dMeshletData);
-    dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
+    dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dMaterials); dfree(c->dTexAlpha); dfree(c->dTexcoords); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
     dfree(c->dRankCmds);
@@ -392,7 +393,11 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
             return fail(c, CHORDVIS_E_INVALID, "upload_scene: object primitive/material id out of range");
         DObjStatic& d = c->hObjStatic[o];
         d.prim = ob.GLTFPrimitiveDetail;
-        d.twoSided = s->materials[ob.GLTFMaterialData].bTwoSided != 0 ? 1u : 0u;
+        const ChordMaterial& mat = s->materials[ob.GLTFMaterialData];
+        // alphaMode 0 / 1 / 2 = opaque / mask / blend (FILTER_CHECK of pipeline_filter.hlsl:100-101); anything else never
+        // matches a bucket's targetAlphaMode and draws nothing, like blend
+        d.matFlags = (mat.bTwoSided != 0 ? CHORD_MATFLAG_TWO_SIDED : 0u) | ((mat.alphaMode > 2u ? 2u : mat.alphaMode) << 1) | (ob.GLTFMaterialData << 8);
+        if (ob.GLTFMaterialData >= (1u << 24)) return fail(c, CHORDVIS_E_CAPACITY, "upload_scene: more than 2^24 materials");
         d.shadingType = s->materials[ob.GLTFMaterialData].materialType;
         d.groupBase = (uint32_t)groupInst;
         groupInst += c->hPrims[d.prim].groupCount;
@@ -413,12 +418,66 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     c->groupInstances = (uint32_t)groupInst; c->cmdCapacity = (uint32_t)std::max<uint64_t>(cmdCap, 1);
     c->cullBlocks = std::max(1u, (c->groupInstances + 255u) / 256u);
 
+    // what the masked buckets sample: alpha channels of every texture level, materials with texture + sampler resolved,
+    // the per-vertex texture coordinates (mesh_raster.hlsl:107-112,198-204)
+    std::vector<DMaterial> dmats(s->materialCount);
+    std::vector<uint8_t> alpha;
+    std::vector<uint32_t> texOffset(s->textureCount, 0xFFFFFFFFu);
+    bool anyMasked = false;
+    for (uint32_t m = 0; m < s->materialCount; m++) anyMasked = anyMasked || s->materials[m].alphaMode == CHORD_ALPHA_MASK;
+    if (anyMasked && s->textures) {
+        for (uint32_t t = 0; t < s->textureCount; t++) {
+            const ChordTexture& tx = s->textures[t];
+            if (!tx.rgba8 || tx.width == 0 || tx.height == 0 || tx.mipCount == 0 || tx.width > 16384u || tx.height > 16384u || tx.mipCount > 15u)
+                return fail(c, CHORDVIS_E_INVALID, "upload_scene: texture without data, or larger than 16384 / 15 levels");
+            size_t texels = 0;
+            for (uint32_t l = 0; l < tx.mipCount; l++) texels += (size_t)std::max(1u, tx.width >> l) * std::max(1u, tx.height >> l);
+            if (alpha.size() + texels >= 0xFFFFFFFFull) return fail(c, CHORDVIS_E_CAPACITY, "upload_scene: more than 4 G texels of alpha");
+            texOffset[t] = (uint32_t)alpha.size();
+            const size_t base = alpha.size();
+            alpha.resize(base + texels);
+            for (size_t i = 0; i < texels; i++) alpha[base + i] = tx.rgba8[i * 4 + 3];
+        }
+    }
+    for (uint32_t m = 0; m < s->materialCount; m++) {
+        const ChordMaterial& mat = s->materials[m];
+        DMaterial& d = dmats[m];
+        std::memset(&d, 0, sizeof(d));
+        d.texOffset = 0xFFFFFFFFu;
+        if (s->textures && mat.baseColorId < s->textureCount && texOffset[mat.baseColorId] != 0xFFFFFFFFu) {
+            const ChordTexture& tx = s->textures[mat.baseColorId];
+            d.texOffset = texOffset[mat.baseColorId]; d.texWidth = tx.width; d.texHeight = tx.height; d.texMips = tx.mipCount;
+        }
+        if (s->samplers && mat.baseColorSampler < s->samplerCount) {
+            const ChordSampler& sm = s->samplers[mat.baseColorSampler];
+            d.minFilter = sm.minFilter; d.magFilter = sm.magFilter; d.wrapS = sm.wrapS; d.wrapT = sm.wrapT;
+        } else { d.minFilter = d.magFilter = CHORD_FILTER_NEAREST; d.wrapS = d.wrapT = CHORD_WRAP_REPEAT; }
+        d.alphaFactor = mat.baseColorFactor[3]; d.alphaCutOff = mat.alphaCutOff;
+    }
+    std::vector<float> uvs;
+    if (anyMasked) {
+        bool anyUv = false;
+        for (uint32_t a = 0; a < s->assetCount; a++) anyUv = anyUv || (s->assets[a].texcoord0 && s->assets[a].texcoord0Count);
+        if (anyUv) {
+            uvs.assign((size_t)nV * 2, 0.0f);
+            for (uint32_t a = 0; a < s->assetCount; a++) {
+                const ChordAssetDesc& as = s->assets[a];
+                if (as.texcoord0 && as.texcoord0Count)
+                    std::memcpy(uvs.data() + (size_t)vB[a] * 2, as.texcoord0, sizeof(float) * 2 * std::min(as.texcoord0Count, as.vertexCount));
+            }
+        }
+    }
+    c->anyMasked = anyMasked;
+
     int rc;
 #define UP(dst, vec)                                                                                          \
     if ((rc = dalloc(c, &dst, vec.size()))) return rc;                                                        \
     if (!vec.empty()) CHORD_HIP(c, hipMemcpy(dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
     UP(c->dMeshlets, meshlets) UP(c->dGroups, groups) UP(c->dGroupIndices, gidx) UP(c->dMeshletData, mdata)
     UP(c->dPositions, pos) UP(c->dPrims, c->hPrims) UP(c->dObjStatic, c->hObjStatic) UP(c->dGroupOwner, owner)
+    UP(c->dMaterials, dmats)
+    if (!alpha.empty()) { UP(c->dTexAlpha, alpha) } else dfree(c->dTexAlpha);
+    if (!uvs.empty()) { UP(c->dTexcoords, uvs) } else dfree(c->dTexcoords);
 #undef UP
     if ((rc = dalloc(c, &c->dObjectsOwned, (size_t)s->objectCount))) return rc;
     CHORD_HIP(c, hipMemcpy(c->dObjectsOwned, s->objects, sizeof(ChordObject) * s->objectCount, hipMemcpyHostToDevice));
@@ -675,27 +734,17 @@ static int render_frame_impl(ChordCtx* c)
     const bool haveHist = c->historySlot != 0;
     if (haveHist) hist = c->hzb[c->historySlot].handle();
     const int next = c->historySlot == 1 ? 2 : 1;
-    const bool hzbOn = haveHist && (c->hView.flags & CHORD_FLAG_HZB_CULL);           // mesh_raster.cpp:293
-    // instanceCulling :321 -- for short scenes the scatter kernel also runs HZB phase 0 of stage 0 (the test reads the
-    // history chain, whose tail the frame's first kernel has just completed)
-    const bool fusedPhase0 = launch_group_cull(c, c->lists[0], hzbOn ? &c->hzb[c->historySlot] : nullptr);
-    CHORD_HIP(c, hipGetLastError());
-    const ChordCountAndCmd post = c->lists[0].handle();
+    ChordCountAndCmd post;
+    if ((rc = chordvis_instance_culling(c, &post))) return rc;                        // :321 (its first kernel also carries the previous frame's HZB tail)
     record(c, S_CULL);
     // buildHZB is fused into the raster: the tile kernel reduces every finished 64x64 tile to mips 0..5 of the
     // chain kept as history (and of the temporary chain stage 1 culls against); only the one-block tail remains.
     c->fuseHzb = true;
     c->fuseHzbSlot = next;
-    c->fuseHzbTemp = hzbOn;
+    c->fuseHzbTemp = haveHist && (c->hView.flags & CHORD_FLAG_HZB_CULL);
     ChordCountAndCmd rejected;
     int stage1 = 0;
-    if (fusedPhase0) {                                                                // gltfVisibilityRenderingStage0 :326 with the cull already done
-        rc = chordvis_render_mesh(c, c->lists[1].handle());
-        rejected = c->lists[2].handle();
-        stage1 = 1;
-    } else {
-        rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1);   // :326
-    }
+    rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1);   // :326
     record(c, S_STAGE0_END);
     c->shouldStage1 = stage1 != 0;
     if (!rc && stage1) {

@@ -42,9 +42,30 @@ struct DMeshlet {              // GPUGLTFMeshlet with dataOffset globalised and 
 
 struct DObjStatic {            // per object, derived once per upload, 16 B
     uint32_t prim;
-    uint32_t twoSided;
+    uint32_t matFlags;         // bit 0 bTwoSided, bits 1-2 alphaMode (0 opaque, 1 mask, 2 blend), bits 8.. material index
     uint32_t groupBase;        // first flattened (object, group) index
     uint32_t shadingType;      // materials[object.GLTFMaterialData].materialType (visibility_tile.hlsl:56-60)
+};
+
+#define CHORD_MATFLAG_TWO_SIDED 1u
+#define CHORD_MATFLAG_ALPHA(f) (((f) >> 1) & 3u)
+#define CHORD_MATFLAG_MATERIAL(f) ((f) >> 8)
+
+// What the masked buckets read of a material (mesh_raster.hlsl:107-112,198-204), texture and sampler pre-resolved.
+struct DMaterial {             // 48 B
+    uint32_t texOffset;        // first alpha byte of level 0 in dTexAlpha; 0xFFFFFFFF: white fallback (alpha 1)
+    uint32_t texWidth, texHeight, texMips;
+    uint32_t minFilter, magFilter, wrapS, wrapT;
+    float    alphaFactor;      // baseColorFactor.w
+    float    alphaCutOff;
+    uint32_t pad[2];
+};
+// extension of a masked triangle's 48-byte record, in the slot behind it
+struct TriRecMaskExt {         // 48 B
+    float    uw[3], vw[3], iw[3];   // u / w, v / w, 1 / w per vertex
+    uint32_t levelFilter;      // level | linear << 8
+    uint32_t material;
+    uint32_t pad;
 };
 
 struct DObjFrame {             // per object, per frame (written by the object-cull kernel), 208 B
@@ -83,8 +104,8 @@ struct TriRec {                // 48 B: one set-up triangle (snapped 24.8 vertic
     int32_t  X[3]; int32_t Y[3];
     float    d[3];
     uint32_t payload;
-    uint32_t twoSided;
-    uint32_t pad;
+    uint32_t twoSided;         // bit 0 two-sided, bit 1 orientation sign of the snapped triangle, bit 2 masked: a TriRecMaskExt follows
+    uint32_t pad;              // 1 / float(2A)
 };
 // 32 B: the same for a triangle whose vertices are at most 64 px apart (deltas fit 16 bits) -- nearly all of them.
 // Orientation sign and 1/2A are recomputed by the consumer from the deltas (the same expressions, exact integers).
@@ -115,8 +136,6 @@ struct DeviceCounters {
     uint32_t pad;
     // triangles (meshlet triangle counts) of the commands each list producer emitted this frame
     unsigned long long trisInstanceCulled, trisHzbVisible0, trisHzbVisible1, pad2;
-    uint32_t orderTicket[2];                    // per raster pass: workgroups of the merged clip / bin / order launch that are done
-    uint32_t pad3[2];
 };
 
 // Everything a frame zeroes lives in ONE allocation so the frame starts with one memset:
@@ -188,6 +207,10 @@ struct ChordCtx {
     uint32_t* dMeshletData = nullptr;
     float* dPositions = nullptr;
     chord::DObjStatic* dObjStatic = nullptr;
+    chord::DMaterial* dMaterials = nullptr;   // per material: what the masked buckets sample
+    uint8_t* dTexAlpha = nullptr;             // alpha channel of every level of every texture, back to back
+    float* dTexcoords = nullptr;              // float2 per vertex (textureCoord0Buffer), or null
+    bool anyMasked = false;
     uint32_t* dGroupOwner = nullptr;  // object id per flattened (object, group)
     ChordObject* dObjectsOwned = nullptr;
     const ChordObject* dObjects = nullptr;
@@ -291,7 +314,7 @@ int fail(ChordCtx* ctx, int code, const char* what, hipError_t e = hipSuccess);
     } while (0)
 
 // kernel launchers (implemented in the .hip translation units) ---------------------------------
-bool launch_group_cull(ChordCtx* c, const CmdList& out, const HzbBuffers* fusedHzb0 = nullptr);   // true: HZB phase 0 ran inside (lists 1 / 2 are filled)
+void launch_group_cull(ChordCtx* c, const CmdList& out);
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
                      const CmdList* outRejected);
 hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles);   // first failing HIP call, or hipSuccess

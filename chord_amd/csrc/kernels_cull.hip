@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
                 const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
                 for (uint32_t i = 0; i < g.meshletCount && i < CHORD_GROUP_MAX_MESHLETS; i++) {
                     const uint32_t mi = prim.meshletBase + p.groupIndices[idxBase + i];  // :178-180
-                    if (meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, st.twoSided != 0, p.meshlets[mi])) {
+                    if (meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (st.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, p.meshlets[mi])) {
                         mask |= 1u << i;
                         tris += (p.meshlets[mi].vertexTriangleCount >> 8) & 0xFFu;
                     }
@@ -376,13 +376,12 @@ __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DV
 
 // PREFIXED: blockCounts already holds exclusive offsets (group_cull_prefix_kernel ran); otherwise every block sums the
 // preceding blocks' counts itself (a few hundred blocks: cheaper than one more launch).
-// HZB0: the phase-0 occlusion test of every command rides on the scatter (short scenes: hzbMainViewCullingCS as a launch of
-// its own costs ~7 us for a few thousand commands, nearly all of it launch + dependent-load latency); the visible /
-// rejected lists are reserved once per block like hzb_cull_kernel does.
-template <bool PREFIXED, bool HZB0>
+// (Tried in round 2: the phase-0 HZB test of every command inside this kernel for short scenes, to save the launch of
+// hzb_cull_kernel: 23.8 us against 5 + 7 us -- a thread owns a group's up to four commands and tests them one after
+// the other, four dependent chains of loads deep, while the stand-alone kernel has one command per thread.)
+template <bool PREFIXED>
 __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams p, ChordDrawCmd* __restrict__ outCmds,
-                                                                 uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters,
-                                                                 HzbCullParams hp)
+                                                                 uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters)
 {
     __shared__ uint32_t red[256];
     uint32_t blockBase;
@@ -405,8 +404,6 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
     uint32_t total;
     const uint32_t off = block_excl_scan(__popc(mask), &total);
     uint32_t tris = 0;
-    uint32_t visBits = 0, rejBits = 0, visTris = 0;
-    ChordDrawCmd hcmd[CHORD_GROUP_MAX_MESHLETS];
     if (mask) {
         const uint32_t o = p.groupOwner[t];
         const DObjStatic st = p.objStatic[o];
@@ -422,47 +419,8 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
                 cmd.slot = slot;                                            // instance_culling.hlsl:203-206
                 outCmds[slot] = cmd;
                 if (!PREFIXED) tris += (p.meshlets[cmd.meshletId].vertexTriangleCount >> 8) & 0xFFu;
-                if (HZB0) {
-                    uint32_t t = 0;
-                    hcmd[i] = cmd;
-                    if (hzb_cmd_visible<0>(hp, *hp.dview, cmd, t)) { visBits |= 1u << i; visTris += t; }
-                    else rejBits |= 1u << i;
-                }
                 slot++;
             }
-        }
-    }
-    if (HZB0) {
-        __shared__ uint32_t sWaveH[4], sBaseH[2];
-        __shared__ unsigned long long sTrisH[4];
-        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        const uint32_t mine = (uint32_t)__popc(visBits) | ((uint32_t)__popc(rejBits) << 16);
-        uint32_t incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t nb = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += nb; }
-        unsigned long long tsum = visTris;
-#pragma unroll
-        for (int offs = 32; offs > 0; offs >>= 1) tsum += __shfl_down(tsum, offs, 64);
-        if (lane == 63u) sWaveH[wave] = incl;
-        if (lane == 0u) sTrisH[wave] = tsum;
-        __syncthreads();
-        uint32_t before = 0, all = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < 4u; w++) { const uint32_t cc = sWaveH[w]; if (w < wave) before += cc; all += cc; }
-        if (threadIdx.x == 0) {
-            const uint32_t nv = all & 0xFFFFu, nr = all >> 16;
-            sBaseH[0] = nv ? atomicAdd(hp.visCount, nv) : 0u;
-            sBaseH[1] = nr ? atomicAdd(hp.rejCount, nr) : 0u;
-            const unsigned long long tt = sTrisH[0] + sTrisH[1] + sTrisH[2] + sTrisH[3];
-            if (tt) atomicAdd(&hp.counters->trisHzbVisible0, tt);
-        }
-        __syncthreads();
-        const uint32_t excl = before + incl - mine;
-        uint32_t vslot = sBaseH[0] + (excl & 0xFFFFu), rslot = sBaseH[1] + (excl >> 16);
-#pragma unroll
-        for (uint32_t k = 0; k < CHORD_GROUP_MAX_MESHLETS; k++) {
-            if (visBits & (1u << k)) hp.visCmds[vslot++] = hcmd[k];
-            if (rejBits & (1u << k)) hp.rejCmds[rslot++] = hcmd[k];
         }
     }
     if (PREFIXED) return;
@@ -551,9 +509,7 @@ static HzbCullParams make_hzb_cull_params(ChordCtx* c, const HzbBuffers& hzb, co
     return p;
 }
 
-// fusedHzb0: short scenes only -- the scatter also runs HZB phase 0 against `fusedHzb0` into lists 1 (visible) / 2 (rejected);
-// returns true when it did (the caller then skips its hzbCulling pass).
-bool launch_group_cull(ChordCtx* c, const CmdList& out, const HzbBuffers* fusedHzb0)
+void launch_group_cull(ChordCtx* c, const CmdList& out)
 {
     GroupCullParams p;
     p.objects = c->dObjects; p.objStatic = c->dObjStatic; p.objFrame = c->dObjFrame; p.prims = c->dPrims;
@@ -587,20 +543,12 @@ bool launch_group_cull(ChordCtx* c, const CmdList& out, const HzbBuffers* fusedH
                            blocks, tail);
     }
     c->viewDirty = false;
-    HzbCullParams hp;
-    std::memset(&hp, 0, sizeof(hp));
     if (blocks > 512u) {
         hipLaunchKernelGGL(group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters);
-        hipLaunchKernelGGL((group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, hp);
-        return false;
+        hipLaunchKernelGGL(group_cull_scatter_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+    } else {
+        hipLaunchKernelGGL(group_cull_scatter_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
     }
-    if (fusedHzb0 && fusedHzb0->minTexels) {
-        hp = make_hzb_cull_params(c, *fusedHzb0, out, c->lists[1], &c->lists[2]);
-        hipLaunchKernelGGL((group_cull_scatter_kernel<false, true>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, hp);
-        return true;
-    }
-    hipLaunchKernelGGL((group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, hp);
-    return false;
 }
 
 // ---- sharded frames: this rank's clusters of a raster pass -----------------------------------------------------

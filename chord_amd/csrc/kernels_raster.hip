@@ -52,6 +52,7 @@ struct RasterParams {
     const uint32_t* count; const ChordDrawCmd* cmds;
     const DObjFrame* objFrame; const DObjStatic* objStatic;
     const DMeshlet* meshlets; const uint32_t* meshletData; const float* positions;
+    const DMaterial* materials; const uint8_t* texAlpha; const float* texcoords;   // masked materials (texcoords may be null: uv = 0)
     unsigned long long* vis;
     float W, H; int32_t Wi, Hi;
     ShardInfo shard;
@@ -369,20 +370,126 @@ __device__ __forceinline__ bool touches_many_tiles(const TriSetup& ts)
     return ((ts.px1 >> TILE_SHIFT) - (ts.px0 >> TILE_SHIFT)) > 1 || ((ts.py1 >> TILE_SHIFT) - (ts.py0 >> TILE_SHIFT)) > 1;
 }
 
-__device__ __forceinline__ void write_record(TriRec* dst, const TriSetup& ts, const float d[3], bool twoSided)
+__device__ __forceinline__ void write_record(TriRec* dst, const TriSetup& ts, const float d[3], bool twoSided, bool masked = false)
 {
     TriRec r;
 #pragma unroll
     for (int i = 0; i < 3; i++) { r.X[i] = ts.X[i]; r.Y[i] = ts.Y[i]; r.d[i] = d[i]; }
     r.payload = ts.payload;
-    r.twoSided = (twoSided ? 1u : 0u) | (ts.s < 0 ? 2u : 0u);     // bit 1: orientation sign of the snapped triangle
+    r.twoSided = (twoSided ? 1u : 0u) | (ts.s < 0 ? 2u : 0u) | (masked ? 4u : 0u);   // bit 1: orientation sign of the snapped triangle, bit 2: a TriRecMaskExt follows
     r.pad = __float_as_uint(ts.invA);                             // 1 / float(2A): the tile kernel does not redo the division
     *dst = r;
+}
+
+// ---- masked materials (mesh_raster.hlsl:34-38,107-112,198-204) -----------------------------------------------------------
+// The reference samples the base-colour texture in the pixel shader and clip()s on its alpha.  Level of detail and
+// filtering are the sampler hardware's business there; here they are pinned (oracle.c header item 9):
+// perspective-correct uv from u/w, v/w, 1/w; ONE level per triangle from the ratio of its doubled uv area (in level-0
+// texels) to its doubled pixel area, level = floor(log2(ratio)) >> 1; nearest or bilinear as the sampler's min / mag
+// filter says; wrap modes on the integer texel index.  A masked triangle takes a 48-byte record (bit 2 of `twoSided`)
+// plus a TriRecMaskExt in the next slot of the same list.
+__device__ __forceinline__ bool filter_is_linear(uint32_t f)
+{
+    return f == CHORD_FILTER_LINEAR || f == CHORD_FILTER_LINEAR_MIPMAP_NEAREST || f == CHORD_FILTER_LINEAR_MIPMAP_LINEAR;
+}
+
+__device__ __forceinline__ uint32_t mask_level_filter(const DMaterial& m, int64_t absArea2, const float u[3], const float v[3])
+{
+    uint32_t level = 0u;
+    bool linear = filter_is_linear(m.magFilter);
+    if (m.texOffset != 0xFFFFFFFFu) {
+        const float texels = (float)m.texWidth * (float)m.texHeight;
+        const float auv = fabsf((u[1] - u[0]) * (v[2] - v[0]) - (u[2] - u[0]) * (v[1] - v[0])) * texels;
+        const float apx = (float)(double)absArea2 * (1.0f / 65536.0f);
+        const float ratio = auv / apx;
+        if (ratio >= 1.0f) {
+            const int32_t e = (int32_t)((__float_as_uint(ratio) >> 23) & 0xFFu) - 127;
+            level = min((uint32_t)(e >> 1), m.texMips - 1u);
+            linear = filter_is_linear(m.minFilter);
+        }
+    }
+    return level | (linear ? 256u : 0u);
+}
+
+__device__ __forceinline__ void write_mask_ext(TriRec* slot, const DMaterial& m, uint32_t material, int64_t absArea2,
+                                               const float u[3], const float v[3], const float w[3])
+{
+    TriRecMaskExt e;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { e.iw[i] = 1.0f / w[i]; e.uw[i] = u[i] * e.iw[i]; e.vw[i] = v[i] * e.iw[i]; }
+    e.levelFilter = mask_level_filter(m, absArea2, u, v);
+    e.material = material; e.pad = 0u;
+    *reinterpret_cast<TriRecMaskExt*>(slot) = e;
+}
+
+__device__ __forceinline__ int32_t wrap_index(long long i, long long n, uint32_t mode)
+{
+    if (mode == CHORD_WRAP_CLAMP_TO_EDGE) return (int32_t)(i < 0 ? 0 : (i > n - 1 ? n - 1 : i));
+    if (mode == CHORD_WRAP_MIRRORED_REPEAT) {
+        long long m = i % (2 * n);
+        if (m < 0) m += 2 * n;
+        return (int32_t)(m < n ? m : 2 * n - 1 - m);
+    }
+    long long m = i % n;
+    if (m < 0) m += n;
+    return (int32_t)m;
+}
+
+__device__ __forceinline__ long long texel_floor(float x)
+{
+    if (!(fabsf(x) < 1.0e9f)) return 0;
+    return (long long)floorf(x);
+}
+
+__device__ float sample_alpha(const uint8_t* __restrict__ texAlpha, const DMaterial& m, uint32_t level, bool linear, float u, float v)
+{
+    if (m.texOffset == 0xFFFFFFFFu) return 1.0f;
+    size_t off = m.texOffset;
+    for (uint32_t l = 0; l < level; l++) off += (size_t)max(1u, m.texWidth >> l) * max(1u, m.texHeight >> l);
+    const long long W = max(1u, m.texWidth >> level), H = max(1u, m.texHeight >> level);
+    const uint8_t* __restrict__ base = texAlpha + off;
+    if (!linear) {
+        const int32_t ix = wrap_index(texel_floor(u * (float)W), W, m.wrapS), iy = wrap_index(texel_floor(v * (float)H), H, m.wrapT);
+        return (float)base[(size_t)iy * (size_t)W + (size_t)ix] * (1.0f / 255.0f);
+    }
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const long long x0 = texel_floor(x), y0 = texel_floor(y);
+    float fx = x - (float)x0, fy = y - (float)y0;
+    if (!(fabsf(x) < 1.0e9f)) fx = 0.0f;
+    if (!(fabsf(y) < 1.0e9f)) fy = 0.0f;
+    const int32_t ix0 = wrap_index(x0, W, m.wrapS), ix1 = wrap_index(x0 + 1, W, m.wrapS);
+    const int32_t iy0 = wrap_index(y0, H, m.wrapT), iy1 = wrap_index(y0 + 1, H, m.wrapT);
+    const float a00 = (float)base[(size_t)iy0 * (size_t)W + (size_t)ix0] * (1.0f / 255.0f), a10 = (float)base[(size_t)iy0 * (size_t)W + (size_t)ix1] * (1.0f / 255.0f);
+    const float a01 = (float)base[(size_t)iy1 * (size_t)W + (size_t)ix0] * (1.0f / 255.0f), a11 = (float)base[(size_t)iy1 * (size_t)W + (size_t)ix1] * (1.0f / 255.0f);
+    const float top = a00 + (a10 - a00) * fx, bot = a01 + (a11 - a01) * fx;
+    return top + (bot - top) * fy;
+}
+
+// extension of a masked triangle of the cluster in flight: texture coordinates from the vertex stream, w from the
+// wave's LDS copy of the clip-space vertices.
+__device__ __forceinline__ void setup_emit_mask_ext(const RasterParams& p, TriRec* slot, uint32_t triWord, uint32_t dataOffset, uint32_t vertexBase,
+                                                 const float* lW, uint32_t material, int64_t absArea2)
+{
+    float u[3], v[3], w[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const uint32_t li = (triWord >> (8 * i)) & 0xFFu;
+        u[i] = 0.0f; v[i] = 0.0f;
+        if (p.texcoords) {
+            const size_t vi = (size_t)(p.meshletData[dataOffset + li] + vertexBase) * 2;
+            u[i] = p.texcoords[vi]; v[i] = p.texcoords[vi + 1];
+        }
+        w[i] = lW[li];
+    }
+    write_mask_ext(slot, p.materials[material], material, absArea2, u, v, w);
 }
 
 // ---- the per-cluster setup kernel -------------------------------------------------------------
 enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
 
+// MASKED: the scene has alpha-tested materials (their clusters emit 48-byte records with a texture-coordinate extension);
+// scenes without any -- every benchmark configuration -- run the instantiation that knows nothing of them.
+template <bool MASKED>
 __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
 {
     __shared__ float sX[4][LDS_VERTS], sY[4][LDS_VERTS], sW[4][LDS_VERTS];
@@ -400,7 +507,7 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
     // the NEXT cluster is fetched while the current one is processed (command at the top of the iteration, records
     // after the vertex phase), which takes two of them off the critical path.
     struct Header {
-        uint32_t objectId, meshletId, slot, V, T, dataOffset, vertexBase;
+        uint32_t objectId, meshletId, slot, V, T, dataOffset, vertexBase, matFlags;
         bool twoSided;
         Mat4 mvp;
     };
@@ -414,7 +521,9 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
         h.V = vt & 0xFFu; h.T = (vt >> 8) & 0xFFu;
         h.dataOffset = __builtin_amdgcn_readfirstlane(mm->dataOffset);
         h.vertexBase = __builtin_amdgcn_readfirstlane(mm->vertexBase);
-        h.twoSided = __builtin_amdgcn_readfirstlane(p.objStatic[h.objectId].twoSided) != 0;
+        h.matFlags = __builtin_amdgcn_readfirstlane(p.objStatic[h.objectId].matFlags);
+        h.twoSided = (h.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u;
+        if (CHORD_MATFLAG_ALPHA(h.matFlags) >= CHORD_ALPHA_BLEND) h.T = 0u;   // blended: in no bucket of renderMesh (mesh_raster.cpp:224)
         const float* __restrict__ mv = p.objFrame[h.objectId].mvp;
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -452,6 +561,7 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
         const uint32_t cu = __builtin_amdgcn_readfirstlane(c);
         const uint32_t slot = hdr.slot, V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
         const bool twoSided = hdr.twoSided;
+        const bool masked = MASKED && CHORD_MATFLAG_ALPHA(hdr.matFlags) == CHORD_ALPHA_MASK;      // (wave-uniform)
         const Mat4 mvp = hdr.mvp;
         const uint32_t triWord[2] = {t0, t1};
 
@@ -543,7 +653,9 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
             const unsigned long long cmA = __ballot(kindA == K_CLIP), cmB = __ballot(kindB == K_CLIP);
             const unsigned long long emA = __ballot(kindA == K_EMIT), emB = __ballot(kindB == K_EMIT);
             // the 32-byte record form takes every triangle whose vertices are at most 64 px apart; the rest go wide
-            const bool cpA = kindA == K_EMIT && fits_compact(tsA), cpB = kindB == K_EMIT && fits_compact(tsB);
+            // (a masked triangle takes a 48-byte record and its extension: two slots of the wide list)
+            const bool cpA = kindA == K_EMIT && !masked && fits_compact(tsA), cpB = kindB == K_EMIT && !masked && fits_compact(tsB);
+            const uint32_t wSlots = masked ? 2u : 1u;
             const unsigned long long ecA = __ballot(cpA), ecB = __ballot(cpB);
             const unsigned long long ewA = emA & ~ecA, ewB = emB & ~ecB;
             const bool lgA = kindA == K_EMIT && touches_many_tiles(tsA), lgB = kindB == K_EMIT && touches_many_tiles(tsB);
@@ -557,7 +669,7 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
             if (lane == 0) {
                 if (nClip) cbase = atomicAdd(&p.counters->clipTriCount[p.pass], nClip);
                 if (nEc) ebaseC = atomicAdd(&p.counters->triCountC[listShard * CHORD_SHARD_STRIDE], nEc);
-                if (nEw) ebaseW = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], nEw);
+                if (nEw) ebaseW = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], nEw * wSlots);
                 if (nLg) lbase = atomicAdd(&p.counters->largeCount[p.pass][listShard * CHORD_SHARD_STRIDE], nLg);
             }
             BinTicket ticket;
@@ -582,18 +694,24 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
                 if (li < p.triCapC) { giA = listShard * p.triCapC + li; write_record_c(&p.trisC[giA], tsA, dA); okA = true; }
                 else atomicOr(&p.counters->overflow, 1u);
             } else if (kindA == K_EMIT) {
-                const uint32_t li = ebaseW + (uint32_t)__popcll(ewA & lt);
-                if (li < p.triCap) { giA = listShard * p.triCap + li; write_record(&p.tris[giA], tsA, dA, twoSided); giA |= CHORD_REC_WIDE; okA = true; }
-                else atomicOr(&p.counters->overflow, 1u);
+                const uint32_t li = ebaseW + wSlots * (uint32_t)__popcll(ewA & lt);
+                if (li + wSlots <= p.triCap) {
+                    giA = listShard * p.triCap + li; write_record(&p.tris[giA], tsA, dA, twoSided, masked);
+                    if (MASKED && masked) setup_emit_mask_ext(p, &p.tris[giA + 1u], triWord[0], dataOffset, vertexBase, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsA.area);
+                    giA |= CHORD_REC_WIDE; okA = true;
+                } else atomicOr(&p.counters->overflow, 1u);
             }
             if (cpB) {
                 const uint32_t li = ebaseC + (uint32_t)__popcll(ecA) + (uint32_t)__popcll(ecB & lt);
                 if (li < p.triCapC) { giB = listShard * p.triCapC + li; write_record_c(&p.trisC[giB], tsB, dB); okB = true; }
                 else atomicOr(&p.counters->overflow, 1u);
             } else if (kindB == K_EMIT) {
-                const uint32_t li = ebaseW + (uint32_t)__popcll(ewA) + (uint32_t)__popcll(ewB & lt);
-                if (li < p.triCap) { giB = listShard * p.triCap + li; write_record(&p.tris[giB], tsB, dB, twoSided); giB |= CHORD_REC_WIDE; okB = true; }
-                else atomicOr(&p.counters->overflow, 1u);
+                const uint32_t li = ebaseW + wSlots * ((uint32_t)__popcll(ewA) + (uint32_t)__popcll(ewB & lt));
+                if (li + wSlots <= p.triCap) {
+                    giB = listShard * p.triCap + li; write_record(&p.tris[giB], tsB, dB, twoSided, masked);
+                    if (MASKED && masked) setup_emit_mask_ext(p, &p.tris[giB + 1u], triWord[1], dataOffset, vertexBase, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsB.area);
+                    giB |= CHORD_REC_WIDE; okB = true;
+                } else atomicOr(&p.counters->overflow, 1u);
             }
             // <= 2x2 tiles: straight into the bins; more: the large list
             if (emA | emB) wave_bin_commit(p, ticket, okA, giA, okB, giB);
@@ -682,28 +800,41 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
         const ChordDrawCmd cmd = p.cmds[ct.cmdIndex];
         const DMeshlet& m = p.meshlets[cmd.meshletId];
         const uint32_t V = m.vertexTriangleCount & 0xFFu;
-        const bool twoSided = p.objStatic[cmd.objectId].twoSided != 0;
+        const uint32_t matFlags = p.objStatic[cmd.objectId].matFlags;
+        const bool twoSided = (matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u;
+        const bool masked = CHORD_MATFLAG_ALPHA(matFlags) == CHORD_ALPHA_MASK;
         const float* mv = p.objFrame[cmd.objectId].mvp;
         Mat4 mvp;
         for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = mv[r * 4 + cc];
         const uint32_t packedIdx = p.meshletData[m.dataOffset + V + ct.tri];
         f4 poly[2][12];
+        float pu[2][12], pv[2][12];                               // texture coordinates ride along (masked materials only)
         for (int i = 0; i < 3; i++) {
             const uint32_t li = (packedIdx >> (8 * i)) & 0xFFu;
             const uint32_t vi = p.meshletData[m.dataOffset + li] + m.vertexBase;
             const float* pos = p.positions + (size_t)vi * 3;
             poly[0][i] = mul_mv(mvp, pos[0], pos[1], pos[2], 1.0f);
+            pu[0][i] = 0.0f; pv[0][i] = 0.0f;
+            if (masked && p.texcoords) { pu[0][i] = p.texcoords[(size_t)vi * 2]; pv[0][i] = p.texcoords[(size_t)vi * 2 + 1]; }
         }
         int np = 3, cur = 0;
         for (int pl = 0; pl < 6 && np >= 3; pl++) {
             int m2 = 0;
             for (int i = 0; i < np; i++) {
-                const f4 P = poly[cur][i], Q = poly[cur][(i + 1) % np];
+                const int j = (i + 1) % np;
+                const f4 P = poly[cur][i], Q = poly[cur][j];
                 const float dp = clip_dist(P, pl), dq = clip_dist(Q, pl);
                 const bool pin = dp >= 0.0f, qin = dq >= 0.0f;
-                if (pin) poly[cur ^ 1][m2++] = P;
-                if (pin && !qin) poly[cur ^ 1][m2++] = clip_intersect(P, Q, dp, dq);
-                else if (!pin && qin) poly[cur ^ 1][m2++] = clip_intersect(Q, P, dq, dp);
+                if (pin) { pu[cur ^ 1][m2] = pu[cur][i]; pv[cur ^ 1][m2] = pv[cur][i]; poly[cur ^ 1][m2++] = P; }
+                if (pin && !qin) {
+                    const float t = dp / (dp - dq);
+                    pu[cur ^ 1][m2] = pu[cur][i] + (pu[cur][j] - pu[cur][i]) * t; pv[cur ^ 1][m2] = pv[cur][i] + (pv[cur][j] - pv[cur][i]) * t;
+                    poly[cur ^ 1][m2++] = clip_intersect(P, Q, dp, dq);
+                } else if (!pin && qin) {
+                    const float t = dq / (dq - dp);
+                    pu[cur ^ 1][m2] = pu[cur][j] + (pu[cur][i] - pu[cur][j]) * t; pv[cur ^ 1][m2] = pv[cur][j] + (pv[cur][i] - pv[cur][j]) * t;
+                    poly[cur ^ 1][m2++] = clip_intersect(Q, P, dq, dp);
+                }
             }
             np = m2; cur ^= 1;
         }
@@ -721,6 +852,7 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
         }
         if (!ok) continue;
         const uint32_t payload = encode_triangle_instance(ct.tri, cmd.slot);
+        const uint32_t slots = masked ? 2u : 1u;
         for (int i = 1; i + 1 < np; i++) {
             TriSetup ts;
             ts.X[0] = PX[0]; ts.X[1] = PX[i]; ts.X[2] = PX[i + 1];
@@ -728,10 +860,16 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
             const float d[3] = {PD[0], PD[i], PD[i + 1]};
             ts.payload = payload;
             if (!tri_setup(ts, twoSided, p.Wi, p.Hi) || !owns_any_row(p.shard, ts.py0, ts.py1)) continue;
-            const uint32_t li = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], 1u);
-            if (li >= p.triCap) { atomicOr(&p.counters->overflow, 1u); continue; }
+            const uint32_t li = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], slots);
+            if (li + slots > p.triCap) { atomicOr(&p.counters->overflow, 1u); continue; }
             const uint32_t gi = listShard * p.triCap + li;
-            write_record(&p.tris[gi], ts, d, twoSided);
+            write_record(&p.tris[gi], ts, d, twoSided, masked);
+            if (masked) {
+                const uint32_t material = CHORD_MATFLAG_MATERIAL(matFlags);
+                const float u3[3] = {pu[cur][0], pu[cur][i], pu[cur][i + 1]}, v3[3] = {pv[cur][0], pv[cur][i], pv[cur][i + 1]};
+                const float w3[3] = {poly[cur][0].w, poly[cur][i].w, poly[cur][i + 1].w};
+                write_mask_ext(&p.tris[gi + 1u], p.materials[material], material, ts.area, u3, v3, w3);
+            }
             // clipped pieces are rare: binned right here, one (scattered) atomic per tile they may touch
             bin_record_tiles(p, ts, gi | CHORD_REC_WIDE);                // clipped pieces take the 48-byte form
         }
@@ -819,10 +957,7 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 #define TILE_SLICE_SHIFT CHORD_TILE_SLICE_SHIFT
 #define TILE_SLICE (1u << TILE_SLICE_SHIFT)
 #define TILE_SPLIT_MIN 6144u       // bins up to this many entries stay whole
-// NT threads of one workgroup.  COHERENT: the bin counts were written by other workgroups of THIS launch (returning
-// device-scope atomics, all performed before the caller drew its ticket): read them with device-scope atomic loads, a
-// plain load may be served from this XCD's L2.
-template <uint32_t NT, bool COHERENT>
+template <uint32_t NT>
 __device__ __forceinline__ void tile_order_part(const RasterParams& p)
 {
     __shared__ uint32_t hist[20], base[20], cursor[20], splitItems;
@@ -837,9 +972,7 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
         const uint32_t t = threadIdx.x + k * NT;
         myBucket[k] = 0xFFFFFFFFu; myPos[k] = 0; mySlices[k] = 1; myCount[k] = 0;
         if (t < tiles) {
-            const uint32_t raw = COHERENT ? __hip_atomic_load(&p.tileCount[(size_t)t * TC_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                          : p.tileCount[(size_t)t * TC_STRIDE];
-            const uint32_t c = min(raw, bin_capacity(p));
+            const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], bin_capacity(p));
             myCount[k] = c;
             if (c > TILE_SPLIT_MIN && !(p.debug & DBG_NO_SPLIT)) {
                 mySlices[k] = min((c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT, CHORD_TILE_MAX_SLICES);
@@ -873,26 +1006,13 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
 
 __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
 {
-    tile_order_part<1024u, false>(p);
+    tile_order_part<1024u>(p);
 }
 
-// Short scenes: clipper, large-record binning and the tile schedule in ONE launch of a small grid.  Every workgroup
-// draws a ticket when its bin writes are done (their bin-count atomics return the slot, so they have been performed by
-// then); the last one orders the tiles.  (With the ~1100 workgroups a long scene wants, the tickets alone -- ~88
-// returning atomics per microsecond on one word -- cost more than the launch they save: tools/microbench/launch_floor.)
-#define MERGED_CLIP_BLOCKS 32u
-#define MERGED_BLOCKS 128u
-__global__ __launch_bounds__(256) void raster_clip_bin_order_kernel(RasterParams p, uint32_t* ticket)
-{
-    __shared__ uint32_t sLast;
-    if (blockIdx.x < MERGED_CLIP_BLOCKS) raster_clip_part(p, blockIdx.x, MERGED_CLIP_BLOCKS);
-    else raster_bin_large_part(p, blockIdx.x - MERGED_CLIP_BLOCKS, gridDim.x - MERGED_CLIP_BLOCKS);
-    __syncthreads();
-    if (threadIdx.x == 0) sLast = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (!sLast) return;
-    tile_order_part<256u, true>(p);
-}
+// (Tried in round 2: clipper + large-record binning + this schedule in ONE launch of 128 workgroups, the last one --
+// found by a ticket -- ordering the tiles with 256 threads: 11.5 us against 5 + 5 us for the two launches.  A kernel
+// boundary costs 2.5 us on this GPU (tools/microbench/launch_floor); the rest of each 5 us is the dependent-load chain
+// of a kernel with next to nothing to do, which merging does not remove.)
 
 // ---- per-tile resolve kernel ------------------------------------------------------------------
 
@@ -996,33 +1116,8 @@ struct UnitParams {           // one batch entry, as the row loop wants it
     uint32_t box;             // x0 | y0 << 8 | x1 << 16 | y1 << 24, tile-local
     int32_t skind;            // s in bit 0 (1 = negative), kind << 1
 };
-// LDS copy of the batch, structure-of-arrays: thread t writes word f at [f][t] (consecutive lanes ->
-// consecutive banks; the 64-byte-stride AoS form was a 32-way bank conflict on every store)
-#define UNIT_WORDS 13
 #define TB 512                  // threads per tile workgroup = entries per batch
-#ifndef CHORD_TILE_V
-#define CHORD_TILE_V 3          // 1: (triangle, row) units re-derived per unit; 2: pre-computed entries + row segments; 3: + unit lists
-#endif
-#define UNIT_CAP 4096           // units per round of a batch (CHORD_TILE_V 3)
-struct UnitParamsSoA { uint32_t w[UNIT_WORDS][TB]; };
-
-__device__ __forceinline__ void unit_store(UnitParamsSoA& soa, uint32_t t, const UnitParams& u)
-{
-    soa.w[0][t] = (uint32_t)u.X[0]; soa.w[1][t] = (uint32_t)u.X[1]; soa.w[2][t] = (uint32_t)u.X[2];
-    soa.w[3][t] = (uint32_t)u.Y[0]; soa.w[4][t] = (uint32_t)u.Y[1]; soa.w[5][t] = (uint32_t)u.Y[2];
-    soa.w[6][t] = __float_as_uint(u.d0); soa.w[7][t] = __float_as_uint(u.e1); soa.w[8][t] = __float_as_uint(u.e2);
-    soa.w[9][t] = __float_as_uint(u.invA); soa.w[10][t] = u.payload; soa.w[11][t] = u.box; soa.w[12][t] = (uint32_t)u.skind;
-}
-
-__device__ __forceinline__ UnitParams unit_load(const UnitParamsSoA& soa, uint32_t t)
-{
-    UnitParams u;
-    u.X[0] = (int32_t)soa.w[0][t]; u.X[1] = (int32_t)soa.w[1][t]; u.X[2] = (int32_t)soa.w[2][t];
-    u.Y[0] = (int32_t)soa.w[3][t]; u.Y[1] = (int32_t)soa.w[4][t]; u.Y[2] = (int32_t)soa.w[5][t];
-    u.d0 = __uint_as_float(soa.w[6][t]); u.e1 = __uint_as_float(soa.w[7][t]); u.e2 = __uint_as_float(soa.w[8][t]);
-    u.invA = __uint_as_float(soa.w[9][t]); u.payload = soa.w[10][t]; u.box = soa.w[11][t]; u.skind = (int32_t)soa.w[12][t];
-    return u;
-}
+#define UNIT_CAP 4096           // units per round of a batch
 
 template <typename E_t>
 __device__ __forceinline__ void scan_row(unsigned long long* __restrict__ tileRow, const UnitParams& u, int32_t ox, int32_t py,
@@ -1092,7 +1187,7 @@ __device__ __forceinline__ uint32_t block_scan_tb(uint32_t v, uint32_t* waveSums
 }
 
 
-// ---- batch entries with pre-computed edge constants (CHORD_TILE_V >= 2) -------------------------------------------
+// ---- batch entries with pre-computed edge constants ---------------------------------------------------------------
 // The thread that fetches a bin entry also reduces it to what a pixel row needs, ONCE: for triangles whose vertices are
 // at most 64 px apart (nearly all) the three edge functions as  E_i(lx, ly) = C_i + ((a_i * lx + b_i * ly) << 8)  with
 // C_i the (top-left-biased) value at the tile's origin pixel and a_i, b_i the 16-bit pixel steps / 256 -- a row unit
@@ -1100,14 +1195,14 @@ __device__ __forceinline__ uint32_t block_scan_tb(uint32_t v, uint32_t* waveSums
 // (about 50 of the ~135 instructions a unit spent before its first pixel).  All values are exact 32-bit integers:
 // |a|, |b| <= 2^14 and a pixel of the tile is at most 2^15 + 128 sub-pixels from a vertex, so |E| < 2^31.
 // Rows wider than SEG pixels are cut into SEG-pixel segments, one unit each: a wave's row loops are at most SEG trips
-// long whatever mix of triangles the tile holds (62 % of the lanes were active before), and a tile covered by a few
+// long whatever mix of triangles the tile holds (62 % of the lanes were active in round 1), and a tile covered by a few
 // huge triangles becomes hundreds of units instead of 64.
 // Wide triangles (kind 1: fp64 edges, kind 2: int64) keep their vertices and derive the edges per unit as before.
 #ifndef SEG_SHIFT
 #define SEG_SHIFT 6             // 64: one unit per row (16 / 32 were measured 3 % / 1 % slower on config 3: more units, same trips)
 #endif
 #define SEG (1 << SEG_SHIFT)
-#define ENTRY_WORDS 12
+#define ENTRY_WORDS 13            // word 12: record index of a masked triangle (its extension follows it)
 struct EntrySoA { uint32_t w[ENTRY_WORDS][TB]; };
 #define EF_KIND_SHIFT 24          // box word: x0 | y0 << 6 | x1 << 12 | y1 << 18 | kind << 24 | bias1 << 26 | bias2 << 27 | sneg << 28
 
@@ -1185,8 +1280,10 @@ __device__ __forceinline__ int32_t scan_span_i32(unsigned long long* __restrict_
 
 // entry record of a triangle that needs row units; returns its unit count
 __device__ __forceinline__ uint32_t entry_store(EntrySoA& en, uint32_t t, const TriSetup& ts, bool narrow,
-                                                int32_t ox, int32_t oy, int32_t x0, int32_t y0, int32_t x1, int32_t y1)
+                                                int32_t ox, int32_t oy, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
+                                                bool masked = false, uint32_t recIndex = 0u)
 {
+    narrow = narrow && !masked;                                   // masked triangles keep their vertices (kind 3, int64 edges: rare)
     uint32_t box = (uint32_t)(x0 - ox) | ((uint32_t)(y0 - oy) << 6) | ((uint32_t)(x1 - ox) << 12) | ((uint32_t)(y1 - oy) << 18);
     if (narrow) {
         const int32_t s = ts.s;
@@ -1212,16 +1309,53 @@ __device__ __forceinline__ uint32_t entry_store(EntrySoA& en, uint32_t t, const 
         for (int i = 0; i < 3; i++) mag = max(mag, max(abs(ts.X[i]), abs(ts.Y[i])));
         en.w[0][t] = (uint32_t)ts.X[0]; en.w[1][t] = (uint32_t)ts.X[1]; en.w[2][t] = (uint32_t)ts.X[2];
         en.w[3][t] = (uint32_t)ts.Y[0]; en.w[4][t] = (uint32_t)ts.Y[1]; en.w[5][t] = (uint32_t)ts.Y[2];
-        box |= (mag < (1 << 25) ? 1u : 2u) << EF_KIND_SHIFT;
+        box |= (masked ? 3u : (mag < (1 << 25) ? 1u : 2u)) << EF_KIND_SHIFT;
         box |= ts.s < 0 ? 1u << 28 : 0u;
+        if (masked) en.w[12][t] = recIndex;
     }
     en.w[6][t] = __float_as_uint(ts.d0); en.w[7][t] = __float_as_uint(ts.e1); en.w[8][t] = __float_as_uint(ts.e2);
     en.w[9][t] = __float_as_uint(ts.invA); en.w[10][t] = ts.payload; en.w[11][t] = box;
     return (uint32_t)(y1 - y0 + 1) * ((uint32_t)((x1 - x0) >> SEG_SHIFT) + 1u);
 }
 
+// A pixel row of a masked triangle: exact int64 edges, canonical depth, and per covered pixel the perspective-correct
+// texture coordinates, one alpha fetch and the clip() of mesh_raster.hlsl:198-204.
+__device__ __forceinline__ void masked_row(const RasterParams& p, unsigned long long* __restrict__ tileRow, const UnitParams& u, uint32_t recIndex,
+                                        int32_t ox, int32_t py, int32_t lx0, int32_t lx1, bool noPixels)
+{
+    const TriRecMaskExt ext = *reinterpret_cast<const TriRecMaskExt*>(&p.tris[recIndex + 1u]);
+    const DMaterial m = p.materials[ext.material];
+    const uint32_t level = ext.levelFilter & 0xFFu;
+    const bool linear = (ext.levelFilter & 256u) != 0u;
+    const int64_t sgn = (u.skind & 1) ? -1 : 1;
+    const int64_t dx0 = u.X[2] - u.X[1], dy0 = u.Y[2] - u.Y[1];
+    const int64_t dx1 = u.X[0] - u.X[2], dy1 = u.Y[0] - u.Y[2];
+    const int64_t dx2 = u.X[1] - u.X[0], dy2 = u.Y[1] - u.Y[0];
+    const int64_t a0 = -sgn * dy0, b0 = sgn * dx0, a1 = -sgn * dy1, b1 = sgn * dx1, a2 = -sgn * dy2, b2 = sgn * dx2;
+    const int64_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? 0 : -1;
+    const int64_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 0 : -1;
+    const int64_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 0 : -1;
+    const int64_t cx = (int64_t)(ox + lx0) * 256 + 128, cy = (int64_t)py * 256 + 128;
+    int64_t E0 = sgn * (dx0 * (cy - u.Y[1]) - dy0 * (cx - u.X[1]));
+    int64_t E1 = sgn * (dx1 * (cy - u.Y[2]) - dy1 * (cx - u.X[2]));
+    int64_t E2 = sgn * (dx2 * (cy - u.Y[0]) - dy2 * (cx - u.X[0]));
+    for (int32_t lx = lx0; lx <= lx1; lx++, E0 += a0 * 256, E1 += a1 * 256, E2 += a2 * 256) {
+        if (E0 + bias0 < 0 || E1 + bias1 < 0 || E2 + bias2 < 0) continue;
+        const float l1 = (float)(double)E1 * u.invA, l2 = (float)(double)E2 * u.invA;
+        const float l0 = (1.0f - l1) - l2;
+        const float den = (l0 * ext.iw[0] + l1 * ext.iw[1]) + l2 * ext.iw[2];
+        const float tu = ((l0 * ext.uw[0] + l1 * ext.uw[1]) + l2 * ext.uw[2]) / den;
+        const float tv = ((l0 * ext.vw[0] + l1 * ext.vw[1]) + l2 * ext.vw[2]) / den;
+        const float alpha = sample_alpha(p.texAlpha, m, level, linear, tu, tv);
+        if (alpha * m.alphaFactor - m.alphaCutOff < 0.0f) continue;                  // clip()
+        const float z = (u.d0 + l1 * u.e1) + l2 * u.e2;
+        if (!noPixels) atomicMax(tileRow + lx, ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)u.payload);
+    }
+}
+
 // one unit = (entry e, its j-th (row, segment))
-__device__ __forceinline__ int32_t entry_unit(const EntrySoA& en, unsigned long long* tile, uint32_t e, uint32_t row, uint32_t seg,
+template <bool MASKED>
+__device__ __forceinline__ int32_t entry_unit(const RasterParams& p, const EntrySoA& en, unsigned long long* tile, uint32_t e, uint32_t row, uint32_t seg,
                                            int32_t ox, int32_t oy, unsigned long long rowMask, bool noPixels)
 {
     const uint32_t box = en.w[11][e];
@@ -1251,8 +1385,9 @@ __device__ __forceinline__ int32_t entry_unit(const EntrySoA& en, unsigned long 
         u.Y[0] = (int32_t)en.w[3][e]; u.Y[1] = (int32_t)en.w[4][e]; u.Y[2] = (int32_t)en.w[5][e];
         u.d0 = d0; u.e1 = e1; u.e2 = e2; u.invA = invA; u.payload = payload; u.box = 0;
         u.skind = (int32_t)((box >> 28) & 1u) | (int32_t)(kind << 1);
-        if (kind == 1u) scan_row<double>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
-        else            scan_row<int64_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
+        if (kind == 1u)      scan_row<double>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
+        else if (kind == 2u) scan_row<int64_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
+        else if (MASKED)     masked_row(p, tileRow, u, en.w[12][e], ox, oy + ly, lx0, lx1, noPixels);
         return lx1 - lx0 + 1;
     }
 }
@@ -1379,26 +1514,23 @@ __device__ __noinline__ bool merge_slices(unsigned long long* tile, unsigned lon
     return true;
 }
 
-template <bool SH>
+template <bool SH, bool MASKED>
 __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
 {
     __shared__ __align__(16) unsigned long long tile[TILE * TPITCH];   // 32.5 KB
-#if CHORD_TILE_V >= 2
-    __shared__ EntrySoA prm;                                     // 24 KB: the batch's entries that need row units
-#if CHORD_TILE_V >= 3
+    __shared__ EntrySoA prm;                                     // 26 KB: the batch's entries that need row units
     __shared__ uint32_t unitList[UNIT_CAP];                      // 16 KB: (entry | row << 9 | segment << 15) of the units of a round
-#endif
-#else
-    __shared__ UnitParamsSoA prm;                                // 26 KB
-#endif
-    __shared__ uint32_t offs[TB + 1];
+    __shared__ uint32_t offs[16];                                // (scratch of the tile-out reduction)
     __shared__ uint32_t waveSums[2][TB / 64];
     __shared__ uint32_t chunkTab[64];                            // the overflow chunks this item's entries live in
     __shared__ uint32_t sTicket;
     if ((p.debug & DBG_TILE_EXIT) && !p.clearTiles) return;
+    // (the item count and the block's first item are fetched together: one round trip, not two dependent ones; the
+    // list has an entry for every tile, so slot 1 + blockIdx.x exists whether or not it is active)
+    uint2 firstItem = p.tileOrder[1u + min(blockIdx.x, p.tilesX * p.tilesY - 1u)];
     const uint32_t active = p.tileOrder[0].x;
     for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
-    const uint2 itemCount = p.tileOrder[1u + oi];
+    const uint2 itemCount = oi == blockIdx.x ? firstItem : p.tileOrder[1u + oi];
     const uint32_t item = itemCount.x;
     const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
     const uint32_t nAll = itemCount.y;                            // (already clamped to the bin capacity)
@@ -1526,26 +1658,12 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                 const int32_t x1 = min(ts.px1, ox + tw - 1), y1 = min(ts.py1, oy + th - 1);
                 if (x1 >= x0 && y1 >= y0) {
                     const bool narrow = narrow_extent(ts);
-                    if (narrow && (x1 - x0 + 1) * (y1 - y0 + 1) <= TINY_AREA) {
+                    const bool maskedRec = MASKED && (name & CHORD_REC_WIDE) && (q2.z & 4u);   // a TriRecMaskExt follows the record
+                    if (narrow && !maskedRec && (x1 - x0 + 1) * (y1 - y0 + 1) <= TINY_AREA) {
                         if (!(p.debug & DBG_NO_TINY)) tile_raster_narrow(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask);
                         if (prof) { cTiny++; cTinyIters += (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1)); }
                     } else {
-#if CHORD_TILE_V >= 2
-                        rows = entry_store(prm, threadIdx.x, ts, narrow, ox, oy, x0, y0, x1, y1);      // (units, not rows)
-#else
-                        int32_t mag = 0;
-#pragma unroll
-                        for (int i = 0; i < 3; i++) mag = max(mag, max(abs(ts.X[i]), abs(ts.Y[i])));
-                        const int32_t kind = narrow ? 0 : (mag < (1 << 25) ? 1 : 2);
-                        UnitParams u;
-#pragma unroll
-                        for (int i = 0; i < 3; i++) { u.X[i] = ts.X[i]; u.Y[i] = ts.Y[i]; }
-                        u.d0 = ts.d0; u.e1 = ts.e1; u.e2 = ts.e2; u.invA = ts.invA; u.payload = ts.payload;
-                        u.box = (uint32_t)(x0 - ox) | ((uint32_t)(y0 - oy) << 8) | ((uint32_t)(x1 - ox) << 16) | ((uint32_t)(y1 - oy) << 24);
-                        u.skind = (ts.s < 0 ? 1 : 0) | (kind << 1);
-                        unit_store(prm, threadIdx.x, u);
-                        rows = (uint32_t)(y1 - y0 + 1);
-#endif
+                        rows = entry_store(prm, threadIdx.x, ts, narrow, ox, oy, x0, y0, x1, y1, maskedRec, name & ~CHORD_REC_WIDE);   // (units, not rows)
                     }
                 }
             }
@@ -1554,13 +1672,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         uint32_t total;
         // (the wave sums alternate between two buffers: a batch without units then needs no barrier but the scan's own)
         const uint32_t off = block_scan_tb(rows, waveSums[(base >> 9) & 1u], &total);
-#if CHORD_TILE_V < 3
-        offs[threadIdx.x] = off;
-        if (threadIdx.x == 0) offs[TB] = total;
-        __syncthreads();
-#endif
         PHASE(3);
-#if CHORD_TILE_V >= 3
         // rounds of UNIT_CAP units: every entry thread lists its units of the round (one LDS word each), then every
         // thread takes units TB apart -- a unit finds its entry with ONE read instead of a 9-step binary search
         for (uint32_t r0 = 0; r0 < total; r0 += UNIT_CAP) {
@@ -1584,50 +1696,12 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
             for (uint32_t ui = threadIdx.x; ui < nr; ui += TB) {
                 const uint32_t d = unitList[ui];
                 if (p.debug & DBG_NO_UNITS) continue;
-                const int32_t trips = entry_unit(prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, rowMask, noPixels);
+                const int32_t trips = entry_unit<MASKED>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, rowMask, noPixels);
                 if (prof) { cUnits++; cUnitIters += (uint32_t)trips; }
             }
             if (r0 + UNIT_CAP < total) __syncthreads();           // the list is rewritten by the next round
         }
-#elif CHORD_TILE_V == 2
-        for (uint32_t u0 = 0; u0 < total; u0 += TB) {
-            const uint32_t ui = u0 + threadIdx.x;
-            if (ui < total) {
-                uint32_t e = 0;                                   // last entry with offs[e] <= ui
-#pragma unroll
-                for (uint32_t st = TB / 2; st > 0; st >>= 1) if (offs[e + st] <= ui) e += st;
-                const uint32_t box = prm.w[11][e];
-                const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> SEG_SHIFT) + 1u, j = ui - offs[e];
-                const uint32_t rowj = nseg == 1u ? j : nseg == 2u ? j >> 1 : nseg == 4u ? j >> 2 : j / 3u;
-                const uint32_t seg = j - rowj * nseg;
-                entry_unit(prm, tile, e, ((box >> 6) & 63u) + rowj, seg, ox, oy, rowMask, noPixels);
-            }
-        }
-#else
-        for (uint32_t u0 = 0; u0 < total; u0 += TB) {
-            const uint32_t ui = u0 + threadIdx.x;
-            if (ui < total) {
-                uint32_t e = 0;                                   // last entry with offs[e] <= ui
-#pragma unroll
-                for (uint32_t st = TB / 2; st > 0; st >>= 1) if (offs[e + st] <= ui) e += st;
-                const UnitParams u = unit_load(prm, e);
-                const int32_t ly = (int32_t)((u.box >> 8) & 0xFFu) + (int32_t)(ui - offs[e]);
-                if ((rowMask >> ly) & 1ull) {
-                    const int32_t lx0 = (int32_t)(u.box & 0xFFu), lx1 = (int32_t)((u.box >> 16) & 0xFFu);
-                    unsigned long long* tileRow = tile + ly * TPITCH;
-                    const int32_t kind = u.skind >> 1;
-                    if (kind == 0)      scan_row<int32_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
-                    else if (kind == 1) scan_row<double>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
-                    else                scan_row<int64_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
-                }
-            }
-        }
-#endif
-#if CHORD_TILE_V >= 3
         if (total) __syncthreads();                               // prm / the unit list are rewritten by the next batch
-#else
-        __syncthreads();                                          // prm / offs are rewritten by the next batch
-#endif
         PHASE(4);
     }
     __syncthreads();
@@ -1718,6 +1792,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     }
     p.objFrame = c->dObjFrame; p.objStatic = c->dObjStatic;
     p.meshlets = c->dMeshlets; p.meshletData = c->dMeshletData; p.positions = c->dPositions;
+    p.materials = c->dMaterials; p.texAlpha = c->dTexAlpha; p.texcoords = c->dTexcoords;
     p.vis = (unsigned long long*)c->dVis;
     p.W = (float)c->width; p.H = (float)c->height; p.Wi = (int32_t)c->width; p.Hi = (int32_t)c->height;
     p.shard = c->shard;
@@ -1748,7 +1823,6 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         LR_HIP(hipMemsetAsync(&c->dCounters->clipTriCount[pass], 0, sizeof(uint32_t), c->stream));
         LR_HIP(hipMemsetAsync(c->dCounters->largeCount[pass], 0, sizeof(c->dCounters->largeCount[pass]), c->stream));
         LR_HIP(hipMemsetAsync(&c->dCounters->binPoolCount[pass], 0, sizeof(uint32_t), c->stream));
-        LR_HIP(hipMemsetAsync(&c->dCounters->orderTicket[pass], 0, sizeof(uint32_t), c->stream));
         if (!c->inFrame) { LR_HIP(hipMemsetAsync(c->dCounters->triCount, 0, sizeof(c->dCounters->triCount), c->stream));
                            LR_HIP(hipMemsetAsync(c->dCounters->triCountC, 0, sizeof(c->dCounters->triCountC), c->stream)); }
     }
@@ -1759,20 +1833,22 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     if (blocks < 1) blocks = 1;
     const bool sh = c->shard.ranks > 1;
     stamp(c, S_HZBCULL);      // closes whatever preceded the raster (HZB cull / list reset)
-    hipLaunchKernelGGL(raster_setup_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+    if (c->anyMasked) hipLaunchKernelGGL(raster_setup_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p);
+    else              hipLaunchKernelGGL(raster_setup_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p);
     stamp(c, S_R_CLUSTER);
-    if (c->cullBlocks <= 512u) {
-        hipLaunchKernelGGL(raster_clip_bin_order_kernel, dim3(MERGED_BLOCKS), dim3(256), 0, c->stream, p, &c->dCounters->orderTicket[pass]);
-    } else {
-        hipLaunchKernelGGL(raster_clip_and_bin_large_kernel, dim3(CLIP_BLOCKS + (uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
-        hipLaunchKernelGGL(raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
-    }
+    hipLaunchKernelGGL(raster_clip_and_bin_large_kernel, dim3(CLIP_BLOCKS + (uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
     stamp(c, S_R_CLIP);
     // first pass of a frame: every tile is written, one block each, dispatched heaviest first; later passes touch
     // few tiles: one resident wave of blocks strides over the (device-side) active list
     const uint32_t tileBlocks = clearTiles ? tiles : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
-    if (sh) hipLaunchKernelGGL(raster_tile_kernel<true>, dim3(tileBlocks), dim3(TB), 0, c->stream, p);
-    else    hipLaunchKernelGGL(raster_tile_kernel<false>, dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+    if (c->anyMasked) {
+        if (sh) hipLaunchKernelGGL((raster_tile_kernel<true, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        else    hipLaunchKernelGGL((raster_tile_kernel<false, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+    } else {
+        if (sh) hipLaunchKernelGGL((raster_tile_kernel<true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        else    hipLaunchKernelGGL((raster_tile_kernel<false, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+    }
     stamp(c, S_R_CHUNK);
     c->rasterCalls++;
     return hipSuccess;

@@ -78,6 +78,7 @@ class AssetDesc(C.Structure):
         ("meshletGroupIndices", C.c_void_p), ("meshletGroupIndexCount", C.c_uint32),
         ("meshletData", C.c_void_p), ("meshletDataCount", C.c_uint32),
         ("positions", C.c_void_p), ("vertexCount", C.c_uint32),
+        ("texcoord0", C.c_void_p), ("texcoord0Count", C.c_uint32),
     ]
 
 
@@ -87,7 +88,41 @@ class SceneDesc(C.Structure):
         ("primitives", C.c_void_p), ("primitiveCount", C.c_uint32),
         ("materials", C.c_void_p), ("materialCount", C.c_uint32),
         ("assets", C.POINTER(AssetDesc)), ("assetCount", C.c_uint32),
+        ("textures", C.c_void_p), ("textureCount", C.c_uint32),
+        ("samplers", C.c_void_p), ("samplerCount", C.c_uint32),
     ]
+
+
+class Texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("mipCount", C.c_uint32), ("pad", C.c_uint32)]
+
+
+SAMPLER = np.dtype([("minFilter", u32), ("magFilter", u32), ("wrapS", u32), ("wrapT", u32)])
+ALPHA_OPAQUE, ALPHA_MASK, ALPHA_BLEND = 0, 1, 2
+FILTER_NEAREST, FILTER_LINEAR = 9728, 9729
+FILTER_NEAREST_MIPMAP_NEAREST, FILTER_LINEAR_MIPMAP_NEAREST, FILTER_NEAREST_MIPMAP_LINEAR, FILTER_LINEAR_MIPMAP_LINEAR = 9984, 9985, 9986, 9987
+WRAP_REPEAT, WRAP_CLAMP_TO_EDGE, WRAP_MIRRORED_REPEAT = 10497, 33071, 33648
+
+
+def mip_chain_rgba8(level0):
+    """All mip levels of an (H, W, 4) uint8 image back to back (2x2 box filter, floor division; odd sizes drop the last
+    row / column like a plain downsample), as ChordTexture::rgba8 wants them.  Returns (bytes array, mipCount)."""
+    img = np.ascontiguousarray(level0, dtype=np.uint8)
+    levels = [img]
+    while img.shape[0] > 1 or img.shape[1] > 1:
+        h, w = max(1, img.shape[0] // 2), max(1, img.shape[1] // 2)
+        a = img[:h * 2 if img.shape[0] > 1 else 1, :w * 2 if img.shape[1] > 1 else 1].astype(np.uint32)
+        if img.shape[0] > 1:
+            a = a[0::2] + a[1::2]
+        else:
+            a = a * 2
+        if img.shape[1] > 1:
+            a = a[:, 0::2] + a[:, 1::2]
+        else:
+            a = a * 2
+        img = ((a + 2) // 4).astype(np.uint8)
+        levels.append(img)
+    return np.concatenate([l.reshape(-1) for l in levels]), len(levels)
 
 
 class HZBDesc(C.Structure):
@@ -115,7 +150,8 @@ class Scene:
     """
 
     def __init__(self, objects, primitives, materials, meshlets, groups, group_indices, meshlet_data, positions,
-                 name="scene"):
+                 name="scene", texcoord0=None, textures=(), samplers=None):
+        """textures: sequence of (H, W, 4) uint8 images (mip chains are built here); samplers: SAMPLER records."""
         self.name = name
         self.objects = np.ascontiguousarray(objects, dtype=OBJECT)
         self.primitives = np.ascontiguousarray(primitives, dtype=PRIMITIVE)
@@ -125,12 +161,20 @@ class Scene:
         self.group_indices = np.ascontiguousarray(group_indices, dtype=u32)
         self.meshlet_data = np.ascontiguousarray(meshlet_data, dtype=u32)
         self.positions = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
+        self.texcoord0 = None if texcoord0 is None else np.ascontiguousarray(texcoord0, dtype=f32).reshape(-1, 2)
+        self.texture_images = list(textures)
+        self._tex_chains = [mip_chain_rgba8(t) for t in self.texture_images]
+        self._textures = (Texture * max(1, len(self._tex_chains)))()
+        for i, (chain, mips) in enumerate(self._tex_chains):
+            self._textures[i] = Texture(chain.ctypes.data, self.texture_images[i].shape[1], self.texture_images[i].shape[0], mips, 0)
+        self.samplers = np.zeros(0, dtype=SAMPLER) if samplers is None else np.ascontiguousarray(samplers, dtype=SAMPLER)
         self._asset = AssetDesc(
             self.meshlets.ctypes.data, len(self.meshlets),
             self.groups.ctypes.data, len(self.groups),
             self.group_indices.ctypes.data, len(self.group_indices),
             self.meshlet_data.ctypes.data, len(self.meshlet_data),
             self.positions.ctypes.data, len(self.positions),
+            self.texcoord0.ctypes.data if self.texcoord0 is not None else None, len(self.texcoord0) if self.texcoord0 is not None else 0,
         )
         self._assets = (AssetDesc * 1)(self._asset)
         self.desc = SceneDesc(
@@ -138,7 +182,18 @@ class Scene:
             self.primitives.ctypes.data, len(self.primitives),
             self.materials.ctypes.data, len(self.materials),
             self._assets, 1,
+            C.cast(self._textures, C.c_void_p) if self._tex_chains else None, len(self._tex_chains),
+            self.samplers.ctypes.data if len(self.samplers) else None, len(self.samplers),
         )
+
+    def with_objects(self, objects=None, materials=None):
+        """The same geometry, textures and samplers under other object / material records (shallow: arrays are shared)."""
+        out = Scene(self.objects if objects is None else objects, self.primitives, self.materials if materials is None else materials,
+                    self.meshlets, self.groups, self.group_indices, self.meshlet_data, self.positions, name=self.name,
+                    texcoord0=self.texcoord0, textures=self.texture_images, samplers=self.samplers)
+        if hasattr(self, "local_to_world"):
+            out.local_to_world = self.local_to_world
+        return out
 
     # --- aggregate counts the reference keeps in PerframeCollected (scene_common.h) -------------
     @property

@@ -100,6 +100,8 @@ class PrimitiveBuilder:
 
     def __init__(self):
         self.positions = []        # list of (n,3) float32
+        self.texcoords = []        # list of (n,2) float32: the surface parameters (u, v) times uv_scale
+        self.uv_scale = (1.0, 1.0)
         self.nverts = 0
         self.meshlets = []         # list of structured arrays (dataOffset relative to primitive)
         self.meshlet_data = []     # list of uint32 arrays
@@ -109,9 +111,10 @@ class PrimitiveBuilder:
         self.group_indices = []
         self.nindices = 0
 
-    def _add_meshlets(self, pos, lod):
-        """pos (M,81,3) float32. Returns meshlet ids (relative to this primitive)."""
+    def _add_meshlets(self, pos, lod, uv=None):
+        """pos (M,81,3) float32, uv (M,81,2). Returns meshlet ids (relative to this primitive)."""
         M = pos.shape[0]
+        self.texcoords.append(np.zeros((M * PATCH_V, 2), np.float32) if uv is None else uv.reshape(-1, 2).astype(np.float32))
         pmin, pmax, axis, cutoff, apex = _meshlet_bounds(pos)
         ml = np.zeros(M, dtype=T.MESHLET)
         ml["posMin"], ml["posMax"] = pmin, pmax
@@ -157,11 +160,12 @@ class PrimitiveBuilder:
             U = u0[:, None, None] + du * k[None, None, :]
             V = v0[:, None, None] + dv * k[None, :, None]
             U, V = np.broadcast_arrays(U, V)
+            self._last_uv = np.stack([U * self.uv_scale[0], V * self.uv_scale[1]], axis=-1).astype(np.float32).reshape(len(u0), 81, 2)
             return S(U, V).astype(np.float32).reshape(len(u0), 81, 3)
 
         pi, pj = np.meshgrid(np.arange(P), np.arange(Q), indexing="xy")     # (Q,P)
         pos0 = sample((pi / P).reshape(-1), (pj / Q).reshape(-1), 1.0 / P, 1.0 / Q)
-        ids0 = self._add_meshlets(pos0, 0).reshape(Q, P)
+        ids0 = self._add_meshlets(pos0, 0, self._last_uv).reshape(Q, P)
         edge = float(np.mean(np.linalg.norm(pos0[:, 8].astype(np.float64) - pos0[:, 0].astype(np.float64), axis=1)))
         e1, e2 = error_scale * edge, 2.0 * error_scale * edge
 
@@ -193,7 +197,7 @@ class PrimitiveBuilder:
         u0 = np.stack([bi * 2 / P, bi * 2 / P + 1.0 / P], axis=-1).reshape(-1)
         v0 = np.repeat((bj * 2 / Q).reshape(-1), 2)
         pos1 = sample(u0, v0, 1.0 / P, 2.0 / Q)
-        ids1 = self._add_meshlets(pos1, 1).reshape(Q // 2, P // 2, 2)
+        ids1 = self._add_meshlets(pos1, 1, self._last_uv).reshape(Q // 2, P // 2, 2)
         if lods == 2:
             self._add_groups(ids1.reshape(-1, 2), c1.reshape(-1, 3), e1, 0.0, FLT_MAX)
             return
@@ -204,7 +208,7 @@ class PrimitiveBuilder:
         # LOD2: four meshlets per 4x4 block, each spanning a 2x2-patch quadrant
         qi, qj = np.meshgrid(np.arange(P // 2), np.arange(Q // 2), indexing="xy")
         pos2 = sample((qi * 2 / P).reshape(-1), (qj * 2 / Q).reshape(-1), 2.0 / P, 2.0 / Q)
-        ids2 = self._add_meshlets(pos2, 2).reshape(Q // 2, P // 2)
+        ids2 = self._add_meshlets(pos2, 2, self._last_uv).reshape(Q // 2, P // 2)
         blk2 = ids2.reshape(Q // 4, 2, P // 4, 2).transpose(0, 2, 1, 3).reshape(-1, 4)
         self._add_groups(blk2, c2.reshape(-1, 3), e2, 0.0, FLT_MAX)
 
@@ -212,6 +216,7 @@ class PrimitiveBuilder:
         pos = np.concatenate(self.positions) if self.positions else np.zeros((0, 3), np.float32)
         return dict(
             positions=pos,
+            texcoords=np.concatenate(self.texcoords) if self.texcoords else np.zeros((0, 2), np.float32),
             meshlets=np.concatenate(self.meshlets),
             meshlet_data=np.concatenate(self.meshlet_data),
             groups=np.concatenate(self.groups),
@@ -227,18 +232,31 @@ class SceneBuilder:
         self.obj_prim = []
         self.obj_mat = []
         self.obj_l2w = []
+        self.textures = []
+        self.samplers = []
 
     @staticmethod
-    def _material(two_sided):
+    def _material(two_sided, alpha_mode=0, texture=0xFFFFFFFF, sampler=0, cutoff=0.5, alpha_factor=1.0):
         m = np.zeros(1, dtype=T.MATERIAL)
         m["bTwoSided"] = two_sided
         m["baseColorFactor"] = 1.0
+        m["baseColorFactor"][0, 3] = alpha_factor
+        m["alphaMode"], m["alphaCutOff"] = alpha_mode, cutoff
+        m["baseColorId"], m["baseColorSampler"] = texture, sampler
         m["materialType"] = 1
         return m
 
-    def add_material(self, two_sided):
-        self.materials.append(self._material(two_sided))
+    def add_material(self, two_sided, alpha_mode=0, texture=0xFFFFFFFF, sampler=0, cutoff=0.5, alpha_factor=1.0):
+        self.materials.append(self._material(two_sided, alpha_mode, texture, sampler, cutoff, alpha_factor))
         return len(self.materials) - 1
+
+    def add_texture(self, rgba8):
+        self.textures.append(np.ascontiguousarray(rgba8, dtype=np.uint8))
+        return len(self.textures) - 1
+
+    def add_sampler(self, min_filter=T.FILTER_LINEAR_MIPMAP_LINEAR, mag_filter=T.FILTER_LINEAR, wrap_s=T.WRAP_REPEAT, wrap_t=T.WRAP_REPEAT):
+        self.samplers.append((min_filter, mag_filter, wrap_s, wrap_t))
+        return len(self.samplers) - 1
 
     def add_primitive(self, builder):
         self.prims.append(builder.finish())
@@ -252,7 +270,7 @@ class SceneBuilder:
 
     def build(self):
         prims = np.zeros(len(self.prims), dtype=T.PRIMITIVE)
-        pos, ml, md, gr, gi = [], [], [], [], []
+        pos, ml, md, gr, gi, uv = [], [], [], [], [], []
         nv = nm = nd = ng = ni = 0
         for i, p in enumerate(self.prims):
             prims[i]["posMin"] = p["positions"].min(axis=0)
@@ -264,13 +282,15 @@ class SceneBuilder:
             prims[i]["meshletGroupIndicesOffset"] = ni
             m = p["meshlets"].copy()
             m["dataOffset"] += nd
-            pos.append(p["positions"]); ml.append(m); md.append(p["meshlet_data"]); gr.append(p["groups"]); gi.append(p["group_indices"])
+            uv.append(p["texcoords"]); pos.append(p["positions"]); ml.append(m); md.append(p["meshlet_data"]); gr.append(p["groups"]); gi.append(p["group_indices"])
             nv += len(p["positions"]); nm += len(m); nd += len(p["meshlet_data"]); ng += len(p["groups"]); ni += len(p["group_indices"])
         objects = np.zeros(len(self.obj_prim), dtype=T.OBJECT)
         objects["GLTFPrimitiveDetail"] = np.array(self.obj_prim, dtype=np.uint32)
         objects["GLTFMaterialData"] = np.array(self.obj_mat, dtype=np.uint32)
         scene = T.Scene(objects, prims, np.concatenate(self.materials), np.concatenate(ml), np.concatenate(gr),
-                        np.concatenate(gi), np.concatenate(md), np.concatenate(pos), name=self.name)
+                        np.concatenate(gi), np.concatenate(md), np.concatenate(pos), name=self.name,
+                        texcoord0=np.concatenate(uv) if (self.textures and uv) else None, textures=self.textures,
+                        samplers=np.array(self.samplers, dtype=T.SAMPLER) if self.samplers else None)
         # glm column-major doubles
         scene.local_to_world = np.ascontiguousarray(np.stack([m.T.reshape(16) for m in self.obj_l2w]), dtype=np.float64)
         return scene
@@ -494,12 +514,88 @@ def small_test_scene(width=160, height=96, lods=3, seed=7, two_sided_every=3):
     return sb.build(), cam
 
 
+def _alpha_textures(seed):
+    """Three procedural RGBA8 textures whose alpha the masked materials test: a checker, an odd-sized noise, a disc."""
+    yy, xx = np.mgrid[0:64, 0:64]
+    checker = np.where(((xx // 8) + (yy // 8)) % 2 == 0, 255, 0).astype(np.uint8)
+    noise = (pcg_hash(np.arange(37 * 21, dtype=np.uint32) + np.uint32(seed * 7919)) & 0xFF).astype(np.uint8).reshape(21, 37)
+    yy, xx = np.mgrid[0:16, 0:16]
+    disc = np.clip(255.0 - 40.0 * np.hypot(xx - 7.5, yy - 7.5), 0, 255).astype(np.uint8)
+    out = []
+    for a in (checker, noise, disc):
+        img = np.zeros(a.shape + (4,), np.uint8)
+        img[..., 0:3] = 200
+        img[..., 3] = a
+        out.append(img)
+    return out
+
+
+def masked_test_scene(width=320, height=200, lods=2, seed=3, position=(-6.5, 2.2, 6.0), front=(0.75, -0.22, -0.62)):
+    """small_test_scene's layout with alpha-tested, blended and white-fallback materials (mesh_raster.hlsl:34-38,107-112,
+    198-204; mesh_raster.cpp:224): holes in the masked surfaces show the geometry behind them, blended objects draw
+    nothing.  Three textures x three samplers (every wrap mode, nearest and linear, with and without minification)."""
+    sb = SceneBuilder("masked_test_scene")
+    tex = [sb.add_texture(t) for t in _alpha_textures(seed)]
+    smp = [sb.add_sampler(T.FILTER_LINEAR_MIPMAP_LINEAR, T.FILTER_LINEAR, T.WRAP_REPEAT, T.WRAP_REPEAT),
+           sb.add_sampler(T.FILTER_NEAREST, T.FILTER_NEAREST, T.WRAP_CLAMP_TO_EDGE, T.WRAP_MIRRORED_REPEAT),
+           sb.add_sampler(T.FILTER_LINEAR_MIPMAP_NEAREST, T.FILTER_NEAREST, T.WRAP_MIRRORED_REPEAT, T.WRAP_CLAMP_TO_EDGE)]
+    mats = [sb.add_material(0, T.ALPHA_MASK, tex[0], smp[0], 0.5, 1.0),        # one-sided checker
+            sb.add_material(1, T.ALPHA_MASK, tex[1], smp[1], 0.4, 0.9),        # two-sided noise, nearest, clamp / mirror
+            sb.add_material(1, T.ALPHA_MASK, tex[2], smp[2], 0.35, 1.0),       # two-sided disc, mirrored / clamp
+            sb.add_material(0, T.ALPHA_BLEND),                                  # blended: draws nothing
+            sb.add_material(0, T.ALPHA_MASK, 0xFFFFFFFF, 99, 0.5, 1.0),        # no texture: white fallback, opaque in effect
+            sb.add_material(1, T.ALPHA_MASK, tex[0], smp[0], 0.5, 0.4)]        # alpha factor below the cut-off: nothing survives
+    pb = PrimitiveBuilder()
+    pb.add_surface(plane_surface((-8, 0, 8), (16, 0, 0), (0, 0, -16), seed, 0.2, 0.7), 8, 8, lods)
+    sb.add_object(sb.add_primitive(pb))                                          # opaque ground
+    for k in range(8):
+        r = rand01(seed + 1, np.arange(k * 4, k * 4 + 4))
+        pb = PrimitiveBuilder()
+        pb.uv_scale = (1.0 + 3.0 * r[3], 0.5 + 2.5 * r[2]) if k % 3 else (-2.0, 3.0)     # tiling, incl. negative coordinates
+        if k % 2 == 0:
+            _building(pb, 1.5 + r[0], 1.5 + r[1], 1.0 + 2.5 * r[2], seed * 100 + k * 8, lods)
+        else:
+            pb.add_surface(cylinder_surface((0, 0, 0), 0.3 + 0.4 * r[0], 1.0 + 2.0 * r[1], seed * 100 + k, 0.03), 4, 4, lods)
+        prim = sb.add_primitive(pb)
+        m = translate(-5.0 + 10.0 * r[2], 0.0, -5.0 + 10.0 * r[3]) @ rotate_y(r[0] * 3.0) @ scale(1.0 + 0.5 * r[1])
+        sb.add_object(prim, m, material=mats[k % len(mats)])
+        if k in (1, 4):                                                          # an opaque copy behind a masked one
+            sb.add_object(prim, translate(0.6, 0.0, -1.2) @ m, material=0)
+    # a masked screen right in front of the camera: magnified texels, clipped by the near plane at the edges
+    pb = PrimitiveBuilder()
+    pb.uv_scale = (3.0, 2.0)
+    f = np.array(front, dtype=np.float64) / np.linalg.norm(front)
+    side = np.cross(f, (0.0, 1.0, 0.0)); side /= np.linalg.norm(side)
+    org = np.array(position) + 0.9 * f - 0.7 * side - np.array((0.0, 0.45, 0.0))
+    pb.add_surface(plane_surface(tuple(org), tuple(1.4 * side), (0.0, 0.9, 0.0), seed + 5, 0.0, 1.0), 4, 4, 1)
+    sb.add_object(sb.add_primitive(pb), material=mats[1])
+    cam = Camera(position, front, width, height)
+    return sb.build(), cam
+
+
 def floor_under_camera(position=(0.3, 0.25, 0.2), front=(0.1, -0.6, -1.0), width=128, height=96):
     """One coarse 16 m floor patch (2 m cells) with the camera just above it: its triangles straddle
     the w = 0 plane and exercise the homogeneous clipper."""
     pb = PrimitiveBuilder()
     pb.add_surface(plane_surface((-8, 0, 8), (16, 0, 0), (0, 0, -16)), 1, 1)
     sb = SceneBuilder("floor_under_camera")
+    sb.add_object(sb.add_primitive(pb))
+    return sb.build(), Camera(position, front, width, height)
+
+
+def masked_floor_under_camera(position=(0.3, 0.25, 0.2), front=(0.1, -0.6, -1.0), width=160, height=120, seed=4):
+    """floor_under_camera with an alpha-tested checker on the (two-sided) floor and an opaque floor 1 m below it: the
+    triangles that straddle the w = 0 plane go through the clipper WITH their texture coordinates."""
+    sb = SceneBuilder("masked_floor_under_camera")
+    tex = sb.add_texture(_alpha_textures(seed)[0])
+    smp = sb.add_sampler(T.FILTER_LINEAR_MIPMAP_LINEAR, T.FILTER_LINEAR, T.WRAP_REPEAT, T.WRAP_MIRRORED_REPEAT)
+    mat = sb.add_material(1, T.ALPHA_MASK, tex, smp, 0.5, 1.0)
+    pb = PrimitiveBuilder()
+    pb.uv_scale = (6.0, 6.0)
+    pb.add_surface(plane_surface((-8, 0, 8), (16, 0, 0), (0, 0, -16)), 1, 1)
+    sb.add_object(sb.add_primitive(pb), material=mat)
+    pb = PrimitiveBuilder()
+    pb.add_surface(plane_surface((-8, -1, 8), (16, 0, 0), (0, 0, -16)), 2, 2)
     sb.add_object(sb.add_primitive(pb))
     return sb.build(), Camera(position, front, width, height)
 

@@ -197,9 +197,11 @@ int chordvis_instance_culling(ChordCtx* ctx, ChordCountAndCmd* out);
 int chordvis_hzb_culling(ChordCtx* ctx, const ChordHZB* hzb, int bFirstStage, ChordCountAndCmd in,
                          ChordCountAndCmd* outVisible, ChordCountAndCmd* outRejected);
 
-/* renderMesh — mesh_raster.cpp:208-254: the 4 material buckets (filterPipeForVisibility +
- * renderMeshRasterPipe) collapse into one software-raster launch that reads bTwoSided per
- * cluster; masked materials are out of scope. */
+/* renderMesh — mesh_raster.cpp:208-254: the 4 material buckets (filterPipeForVisibility + renderMeshRasterPipe, alphaMode
+ * 0/1 x two-sided 0/1) collapse into one software-raster pass that reads bTwoSided and alphaMode per cluster.  Masked
+ * materials (mesh_raster.hlsl:34-38,107-112,198-204) are alpha-tested per pixel with a software texture fetch whose
+ * level of detail and filter are pinned (the reference leaves them to the sampler hardware);
+ * blended materials (alphaMode 2) are in no bucket and draw nothing, as in the reference. */
 int chordvis_render_mesh(ChordCtx* ctx, ChordCountAndCmd in);
 
 /* gltfVisibilityRenderingStage0 — mesh_raster.cpp:269-311.  hzbPrev NULL/invalid or HZB culling

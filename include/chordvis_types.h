@@ -159,6 +159,35 @@ typedef struct ChordDrawCmd {
     uint32_t slot;         /* index in the post-instanceCulling list; the visibility payload */
 } ChordDrawCmd;
 
+/* GLTFMaterialGPUData::alphaMode -- EAlphaMode (asset_gltf.h:161; asset_gltf_material.cpp:703-705).  The visibility and
+ * depth passes draw the opaque and the masked bucket; blended materials are in neither (mesh_raster.cpp:178,224). */
+#define CHORD_ALPHA_OPAQUE 0u
+#define CHORD_ALPHA_MASK   1u
+#define CHORD_ALPHA_BLEND  2u
+
+/* GLTFSampler (asset_gltf.h:9-39), the glTF enum values as the reference keeps them. */
+#define CHORD_FILTER_NEAREST                 9728u
+#define CHORD_FILTER_LINEAR                  9729u
+#define CHORD_FILTER_NEAREST_MIPMAP_NEAREST  9984u
+#define CHORD_FILTER_LINEAR_MIPMAP_NEAREST   9985u
+#define CHORD_FILTER_NEAREST_MIPMAP_LINEAR   9986u
+#define CHORD_FILTER_LINEAR_MIPMAP_LINEAR    9987u
+#define CHORD_WRAP_REPEAT           10497u
+#define CHORD_WRAP_CLAMP_TO_EDGE    33071u
+#define CHORD_WRAP_MIRRORED_REPEAT  33648u
+typedef struct ChordSampler {
+    uint32_t minFilter, magFilter, wrapS, wrapT;
+} ChordSampler;
+
+/* A base-colour texture as the masked buckets read it (mesh_raster.hlsl:198-204: only .w of the sample is used):
+ * RGBA8, `mipCount` levels back to back starting with level 0 (level l is max(1, width >> l) x max(1, height >> l)).
+ * ChordMaterial::baseColorId / baseColorSampler index ChordSceneDesc::textures / samplers (the reference's bindless ids);
+ * an id >= textureCount reads as the reference's white fallback (alpha 1, asset_gltf.cpp:374). */
+typedef struct ChordTexture {
+    const uint8_t* rgba8;
+    uint32_t width, height, mipCount, pad;
+} ChordTexture;
+
 /* One GLTFPrimitiveDatasBuffer (gltf.h:94-116): bindless ids -> host pointers. */
 typedef struct ChordAssetDesc {
     const ChordMeshlet*      meshlets;           uint32_t meshletCount;
@@ -166,6 +195,8 @@ typedef struct ChordAssetDesc {
     const uint32_t*          meshletGroupIndices;uint32_t meshletGroupIndexCount;
     const uint32_t*          meshletData;        uint32_t meshletDataCount;  /* u32 words */
     const float*             positions;          uint32_t vertexCount;       /* float3 tightly packed */
+    const float*             texcoord0;          uint32_t texcoord0Count;    /* float2 per vertex (textureCoord0Buffer), or NULL / 0:
+                                                                              * masked materials then sample at uv (0, 0) */
 } ChordAssetDesc;
 
 typedef struct ChordSceneDesc {
@@ -173,6 +204,8 @@ typedef struct ChordSceneDesc {
     const ChordPrimitive* primitives; uint32_t primitiveCount;
     const ChordMaterial*  materials;  uint32_t materialCount;
     const ChordAssetDesc* assets;     uint32_t assetCount;
+    const ChordTexture*   textures;   uint32_t textureCount;   /* may be NULL / 0 */
+    const ChordSampler*   samplers;   uint32_t samplerCount;   /* may be NULL / 0: REPEAT, NEAREST */
 } ChordSceneDesc;
 
 /* Visibility texel — base.hlsli:437-447 (low 32 bits) under the depth bits

@@ -29,6 +29,20 @@
  *  (6) Packed pixel = (asuint(depth) << 32) | encodeTriangleIdInstanceId(tri, slot); clear 0.
  *  (7) Cluster slots are assigned in (objectId, groupIdx, meshlet-in-group) order.
  *  (8) Depth test GREATER_OR_EQUAL + draw order  ==>  64-bit max of the packed word.
+ *  (9) Masked materials (alphaMode 1; mesh_raster.hlsl:34-38,107-112,198-204).  The reference's
+ *      baseColorTexture.Sample() takes its level of detail from screen-space derivatives and filters as the
+ *      sampler (8x anisotropic, asset_gltf.cpp:394-481) and the hardware see fit; fixed here:
+ *      - vertex attributes u/w, v/w, 1/w (fp32 divisions by the clip w); at a pixel, with the depth's l1, l2:
+ *        l0 = (1 - l1) - l2, den = (l0*iw0 + l1*iw1) + l2*iw2, u = ((l0*uw0 + l1*uw1) + l2*uw2) / den (v alike);
+ *      - ONE level per (clipped piece of a) triangle: ratio = Auv / Apx, Auv = |(u1-u0)(v2-v0) - (u2-u0)(v1-v0)| *
+ *        (float(W0) * float(H0)) (doubled uv area in level-0 texels), Apx = float(|2A|) * (1/65536) (doubled pixel
+ *        area); ratio >= 1: level = min(mips - 1, floor(log2(ratio)) >> 1) (exponent bits), filter = minFilter;
+ *        otherwise level 0, filter = magFilter.  No anisotropy, no blend between levels;
+ *      - NEAREST: texel (floor(u*W), floor(v*H)); LINEAR: x = u*W - 0.5, x0 = floor(x), f = x - x0, the four texels
+ *        around, a = lerp(lerp(a00,a10,fx), lerp(a01,a11,fx), fy), lerp(a,b,t) = a + (b-a)*t, texel = byte * (1/255);
+ *        wrap per axis REPEAT / CLAMP_TO_EDGE / MIRRORED_REPEAT on the integer texel index;
+ *      - clip(a * baseColorFactor.w - alphaCutOff): the fragment is dropped iff that is < 0.
+ *      Blended materials (alphaMode 2) are in no bucket of renderMesh (mesh_raster.cpp:224) and draw nothing.
  */
 #include "oracle.h"
 
@@ -494,10 +508,106 @@ static inline void vis_max(uint64_t* p, uint64_t v, int atomic)
 
 static inline int64_t floor_shift8(int64_t v) { return v >= 0 ? (v >> 8) : -((-v + 255) >> 8); }
 
+/* ---- masked materials: canonical texture fetch (header item 9) ---- */
+typedef struct {
+    float uw[3], vw[3], iw[3];
+    const ChordTexture* tex;        /* NULL: white fallback (alpha 1) */
+    ChordSampler smp;
+    uint32_t level;
+    int linear;
+    float alphaFactor, alphaCutOff;
+} MaskCtx;
+
+static inline int wrap_index(int64_t i, int64_t n, uint32_t mode)
+{
+    if (mode == CHORD_WRAP_CLAMP_TO_EDGE) return (int)(i < 0 ? 0 : (i > n - 1 ? n - 1 : i));
+    if (mode == CHORD_WRAP_MIRRORED_REPEAT) {
+        int64_t m = i % (2 * n);
+        if (m < 0) m += 2 * n;
+        return (int)(m < n ? m : 2 * n - 1 - m);
+    }
+    int64_t m = i % n;                                   /* REPEAT (and anything unknown) */
+    if (m < 0) m += n;
+    return (int)m;
+}
+
+static inline int64_t texel_floor(float x)
+{
+    if (!(fabsf(x) < 1.0e9f)) return 0;                  /* NaN / out of any texture: texel 0 */
+    return (int64_t)floorf(x);
+}
+
+float orc_sample_alpha(const ChordTexture* tex, const ChordSampler* smp, uint32_t level, int linear, float u, float v)
+{
+    if (!tex || !tex->rgba8) return 1.0f;
+    if (level >= tex->mipCount) level = tex->mipCount - 1u;
+    size_t off = 0;
+    for (uint32_t l = 0; l < level; l++) {
+        uint32_t w = tex->width >> l, h = tex->height >> l;
+        off += (size_t)(w ? w : 1u) * (h ? h : 1u);
+    }
+    const int64_t W = (tex->width >> level) ? (tex->width >> level) : 1, H = (tex->height >> level) ? (tex->height >> level) : 1;
+    const uint8_t* base = tex->rgba8 + off * 4u;
+#define TEXEL_A(ix, iy) ((float)base[((size_t)(iy) * (size_t)W + (size_t)(ix)) * 4u + 3u] * (1.0f / 255.0f))
+    if (!linear) {
+        const int ix = wrap_index(texel_floor(u * (float)W), W, smp->wrapS), iy = wrap_index(texel_floor(v * (float)H), H, smp->wrapT);
+        return TEXEL_A(ix, iy);
+    }
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const int64_t x0 = texel_floor(x), y0 = texel_floor(y);
+    float fx = x - (float)x0, fy = y - (float)y0;
+    if (!(fabsf(x) < 1.0e9f)) fx = 0.0f;
+    if (!(fabsf(y) < 1.0e9f)) fy = 0.0f;
+    const int ix0 = wrap_index(x0, W, smp->wrapS), ix1 = wrap_index(x0 + 1, W, smp->wrapS);
+    const int iy0 = wrap_index(y0, H, smp->wrapT), iy1 = wrap_index(y0 + 1, H, smp->wrapT);
+    const float a00 = TEXEL_A(ix0, iy0), a10 = TEXEL_A(ix1, iy0), a01 = TEXEL_A(ix0, iy1), a11 = TEXEL_A(ix1, iy1);
+#undef TEXEL_A
+    const float top = a00 + (a10 - a00) * fx, bot = a01 + (a11 - a01) * fx;
+    return top + (bot - top) * fy;
+}
+
+static inline int filter_is_linear(uint32_t f)
+{
+    return f == CHORD_FILTER_LINEAR || f == CHORD_FILTER_LINEAR_MIPMAP_NEAREST || f == CHORD_FILTER_LINEAR_MIPMAP_LINEAR;
+}
+
+/* per (piece of a) triangle: attributes over w, the level and the filter */
+static void mask_setup(MaskCtx* mk, const ChordSceneDesc* scene, const ChordMaterial* mat, int64_t absArea2,
+                       const float u[3], const float v[3], const float w[3])
+{
+    for (int i = 0; i < 3; i++) { mk->iw[i] = 1.0f / w[i]; mk->uw[i] = u[i] * mk->iw[i]; mk->vw[i] = v[i] * mk->iw[i]; }
+    mk->tex = (scene->textures && mat->baseColorId < scene->textureCount) ? &scene->textures[mat->baseColorId] : NULL;
+    if (scene->samplers && mat->baseColorSampler < scene->samplerCount) mk->smp = scene->samplers[mat->baseColorSampler];
+    else { mk->smp.minFilter = mk->smp.magFilter = CHORD_FILTER_NEAREST; mk->smp.wrapS = mk->smp.wrapT = CHORD_WRAP_REPEAT; }
+    mk->alphaFactor = mat->baseColorFactor[3]; mk->alphaCutOff = mat->alphaCutOff;
+    mk->level = 0; mk->linear = filter_is_linear(mk->smp.magFilter);
+    if (mk->tex) {
+        const float texels = (float)mk->tex->width * (float)mk->tex->height;
+        const float auv = fabsf((u[1] - u[0]) * (v[2] - v[0]) - (u[2] - u[0]) * (v[1] - v[0])) * texels;
+        const float apx = (float)(double)absArea2 * (1.0f / 65536.0f);
+        const float ratio = auv / apx;
+        if (ratio >= 1.0f) {
+            const int32_t e = (int32_t)((f2u(ratio) >> 23) & 0xFFu) - 127;      /* floor(log2(ratio)), 128 for inf */
+            uint32_t level = (uint32_t)(e >> 1);
+            if (level > mk->tex->mipCount - 1u) level = mk->tex->mipCount - 1u;
+            mk->level = level; mk->linear = filter_is_linear(mk->smp.minFilter);
+        }
+    }
+}
+
+uint32_t orc_mask_level(const ChordSceneDesc* scene, const ChordMaterial* mat, int64_t absArea2, const float u[3], const float v[3], int* linear)
+{
+    MaskCtx mk; const float w[3] = {1.0f, 1.0f, 1.0f};
+    mask_setup(&mk, scene, mat, absArea2, u, v, w);
+    if (linear) *linear = mk.linear;
+    return mk.level;
+}
+
 typedef struct { int atomic; } RasterCtx;
 
 static void raster_snapped(const int32_t X[3], const int32_t Y[3], const float d[3], int twoSided, uint32_t payload,
-                           uint32_t W, uint32_t H, const OrcShard* shard, uint64_t* vis, OrcRasterStats* st, int atomic)
+                           uint32_t W, uint32_t H, const OrcShard* shard, uint64_t* vis, OrcRasterStats* st, int atomic,
+                           MaskCtx* mk, const ChordSceneDesc* scene, const ChordMaterial* mat, const float tu[3], const float tv[3], const float tw[3])
 {
     /* signed doubled area in y-down screen space; reference front faces
      * (det > 0 in clip (x,y,w), mesh_raster.hlsl:143-149; CCW front + Y-flipped
@@ -533,6 +643,7 @@ static void raster_snapped(const int32_t X[3], const int32_t Y[3], const float d
     }
     const float invA = 1.0f / (float)(double)A;
     const float e1 = d[1] - d[0], e2 = d[2] - d[0];
+    if (mk) mask_setup(mk, scene, mat, A, tu, tv, tw);
 
     for (int64_t py = py0; py <= py1; py++) {
         if (!owns_row(shard, (uint32_t)py)) continue;
@@ -546,6 +657,14 @@ static void raster_snapped(const int32_t X[3], const int32_t Y[3], const float d
             }
             if (!inside) continue;
             float l1 = (float)(double)E[1] * invA, l2 = (float)(double)E[2] * invA;
+            if (mk) {                                    /* mesh_raster.hlsl:198-204 */
+                const float l0 = (1.0f - l1) - l2;
+                const float den = (l0 * mk->iw[0] + l1 * mk->iw[1]) + l2 * mk->iw[2];
+                const float tu_ = ((l0 * mk->uw[0] + l1 * mk->uw[1]) + l2 * mk->uw[2]) / den;
+                const float tv_ = ((l0 * mk->vw[0] + l1 * mk->vw[1]) + l2 * mk->vw[2]) / den;
+                const float a = orc_sample_alpha(mk->tex, &mk->smp, mk->level, mk->linear, tu_, tv_);
+                if (a * mk->alphaFactor - mk->alphaCutOff < 0.0f) { if (st) st->fragmentsClipped++; continue; }
+            }
             float z = (d[0] + l1 * e1) + l2 * e2;
             uint64_t packed = ((uint64_t)f2u(z) << 32) | payload;
             vis_max(&vis[(size_t)py * W + (size_t)px], packed, atomic);
@@ -558,7 +677,7 @@ void orc_raster_snapped_triangle(const int32_t X[3], const int32_t Y[3], const f
                                  int twoSided, uint32_t payload, uint32_t W, uint32_t H,
                                  const OrcShard* shard, uint64_t* vis, OrcRasterStats* stats)
 {
-    raster_snapped(X, Y, d, twoSided, payload, W, H, shard, vis, stats, 0);
+    raster_snapped(X, Y, d, twoSided, payload, W, H, shard, vis, stats, 0, NULL, NULL, NULL, NULL, NULL, NULL);
 }
 
 #define ORC_GUARD 1024.0f
@@ -615,6 +734,8 @@ static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCulli
     const ChordMeshlet* m = &as->meshlets[cmd->meshletId];
     const uint32_t V = m->vertexTriangleCount & 0xFFu, T = (m->vertexTriangleCount >> 8) & 0xFFu;
     const int twoSided = mat->bTwoSided != 0;       /* mesh_raster.cpp:224-235: DIM_TWO_SIDED bucket */
+    const int masked = mat->alphaMode == CHORD_ALPHA_MASK;   /* DIM_MASKED_MATERIAL bucket */
+    MaskCtx mkStore; MaskCtx* mk = masked ? &mkStore : NULL;
     const float W = iv->renderDimension[0], H = iv->renderDimension[1];
     const uint32_t Wi = (uint32_t)W, Hi = (uint32_t)H;
 
@@ -622,12 +743,16 @@ static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCulli
     mul_mm(&iv->translatedWorldToClip, &obj->basicData.localToTranslatedWorld, &mvp);
 
     f4 hs[CHORD_MESHLET_MAX_VERTICES + 1];
+    float tus[CHORD_MESHLET_MAX_VERTICES + 1], tvs[CHORD_MESHLET_MAX_VERTICES + 1];
     for (uint32_t i = 0; i < V; i++) {
         uint32_t vi = prim->vertexOffset + as->meshletData[m->dataOffset + i];
         const float* p = &as->positions[(size_t)vi * 3];
         hs[i] = mul_mv(&mvp, p[0], p[1], p[2], 1.0f);
+        tus[i] = tvs[i] = 0.0f;
+        if (masked && as->texcoord0 && vi < as->texcoord0Count) { tus[i] = as->texcoord0[(size_t)vi * 2]; tvs[i] = as->texcoord0[(size_t)vi * 2 + 1]; }   /* mesh_raster.hlsl:109 */
     }
     if (st) { st->clusters++; st->trianglesSubmitted += T; }
+    if (mat->alphaMode >= CHORD_ALPHA_BLEND) return;     /* neither bucket of renderMesh draws it (mesh_raster.cpp:224) */
 
     for (uint32_t t = 0; t < T; t++) {
         uint32_t packedIdx = as->meshletData[m->dataOffset + V + t];
@@ -663,22 +788,34 @@ static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCulli
                 Y[i] = (int32_t)rintf((v[i] * H) * 256.0f);
                 d[i] = h[i].z / h[i].w;
             }
-            raster_snapped(X, Y, d, twoSided, payload, Wi, Hi, shard, vis, st, atomic);
+            const float tu3[3] = {tus[idx[0]], tus[idx[1]], tus[idx[2]]}, tv3[3] = {tvs[idx[0]], tvs[idx[1]], tvs[idx[2]]};
+            const float tw3[3] = {h[0].w, h[1].w, h[2].w};
+            raster_snapped(X, Y, d, twoSided, payload, Wi, Hi, shard, vis, st, atomic, mk, scene, mat, tu3, tv3, tw3);
         } else {
             if (st) st->trianglesClipped++;
             f4 poly[2][12];
+            float pu[2][12], pv[2][12];                  /* texture coordinates ride along (same t, from the inside end) */
             int n = 3, cur = 0;
             poly[0][0] = h[0]; poly[0][1] = h[1]; poly[0][2] = h[2];
+            for (int i = 0; i < 3; i++) { pu[0][i] = tus[idx[i]]; pv[0][i] = tvs[idx[i]]; }
             for (int k = 0; k < 6 && n >= 3; k++) {
                 int m2 = 0;
                 f4* in = poly[cur]; f4* out = poly[cur ^ 1];
                 for (int i = 0; i < n; i++) {
-                    const f4* P = &in[i]; const f4* Q = &in[(i + 1) % n];
+                    const int j = (i + 1) % n;
+                    const f4* P = &in[i]; const f4* Q = &in[j];
                     float dp = clip_dist(P, k), dq = clip_dist(Q, k);
                     int pin = dp >= 0.0f, qin = dq >= 0.0f;
-                    if (pin) out[m2++] = *P;
-                    if (pin && !qin) out[m2++] = clip_intersect(P, Q, dp, dq);
-                    else if (!pin && qin) out[m2++] = clip_intersect(Q, P, dq, dp);
+                    if (pin) { pu[cur ^ 1][m2] = pu[cur][i]; pv[cur ^ 1][m2] = pv[cur][i]; out[m2++] = *P; }
+                    if (pin && !qin) {
+                        const float t = dp / (dp - dq);
+                        pu[cur ^ 1][m2] = pu[cur][i] + (pu[cur][j] - pu[cur][i]) * t; pv[cur ^ 1][m2] = pv[cur][i] + (pv[cur][j] - pv[cur][i]) * t;
+                        out[m2++] = clip_intersect(P, Q, dp, dq);
+                    } else if (!pin && qin) {
+                        const float t = dq / (dq - dp);
+                        pu[cur ^ 1][m2] = pu[cur][j] + (pu[cur][i] - pu[cur][j]) * t; pv[cur ^ 1][m2] = pv[cur][j] + (pv[cur][i] - pv[cur][j]) * t;
+                        out[m2++] = clip_intersect(Q, P, dq, dp);
+                    }
                 }
                 n = m2; cur ^= 1;
             }
@@ -693,7 +830,9 @@ static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCulli
             for (int i = 1; i + 1 < n; i++) {
                 int32_t X[3] = {PX[0], PX[i], PX[i + 1]}, Y[3] = {PY[0], PY[i], PY[i + 1]};
                 float d[3] = {PD[0], PD[i], PD[i + 1]};
-                raster_snapped(X, Y, d, twoSided, payload, Wi, Hi, shard, vis, st, atomic);
+                const float tu3[3] = {pu[cur][0], pu[cur][i], pu[cur][i + 1]}, tv3[3] = {pv[cur][0], pv[cur][i], pv[cur][i + 1]};
+                const float tw3[3] = {poly[cur][0].w, poly[cur][i].w, poly[cur][i + 1].w};
+                raster_snapped(X, Y, d, twoSided, payload, Wi, Hi, shard, vis, st, atomic, mk, scene, mat, tu3, tv3, tw3);
             }
         }
     }

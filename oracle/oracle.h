@@ -34,6 +34,7 @@ typedef struct OrcRasterStats {
     uint64_t trianglesClipped;   /* survivors that needed the homogeneous clipper           */
     uint64_t trianglesRastered;  /* survivors scan-converted (after snapped-area rejection) */
     uint64_t fragments;          /* covered pixel centres (before the depth test)           */
+    uint64_t fragmentsClipped;   /* covered pixel centres a masked material's clip() dropped (not in `fragments`) */
 } OrcRasterStats;
 
 /* Screen ownership for the multi-GPU shard: rows are cut into stripes of
@@ -92,6 +93,11 @@ void orc_raster(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv,
 
 /* Scan-convert one screen-space triangle given snapped 24.8 coordinates
  * (exposed for the raster-rule known-answer tests). */
+/* canonical masked-material texture fetch (oracle.c header item 9): alpha of texture `tex` (NULL: 1) at (u, v) */
+float orc_sample_alpha(const ChordTexture* tex, const ChordSampler* smp, uint32_t level, int linear, float u, float v);
+/* level / filter a triangle with doubled snapped area absArea2 and texture coordinates u[], v[] samples `mat`'s texture at */
+uint32_t orc_mask_level(const ChordSceneDesc* scene, const ChordMaterial* mat, int64_t absArea2, const float u[3], const float v[3], int* linear);
+
 void orc_raster_snapped_triangle(const int32_t X[3], const int32_t Y[3], const float d[3],
                                  int twoSided, uint32_t payload, uint32_t W, uint32_t H,
                                  const OrcShard* shard, uint64_t* vis, OrcRasterStats* stats);

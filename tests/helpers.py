@@ -43,10 +43,8 @@ def with_shading_types(scene, types=(1, 37, 100, 64, 127)):
     mats["materialType"] = np.asarray(types, dtype=np.uint32)[np.arange(len(mats)) % len(types)]
     objs = scene.objects.copy()
     objs["GLTFMaterialData"] = np.arange(len(objs), dtype=np.uint32)
-    out = R.Scene(objs, scene.primitives, mats, scene.meshlets, scene.groups, scene.group_indices,
-                  scene.meshlet_data, scene.positions, name=scene.name + "+types")
-    if hasattr(scene, "local_to_world"):
-        out.local_to_world = scene.local_to_world
+    out = scene.with_objects(objs, mats)
+    out.name = scene.name + "+types"
     return out
 
 

@@ -15,7 +15,7 @@ ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 class RasterStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "clusters", "trianglesSubmitted", "trianglesBackface", "trianglesNear", "trianglesOffscreen",
-        "trianglesSmall", "trianglesClipped", "trianglesRastered", "fragments")]
+        "trianglesSmall", "trianglesClipped", "trianglesRastered", "fragments", "fragmentsClipped")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -50,6 +50,10 @@ def _load():
     lib.orc_raster.argtypes = [P(R.SceneDesc), vp, vp, u32, P(Shard), vp, P(RasterStats)]
     lib.orc_raster_snapped_triangle.restype = None
     lib.orc_raster_snapped_triangle.argtypes = [vp, vp, vp, i32, u32, u32, u32, P(Shard), vp, P(RasterStats)]
+    lib.orc_sample_alpha.restype = C.c_float
+    lib.orc_sample_alpha.argtypes = [P(R.Texture), vp, u32, i32, C.c_float, C.c_float]
+    lib.orc_mask_level.restype = u32
+    lib.orc_mask_level.argtypes = [P(R.SceneDesc), vp, C.c_int64, vp, vp, P(i32)]
     lib.orc_frame.restype = None
     lib.orc_frame.argtypes = [P(R.SceneDesc), vp, vp, u32, vp, P(Shard), vp, vp, u32, vp, vp, vp, vp, P(RasterStats)]
     lib.orc_visibility_mark.restype, lib.orc_visibility_mark.argtypes = None, [P(R.SceneDesc), vp, u32, u32, vp, u32, vp]

@@ -29,6 +29,12 @@ SCENES = [
     ("small_64", lambda: scenes.small_test_scene(64, 64, seed=4), H.ALL_FLAGS),
     ("small_4096", lambda: scenes.small_test_scene(4096, 4096, seed=6), H.ALL_FLAGS),
     ("small_odd", lambda: scenes.small_test_scene(1237, 701, seed=8), H.ALL_FLAGS),
+    # alpha-tested, blended and white-fallback materials (mesh_raster.hlsl:34-38,107-112,198-204; mesh_raster.cpp:224)
+    ("masked", lambda: scenes.masked_test_scene(320, 200), H.ALL_FLAGS),
+    ("masked_hd", lambda: scenes.masked_test_scene(1280, 720, lods=3, seed=9), H.ALL_FLAGS),
+    # triangles of a masked floor straddling the camera plane: the clipper carries their texture coordinates
+    ("masked_clipped", scenes.masked_floor_under_camera, H.ALL_FLAGS),
+    ("masked_clipped_2", lambda: scenes.masked_floor_under_camera((1.1, 0.4, -0.7), (-0.7, -0.35, -0.6), 333, 211), R.FLAG_FRUSTUM_CULL),
 ]
 
 
@@ -309,6 +315,7 @@ SHARDED = [
     ("subpixel_540p_8ranks", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4), 8, None),
     # full size: long bins, pool chunks and split tiles in both raster passes of a sharded frame
     ("street_x64_4k_2ranks", scenes.config4_street_x64, 2, None),
+    ("masked_3ranks", lambda: scenes.masked_test_scene(320, 200), 3, 14),
 ]
 
 
@@ -434,8 +441,7 @@ def test_moving_camera_sequence_matches_oracle(gpu, name, builder):
     objs = {"a": L.fill_objects(scene, cam_a, cam_b).copy(), "b": L.fill_objects(scene, cam_b, cam_a).copy()}
 
     def scene_with(o):
-        return R.Scene(o, scene.primitives, scene.materials, scene.meshlets, scene.groups, scene.group_indices,
-                       scene.meshlet_data, scene.positions, name=scene.name)
+        return scene.with_objects(o)
     from chord_amd.renderer import VisibilityRenderer
     r = VisibilityRenderer(0)
     r.upload_scene(scene)
