@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=("auto", "lib", "torch"),
                     help="N > 1: who issues the all-gathers -- the library (RCCL communicator on the context) or torch.distributed")
     ap.add_argument("--cpu-baseline-frames", type=int, default=48, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
+    ap.add_argument("--cull", default="flat", choices=("flat", "hierarchical"),
+                    help="instanceCulling: the reference's flat group dispatch, or the BVH walk (same command list)")
     ap.add_argument("--no-hzb", action="store_true", help="disable HZB occlusion culling (frustum+cone only)")
     ap.add_argument("--debug-flags", type=int, default=0, help="raster ablation switches (measurement only; voids parity)")
     args = ap.parse_args()
@@ -131,6 +133,8 @@ def main():
     if wl == "subpixel_1g":              # ~1 G records of 48 B and as many bin entries in one pass (a rank holds 1/N of them)
         share = max(1, world // 2) if world > 1 else 1
         r.set_limits(max_triangle_records=(1152 << 20) // share, bin_pool_chunks=(1200 << 10) // share, bin_max_chunks_per_tile=2048)
+    if args.cull == "hierarchical":
+        r.set_cull_mode(1)
     r.upload_scene(scene)
     if world > 1:
         from chord_amd.sharding import pick_stripe_rows
@@ -367,7 +371,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32+u64", "data": "synthetic",
             "config": {"workload": wl, **({"ABLATION_debug_flags": args.debug_flags} if args.debug_flags else {}), "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(),
-                       "objects": len(scene.objects), "hzb": not args.no_hzb,
+                       "objects": len(scene.objects), "hzb": not args.no_hzb, "cull": args.cull,
                        "parallelism": "stripes%d" % world if world > 1 else "single"},
             "triangles_submitted_per_step": tris_per_pair / 2.0,
             # end to end over ALL scene triangles (LOD 0), i.e. including what culling removed

@@ -13,6 +13,7 @@
 #include "device_layer.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
@@ -268,7 +269,7 @@ int chordvis_destroy(ChordCtx* c)
     (void)hipStreamSynchronize(c->stream);
     (void)chordvis_comm_destroy(c);
     dfree(c->dPrims); dfree(c->dGroups); dfree(c->dMeshlets); dfree(c->dGroupIndices); dfree(c->dMeshletData);
-    dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dMaterials); dfree(c->dTexAlpha); dfree(c->dTexcoords); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
+    dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dMaterials); dfree(c->dTexAlpha); dfree(c->dTexcoords); dfree(c->dBvhNodes); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
     dfree(c->dRankCmds);
@@ -311,6 +312,10 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         iB[a + 1] = iB[a] + as.meshletGroupIndexCount; dB[a + 1] = dB[a] + as.meshletDataCount; vB[a + 1] = vB[a] + as.vertexCount;
     }
     const uint32_t nM = mB.back(), nG = gB.back(), nI = iB.back(), nD = dB.back(), nV = vB.back();
+    std::vector<uint32_t> nB(s->assetCount + 1, 0);
+    for (uint32_t a = 0; a < s->assetCount; a++) nB[a + 1] = nB[a] + (s->assets[a].bvhNodes ? s->assets[a].bvhNodeCount : 0u);
+    std::vector<DBVHNode> bvh(nB.back());
+    bool bvhComplete = nB.back() > 0;
 
     std::vector<DMeshlet> meshlets(nM);
     std::vector<DGroup> groups(nG);
@@ -362,6 +367,45 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         d.groupIndicesBase = iB[a] + p.meshletGroupIndicesOffset;
         d.groupCount = p.meshletGroupCount;
         d.assetMeshletBase = mB[a];
+        d.bvhBase = 0xFFFFFFFFu;
+        if (as.bvhNodes && as.bvhNodeCount && p.bvhNodeOffset < as.bvhNodeCount) {
+            // GPUBVHNode tree of the primitive (gltf.h:16-24): copied, and checked for what the hierarchical cull relies on --
+            // indices in range, every group of the primitive in exactly one node's leaf range, every non-root node's
+            // sphere around the parent-error spheres of the groups beneath it
+            const ChordBVHNode* nodes = as.bvhNodes + p.bvhNodeOffset;
+            const uint32_t count = nodes[0].bvhNodeCount;
+            if (count == 0 || (uint64_t)p.bvhNodeOffset + count > as.bvhNodeCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: BVH root's node count exceeds the node buffer");
+            std::vector<uint8_t> seen(p.meshletGroupCount, 0);
+            std::vector<float> need(count, 0.0f);           // smallest radius each node's sphere must have
+            for (uint32_t n = count; n-- > 0;) {            // children come after their parent (breadth-first order)
+                const ChordBVHNode& nd = nodes[n];
+                if ((uint64_t)nd.leafMeshletGroupOffset + nd.leafMeshletGroupCount > p.meshletGroupCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: BVH leaf range outside the primitive's groups");
+                for (uint32_t g = 0; g < nd.leafMeshletGroupCount; g++) {
+                    const uint32_t gi = nd.leafMeshletGroupOffset + g;
+                    if (seen[gi]++) return fail(c, CHORDVIS_E_INVALID, "upload_scene: a cluster group is listed by two BVH nodes");
+                    const ChordMeshletGroup& gr = as.meshletGroups[p.meshletGroupOffset + gi];
+                    if (n != 0) {
+                        if (!(gr.parentError < CHORD_ERROR_RADIUS_ROOT)) return fail(c, CHORDVIS_E_INVALID, "upload_scene: an un-parented group below the BVH root");
+                        const float dx = gr.parentPosCenter[0] - nd.sphere[0], dy = gr.parentPosCenter[1] - nd.sphere[1], dz = gr.parentPosCenter[2] - nd.sphere[2];
+                        need[n] = std::max(need[n], std::sqrt(dx * dx + dy * dy + dz * dz) + gr.parentError);
+                    }
+                }
+                for (uint32_t k = 0; k < CHORD_BVH_WIDTH; k++) {
+                    const uint32_t ch = nd.children[k];
+                    if (ch == CHORD_BVH_NO_CHILD) continue;
+                    if (ch <= n || ch >= count) return fail(c, CHORDVIS_E_INVALID, "upload_scene: BVH child index out of order / range");
+                    const ChordBVHNode& cn = nodes[ch];
+                    const float dx = cn.sphere[0] - nd.sphere[0], dy = cn.sphere[1] - nd.sphere[1], dz = cn.sphere[2] - nd.sphere[2];
+                    need[n] = std::max(need[n], std::sqrt(dx * dx + dy * dy + dz * dz) + need[ch]);
+                }
+                if (!(need[n] <= nd.sphere[3] * 1.0001f + 1.0e-6f)) return fail(c, CHORDVIS_E_INVALID, "upload_scene: a BVH node's sphere does not contain the parent-error spheres beneath it");
+                DBVHNode& dn = bvh[nB[a] + p.bvhNodeOffset + n];
+                std::memcpy(dn.sphere, nd.sphere, 16); std::memcpy(dn.children, nd.children, 32);
+                dn.bvhNodeCount = nd.bvhNodeCount; dn.leafGroupOffset = nd.leafMeshletGroupOffset; dn.leafGroupCount = nd.leafMeshletGroupCount; dn.pad = 0;
+            }
+            for (uint32_t gi = 0; gi < p.meshletGroupCount; gi++) if (!seen[gi]) return fail(c, CHORDVIS_E_INVALID, "upload_scene: a cluster group is missing from the primitive's BVH");
+            d.bvhBase = nB[a] + p.bvhNodeOffset;
+        } else bvhComplete = false;
         for (uint32_t gi = 0; gi < p.meshletGroupCount; gi++) {
             const ChordMeshletGroup& g = as.meshletGroups[p.meshletGroupOffset + gi];
             for (uint32_t i = 0; i < g.meshletCount; i++) {
@@ -476,6 +520,8 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     UP(c->dMeshlets, meshlets) UP(c->dGroups, groups) UP(c->dGroupIndices, gidx) UP(c->dMeshletData, mdata)
     UP(c->dPositions, pos) UP(c->dPrims, c->hPrims) UP(c->dObjStatic, c->hObjStatic) UP(c->dGroupOwner, owner)
     UP(c->dMaterials, dmats)
+    if (!bvh.empty()) { UP(c->dBvhNodes, bvh) } else dfree(c->dBvhNodes);
+    c->bvhComplete = bvhComplete;
     if (!alpha.empty()) { UP(c->dTexAlpha, alpha) } else dfree(c->dTexAlpha);
     if (!uvs.empty()) { UP(c->dTexcoords, uvs) } else dfree(c->dTexcoords);
 #undef UP
@@ -483,7 +529,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     CHORD_HIP(c, hipMemcpy(c->dObjectsOwned, s->objects, sizeof(ChordObject) * s->objectCount, hipMemcpyHostToDevice));
     c->dObjects = c->dObjectsOwned;
     if ((rc = dalloc(c, &c->dObjFrame, (size_t)s->objectCount))) return rc;
-    if ((rc = dalloc(c, &c->dGroupMask, (size_t)c->groupInstances))) return rc;
+    if ((rc = dalloc(c, &c->dGroupMask, (size_t)c->groupInstances + 16))) return rc;   // (+16: zeroed in 16-byte vectors)
     if ((rc = dalloc(c, &c->dBlockCounts, (size_t)c->cullBlocks * 2))) return rc;   // counts, then triangles, per count block
     for (int i = 0; i < 3; i++) {
         if ((rc = dalloc(c, &c->lists[i].cmds, (size_t)c->cmdCapacity))) return rc;
@@ -509,6 +555,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     c->sceneLoaded = true;
     c->historySlot = 0;
     c->pendingTailSlot = 0;
+    if (c->cullMode == 1 && !c->bvhComplete) return fail(c, CHORDVIS_E_INVALID, "upload_scene: hierarchical culling is selected and a primitive has no BVH");
     return CHORDVIS_OK;
 }
 
@@ -568,6 +615,14 @@ int chordvis_set_limits(ChordCtx* c, const ChordLimits* limits)
         if (limits->binMaxChunksPerTile > CHORD_BIN_MAX_CHUNKS_LIMIT) return fail(c, CHORDVIS_E_INVALID, "set_limits: at most 3072 overflow chunks per tile");
         c->binMaxChunks = limits->binMaxChunksPerTile;
     }
+    return CHORDVIS_OK;
+}
+
+int chordvis_set_cull_mode(ChordCtx* c, int hierarchical)
+{
+    if (!c || hierarchical < 0 || hierarchical > 1) return fail(c, CHORDVIS_E_INVALID, "set_cull_mode: 0 (flat) or 1 (hierarchical)");
+    if (hierarchical && c->sceneLoaded && !c->bvhComplete) return fail(c, CHORDVIS_E_INVALID, "set_cull_mode: the uploaded scene has primitives without a BVH");
+    c->cullMode = hierarchical;
     return CHORDVIS_OK;
 }
 

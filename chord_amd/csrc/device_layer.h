@@ -24,7 +24,13 @@ struct DPrim {                 // per GLTFPrimitiveBuffer, 48 B
     uint32_t groupIndicesBase;                      // asset index base + primitive.meshletGroupIndicesOffset
     uint32_t groupCount;
     uint32_t assetMeshletBase;                      // to convert device meshlet ids back to asset-relative ones
-    uint32_t pad;
+    uint32_t bvhBase;                               // first node of the primitive's tree in dBvhNodes, 0xFFFFFFFF: none
+};
+
+struct DBVHNode {              // GPUBVHNode (60 B) padded to one 64-byte line
+    float    sphere[4];
+    uint32_t children[8];
+    uint32_t bvhNodeCount, leafGroupOffset, leafGroupCount, pad;
 };
 
 struct DGroup {                // GPUGLTFMeshletGroup padded to 48 B for 16-B loads
@@ -212,6 +218,9 @@ struct ChordCtx {
     float* dTexcoords = nullptr;              // float2 per vertex (textureCoord0Buffer), or null
     bool anyMasked = false;
     uint32_t* dGroupOwner = nullptr;  // object id per flattened (object, group)
+    chord::DBVHNode* dBvhNodes = nullptr;   // every primitive's tree (or null: the scene came without)
+    bool bvhComplete = false;         // every primitive has a validated tree
+    int cullMode = 0;                 // 0 flat (the reference's dispatch), 1 hierarchical (chordvis_set_cull_mode)
     ChordObject* dObjectsOwned = nullptr;
     const ChordObject* dObjects = nullptr;
     std::vector<chord::DPrim> hPrims;

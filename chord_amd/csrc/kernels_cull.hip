@@ -19,6 +19,7 @@
 
 #include "hzb_device.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace chord {
@@ -190,10 +191,12 @@ struct GroupCullParams {
 __global__ __launch_bounds__(256) void object_cull_kernel(const ChordObject* __restrict__ objects, const DObjStatic* __restrict__ objStatic,
                                                           const DPrim* __restrict__ prims, const DView dv, DView* __restrict__ dviewOut,
                                                           DObjFrame* __restrict__ objFrame, uint32_t objectCount,
-                                                          uint4* __restrict__ zeroBase, uint32_t zeroVec4, FrameTail tail)
+                                                          uint4* __restrict__ zeroBase, uint32_t zeroVec4, FrameTail tail,
+                                                          uint4* __restrict__ zeroBase2, uint32_t zeroVec4b)
 {
     if (tail.run && blockIdx.x == gridDim.x - 1u) { hzb_tail_block(tail.p, 1, 1, (uint32_t)CHORD_TILE_SHIFT); return; }
     const uint32_t o = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t i = o; i < zeroVec4b; i += (gridDim.x - tail.run) * 256u) zeroBase2[i] = make_uint4(0u, 0u, 0u, 0u);   // group masks (hierarchical mode)
     if (dviewOut && blockIdx.x == 0) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
         uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
@@ -206,6 +209,8 @@ __global__ __launch_bounds__(256) void object_cull_kernel(const ChordObject* __r
 // Short scenes: first the objects this block's group instances belong to (instanceCullingCS, one thread per object; an object whose
 // groups span several blocks is done by each of them -- same values), the frame's housekeeping that used to ride on the
 // object kernel (view block published for the later kernels, FrameState zeroed), then the groups.
+// FROM_MASK: the per-group meshlet masks were written by bvh_cull_kernel (hierarchical mode); this kernel only counts them.
+template <bool FROM_MASK>
 __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p, const DView dv, DView* __restrict__ dviewOut,
                                                                DObjFrame* __restrict__ objFrameOut, uint4* __restrict__ zeroBase, uint32_t zeroVec4,
                                                                uint32_t cullBlocks, FrameTail tail)
@@ -228,6 +233,18 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
     }
     __syncthreads();                                       // the object records of this block are written (and visible to it)
     uint32_t mask = 0, tris = 0;
+    if (FROM_MASK) {
+        if (t < p.groupInstances) mask = p.groupMask[t];
+        if (mask) {
+            const uint32_t o = p.groupOwner[t];
+            const DObjStatic st = p.objStatic[o];
+            const DPrim& prim = p.prims[st.prim];
+            const DGroup& g = p.groups[prim.groupBase + (t - st.groupBase)];
+            const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
+            for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++)
+                if (mask & (1u << i)) tris += (p.meshlets[prim.meshletBase + p.groupIndices[idxBase + i]].vertexTriangleCount >> 8) & 0xFFu;
+        }
+    } else
     if (t < p.groupInstances) {
         const uint32_t o = p.groupOwner[t];
         const DObjFrame& of = p.objFrame[o];
@@ -253,6 +270,93 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
     (void)block_excl_scan(__popc(mask), &total);
     (void)block_excl_scan(tris, &blockTris);
     if (threadIdx.x == 0) { p.blockCounts[blockIdx.x] = total; p.blockCounts[cullBlocks + blockIdx.x] = blockTris; }
+}
+
+// ---- hierarchical cull (chordvis_set_cull_mode 1) ---------------------------------------------------------------------
+// Resident waves walk the GPUBVHNode trees (gltf.h:16-24) the reference builds and never reads: one wave per visible
+// object at a time (grid stride over the objects), a small stack in LDS, the up to eight children of a node and the
+// groups of its leaf range handled by the wave's lanes.  A node's sphere bounds the parent-error spheres of every group
+// in its subtree (checked at upload), and the projected error of a sphere is monotone in containment, so when the
+// NODE's sphere already projects to at most (1 - 1/64) px with the eye outside it, every group beneath fails the "parent
+// is too coarse" half of isMeshletGroupVisibile (nanite_shared.hlsli:15-49) -- the 1/64 px margin is far above what the
+// fp32 evaluation of either side can differ by -- and the subtree is dropped.  Surviving groups run exactly the flat
+// test and record their meshlet mask; group_cull_count_kernel<true> / the scatter then build the same command array
+// the flat dispatch builds.  (The root's own leaves are the un-parented groups: always tested.)
+struct BvhCullParams {
+    GroupCullParams g;
+    const DBVHNode* nodes;
+    uint32_t objectCount;
+};
+#define BVH_STACK 128
+#define BVH_NODE_MARGIN (1.0f - 1.0f / 64.0f)
+
+__global__ __launch_bounds__(256) void bvh_cull_kernel(BvhCullParams bp, const DView dv)
+{
+    __shared__ uint32_t sStack[4][BVH_STACK];
+    const GroupCullParams& p = bp.g;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* stack = sStack[wave];
+    const uint32_t waves = gridDim.x * 4u;
+    for (uint32_t o = blockIdx.x * 4u + wave; o < bp.objectCount; o += waves) {
+        const DObjFrame& of = p.objFrame[o];
+        if (!__builtin_amdgcn_readfirstlane(of.visible)) continue;
+        const DObjStatic st = p.objStatic[o];
+        const DPrim& prim = p.prims[st.prim];
+        const uint32_t nodeBase = __builtin_amdgcn_readfirstlane(prim.bvhBase);
+        const Mat4 M = load_mat(p.objects[o].basicData.localToTranslatedWorld);
+        const bool twoSided = (st.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0;
+        uint32_t sp = 1;
+        if (lane == 0) stack[0] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        while (sp > 0) {
+            const uint32_t n = __builtin_amdgcn_readfirstlane(stack[sp - 1u]);
+            sp--;
+            const DBVHNode& nd = bp.nodes[nodeBase + n];
+            bool dropped = false;
+            if (n != 0u) {
+                const float pe = projected_error_px(dv.view.lodScale, of.localToView, of.maxScale, nd.sphere, nd.sphere[3]);
+                dropped = pe > 0.0f && pe <= BVH_NODE_MARGIN;
+            } else if (nd.sphere[3] > 0.0f) {
+                // the root's sphere bounds every parented group of the primitive: when it is small on screen only the
+                // root's own leaves (un-parented groups, and parented ones of a primitive too small to split) remain
+                const float pe = projected_error_px(dv.view.lodScale, of.localToView, of.maxScale, nd.sphere, nd.sphere[3]);
+                if (pe > 0.0f && pe <= BVH_NODE_MARGIN) {
+                    // children dropped; the leaves are still walked below (their own tests decide)
+                    dropped = true;
+                }
+            }
+            const uint32_t leafOff = __builtin_amdgcn_readfirstlane(nd.leafGroupOffset), leafCnt = __builtin_amdgcn_readfirstlane(nd.leafGroupCount);
+            if (!dropped || n == 0u) {
+                for (uint32_t gb = 0; gb < leafCnt; gb += 64u) {
+                    const uint32_t gi = gb + lane;
+                    if (gi < leafCnt) {
+                        const uint32_t gl = leafOff + gi;                      // group index inside the primitive
+                        const DGroup g = p.groups[prim.groupBase + gl];
+                        uint32_t mask = 0;
+                        if (group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {
+                            const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
+                            for (uint32_t i = 0; i < g.meshletCount && i < CHORD_GROUP_MAX_MESHLETS; i++) {
+                                const uint32_t mi = prim.meshletBase + p.groupIndices[idxBase + i];
+                                if (meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, twoSided, p.meshlets[mi])) mask |= 1u << i;
+                            }
+                        }
+                        if (mask) p.groupMask[st.groupBase + gl] = (uint8_t)mask;   // (the array was zeroed by the frame's first kernel)
+                    }
+                }
+            }
+            if (!dropped) {
+                const uint32_t child = lane < CHORD_BVH_WIDTH ? nd.children[lane] : CHORD_BVH_NO_CHILD;
+                const unsigned long long has = __ballot(child != CHORD_BVH_NO_CHILD);
+                const uint32_t cnt = (uint32_t)__popcll(has);
+                if (sp + cnt <= BVH_STACK) {
+                    if (child != CHORD_BVH_NO_CHILD) stack[sp + (uint32_t)__popcll(has & ((1ull << lane) - 1ull))] = child;
+                    sp += cnt;
+                }
+                // (a full stack cannot happen: 14 levels x 7 pending siblings < 128; upload_scene bounds the depth)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
 }
 
 // Long scenes (thousands of count blocks): one workgroup turns the per-block counts into exclusive offsets, so the
@@ -533,13 +637,26 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     }
     FrameTail none;
     std::memset(&none, 0, sizeof(none));
-    if (blocks > 512u) {
+    const bool hier = c->cullMode == 1 && c->bvhComplete && c->dBvhNodes;
+    if (blocks > 512u || hier) {
+        // (the mask array is a multiple of 16 bytes long: dalloc rounds nothing, so the tail is zeroed by the last partial vector
+        // only when it exists -- the buffer is allocated with 16 bytes of slack, see upload_scene)
         hipLaunchKernelGGL(object_cull_kernel, dim3((c->objectCount + 255u) / 256u + tail.run), dim3(256), 0, c->stream, c->dObjects, c->dObjStatic,
-                           c->dPrims, c->hView, publish, c->dObjFrame, c->objectCount, zeroBase, zeroVec4, tail);
-        hipLaunchKernelGGL(group_cull_count_kernel, dim3(blocks), dim3(256), 0, c->stream, p, c->hView, (DView*)nullptr,
-                           (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
+                           c->dPrims, c->hView, publish, c->dObjFrame, c->objectCount, zeroBase, zeroVec4, tail,
+                           reinterpret_cast<uint4*>(c->dGroupMask), hier ? (c->groupInstances + 15u) / 16u : 0u);
+        if (hier) {
+            BvhCullParams bp;
+            bp.g = p; bp.nodes = c->dBvhNodes; bp.objectCount = c->objectCount;
+            const uint32_t bb = std::min((c->objectCount + 3u) / 4u, (uint32_t)c->numCUs * 8u);
+            hipLaunchKernelGGL(bvh_cull_kernel, dim3(std::max(bb, 1u)), dim3(256), 0, c->stream, bp, c->hView);
+            hipLaunchKernelGGL(group_cull_count_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p, c->hView, (DView*)nullptr,
+                               (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
+        } else {
+            hipLaunchKernelGGL(group_cull_count_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p, c->hView, (DView*)nullptr,
+                               (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
+        }
     } else {
-        hipLaunchKernelGGL(group_cull_count_kernel, dim3(blocks + tail.run), dim3(256), 0, c->stream, p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4,
+        hipLaunchKernelGGL(group_cull_count_kernel<false>, dim3(blocks + tail.run), dim3(256), 0, c->stream, p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4,
                            blocks, tail);
     }
     c->viewDirty = false;

@@ -111,6 +111,7 @@ def _load():
         "chordvis_set_view": (i32, [vp, vp, vp, u32]),
         "chordvis_allocate_gbuffer": (i32, [vp, u32, u32, vp]),
         "chordvis_set_shard": (i32, [vp, u32, u32, u32]),
+        "chordvis_set_cull_mode": (i32, [vp, i32]),
         "chordvis_visibility_words": (u64, [vp]),
         "chordvis_visibility_chunk_words": (u64, [vp]),
         "chordvis_visibility_ptr": (vp, [vp]),

@@ -20,6 +20,9 @@ MESHLET_GROUP = np.dtype([
     ("parentPosCenter", f32, 3), ("error", f32),
     ("meshletOffset", u32), ("meshletCount", u32),
 ])
+BVH_NODE = np.dtype([
+    ("sphere", f32, 4), ("children", u32, 8), ("bvhNodeCount", u32), ("leafMeshletGroupOffset", u32), ("leafMeshletGroupCount", u32),
+])
 PRIMITIVE = np.dtype([
     ("posMin", f32, 3), ("primitiveDatasBufferId", u32),
     ("posMax", f32, 3), ("vertexOffset", u32),
@@ -60,7 +63,7 @@ CAMERA_VIEW = np.dtype([
 ])
 DRAW_CMD = np.dtype([("objectId", u32), ("meshletId", u32), ("slot", u32)])
 
-assert MESHLET.itemsize == 64 and MESHLET_GROUP.itemsize == 40 and PRIMITIVE.itemsize == 96
+assert MESHLET.itemsize == 64 and MESHLET_GROUP.itemsize == 40 and PRIMITIVE.itemsize == 96 and BVH_NODE.itemsize == 60
 assert MATERIAL.itemsize == 96 and OBJECT.itemsize == 224 and INSTANCE_CULLING_VIEW.itemsize == 288
 assert CAMERA_VIEW.itemsize == 224 and DRAW_CMD.itemsize == 12
 
@@ -79,6 +82,7 @@ class AssetDesc(C.Structure):
         ("meshletData", C.c_void_p), ("meshletDataCount", C.c_uint32),
         ("positions", C.c_void_p), ("vertexCount", C.c_uint32),
         ("texcoord0", C.c_void_p), ("texcoord0Count", C.c_uint32),
+        ("bvhNodes", C.c_void_p), ("bvhNodeCount", C.c_uint32),
     ]
 
 
@@ -150,7 +154,7 @@ class Scene:
     """
 
     def __init__(self, objects, primitives, materials, meshlets, groups, group_indices, meshlet_data, positions,
-                 name="scene", texcoord0=None, textures=(), samplers=None):
+                 name="scene", texcoord0=None, textures=(), samplers=None, bvh_nodes=None):
         """textures: sequence of (H, W, 4) uint8 images (mip chains are built here); samplers: SAMPLER records."""
         self.name = name
         self.objects = np.ascontiguousarray(objects, dtype=OBJECT)
@@ -161,6 +165,7 @@ class Scene:
         self.group_indices = np.ascontiguousarray(group_indices, dtype=u32)
         self.meshlet_data = np.ascontiguousarray(meshlet_data, dtype=u32)
         self.positions = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
+        self.bvh_nodes = None if bvh_nodes is None else np.ascontiguousarray(bvh_nodes, dtype=BVH_NODE)
         self.texcoord0 = None if texcoord0 is None else np.ascontiguousarray(texcoord0, dtype=f32).reshape(-1, 2)
         self.texture_images = list(textures)
         self._tex_chains = [mip_chain_rgba8(t) for t in self.texture_images]
@@ -175,6 +180,7 @@ class Scene:
             self.meshlet_data.ctypes.data, len(self.meshlet_data),
             self.positions.ctypes.data, len(self.positions),
             self.texcoord0.ctypes.data if self.texcoord0 is not None else None, len(self.texcoord0) if self.texcoord0 is not None else 0,
+            self.bvh_nodes.ctypes.data if self.bvh_nodes is not None else None, len(self.bvh_nodes) if self.bvh_nodes is not None else 0,
         )
         self._assets = (AssetDesc * 1)(self._asset)
         self.desc = SceneDesc(
@@ -190,7 +196,7 @@ class Scene:
         """The same geometry, textures and samplers under other object / material records (shallow: arrays are shared)."""
         out = Scene(self.objects if objects is None else objects, self.primitives, self.materials if materials is None else materials,
                     self.meshlets, self.groups, self.group_indices, self.meshlet_data, self.positions, name=self.name,
-                    texcoord0=self.texcoord0, textures=self.texture_images, samplers=self.samplers)
+                    texcoord0=self.texcoord0, textures=self.texture_images, samplers=self.samplers, bvh_nodes=self.bvh_nodes)
         if hasattr(self, "local_to_world"):
             out.local_to_world = self.local_to_world
         return out

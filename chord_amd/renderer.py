@@ -65,6 +65,10 @@ class VisibilityRenderer:
         self._check(L.lib.chordvis_allocate_gbuffer(self._ctx, width, height, device_visibility), "allocate_gbuffer")
         self.width, self.height = width, height
 
+    def set_cull_mode(self, hierarchical):
+        """0: flat group cull (the reference's dispatch); 1: walk the primitives' BVHs (same command list)."""
+        self._check(L.lib.chordvis_set_cull_mode(self._ctx, int(hierarchical)), "set_cull_mode")
+
     def set_shard(self, stripe_rows, ranks, rank):
         self._check(L.lib.chordvis_set_shard(self._ctx, stripe_rows, ranks, rank), "set_shard")
 

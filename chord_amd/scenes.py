@@ -214,7 +214,10 @@ class PrimitiveBuilder:
 
     def finish(self):
         pos = np.concatenate(self.positions) if self.positions else np.zeros((0, 3), np.float32)
+        groups, nodes = build_bvh(np.concatenate(self.groups))
+        self.groups = [groups]
         return dict(
+            bvh_nodes=nodes,
             positions=pos,
             texcoords=np.concatenate(self.texcoords) if self.texcoords else np.zeros((0, 2), np.float32),
             meshlets=np.concatenate(self.meshlets),
@@ -222,6 +225,77 @@ class PrimitiveBuilder:
             groups=np.concatenate(self.groups),
             group_indices=np.concatenate(self.group_indices),
         )
+
+
+def build_bvh(groups):
+    """The 8-wide tree over the parented cluster groups of one primitive, shaped like the reference's buildBVHTree /
+    buildBVH / flattenBVH (nanite_builder.cpp:77-416): un-parented groups are the root's leaves; the others are split
+    2 x 2 x 2 by sorting on the longest axis of the union of their parent-error boxes until fewer than 8 remain; nodes are
+    flattened breadth first and the groups re-ordered as the nodes list them.  Returns (groups in tree order, nodes)."""
+    groups = np.asarray(groups, dtype=T.MESHLET_GROUP)
+    parented = np.nonzero(groups["parentError"] < 3.0e38)[0]
+    roots = np.nonzero(groups["parentError"] >= 3.0e38)[0]
+    pc = groups["parentPosCenter"].astype(np.float32)
+    pe = groups["parentError"].astype(np.float32)
+
+    def bounds(ids):
+        if len(ids) == 0:
+            return np.zeros(3, np.float32), np.zeros(3, np.float32)
+        return (pc[ids] - pe[ids, None]).min(axis=0), (pc[ids] + pe[ids, None]).max(axis=0)
+
+    def longest(mn, mx):
+        d = mx - mn
+        a = 0
+        if d[1] >= d[0] and d[1] >= d[2]:
+            a = 1
+        if d[2] >= d[0] and d[2] >= d[1]:
+            a = 2
+        return a
+
+    def halves(ids, mn, mx):
+        order = ids[np.argsort(pc[ids, longest(mn, mx)], kind="stable")]
+        n = len(order)
+        return [order[i * n // 2:(i + 1) * n // 2] for i in range(2)]
+
+    class Node:
+        pass
+    root = Node()
+    root.mn, root.mx = bounds(parented)
+    root.leaves, root.children, root.depth, root.todo = list(roots), [None] * 8, 0, parented
+    queue, order = [root], []
+    while queue:
+        nd = queue.pop(0)
+        order.append(nd)
+        ids = nd.todo
+        if len(ids) == 0:
+            continue
+        if len(ids) < 8 or nd.depth == 13:                       # kNaniteBVHLevelNodeCount / kNaniteMaxBVHLevelCount - 1
+            nd.leaves = nd.leaves + list(ids)
+            continue
+        for i, h0 in enumerate(halves(ids, nd.mn, nd.mx)):
+            for j, h1 in enumerate(halves(h0, *bounds(h0))):
+                for k, h2 in enumerate(halves(h1, *bounds(h1))):
+                    ch = Node()
+                    ch.mn, ch.mx = bounds(h2)
+                    ch.leaves, ch.children, ch.depth, ch.todo = [], [None] * 8, nd.depth + 1, h2
+                    nd.children[(i * 2 + j) * 2 + k] = ch
+                    queue.append(ch)
+    # breadth-first flatten (the queue above already visits in that order)
+    for i, nd in enumerate(order):
+        nd.index = i
+    nodes = np.zeros(len(order), dtype=T.BVH_NODE)
+    new_order = []
+    for nd in order:
+        n = nodes[nd.index]
+        n["sphere"][:3] = 0.5 * (nd.mx + nd.mn)
+        n["sphere"][3] = 0.5 * np.float32(np.linalg.norm((nd.mx - nd.mn).astype(np.float32)))
+        n["children"] = [c.index if c is not None else 0xFFFFFFFF for c in nd.children]
+        n["leafMeshletGroupOffset"], n["leafMeshletGroupCount"] = len(new_order), len(nd.leaves)
+        new_order += nd.leaves
+    for nd in reversed(order):
+        nodes[nd.index]["bvhNodeCount"] = 1 + sum(int(nodes[c.index]["bvhNodeCount"]) for c in nd.children if c is not None)
+    assert sorted(new_order) == list(range(len(groups))) and nodes[0]["bvhNodeCount"] == len(nodes)
+    return groups[np.array(new_order, dtype=np.int64)], nodes
 
 
 class SceneBuilder:
@@ -270,8 +344,8 @@ class SceneBuilder:
 
     def build(self):
         prims = np.zeros(len(self.prims), dtype=T.PRIMITIVE)
-        pos, ml, md, gr, gi, uv = [], [], [], [], [], []
-        nv = nm = nd = ng = ni = 0
+        pos, ml, md, gr, gi, uv, bv = [], [], [], [], [], [], []
+        nv = nm = nd = ng = ni = nb = 0
         for i, p in enumerate(self.prims):
             prims[i]["posMin"] = p["positions"].min(axis=0)
             prims[i]["posMax"] = p["positions"].max(axis=0)
@@ -280,6 +354,8 @@ class SceneBuilder:
             prims[i]["meshletOffset"] = nm
             prims[i]["meshletGroupOffset"], prims[i]["meshletGroupCount"] = ng, len(p["groups"])
             prims[i]["meshletGroupIndicesOffset"] = ni
+            prims[i]["bvhNodeOffset"] = nb
+            bv.append(p["bvh_nodes"]); nb += len(p["bvh_nodes"])
             m = p["meshlets"].copy()
             m["dataOffset"] += nd
             uv.append(p["texcoords"]); pos.append(p["positions"]); ml.append(m); md.append(p["meshlet_data"]); gr.append(p["groups"]); gi.append(p["group_indices"])
@@ -290,7 +366,8 @@ class SceneBuilder:
         scene = T.Scene(objects, prims, np.concatenate(self.materials), np.concatenate(ml), np.concatenate(gr),
                         np.concatenate(gi), np.concatenate(md), np.concatenate(pos), name=self.name,
                         texcoord0=np.concatenate(uv) if (self.textures and uv) else None, textures=self.textures,
-                        samplers=np.array(self.samplers, dtype=T.SAMPLER) if self.samplers else None)
+                        samplers=np.array(self.samplers, dtype=T.SAMPLER) if self.samplers else None,
+                        bvh_nodes=np.concatenate(bv) if bv else None)
         # glm column-major doubles
         scene.local_to_world = np.ascontiguousarray(np.stack([m.T.reshape(16) for m in self.obj_l2w]), dtype=np.float64)
         return scene

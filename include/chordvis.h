@@ -167,6 +167,13 @@ int chordvis_bind_objects(ChordCtx* ctx, const ChordObject* deviceObjects, uint3
 int chordvis_set_view(ChordCtx* ctx, const ChordCameraView* view, const ChordInstanceCullingView* instanceView,
                       uint32_t switchFlags);
 
+/* How instanceCulling walks a primitive's cluster groups.  0 (default): flat, one thread per (object, group) like the
+ * reference's dispatch (instance_culling.cpp:144-157; it uploads the BVH and never reads it, instance_culling.hlsl:96-99).
+ * 1: hierarchical -- resident waves walk every visible object's GPUBVHNode tree (ChordAssetDesc::bvhNodes) and drop a
+ * subtree when its sphere, which bounds the parent-error spheres beneath it, already projects below the LOD
+ * threshold; only the groups of surviving nodes are tested.  The command list is the same array either way. */
+int chordvis_set_cull_mode(ChordCtx* ctx, int hierarchical);
+
 /* allocateGBufferTextures (render_textures.cpp:20-45): size the visibility target.  deviceVisibility
  * may be a caller-owned device buffer of chordvis_visibility_words(ctx) uint64 (used for the
  * multi-GPU all-gather), or NULL for a context-owned one. */

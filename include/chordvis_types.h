@@ -73,6 +73,23 @@ typedef struct ChordMeshletGroup {
     uint32_t meshletCount;         /* <= 4                                 */
 } ChordMeshletGroup;
 
+/* GPUBVHNode -- gltf.h:16-24, built by buildBVHTree / flattenBVH (nanite_builder.cpp:215-416): an 8-wide tree over the
+ * PARENTED cluster groups of a primitive, keyed on their parent-error spheres; `sphere` bounds the parent spheres of
+ * every group in the node's subtree (nanite_builder.cpp:53-56), the root's own leaves are the un-parented groups.
+ * Indices are relative to the primitive's first node / first group; nodes are in breadth-first order and the
+ * primitive's groups in the order the nodes list them.  The reference uploads the tree and never walks it
+ * (instance_culling.hlsl:96-99); chordvis_set_cull_mode(ctx, 1) does. */
+#define CHORD_BVH_WIDTH 8u             /* kNaniteBVHLevelNodeCount, base.h:433 */
+#define CHORD_BVH_MAX_LEVELS 14u       /* kNaniteMaxBVHLevelCount,  base.h:432 */
+#define CHORD_BVH_NO_CHILD 0xFFFFFFFFu
+typedef struct ChordBVHNode {
+    float    sphere[4];
+    uint32_t children[8];
+    uint32_t bvhNodeCount;             /* nodes of the subtree, this one included */
+    uint32_t leafMeshletGroupOffset;
+    uint32_t leafMeshletGroupCount;
+} ChordBVHNode;
+
 typedef struct ChordPrimitive {
     float    posMin[3];
     uint32_t primitiveDatasBufferId;   /* index into ChordSceneDesc.assets */
@@ -197,6 +214,8 @@ typedef struct ChordAssetDesc {
     const float*             positions;          uint32_t vertexCount;       /* float3 tightly packed */
     const float*             texcoord0;          uint32_t texcoord0Count;    /* float2 per vertex (textureCoord0Buffer), or NULL / 0:
                                                                               * masked materials then sample at uv (0, 0) */
+    const ChordBVHNode*      bvhNodes;           uint32_t bvhNodeCount;      /* bvhNodeBuffer, or NULL / 0 (flat culling only);
+                                                                              * primitive p's tree starts at bvhNodeOffset */
 } ChordAssetDesc;
 
 typedef struct ChordSceneDesc {
@@ -234,6 +253,7 @@ typedef struct ChordHZBDesc {
 }
 static_assert(sizeof(ChordMeshlet) == 64, "GPUGLTFMeshlet");
 static_assert(sizeof(ChordMeshletGroup) == 40, "GPUGLTFMeshletGroup");
+static_assert(sizeof(ChordBVHNode) == 60, "GPUBVHNode");
 static_assert(sizeof(ChordPrimitive) == 96, "GLTFPrimitiveBuffer");
 static_assert(sizeof(ChordMaterial) == 96, "GLTFMaterialGPUData");
 static_assert(sizeof(ChordObjectBasicData) == 208, "GPUObjectBasicData");

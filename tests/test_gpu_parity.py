@@ -549,3 +549,73 @@ def test_config3_4k_ground_level_views_match_oracle(gpu, pos, front):
     st = r.stats()
     assert st["overflow"] == 0 and st["triangleRecords"] > st["triangleRecordsCompact"]      # wide records exist
     r.close()
+
+
+HIER = [
+    ("small", lambda: scenes.small_test_scene(320, 200, seed=13)),
+    ("masked", lambda: scenes.masked_test_scene(320, 200)),
+    ("street_720p", lambda: scenes.config3_street(1280, 720)),
+    ("street_4k", scenes.config3_street),
+    ("street_x16_1080p", lambda: scenes.config4_street_x64(1920, 1080, grid=4)),
+    ("subpixel_small", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4)),
+]
+
+
+@pytest.mark.parametrize("name,builder", HIER, ids=[h[0] for h in HIER])
+def test_hierarchical_cull_builds_the_same_command_list_and_frames(gpu, name, builder):
+    """chordvis_set_cull_mode(1): resident waves walk the primitives' GPUBVHNode trees (which the reference builds and
+    never reads) and drop subtrees by their parent-error spheres; the command ARRAY (slots included) must equal the flat
+    dispatch's -- i.e. the oracle's -- from several distances, and so must two frames with two-pass occlusion culling."""
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam0 = builder()
+    assert scene.bvh_nodes is not None and len(scene.bvh_nodes) >= len(scene.primitives)
+    w, h, flags = cam0.width, cam0.height, H.ALL_FLAGS
+    r = VisibilityRenderer(0)
+    r.set_cull_mode(1)
+    r.upload_scene(scene)
+    r.allocate_gbuffer(w, h)
+    f = np.array(cam0.front, dtype=np.float64)
+    f /= np.linalg.norm(f)
+    for back in (0.0, 12.0, 60.0, 400.0):                        # farther away: coarser LODs, more subtrees dropped
+        cam = cam0.moved(tuple(-back * f))
+        L.fill_objects(scene, cam)
+        view, iv = L.make_views(cam)
+        r.update_objects(scene.objects)
+        r.set_view(view, iv, flags)
+        got = r.read_cmds(r.instance_culling())
+        want = orc.instance_culling(scene, view, iv, flags)
+        assert len(got) == len(want) and np.array_equal(got, want), "%s at -%g m: %d vs %d commands" % (name, back, len(got), len(want))
+    L.fill_objects(scene, cam0)
+    view, iv = L.make_views(cam0)
+    r.update_objects(scene.objects)
+    r.set_view(view, iv, flags)
+    r.reset_history()
+    prev = None
+    for frame in range(2):
+        r.render_frame()
+        want = orc.frame(scene, view, iv, flags, prev_hzb_min=prev)
+        H.assert_vis_equal(r.read_visibility(), want["vis"], w, h, "%s frame %d" % (name, frame))
+        prev = want["hzb_min"]
+    r.close()
+
+
+def test_hierarchical_cull_is_refused_without_trees(gpu):
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam = scenes.small_test_scene(160, 96)
+    bare = R.Scene(scene.objects, scene.primitives, scene.materials, scene.meshlets, scene.groups, scene.group_indices,
+                   scene.meshlet_data, scene.positions)
+    r = VisibilityRenderer(0)
+    r.upload_scene(bare)
+    with pytest.raises(L.ChordvisError):
+        r.set_cull_mode(1)
+    # a tree whose sphere does not bound its groups is rejected at upload
+    bad = scene.bvh_nodes.copy()
+    k = int(np.argmax((np.arange(len(bad)) > 0) & (bad["leafMeshletGroupCount"] > 0)))
+    bad["sphere"][k, 3] *= 0.25
+    broken = R.Scene(scene.objects, scene.primitives, scene.materials, scene.meshlets, scene.groups, scene.group_indices,
+                     scene.meshlet_data, scene.positions, bvh_nodes=bad)
+    with pytest.raises(L.ChordvisError):
+        r.upload_scene(broken)
+    r.close()
