@@ -231,6 +231,42 @@ void stamp(ChordCtx* c, int tag)
 }
 }
 
+namespace chord {
+// Per-context work buffers that depend on the scene's counts (object frames, group masks, command lists, raster work
+// lists): the tail of chordvis_upload_scene, shared with the depth-view child context (depth_views.cpp).
+int alloc_scene_work_buffers(ChordCtx* c)
+{
+    int rc;
+    const uint64_t instTriangles = c->instTriangles;
+    if ((rc = dalloc(c, &c->dObjectsOwned, (size_t)c->objectCount))) return rc;
+    if ((rc = dalloc(c, &c->dObjFrame, (size_t)c->objectCount))) return rc;
+    if ((rc = dalloc(c, &c->dGroupMask, (size_t)c->groupInstances + 16))) return rc;   // (+16: zeroed in 16-byte vectors)
+    if ((rc = dalloc(c, &c->dBlockCounts, (size_t)c->cullBlocks * 2))) return rc;   // counts, then triangles, per count block
+    for (int i = 0; i < 3; i++) {
+        if ((rc = dalloc(c, &c->lists[i].cmds, (size_t)c->cmdCapacity))) return rc;
+        c->lists[i].count = c->dCounts + i;
+        c->lists[i].capacity = c->cmdCapacity;
+    }
+    // raster work lists, sized from the scene like the reference sizes its command buffers from lod0MeshletCount
+    // (instance_culling.cpp:141): a triangle instance is set up at most once per frame (stage 0 or stage 1), so the
+    // records of a frame never exceed the triangles of every meshlet instance (all LODs) plus the pieces the clipper
+    // adds; chordvis_set_limits caps (or, for scenes beyond the default cap, raises) the budget.  Exhaustion is
+    // detected on the device and reported by chordvis_stats.  Nearly all triangles take the 32-byte form; the 48-byte
+    // list (triangles wider than 64 px, clipped pieces) gets the same bound up to a quarter of the limit.
+    // (x2 + 256 Ki: the list is cut into 64 shards that fill unevenly, and a clipped triangle becomes several records)
+    const uint64_t need = (2 * instTriangles + (256u << 10) + CHORD_LIST_SHARDS - 1) & ~(uint64_t)(CHORD_LIST_SHARDS - 1);
+    c->triCapC = (uint32_t)std::min<uint64_t>(c->limitRecords, need);
+    c->triCap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->limitRecords / 4, 1u << 20), need) & ~(CHORD_LIST_SHARDS - 1u);
+    c->clipTriCap = 1u << 20;
+    if ((rc = dalloc(c, &c->dTris, (size_t)c->triCap))) return rc;
+    if ((rc = dalloc(c, &c->dTrisC, (size_t)c->triCapC))) return rc;
+    if ((rc = dalloc(c, &c->dClipTris, (size_t)c->clipTriCap))) return rc;
+    c->largeCap = 8u << 20;
+    if ((rc = dalloc(c, &c->dLargeList, (size_t)c->largeCap))) return rc;
+    return CHORDVIS_OK;
+}
+}
+
 extern "C" {
 
 // ------------------------------------------------------------------------------------ context --
@@ -268,6 +304,13 @@ int chordvis_destroy(ChordCtx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)chordvis_comm_destroy(c);
+    if (c->depthCtx) { chordvis_destroy(c->depthCtx); c->depthCtx = nullptr; }
+    for (float*& d : c->dDepthImages) dfree(d);
+    if (c->sharedScene) {       // a depth-view child: the scene buffers are the parent's
+        c->dPrims = nullptr; c->dGroups = nullptr; c->dMeshlets = nullptr; c->dGroupIndices = nullptr; c->dMeshletData = nullptr;
+        c->dPositions = nullptr; c->dObjStatic = nullptr; c->dGroupOwner = nullptr; c->dMaterials = nullptr; c->dTexAlpha = nullptr;
+        c->dTexcoords = nullptr; c->dBvhNodes = nullptr;
+    }
     dfree(c->dPrims); dfree(c->dGroups); dfree(c->dMeshlets); dfree(c->dGroupIndices); dfree(c->dMeshletData);
     dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dMaterials); dfree(c->dTexAlpha); dfree(c->dTexcoords); dfree(c->dBvhNodes); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
@@ -376,7 +419,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
             const uint32_t count = nodes[0].bvhNodeCount;
             if (count == 0 || (uint64_t)p.bvhNodeOffset + count > as.bvhNodeCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: BVH root's node count exceeds the node buffer");
             std::vector<uint8_t> seen(p.meshletGroupCount, 0);
-            std::vector<float> need(count, 0.0f);           // smallest radius each node's sphere must have
+            std::vector<std::vector<uint32_t>> below(count);    // parented groups of each node's subtree
             for (uint32_t n = count; n-- > 0;) {            // children come after their parent (breadth-first order)
                 const ChordBVHNode& nd = nodes[n];
                 if ((uint64_t)nd.leafMeshletGroupOffset + nd.leafMeshletGroupCount > p.meshletGroupCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: BVH leaf range outside the primitive's groups");
@@ -386,24 +429,48 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
                     const ChordMeshletGroup& gr = as.meshletGroups[p.meshletGroupOffset + gi];
                     if (n != 0) {
                         if (!(gr.parentError < CHORD_ERROR_RADIUS_ROOT)) return fail(c, CHORDVIS_E_INVALID, "upload_scene: an un-parented group below the BVH root");
-                        const float dx = gr.parentPosCenter[0] - nd.sphere[0], dy = gr.parentPosCenter[1] - nd.sphere[1], dz = gr.parentPosCenter[2] - nd.sphere[2];
-                        need[n] = std::max(need[n], std::sqrt(dx * dx + dy * dy + dz * dz) + gr.parentError);
+                        below[n].push_back(gi);
                     }
                 }
                 for (uint32_t k = 0; k < CHORD_BVH_WIDTH; k++) {
                     const uint32_t ch = nd.children[k];
                     if (ch == CHORD_BVH_NO_CHILD) continue;
                     if (ch <= n || ch >= count) return fail(c, CHORDVIS_E_INVALID, "upload_scene: BVH child index out of order / range");
-                    const ChordBVHNode& cn = nodes[ch];
-                    const float dx = cn.sphere[0] - nd.sphere[0], dy = cn.sphere[1] - nd.sphere[1], dz = cn.sphere[2] - nd.sphere[2];
-                    need[n] = std::max(need[n], std::sqrt(dx * dx + dy * dy + dz * dz) + need[ch]);
+                    below[n].insert(below[n].end(), below[ch].begin(), below[ch].end());
+                    std::vector<uint32_t>().swap(below[ch]);
                 }
-                if (!(need[n] <= nd.sphere[3] * 1.0001f + 1.0e-6f)) return fail(c, CHORDVIS_E_INVALID, "upload_scene: a BVH node's sphere does not contain the parent-error spheres beneath it");
+                // the sphere bounds the parent-error sphere of every group beneath (the root: beneath its children)
+                for (uint32_t gi : below[n]) {
+                    const ChordMeshletGroup& gr = as.meshletGroups[p.meshletGroupOffset + gi];
+                    const float dx = gr.parentPosCenter[0] - nd.sphere[0], dy = gr.parentPosCenter[1] - nd.sphere[1], dz = gr.parentPosCenter[2] - nd.sphere[2];
+                    if (!(std::sqrt(dx * dx + dy * dy + dz * dz) + gr.parentError <= nd.sphere[3] * 1.0001f + 1.0e-6f))
+                        return fail(c, CHORDVIS_E_INVALID, "upload_scene: a BVH node's sphere does not contain the parent-error spheres beneath it");
+                }
                 DBVHNode& dn = bvh[nB[a] + p.bvhNodeOffset + n];
                 std::memcpy(dn.sphere, nd.sphere, 16); std::memcpy(dn.children, nd.children, 32);
                 dn.bvhNodeCount = nd.bvhNodeCount; dn.leafGroupOffset = nd.leafMeshletGroupOffset; dn.leafGroupCount = nd.leafMeshletGroupCount; dn.pad = 0;
             }
             for (uint32_t gi = 0; gi < p.meshletGroupCount; gi++) if (!seen[gi]) return fail(c, CHORDVIS_E_INVALID, "upload_scene: a cluster group is missing from the primitive's BVH");
+            {   // breadth-first order: a level is a contiguous range; every node keeps the end of its level (DBVHNode::pad)
+                std::vector<uint32_t> level(count, 0xFFFFFFFFu);
+                level[0] = 0;
+                for (uint32_t n = 0; n < count; n++) {
+                    if (level[n] == 0xFFFFFFFFu) return fail(c, CHORDVIS_E_INVALID, "upload_scene: a BVH node is not reachable from the root");
+                    for (uint32_t k = 0; k < CHORD_BVH_WIDTH; k++) {
+                        const uint32_t ch = nodes[n].children[k];
+                        if (ch == CHORD_BVH_NO_CHILD) continue;
+                        if (level[ch] != 0xFFFFFFFFu) return fail(c, CHORDVIS_E_INVALID, "upload_scene: a BVH node has two parents");
+                        level[ch] = level[n] + 1;
+                    }
+                    if (n && level[n] < level[n - 1]) return fail(c, CHORDVIS_E_INVALID, "upload_scene: BVH nodes are not in breadth-first order");
+                    if (level[n] >= CHORD_BVH_MAX_LEVELS) return fail(c, CHORDVIS_E_INVALID, "upload_scene: BVH deeper than kNaniteMaxBVHLevelCount");
+                }
+                uint32_t end = count;
+                for (uint32_t n = count; n-- > 0;) {
+                    if (n + 1 < count && level[n + 1] != level[n]) end = n + 1;
+                    bvh[nB[a] + p.bvhNodeOffset + n].pad = end;
+                }
+            }
             d.bvhBase = nB[a] + p.bvhNodeOffset;
         } else bvhComplete = false;
         for (uint32_t gi = 0; gi < p.meshletGroupCount; gi++) {
@@ -525,33 +592,11 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     if (!alpha.empty()) { UP(c->dTexAlpha, alpha) } else dfree(c->dTexAlpha);
     if (!uvs.empty()) { UP(c->dTexcoords, uvs) } else dfree(c->dTexcoords);
 #undef UP
-    if ((rc = dalloc(c, &c->dObjectsOwned, (size_t)s->objectCount))) return rc;
+    c->instTriangles = instTriangles;
+    if (c->depthCtx) { chordvis_destroy(c->depthCtx); c->depthCtx = nullptr; }       // (it aliased the old scene buffers)
+    if ((rc = chord::alloc_scene_work_buffers(c))) return rc;
     CHORD_HIP(c, hipMemcpy(c->dObjectsOwned, s->objects, sizeof(ChordObject) * s->objectCount, hipMemcpyHostToDevice));
     c->dObjects = c->dObjectsOwned;
-    if ((rc = dalloc(c, &c->dObjFrame, (size_t)s->objectCount))) return rc;
-    if ((rc = dalloc(c, &c->dGroupMask, (size_t)c->groupInstances + 16))) return rc;   // (+16: zeroed in 16-byte vectors)
-    if ((rc = dalloc(c, &c->dBlockCounts, (size_t)c->cullBlocks * 2))) return rc;   // counts, then triangles, per count block
-    for (int i = 0; i < 3; i++) {
-        if ((rc = dalloc(c, &c->lists[i].cmds, (size_t)c->cmdCapacity))) return rc;
-        c->lists[i].count = c->dCounts + i;
-        c->lists[i].capacity = c->cmdCapacity;
-    }
-    // raster work lists, sized from the scene like the reference sizes its command buffers from lod0MeshletCount
-    // (instance_culling.cpp:141): a triangle instance is set up at most once per frame (stage 0 or stage 1), so the
-    // records of a frame never exceed the triangles of every meshlet instance (all LODs) plus the pieces the clipper
-    // adds; chordvis_set_limits caps (or, for scenes beyond the default cap, raises) the budget.  Exhaustion is
-    // detected on the device and reported by chordvis_stats.  Nearly all triangles take the 32-byte form; the 48-byte
-    // list (triangles wider than 64 px, clipped pieces) gets the same bound up to a quarter of the limit.
-    // (x2 + 256 Ki: the list is cut into 64 shards that fill unevenly, and a clipped triangle becomes several records)
-    const uint64_t need = (2 * instTriangles + (256u << 10) + CHORD_LIST_SHARDS - 1) & ~(uint64_t)(CHORD_LIST_SHARDS - 1);
-    c->triCapC = (uint32_t)std::min<uint64_t>(c->limitRecords, need);
-    c->triCap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->limitRecords / 4, 1u << 20), need) & ~(CHORD_LIST_SHARDS - 1u);
-    c->clipTriCap = 1u << 20;
-    if ((rc = dalloc(c, &c->dTris, (size_t)c->triCap))) return rc;
-    if ((rc = dalloc(c, &c->dTrisC, (size_t)c->triCapC))) return rc;
-    if ((rc = dalloc(c, &c->dClipTris, (size_t)c->clipTriCap))) return rc;
-    c->largeCap = 8u << 20;
-    if ((rc = dalloc(c, &c->dLargeList, (size_t)c->largeCap))) return rc;
     c->sceneLoaded = true;
     c->historySlot = 0;
     c->pendingTailSlot = 0;

@@ -1,0 +1,188 @@
+// Depth-only views: the passes renderShadow runs per cascade (mesh_raster.cpp:331-546) behind the C ABI.
+//
+//   chordvis_set_instance_views       <- the InstanceCullingViewInfo[] buffer (cascadeViewInfos; base.h:121-135)
+//   chordvis_instance_culling_view    <- instanceCulling(queue, ctx, viewsSRV, cascadeId)       gltf_rendering.h:38-43, mesh_raster.cpp:452
+//   chordvis_hzb_culling_generic      <- detail::hzbCullingGeneric                              instance_culling.cpp:232-284
+//   chordvis_render_mesh_depth        <- clearDepthStencil + renderMeshDepth(PASS_TYPE_DEPTH)  mesh_raster.cpp:159-206,500-522
+//   chordvis_build_hzb_from_depth     <- buildHZB(queue, depth, true, false, false)            mesh_raster.cpp:466,527
+//
+// A view of another size than the main render target needs its own tile bins, lists and visibility words; they live in
+// a CHILD context of the cascade size that shares the parent's scene buffers (geometry, materials, textures, BVH) and
+// stream.  Every kernel is the main path's: the object pass takes the view's translatedWorldToClip / frustum planes
+// from the InstanceCullingViewInfo (orthographic for a cascade: base.hlsli:243-272) while the LOD cut keeps using the
+// MAIN camera (instance_culling.hlsl:166-174), the rasterizer runs with cull mode NONE, no id output, depth clamp and
+// depth bias, and the D32 image is the high half of the 64-bit words.
+
+#include "device_layer.h"
+
+#include <cstring>
+
+using namespace chord;
+
+namespace {
+
+int need_child(ChordCtx* c, const char* fn)
+{
+    if (!c) return CHORDVIS_E_INVALID;
+    if (!c->depthCtx) {
+        char buf[160];
+        std::snprintf(buf, sizeof(buf), "%s: chordvis_allocate_depth_views must come first (after upload_scene)", fn);
+        return fail(c, CHORDVIS_E_INVALID, buf);
+    }
+    return CHORDVIS_OK;
+}
+
+int child_fail(ChordCtx* c, int rc)
+{
+    if (rc && c->depthCtx) c->lastError = c->depthCtx->lastError;
+    return rc;
+}
+
+void double3_of(const uint32_t words[8], double out[3]) { std::memcpy(out, words, sizeof(double) * 3); }   // GPUStorageDouble4
+
+} // namespace
+
+extern "C" {
+
+int chordvis_allocate_depth_views(ChordCtx* c, uint32_t dim, uint32_t viewCount)
+{
+    if (!c || !c->sceneLoaded) return fail(c, CHORDVIS_E_INVALID, "allocate_depth_views: upload_scene must come first");
+    if (dim < 64 || dim > 4096 || viewCount == 0 || viewCount > 32) return fail(c, CHORDVIS_E_INVALID, "allocate_depth_views: dim 64..4096, 1..32 views (kMaxCascadeCount)");
+    if (c->shard.ranks > 1 || c->sharedScene) return fail(c, CHORDVIS_E_INVALID, "allocate_depth_views: not on a sharded or child context");
+    if (c->depthCtx) { chordvis_destroy(c->depthCtx); c->depthCtx = nullptr; }
+    for (float*& d : c->dDepthImages) if (d) { (void)hipFree(d); d = nullptr; }
+    ChordCtx* k = nullptr;
+    int rc = chordvis_create(c->device, c->stream, &k);
+    if (rc) return fail(c, rc, "allocate_depth_views: child context");
+    if (!c->stream) { chordvis_destroy(k); return fail(c, CHORDVIS_E_INVALID, "allocate_depth_views: no stream"); }
+    if (k->ownStream) {                                   // (parent stream is never null after create, but be safe)
+        (void)hipStreamDestroy(k->stream); k->stream = c->stream; k->ownStream = false;
+    }
+    k->sharedScene = true;
+    k->dPrims = c->dPrims; k->dGroups = c->dGroups; k->dMeshlets = c->dMeshlets; k->dGroupIndices = c->dGroupIndices;
+    k->dMeshletData = c->dMeshletData; k->dPositions = c->dPositions; k->dObjStatic = c->dObjStatic; k->dGroupOwner = c->dGroupOwner;
+    k->dMaterials = c->dMaterials; k->dTexAlpha = c->dTexAlpha; k->dTexcoords = c->dTexcoords; k->dBvhNodes = c->dBvhNodes;
+    k->bvhComplete = c->bvhComplete; k->anyMasked = c->anyMasked; k->hPrims = c->hPrims; k->hObjStatic = c->hObjStatic;
+    k->objectCount = c->objectCount; k->primCount = c->primCount; k->materialCount = c->materialCount; k->meshletCount = c->meshletCount;
+    k->groupCount = c->groupCount; k->groupInstances = c->groupInstances; k->cmdCapacity = c->cmdCapacity; k->cullBlocks = c->cullBlocks;
+    k->instTriangles = c->instTriangles; k->limitRecords = c->limitRecords; k->limitPoolChunks = c->limitPoolChunks; k->binMaxChunks = c->binMaxChunks;
+    c->depthCtx = k;
+    if ((rc = alloc_scene_work_buffers(k))) return child_fail(c, rc);
+    k->dObjects = c->dObjects;
+    k->sceneLoaded = true;
+    if ((rc = chordvis_allocate_gbuffer(k, dim, dim, nullptr))) return child_fail(c, rc);
+    c->depthDim = dim;
+    c->dDepthImages.assign(viewCount, nullptr);
+    for (uint32_t i = 0; i < viewCount; i++) {
+        CHORD_HIP(c, hipMalloc((void**)&c->dDepthImages[i], sizeof(float) * (size_t)dim * dim));
+        CHORD_HIP(c, hipMemsetAsync(c->dDepthImages[i], 0, sizeof(float) * (size_t)dim * dim, c->stream));
+    }
+    return CHORDVIS_OK;
+}
+
+int chordvis_set_instance_views(ChordCtx* c, const ChordInstanceCullingView* hostViews, uint32_t count)
+{
+    if (!c || !hostViews || count == 0 || count > 32) return fail(c, CHORDVIS_E_INVALID, "set_instance_views: 1..32 views");
+    c->instanceViews.assign(hostViews, hostViews + count);
+    return CHORDVIS_OK;
+}
+
+int chordvis_instance_culling_view(ChordCtx* c, uint32_t instanceViewOffset, ChordCountAndCmd* out)
+{
+    int rc = need_child(c, "instance_culling_view");
+    if (rc) return rc;
+    if (!c->viewSet) return fail(c, CHORDVIS_E_INVALID, "instance_culling_view: set_view (the main camera: the LOD cut uses it) must come first");
+    if (instanceViewOffset >= c->instanceViews.size()) return fail(c, CHORDVIS_E_INVALID, "instance_culling_view: instanceViewOffset beyond set_instance_views");
+    ChordCtx* k = c->depthCtx;
+    const ChordInstanceCullingView& iv = c->instanceViews[instanceViewOffset];
+    if ((uint32_t)iv.renderDimension[0] != k->width || (uint32_t)iv.renderDimension[1] != k->height)
+        return fail(c, CHORDVIS_E_INVALID, "instance_culling_view: the view's renderDimension differs from the allocated depth views");
+    k->dObjects = c->dObjects;
+    k->cullMode = c->cullMode;
+    k->hView.view = c->hView.view;                       // instance_culling.hlsl:166-174: LOD selection always by the main view
+    k->hView.iv = iv;
+    k->hView.flags = c->hView.flags;
+    k->hView.width = k->width; k->hView.height = k->height;
+    k->viewSet = true; k->viewDirty = true;
+    k->depthViewCurrent = (int)instanceViewOffset;
+    launch_group_cull(k, k->lists[0]);
+    CHORD_HIP(c, hipGetLastError());
+    if (out) *out = k->lists[0].handle();
+    return CHORDVIS_OK;
+}
+
+int chordvis_hzb_culling_generic(ChordCtx* c, const ChordHZB* hzb, float extentScale, uint32_t instanceViewOffset,
+                                 int bObjectUseLastFrameProject, ChordCountAndCmd in, ChordCountAndCmd* out)
+{
+    int rc = need_child(c, "hzb_culling_generic");
+    if (rc) return rc;
+    if (!hzb || !hzb->minTexels || !in.count || !in.cmds || !out) return fail(c, CHORDVIS_E_INVALID, "hzb_culling_generic: invalid HZB or command list");
+    if (instanceViewOffset >= c->instanceViews.size()) return fail(c, CHORDVIS_E_INVALID, "hzb_culling_generic: instanceViewOffset beyond set_instance_views");
+    ChordCtx* k = c->depthCtx;
+    if (in.cmds == k->lists[1].cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling_generic: input aliases the output list");
+    const ChordInstanceCullingView& iv = c->instanceViews[instanceViewOffset];
+    double mainCam[3], viewCam[3];
+    double3_of(c->hView.iv.cameraWorldPos, mainCam);      // perView.cameraWorldPos (renderer.cpp:251-263 copies it into the main view's info)
+    double3_of(iv.cameraWorldPos, viewCam);
+    const float rel[3] = {(float)(mainCam[0] - viewCam[0]), (float)(mainCam[1] - viewCam[1]), (float)(mainCam[2] - viewCam[2])};
+    HzbBuffers hb;
+    hb.desc = hzb->desc; hb.minTexels = hzb->minTexels; hb.maxTexels = hzb->maxTexels; hb.validRange = hzb->validRange; hb.valid = true;
+    CmdList inL; inL.count = in.count; inL.cmds = in.cmds; inL.capacity = in.capacity;
+    k->hView.flags = c->hView.flags;
+    CHORD_HIP(c, hipMemsetAsync(k->lists[1].count, 0, sizeof(uint32_t), k->stream));
+    launch_hzb_cull_generic(k, hb, iv, rel, extentScale, bObjectUseLastFrameProject != 0, inL, k->lists[1]);
+    CHORD_HIP(c, hipGetLastError());
+    *out = k->lists[1].handle();
+    return CHORDVIS_OK;
+}
+
+int chordvis_render_mesh_depth(ChordCtx* c, uint32_t instanceViewOffset, int bDepthClamped, float depthBiasConst, float depthBiasSlope,
+                               ChordCountAndCmd in, ChordDepthTarget* out)
+{
+    int rc = need_child(c, "render_mesh_depth");
+    if (rc) return rc;
+    ChordCtx* k = c->depthCtx;
+    if (instanceViewOffset >= c->dDepthImages.size()) return fail(c, CHORDVIS_E_INVALID, "render_mesh_depth: view beyond allocate_depth_views");
+    if (k->depthViewCurrent != (int)instanceViewOffset)
+        return fail(c, CHORDVIS_E_INVALID, "render_mesh_depth: chordvis_instance_culling_view(instanceViewOffset) must come first (it sets up the view's object matrices)");
+    if ((rc = chordvis_clear_gbuffer(k))) return child_fail(c, rc);              // queue.clearDepthStencil(depth, 0.0), mesh_raster.cpp:500-501
+    k->depthOnly = true; k->depthClamp = bDepthClamped != 0; k->depthBiasConst = depthBiasConst; k->depthBiasSlope = depthBiasSlope;
+    rc = (in.count && in.cmds) ? chordvis_render_mesh(k, in) : CHORDVIS_OK;
+    k->depthOnly = false; k->depthClamp = false; k->depthBiasConst = 0.0f; k->depthBiasSlope = 0.0f;
+    if (rc) return child_fail(c, rc);
+    launch_depth_extract(k, (const unsigned long long*)k->dVis, c->dDepthImages[instanceViewOffset], (size_t)k->width * k->height);
+    CHORD_HIP(c, hipGetLastError());
+    if (out) { out->depth = c->dDepthImages[instanceViewOffset]; out->width = k->width; out->height = k->height; }
+    return CHORDVIS_OK;
+}
+
+int chordvis_build_hzb_from_depth(ChordCtx* c, const ChordDepthTarget* depth, ChordHZB* out)
+{
+    int rc = need_child(c, "build_hzb_from_depth");
+    if (rc) return rc;
+    ChordCtx* k = c->depthCtx;
+    if (!depth || !depth->depth || depth->width != k->width || depth->height != k->height)
+        return fail(c, CHORDVIS_E_INVALID, "build_hzb_from_depth: not a depth target of this context's depth views");
+    // the HZB kernels read the depth half of 64-bit words: the image goes (back) into the child's words
+    launch_depth_expand(k, depth->depth, (unsigned long long*)k->dVis, (size_t)k->width * k->height);
+    CHORD_HIP(c, hipGetLastError());
+    k->viewSet = true;
+    return child_fail(c, chordvis_build_hzb(k, 1, 0, 0, 0, out));
+}
+
+int chordvis_readback_depth(ChordCtx* c, const ChordDepthTarget* depth, float* host)
+{
+    if (!c || !depth || !depth->depth || !host) return fail(c, CHORDVIS_E_INVALID, "readback_depth: null argument");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    CHORD_HIP(c, hipMemcpy(host, depth->depth, sizeof(float) * (size_t)depth->width * depth->height, hipMemcpyDeviceToHost));
+    return CHORDVIS_OK;
+}
+
+int chordvis_depth_view_stats(ChordCtx* c, ChordStats* out)
+{
+    int rc = need_child(c, "depth_view_stats");
+    if (rc) return rc;
+    return child_fail(c, chordvis_stats(c->depthCtx, out));
+}
+
+} // extern "C"

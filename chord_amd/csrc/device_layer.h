@@ -206,6 +206,7 @@ struct ChordCtx {
     uint32_t meshletCount = 0, groupCount = 0;
     uint32_t groupInstances = 0;      // sum over objects of their primitive's group count
     uint32_t cmdCapacity = 0;         // sum over objects of their primitive's meshlet count (all LODs)
+    uint64_t instTriangles = 0;       // triangles of every meshlet instance (sizes the record lists)
     chord::DPrim* dPrims = nullptr;
     chord::DGroup* dGroups = nullptr;
     chord::DMeshlet* dMeshlets = nullptr;
@@ -221,6 +222,13 @@ struct ChordCtx {
     chord::DBVHNode* dBvhNodes = nullptr;   // every primitive's tree (or null: the scene came without)
     bool bvhComplete = false;         // every primitive has a validated tree
     int cullMode = 0;                 // 0 flat (the reference's dispatch), 1 hierarchical (chordvis_set_cull_mode)
+    // depth-only views (shadow cascades): a child context of the cascade size that shares this context's scene buffers
+    ChordCtx* depthCtx = nullptr;
+    bool sharedScene = false;         // this IS such a child: the scene buffers belong to the parent
+    std::vector<float*> dDepthImages; // one D32 image per view (cascadeDim^2 floats)
+    uint32_t depthDim = 0;
+    int depthViewCurrent = -1;        // (child) the view whose object matrices dObjFrame holds
+    std::vector<ChordInstanceCullingView> instanceViews;   // chordvis_set_instance_views (cascadeViewInfos)
     ChordObject* dObjectsOwned = nullptr;
     const ChordObject* dObjects = nullptr;
     std::vector<chord::DPrim> hPrims;
@@ -296,6 +304,9 @@ struct ChordCtx {
     uint32_t largeCap = 0;
     chord::DeviceCounters* dCounters = nullptr;
     bool pendingClear = false;         // the next raster pass starts every tile from zero (fused clear)
+    // depth-only pass state (renderMeshDepth, mesh_raster.cpp:159-206); set by chordvis_render_mesh_depth around its raster
+    bool depthOnly = false, depthClamp = false;
+    float depthBiasConst = 0.0f, depthBiasSlope = 0.0f;
 
     // timers: mode 0 off, 1 = last frame only, 2 = accumulate until chordvis_stats
     int timers = 0;
@@ -315,6 +326,7 @@ struct ChordCtx {
 namespace chord {
 
 int fail(ChordCtx* ctx, int code, const char* what, hipError_t e = hipSuccess);
+int alloc_scene_work_buffers(ChordCtx* c);
 
 #define CHORD_HIP(ctx, call)                                                         \
     do {                                                                             \
@@ -327,6 +339,10 @@ void launch_group_cull(ChordCtx* c, const CmdList& out);
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
                      const CmdList* outRejected);
 hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles);   // first failing HIP call, or hipSuccess
+void launch_hzb_cull_generic(ChordCtx* c, const HzbBuffers& hzb, const ChordInstanceCullingView& iv, const float rel[3], float extentScale,
+                             bool useLastFrame, const CmdList& in, const CmdList& out);
+void launch_depth_extract(ChordCtx* c, const unsigned long long* vis, float* depth, size_t words);              // high word of every visibility word
+void launch_depth_expand(ChordCtx* c, const float* depth, unsigned long long* vis, size_t words);               // and back: depth << 32
 void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange, bool fromExchange);
 void launch_hzb_mip0_exchange(ChordCtx* c);
 void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange);   // mips 6.. + range from per-tile partials

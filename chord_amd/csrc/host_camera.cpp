@@ -15,6 +15,7 @@
 #include "../../include/chordvis.h"
 
 #include <cmath>
+#include <vector>
 #include <cstring>
 
 namespace {
@@ -162,6 +163,19 @@ int chordvis_camera_fill_view(const ChordCameraDesc* cam, const ChordCameraView*
     outView->cameraFovy = cam->fovy;
     outView->zNear = (float)cam->zNear;
     outView->zFar = (float)cam->zFar;
+    {   // camera.cpp:25-31 with viewport.cpp:444: glm::perspectiveRH_ZO(fovy, aspect, zNear := zFar, zFar := zNear) -- still reverse Z
+        const float zN = (float)cam->zFar, zF = (float)cam->zNear;
+        ChordMat4 pz;
+        std::memset(&pz, 0, sizeof(pz));
+        at(pz, 0, 0) = 1.0f / (aspect * tanHalfFovy);
+        at(pz, 1, 1) = 1.0f / tanHalfFovy;
+        at(pz, 2, 2) = zF / (zN - zF);
+        at(pz, 3, 2) = -1.0f;
+        at(pz, 2, 3) = -(zF * zN) / (zF - zN);
+        const ChordMat4 vpz = matmul(pz, view);
+        if (!inverse4<float>(vpz.m, outView->clipToTranslatedWorldWithZFar_NoJitter.m))
+            std::memset(&outView->clipToTranslatedWorldWithZFar_NoJitter, 0, sizeof(ChordMat4));
+    }
     // projectSphereToScreen's view-constant factor, base.hlsli:503-518: height * 0.5 / tan(fovy / 2)
     outView->lodScale = outView->renderDimension[1] * 0.5f / std::tan(0.5f * cam->fovy);
 
@@ -248,6 +262,187 @@ int chordvis_object_basic_data_batch(uint32_t count, const double* localToWorld,
                                             prevLocalToWorld ? prevLocalToWorld + (size_t)i * 16 : nullptr,
                                             cameraPos, cameraPosLast, &objects[i].basicData);
         if (rc != CHORDVIS_OK) return rc;
+    }
+    return CHORDVIS_OK;
+}
+
+// cascadeComputeCS (cascade_setup.hlsl:79-372) on the host.  The reference runs these few hundred flops per cascade as a
+// one-group compute shader only because it reads the SDSM depth range from a GPU buffer; here the caller hands that range
+// over (or NULL: the shader's own "no valid range buffer" branch, :118).  fp32 in the shader's operation order.
+int chordvis_cascade_setup(const ChordCascadeConfig* cfg, const ChordCameraView* view, const ChordInstanceCullingView* mainInstanceView,
+                           const float lightDirIn[3], const uint32_t validDepthMinMax[2], uint32_t tickCount, int bCacheValid,
+                           ChordInstanceCullingView* views)
+{
+    if (!cfg || !view || !mainInstanceView || !lightDirIn || !views) return CHORDVIS_E_INVALID;
+    if (cfg->cascadeCount < 1 || (uint32_t)cfg->cascadeCount > CHORD_MAX_CASCADES || cfg->realtimeCascadeCount < 0 ||
+        cfg->realtimeCascadeCount > cfg->cascadeCount || cfg->cascadeDim < 64) return CHORDVIS_E_INVALID;
+    const uint32_t cascadeCount = (uint32_t)cfg->cascadeCount, realtimeCount = (uint32_t)cfg->realtimeCascadeCount;
+    const V3 upDir = {0.0f, 1.0f, 0.0f};
+    const float nearZ = view->zNear, farZ = view->zFar, clipRange = farZ - nearZ;
+    auto logCascadeSplit = [&](float farDepthPlane, float nearDepthPlane, uint32_t cascadeId, uint32_t count, float lambda) {
+        const float range = farDepthPlane - nearDepthPlane, ratio = farDepthPlane / nearDepthPlane;      // :56-74
+        const float p = (float)(cascadeId + 1) / (float)count;
+        const float logScale = nearDepthPlane * std::pow(std::fabs(ratio), p);
+        const float uniformScale = nearDepthPlane + range * p;
+        const float d = lambda * (logScale - uniformScale) + uniformScale;
+        return (d - nearZ) / clipRange;
+    };
+    auto mulPoint = [](const ChordMat4& M, float x, float y, float z, float w, float out[4]) {
+        for (int r = 0; r < 4; r++) out[r] = ((at(M, r, 0) * x + at(M, r, 1) * y) + at(M, r, 2) * z) + at(M, r, 3) * w;
+    };
+    struct Cascade { float sphereRadius, cascadeSphereRadius, sphereRadius0, minZ; V3 center; };
+    std::vector<Cascade> cs(cascadeCount);
+    // ---- per cascade up to the bounding sphere (the shader then needs WaveActiveMax over the cascades, :259)
+    for (uint32_t cascadeId = 0; cascadeId < cascadeCount; cascadeId++) {
+        float minZ, maxZ, splitLambda, splitStart;
+        uint32_t splitCascadeCount, splitCascadeId;
+        if (cascadeId < realtimeCount) {                                                                  // :108-141
+            minZ = nearZ + cfg->cascadeStartDistance; maxZ = nearZ + cfg->cascadeEndDistance;
+            splitLambda = cfg->splitLambda; splitCascadeCount = realtimeCount; splitCascadeId = cascadeId;
+            if (validDepthMinMax) {
+                float minZValid, maxZValid;
+                std::memcpy(&minZValid, &validDepthMinMax[0], 4); std::memcpy(&maxZValid, &validDepthMinMax[1], 4);
+                if (maxZValid > 0.0f) minZ = std::fmax(minZ, nearZ / maxZValid);
+                if (minZValid > 0.0f) {
+                    const float stableDistance = cfg->cascadeEndDistance - cfg->cascadeStartDistance;
+                    maxZ = std::fmax(maxZ, minZ * 1.1f);
+                    maxZ = std::fmin(maxZ, minZ + stableDistance);
+                    maxZ = std::fmin(maxZ, nearZ / minZValid);
+                }
+            }
+            splitStart = minZ - nearZ;
+        } else {                                                                                          // :142-153
+            maxZ = nearZ + cfg->farCascadeEndDistance; splitLambda = cfg->farCascadeSplitLambda;
+            minZ = nearZ + cfg->cascadeEndDistance; splitStart = cfg->cascadeEndDistance;
+            splitCascadeCount = cascadeCount - realtimeCount; splitCascadeId = cascadeId - realtimeCount;
+        }
+        const float splitDist = logCascadeSplit(maxZ, minZ, splitCascadeId, splitCascadeCount, splitLambda);
+        const float prevSplitDist = splitCascadeId == 0 ? splitStart / clipRange
+                                                        : logCascadeSplit(maxZ, minZ, splitCascadeId - 1, splitCascadeCount, splitLambda);
+        const float splitDist_0 = logCascadeSplit(nearZ, nearZ + cfg->farCascadeEndDistance, 0, cascadeCount, cfg->farCascadeSplitLambda);   // :163 (argument order as written there)
+        const float prevSplitDist_0 = 0.0f;
+        V3 corner[8], corner0[8];
+        static const float kNdc[8][3] = {{-1, 1, 1}, {1, 1, 1}, {1, -1, 1}, {-1, -1, 1}, {-1, 1, 0}, {1, 1, 0}, {1, -1, 0}, {-1, -1, 0}};
+        for (int i = 0; i < 8; i++) {
+            float h[4];
+            mulPoint(view->clipToTranslatedWorldWithZFar_NoJitter, kNdc[i][0], kNdc[i][1], kNdc[i][2], 1.0f, h);
+            corner[i] = {h[0] / h[3], h[1] / h[3], h[2] / h[3]};
+        }
+        for (int i = 0; i < 4; i++) {                                                                     // :181-191
+            const V3 ray = sub(corner[i + 4], corner[i]);
+            corner0[i + 4] = add(corner[i], mul(ray, splitDist_0));
+            corner0[i] = add(corner[i], mul(ray, prevSplitDist_0));
+        }
+        for (int i = 0; i < 4; i++) {                                                                     // :194-203
+            const V3 ray = sub(corner[i + 4], corner[i]);
+            const V3 nearRay = mul(ray, prevSplitDist), farRay = mul(ray, splitDist);
+            corner[i + 4] = add(corner[i], farRay);
+            corner[i] = add(corner[i], nearRay);
+        }
+        V3 center = {0, 0, 0}, center0 = {0, 0, 0};
+        for (int i = 0; i < 8; i++) { center = add(center, corner[i]); center0 = add(center0, corner0[i]); }
+        center = {center.x / 8.0f, center.y / 8.0f, center.z / 8.0f};
+        center0 = {center0.x / 8.0f, center0.y / 8.0f, center0.z / 8.0f};
+        float sphereRadius = 0.0f, sphereRadius0 = 0.0f;
+        for (int i = 0; i < 8; i++) {
+            const V3 d = sub(corner[i], center), d0 = sub(corner0[i], center0);
+            sphereRadius = std::fmax(sphereRadius, std::sqrt(dot(d, d)));
+            sphereRadius0 = std::fmax(sphereRadius0, std::sqrt(dot(d0, d0)));
+        }
+        cs[cascadeId] = {sphereRadius, std::ceil(sphereRadius * 16.0f) / 16.0f, sphereRadius0, minZ, center};
+    }
+    float maxCascadeSphereRadius = 0.0f;                                                                  // WaveActiveMax, :259
+    for (const Cascade& c : cs) maxCascadeSphereRadius = std::fmax(maxCascadeSphereRadius, c.cascadeSphereRadius);
+    // ---- view, projection, texel snapping, planes
+    for (uint32_t cascadeId = 0; cascadeId < cascadeCount; cascadeId++) {
+        const Cascade& c = cs[cascadeId];
+        const float maxE = c.cascadeSphereRadius, minE = -maxE;
+        const float extentZ = maxCascadeSphereRadius * 2.0f;                                               // :267
+        float radiusScale, zStartBiasScale;
+        if (cascadeId >= realtimeCount) { radiusScale = c.sphereRadius0 / c.sphereRadius; zStartBiasScale = 1.0f; }
+        else {
+            radiusScale = 10.0f * cfg->radiusScaleFixed / c.sphereRadius;
+            radiusScale = radiusScale / (radiusScale + 1.0f);
+            const float startDistanceFactor = (c.minZ - nearZ) / (cfg->cascadeEndDistance - cfg->cascadeStartDistance);
+            zStartBiasScale = 0.25f + startDistanceFactor;
+        }
+        radiusScale = std::fmin(radiusScale, 1.0f);
+        const V3 lightDir = normalize(V3{lightDirIn[0], lightDirIn[1], lightDirIn[2]});
+        const V3 shadowCameraPos = sub(c.center, mul(mul(lightDir, extentZ), 0.5f));                       // :294
+        const float nearZProj = 0.0f, farZProj = extentZ;
+        // lookAt_RH(eye, center, up), base.hlsli:637-666
+        const V3 f = normalize(sub(c.center, shadowCameraPos));
+        const V3 sv = normalize(cross(f, upDir));
+        const V3 u = cross(sv, f);
+        ChordMat4 shadowView;
+        std::memset(&shadowView, 0, sizeof(shadowView));
+        at(shadowView, 0, 0) = sv.x; at(shadowView, 0, 1) = sv.y; at(shadowView, 0, 2) = sv.z; at(shadowView, 0, 3) = -dot(sv, shadowCameraPos);
+        at(shadowView, 1, 0) = u.x;  at(shadowView, 1, 1) = u.y;  at(shadowView, 1, 2) = u.z;  at(shadowView, 1, 3) = -dot(u, shadowCameraPos);
+        at(shadowView, 2, 0) = -f.x; at(shadowView, 2, 1) = -f.y; at(shadowView, 2, 2) = -f.z; at(shadowView, 2, 3) = dot(f, shadowCameraPos);
+        at(shadowView, 3, 3) = 1.0f;
+        // ortho_RH_ZeroOne(left, right, bottom, top, zNear := farZProj, zFar := nearZProj), base.hlsli:668-682 (reverse Z)
+        ChordMat4 shadowProj;
+        std::memset(&shadowProj, 0, sizeof(shadowProj));
+        {
+            const float left = minE, right = maxE, bottom = minE, top = maxE, zn = farZProj, zf = nearZProj;
+            at(shadowProj, 0, 0) = 2.0f / (right - left);
+            at(shadowProj, 1, 1) = 2.0f / (top - bottom);
+            at(shadowProj, 2, 2) = -1.0f / (zf - zn);
+            at(shadowProj, 0, 3) = -(right + left) / (right - left);
+            at(shadowProj, 1, 3) = -(top + bottom) / (top - bottom);
+            at(shadowProj, 2, 3) = -zn / (zf - zn);
+            at(shadowProj, 3, 3) = 1.0f;
+        }
+        // texel alignment, :312-326
+        const float sMapSize = (float)cfg->cascadeDim;
+        const ChordMat4 vp0 = matmul(shadowProj, shadowView);
+        float origin[4];
+        mulPoint(vp0, 0.0f, 0.0f, 0.0f, 1.0f, origin);
+        for (int i = 0; i < 4; i++) origin[i] *= (sMapSize / 2.0f);
+        const float roX = (std::nearbyint(origin[0]) - origin[0]) * (2.0f / sMapSize);                     // round(): half to even
+        const float roY = (std::nearbyint(origin[1]) - origin[1]) * (2.0f / sMapSize);
+        at(shadowProj, 0, 3) += roX;
+        at(shadowProj, 1, 3) += roY;
+        const ChordMat4 finalVP = matmul(shadowProj, shadowView);
+        ChordMat4 reverseToWorld;
+        if (!inverse4<float>(finalVP.m, reverseToWorld.m)) return CHORDVIS_E_INVALID;                      // (matrixInverse, base.hlsli:684-730: the same cofactor expansion)
+        V3 p[8];
+        for (int i = 0; i < 8; i++) {
+            static const float kNdc[8][3] = {{-1, 1, 1}, {1, 1, 1}, {1, -1, 1}, {-1, -1, 1}, {-1, 1, 0}, {1, 1, 0}, {1, -1, 0}, {-1, -1, 0}};
+            float h[4];
+            mulPoint(reverseToWorld, kNdc[i][0], kNdc[i][1], kNdc[i][2], 1.0f, h);
+            p[i] = {h[0] / h[3], h[1] / h[3], h[2] / h[3]};
+        }
+        float planes[6][4];
+        auto plane = [&](int i, V3 a, V3 b, V3 o) {                                                        // normalize(cross(a - o, b - o)), -dot(n, o)
+            const V3 n = normalize(cross(sub(a, o), sub(b, o)));
+            planes[i][0] = n.x; planes[i][1] = n.y; planes[i][2] = n.z; planes[i][3] = -dot(n, o);
+            return n;
+        };
+        plane(0, p[4], p[3], p[7]);                                                                        // left   :345-346
+        plane(1, p[6], p[3], p[2]);                                                                        // down
+        plane(2, p[6], p[1], p[5]);                                                                        // right
+        plane(3, p[5], p[0], p[4]);                                                                        // top
+        const V3 frontN = plane(4, p[1], p[3], p[0]);                                                      // front
+        plane(5, p[5], p[7], p[6]);                                                                        // back
+        planes[5][3] = -dot(frontN, p[6]);                                                                 // :365 uses frontN for the back plane's distance
+        // isCascadeCacheValid, :8-22
+        bool keep = false;
+        if (bCacheValid && cascadeId >= realtimeCount) {
+            const uint32_t period = cascadeCount - realtimeCount;
+            keep = (tickCount % period) != (cascadeId - realtimeCount);
+        }
+        if (keep) continue;                                                                                // "Don't override view info."
+        ChordInstanceCullingView& vi = views[cascadeId];
+        std::memset(&vi, 0, sizeof(vi));
+        vi.translatedWorldToClip = finalVP;
+        vi.clipToTranslatedWorld = reverseToWorld;
+        std::memcpy(vi.cameraWorldPos, mainInstanceView->cameraWorldPos, sizeof(vi.cameraWorldPos));
+        vi.orthoDepthConvertToView[0] = at(shadowProj, 2, 2); vi.orthoDepthConvertToView[1] = at(shadowProj, 2, 3);
+        vi.orthoDepthConvertToView[2] = zStartBiasScale; vi.orthoDepthConvertToView[3] = radiusScale;
+        vi.renderDimension[0] = (float)cfg->cascadeDim; vi.renderDimension[1] = (float)cfg->cascadeDim;
+        vi.renderDimension[2] = 1.0f / (float)cfg->cascadeDim; vi.renderDimension[3] = 1.0f / (float)cfg->cascadeDim;
+        std::memcpy(vi.frustumPlanesRS, planes, sizeof(planes));
     }
     return CHORDVIS_OK;
 }

@@ -274,89 +274,112 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
 
 // ---- hierarchical cull (chordvis_set_cull_mode 1) ---------------------------------------------------------------------
 // Resident waves walk the GPUBVHNode trees (gltf.h:16-24) the reference builds and never reads: one wave per visible
-// object at a time (grid stride over the objects), a small stack in LDS, the up to eight children of a node and the
-// groups of its leaf range handled by the wave's lanes.  A node's sphere bounds the parent-error spheres of every group
-// in its subtree (checked at upload), and the projected error of a sphere is monotone in containment, so when the
-// NODE's sphere already projects to at most (1 - 1/64) px with the eye outside it, every group beneath fails the "parent
-// is too coarse" half of isMeshletGroupVisibile (nanite_shared.hlsli:15-49) -- the 1/64 px margin is far above what the
-// fp32 evaluation of either side can differ by -- and the subtree is dropped.  Surviving groups run exactly the flat
-// test and record their meshlet mask; group_cull_count_kernel<true> / the scatter then build the same command array
-// the flat dispatch builds.  (The root's own leaves are the un-parented groups: always tested.)
+// object at a time (grid stride over the objects), LEVEL by level -- the nodes are stored breadth first, so a level is a
+// contiguous range (its end is kept in every node at upload) -- with one node per lane and the set of live nodes as a
+// bitmap in LDS.  A node's sphere bounds the parent-error spheres of every group in its subtree (checked at upload),
+// and the projected error of a sphere is monotone in containment, so when the NODE's sphere already projects to at most
+// (1 - 1/64) px with the eye outside it, every group beneath fails the "parent is too coarse" half of
+// isMeshletGroupVisibile (nanite_shared.hlsli:15-49) -- the 1/64 px margin is far above what the fp32 evaluation of
+// either side can differ by -- and its children are never marked live.  The groups of a surviving node run exactly the
+// flat test and record their meshlet mask; group_cull_count_kernel<true> / the scatter then build the same command
+// array the flat dispatch builds.  The root's own leaves are the un-parented groups (and the parented ones of a
+// primitive too small to split): always tested, spread over the wave's lanes.
+// (First version: one node per step from a stack -- a 585-node tree cost its wave 2.8 ms of dependent round trips.)
 struct BvhCullParams {
     GroupCullParams g;
     const DBVHNode* nodes;
     uint32_t objectCount;
 };
-#define BVH_STACK 128
+#define BVH_LIVE_WORDS 256u                 // nodes beyond 8192 of one tree are simply treated as live (their groups are tested)
 #define BVH_NODE_MARGIN (1.0f - 1.0f / 64.0f)
+
+__device__ __forceinline__ uint32_t bvh_group_mask(const GroupCullParams& p, const DView& dv, const DObjFrame& of, const Mat4& M, bool twoSided,
+                                                   const DPrim& prim, uint32_t gl)
+{
+    const DGroup g = p.groups[prim.groupBase + gl];
+    uint32_t mask = 0;
+    if (group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {
+        const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
+        for (uint32_t i = 0; i < g.meshletCount && i < CHORD_GROUP_MAX_MESHLETS; i++) {
+            const uint32_t mi = prim.meshletBase + p.groupIndices[idxBase + i];
+            if (meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, twoSided, p.meshlets[mi])) mask |= 1u << i;
+        }
+    }
+    return mask;
+}
 
 __global__ __launch_bounds__(256) void bvh_cull_kernel(BvhCullParams bp, const DView dv)
 {
-    __shared__ uint32_t sStack[4][BVH_STACK];
+    __shared__ uint32_t sLive[4][BVH_LIVE_WORDS];
     const GroupCullParams& p = bp.g;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* stack = sStack[wave];
+    uint32_t* live = sLive[wave];
     const uint32_t waves = gridDim.x * 4u;
-    for (uint32_t o = blockIdx.x * 4u + wave; o < bp.objectCount; o += waves) {
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    // work unit = (object, part): part 0 is the root's own leaf groups, parts 1..8 the subtrees of the root's children --
+    // a big primitive's tree (the street's ground: 585 nodes, 4 k groups) is shared by nine waves instead of one
+    for (uint32_t unit = blockIdx.x * 4u + wave; unit < bp.objectCount * 9u; unit += waves) {
+        const uint32_t o = unit / 9u, part = unit - o * 9u;
         const DObjFrame& of = p.objFrame[o];
         if (!__builtin_amdgcn_readfirstlane(of.visible)) continue;
         const DObjStatic st = p.objStatic[o];
         const DPrim& prim = p.prims[st.prim];
-        const uint32_t nodeBase = __builtin_amdgcn_readfirstlane(prim.bvhBase);
+        const DBVHNode* __restrict__ nodes = bp.nodes + __builtin_amdgcn_readfirstlane(prim.bvhBase);
         const Mat4 M = load_mat(p.objects[o].basicData.localToTranslatedWorld);
         const bool twoSided = (st.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0;
-        uint32_t sp = 1;
-        if (lane == 0) stack[0] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        while (sp > 0) {
-            const uint32_t n = __builtin_amdgcn_readfirstlane(stack[sp - 1u]);
-            sp--;
-            const DBVHNode& nd = bp.nodes[nodeBase + n];
-            bool dropped = false;
-            if (n != 0u) {
-                const float pe = projected_error_px(dv.view.lodScale, of.localToView, of.maxScale, nd.sphere, nd.sphere[3]);
-                dropped = pe > 0.0f && pe <= BVH_NODE_MARGIN;
-            } else if (nd.sphere[3] > 0.0f) {
-                // the root's sphere bounds every parented group of the primitive: when it is small on screen only the
-                // root's own leaves (un-parented groups, and parented ones of a primitive too small to split) remain
-                const float pe = projected_error_px(dv.view.lodScale, of.localToView, of.maxScale, nd.sphere, nd.sphere[3]);
-                if (pe > 0.0f && pe <= BVH_NODE_MARGIN) {
-                    // children dropped; the leaves are still walked below (their own tests decide)
-                    dropped = true;
-                }
+        const uint32_t N = __builtin_amdgcn_readfirstlane(nodes[0].bvhNodeCount);
+        if (part == 0u) {
+            // the root's own leaves are always tested (its sphere only decides for its children)
+            const uint32_t leafOff = nodes[0].leafGroupOffset, leafCnt = nodes[0].leafGroupCount;
+            for (uint32_t gi = lane; gi < leafCnt; gi += 64u) {
+                const uint32_t mask = bvh_group_mask(p, dv, of, M, twoSided, prim, leafOff + gi);
+                if (mask) p.groupMask[st.groupBase + leafOff + gi] = (uint8_t)mask;   // (the array was zeroed by the frame's first kernel)
             }
-            const uint32_t leafOff = __builtin_amdgcn_readfirstlane(nd.leafGroupOffset), leafCnt = __builtin_amdgcn_readfirstlane(nd.leafGroupCount);
-            if (!dropped || n == 0u) {
-                for (uint32_t gb = 0; gb < leafCnt; gb += 64u) {
-                    const uint32_t gi = gb + lane;
-                    if (gi < leafCnt) {
-                        const uint32_t gl = leafOff + gi;                      // group index inside the primitive
-                        const DGroup g = p.groups[prim.groupBase + gl];
-                        uint32_t mask = 0;
-                        if (group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {
-                            const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
-                            for (uint32_t i = 0; i < g.meshletCount && i < CHORD_GROUP_MAX_MESHLETS; i++) {
-                                const uint32_t mi = prim.meshletBase + p.groupIndices[idxBase + i];
-                                if (meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, twoSided, p.meshlets[mi])) mask |= 1u << i;
-                            }
-                        }
-                        if (mask) p.groupMask[st.groupBase + gl] = (uint8_t)mask;   // (the array was zeroed by the frame's first kernel)
-                    }
-                }
-            }
-            if (!dropped) {
-                const uint32_t child = lane < CHORD_BVH_WIDTH ? nd.children[lane] : CHORD_BVH_NO_CHILD;
-                const unsigned long long has = __ballot(child != CHORD_BVH_NO_CHILD);
-                const uint32_t cnt = (uint32_t)__popcll(has);
-                if (sp + cnt <= BVH_STACK) {
-                    if (child != CHORD_BVH_NO_CHILD) stack[sp + (uint32_t)__popcll(has & ((1ull << lane) - 1ull))] = child;
-                    sp += cnt;
-                }
-                // (a full stack cannot happen: 14 levels x 7 pending siblings < 128; upload_scene bounds the depth)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            continue;
+        }
+        const uint32_t top = __builtin_amdgcn_readfirstlane(nodes[0].children[part - 1u]);
+        if (top == CHORD_BVH_NO_CHILD) continue;
+        {
+            const float r = nodes[0].sphere[3];
+            if (r > 0.0f) {
+                const float pe = projected_error_px(dv.view.lodScale, of.localToView, of.maxScale, nodes[0].sphere, r);
+                if (pe > 0.0f && pe <= BVH_NODE_MARGIN) continue;             // every parented group of the primitive is below the threshold
             }
         }
+        for (uint32_t w = lane; w < min((N + 31u) >> 5, BVH_LIVE_WORDS); w += 64u) live[w] = 0u;
+        WAVE_SYNC();
+        if (lane == 0u && (top >> 5) < BVH_LIVE_WORDS) live[top >> 5] = 1u << (top & 31u);
+        WAVE_SYNC();
+        // ---- level by level: whole levels are scanned, only this subtree's nodes are live
+        uint32_t ls = 1u;
+        while (ls < N) {
+            const uint32_t le = min(__builtin_amdgcn_readfirstlane(nodes[ls].pad), N);     // one past the last node of this level
+            bool anyChild = false;
+            for (uint32_t base = ls; base < le; base += 64u) {
+                const uint32_t n = base + lane;
+                bool alive = n < le;
+                if (alive && (n >> 5) < BVH_LIVE_WORDS) alive = (live[n >> 5] >> (n & 31u)) & 1u;
+                if (!alive) continue;
+                const DBVHNode& nd = nodes[n];
+                const float pe = projected_error_px(dv.view.lodScale, of.localToView, of.maxScale, nd.sphere, nd.sphere[3]);
+                if (pe > 0.0f && pe <= BVH_NODE_MARGIN) continue;                          // the whole subtree is below the threshold
+#pragma unroll
+                for (uint32_t k = 0; k < CHORD_BVH_WIDTH; k++) {
+                    const uint32_t ch = nd.children[k];
+                    if (ch != CHORD_BVH_NO_CHILD) { anyChild = true; if ((ch >> 5) < BVH_LIVE_WORDS) atomicOr(&live[ch >> 5], 1u << (ch & 31u)); }
+                }
+                const uint32_t leafOff = nd.leafGroupOffset, leafCnt = nd.leafGroupCount;  // (fewer than 8 below the root)
+                for (uint32_t gi = 0; gi < leafCnt; gi++) {
+                    const uint32_t mask = bvh_group_mask(p, dv, of, M, twoSided, prim, leafOff + gi);
+                    if (mask) p.groupMask[st.groupBase + leafOff + gi] = (uint8_t)mask;
+                }
+            }
+            WAVE_SYNC();
+            if (__ballot(anyChild) == 0ull) break;
+            ls = le;
+        }
     }
+#undef WAVE_SYNC
 }
 
 // Long scenes (thousands of count blocks): one workgroup turns the per-block counts into exclusive offsets, so the
@@ -598,6 +621,110 @@ __global__ __launch_bounds__(256) void hzb_cull_kernel(HzbCullParams p)
     }
 }
 
+// ---- one-pass occlusion cull of a (shadow) view -- hzb_culling_generic.hlsl:37-172 --------------------------------------
+// Differences from the main-view test: the view is an InstanceCullingViewInfo handed in with the call (instanceViewId /
+// instanceViewOffset), the object matrix is moved by the distance between the main camera and the view's camera (:78-81),
+// a cluster is only tested when every projected corner lies strictly inside the view volume (:95), the pixel rectangle is
+// widened by extentScale (:103), 2 x 2 taps one level lower (:120-144), and there is one output list.  Same block-wide
+// reservation as hzb_cull_kernel.
+struct HzbCullGenericParams {
+    const ChordObject* objects; const DMeshlet* meshlets;
+    ChordInstanceCullingView iv;
+    float rel[3]; float extentScale; uint32_t flags; uint32_t useLastFrame;
+    const uint16_t* hzbMin; ChordHZBDesc desc;
+    const uint32_t* inCount; const ChordDrawCmd* inCmds;
+    uint32_t* outCount; ChordDrawCmd* outCmds;
+};
+
+__global__ __launch_bounds__(256) void hzb_cull_generic_kernel(HzbCullGenericParams p)
+{
+    __shared__ uint32_t sWave[4], sBase;
+    const uint32_t count = *p.inCount;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+        const uint32_t i = base + threadIdx.x;
+        ChordDrawCmd cmd = ChordDrawCmd{0, 0, 0};
+        bool visible = false;
+        if (i < count) {
+            cmd = p.inCmds[i];
+            visible = true;
+            if (p.flags & CHORD_FLAG_HZB_CULL) {
+                const DMeshlet& m = p.meshlets[cmd.meshletId];
+                f3 c, e;
+                aabb_center_extent(m.posMin, m.posMax, c, e);
+                const ChordObject& obj = p.objects[cmd.objectId];
+                Mat4 l2w = load_mat(p.useLastFrame ? obj.basicData.localToTranslatedWorldLastFrame : obj.basicData.localToTranslatedWorld);
+                l2w.r[0][3] += p.rel[0]; l2w.r[1][3] += p.rel[1]; l2w.r[2][3] += p.rel[2];
+                const Mat4 mvp = mul_mm(load_mat(p.iv.translatedWorldToClip), l2w);
+                f3 mx = {-10.0f, -10.0f, -10.0f}, mn = {10.0f, 10.0f, 10.0f};
+                bool can = true;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const f3 uvz = project_pos_to_uvz(extent_corner(c, e, k), mvp);
+                    mn.x = fminf(mn.x, uvz.x); mn.y = fminf(mn.y, uvz.y); mn.z = fminf(mn.z, uvz.z);
+                    mx.x = fmaxf(mx.x, uvz.x); mx.y = fmaxf(mx.y, uvz.y); mx.z = fmaxf(mx.z, uvz.z);
+                    can = can && (uvz.x < 1.0f && uvz.y < 1.0f && uvz.z < 1.0f) && (uvz.x > 0.0f && uvz.y > 0.0f && uvz.z > 0.0f);
+                }
+                if (can) {
+                    const float W = p.iv.renderDimension[0], H = p.iv.renderDimension[1];
+                    int rx = (int)(mn.x * W + p.extentScale * -0.5f);
+                    int ry = (int)(mn.y * H + p.extentScale * -0.5f);
+                    int rz = (int)(mx.x * W + p.extentScale * 0.5f);
+                    int rw = (int)(mx.y * H + p.extentScale * 0.5f);
+                    rx = max(0, rx); ry = max(0, ry);
+                    rz = (int)fminf(W - 1.0f, (float)rz);
+                    rw = (int)fminf(H - 1.0f, (float)rw);
+                    if (rz < rx || rw < ry) visible = false;
+                    else {
+                        const int mx0 = rx >> 1, my0 = ry >> 1, mz0 = rz >> 1, mw0 = rw >> 1;
+                        int lv = max(0, max(first_bit_high(mz0 - mx0), first_bit_high(mw0 - my0)));
+                        if (((mz0 >> lv) - (mx0 >> lv) >= 2) || ((mw0 >> lv) - (my0 >> lv) >= 2)) lv += 1;
+                        lv = min(lv, (int)p.desc.mipCount - 1);
+                        const int cx = mx0 >> lv, cy = my0 >> lv, cz = mz0 >> lv, cw = mw0 >> lv;
+                        const uint32_t mw = max(1u, p.desc.width >> lv);
+                        const uint16_t* mip = p.hzbMin + p.desc.mipOffset[lv];
+                        float zMin = 10.0f;
+#pragma unroll
+                        for (int x = 0; x < 2; x++)
+#pragma unroll
+                            for (int y = 0; y < 2; y++) {
+                                const int sx = min(cz, cx + x), sy = min(cw, cy + y);
+                                zMin = fminf(zMin, f16_to_f32(mip[(uint32_t)sy * mw + (uint32_t)sx]));
+                            }
+                        if (zMin > mx.z) visible = false;
+                    }
+                }
+            }
+        }
+        const uint32_t mine = visible ? 1u : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t nb = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += nb; }
+        if (lane == 63u) sWave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; w++) { const uint32_t cc = sWave[w]; if (w < wave) before += cc; all += cc; }
+        if (threadIdx.x == 0) sBase = all ? atomicAdd(p.outCount, all) : 0u;
+        __syncthreads();
+        if (visible) p.outCmds[sBase + before + incl - mine] = cmd;
+        __syncthreads();
+    }
+}
+
+void launch_hzb_cull_generic(ChordCtx* c, const HzbBuffers& hzb, const ChordInstanceCullingView& iv, const float rel[3], float extentScale,
+                             bool useLastFrame, const CmdList& in, const CmdList& out)
+{
+    HzbCullGenericParams p;
+    p.objects = c->dObjects; p.meshlets = c->dMeshlets; p.iv = iv;
+    p.rel[0] = rel[0]; p.rel[1] = rel[1]; p.rel[2] = rel[2]; p.extentScale = extentScale; p.flags = c->hView.flags; p.useLastFrame = useLastFrame ? 1u : 0u;
+    p.hzbMin = hzb.minTexels; p.desc = hzb.desc;
+    p.inCount = in.count; p.inCmds = in.cmds; p.outCount = out.count; p.outCmds = out.cmds;
+    uint32_t blocks = (in.capacity + 255u) / 256u;
+    blocks = std::max(1u, std::min(blocks, (uint32_t)c->numCUs * 8u));
+    hipLaunchKernelGGL(hzb_cull_generic_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+}
+
 // ---------------------------------------------------------------------------------- launchers --
 
 static HzbCullParams make_hzb_cull_params(ChordCtx* c, const HzbBuffers& hzb, const CmdList& in, const CmdList& outVisible, const CmdList* outRejected)
@@ -647,7 +774,7 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
         if (hier) {
             BvhCullParams bp;
             bp.g = p; bp.nodes = c->dBvhNodes; bp.objectCount = c->objectCount;
-            const uint32_t bb = std::min((c->objectCount + 3u) / 4u, (uint32_t)c->numCUs * 8u);
+            const uint32_t bb = std::min((c->objectCount * 9u + 3u) / 4u, (uint32_t)c->numCUs * 8u);
             hipLaunchKernelGGL(bvh_cull_kernel, dim3(std::max(bb, 1u)), dim3(256), 0, c->stream, bp, c->hView);
             hipLaunchKernelGGL(group_cull_count_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p, c->hView, (DView*)nullptr,
                                (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);

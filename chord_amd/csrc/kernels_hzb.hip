@@ -19,6 +19,8 @@
 
 #include "hzb_device.h"
 
+#include <algorithm>
+
 namespace chord {
 
 __device__ __forceinline__ size_t vis_row_base(const ShardInfo& s, bool sharded, uint32_t y, uint32_t W)
@@ -242,6 +244,27 @@ void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange)
     if (p.desc.mipCount > (uint32_t)CHORD_TILE_SHIFT || bValidRange)
         hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, bMax ? 1 : 0, bValidRange ? 1 : 0, (uint32_t)CHORD_TILE_SHIFT);
     out.valid = true;
+}
+
+__global__ __launch_bounds__(256) void depth_extract_kernel(const unsigned long long* __restrict__ vis, float* __restrict__ depth, size_t words)
+{
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < words; i += (size_t)gridDim.x * 256u)
+        depth[i] = __uint_as_float((uint32_t)(vis[i] >> 32));
+}
+__global__ __launch_bounds__(256) void depth_expand_kernel(const float* __restrict__ depth, unsigned long long* __restrict__ vis, size_t words)
+{
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < words; i += (size_t)gridDim.x * 256u)
+        vis[i] = (unsigned long long)__float_as_uint(depth[i]) << 32;
+}
+void launch_depth_extract(ChordCtx* c, const unsigned long long* vis, float* depth, size_t words)
+{
+    const uint32_t blocks = (uint32_t)std::min<size_t>((words + 255u) / 256u, (size_t)c->numCUs * 16u);
+    hipLaunchKernelGGL(depth_extract_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, c->stream, vis, depth, words);
+}
+void launch_depth_expand(ChordCtx* c, const float* depth, unsigned long long* vis, size_t words)
+{
+    const uint32_t blocks = (uint32_t)std::min<size_t>((words + 255u) / 256u, (size_t)c->numCUs * 16u);
+    hipLaunchKernelGGL(depth_expand_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, c->stream, depth, vis, words);
 }
 
 void launch_detile(ChordCtx* c)

@@ -74,6 +74,8 @@ struct RasterParams {
     uint32_t* tileRange;                                // per tile {min bits, max bits} of valid depth
     unsigned long long* tileClocks;                     // debug: per-tile elapsed wall clock ticks (DBG_TILE_CLOCKS)
     unsigned long long* tilePhase;                      // debug: 8 phase accumulators per tile
+    uint32_t depthOnly, depthClamp;                     // PASS_TYPE_DEPTH (renderMeshDepth, mesh_raster.cpp:159-206): cull NONE, no id; depth clamp: near / far do not clip
+    float biasConst, biasSlope;                         // vkCmdSetDepthBias(const, 0, slope), applied to the vertex depths of a depth-pass triangle
     uint32_t clearTiles;                                // first raster pass of a frame: tiles start from 0
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
@@ -122,6 +124,13 @@ __device__ __forceinline__ bool owns_any_row(const ShardInfo& s, int32_t y0, int
     const uint32_t o0 = shard_owner_of_stripe(s, s0);
     const uint32_t ahead = s.rank >= o0 ? s.rank - o0 : s.rank + s.ranks - o0;
     return s0 + ahead <= s1;
+}
+
+// depth clamp (shadow views): the near / far planes do not clip
+__device__ __forceinline__ bool in_fast_volume_xy(const f4& h)
+{
+    return h.w > 0.0f && (GUARD_BAND * h.w + h.x) >= 0.0f && (GUARD_BAND * h.w - h.x) >= 0.0f &&
+           (GUARD_BAND * h.w + h.y) >= 0.0f && (GUARD_BAND * h.w - h.y) >= 0.0f;
 }
 
 __device__ __forceinline__ bool in_fast_volume(const f4& h)
@@ -184,6 +193,23 @@ __device__ __forceinline__ bool tri_setup(TriSetup& ts, bool twoSided, int32_t W
     if (ts.px1 < ts.px0 || ts.py1 < ts.py0) return false;
     ts.invA = 1.0f / (float)(double)ts.area;
     return true;
+}
+
+// Depth bias of a depth-pass triangle (oracle.c header item 10): o = slope * max(|dz/dx|, |dz/dy|) + const * 2^(exponent(max |d|) - 23)
+__device__ __forceinline__ float depth_bias(const TriSetup& ts, const float d[3], float biasConst, float biasSlope)
+{
+    const int64_t s = ts.s;
+    const float invA = ts.invA;
+    const int64_t a1 = -s * (int64_t)(ts.Y[0] - ts.Y[2]), b1 = s * (int64_t)(ts.X[0] - ts.X[2]);
+    const int64_t a2 = -s * (int64_t)(ts.Y[1] - ts.Y[0]), b2 = s * (int64_t)(ts.X[1] - ts.X[0]);
+    const float e1 = d[1] - d[0], e2 = d[2] - d[0];
+    const float dzdx = ((float)(double)(a1 * 256) * invA) * e1 + ((float)(double)(a2 * 256) * invA) * e2;
+    const float dzdy = ((float)(double)(b1 * 256) * invA) * e1 + ((float)(double)(b2 * 256) * invA) * e2;
+    const float m = fmaxf(fabsf(dzdx), fabsf(dzdy));
+    const float mz = fmaxf(fabsf(d[0]), fmaxf(fabsf(d[1]), fabsf(d[2])));
+    const int32_t e = (int32_t)((__float_as_uint(mz) >> 23) & 0xFFu) - 23;
+    const float r = (e > 0 && e < 255) ? __uint_as_float((uint32_t)e << 23) : 0.0f;
+    return biasSlope * m + biasConst * r;
 }
 
 // Setup of a record that raster_setup_kernel / raster_clip_kernel already validated: bbox + stored sign / invA.
@@ -560,7 +586,7 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
     for (; c < count; c += stride) {
         const uint32_t cu = __builtin_amdgcn_readfirstlane(c);
         const uint32_t slot = hdr.slot, V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
-        const bool twoSided = hdr.twoSided;
+        const bool twoSided = hdr.twoSided || p.depthOnly != 0u;                       // depth passes: cull mode NONE (mesh_raster.cpp:188-190)
         const bool masked = MASKED && CHORD_MATFLAG_ALPHA(hdr.matFlags) == CHORD_ALPHA_MASK;      // (wave-uniform)
         const Mat4 mvp = hdr.mvp;
         const uint32_t triWord[2] = {t0, t1};
@@ -575,7 +601,7 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
             lX[i] = h.x; lY[i] = h.y; lW[i] = h.w;
             lU[i] = h.x / aw * 0.5f + 0.5f;                                      // :159-161
             lV[i] = h.y / aw * -0.5f + 0.5f;
-            const bool fast = in_fast_volume(h);
+            const bool fast = p.depthClamp ? in_fast_volume_xy(h) : in_fast_volume(h);
             lD[i] = fast ? h.z / h.w : __builtin_nanf("");
             notFast = notFast || !fast;
         };
@@ -628,14 +654,17 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
                 culled = culled || (rintf(minU * p.W) == rintf(maxU * p.W) || rintf(minV * p.H) == rintf(maxV * p.H)); // #3 :174-179
                 if (!culled) {
                     d[0] = lD[i0]; d[1] = lD[i1]; d[2] = lD[i2];
-                    ts.payload = encode_triangle_instance(t, slot);
+                    ts.payload = p.depthOnly ? 0u : encode_triangle_instance(t, slot);   // PASS_TYPE_DEPTH writes no id
                     if (!allFast && (d[0] != d[0] || d[1] != d[1] || d[2] != d[2])) {
                         kind = K_CLIP;
                     } else {
                         ts.X[0] = (int32_t)rintf((u0 * p.W) * 256.0f); ts.Y[0] = (int32_t)rintf((v0 * p.H) * 256.0f);
                         ts.X[1] = (int32_t)rintf((u1 * p.W) * 256.0f); ts.Y[1] = (int32_t)rintf((v1 * p.H) * 256.0f);
                         ts.X[2] = (int32_t)rintf((u2 * p.W) * 256.0f); ts.Y[2] = (int32_t)rintf((v2 * p.H) * 256.0f);
-                        if (tri_setup(ts, twoSided, p.Wi, p.Hi) && owns_any_row(p.shard, ts.py0, ts.py1)) kind = K_EMIT;
+                        if (tri_setup(ts, twoSided, p.Wi, p.Hi) && owns_any_row(p.shard, ts.py0, ts.py1)) {
+                            kind = K_EMIT;
+                            if (p.biasConst != 0.0f || p.biasSlope != 0.0f) { const float o = depth_bias(ts, d, p.biasConst, p.biasSlope); d[0] += o; d[1] += o; d[2] += o; }
+                        }
                     }
                 }
             }
@@ -801,7 +830,7 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
         const DMeshlet& m = p.meshlets[cmd.meshletId];
         const uint32_t V = m.vertexTriangleCount & 0xFFu;
         const uint32_t matFlags = p.objStatic[cmd.objectId].matFlags;
-        const bool twoSided = (matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u;
+        const bool twoSided = (matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u || p.depthOnly != 0u;
         const bool masked = CHORD_MATFLAG_ALPHA(matFlags) == CHORD_ALPHA_MASK;
         const float* mv = p.objFrame[cmd.objectId].mvp;
         Mat4 mvp;
@@ -818,7 +847,7 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
             if (masked && p.texcoords) { pu[0][i] = p.texcoords[(size_t)vi * 2]; pv[0][i] = p.texcoords[(size_t)vi * 2 + 1]; }
         }
         int np = 3, cur = 0;
-        for (int pl = 0; pl < 6 && np >= 3; pl++) {
+        for (int pl = p.depthClamp ? 2 : 0; pl < 6 && np >= 3; pl++) {
             int m2 = 0;
             for (int i = 0; i < np; i++) {
                 const int j = (i + 1) % np;
@@ -851,15 +880,16 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
             PD[i] = h.z / h.w;
         }
         if (!ok) continue;
-        const uint32_t payload = encode_triangle_instance(ct.tri, cmd.slot);
+        const uint32_t payload = p.depthOnly ? 0u : encode_triangle_instance(ct.tri, cmd.slot);
         const uint32_t slots = masked ? 2u : 1u;
         for (int i = 1; i + 1 < np; i++) {
             TriSetup ts;
             ts.X[0] = PX[0]; ts.X[1] = PX[i]; ts.X[2] = PX[i + 1];
             ts.Y[0] = PY[0]; ts.Y[1] = PY[i]; ts.Y[2] = PY[i + 1];
-            const float d[3] = {PD[0], PD[i], PD[i + 1]};
+            float d[3] = {PD[0], PD[i], PD[i + 1]};
             ts.payload = payload;
             if (!tri_setup(ts, twoSided, p.Wi, p.Hi) || !owns_any_row(p.shard, ts.py0, ts.py1)) continue;
+            if (p.biasConst != 0.0f || p.biasSlope != 0.0f) { const float o = depth_bias(ts, d, p.biasConst, p.biasSlope); d[0] += o; d[1] += o; d[2] += o; }
             const uint32_t li = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], slots);
             if (li + slots > p.triCap) { atomicOr(&p.counters->overflow, 1u); continue; }
             const uint32_t gi = listShard * p.triCap + li;
@@ -1054,7 +1084,7 @@ __device__ __forceinline__ void lds_write(unsigned long long* tile, int32_t lx, 
 // 16x1 box in the same wave = 256 trips); flattened it pays max(area) <= TINY_AREA.
 __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
                                                    int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels,
-                                                   unsigned long long rowMask)
+                                                   unsigned long long rowMask, const bool clampZ)
 {
     const int32_t s = ts.s;
     const int32_t dx0 = ts.X[2] - ts.X[1], dy0 = ts.Y[2] - ts.Y[1];
@@ -1082,7 +1112,8 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
     for (int32_t i = 0; i < count; i++) {
         const bool inside = (E0 | E1 | E2) >= 0 && ((rowMask >> ly) & 1ull) && !noPixels;
         const float l1 = (float)(E1 - bias1) * ts.invA, l2 = (float)(E2 - bias2) * ts.invA;
-        const float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
+        float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
+        if (clampZ) z = fminf(fmaxf(z, 0.0f), 1.0f);
         atomicMax(px, inside ? (((unsigned long long)__float_as_uint(z) << 32) | payload) : 0ull);   // ds_max_u64
         col++;
         const bool wrap = col == w;
@@ -1121,7 +1152,7 @@ struct UnitParams {           // one batch entry, as the row loop wants it
 
 template <typename E_t>
 __device__ __forceinline__ void scan_row(unsigned long long* __restrict__ tileRow, const UnitParams& u, int32_t ox, int32_t py,
-                                         int32_t lx0, int32_t lx1, bool noPixels)
+                                         int32_t lx0, int32_t lx1, bool noPixels, const bool clampZ)
 {
     const E_t s = (u.skind & 1) ? (E_t)-1 : (E_t)1;
     const E_t dx0 = (E_t)(u.X[2] - u.X[1]), dy0 = (E_t)(u.Y[2] - u.Y[1]);
@@ -1160,7 +1191,8 @@ __device__ __forceinline__ void scan_row(unsigned long long* __restrict__ tileRo
                                                               : (((int64_t)E0 | (int64_t)E1 | (int64_t)E2) >= 0);
         // canonical l_i = float(E_i) * invA with E_i the unbiased integer
         const float l1 = (float)(double)(E1 - bias1) * u.invA, l2 = (float)(double)(E2 - bias2) * u.invA;
-        const float z = (u.d0 + l1 * u.e1) + l2 * u.e2;
+        float z = (u.d0 + l1 * u.e1) + l2 * u.e2;
+        if (clampZ) z = fminf(fmaxf(z, 0.0f), 1.0f);
         const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | payload;
         atomicMax(px, inside && !noPixels ? packed : 0ull);      // ds_max_u64
         E0 += st0; E1 += st1; E2 += st2; px++;
@@ -1209,7 +1241,7 @@ struct EntrySoA { uint32_t w[ENTRY_WORDS][TB]; };
 template <typename E_t>
 __device__ __forceinline__ int32_t scan_span(unsigned long long* __restrict__ tileRow, E_t E0, E_t E1, E_t E2, E_t st0, E_t st1, E_t st2,
                                           E_t bias1, E_t bias2, float d0, float e1, float e2, float invA, uint32_t payloadIn,
-                                          int32_t lx0, int32_t lx1, bool noPixels)
+                                          int32_t lx0, int32_t lx1, bool noPixels, const bool clampZ = false)
 {
     // Span of the row in steps k from lx0 (see scan_row): fp32 estimates only BOUND the loop, coverage is exact inside.
     float klo = 0.0f, khi = (float)(lx1 - lx0);
@@ -1231,7 +1263,8 @@ __device__ __forceinline__ int32_t scan_span(unsigned long long* __restrict__ ti
         const bool inside = std::is_floating_point<E_t>::value ? (E0 >= (E_t)0 && E1 >= (E_t)0 && E2 >= (E_t)0)
                                                               : (((int64_t)E0 | (int64_t)E1 | (int64_t)E2) >= 0);
         const float l1 = (float)(double)(E1 - bias1) * invA, l2 = (float)(double)(E2 - bias2) * invA;
-        const float z = (d0 + l1 * e1) + l2 * e2;
+        float z = (d0 + l1 * e1) + l2 * e2;
+        if (clampZ) z = fminf(fmaxf(z, 0.0f), 1.0f);
         const unsigned long long packed = ((unsigned long long)__float_as_uint(z) << 32) | payload;
         atomicMax(px, inside && !noPixels ? packed : 0ull);      // ds_max_u64
         E0 += st0; E1 += st1; E2 += st2; px++;
@@ -1243,7 +1276,7 @@ __device__ __forceinline__ int32_t scan_span(unsigned long long* __restrict__ ti
 __device__ __forceinline__ int32_t scan_span_i32(unsigned long long* __restrict__ tileRow, int32_t E0, int32_t E1, int32_t E2,
                                               int32_t st0, int32_t st1, int32_t st2, int32_t bias1, int32_t bias2,
                                               float d0, float e1, float e2, float invA, uint32_t payloadIn,
-                                              int32_t lx0, int32_t lx1, bool noPixels)
+                                              int32_t lx0, int32_t lx1, bool noPixels, const bool clampZ)
 {
     float klo = 0.0f, khi = (float)(lx1 - lx0);
     {
@@ -1269,8 +1302,9 @@ __device__ __forceinline__ int32_t scan_span_i32(unsigned long long* __restrict_
         const bool insideB = ((E0 + st0) | (E1 + st1) | (E2 + st2)) >= 0;
         const float l1a = (float)U1 * invA, l2a = (float)U2 * invA;   // (float)(double)E == (float)E: one rounding of an exact integer
         const float l1b = (float)(U1 + st1) * invA, l2b = (float)(U2 + st2) * invA;
-        const float za = (d0 + l1a * e1) + l2a * e2;
-        const float zb = (d0 + l1b * e1) + l2b * e2;
+        float za = (d0 + l1a * e1) + l2a * e2;
+        float zb = (d0 + l1b * e1) + l2b * e2;
+        if (clampZ) { za = fminf(fmaxf(za, 0.0f), 1.0f); zb = fminf(fmaxf(zb, 0.0f), 1.0f); }
         atomicMax(px, insideA && !noPixels ? (((unsigned long long)__float_as_uint(za) << 32) | payload) : 0ull);      // ds_max_u64
         atomicMax(px + 1, insideB && !noPixels ? (((unsigned long long)__float_as_uint(zb) << 32) | payload) : 0ull);
         E0 += 2 * st0; E1 += 2 * st1; E2 += 2 * st2; U1 += 2 * st1; U2 += 2 * st2; px += 2;
@@ -1321,7 +1355,7 @@ __device__ __forceinline__ uint32_t entry_store(EntrySoA& en, uint32_t t, const 
 // A pixel row of a masked triangle: exact int64 edges, canonical depth, and per covered pixel the perspective-correct
 // texture coordinates, one alpha fetch and the clip() of mesh_raster.hlsl:198-204.
 __device__ __forceinline__ void masked_row(const RasterParams& p, unsigned long long* __restrict__ tileRow, const UnitParams& u, uint32_t recIndex,
-                                        int32_t ox, int32_t py, int32_t lx0, int32_t lx1, bool noPixels)
+                                        int32_t ox, int32_t py, int32_t lx0, int32_t lx1, bool noPixels, const bool clampZ)
 {
     const TriRecMaskExt ext = *reinterpret_cast<const TriRecMaskExt*>(&p.tris[recIndex + 1u]);
     const DMaterial m = p.materials[ext.material];
@@ -1348,13 +1382,14 @@ __device__ __forceinline__ void masked_row(const RasterParams& p, unsigned long 
         const float tv = ((l0 * ext.vw[0] + l1 * ext.vw[1]) + l2 * ext.vw[2]) / den;
         const float alpha = sample_alpha(p.texAlpha, m, level, linear, tu, tv);
         if (alpha * m.alphaFactor - m.alphaCutOff < 0.0f) continue;                  // clip()
-        const float z = (u.d0 + l1 * u.e1) + l2 * u.e2;
+        float z = (u.d0 + l1 * u.e1) + l2 * u.e2;
+        if (clampZ) z = fminf(fmaxf(z, 0.0f), 1.0f);
         if (!noPixels) atomicMax(tileRow + lx, ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)u.payload);
     }
 }
 
 // one unit = (entry e, its j-th (row, segment))
-template <bool MASKED>
+template <bool MASKED, bool DEPTH>
 __device__ __forceinline__ int32_t entry_unit(const RasterParams& p, const EntrySoA& en, unsigned long long* tile, uint32_t e, uint32_t row, uint32_t seg,
                                            int32_t ox, int32_t oy, unsigned long long rowMask, bool noPixels)
 {
@@ -1378,16 +1413,16 @@ __device__ __forceinline__ int32_t entry_unit(const RasterParams& p, const Entry
         const int32_t E1 = (int32_t)en.w[4][e] + (__mul24(a1, lx0) + __mul24(b1, ly)) * 256;
         const int32_t E2 = (int32_t)en.w[5][e] + (__mul24(a2, lx0) + __mul24(b2, ly)) * 256;
         return scan_span_i32(tileRow, E0, E1, E2, a0 * 256, a1 * 256, a2 * 256, (box >> 26) & 1u ? -1 : 0, (box >> 27) & 1u ? -1 : 0,
-                             d0, e1, e2, invA, payload, lx0, lx1, noPixels);
+                             d0, e1, e2, invA, payload, lx0, lx1, noPixels, DEPTH);
     } else {
         UnitParams u;
         u.X[0] = (int32_t)en.w[0][e]; u.X[1] = (int32_t)en.w[1][e]; u.X[2] = (int32_t)en.w[2][e];
         u.Y[0] = (int32_t)en.w[3][e]; u.Y[1] = (int32_t)en.w[4][e]; u.Y[2] = (int32_t)en.w[5][e];
         u.d0 = d0; u.e1 = e1; u.e2 = e2; u.invA = invA; u.payload = payload; u.box = 0;
         u.skind = (int32_t)((box >> 28) & 1u) | (int32_t)(kind << 1);
-        if (kind == 1u)      scan_row<double>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
-        else if (kind == 2u) scan_row<int64_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels);
-        else if (MASKED)     masked_row(p, tileRow, u, en.w[12][e], ox, oy + ly, lx0, lx1, noPixels);
+        if (kind == 1u)      scan_row<double>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels, DEPTH);
+        else if (kind == 2u) scan_row<int64_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels, DEPTH);
+        else if (MASKED)     masked_row(p, tileRow, u, en.w[12][e], ox, oy + ly, lx0, lx1, noPixels, DEPTH);
         return lx1 - lx0 + 1;
     }
 }
@@ -1514,7 +1549,8 @@ __device__ __noinline__ bool merge_slices(unsigned long long* tile, unsigned lon
     return true;
 }
 
-template <bool SH, bool MASKED>
+// DEPTH: a depth-only pass with depth clamp (shadow views): the interpolated depth is clamped to [0, 1]
+template <bool SH, bool MASKED, bool DEPTH>
 __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
 {
     __shared__ __align__(16) unsigned long long tile[TILE * TPITCH];   // 32.5 KB
@@ -1660,7 +1696,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                     const bool narrow = narrow_extent(ts);
                     const bool maskedRec = MASKED && (name & CHORD_REC_WIDE) && (q2.z & 4u);   // a TriRecMaskExt follows the record
                     if (narrow && !maskedRec && (x1 - x0 + 1) * (y1 - y0 + 1) <= TINY_AREA) {
-                        if (!(p.debug & DBG_NO_TINY)) tile_raster_narrow(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask);
+                        if (!(p.debug & DBG_NO_TINY)) tile_raster_narrow(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask, DEPTH);
                         if (prof) { cTiny++; cTinyIters += (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1)); }
                     } else {
                         rows = entry_store(prm, threadIdx.x, ts, narrow, ox, oy, x0, y0, x1, y1, maskedRec, name & ~CHORD_REC_WIDE);   // (units, not rows)
@@ -1696,7 +1732,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
             for (uint32_t ui = threadIdx.x; ui < nr; ui += TB) {
                 const uint32_t d = unitList[ui];
                 if (p.debug & DBG_NO_UNITS) continue;
-                const int32_t trips = entry_unit<MASKED>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, rowMask, noPixels);
+                const int32_t trips = entry_unit<MASKED, DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, rowMask, noPixels);
                 if (prof) { cUnits++; cUnitIters += (uint32_t)trips; }
             }
             if (r0 + UNIT_CAP < total) __syncthreads();           // the list is rewritten by the next round
@@ -1811,6 +1847,8 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.largeList = c->dLargeList + (size_t)pass * (c->largeCap / 2); p.largeCap = c->largeCap / 2 / CHORD_LIST_SHARDS;   // per shard
     p.counters = c->dCounters;
     p.clearTiles = clearTiles ? 1u : 0u;
+    p.depthOnly = c->depthOnly ? 1u : 0u; p.depthClamp = c->depthClamp ? 1u : 0u;
+    p.biasConst = c->depthBiasConst; p.biasSlope = c->depthBiasSlope;
     p.debug = c->debugFlags;
     p.tileClocks = c->dTileClocks + (size_t)pass * CHORD_MAX_TILES;
     p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrder); p.tileSlabs = c->dTileSlabs;
@@ -1842,12 +1880,15 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // first pass of a frame: every tile is written, one block each, dispatched heaviest first; later passes touch
     // few tiles: one resident wave of blocks strides over the (device-side) active list
     const uint32_t tileBlocks = clearTiles ? tiles : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
-    if (c->anyMasked) {
-        if (sh) hipLaunchKernelGGL((raster_tile_kernel<true, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
-        else    hipLaunchKernelGGL((raster_tile_kernel<false, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+    if (c->depthClamp && !sh) {
+        if (c->anyMasked) hipLaunchKernelGGL((raster_tile_kernel<false, true, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        else              hipLaunchKernelGGL((raster_tile_kernel<false, false, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+    } else if (c->anyMasked) {
+        if (sh) hipLaunchKernelGGL((raster_tile_kernel<true, true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        else    hipLaunchKernelGGL((raster_tile_kernel<false, true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
     } else {
-        if (sh) hipLaunchKernelGGL((raster_tile_kernel<true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
-        else    hipLaunchKernelGGL((raster_tile_kernel<false, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        if (sh) hipLaunchKernelGGL((raster_tile_kernel<true, false, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        else    hipLaunchKernelGGL((raster_tile_kernel<false, false, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
     }
     stamp(c, S_R_CHUNK);
     c->rasterCalls++;

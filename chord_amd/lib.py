@@ -36,6 +36,10 @@ class ShadingTiles(C.Structure):
     _fields_ = [("tileCmd", C.c_void_p), ("count", C.c_void_p), ("dispatchIndirect", C.c_void_p), ("capacity", C.c_uint32)]
 
 
+class DepthTarget(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
 class HZB(C.Structure):
     _fields_ = [("desc", R.HZBDesc), ("minTexels", C.c_void_p), ("maxTexels", C.c_void_p), ("validRange", C.c_void_p)]
 
@@ -99,6 +103,7 @@ def _load():
         "chordvis_version": (C.c_char_p, []),
         "chordvis_hzb_desc": (i32, [u32, u32, P(R.HZBDesc)]),
         "chordvis_camera_fill_view": (i32, [P(CameraDesc), vp, vp, vp]),
+        "chordvis_cascade_setup": (i32, [vp, vp, vp, vp, vp, u32, i32, vp]),
         "chordvis_object_basic_data": (i32, [vp, vp, vp, vp, vp]),
         "chordvis_object_basic_data_batch": (i32, [u32, vp, vp, vp, vp, vp]),
         "chordvis_create": (i32, [i32, vp, P(vp)]),
@@ -159,6 +164,14 @@ def _load():
         "chordvis_group_set_view": (i32, [vp, vp, vp, u32]),
         "chordvis_group_render_frame": (i32, [vp]),
         "chordvis_group_sync": (i32, [vp]),
+        "chordvis_allocate_depth_views": (i32, [vp, u32, u32]),
+        "chordvis_set_instance_views": (i32, [vp, vp, u32]),
+        "chordvis_instance_culling_view": (i32, [vp, u32, P(CountAndCmd)]),
+        "chordvis_hzb_culling_generic": (i32, [vp, P(HZB), C.c_float, u32, i32, CountAndCmd, P(CountAndCmd)]),
+        "chordvis_render_mesh_depth": (i32, [vp, u32, i32, C.c_float, C.c_float, CountAndCmd, P(DepthTarget)]),
+        "chordvis_build_hzb_from_depth": (i32, [vp, P(DepthTarget), P(HZB)]),
+        "chordvis_readback_depth": (i32, [vp, P(DepthTarget), vp]),
+        "chordvis_depth_view_stats": (i32, [vp, P(Stats)]),
         "chordvis_enable_timers": (i32, [vp, i32]),
         "chordvis_stats": (i32, [vp, P(Stats)]),
         "chordvis_set_debug": (i32, [vp, u32]),
@@ -223,3 +236,17 @@ def fill_objects(scene, camera, camera_last=None):
     if rc != OK:
         raise ChordvisError("chordvis_object_basic_data_batch -> %d" % rc)
     return scene.objects
+
+
+def cascade_setup(config, view, main_iv, light_dir, valid_range=None, tick=0, cache_valid=False, views=None):
+    """cascadeComputeCS on the host: InstanceCullingViewInfo records of the shadow cascades (in/out `views`)."""
+    n = int(config["cascadeCount"][0])
+    if views is None:
+        views = np.zeros(n, dtype=R.INSTANCE_CULLING_VIEW)
+    ld = np.asarray(light_dir, dtype=np.float32)
+    vr = None if valid_range is None else np.asarray(valid_range, dtype=np.uint32)
+    rc = lib.chordvis_cascade_setup(config.ctypes.data, view.ctypes.data, main_iv.ctypes.data, ld.ctypes.data,
+                                    vr.ctypes.data if vr is not None else None, int(tick), int(cache_valid), views.ctypes.data)
+    if rc != OK:
+        raise ChordvisError("chordvis_cascade_setup -> %d" % rc)
+    return views

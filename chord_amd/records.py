@@ -60,12 +60,29 @@ CAMERA_VIEW = np.dtype([
     ("translatedWorldToClipLastFrame", f32, 16),
     ("renderDimension", f32, 4),
     ("cameraFovy", f32), ("zNear", f32), ("zFar", f32), ("lodScale", f32),
+    ("clipToTranslatedWorldWithZFar_NoJitter", f32, 16),
 ])
+CASCADE_CONFIG = np.dtype([
+    ("cascadeCount", np.int32), ("realtimeCascadeCount", np.int32), ("cascadeDim", u32),
+    ("cascadeStartDistance", f32), ("cascadeEndDistance", f32), ("farCascadeEndDistance", f32), ("splitLambda", f32),
+    ("farCascadeSplitLambda", f32), ("shadowBiasConst", f32), ("shadowBiasSlope", f32), ("radiusScaleFixed", f32),
+])
+
+
+def default_cascade_config(**kw):
+    """CascadeShadowMapConfig defaults (render_helper.h:467-483)."""
+    c = np.zeros(1, dtype=CASCADE_CONFIG)
+    c["cascadeCount"], c["realtimeCascadeCount"], c["cascadeDim"] = 8, 3, 2048
+    c["cascadeStartDistance"], c["cascadeEndDistance"], c["farCascadeEndDistance"] = 0.0, 80.0, 800.0
+    c["splitLambda"], c["farCascadeSplitLambda"], c["radiusScaleFixed"] = 0.8, 0.8, 10.0
+    for k, v in kw.items():
+        c[k] = v
+    return c
 DRAW_CMD = np.dtype([("objectId", u32), ("meshletId", u32), ("slot", u32)])
 
 assert MESHLET.itemsize == 64 and MESHLET_GROUP.itemsize == 40 and PRIMITIVE.itemsize == 96 and BVH_NODE.itemsize == 60
 assert MATERIAL.itemsize == 96 and OBJECT.itemsize == 224 and INSTANCE_CULLING_VIEW.itemsize == 288
-assert CAMERA_VIEW.itemsize == 224 and DRAW_CMD.itemsize == 12
+assert CAMERA_VIEW.itemsize == 288 and DRAW_CMD.itemsize == 12 and CASCADE_CONFIG.itemsize == 44
 
 FLAG_FRUSTUM_CULL = 1 << 0
 FLAG_HZB_CULL = 1 << 1

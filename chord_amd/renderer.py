@@ -170,6 +170,46 @@ class VisibilityRenderer:
         lim = L.Limits(int(max_triangle_records), int(bin_pool_chunks), int(bin_max_chunks_per_tile))
         self._check(L.lib.chordvis_set_limits(self._ctx, C.byref(lim)), "set_limits")
 
+    # -- depth-only views (renderShadow's passes, mesh_raster.cpp:331-546) ------------------------------------
+    def allocate_depth_views(self, dim, view_count):
+        self._check(L.lib.chordvis_allocate_depth_views(self._ctx, dim, view_count), "allocate_depth_views")
+
+    def set_instance_views(self, views):
+        views = np.ascontiguousarray(views, dtype=R.INSTANCE_CULLING_VIEW)
+        self._check(L.lib.chordvis_set_instance_views(self._ctx, views.ctypes.data, len(views)), "set_instance_views")
+
+    def instance_culling_view(self, view_offset):
+        out = L.CountAndCmd()
+        self._check(L.lib.chordvis_instance_culling_view(self._ctx, view_offset, C.byref(out)), "instance_culling_view")
+        return out
+
+    def hzb_culling_generic(self, hzb, extent_scale, view_offset, use_last_frame, in_list):
+        out = L.CountAndCmd()
+        self._check(L.lib.chordvis_hzb_culling_generic(self._ctx, C.byref(hzb), extent_scale, view_offset, int(use_last_frame), in_list, C.byref(out)),
+                    "hzb_culling_generic")
+        return out
+
+    def render_mesh_depth(self, view_offset, in_list, depth_clamped=True, bias_const=0.0, bias_slope=0.0):
+        out = L.DepthTarget()
+        self._check(L.lib.chordvis_render_mesh_depth(self._ctx, view_offset, int(depth_clamped), bias_const, bias_slope, in_list, C.byref(out)),
+                    "render_mesh_depth")
+        return out
+
+    def build_hzb_from_depth(self, depth):
+        out = L.HZB()
+        self._check(L.lib.chordvis_build_hzb_from_depth(self._ctx, C.byref(depth), C.byref(out)), "build_hzb_from_depth")
+        return out
+
+    def read_depth(self, depth):
+        out = np.empty(depth.width * depth.height, dtype=np.float32)
+        self._check(L.lib.chordvis_readback_depth(self._ctx, C.byref(depth), out.ctypes.data), "readback_depth")
+        return out
+
+    def depth_view_stats(self):
+        st = L.Stats()
+        self._check(L.lib.chordvis_depth_view_stats(self._ctx, C.byref(st)), "depth_view_stats")
+        return st.as_dict()
+
     # -- consumers' first step (visibility_tile.cpp) -------------------------------------------------------
     def visibility_mark(self, drawed_meshlet_cmd=None):
         """visibilityMark (visibility_tile.cpp:20-57); the command list defaults to last_frame_cmds()."""

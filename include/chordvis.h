@@ -131,6 +131,16 @@ int chordvis_hzb_desc(uint32_t srcWidth, uint32_t srcHeight, ChordHZBDesc* out);
 int chordvis_camera_fill_view(const ChordCameraDesc* camera, const ChordCameraView* lastFrame,
                               ChordCameraView* outView, ChordInstanceCullingView* outInstanceView);
 
+/* cascadeComputeCS (cascade_setup.hlsl:79-372, driven by renderShadow mesh_raster.cpp:417-441): the InstanceCullingViewInfo of
+ * every shadow cascade -- log / uniform split of the view range (SDSM-tightened for the realtime cascades when the valid
+ * depth range of the last buildHZB is given), bounding sphere, light-space lookAt + reverse-Z ortho projection snapped
+ * to whole texels, frustum planes.  Host code: the reference runs it on the GPU only to read the depth range without a
+ * readback; validDepthMinMax NULL takes the shader's own no-range branch (:118).  views[] is in/out: cascades whose
+ * cache is still valid (isCascadeCacheValid, :8-22) are left untouched. */
+int chordvis_cascade_setup(const ChordCascadeConfig* config, const ChordCameraView* view, const ChordInstanceCullingView* mainInstanceView,
+                           const float lightDir[3], const uint32_t validDepthMinMax[2], uint32_t tickCount, int bCacheValid,
+                           ChordInstanceCullingView* views /* [config->cascadeCount] */);
+
 /* SceneNode::getObjectBasicData (scene_node.cpp:42-90): camera-relative f64 -> f32 transforms.
  * Matrices are glm column-major doubles. */
 int chordvis_object_basic_data(const double localToWorld[16], const double prevLocalToWorld[16],
@@ -285,6 +295,37 @@ int chordvis_group_set_view(ChordGroup* group, const ChordCameraView* view, cons
  * device (no host synchronisation; chordvis_group_sync waits) */
 int chordvis_group_render_frame(ChordGroup* group);
 int chordvis_group_sync(ChordGroup* group);
+
+/* ------------------------------------------------------------------ depth-only views (what renderShadow runs per
+ * cascade, mesh_raster.cpp:331-546).  Every pass of the reference takes (instanceViewId, instanceViewOffset) -- a buffer of
+ * InstanceCullingViewInfo and an index into it (gltf_rendering.h:38-43,54-64,89-110); here the buffer is set once and the
+ * passes take the offset.  Views have their own square size (CascadeShadowMapConfig::cascadeDim, render_helper.h:469). */
+typedef struct ChordDepthTarget {     /* a VK_FORMAT_D32_SFLOAT image (mesh_raster.cpp:407-416): device floats, row-major, reverse-Z, clear 0 */
+    float*   depth;
+    uint32_t width, height;
+} ChordDepthTarget;
+/* after upload_scene: targets + work lists for `viewCount` views of dim x dim pixels */
+int chordvis_allocate_depth_views(ChordCtx* ctx, uint32_t dim, uint32_t viewCount);
+/* the InstanceCullingViewInfo[] of the views ("CascadeViewInfos", mesh_raster.cpp:417-421); host array, copied */
+int chordvis_set_instance_views(ChordCtx* ctx, const ChordInstanceCullingView* hostViews, uint32_t count);
+/* instanceCulling(queue, ctx, instanceCullingViewInfo, instanceCullingViewInfoOffset) for a view other than the main one
+ * (mesh_raster.cpp:452): object / meshlet frustum tests against the view (orthoFrustumCulling for an orthographic one,
+ * base.hlsli:251-272), LOD cut by the MAIN camera (chordvis_set_view).  The list stays valid until the next call. */
+int chordvis_instance_culling_view(ChordCtx* ctx, uint32_t instanceViewOffset, ChordCountAndCmd* out);
+/* detail::hzbCullingGeneric (instance_culling.cpp:232-284, hzb_culling_generic.hlsl): one-pass occlusion cull of a view's list
+ * against an HZB of that view's depth (chordvis_build_hzb_from_depth) */
+int chordvis_hzb_culling_generic(ChordCtx* ctx, const ChordHZB* hzb, float extentScale, uint32_t instanceViewOffset,
+                                 int bObjectUseLastFrameProject, ChordCountAndCmd in, ChordCountAndCmd* out);
+/* queue.clearDepthStencil(depth, 0) + renderMeshDepth(PASS_TYPE_DEPTH) (mesh_raster.cpp:159-206,500-522): both alpha buckets,
+ * cull mode NONE, depth test GREATER_OR_EQUAL, optional depth clamp and vkCmdSetDepthBias(const, 0, slope).  The view must
+ * be the one of the last chordvis_instance_culling_view. */
+int chordvis_render_mesh_depth(ChordCtx* ctx, uint32_t instanceViewOffset, int bDepthClamped, float depthBiasConst, float depthBiasSlope,
+                               ChordCountAndCmd in, ChordDepthTarget* out);
+/* buildHZB(queue, depth, true, false, false) on a depth target (mesh_raster.cpp:466,527) */
+int chordvis_build_hzb_from_depth(ChordCtx* ctx, const ChordDepthTarget* depth, ChordHZB* out);
+int chordvis_readback_depth(ChordCtx* ctx, const ChordDepthTarget* depth, float* host);
+/* chordvis_stats of the depth views' last pass (overflow flag, record / bin counts) */
+int chordvis_depth_view_stats(ChordCtx* ctx, ChordStats* out);
 
 /* handles of the last frame (post-instanceCulling list: consumer contract, lighting.hlsl:318-345) */
 int chordvis_last_frame_cmds(ChordCtx* ctx, ChordCountAndCmd* out);

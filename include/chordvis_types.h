@@ -168,7 +168,25 @@ typedef struct ChordCameraView {
     float     zNear;
     float     zFar;
     float     lodScale;                   /* (h * 0.5f) / tanf(0.5f * fovy), base.hlsli:503-518 */
+    ChordMat4 clipToTranslatedWorldWithZFar_NoJitter;   /* camera.cpp:25-31: inverse of (perspectiveRH_ZO(fovy, aspect, zFar, zNear) * view);
+                                                         * read by the cascade setup only (cascade_setup.hlsl:175) */
 } ChordCameraView;
+
+/* CascadeShadowMapConfig -- render_helper.h:462-484 (the fields the cascade setup and the depth passes read) */
+typedef struct ChordCascadeConfig {
+    int32_t  cascadeCount;            /* 8 */
+    int32_t  realtimeCascadeCount;    /* 3 */
+    uint32_t cascadeDim;              /* 2048 */
+    float    cascadeStartDistance;    /* 0 */
+    float    cascadeEndDistance;      /* 80 */
+    float    farCascadeEndDistance;   /* 800 */
+    float    splitLambda;             /* 0.8 */
+    float    farCascadeSplitLambda;   /* 0.8 */
+    float    shadowBiasConst;         /* 0 */
+    float    shadowBiasSlope;         /* 0 */
+    float    radiusScaleFixed;        /* 10 */
+} ChordCascadeConfig;
+#define CHORD_MAX_CASCADES 32u        /* the setup shader's group size (cascade_setup.hlsl:79) */
 
 typedef struct ChordDrawCmd {
     uint32_t objectId;

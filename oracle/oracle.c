@@ -43,6 +43,13 @@
  *        wrap per axis REPEAT / CLAMP_TO_EDGE / MIRRORED_REPEAT on the integer texel index;
  *      - clip(a * baseColorFactor.w - alphaCutOff): the fragment is dropped iff that is < 0.
  *      Blended materials (alphaMode 2) are in no bucket of renderMesh (mesh_raster.cpp:224) and draw nothing.
+ * (10) Depth-only passes (PASS_TYPE_DEPTH, renderMeshDepth mesh_raster.cpp:159-206: shadow views).  Cull mode NONE for every
+ *      bucket, no id output: the word is asuint(depth) << 32.  Depth clamp (VkPipelineRasterizationStateCreateInfo::
+ *      depthClampEnable): no clipping against the near / far planes -- a vertex is "fast" iff w > 0 and inside the guard
+ *      band, the clipper skips planes 0 and 1 -- and the interpolated depth is clamped to [0, 1].  Depth bias
+ *      (vkCmdSetDepthBias(const, 0, slope)): o = slope * m + const * r with m = max(|dz/dx|, |dz/dy|) of the snapped
+ *      triangle's depth plane (dz/dx = (float(256 a1) * invA) * e1 + (float(256 a2) * invA) * e2, dz/dy with b) and
+ *      r = 2^(exponent(max |d_i|) - 23); fixed here as: the three VERTEX depths are biased by o before interpolation.
  */
 #include "oracle.h"
 
@@ -607,7 +614,8 @@ typedef struct { int atomic; } RasterCtx;
 
 static void raster_snapped(const int32_t X[3], const int32_t Y[3], const float d[3], int twoSided, uint32_t payload,
                            uint32_t W, uint32_t H, const OrcShard* shard, uint64_t* vis, OrcRasterStats* st, int atomic,
-                           MaskCtx* mk, const ChordSceneDesc* scene, const ChordMaterial* mat, const float tu[3], const float tv[3], const float tw[3])
+                           MaskCtx* mk, const ChordSceneDesc* scene, const ChordMaterial* mat, const float tu[3], const float tv[3], const float tw[3],
+                           int depthClamp)
 {
     /* signed doubled area in y-down screen space; reference front faces
      * (det > 0 in clip (x,y,w), mesh_raster.hlsl:143-149; CCW front + Y-flipped
@@ -666,6 +674,7 @@ static void raster_snapped(const int32_t X[3], const int32_t Y[3], const float d
                 if (a * mk->alphaFactor - mk->alphaCutOff < 0.0f) { if (st) st->fragmentsClipped++; continue; }
             }
             float z = (d[0] + l1 * e1) + l2 * e2;
+            if (depthClamp) z = fminf(fmaxf(z, 0.0f), 1.0f);
             uint64_t packed = ((uint64_t)f2u(z) << 32) | payload;
             vis_max(&vis[(size_t)py * W + (size_t)px], packed, atomic);
             if (st) st->fragments++;
@@ -677,7 +686,7 @@ void orc_raster_snapped_triangle(const int32_t X[3], const int32_t Y[3], const f
                                  int twoSided, uint32_t payload, uint32_t W, uint32_t H,
                                  const OrcShard* shard, uint64_t* vis, OrcRasterStats* stats)
 {
-    raster_snapped(X, Y, d, twoSided, payload, W, H, shard, vis, stats, 0, NULL, NULL, NULL, NULL, NULL, NULL);
+    raster_snapped(X, Y, d, twoSided, payload, W, H, shard, vis, stats, 0, NULL, NULL, NULL, NULL, NULL, NULL, 0);
 }
 
 #define ORC_GUARD 1024.0f
@@ -702,6 +711,15 @@ static inline int vertex_in_fast_volume(const f4* v)
     return 1;
 }
 
+/* depth clamp: the near / far planes do not clip */
+static inline int vertex_fast(const f4* v, int depthClamp)
+{
+    if (!depthClamp) return vertex_in_fast_volume(v);
+    if (!(v->w > 0.0f)) return 0;
+    for (int k = 2; k < 6; k++) if (!(clip_dist(v, k) >= 0.0f)) return 0;
+    return 1;
+}
+
 static inline f4 clip_intersect(const f4* in, const f4* out, float din, float dout)
 {
     float t = din / (din - dout);
@@ -723,8 +741,41 @@ static inline void snap_vertex(const f4* h, float W, float H, int32_t* X, int32_
     *d = h->z / h->w;
 }
 
+typedef struct { int depthOnly, depthClamp; float biasConst, biasSlope; } PassMode;
+static const PassMode kClusterPass = {0, 0, 0.0f, 0.0f};
+
+/* depth bias of a snapped triangle (header item 10) */
+static float depth_bias(const PassMode* pm, const int32_t X[3], const int32_t Y[3], const float d[3])
+{
+    if (pm->biasConst == 0.0f && pm->biasSlope == 0.0f) return 0.0f;
+    int64_t area2 = (int64_t)(X[1] - X[0]) * (int64_t)(Y[2] - Y[0]) - (int64_t)(X[2] - X[0]) * (int64_t)(Y[1] - Y[0]);
+    if (area2 == 0) return 0.0f;
+    const int64_t s = area2 < 0 ? -1 : 1;
+    const float invA = 1.0f / (float)(double)(area2 * s);
+    /* edge i opposite vertex i: E1 = orient(V2, V0, P), E2 = orient(V0, V1, P); dE/dx = a = -s * dy, dE/dy = b = s * dx (per sub-pixel) */
+    const int64_t a1 = -s * (int64_t)(Y[0] - Y[2]), b1 = s * (int64_t)(X[0] - X[2]);
+    const int64_t a2 = -s * (int64_t)(Y[1] - Y[0]), b2 = s * (int64_t)(X[1] - X[0]);
+    const float e1 = d[1] - d[0], e2 = d[2] - d[0];
+    const float dzdx = ((float)(double)(a1 * 256) * invA) * e1 + ((float)(double)(a2 * 256) * invA) * e2;
+    const float dzdy = ((float)(double)(b1 * 256) * invA) * e1 + ((float)(double)(b2 * 256) * invA) * e2;
+    const float m = fmaxf(fabsf(dzdx), fabsf(dzdy));
+    const float mz = fmaxf(fabsf(d[0]), fmaxf(fabsf(d[1]), fabsf(d[2])));
+    const int32_t e = (int32_t)((f2u(mz) >> 23) & 0xFFu) - 23;
+    const float r = (e > 0 && e < 255) ? u2f((uint32_t)e << 23) : 0.0f;
+    return pm->biasSlope * m + pm->biasConst * r;
+}
+
+static void raster_cluster_pass(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, const ChordDrawCmd* cmd,
+                                const OrcShard* shard, uint64_t* vis, OrcRasterStats* st, int atomic, const PassMode* pm);
+
 static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, const ChordDrawCmd* cmd,
                            const OrcShard* shard, uint64_t* vis, OrcRasterStats* st, int atomic)
+{
+    raster_cluster_pass(scene, iv, cmd, shard, vis, st, atomic, &kClusterPass);
+}
+
+static void raster_cluster_pass(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, const ChordDrawCmd* cmd,
+                                const OrcShard* shard, uint64_t* vis, OrcRasterStats* st, int atomic, const PassMode* pm)
 {
     /* mesh_raster.hlsl:66-185 */
     const ChordObject* obj = &scene->objects[cmd->objectId];
@@ -733,7 +784,7 @@ static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCulli
     const ChordAssetDesc* as = &scene->assets[prim->primitiveDatasBufferId];
     const ChordMeshlet* m = &as->meshlets[cmd->meshletId];
     const uint32_t V = m->vertexTriangleCount & 0xFFu, T = (m->vertexTriangleCount >> 8) & 0xFFu;
-    const int twoSided = mat->bTwoSided != 0;       /* mesh_raster.cpp:224-235: DIM_TWO_SIDED bucket */
+    const int twoSided = mat->bTwoSided != 0 || pm->depthOnly;   /* mesh_raster.cpp:224-235: DIM_TWO_SIDED bucket; depth passes: always (:188-190) */
     const int masked = mat->alphaMode == CHORD_ALPHA_MASK;   /* DIM_MASKED_MATERIAL bucket */
     MaskCtx mkStore; MaskCtx* mk = masked ? &mkStore : NULL;
     const float W = iv->renderDimension[0], H = iv->renderDimension[1];
@@ -780,8 +831,8 @@ static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCulli
         /* #3 small primitive */
         if (rintf(minU * W) == rintf(maxU * W) || rintf(minV * H) == rintf(maxV * H)) { if (st) st->trianglesSmall++; continue; }
 
-        uint32_t payload = chord_encode_triangle_instance(t, cmd->slot);
-        if (vertex_in_fast_volume(&h[0]) && vertex_in_fast_volume(&h[1]) && vertex_in_fast_volume(&h[2])) {
+        uint32_t payload = pm->depthOnly ? 0u : chord_encode_triangle_instance(t, cmd->slot);
+        if (vertex_fast(&h[0], pm->depthClamp) && vertex_fast(&h[1], pm->depthClamp) && vertex_fast(&h[2], pm->depthClamp)) {
             int32_t X[3], Y[3]; float d[3];
             for (int i = 0; i < 3; i++) {
                 X[i] = (int32_t)rintf((u[i] * W) * 256.0f);
@@ -790,7 +841,8 @@ static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCulli
             }
             const float tu3[3] = {tus[idx[0]], tus[idx[1]], tus[idx[2]]}, tv3[3] = {tvs[idx[0]], tvs[idx[1]], tvs[idx[2]]};
             const float tw3[3] = {h[0].w, h[1].w, h[2].w};
-            raster_snapped(X, Y, d, twoSided, payload, Wi, Hi, shard, vis, st, atomic, mk, scene, mat, tu3, tv3, tw3);
+            if (pm->depthOnly) { const float o = depth_bias(pm, X, Y, d); d[0] += o; d[1] += o; d[2] += o; }
+            raster_snapped(X, Y, d, twoSided, payload, Wi, Hi, shard, vis, st, atomic, mk, scene, mat, tu3, tv3, tw3, pm->depthClamp);
         } else {
             if (st) st->trianglesClipped++;
             f4 poly[2][12];
@@ -798,7 +850,7 @@ static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCulli
             int n = 3, cur = 0;
             poly[0][0] = h[0]; poly[0][1] = h[1]; poly[0][2] = h[2];
             for (int i = 0; i < 3; i++) { pu[0][i] = tus[idx[i]]; pv[0][i] = tvs[idx[i]]; }
-            for (int k = 0; k < 6 && n >= 3; k++) {
+            for (int k = pm->depthClamp ? 2 : 0; k < 6 && n >= 3; k++) {
                 int m2 = 0;
                 f4* in = poly[cur]; f4* out = poly[cur ^ 1];
                 for (int i = 0; i < n; i++) {
@@ -832,7 +884,8 @@ static void raster_cluster(const ChordSceneDesc* scene, const ChordInstanceCulli
                 float d[3] = {PD[0], PD[i], PD[i + 1]};
                 const float tu3[3] = {pu[cur][0], pu[cur][i], pu[cur][i + 1]}, tv3[3] = {pv[cur][0], pv[cur][i], pv[cur][i + 1]};
                 const float tw3[3] = {poly[cur][0].w, poly[cur][i].w, poly[cur][i + 1].w};
-                raster_snapped(X, Y, d, twoSided, payload, Wi, Hi, shard, vis, st, atomic, mk, scene, mat, tu3, tv3, tw3);
+                if (pm->depthOnly) { const float o = depth_bias(pm, X, Y, d); d[0] += o; d[1] += o; d[2] += o; }
+                raster_snapped(X, Y, d, twoSided, payload, Wi, Hi, shard, vis, st, atomic, mk, scene, mat, tu3, tv3, tw3, pm->depthClamp);
             }
         }
     }
@@ -881,6 +934,80 @@ void orc_raster_mt(const ChordSceneDesc* scene, const ChordInstanceCullingView* 
             for (size_t k = 0; k < sizeof(OrcRasterStats) / 8; k++) a[k] += b[k];
         }
     }
+}
+
+/* renderMeshDepth (mesh_raster.cpp:159-206) into a cleared 64-bit buffer whose high words are the D32 image */
+void orc_raster_depth(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, const ChordDrawCmd* cmds, uint32_t count,
+                      int depthClamp, float biasConst, float biasSlope, uint64_t* vis, OrcRasterStats* stats)
+{
+    PassMode pm = {1, depthClamp, biasConst, biasSlope};
+    for (uint32_t i = 0; i < count; i++) raster_cluster_pass(scene, iv, &cmds[i], NULL, vis, stats, 0, &pm);
+}
+
+/* hzb_culling_generic.hlsl:37-172 -- one-pass occlusion cull of a (shadow) view against an HZB of that view's depth */
+uint32_t orc_hzb_culling_generic(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, const double mainCameraWorldPos[3],
+                                 uint32_t flags, float extentScale, int bObjectUseLastFrameProject,
+                                 const ChordHZBDesc* hzb, const uint16_t* hzbMin,
+                                 const ChordDrawCmd* inCmds, uint32_t inCount, ChordDrawCmd* outCmds)
+{
+    uint32_t nv = 0;
+    double ivCam[3];
+    memcpy(ivCam, iv->cameraWorldPos, sizeof(ivCam));               /* GPUStorageDouble4: the first three doubles */
+    const float rel[3] = {(float)(mainCameraWorldPos[0] - ivCam[0]), (float)(mainCameraWorldPos[1] - ivCam[1]), (float)(mainCameraWorldPos[2] - ivCam[2])};   /* :78 */
+    for (uint32_t i = 0; i < inCount; i++) {
+        const ChordDrawCmd* cmd = &inCmds[i];
+        const ChordObject* obj = &scene->objects[cmd->objectId];
+        const ChordPrimitive* prim = &scene->primitives[obj->GLTFPrimitiveDetail];
+        const ChordAssetDesc* as = &scene->assets[prim->primitiveDatasBufferId];
+        const ChordMeshlet* m = &as->meshlets[cmd->meshletId];
+        int visible = 1;
+        if (flags & CHORD_FLAG_HZB_CULL) {
+            f3 c, e;
+            aabb_center_extent(m->posMin, m->posMax, 1, &c, &e);
+            ChordMat4 l2w = bObjectUseLastFrameProject ? obj->basicData.localToTranslatedWorldLastFrame : obj->basicData.localToTranslatedWorld;
+            MAT(&l2w, 0, 3) += rel[0]; MAT(&l2w, 1, 3) += rel[1]; MAT(&l2w, 2, 3) += rel[2];     /* :79-81 */
+            ChordMat4 mvp;
+            mul_mm(&iv->translatedWorldToClip, &l2w, &mvp);
+            f3 mx = {-10.0f, -10.0f, -10.0f}, mn = {10.0f, 10.0f, 10.0f};
+            int can = 1;
+            for (int k = 0; k < 8; k++) {
+                f3 uvz = project_pos_to_uvz(extent_corner(c, e, k), &mvp);
+                mn.x = fminf(mn.x, uvz.x); mn.y = fminf(mn.y, uvz.y); mn.z = fminf(mn.z, uvz.z);
+                mx.x = fmaxf(mx.x, uvz.x); mx.y = fmaxf(mx.y, uvz.y); mx.z = fmaxf(mx.z, uvz.z);
+                can = can && (uvz.x < 1.0f && uvz.y < 1.0f && uvz.z < 1.0f) && (uvz.x > 0.0f && uvz.y > 0.0f && uvz.z > 0.0f);   /* :95 */
+            }
+            if (can) {
+                const float W = iv->renderDimension[0], H = iv->renderDimension[1];
+                int32_t rx = (int32_t)(mn.x * W + extentScale * -0.5f);           /* :103 */
+                int32_t ry = (int32_t)(mn.y * H + extentScale * -0.5f);
+                int32_t rz = (int32_t)(mx.x * W + extentScale * 0.5f);
+                int32_t rw = (int32_t)(mx.y * H + extentScale * 0.5f);
+                if (rx < 0) rx = 0;
+                if (ry < 0) ry = 0;
+                rz = (int32_t)fminf(W - 1.0f, (float)rz);
+                rw = (int32_t)fminf(H - 1.0f, (float)rw);
+                if (rz < rx || rw < ry) visible = 0;
+                else {
+                    const int32_t mx0 = rx >> 1, my0 = ry >> 1, mz0 = rz >> 1, mw0 = rw >> 1;
+                    const int lx = first_bit_high(mz0 - mx0), ly = first_bit_high(mw0 - my0);
+                    int lv = lx > ly ? lx : ly;
+                    if (lv < 0) lv = 0;
+                    if (((mz0 >> lv) - (mx0 >> lv) >= 2) || ((mw0 >> lv) - (my0 >> lv) >= 2)) lv += 1;   /* :125-126 */
+                    if (lv > (int)hzb->mipCount - 1) lv = (int)hzb->mipCount - 1;   /* (a Load beyond the last mip returns 0: never reached at these sizes) */
+                    const int32_t cx = mx0 >> lv, cy = my0 >> lv, cz = mz0 >> lv, cw = mw0 >> lv;
+                    float zMin = 10.0f;
+                    const uint32_t mw = mip_w(hzb, (uint32_t)lv);
+                    for (int x = 0; x < 2; x++) for (int y = 0; y < 2; y++) {
+                        const int32_t sx = cx + x < cz ? cx + x : cz, sy = cy + y < cw ? cy + y : cw;
+                        zMin = fminf(zMin, orc_f16_to_f32(hzbMin[hzb->mipOffset[lv] + (size_t)sy * mw + (size_t)sx]));
+                    }
+                    if (zMin > mx.z) visible = 0;
+                }
+            }
+        }
+        if (visible) outCmds[nv++] = *cmd;
+    }
+    return nv;
 }
 
 /* ------------------------------------------------------------------ frame -- */

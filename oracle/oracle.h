@@ -93,6 +93,16 @@ void orc_raster(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv,
 
 /* Scan-convert one screen-space triangle given snapped 24.8 coordinates
  * (exposed for the raster-rule known-answer tests). */
+/* renderMeshDepth (mesh_raster.cpp:159-206): PASS_TYPE_DEPTH of `cmds` for view `iv` into `vis` (NOT cleared here); the D32
+ * image is the high word of every element, the low word stays 0 */
+void orc_raster_depth(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, const ChordDrawCmd* cmds, uint32_t count,
+                      int depthClamp, float biasConst, float biasSlope, uint64_t* vis, OrcRasterStats* stats);
+/* hzb_culling_generic.hlsl:37-172; returns the number of commands kept in outCmds (input order) */
+uint32_t orc_hzb_culling_generic(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, const double mainCameraWorldPos[3],
+                                 uint32_t flags, float extentScale, int bObjectUseLastFrameProject,
+                                 const ChordHZBDesc* hzb, const uint16_t* hzbMin,
+                                 const ChordDrawCmd* inCmds, uint32_t inCount, ChordDrawCmd* outCmds);
+
 /* canonical masked-material texture fetch (oracle.c header item 9): alpha of texture `tex` (NULL: 1) at (u, v) */
 float orc_sample_alpha(const ChordTexture* tex, const ChordSampler* smp, uint32_t level, int linear, float u, float v);
 /* level / filter a triangle with doubled snapped area absArea2 and texture coordinates u[], v[] samples `mat`'s texture at */

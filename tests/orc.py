@@ -50,6 +50,10 @@ def _load():
     lib.orc_raster.argtypes = [P(R.SceneDesc), vp, vp, u32, P(Shard), vp, P(RasterStats)]
     lib.orc_raster_snapped_triangle.restype = None
     lib.orc_raster_snapped_triangle.argtypes = [vp, vp, vp, i32, u32, u32, u32, P(Shard), vp, P(RasterStats)]
+    lib.orc_raster_depth.restype = None
+    lib.orc_raster_depth.argtypes = [P(R.SceneDesc), vp, vp, u32, i32, C.c_float, C.c_float, vp, P(RasterStats)]
+    lib.orc_hzb_culling_generic.restype = u32
+    lib.orc_hzb_culling_generic.argtypes = [P(R.SceneDesc), vp, vp, u32, C.c_float, i32, P(R.HZBDesc), vp, vp, u32, vp]
     lib.orc_sample_alpha.restype = C.c_float
     lib.orc_sample_alpha.argtypes = [P(R.Texture), vp, u32, i32, C.c_float, C.c_float]
     lib.orc_mask_level.restype = u32
@@ -195,3 +199,24 @@ def shading_tiles(marker, shading_type):
     args = np.zeros(4, dtype=np.uint32)
     n = lib.orc_shading_tiles(marker.ctypes.data, mw, mh, shading_type, tiles.ctypes.data, args.ctypes.data)
     return tiles[:n].copy(), args
+
+
+def raster_depth(scene, iv, cmds, w, h, depth_clamp=True, bias_const=0.0, bias_slope=0.0):
+    """renderMeshDepth into a cleared target; returns (float32 depth image flattened, stats)."""
+    vis = np.zeros(w * h, dtype=np.uint64)
+    st = RasterStats()
+    cmds = np.ascontiguousarray(cmds, dtype=R.DRAW_CMD)
+    lib.orc_raster_depth(C.byref(scene.desc), iv.ctypes.data, cmds.ctypes.data, len(cmds), int(depth_clamp), bias_const, bias_slope,
+                         vis.ctypes.data, C.byref(st))
+    assert not (vis & np.uint64(0xFFFFFFFF)).any()
+    return (vis >> np.uint64(32)).astype(np.uint32).view(np.float32), st
+
+
+def hzb_culling_generic(scene, iv, main_camera_pos, flags, extent_scale, use_last_frame, desc, hzb_min, cmds):
+    cmds = np.ascontiguousarray(cmds, dtype=R.DRAW_CMD)
+    out = np.zeros(max(1, len(cmds)), dtype=R.DRAW_CMD)
+    cam = np.asarray(main_camera_pos, dtype=np.float64)
+    hzb_min = np.ascontiguousarray(hzb_min, dtype=np.uint16)
+    n = lib.orc_hzb_culling_generic(C.byref(scene.desc), iv.ctypes.data, cam.ctypes.data, flags, extent_scale, int(use_last_frame),
+                                    C.byref(desc), hzb_min.ctypes.data, cmds.ctypes.data, len(cmds), out.ctypes.data)
+    return out[:n].copy()

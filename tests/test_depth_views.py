@@ -1,0 +1,160 @@
+"""Depth-only views: cascade setup on the host, the oracle's depth pass and generic HZB cull (CPU), and the
+GPU passes against them (gpu)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+import orc
+from chord_amd import lib as L, records as R
+from chord_amd import scenes
+
+LIGHT = (0.35, -1.0, 0.25)
+
+
+def _cascades(cam, **kw):
+    view, iv = L.make_views(cam)
+    cfg = R.default_cascade_config(**kw)
+    return cfg, view, iv, L.cascade_setup(cfg, view, iv, LIGHT)
+
+
+def _m(rec, name):
+    return rec[name].reshape(4, 4).T.astype(np.float64)        # glm column-major -> M[r][c]
+
+
+def test_cascade_views_are_texel_snapped_orthographic_boxes_around_their_split():
+    scene, cam = scenes.small_test_scene(320, 200)
+    cfg, view, iv, views = _cascades(cam, cascadeCount=5, realtimeCascadeCount=2, cascadeDim=1024, cascadeEndDistance=30.0, farCascadeEndDistance=120.0)
+    inv_zfar = _m(view[0], "clipToTranslatedWorldWithZFar_NoJitter")
+    near, far = float(view["zNear"][0]), float(view["zFar"][0])
+    prev_end = 0.0
+    radii = []
+    for k, v in enumerate(views):
+        vp, inv = _m(v, "translatedWorldToClip"), _m(v, "clipToTranslatedWorld")
+        assert np.array_equal(vp[3], [0, 0, 0, 1])                                      # orthographic: isOrthoProjection, base.hlsli:243-246
+        assert np.allclose(vp @ inv, np.eye(4), atol=2e-4)
+        assert v["renderDimension"].tolist() == [1024.0, 1024.0, 1.0 / 1024, 1.0 / 1024]
+        # texel alignment (cascade_setup.hlsl:312-326): the world origin lands on a whole texel
+        o = vp @ np.array([0, 0, 0, 1.0]) * 512.0
+        assert abs(o[0] - round(o[0])) < 2e-2 and abs(o[1] - round(o[1])) < 2e-2
+        # inward planes of the box: its centre is inside all six, and clip-space corners are on them
+        centre = (inv @ np.array([0, 0, 0.5, 1.0]))[:3]
+        assert all(np.dot(pl[:3], centre) + pl[3] > 0 for pl in v["frustumPlanesRS"][:5])
+        radii.append(1.0 / np.linalg.norm(vp[0, :3]))                                 # row 0 = s / R
+    assert all(b >= a for a, b in zip(radii, radii[1:]))                                 # farther cascades are at least as wide
+    # cache: with a valid cache only the scheduled far cascade is rewritten (isCascadeCacheValid, :8-22)
+    marker = views.copy()
+    marker["renderDimension"][:, 0] = -1.0
+    for tick in range(3):
+        out = L.cascade_setup(cfg, view, iv, LIGHT, tick=tick, cache_valid=True, views=marker.copy())
+        rewritten = [k for k in range(5) if out["renderDimension"][k, 0] != -1.0]
+        assert rewritten == [0, 1, 2 + tick % 3]
+
+
+def test_sdsm_range_tightens_the_realtime_cascades():
+    scene, cam = scenes.small_test_scene(320, 200)
+    view, iv = L.make_views(cam)
+    cfg = R.default_cascade_config(cascadeCount=4, realtimeCascadeCount=2, cascadeDim=512)
+    wide = L.cascade_setup(cfg, view, iv, LIGHT)
+    near = float(view["zNear"][0])
+    # depths seen: view z from 4 m to 9 m  ->  device depth = zNear / z
+    rng = np.array([np.float32(near / 9.0), np.float32(near / 4.0)], dtype=np.float32).view(np.uint32)
+    tight = L.cascade_setup(cfg, view, iv, LIGHT, valid_range=rng)
+    r_wide = 1.0 / np.linalg.norm(wide["translatedWorldToClip"][:, [0, 4, 8]], axis=1)
+    r_tight = 1.0 / np.linalg.norm(tight["translatedWorldToClip"][:, [0, 4, 8]], axis=1)
+    assert (r_tight[:2] < r_wide[:2]).all() and np.array_equal(r_tight[2:], r_wide[2:])
+
+
+def _setup(width=320, height=200, dim=256, **kw):
+    scene, cam = scenes.masked_test_scene(width, height)
+    L.fill_objects(scene, cam)
+    cfg, view, iv, views = _cascades(cam, cascadeCount=3, realtimeCascadeCount=2, cascadeDim=dim, cascadeEndDistance=14.0,
+                                     farCascadeEndDistance=40.0, **kw)
+    return scene, cam, cfg, view, iv, views
+
+
+def test_oracle_depth_pass_properties():
+    scene, cam, cfg, view, iv, views = _setup()
+    dim = int(cfg["cascadeDim"][0])
+    flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | R.FLAG_HZB_CULL
+    cmds = orc.instance_culling(scene, view, views[1:2], flags)
+    assert len(cmds) > 0
+    depth, st = orc.raster_depth(scene, views[1:2], cmds, dim, dim)
+    assert st.trianglesBackface == 0                                            # cull mode NONE (mesh_raster.cpp:188-190)
+    assert (depth >= 0).all() and (depth <= 1).all() and (depth > 0).any()
+    assert st.fragmentsClipped > 0                                              # the masked bucket alpha-tests in depth passes too
+    # the depth image equals the depth half of a two-sided cluster pass where no clamping happens
+    two = scene.materials.copy()
+    two["bTwoSided"] = 1
+    vis, _ = orc.raster(scene.with_objects(None, two), views[1:2], cmds, dim, dim)
+    ref = (vis >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    blend = scene.materials["alphaMode"][scene.objects["GLTFMaterialData"]] == R.ALPHA_BLEND
+    assert np.array_equal(depth, ref) or (np.abs(depth - ref) > 0).sum() < depth.size    # (identical unless something is clamped)
+    assert np.array_equal(depth[(ref > 0) & (ref < 1)], ref[(ref > 0) & (ref < 1)]) and not blend.all()
+    # depth bias moves every covered texel by a bounded amount, towards the bias' sign
+    biased, _ = orc.raster_depth(scene, views[1:2], cmds, dim, dim, bias_const=-64.0, bias_slope=-1.5)
+    covered = depth > 0
+    assert (biased[covered] <= depth[covered]).all() and (biased[covered] < depth[covered]).any()
+    # generic HZB cull: nothing is occluded by an empty HZB; against the view's own depth the survivors are a subset
+    desc = orc.hzb_desc(dim, dim)
+    campos = np.frombuffer(iv["cameraWorldPos"][0].tobytes(), dtype=np.float64)[:3]
+    empty = np.zeros(desc.totalTexels, np.uint16)
+    assert len(orc.hzb_culling_generic(scene, views[1:2], campos, flags, 1.5, False, desc, empty, cmds)) == len(cmds)
+    words = depth.view(np.uint32).astype(np.uint64) << np.uint64(32)
+    _, hmin, _, _ = orc.hzb_build(words, dim, dim)
+    kept = orc.hzb_culling_generic(scene, views[1:2], campos, flags, 1.5, False, desc, hmin, cmds)
+    assert 0 < len(kept) <= len(cmds) and np.isin(kept["slot"], cmds["slot"]).all()
+    # ... and drawing only the survivors yields the same depth image (what was dropped was hidden)
+    again, _ = orc.raster_depth(scene, views[1:2], kept, dim, dim)
+    assert np.array_equal(again, depth)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,bias", [(256, (0.0, 0.0)), (512, (-48.0, -1.25)), (1000, (0.0, 0.0))], ids=["256", "512_biased", "1000_odd"])
+def test_cascade_depth_passes_match_oracle(gpu, dim, bias):
+    """renderShadow's loop (mesh_raster.cpp:443-531) cascade by cascade, far to near: instanceCulling for the cascade's
+    orthographic view, hzbCullingGeneric against the previous cascade's HZB, clear + renderMeshDepth, buildHZB -- every
+    list, depth image and HZB chain bit for bit against the oracle."""
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam, cfg, view, iv, views = _setup(dim=dim)
+    flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | R.FLAG_HZB_CULL
+    r = VisibilityRenderer(0)
+    r.upload_scene(scene)
+    r.allocate_gbuffer(cam.width, cam.height)
+    r.set_view(view, iv, flags)
+    r.allocate_depth_views(dim, len(views))
+    r.set_instance_views(views)
+    desc = orc.hzb_desc(dim, dim)
+    campos = np.frombuffer(iv["cameraWorldPos"][0].tobytes(), dtype=np.float64)[:3]
+    prev_hzb, prev_hzb_gpu = None, None
+    for k in range(len(views) - 1, -1, -1):
+        vk = views[k:k + 1]
+        got_list = r.instance_culling_view(k)
+        want_cmds = orc.instance_culling(scene, view, vk, flags)
+        assert np.array_equal(r.read_cmds(got_list), want_cmds), "cascade %d: culled list" % k
+        if prev_hzb is not None:
+            got_list = r.hzb_culling_generic(prev_hzb_gpu, 1.5, k + 1, False, got_list)      # the previous cascade's view (mesh_raster.cpp:484-497)
+            want_cmds = orc.hzb_culling_generic(scene, views[k + 1:k + 2], campos, flags, 1.5, False, desc, prev_hzb, want_cmds)
+            assert np.array_equal(H.sort_cmds(r.read_cmds(got_list)), H.sort_cmds(want_cmds)), "cascade %d: generic HZB cull" % k
+        target = r.render_mesh_depth(k, got_list, True, bias[0], bias[1])
+        want_depth, st = orc.raster_depth(scene, vk, want_cmds, dim, dim, True, bias[0], bias[1])
+        got_depth = r.read_depth(target)
+        bad = np.nonzero(got_depth.view(np.uint32) != want_depth.view(np.uint32))[0]
+        assert len(bad) == 0, "cascade %d: %d texels differ, first %d: %r vs %r" % (k, len(bad), bad[0], got_depth[bad[0]], want_depth[bad[0]])
+        assert r.depth_view_stats()["overflow"] == 0
+        if k != 0:
+            prev_hzb_gpu = r.build_hzb_from_depth(target)
+            mn, _, _ = r.read_hzb(prev_hzb_gpu)
+            words = want_depth.view(np.uint32).astype(np.uint64) << np.uint64(32)
+            _, prev_hzb, _, _ = orc.hzb_build(words, dim, dim)
+            for lv in range(desc.mipCount):
+                w_, h_ = desc.mip_dims(lv); vw, vh = desc.valid_dims(lv)
+                a = mn[desc.mipOffset[lv]: desc.mipOffset[lv] + w_ * h_].reshape(h_, w_)[:vh, :vw]
+                b = prev_hzb[desc.mipOffset[lv]: desc.mipOffset[lv] + w_ * h_].reshape(h_, w_)[:vh, :vw]
+                assert np.array_equal(a, b), "cascade %d: HZB mip %d" % (k, lv)
+    # the main view is untouched by the depth passes
+    r.render_frame()
+    want = orc.frame(scene, view, iv, flags)
+    H.assert_vis_equal(r.read_visibility(), want["vis"], cam.width, cam.height, "main view after the shadow passes")
+    r.close()
