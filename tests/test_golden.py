@@ -20,7 +20,12 @@ def load_gold():
     scene = R.Scene(g["objects"].view(R.OBJECT), g["primitives"].view(R.PRIMITIVE), g["materials"].view(R.MATERIAL),
                     g["meshlets"].view(R.MESHLET), g["groups"].view(R.MESHLET_GROUP), g["group_indices"],
                     g["meshlet_data"], g["positions"], name="config1_golden")
-    view = g["view"].view(R.CAMERA_VIEW).copy()
+    # (the fixture predates ChordCameraView::clipToTranslatedWorldWithZFar_NoJitter, a trailing field only the cascade
+    # setup reads: the stored record is the prefix of today's)
+    raw = np.zeros(R.CAMERA_VIEW.itemsize, dtype=np.uint8)
+    stored = g["view"].view(np.uint8).reshape(-1)
+    raw[:len(stored)] = stored
+    view = raw.view(R.CAMERA_VIEW).copy()
     iv = g["iv"].view(R.INSTANCE_CULLING_VIEW).copy()
     return g, scene, view, iv, int(g["flags"])
 
@@ -50,7 +55,8 @@ def test_generator_and_host_camera_reproduce_golden_inputs():
     assert np.array_equal(scene.meshlet_data, gscene.meshlet_data)
     assert np.array_equal(scene.groups.view(np.uint8), gscene.groups.view(np.uint8))
     assert np.array_equal(scene.objects.view(np.uint8), gscene.objects.view(np.uint8))
-    assert np.array_equal(view.view(np.uint8), gview.view(np.uint8))
+    stored = len(g["view"].view(np.uint8).reshape(-1))                  # the fixture holds the record as it was when committed (a prefix)
+    assert np.array_equal(view.view(np.uint8).reshape(-1)[:stored], gview.view(np.uint8).reshape(-1)[:stored])
     assert np.array_equal(iv.view(np.uint8), giv.view(np.uint8))
 
 
