@@ -16,6 +16,7 @@
 #include "device_layer.h"
 
 #include <cstring>
+#include <vector>
 
 using namespace chord;
 
@@ -111,16 +112,24 @@ int chordvis_instance_culling_view(ChordCtx* c, uint32_t instanceViewOffset, Cho
     return CHORDVIS_OK;
 }
 
+static int generic_cull(ChordCtx* c, const ChordHZB* hzb, float extentScale, const ChordInstanceCullingView& iv,
+                        int bObjectUseLastFrameProject, ChordCountAndCmd in, ChordCountAndCmd* out);
+
 int chordvis_hzb_culling_generic(ChordCtx* c, const ChordHZB* hzb, float extentScale, uint32_t instanceViewOffset,
                                  int bObjectUseLastFrameProject, ChordCountAndCmd in, ChordCountAndCmd* out)
 {
     int rc = need_child(c, "hzb_culling_generic");
     if (rc) return rc;
-    if (!hzb || !hzb->minTexels || !in.count || !in.cmds || !out) return fail(c, CHORDVIS_E_INVALID, "hzb_culling_generic: invalid HZB or command list");
     if (instanceViewOffset >= c->instanceViews.size()) return fail(c, CHORDVIS_E_INVALID, "hzb_culling_generic: instanceViewOffset beyond set_instance_views");
+    return generic_cull(c, hzb, extentScale, c->instanceViews[instanceViewOffset], bObjectUseLastFrameProject, in, out);
+}
+
+static int generic_cull(ChordCtx* c, const ChordHZB* hzb, float extentScale, const ChordInstanceCullingView& iv,
+                        int bObjectUseLastFrameProject, ChordCountAndCmd in, ChordCountAndCmd* out)
+{
+    if (!hzb || !hzb->minTexels || !in.count || !in.cmds || !out) return fail(c, CHORDVIS_E_INVALID, "hzb_culling_generic: invalid HZB or command list");
     ChordCtx* k = c->depthCtx;
     if (in.cmds == k->lists[1].cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling_generic: input aliases the output list");
-    const ChordInstanceCullingView& iv = c->instanceViews[instanceViewOffset];
     double mainCam[3], viewCam[3];
     double3_of(c->hView.iv.cameraWorldPos, mainCam);      // perView.cameraWorldPos (renderer.cpp:251-263 copies it into the main view's info)
     double3_of(iv.cameraWorldPos, viewCam);
@@ -175,6 +184,71 @@ int chordvis_readback_depth(ChordCtx* c, const ChordDepthTarget* depth, float* h
     if (!c || !depth || !depth->depth || !host) return fail(c, CHORDVIS_E_INVALID, "readback_depth: null argument");
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
     CHORD_HIP(c, hipMemcpy(host, depth->depth, sizeof(float) * (size_t)depth->width * depth->height, hipMemcpyDeviceToHost));
+    return CHORDVIS_OK;
+}
+
+// renderShadow -- mesh_raster.cpp:331-546.  The cascades' depth images and views live in the context from call to call
+// (CascadeShadowHistory, extractCascadeShadowHistory :548-563); a cascade whose cache is valid this tick is left alone.
+int chordvis_render_shadow(ChordCtx* c, const ChordCascadeConfig* cfg, const float lightDir[3], const uint32_t validDepthMinMax[2],
+                           uint32_t tickCount, int bHzbCulling, ChordDepthTarget* outDepths, ChordInstanceCullingView* outViews,
+                           uint32_t* outRenderedMask)
+{
+    if (!c || !cfg || !lightDir) return fail(c, CHORDVIS_E_INVALID, "render_shadow: null argument");
+    if (!c->viewSet || !c->sceneLoaded) return fail(c, CHORDVIS_E_INVALID, "render_shadow: upload_scene and set_view (the main camera) must come first");
+    if (cfg->cascadeCount < 1 || (uint32_t)cfg->cascadeCount > CHORD_MAX_CASCADES || cfg->realtimeCascadeCount < 0 || cfg->realtimeCascadeCount > cfg->cascadeCount)
+        return fail(c, CHORDVIS_E_INVALID, "render_shadow: cascade counts out of range");
+    const uint32_t count = (uint32_t)cfg->cascadeCount, realtime = (uint32_t)cfg->realtimeCascadeCount;
+    int rc;
+    // bCacheValid (:367-371): depth images exist, same direction, same config
+    const bool sameCfg = c->shadowHistoryValid && std::memcmp(&c->shadowHistoryConfig, cfg, sizeof(*cfg)) == 0 &&
+                         std::memcmp(c->shadowHistoryDir, lightDir, sizeof(float) * 3) == 0 &&
+                         c->depthCtx && c->depthDim == cfg->cascadeDim && c->dDepthImages.size() == count;
+    const bool bCacheValid = sameCfg;
+    if (!c->depthCtx || c->depthDim != cfg->cascadeDim || c->dDepthImages.size() != count) {
+        if ((rc = chordvis_allocate_depth_views(c, cfg->cascadeDim, count))) return rc;
+    }
+    auto cacheValid = [&](uint32_t cascadeId) {                                       // isCascadeCacheValid, cascade_setup.hlsl:8-22
+        if (!bCacheValid || cascadeId < realtime) return false;
+        return (tickCount % (count - realtime)) != (cascadeId - realtime);
+    };
+    // cascade setup pass (:417-441): last frame's views stay in place where the cache holds
+    std::vector<ChordInstanceCullingView> historyViews = c->instanceViews;
+    if (c->instanceViews.size() != count) c->instanceViews.assign(count, ChordInstanceCullingView{});
+    if ((rc = chordvis_cascade_setup(cfg, &c->hView.view, &c->hView.iv, lightDir, validDepthMinMax, tickCount, bCacheValid ? 1 : 0, c->instanceViews.data())))
+        return fail(c, rc, "render_shadow: cascade setup");
+    ChordHZB prevHzb;
+    std::memset(&prevHzb, 0, sizeof(prevHzb));
+    bool havePrev = false;
+    uint32_t prevCascade = 0, rendered = 0;
+    for (int32_t cascadeId = (int32_t)count - 1; cascadeId >= 0; cascadeId--) {       // :443-531
+        if (cacheValid((uint32_t)cascadeId)) continue;
+        ChordCountAndCmd list;
+        if ((rc = chordvis_instance_culling_view(c, (uint32_t)cascadeId, &list))) return rc;
+        if (!havePrev) {
+            // the first cascade rendered this tick: cull against the HZB of its own cached depth, seen from last frame's view (:457-480)
+            if (bCacheValid && bHzbCulling && historyViews.size() == count) {
+                ChordDepthTarget hist = {c->dDepthImages[cascadeId], c->depthDim, c->depthDim};
+                ChordHZB hzb;
+                if ((rc = chordvis_build_hzb_from_depth(c, &hist, &hzb))) return rc;
+                if ((rc = generic_cull(c, &hzb, 1.5f, historyViews[cascadeId], 0, list, &list))) return rc;   // sShadowExtentScaleForHZBCulling, :35
+            }
+        } else if (bHzbCulling) {
+            if ((rc = generic_cull(c, &prevHzb, 1.5f, c->instanceViews[prevCascade], 0, list, &list))) return rc;   // :484-497
+        }
+        ChordDepthTarget target;
+        if ((rc = chordvis_render_mesh_depth(c, (uint32_t)cascadeId, 1, cfg->shadowBiasConst, cfg->shadowBiasSlope, list, &target))) return rc;
+        rendered |= 1u << cascadeId;
+        if (cascadeId != 0) {                                                         // :525-529
+            if ((rc = chordvis_build_hzb_from_depth(c, &target, &prevHzb))) return rc;
+            havePrev = true; prevCascade = (uint32_t)cascadeId;
+        }
+    }
+    c->shadowHistoryValid = true;                                                     // extractCascadeShadowHistory
+    c->shadowHistoryConfig = *cfg;
+    std::memcpy(c->shadowHistoryDir, lightDir, sizeof(float) * 3);
+    if (outDepths) for (uint32_t i = 0; i < count; i++) outDepths[i] = ChordDepthTarget{c->dDepthImages[i], c->depthDim, c->depthDim};
+    if (outViews) std::memcpy(outViews, c->instanceViews.data(), sizeof(ChordInstanceCullingView) * count);
+    if (outRenderedMask) *outRenderedMask = rendered;
     return CHORDVIS_OK;
 }
 

@@ -227,6 +227,9 @@ struct ChordCtx {
     bool sharedScene = false;         // this IS such a child: the scene buffers belong to the parent
     std::vector<float*> dDepthImages; // one D32 image per view (cascadeDim^2 floats)
     uint32_t depthDim = 0;
+    bool shadowHistoryValid = false;  // CascadeShadowHistory (mesh_raster.cpp:548-563): config + light direction of the cached cascades
+    ChordCascadeConfig shadowHistoryConfig{};
+    float shadowHistoryDir[3] = {0, 0, 0};
     int depthViewCurrent = -1;        // (child) the view whose object matrices dObjFrame holds
     std::vector<ChordInstanceCullingView> instanceViews;   // chordvis_set_instance_views (cascadeViewInfos)
     ChordObject* dObjectsOwned = nullptr;

@@ -172,6 +172,7 @@ def _load():
         "chordvis_build_hzb_from_depth": (i32, [vp, P(DepthTarget), P(HZB)]),
         "chordvis_readback_depth": (i32, [vp, P(DepthTarget), vp]),
         "chordvis_depth_view_stats": (i32, [vp, P(Stats)]),
+        "chordvis_render_shadow": (i32, [vp, vp, vp, vp, u32, i32, vp, vp, P(u32)]),
         "chordvis_enable_timers": (i32, [vp, i32]),
         "chordvis_stats": (i32, [vp, P(Stats)]),
         "chordvis_set_debug": (i32, [vp, u32]),

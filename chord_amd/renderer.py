@@ -205,6 +205,18 @@ class VisibilityRenderer:
         self._check(L.lib.chordvis_readback_depth(self._ctx, C.byref(depth), out.ctypes.data), "readback_depth")
         return out
 
+    def render_shadow(self, config, light_dir, tick, valid_range=None, hzb_culling=True):
+        """renderShadow: returns (depth targets, views, mask of the cascades re-rendered by this call)."""
+        n = int(config["cascadeCount"][0])
+        depths = (L.DepthTarget * n)()
+        views = np.zeros(n, dtype=R.INSTANCE_CULLING_VIEW)
+        ld = np.asarray(light_dir, dtype=np.float32)
+        vr = None if valid_range is None else np.asarray(valid_range, dtype=np.uint32)
+        mask = C.c_uint32(0)
+        self._check(L.lib.chordvis_render_shadow(self._ctx, config.ctypes.data, ld.ctypes.data, vr.ctypes.data if vr is not None else None,
+                                                 int(tick), int(hzb_culling), depths, views.ctypes.data, C.byref(mask)), "render_shadow")
+        return list(depths), views, mask.value
+
     def depth_view_stats(self):
         st = L.Stats()
         self._check(L.lib.chordvis_depth_view_stats(self._ctx, C.byref(st)), "depth_view_stats")

@@ -324,6 +324,16 @@ int chordvis_render_mesh_depth(ChordCtx* ctx, uint32_t instanceViewOffset, int b
 /* buildHZB(queue, depth, true, false, false) on a depth target (mesh_raster.cpp:466,527) */
 int chordvis_build_hzb_from_depth(ChordCtx* ctx, const ChordDepthTarget* depth, ChordHZB* out);
 int chordvis_readback_depth(ChordCtx* ctx, const ChordDepthTarget* depth, float* host);
+/* renderShadow (mesh_raster.cpp:331-546): cascade setup, then per cascade from the farthest to the nearest: instanceCulling for
+ * its view, hzbCullingGeneric against the previous cascade's HZB (or, for the first one, against the HZB of its own cached
+ * depth from last frame's view), clear + renderMeshDepth with depth clamp and the configured bias, buildHZB.  The context
+ * keeps the depth images and views from call to call (CascadeShadowHistory): with an unchanged config and light direction
+ * the far cascades are refreshed one per tick (isCascadeCacheValid, cascade_setup.hlsl:8-22).  validDepthMinMax: the
+ * valid range of the main view's last buildHZB (chordvis_readback_hzb) or NULL.  outRenderedMask: bit i = cascade i was
+ * re-rendered by this call. */
+int chordvis_render_shadow(ChordCtx* ctx, const ChordCascadeConfig* config, const float lightDir[3], const uint32_t validDepthMinMax[2],
+                           uint32_t tickCount, int bHzbCulling, ChordDepthTarget* outDepths /* [cascadeCount] or NULL */,
+                           ChordInstanceCullingView* outViews /* [cascadeCount] or NULL */, uint32_t* outRenderedMask);
 /* chordvis_stats of the depth views' last pass (overflow flag, record / bin counts) */
 int chordvis_depth_view_stats(ChordCtx* ctx, ChordStats* out);
 

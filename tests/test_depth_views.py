@@ -158,3 +158,72 @@ def test_cascade_depth_passes_match_oracle(gpu, dim, bias):
     want = orc.frame(scene, view, iv, flags)
     H.assert_vis_equal(r.read_visibility(), want["vis"], cam.width, cam.height, "main view after the shadow passes")
     r.close()
+
+
+def _replay_shadow(scene, view, iv, cfg, tick, hist, flags, hzb_culling=True):
+    """renderShadow (mesh_raster.cpp:331-546) replayed with the oracle's pieces.  hist: {"depths", "views"} or None."""
+    n, realtime, dim = int(cfg["cascadeCount"][0]), int(cfg["realtimeCascadeCount"][0]), int(cfg["cascadeDim"][0])
+    cache = hist is not None
+    views = L.cascade_setup(cfg, view, iv, LIGHT, tick=tick, cache_valid=cache, views=None if hist is None else hist["views"].copy())
+    depths = [None] * n if hist is None else list(hist["depths"])
+    desc = orc.hzb_desc(dim, dim)
+    campos = np.frombuffer(iv["cameraWorldPos"][0].tobytes(), dtype=np.float64)[:3]
+
+    def cache_valid(k):
+        return cache and k >= realtime and (tick % (n - realtime)) != (k - realtime)
+
+    def hzb_of(depth):
+        return orc.hzb_build(depth.view(np.uint32).astype(np.uint64) << np.uint64(32), dim, dim)[1]
+
+    prev, prev_k, rendered = None, None, 0
+    for k in range(n - 1, -1, -1):
+        if cache_valid(k):
+            continue
+        cmds = orc.instance_culling(scene, view, views[k:k + 1], flags)
+        if prev is None:
+            if cache and hzb_culling:
+                cmds = orc.hzb_culling_generic(scene, hist["views"][k:k + 1], campos, flags, 1.5, False, desc, hzb_of(hist["depths"][k]), cmds)
+        elif hzb_culling:
+            cmds = orc.hzb_culling_generic(scene, views[prev_k:prev_k + 1], campos, flags, 1.5, False, desc, prev, cmds)
+        depths[k], _ = orc.raster_depth(scene, views[k:k + 1], cmds, dim, dim, True, float(cfg["shadowBiasConst"][0]), float(cfg["shadowBiasSlope"][0]))
+        rendered |= 1 << k
+        if k != 0:
+            prev, prev_k = hzb_of(depths[k]), k
+    return {"depths": depths, "views": views}, rendered
+
+
+@pytest.mark.gpu
+def test_render_shadow_with_cascade_cache_matches_the_replay(gpu):
+    """chordvis_render_shadow over five ticks: the first renders every cascade, the following ones the realtime cascades
+    plus one far cascade per tick (isCascadeCacheValid), each first culled against the HZB of its own cached depth; the
+    camera moves on the last two ticks.  Every cascade's depth image and view against the oracle replay, every tick."""
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam0 = scenes.masked_test_scene(320, 200)
+    cfg = R.default_cascade_config(cascadeCount=5, realtimeCascadeCount=2, cascadeDim=384, cascadeEndDistance=12.0, farCascadeEndDistance=60.0,
+                                   shadowBiasConst=-8.0, shadowBiasSlope=-0.5)
+    flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | R.FLAG_HZB_CULL
+    r = VisibilityRenderer(0)
+    r.upload_scene(scene)
+    r.allocate_gbuffer(cam0.width, cam0.height)
+    hist = None
+    f = np.array(cam0.front, dtype=np.float64); f /= np.linalg.norm(f)
+    masks = []
+    for tick in range(5):
+        cam = cam0 if tick < 3 else cam0.moved(tuple(0.4 * (tick - 2) * f))
+        objs = L.fill_objects(scene, cam).copy()
+        view, iv = L.make_views(cam)
+        r.update_objects(objs)
+        r.set_view(view, iv, flags)
+        depths, views, mask = r.render_shadow(cfg, LIGHT, tick)
+        hist, want_mask = _replay_shadow(scene.with_objects(objs), view, iv, cfg, tick, hist, flags)
+        masks.append(mask)
+        assert mask == want_mask, "tick %d: rendered cascades %s vs %s" % (tick, bin(mask), bin(want_mask))
+        assert np.array_equal(views.view(np.uint8), hist["views"].view(np.uint8)), "tick %d: cascade views" % tick
+        for k in range(5):
+            got = r.read_depth(depths[k])
+            assert np.array_equal(got.view(np.uint32), hist["depths"][k].view(np.uint32)), "tick %d cascade %d" % (tick, k)
+    assert masks[0] == 0b11111 and masks[1:] == [0b00011 | (1 << (2 + t % 3)) for t in range(1, 5)]
+    # a new light direction invalidates the cache: everything is rendered again
+    _, _, mask = r.render_shadow(cfg, (0.1, -1.0, -0.4), 5)
+    assert mask == 0b11111
+    r.close()
