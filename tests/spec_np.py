@@ -1,0 +1,227 @@
+"""An independent restatement of SURVEY.md Appendix A, stages A1-A4 (object cull, group LOD cut + meshlet cull, HZB
+occlusion test, HZB build), written from that text in vectorised numpy float32 -- not from oracle/oracle.c, whose
+structure (scalar loops, per-command) it deliberately does not share.  tests/test_spec_np.py requires both to agree
+bit for bit; a slip in either restatement of the HLSL shows up as a difference.  TEST INFRASTRUCTURE.
+
+Arithmetic: numpy float32 array operations round every + - * / sqrt separately (no contraction), which is the canonical
+arithmetic of SURVEY 8c.  Matrices are stored glm column-major: M[r][c] = m[c * 4 + r]."""
+import numpy as np
+
+f32 = np.float32
+# kExtentApplyFactor (base.hlsli:184-194)
+EXTENT = np.array([[1, 1, 1], [-1, -1, -1], [1, 1, -1], [1, -1, 1], [-1, 1, 1], [1, -1, -1], [-1, -1, 1], [-1, 1, -1]], dtype=f32)
+
+
+def mat(m16):
+    """(..., 16) glm column-major -> (..., 4, 4) indexed [r][c]"""
+    return np.swapaxes(np.asarray(m16, dtype=f32).reshape(m16.shape[:-1] + (4, 4)), -1, -2)
+
+
+def mul_mm(A, B):
+    """mul(A, B)[r][c] = ((A[r][0]*B[0][c] + A[r][1]*B[1][c]) + A[r][2]*B[2][c]) + A[r][3]*B[3][c]"""
+    out = np.empty(np.broadcast_shapes(A.shape, B.shape), dtype=f32)
+    for r in range(4):
+        for c in range(4):
+            out[..., r, c] = ((A[..., r, 0] * B[..., 0, c] + A[..., r, 1] * B[..., 1, c]) + A[..., r, 2] * B[..., 2, c]) + A[..., r, 3] * B[..., 3, c]
+    return out
+
+
+def mul_mv(M, x, y, z, w=f32(1.0)):
+    """mul(M, v) rows: ((M[r][0]*v0 + M[r][1]*v1) + M[r][2]*v2) + M[r][3]*v3  -> (..., 4)"""
+    return np.stack([((M[..., r, 0] * x + M[..., r, 1] * y) + M[..., r, 2] * z) + M[..., r, 3] * w for r in range(4)], axis=-1)
+
+
+def dot3(a, b):
+    return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+
+
+def corners(pmin, pmax):
+    """c = (posMin + posMax) * 0.5, e = posMax - c, the eight corners c + e * s_k  -> (..., 8, 3)"""
+    c = (pmin + pmax) * f32(0.5)
+    e = pmax - c
+    return c[..., None, :] + e[..., None, :] * EXTENT
+
+
+def project_uvz(p, M):
+    """projectPosToUVz: clip / w, then xy * (0.5, -0.5) + 0.5"""
+    h = mul_mv(M, p[..., 0], p[..., 1], p[..., 2])
+    x, y, z = h[..., 0] / h[..., 3], h[..., 1] / h[..., 3], h[..., 2] / h[..., 3]
+    return np.stack([x * f32(0.5) + f32(0.5), y * f32(-0.5) + f32(0.5), z], axis=-1)
+
+
+def box_culled(planes, pmin, pmax, M, MVP):
+    """A1's test of one box per row: True = culled.  Orthographic (MVP[3][3] == 1): culled iff the projected rectangle misses
+    the unit square; else iff all eight corners are behind one of the six planes (dot(n, p) > -d means in front)."""
+    P = corners(pmin, pmax)                                                   # (N, 8, 3)
+    ortho = MVP[..., 3, 3] == f32(1.0)
+    with np.errstate(all="ignore"):
+        uvz = project_uvz(P, MVP[..., None, :, :])
+        mn, mx = uvz.min(axis=-2), uvz.max(axis=-2)
+        mn = np.minimum(mn, f32(10.0)); mx = np.maximum(mx, f32(-10.0))       # the shader's running min / max start at +-10
+        ortho_culled = (mn[..., 0] >= 1) | (mn[..., 1] >= 1) | (mx[..., 0] <= 0) | (mx[..., 1] <= 0)
+    h = mul_mv(M[..., None, :, :], P[..., 0], P[..., 1], P[..., 2])[..., :3]  # corners in relative world space
+    d = (planes[None, :, None, 0] * h[:, None, :, 0] + planes[None, :, None, 1] * h[:, None, :, 1]) + planes[None, :, None, 2] * h[:, None, :, 2]
+    behind_all = (~(d > -planes[None, :, None, 3])).all(axis=-1)              # (N, 6)
+    persp_culled = behind_all.any(axis=-1)
+    return np.where(ortho, ortho_culled, persp_culled)
+
+
+def projected_error(K, l2v, scale, center, radius):
+    """px(center, r) of A2: -1 when the eye is inside the (scaled) sphere, else K * R / sqrt(d2 - R^2)"""
+    q = mul_mv(l2v, center[..., 0], center[..., 1], center[..., 2])
+    with np.errstate(all="ignore"):                                           # (un-parented groups carry FLT_MAX radii)
+        R = scale * radius
+        d2 = dot3(q, q)
+        r2 = R * R
+        px = K * R / np.sqrt(d2 - r2)
+    return np.where(d2 <= r2, f32(-1.0), px)
+
+
+def instance_culling(scene, view, iv, flags):
+    """A1 + A2: the command list (objectId, meshletId, slot) in (object, group, meshlet-in-group) order."""
+    O = scene.objects
+    prim = scene.primitives[O["GLTFPrimitiveDetail"]]
+    two_sided = scene.materials["bTwoSided"][O["GLTFMaterialData"]] != 0
+    M = mat(O["localToTranslatedWorld"])
+    VP = mat(iv["translatedWorldToClip"])[0]
+    MVP = mul_mm(VP, M)
+    planes = iv["frustumPlanesRS"][0].astype(f32)
+    obj_vis = np.ones(len(O), bool)
+    if flags & 1:
+        obj_vis = ~box_culled(planes, prim["posMin"].astype(f32), prim["posMax"].astype(f32), M, MVP)
+    # flatten (object, group)
+    counts = np.where(obj_vis, prim["meshletGroupCount"], 0).astype(np.int64)
+    owner = np.repeat(np.arange(len(O)), counts)
+    if len(owner) == 0:
+        return np.zeros(0, dtype=[("objectId", np.uint32), ("meshletId", np.uint32), ("slot", np.uint32)])
+    gi = np.arange(len(owner)) - np.repeat(np.cumsum(counts) - counts, counts)
+    g = scene.groups[prim["meshletGroupOffset"][owner].astype(np.int64) + gi]
+    V = mat(view["translatedWorldToView"])[0]
+    l2v = mul_mm(V, M)[owner]
+    scale = O["scaleExtractFromMatrix"][owner, 3].astype(f32)
+    K = f32(view["lodScale"][0])
+    pe = projected_error(K, l2v, scale, g["parentPosCenter"].astype(f32), g["parentError"].astype(f32))
+    er = projected_error(K, l2v, scale, g["clusterPosCenter"].astype(f32), g["error"].astype(f32))
+    parent_ok = (g["parentError"] > f32(3e38)) | ~((pe > 0) & (pe <= 1))
+    self_ok = (g["error"] < f32(-0.5)) | ((er >= 0) & (er <= 1))
+    keep = parent_ok & self_ok
+    owner, g = owner[keep], g[keep]
+    # meshlets of the kept groups (<= 4 each), in group order
+    mc = g["meshletCount"].astype(np.int64)
+    gowner = np.repeat(owner, mc)
+    k = np.arange(len(gowner)) - np.repeat(np.cumsum(mc) - mc, mc)
+    p2 = scene.primitives[O["GLTFPrimitiveDetail"][gowner]]
+    idx = p2["meshletGroupIndicesOffset"].astype(np.int64) + np.repeat(g["meshletOffset"].astype(np.int64), mc) + k
+    mid = p2["meshletOffset"].astype(np.int64) + scene.group_indices[idx]
+    m = scene.meshlets[mid]
+    vis = np.ones(len(mid), bool)
+    if flags & 4:                                                             # cone (one-sided materials only)
+        W2L = mat(O["translatedWorldToLocal"])[gowner]
+        cam = mul_mv(W2L, f32(0), f32(0), f32(0))[..., :3]
+        v = m["coneApex"].astype(f32) - cam
+        with np.errstate(all="ignore"):
+            n = v / np.sqrt(dot3(v, v))[..., None]
+            cone_culled = dot3(n, m["coneAxis"].astype(f32)) >= m["coneCutOff"].astype(f32)
+        vis &= ~(cone_culled & ~two_sided[gowner])
+    if flags & 1:
+        vis &= ~box_culled(planes, m["posMin"].astype(f32), m["posMax"].astype(f32), M[gowner], MVP[gowner])
+    out = np.zeros(int(vis.sum()), dtype=[("objectId", np.uint32), ("meshletId", np.uint32), ("slot", np.uint32)])
+    out["objectId"], out["meshletId"] = gowner[vis], mid[vis]
+    out["slot"] = np.arange(len(out))
+    return out
+
+
+def f16_bits(x):
+    return np.asarray(x, dtype=f32).astype(np.float16).view(np.uint16)       # IEEE round-to-nearest-even
+
+
+def hzb_layout(W, H):
+    """A4 / hzb.cpp:49-63: mip-0 extent, level count, offsets"""
+    def npot(v):
+        return 1 << (int(v) - 1).bit_length()
+    w0, h0 = npot(W) // 2, npot(H) // 2
+    if w0 == W:
+        w0 //= 2
+    if h0 == H:
+        h0 //= 2
+    w0, h0 = max(w0, 1), max(h0, 1)
+    levels = int(np.floor(np.log2(max(w0, h0)))) + 1
+    dims = [(max(1, w0 >> l), max(1, h0 >> l)) for l in range(levels)]
+    offs = np.concatenate([[0], np.cumsum([w * h for w, h in dims])])
+    return dims, offs
+
+
+def hzb_build(depth, W, H, want_max=False):
+    """A4: texel (x, y) of mip l = min (max) over the 2^(l+1) square of edge-clamped source depth, as binary16; max chain
+    +1 ulp from mip 5 up.  Only texels inside the image are defined; returned per level as (min, max) float16-bit arrays
+    cut to the valid extent ((W-1)>>1>>l)+1."""
+    depth = np.asarray(depth, dtype=f32).reshape(H, W)
+    dims, offs = hzb_layout(W, H)
+    out = []
+    for l, (mw, mh) in enumerate(dims):
+        s = 2 ** (l + 1)
+        vw, vh = min(mw, (((W - 1) >> 1) >> l) + 1), min(mh, (((H - 1) >> 1) >> l) + 1)
+        ys = np.minimum(np.arange(vh)[:, None] * s + np.arange(s)[None, :], H - 1)       # (vh, s) clamped rows
+        xs = np.minimum(np.arange(vw)[:, None] * s + np.arange(s)[None, :], W - 1)
+        blk = depth[ys[:, None, :, None], xs[None, :, None, :]]                           # (vh, vw, s, s)
+        mn = f16_bits(blk.min(axis=(2, 3)))
+        mx = None
+        if want_max:
+            # the +1 ulp is applied when mip 5 is STORED and every coarser level reduces the stored halves
+            if l < 5:
+                mx = f16_bits(blk.max(axis=(2, 3)))
+            elif l == 5:
+                mx = (f16_bits(blk.max(axis=(2, 3))).astype(np.uint32) + 1).astype(np.uint16)
+            else:
+                prev = out[-1][1].view(np.float16).astype(f32)
+                ph, pw = prev.shape
+                yy = np.minimum(np.arange(vh)[:, None] * 2 + np.arange(2)[None, :], ph - 1)
+                xx = np.minimum(np.arange(vw)[:, None] * 2 + np.arange(2)[None, :], pw - 1)
+                mx = f16_bits(prev[yy[:, None, :, None], xx[None, :, None, :]].max(axis=(2, 3)))
+        out.append((mn, mx))
+    return dims, offs, out
+
+
+def hzb_visible(scene, view, cmds, phase, hzb_levels, dims):
+    """A3 for every command: True = visible.  hzb_levels[l] = float16-bit array of the valid extent of mip l (min chain)."""
+    O = scene.objects[cmds["objectId"]]
+    prim = scene.primitives[O["GLTFPrimitiveDetail"]]
+    m = scene.meshlets[cmds["meshletId"]]
+    if phase == 0:
+        MVP = mul_mm(mat(view["translatedWorldToClipLastFrame"])[0], mat(O["localToTranslatedWorldLastFrame"]))
+    else:
+        MVP = mul_mm(mat(view["translatedWorldToClip"])[0], mat(O["localToTranslatedWorld"]))
+    P = corners(m["posMin"].astype(f32), m["posMax"].astype(f32))
+    with np.errstate(all="ignore"):
+        uvz = project_uvz(P, MVP[:, None])
+        mn = np.minimum(uvz.min(axis=1), f32(10.0)); mx = np.maximum(uvz.max(axis=1), f32(-10.0))
+    in_range = (mx[:, 2] < 1) & (mn[:, 2] > 0)
+    off_screen = in_range & ((mn[:, 0] >= 1) | (mn[:, 1] >= 1) | (mx[:, 0] <= 0) | (mx[:, 1] <= 0))
+    W, H = f32(view["renderDimension"][0, 0]), f32(view["renderDimension"][0, 1])
+    visible = ~off_screen
+    test = visible & in_range
+    sat = lambda a: np.minimum(np.maximum(a, f32(0)), f32(1))
+    with np.errstate(all="ignore"):
+        rx = (sat(mn[:, 0]) * W + f32(0.5)).astype(np.int32); ry = (sat(mn[:, 1]) * H + f32(0.5)).astype(np.int32)
+        rz = (sat(mx[:, 0]) * W + f32(-0.5)).astype(np.int32); rw = (sat(mx[:, 1]) * H + f32(-0.5)).astype(np.int32)
+    rx, ry = np.maximum(rx, 0), np.maximum(ry, 0)
+    rz = np.minimum(W - f32(1), rz.astype(f32)).astype(np.int32); rw = np.minimum(H - f32(1), rw.astype(f32)).astype(np.int32)
+    empty = (rz < rx) | (rw < ry)
+    for i in np.nonzero(test)[0]:
+        if empty[i]:
+            visible[i] = False
+            continue
+        x0, y0, x1, y1 = rx[i] >> 1, ry[i] >> 1, rz[i] >> 1, rw[i] >> 1
+        fbh = lambda v: int(v).bit_length() - 1                                # firstbithigh, -1 for 0
+        lv = max(0, max(fbh(x1 - x0), fbh(y1 - y0)) - 1)
+        if ((x1 >> lv) - (x0 >> lv) >= 4) or ((y1 >> lv) - (y0 >> lv) >= 4):
+            lv += 1
+        cx, cy, cz, cw = x0 >> lv, y0 >> lv, x1 >> lv, y1 >> lv
+        tex = hzb_levels[lv].view(np.float16)
+        zmin = f32(10.0)
+        for xx in range(4):
+            for yy in range(4):
+                zmin = min(zmin, f32(tex[min(cw, cy + yy), min(cz, cx + xx)]))
+        if zmin > mx[i, 2]:
+            visible[i] = False
+    return visible
