@@ -106,6 +106,11 @@ def _load():
         "chordvis_cascade_setup": (i32, [vp, vp, vp, vp, vp, u32, i32, vp]),
         "chordvis_object_basic_data": (i32, [vp, vp, vp, vp, vp]),
         "chordvis_object_basic_data_batch": (i32, [u32, vp, vp, vp, vp, vp]),
+        "chordvis_nanite_build": (i32, [vp, u32, vp, u32, vp, P(vp)]),
+        "chordvis_built_asset_desc": (i32, [vp, P(R.AssetDesc), vp, P(u32)]),
+        "chordvis_free_built_asset": (None, [vp]),
+        "chordvis_save_asset": (i32, [vp, C.c_char_p]),
+        "chordvis_load_asset": (i32, [C.c_char_p, P(vp)]),
         "chordvis_create": (i32, [i32, vp, P(vp)]),
         "chordvis_destroy": (i32, [vp]),
         "chordvis_last_error": (C.c_char_p, [vp]),
@@ -251,3 +256,41 @@ def cascade_setup(config, view, main_iv, light_dir, valid_range=None, tick=0, ca
     if rc != OK:
         raise ChordvisError("chordvis_cascade_setup -> %d" % rc)
     return views
+
+
+class BuiltAsset:
+    """chordvis_nanite_build: meshlets / groups / BVH of a triangle mesh as numpy copies (the native object is freed)."""
+
+    def __init__(self, handle):
+        ad, prim, lods = R.AssetDesc(), np.zeros(1, dtype=R.PRIMITIVE), C.c_uint32(0)
+        rc = lib.chordvis_built_asset_desc(handle, C.byref(ad), prim.ctypes.data, C.byref(lods))
+        if rc != OK:
+            raise ChordvisError("chordvis_built_asset_desc -> %d" % rc)
+
+        def arr(ptr, n, dt):
+            return np.frombuffer((C.c_uint8 * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy() if n else np.zeros(0, dtype=dt)
+        self.meshlets = arr(ad.meshlets, ad.meshletCount, R.MESHLET)
+        self.groups = arr(ad.meshletGroups, ad.meshletGroupCount, R.MESHLET_GROUP)
+        self.group_indices = arr(ad.meshletGroupIndices, ad.meshletGroupIndexCount, np.uint32)
+        self.meshlet_data = arr(ad.meshletData, ad.meshletDataCount, np.uint32)
+        self.positions = arr(ad.positions, ad.vertexCount * 3, np.float32).reshape(-1, 3)
+        self.texcoord0 = arr(ad.texcoord0, ad.texcoord0Count * 2, np.float32).reshape(-1, 2) if ad.texcoord0 else None
+        self.bvh_nodes = arr(ad.bvhNodes, ad.bvhNodeCount, R.BVH_NODE)
+        self.primitive = prim
+        self.lod_count = lods.value
+
+
+def nanite_build(positions, indices, texcoord0=None, keep_handle=False):
+    pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+    uv = None if texcoord0 is None else np.ascontiguousarray(texcoord0, dtype=np.float32).reshape(-1, 2)
+    h = C.c_void_p()
+    rc = lib.chordvis_nanite_build(pos.ctypes.data, len(pos), idx.ctypes.data, len(idx), uv.ctypes.data if uv is not None else None, C.byref(h))
+    if rc != OK:
+        raise ChordvisError("chordvis_nanite_build -> %d" % rc)
+    if keep_handle:
+        return h
+    try:
+        return BuiltAsset(h)
+    finally:
+        lib.chordvis_free_built_asset(h)

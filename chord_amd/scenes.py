@@ -677,6 +677,52 @@ def masked_floor_under_camera(position=(0.3, 0.25, 0.2), front=(0.1, -0.6, -1.0)
     return sb.build(), Camera(position, front, width, height)
 
 
+def bumpy_sphere_mesh(n=96, seed=1):
+    """An indexed triangle mesh (not grid patches): a sphere with low-frequency bumps, open at the poles."""
+    u, v = np.meshgrid(np.linspace(0, 2 * np.pi, n, endpoint=False), np.linspace(0.05, np.pi - 0.05, n))
+    r = 1.0 + 0.05 * np.sin((4 + seed) * u) * np.sin(7 * v)
+    pos = np.stack([r * np.sin(v) * np.cos(u), r * np.cos(v), r * np.sin(v) * np.sin(u)], -1).reshape(-1, 3).astype(np.float32)
+    j, i = np.meshgrid(np.arange(n - 1), np.arange(n), indexing="ij")
+    a, b, c, d = j * n + i, j * n + (i + 1) % n, (j + 1) * n + i, (j + 1) * n + (i + 1) % n
+    idx = np.stack([a, c, b, b, c, d], -1).reshape(-1).astype(np.uint32)
+    uv = np.stack([u / (2 * np.pi), v / np.pi], -1).reshape(-1, 2).astype(np.float32)
+    return pos, idx, uv
+
+
+def built_mesh_scene(width=640, height=360, n=96):
+    """Meshes that went through chordvis_nanite_build (own clusterizer / partition / simplifier) instead of the
+    grid-patch generator: instances of a bumpy sphere from 3 m to 400 m so that every LOD level of the DAG is in use."""
+    from . import lib as L
+    prims, objs = [], []
+    for seed in (1, 2):
+        pos, idx, uv = bumpy_sphere_mesh(n, seed)
+        prims.append(L.nanite_build(pos, idx, uv))
+    pr = np.zeros(len(prims), dtype=T.PRIMITIVE)
+    ml, md, gr, gi, ps, bv, uvs = [], [], [], [], [], [], []
+    nv = nm = nd = ng = ni = nb = 0
+    for k, a in enumerate(prims):
+        pr[k] = a.primitive[0]
+        pr[k]["vertexOffset"], pr[k]["meshletOffset"], pr[k]["meshletGroupOffset"] = nv, nm, ng
+        pr[k]["meshletGroupIndicesOffset"], pr[k]["bvhNodeOffset"] = ni, nb
+        m = a.meshlets.copy(); m["dataOffset"] += nd
+        ml.append(m); md.append(a.meshlet_data); gr.append(a.groups); gi.append(a.group_indices); ps.append(a.positions); bv.append(a.bvh_nodes); uvs.append(a.texcoord0)
+        nv += len(a.positions); nm += len(m); nd += len(a.meshlet_data); ng += len(a.groups); ni += len(a.group_indices); nb += len(a.bvh_nodes)
+    mats = np.concatenate([SceneBuilder._material(0), SceneBuilder._material(1)])
+    l2w = []
+    dists = [3.0, 6.0, 14.0, 30.0, 70.0, 160.0, 400.0]
+    for k, dist in enumerate(dists):
+        m = translate(((k % 3) - 1) * 0.3 * dist, 0.08 * dist * ((k // 3) - 1), -dist) @ rotate_y(0.7 * k) @ scale(1.0 + 0.15 * k)
+        l2w.append(m)
+    objects = np.zeros(len(l2w), dtype=T.OBJECT)
+    objects["GLTFPrimitiveDetail"] = np.arange(len(l2w)) % len(prims)
+    objects["GLTFMaterialData"] = (np.arange(len(l2w)) // 2) % 2
+    scene = T.Scene(objects, pr, mats, np.concatenate(ml), np.concatenate(gr), np.concatenate(gi), np.concatenate(md), np.concatenate(ps),
+                    name="built_mesh_scene", texcoord0=np.concatenate(uvs), bvh_nodes=np.concatenate(bv))
+    scene.local_to_world = np.ascontiguousarray(np.stack([m.T.reshape(16) for m in l2w]), dtype=np.float64)
+    scene.built = prims
+    return scene, Camera((0.0, 0.4, 1.0), (0.0, -0.05, -1.0), width, height)
+
+
 def config5_subpixel(width=3840, height=2160, prims=1024, patches_per_prim=1024, instances=8, patch_px=8.0, seed=5):
     """BASELINE config 5: `prims * patches_per_prim` unique camera-facing patches, each ~patch_px x patch_px
     pixels (128 triangles of ~0.5 px^2 at patch_px = 8), centres uniform over the screen, view depth uniform in

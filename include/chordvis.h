@@ -152,6 +152,22 @@ int chordvis_object_basic_data_batch(uint32_t count, const double* localToWorld 
                                      const double* prevLocalToWorld, const double cameraPos[3],
                                      const double cameraPosLast[3], ChordObject* objects);
 
+/* ------------------------------------------------------------------ producer of the input format (host-only, offline)
+ * NaniteBuilder::build (nanite_builder.cpp:882-921): LOD-0 meshlets, up to 11 rounds of group / merge / simplify / split
+ * with the simplification error handed up the DAG, cluster groups of at most 4 meshlets, the 8-wide BVH; packed like
+ * asset_gltf_helper.cpp:496-548.  The clusterizer, the graph partition and the simplifier are this library's own (the
+ * reference calls meshoptimizer and METIS), so the meshlets differ from the reference's for the same mesh; the format and
+ * its invariants are the same (nanite_builder.cpp).  Indices: triangle list; texcoord0 may be NULL. */
+typedef struct ChordBuiltAsset ChordBuiltAsset;
+int chordvis_nanite_build(const float* positions, uint32_t vertexCount, const uint32_t* indices, uint32_t indexCount,
+                          const float* texcoord0, ChordBuiltAsset** outAsset);
+/* views into the built arrays (valid until chordvis_free_built_asset): one ChordAssetDesc holding one primitive */
+int chordvis_built_asset_desc(const ChordBuiltAsset* asset, ChordAssetDesc* outAsset, ChordPrimitive* outPrimitive, uint32_t* outLodCount);
+void chordvis_free_built_asset(ChordBuiltAsset* asset);
+/* a flat container for a built asset (the reference: cereal + LZ4 archives, serialize.h:217-320) */
+int chordvis_save_asset(const ChordBuiltAsset* asset, const char* path);
+int chordvis_load_asset(const char* path, ChordBuiltAsset** outAsset);
+
 /* ------------------------------------------------------------------ context (graphics::Context, graphics.h:88-345) */
 
 /* hipStream: an existing hipStream_t to enqueue on (e.g. the caller's current stream), or NULL for a context-owned

@@ -1,0 +1,138 @@
+"""chordvis_nanite_build: the invariants the runtime relies on (nanite_builder.cpp's own checks and the shape of
+its output), the container, and -- gpu -- frames of built meshes against the oracle in both cull modes."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+import orc
+from chord_amd import lib as L, records as R
+from chord_amd import scenes
+
+
+def _tris_of(a, m):
+    V, T = int(m["vertexTriangleCount"]) & 0xFF, (int(m["vertexTriangleCount"]) >> 8) & 0xFF
+    d = a.meshlet_data[m["dataOffset"]: m["dataOffset"] + V + T]
+    verts, words = d[:V], d[V:]
+    loc = np.stack([words & 0xFF, (words >> 8) & 0xFF, (words >> 16) & 0xFF], -1)
+    assert (loc < V).all()
+    return verts[loc]                                                           # (T, 3) global vertex ids
+
+
+def test_built_asset_invariants():
+    pos, idx, uv = scenes.bumpy_sphere_mesh(96, 1)
+    a = L.nanite_build(pos, idx, uv)
+    V = a.meshlets["vertexTriangleCount"] & 0xFF
+    T = (a.meshlets["vertexTriangleCount"] >> 8) & 0xFF
+    assert V.max() <= 255 and T.max() <= 128 and T.min() >= 1                      # base.h:428-430
+    assert a.lod_count >= 4 and set(np.unique(a.meshlets["lod"])) == set(range(a.lod_count))
+    # LOD 0 is the input: every triangle exactly once (as vertex triples up to rotation)
+    def canon(t):
+        t = np.asarray(t, dtype=np.int64)
+        r = np.argmin(t, axis=1)
+        return np.stack([np.take_along_axis(t, ((r + k) % 3)[:, None], 1)[:, 0] for k in range(3)], -1)
+    lod0 = np.concatenate([_tris_of(a, m) for m in a.meshlets[a.meshlets["lod"] == 0]])
+    want = canon(idx.reshape(-1, 3)); got = canon(lod0)
+    order = lambda x: x[np.lexsort(x.T[::-1])]
+    assert np.array_equal(order(got), order(want))
+    # every level roughly halves the triangles (kGroupSimplifyThreshold 0.5, accepted only below 0.8: nanite_builder.cpp:18-21,838)
+    per_lod = [int(T[a.meshlets["lod"] == l].sum()) for l in range(a.lod_count)]
+    assert all(b < 0.8 * c for c, b in zip(per_lod, per_lod[1:]))
+    # groups: at most 4 meshlets, each meshlet in exactly one, members share the group's spheres
+    g = a.groups
+    assert g["meshletCount"].max() <= 4 and g["meshletCount"].min() >= 1        # nanite_builder.cpp:411-414
+    members = np.concatenate([a.group_indices[x["meshletOffset"]: x["meshletOffset"] + x["meshletCount"]] for x in g])
+    assert np.array_equal(np.sort(members), np.arange(len(a.meshlets)))
+    lod_of_group = np.array([a.meshlets["lod"][a.group_indices[x["meshletOffset"]]] for x in g])
+    assert ((g["error"] == -1.0) == (lod_of_group == 0)).all()                   # :891
+    assert (g["parentError"][g["parentError"] < 3e38] >= np.maximum(g["error"], 0)[g["parentError"] < 3e38]).all()   # error only grows up the DAG (:853)
+    assert (g["parentError"] >= 3e38).any()                                      # the coarsest level is un-parented
+    # a child group's parent sphere IS some coarser group's own sphere (the hand-over of :857-868)
+    own = {(tuple(x["clusterPosCenter"]), float(x["error"])) for x in g if x["error"] >= 0}
+    for x in g[g["parentError"] < 3e38]:
+        assert (tuple(x["parentPosCenter"]), float(x["parentError"])) in own
+    # cones: a camera far along the axis sees the front of every triangle of the cluster, so the test must not cull it;
+    # one far behind the apex along -axis must be culled (meshlet_visible: dot(normalize(apex - cam), axis) >= cutoff culls)
+    for m in a.meshlets[::7]:
+        if m["coneCutOff"] >= 1.0:
+            continue
+        axis, apex = m["coneAxis"].astype(np.float64), m["coneApex"].astype(np.float64)
+        front, back = apex + 50.0 * axis, apex - 50.0 * axis
+        for cam, culled in ((front, False), (back, True)):
+            v = apex - cam
+            assert (np.dot(v / np.linalg.norm(v), axis) >= m["coneCutOff"]) == culled
+    # BVH: shape of the reference builder + what chordvis_upload_scene checks (spheres contain the parent spheres beneath)
+    nodes = a.bvh_nodes
+    assert nodes[0]["bvhNodeCount"] == len(nodes)
+    listed = np.concatenate([np.arange(n["leafMeshletGroupOffset"], n["leafMeshletGroupOffset"] + n["leafMeshletGroupCount"]) for n in nodes])
+    assert np.array_equal(listed, np.arange(len(g)))
+
+
+def test_degenerate_inputs_and_container(tmp_path):
+    h = C.c_void_p()
+    pos = np.zeros((3, 3), np.float32); idx = np.array([0, 1, 5], np.uint32)
+    assert L.lib.chordvis_nanite_build(pos.ctypes.data, 3, idx.ctypes.data, 3, None, C.byref(h)) == L.E_INVALID      # index out of range
+    assert L.lib.chordvis_nanite_build(pos.ctypes.data, 3, idx.ctypes.data, 2, None, C.byref(h)) == L.E_INVALID      # not a triangle list
+    # one triangle: one meshlet, one un-parented LOD-0 group, a root-only tree
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    a = L.nanite_build(pos, [0, 1, 2])
+    assert len(a.meshlets) == 1 and len(a.groups) == 1 and a.groups["error"][0] == -1.0 and a.groups["parentError"][0] > 3e38 and len(a.bvh_nodes) == 1
+    # container round trip
+    p, i, uv = scenes.bumpy_sphere_mesh(48, 2)
+    h = L.nanite_build(p, i, uv, keep_handle=True)
+    path = str(tmp_path / "sphere.chordasset").encode()
+    assert L.lib.chordvis_save_asset(h, path) == L.OK
+    h2 = C.c_void_p()
+    assert L.lib.chordvis_load_asset(path, C.byref(h2)) == L.OK
+    a1, a2 = L.BuiltAsset(h), L.BuiltAsset(h2)
+    for f in ("meshlets", "groups", "group_indices", "meshlet_data", "positions", "texcoord0", "bvh_nodes", "primitive"):
+        assert np.array_equal(getattr(a1, f).view(np.uint8), getattr(a2, f).view(np.uint8)), f
+    L.lib.chordvis_free_built_asset(h); L.lib.chordvis_free_built_asset(h2)
+    open(path.decode(), "wb").write(b"not an asset")
+    assert L.lib.chordvis_load_asset(path, C.byref(h2)) == L.E_INVALID
+
+
+def test_lod_selection_uses_every_level_and_covers_the_silhouette():
+    scene, cam, view, iv = H.setup_scene(scenes.built_mesh_scene)
+    cmds = orc.instance_culling(scene, view, iv, H.ALL_FLAGS)
+    lods = scene.meshlets["lod"][cmds["meshletId"]]
+    per_obj = [set(lods[cmds["objectId"] == o].tolist()) for o in range(len(scene.objects))]
+    mean_lod = [float(lods[cmds["objectId"] == o].mean()) for o in range(len(scene.objects))]
+    assert all(per_obj) and mean_lod[0] < mean_lod[3] < mean_lod[-1]              # coarser with distance (regions whose simplification stalled stay finer)
+    assert max(per_obj[-1]) >= 4 and len(set().union(*per_obj)) >= 4              # ... and most levels of the DAG are in use somewhere
+    tri = ((scene.meshlets["vertexTriangleCount"] >> 8) & 0xFF)[cmds["meshletId"]]
+    per_obj_tris = [int(tri[cmds["objectId"] == o].sum()) for o in range(len(scene.objects))]
+    assert per_obj_tris[-1] < 0.5 * per_obj_tris[0]                               # the far instance costs a fraction of the near one (locked group borders bound how far a level reduces)
+    # the LOD cut does not open holes: what the selected clusters cover is (nearly) what LOD 0 alone covers
+    fr = orc.frame(scene, view, iv, H.ALL_FLAGS)
+    lod0 = scene.groups.copy()
+    keep = lod0["error"] < -0.5
+    lod0["parentError"][keep] = 3.4e38                                            # LOD 0 groups un-parented ...
+    lod0["error"][~keep] = 1e30; lod0["parentError"][~keep] = 1e-30               # ... everything else never selected
+    only0 = R.Scene(scene.objects, scene.primitives, scene.materials, scene.meshlets, lod0, scene.group_indices, scene.meshlet_data,
+                    scene.positions)
+    f0 = orc.frame(only0, view, iv, H.ALL_FLAGS)
+    a, b = fr["vis"] != 0, f0["vis"] != 0
+    assert (a != b).sum() <= 0.01 * b.sum() + 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hier", [0, 1], ids=["flat", "hierarchical"])
+def test_built_meshes_render_like_the_oracle(gpu, hier):
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam, view, iv = H.setup_scene(scenes.built_mesh_scene)
+    r = VisibilityRenderer(0)
+    r.set_cull_mode(hier)
+    r.upload_scene(scene)                                                         # (validates the builder's BVH)
+    r.allocate_gbuffer(cam.width, cam.height)
+    r.set_view(view, iv, H.ALL_FLAGS)
+    assert np.array_equal(r.read_cmds(r.instance_culling()), orc.instance_culling(scene, view, iv, H.ALL_FLAGS))
+    prev = None
+    for frame in range(2):
+        r.render_frame()
+        want = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=prev)
+        H.assert_vis_equal(r.read_visibility(), want["vis"], cam.width, cam.height, "built meshes, frame %d" % frame)
+        prev = want["hzb_min"]
+    r.close()
