@@ -286,8 +286,8 @@ def main():
     # the committed summary of those passes over this same command (profiles/, tools/profile.sh), per launch
     traffic, traffic_src = None, None
     tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                      {"street_4k_hzb": "r01_config3_4k_hzb_traffic.json", "street_x64_4k_hzb": "r01_config4_x64_4k_hzb_traffic.json",
-                       "subpixel_1g": "r01_config5_subpixel_1g_traffic.json"}.get(wl, ""))
+                      {"street_4k_hzb": "r02_config3_4k_hzb_traffic.json", "street_x64_4k_hzb": "r02_config4_x64_4k_hzb_traffic.json",
+                       "subpixel_1g": "r02_config5_subpixel_1g_traffic.json"}.get(wl, ""))
     if world == 1 and not args.debug_flags and (not args.no_hzb or wl.startswith("subpixel")) and os.path.isfile(tj):
         try:
             tk = json.load(open(tj))
