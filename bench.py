@@ -273,11 +273,15 @@ def main():
     rec_bytes = 32.0 * recs_c + 48.0 * (recs - recs_c)            # what the setup kernel writes
     rec_size = rec_bytes / recs if recs else 32.0                 # average record a bin entry leads to
     bins = sum(pv["binEntries"] for pv in per_view) / 2.0
+    # small clusters leave the setup kernel as pixel blocks (one per cluster and tile: 8 B per window pixel + header) instead
+    # of records; a block is one bin entry, read once by the tile kernel
+    blocks = sum(pv["pixelBlocks"] for pv in per_view) / 2.0
+    block_bytes = sum(pv["pixelBlockBytes"] for pv in per_view) / 2.0
     tiles1 = sum(pv["tilesTouched"][1] for pv in per_view) / 2.0
     launches = max(1, st["rasterLaunches"])
     kernels = {
-        "raster_setup_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame + rec_bytes + 4.0 * bins),
-        "raster_tile_kernel": (st["msRasterChunk"], (4.0 + rec_size) * bins + 8.0 * pixels + (launches - 1) * 16.0 * 4096 * tiles1),
+        "raster_setup_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame + rec_bytes + block_bytes + 4.0 * bins),
+        "raster_tile_kernel": (st["msRasterChunk"], 4.0 * bins + rec_size * (bins - blocks) + block_bytes + 8.0 * pixels + (launches - 1) * 16.0 * 4096 * tiles1),
     }
     dom = max(kernels, key=lambda k: kernels[k][0])
     dom_ms, dom_bytes = kernels[dom]
@@ -376,7 +380,7 @@ def main():
             "triangles_submitted_per_step": tris_per_pair / 2.0,
             # end to end over ALL scene triangles (LOD 0), i.e. including what culling removed
             "scene_gtri_per_s": round(scene.triangle_count_lod0() / (ms_per_step * 1e-3) / 1e9, 3),
-            "clusters_rastered_per_step": clusters_per_frame, "triangle_records_per_step": recs, "bin_entries_per_step": bins,
+            "clusters_rastered_per_step": clusters_per_frame, "triangle_records_per_step": recs, "bin_entries_per_step": bins, "pixel_blocks_per_step": blocks, "pixel_block_bytes_per_step": block_bytes,
             "gpu_ms": {k: round(st[k], 4) for k in ("msClear", "msInstanceCulling", "msStage0", "msHzbStage0", "msStage1",
                                                      "msHzbFinal", "msFrame", "msRasterCluster", "msRasterClip", "msRasterChunk")},
             "counts_view_a": {k: per_view[0][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},

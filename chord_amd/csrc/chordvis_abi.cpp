@@ -260,6 +260,10 @@ int alloc_scene_work_buffers(ChordCtx* c)
     c->clipTriCap = 1u << 20;
     if ((rc = dalloc(c, &c->dTris, (size_t)c->triCap))) return rc;
     if ((rc = dalloc(c, &c->dTrisC, (size_t)c->triCapC))) return rc;
+    // pixel blocks of small clusters: a cluster takes the block form only when that is fewer bytes than its records would
+    // be, so the compact list's byte budget bounds the pool too
+    c->blockCap = (uint32_t)std::min<uint64_t>((uint64_t)c->triCapC * 2u / CHORD_LIST_SHARDS, CHORD_REC_INDEX_MASK / CHORD_LIST_SHARDS);
+    if ((rc = dalloc(c, &c->dBlockPool, (size_t)c->blockCap * CHORD_LIST_SHARDS * 2u))) return rc;
     if ((rc = dalloc(c, &c->dClipTris, (size_t)c->clipTriCap))) return rc;
     c->largeCap = 8u << 20;
     if ((rc = dalloc(c, &c->dLargeList, (size_t)c->largeCap))) return rc;
@@ -319,7 +323,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
-    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
+    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
     dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1064,6 +1068,7 @@ int chordvis_set_debug(ChordCtx* c, uint32_t flags)
 {
     if (!c) return CHORDVIS_E_INVALID;
     c->debugFlags = flags;
+    if (c->depthCtx) c->depthCtx->debugFlags = flags;      // (the depth views' child context follows)
     return CHORDVIS_OK;
 }
 
@@ -1200,12 +1205,15 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
     for (uint32_t i = 0; i < CHORD_LIST_SHARDS; i++) {
         out->triangleRecords += dc.triCount[i * CHORD_SHARD_STRIDE] + dc.triCountC[i * CHORD_SHARD_STRIDE];
         out->triangleRecordsCompact += dc.triCountC[i * CHORD_SHARD_STRIDE];
+        out->pixelBlockBytes += (uint64_t)dc.blockGranules[i * CHORD_SHARD_STRIDE] * 16u;
     }
     if (c->tilesX) {
         std::vector<uint32_t> tc((size_t)c->tilesX * c->tilesY);
         for (int pass = 0; pass < 2; pass++) {
             CHORD_HIP(c, hipMemcpy2D(tc.data(), 4, c->dFrameState->tileCount + (size_t)pass * c->tilesX * c->tilesY * CHORD_TILECOUNT_STRIDE, 4 * CHORD_TILECOUNT_STRIDE, 4, tc.size(), hipMemcpyDeviceToHost));
             for (uint32_t v : tc) { out->binEntries += v; out->tilesTouched[pass] += v ? 1u : 0u; }
+            CHORD_HIP(c, hipMemcpy2D(tc.data(), 4, c->dFrameState->tileCount + (size_t)pass * c->tilesX * c->tilesY * CHORD_TILECOUNT_STRIDE + 2, 4 * CHORD_TILECOUNT_STRIDE, 4, tc.size(), hipMemcpyDeviceToHost));
+            for (uint32_t v : tc) out->pixelBlocks += v;
         }
     }
     if (c->timers && c->framesStamped && c->stampTags.size() > 1) {

@@ -68,6 +68,7 @@ int chordvis_allocate_depth_views(ChordCtx* c, uint32_t dim, uint32_t viewCount)
     k->groupCount = c->groupCount; k->groupInstances = c->groupInstances; k->cmdCapacity = c->cmdCapacity; k->cullBlocks = c->cullBlocks;
     k->instTriangles = c->instTriangles; k->limitRecords = c->limitRecords; k->limitPoolChunks = c->limitPoolChunks; k->binMaxChunks = c->binMaxChunks;
     c->depthCtx = k;
+    k->debugFlags = c->debugFlags;
     if ((rc = alloc_scene_work_buffers(k))) return child_fail(c, rc);
     k->dObjects = c->dObjects;
     k->sceneLoaded = true;

@@ -123,6 +123,14 @@ struct TriRecC {
     uint32_t payload;
 };
 #define CHORD_REC_WIDE 0x80000000u
+// Pixel blocks (kernels_raster.hip "small clusters"): a cluster whose emitted triangles all fall into a window of
+// CHORD_BLOCK_WIN x CHORD_BLOCK_WIN pixels is resolved by its setup wave in LDS and leaves the kernel as one dense block of
+// packed visibility words per tile it touches instead of one record + bin entry per triangle.  A block lives in the
+// block pool at a 16-byte granule offset: word 0 = header (x0 | y0 << 6 | (w-1) << 12 | (h-1) << 16, tile-local, and
+// ceil(65536 / w) in the high half), then w x h words, row-major.  Its bin entry is CHORD_REC_BLOCK | granule offset.
+#define CHORD_REC_BLOCK 0xC0000000u
+#define CHORD_REC_INDEX_MASK 0x3FFFFFFFu
+#define CHORD_BLOCK_WIN 16
 struct ClipTri { uint32_t cmdIndex; uint32_t tri; };       // needs the homogeneous clipper
 
 // The record list is cut into LIST_SHARDS independent sub-lists (own counter, own region) so that
@@ -140,6 +148,7 @@ struct DeviceCounters {
     uint32_t overflow;                          // bit0 record list / tile bin / large list, bit1 clip list, bit2 bin chunk wait timed out
     uint32_t binPoolCount[2];                   // per raster pass: overflow chunks handed out
     uint32_t pad;
+    uint32_t blockGranules[CHORD_LIST_SHARDS * CHORD_SHARD_STRIDE];   // 16-byte granules of the block pool handed out this frame, per shard
     // triangles (meshlet triangle counts) of the commands each list producer emitted this frame
     unsigned long long trisInstanceCulled, trisHzbVisible0, trisHzbVisible1, pad2;
 };
@@ -280,6 +289,8 @@ struct ChordCtx {
     chord::TriRec* dTris = nullptr;
     uint32_t triCap = 0;               // 48-byte records, all shards together
     chord::TriRecC* dTrisC = nullptr;
+    unsigned long long* dBlockPool = nullptr;   // pixel blocks of small clusters (CHORD_REC_BLOCK), [CHORD_LIST_SHARDS][blockCap] granules of 16 bytes
+    uint32_t blockCap = 0;             // granules per shard
     uint32_t triCapC = 0;              // 32-byte records, all shards together
     chord::FrameState* dFrameState = nullptr;
     uint32_t* dTileBins = nullptr;     // [2 passes][tiles][binCap]: the first binCap entries of every tile's bin

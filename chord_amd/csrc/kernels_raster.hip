@@ -61,6 +61,8 @@ struct RasterParams {
     uint32_t* tileCount; uint32_t* tileBins; uint32_t binCap; uint32_t tilesX, tilesY;
     uint32_t* binPool; uint32_t binPoolChunks; uint32_t* binPoolCount;   // overflow chunks of this pass
     unsigned long long* binChunkTab; uint32_t binStamp; uint32_t binMaxChunks;   // [tile][binMaxChunks] serial << 32 | chunk
+    unsigned long long* blockPool; uint32_t blockCap;   // pixel blocks of small clusters, granules of 16 bytes per list shard (0: path off)
+    uint32_t blockForce;                                // debug: every launch takes the setup kernel's BLOCKS body
     ClipTri* clipTris; uint32_t clipTriCap; uint32_t pass;   // raster pass of the frame (0 / 1): clip / large count slot
     uint32_t* largeList; uint32_t largeCap;                  // records touching more than 2x2 tiles (binned by raster_bin_large_kernel)
     DeviceCounters* counters;
@@ -510,22 +512,109 @@ __device__ __forceinline__ void setup_emit_mask_ext(const RasterParams& p, TriRe
     write_mask_ext(slot, p.materials[material], material, absArea2, u, v, w);
 }
 
+template <int PITCH>
+__device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
+                                                   int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels,
+                                                   unsigned long long rowMask, const bool clampZ);
+
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = min(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
 // ---- the per-cluster setup kernel -------------------------------------------------------------
 enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
+#define WIN CHORD_BLOCK_WIN
+#define DBG_NO_BLOCKS 32768u     // small clusters take the record path too (A/B of the pixel blocks; results identical)
+#define DBG_FORCE_BLOCKS 65536u  // the setup kernel takes its BLOCKS body whatever the cluster count (tests: small scenes)
 
-// MASKED: the scene has alpha-tested materials (their clusters emit 48-byte records with a texture-coordinate extension);
-// scenes without any -- every benchmark configuration -- run the instantiation that knows nothing of them.
-template <bool MASKED>
-__global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
+// A small cluster's triangles -> pixel window in LDS -> one dense block of packed words per tile the window touches.
+__device__ __forceinline__ void cluster_blocks(const RasterParams& p, bool eA, TriSetup& tsA, const float* dA, bool eB, TriSetup& tsB, const float* dB,
+                                               unsigned long long* win, int32_t bx0, int32_t by0, int32_t bx1, int32_t by1, uint32_t listShard)
 {
-    __shared__ float sX[4][LDS_VERTS], sY[4][LDS_VERTS], sW[4][LDS_VERTS];
-    __shared__ float sU[4][LDS_VERTS], sV[4][LDS_VERTS], sD[4][LDS_VERTS];
+    const uint32_t lane = threadIdx.x & 63u;
+    // the window's parts per tile (<= 2 x 2): lane r < 4 owns the part in tile (r & 1 ? tx1 : tx0, r & 2 ? ty1 : ty0)
+    const int32_t tx0 = bx0 >> TILE_SHIFT, tx1 = bx1 >> TILE_SHIFT, ty0 = by0 >> TILE_SHIFT, ty1 = by1 >> TILE_SHIFT;
+    const uint32_t r = lane & 3u;
+    const bool sx = (r & 1u) != 0u, sy = (r & 2u) != 0u;
+    const int32_t rx0 = sx ? tx1 << TILE_SHIFT : bx0, rx1 = (sx || tx1 == tx0) ? bx1 : (tx0 << TILE_SHIFT) + TILE - 1;
+    const int32_t ry0 = sy ? ty1 << TILE_SHIFT : by0, ry1 = (sy || ty1 == ty0) ? by1 : (ty0 << TILE_SHIFT) + TILE - 1;
+    const uint32_t rw = (uint32_t)(rx1 - rx0 + 1), rh = (uint32_t)(ry1 - ry0 + 1);
+    const bool has = lane < 4u && !(sx && tx1 == tx0) && !(sy && ty1 == ty0) && owns_any_row(p.shard, ry0, ry1);
+    const uint32_t hasMask = (uint32_t)__ballot(has) & 15u;
+    const uint32_t gran = has ? (rw * rh + 2u) >> 1 : 0u;                  // header + w x h words, in 16-byte granules
+    const uint32_t g0 = bcast(gran, 0), g1 = bcast(gran, 1), g2 = bcast(gran, 2), g3 = bcast(gran, 3);
+    const uint32_t before = (r > 0u ? g0 : 0u) + (r > 1u ? g1 : 0u) + (r > 2u ? g2 : 0u), G = g0 + g1 + g2 + g3;
+    const uint32_t tile = (uint32_t)(sy ? ty1 : ty0) * p.tilesX + (uint32_t)(sx ? tx1 : tx0);
+    // one round trip: pool space (lane 0) and a bin slot per touched tile (lanes 0..3; word 2 of the tile's counter line
+    // counts its blocks) ...
+    uint32_t gbase = 0, slot = 0;
+    if (lane == 0u && G) gbase = atomicAdd(&p.counters->blockGranules[listShard * CHORD_SHARD_STRIDE], G);
+    if (has) { slot = atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE], 1u); atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE + 2u], 1u); }
+    // ... and the cluster is resolved while they are in flight
+#pragma unroll
+    for (int k = 0; k < WIN * WIN / 64; k++) win[lane + 64u * k] = 0ull;
+    unsigned long long rowMaskW = ~0ull;
+    if (p.shard.ranks > 1u) {
+        rowMaskW = 0ull;
+        for (int32_t ly = 0; ly <= by1 - by0; ly++) if (owns_row<true>(p.shard, by0 + ly)) rowMaskW |= 1ull << ly;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool clampZ = p.depthClamp != 0u;
+    // (the same per-pixel arithmetic as the tile kernel's tiny-triangle scan of the record this triangle would have been)
+    if (eA) {
+        tsA.d0 = dA[0]; tsA.e1 = dA[1] - dA[0]; tsA.e2 = dA[2] - dA[0];
+        tile_raster_narrow<WIN>(win, tsA, bx0, by0, tsA.px0, tsA.py0, tsA.px1, tsA.py1, false, rowMaskW, clampZ);
+    }
+    if (eB) {
+        tsB.d0 = dB[0]; tsB.e1 = dB[1] - dB[0]; tsB.e2 = dB[2] - dB[0];
+        tile_raster_narrow<WIN>(win, tsB, bx0, by0, tsB.px0, tsB.py0, tsB.px1, tsB.py1, false, rowMaskW, clampZ);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    gbase = bcast(gbase, 0);
+    const bool fits = gbase + G <= p.blockCap;
+    if (!fits && lane == 0u) atomicOr(&p.counters->overflow, 1u);
+    const uint32_t off = listShard * p.blockCap + gbase + before;              // granule offset of lane r's block
+    if (has) bin_alloc(p, tile, slot);
+    if (has && fits) {
+        p.blockPool[(size_t)off * 2u] = (unsigned long long)((uint32_t)(rx0 & (TILE - 1)) | (uint32_t)(ry0 & (TILE - 1)) << 6 | (rw - 1u) << 12 | (rh - 1u) << 16) |
+                                       ((unsigned long long)((65536u + rw - 1u) / rw) << 32);
+        bin_put(p, tile, slot, CHORD_REC_BLOCK | off);
+    }
+    for (int k = 0; k < WIN * WIN / 64; k++) {
+        const uint32_t idx = lane + 64u * k;
+        const int32_t x = bx0 + (int32_t)(idx & (WIN - 1)), y = by0 + (int32_t)(idx / WIN);
+        const uint32_t q = ((x >> TILE_SHIFT) != tx0 ? 1u : 0u) | ((y >> TILE_SHIFT) != ty0 ? 2u : 0u);
+        const uint32_t qoff = (uint32_t)__shfl((int)off, (int)q, 64);
+        const int32_t qx0 = (q & 1u) ? tx1 << TILE_SHIFT : bx0, qy0 = (q & 2u) ? ty1 << TILE_SHIFT : by0;
+        const int32_t qw = (q & 1u) ? bx1 - (tx1 << TILE_SHIFT) + 1 : min(bx1, (tx0 << TILE_SHIFT) + TILE - 1) - bx0 + 1;
+        if (x <= bx1 && y <= by1 && fits && ((hasMask >> q) & 1u))
+            p.blockPool[(size_t)qoff * 2u + 1u + (size_t)((y - qy0) * qw + (x - qx0))] = win[idx];
+    }
+}
 
+// BLOCKS: the instantiation that can turn small clusters into pixel blocks (cluster_blocks).  It is a second body of the
+// same kernel, chosen per launch (below), because the block code costs the record path registers: with it inlined the
+// kernel spills 50 VGPRs at its 128-VGPR budget, also where no cluster is small.
+template <bool MASKED, bool BLOCKS>
+__device__ __forceinline__ void raster_setup_body(const RasterParams& p, const uint32_t count, float (*sVert)[4][LDS_VERTS], unsigned long long (*sWin)[WIN * WIN])
+{
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    float* lX = sX[wave]; float* lY = sY[wave]; float* lW = sW[wave];
-    float* lU = sU[wave]; float* lV = sV[wave]; float* lD = sD[wave];
+    float* lX = sVert[0][wave]; float* lY = sVert[1][wave]; float* lW = sVert[2][wave];
+    float* lU = sVert[3][wave]; float* lV = sVert[4][wave]; float* lD = sVert[5][wave];
 
-    const uint32_t count = *p.count;
     const uint32_t listShard = (blockIdx.x * 4u + wave) % CHORD_LIST_SHARDS;
 
     // Wave-uniform header of a cluster (scalar loads: the addresses are uniform).  The chain command -> meshlet /
@@ -692,6 +781,27 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
             const uint32_t nClip = (uint32_t)(__popcll(cmA) + __popcll(cmB));
             const uint32_t nEc = (uint32_t)(__popcll(ecA) + __popcll(ecB)), nEw = (uint32_t)(__popcll(ewA) + __popcll(ewB));
             const uint32_t nLg = (uint32_t)(__popcll(lmA) + __popcll(lmB));
+            // ---- small cluster: every emitted triangle inside one WIN x WIN pixel window (and narrow, unclipped, opaque).
+            //      The wave resolves the cluster in LDS -- the same per-pixel arithmetic as the tile kernel's tiny-triangle
+            //      scan -- and emits the window as dense blocks of packed words, one per tile it touches (<= 2 x 2), when
+            //      that is fewer bytes than the records + bin entries of its triangles (36 B each).  For sub-pixel
+            //      geometry this is 5-7x less traffic out of this kernel and into the tile kernel, which merges a block
+            //      with one LDS max per word instead of setting up, scanning and depth-interpolating every triangle again.
+            bool blocksDone = false;
+            if (BLOCKS && !masked && (emA | emB) != 0ull && (ewA | ewB | cmA | cmB) == 0ull) {
+                const bool eA = kindA == K_EMIT, eB = kindB == K_EMIT;
+                int32_t bx0 = min(eA ? tsA.px0 : 0x7FFF, eB ? tsB.px0 : 0x7FFF), by0 = min(eA ? tsA.py0 : 0x7FFF, eB ? tsB.py0 : 0x7FFF);
+                int32_t bx1 = max(eA ? tsA.px1 : -1, eB ? tsB.px1 : -1), by1 = max(eA ? tsA.py1 : -1, eB ? tsB.py1 : -1);
+                if (__ballot(bx1 - bx0 >= WIN || by1 - by0 >= WIN) == 0ull) {            // (no single lane is already too wide)
+                    bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0); bx1 = wave_max_i32(bx1); by1 = wave_max_i32(by1);
+                    const int32_t bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+                    if (bw <= WIN && bh <= WIN && (uint32_t)(bw * bh + 8) * 8u <= nEc * 36u) {
+                        blocksDone = true;
+                        cluster_blocks(p, eA, tsA, dA, eB, tsB, dB, sWin[wave], bx0, by0, bx1, by1, listShard);
+                    }
+                }
+            }
+            if (!blocksDone) {
             // every reservation of the cluster travels together: the list reservations (lane 0) and the bin
             // reservations; nothing is stored before they are back
             uint32_t cbase = 0, ebaseC = 0, ebaseW = 0, lbase = 0;
@@ -752,6 +862,7 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
                 const uint32_t k = lbase + (uint32_t)__popcll(lmA) + (uint32_t)__popcll(lmB & lt);
                 if (k < p.largeCap) p.largeList[(size_t)listShard * p.largeCap + k] = giB & ~CHORD_REC_WIDE; else atomicOr(&p.counters->overflow, 1u);
             }
+            }
         }
         // LDS of this wave is rewritten by the next cluster: order the reads above before those writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -768,6 +879,22 @@ __global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
         if (w < CHORD_MAX_TILES * 8u / 5u) for (int i = 0; i < 5; i++) p.tilePhase[(size_t)w * 5u + i] = sph[i];
     }
 #undef SPHASE
+}
+
+// MASKED: the scene has alpha-tested materials (their clusters emit 48-byte records with a texture-coordinate extension);
+// scenes without any -- every benchmark configuration -- run the instantiation that knows nothing of them.
+template <bool MASKED>
+__global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
+{
+    __shared__ float sVert[6][4][LDS_VERTS];                   // x, y, w, u, v, depth of a wave's cluster (24 KB)
+    __shared__ unsigned long long sWin[4][WIN * WIN];          // a small cluster's pixel window (8 KB)
+    const uint32_t count = *p.count;
+    // Pixel blocks pay when clusters are small, and then there are many of them: the launch takes the BLOCKS body when
+    // its clusters have fewer than 16 pixels of this rank's screen each on average (BASELINE config 5: one pixel per
+    // cluster; config 4: 32; config 3: 2 000).  Either body produces the same image.
+    const unsigned long long pixels = (unsigned long long)p.Wi * (unsigned long long)p.Hi / (p.shard.ranks > 1u ? p.shard.ranks : 1u);
+    if (p.blockCap != 0u && (p.blockForce != 0u || (unsigned long long)count * 16ull >= pixels)) raster_setup_body<MASKED, true>(p, count, sVert, sWin);
+    else raster_setup_body<MASKED, false>(p, count, sVert, sWin);
 }
 
 // One lane bins one record into every tile its clamped bbox may touch (conservative edge test at the tile
@@ -1082,6 +1209,7 @@ __device__ __forceinline__ void lds_write(unsigned long long* tile, int32_t lx, 
 // one lane scans its own (tile-clipped) tiny bbox with 32-bit edge functions.  ONE flattened loop over the
 // bbox pixels: with nested row/column loops a wave pays max(rows) x max(cols) over its lanes (a 1x16 and a
 // 16x1 box in the same wave = 256 trips); flattened it pays max(area) <= TINY_AREA.
+template <int PITCH>
 __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
                                                    int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels,
                                                    unsigned long long rowMask, const bool clampZ)
@@ -1107,7 +1235,7 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
     const int32_t sx0 = a0 * 256, sx1 = a1 * 256, sx2 = a2 * 256;
     const int32_t sw0 = b0 * 256 - (w - 1) * sx0, sw1 = b1 * 256 - (w - 1) * sx1, sw2 = b2 * 256 - (w - 1) * sx2;
     int32_t ly = y0 - oy, col = 0;
-    unsigned long long* px = tile + ly * TPITCH + (x0 - ox);
+    unsigned long long* px = tile + ly * PITCH + (x0 - ox);
     const unsigned long long payload = (unsigned long long)ts.payload;
     for (int32_t i = 0; i < count; i++) {
         const bool inside = (E0 | E1 | E2) >= 0 && ((rowMask >> ly) & 1ull) && !noPixels;
@@ -1118,7 +1246,7 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
         col++;
         const bool wrap = col == w;
         E0 += wrap ? sw0 : sx0; E1 += wrap ? sw1 : sx1; E2 += wrap ? sw2 : sx2;
-        px += wrap ? TPITCH - w + 1 : 1;
+        px += wrap ? PITCH - w + 1 : 1;
         ly += wrap ? 1 : 0;
         col = wrap ? 0 : col;
     }
@@ -1550,6 +1678,50 @@ __device__ __noinline__ bool merge_slices(unsigned long long* tile, unsigned lon
 }
 
 // DEPTH: a depth-only pass with depth clamp (shadow views): the interpolated depth is clamped to [0, 1]
+// Pixel blocks of small clusters (CHORD_REC_BLOCK): the wave merges the blocks its lanes hold as bin entries, two at a time,
+// every lane a word: coalesced 8-byte loads and one ds_max_u64 per non-empty word.  (header: see device_layer.h)
+__device__ __forceinline__ void merge_block_word(unsigned long long* tile, unsigned long long v, uint32_t i, uint32_t hdr, uint32_t rcp)
+{
+    const uint32_t w = ((hdr >> 12) & 15u) + 1u;
+    const uint32_t row = (i * rcp) >> 16, col = i - row * w;              // exact for i < 256, w <= 16
+    const uint32_t lx = (hdr & 63u) + col, ly = ((hdr >> 6) & 63u) + row;
+    if (v != 0ull && lx < (uint32_t)TILE && ly < (uint32_t)TILE) atomicMax(&tile[ly * TPITCH + lx], v);
+}
+
+__device__ __forceinline__ void merge_blocks(unsigned long long* tile, const unsigned long long* __restrict__ pool, unsigned long long todo,
+                                             uint32_t name, uint32_t hdrLo, uint32_t hdrHi, uint32_t lane)
+{
+    // four blocks per step: the first 128 words of each are in flight together (a block of sub-pixel geometry has 64..121),
+    // so a wave keeps ~4 KB of loads outstanding instead of one block's worth per memory round trip
+    while (todo) {
+        uint32_t h[4], r[4], n[4];
+        const unsigned long long* src[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool any = todo != 0ull;
+            const int l = any ? __ffsll((long long)todo) - 1 : 0;
+            todo &= todo - 1ull;                                    // (0 stays 0)
+            h[j] = bcast(hdrLo, l); r[j] = bcast(hdrHi, l);
+            src[j] = pool + (size_t)(bcast(name, l) & CHORD_REC_INDEX_MASK) * 2u + 1u;
+            n[j] = any ? (((h[j] >> 12) & 15u) + 1u) * (((h[j] >> 16) & 15u) + 1u) : 0u;
+        }
+        unsigned long long a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            a[j] = lane < n[j] ? src[j][lane] : 0ull;
+            b[j] = lane + 64u < n[j] ? src[j][lane + 64u] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            merge_block_word(tile, a[j], lane, h[j], r[j]);
+            merge_block_word(tile, b[j], lane + 64u, h[j], r[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            for (uint32_t i = lane + 128u; i < n[j]; i += 64u) merge_block_word(tile, src[j][i], i, h[j], r[j]);
+    }
+}
+
 template <bool SH, bool MASKED, bool DEPTH>
 __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
 {
@@ -1633,12 +1805,32 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         __syncthreads();
     }
     const uint32_t wideLimit = p.triCap * CHORD_LIST_SHARDS, compactLimit = p.triCapC * CHORD_LIST_SHARDS;
-    auto binEntry = [&](uint32_t k) -> uint32_t {              // record name of bin entry k, ~0u = none
+    auto binWord = [&](uint32_t k) -> uint32_t {               // bin entry k as stored, ~0u = none
         if (k < p.binCap) return bin[k];
         const uint32_t o = k - p.binCap, cj = (o >> CHORD_BIN_CHUNK_SHIFT) - chunk0;
         const uint32_t id = cj < 64u ? chunkTab[cj] : CHORD_BIN_CHUNK_INVALID;
         if (id == CHORD_BIN_CHUNK_INVALID) return 0xFFFFFFFFu;
-        const uint32_t gi = p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))];
+        return p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))];
+    };
+    // ---- pixel blocks of small clusters first: their own pass over the item's entries (nothing of the triangle
+    //      pipeline below is live here; tiles without blocks -- word 2 of the tile's counter line -- skip it) ----------
+    if (p.blockCap != 0u && !noPixels && p.tileCount[(size_t)tileId * TC_STRIDE + 2u] != 0u) {
+        const uint32_t blockLimit = p.blockCap * CHORD_LIST_SHARDS;
+        uint32_t giNext = lo + threadIdx.x < n ? binWord(lo + threadIdx.x) : 0xFFFFFFFFu;
+        for (uint32_t base = lo; base < n; base += TB) {
+            const uint32_t gi = giNext;
+            giNext = base + TB + threadIdx.x < n ? binWord(base + TB + threadIdx.x) : 0xFFFFFFFFu;
+            // (never a block outside the pool: a slot drawn but not written after a reported overflow holds anything)
+            const bool isBlock = gi != 0xFFFFFFFFu && gi >= CHORD_REC_BLOCK && (gi & CHORD_REC_INDEX_MASK) < blockLimit;
+            uint2 hdr = make_uint2(0u, 0u);
+            if (isBlock) hdr = *reinterpret_cast<const uint2*>(p.blockPool + (size_t)(gi & CHORD_REC_INDEX_MASK) * 2u);
+            merge_blocks(tile, p.blockPool, __ballot(isBlock), gi, hdr.x, hdr.y, threadIdx.x & 63u);
+        }
+    }
+    auto binEntry = [&](uint32_t k) -> uint32_t {              // record name of bin entry k, ~0u = none (or a pixel block)
+        const uint32_t gi = binWord(k);
+        if (gi >= CHORD_REC_BLOCK) return 0xFFFFFFFFu;         // (incl. ~0u itself)
+        if (k < p.binCap) return gi;
         const bool okIdx = (gi & CHORD_REC_WIDE) ? (gi & ~CHORD_REC_WIDE) < wideLimit : gi < compactLimit;
         return okIdx ? gi : 0xFFFFFFFFu;                       // (only after a reported overflow)
     };
@@ -1696,7 +1888,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                     const bool narrow = narrow_extent(ts);
                     const bool maskedRec = MASKED && (name & CHORD_REC_WIDE) && (q2.z & 4u);   // a TriRecMaskExt follows the record
                     if (narrow && !maskedRec && (x1 - x0 + 1) * (y1 - y0 + 1) <= TINY_AREA) {
-                        if (!(p.debug & DBG_NO_TINY)) tile_raster_narrow(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask, DEPTH);
+                        if (!(p.debug & DBG_NO_TINY)) tile_raster_narrow<TPITCH>(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask, DEPTH);
                         if (prof) { cTiny++; cTinyIters += (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1)); }
                     } else {
                         rows = entry_store(prm, threadIdx.x, ts, narrow, ox, oy, x0, y0, x1, y1, maskedRec, name & ~CHORD_REC_WIDE);   // (units, not rows)
@@ -1832,6 +2024,8 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.vis = (unsigned long long*)c->dVis;
     p.W = (float)c->width; p.H = (float)c->height; p.Wi = (int32_t)c->width; p.Hi = (int32_t)c->height;
     p.shard = c->shard;
+    p.blockPool = c->dBlockPool; p.blockCap = (c->debugFlags & DBG_NO_BLOCKS) ? 0u : c->blockCap;
+    p.blockForce = (c->debugFlags & DBG_FORCE_BLOCKS) ? 1u : 0u;
     p.tris = c->dTris; p.triCap = c->triCap / CHORD_LIST_SHARDS;
     p.trisC = c->dTrisC; p.triCapC = c->triCapC / CHORD_LIST_SHARDS;
     const uint32_t tiles = c->tilesX * c->tilesY;
@@ -1862,7 +2056,8 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         LR_HIP(hipMemsetAsync(c->dCounters->largeCount[pass], 0, sizeof(c->dCounters->largeCount[pass]), c->stream));
         LR_HIP(hipMemsetAsync(&c->dCounters->binPoolCount[pass], 0, sizeof(uint32_t), c->stream));
         if (!c->inFrame) { LR_HIP(hipMemsetAsync(c->dCounters->triCount, 0, sizeof(c->dCounters->triCount), c->stream));
-                           LR_HIP(hipMemsetAsync(c->dCounters->triCountC, 0, sizeof(c->dCounters->triCountC), c->stream)); }
+                           LR_HIP(hipMemsetAsync(c->dCounters->triCountC, 0, sizeof(c->dCounters->triCountC), c->stream));
+                           LR_HIP(hipMemsetAsync(c->dCounters->blockGranules, 0, sizeof(c->dCounters->blockGranules), c->stream)); }
     }
 
     uint32_t blocks = (in.capacity + 3u) / 4u;

@@ -62,6 +62,8 @@ class Stats(C.Structure):
         ("countStage0Rejected", C.c_uint32), ("countStage1Visible", C.c_uint32), ("trianglesSubmitted", C.c_uint64),
         ("triangleRecords", C.c_uint64), ("binEntries", C.c_uint64), ("tilesTouched", C.c_uint32 * 2),
         ("triangleRecordsCompact", C.c_uint64),
+        ("pixelBlockBytes", C.c_uint64),
+        ("pixelBlocks", C.c_uint64),
     ]
 
     def as_dict(self):

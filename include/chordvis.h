@@ -115,6 +115,9 @@ typedef struct ChordStats {
     uint64_t binEntries;           /* (triangle, 64x64 tile) pairs binned (this frame, both raster passes) */
     uint32_t tilesTouched[2];      /* 64x64 tiles with at least one bin entry, per raster pass            */
     uint64_t triangleRecordsCompact; /* of triangleRecords, those in the 32-byte form (the rest take 48 bytes) */
+    uint64_t pixelBlockBytes;      /* bytes of pixel blocks emitted for small clusters in place of records (this frame); their
+                                      triangles are not in triangleRecords, a block counts as one bin entry per tile */
+    uint64_t pixelBlocks;          /* number of those blocks (= their bin entries) */
 } ChordStats;
 
 /* ------------------------------------------------------------------ host-only (no device needed) */
@@ -387,7 +390,10 @@ int chordvis_stats(ChordCtx* ctx, ChordStats* out);
  * emits no records / bins, 16 per-tile clocks (chordvis_debug_tile_profile), 32 skip the per-lane scan of tiny
  * triangles, 64 tile kernel of later passes returns at once, 128 no tile-out, 256 tile-out without the HZB
  * reduction, 512 setup-kernel phase clocks (chordvis_debug_setup_profile), 1024 fused tile-out skips the visibility
- * stores, 2048 never split long bins.  0 = production; anything else voids parity. */
+ * stores, 2048 never split long bins, 4096 / 8192 / 16384 tile kernel skips its row units / entry set-up / the bin
+ * altogether.  0 = production; any of those voids parity.  Two switches do NOT change results (tests run both): 32768 small
+ * clusters never leave the setup kernel as pixel blocks, 65536 every launch takes the setup kernel's pixel-block body
+ * (by default it does when a launch has more than one cluster per 16 pixels). */
 int chordvis_set_debug(ChordCtx* ctx, uint32_t flags);
 /* debugging aid: raw read of an internal buffer (0 tile counts, 1 fixed bins, 2 chunk table, 3 bin pool, 4 / 5 32- / 48-byte records) */
 int chordvis_debug_read(ChordCtx* ctx, int which, uint64_t offset, uint64_t bytes, void* host);

@@ -111,8 +111,10 @@ def test_oracle_depth_pass_properties():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,bias", [(256, (0.0, 0.0)), (512, (-48.0, -1.25)), (1000, (0.0, 0.0))], ids=["256", "512_biased", "1000_odd"])
-def test_cascade_depth_passes_match_oracle(gpu, dim, bias):
+@pytest.mark.parametrize("dim,bias,debug", [(256, (0.0, 0.0), 0), (512, (-48.0, -1.25), 0), (1000, (0.0, 0.0), 0),
+                                            (256, (0.0, 0.0), 65536), (512, (-48.0, -1.25), 65536)],
+                         ids=["256", "512_biased", "1000_odd", "256_pixel_blocks", "512_biased_pixel_blocks"])
+def test_cascade_depth_passes_match_oracle(gpu, dim, bias, debug):
     """renderShadow's loop (mesh_raster.cpp:443-531) cascade by cascade, far to near: instanceCulling for the cascade's
     orthographic view, hzbCullingGeneric against the previous cascade's HZB, clear + renderMeshDepth, buildHZB -- every
     list, depth image and HZB chain bit for bit against the oracle."""
@@ -123,6 +125,7 @@ def test_cascade_depth_passes_match_oracle(gpu, dim, bias):
     r.upload_scene(scene)
     r.allocate_gbuffer(cam.width, cam.height)
     r.set_view(view, iv, flags)
+    r.set_debug(debug)           # 65536: small clusters leave the setup kernel as pixel blocks (depth words, clamp and bias included)
     r.allocate_depth_views(dim, len(views))
     r.set_instance_views(views)
     desc = orc.hzb_desc(dim, dim)

@@ -10,12 +10,19 @@ from chord_amd import scenes
 pytestmark = pytest.mark.gpu
 
 
-def _renderer(gpu, scene, view, iv, w, h, flags):
+# chordvis_set_debug switches that do not change results: small clusters as pixel blocks never / on every launch
+# (by default the setup kernel decides per launch from the cluster count)
+NO_BLOCKS, FORCE_BLOCKS = 32768, 65536
+
+
+def _renderer(gpu, scene, view, iv, w, h, flags, debug=0):
     from chord_amd.renderer import VisibilityRenderer
     r = VisibilityRenderer(0)
     r.upload_scene(scene)
     r.allocate_gbuffer(w, h)
     r.set_view(view, iv, flags)
+    if debug:
+        r.set_debug(debug)
     return r
 
 
@@ -99,6 +106,41 @@ def test_two_pass_hzb_frame_matches_oracle(gpu, name, builder, flags):
     mn, mx, rng = r.read_hzb(r.history_hzb())
     assert np.array_equal(mn, want1["hzb_min"]) and np.array_equal(mx, want1["hzb_max"]) and np.array_equal(rng, want1["valid_range"])
     r.close()
+
+
+BLOCK_SCENES = [
+    ("small", lambda: scenes.small_test_scene(160, 96)),
+    ("small_hd", lambda: scenes.small_test_scene(640, 360, seed=11)),
+    ("masked", lambda: scenes.masked_test_scene(320, 200)),
+    ("street_360p", lambda: scenes.config3_street(640, 360)),
+    ("clip_view", lambda: scenes.floor_under_camera()),
+]
+
+
+@pytest.mark.parametrize("name,builder", BLOCK_SCENES, ids=[b[0] for b in BLOCK_SCENES])
+def test_pixel_blocks_of_small_clusters_are_exact(gpu, name, builder):
+    """The setup kernel's second body (clusters inside a 16x16-pixel window leave as dense blocks of packed words instead of
+    triangle records) forced on for scenes that would not select it by themselves: two frames (no history / two-pass HZB)
+    against the oracle, and word for word against the record path.  Clusters with masked, clipped or wide triangles, or
+    that are cheaper as records, keep taking records inside this body."""
+    scene, cam, view, iv = H.setup_scene(builder)
+    w, h = cam.width, cam.height
+    want0 = orc.frame(scene, view, iv, H.ALL_FLAGS)
+    want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want0["hzb_min"])
+    rb = _renderer(gpu, scene, view, iv, w, h, H.ALL_FLAGS, FORCE_BLOCKS)
+    rr = _renderer(gpu, scene, view, iv, w, h, H.ALL_FLAGS, NO_BLOCKS)
+    for frame, want in enumerate((want0, want1)):
+        rb.render_frame(); rr.render_frame()
+        got = rb.read_visibility()
+        H.assert_vis_equal(got, want["vis"], w, h, "%s frame %d, pixel blocks" % (name, frame))
+        assert np.array_equal(got, rr.read_visibility())
+        mn, mx, rng = rb.read_hzb(rb.history_hzb())
+        mn2, mx2, rng2 = rr.read_hzb(rr.history_hzb())
+        assert np.array_equal(mn, mn2) and np.array_equal(mx, mx2) and np.array_equal(rng, rng2)
+        sb, sr = rb.stats(), rr.stats()
+        assert sb["overflow"] == 0 and sr["pixelBlockBytes"] == 0
+        assert sb["trianglesSubmitted"] == sr["trianglesSubmitted"] and sb["triangleRecords"] <= sr["triangleRecords"]
+    rb.close(); rr.close()
 
 
 def test_hzb_culling_lists_match_oracle(gpu):
@@ -185,7 +227,15 @@ def test_bins_beyond_the_fixed_capacity_use_overflow_chunks(gpu):
     scene, cam, view, iv = H.setup_scene(scenes.config4_street_x64, W, Hh)
     want0 = orc.frame(scene, view, iv, H.ALL_FLAGS)
     want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want0["hzb_min"])
-    r = _renderer(gpu, scene, view, iv, W, Hh, H.ALL_FLAGS)
+    # (at this size nearly every cluster is small; as pixel blocks they leave the bins short -- that variant must be exact too)
+    rb = _renderer(gpu, scene, view, iv, W, Hh, H.ALL_FLAGS, FORCE_BLOCKS)
+    rb.render_frame()
+    H.assert_vis_equal(rb.read_visibility(), want0["vis"], W, Hh, "config4 frame 0, pixel blocks")
+    assert rb.stats()["pixelBlockBytes"] > 0 and rb.stats()["overflow"] == 0
+    rb.render_frame()
+    H.assert_vis_equal(rb.read_visibility(), want1["vis"], W, Hh, "config4 frame 1, pixel blocks")
+    rb.close()
+    r = _renderer(gpu, scene, view, iv, W, Hh, H.ALL_FLAGS, NO_BLOCKS)
     r.render_frame()
     H.assert_vis_equal(r.read_visibility(), want0["vis"], W, Hh, "config4 frame 0")
     tiles = ((W + 63) // 64) * ((Hh + 63) // 64)
@@ -232,22 +282,29 @@ def test_config5_subpixel_reduced_matches_oracle(gpu):
     assert want["stats"].trianglesRastered > 0.8 * want["stats"].trianglesSubmitted
     assert 0.3 * want["stats"].trianglesRastered < want["stats"].fragments < 0.8 * want["stats"].trianglesRastered
     from chord_amd.renderer import VisibilityRenderer
-    r = VisibilityRenderer(0)
-    r.set_limits(max_triangle_records=8 << 20, bin_pool_chunks=16384, bin_max_chunks_per_tile=2048)
-    r.upload_scene(scene)
-    r.allocate_gbuffer(W, Hh)
-    r.set_view(view, iv, flags)
-    r.render_frame()
-    H.assert_vis_equal(r.read_visibility(), want["vis"], W, Hh, "config5 reduced")
-    st = r.stats()
-    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["stats"].trianglesSubmitted
-    assert st["triangleRecords"] == want["stats"].trianglesRastered
-    # two-pass HZB on the same scene (occlusion between the patch layers)
     want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want["hzb_min"])
-    r.set_view(view, iv, H.ALL_FLAGS)
-    r.render_frame()
-    H.assert_vis_equal(r.read_visibility(), want1["vis"], W, Hh, "config5 reduced, HZB frame")
-    r.close()
+    for mode in (NO_BLOCKS, FORCE_BLOCKS):               # one record per triangle / one pixel block per cluster and tile
+        r = VisibilityRenderer(0)
+        r.set_limits(max_triangle_records=8 << 20, bin_pool_chunks=16384, bin_max_chunks_per_tile=2048)
+        r.upload_scene(scene)
+        r.allocate_gbuffer(W, Hh)
+        r.set_view(view, iv, flags)
+        r.set_debug(mode)
+        r.render_frame()
+        H.assert_vis_equal(r.read_visibility(), want["vis"], W, Hh, "config5 reduced, mode %d" % mode)
+        st = r.stats()
+        assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["stats"].trianglesSubmitted
+        if mode == NO_BLOCKS:
+            assert st["triangleRecords"] == want["stats"].trianglesRastered and st["pixelBlockBytes"] == 0
+        else:
+            # nearly every patch is one block (<= 2 x 2 with its tile crossings): far fewer bytes than 36 per triangle
+            assert st["triangleRecords"] < 0.05 * want["stats"].trianglesRastered
+            assert 0 < st["pixelBlockBytes"] < 0.5 * 36 * want["stats"].trianglesRastered
+        # two-pass HZB on the same scene (occlusion between the patch layers)
+        r.set_view(view, iv, H.ALL_FLAGS)
+        r.render_frame()
+        H.assert_vis_equal(r.read_visibility(), want1["vis"], W, Hh, "config5 reduced, HZB frame, mode %d" % mode)
+        r.close()
 
 
 def test_config5_subpixel_quarter_size_4k_matches_oracle(gpu):
@@ -316,6 +373,10 @@ SHARDED = [
     # full size: long bins, pool chunks and split tiles in both raster passes of a sharded frame
     ("street_x64_4k_2ranks", scenes.config4_street_x64, 2, None),
     ("masked_3ranks", lambda: scenes.masked_test_scene(320, 200), 3, 14),
+    # small clusters as pixel blocks on every rank (rows of a block that another rank owns stay empty)
+    ("subpixel_540p_8ranks_blocks", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4), 8, None),
+    ("street_x64_360p_3ranks_blocks", lambda: scenes.config4_street_x64(640, 360), 3, 18),
+    ("masked_3ranks_blocks", lambda: scenes.masked_test_scene(320, 200), 3, 14),
 ]
 
 
@@ -341,6 +402,8 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, r
         r.set_shard(stripe, ranks, rk)
         r.allocate_gbuffer(w, h)
         r.set_view(view, iv, flags)
+        if name.endswith("_blocks"):
+            r.set_debug(FORCE_BLOCKS)
         ctxs.append(r)
     hip = L._preload_hip_runtime()
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
