@@ -323,12 +323,41 @@ def test_config5_subpixel_quarter_size_4k_matches_oracle(gpu):
     r.upload_scene(scene)
     r.allocate_gbuffer(cam.width, cam.height)
     r.set_view(view, iv, flags)
+    r.set_debug(NO_BLOCKS)                  # one record per triangle: the long bins, slices and pool chunks are the point here
     r.render_frame()
     got = r.read_visibility()
     st = r.stats()
     want = orc.frame_mt(scene, view, iv, flags, None, threads=16)
-    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["triangles_submitted"]
+    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["triangles_submitted"] and st["pixelBlockBytes"] == 0
     H.assert_vis_equal(got, want["vis"], cam.width, cam.height, "config5 quarter size")
+    r.close()
+
+
+def test_config5_subpixel_full_size_matches_oracle(gpu):
+    """BASELINE config 5 at FULL size, the N > 1 bench workload: 1 073 741 824 sub-pixel triangles (8.4 M clusters) into
+    3840x2160 in one pass, bit for bit against the multi-threaded oracle replay.  Run as the bench runs it: the setup
+    kernel selects its pixel-block body by itself (more than one cluster per 16 pixels), so nearly every cluster leaves it
+    as one block per tile instead of 128 records."""
+    import os
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam = scenes.config5_subpixel(3840, 2160)
+    assert scene.triangle_count_lod0() == 1 << 30
+    L.fill_objects(scene, cam)
+    view, iv = L.make_views(cam)
+    flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL
+    r = VisibilityRenderer(0)
+    r.set_limits(max_triangle_records=1152 << 20, bin_pool_chunks=1200 << 10, bin_max_chunks_per_tile=2048)
+    r.upload_scene(scene)
+    r.allocate_gbuffer(cam.width, cam.height)
+    r.set_view(view, iv, flags)
+    r.render_frame()
+    got = r.read_visibility()
+    st = r.stats()
+    want = orc.frame_mt(scene, view, iv, flags, None, threads=min(32, os.cpu_count() or 1))
+    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["triangles_submitted"] == 1 << 30
+    assert st["pixelBlocks"] > 8 << 20 and st["triangleRecords"] < 1 << 20        # the block body ran
+    H.assert_vis_equal(got, want["vis"], cam.width, cam.height, "config5 full size")
     r.close()
 
 

@@ -12,9 +12,9 @@ cam_b = cam.moved(tuple(0.5 * f))
 va0, _ = L.make_views(cam); vb0, _ = L.make_views(cam_b)
 views = [L.make_views(cam, vb0), L.make_views(cam_b, va0)]
 objs = [L.fill_objects(scene, cam, cam_b).copy(), L.fill_objects(scene, cam_b, cam).copy()]
-flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | R.FLAG_HZB_CULL
+flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | (0 if wl.startswith("subpixel") else R.FLAG_HZB_CULL)
 r = VisibilityRenderer(0); r.upload_scene(scene); r.allocate_gbuffer(cam.width, cam.height)
-r.set_debug(512)
+r.set_debug(512 | (int(sys.argv[2]) if len(sys.argv) > 2 else 0))      # e.g. 65536: pixel-block body (its block code counts as "emit")
 for i in range(5):
     r.update_objects(objs[i & 1]); r.set_view(views[i & 1][0], views[i & 1][1], flags); r.render_frame()
 st = r.stats()
