@@ -180,8 +180,14 @@ __device__ __forceinline__ void write_record_c(TriRecC* dst, const TriSetup& ts,
 
 __device__ __forceinline__ bool tri_setup(TriSetup& ts, bool twoSided, int32_t Wi, int32_t Hi)
 {
-    const int64_t area2 = (int64_t)(ts.X[1] - ts.X[0]) * (int64_t)(ts.Y[2] - ts.Y[0]) -
-                          (int64_t)(ts.X[2] - ts.X[0]) * (int64_t)(ts.Y[1] - ts.Y[0]);
+    const int32_t dx1 = ts.X[1] - ts.X[0], dy1 = ts.Y[1] - ts.Y[0], dx2 = ts.X[2] - ts.X[0], dy2 = ts.Y[2] - ts.Y[0];
+    int64_t area2;
+    // deltas below 2^15 (vertices within 128 px of vertex 0 -- nearly every triangle): both products fit 2^30 and their
+    // difference an int32, from full-rate 24-bit multiplies; v_mul_lo/hi_u32 of the general form are quarter rate
+    const bool small = (uint32_t)(dx1 + 32767) < 65535u && (uint32_t)(dy1 + 32767) < 65535u &&
+                       (uint32_t)(dx2 + 32767) < 65535u && (uint32_t)(dy2 + 32767) < 65535u;
+    if (small) area2 = (int64_t)(__mul24(dx1, dy2) - __mul24(dx2, dy1));
+    else area2 = (int64_t)dx1 * (int64_t)dy2 - (int64_t)dx2 * (int64_t)dy1;
     if (area2 == 0) return false;
     if (!twoSided && area2 > 0) return false;            // VK_CULL_MODE_BACK_BIT (mesh_raster.cpp:235)
     ts.s = area2 < 0 ? -1 : 1;
@@ -193,7 +199,8 @@ __device__ __forceinline__ bool tri_setup(TriSetup& ts, bool twoSided, int32_t W
     ts.px1 = min(Wi - 1, (maxX - 128) >> 8);
     ts.py1 = min(Hi - 1, (maxY - 128) >> 8);
     if (ts.px1 < ts.px0 || ts.py1 < ts.py0) return false;
-    ts.invA = 1.0f / (float)(double)ts.area;
+    // (float)(double)area: one rounding of an exact value either way -- an int32 conversion when the area fits
+    ts.invA = 1.0f / (small ? (float)(int32_t)ts.area : (float)(double)ts.area);
     return true;
 }
 
@@ -1220,26 +1227,29 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
                                                    int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels,
                                                    unsigned long long rowMask, const bool clampZ)
 {
-    const int32_t s = ts.s;
+    // (32-bit multiplies are quarter rate on this GPU; every product here has factors below 2^23 -- vertices at most 64 px
+    // apart, a pixel centre inside their bbox -- and takes the full-rate 24-bit form; +-s is a select, not a multiply)
+    const bool neg = ts.s < 0;
     const int32_t dx0 = ts.X[2] - ts.X[1], dy0 = ts.Y[2] - ts.Y[1];
     const int32_t dx1 = ts.X[0] - ts.X[2], dy1 = ts.Y[0] - ts.Y[2];
     const int32_t dx2 = ts.X[1] - ts.X[0], dy2 = ts.Y[1] - ts.Y[0];
-    const int32_t a0 = -s * dy0, b0 = s * dx0;
-    const int32_t a1 = -s * dy1, b1 = s * dx1;
-    const int32_t a2 = -s * dy2, b2 = s * dx2;
+    const int32_t a0 = neg ? dy0 : -dy0, b0 = neg ? -dx0 : dx0;
+    const int32_t a1 = neg ? dy1 : -dy1, b1 = neg ? -dx1 : dx1;
+    const int32_t a2 = neg ? dy2 : -dy2, b2 = neg ? -dx2 : dx2;
     const int32_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? 0 : -1;
     const int32_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 0 : -1;
     const int32_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 0 : -1;
     const int32_t cx0 = x0 * 256 + 128, cy0 = y0 * 256 + 128;
-    int32_t r0 = s * (dx0 * (cy0 - ts.Y[1]) - dy0 * (cx0 - ts.X[1])) + bias0;   // bias folded in: inside <=> all >= 0
-    int32_t r1 = s * (dx1 * (cy0 - ts.Y[2]) - dy1 * (cx0 - ts.X[2])) + bias1;
-    int32_t r2 = s * (dx2 * (cy0 - ts.Y[0]) - dy2 * (cx0 - ts.X[0])) + bias2;
+    // s * (dx * (cy - Y) - dy * (cx - X)) = b * (cy - Y) + a * (cx - X)
+    int32_t r0 = __mul24(b0, cy0 - ts.Y[1]) + __mul24(a0, cx0 - ts.X[1]) + bias0;   // bias folded in: inside <=> all >= 0
+    int32_t r1 = __mul24(b1, cy0 - ts.Y[2]) + __mul24(a1, cx0 - ts.X[2]) + bias1;
+    int32_t r2 = __mul24(b2, cy0 - ts.Y[0]) + __mul24(a2, cx0 - ts.X[0]) + bias2;
     int32_t E0 = r0, E1 = r1, E2 = r2;
-    const int32_t w = x1 - x0 + 1, count = w * (y1 - y0 + 1);
+    const int32_t w = x1 - x0 + 1, count = __mul24(w, y1 - y0 + 1);
     // step to the next pixel / from the last pixel of a row to the first of the next; the body is branch-free:
     // a pixel outside the triangle (or in a row another rank owns) merges 0, which ds_max ignores
     const int32_t sx0 = a0 * 256, sx1 = a1 * 256, sx2 = a2 * 256;
-    const int32_t sw0 = b0 * 256 - (w - 1) * sx0, sw1 = b1 * 256 - (w - 1) * sx1, sw2 = b2 * 256 - (w - 1) * sx2;
+    const int32_t sw0 = b0 * 256 - __mul24(w - 1, sx0), sw1 = b1 * 256 - __mul24(w - 1, sx1), sw2 = b2 * 256 - __mul24(w - 1, sx2);
     int32_t ly = y0 - oy, col = 0;
     unsigned long long* px = tile + ly * PITCH + (x0 - ox);
     const unsigned long long payload = (unsigned long long)ts.payload;
