@@ -10,7 +10,7 @@ from chord_amd.sharding import pick_stripe_rows
 wl = sys.argv[1] if len(sys.argv) > 1 else "subpixel_64m"
 scene, cam = bench.build_workload(wl)
 view, iv = L.make_views(cam)
-flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL
+flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | (0 if wl.startswith("subpixel") else R.FLAG_HZB_CULL)
 objs = L.fill_objects(scene, cam, cam)
 for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
     r = VisibilityRenderer(0)
@@ -22,6 +22,7 @@ for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
         r.set_shard(int(os.environ.get("STRIPE", pick_stripe_rows(cam.height, ranks))), ranks, 0)
     r.allocate_gbuffer(cam.width, cam.height)
     r.update_objects(objs); r.set_view(view, iv, flags)
+    r.enable_timers(2)
 
     def frame():
         if ranks == 1:
@@ -38,5 +39,7 @@ for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
     r.sync()
     ms = (time.perf_counter() - t0) / n * 1e3
     st = r.stats()
-    print("ranks %d: rank 0 compute %.3f ms/frame, records %d, overflow %d" % (ranks, ms, st["triangleRecords"], st["overflow"]))
+    print("ranks %d: rank 0 compute %.3f ms/frame, records %d, overflow %d;  GPU stamps (ms): cull %.3f stage0 %.3f hzb0 %.3f stage1 %.3f hzbFinal %.3f | setup %.3f clip+order %.3f tile %.3f"
+          % (ranks, ms, st["triangleRecords"], st["overflow"], st["msInstanceCulling"], st["msStage0"], st["msHzbStage0"], st["msStage1"], st["msHzbFinal"],
+             st["msRasterCluster"], st["msRasterClip"], st["msRasterChunk"]))
     r.close()
