@@ -1578,8 +1578,11 @@ __device__ __forceinline__ int32_t entry_unit(const RasterParams& p, const Entry
 // Wave w owns pixel rows 8w..8w+7: lanes 0-31 read two pixels of an even row, lanes 32-63 of the odd row below, so a
 // mip-0 texel is one cross-half shuffle away, mips 1-2 are shuffles + the running rows of the wave, and only mips
 // 3-5 (8x8 values per tile) cross waves through LDS: one barrier per tile.
-__device__ __forceinline__ void tile_out_and_hzb(const RasterParams& p, const unsigned long long* tile, float* sM2, uint32_t* sRange,
-                                                 uint32_t tileId, int32_t ox, int32_t oy, int32_t tw, int32_t th)
+// INTERIOR: every HZB texel of the tile, at every level, lies inside the chain's valid extent (all tiles but those at the
+// right / bottom screen edge): no per-texel bounds arithmetic.
+template <bool INTERIOR>
+__device__ __forceinline__ void tile_out_and_hzb_body(const RasterParams& p, const unsigned long long* tile, float* sM2, uint32_t* sRange,
+                                                      uint32_t tileId, int32_t ox, int32_t oy, int32_t tw, int32_t th)
 {
     static_assert(TILE == 64 && TB == 512, "wave w <-> pixel rows 8w..8w+7");
     const ChordHZBDesc& d = p.hzbDesc;
@@ -1588,7 +1591,7 @@ __device__ __forceinline__ void tile_out_and_hzb(const RasterParams& p, const un
     auto vw = [&](uint32_t lv) { return min(max(1u, d.width >> lv), (((d.srcWidth - 1u) >> 1) >> lv) + 1u); };
     auto vh = [&](uint32_t lv) { return min(max(1u, d.height >> lv), (((d.srcHeight - 1u) >> 1) >> lv) + 1u); };
     auto put = [&](uint32_t lv, uint32_t gx, uint32_t gy, float mn, float mx) {
-        if (lv < d.mipCount && gx < vw(lv) && gy < vh(lv)) {
+        if (INTERIOR || (lv < d.mipCount && gx < vw(lv) && gy < vh(lv))) {
             const size_t o = d.mipOffset[lv] + (size_t)gy * max(1u, d.width >> lv) + gx;
             const uint16_t hmn = f32_to_f16(mn);
             uint16_t hmx = f32_to_f16(mx);
@@ -1598,38 +1601,44 @@ __device__ __forceinline__ void tile_out_and_hzb(const RasterParams& p, const un
             p.hzbMaxB[o] = hmx;
         }
     };
+    // A lane owns 2x2 pixel quads: column pair l, row pairs q = 2 half + rp (rp = 0, 1) of the wave's four.  A mip-0 texel
+    // is lane-local, a mip-1 texel is the lane's two iterations and its x neighbour (DPP), a mip-2 texel adds the x
+    // neighbour two over and the other half of the wave (the one cross-half exchange per lane); 8-byte LDS reads of
+    // consecutive words per half-wave, 512-byte coalesced visibility stores per row.
     uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
-    float m1n = 0.0f, m1x = 0.0f, m2n = 0.0f, m2x = 0.0f;
+    float m1n = 0.0f, m1x = 0.0f;
 #pragma unroll
-    for (uint32_t rp = 0; rp < 4u; rp++) {
-        const int32_t row = (int32_t)(8u * wave + 2u * rp + half), x2 = (int32_t)(2u * l);
-        const int32_t rc = min(row, th - 1), xa = min(x2, tw - 1), xb = min(x2 + 1, tw - 1);
-        const unsigned long long va = tile[rc * TPITCH + xa], vb = tile[rc * TPITCH + xb];
-        if (row < th && x2 < tw && !(p.debug & DBG_NO_VIS_STORE)) {
+    for (uint32_t rp = 0; rp < 2u; rp++) {
+        const uint32_t q = 2u * half + rp;
+        const int32_t row = (int32_t)(8u * wave + 2u * q), x2 = (int32_t)(2u * l);
+        const int32_t r0 = min(row, th - 1), r1 = min(row + 1, th - 1), xa = min(x2, tw - 1), xb = min(x2 + 1, tw - 1);
+        const unsigned long long v00 = tile[r0 * TPITCH + xa], v01 = tile[r0 * TPITCH + xb];
+        const unsigned long long v10 = tile[r1 * TPITCH + xa], v11 = tile[r1 * TPITCH + xb];
+        if (!(p.debug & DBG_NO_VIS_STORE) && (INTERIOR || x2 < tw)) {
             unsigned long long* dst = p.vis + (size_t)(oy + row) * (size_t)p.Wi + ox + x2;
-            if (x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(va, vb);
-            else dst[0] = va;
+            if (INTERIOR || row < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(v00, v01); else dst[0] = v00; }
+            if (INTERIOR || row + 1 < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst + p.Wi) = make_ulonglong2(v10, v11); else dst[p.Wi] = v10; }
         }
-        const float da = __uint_as_float((uint32_t)(va >> 32)), db = __uint_as_float((uint32_t)(vb >> 32));
-        if (da > 0.0f) { const uint32_t bits = __float_as_uint(da); if (da < 1.0f) rmin = min(rmin, bits); rmax = max(rmax, bits); }   // hzb.hlsl:163-176
-        if (db > 0.0f) { const uint32_t bits = __float_as_uint(db); if (db < 1.0f) rmin = min(rmin, bits); rmax = max(rmax, bits); }
-        float mn = fminf(da, db), mx = fmaxf(da, db);
-        mn = fminf(mn, __shfl_xor(mn, 32, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));       // mip 0 texel (l, 4 wave + rp)
-        if (half == 0u) put(0u, tX * 32u + l, tY * 32u + 4u * wave + rp, mn, mx);
-        const float pn = fminf(mn, __shfl_xor(mn, 1, 64)), px = fmaxf(mx, __shfl_xor(mx, 1, 64));   // x pair
-        if (rp & 1u) {
-            m1n = fminf(m1n, pn); m1x = fmaxf(m1x, px);                                        // mip 1 texel (l/2, 2 wave + rp/2)
-            if (half == 0u && (l & 1u) == 0u) put(1u, tX * 16u + (l >> 1), tY * 16u + 2u * wave + (rp >> 1), m1n, m1x);
-            const float qn = fminf(m1n, __shfl_xor(m1n, 2, 64)), qx = fmaxf(m1x, __shfl_xor(m1x, 2, 64));
-            if (rp == 1u) { m2n = qn; m2x = qx; }
-            else {
-                m2n = fminf(m2n, qn); m2x = fmaxf(m2x, qx);                                    // mip 2 texel (l/4, wave)
-                if (half == 0u && (l & 3u) == 0u) {
-                    put(2u, tX * 8u + (l >> 2), tY * 8u + wave, m2n, m2x);
-                    sM2[wave * 8u + (l >> 2)] = m2n; sM2[64u + wave * 8u + (l >> 2)] = m2x;
-                }
-            }
-        } else { m1n = pn; m1x = px; }
+        const float dq[4] = {__uint_as_float((uint32_t)(v00 >> 32)), __uint_as_float((uint32_t)(v01 >> 32)),
+                             __uint_as_float((uint32_t)(v10 >> 32)), __uint_as_float((uint32_t)(v11 >> 32))};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                                       // valid range (hzb.hlsl:163-176), branch-free
+            const uint32_t bits = __float_as_uint(dq[k]);
+            const bool drawn = dq[k] > 0.0f;
+            rmax = max(rmax, drawn ? bits : 0u);
+            rmin = min(rmin, (drawn && dq[k] < 1.0f) ? bits : 0xFFFFFFFFu);
+        }
+        const float mn = fminf(fminf(dq[0], dq[1]), fminf(dq[2], dq[3])), mx = fmaxf(fmaxf(dq[0], dq[1]), fmaxf(dq[2], dq[3]));
+        put(0u, tX * 32u + l, tY * 32u + 4u * wave + q, mn, mx);           // mip 0 texel (l, 4 wave + q)
+        if (rp == 0u) { m1n = mn; m1x = mx; } else { m1n = fminf(m1n, mn); m1x = fmaxf(m1x, mx); }
+    }
+    m1n = fminf(m1n, __shfl_xor(m1n, 1, 64)); m1x = fmaxf(m1x, __shfl_xor(m1x, 1, 64));   // mip 1 texel (l/2, 2 wave + half)
+    if ((l & 1u) == 0u) put(1u, tX * 16u + (l >> 1), tY * 16u + 2u * wave + half, m1n, m1x);
+    float m2n = fminf(m1n, __shfl_xor(m1n, 2, 64)), m2x = fmaxf(m1x, __shfl_xor(m1x, 2, 64));
+    m2n = fminf(m2n, __shfl_xor(m2n, 32, 64)); m2x = fmaxf(m2x, __shfl_xor(m2x, 32, 64));   // mip 2 texel (l/4, wave)
+    if (half == 0u && (l & 3u) == 0u) {
+        put(2u, tX * 8u + (l >> 2), tY * 8u + wave, m2n, m2x);
+        sM2[wave * 8u + (l >> 2)] = m2n; sM2[64u + wave * 8u + (l >> 2)] = m2x;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1657,6 +1666,18 @@ __device__ __forceinline__ void tile_out_and_hzb(const RasterParams& p, const un
             p.tileRange[2u * tileId] = lo; p.tileRange[2u * tileId + 1u] = hi;   // reduced over tiles by hzb_tail_kernel
         }
     }
+}
+
+__device__ __forceinline__ void tile_out_and_hzb(const RasterParams& p, const unsigned long long* tile, float* sM2, uint32_t* sRange,
+                                                 uint32_t tileId, int32_t ox, int32_t oy, int32_t tw, int32_t th)
+{
+    const ChordHZBDesc& d = p.hzbDesc;
+    const uint32_t tX = tileId % p.tilesX, tY = tileId / p.tilesX;
+    const uint32_t vw0 = min(max(1u, d.width), ((d.srcWidth - 1u) >> 1) + 1u), vh0 = min(max(1u, d.height), ((d.srcHeight - 1u) >> 1) + 1u);
+    // (valid extents shrink by floor per level, so a tile inside level 0's is inside every level's up to 5)
+    const bool interior = tw == TILE && th == TILE && d.mipCount > 5u && (tX + 1u) * 32u <= vw0 && (tY + 1u) * 32u <= vh0;
+    if (interior) tile_out_and_hzb_body<true>(p, tile, sM2, sRange, tileId, ox, oy, tw, th);
+    else tile_out_and_hzb_body<false>(p, tile, sM2, sRange, tileId, ox, oy, tw, th);
 }
 
 // Split tiles (see raster_tile_kernel): merges this slice's LDS tile into the tile's accumulation slab and draws a
