@@ -2112,8 +2112,9 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // first pass of a frame: every tile is written, one block each, dispatched heaviest first; later passes touch
     // few tiles: one resident wave of blocks strides over the (device-side) active list
     // (a static snake assignment of 2 or 4 items per block with the next item prefetched -- half / a quarter of the blocks,
-    // start-up round trips paid once -- was measured: tile kernel +4 % on config 3, +12..18 % on config 4; the dispatcher's
-    // dynamic hand-out of one item per block balances better than any static split)
+    // start-up round trips paid once, also with a loop-end barrier that does not wait for the visibility stores to drain --
+    // was measured: tile kernel +4..6 % on config 3, +11..18 % on config 4; the dispatcher's dynamic hand-out of one item
+    // per block balances better than any static split)
     const uint32_t tileBlocks = clearTiles ? tiles : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
     if (c->depthClamp && !sh) {
         if (c->anyMasked) hipLaunchKernelGGL((raster_tile_kernel<false, true, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
