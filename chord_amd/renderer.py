@@ -277,6 +277,11 @@ class VisibilityRenderer:
         """0 off, 1 last frame, 2 accumulate until stats(); only every `period`-th frame is stamped."""
         self._check(L.lib.chordvis_enable_timers(self._ctx, int(mode) | (int(period) << 8)), "enable_timers")
 
+    def last_error(self):
+        """Text of the last error this context reported (chordvis_last_error)."""
+        msg = L.lib.chordvis_last_error(self._ctx)
+        return msg.decode(errors="replace") if msg else ""
+
     def set_debug(self, flags):
         """Measurement-only ablation switches (0 = production)."""
         self._check(L.lib.chordvis_set_debug(self._ctx, int(flags)), "set_debug")
