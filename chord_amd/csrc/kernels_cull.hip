@@ -252,14 +252,21 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
             const DObjStatic st = p.objStatic[o];
             const DPrim& prim = p.prims[st.prim];
             const DGroup g = p.groups[prim.groupBase + (t - st.groupBase)];
-            if (group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {     // instance_culling.hlsl:174
+            if (g.meshletCount != 0u && group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {     // instance_culling.hlsl:174
                 const Mat4 M = load_mat(p.objects[o].basicData.localToTranslatedWorld);
                 const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
-                for (uint32_t i = 0; i < g.meshletCount && i < CHORD_GROUP_MAX_MESHLETS; i++) {
-                    const uint32_t mi = prim.meshletBase + p.groupIndices[idxBase + i];  // :178-180
-                    if (meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (st.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, p.meshlets[mi])) {
+                // the (up to) four meshlets of the group: their indices in one round trip, the records in a second one --
+                // not index -> record four times in a row (a slot beyond the group's count re-reads its first meshlet)
+                const uint32_t cnt = min(g.meshletCount, (uint32_t)CHORD_GROUP_MAX_MESHLETS);
+                uint32_t mi[CHORD_GROUP_MAX_MESHLETS];
+#pragma unroll
+                for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) mi[i] = prim.meshletBase + p.groupIndices[idxBase + (i < cnt ? i : 0u)];  // :178-180
+#pragma unroll
+                for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
+                    const DMeshlet m = p.meshlets[mi[i]];
+                    if (i < cnt && meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (st.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, m)) {
                         mask |= 1u << i;
-                        tris += (p.meshlets[mi].vertexTriangleCount >> 8) & 0xFFu;
+                        tris += (m.vertexTriangleCount >> 8) & 0xFFu;
                     }
                 }
             }
