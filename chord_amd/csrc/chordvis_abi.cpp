@@ -852,10 +852,17 @@ static int render_frame_impl(ChordCtx* c)
     record(c, S_STAGE0_END);
     c->shouldStage1 = stage1 != 0;
     if (!rc && stage1) {
-        launch_hzb_tail(c, c->hzb[0], false, false);                                  // buildHZB(min)  :334
+        // buildHZB(min) :334 -- levels 0..5 came out of the tile kernel; the one-block tail (levels 6..) is reduced by the
+        // blocks of the phase-1 cull themselves unless the chain does not fit their LDS budget (never for targets <= 4096^2)
+        const ChordHZBDesc& hd = c->hzb[0].desc;
+        uint32_t tailFloats = 0;
+        for (uint32_t l = 6; l < hd.mipCount; l++) tailFloats += std::max(1u, hd.width >> l) * std::max(1u, hd.height >> l);
+        c->hzbTailInCull = hd.mipCount > 6u && tailFloats <= 1408u && !(c->debugFlags & 131072u);
+        if (!c->hzbTailInCull) launch_hzb_tail(c, c->hzb[0], false, false);
         record(c, S_HZB0);
         ChordHZB tmp = c->hzb[0].handle();
         rc = chordvis_visibility_stage1(c, &tmp, rejected);                           // :337
+        c->hzbTailInCull = false;
         record(c, S_STAGE1_END);
     }
     c->fuseHzb = false;

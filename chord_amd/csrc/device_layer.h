@@ -333,6 +333,7 @@ struct ChordCtx {
     uint32_t rasterCalls = 0;          // renderMesh calls since the last clear
     bool shouldStage1 = false;
     chord::CmdList lastRejected;
+    bool hzbTailInCull = false;        // render_frame: the phase-1 HZB cull reduces levels 6.. of the chain itself (no hzb_tail_kernel before it)
     uint32_t debugFlags = 0;           // ablation switches for measurements (chordvis_set_debug)
     unsigned long long* dTileClocks = nullptr;   // [2][CHORD_MAX_TILES] per-tile ticks when debug bit 4 is set
 };

@@ -433,15 +433,50 @@ __global__ __launch_bounds__(1024) void group_cull_prefix_kernel(uint32_t* __res
 struct HzbCullParams {
     const DObjFrame* objFrame; const DMeshlet* meshlets; const DView* dview;
     const uint16_t* hzbMin; ChordHZBDesc desc;
+    uint16_t* hzbTailOut;                  // TAIL kernels: block 0 also stores the levels it reduced (the chain stays complete in memory)
     const uint32_t* inCount; const ChordDrawCmd* inCmds;
     uint32_t* visCount; ChordDrawCmd* visCmds;
     uint32_t* rejCount; ChordDrawCmd* rejCmds;
     DeviceCounters* counters;
 };
 
+// The tail of the min chain (levels 6.. from the stored level 5: 60 x 34 texels at 4K) reduced by the calling block into
+// LDS, level by level: what hzb_tail_kernel computes (hzb_device.h: 2x2 taps clamped to the valid extent of the level
+// below; min of binary16 values is one of them, so f32 copies are exact), without a launch of its own between the first
+// raster pass and the phase-1 cull -- a few hundred texels per block against ~6 us of launch + drain.  sOff[l] = offset of
+// level l, stored at the level's full pitch like the chain in memory.
+#define HZB_TAIL_FIRST 6u
+#define HZB_TAIL_FLOATS 1408u              // a 4096^2 target (the largest): 32^2 + 16^2 + 8^2 + 4^2 + 2^2 + 1 = 1365
+__device__ __forceinline__ void hzb_tail_to_lds(const uint16_t* __restrict__ hzbMin, uint16_t* out, const ChordHZBDesc& d, float* sTail, uint32_t* sOff)
+{
+    uint32_t off = 0, poff = 0;
+    for (uint32_t l = HZB_TAIL_FIRST; l < d.mipCount; l++) {
+        const uint32_t vw = valid_w(d, l), vh = valid_h(d, l), mw = max(1u, d.width >> l), mh = max(1u, d.height >> l);
+        const uint32_t gw = valid_w(d, l - 1), gh = valid_h(d, l - 1), pmw = max(1u, d.width >> (l - 1));
+        if (threadIdx.x == 0) sOff[l] = off;
+        for (uint32_t i = threadIdx.x; i < vw * vh; i += 256u) {
+            const uint32_t x = i % vw, y = i / vw;
+            float mn = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                for (int ii = 0; ii < 2; ii++) {
+                    const uint32_t cx = min(2u * x + ii, gw - 1u), cy = min(2u * y + jj, gh - 1u);
+                    const float a = l == HZB_TAIL_FIRST ? f16_to_f32(hzbMin[d.mipOffset[l - 1] + cy * pmw + cx]) : sTail[poff + cy * pmw + cx];
+                    mn = (ii == 0 && jj == 0) ? a : fminf(mn, a);
+                }
+            sTail[off + y * mw + x] = mn;
+            if (out) out[d.mipOffset[l] + y * mw + x] = f32_to_f16(mn);
+        }
+        poff = off; off += mw * mh;
+        __syncthreads();
+    }
+}
+
 // occlusion test of one command (hzb_mainview_culling.hlsl:60-161)
-template <int PHASE>
-__device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DView& dv, const ChordDrawCmd& cmd, uint32_t& tris)
+template <int PHASE, bool TAIL = false>
+__device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DView& dv, const ChordDrawCmd& cmd, uint32_t& tris,
+                                                const float* sTail = nullptr, const uint32_t* sTailOff = nullptr)
 {
     bool visible = true;
     {
@@ -492,6 +527,17 @@ __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DV
                         const uint32_t mw = max(1u, p.desc.width >> lv);
                         const uint16_t* mip = p.hzbMin + p.desc.mipOffset[lv];
                         float zMin = 10.0f;
+                        if (TAIL && lv >= (int)HZB_TAIL_FIRST) {
+                            // levels 6.. were reduced by this block into LDS (hzb_tail_to_lds): same values, no launch for them
+                            const float* lmip = sTail + sTailOff[lv];
+#pragma unroll
+                            for (int x = 0; x < 4; x++)
+#pragma unroll
+                                for (int y = 0; y < 4; y++) {
+                                    const int sx = min(cz, cx + x), sy = min(cw, cy + y);
+                                    zMin = fminf(zMin, lmip[(uint32_t)sy * mw + (uint32_t)sx]);
+                                }
+                        } else
 #pragma unroll
                         for (int x = 0; x < 4; x++)
 #pragma unroll
@@ -573,14 +619,20 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
 // = 92 us on this GPU (~88/us per line, measured); the kernel took 76 us.  List order is free (cmd.z is carried).
 // K = commands per thread: 4 for long lists, 1 for short ones (a short list is latency-bound: one command per thread
 // keeps the dependent chain of loads short and still needs only count/256 reservations).
-template <int PHASE, uint32_t K>
+template <int PHASE, uint32_t K, bool TAIL>
 __global__ __launch_bounds__(256) void hzb_cull_kernel(HzbCullParams p)
 {
     __shared__ uint32_t sWave[4], sBase[2];
     __shared__ unsigned long long sTris[4];
+    __shared__ float sTail[TAIL ? HZB_TAIL_FLOATS : 1u];
+    __shared__ uint32_t sTailOff[CHORD_HZB_MAX_MIPS];
     const uint32_t count = *p.inCount;
     const DView& dv = *p.dview;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // TAIL: the chain this launch culls against has its levels 0..5 in memory; every block with work reduces the rest
+    // itself (block 0 also stores them)
+    if (TAIL && (blockIdx.x * (256u * K) < count || blockIdx.x == 0u) && (dv.flags & CHORD_FLAG_HZB_CULL))
+        hzb_tail_to_lds(p.hzbMin, blockIdx.x == 0u ? p.hzbTailOut : nullptr, p.desc, sTail, sTailOff);
     for (uint32_t base = blockIdx.x * (256u * K); base < count; base += gridDim.x * (256u * K)) {
         ChordDrawCmd cmd[K];
         uint32_t visBits = 0, rejBits = 0, tris = 0;
@@ -591,7 +643,7 @@ __global__ __launch_bounds__(256) void hzb_cull_kernel(HzbCullParams p)
             if (i < count) {
                 cmd[k] = p.inCmds[i];
                 uint32_t t = 0;
-                if (hzb_cmd_visible<PHASE>(p, dv, cmd[k], t)) { visBits |= 1u << k; tris += t; }
+                if (hzb_cmd_visible<PHASE, TAIL>(p, dv, cmd[k], t, sTail, sTailOff)) { visBits |= 1u << k; tris += t; }
                 else rejBits |= 1u << k;
             }
         }
@@ -738,7 +790,7 @@ static HzbCullParams make_hzb_cull_params(ChordCtx* c, const HzbBuffers& hzb, co
 {
     HzbCullParams p;
     p.objFrame = c->dObjFrame; p.meshlets = c->dMeshlets; p.dview = c->dView;
-    p.hzbMin = hzb.minTexels; p.desc = hzb.desc;
+    p.hzbMin = hzb.minTexels; p.desc = hzb.desc; p.hzbTailOut = hzb.minTexels;
     p.inCount = in.count; p.inCmds = in.cmds;
     p.visCount = outVisible.count; p.visCmds = outVisible.cmds;
     p.rejCount = outRejected ? outRejected->count : nullptr;
@@ -905,10 +957,14 @@ void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdLis
     const uint32_t maxBlocks = (uint32_t)c->numCUs * 8u;
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
-    if (phase == 0) { if (longList) hipLaunchKernelGGL((hzb_cull_kernel<0, 4u>), dim3(blocks), dim3(256), 0, c->stream, p);
-                      else          hipLaunchKernelGGL((hzb_cull_kernel<0, 1u>), dim3(blocks), dim3(256), 0, c->stream, p); }
-    else            { if (longList) hipLaunchKernelGGL((hzb_cull_kernel<1, 4u>), dim3(blocks), dim3(256), 0, c->stream, p);
-                      else          hipLaunchKernelGGL((hzb_cull_kernel<1, 1u>), dim3(blocks), dim3(256), 0, c->stream, p); }
+    if (phase == 0) { if (longList) hipLaunchKernelGGL((hzb_cull_kernel<0, 4u, false>), dim3(blocks), dim3(256), 0, c->stream, p);
+                      else          hipLaunchKernelGGL((hzb_cull_kernel<0, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
+    else if (c->hzbTailInCull) {
+        // (inside chordvis_render_frame: the tile kernel wrote levels 0..5 of this chain; no hzb_tail_kernel ran)
+        if (longList) hipLaunchKernelGGL((hzb_cull_kernel<1, 4u, true>), dim3(blocks), dim3(256), 0, c->stream, p);
+        else          hipLaunchKernelGGL((hzb_cull_kernel<1, 1u, true>), dim3(blocks), dim3(256), 0, c->stream, p);
+    } else          { if (longList) hipLaunchKernelGGL((hzb_cull_kernel<1, 4u, false>), dim3(blocks), dim3(256), 0, c->stream, p);
+                      else          hipLaunchKernelGGL((hzb_cull_kernel<1, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
 }
 
 } // namespace chord
