@@ -225,3 +225,133 @@ def hzb_visible(scene, view, cmds, phase, hzb_levels, dims):
         if zmin > mx[i, 2]:
             visible[i] = False
     return visible
+
+
+def hzb_visible_generic(scene, cull_view, main_camera_pos, cmds, extent_scale, use_last_frame, hzb_levels):
+    """hzb_culling_generic.hlsl:37-172 for every command: True = kept.  cull_view = the InstanceCullingViewInfo whose HZB is
+    tested (its matrix, render dimension and camera position); main_camera_pos = PerframeCameraView.cameraWorldPos (float64
+    triple) the object matrices are relative to.  hzb_levels[l] = float16-bit min texels of mip l (valid extent)."""
+    O = scene.objects[cmds["objectId"]]
+    m = scene.meshlets[cmds["meshletId"]]
+    l2w = mat(O["localToTranslatedWorldLastFrame" if use_last_frame else "localToTranslatedWorld"]).copy()
+    view_pos = np.frombuffer(np.ascontiguousarray(cull_view["cameraWorldPos"][0]).tobytes(), dtype=np.float64)[:3]
+    rel = (np.asarray(main_camera_pos, dtype=np.float64) - view_pos).astype(f32)       # float3(double3 - double3)
+    for r in range(3):
+        l2w[:, r, 3] = l2w[:, r, 3] + rel[r]
+    MVP = mul_mm(mat(cull_view["translatedWorldToClip"])[0], l2w)
+    P = corners(m["posMin"].astype(f32), m["posMax"].astype(f32))
+    with np.errstate(all="ignore"):
+        uvz = project_uvz(P, MVP[:, None])                                               # (n, 8, 3)
+        mn = np.minimum(uvz.min(axis=1), f32(10.0)); mx = np.maximum(uvz.max(axis=1), f32(-10.0))
+        can = ((uvz < 1) & (uvz > 0)).all(axis=(1, 2))                                   # every corner strictly inside the unit cube
+    W, H = f32(cull_view["renderDimension"][0, 0]), f32(cull_view["renderDimension"][0, 1])
+    es = f32(extent_scale)
+    with np.errstate(all="ignore"):
+        x0 = (mn[:, 0] * W + es * f32(-0.5)).astype(np.int32); y0 = (mn[:, 1] * H + es * f32(-0.5)).astype(np.int32)
+        x1 = (mx[:, 0] * W + es * f32(0.5)).astype(np.int32); y1 = (mx[:, 1] * H + es * f32(0.5)).astype(np.int32)
+    x0, y0 = np.maximum(x0, 0), np.maximum(y0, 0)
+    x1 = np.minimum(W - f32(1), x1.astype(f32)).astype(np.int32); y1 = np.minimum(H - f32(1), y1.astype(f32)).astype(np.int32)
+    keep = np.ones(len(cmds), dtype=bool)
+    fbh = lambda v: int(v).bit_length() - 1                                              # firstbithigh, -1 for 0
+    for i in np.nonzero(can)[0]:
+        if x1[i] < x0[i] or y1[i] < y0[i]:
+            keep[i] = False
+            continue
+        a, b, c, d = x0[i] >> 1, y0[i] >> 1, x1[i] >> 1, y1[i] >> 1
+        lv = max(0, max(fbh(c - a), fbh(d - b)))
+        if ((c >> lv) - (a >> lv) >= 2) or ((d >> lv) - (b >> lv) >= 2):
+            lv += 1
+        cx, cy, cz, cw = a >> lv, b >> lv, c >> lv, d >> lv
+        tex = hzb_levels[lv].view(np.float16)
+        zmin = f32(10.0)
+        for xx in range(2):
+            for yy in range(2):
+                zmin = min(zmin, f32(tex[min(cw, cy + yy), min(cz, cx + xx)]))
+        if zmin > mx[i, 2]:
+            keep[i] = False
+    return keep
+
+
+def cascade_views_f64(cfg, view, light_dir, valid_range=None):
+    """cascadeComputeCS (cascade_setup.hlsl:79-372) in float64 numpy, written from the shader text: per cascade the matrices
+    M[r][c] `translatedWorldToClip`, `clipToTranslatedWorld`, the six frustum planes and orthoDepthConvertToView.  Not a
+    bit-level statement (the reference runs it in fp32 on the GPU; chordvis_cascade_setup in fp32 on the host): the test
+    compares within fp32 tolerances and treats a texel snap that rounds the other way as one texel of difference."""
+    count, realtime, dim = int(cfg["cascadeCount"][0]), int(cfg["realtimeCascadeCount"][0]), int(cfg["cascadeDim"][0])
+    start, end, far_end = float(cfg["cascadeStartDistance"][0]), float(cfg["cascadeEndDistance"][0]), float(cfg["farCascadeEndDistance"][0])
+    lam, far_lam, rs = float(cfg["splitLambda"][0]), float(cfg["farCascadeSplitLambda"][0]), float(cfg["radiusScaleFixed"][0])
+    near, far = float(view["zNear"][0]), float(view["zFar"][0])
+    clip_range = far - near
+    inv_zfar = np.asarray(view["clipToTranslatedWorldWithZFar_NoJitter"][0], dtype=np.float64).reshape(4, 4).T
+    L = np.asarray(light_dir, dtype=np.float64); L = L / np.linalg.norm(L)
+
+    def split(far_plane, near_plane, k, n, lam_):
+        rng, ratio, p = far_plane - near_plane, far_plane / near_plane, (k + 1) / n
+        d = lam_ * (near_plane * abs(ratio) ** p - (near_plane + rng * p)) + (near_plane + rng * p)
+        return (d - near) / clip_range
+
+    ndc = np.array([[-1, 1, 1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 0], [1, 1, 0], [1, -1, 0], [-1, -1, 0]], dtype=np.float64)
+
+    def unproject(M, p):
+        q = M @ np.append(p, 1.0)
+        return q[:3] / q[3]
+    base = np.array([unproject(inv_zfar, p) for p in ndc])
+    per = []
+    for k in range(count):
+        if k < realtime:
+            mn, mx, lam_, n, kk = near + start, near + end, lam, realtime, k
+            if valid_range is not None:
+                lo, hi = np.asarray(valid_range, dtype=np.uint32).view(np.float32).astype(np.float64)
+                if hi > 0:
+                    mn = max(mn, near / hi)
+                if lo > 0:
+                    mx = max(mx, mn * 1.1); mx = min(mx, mn + (end - start)); mx = min(mx, near / lo)
+            s0 = mn - near
+        else:
+            mx, lam_, mn, s0, n, kk = near + far_end, far_lam, near + end, end, count - realtime, k - realtime
+        d1 = split(mx, mn, kk, n, lam_)
+        d0 = s0 / clip_range if kk == 0 else split(mx, mn, kk - 1, n, lam_)
+        d1_0 = split(near, near + far_end, 0, count, far_lam)              # (the shader's argument order: far = nearZ, near = nearZ + farEnd)
+        cor = np.empty((8, 3)); cor0 = np.empty((8, 3))
+        for i in range(4):
+            ray = base[i + 4] - base[i]
+            cor[i], cor[i + 4] = base[i] + ray * d0, base[i] + ray * d1
+            cor0[i], cor0[i + 4] = base[i] + ray * 0.0, base[i] + ray * d1_0
+        c, c0 = cor.mean(axis=0), cor0.mean(axis=0)
+        r = max(np.linalg.norm(cor - c, axis=1)); r0 = max(np.linalg.norm(cor0 - c0, axis=1))
+        per.append(dict(c=c, r=r, r0=r0, R=np.ceil(r * 16.0) / 16.0, mn=mn))
+    zmax = max(p["R"] for p in per) * 2.0
+    out = []
+    for k, p in enumerate(per):
+        R_ = p["R"]
+        if k >= realtime:
+            radius_scale, zbias = p["r0"] / p["r"], 1.0
+        else:
+            radius_scale = 10.0 * rs / p["r"]; radius_scale = radius_scale / (radius_scale + 1.0)
+            zbias = 0.25 + (p["mn"] - near) / (end - start)
+        radius_scale = min(radius_scale, 1.0)
+        eye = p["c"] - L * zmax * 0.5
+        f = p["c"] - eye; f /= np.linalg.norm(f)
+        s = np.cross(f, [0.0, 1.0, 0.0]); s /= np.linalg.norm(s)
+        u = np.cross(s, f)
+        V = np.eye(4); V[0, :3], V[1, :3], V[2, :3] = s, u, -f
+        V[0, 3], V[1, 3], V[2, 3] = -np.dot(s, eye), -np.dot(u, eye), np.dot(f, eye)
+        P = np.zeros((4, 4))                                               # ortho_RH_ZeroOne(-R, R, -R, R, zNear = zmax, zFar = 0): reverse Z
+        P[0, 0], P[1, 1], P[2, 2], P[3, 3] = 2.0 / (2 * R_), 2.0 / (2 * R_), -1.0 / (0.0 - zmax), 1.0
+        P[2, 3] = -zmax / (0.0 - zmax)
+        o = (P @ V @ np.array([0, 0, 0, 1.0])) * (dim / 2.0)
+        snap = (np.round(o[:2]) - o[:2]) * (2.0 / dim)
+        P[0, 3] += snap[0]; P[1, 3] += snap[1]
+        VP = P @ V
+        inv = np.linalg.inv(VP)
+        q = np.array([unproject(inv, x) for x in ndc])
+
+        def plane(a, b, o_):
+            n_ = np.cross(a - o_, b - o_); n_ /= np.linalg.norm(n_)
+            return n_
+        nl, nd, nr = plane(q[4], q[3], q[7]), plane(q[6], q[3], q[2]), plane(q[6], q[1], q[5])
+        nt, nf, nb = plane(q[5], q[0], q[4]), plane(q[1], q[3], q[0]), plane(q[5], q[7], q[6])
+        planes = np.array([np.append(nl, -np.dot(nl, q[7])), np.append(nd, -np.dot(nd, q[2])), np.append(nr, -np.dot(nr, q[5])),
+                           np.append(nt, -np.dot(nt, q[4])), np.append(nf, -np.dot(nf, q[0])), np.append(nb, -np.dot(nf, q[6]))])
+        out.append(dict(vp=VP, inv=inv, planes=planes, ortho=np.array([P[2, 2], P[2, 3], zbias, radius_scale]), texel=2.0 / dim, radius=R_))
+    return out

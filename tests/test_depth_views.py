@@ -230,3 +230,34 @@ def test_render_shadow_with_cascade_cache_matches_the_replay(gpu):
     _, _, mask = r.render_shadow(cfg, (0.1, -1.0, -0.4), 5)
     assert mask == 0b11111
     r.close()
+
+
+@pytest.mark.parametrize("ranged", [False, True], ids=["full_range", "sdsm_range"])
+def test_cascade_setup_agrees_with_a_float64_restatement_of_the_shader(ranged):
+    """chordvis_cascade_setup (fp32, host C++) against tests/spec_np.py::cascade_views_f64, written from cascade_setup.hlsl in
+    float64: matrices, inverse, the six planes and orthoDepthConvertToView of every cascade agree to fp32 accuracy (a texel
+    snap that rounds the other way in fp32 may move the view by exactly one texel)."""
+    import spec_np as S
+    for builder in (lambda: scenes.small_test_scene(320, 200), lambda: scenes.config3_street(640, 360)):
+        scene, cam = builder()
+        view, iv = L.make_views(cam)
+        cfg = R.default_cascade_config(cascadeCount=6, realtimeCascadeCount=2, cascadeDim=1024, cascadeEndDistance=40.0, farCascadeEndDistance=400.0)
+        near = float(view["zNear"][0])
+        rng = np.array([np.float32(near / 25.0), np.float32(near / 3.0)], dtype=np.float32).view(np.uint32) if ranged else None
+        got = L.cascade_setup(cfg, view, iv, LIGHT, valid_range=rng)
+        want = S.cascade_views_f64(cfg, view, LIGHT, valid_range=rng)
+        for k, (g, w) in enumerate(zip(got, want)):
+            vp, inv = _m(g, "translatedWorldToClip"), _m(g, "clipToTranslatedWorld")
+            d = vp - w["vp"]
+            # the snap: [0][3] / [1][3] may differ by one whole texel step; everything else to fp32 accuracy of its magnitude
+            for r in (0, 1):
+                steps = d[r, 3] / w["texel"]
+                assert abs(steps - round(steps)) < 2e-2 and abs(round(steps)) <= 1, "cascade %d row %d: snap differs by %.3f texels" % (k, r, steps)
+                d[r, 3] -= round(steps) * w["texel"]
+            scale = np.abs(w["vp"]).max()
+            assert np.abs(d).max() < 2e-5 * max(1.0, scale), "cascade %d: translatedWorldToClip" % k
+            assert np.allclose(vp @ inv, np.eye(4), atol=5e-4)
+            pl = g["frustumPlanesRS"].astype(np.float64)
+            assert np.abs(pl[:, :3] - w["planes"][:, :3]).max() < 1e-4, "cascade %d: plane normals" % k
+            assert np.abs(pl[:, 3] - w["planes"][:, 3]).max() < 2e-3 * max(1.0, w["radius"]), "cascade %d: plane distances" % k
+            assert np.allclose(g["orthoDepthConvertToView"].astype(np.float64), w["ortho"], rtol=2e-5, atol=1e-6), "cascade %d: orthoDepthConvertToView" % k

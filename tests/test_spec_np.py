@@ -67,3 +67,33 @@ def test_object_cull_of_orthographic_views_agrees():
         assert len(want) > 0 and len(got) == len(want) and np.array_equal(got["meshletId"], want["meshletId"]) and np.array_equal(got["objectId"], want["objectId"])
     # the first cascade is small: it must actually cull something the last one keeps
     assert len(orc.instance_culling(scene, view, views[0:1], H.ALL_FLAGS)) < len(orc.instance_culling(scene, view, views[3:4], H.ALL_FLAGS))
+
+
+@pytest.mark.parametrize("name,builder,dim,last", [("small", lambda: scenes.small_test_scene(320, 200, seed=7), 256, False),
+                                                   ("street", lambda: scenes.config3_street(640, 360), 256, False),
+                                                   ("masked", lambda: scenes.masked_test_scene(320, 200), 256, True)],
+                         ids=["small", "street", "masked_last_frame"])
+def test_generic_hzb_cull_of_cascade_views_agrees(name, builder, dim, last):
+    """hzb_culling_generic.hlsl (2x2 taps, extentScale, the culling view's own matrix and camera offset) for shadow cascades:
+    the oracle's survivors against the numpy restatement, on the HZB of a cascade's depth image."""
+    scene, cam = builder()
+    L.fill_objects(scene, cam, cam.moved((0.3, 0.0, -0.2)))
+    view, iv = L.make_views(cam)
+    cfg = R.default_cascade_config(cascadeCount=3, realtimeCascadeCount=2, cascadeDim=dim, cascadeEndDistance=14.0, farCascadeEndDistance=40.0)
+    views = L.cascade_setup(cfg, view, iv, (0.35, -1.0, 0.25))
+    flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | R.FLAG_HZB_CULL
+    campos = np.frombuffer(iv["cameraWorldPos"][0].tobytes(), dtype=np.float64)[:3]
+    desc = orc.hzb_desc(dim, dim)
+    rejected = 0
+    for k_hzb, k_list in ((2, 1), (1, 0), (1, 1), (2, 2)):               # cull cascade k_list's list against cascade k_hzb's depth
+        cmds_h = orc.instance_culling(scene, view, views[k_hzb:k_hzb + 1], flags)
+        depth, _ = orc.raster_depth(scene, views[k_hzb:k_hzb + 1], cmds_h, dim, dim)
+        words = depth.view(np.uint32).astype(np.uint64) << np.uint64(32)
+        _, hmin, _, _ = orc.hzb_build(words, dim, dim)
+        dims, offs, levels = S.hzb_build(depth, dim, dim)
+        cmds = orc.instance_culling(scene, view, views[k_list:k_list + 1], flags)
+        kept = orc.hzb_culling_generic(scene, views[k_hzb:k_hzb + 1], campos, flags, 1.5, last, desc, hmin, cmds)
+        keep = S.hzb_visible_generic(scene, views[k_hzb:k_hzb + 1], campos, cmds, 1.5, last, [lv[0] for lv in levels])
+        assert np.array_equal(cmds["slot"][keep], kept["slot"]), "%s: cascade %d list against cascade %d HZB" % (name, k_list, k_hzb)
+        rejected += int((~keep).sum())
+    assert rejected > 0                                                   # (not vacuous: something is occluded in light space)
