@@ -131,10 +131,17 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         c->hzbExchangeHalves = c->hzbExchangeChunkHalves * N;
         if ((rc = dalloc(c, &c->dHzbExchange, c->hzbExchangeHalves))) return rc;
         CHORD_HIP(c, hipMemsetAsync(c->dHzbExchange, 0, c->hzbExchangeHalves * 2, c->stream));
+        // pipelined frames (chordvis_frame_phase_c_begin / _finish): the max chain's mip 0 and the ranks' valid-range pairs
+        if ((rc = dalloc(c, &c->dHzbExchangeMax, c->hzbExchangeHalves))) return rc;
+        CHORD_HIP(c, hipMemsetAsync(c->dHzbExchangeMax, 0, c->hzbExchangeHalves * 2, c->stream));
+        if ((rc = dalloc(c, &c->dRangeExchange, (size_t)N * 2))) return rc;
+        CHORD_HIP(c, hipMemsetAsync(c->dRangeExchange, 0, (size_t)N * 8, c->stream));
     } else {
-        dfree(c->dHzbExchange);
+        dfree(c->dHzbExchange); dfree(c->dHzbExchangeMax); dfree(c->dRangeExchange);
         c->hzbExchangeHalves = c->hzbExchangeChunkHalves = 0;
     }
+    // (a second pair of visibility buffers is made by chordvis_swap_visibility when a pipelined host first asks for it)
+    dfree(c->dVisAlt); dfree(c->dVisResolvedAlt);
     return CHORDVIS_OK;
 }
 
@@ -323,7 +330,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
-    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
+    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dHzbExchangeMax); dfree(c->dRangeExchange); dfree(c->dVisAlt); dfree(c->dVisResolvedAlt); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
     dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -700,6 +707,30 @@ uint64_t chordvis_visibility_chunk_words(ChordCtx* c) { return c ? chordvis_visi
 uint64_t* chordvis_visibility_ptr(ChordCtx* c) { return c ? c->dVis : nullptr; }
 uint64_t* chordvis_resolved_visibility_ptr(ChordCtx* c) { return c ? (c->shard.ranks > 1 ? c->dVisResolved : c->dVis) : nullptr; }
 uint16_t* chordvis_hzb_exchange_ptr(ChordCtx* c) { return c ? c->dHzbExchange : nullptr; }
+uint16_t* chordvis_hzb_exchange_max_ptr(ChordCtx* c) { return c ? c->dHzbExchangeMax : nullptr; }
+uint32_t* chordvis_range_exchange_ptr(ChordCtx* c) { return c ? c->dRangeExchange : nullptr; }
+
+// Pipelined sharded frames keep TWO frames' visibility words alive: the one whose all-gather is still travelling and the
+// one being rasterized.  Swaps the roles of the two buffer pairs (the second pair is allocated on first use); call between
+// frames, before chordvis_frame_phase_a.
+int chordvis_swap_visibility(ChordCtx* c)
+{
+    if (!c || !c->dVis) return fail(c, CHORDVIS_E_INVALID, "swap_visibility: allocate_gbuffer must come first");
+    if (c->shard.ranks <= 1 || c->visExternal) return fail(c, CHORDVIS_E_INVALID, "swap_visibility: only for sharded contexts that own their visibility buffer");
+    if (c->inFrame) return fail(c, CHORDVIS_E_INVALID, "swap_visibility: not inside a frame");
+    int rc;
+    if (!c->dVisAlt) {
+        if ((rc = dalloc(c, &c->dVisAlt, c->visWords))) return rc;
+        if ((rc = dalloc(c, &c->dVisResolvedAlt, (uint64_t)c->width * c->height))) return rc;
+        CHORD_HIP(c, hipMemsetAsync(c->dVisAlt, 0, c->visWords * 8, c->stream));
+        CHORD_HIP(c, hipMemsetAsync(c->dVisResolvedAlt, 0, (uint64_t)c->width * c->height * 8, c->stream));
+    }
+    std::swap(c->dVisOwned, c->dVisAlt);
+    c->dVis = c->dVisOwned;
+    std::swap(c->dVisResolved, c->dVisResolvedAlt);
+    std::swap(c->visReadyEvent[0], c->visReadyEvent[1]);
+    return CHORDVIS_OK;
+}
 uint64_t chordvis_hzb_exchange_halves(ChordCtx* c) { return c ? c->hzbExchangeHalves : 0; }
 uint64_t chordvis_hzb_exchange_chunk_halves(ChordCtx* c) { return c ? c->hzbExchangeChunkHalves : 0; }
 
@@ -934,6 +965,39 @@ static int frame_phase_c_impl(ChordCtx* c)
     return CHORDVIS_OK;
 }
 
+// Pipelined form of phase c, for hosts that overlap the visibility all-gather of a frame with the next frame: the final HZB
+// does not wait for the gathered image.
+//   phase_c_begin   own-stripe mip 0 of the min and max chains into the exchange buffers, the rank's valid-range pair
+//   [host: all-gather chordvis_hzb_exchange_ptr, chordvis_hzb_exchange_max_ptr (chunk = hzb_exchange_chunk_halves) and
+//          chordvis_range_exchange_ptr (2 words per rank)]
+//   phase_c_finish  the chain from the exchanged mip 0 (identical to buildHZB over the whole image); ends the frame
+//   [host, whenever the visibility all-gather of that frame has landed: chordvis_frame_resolve_visibility]
+static int frame_phase_c_begin_impl(ChordCtx* c)
+{
+    int rc = ready(c, "frame_phase_c_begin");
+    if (rc) return rc;
+    if (c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_phase_c_begin: the context is not sharded");
+    const int next = c->historySlot == 1 ? 2 : 1;
+    launch_hzb_final_exchange(c, c->hzb[next]);
+    CHORD_HIP(c, hipGetLastError());
+    return CHORDVIS_OK;
+}
+
+static int frame_phase_c_finish_impl(ChordCtx* c)
+{
+    int rc = ready(c, "frame_phase_c_finish");
+    if (rc) return rc;
+    if (c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_phase_c_finish: the context is not sharded");
+    record(c, S_OTHER);
+    const int next = c->historySlot == 1 ? 2 : 1;
+    launch_hzb_build_final_from_exchange(c, c->hzb[next]);
+    CHORD_HIP(c, hipGetLastError());
+    record(c, S_HZBF);
+    c->historySlot = next;
+    c->inFrame = false;
+    return CHORDVIS_OK;
+}
+
 // A failed frame must not leave frame-scoped state behind (the stand-alone passes that may follow would skip their
 // count resets, a later frame would inherit a fused-HZB request).
 static int end_failed_frame(ChordCtx* c, int rc)
@@ -948,6 +1012,18 @@ int chordvis_render_frame(ChordCtx* c) { return end_failed_frame(c, render_frame
 int chordvis_frame_phase_a(ChordCtx* c) { return end_failed_frame(c, frame_phase_a_impl(c)); }
 int chordvis_frame_phase_b(ChordCtx* c) { return end_failed_frame(c, frame_phase_b_impl(c)); }
 int chordvis_frame_phase_c(ChordCtx* c) { return end_failed_frame(c, frame_phase_c_impl(c)); }
+int chordvis_frame_phase_c_begin(ChordCtx* c) { return end_failed_frame(c, frame_phase_c_begin_impl(c)); }
+int chordvis_frame_phase_c_finish(ChordCtx* c) { return end_failed_frame(c, frame_phase_c_finish_impl(c)); }
+
+// The row-major copy of the (gathered) rank-major visibility words of the CURRENT buffer pair, on `hipStream` (NULL: the
+// context's stream) -- phase c's first half, for pipelined hosts that run it beside the next frame.
+int chordvis_frame_resolve_visibility(ChordCtx* c, void* hipStream)
+{
+    if (!c || !c->dVis || c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_resolve_visibility: a sharded context with a gbuffer");
+    launch_detile(c, (hipStream_t)hipStream);
+    CHORD_HIP(c, hipGetLastError());
+    return CHORDVIS_OK;
+}
 
 int chordvis_last_frame_cmds(ChordCtx* c, ChordCountAndCmd* out)
 {
@@ -1024,8 +1100,19 @@ int chordvis_readback_visibility(ChordCtx* c, uint64_t* host)
 {
     if (!c || !host || !c->dVis) return fail(c, CHORDVIS_E_INVALID, "readback_visibility: no gbuffer");
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->visReadyEvent[0]) CHORD_HIP(c, hipEventSynchronize(c->visReadyEvent[0]));   // (pipelined group: the image is resolved beside the stream)
     const uint64_t* src = c->shard.ranks > 1 ? c->dVisResolved : c->dVis;
     CHORD_HIP(c, hipMemcpy(host, src, (size_t)c->width * c->height * 8, hipMemcpyDeviceToHost));
+    return CHORDVIS_OK;
+}
+
+// Pipelined sharded frames: the image of the frame BEFORE the last submitted one (the other buffer pair).
+int chordvis_readback_previous_visibility(ChordCtx* c, uint64_t* host)
+{
+    if (!c || !host || !c->dVisResolvedAlt) return fail(c, CHORDVIS_E_INVALID, "readback_previous_visibility: no second frame in flight (chordvis_swap_visibility)");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->visReadyEvent[1]) CHORD_HIP(c, hipEventSynchronize(c->visReadyEvent[1]));
+    CHORD_HIP(c, hipMemcpy(host, c->dVisResolvedAlt, (size_t)c->width * c->height * 8, hipMemcpyDeviceToHost));
     return CHORDVIS_OK;
 }
 

@@ -283,6 +283,11 @@ struct ChordCtx {
     bool fuseHzbTemp = false;             // ... also into the temporary chain (slot 0) for stage 1
     int fuseHzbSlot = 1;                  // history slot being produced this frame
     uint16_t* dHzbExchange = nullptr;
+    uint16_t* dHzbExchangeMax = nullptr;   // pipelined sharded frames: own-stripe mip 0 of the max chain, rank-major like dHzbExchange
+    uint32_t* dRangeExchange = nullptr;    // ... and one valid-range pair per rank
+    uint64_t* dVisAlt = nullptr;           // ... the visibility words (rank-major) and their row-major copy of the OTHER frame in flight
+    uint64_t* dVisResolvedAlt = nullptr;
+    hipEvent_t visReadyEvent[2] = {nullptr, nullptr};   // [0]: the resolved image of the last submitted frame is complete, [1]: of the frame before
     uint64_t hzbExchangeHalves = 0, hzbExchangeChunkHalves = 0;
 
     // raster work lists: triangle records, per-tile bins, clip list
@@ -361,7 +366,9 @@ void launch_depth_expand(ChordCtx* c, const float* depth, unsigned long long* vi
 void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange, bool fromExchange);
 void launch_hzb_mip0_exchange(ChordCtx* c);
 void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange);   // mips 6.. + range from per-tile partials
-void launch_detile(ChordCtx* c);
+void launch_detile(ChordCtx* c, hipStream_t stream = nullptr);
+void launch_hzb_final_exchange(ChordCtx* c, HzbBuffers& out);
+void launch_hzb_build_final_from_exchange(ChordCtx* c, HzbBuffers& out);
 void launch_stripe_filter(ChordCtx* c, const CmdList& in, const CmdList& out);
 void launch_visibility_mark(ChordCtx* c, const unsigned long long* vis, const ChordDrawCmd* cmds, const uint32_t* cmdCount, uint32_t* marker);
 void launch_shading_tiles(ChordCtx* c, const uint32_t* marker, uint32_t shadingType, uint32_t* tiles, uint32_t* count, uint32_t* args);

@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void hzb_mip0_kernel(HzbParams p, int wantMax,
         mn = fminf(fminf(fminf(d00, d10), d01), d11);
         mx = fmaxf(fmaxf(fmaxf(d00, d10), d01), d11);
         if (MODE == 1) {
-            p.exchange[exchange_row(p.shard, y) * p.exchangePitch + x] = f32_to_f16(mn);
+            const size_t eo = exchange_row(p.shard, y) * p.exchangePitch + x;
+            p.exchange[eo] = f32_to_f16(mn);
+            if (wantMax && p.exchangeMax) p.exchangeMax[eo] = f32_to_f16(mx);
         } else {
             const uint32_t mw = max(1u, p.desc.width);
             p.hzbMin[p.desc.mipOffset[0] + y * mw + x] = f32_to_f16(mn);
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void hzb_mip0_kernel(HzbParams p, int wantMax,
             }
         }
     }
-    if (MODE != 1 && wantRange) {
+    if (wantRange) {                                             // (MODE 1: of the rank's own stripes; blocks without an owned row write the neutral pair)
         // The reference does one InterlockedMin/Max per wave on a single word (hzb.hlsl:168-176); on
         // MI355X one word sustains only ~88 atomics/us (32k waves at 4K = 0.7 ms), so each block
         // writes one partial instead and the single-block tail kernel reduces them.
@@ -123,9 +125,16 @@ __global__ __launch_bounds__(256) void hzb_mips_kernel(HzbParams p, int wantMax)
                 const uint32_t cx = min(2u * X + i, pw - 1u), cy = min(2u * Y + j, ph - 1u);
                 float a, b = 0.0f;
                 if (FROM_EXCHANGE) {
-                    const uint16_t h = p.exchange[exchange_row(p.shard, cy) * p.exchangePitch + cx];
+                    const size_t eo = exchange_row(p.shard, cy) * p.exchangePitch + cx;
+                    const uint16_t h = p.exchange[eo];
                     a = f16_to_f32(h);
-                    if (2u * X + i == cx && 2u * Y + j == cy) p.hzbMin[d.mipOffset[0] + cy * pmw + cx] = h;
+                    const bool mine = 2u * X + i == cx && 2u * Y + j == cy;     // (not an edge-clamped duplicate)
+                    if (mine) p.hzbMin[d.mipOffset[0] + cy * pmw + cx] = h;
+                    if (wantMax) {
+                        const uint16_t hx = p.exchangeMax[eo];
+                        b = f16_to_f32(hx);
+                        if (mine) p.hzbMax[d.mipOffset[0] + cy * pmw + cx] = hx;
+                    }
                 } else {
                     a = f16_to_f32(p.hzbMin[d.mipOffset[0] + cy * pmw + cx]);
                     if (wantMax) b = f16_to_f32(p.hzbMax[d.mipOffset[0] + cy * pmw + cx]);
@@ -192,13 +201,32 @@ __global__ __launch_bounds__(256) void detile_kernel(const unsigned long long* _
         dst[(size_t)y * W + x] = src[sb + x];
 }
 
+// One block: a rank's per-block valid-range partials -> its pair in the range exchange buffer (slot = rank).
+__global__ __launch_bounds__(256) void range_reduce_kernel(const uint32_t* __restrict__ partials, uint32_t count, uint32_t* __restrict__ outPair)
+{
+    __shared__ uint32_t sMn[4], sMx[4];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    for (uint32_t i = threadIdx.x; i < count; i += 256u) { mn = min(mn, partials[2u * i]); mx = max(mx, partials[2u * i + 1u]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_down((int)mn, off, 64));
+        mx = max(mx, (uint32_t)__shfl_down((int)mx, off, 64));
+    }
+    if ((threadIdx.x & 63u) == 0u) { sMn[threadIdx.x >> 6] = mn; sMx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        outPair[0] = min(min(sMn[0], sMn[1]), min(sMn[2], sMn[3]));
+        outPair[1] = max(max(sMx[0], sMx[1]), max(sMx[2], sMx[3]));
+    }
+}
+
 static HzbParams make_params(ChordCtx* c, HzbBuffers& out)
 {
     HzbParams p;
     p.vis = (const unsigned long long*)c->dVis; p.W = (int32_t)c->width; p.H = (int32_t)c->height;
     p.shard = c->shard; p.desc = out.desc;
     p.hzbMin = out.minTexels; p.hzbMax = out.maxTexels; p.validRange = out.validRange;
-    p.exchange = c->dHzbExchange; p.exchangePitch = out.desc.width;
+    p.exchange = c->dHzbExchange; p.exchangeMax = nullptr; p.exchangePitch = out.desc.width;
     p.rangePartials = c->dRangePartials; p.rangePartialCount = 0;
     return p;
 }
@@ -226,6 +254,34 @@ void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool b
     if (fromExchange) hipLaunchKernelGGL(hzb_mips_kernel<true>, g1, dim3(256), 0, c->stream, p, 0);
     else              hipLaunchKernelGGL(hzb_mips_kernel<false>, g1, dim3(256), 0, c->stream, p, wantMax);
     if (p.desc.mipCount > 6 || wantRange) hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, wantMax, wantRange, 6u);
+    out.valid = true;
+}
+
+// Pipelined sharded frame: the FINAL chain of a frame from the ranks' own-stripe mip 0 instead of from the
+// gathered visibility words.  Step 1, before the exchange: own-stripe mip 0 min + max into the two exchange buffers, the
+// rank's valid-range pair into its slot of the range exchange.
+void launch_hzb_final_exchange(ChordCtx* c, HzbBuffers& out)
+{
+    HzbParams p = make_params(c, out);
+    p.exchangeMax = c->dHzbExchangeMax;
+    const uint32_t vw = min(p.desc.width, (((uint32_t)p.W - 1u) >> 1) + 1u), vh = min(p.desc.height, (((uint32_t)p.H - 1u) >> 1) + 1u);
+    const dim3 g0((vw + 63u) / 64u, (vh + 3u) / 4u);
+    hipLaunchKernelGGL(hzb_mip0_kernel<1>, g0, dim3(256), 0, c->stream, p, 1, 1);
+    hipLaunchKernelGGL(range_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const uint32_t*)c->dRangePartials, g0.x * g0.y,
+                       c->dRangeExchange + 2u * c->shard.rank);
+}
+
+// Step 2, after the three exchange buffers were all-gathered: mips 0..5 of both chains from the exchanged mip 0, the tail
+// and the valid range from the ranks' pairs -- the chain chordvis_build_hzb(min, max, range) makes from the full image.
+void launch_hzb_build_final_from_exchange(ChordCtx* c, HzbBuffers& out)
+{
+    HzbParams p = make_params(c, out);
+    p.exchangeMax = c->dHzbExchangeMax;
+    const uint32_t vw = min(p.desc.width, (((uint32_t)p.W - 1u) >> 1) + 1u), vh = min(p.desc.height, (((uint32_t)p.H - 1u) >> 1) + 1u);
+    const dim3 g1((vw + 31u) / 32u, (vh + 31u) / 32u);
+    hipLaunchKernelGGL(hzb_mips_kernel<true>, g1, dim3(256), 0, c->stream, p, 1);
+    p.rangePartials = c->dRangeExchange; p.rangePartialCount = c->shard.ranks;
+    hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, 1, 1, 6u);
     out.valid = true;
 }
 
@@ -267,10 +323,10 @@ void launch_depth_expand(ChordCtx* c, const float* depth, unsigned long long* vi
     hipLaunchKernelGGL(depth_expand_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, c->stream, depth, vis, words);
 }
 
-void launch_detile(ChordCtx* c)
+void launch_detile(ChordCtx* c, hipStream_t stream)
 {
     const dim3 g((c->width + 255u) / 256u > 8u ? 8u : (c->width + 255u) / 256u, c->height);
-    hipLaunchKernelGGL(detile_kernel, g, dim3(256), 0, c->stream, (const unsigned long long*)c->dVis,
+    hipLaunchKernelGGL(detile_kernel, g, dim3(256), 0, stream ? stream : c->stream, (const unsigned long long*)c->dVis,
                        (unsigned long long*)c->dVisResolved, c->width, c->height, c->shard);
 }
 

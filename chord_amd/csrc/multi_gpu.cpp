@@ -195,8 +195,15 @@ struct ChordGroup {
     uint32_t stripeRows = 0;
     // copy streams and events: index [src * n + dst]
     std::vector<hipStream_t> copyStream;
-    std::vector<hipEvent_t> evArrived[2];       // per exchange (0 = HZB mip 0, 1 = visibility)
-    std::vector<hipEvent_t> evReady[2];         // per rank
+    std::vector<hipEvent_t> evArrived[4];       // per exchange (0 = HZB exchanges, 1 = visibility; 2 / 3 = visibility of a pipelined frame, by parity)
+    std::vector<hipEvent_t> evReady[4];         // per rank
+    // pipelined mode: the visibility all-gather + row-major copy of frame i run beside frame i + 1 (per-rank resolve stream,
+    // "image complete" event per buffer parity)
+    bool pipelined = false;
+    uint64_t frameSerial = 0;
+    std::vector<hipStream_t> resolveStream;
+    std::vector<hipStream_t> bulkCopyStream;    // [src * n + dst]: the travelling image has its own copy streams -- the small HZB exchanges of the same and the next frame must not queue behind it
+    std::vector<hipEvent_t> evVisReady[2];
     // worker threads: one per rank, parked on a condition variable between jobs
     std::vector<std::thread> workers;
     std::mutex m;
@@ -267,9 +274,11 @@ int run_all(ChordGroup* g, const std::function<int(uint32_t)>& fn, const char* w
 // (r, d) copy stream once both ends are ready -- r has produced it, d has finished with the region it lands in (d's
 // stream is past every earlier reader of its buffer when it records `ready`).  A compute stream then waits for every
 // copy that ends in its buffer AND every copy that leaves it (the source region is rewritten by the next frame).
-int group_all_gather(ChordGroup* g, uint32_t r, int which, const std::function<char*(uint32_t)>& base, size_t chunkBytes)
+int group_all_gather(ChordGroup* g, uint32_t r, int which, const std::function<char*(uint32_t)>& base, size_t chunkBytes, hipStream_t waiter = nullptr,
+                     bool bulk = false)
 {
     ChordCtx* c = g->ctx[r];
+    if (!waiter) waiter = c->stream;                              // who continues once the buffer is complete (default: the rank's compute stream)
     const uint32_t n = g->n;
     int rc = CHORDVIS_OK;
     // a failing call is remembered, but the rank keeps walking through both host barriers: its peers wait there
@@ -278,7 +287,7 @@ int group_all_gather(ChordGroup* g, uint32_t r, int which, const std::function<c
     group_barrier(g);                                             // every `ready` is recorded
     for (uint32_t d = 0; d < n; d++) {
         if (d == r) continue;
-        hipStream_t cs = g->copyStream[(size_t)r * n + d];
+        hipStream_t cs = bulk ? g->bulkCopyStream[(size_t)r * n + d] : g->copyStream[(size_t)r * n + d];
         GG_HIP(hipStreamWaitEvent(cs, g->evReady[which][r], 0));
         GG_HIP(hipStreamWaitEvent(cs, g->evReady[which][d], 0));
         GG_HIP(hipMemcpyPeerAsync(base(d) + (size_t)r * chunkBytes, g->device[d], base(r) + (size_t)r * chunkBytes, g->device[r], chunkBytes, cs));
@@ -287,8 +296,8 @@ int group_all_gather(ChordGroup* g, uint32_t r, int which, const std::function<c
     group_barrier(g);                                             // every `arrived` is recorded
     for (uint32_t o = 0; o < n; o++) {
         if (o == r) continue;
-        GG_HIP(hipStreamWaitEvent(c->stream, g->evArrived[which][(size_t)o * n + r], 0));   // into my buffer
-        GG_HIP(hipStreamWaitEvent(c->stream, g->evArrived[which][(size_t)r * n + o], 0));   // out of my buffer
+        GG_HIP(hipStreamWaitEvent(waiter, g->evArrived[which][(size_t)o * n + r], 0));   // into my buffer
+        GG_HIP(hipStreamWaitEvent(waiter, g->evArrived[which][(size_t)r * n + o], 0));   // out of my buffer
     }
 #undef GG_HIP
     return rc;
@@ -313,7 +322,10 @@ int chordvis_create_group(uint32_t n, const int* deviceOrdinals, ChordGroup** ou
     int rc = CHORDVIS_OK;
     for (uint32_t r = 0; r < n && !rc; r++) rc = chordvis_create(g->device[r], nullptr, &g->ctx[r]);
     g->copyStream.assign((size_t)n * n, nullptr);
-    for (int w = 0; w < 2; w++) { g->evArrived[w].assign((size_t)n * n, nullptr); g->evReady[w].assign(n, nullptr); }
+    g->bulkCopyStream.assign((size_t)n * n, nullptr);
+    for (int w = 0; w < 4; w++) { g->evArrived[w].assign((size_t)n * n, nullptr); g->evReady[w].assign(n, nullptr); }
+    g->resolveStream.assign(n, nullptr);
+    for (int w = 0; w < 2; w++) g->evVisReady[w].assign(n, nullptr);
     for (uint32_t r = 0; r < n && !rc; r++) {
         if (hipSetDevice(g->device[r]) != hipSuccess) { rc = CHORDVIS_E_NO_DEVICE; break; }
         for (uint32_t d = 0; d < n; d++) {
@@ -323,10 +335,13 @@ int chordvis_create_group(uint32_t n, const int* deviceOrdinals, ChordGroup** ou
                 if (can) { const hipError_t e = hipDeviceEnablePeerAccess(g->device[d], 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = CHORDVIS_E_HIP; (void)hipGetLastError(); }
             }
             if (d != r && hipStreamCreateWithFlags(&g->copyStream[(size_t)r * n + d], hipStreamNonBlocking) != hipSuccess) rc = CHORDVIS_E_HIP;
-            for (int w = 0; w < 2; w++)
+            if (d != r && hipStreamCreateWithFlags(&g->bulkCopyStream[(size_t)r * n + d], hipStreamNonBlocking) != hipSuccess) rc = CHORDVIS_E_HIP;
+            for (int w = 0; w < 4; w++)
                 if (d != r && hipEventCreateWithFlags(&g->evArrived[w][(size_t)r * n + d], hipEventDisableTiming) != hipSuccess) rc = CHORDVIS_E_HIP;
         }
-        for (int w = 0; w < 2; w++) if (hipEventCreateWithFlags(&g->evReady[w][r], hipEventDisableTiming) != hipSuccess) rc = CHORDVIS_E_HIP;
+        for (int w = 0; w < 4; w++) if (hipEventCreateWithFlags(&g->evReady[w][r], hipEventDisableTiming) != hipSuccess) rc = CHORDVIS_E_HIP;
+        if (hipStreamCreateWithFlags(&g->resolveStream[r], hipStreamNonBlocking) != hipSuccess) rc = CHORDVIS_E_HIP;
+        for (int w = 0; w < 2; w++) if (hipEventCreateWithFlags(&g->evVisReady[w][r], hipEventDisableTiming) != hipSuccess) rc = CHORDVIS_E_HIP;
     }
     if (rc) { chordvis_destroy_group(g); return rc; }
     for (uint32_t r = 0; r < n; r++) g->workers.emplace_back(worker_main, g, r);
@@ -345,10 +360,14 @@ int chordvis_destroy_group(ChordGroup* g)
     for (std::thread& t : g->workers) t.join();
     for (uint32_t r = 0; r < g->n; r++) if (g->ctx[r]) (void)hipStreamSynchronize(g->ctx[r]->stream);
     for (hipStream_t s : g->copyStream) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-    for (int w = 0; w < 2; w++) {
+    for (hipStream_t s : g->bulkCopyStream) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipStream_t s : g->resolveStream) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (int w = 0; w < 4; w++) {
         for (hipEvent_t e : g->evArrived[w]) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : g->evReady[w]) if (e) (void)hipEventDestroy(e);
     }
+    for (ChordCtx* c : g->ctx) if (c) { c->visReadyEvent[0] = c->visReadyEvent[1] = nullptr; }   // (the group's events)
+    for (int w = 0; w < 2; w++) for (hipEvent_t e : g->evVisReady[w]) if (e) (void)hipEventDestroy(e);
     for (ChordCtx* c : g->ctx) if (c) chordvis_destroy(c);
     delete g;
     return CHORDVIS_OK;
@@ -398,10 +417,13 @@ int chordvis_group_set_view(ChordGroup* g, const ChordCameraView* view, const Ch
     return CHORDVIS_OK;
 }
 
+static int group_render_frame_pipelined(ChordGroup* g);
+
 int chordvis_group_render_frame(ChordGroup* g)
 {
     if (!g) return CHORDVIS_E_INVALID;
     if (g->n == 1) return run_all(g, [&](uint32_t r) { return chordvis_render_frame(g->ctx[r]); }, "group_render_frame");
+    if (g->pipelined) return group_render_frame_pipelined(g);
     // A rank that fails keeps walking through the host barriers (its peers would wait for it forever otherwise).
     return run_all(g, [&](uint32_t r) {
         ChordCtx* c = g->ctx[r];
@@ -425,10 +447,86 @@ int chordvis_group_render_frame(ChordGroup* g)
     }, "group_render_frame");
 }
 
+// Pipelined frames (VERDICT r01 item 2 / DESIGN.md 6): the visibility all-gather of frame i -- 58 of 66 MB arriving per rank
+// at 4K -- and its row-major copy leave the frame's critical path and run beside frame i + 1:
+//   * two buffer pairs per rank (chordvis_swap_visibility): frame i + 1 rasters into the other one;
+//   * the history HZB of frame i comes from an exchange of the ranks' own-stripe mip 0 (min, max) and valid-range pairs
+//     (3 small all-gathers, 2 x 4 MB + a few bytes at 4K) instead of from the gathered image: chordvis_frame_phase_c_begin /
+//     _finish -- bit for bit the chain the unpipelined frame builds;
+//   * the gather itself waits on the rank's "phase b done" event, travels on the (source, destination) copy streams, and is
+//     followed by the row-major copy on the rank's resolve stream; "image complete" is an event per buffer pair that
+//     the read-back / consumer entry points of the context wait for.
+// A buffer pair is reused two frames later; by then its gather has long finished -- the host waits for it before the swap.
+int chordvis_group_set_pipelined(ChordGroup* g, int enable)
+{
+    if (!g) return CHORDVIS_E_INVALID;
+    if (g->n < 2 && enable) return gfail(g, CHORDVIS_E_INVALID, "group_set_pipelined: needs at least two ranks");
+    const int rc = chordvis_group_sync(g);
+    if (rc) return rc;
+    g->pipelined = enable != 0;
+    return CHORDVIS_OK;
+}
+
+static int group_render_frame_pipelined(ChordGroup* g)
+{
+    const uint64_t serial = g->frameSerial++;
+    const int parity = (int)(serial & 1u);
+    return run_all(g, [&, parity](uint32_t r) {
+        ChordCtx* c = g->ctx[r];
+        int rc = CHORDVIS_OK;
+#define GP_HIP(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess && !rc) rc = fail(c, CHORDVIS_E_HIP, #call, e_); } while (0)
+        // the buffer pair this frame takes over was last used two frames ago: its gather and copy are complete on every rank
+        // once every rank has seen its "image complete" event of that frame (recorded behind the waits for all copies into
+        // AND out of the rank's buffer).  NOT a drain of the resolve stream: the previous frame's image is still travelling,
+        // and this frame's kernels are to be enqueued beside it.
+        GP_HIP(hipEventSynchronize(g->evVisReady[parity][r]));
+        group_barrier(g);
+        { const int e = chordvis_swap_visibility(c); if (!rc) rc = e; }
+        c->visReadyEvent[0] = g->evVisReady[parity][r];
+        c->visReadyEvent[1] = g->evVisReady[parity ^ 1][r];
+        const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
+        if (!rc) rc = chordvis_frame_phase_a(c);
+        if (stage1) {
+            const int e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dHzbExchange); },
+                                           (size_t)c->hzbExchangeChunkHalves * 2);
+            if (!rc) rc = e;
+        }
+        if (!rc) rc = chordvis_frame_phase_b(c);
+        // the image: gathered and copied beside what follows (and beside the next frame)
+        {
+            const int e = group_all_gather(g, r, 2 + parity, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dVis); },
+                                           (size_t)(c->visWords / g->n) * 8, g->resolveStream[r], true);
+            if (!rc) rc = e;
+            // (the resolve stream also needs the rank's own chunk: the `ready` event of this exchange was recorded on the
+            // compute stream after phase b)
+            GP_HIP(hipStreamWaitEvent(g->resolveStream[r], g->evReady[2 + parity][r], 0));
+            if (!rc) rc = chordvis_frame_resolve_visibility(c, g->resolveStream[r]);
+            GP_HIP(hipEventRecord(g->evVisReady[parity][r], g->resolveStream[r]));
+        }
+        // the history HZB, from the ranks' own-stripe mip 0
+        if (!rc) rc = chordvis_frame_phase_c_begin(c);
+        {
+            int e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dHzbExchange); }, (size_t)c->hzbExchangeChunkHalves * 2);
+            if (!rc) rc = e;
+            e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dHzbExchangeMax); }, (size_t)c->hzbExchangeChunkHalves * 2);
+            if (!rc) rc = e;
+            e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dRangeExchange); }, 8);
+            if (!rc) rc = e;
+        }
+        if (!rc) rc = chordvis_frame_phase_c_finish(c);
+#undef GP_HIP
+        return rc;
+    }, "group_render_frame (pipelined)");
+}
+
 int chordvis_group_sync(ChordGroup* g)
 {
     if (!g) return CHORDVIS_E_INVALID;
-    return run_all(g, [&](uint32_t r) { return chordvis_sync(g->ctx[r]); }, "group_sync");
+    return run_all(g, [&](uint32_t r) {
+        int rc = chordvis_sync(g->ctx[r]);
+        if (!rc && g->resolveStream[r] && hipStreamSynchronize(g->resolveStream[r]) != hipSuccess) rc = fail(g->ctx[r], CHORDVIS_E_HIP, "group_sync: resolve stream", hipGetLastError());
+        return rc;
+    }, "group_sync");
 }
 
 } // extern "C"

@@ -138,6 +138,12 @@ def _load():
         "chordvis_frame_phase_a": (i32, [vp]),
         "chordvis_frame_phase_b": (i32, [vp]),
         "chordvis_frame_phase_c": (i32, [vp]),
+        "chordvis_frame_phase_c_begin": (i32, [vp]),
+        "chordvis_frame_phase_c_finish": (i32, [vp]),
+        "chordvis_frame_resolve_visibility": (i32, [vp, vp]),
+        "chordvis_swap_visibility": (i32, [vp]),
+        "chordvis_hzb_exchange_max_ptr": (vp, [vp]),
+        "chordvis_range_exchange_ptr": (vp, [vp]),
         "chordvis_reset_history": (i32, [vp]),
         "chordvis_hzb_exchange_ptr": (vp, [vp]),
         "chordvis_hzb_exchange_halves": (u64, [vp]),
@@ -146,6 +152,7 @@ def _load():
         "chordvis_last_frame_cmds": (i32, [vp, P(CountAndCmd)]),
         "chordvis_history_hzb": (i32, [vp, P(HZB)]),
         "chordvis_readback_visibility": (i32, [vp, vp]),
+        "chordvis_readback_previous_visibility": (i32, [vp, vp]),
         "chordvis_readback_cmds": (i32, [vp, CountAndCmd, vp, u32, P(u32)]),
         "chordvis_readback_hzb": (i32, [vp, P(HZB), vp, vp, vp]),
         "chordvis_upload_history_hzb": (i32, [vp, vp]),
@@ -171,6 +178,7 @@ def _load():
         "chordvis_group_set_view": (i32, [vp, vp, vp, u32]),
         "chordvis_group_render_frame": (i32, [vp]),
         "chordvis_group_sync": (i32, [vp]),
+        "chordvis_group_set_pipelined": (i32, [vp, i32]),
         "chordvis_allocate_depth_views": (i32, [vp, u32, u32]),
         "chordvis_set_instance_views": (i32, [vp, vp, u32]),
         "chordvis_instance_culling_view": (i32, [vp, u32, P(CountAndCmd)]),

@@ -256,6 +256,12 @@ class VisibilityRenderer:
         self._check(L.lib.chordvis_readback_visibility(self._ctx, out.ctypes.data), "readback_visibility")
         return out
 
+    def read_previous_visibility(self):
+        """Pipelined sharded frames: the image of the frame before the last submitted one."""
+        out = np.zeros(self.width * self.height, dtype=np.uint64)
+        self._check(L.lib.chordvis_readback_previous_visibility(self._ctx, out.ctypes.data), "readback_previous_visibility")
+        return out
+
     def read_cmds(self, handle):
         n = C.c_uint32(0)
         self._check(L.lib.chordvis_readback_cmds(self._ctx, handle, None, 0, C.byref(n)), "readback_cmds")
@@ -377,3 +383,7 @@ class VisibilityGroup:
 
     def sync(self):
         self._check(L.lib.chordvis_group_sync(self._g), "group_sync")
+
+    def set_pipelined(self, enable=True):
+        """The visibility all-gather of frame i travels beside frame i + 1 (chordvis_group_set_pipelined)."""
+        self._check(L.lib.chordvis_group_set_pipelined(self._g, 1 if enable else 0), "group_set_pipelined")

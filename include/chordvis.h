@@ -266,6 +266,20 @@ int chordvis_render_frame(ChordCtx* ctx);
 int chordvis_frame_phase_a(ChordCtx* ctx);
 int chordvis_frame_phase_b(ChordCtx* ctx);
 int chordvis_frame_phase_c(ChordCtx* ctx);
+/* Pipelined form of phase c, for hosts that let the visibility all-gather of frame i travel beside frame i + 1 (two frames'
+ * words alive: chordvis_swap_visibility before every phase a).  The frame's final HZB then comes from an exchange of the
+ * ranks' own-stripe mip 0 instead of from the gathered image -- the same chain, bit for bit:
+ *   chordvis_frame_phase_c_begin    own-stripe mip 0 (min, max) into the two exchange buffers, the rank's valid-range pair
+ *   [all-gather chordvis_hzb_exchange_ptr, chordvis_hzb_exchange_max_ptr (chunk = hzb_exchange_chunk_halves) and
+ *    chordvis_range_exchange_ptr (two uint32 per rank)]
+ *   chordvis_frame_phase_c_finish   the chain from the exchanged mip 0, history swap; the frame is over
+ *   [whenever the visibility all-gather of the frame has landed: chordvis_frame_resolve_visibility, on any stream]   */
+int chordvis_frame_phase_c_begin(ChordCtx* ctx);
+int chordvis_frame_phase_c_finish(ChordCtx* ctx);
+int chordvis_frame_resolve_visibility(ChordCtx* ctx, void* hipStream /* NULL: the context's */);
+int chordvis_swap_visibility(ChordCtx* ctx);
+uint16_t* chordvis_hzb_exchange_max_ptr(ChordCtx* ctx);
+uint32_t* chordvis_range_exchange_ptr(ChordCtx* ctx);
 int chordvis_reset_history(ChordCtx* ctx);
 /* exchange buffer for the mid-frame HZB mip-0 all-gather (f16, rank-major) */
 uint16_t* chordvis_hzb_exchange_ptr(ChordCtx* ctx);
@@ -314,6 +328,11 @@ int chordvis_group_set_view(ChordGroup* group, const ChordCameraView* view, cons
  * device (no host synchronisation; chordvis_group_sync waits) */
 int chordvis_group_render_frame(ChordGroup* group);
 int chordvis_group_sync(ChordGroup* group);
+/* Pipelined frames: chordvis_group_render_frame returns once frame i is enqueued with its visibility all-gather and row-major
+ * copy running beside whatever follows (frame i + 1); every rank's history HZB is complete at the end of the call's work as
+ * before.  chordvis_readback_visibility / the consumer entry points of a rank's context wait for ITS image;
+ * chordvis_readback_previous_visibility reads the frame before the last submitted one. */
+int chordvis_group_set_pipelined(ChordGroup* group, int enable);
 
 /* ------------------------------------------------------------------ depth-only views (what renderShadow runs per
  * cascade, mesh_raster.cpp:331-546).  Every pass of the reference takes (instanceViewId, instanceViewOffset) -- a buffer of
@@ -371,6 +390,7 @@ int chordvis_prepare_shading_tile_param(ChordCtx* ctx, uint32_t shadingType, con
 /* ------------------------------------------------------------------ readback / stats (synchronize) */
 
 int chordvis_readback_visibility(ChordCtx* ctx, uint64_t* hostWords /* width*height, row-major */);
+int chordvis_readback_previous_visibility(ChordCtx* ctx, uint64_t* hostWords);   /* pipelined sharded frames: the other buffer pair */
 int chordvis_readback_cmds(ChordCtx* ctx, ChordCountAndCmd handle, ChordDrawCmd* hostCmds, uint32_t cap, uint32_t* outCount);
 int chordvis_readback_hzb(ChordCtx* ctx, const ChordHZB* hzb, uint16_t* hostMin, uint16_t* hostMax, uint32_t hostValidRange[2]);
 /* host: 4 words per marker texel; tiles: 2 words per tile (at most hostCapacity tiles are copied) */

@@ -79,6 +79,68 @@ def _check_ranks(g, want, w, h, what):
         assert [st[k] for k in keys] == [wst[k] for k in keys]
 
 
+PIPELINED = [
+    ("small_2", lambda: scenes.small_test_scene(320, 200, seed=17), 2, 14),
+    ("small_3", lambda: scenes.small_test_scene(320, 200, seed=23), 3, 0),
+    ("street_720p_4", lambda: scenes.config3_street(1280, 720), 4, 0),
+    ("street_x64_360p_8", lambda: scenes.config4_street_x64(640, 360), 8, 0),
+]
+
+
+@pytest.mark.parametrize("name,builder,ranks,stripe", PIPELINED, ids=[g[0] for g in PIPELINED])
+def test_pipelined_group_frames_equal_the_single_gpu_frames(gpu, name, builder, ranks, stripe):
+    """chordvis_group_set_pipelined: the visibility all-gather and row-major copy of frame i run beside frame i + 1 (two
+    buffer pairs per rank), and the history HZB comes from an exchange of own-stripe mip 0 (min, max) and valid-range pairs
+    instead of from the gathered image.  Six frames with a moving camera, never synchronised in between: every rank's
+    image of every frame (read as 'the frame before' once the next one is submitted, then as the last one), HZB chain and
+    counts equal the single-GPU frames."""
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityGroup, VisibilityRenderer
+    scene, cam0 = builder()
+    w, h, flags = cam0.width, cam0.height, H.ALL_FLAGS
+    f = np.array(cam0.front, dtype=np.float64)
+    f /= np.linalg.norm(f)
+    cams = [cam0.moved(tuple(0.25 * k * f)) for k in range(6)]
+    ref = VisibilityRenderer(0)
+    ref.upload_scene(scene)
+    ref.allocate_gbuffer(w, h)
+    g = VisibilityGroup([0] * ranks)
+    g.upload_scene(scene)
+    g.allocate_gbuffer(w, h, stripe)
+    g.set_pipelined(True)
+    inputs, wants, last_view = [], [], None
+    for k, cam in enumerate(cams):
+        objs = L.fill_objects(scene, cam, cams[k - 1] if k else None).copy()
+        view, iv = L.make_views(cam, last_view)
+        last_view = L.make_views(cam)[0]
+        inputs.append((objs, view, iv))
+        ref.update_objects(objs)
+        ref.set_view(view, iv, flags)
+        ref.render_frame()
+        wants.append((ref.read_visibility(), ref.read_hzb(ref.history_hzb()), ref.stats()))
+    for k, (objs, view, iv) in enumerate(inputs):
+        g.update_objects(objs)
+        g.set_view(view, iv, flags)
+        g.render_frame()                                   # frame k enqueued; frame k - 1's image may still be travelling
+        if k in (1, 3, 5):
+            for rk, r in enumerate(g.ranks):
+                H.assert_vis_equal(r.read_previous_visibility(), wants[k - 1][0], w, h, "frame %d (as the previous one) rank %d" % (k - 1, rk))
+        if k >= 2:
+            _check_ranks(g, wants[k], w, h, "pipelined frame %d" % k)
+    # back to the unpipelined protocol on the same group: the history carries over
+    g.set_pipelined(False)
+    objs, view, iv = inputs[-1]
+    g.update_objects(objs)
+    g.set_view(*L.make_views(cams[-1], L.make_views(cams[-1])[0]), flags)
+    g.render_frame()
+    ref.update_objects(objs)
+    ref.set_view(*L.make_views(cams[-1], L.make_views(cams[-1])[0]), flags)
+    ref.render_frame()
+    _check_ranks(g, (ref.read_visibility(), ref.read_hzb(ref.history_hzb()), ref.stats()), w, h, "unpipelined frame after pipelined ones")
+    g.close()
+    ref.close()
+
+
 def test_library_owned_rccl_exchange_world_size_1(gpu):
     """chordvis_comm_*: librccl resolved at run time (the copy PyTorch already loaded), a communicator attached to the
     context, chordvis_render_frame issuing ncclAllGather on the context's stream.  One rank is all a one-GPU box can
