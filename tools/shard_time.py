@@ -27,6 +27,11 @@ for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
     def frame():
         if ranks == 1:
             r.render_frame()
+        elif os.environ.get("PIPELINED") == "1":
+            # the pipelined protocol's critical path: no visibility gather, no row-major copy, history HZB from the exchange
+            L.lib.chordvis_swap_visibility(r._ctx)
+            r.frame_phase_a(); r.frame_phase_b()
+            assert L.lib.chordvis_frame_phase_c_begin(r._ctx) == 0 and L.lib.chordvis_frame_phase_c_finish(r._ctx) == 0
         else:
             r.frame_phase_a(); r.frame_phase_b(); r.frame_phase_c()
     for _ in range(3):
