@@ -8,15 +8,20 @@ import numpy as np
 
 
 def pick_stripe_rows(height, ranks):
-    """Even stripe height in [32, 96] with the least padding of ceil(H / S) to a multiple of `ranks`."""
+    """chordvis_pick_stripe_rows: even stripe height in [32, 256], at least two stripes per rank, that minimises
+    padding / height + 18 / rows -- the idle share of the rank holding the padded stripe plus the share of (16-pixel) clusters
+    that straddle two stripes and are set up by both owners; ties towards the taller stripe."""
+    ranks = max(1, int(ranks))
     best = None
-    for s in range(32, 97, 2):
+    for s in range(32, 258, 2):
         stripes = -(-height // s)
         per = -(-stripes // ranks)
+        if ranks > 1 and per < 2 and s > 32:
+            continue
         pad = per * ranks * s - height
-        key = (pad, abs(s - 64))
-        if best is None or key < best[0]:
-            best = (key, s)
+        num = pad * s + 18 * height                       # cost = num / (height * s)
+        if best is None or num * best[1] < best[0] * s or (num * best[1] == best[0] * s and s > best[1]):
+            best = (num, s)
     return best[1]
 
 
