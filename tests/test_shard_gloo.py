@@ -10,6 +10,19 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_stripe_height_rule_is_the_same_in_the_library_and_on_the_host():
+    """chordvis_pick_stripe_rows (C, what ChordGroup uses) and chord_amd.sharding.pick_stripe_rows (what bench.py passes to
+    chordvis_set_shard on every rank) must agree -- ranks that disagreed about the stripes would assemble garbage."""
+    from chord_amd import lib as L
+    from chord_amd.sharding import pick_stripe_rows
+    for h in list(range(64, 4097, 24)) + [2160, 1080, 1440, 720, 4096]:
+        for n in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16):
+            s = pick_stripe_rows(h, n)
+            assert s == L.lib.chordvis_pick_stripe_rows(h, n), (h, n)
+            assert s % 2 == 0 and 32 <= s <= 256
+    assert [pick_stripe_rows(2160, n) for n in (2, 4, 8)] == [216, 180, 136]
+
+
 def test_stripe_layout_round_trip_and_ownership():
     from chord_amd.sharding import StripeLayout, pick_stripe_rows
     for (w, h, ranks) in ((320, 200, 2), (3840, 2160, 8), (3840, 2160, 4), (1920, 1080, 2), (257, 131, 3)):
