@@ -25,7 +25,12 @@ CASES = {
     "config3_street_640x360": (lambda: scenes.config3_street(640, 360), ALL),
     "config5_subpixel_480x270": (lambda: scenes.config5_subpixel(480, 270, prims=4, patches_per_prim=256, instances=2),
                                  R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL),
+    # alpha-tested materials (oracle item 9: the pinned texture fetch) and, below, depth-only views of the same scene (item 10)
+    "masked_320x200": (lambda: scenes.masked_test_scene(320, 200), ALL),
 }
+DEPTH_CASES = {"masked_320x200": dict(cascadeCount=3, realtimeCascadeCount=2, cascadeDim=256, cascadeEndDistance=14.0, farCascadeEndDistance=40.0,
+                                      shadowBiasConst=-8.0, shadowBiasSlope=-0.5)}
+LIGHT = (0.35, -1.0, 0.25)
 
 
 def sha(a):
@@ -46,6 +51,23 @@ def digests(name):
         out["frame1"] = {"vis": sha(f1["vis"]), "hzb_min": sha(f1["hzb_min"]), "hzb_max": sha(f1["hzb_max"]),
                          "cmds": sha(f1["cmds"]), "counts": [int(x) for x in f1["counts"]],
                          "covered": int((f1["vis"] != 0).sum())}
+    if name in DEPTH_CASES:
+        # shadow cascades: per-view instance cull, depth raster with clamp + bias, generic HZB cull against the farther cascade
+        cfg = R.default_cascade_config(**DEPTH_CASES[name])
+        dim = int(cfg["cascadeDim"][0])
+        views = L.cascade_setup(cfg, view, iv, LIGHT)
+        campos = np.frombuffer(iv["cameraWorldPos"][0].tobytes(), dtype=np.float64)[:3]
+        desc = orc.hzb_desc(dim, dim)
+        prev = None
+        for k in range(len(views) - 1, -1, -1):
+            cmds = orc.instance_culling(scene, view, views[k:k + 1], flags)
+            kept = cmds if prev is None else orc.hzb_culling_generic(scene, views[prev[0]:prev[0] + 1], campos, flags, 1.5, False, desc, prev[1], cmds)
+            depth, _ = orc.raster_depth(scene, views[k:k + 1], kept, dim, dim, bias_const=float(cfg["shadowBiasConst"][0]), bias_slope=float(cfg["shadowBiasSlope"][0]))
+            words = depth.view(np.uint32).astype(np.uint64) << np.uint64(32)
+            _, hmin, _, _ = orc.hzb_build(words, dim, dim)
+            out["cascade%d" % k] = {"view": sha(views[k:k + 1]), "cmds": sha(cmds), "kept": sha(kept), "depth": sha(depth), "hzb_min": sha(hmin),
+                                    "covered": int((depth > 0).sum())}
+            prev = (k, hmin)
     return out
 
 
