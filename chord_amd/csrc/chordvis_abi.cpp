@@ -326,7 +326,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dMaterials); dfree(c->dTexAlpha); dfree(c->dTexcoords); dfree(c->dBvhNodes); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
-    dfree(c->dRankCmds);
+    dfree(c->dRankCmds); dfree(c->dLeftCmds);
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
@@ -535,6 +535,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     }
 
     dfree(c->dRankCmds);                                   // sized by cmdCapacity; re-made by the first sharded raster pass
+    dfree(c->dLeftCmds);
     c->objectCount = s->objectCount; c->primCount = s->primitiveCount; c->materialCount = s->materialCount;
     c->meshletCount = nM; c->groupCount = nG;
     c->groupInstances = (uint32_t)groupInst; c->cmdCapacity = (uint32_t)std::max<uint64_t>(cmdCap, 1);
@@ -548,7 +549,13 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     bool anyMasked = false;
     for (uint32_t m = 0; m < s->materialCount; m++) anyMasked = anyMasked || s->materials[m].alphaMode == CHORD_ALPHA_MASK;
     if (anyMasked && s->textures) {
+        // only the textures an alpha-tested material samples are looked at (a host may hand over its whole bindless table, with
+        // pixel data only where the visibility pass needs it); every other entry stays "white"
+        std::vector<uint8_t> sampled(s->textureCount, 0);
+        for (uint32_t m = 0; m < s->materialCount; m++)
+            if (s->materials[m].alphaMode == CHORD_ALPHA_MASK && s->materials[m].baseColorId < s->textureCount) sampled[s->materials[m].baseColorId] = 1;
         for (uint32_t t = 0; t < s->textureCount; t++) {
+            if (!sampled[t]) continue;
             const ChordTexture& tx = s->textures[t];
             if (!tx.rgba8 || tx.width == 0 || tx.height == 0 || tx.mipCount == 0 || tx.width > 16384u || tx.height > 16384u || tx.mipCount > 15u)
                 return fail(c, CHORDVIS_E_INVALID, "upload_scene: texture without data, or larger than 16384 / 15 levels");
@@ -584,8 +591,11 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
             uvs.assign((size_t)nV * 2, 0.0f);
             for (uint32_t a = 0; a < s->assetCount; a++) {
                 const ChordAssetDesc& as = s->assets[a];
-                if (as.texcoord0 && as.texcoord0Count)
-                    std::memcpy(uvs.data() + (size_t)vB[a] * 2, as.texcoord0, sizeof(float) * 2 * std::min(as.texcoord0Count, as.vertexCount));
+                if (as.texcoord0 && as.texcoord0Count) {
+                    // (a shorter array would silently read as uv = (0, 0) for the vertices beyond it)
+                    if (as.texcoord0Count != as.vertexCount) return fail(c, CHORDVIS_E_INVALID, "upload_scene: texcoord0Count must equal vertexCount (or be 0: no texture coordinates)");
+                    std::memcpy(uvs.data() + (size_t)vB[a] * 2, as.texcoord0, sizeof(float) * 2 * as.vertexCount);
+                }
             }
         }
     }
@@ -1025,6 +1035,25 @@ int chordvis_frame_resolve_visibility(ChordCtx* c, void* hipStream)
     return CHORDVIS_OK;
 }
 
+// Orders `hipStream` (NULL: the context's stream) behind the completion of the resolved image of the last submitted frame.
+// Needed only after pipelined ChordGroup frames, whose image is gathered beside the context's stream; a no-op otherwise.
+int chordvis_wait_visibility(ChordCtx* c, void* hipStream)
+{
+    if (!c || !c->dVis) return fail(c, CHORDVIS_E_INVALID, "wait_visibility: no gbuffer");
+    hipStream_t s = hipStream ? (hipStream_t)hipStream : c->stream;
+    if (c->visReadyEvent[0]) CHORD_HIP(c, hipStreamWaitEvent(s, c->visReadyEvent[0], 0));
+    else if (s != c->stream) {
+        // not pipelined: the image is complete when the context's stream is; order the foreign stream behind it
+        hipEvent_t e = nullptr;
+        CHORD_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hipError_t rc = hipEventRecord(e, c->stream);
+        if (rc == hipSuccess) rc = hipStreamWaitEvent(s, e, 0);
+        (void)hipEventDestroy(e);                                    // (destruction is deferred until the event has completed)
+        if (rc != hipSuccess) return fail(c, CHORDVIS_E_HIP, "wait_visibility", rc);
+    }
+    return CHORDVIS_OK;
+}
+
 int chordvis_last_frame_cmds(ChordCtx* c, ChordCountAndCmd* out)
 {
     if (!c || !out || !c->sceneLoaded) return fail(c, CHORDVIS_E_INVALID, "last_frame_cmds: no scene");
@@ -1053,6 +1082,8 @@ int chordvis_visibility_mark(ChordCtx* c, ChordCountAndCmd drawed, ChordTileMark
         if ((rc = dalloc(c, &c->dShadingTiles, (size_t)mW * mH * 2 + 8))) return rc;
     }
     const unsigned long long* vis = (const unsigned long long*)(c->shard.ranks > 1 ? c->dVisResolved : c->dVis);
+    // (pipelined group frames: the image is gathered and resolved beside the context's stream)
+    if (c->visReadyEvent[0]) CHORD_HIP(c, hipStreamWaitEvent(c->stream, c->visReadyEvent[0], 0));
     chord::launch_visibility_mark(c, vis, drawed.cmds, drawed.count, c->dTileMarker);
     CHORD_HIP(c, hipGetLastError());
     out->marker = c->dTileMarker;
@@ -1306,7 +1337,7 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
         for (int pass = 0; pass < 2; pass++) {
             CHORD_HIP(c, hipMemcpy2D(tc.data(), 4, c->dFrameState->tileCount + (size_t)pass * c->tilesX * c->tilesY * CHORD_TILECOUNT_STRIDE, 4 * CHORD_TILECOUNT_STRIDE, 4, tc.size(), hipMemcpyDeviceToHost));
             for (uint32_t v : tc) { out->binEntries += v; out->tilesTouched[pass] += v ? 1u : 0u; }
-            CHORD_HIP(c, hipMemcpy2D(tc.data(), 4, c->dFrameState->tileCount + (size_t)pass * c->tilesX * c->tilesY * CHORD_TILECOUNT_STRIDE + 2, 4 * CHORD_TILECOUNT_STRIDE, 4, tc.size(), hipMemcpyDeviceToHost));
+            CHORD_HIP(c, hipMemcpy2D(tc.data(), 4, c->dFrameState->tileCount + (size_t)pass * c->tilesX * c->tilesY * CHORD_TILECOUNT_STRIDE + 1, 4 * CHORD_TILECOUNT_STRIDE, 4, tc.size(), hipMemcpyDeviceToHost));
             for (uint32_t v : tc) out->pixelBlocks += v;
         }
     }

@@ -69,16 +69,26 @@ int chordvis_allocate_depth_views(ChordCtx* c, uint32_t dim, uint32_t viewCount)
     k->instTriangles = c->instTriangles; k->limitRecords = c->limitRecords; k->limitPoolChunks = c->limitPoolChunks; k->binMaxChunks = c->binMaxChunks;
     c->depthCtx = k;
     k->debugFlags = c->debugFlags;
-    if ((rc = alloc_scene_work_buffers(k))) return child_fail(c, rc);
+    // a failure past this point leaves nothing half-made behind: the child, the images and depthDim go together
+    auto undo = [&](int code) -> int {
+        if (c->depthCtx) c->lastError = c->depthCtx->lastError;
+        for (float*& d : c->dDepthImages) if (d) { (void)hipFree(d); d = nullptr; }
+        c->dDepthImages.clear();
+        c->depthDim = 0;
+        if (c->depthCtx) { chordvis_destroy(c->depthCtx); c->depthCtx = nullptr; }
+        return code;
+    };
+    if ((rc = alloc_scene_work_buffers(k))) return undo(rc);
     k->dObjects = c->dObjects;
     k->sceneLoaded = true;
-    if ((rc = chordvis_allocate_gbuffer(k, dim, dim, nullptr))) return child_fail(c, rc);
-    c->depthDim = dim;
+    if ((rc = chordvis_allocate_gbuffer(k, dim, dim, nullptr))) return undo(rc);
     c->dDepthImages.assign(viewCount, nullptr);
     for (uint32_t i = 0; i < viewCount; i++) {
-        CHORD_HIP(c, hipMalloc((void**)&c->dDepthImages[i], sizeof(float) * (size_t)dim * dim));
-        CHORD_HIP(c, hipMemsetAsync(c->dDepthImages[i], 0, sizeof(float) * (size_t)dim * dim, c->stream));
+        hipError_t e = hipMalloc((void**)&c->dDepthImages[i], sizeof(float) * (size_t)dim * dim);
+        if (e == hipSuccess) e = hipMemsetAsync(c->dDepthImages[i], 0, sizeof(float) * (size_t)dim * dim, c->stream);
+        if (e != hipSuccess) { const int code = fail(c, CHORDVIS_E_HIP, "allocate_depth_views: depth image", e); const std::string msg = c->lastError; undo(code); c->lastError = msg; return code; }
     }
+    c->depthDim = dim;
     return CHORDVIS_OK;
 }
 

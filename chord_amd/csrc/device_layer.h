@@ -131,7 +131,7 @@ struct TriRecC {
 #define CHORD_REC_BLOCK 0xC0000000u
 #define CHORD_REC_INDEX_MASK 0x3FFFFFFFu
 #define CHORD_BLOCK_WIN 16
-struct ClipTri { uint32_t cmdIndex; uint32_t tri; };       // needs the homogeneous clipper
+struct ClipTri { uint32_t objectId, meshletId, slot, tri; };    // needs the homogeneous clipper (the draw command rides along: the setup kernels read different lists)
 
 // The record list is cut into LIST_SHARDS independent sub-lists (own counter, own region) so that
 // list allocation is not serialised on one memory-side atomic (one word sustains only ~88 returning
@@ -176,7 +176,7 @@ struct DeviceCounters {
 #endif
 struct FrameState {
     DeviceCounters counters;
-    uint32_t listCounts[8];        // [0..3] command lists of the frame, [4 + pass] this rank's clusters of a raster pass (sharded)
+    uint32_t listCounts[8];        // [0..3] command lists of the frame, [4 + pass] this rank's clusters of a raster pass (sharded), [6 + pass] clusters a dense launch's block kernel left over
     uint32_t tileCount[2 * CHORD_MAX_TILES * CHORD_TILECOUNT_STRIDE];   // pass p starts at p * tiles * stride
 };
 
@@ -261,6 +261,7 @@ struct ChordCtx {
     // command lists: 0 = post instanceCulling, 1 = hzb visible, 2 = hzb rejected
     chord::CmdList lists[3];
     ChordDrawCmd* dRankCmds = nullptr; // sharded frames: the commands of a raster pass whose clusters touch this rank's rows
+    ChordDrawCmd* dLeftCmds = nullptr; // dense launches: the clusters the block kernel left to the record kernel (kernels_raster.hip)
     uint32_t* dCounts = nullptr;      // 4 x u32 backing the list counts
 
     // gbuffer

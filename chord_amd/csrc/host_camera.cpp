@@ -266,7 +266,10 @@ int chordvis_object_basic_data_batch(uint32_t count, const double* localToWorld,
     return CHORDVIS_OK;
 }
 
-// cascadeComputeCS (cascade_setup.hlsl:79-372) on the host.  The reference runs these few hundred flops per cascade as a
+// cascadeComputeCS (cascade_setup.hlsl:79-372) on the host: a TRANSLITERATION of the shader, statement for statement and with
+// its identifiers (splitLambda, splitCascadeCount, stableDistance, zStartBiasScale, radiusScale, the argument order at :163, the
+// reuse of frontN at :365) -- it has to produce the same fp32 values, so the operation order is the shader's and nothing here
+// is an independent design.  The reference runs these few hundred flops per cascade as a
 // one-group compute shader only because it reads the SDSM depth range from a GPU buffer; here the caller hands that range
 // over (or NULL: the shader's own "no valid range buffer" branch, :118).  fp32 in the shader's operation order.
 int chordvis_cascade_setup(const ChordCascadeConfig* cfg, const ChordCameraView* view, const ChordInstanceCullingView* mainInstanceView,

@@ -34,6 +34,7 @@
 #include "device_layer.h"
 #include "device_math.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace chord {
@@ -47,9 +48,14 @@ namespace chord {
 #define TPITCH (TILE + 1)
 #define SMALL_AREA 256          // clipped bbox pixels a single lane scans on its own
 #define TC_STRIDE CHORD_TILECOUNT_STRIDE   // one bin counter per 64-byte line (no false sharing between tiles)
+// words of a tile's counter line: 0 = bin entries, 1 = of which pixel blocks (words 0 and 1 are ONE 64-bit counter for the
+// block path: a block's bin slot and the block count travel in a single atomic), 2 = ticket of the slices of a split tile
+#define TC_BLOCKS 1u
+#define TC_TICKET 2u
 
 struct RasterParams {
     const uint32_t* count; const ChordDrawCmd* cmds;
+    uint32_t* leftCount; ChordDrawCmd* leftCmds;         // clusters of a dense launch that do not become pixel blocks (raster_setup_blocks_kernel -> raster_setup_kernel), or NULL
     const DObjFrame* objFrame; const DObjStatic* objStatic;
     const DMeshlet* meshlets; const uint32_t* meshletData; const float* positions;
     const DMaterial* materials; const uint8_t* texAlpha; const float* texcoords;   // masked materials (texcoords may be null: uv = 0)
@@ -543,86 +549,8 @@ enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
 #define DBG_NO_BLOCKS 32768u     // small clusters take the record path too (A/B of the pixel blocks; results identical)
 #define DBG_FORCE_BLOCKS 65536u  // the setup kernel takes its BLOCKS body whatever the cluster count (tests: small scenes)
 
-// A small cluster's triangles -> pixel window in LDS -> one dense block of packed words per tile the window touches.
-__device__ __forceinline__ void cluster_blocks(const RasterParams& p, bool eA, TriSetup& tsA, const float* dA, bool eB, TriSetup& tsB, const float* dB,
-                                               unsigned long long* win, int32_t bx0, int32_t by0, int32_t bx1, int32_t by1, uint32_t listShard)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    // the window's parts per tile (<= 2 x 2): lane r < 4 owns the part in tile (r & 1 ? tx1 : tx0, r & 2 ? ty1 : ty0)
-    const int32_t tx0 = bx0 >> TILE_SHIFT, tx1 = bx1 >> TILE_SHIFT, ty0 = by0 >> TILE_SHIFT, ty1 = by1 >> TILE_SHIFT;
-    const uint32_t r = lane & 3u;
-    const bool sx = (r & 1u) != 0u, sy = (r & 2u) != 0u;
-    const int32_t rx0 = sx ? tx1 << TILE_SHIFT : bx0, rx1 = (sx || tx1 == tx0) ? bx1 : (tx0 << TILE_SHIFT) + TILE - 1;
-    const int32_t ry0 = sy ? ty1 << TILE_SHIFT : by0, ry1 = (sy || ty1 == ty0) ? by1 : (ty0 << TILE_SHIFT) + TILE - 1;
-    const uint32_t rw = (uint32_t)(rx1 - rx0 + 1), rh = (uint32_t)(ry1 - ry0 + 1);
-    const bool has = lane < 4u && !(sx && tx1 == tx0) && !(sy && ty1 == ty0) && owns_any_row(p.shard, ry0, ry1);
-    const uint32_t hasMask = (uint32_t)__ballot(has) & 15u;
-    const uint32_t gran = has ? (rw * rh + 2u) >> 1 : 0u;                  // header + w x h words, in 16-byte granules
-    const uint32_t g0 = bcast(gran, 0), g1 = bcast(gran, 1), g2 = bcast(gran, 2), g3 = bcast(gran, 3);
-    const uint32_t before = (r > 0u ? g0 : 0u) + (r > 1u ? g1 : 0u) + (r > 2u ? g2 : 0u), G = g0 + g1 + g2 + g3;
-    const uint32_t tile = (uint32_t)(sy ? ty1 : ty0) * p.tilesX + (uint32_t)(sx ? tx1 : tx0);
-    // one round trip: pool space (lane 0) and a bin slot per touched tile (lanes 0..3; word 2 of the tile's counter line
-    // counts its blocks) ...
-    uint32_t gbase = 0, slot = 0;
-#ifndef BLK_NO_ATOMIC
-    if (lane == 0u && G) gbase = atomicAdd(&p.counters->blockGranules[listShard * CHORD_SHARD_STRIDE], G);
-    if (has) { slot = atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE], 1u); atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE + 2u], 1u); }
-#endif
-    // ... and the cluster is resolved while they are in flight
-#pragma unroll
-    for (int k = 0; k < WIN * WIN / 64; k++) win[lane + 64u * k] = 0ull;
-    unsigned long long rowMaskW = ~0ull;
-    if (p.shard.ranks > 1u) {
-        rowMaskW = 0ull;
-        for (int32_t ly = 0; ly <= by1 - by0; ly++) if (owns_row<true>(p.shard, by0 + ly)) rowMaskW |= 1ull << ly;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const bool clampZ = p.depthClamp != 0u;
-    // (the same per-pixel arithmetic as the tile kernel's tiny-triangle scan of the record this triangle would have been)
-#ifndef BLK_NO_RASTER
-    if (eA) {
-        tsA.d0 = dA[0]; tsA.e1 = dA[1] - dA[0]; tsA.e2 = dA[2] - dA[0];
-        tile_raster_narrow<WIN>(win, tsA, bx0, by0, tsA.px0, tsA.py0, tsA.px1, tsA.py1, false, rowMaskW, clampZ);
-    }
-    if (eB) {
-        tsB.d0 = dB[0]; tsB.e1 = dB[1] - dB[0]; tsB.e2 = dB[2] - dB[0];
-        tile_raster_narrow<WIN>(win, tsB, bx0, by0, tsB.px0, tsB.py0, tsB.px1, tsB.py1, false, rowMaskW, clampZ);
-    }
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    gbase = bcast(gbase, 0);
-    const bool fits = gbase + G <= p.blockCap;
-    if (!fits && lane == 0u) atomicOr(&p.counters->overflow, 1u);
-    const uint32_t off = listShard * p.blockCap + gbase + before;              // granule offset of lane r's block
-#ifndef BLK_NO_STORE
-    if (has) bin_alloc(p, tile, slot);
-    if (has && fits) {
-        p.blockPool[(size_t)off * 2u] = (unsigned long long)((uint32_t)(rx0 & (TILE - 1)) | (uint32_t)(ry0 & (TILE - 1)) << 6 | (rw - 1u) << 12 | (rh - 1u) << 16) |
-                                       ((unsigned long long)((65536u + rw - 1u) / rw) << 32);
-        bin_put(p, tile, slot, CHORD_REC_BLOCK | off);
-    }
-    for (int k = 0; k < WIN * WIN / 64; k++) {
-        const uint32_t idx = lane + 64u * k;
-        const int32_t x = bx0 + (int32_t)(idx & (WIN - 1)), y = by0 + (int32_t)(idx / WIN);
-        const uint32_t q = ((x >> TILE_SHIFT) != tx0 ? 1u : 0u) | ((y >> TILE_SHIFT) != ty0 ? 2u : 0u);
-        const uint32_t qoff = (uint32_t)__shfl((int)off, (int)q, 64);
-        const int32_t qx0 = (q & 1u) ? tx1 << TILE_SHIFT : bx0, qy0 = (q & 2u) ? ty1 << TILE_SHIFT : by0;
-        const int32_t qw = (q & 1u) ? bx1 - (tx1 << TILE_SHIFT) + 1 : min(bx1, (tx0 << TILE_SHIFT) + TILE - 1) - bx0 + 1;
-        if (x <= bx1 && y <= by1 && fits && ((hasMask >> q) & 1u))
-            p.blockPool[(size_t)qoff * 2u + 1u + (size_t)((y - qy0) * qw + (x - qx0))] = win[idx];
-    }
-#endif
-}
-
-// BLOCKS: the instantiation that can turn small clusters into pixel blocks (cluster_blocks).  It is a second body of the
-// same kernel, chosen per launch (below), because the block code costs the record path registers: with it inlined the
-// kernel spills 50 VGPRs at its 128-VGPR budget, also where no cluster is small.
-template <bool MASKED, bool BLOCKS>
-__device__ __forceinline__ void raster_setup_body(const RasterParams& p, const uint32_t count, float (*sVert)[4][LDS_VERTS], unsigned long long (*sWin)[WIN * WIN])
+template <bool MASKED>
+__device__ __forceinline__ void raster_setup_body(const RasterParams& p, const uint32_t count, float (*sVert)[4][LDS_VERTS])
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* lX = sVert[0][wave]; float* lY = sVert[1][wave]; float* lW = sVert[2][wave];
@@ -686,7 +614,6 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
     unsigned long long sph[5] = {0, 0, 0, 0, 0}, stp = sprof ? wall_clock64() : 0ull;
 #define SPHASE(i) do { if (sprof) { const unsigned long long tn = wall_clock64(); sph[i] += tn - stp; stp = tn; } } while (0)
     for (; c < count; c += stride) {
-        const uint32_t cu = __builtin_amdgcn_readfirstlane(c);
         const uint32_t slot = hdr.slot, V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
         const bool twoSided = hdr.twoSided || p.depthOnly != 0u;                       // depth passes: cull mode NONE (mesh_raster.cpp:188-190)
         const bool masked = MASKED && CHORD_MATFLAG_ALPHA(hdr.matFlags) == CHORD_ALPHA_MASK;      // (wave-uniform)
@@ -794,27 +721,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
             const uint32_t nClip = (uint32_t)(__popcll(cmA) + __popcll(cmB));
             const uint32_t nEc = (uint32_t)(__popcll(ecA) + __popcll(ecB)), nEw = (uint32_t)(__popcll(ewA) + __popcll(ewB));
             const uint32_t nLg = (uint32_t)(__popcll(lmA) + __popcll(lmB));
-            // ---- small cluster: every emitted triangle inside one WIN x WIN pixel window (and narrow, unclipped, opaque).
-            //      The wave resolves the cluster in LDS -- the same per-pixel arithmetic as the tile kernel's tiny-triangle
-            //      scan -- and emits the window as dense blocks of packed words, one per tile it touches (<= 2 x 2), when
-            //      that is fewer bytes than the records + bin entries of its triangles (36 B each).  For sub-pixel
-            //      geometry this is 5-7x less traffic out of this kernel and into the tile kernel, which merges a block
-            //      with one LDS max per word instead of setting up, scanning and depth-interpolating every triangle again.
-            bool blocksDone = false;
-            if (BLOCKS && !masked && (emA | emB) != 0ull && (ewA | ewB | cmA | cmB) == 0ull) {
-                const bool eA = kindA == K_EMIT, eB = kindB == K_EMIT;
-                int32_t bx0 = min(eA ? tsA.px0 : 0x7FFF, eB ? tsB.px0 : 0x7FFF), by0 = min(eA ? tsA.py0 : 0x7FFF, eB ? tsB.py0 : 0x7FFF);
-                int32_t bx1 = max(eA ? tsA.px1 : -1, eB ? tsB.px1 : -1), by1 = max(eA ? tsA.py1 : -1, eB ? tsB.py1 : -1);
-                if (__ballot(bx1 - bx0 >= WIN || by1 - by0 >= WIN) == 0ull) {            // (no single lane is already too wide)
-                    bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0); bx1 = wave_max_i32(bx1); by1 = wave_max_i32(by1);
-                    const int32_t bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-                    if (bw <= WIN && bh <= WIN && (uint32_t)(bw * bh + 8) * 8u <= nEc * 36u) {
-                        blocksDone = true;
-                        cluster_blocks(p, eA, tsA, dA, eB, tsB, dB, sWin[wave], bx0, by0, bx1, by1, listShard);
-                    }
-                }
-            }
-            if (!blocksDone) {
+            {
             // every reservation of the cluster travels together: the list reservations (lane 0) and the bin
             // reservations; nothing is stored before they are back
             uint32_t cbase = 0, ebaseC = 0, ebaseW = 0, lbase = 0;
@@ -830,12 +737,12 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
             SPHASE(3);
             if (kindA == K_CLIP) {
                 const uint32_t k = cbase + (uint32_t)__popcll(cmA & lt);
-                if (k < p.clipTriCap) { ClipTri ct; ct.cmdIndex = cu; ct.tri = lane; p.clipTris[k] = ct; }
+                if (k < p.clipTriCap) { ClipTri ct; ct.objectId = hdr.objectId; ct.meshletId = hdr.meshletId; ct.slot = hdr.slot; ct.tri = lane; p.clipTris[k] = ct; }
                 else atomicOr(&p.counters->overflow, 2u);
             }
             if (kindB == K_CLIP) {
                 const uint32_t k = cbase + (uint32_t)__popcll(cmA) + (uint32_t)__popcll(cmB & lt);
-                if (k < p.clipTriCap) { ClipTri ct; ct.cmdIndex = cu; ct.tri = lane + 64u; p.clipTris[k] = ct; }
+                if (k < p.clipTriCap) { ClipTri ct; ct.objectId = hdr.objectId; ct.meshletId = hdr.meshletId; ct.slot = hdr.slot; ct.tri = lane + 64u; p.clipTris[k] = ct; }
                 else atomicOr(&p.counters->overflow, 2u);
             }
             // giX names the record in a bin: compact index, or CHORD_REC_WIDE | wide index
@@ -894,20 +801,363 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
 #undef SPHASE
 }
 
+// ---- the BLOCKS body, round 3: the same clusters -> the same blocks, organised around registers --------------------------
+// Round 2's BLOCKS instantiation of raster_setup_body wanted 159 VGPRs and ran at the kernel's 128 with 22 of them in scratch
+// (92 bytes per lane, re-read per cluster: the 21 GB of WRITE_SIZE the round-2 profile of BASELINE config 5 could not account
+// for -- tools/microbench/write_size_calib shows the block stores themselves are counted at face value).  What it kept alive
+// across the block code was the whole set-up of BOTH triangles of a lane (snapped vertices, depths, areas, bounds: 2 x 19
+// registers) next to the software pipeline of the next cluster.  This body keeps, per triangle, a 2-bit kind and its pixel
+// bounds (two packed registers) between the classification and the resolve, and sets a triangle up again from the wave's LDS
+// copy of the vertices right before it is scan-converted, one triangle at a time.  The price is the snapping and the area of
+// an emitted triangle twice (~45 VALU instructions per triangle of ~600); the division moves, it is not repeated.
+// Wave-uniform records (draw command, meshlet header, object matrix) come through the scalar cache (constant address space:
+// s_load instead of a vector load + v_readfirstlane per dword), and a block leaves the wave as 16-byte stores of consecutive
+// word pairs (header | word 0, word 1 | word 2, ...): half the store instructions, whole 16-byte granules.
+struct SetupHeader { uint32_t objectId, meshletId, slot, V, T, dataOffset, vertexBase, matFlags; };
+
+template <typename T>
+__device__ __forceinline__ T scalar_load(const T* ptr)
+{
+    // uniform address, data written by an earlier kernel: the scalar cache is coherent at kernel boundaries
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(ptr));
+}
+
+// tri_setup without the division: false when the triangle is rejected (zero area, back face after snapping, empty bbox)
+__device__ __forceinline__ bool tri_setup_geom(TriSetup& ts, bool twoSided, int32_t Wi, int32_t Hi, bool& small)
+{
+    const int32_t dx1 = ts.X[1] - ts.X[0], dy1 = ts.Y[1] - ts.Y[0], dx2 = ts.X[2] - ts.X[0], dy2 = ts.Y[2] - ts.Y[0];
+    int64_t area2;
+    small = (uint32_t)(dx1 + 32767) < 65535u && (uint32_t)(dy1 + 32767) < 65535u &&
+            (uint32_t)(dx2 + 32767) < 65535u && (uint32_t)(dy2 + 32767) < 65535u;
+    if (small) area2 = (int64_t)(__mul24(dx1, dy2) - __mul24(dx2, dy1));
+    else area2 = (int64_t)dx1 * (int64_t)dy2 - (int64_t)dx2 * (int64_t)dy1;
+    if (area2 == 0) return false;
+    if (!twoSided && area2 > 0) return false;
+    ts.s = area2 < 0 ? -1 : 1;
+    ts.area = area2 < 0 ? -area2 : area2;
+    const int32_t minX = min(ts.X[0], min(ts.X[1], ts.X[2])), maxX = max(ts.X[0], max(ts.X[1], ts.X[2]));
+    const int32_t minY = min(ts.Y[0], min(ts.Y[1], ts.Y[2])), maxY = max(ts.Y[0], max(ts.Y[1], ts.Y[2]));
+    ts.px0 = max(0, (minX + 127) >> 8);
+    ts.py0 = max(0, (minY + 127) >> 8);
+    ts.px1 = min(Wi - 1, (maxX - 128) >> 8);
+    ts.py1 = min(Hi - 1, (maxY - 128) >> 8);
+    return !(ts.px1 < ts.px0 || ts.py1 < ts.py0);
+}
+
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// classification of one triangle of the cluster in LDS: kind, and for K_EMIT its pixel bounds (x0 | x1 << 16, y0 | y1 << 16)
+// and whether it is narrow (fits_compact).  The same culls and the same integers as cluster_records / raster_setup_body.
+__device__ __forceinline__ int classify_triangle(const RasterParams& p, uint32_t t, uint32_t T, uint32_t packedIdx, bool twoSided, bool allFast,
+                                                 const float* lX, const float* lY, const float* lW, const float* lU, const float* lV, const float* lD,
+                                                 uint32_t& boxX, uint32_t& boxY, bool& narrow)
+{
+    boxX = 0u; boxY = 0u; narrow = false;
+    if (t >= T) return K_NONE;
+    const uint32_t i0 = packedIdx & 0xFFu, i1 = (packedIdx >> 8) & 0xFFu, i2 = (packedIdx >> 16) & 0xFFu;
+    const float w0 = lW[i0], w1 = lW[i1], w2 = lW[i2];
+    bool culled = false;
+    if (!twoSided) {                                                  // #0 mesh_raster.hlsl:143-149
+        const float x0 = lX[i0], y0 = lY[i0], x1 = lX[i1], y1 = lY[i1], x2 = lX[i2], y2 = lY[i2];
+        const float det = (x0 * (y1 * w2 - w1 * y2) - y0 * (x1 * w2 - w1 * x2)) + w0 * (x1 * y2 - y1 * x2);
+        culled = det <= 0.0f;
+    }
+    culled = culled || (w0 <= 0.0f && w1 <= 0.0f && w2 <= 0.0f);     // #1 :152-155
+    const float u0 = lU[i0], v0 = lV[i0], u1 = lU[i1], v1 = lV[i1], u2 = lU[i2], v2 = lV[i2];
+    const float maxU = fmaxf(u0, fmaxf(u1, u2)), maxV = fmaxf(v0, fmaxf(v1, v2));
+    const float minU = fminf(u0, fminf(u1, u2)), minV = fminf(v0, fminf(v1, v2));
+    culled = culled || ((minU >= 1.0f || minV >= 1.0f) || (maxU <= 0.0f || maxV <= 0.0f));   // #2 :168-171
+    culled = culled || (rintf(minU * p.W) == rintf(maxU * p.W) || rintf(minV * p.H) == rintf(maxV * p.H)); // #3 :174-179
+    if (culled) return K_NONE;
+    if (!allFast) { const float d0 = lD[i0], d1 = lD[i1], d2 = lD[i2]; if (d0 != d0 || d1 != d1 || d2 != d2) return K_CLIP; }
+    TriSetup ts;
+    ts.X[0] = (int32_t)rintf((u0 * p.W) * 256.0f); ts.Y[0] = (int32_t)rintf((v0 * p.H) * 256.0f);
+    ts.X[1] = (int32_t)rintf((u1 * p.W) * 256.0f); ts.Y[1] = (int32_t)rintf((v1 * p.H) * 256.0f);
+    ts.X[2] = (int32_t)rintf((u2 * p.W) * 256.0f); ts.Y[2] = (int32_t)rintf((v2 * p.H) * 256.0f);
+    bool small;
+    if (!tri_setup_geom(ts, twoSided, p.Wi, p.Hi, small) || !owns_any_row(p.shard, ts.py0, ts.py1)) return K_NONE;
+    boxX = (uint32_t)ts.px0 | ((uint32_t)ts.px1 << 16); boxY = (uint32_t)ts.py0 | ((uint32_t)ts.py1 << 16);
+    narrow = narrow_extent(ts);
+    return K_EMIT;
+}
+
+// set-up of an emitted, narrow triangle again from LDS and its scan conversion into the wave's pixel window
+__device__ __forceinline__ void resolve_triangle(const RasterParams& p, uint32_t t, uint32_t slot, uint32_t packedIdx, bool twoSided,
+                                                 const float* lU, const float* lV, const float* lD, unsigned long long* win,
+                                                 int32_t bx0, int32_t by0, unsigned long long rowMaskW)
+{
+    const uint32_t i0 = packedIdx & 0xFFu, i1 = (packedIdx >> 8) & 0xFFu, i2 = (packedIdx >> 16) & 0xFFu;
+    TriSetup ts;
+    ts.X[0] = (int32_t)rintf((lU[i0] * p.W) * 256.0f); ts.Y[0] = (int32_t)rintf((lV[i0] * p.H) * 256.0f);
+    ts.X[1] = (int32_t)rintf((lU[i1] * p.W) * 256.0f); ts.Y[1] = (int32_t)rintf((lV[i1] * p.H) * 256.0f);
+    ts.X[2] = (int32_t)rintf((lU[i2] * p.W) * 256.0f); ts.Y[2] = (int32_t)rintf((lV[i2] * p.H) * 256.0f);
+    (void)tri_setup(ts, twoSided, p.Wi, p.Hi);                          // (true: the classification accepted exactly these integers)
+    float d[3] = {lD[i0], lD[i1], lD[i2]};
+    if (p.biasConst != 0.0f || p.biasSlope != 0.0f) { const float o = depth_bias(ts, d, p.biasConst, p.biasSlope); d[0] += o; d[1] += o; d[2] += o; }
+    ts.payload = p.depthOnly ? 0u : encode_triangle_instance(t, slot);
+    ts.d0 = d[0]; ts.e1 = d[1] - d[0]; ts.e2 = d[2] - d[0];
+    tile_raster_narrow<WIN>(win, ts, bx0, by0, ts.px0, ts.py0, ts.px1, ts.py1, false, rowMaskW, p.depthClamp != 0u);
+}
+
+#ifndef BLOCKS_LDS_VERTS
+#define BLOCKS_LDS_VERTS 128    // vertices per cluster the block kernel takes (larger clusters are left to the record kernel): 12 + 8 KB of LDS per workgroup
+#endif
+__device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, const uint32_t count, float (*sVert)[4][BLOCKS_LDS_VERTS], unsigned long long (*sWin)[WIN * WIN])
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float* lX = sVert[0][wave]; float* lY = sVert[1][wave]; float* lW = sVert[2][wave];
+    float* lU = sVert[3][wave]; float* lV = sVert[4][wave]; float* lD = sVert[5][wave];
+    unsigned long long* win = sWin[wave];
+    const uint32_t listShard = (blockIdx.x * 4u + wave) % CHORD_LIST_SHARDS;
+
+    auto header_at = [&](uint32_t i) -> SetupHeader {
+        const uint32_t k = __builtin_amdgcn_readfirstlane(min(i, count - 1u));
+        SetupHeader h;
+        const uint32_t* __restrict__ cw = reinterpret_cast<const uint32_t*>(p.cmds + k);
+        h.objectId = scalar_load(cw); h.meshletId = scalar_load(cw + 1); h.slot = scalar_load(cw + 2);
+        const DMeshlet* __restrict__ mm = &p.meshlets[h.meshletId];
+        const uint32_t vt = scalar_load(&mm->vertexTriangleCount);
+        h.V = vt & 0xFFu; h.T = (vt >> 8) & 0xFFu;
+        h.dataOffset = scalar_load(&mm->dataOffset);
+        h.vertexBase = scalar_load(&mm->vertexBase);
+        h.matFlags = scalar_load(&p.objStatic[h.objectId].matFlags);
+        if (CHORD_MATFLAG_ALPHA(h.matFlags) >= CHORD_ALPHA_BLEND) h.T = 0u;   // blended: in no bucket of renderMesh (mesh_raster.cpp:224)
+        return h;
+    };
+    auto mvp_of = [&](uint32_t objectId) -> Mat4 {
+        Mat4 m;
+        const float* __restrict__ mv = p.objFrame[objectId].mvp;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) m.r[r][cc] = scalar_load(mv + r * 4 + cc);
+        return m;
+    };
+    const uint32_t stride = gridDim.x * 4u;
+    uint32_t c = blockIdx.x * 4u + wave;
+    if (c >= count) return;
+    SetupHeader hdr = header_at(c);
+    SetupHeader hdrN = header_at(c + stride);
+#ifdef BLK_MVP_AHEAD
+    Mat4 mvpN = mvp_of(hdr.objectId);
+#endif
+    uint32_t t0 = 0, t1 = 0;
+    float pax, pay, paz, pbx, pby, pbz;
+    {
+        const uint32_t ia = p.meshletData[hdr.dataOffset + min(lane, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
+        const uint32_t ib = p.meshletData[hdr.dataOffset + min(lane + 64u, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
+        if (lane < hdr.T) t0 = p.meshletData[hdr.dataOffset + hdr.V + lane];
+        if (lane + 64u < hdr.T) t1 = p.meshletData[hdr.dataOffset + hdr.V + 64u + lane];
+        const float* __restrict__ pa = p.positions + (size_t)ia * 3;
+        const float* __restrict__ pb = p.positions + (size_t)ib * 3;
+        pax = pa[0]; pay = pa[1]; paz = pa[2]; pbx = pb[0]; pby = pb[1]; pbz = pb[2];
+    }
+    const bool sprof = (p.debug & DBG_SETUP_CLOCKS) != 0;
+    unsigned long long sph[5] = {0, 0, 0, 0, 0}, stp = sprof ? wall_clock64() : 0ull;
+#define SPHASE(i) do { if (sprof) { const unsigned long long tn = wall_clock64(); sph[i] += tn - stp; stp = tn; } } while (0)
+    for (; c < count; c += stride) {
+        const uint32_t V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
+        const bool twoSided = (hdr.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u || p.depthOnly != 0u;
+        const bool masked = CHORD_MATFLAG_ALPHA(hdr.matFlags) == CHORD_ALPHA_MASK;
+        if (sprof) { volatile uint32_t sink = V + T; (void)sink; }
+        SPHASE(0);
+        const bool tooBig = V > (uint32_t)BLOCKS_LDS_VERTS;                  // (wave-uniform) more vertices than the wave's LDS arrays hold
+        (void)dataOffset; (void)vertexBase;
+        // ---- vertex phase (mesh_raster.hlsl:84-105), as raster_setup_body -------------------------------------------------
+        bool notFast = false;
+        if (!tooBig) {
+#ifdef BLK_MVP_AHEAD
+            const Mat4 mvp = mvpN;
+#else
+            // (fetched here, not an iteration ahead: sixteen more scalar registers alive across the whole cluster cost more
+            // lane spills than the other resident waves cover of this one scalar-cache round trip)
+            const Mat4 mvp = mvp_of(hdr.objectId);
+#endif
+            auto vertex = [&](uint32_t i, float x, float y, float z) {
+                const f4 h = mul_mv(mvp, x, y, z, 1.0f);
+                const float aw = fabsf(h.w);
+                lX[i] = h.x; lY[i] = h.y; lW[i] = h.w;
+                lU[i] = h.x / aw * 0.5f + 0.5f;
+                lV[i] = h.y / aw * -0.5f + 0.5f;
+                const bool fast = p.depthClamp ? in_fast_volume_xy(h) : in_fast_volume(h);
+                lD[i] = fast ? h.z / h.w : __builtin_nanf("");
+                notFast = notFast || !fast;
+            };
+            if (lane < V) vertex(lane, pax, pay, paz);
+            if (lane + 64u < V) vertex(lane + 64u, pbx, pby, pbz);
+#if BLOCKS_LDS_VERTS > 128
+            for (uint32_t i = lane + 128u; i < V; i += 64u) {
+                const float* __restrict__ pp = p.positions + (size_t)(p.meshletData[dataOffset + i] + vertexBase) * 3;
+                vertex(i, pp[0], pp[1], pp[2]);
+            }
+#endif
+        }
+        const bool allFast = __ballot(notFast) == 0ull;
+        WAVE_LDS_SYNC();
+        SPHASE(1);
+        // next cluster: vertex indices and triangle words
+#ifdef BLK_MVP_AHEAD
+        mvpN = mvp_of(hdrN.objectId);
+#endif
+        const uint32_t nia = p.meshletData[hdrN.dataOffset + min(lane, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
+        const uint32_t nib = p.meshletData[hdrN.dataOffset + min(lane + 64u, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
+        const uint32_t nt0 = lane < hdrN.T ? p.meshletData[hdrN.dataOffset + hdrN.V + lane] : 0u;
+        const uint32_t nt1 = lane + 64u < hdrN.T ? p.meshletData[hdrN.dataOffset + hdrN.V + 64u + lane] : 0u;
+
+        // ---- classification: kind + pixel bounds per triangle, nothing else survives it ----------------------------------
+        uint32_t bxA, byA, bxB, byB;
+        bool nwA, nwB;
+        int kindA = classify_triangle(p, lane, tooBig ? 0u : T, t0, twoSided, allFast, lX, lY, lW, lU, lV, lD, bxA, byA, nwA);
+        int kindB = classify_triangle(p, lane + 64u, tooBig ? 0u : T, t1, twoSided, allFast, lX, lY, lW, lU, lV, lD, bxB, byB, nwB);
+        if (p.debug & DBG_NO_BIN) { kindA = K_NONE; kindB = K_NONE; }
+        SPHASE(2);
+        // next cluster: its positions (the indices have arrived behind the classification)
+        const float* __restrict__ npa = p.positions + (size_t)nia * 3;
+        const float* __restrict__ npb = p.positions + (size_t)nib * 3;
+        const float nax = npa[0], nay = npa[1], naz = npa[2], nbx = npb[0], nby = npb[1], nbz = npb[2];
+
+        const bool eA = kindA == K_EMIT, eB = kindB == K_EMIT;
+        const unsigned long long emA = __ballot(eA), emB = __ballot(eB);
+        const unsigned long long bad = __ballot(kindA == K_CLIP || kindB == K_CLIP || (eA && !nwA) || (eB && !nwB)) | (tooBig && T != 0u ? 1ull : 0ull);
+        bool blocksDone = false;
+        if (!masked && (emA | emB) != 0ull && bad == 0ull) {
+            int32_t bx0 = min(eA ? (int32_t)(bxA & 0xFFFFu) : 0x7FFF, eB ? (int32_t)(bxB & 0xFFFFu) : 0x7FFF);
+            int32_t by0 = min(eA ? (int32_t)(byA & 0xFFFFu) : 0x7FFF, eB ? (int32_t)(byB & 0xFFFFu) : 0x7FFF);
+            int32_t bx1 = max(eA ? (int32_t)(bxA >> 16) : -1, eB ? (int32_t)(bxB >> 16) : -1);
+            int32_t by1 = max(eA ? (int32_t)(byA >> 16) : -1, eB ? (int32_t)(byB >> 16) : -1);
+            if (__ballot(bx1 - bx0 >= WIN || by1 - by0 >= WIN) == 0ull) {            // (no single lane is already too wide)
+                bx0 = __builtin_amdgcn_readfirstlane(wave_min_i32(bx0)); by0 = __builtin_amdgcn_readfirstlane(wave_min_i32(by0));
+                bx1 = __builtin_amdgcn_readfirstlane(wave_max_i32(bx1)); by1 = __builtin_amdgcn_readfirstlane(wave_max_i32(by1));
+                const int32_t bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+                const uint32_t nE = (uint32_t)(__popcll(emA) + __popcll(emB));
+                if (bw <= WIN && bh <= WIN && (uint32_t)(bw * bh + 8) * 8u <= nE * 36u) {
+                    blocksDone = true;
+                    // the window's parts per tile (<= 2 x 2): lane r < 4 owns the part in tile (r & 1 ? tx1 : tx0, r & 2 ? ty1 : ty0)
+                    const int32_t tx0 = bx0 >> TILE_SHIFT, tx1 = bx1 >> TILE_SHIFT, ty0 = by0 >> TILE_SHIFT, ty1 = by1 >> TILE_SHIFT;
+                    const uint32_t r = lane & 3u;
+                    const bool sx = (r & 1u) != 0u, sy = (r & 2u) != 0u;
+                    const int32_t rx0 = sx ? tx1 << TILE_SHIFT : bx0, rx1 = (sx || tx1 == tx0) ? bx1 : (tx0 << TILE_SHIFT) + TILE - 1;
+                    const int32_t ry0 = sy ? ty1 << TILE_SHIFT : by0, ry1 = (sy || ty1 == ty0) ? by1 : (ty0 << TILE_SHIFT) + TILE - 1;
+                    const uint32_t rw = (uint32_t)(rx1 - rx0 + 1), rh = (uint32_t)(ry1 - ry0 + 1);
+                    const bool has = lane < 4u && !(sx && tx1 == tx0) && !(sy && ty1 == ty0) && owns_any_row(p.shard, ry0, ry1);
+                    const uint32_t hasMask = (uint32_t)__ballot(has) & 15u;
+                    const uint32_t gran = has ? (rw * rh + 2u) >> 1 : 0u;              // header + w x h words, in 16-byte granules
+                    const uint32_t g0 = bcast(gran, 0), g1 = bcast(gran, 1), g2 = bcast(gran, 2), g3 = bcast(gran, 3);
+                    const uint32_t before = (r > 0u ? g0 : 0u) + (r > 1u ? g1 : 0u) + (r > 2u ? g2 : 0u), G = g0 + g1 + g2 + g3;
+                    const uint32_t tile = (uint32_t)(sy ? ty1 : ty0) * p.tilesX + (uint32_t)(sx ? tx1 : tx0);
+                    // one round trip: pool space (lane 0) and, per touched tile, ONE 64-bit add on the tile's counter pair
+                    // (low word: bin slot, high word: the tile's block count) ...
+                    uint32_t gbase = 0, slot = 0;
+                    if (lane == 0u && G) gbase = atomicAdd(&p.counters->blockGranules[listShard * CHORD_SHARD_STRIDE], G);
+                    if (has) slot = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&p.tileCount[(size_t)tile * TC_STRIDE]), 0x100000001ull);
+                    // ... and the cluster is resolved while they are in flight
+#pragma unroll
+                    for (int k = 0; k < WIN * WIN / 64; k++) win[lane + 64u * k] = 0ull;
+                    unsigned long long rowMaskW = ~0ull;
+                    if (p.shard.ranks > 1u) {
+                        rowMaskW = 0ull;
+                        for (int32_t ly = 0; ly <= by1 - by0; ly++) if (owns_row<true>(p.shard, by0 + ly)) rowMaskW |= 1ull << ly;
+                    }
+                    WAVE_LDS_SYNC();
+                    if (eA) resolve_triangle(p, lane, hdr.slot, t0, twoSided, lU, lV, lD, win, bx0, by0, rowMaskW);
+                    __builtin_amdgcn_sched_barrier(0);                           // (one triangle's set-up alive at a time)
+                    if (eB) resolve_triangle(p, lane + 64u, hdr.slot, t1, twoSided, lU, lV, lD, win, bx0, by0, rowMaskW);
+                    WAVE_LDS_SYNC();
+                    SPHASE(3);
+                    gbase = bcast(gbase, 0);
+                    const bool fits = gbase + G <= p.blockCap;
+                    if (!fits && lane == 0u) atomicOr(&p.counters->overflow, 1u);
+                    const uint32_t off = listShard * p.blockCap + gbase + before;              // granule offset of lane r's block
+                    if (has) bin_alloc(p, tile, slot);
+                    if (has && fits) bin_put(p, tile, slot, CHORD_REC_BLOCK | off);
+                    if (fits) {
+                        for (uint32_t q = 0; q < 4u; q++) {                      // (wave-uniform: the parts that exist, one in 4 of 5 clusters)
+                            if (!((hasMask >> q) & 1u)) continue;
+                            const uint32_t qoff = bcast(off, (int)q), qw = bcast(rw, (int)q), qh = bcast(rh, (int)q);
+                            const uint32_t qx = (uint32_t)bcast(rx0 - bx0, (int)q), qy = (uint32_t)bcast(ry0 - by0, (int)q);
+                            const uint32_t qlx = (uint32_t)bcast(rx0 & (TILE - 1), (int)q), qly = (uint32_t)bcast(ry0 & (TILE - 1), (int)q);
+                            const uint32_t n = qw * qh, gq = (n + 2u) >> 1;
+                            // ceil(65536 / w), w <= 16: exact from the 1-ulp reciprocal (the quotient is an integer only for powers of two, where
+                            // the reciprocal is exact, and otherwise at least 1/16 away from one)
+                            const uint32_t rcp = (uint32_t)ceilf(65536.0f * __builtin_amdgcn_rcpf((float)qw));
+                            const unsigned long long header = (unsigned long long)(qlx | qly << 6 | (qw - 1u) << 12 | (qh - 1u) << 16) | ((unsigned long long)rcp << 32);
+                            ulonglong2* dst = reinterpret_cast<ulonglong2*>(p.blockPool + (size_t)qoff * 2u);
+                            for (uint32_t g = lane; g < gq; g += 64u) {
+                                // granule g = words 2g - 1, 2g of the block (word -1: the header)
+                                const uint32_t j1 = 2u * g, j0 = g == 0u ? 0u : j1 - 1u;
+                                const uint32_t row0 = (j0 * rcp) >> 16, row1 = (j1 * rcp) >> 16;       // exact for j < 256, w <= 16
+                                const unsigned long long w0 = g == 0u ? header : win[(qy + row0) * WIN + qx + (j0 - row0 * qw)];
+                                const unsigned long long w1 = j1 < n ? win[(qy + row1) * WIN + qx + (j1 - row1 * qw)] : 0ull;
+                                dst[g] = make_ulonglong2(w0, w1);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!blocksDone && ((emA | emB) != 0ull || bad != 0ull)) {
+            // not a block (large, clipped, masked, wide window, too few triangles for its window): the cluster goes to the
+            // record kernel that follows this one (raster_setup_kernel reads the leftover list of a dense launch)
+            if (lane == 0u) {
+                const uint32_t k = atomicAdd(p.leftCount, 1u);
+                ChordDrawCmd cmd; cmd.objectId = hdr.objectId; cmd.meshletId = hdr.meshletId; cmd.slot = hdr.slot;
+                p.leftCmds[k] = cmd;                                      // (capacity = the input list's: never full)
+            }
+            SPHASE(3);
+        }
+        // LDS of this wave is rewritten by the next cluster: order the reads above before those writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        hdr = hdrN;
+        hdrN = header_at(c + 2u * stride);
+        t0 = nt0; t1 = nt1;
+        pax = nax; pay = nay; paz = naz; pbx = nbx; pby = nby; pbz = nbz;
+        SPHASE(4);
+    }
+    if (sprof && lane == 0u) {
+        const uint32_t w = blockIdx.x * 4u + wave;
+        if (w < CHORD_MAX_TILES * 8u / 5u) for (int i = 0; i < 5; i++) p.tilePhase[(size_t)w * 5u + i] = sph[i];
+    }
+#undef SPHASE
+}
+
+// Which clusters a launch of the record kernel sets up.  Pixel blocks pay when clusters are small, and then there are many of
+// them: a launch is DENSE when its clusters have fewer than 16 pixels of this rank's screen each on average (BASELINE config
+// 5: one pixel per cluster; config 4: 32; config 3: 2 000).  A dense launch runs raster_setup_blocks_kernel first, which turns
+// every cluster it can into pixel blocks and leaves the others in the leftover list; the record kernel then sets up the
+// leftover list instead of the input list.  Either way the image is the same.  (Both kernels evaluate this from the same
+// device-side count; the host only knows whether a list COULD be dense, from its capacity, and skips the block kernel
+// when it cannot.)
+__device__ __forceinline__ bool launch_is_dense(const RasterParams& p, uint32_t count)
+{
+    const unsigned long long pixels = (unsigned long long)p.Wi * (unsigned long long)p.Hi / (p.shard.ranks > 1u ? p.shard.ranks : 1u);
+    return p.blockCap != 0u && p.leftCmds != nullptr && (p.blockForce != 0u || (unsigned long long)count * 16ull >= pixels);
+}
+
+#ifndef SETUP_MIN_WAVES
+#define SETUP_MIN_WAVES 4       // waves per SIMD the register allocation of the record kernel aims at
+#endif
+#ifndef BLOCKS_MIN_WAVES
+#define BLOCKS_MIN_WAVES 6      // ... of the block kernel (80 VGPRs, 20 KB of LDS per 256 threads, 106 SGPRs: 6 workgroups per CU)
+#endif
 // MASKED: the scene has alpha-tested materials (their clusters emit 48-byte records with a texture-coordinate extension);
 // scenes without any -- every benchmark configuration -- run the instantiation that knows nothing of them.
 template <bool MASKED>
-__global__ __launch_bounds__(256, 4) void raster_setup_kernel(RasterParams p)
+__global__ __launch_bounds__(256, SETUP_MIN_WAVES) void raster_setup_kernel(RasterParams p)
 {
     __shared__ float sVert[6][4][LDS_VERTS];                   // x, y, w, u, v, depth of a wave's cluster (24 KB)
+    uint32_t count = *p.count;
+    if (launch_is_dense(p, count)) { count = *p.leftCount; p.cmds = p.leftCmds; }
+    raster_setup_body<MASKED>(p, count, sVert);
+}
+
+__global__ __launch_bounds__(256, BLOCKS_MIN_WAVES) void raster_setup_blocks_kernel(RasterParams p)
+{
+    __shared__ float sVert[6][4][BLOCKS_LDS_VERTS];            // x, y, w, u, v, depth of a wave's cluster (12 KB)
     __shared__ unsigned long long sWin[4][WIN * WIN];          // a small cluster's pixel window (8 KB)
     const uint32_t count = *p.count;
-    // Pixel blocks pay when clusters are small, and then there are many of them: the launch takes the BLOCKS body when
-    // its clusters have fewer than 16 pixels of this rank's screen each on average (BASELINE config 5: one pixel per
-    // cluster; config 4: 32; config 3: 2 000).  Either body produces the same image.
-    const unsigned long long pixels = (unsigned long long)p.Wi * (unsigned long long)p.Hi / (p.shard.ranks > 1u ? p.shard.ranks : 1u);
-    if (p.blockCap != 0u && (p.blockForce != 0u || (unsigned long long)count * 16ull >= pixels)) raster_setup_body<MASKED, true>(p, count, sVert, sWin);
-    else raster_setup_body<MASKED, false>(p, count, sVert, sWin);
+    if (!launch_is_dense(p, count)) return;
+    raster_setup_blocks_body(p, count, sVert, sWin);
 }
 
 // One lane bins one record into every tile its clamped bbox may touch (conservative edge test at the tile
@@ -966,7 +1216,7 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
     const uint32_t listShard = (block * 4u + (threadIdx.x >> 6)) % CHORD_LIST_SHARDS;
     for (uint32_t k = block * 256u + threadIdx.x; k < n; k += blocks * 256u) {
         const ClipTri ct = p.clipTris[k];
-        const ChordDrawCmd cmd = p.cmds[ct.cmdIndex];
+        ChordDrawCmd cmd; cmd.objectId = ct.objectId; cmd.meshletId = ct.meshletId; cmd.slot = ct.slot;
         const DMeshlet& m = p.meshlets[cmd.meshletId];
         const uint32_t V = m.vertexTriangleCount & 0xFFu;
         const uint32_t matFlags = p.objStatic[cmd.objectId].matFlags;
@@ -1854,7 +2104,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     };
     // ---- pixel blocks of small clusters first: their own pass over the item's entries (nothing of the triangle
     //      pipeline below is live here; tiles without blocks -- word 2 of the tile's counter line -- skip it) ----------
-    if (p.blockCap != 0u && !noPixels && p.tileCount[(size_t)tileId * TC_STRIDE + 2u] != 0u) {
+    if (p.blockCap != 0u && !noPixels && p.tileCount[(size_t)tileId * TC_STRIDE + TC_BLOCKS] != 0u) {
         const uint32_t blockLimit = p.blockCap * CHORD_LIST_SHARDS;
         uint32_t giNext = lo + threadIdx.x < n ? binWord(lo + threadIdx.x) : 0xFFFFFFFFu;
         for (uint32_t base = lo; base < n; base += TB) {
@@ -1980,7 +2230,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     //      draws its ticket after every one of its atomics has returned, so no cache-wide release/acquire is
     //      needed (an agent-scope fence writes back the whole L2 of the XCD: measured 2x slower here). ----------
     if (mergeSlices) {
-        if (!merge_slices(tile, p.tileSlabs + (size_t)tileId * (TILE * TILE), &p.tileCount[(size_t)tileId * TC_STRIDE + 1u],
+        if (!merge_slices(tile, p.tileSlabs + (size_t)tileId * (TILE * TILE), &p.tileCount[(size_t)tileId * TC_STRIDE + TC_TICKET],
                           slices, &sTicket, &p.counters->overflow)) continue;   // not the last slice: done
         if (rmw) {
             for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
@@ -2100,12 +2350,26 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
                            LR_HIP(hipMemsetAsync(c->dCounters->blockGranules, 0, sizeof(c->dCounters->blockGranules), c->stream)); }
     }
 
+    // Pixel blocks: a list can only be dense (launch_is_dense) when its capacity allows one cluster per 16 pixels of the rank's
+    // screen; then the block kernel runs ahead of the record kernel, which sets up what the block kernel left over.
+    const uint64_t rankPixels = (uint64_t)c->width * c->height / (c->shard.ranks > 1 ? c->shard.ranks : 1u);
+    const bool maybeDense = p.blockCap != 0u && (p.blockForce != 0u || (uint64_t)in.capacity * 16ull >= rankPixels);
+    p.leftCount = nullptr; p.leftCmds = nullptr;
+    if (maybeDense) {
+        if (!c->dLeftCmds) LR_HIP(hipMalloc((void**)&c->dLeftCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity));
+        p.leftCount = c->dCounts + 6 + pass; p.leftCmds = c->dLeftCmds;
+        if (!c->inFrame || c->rasterCalls >= 2) LR_HIP(hipMemsetAsync(p.leftCount, 0, sizeof(uint32_t), c->stream));
+    }
     uint32_t blocks = (in.capacity + 3u) / 4u;
-    const uint32_t maxBlocks = (uint32_t)c->numCUs * 4u;    // what is resident at 4 waves per SIMD
+    const uint32_t maxBlocks = (uint32_t)c->numCUs * SETUP_MIN_WAVES;    // what is resident at SETUP_MIN_WAVES waves per SIMD
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
     const bool sh = c->shard.ranks > 1;
     stamp(c, S_HZBCULL);      // closes whatever preceded the raster (HZB cull / list reset)
+    if (maybeDense) {
+        const uint32_t bb = std::max(1u, std::min((in.capacity + 3u) / 4u, (uint32_t)c->numCUs * BLOCKS_MIN_WAVES));
+        hipLaunchKernelGGL(raster_setup_blocks_kernel, dim3(bb), dim3(256), 0, c->stream, p);
+    }
     if (c->anyMasked) hipLaunchKernelGGL(raster_setup_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p);
     else              hipLaunchKernelGGL(raster_setup_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p);
     stamp(c, S_R_CLUSTER);

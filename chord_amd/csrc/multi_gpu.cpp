@@ -65,7 +65,11 @@ const Rccl* rccl()
             h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
             if (h) { origin = std::string(n) + (pass == 0 ? " (already loaded)" : ""); break; }
         }
-    if (!h) { gRcclError = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return nullptr; }
+    if (!h) {
+        const char* e = dlerror();                                // (one call: dlerror() clears the message it returns)
+        gRcclError = std::string("librccl.so not found: ") + (e ? e : "");
+        return nullptr;
+    }
     Rccl r;
     r.handle = h; r.origin = origin;
 #define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name))
@@ -167,26 +171,31 @@ int chordvis_comm_info(ChordCtx* c, int* ncclVersion, uint32_t* nranks, char* li
 namespace chord {
 
 // The sharded frame of a context with a communicator: everything on the context's stream, no host synchronisation.
+// A rank whose phase fails (a capacity or HIP error on that rank only) still issues BOTH collectives: its peers are already
+// inside them on their streams and would wait forever otherwise.  Whether the mid-frame exchange happens is decided before
+// phase a from state every rank shares (frame history + flags), like the ChordGroup path; the first error is returned after
+// the last collective.
 int comm_render_frame(ChordCtx* c)
 {
     const Rccl* r = rccl();
     if (!r || !c->comm) return fail(c, CHORDVIS_E_COMM, "render_frame: sharded context without a communicator (chordvis_comm_init_rank, or drive chordvis_frame_phase_a/b/c)");
-    int rc;
-    if ((rc = chordvis_frame_phase_a(c))) return rc;
-    if (c->shouldStage1) {
+    const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
+    int rc = chordvis_frame_phase_a(c);
+    if (stage1) {
         // RCCL has no 16-bit integer type; the payload is opaque f16 bits
         const size_t bytes = (size_t)c->hzbExchangeChunkHalves * 2;
         char* base = reinterpret_cast<char*>(c->dHzbExchange);
         const int e = r->AllGather(base + (size_t)c->shard.rank * bytes, base, bytes, kNcclUint8, (NcclComm)c->comm, c->stream);
-        if (e != kNcclSuccess) return nccl_fail(c, r, "ncclAllGather(hzb mip 0)", e);
+        if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(hzb mip 0)", e);
     }
-    if ((rc = chordvis_frame_phase_b(c))) return rc;
+    if (!rc) rc = chordvis_frame_phase_b(c);
     {
         const size_t words = (size_t)(c->visWords / c->shard.ranks);
         const int e = r->AllGather(c->dVis + (size_t)c->shard.rank * words, c->dVis, words, kNcclUint64, (NcclComm)c->comm, c->stream);
-        if (e != kNcclSuccess) return nccl_fail(c, r, "ncclAllGather(visibility)", e);
+        if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(visibility)", e);
     }
-    return chordvis_frame_phase_c(c);
+    if (!rc) rc = chordvis_frame_phase_c(c);
+    return rc;
 }
 
 } // namespace chord

@@ -5,10 +5,14 @@
 // border locked, split into the next level's meshlets, hand the simplification error up as the children's parentError)
 // -> buildBVHTree (:313-416); packing as asset_gltf_helper.cpp:496-548.  Host code, offline, no device involved.
 //
-// The reference delegates three steps to third-party code that is not restated from its source here:
-//   meshopt_buildMeshlets / meshopt_computeMeshletBounds (vendored meshoptimizer 0.21)  -> clusterize() / meshlet_bounds():
-//       greedy growth over triangle adjacency; bounds and the normal cone as meshoptimizer DOCUMENTS them (axis = mean normal,
-//       cutoff from the widest deviation, apex pushed back along the axis until every triangle's plane is in front)
+// The reference delegates three steps to third-party code:
+//   meshopt_buildMeshlets (vendored meshoptimizer 0.21, MIT)  -> clusterize(): own greedy growth over triangle adjacency
+//   meshopt_computeMeshletBounds (same library, meshopt_clusterizer.cpp:792-845) -> meshlet_bounds(): the cone part FOLLOWS
+//       that function (credit: meshoptimizer, (c) Arseny Kapoulkine, MIT licence) -- the `mindp <= 0.1` cut, cutoff =
+//       sqrt(1 - mindp^2) and apex = center - axis * max(dc / dn) are its formulas and its names; simplified here: the axis is
+//       the normalised MEAN normal (meshoptimizer fits a bounding sphere of the normals) and the centre is the AABB's (it uses
+//       the bounding sphere's).  tests/test_nanite_builder.py checks the result against fixtures produced by the vendored
+//       function itself (tests/golden/meshopt_bounds.json): never less conservative, and within a stated angle of it
 //   METIS_PartGraphKway (binary-only in the reference tree, version not recorded)          -> partition_groups(): greedy
 //       graph growing by shared-edge weight into parts of min(n / 2, 4) meshlets
 //   meshopt_simplifyWithAttributes (LockBorder | Sparse | ErrorAbsolute)                   -> simplify(): half-edge collapses

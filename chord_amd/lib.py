@@ -158,6 +158,7 @@ def _load():
         "chordvis_upload_history_hzb": (i32, [vp, vp]),
         "chordvis_set_limits": (i32, [vp, P(Limits)]),
         "chordvis_visibility_mark": (i32, [vp, CountAndCmd, P(TileMarker)]),
+        "chordvis_wait_visibility": (i32, [vp, vp]),
         "chordvis_prepare_shading_tile_param": (i32, [vp, u32, P(TileMarker), P(ShadingTiles)]),
         "chordvis_readback_tile_marker": (i32, [vp, P(TileMarker), vp]),
         "chordvis_readback_shading_tiles": (i32, [vp, P(ShadingTiles), vp, u32, P(u32), vp]),

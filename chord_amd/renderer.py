@@ -230,6 +230,10 @@ class VisibilityRenderer:
         self._check(L.lib.chordvis_visibility_mark(self._ctx, cmd, C.byref(out)), "visibility_mark")
         return out
 
+    def wait_visibility(self, stream=None):
+        """Orders `stream` (default: the context's) behind the completion of the last frame's resolved image."""
+        self._check(L.lib.chordvis_wait_visibility(self._ctx, stream), "wait_visibility")
+
     def prepare_shading_tile_param(self, shading_type, marker):
         """prepareShadingTileParam (visibility_tile.cpp:59-110)."""
         out = L.ShadingTiles()

@@ -56,10 +56,12 @@ typedef struct ChordHZB {
 } ChordHZB;
 
 /* Work-list capacities (the counterpart of the reference's pool sizes); zero fields keep the default.  Call before
- * chordvis_upload_scene / chordvis_allocate_gbuffer.  Defaults fit BASELINE configs 1-4; config 5 (1 G sub-pixel
- * triangles in one pass) needs ~1.1 G records and ~1.1 M pool chunks per pass. */
+ * chordvis_upload_scene / chordvis_allocate_gbuffer.  The record lists are sized FROM THE SCENE at upload
+ * (2 x its instanced triangles + 256 Ki, chordvis_abi.cpp alloc_scene_work_buffers) and capped by these limits; the default
+ * caps fit BASELINE configs 1-4 and config 5 with pixel blocks; config 5 in the record form (1 G sub-pixel triangles in one
+ * pass, debug only) needs ~1.1 G records and ~1.1 M pool chunks per pass. */
 typedef struct ChordLimits {
-    uint64_t maxTriangleRecords;   /* 48 B each, per frame; default 64 Mi */
+    uint64_t maxTriangleRecords;   /* upper bound of the 32-byte record list (the 48-byte list gets a quarter, at least 1 Mi); default cap 64 Mi */
     uint32_t binPoolChunks;        /* 1024-entry overflow chunks per raster pass; default 32 Ki */
     uint32_t binMaxChunksPerTile;  /* default 240, at most 3072 */
 } ChordLimits;
@@ -293,7 +295,8 @@ uint64_t* chordvis_resolved_visibility_ptr(ChordCtx* ctx);
  * frame -- own-stripe HZB mip 0 between the raster passes, own-stripe visibility words at the end -- are issued by the library,
  * so the host keeps ONE call per frame, like DeferredRenderer::render (renderer.cpp:319-345). */
 
-/* even stripe height in [32, 96] with the least padding for `ranks` ranks */
+/* even stripe height in [32, 256]: the tallest that leaves every rank at least two stripes, weighing the padding of the last
+ * stripe against the share of clusters that straddle two stripes (multi_gpu.cpp: it minimises padding / height + 18 / rows) */
 uint32_t chordvis_pick_stripe_rows(uint32_t height, uint32_t ranks);
 
 /* (a) one process per GPU (torch.distributed / MPI hosts): attach an RCCL communicator to a sharded context; from then on
@@ -384,6 +387,11 @@ int chordvis_history_hzb(ChordCtx* ctx, ChordHZB* out);
  * the (resolved, row-major) visibility buffer, which material shading types occur.  drawedMeshletCmd = the list
  * the visibility ids index, i.e. chordvis_last_frame_cmds (renderer.cpp:354,359). */
 int chordvis_visibility_mark(ChordCtx* ctx, ChordCountAndCmd drawedMeshletCmd, ChordTileMarker* out);
+/* Consumers that read chordvis_resolved_visibility_ptr() on a stream of their own (lighting.hlsl:318-329 is the reference's):
+ * orders `hipStream` (NULL: the context's) behind the completion of the last submitted frame's image.  After pipelined
+ * ChordGroup frames the image is gathered beside the context's stream, so this -- or one of the library's own consumers /
+ * read-backs, which wait by themselves -- must come before the first read. */
+int chordvis_wait_visibility(ChordCtx* ctx, void* hipStream);
 /* prepareShadingTileParam — visibility_tile.cpp:59-110 (tilePrepareCS + prepareTileParamCS, visibility_tile.hlsl:136-219) */
 int chordvis_prepare_shading_tile_param(ChordCtx* ctx, uint32_t shadingType, const ChordTileMarker* marker, ChordShadingTiles* out);
 
