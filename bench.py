@@ -9,11 +9,15 @@ apart so that every frame culls against the HZB of a *different* previous frame 
 
   N = 1   workload "street_4k_hzb"  BASELINE config 3 (Bistro-class, 3840x2160, two-pass HZB)
   N > 1   workload "subpixel_1g"    BASELINE config 5 (1.07 G sub-pixel triangles per frame), rows sharded in
-          interleaved stripes across the ranks, HZB mip 0 (two-pass workloads) + visibility reassembled with RCCL
-          all-gathers issued by the library itself (chordvis_comm_init_rank: --exchange lib) or by torch.distributed
-          on the context's stream (--exchange torch); every N > 1 line carries the same workload rendered unsharded on
-          rank 0's GPU (single_gpu_same_workload) and speedup_vs_single.  --workload overrides either default, so the
-          N = 1 point of any curve can be re-run on the N > 1 workload.
+          interleaved stripes across the ranks, HZB mip 0 (two-pass workloads) + visibility reassembled with all-gathers
+          issued by the library itself over RCCL (chordvis_comm_init_rank: --exchange lib), by torch.distributed on the
+          context's stream (--exchange torch), or by ONE process driving all N devices with peer copies (ChordGroup:
+          --exchange group).  `auto` tries them in that order, so a node whose RCCL does not come up still yields a curve;
+          the line says which one ran (`exchange`) and why the others did not (`exchange_fallbacks`).  The control plane
+          (barriers, the communicator id, the max over ranks) is a gloo group: it does not depend on RCCL.  Every N > 1
+          line carries the same workload rendered unsharded on rank 0's GPU (single_gpu_same_workload, speedup_vs_single)
+          and, per rank, the GPU time of every phase and exchange of the frame (`phases_ms`).  --workload overrides either
+          default, so the N = 1 point of any curve can be re-run on the N > 1 workload.
   `python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one process per GPU).
 
 value = triangles of the clusters submitted to the rasterizer per frame (post-cull, the unit of
@@ -51,6 +55,10 @@ def build_workload(name):
         return scenes.config5_subpixel(3840, 2160)
     if name == "subpixel_64m":           # the same at 1/16 size (64 Ki patches x 8): fits the default work-list limits
         return scenes.config5_subpixel(3840, 2160, prims=64)
+    if name == "subpixel_1g_hotspot":    # config 5, variant "hotspot" (SURVEY 8d): the same 1.07 G triangles, centres Gaussian (sigma 64 px) around the screen centre
+        return scenes.config5_subpixel(3840, 2160, hotspot_sigma_px=64.0)
+    if name == "subpixel_64m_hotspot":
+        return scenes.config5_subpixel(3840, 2160, prims=64, hotspot_sigma_px=64.0)
     if name == "street_720p_hzb":        # config 3 at 1280x720: the small two-pass workload of the N > 1 protocol tests
         return scenes.config3_street(1280, 720)
     if name == "atrium_1080p":
@@ -64,8 +72,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="auto", help="street_4k_hzb | street_x64_4k_hzb | street_x16_4k_hzb | subpixel_1g | subpixel_64m | atrium_1080p")
-    ap.add_argument("--exchange", default="auto", choices=("auto", "lib", "torch"),
-                    help="N > 1: who issues the all-gathers -- the library (RCCL communicator on the context) or torch.distributed")
+    ap.add_argument("--exchange", default="auto", choices=("auto", "lib", "torch", "group"),
+                    help="N > 1: who issues the all-gathers -- the library over RCCL, torch.distributed, or one process with N devices (ChordGroup, peer copies); auto = the first that works")
     ap.add_argument("--cpu-baseline-frames", type=int, default=48, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
     ap.add_argument("--cull", default="flat", choices=("flat", "hierarchical"),
                     help="instanceCulling: the reference's flat group dispatch, or the BVH walk (same command list)")
@@ -89,10 +97,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
+        # control plane on gloo (CPU): barriers, the communicator id and the max over ranks work whatever state RCCL is in
+        dist.init_process_group(backend="gloo")
     # Every kernel of the path AND every collective of the frame is enqueued on ONE explicit stream.  (PyTorch's
     # default stream has handle 0; handed to chordvis_create that reads as "no stream given" and the context would run
     # on a private non-blocking stream that nothing orders against the collectives.)
@@ -130,7 +136,7 @@ def main():
 
     assert stream.cuda_stream != 0
     r = VisibilityRenderer(local_rank, stream.cuda_stream)
-    if wl == "subpixel_1g":              # ~1 G records of 48 B and as many bin entries in one pass (a rank holds 1/N of them)
+    if wl.startswith("subpixel_1g"):     # ~1 G records of 48 B and as many bin entries in one pass (a rank holds 1/N of them)
         share = max(1, world // 2) if world > 1 else 1
         r.set_limits(max_triangle_records=(1152 << 20) // share, bin_pool_chunks=(1200 << 10) // share, bin_max_chunks_per_tile=2048)
     if args.cull == "hierarchical":
@@ -148,46 +154,81 @@ def main():
 
     # ---- who issues the two all-gathers of a sharded frame -------------------------------------------------------
     #   lib    the library (RCCL communicator attached to the context: ONE call per frame, like the reference's host)
-    #   torch  torch.distributed on the context's stream between chordvis_frame_phase_a/b/c
+    #   torch  torch.distributed (an NCCL group) on the context's stream between chordvis_frame_phase_a/b/c
+    #   group  ONE process (rank 0) drives all N devices through ChordGroup: peer copies, no RCCL at all
     exchange = "none"
     comm = None
+    fallbacks = []
+    nccl_pg = None
+
+    def all_agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def try_lib():
+        nonlocal comm
+        from chord_amd.renderer import comm_unique_id
+        uid, err = [None], None
+        if rank == 0:
+            try:
+                uid[0] = comm_unique_id()
+            except Exception as e:                       # noqa: BLE001  (no librccl: every rank falls back together)
+                err = "comm_unique_id: %s" % e
+        dist.broadcast_object_list(uid, src=0)
+        ok = uid[0] is not None
+        if ok:
+            try:
+                r.comm_init_rank(world, rank, uid[0])
+                comm = r.comm_info()
+            except Exception as e:                       # noqa: BLE001
+                ok, err = False, "rank %d comm_init_rank: %s" % (rank, e)
+        if not all_agree(ok):
+            if ok:
+                r.comm_destroy()
+            return err or "another rank could not attach its communicator"
+        return None
+
+    def try_torch():
+        nonlocal nccl_pg
+        if backend != "nccl":
+            return None                                  # test hook: gloo, host-staged
+        ok, err = True, None
+        try:
+            nccl_pg = dist.new_group(backend="nccl")
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe, group=nccl_pg)
+            torch.cuda.synchronize(dev)
+            ok = float(probe.item()) == float(world)
+        except Exception as e:                           # noqa: BLE001
+            ok, err = False, "rank %d nccl group: %s" % (rank, e)
+        if not all_agree(ok):
+            return err or "another rank's NCCL group failed"
+        return None
+
+    group = None
     if world > 1:
-        want = args.exchange if backend == "nccl" else "torch"
-        if want in ("auto", "lib"):
-            ok = 1
-            from chord_amd.renderer import comm_unique_id
-            uid = [None]
+        order = {"auto": ["lib", "torch", "group"], "lib": ["lib"], "torch": ["torch"], "group": ["group"]}[args.exchange]
+        if backend != "nccl":
+            order = [m for m in order if m != "lib"] or ["torch"]      # (test hook: no RCCL ranks on one device)
+        for mode in order:
+            why = try_lib() if mode == "lib" else try_torch() if mode == "torch" else None
+            if why is None:
+                exchange = mode
+                break
+            fallbacks.append({mode: why})
             if rank == 0:
-                try:
-                    uid[0] = comm_unique_id()
-                except Exception as e:                   # noqa: BLE001  (no librccl: every rank falls back together)
-                    print("[bench] library-owned RCCL exchange unavailable (%s); using torch.distributed" % e, file=sys.stderr)
-            dist.broadcast_object_list(uid, src=0)
-            if uid[0] is None:
-                ok = 0
-            else:
-                try:
-                    r.comm_init_rank(world, rank, uid[0])
-                    comm = r.comm_info()
-                except Exception as e:                   # noqa: BLE001
-                    ok = 0
-                    print("[bench] rank %d: chordvis_comm_init_rank failed (%s); using torch.distributed" % (rank, e), file=sys.stderr)
-            if want == "lib" and not ok:
-                raise SystemExit("--exchange lib: the library-owned RCCL communicator could not be set up")
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                exchange = "lib"
-            else:
-                if ok:
-                    r.comm_destroy()
-                exchange = "torch"
-        else:
-            exchange = "torch"
+                print("[bench] exchange %r unavailable (%s)" % (mode, why), file=sys.stderr)
+        if exchange == "none":
+            raise SystemExit("--exchange %s: no exchange could be set up: %r" % (args.exchange, fallbacks))
+    if exchange == "group":
+        r.close()                                        # (the group makes its own contexts, one per device)
+        del vis_t
+        return run_group(args, wl, scene, views, (obj_a, obj_b), flags, W, H, world, rank, dev, stream, fallbacks)
 
     def all_gather(full, mine):
         if backend == "nccl":
-            dist.all_gather_into_tensor(full, mine)      # ordered on the current stream (= the context's)
+            dist.all_gather_into_tensor(full, mine, group=nccl_pg)      # ordered on the current stream (= the context's)
         else:                                            # test hook (gloo has no device all-gather): staged through the host
             torch.cuda.current_stream(dev).synchronize()
             parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
@@ -250,13 +291,11 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     st = r.stats()                                  # per-frame GPU timestamps averaged over the timed steps
+    rank_elapsed = elapsed
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    tris_total = tris_per_pair * (args.steps // 2) + (per_view[0]["trianglesSubmitted"] if args.steps & 1 else 0)
-    value = tris_total / elapsed / 1e9
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, inside the timed region)
@@ -289,9 +328,11 @@ def main():
     # HBM traffic of that kernel from the PMC counters: they need their own rocprofv3 passes, so the figure comes from
     # the committed summary of those passes over this same command (profiles/, tools/profile.sh), per launch
     traffic, traffic_src = None, None
-    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                      {"street_4k_hzb": "r02_config3_4k_hzb_traffic.json", "street_x64_4k_hzb": "r02_config4_x64_4k_hzb_traffic.json",
-                       "subpixel_1g": "r02_config5_subpixel_1g_traffic.json"}.get(wl, ""))
+    prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    tail = {"street_4k_hzb": "config3_4k_hzb_traffic.json", "street_x64_4k_hzb": "config4_x64_4k_hzb_traffic.json",
+            "subpixel_1g": "config5_subpixel_1g_traffic.json"}.get(wl)
+    cands = sorted(f for f in os.listdir(prof_dir) if tail and f.endswith(tail)) if os.path.isdir(prof_dir) else []
+    tj = os.path.join(prof_dir, cands[-1]) if cands else ""              # the newest round's
     if world == 1 and not args.debug_flags and (not args.no_hzb or wl.startswith("subpixel")) and os.path.isfile(tj):
         try:
             tk = json.load(open(tj))
@@ -301,6 +342,7 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                "from_committed_profile": traffic is not None,   # (PMC passes cannot run inside this process: not observed in THIS run)
                 "avg_launch_us": round(dom_ms / launches * 1e3, 2), "launches_per_step": launches,
                 "algorithmic_bytes_per_launch": int(dom_bytes / launches),
                 "other_kernel": {k: {"avg_launch_us": round(v[0] / launches * 1e3, 2), "algorithmic_bytes_per_launch": int(v[1] / launches)}
@@ -312,7 +354,7 @@ def main():
     if world > 1:
         if rank == 0:
             r1 = VisibilityRenderer(local_rank, stream.cuda_stream)
-            if wl == "subpixel_1g":
+            if wl.startswith("subpixel_1g"):
                 r1.set_limits(max_triangle_records=1152 << 20, bin_pool_chunks=1200 << 10, bin_max_chunks_per_tile=2048)
             r1.upload_scene(scene)
             r1.allocate_gbuffer(W, H)
@@ -332,10 +374,34 @@ def main():
                 frame1(i)
             torch.cuda.synchronize(dev)
             s1 = time.perf_counter()
+            # the unit of the metric -- triangles of the clusters submitted to the rasterizer -- is the FRAME's: a rank of a
+            # sharded frame culls and counts only the clusters that touch its rows, so the count comes from this run
+            ref_view = [None, None]
+            for i in range(2):
+                frame1(i)
+                ref_view[i & 1] = r1.stats()
+            tris_per_pair = ref_view[0]["trianglesSubmitted"] + ref_view[1]["trianglesSubmitted"]
             single_ref = {"workload": wl, "n_gpus": 1, "steps": n1, "ms_per_step": round((s1 - s0) / n1 * 1e3, 4),
-                          "value": round(tris_per_pair * (n1 // 2) / (s1 - s0) / 1e9, 4), "unit": "Gtri/s"}
+                          "value": round(tris_per_pair * (n1 // 2) / (s1 - s0) / 1e9, 4), "unit": "Gtri/s",
+                          "triangles_submitted_view_a": ref_view[0]["trianglesSubmitted"], "triangles_submitted_view_b": ref_view[1]["trianglesSubmitted"]}
             r1.close()
         dist.barrier()
+    tris_view_a = (single_ref["triangles_submitted_view_a"] if single_ref else per_view[0]["trianglesSubmitted"])
+    tris_total = tris_per_pair * (args.steps // 2) + (tris_view_a if args.steps & 1 else 0)
+    value = tris_total / elapsed / 1e9
+
+    # per rank: GPU time of every phase and exchange of the frame (hipEvent stamps on every 8th timed step), host wall time
+    phases = None
+    if world > 1:
+        mine = {"rank": rank, "wall_ms_per_step": round(rank_elapsed / args.steps * 1e3, 4),
+                "phase_a_cull": round(st["msClear"] + st["msInstanceCulling"], 4), "phase_a_stage0": round(st["msStage0"], 4),
+                "hzb_mid": round(st["msHzbStage0"], 4), "exchange_hzb": round(st["msExchangeHzb"], 4),
+                "phase_b_stage1": round(st["msStage1"], 4), "exchange_vis": round(st["msExchangeVis"], 4),
+                "phase_c_final_hzb": round(st["msHzbFinal"], 4), "setup_kernels": round(st["msRasterCluster"], 4), "tile_kernels": round(st["msRasterChunk"], 4),
+                "clusters": [per_view[0]["countStage0Visible"] + per_view[0]["countStage1Visible"], per_view[1]["countStage0Visible"] + per_view[1]["countStage1Visible"]]}
+        allp = [None] * world
+        dist.all_gather_object(allp, mine)
+        phases = allp
 
     # ---- CPU baseline: the oracle replaying the same frame on the host (rank 0, N = 1) ----------
     cpu = None
@@ -371,7 +437,7 @@ def main():
     if rank == 0:
         line = {
             "metric": "Gtri/s into 4K 64-bit visbuffer", "value": round(value, 4), "unit": "Gtri/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "timed_region_s": round(elapsed, 6),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32+u64", "data": "synthetic",
             "config": {"workload": wl, **({"ABLATION_debug_flags": args.debug_flags} if args.debug_flags else {}), "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(),
@@ -383,6 +449,7 @@ def main():
             "clusters_rastered_per_step": clusters_per_frame, "triangle_records_per_step": recs, "bin_entries_per_step": bins, "pixel_blocks_per_step": blocks, "pixel_block_bytes_per_step": block_bytes,
             "gpu_ms": {k: round(st[k], 4) for k in ("msClear", "msInstanceCulling", "msStage0", "msHzbStage0", "msStage1",
                                                      "msHzbFinal", "msFrame", "msRasterCluster", "msRasterClip", "msRasterChunk")},
+            "tiles_touched_view_a": per_view[0]["tilesTouched"], "tiles_total": ((W + 63) // 64) * ((H + 63) // 64),
             "counts_view_a": {k: per_view[0][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},
             "counts_view_b": {k: per_view[1][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},
             "roofline": roofline,
@@ -390,6 +457,8 @@ def main():
         }
         if world > 1:
             line["exchange"] = exchange
+            line["exchange_fallbacks"] = fallbacks
+            line["phases_ms"] = phases
             line["rccl_ranks"] = comm["ranks"] if (comm and exchange == "lib") else (dist.get_world_size() if backend == "nccl" else 0)
             line["rccl_version"] = (comm["nccl_version_code"] if comm else (_torch_nccl_version() if backend == "nccl" else None))
             line["collective_backend"] = backend
@@ -400,6 +469,89 @@ def main():
     r.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_group(args, wl, scene, views, objs, flags, W, H, world, rank, dev, stream, fallbacks):
+    """--exchange group: rank 0 alone drives all N devices through ChordGroup (one worker thread per device, direct peer copies
+    between the ranks' buffers; no RCCL).  The other processes of the launch only wait.  Same workload, same frames, same
+    timing rule (barrier + synchronize on both sides of exactly --steps frames); one JSON line."""
+    from chord_amd.renderer import VisibilityGroup, VisibilityRenderer
+    line = None
+    if rank == 0:
+        one_device = os.environ.get("CHORDVIS_BENCH_ONE_DEVICE") == "1"
+        g = VisibilityGroup([0] * world if one_device else list(range(world)))
+        if wl.startswith("subpixel_1g"):
+            share = max(1, world // 2)
+            g.set_limits(max_triangle_records=(1152 << 20) // share, bin_pool_chunks=(1200 << 10) // share, bin_max_chunks_per_tile=2048)
+        g.upload_scene(scene)
+        g.allocate_gbuffer(W, H, 0)
+
+        def frame(i):
+            g.update_objects(objs[i & 1])                # (host arrays: the group API has no bind_objects; 224 B per object and rank)
+            g.set_view(views[i & 1][0], views[i & 1][1], flags)
+            g.render_frame()
+        for r_ in g.ranks:
+            r_.enable_timers(0)
+        for i in range(max(args.warmup, 4)):
+            frame(i)
+        g.sync()
+        for r_ in g.ranks:
+            r_.enable_timers(2, period=8)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            frame(i)
+        g.sync()
+        elapsed = time.perf_counter() - t0
+        sts = [r_.stats() for r_ in g.ranks]
+        g.close()
+        r1 = VisibilityRenderer(0, stream.cuda_stream)
+        if wl.startswith("subpixel_1g"):
+            r1.set_limits(max_triangle_records=1152 << 20, bin_pool_chunks=1200 << 10, bin_max_chunks_per_tile=2048)
+        r1.upload_scene(scene)
+        r1.allocate_gbuffer(W, H)
+        r1.enable_timers(0)
+
+        def frame1(i):
+            r1.update_objects(objs[i & 1])
+            r1.set_view(views[i & 1][0], views[i & 1][1], flags)
+            r1.render_frame()
+        n1 = max(8, min(args.steps, 100)) & ~1
+        for i in range(8):
+            frame1(i)
+        r1.sync()
+        s0 = time.perf_counter()
+        for i in range(n1):
+            frame1(i)
+        r1.sync()
+        s1 = time.perf_counter()
+        ref_view = [None, None]
+        for i in range(2):
+            frame1(i)
+            ref_view[i & 1] = r1.stats()
+        r1.close()
+        tris_per_pair = ref_view[0]["trianglesSubmitted"] + ref_view[1]["trianglesSubmitted"]
+        tris_total = tris_per_pair * (args.steps // 2) + (ref_view[0]["trianglesSubmitted"] if args.steps & 1 else 0)
+        ms = elapsed / args.steps * 1e3
+        single = {"workload": wl, "n_gpus": 1, "steps": n1, "ms_per_step": round((s1 - s0) / n1 * 1e3, 4),
+                  "value": round(tris_per_pair * (n1 // 2) / (s1 - s0) / 1e9, 4), "unit": "Gtri/s"}
+        line = {"metric": "Gtri/s into 4K 64-bit visbuffer", "value": round(tris_total / elapsed / 1e9, 4), "unit": "Gtri/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "timed_region_s": round(elapsed, 6),
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
+                "config": {"workload": wl, "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(), "objects": len(scene.objects),
+                           "hzb": not args.no_hzb, "cull": args.cull, "parallelism": "stripes%d" % world},
+                "triangles_submitted_per_step": tris_per_pair / 2.0,
+                "exchange": "group", "exchange_fallbacks": fallbacks, "collective_backend": "hipMemcpyPeerAsync",
+                "phases_ms": [{"rank": k, "phase_a_cull": round(st["msClear"] + st["msInstanceCulling"], 4), "phase_a_stage0": round(st["msStage0"], 4),
+                               "hzb_mid": round(st["msHzbStage0"], 4), "exchange_hzb": round(st["msExchangeHzb"], 4), "phase_b_stage1": round(st["msStage1"], 4),
+                               "exchange_vis": round(st["msExchangeVis"], 4), "phase_c_final_hzb": round(st["msHzbFinal"], 4),
+                               "setup_kernels": round(st["msRasterCluster"], 4), "tile_kernels": round(st["msRasterChunk"], 4)} for k, st in enumerate(sts)],
+                "roofline": None, "cpu_baseline": None,
+                "single_gpu_same_workload": single, "speedup_vs_single": round(single["ms_per_step"] / ms, 4)}
+    dist.barrier()
+    if line is not None:
+        print(json.dumps(line), flush=True)
+    dist.destroy_process_group()
+    return 0
 
 
 def _torch_nccl_version():

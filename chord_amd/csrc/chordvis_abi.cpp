@@ -248,7 +248,7 @@ int alloc_scene_work_buffers(ChordCtx* c)
     if ((rc = dalloc(c, &c->dObjectsOwned, (size_t)c->objectCount))) return rc;
     if ((rc = dalloc(c, &c->dObjFrame, (size_t)c->objectCount))) return rc;
     if ((rc = dalloc(c, &c->dGroupMask, (size_t)c->groupInstances + 16))) return rc;   // (+16: zeroed in 16-byte vectors)
-    if ((rc = dalloc(c, &c->dBlockCounts, (size_t)c->cullBlocks * 2))) return rc;   // counts, then triangles, per count block
+    if ((rc = dalloc(c, &c->dBlockCounts, (size_t)c->cullBlocks * 3))) return rc;   // counts, triangles, the rank's own counts (sharded), per count block
     for (int i = 0; i < 3; i++) {
         if ((rc = dalloc(c, &c->lists[i].cmds, (size_t)c->cmdCapacity))) return rc;
         c->lists[i].count = c->dCounts + i;
@@ -326,7 +326,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dMaterials); dfree(c->dTexAlpha); dfree(c->dTexcoords); dfree(c->dBvhNodes); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
-    dfree(c->dRankCmds); dfree(c->dLeftCmds);
+    dfree(c->dRankCmds); dfree(c->dLeftCmds); dfree(c->dMineCmds);
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
@@ -535,7 +535,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     }
 
     dfree(c->dRankCmds);                                   // sized by cmdCapacity; re-made by the first sharded raster pass
-    dfree(c->dLeftCmds);
+    dfree(c->dLeftCmds); dfree(c->dMineCmds);
     c->objectCount = s->objectCount; c->primCount = s->primitiveCount; c->materialCount = s->materialCount;
     c->meshletCount = nM; c->groupCount = nG;
     c->groupInstances = (uint32_t)groupInst; c->cmdCapacity = (uint32_t)std::max<uint64_t>(cmdCap, 1);
@@ -698,6 +698,7 @@ int chordvis_set_shard(ChordCtx* c, uint32_t stripeRows, uint32_t ranks, uint32_
     c->shard.stripeRows = stripeRows; c->shard.ranks = ranks; c->shard.rank = rank;
     c->shard.stripeMagic = stripeRows > 1 ? (uint32_t)((0x100000000ull + stripeRows - 1) / stripeRows) : 0xFFFFFFFFu;
     c->shard.rankMagic = ranks > 1 ? (uint32_t)((0x100000000ull + ranks - 1) / ranks) : 0xFFFFFFFFu;
+    c->mineValid = false; c->listMine[1] = c->listMine[2] = false;       // (lists culled for another ownership)
     if (c->width) {
         if (c->visExternal) { c->dVis = nullptr; return fail(c, CHORDVIS_E_INVALID, "set_shard after allocate_gbuffer with an external buffer: call allocate_gbuffer again"); }
         return configure_targets(c, nullptr);
@@ -784,10 +785,20 @@ int chordvis_hzb_culling(ChordCtx* c, const ChordHZB* hzb, int bFirstStage, Chor
     if ((rc = flush_pending_tail(c))) return rc;
     if ((rc = flush_view(c))) return rc;
     const HzbBuffers hb = from_handle(hzb);
-    const CmdList inL = from_handle(in);
+    CmdList inL = from_handle(in);
+    // Sharded frames: a rank culls (and later rasters) only the clusters that touch its pixel rows -- the group cull wrote them
+    // to a list of their own -- so the occlusion tests shard with the screen like the raster does.  The decision per cluster
+    // is a function of the cluster and the (exchanged, identical) HZB, so every owner of a straddling cluster decides alike.
+    bool inMine = false;
+    if (c->shard.ranks > 1) {
+        if (inL.cmds == c->lists[0].cmds && c->mineValid) { inL.count = c->dCounts + 4; inL.cmds = c->dMineCmds; inMine = true; }
+        else if (inL.cmds == c->dMineCmds && c->mineValid) inMine = true;
+        else for (int k = 1; k < 3; k++) if (inL.cmds == c->lists[k].cmds && c->listMine[k]) inMine = true;
+    }
     if (bFirstStage) {
         if (inL.cmds == c->lists[1].cmds || inL.cmds == c->lists[2].cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling: first stage input must be the instanceCulling list");
         if (!c->inFrame) CHORD_HIP(c, hipMemsetAsync(c->dCounts + 1, 0, 8, c->stream));
+        c->listMine[1] = c->listMine[2] = inMine;
         launch_hzb_cull(c, hb, 0, inL, c->lists[1], &c->lists[2]);
         if (outVisible) *outVisible = c->lists[1].handle();
         if (outRejected) *outRejected = c->lists[2].handle();
@@ -796,6 +807,7 @@ int chordvis_hzb_culling(ChordCtx* c, const ChordHZB* hzb, int bFirstStage, Chor
         CmdList vis1 = c->lists[1];
         vis1.count = c->dCounts + 3;
         if (!c->inFrame) CHORD_HIP(c, hipMemsetAsync(c->dCounts + 3, 0, 4, c->stream));
+        c->listMine[1] = inMine;
         launch_hzb_cull(c, hb, 1, inL, vis1, nullptr);
         if (outVisible) *outVisible = vis1.handle();
         if (outRejected) *outRejected = ChordCountAndCmd{nullptr, nullptr, 0};
@@ -949,7 +961,7 @@ static int frame_phase_b_impl(ChordCtx* c)
     int rc = ready(c, "frame_phase_b");
     if (rc) return rc;
     if (!c->shouldStage1) return CHORDVIS_OK;
-    record(c, S_OTHER);          // time spent in the caller's all-gather
+    record(c, S_EXCH_HZB);       // time spent in the all-gather of the HZB mip-0 exchange buffer (the library's or the caller's)
     if (c->shard.ranks > 1) launch_hzb_build(c, c->hzb[0], true, false, false, true);
     else launch_hzb_build(c, c->hzb[0], true, false, false, false);
     CHORD_HIP(c, hipGetLastError());
@@ -965,7 +977,7 @@ static int frame_phase_c_impl(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_c");
     if (rc) return rc;
-    record(c, S_OTHER);          // time spent in the caller's all-gather
+    record(c, S_EXCH_VIS);       // time spent in the all-gather of the visibility words
     if (c->shard.ranks > 1) { launch_detile(c); CHORD_HIP(c, hipGetLastError()); }
     const int next = c->historySlot == 1 ? 2 : 1;
     if ((rc = chordvis_build_hzb(c, 1, 1, 1, next, nullptr))) return rc;
@@ -1343,7 +1355,7 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
     }
     if (c->timers && c->framesStamped && c->stampTags.size() > 1) {
         // walk the stamps: the segment ending at stamp i is attributed by its tag and the current stage
-        float clear = 0, cull = 0, st0 = 0, hzb0 = 0, st1 = 0, hzbf = 0, rc_ = 0, rk = 0, rh = 0, other = 0;
+        float clear = 0, cull = 0, st0 = 0, hzb0 = 0, st1 = 0, hzbf = 0, rc_ = 0, rk = 0, rh = 0, other = 0, exh = 0, exv = 0;
         int stage = 0;   // 0 = stage 0, 1 = stage 1
         for (size_t i = 1; i < c->stampTags.size(); i++) {
             const int tag = c->stampTags[i];
@@ -1359,6 +1371,8 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
             case S_R_CHUNK: rh += ms; (stage == 0 ? st0 : st1) += ms; break;
             case S_HZB0: hzb0 += ms; break;
             case S_HZBF: hzbf += ms; break;
+            case S_EXCH_HZB: exh += ms; break;
+            case S_EXCH_VIS: exv += ms; break;
             default: other += ms; break;
             }
             if (tag == S_STAGE0_END) stage = 1;
@@ -1367,7 +1381,8 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
         out->msClear = clear * inv; out->msInstanceCulling = cull * inv; out->msStage0 = st0 * inv;
         out->msHzbStage0 = hzb0 * inv; out->msStage1 = st1 * inv; out->msHzbFinal = hzbf * inv;
         out->msRasterCluster = rc_ * inv; out->msRasterClip = rk * inv; out->msRasterChunk = rh * inv;
-        out->msFrame = (clear + cull + st0 + hzb0 + st1 + hzbf + other) * inv;
+        out->msExchangeHzb = exh * inv; out->msExchangeVis = exv * inv;
+        out->msFrame = (clear + cull + st0 + hzb0 + st1 + hzbf + other + exh + exv) * inv;
         out->framesTimed = c->framesStamped;
     }
     if (c->timers == 2) { c->stampTags.clear(); c->framesStamped = 0; }

@@ -176,7 +176,7 @@ struct DeviceCounters {
 #endif
 struct FrameState {
     DeviceCounters counters;
-    uint32_t listCounts[8];        // [0..3] command lists of the frame, [4 + pass] this rank's clusters of a raster pass (sharded), [6 + pass] clusters a dense launch's block kernel left over
+    uint32_t listCounts[8];        // [0..3] command lists of the frame, [4] this rank's share of list 0 (sharded: written by the group cull), [5] this rank's clusters of a foreign list (stripe filter), [6 + pass] clusters a dense launch's block kernel left over
     uint32_t tileCount[2 * CHORD_MAX_TILES * CHORD_TILECOUNT_STRIDE];   // pass p starts at p * tiles * stride
 };
 
@@ -198,7 +198,8 @@ struct HzbBuffers {
 
 // GPU timestamp tags: a stamp closes the segment that started at the previous stamp.
 enum StampTag { S_FRAME_BEGIN = 0, S_CLEAR, S_CULL, S_HZBCULL, S_R_CLUSTER, S_R_CLIP, S_R_CHUNK, S_STAGE0_END,
-                S_HZB0, S_STAGE1_END, S_HZBF, S_OTHER };
+                S_HZB0, S_STAGE1_END, S_HZBF, S_OTHER,
+                S_EXCH_HZB, S_EXCH_VIS };   // sharded frames: the segment is the mid-frame HZB exchange / the visibility all-gather
 
 } // namespace chord
 
@@ -261,6 +262,9 @@ struct ChordCtx {
     // command lists: 0 = post instanceCulling, 1 = hzb visible, 2 = hzb rejected
     chord::CmdList lists[3];
     ChordDrawCmd* dRankCmds = nullptr; // sharded frames: the commands of a raster pass whose clusters touch this rank's rows
+    ChordDrawCmd* dMineCmds = nullptr; // sharded frames: the post-instanceCulling commands of THIS rank's clusters, written by the group cull itself (count: listCounts[4])
+    bool mineValid = false;            // ... produced by the last chordvis_instance_culling
+    bool listMine[3] = {false, false, false};   // lists[k] currently holds only this rank's clusters (it was culled from the rank's list)
     ChordDrawCmd* dLeftCmds = nullptr; // dense launches: the clusters the block kernel left to the record kernel (kernels_raster.hip)
     uint32_t* dCounts = nullptr;      // 4 x u32 backing the list counts
 

@@ -184,7 +184,44 @@ struct GroupCullParams {
     const ChordObject* objects; const DObjStatic* objStatic; const DObjFrame* objFrame; const DPrim* prims;
     const DGroup* groups; const uint32_t* groupIndices; const DMeshlet* meshlets; const uint32_t* groupOwner;
     const DView* dview; uint8_t* groupMask; uint32_t* blockCounts; uint32_t groupInstances;
+    // sharded frames: the commands whose clusters touch one of this rank's pixel rows are ALSO written to the rank's own
+    // list (in the same deterministic order), decided where the meshlet record is already in registers
+    ShardInfo shard; float H; int32_t Hi; ChordDrawCmd* mineCmds; uint32_t* mineCount;
 };
+
+// Does the cluster touch one of this rank's pixel rows?  Conservative: the 8 projected AABB corners, one pixel of slack; any
+// corner at or behind the camera plane keeps the cluster.  Dropping a cluster that fails is invisible in the image -- only
+// triangles without an owned row go, exactly as the per-triangle ownership test of the setup kernel would decide.
+__device__ __forceinline__ bool shard_owns_any_row(const ShardInfo& s, int32_t y0, int32_t y1)
+{
+    const uint32_t s0 = shard_stripe_of(s, (uint32_t)y0), s1 = shard_stripe_of(s, (uint32_t)y1);
+    if (s1 - s0 + 1u >= s.ranks) return true;
+    const uint32_t o0 = shard_owner_of_stripe(s, s0);
+    const uint32_t ahead = s.rank >= o0 ? s.rank - o0 : s.rank + s.ranks - o0;
+    return s0 + ahead <= s1;
+}
+
+__device__ __forceinline__ bool cluster_touches_rank(const ShardInfo& shard, const float* __restrict__ mv, const DMeshlet& m, float H, int32_t Hi)
+{
+    Mat4 mvp;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = mv[r * 4 + cc];
+    float ylo = 3.0e38f, yhi = -3.0e38f;
+    bool unbounded = false;
+#pragma unroll
+    for (uint32_t q = 0; q < 8u; q++) {
+        const f4 h = mul_mv(mvp, (q & 1u) ? m.posMax[0] : m.posMin[0], (q & 2u) ? m.posMax[1] : m.posMin[1],
+                            (q & 4u) ? m.posMax[2] : m.posMin[2], 1.0f);
+        const float y = (h.y / h.w * -0.5f + 0.5f) * H;
+        if (!(h.w > 1.0e-6f) || !(fabsf(y) < 1.0e7f)) unbounded = true;
+        else { ylo = fminf(ylo, y); yhi = fmaxf(yhi, y); }
+    }
+    if (unbounded) return true;
+    const int32_t y0 = max((int32_t)floorf(ylo) - 1, 0), y1 = min((int32_t)ceilf(yhi) + 1, Hi - 1);
+    return y1 >= y0 && shard_owns_any_row(shard, y0, y1);
+}
 
 // The object pass as a kernel of its own: for long scenes (thousands of count blocks) the fused form below makes every count
 // block wait for its objects first, which costs more than the launch it saves (config 4: +4 us).
@@ -232,9 +269,10 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
         }
     }
     __syncthreads();                                       // the object records of this block are written (and visible to it)
-    uint32_t mask = 0, tris = 0;
+    uint32_t mask = 0, tris = 0, mine = 0;
+    const bool sharded = p.shard.ranks > 1u;
     if (FROM_MASK) {
-        if (t < p.groupInstances) mask = p.groupMask[t];
+        if (t < p.groupInstances) mask = p.groupMask[t] & 15u;
         if (mask) {
             const uint32_t o = p.groupOwner[t];
             const DObjStatic st = p.objStatic[o];
@@ -242,7 +280,12 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
             const DGroup& g = p.groups[prim.groupBase + (t - st.groupBase)];
             const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
             for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++)
-                if (mask & (1u << i)) tris += (p.meshlets[prim.meshletBase + p.groupIndices[idxBase + i]].vertexTriangleCount >> 8) & 0xFFu;
+                if (mask & (1u << i)) {
+                    const DMeshlet& m = p.meshlets[prim.meshletBase + p.groupIndices[idxBase + i]];
+                    tris += (m.vertexTriangleCount >> 8) & 0xFFu;
+                    if (sharded && cluster_touches_rank(p.shard, p.objFrame[o].mvp, m, p.H, p.Hi)) mine |= 1u << i;
+                }
+            if (sharded) p.groupMask[t] = (uint8_t)(mask | (mine << 4));
         }
     } else
     if (t < p.groupInstances) {
@@ -267,16 +310,21 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
                     if (i < cnt && meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (st.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, m)) {
                         mask |= 1u << i;
                         tris += (m.vertexTriangleCount >> 8) & 0xFFu;
+                        if (sharded && cluster_touches_rank(p.shard, of.mvp, m, p.H, p.Hi)) mine |= 1u << i;
                     }
                 }
             }
         }
-        p.groupMask[t] = (uint8_t)mask;
+        p.groupMask[t] = (uint8_t)(mask | (mine << 4));                  // low nibble: visible meshlets, high nibble: of which this rank's
     }
     uint32_t total, blockTris;
-    (void)block_excl_scan(__popc(mask), &total);
+    // (counts below 2^12 per block: the visible count in the low half, the rank's in the high half of one scan)
+    (void)block_excl_scan((uint32_t)__popc(mask) | ((uint32_t)__popc(mine) << 16), &total);
     (void)block_excl_scan(tris, &blockTris);
-    if (threadIdx.x == 0) { p.blockCounts[blockIdx.x] = total; p.blockCounts[cullBlocks + blockIdx.x] = blockTris; }
+    if (threadIdx.x == 0) {
+        p.blockCounts[blockIdx.x] = total & 0xFFFFu; p.blockCounts[cullBlocks + blockIdx.x] = blockTris;
+        if (sharded) p.blockCounts[2u * cullBlocks + blockIdx.x] = total >> 16;
+    }
 }
 
 // ---- hierarchical cull (chordvis_set_cull_mode 1) ---------------------------------------------------------------------
@@ -393,28 +441,34 @@ __global__ __launch_bounds__(256) void bvh_cull_kernel(BvhCullParams bp, const D
 // scatter kernel reads its base instead of summing all preceding counts itself (that is quadratic in the number of
 // blocks: 34 us at config 4), and adds up the triangles of the list (the Gtri/s unit).
 __global__ __launch_bounds__(1024) void group_cull_prefix_kernel(uint32_t* __restrict__ blockCounts, uint32_t blocks,
-                                                                 uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters)
+                                                                 uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters,
+                                                                 uint32_t* __restrict__ mineCount)
 {
     __shared__ uint32_t sWave[16];
     __shared__ unsigned long long sTris[16];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t carry = 0;
     unsigned long long tris = 0;
-    for (uint32_t base = 0; base < blocks; base += 1024u) {
-        const uint32_t b = base + threadIdx.x;
-        const uint32_t v = b < blocks ? blockCounts[b] : 0u;
-        if (b < blocks) tris += blockCounts[blocks + b];
-        uint32_t incl = v;
+    // sharded frames (mineCount != NULL): the same scan once more over the rank's own counts, blockCounts[2 * blocks ..)
+    for (uint32_t which = 0; which < (mineCount ? 2u : 1u); which++) {
+        uint32_t* __restrict__ cnt = blockCounts + (which ? 2u * blocks : 0u);
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < blocks; base += 1024u) {
+            const uint32_t b = base + threadIdx.x;
+            const uint32_t v = b < blocks ? cnt[b] : 0u;
+            if (which == 0u && b < blocks) tris += blockCounts[blocks + b];
+            uint32_t incl = v;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t nb = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += nb; }
-        if (lane == 63u) sWave[wave] = incl;
-        __syncthreads();
-        uint32_t before = 0, all = 0;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t nb = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += nb; }
+            if (lane == 63u) sWave[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < 16u; w++) { const uint32_t c = sWave[w]; if (w < wave) before += c; all += c; }
-        if (b < blocks) blockCounts[b] = carry + before + incl - v;
-        carry += all;
-        __syncthreads();
+            for (uint32_t w = 0; w < 16u; w++) { const uint32_t c = sWave[w]; if (w < wave) before += c; all += c; }
+            if (b < blocks) cnt[b] = carry + before + incl - v;
+            carry += all;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *(which ? mineCount : outCount) = carry;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tris += __shfl_down(tris, off, 64);
@@ -423,7 +477,6 @@ __global__ __launch_bounds__(1024) void group_cull_prefix_kernel(uint32_t* __res
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
         for (uint32_t w = 0; w < 16u; w++) t += sTris[w];
-        *outCount = carry;
         if (t) atomicAdd(&counters->trisInstanceCulled, t);
     }
 }
@@ -563,26 +616,30 @@ template <bool PREFIXED>
 __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams p, ChordDrawCmd* __restrict__ outCmds,
                                                                  uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters)
 {
-    __shared__ uint32_t red[256];
-    uint32_t blockBase;
-    if (PREFIXED) blockBase = p.blockCounts[blockIdx.x];
+    __shared__ uint32_t red[256], redMine[256];
+    const bool sharded = p.shard.ranks > 1u;
+    const uint32_t cullBlocks = gridDim.x;
+    uint32_t blockBase, mineBase = 0;
+    if (PREFIXED) { blockBase = p.blockCounts[blockIdx.x]; if (sharded) mineBase = p.blockCounts[2u * cullBlocks + blockIdx.x]; }
     else {
-        uint32_t part = 0;
-        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) part += p.blockCounts[b];
-        red[threadIdx.x] = part;
+        uint32_t part = 0, partMine = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) { part += p.blockCounts[b]; if (sharded) partMine += p.blockCounts[2u * cullBlocks + b]; }
+        red[threadIdx.x] = part; redMine[threadIdx.x] = partMine;
         __syncthreads();
         for (uint32_t s = 128; s > 0; s >>= 1) {
-            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            if (threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; redMine[threadIdx.x] += redMine[threadIdx.x + s]; }
             __syncthreads();
         }
-        blockBase = red[0];
+        blockBase = red[0]; mineBase = redMine[0];
         __syncthreads();
     }
 
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t mask = t < p.groupInstances ? p.groupMask[t] : 0u;
+    const uint32_t both = t < p.groupInstances ? p.groupMask[t] : 0u;
+    const uint32_t mask = both & 15u, mine = sharded ? both >> 4 : 0u;
     uint32_t total;
-    const uint32_t off = block_excl_scan(__popc(mask), &total);
+    const uint32_t offs = block_excl_scan((uint32_t)__popc(mask) | ((uint32_t)__popc(mine) << 16), &total);
+    const uint32_t off = offs & 0xFFFFu;
     uint32_t tris = 0;
     if (mask) {
         const uint32_t o = p.groupOwner[t];
@@ -590,7 +647,7 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
         const DPrim& prim = p.prims[st.prim];
         const DGroup& g = p.groups[prim.groupBase + (t - st.groupBase)];
         const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
-        uint32_t slot = blockBase + off;
+        uint32_t slot = blockBase + off, mslot = mineBase + (offs >> 16);
         for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
             if (mask & (1u << i)) {
                 ChordDrawCmd cmd;
@@ -598,13 +655,14 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
                 cmd.meshletId = prim.meshletBase + p.groupIndices[idxBase + i];
                 cmd.slot = slot;                                            // instance_culling.hlsl:203-206
                 outCmds[slot] = cmd;
+                if (mine & (1u << i)) p.mineCmds[mslot++] = cmd;            // the rank's own list: same order, same slots
                 if (!PREFIXED) tris += (p.meshlets[cmd.meshletId].vertexTriangleCount >> 8) & 0xFFu;
                 slot++;
             }
         }
     }
     if (PREFIXED) return;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *outCount = blockBase + total;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *outCount = blockBase + (total & 0xFFFFu); if (sharded) *p.mineCount = mineBase + (total >> 16); }
     // triangles this list submits (the Gtri/s unit): one fire-and-forget atomic per block
     uint32_t blockTris;
     (void)block_excl_scan(tris, &blockTris);
@@ -805,6 +863,14 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     p.objects = c->dObjects; p.objStatic = c->dObjStatic; p.objFrame = c->dObjFrame; p.prims = c->dPrims;
     p.groups = c->dGroups; p.groupIndices = c->dGroupIndices; p.meshlets = c->dMeshlets; p.groupOwner = c->dGroupOwner;
     p.dview = c->dView; p.groupMask = c->dGroupMask; p.blockCounts = c->dBlockCounts; p.groupInstances = c->groupInstances;
+    p.shard = c->shard; p.H = (float)c->height; p.Hi = (int32_t)c->height; p.mineCmds = nullptr; p.mineCount = nullptr;
+    c->mineValid = false;
+    if (c->shard.ranks > 1 && c->height) {
+        // sharded frame: the rank's own commands leave the cull as a list of their own (no pass over the full list later)
+        if (!c->dMineCmds && hipMalloc((void**)&c->dMineCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity) != hipSuccess) c->dMineCmds = nullptr;
+        if (c->dMineCmds) { p.mineCmds = c->dMineCmds; p.mineCount = c->dCounts + 4; c->mineValid = true; }
+        else p.shard.ranks = 1;                              // (allocation failed: launch_raster falls back to the stripe filter)
+    } else p.shard.ranks = 1;
     const uint32_t blocks = c->cullBlocks;
     uint4* zeroBase = nullptr;
     uint32_t zeroVec4 = 0;
@@ -847,7 +913,7 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     }
     c->viewDirty = false;
     if (blocks > 512u) {
-        hipLaunchKernelGGL(group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters);
+        hipLaunchKernelGGL(group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters, p.mineCount);
         hipLaunchKernelGGL(group_cull_scatter_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
     } else {
         hipLaunchKernelGGL(group_cull_scatter_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
@@ -869,15 +935,6 @@ struct StripeFilterParams {
     ShardInfo shard; float H; int32_t Hi;
 };
 
-__device__ __forceinline__ bool shard_owns_any_row(const ShardInfo& s, int32_t y0, int32_t y1)
-{
-    const uint32_t s0 = shard_stripe_of(s, (uint32_t)y0), s1 = shard_stripe_of(s, (uint32_t)y1);
-    if (s1 - s0 + 1u >= s.ranks) return true;
-    const uint32_t o0 = shard_owner_of_stripe(s, s0);
-    const uint32_t ahead = s.rank >= o0 ? s.rank - o0 : s.rank + s.ranks - o0;
-    return s0 + ahead <= s1;
-}
-
 __global__ __launch_bounds__(256) void stripe_filter_kernel(StripeFilterParams p)
 {
     __shared__ uint32_t sWave[4], sBase;
@@ -892,28 +949,7 @@ __global__ __launch_bounds__(256) void stripe_filter_kernel(StripeFilterParams p
             cmd[k] = ChordDrawCmd{0, 0, 0};
             if (i < count) {
                 cmd[k] = p.inCmds[i];
-                const DMeshlet& m = p.meshlets[cmd[k].meshletId];
-                const float* __restrict__ mv = p.objFrame[cmd[k].objectId].mvp;
-                Mat4 mvp;
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = mv[r * 4 + cc];
-                float ylo = 3.0e38f, yhi = -3.0e38f;
-                bool unbounded = false;
-#pragma unroll
-                for (uint32_t q = 0; q < 8u; q++) {
-                    const f4 h = mul_mv(mvp, (q & 1u) ? m.posMax[0] : m.posMin[0], (q & 2u) ? m.posMax[1] : m.posMin[1],
-                                        (q & 4u) ? m.posMax[2] : m.posMin[2], 1.0f);
-                    const float y = (h.y / h.w * -0.5f + 0.5f) * p.H;
-                    if (!(h.w > 1.0e-6f) || !(fabsf(y) < 1.0e7f)) unbounded = true;
-                    else { ylo = fminf(ylo, y); yhi = fmaxf(yhi, y); }
-                }
-                bool mine = true;
-                if (!unbounded) {
-                    const int32_t y0 = max((int32_t)floorf(ylo) - 1, 0), y1 = min((int32_t)ceilf(yhi) + 1, p.Hi - 1);
-                    mine = y1 >= y0 && shard_owns_any_row(p.shard, y0, y1);
-                }
+                const bool mine = cluster_touches_rank(p.shard, p.objFrame[cmd[k].objectId].mvp, p.meshlets[cmd[k].meshletId], p.H, p.Hi);
                 if (mine) keep |= 1u << k;
             }
         }

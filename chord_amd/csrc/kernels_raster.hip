@@ -1981,34 +1981,37 @@ __device__ __forceinline__ void merge_block_word(unsigned long long* tile, unsig
 __device__ __forceinline__ void merge_blocks(unsigned long long* tile, const unsigned long long* __restrict__ pool, unsigned long long todo,
                                              uint32_t name, uint32_t hdrLo, uint32_t hdrHi, uint32_t lane)
 {
-    // four blocks per step: the first 128 words of each are in flight together (a block of sub-pixel geometry has 64..121),
-    // so a wave keeps ~4 KB of loads outstanding instead of one block's worth per memory round trip
+    // four blocks per step, a 16-byte granule per lane and block: granule g holds the block's words 2g - 1 and 2g (word -1 is
+    // the header), so the first 127 words of each of the four are in flight together (a block of sub-pixel geometry has
+    // 64..121) -- ~4 KB of loads outstanding per wave instead of one block's worth per memory round trip, in 16-byte
+    // requests (8-byte loads run at 0.54-0.70x their rate, MI355X_MICROARCH.md)
     while (todo) {
         uint32_t h[4], r[4], n[4];
-        const unsigned long long* src[4];
+        const ulonglong2* src[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const bool any = todo != 0ull;
             const int l = any ? __ffsll((long long)todo) - 1 : 0;
             todo &= todo - 1ull;                                    // (0 stays 0)
             h[j] = bcast(hdrLo, l); r[j] = bcast(hdrHi, l);
-            src[j] = pool + (size_t)(bcast(name, l) & CHORD_REC_INDEX_MASK) * 2u + 1u;
+            src[j] = reinterpret_cast<const ulonglong2*>(pool + (size_t)(bcast(name, l) & CHORD_REC_INDEX_MASK) * 2u);
             n[j] = any ? (((h[j] >> 12) & 15u) + 1u) * (((h[j] >> 16) & 15u) + 1u) : 0u;
         }
-        unsigned long long a[4], b[4];
+        ulonglong2 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) a[j] = 2u * lane <= n[j] && n[j] != 0u ? src[j][lane] : make_ulonglong2(0ull, 0ull);   // granule g exists iff 2g - 1 < n
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            a[j] = lane < n[j] ? src[j][lane] : 0ull;
-            b[j] = lane + 64u < n[j] ? src[j][lane + 64u] : 0ull;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            merge_block_word(tile, a[j], lane, h[j], r[j]);
-            merge_block_word(tile, b[j], lane + 64u, h[j], r[j]);
+            if (lane != 0u) merge_block_word(tile, a[j].x, 2u * lane - 1u, h[j], r[j]);
+            if (2u * lane < n[j]) merge_block_word(tile, a[j].y, 2u * lane, h[j], r[j]);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            for (uint32_t i = lane + 128u; i < n[j]; i += 64u) merge_block_word(tile, src[j][i], i, h[j], r[j]);
+            for (uint32_t g = lane + 64u; 2u * g <= n[j]; g += 64u) {
+                const ulonglong2 v = src[j][g];
+                merge_block_word(tile, v.x, 2u * g - 1u, h[j], r[j]);
+                if (2u * g < n[j]) merge_block_word(tile, v.y, 2u * g, h[j], r[j]);
+            }
     }
 }
 
@@ -2299,14 +2302,22 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         p.hzbMinB = c->hzb[c->fuseHzbSlot].minTexels; p.hzbMaxB = c->hzb[c->fuseHzbSlot].maxTexels;
     }
     p.count = in.count; p.cmds = in.cmds;
-    if (c->shard.ranks > 1 && !c->dRankCmds) LR_HIP(hipMalloc((void**)&c->dRankCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity));   // first sharded pass
-    if (c->shard.ranks > 1 && c->dRankCmds) {
-        // sharded frame: only the clusters that touch this rank's pixel rows reach the setup kernel
-        CmdList mine;
-        mine.count = c->dCounts + 4 + (c->rasterCalls & 1u); mine.cmds = c->dRankCmds; mine.capacity = in.capacity;
-        if (!c->inFrame || c->rasterCalls >= 2) LR_HIP(hipMemsetAsync(mine.count, 0, sizeof(uint32_t), c->stream));
-        launch_stripe_filter(c, in, mine);
-        p.count = mine.count; p.cmds = mine.cmds;
+    if (c->shard.ranks > 1) {
+        // sharded frame: only the clusters that touch this rank's pixel rows reach the setup kernel.  The lists of a frame
+        // are the rank's own already (the group cull writes the rank's share of list 0 beside the full list; the HZB culls
+        // of a sharded frame start from it); a list of unknown origin goes through the stripe filter first.
+        bool mine = false;
+        if (in.cmds == c->lists[0].cmds && c->mineValid) { p.count = c->dCounts + 4; p.cmds = c->dMineCmds; mine = true; }
+        else if (in.cmds == c->dMineCmds && c->mineValid) mine = true;
+        else for (int k = 1; k < 3; k++) if (in.cmds == c->lists[k].cmds && c->listMine[k]) mine = true;
+        if (!mine) {
+            if (!c->dRankCmds) LR_HIP(hipMalloc((void**)&c->dRankCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity));
+            CmdList filtered;
+            filtered.count = c->dCounts + 5; filtered.cmds = c->dRankCmds; filtered.capacity = in.capacity;
+            LR_HIP(hipMemsetAsync(filtered.count, 0, sizeof(uint32_t), c->stream));
+            launch_stripe_filter(c, in, filtered);
+            p.count = filtered.count; p.cmds = filtered.cmds;
+        }
     }
     p.objFrame = c->dObjFrame; p.objStatic = c->dObjStatic;
     p.meshlets = c->dMeshlets; p.meshletData = c->dMeshletData; p.positions = c->dPositions;

@@ -19,7 +19,9 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -227,7 +229,16 @@ struct ChordGroup {
     uint32_t pending = 0;
     std::vector<int> jobRc;
     bool quit = false;
-    // host barrier between the steps of an exchange (an event must be RECORDED before another thread enqueues a wait on it)
+    // An event must be RECORDED before another thread enqueues a wait on it.  Round 2 put two host barriers (mutex + condition
+    // variable over all rank threads) into every exchange; now a rank PUBLISHES what it has recorded as a generation number per
+    // event and a peer spins (no sleep: the threads run concurrently and are microseconds apart) until the generation it needs
+    // is there -- pairwise, lock-free, no wake-up latency.  Generations count the uses of an event channel, in lockstep on every
+    // rank; an event is re-recorded for generation k + 1 only after every consumer of generation k has enqueued its wait
+    // (group_all_gather, "reuse").
+    std::unique_ptr<std::atomic<uint64_t>[]> readyGen[4];     // [which][rank]
+    std::unique_ptr<std::atomic<uint64_t>[]> arrivedGen[4];   // [which][src * n + dst]
+    std::vector<uint64_t> useCount[4];                         // [which][rank]: private to the rank's thread
+    // one barrier remains, once per pipelined frame (the swap of the buffer pairs)
     std::mutex bm;
     std::condition_variable bcv;
     uint32_t bCount = 0; uint64_t bGen = 0;
@@ -284,10 +295,19 @@ int run_all(ChordGroup* g, const std::function<int(uint32_t)>& fn, const char* w
     return CHORDVIS_OK;
 }
 
+inline void spin_until(const std::atomic<uint64_t>& a, uint64_t gen)
+{
+    uint32_t spins = 0;
+    while (a.load(std::memory_order_acquire) < gen) { if (++spins > 4096u) std::this_thread::yield(); }
+}
+
 // Direct all-gather of rank-major buffers, called by every rank's thread: rank r's chunk travels to each peer on the
 // (r, d) copy stream once both ends are ready -- r has produced it, d has finished with the region it lands in (d's
 // stream is past every earlier reader of its buffer when it records `ready`).  A compute stream then waits for every
 // copy that ends in its buffer AND every copy that leaves it (the source region is rewritten by the next frame).
+// Host side: no barrier.  Reuse of the channel's events: ready[r] of use k + 1 is recorded after r saw arrived[o -> r] of use
+// k from every peer o (o records it after enqueueing its waits on ready[r]); arrived[r -> d] of use k + 1 is recorded after r
+// saw ready[d] of use k + 1, which d publishes after it enqueued, in use k, its waits on arrived[r -> d].
 int group_all_gather(ChordGroup* g, uint32_t r, int which, const std::function<char*(uint32_t)>& base, size_t chunkBytes, hipStream_t waiter = nullptr,
                      bool bulk = false)
 {
@@ -295,21 +315,24 @@ int group_all_gather(ChordGroup* g, uint32_t r, int which, const std::function<c
     if (!waiter) waiter = c->stream;                              // who continues once the buffer is complete (default: the rank's compute stream)
     const uint32_t n = g->n;
     int rc = CHORDVIS_OK;
-    // a failing call is remembered, but the rank keeps walking through both host barriers: its peers wait there
+    // a failing call is remembered, but the rank keeps publishing its generations: its peers spin on them
 #define GG_HIP(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess && !rc) rc = fail(c, CHORDVIS_E_HIP, #call, e_); } while (0)
+    const uint64_t gen = ++g->useCount[which][r];
     GG_HIP(hipEventRecord(g->evReady[which][r], c->stream));
-    group_barrier(g);                                             // every `ready` is recorded
-    for (uint32_t d = 0; d < n; d++) {
-        if (d == r) continue;
+    g->readyGen[which][r].store(gen, std::memory_order_release);
+    for (uint32_t k = 1; k < n; k++) {
+        const uint32_t d = (r + k) % n;                           // (every rank starts with a different peer)
+        spin_until(g->readyGen[which][d], gen);
         hipStream_t cs = bulk ? g->bulkCopyStream[(size_t)r * n + d] : g->copyStream[(size_t)r * n + d];
         GG_HIP(hipStreamWaitEvent(cs, g->evReady[which][r], 0));
         GG_HIP(hipStreamWaitEvent(cs, g->evReady[which][d], 0));
         GG_HIP(hipMemcpyPeerAsync(base(d) + (size_t)r * chunkBytes, g->device[d], base(r) + (size_t)r * chunkBytes, g->device[r], chunkBytes, cs));
         GG_HIP(hipEventRecord(g->evArrived[which][(size_t)r * n + d], cs));
+        g->arrivedGen[which][(size_t)r * n + d].store(gen, std::memory_order_release);
     }
-    group_barrier(g);                                             // every `arrived` is recorded
-    for (uint32_t o = 0; o < n; o++) {
-        if (o == r) continue;
+    for (uint32_t k = 1; k < n; k++) {
+        const uint32_t o = (r + k) % n;
+        spin_until(g->arrivedGen[which][(size_t)o * n + r], gen);
         GG_HIP(hipStreamWaitEvent(waiter, g->evArrived[which][(size_t)o * n + r], 0));   // into my buffer
         GG_HIP(hipStreamWaitEvent(waiter, g->evArrived[which][(size_t)r * n + o], 0));   // out of my buffer
     }
@@ -337,7 +360,13 @@ int chordvis_create_group(uint32_t n, const int* deviceOrdinals, ChordGroup** ou
     for (uint32_t r = 0; r < n && !rc; r++) rc = chordvis_create(g->device[r], nullptr, &g->ctx[r]);
     g->copyStream.assign((size_t)n * n, nullptr);
     g->bulkCopyStream.assign((size_t)n * n, nullptr);
-    for (int w = 0; w < 4; w++) { g->evArrived[w].assign((size_t)n * n, nullptr); g->evReady[w].assign(n, nullptr); }
+    for (int w = 0; w < 4; w++) {
+        g->evArrived[w].assign((size_t)n * n, nullptr); g->evReady[w].assign(n, nullptr);
+        g->readyGen[w].reset(new std::atomic<uint64_t>[n]); g->arrivedGen[w].reset(new std::atomic<uint64_t>[(size_t)n * n]);
+        for (uint32_t i = 0; i < n; i++) g->readyGen[w][i].store(0);
+        for (size_t i = 0; i < (size_t)n * n; i++) g->arrivedGen[w][i].store(0);
+        g->useCount[w].assign(n, 0);
+    }
     g->resolveStream.assign(n, nullptr);
     for (int w = 0; w < 2; w++) g->evVisReady[w].assign(n, nullptr);
     for (uint32_t r = 0; r < n && !rc; r++) {

@@ -64,6 +64,7 @@ class Stats(C.Structure):
         ("triangleRecordsCompact", C.c_uint64),
         ("pixelBlockBytes", C.c_uint64),
         ("pixelBlocks", C.c_uint64),
+        ("msExchangeHzb", C.c_float), ("msExchangeVis", C.c_float),
     ]
 
     def as_dict(self):

@@ -723,12 +723,15 @@ def built_mesh_scene(width=640, height=360, n=96):
     return scene, Camera((0.0, 0.4, 1.0), (0.0, -0.05, -1.0), width, height)
 
 
-def config5_subpixel(width=3840, height=2160, prims=1024, patches_per_prim=1024, instances=8, patch_px=8.0, seed=5):
+def config5_subpixel(width=3840, height=2160, prims=1024, patches_per_prim=1024, instances=8, patch_px=8.0, seed=5, hotspot_sigma_px=None):
     """BASELINE config 5: `prims * patches_per_prim` unique camera-facing patches, each ~patch_px x patch_px
     pixels (128 triangles of ~0.5 px^2 at patch_px = 8), centres uniform over the screen, view depth uniform in
     [5, 50], instanced `instances` times with slightly shifted transforms; LOD0 only.  The defaults give
     1 048 576 patches = 134 M unique triangles (1.0 GB of positions + 0.84 GB of meshlet data), x 8 = 1.07 G triangles.
-    Camera at the origin looking down -z (so world space = view space)."""
+    Camera at the origin looking down -z (so world space = view space).
+    hotspot_sigma_px: SURVEY 8d's variant "hotspot" -- the centres are Gaussian around the screen centre with that sigma in
+    pixels (Box-Muller on the same counter-based random numbers) instead of uniform: every cluster of the frame lands in a
+    few dozen screen tiles, which is the atomic-contention case the configuration is named for."""
     assert patches_per_prim % 4 == 0
     cam = Camera((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), width, height)
     th = math.tan(0.5 * cam.fovy) if hasattr(cam, "fovy") else math.tan(0.5 * math.radians(45.0))
@@ -738,8 +741,15 @@ def config5_subpixel(width=3840, height=2160, prims=1024, patches_per_prim=1024,
     M = patches_per_prim
     for p in range(prims):
         idx = (np.arange(M, dtype=np.uint64) + np.uint64(p) * np.uint64(M)) * np.uint64(4)
-        sx = rand01(seed, idx + np.uint64(0)) * width
-        sy = rand01(seed, idx + np.uint64(1)) * height
+        if hotspot_sigma_px is None:
+            sx = rand01(seed, idx + np.uint64(0)) * width
+            sy = rand01(seed, idx + np.uint64(1)) * height
+        else:
+            u1 = np.maximum(rand01(seed, idx + np.uint64(0)), 1.0e-12)
+            u2 = rand01(seed, idx + np.uint64(1))
+            rad = np.sqrt(-2.0 * np.log(u1)) * float(hotspot_sigma_px)
+            sx = np.clip(0.5 * width + rad * np.cos(2.0 * np.pi * u2), 0.0, width - 1.0)
+            sy = np.clip(0.5 * height + rad * np.sin(2.0 * np.pi * u2), 0.0, height - 1.0)
         zv = 5.0 + 45.0 * rand01(seed, idx + np.uint64(2))
         size = patch_px * 2.0 * zv * th / height
         cx = (sx / width * 2.0 - 1.0) * zv * th * aspect

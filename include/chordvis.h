@@ -120,6 +120,8 @@ typedef struct ChordStats {
     uint64_t pixelBlockBytes;      /* bytes of pixel blocks emitted for small clusters in place of records (this frame); their
                                       triangles are not in triangleRecords, a block counts as one bin entry per tile */
     uint64_t pixelBlocks;          /* number of those blocks (= their bin entries) */
+    float    msExchangeHzb;        /* sharded frames: stream time between phase a and phase b = the all-gather of the HZB mip-0 exchange buffer */
+    float    msExchangeVis;        /* ... between phase b and phase c = the all-gather of the visibility words (incl. waiting for the slowest rank) */
 } ChordStats;
 
 /* ------------------------------------------------------------------ host-only (no device needed) */

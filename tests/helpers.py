@@ -68,3 +68,16 @@ def brute_force_marker(scene, vis, w, h, cmds):
 def tiles_with_type(marker, t):
     ys, xs = np.nonzero(marker[:, :, t // 32] & np.uint32(1 << (t % 32)))
     return sorted((int(x) * 8, int(y) * 8) for x, y in zip(xs, ys))
+
+
+def assert_rank_counts(rank_stats, single):
+    """Counts of a sharded frame against the single-GPU frame's.  The instance cull is replicated (identical list, identical
+    slots: the visibility ids agree); the occlusion culls of a rank run over the clusters that touch ITS pixel rows only, so
+    per stage every rank counts at most the frame's clusters and together they count every one of them at least once
+    (a cluster that straddles two stripes is culled -- identically -- by both owners)."""
+    assert all(st["overflow"] == 0 for st in rank_stats)
+    assert all(st["countInstanceCulled"] == single["countInstanceCulled"] for st in rank_stats)
+    for k in ("countStage0Visible", "countStage0Rejected", "countStage1Visible"):
+        vals = [st[k] for st in rank_stats]
+        assert max(vals) <= single[k], (k, vals, single[k])
+        assert sum(vals) >= single[k], (k, vals, single[k])

@@ -74,9 +74,7 @@ def _check_ranks(g, want, w, h, what):
         H.assert_vis_equal(r.read_visibility(), wvis, w, h, "%s rank %d" % (what, rk))
         mn, mx, rng = r.read_hzb(r.history_hzb())
         assert np.array_equal(mn, wmn) and np.array_equal(mx, wmx) and np.array_equal(rng, wrng), "%s rank %d HZB" % (what, rk)
-        st = r.stats()
-        keys = ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible")
-        assert [st[k] for k in keys] == [wst[k] for k in keys]
+    H.assert_rank_counts([r.stats() for r in g.ranks], wst)
 
 
 PIPELINED = [
@@ -202,8 +200,19 @@ def test_bench_two_ranks_self_spawned_on_one_device(gpu):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["exchange"] == "torch"
     assert line["config"]["workload"] == "street_720p_hzb" and line["single_gpu_same_workload"]["workload"] == "street_720p_hzb"
     assert line["speedup_vs_single"] > 0 and line["value"] > 0
-    # the sharded frames submit exactly the triangles the single-GPU frames do
     assert line["counts_view_a"]["countInstanceCulled"] > 0
+    # per rank: GPU time of every phase and both exchanges, so that a scaling record explains itself
+    assert len(line["phases_ms"]) == 2 and {p["rank"] for p in line["phases_ms"]} == {0, 1}
+    assert all(k in line["phases_ms"][0] for k in ("phase_a_stage0", "exchange_hzb", "phase_b_stage1", "exchange_vis", "phase_c_final_hzb"))
+
+
+def test_bench_two_ranks_group_fallback_on_one_device(gpu):
+    """`--exchange group`: the third way to a scaling curve when RCCL does not come up -- rank 0 drives every device through
+    ChordGroup (peer copies), the other processes wait.  Two 'devices' = device 0 twice here."""
+    line = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "4", "--workload", "street_720p_hzb", "--exchange", "group"],
+                      {"CHORDVIS_BENCH_BACKEND": "gloo", "CHORDVIS_BENCH_ONE_DEVICE": "1"})
+    assert line["n_gpus"] == 2 and line["exchange"] == "group" and line["value"] > 0 and line["speedup_vs_single"] > 0
+    assert len(line["phases_ms"]) == 2 and all("exchange_vis" in p for p in line["phases_ms"])
 
 
 def test_bench_single_gpu_line_has_the_contract_fields(gpu):
