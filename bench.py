@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--workload", default="auto", help="street_4k_hzb | street_x64_4k_hzb | street_x16_4k_hzb | subpixel_1g | subpixel_64m | atrium_1080p")
     ap.add_argument("--exchange", default="auto", choices=("auto", "lib", "torch", "group"),
                     help="N > 1: who issues the all-gathers -- the library over RCCL, torch.distributed, or one process with N devices (ChordGroup, peer copies); auto = the first that works")
+    ap.add_argument("--pipelined", action="store_true", help="N > 1, --exchange lib: the visibility all-gather of frame i runs beside frame i + 1 (second RCCL communicator)")
+    ap.add_argument("--stripe-rows", type=int, default=0, help="N > 1: rows per stripe (even); 0 = chordvis_pick_stripe_rows")
     ap.add_argument("--cpu-baseline-frames", type=int, default=48, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
     ap.add_argument("--cull", default="flat", choices=("flat", "hierarchical"),
                     help="instanceCulling: the reference's flat group dispatch, or the BVH walk (same command list)")
@@ -142,15 +144,13 @@ def main():
     if args.cull == "hierarchical":
         r.set_cull_mode(1)
     r.upload_scene(scene)
+    stripe_rows = 0
     if world > 1:
         from chord_amd.sharding import pick_stripe_rows
-        r.set_shard(pick_stripe_rows(H, world), world, rank)
+        stripe_rows = args.stripe_rows or pick_stripe_rows(H, world)
+        r.set_shard(stripe_rows, world, rank)
     r.allocate_gbuffer(W, H)
-    words = r.visibility_words()
-    vis_t = torch.zeros(words, dtype=torch.int64, device=dev)      # caller-owned visibility (all-gather target)
-    r.allocate_gbuffer(W, H, vis_t.data_ptr())
-    chunk = r.visibility_chunk_words()
-    vis_mine = vis_t[rank * chunk:(rank + 1) * chunk]
+    vis_t = vis_mine = None                              # (--exchange torch: a caller-owned visibility buffer, below)
 
     # ---- who issues the two all-gathers of a sharded frame -------------------------------------------------------
     #   lib    the library (RCCL communicator attached to the context: ONE call per frame, like the reference's host)
@@ -223,8 +223,22 @@ def main():
             raise SystemExit("--exchange %s: no exchange could be set up: %r" % (args.exchange, fallbacks))
     if exchange == "group":
         r.close()                                        # (the group makes its own contexts, one per device)
-        del vis_t
         return run_group(args, wl, scene, views, (obj_a, obj_b), flags, W, H, world, rank, dev, stream, fallbacks)
+
+    pipelined = False
+    if exchange == "lib" and args.pipelined:
+        # the image of frame i travels beside frame i + 1 on a second communicator (chordvis_comm_set_pipelined)
+        from chord_amd.renderer import comm_unique_id
+        uid2 = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid2, src=0)
+        r.comm_set_pipelined(uid2[0])
+        pipelined = True
+    if exchange == "torch":
+        words = r.visibility_words()
+        vis_t = torch.zeros(words, dtype=torch.int64, device=dev)      # caller-owned visibility (all-gather target)
+        r.allocate_gbuffer(W, H, vis_t.data_ptr())
+        chunk = r.visibility_chunk_words()
+        vis_mine = vis_t[rank * chunk:(rank + 1) * chunk]
 
     def all_gather(full, mine):
         if backend == "nccl":
@@ -457,6 +471,8 @@ def main():
         }
         if world > 1:
             line["exchange"] = exchange
+            line["pipelined"] = pipelined
+            line["stripe_rows"] = stripe_rows
             line["exchange_fallbacks"] = fallbacks
             line["phases_ms"] = phases
             line["rccl_ranks"] = comm["ranks"] if (comm and exchange == "lib") else (dist.get_world_size() if backend == "nccl" else 0)

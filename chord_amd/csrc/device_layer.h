@@ -272,6 +272,12 @@ struct ChordCtx {
     uint32_t width = 0, height = 0;
     chord::ShardInfo shard{64, 1, 0, 0};
     void* comm = nullptr;             // ncclComm_t of a one-process-per-GPU host (chordvis_comm_init_rank), or null
+    // pipelined frames over RCCL (chordvis_comm_set_pipelined): a second communicator carries the image of frame i beside frame i + 1
+    void* commBulk = nullptr;
+    hipStream_t commResolveStream = nullptr;
+    hipEvent_t commPhaseB = nullptr, commVisReady[2] = {nullptr, nullptr};
+    bool commPipelined = false;
+    uint64_t commFrameSerial = 0;
     uint64_t* dVis = nullptr;         // in use (owned or caller's)
     uint64_t* dVisOwned = nullptr;
     uint64_t* dVisResolved = nullptr; // row-major copy when ranks > 1

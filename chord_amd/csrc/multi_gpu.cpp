@@ -146,15 +146,58 @@ int chordvis_comm_init_rank(ChordCtx* c, uint32_t nranks, uint32_t rank, const v
     return CHORDVIS_OK;
 }
 
+static void comm_drop_pipeline(ChordCtx* c, const Rccl* r)
+{
+    if (c->commResolveStream) (void)hipStreamSynchronize(c->commResolveStream);
+    if (c->commBulk && r) (void)r->CommDestroy((NcclComm)c->commBulk);
+    c->commBulk = nullptr;
+    if (c->commResolveStream) { (void)hipStreamDestroy(c->commResolveStream); c->commResolveStream = nullptr; }
+    if (c->commPhaseB) { (void)hipEventDestroy(c->commPhaseB); c->commPhaseB = nullptr; }
+    for (int k = 0; k < 2; k++) if (c->commVisReady[k]) {
+        if (c->visReadyEvent[0] == c->commVisReady[k]) c->visReadyEvent[0] = nullptr;
+        if (c->visReadyEvent[1] == c->commVisReady[k]) c->visReadyEvent[1] = nullptr;
+        (void)hipEventDestroy(c->commVisReady[k]); c->commVisReady[k] = nullptr;
+    }
+    c->commPipelined = false;
+}
+
 int chordvis_comm_destroy(ChordCtx* c)
 {
     if (!c) return CHORDVIS_E_INVALID;
-    if (c->comm) {
+    if (c->comm || c->commBulk) {
         const Rccl* r = rccl();
         (void)hipStreamSynchronize(c->stream);
-        if (r) (void)r->CommDestroy((NcclComm)c->comm);
+        comm_drop_pipeline(c, r);
+        if (r && c->comm) (void)r->CommDestroy((NcclComm)c->comm);
         c->comm = nullptr;
     }
+    return CHORDVIS_OK;
+}
+
+// Pipelined frames over RCCL (the ChordGroup form: chordvis_group_set_pipelined).  id128: a SECOND unique id, for the
+// communicator that carries the 66 MB image of frame i on a stream of its own while frame i + 1 is rendered; NULL switches the
+// protocol off again (after the frames in flight have drained).
+int chordvis_comm_set_pipelined(ChordCtx* c, const void* id128)
+{
+    if (!c || !c->comm) return fail(c, CHORDVIS_E_INVALID, "comm_set_pipelined: chordvis_comm_init_rank must come first");
+    const Rccl* r = rccl();
+    if (!r) return fail(c, CHORDVIS_E_COMM, gRcclError.c_str());
+    CHORD_HIP(c, hipSetDevice(c->device));
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    comm_drop_pipeline(c, r);
+    if (!id128) return CHORDVIS_OK;
+    if (c->visExternal) return fail(c, CHORDVIS_E_INVALID, "comm_set_pipelined: the context must own its visibility buffer (two frames are alive at once)");
+    NcclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    NcclComm comm = nullptr;
+    const int rc = r->CommInitRank(&comm, (int)c->shard.ranks, id, (int)c->shard.rank);
+    if (rc != kNcclSuccess) return nccl_fail(c, r, "ncclCommInitRank (image communicator)", rc);
+    c->commBulk = comm;
+    CHORD_HIP(c, hipStreamCreateWithFlags(&c->commResolveStream, hipStreamNonBlocking));
+    CHORD_HIP(c, hipEventCreateWithFlags(&c->commPhaseB, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) CHORD_HIP(c, hipEventCreateWithFlags(&c->commVisReady[k], hipEventDisableTiming));
+    c->commPipelined = true;
+    c->commFrameSerial = 0;
     return CHORDVIS_OK;
 }
 
@@ -177,10 +220,82 @@ namespace chord {
 // inside them on their streams and would wait forever otherwise.  Whether the mid-frame exchange happens is decided before
 // phase a from state every rank shares (frame history + flags), like the ChordGroup path; the first error is returned after
 // the last collective.
+// ---- pipelined frame of one rank, shared by the two transports ---------------------------------------------------------------
+// (chordvis_comm_set_pipelined over RCCL, chordvis_group_set_pipelined over peer copies)  The image of frame i is
+// gathered on the side -- behind the rank's "phase b done" point, on the resolve stream -- and copied to row-major there, while
+// the compute stream goes on to the history HZB, built from three small exchanges of own-stripe data (mip 0 of the min and max
+// chains, the valid-range pair) instead of from the gathered image, and then to frame i + 1, which rasters into the other
+// buffer pair.  The pair a frame takes over was last used two frames ago; the caller has waited for that frame's "image
+// complete" event (and, in a group, for every rank to have done so) before calling.  ONE body, so that the sequence the
+// one-device group tests exercise with 2..8 ranks is the sequence an RCCL host runs; a transport supplies
+//   small(which, base, chunkBytes)   all-gather of a rank-major buffer of the context, ordered on the compute stream
+//   image()                          all-gather of the current visibility buffer behind everything enqueued so far on the compute
+//                                    stream, such that `resolveStream` may read the complete buffer afterwards
+// A failing step is remembered; the rank still walks through every exchange (its peers are inside them).
+template <class Transport>
+int pipelined_frame_body(ChordCtx* c, hipEvent_t visReadyThis, hipEvent_t visReadyOther, hipStream_t resolveStream, Transport& tr)
+{
+    int rc = CHORDVIS_OK;
+    { const int e = chordvis_swap_visibility(c); if (!rc) rc = e; }
+    c->visReadyEvent[0] = visReadyThis;
+    c->visReadyEvent[1] = visReadyOther;
+    const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
+    if (!rc) rc = chordvis_frame_phase_a(c);
+    const size_t hzbBytes = (size_t)c->hzbExchangeChunkHalves * 2;
+    if (stage1) { const int e = tr.small(0, hzbBytes); if (!rc) rc = e; }
+    if (!rc) rc = chordvis_frame_phase_b(c);
+    {
+        int e = tr.image();
+        if (!rc) rc = e;
+        if (!rc) rc = chordvis_frame_resolve_visibility(c, resolveStream);
+        const hipError_t he = hipEventRecord(visReadyThis, resolveStream);
+        if (he != hipSuccess && !rc) rc = fail(c, CHORDVIS_E_HIP, "hipEventRecord(image complete)", he);
+    }
+    if (!rc) rc = chordvis_frame_phase_c_begin(c);
+    { int e = tr.small(0, hzbBytes); if (!rc) rc = e; e = tr.small(1, hzbBytes); if (!rc) rc = e; e = tr.small(2, 8); if (!rc) rc = e; }
+    if (!rc) rc = chordvis_frame_phase_c_finish(c);
+    return rc;
+}
+
+// the rank-major exchange buffers of a context by number: 0 = HZB min mip 0, 1 = HZB max mip 0, 2 = valid-range pairs
+static char* exchange_buffer(ChordCtx* c, int which)
+{
+    return which == 0 ? reinterpret_cast<char*>(c->dHzbExchange) : which == 1 ? reinterpret_cast<char*>(c->dHzbExchangeMax) : reinterpret_cast<char*>(c->dRangeExchange);
+}
+
+struct RcclTransport {
+    ChordCtx* c; const Rccl* r;
+    int small(int which, size_t bytes)
+    {
+        char* base = exchange_buffer(c, which);
+        const int e = r->AllGather(base + (size_t)c->shard.rank * bytes, base, bytes, kNcclUint8, (NcclComm)c->comm, c->stream);
+        return e == kNcclSuccess ? CHORDVIS_OK : nccl_fail(c, r, "ncclAllGather(exchange buffer)", e);
+    }
+    int image()
+    {
+        hipError_t he = hipEventRecord(c->commPhaseB, c->stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(c->commResolveStream, c->commPhaseB, 0);
+        if (he != hipSuccess) return fail(c, CHORDVIS_E_HIP, "image gather: stream order", he);
+        const size_t words = (size_t)(c->visWords / c->shard.ranks);
+        const int e = r->AllGather(c->dVis + (size_t)c->shard.rank * words, c->dVis, words, kNcclUint64, (NcclComm)c->commBulk, c->commResolveStream);
+        return e == kNcclSuccess ? CHORDVIS_OK : nccl_fail(c, r, "ncclAllGather(visibility)", e);
+    }
+};
+
+static int comm_render_frame_pipelined(ChordCtx* c, const Rccl* r)
+{
+    const int parity = (int)(c->commFrameSerial++ & 1u);
+    const hipError_t he = hipEventSynchronize(c->commVisReady[parity]);      // (a never-recorded event reads as complete)
+    RcclTransport tr{c, r};
+    const int rc = pipelined_frame_body(c, c->commVisReady[parity], c->commVisReady[parity ^ 1], c->commResolveStream, tr);
+    return he != hipSuccess ? fail(c, CHORDVIS_E_HIP, "hipEventSynchronize(image of two frames ago)", he) : rc;
+}
+
 int comm_render_frame(ChordCtx* c)
 {
     const Rccl* r = rccl();
     if (!r || !c->comm) return fail(c, CHORDVIS_E_COMM, "render_frame: sharded context without a communicator (chordvis_comm_init_rank, or drive chordvis_frame_phase_a/b/c)");
+    if (c->commPipelined) return comm_render_frame_pipelined(c, r);
     const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
     int rc = chordvis_frame_phase_a(c);
     if (stage1) {
@@ -510,55 +625,40 @@ int chordvis_group_set_pipelined(ChordGroup* g, int enable)
     return CHORDVIS_OK;
 }
 
+struct GroupTransport {
+    ChordGroup* g; uint32_t r; int parity;
+    int small(int which, size_t bytes)
+    {
+        return group_all_gather(g, r, 0, [&, which](uint32_t k) { return chord::exchange_buffer(g->ctx[k], which); }, bytes);
+    }
+    int image()
+    {
+        ChordCtx* c = g->ctx[r];
+        const int e = group_all_gather(g, r, 2 + parity, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dVis); },
+                                       (size_t)(c->visWords / g->n) * 8, g->resolveStream[r], true);
+        // (the resolve stream also needs the rank's own chunk: the `ready` event of this exchange was recorded on the compute
+        // stream after phase b)
+        const hipError_t he = hipStreamWaitEvent(g->resolveStream[r], g->evReady[2 + parity][r], 0);
+        if (he != hipSuccess && !e) return fail(c, CHORDVIS_E_HIP, "image gather: own chunk", he);
+        return e;
+    }
+};
+
 static int group_render_frame_pipelined(ChordGroup* g)
 {
     const uint64_t serial = g->frameSerial++;
     const int parity = (int)(serial & 1u);
     return run_all(g, [&, parity](uint32_t r) {
         ChordCtx* c = g->ctx[r];
-        int rc = CHORDVIS_OK;
-#define GP_HIP(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess && !rc) rc = fail(c, CHORDVIS_E_HIP, #call, e_); } while (0)
         // the buffer pair this frame takes over was last used two frames ago: its gather and copy are complete on every rank
         // once every rank has seen its "image complete" event of that frame (recorded behind the waits for all copies into
         // AND out of the rank's buffer).  NOT a drain of the resolve stream: the previous frame's image is still travelling,
         // and this frame's kernels are to be enqueued beside it.
-        GP_HIP(hipEventSynchronize(g->evVisReady[parity][r]));
+        const hipError_t he = hipEventSynchronize(g->evVisReady[parity][r]);
         group_barrier(g);
-        { const int e = chordvis_swap_visibility(c); if (!rc) rc = e; }
-        c->visReadyEvent[0] = g->evVisReady[parity][r];
-        c->visReadyEvent[1] = g->evVisReady[parity ^ 1][r];
-        const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
-        if (!rc) rc = chordvis_frame_phase_a(c);
-        if (stage1) {
-            const int e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dHzbExchange); },
-                                           (size_t)c->hzbExchangeChunkHalves * 2);
-            if (!rc) rc = e;
-        }
-        if (!rc) rc = chordvis_frame_phase_b(c);
-        // the image: gathered and copied beside what follows (and beside the next frame)
-        {
-            const int e = group_all_gather(g, r, 2 + parity, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dVis); },
-                                           (size_t)(c->visWords / g->n) * 8, g->resolveStream[r], true);
-            if (!rc) rc = e;
-            // (the resolve stream also needs the rank's own chunk: the `ready` event of this exchange was recorded on the
-            // compute stream after phase b)
-            GP_HIP(hipStreamWaitEvent(g->resolveStream[r], g->evReady[2 + parity][r], 0));
-            if (!rc) rc = chordvis_frame_resolve_visibility(c, g->resolveStream[r]);
-            GP_HIP(hipEventRecord(g->evVisReady[parity][r], g->resolveStream[r]));
-        }
-        // the history HZB, from the ranks' own-stripe mip 0
-        if (!rc) rc = chordvis_frame_phase_c_begin(c);
-        {
-            int e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dHzbExchange); }, (size_t)c->hzbExchangeChunkHalves * 2);
-            if (!rc) rc = e;
-            e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dHzbExchangeMax); }, (size_t)c->hzbExchangeChunkHalves * 2);
-            if (!rc) rc = e;
-            e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dRangeExchange); }, 8);
-            if (!rc) rc = e;
-        }
-        if (!rc) rc = chordvis_frame_phase_c_finish(c);
-#undef GP_HIP
-        return rc;
+        GroupTransport tr{g, r, parity};
+        const int rc = chord::pipelined_frame_body(c, g->evVisReady[parity][r], g->evVisReady[parity ^ 1][r], g->resolveStream[r], tr);
+        return he != hipSuccess ? fail(c, CHORDVIS_E_HIP, "hipEventSynchronize(image of two frames ago)", he) : rc;
     }, "group_render_frame (pipelined)");
 }
 

@@ -9,10 +9,11 @@
 //   meshopt_buildMeshlets (vendored meshoptimizer 0.21, MIT)  -> clusterize(): own greedy growth over triangle adjacency
 //   meshopt_computeMeshletBounds (same library, meshopt_clusterizer.cpp:792-845) -> meshlet_bounds(): the cone part FOLLOWS
 //       that function (credit: meshoptimizer, (c) Arseny Kapoulkine, MIT licence) -- the `mindp <= 0.1` cut, cutoff =
-//       sqrt(1 - mindp^2) and apex = center - axis * max(dc / dn) are its formulas and its names; simplified here: the axis is
-//       the normalised MEAN normal (meshoptimizer fits a bounding sphere of the normals) and the centre is the AABB's (it uses
-//       the bounding sphere's).  tests/test_nanite_builder.py checks the result against fixtures produced by the vendored
-//       function itself (tests/golden/meshopt_bounds.json): never less conservative, and within a stated angle of it
+//       sqrt(1 - mindp^2) and apex = center - axis * max(dc / dn) are its formulas and its names, and like it the axis is the
+//       centre of a bounding sphere of the normals and the reference point the centre of one of the positions (own
+//       implementation of Ritter's sphere, bounding_sphere()).  tests/test_nanite_builder.py checks the result against fixtures
+//       produced by the vendored function itself (tests/golden/meshopt_bounds.json): safe against ground truth, never culls a
+//       sampled camera the reference's cone keeps, axis within a stated angle of it
 //   METIS_PartGraphKway (binary-only in the reference tree, version not recorded)          -> partition_groups(): greedy
 //       graph growing by shared-edge weight into parts of min(n / 2, 4) meshlets
 //   meshopt_simplifyWithAttributes (LockBorder | Sparse | ErrorAbsolute)                   -> simplify(): half-edge collapses
@@ -62,13 +63,50 @@ struct BMeshlet {
 inline uint64_t edge_key(uint32_t a, uint32_t b) { return a < b ? ((uint64_t)b << 32) | a : ((uint64_t)a << 32) | b; }
 
 // ---- buildMeshlets: greedy growth over the triangle adjacency ---------------------------------------------------------
+// Ritter's approximate bounding sphere (1990): the most separated pair of the six axis-extremal points seeds the sphere,
+// every point still outside grows it just enough.  Used for the meshlet's positions (cone apex reference point) and for its
+// unit normals seen as points (the centre of THAT sphere is the cone axis: a minimal-cone estimate instead of the mean
+// normal, which a few outlying triangles tilt away from the bulk).
+struct Sphere { V3 c; float r; };
+Sphere bounding_sphere(const std::vector<V3>& pts)
+{
+    Sphere s{{0, 0, 0}, 0.0f};
+    if (pts.empty()) return s;
+    size_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (size_t i = 0; i < pts.size(); i++) {
+        const float v[3] = {pts[i].x, pts[i].y, pts[i].z};
+        for (int k = 0; k < 3; k++) {
+            const float l = k == 0 ? pts[lo[k]].x : k == 1 ? pts[lo[k]].y : pts[lo[k]].z;
+            const float h = k == 0 ? pts[hi[k]].x : k == 1 ? pts[hi[k]].y : pts[hi[k]].z;
+            if (v[k] < l) lo[k] = i;
+            if (v[k] > h) hi[k] = i;
+        }
+    }
+    int best = 0; float bestD = -1.0f;
+    for (int k = 0; k < 3; k++) { const V3 d = pts[hi[k]] - pts[lo[k]]; const float d2 = dot(d, d); if (d2 > bestD) { bestD = d2; best = k; } }
+    s.c = (pts[lo[best]] + pts[hi[best]]) * 0.5f;
+    s.r = std::sqrt(bestD) * 0.5f;
+    for (const V3& p : pts) {
+        const V3 d = p - s.c;
+        const float d2 = dot(d, d);
+        if (d2 > s.r * s.r) {
+            const float dl = std::sqrt(d2), k = 0.5f + (s.r / dl) * 0.5f;      // new centre between the far side of the old sphere and p
+            s.c = s.c * k + p * (1.0f - k);
+            s.r = (s.r + dl) * 0.5f;
+        }
+    }
+    return s;
+}
+
+// Bounds + normal cone of a meshlet.  The cone follows meshopt_computeMeshletBounds (vendored meshoptimizer 0.21,
+// meshopt_clusterizer.cpp:792-845, MIT): axis = centre of the normals' bounding sphere, `mindp <= 0.1` -> no cone, cutoff =
+// sqrt(1 - mindp^2), apex = centre - axis * max(dc / dn) -- its formulas and names, see the header comment.
 void meshlet_bounds(BMeshlet& m, const std::vector<V3>& pos)
 {
     m.posMin = {FLT_MAX, FLT_MAX, FLT_MAX}; m.posMax = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (uint32_t v : m.verts) { m.posMin = vmin(m.posMin, pos[v]); m.posMax = vmax(m.posMax, pos[v]); }
     const size_t T = m.tris.size() / 3;
-    std::vector<V3> normals, corners;
-    V3 axis = {0, 0, 0};
+    std::vector<V3> normals, corners, used;
     for (size_t t = 0; t < T; t++) {
         const V3 a = pos[m.verts[m.tris[3 * t]]], b = pos[m.verts[m.tris[3 * t + 1]]], c = pos[m.verts[m.tris[3 * t + 2]]];
         V3 n = cross(b - a, c - a);
@@ -76,12 +114,14 @@ void meshlet_bounds(BMeshlet& m, const std::vector<V3>& pos)
         if (l == 0.0f) continue;
         n = n * (1.0f / l);
         normals.push_back(n); corners.push_back(a);
-        axis = axis + n;
+        used.push_back(a); used.push_back(b); used.push_back(c);
     }
-    const V3 center = (m.posMin + m.posMax) * 0.5f;
-    const float al = len(axis);
     m.coneAxis = {0, 0, 0}; m.coneApex = {0, 0, 0}; m.coneCutOff = 1.0f;          // degenerate: never culled (dot <= 1 is >= 1 only at equality)
-    if (normals.empty() || al == 0.0f) return;
+    if (normals.empty()) return;
+    const V3 center = bounding_sphere(used).c;
+    V3 axis = bounding_sphere(normals).c;
+    const float al = len(axis);
+    if (al == 0.0f) return;
     axis = axis * (1.0f / al);
     float mindp = 1.0f;
     for (const V3& n : normals) mindp = std::min(mindp, dot(n, axis));
@@ -93,7 +133,8 @@ void meshlet_bounds(BMeshlet& m, const std::vector<V3>& pos)
     }
     m.coneAxis = axis;
     m.coneApex = center - axis * maxt;
-    m.coneCutOff = std::sqrt(1.0f - mindp * mindp);
+    // (a hair wider than the exact bound: the runtime evaluates the test in fp32 after a matrix transform of the camera)
+    m.coneCutOff = std::min(1.0f, std::sqrt(1.0f - mindp * mindp) + 1.0e-4f);
 }
 
 std::vector<BMeshlet> clusterize(const std::vector<V3>& pos, const std::vector<uint32_t>& indices, uint32_t lod, float error, V3 clusterCenter)
@@ -412,6 +453,29 @@ struct ChordBuiltAsset {
 };
 
 extern "C" {
+
+// The bounds and normal cone the builder gives a meshlet, for a meshlet handed in as such (tests: against the reference's
+// meshopt_computeMeshletBounds, tests/golden/meshopt_bounds.json).  positions: the meshlet's own vertices; triangles: 3 local
+// indices per triangle.
+int chordvis_meshlet_bounds(const float* positions, uint32_t vertexCount, const uint8_t* triangles, uint32_t triangleCount, ChordMeshlet* out)
+{
+    if (!positions || !triangles || !out || vertexCount == 0 || vertexCount > 255 || triangleCount == 0 || triangleCount > 128) return CHORDVIS_E_INVALID;
+    std::vector<V3> pos(vertexCount);
+    for (uint32_t v = 0; v < vertexCount; v++) pos[v] = {positions[3 * v], positions[3 * v + 1], positions[3 * v + 2]};
+    BMeshlet m;
+    m.verts.resize(vertexCount);
+    for (uint32_t v = 0; v < vertexCount; v++) m.verts[v] = v;
+    for (uint32_t t = 0; t < triangleCount * 3; t++) { if (triangles[t] >= vertexCount) return CHORDVIS_E_INVALID; m.tris.push_back(triangles[t]); }
+    meshlet_bounds(m, pos);
+    std::memset(out, 0, sizeof(*out));
+    out->posMin[0] = m.posMin.x; out->posMin[1] = m.posMin.y; out->posMin[2] = m.posMin.z;
+    out->posMax[0] = m.posMax.x; out->posMax[1] = m.posMax.y; out->posMax[2] = m.posMax.z;
+    out->coneAxis[0] = m.coneAxis.x; out->coneAxis[1] = m.coneAxis.y; out->coneAxis[2] = m.coneAxis.z;
+    out->coneApex[0] = m.coneApex.x; out->coneApex[1] = m.coneApex.y; out->coneApex[2] = m.coneApex.z;
+    out->coneCutOff = m.coneCutOff;
+    out->vertexTriangleCount = vertexCount | (triangleCount << 8);
+    return CHORDVIS_OK;
+}
 
 int chordvis_nanite_build(const float* positionsIn, uint32_t vertexCount, const uint32_t* indicesIn, uint32_t indexCount,
                           const float* texcoord0, ChordBuiltAsset** out)

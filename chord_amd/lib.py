@@ -110,6 +110,7 @@ def _load():
         "chordvis_object_basic_data": (i32, [vp, vp, vp, vp, vp]),
         "chordvis_object_basic_data_batch": (i32, [u32, vp, vp, vp, vp, vp]),
         "chordvis_nanite_build": (i32, [vp, u32, vp, u32, vp, P(vp)]),
+        "chordvis_meshlet_bounds": (i32, [vp, u32, vp, u32, vp]),
         "chordvis_built_asset_desc": (i32, [vp, P(R.AssetDesc), vp, P(u32)]),
         "chordvis_free_built_asset": (None, [vp]),
         "chordvis_save_asset": (i32, [vp, C.c_char_p]),
@@ -167,6 +168,7 @@ def _load():
         "chordvis_comm_unique_id": (i32, [vp]),
         "chordvis_comm_init_rank": (i32, [vp, u32, u32, vp]),
         "chordvis_comm_destroy": (i32, [vp]),
+        "chordvis_comm_set_pipelined": (i32, [vp, vp]),
         "chordvis_comm_info": (i32, [vp, P(i32), P(u32), vp, u32]),
         "chordvis_create_group": (i32, [u32, P(i32), P(vp)]),
         "chordvis_destroy_group": (i32, [vp]),
@@ -207,6 +209,8 @@ def _load():
             missing.append(name)
             continue
         fn.restype, fn.argtypes = res, args
+    if missing and os.environ.get("CHORDVIS_AB_OLD_LIB") == "1":
+        missing = []                                     # measurement only: A/B against a library of an earlier round (tools/)
     if missing:
         raise ChordvisError("libchordvis.so lacks symbols declared in include/chordvis.h: %s" % ", ".join(missing))
     return lib, sorted(protos)

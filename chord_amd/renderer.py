@@ -142,6 +142,11 @@ class VisibilityRenderer:
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         self._check(L.lib.chordvis_comm_init_rank(self._ctx, nranks, rank, buf), "comm_init_rank")
 
+    def comm_set_pipelined(self, unique_id):
+        """Second communicator (its own unique id, or None to switch off): the image of frame i travels beside frame i + 1."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id)) if unique_id is not None else None
+        self._check(L.lib.chordvis_comm_set_pipelined(self._ctx, buf), "comm_set_pipelined")
+
     def comm_destroy(self):
         self._check(L.lib.chordvis_comm_destroy(self._ctx), "comm_destroy")
 

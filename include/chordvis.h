@@ -168,6 +168,10 @@ int chordvis_object_basic_data_batch(uint32_t count, const double* localToWorld 
 typedef struct ChordBuiltAsset ChordBuiltAsset;
 int chordvis_nanite_build(const float* positions, uint32_t vertexCount, const uint32_t* indices, uint32_t indexCount,
                           const float* texcoord0, ChordBuiltAsset** outAsset);
+/* bounds + normal cone of ONE meshlet as the builder computes them (posMin/posMax, coneAxis, coneCutOff, coneApex of `out`;
+ * the reference: meshopt_computeMeshletBounds, nanite_builder.cpp:476-486).  positions: the meshlet's own <= 255 vertices;
+ * localTriangles: 3 indices into them per triangle (<= 128 triangles). */
+int chordvis_meshlet_bounds(const float* positions, uint32_t vertexCount, const uint8_t* localTriangles, uint32_t triangleCount, ChordMeshlet* out);
 /* views into the built arrays (valid until chordvis_free_built_asset): one ChordAssetDesc holding one primitive */
 int chordvis_built_asset_desc(const ChordBuiltAsset* asset, ChordAssetDesc* outAsset, ChordPrimitive* outPrimitive, uint32_t* outLodCount);
 void chordvis_free_built_asset(ChordBuiltAsset* asset);
@@ -310,6 +314,12 @@ uint32_t chordvis_pick_stripe_rows(uint32_t height, uint32_t ranks);
 int chordvis_comm_unique_id(void* out128);
 int chordvis_comm_init_rank(ChordCtx* ctx, uint32_t nranks, uint32_t rank, const void* id128);
 int chordvis_comm_destroy(ChordCtx* ctx);
+/* Pipelined frames over RCCL (the ChordGroup form: chordvis_group_set_pipelined below).  id128: a SECOND unique id (the same
+ * on every rank) for the communicator that carries the image of frame i, on a stream of its own, beside frame i + 1; the
+ * history HZB then comes from three small exchanges of own-stripe data instead of from the gathered image (bit for bit the
+ * same chain).  chordvis_readback_visibility / chordvis_visibility_mark / chordvis_wait_visibility wait for the image.
+ * NULL switches back to the plain protocol.  The context must own its visibility buffer. */
+int chordvis_comm_set_pipelined(ChordCtx* ctx, const void* id128);
 /* NCCL_VERSION_CODE of the loaded library, ranks of ctx's communicator (0 = none; ctx may be NULL), where librccl came from */
 int chordvis_comm_info(ChordCtx* ctx, int* ncclVersion, uint32_t* nranks, char* libraryOrigin, uint32_t originBytes);
 

@@ -331,7 +331,7 @@ def test_config5_hotspot_reduced_matches_oracle(gpu):
         assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["stats"].trianglesSubmitted
         # the contention case: most tiles of the screen are empty, the hot ones hold tens of thousands of entries
         assert st["tilesTouched"][0] < 0.5 * ((W + 63) // 64) * ((Hh + 63) // 64)
-        assert st["binEntries"] / max(1, st["tilesTouched"][0]) > (1000 if mode == FORCE_BLOCKS else 20000)
+        assert st["binEntries"] / max(1, st["tilesTouched"][0]) > (300 if mode == FORCE_BLOCKS else 20000)   # (a block per cluster and tile / a record per triangle)
         r.close()
 
 

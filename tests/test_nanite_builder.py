@@ -136,3 +136,67 @@ def test_built_meshes_render_like_the_oracle(gpu, hier):
         H.assert_vis_equal(r.read_visibility(), want["vis"], cam.width, cam.height, "built meshes, frame %d" % frame)
         prev = want["hzb_min"]
     r.close()
+
+
+# ---- the builder's meshlet bounds against the REFERENCE's (vendored meshoptimizer, tests/golden/meshopt_bounds.json) ---------
+def _cone_culls(apex, axis, cutoff, cam):
+    """nanite_shared.hlsli:65-75 / meshopt convention: culled iff dot(normalize(apex - cam), axis) >= cutoff."""
+    v = apex - cam
+    n = np.linalg.norm(v)
+    return n > 0 and float(np.dot(v / n, axis)) >= cutoff
+
+
+def test_meshlet_bounds_against_the_reference_meshoptimizer_fixture():
+    """207 meshlets built by the reference's own meshopt_buildMeshlets (two bumpy spheres, a cube) with the bounds its
+    meshopt_computeMeshletBounds gives them (fixture: make_meshopt_fixture.sh compiles the vendored sources in the build
+    container).  chordvis_meshlet_bounds -- what chordvis_nanite_build stores -- must
+      * be SAFE: a camera position its cone culls sees every triangle of the meshlet from behind (ground truth, the property
+        the runtime's cone test relies on; the reference's cone is held to the same bar to validate the sampling);
+      * be as conservative as the reference's cone where both are cones: it never culls a sampled camera the reference keeps;
+      * stay near it: axis within half a degree, and the AABB containing the reference's bounding sphere centre."""
+    import ctypes as C
+    import json
+    import os
+    from chord_amd import lib as L, records as R
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meshopt_bounds.json")))
+    rng = np.random.default_rng(7)
+    dirs = rng.normal(size=(96, 3))
+    dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    checked = cones = stricter = 0
+    worst_angle = 0.0
+    for mesh in fx["meshes"]:
+        for ml in mesh["meshlets"]:
+            pos = np.asarray(ml["positions"], np.float32).reshape(-1, 3)
+            tri = np.asarray(ml["triangles"], np.uint8).reshape(-1, 3)
+            out = np.zeros(1, dtype=R.MESHLET)
+            assert L.lib.chordvis_meshlet_bounds(pos.ctypes.data, len(pos), tri.ctypes.data, len(tri), out.ctypes.data) == 0
+            m = out[0]
+            assert np.allclose(m["posMin"], pos.min(axis=0)) and np.allclose(m["posMax"], pos.max(axis=0))
+            rc, rr = np.asarray(ml["center"], np.float64), ml["radius"]
+            assert (rc >= m["posMin"] - 1e-5).all() and (rc <= m["posMax"] + 1e-5).all()
+            axis, apex, cutoff = m["coneAxis"].astype(np.float64), m["coneApex"].astype(np.float64), float(m["coneCutOff"])
+            raxis, rapex, rcut = np.asarray(ml["cone_axis"]), np.asarray(ml["cone_apex"]), ml["cone_cutoff"]
+            p64 = pos.astype(np.float64)
+            a, b, c = p64[tri[:, 0]], p64[tri[:, 1]], p64[tri[:, 2]]
+            nrm = np.cross(b - a, c - a)
+            keep = np.linalg.norm(nrm, axis=1) > 0
+            nrm, a = nrm[keep], a[keep]
+            if rcut < 1.0 and cutoff < 1.0:
+                cones += 1
+                ang = np.degrees(np.arccos(np.clip(np.dot(axis, raxis) / (np.linalg.norm(axis) * np.linalg.norm(raxis)), -1, 1)))
+                worst_angle = max(worst_angle, ang)
+            ext = float(np.linalg.norm(m["posMax"] - m["posMin"]))
+            for d in dirs:
+                for dist in (0.6 * ext, 2.0 * ext, 50.0 * ext):
+                    cam = rc + d * (rr + dist)
+                    front = (np.einsum("ij,ij->i", nrm, cam[None, :] - a) > 1e-9 * ext * ext).any()    # some triangle faces the camera
+                    ours = _cone_culls(apex, axis, cutoff, cam) if cutoff < 1.0 else False
+                    ref = _cone_culls(rapex, raxis, rcut, cam) if rcut < 1.0 else False
+                    checked += 1
+                    assert not (ours and front), "the builder's cone culls a camera that sees a front face (%s)" % mesh["name"]
+                    assert not (ref and front), "sampling check: the reference's cone culls a visible meshlet?"
+                    if ours and not ref:
+                        stricter += 1
+    assert cones >= 150 and checked > 50000
+    assert worst_angle <= 0.5, worst_angle
+    assert stricter == 0, "%d of %d sampled cameras are culled by the builder's cone but kept by meshoptimizer's" % (stricter, checked)
