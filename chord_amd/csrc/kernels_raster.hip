@@ -1688,9 +1688,14 @@ __device__ __forceinline__ int32_t scan_span_i32(unsigned long long* __restrict_
     }
     const int32_t k0 = (int32_t)klo, k1 = (int32_t)khi;
     E0 += __mul24(k0, st0); E1 += __mul24(k0, st1); E2 += __mul24(k0, st2);     // |st| <= 2^22, 0 <= k0 < 2^12: 24-bit operands
+    // (Round 3: trimming the ~3 slack pixels of the fp32 bounds with exact edge tests before the loop -- 1.5 of a row's 5.6
+    // two-pixel trips -- and predicating the merges instead of merging 0 were both measured: tile kernel 107 -> 109 / 108 us
+    // on config 3, 197 -> 200 / 197 on config 4.  The LDS atomic pipe is ~55 % busy in pass 0 but it is not what the kernel
+    // waits for; profiles/r03_tile_kernel_experiments.txt.)
     int32_t U1 = E1 - bias1, U2 = E2 - bias2;                    // the unbiased values the canonical depth uses
     unsigned long long* px = tileRow + lx0 + k0;
     const unsigned long long payload = noPixels ? 0ull : (unsigned long long)payloadIn;
+    const int32_t kFirst = k0;
     // two pixels per trip.  The second may lie one past the bound: coverage is decided by the exact edge values, and
     // the word it would touch is at most the row's padding word (lx1 <= 63), a pixel right of the screen or a pixel of
     // the next segment of the same row (which merges the same value) -- never another row.
@@ -1706,7 +1711,7 @@ __device__ __forceinline__ int32_t scan_span_i32(unsigned long long* __restrict_
         atomicMax(px + 1, insideB && !noPixels ? (((unsigned long long)__float_as_uint(zb) << 32) | payload) : 0ull);
         E0 += 2 * st0; E1 += 2 * st1; E2 += 2 * st2; U1 += 2 * st1; U2 += 2 * st2; px += 2;
     }
-    return max(k1 - k0 + 1, 0);
+    return max(k1 - kFirst + 1, 0);
 }
 
 // entry record of a triangle that needs row units; returns its unit count
