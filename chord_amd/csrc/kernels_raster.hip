@@ -298,7 +298,8 @@ __device__ __forceinline__ BinElect wave_bin_elect(bool has, uint32_t tile, uint
 __device__ __forceinline__ uint32_t bin_capacity(const RasterParams& p) { return p.binCap + p.binMaxChunks * CHORD_BIN_CHUNK; }
 
 // step 1 of a bin write: the lane that drew the first slot of an overflow chunk allocates it and publishes it.  Never waits.
-__device__ __forceinline__ void bin_alloc(const RasterParams& p, uint32_t tile, uint32_t slot)
+template <class P>
+__device__ __forceinline__ void bin_alloc(const P& p, uint32_t tile, uint32_t slot)
 {
     if (slot < p.binCap) return;
     const uint32_t o = slot - p.binCap, j = o >> CHORD_BIN_CHUNK_SHIFT;
@@ -313,7 +314,8 @@ __device__ __forceinline__ void bin_alloc(const RasterParams& p, uint32_t tile, 
 // first slot, whose atomicAdd preceded this lane's: it has passed every wait of its own earlier writes and reaches its
 // bin_alloc without waiting -- PROVIDED every caller runs bin_alloc for ALL the slots it has drawn before its first
 // bin_put; wave_bin_commit draws eight slots per lane at once and therefore allocates for all eight first).
-__device__ __forceinline__ void bin_put(const RasterParams& p, uint32_t tile, uint32_t slot, uint32_t gi)
+template <class P>
+__device__ __forceinline__ void bin_put(const P& p, uint32_t tile, uint32_t slot, uint32_t gi)
 {
     if (slot < p.binCap) { p.tileBins[(size_t)tile * p.binCap + slot] = gi; return; }
     const uint32_t o = slot - p.binCap, j = o >> CHORD_BIN_CHUNK_SHIFT;
@@ -844,6 +846,32 @@ __device__ __forceinline__ bool tri_setup_geom(TriSetup& ts, bool twoSided, int3
     return !(ts.px1 < ts.px0 || ts.py1 < ts.py0);
 }
 
+// What the block kernel needs only when a cluster's blocks are written (a few lanes, once per cluster).  Kept in scalar
+// registers across the whole loop these 22 dwords push the kernel past its 102 SGPRs, and every scalar the compiler parks in a
+// VGPR lane costs a VALU instruction each way (~300 v_readlane / v_writelane in the loop body: 15 % of its VALU work).  They
+// are re-read from the kernel-argument segment (scalar cache) right where they are used instead; the pointer goes through an
+// empty asm so that the loads cannot be hoisted back out of the loop.
+struct BlockEmitParams {
+    uint32_t* tileCount; uint32_t* tileBins; uint32_t binCap;
+    uint32_t* binPool; uint32_t binPoolChunks; uint32_t* binPoolCount;
+    unsigned long long* binChunkTab; uint32_t binStamp; uint32_t binMaxChunks;
+    unsigned long long* blockPool; uint32_t blockCap;
+    DeviceCounters* counters;
+};
+__device__ __forceinline__ BlockEmitParams load_block_emit_params()
+{
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const RasterParams* q = reinterpret_cast<const RasterParams*>(kp);            // (the kernel's one by-value argument)
+    BlockEmitParams e;
+    e.tileCount = scalar_load(&q->tileCount); e.tileBins = scalar_load(&q->tileBins); e.binCap = scalar_load(&q->binCap);
+    e.binPool = scalar_load(&q->binPool); e.binPoolChunks = scalar_load(&q->binPoolChunks); e.binPoolCount = scalar_load(&q->binPoolCount);
+    e.binChunkTab = scalar_load(&q->binChunkTab); e.binStamp = scalar_load(&q->binStamp); e.binMaxChunks = scalar_load(&q->binMaxChunks);
+    e.blockPool = scalar_load(&q->blockPool); e.blockCap = scalar_load(&q->blockCap);
+    e.counters = scalar_load(&q->counters);
+    return e;
+}
+
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 // classification of one triangle of the cluster in LDS: kind, and for K_EMIT its pixel bounds (x0 | x1 << 16, y0 | y1 << 16)
@@ -910,23 +938,34 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
     unsigned long long* win = sWin[wave];
     const uint32_t listShard = (blockIdx.x * 4u + wave) % CHORD_LIST_SHARDS;
 
+#ifdef BLK_HOT_PARAMS
+    auto kq = [&]() -> const RasterParams* { return &p; };
+#else
+    // the scene pointers are re-read from the kernel-argument segment where they are used (see BlockEmitParams)
+    auto kq = [&]() -> const RasterParams* {
+        unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        return reinterpret_cast<const RasterParams*>(kp);
+    };
+#endif
     auto header_at = [&](uint32_t i) -> SetupHeader {
         const uint32_t k = __builtin_amdgcn_readfirstlane(min(i, count - 1u));
         SetupHeader h;
-        const uint32_t* __restrict__ cw = reinterpret_cast<const uint32_t*>(p.cmds + k);
+        const RasterParams* q = kq();
+        const uint32_t* __restrict__ cw = reinterpret_cast<const uint32_t*>(scalar_load(&q->cmds) + k);
         h.objectId = scalar_load(cw); h.meshletId = scalar_load(cw + 1); h.slot = scalar_load(cw + 2);
-        const DMeshlet* __restrict__ mm = &p.meshlets[h.meshletId];
+        const DMeshlet* __restrict__ mm = &scalar_load(&q->meshlets)[h.meshletId];
         const uint32_t vt = scalar_load(&mm->vertexTriangleCount);
         h.V = vt & 0xFFu; h.T = (vt >> 8) & 0xFFu;
         h.dataOffset = scalar_load(&mm->dataOffset);
         h.vertexBase = scalar_load(&mm->vertexBase);
-        h.matFlags = scalar_load(&p.objStatic[h.objectId].matFlags);
+        h.matFlags = scalar_load(&scalar_load(&q->objStatic)[h.objectId].matFlags);
         if (CHORD_MATFLAG_ALPHA(h.matFlags) >= CHORD_ALPHA_BLEND) h.T = 0u;   // blended: in no bucket of renderMesh (mesh_raster.cpp:224)
         return h;
     };
     auto mvp_of = [&](uint32_t objectId) -> Mat4 {
         Mat4 m;
-        const float* __restrict__ mv = p.objFrame[objectId].mvp;
+        const float* __restrict__ mv = scalar_load(&kq()->objFrame)[objectId].mvp;
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -944,12 +983,14 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
     uint32_t t0 = 0, t1 = 0;
     float pax, pay, paz, pbx, pby, pbz;
     {
-        const uint32_t ia = p.meshletData[hdr.dataOffset + min(lane, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
-        const uint32_t ib = p.meshletData[hdr.dataOffset + min(lane + 64u, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
-        if (lane < hdr.T) t0 = p.meshletData[hdr.dataOffset + hdr.V + lane];
-        if (lane + 64u < hdr.T) t1 = p.meshletData[hdr.dataOffset + hdr.V + 64u + lane];
-        const float* __restrict__ pa = p.positions + (size_t)ia * 3;
-        const float* __restrict__ pb = p.positions + (size_t)ib * 3;
+        const uint32_t* __restrict__ md = scalar_load(&kq()->meshletData);
+        const float* __restrict__ ps = scalar_load(&kq()->positions);
+        const uint32_t ia = md[hdr.dataOffset + min(lane, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
+        const uint32_t ib = md[hdr.dataOffset + min(lane + 64u, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
+        if (lane < hdr.T) t0 = md[hdr.dataOffset + hdr.V + lane];
+        if (lane + 64u < hdr.T) t1 = md[hdr.dataOffset + hdr.V + 64u + lane];
+        const float* __restrict__ pa = ps + (size_t)ia * 3;
+        const float* __restrict__ pb = ps + (size_t)ib * 3;
         pax = pa[0]; pay = pa[1]; paz = pa[2]; pbx = pb[0]; pby = pb[1]; pbz = pb[2];
     }
     const bool sprof = (p.debug & DBG_SETUP_CLOCKS) != 0;
@@ -987,7 +1028,7 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
             if (lane + 64u < V) vertex(lane + 64u, pbx, pby, pbz);
 #if BLOCKS_LDS_VERTS > 128
             for (uint32_t i = lane + 128u; i < V; i += 64u) {
-                const float* __restrict__ pp = p.positions + (size_t)(p.meshletData[dataOffset + i] + vertexBase) * 3;
+                const float* __restrict__ pp = scalar_load(&kq()->positions) + (size_t)(scalar_load(&kq()->meshletData)[dataOffset + i] + vertexBase) * 3;
                 vertex(i, pp[0], pp[1], pp[2]);
             }
 #endif
@@ -999,10 +1040,11 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
 #ifdef BLK_MVP_AHEAD
         mvpN = mvp_of(hdrN.objectId);
 #endif
-        const uint32_t nia = p.meshletData[hdrN.dataOffset + min(lane, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
-        const uint32_t nib = p.meshletData[hdrN.dataOffset + min(lane + 64u, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
-        const uint32_t nt0 = lane < hdrN.T ? p.meshletData[hdrN.dataOffset + hdrN.V + lane] : 0u;
-        const uint32_t nt1 = lane + 64u < hdrN.T ? p.meshletData[hdrN.dataOffset + hdrN.V + 64u + lane] : 0u;
+        const uint32_t* __restrict__ md = scalar_load(&kq()->meshletData);
+        const uint32_t nia = md[hdrN.dataOffset + min(lane, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
+        const uint32_t nib = md[hdrN.dataOffset + min(lane + 64u, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
+        const uint32_t nt0 = lane < hdrN.T ? md[hdrN.dataOffset + hdrN.V + lane] : 0u;
+        const uint32_t nt1 = lane + 64u < hdrN.T ? md[hdrN.dataOffset + hdrN.V + 64u + lane] : 0u;
 
         // ---- classification: kind + pixel bounds per triangle, nothing else survives it ----------------------------------
         uint32_t bxA, byA, bxB, byB;
@@ -1012,8 +1054,9 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
         if (p.debug & DBG_NO_BIN) { kindA = K_NONE; kindB = K_NONE; }
         SPHASE(2);
         // next cluster: its positions (the indices have arrived behind the classification)
-        const float* __restrict__ npa = p.positions + (size_t)nia * 3;
-        const float* __restrict__ npb = p.positions + (size_t)nib * 3;
+        const float* __restrict__ ps = scalar_load(&kq()->positions);
+        const float* __restrict__ npa = ps + (size_t)nia * 3;
+        const float* __restrict__ npb = ps + (size_t)nib * 3;
         const float nax = npa[0], nay = npa[1], naz = npa[2], nbx = npb[0], nby = npb[1], nbz = npb[2];
 
         const bool eA = kindA == K_EMIT, eB = kindB == K_EMIT;
@@ -1048,8 +1091,13 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                     // one round trip: pool space (lane 0) and, per touched tile, ONE 64-bit add on the tile's counter pair
                     // (low word: bin slot, high word: the tile's block count) ...
                     uint32_t gbase = 0, slot = 0;
-                    if (lane == 0u && G) gbase = atomicAdd(&p.counters->blockGranules[listShard * CHORD_SHARD_STRIDE], G);
-                    if (has) slot = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&p.tileCount[(size_t)tile * TC_STRIDE]), 0x100000001ull);
+#ifdef BLK_HOT_PARAMS
+                    const RasterParams& e = p;
+#else
+                    const BlockEmitParams e = load_block_emit_params();
+#endif
+                    if (lane == 0u && G) gbase = atomicAdd(&e.counters->blockGranules[listShard * CHORD_SHARD_STRIDE], G);
+                    if (has) slot = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&e.tileCount[(size_t)tile * TC_STRIDE]), 0x100000001ull);
                     // ... and the cluster is resolved while they are in flight
 #pragma unroll
                     for (int k = 0; k < WIN * WIN / 64; k++) win[lane + 64u * k] = 0ull;
@@ -1065,11 +1113,11 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                     WAVE_LDS_SYNC();
                     SPHASE(3);
                     gbase = bcast(gbase, 0);
-                    const bool fits = gbase + G <= p.blockCap;
-                    if (!fits && lane == 0u) atomicOr(&p.counters->overflow, 1u);
-                    const uint32_t off = listShard * p.blockCap + gbase + before;              // granule offset of lane r's block
-                    if (has) bin_alloc(p, tile, slot);
-                    if (has && fits) bin_put(p, tile, slot, CHORD_REC_BLOCK | off);
+                    const bool fits = gbase + G <= e.blockCap;
+                    if (!fits && lane == 0u) atomicOr(&e.counters->overflow, 1u);
+                    const uint32_t off = listShard * e.blockCap + gbase + before;              // granule offset of lane r's block
+                    if (has) bin_alloc(e, tile, slot);
+                    if (has && fits) bin_put(e, tile, slot, CHORD_REC_BLOCK | off);
                     if (fits) {
                         for (uint32_t q = 0; q < 4u; q++) {                      // (wave-uniform: the parts that exist, one in 4 of 5 clusters)
                             if (!((hasMask >> q) & 1u)) continue;
@@ -1081,7 +1129,7 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                             // the reciprocal is exact, and otherwise at least 1/16 away from one)
                             const uint32_t rcp = (uint32_t)ceilf(65536.0f * __builtin_amdgcn_rcpf((float)qw));
                             const unsigned long long header = (unsigned long long)(qlx | qly << 6 | (qw - 1u) << 12 | (qh - 1u) << 16) | ((unsigned long long)rcp << 32);
-                            ulonglong2* dst = reinterpret_cast<ulonglong2*>(p.blockPool + (size_t)qoff * 2u);
+                            ulonglong2* dst = reinterpret_cast<ulonglong2*>(e.blockPool + (size_t)qoff * 2u);
                             for (uint32_t g = lane; g < gq; g += 64u) {
                                 // granule g = words 2g - 1, 2g of the block (word -1: the header)
                                 const uint32_t j1 = 2u * g, j0 = g == 0u ? 0u : j1 - 1u;
@@ -1099,9 +1147,9 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
             // not a block (large, clipped, masked, wide window, too few triangles for its window): the cluster goes to the
             // record kernel that follows this one (raster_setup_kernel reads the leftover list of a dense launch)
             if (lane == 0u) {
-                const uint32_t k = atomicAdd(p.leftCount, 1u);
+                const uint32_t k = atomicAdd(scalar_load(&kq()->leftCount), 1u);
                 ChordDrawCmd cmd; cmd.objectId = hdr.objectId; cmd.meshletId = hdr.meshletId; cmd.slot = hdr.slot;
-                p.leftCmds[k] = cmd;                                      // (capacity = the input list's: never full)
+                scalar_load(&kq()->leftCmds)[k] = cmd;                                      // (capacity = the input list's: never full)
             }
             SPHASE(3);
         }

@@ -689,14 +689,12 @@ def bumpy_sphere_mesh(n=96, seed=1):
     return pos, idx, uv
 
 
-def built_mesh_scene(width=640, height=360, n=96):
-    """Meshes that went through chordvis_nanite_build (own clusterizer / partition / simplifier) instead of the
-    grid-patch generator: instances of a bumpy sphere from 3 m to 400 m so that every LOD level of the DAG is in use."""
+def scene_from_meshes(meshes, local_to_world, prim_of_object=None, two_sided_of_object=None, name="mesh_scene"):
+    """A scene of triangle meshes that go through chordvis_nanite_build (own clusterizer / partition / simplifier, SURVEY
+    8f-4): `meshes` = [(positions, indices, texcoord0 or None), ...], one primitive each; `local_to_world` = 4x4 matrices, one
+    object each (object k instantiates primitive prim_of_object[k], default k mod len(meshes))."""
     from . import lib as L
-    prims, objs = [], []
-    for seed in (1, 2):
-        pos, idx, uv = bumpy_sphere_mesh(n, seed)
-        prims.append(L.nanite_build(pos, idx, uv))
+    prims = [L.nanite_build(pos, idx, uv) for pos, idx, uv in meshes]
     pr = np.zeros(len(prims), dtype=T.PRIMITIVE)
     ml, md, gr, gi, ps, bv, uvs = [], [], [], [], [], [], []
     nv = nm = nd = ng = ni = nb = 0
@@ -705,22 +703,34 @@ def built_mesh_scene(width=640, height=360, n=96):
         pr[k]["vertexOffset"], pr[k]["meshletOffset"], pr[k]["meshletGroupOffset"] = nv, nm, ng
         pr[k]["meshletGroupIndicesOffset"], pr[k]["bvhNodeOffset"] = ni, nb
         m = a.meshlets.copy(); m["dataOffset"] += nd
-        ml.append(m); md.append(a.meshlet_data); gr.append(a.groups); gi.append(a.group_indices); ps.append(a.positions); bv.append(a.bvh_nodes); uvs.append(a.texcoord0)
+        ml.append(m); md.append(a.meshlet_data); gr.append(a.groups); gi.append(a.group_indices); ps.append(a.positions); bv.append(a.bvh_nodes)
+        uvs.append(a.texcoord0 if a.texcoord0 is not None else np.zeros((len(a.positions), 2), np.float32))
         nv += len(a.positions); nm += len(m); nd += len(a.meshlet_data); ng += len(a.groups); ni += len(a.group_indices); nb += len(a.bvh_nodes)
     mats = np.concatenate([SceneBuilder._material(0), SceneBuilder._material(1)])
-    l2w = []
-    dists = [3.0, 6.0, 14.0, 30.0, 70.0, 160.0, 400.0]
-    for k, dist in enumerate(dists):
-        m = translate(((k % 3) - 1) * 0.3 * dist, 0.08 * dist * ((k // 3) - 1), -dist) @ rotate_y(0.7 * k) @ scale(1.0 + 0.15 * k)
-        l2w.append(m)
-    objects = np.zeros(len(l2w), dtype=T.OBJECT)
-    objects["GLTFPrimitiveDetail"] = np.arange(len(l2w)) % len(prims)
-    objects["GLTFMaterialData"] = (np.arange(len(l2w)) // 2) % 2
+    objects = np.zeros(len(local_to_world), dtype=T.OBJECT)
+    objects["GLTFPrimitiveDetail"] = (np.arange(len(local_to_world)) % len(prims)) if prim_of_object is None else np.asarray(prim_of_object)
+    objects["GLTFMaterialData"] = 0 if two_sided_of_object is None else np.asarray(two_sided_of_object)
     scene = T.Scene(objects, pr, mats, np.concatenate(ml), np.concatenate(gr), np.concatenate(gi), np.concatenate(md), np.concatenate(ps),
-                    name="built_mesh_scene", texcoord0=np.concatenate(uvs), bvh_nodes=np.concatenate(bv))
-    scene.local_to_world = np.ascontiguousarray(np.stack([m.T.reshape(16) for m in l2w]), dtype=np.float64)
+                    name=name, texcoord0=np.concatenate(uvs), bvh_nodes=np.concatenate(bv))
+    scene.local_to_world = np.ascontiguousarray(np.stack([np.asarray(m).T.reshape(16) for m in local_to_world]), dtype=np.float64)
     scene.built = prims
+    return scene
+
+
+def built_mesh_scene(width=640, height=360, n=96):
+    """Meshes that went through chordvis_nanite_build instead of the grid-patch generator: instances of a bumpy sphere from
+    3 m to 400 m so that every LOD level of the DAG is in use."""
+    dists = [3.0, 6.0, 14.0, 30.0, 70.0, 160.0, 400.0]
+    l2w = [translate(((k % 3) - 1) * 0.3 * dist, 0.08 * dist * ((k // 3) - 1), -dist) @ rotate_y(0.7 * k) @ scale(1.0 + 0.15 * k) for k, dist in enumerate(dists)]
+    scene = scene_from_meshes([bumpy_sphere_mesh(n, seed) for seed in (1, 2)], l2w, two_sided_of_object=(np.arange(len(l2w)) // 2) % 2, name="built_mesh_scene")
     return scene, Camera((0.0, 0.4, 1.0), (0.0, -0.05, -1.0), width, height)
+
+
+def big_built_mesh_scene(width=1280, height=720, n=360):
+    """One 258 k-triangle mesh through the builder (7 575 LOD-0 meshlets, 10+ LOD levels), seen close, at mid range and far."""
+    l2w = [translate(-0.9, 0.0, -2.4) @ rotate_y(0.3), translate(1.5, 0.2, -7.0) @ rotate_y(1.1), translate(0.0, 3.0, -60.0)]
+    scene = scene_from_meshes([bumpy_sphere_mesh(n, 3)], l2w, name="big_built_mesh_scene")
+    return scene, Camera((0.0, 0.2, 1.0), (0.0, -0.02, -1.0), width, height)
 
 
 def config5_subpixel(width=3840, height=2160, prims=1024, patches_per_prim=1024, instances=8, patch_px=8.0, seed=5, hotspot_sigma_px=None):
