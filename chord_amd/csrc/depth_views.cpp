@@ -117,6 +117,11 @@ int chordvis_instance_culling_view(ChordCtx* c, uint32_t instanceViewOffset, Cho
     k->hView.width = k->width; k->hView.height = k->height;
     k->viewSet = true; k->viewDirty = true;
     k->depthViewCurrent = (int)instanceViewOffset;
+    // a view's passes start here: ONE memset zeroes everything they count with (counters, list counts, both passes' tile bins),
+    // instead of the seven small ones a raster pass outside a frame issues for itself (each a launch of its own)
+    k->frameStateZeroBytes = offsetof(chord::FrameState, tileCount) + sizeof(uint32_t) * CHORD_TILECOUNT_STRIDE * ((size_t)2 * k->tilesX * k->tilesY);
+    CHORD_HIP(c, hipMemsetAsync(k->dFrameState, 0, k->frameStateZeroBytes, k->stream));
+    k->rasterCalls = 0; k->inFrame = true;
     launch_group_cull(k, k->lists[0]);
     CHORD_HIP(c, hipGetLastError());
     if (out) *out = k->lists[0].handle();
@@ -165,13 +170,29 @@ int chordvis_render_mesh_depth(ChordCtx* c, uint32_t instanceViewOffset, int bDe
     if (instanceViewOffset >= c->dDepthImages.size()) return fail(c, CHORDVIS_E_INVALID, "render_mesh_depth: view beyond allocate_depth_views");
     if (k->depthViewCurrent != (int)instanceViewOffset)
         return fail(c, CHORDVIS_E_INVALID, "render_mesh_depth: chordvis_instance_culling_view(instanceViewOffset) must come first (it sets up the view's object matrices)");
-    if ((rc = chordvis_clear_gbuffer(k))) return child_fail(c, rc);              // queue.clearDepthStencil(depth, 0.0), mesh_raster.cpp:500-501
-    k->depthOnly = true; k->depthClamp = bDepthClamped != 0; k->depthBiasConst = depthBiasConst; k->depthBiasSlope = depthBiasSlope;
-    rc = (in.count && in.cmds) ? chordvis_render_mesh(k, in) : CHORDVIS_OK;
-    k->depthOnly = false; k->depthClamp = false; k->depthBiasConst = 0.0f; k->depthBiasSlope = 0.0f;
-    if (rc) return child_fail(c, rc);
-    launch_depth_extract(k, (const unsigned long long*)k->dVis, c->dDepthImages[instanceViewOffset], (size_t)k->width * k->height);
-    CHORD_HIP(c, hipGetLastError());
+    // queue.clearDepthStencil(depth, 0.0) + the depth-only draw (mesh_raster.cpp:500-501, 159-206).  Like the main view's first
+    // pass the raster clears by writing every tile (no 33 MB memset of the words), and the tile kernel's fused tile-out writes
+    // the D32 image itself and reduces the tile to HZB mips 0..5 of the child's chain 0 (round 2: memset, global-atomic
+    // tile-out, an extract pass over the words, and for buildHZB an expand pass + the two mip kernels: four more passes over
+    // the image per cascade).
+    if (!k->inFrame || k->rasterCalls != 0) {            // (not the first depth pass since chordvis_instance_culling_view zeroed the state)
+        CHORD_HIP(c, hipMemsetAsync(k->dCounters, 0, sizeof(DeviceCounters), k->stream));
+        k->rasterCalls = 0; k->inFrame = false;
+    }
+    c->fusedDepthView = -1;
+    if (in.count && in.cmds) {
+        k->pendingClear = true;
+        k->fuseHzb = true; k->fuseHzbSlot = 0; k->fuseHzbTemp = false;
+        k->depthOutTarget = c->dDepthImages[instanceViewOffset];
+        k->depthOnly = true; k->depthClamp = bDepthClamped != 0; k->depthBiasConst = depthBiasConst; k->depthBiasSlope = depthBiasSlope;
+        rc = chordvis_render_mesh(k, in);
+        k->depthOnly = false; k->depthClamp = false; k->depthBiasConst = 0.0f; k->depthBiasSlope = 0.0f;
+        k->fuseHzb = false; k->depthOutTarget = nullptr; k->pendingClear = false; k->inFrame = false;
+        if (rc) return child_fail(c, rc);
+        c->fusedDepthView = (int)instanceViewOffset;
+    } else {
+        CHORD_HIP(c, hipMemsetAsync(c->dDepthImages[instanceViewOffset], 0, sizeof(float) * (size_t)k->width * k->height, k->stream));   // {nullptr, nullptr}: nothing to draw
+    }
     if (out) { out->depth = c->dDepthImages[instanceViewOffset]; out->width = k->width; out->height = k->height; }
     return CHORDVIS_OK;
 }
@@ -183,10 +204,20 @@ int chordvis_build_hzb_from_depth(ChordCtx* c, const ChordDepthTarget* depth, Ch
     ChordCtx* k = c->depthCtx;
     if (!depth || !depth->depth || depth->width != k->width || depth->height != k->height)
         return fail(c, CHORDVIS_E_INVALID, "build_hzb_from_depth: not a depth target of this context's depth views");
-    // the HZB kernels read the depth half of 64-bit words: the image goes (back) into the child's words
+    k->viewSet = true;
+    if (c->fusedDepthView >= 0 && (size_t)c->fusedDepthView < c->dDepthImages.size() && depth->depth == c->dDepthImages[c->fusedDepthView]) {
+        // the image came straight out of chordvis_render_mesh_depth: levels 0..5 of its min chain are already in chain 0
+        // (tile kernel); the one-block tail finishes it -- the values chordvis_build_hzb computes from the image
+        launch_hzb_tail(k, k->hzb[0], false, false);
+        CHORD_HIP(c, hipGetLastError());
+        if (out) { *out = k->hzb[0].handle(); out->maxTexels = nullptr; out->validRange = nullptr; }
+        return CHORDVIS_OK;
+    }
+    // any other image of these views (a cached cascade): the HZB kernels read the depth half of 64-bit words, so the image
+    // goes (back) into the child's words first
+    c->fusedDepthView = -1;
     launch_depth_expand(k, depth->depth, (unsigned long long*)k->dVis, (size_t)k->width * k->height);
     CHORD_HIP(c, hipGetLastError());
-    k->viewSet = true;
     return child_fail(c, chordvis_build_hzb(k, 1, 0, 0, 0, out));
 }
 

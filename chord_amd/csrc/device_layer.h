@@ -241,6 +241,8 @@ struct ChordCtx {
     ChordCascadeConfig shadowHistoryConfig{};
     float shadowHistoryDir[3] = {0, 0, 0};
     int depthViewCurrent = -1;        // (child) the view whose object matrices dObjFrame holds
+    float* depthOutTarget = nullptr;  // (child) set around a depth pass: the fused tile-out writes this D32 image directly
+    int fusedDepthView = -1;          // (parent) the view whose HZB mips 0..5 the child's chain 0 holds, straight out of its depth pass
     std::vector<ChordInstanceCullingView> instanceViews;   // chordvis_set_instance_views (cascadeViewInfos)
     ChordObject* dObjectsOwned = nullptr;
     const ChordObject* dObjects = nullptr;

@@ -60,6 +60,7 @@ struct RasterParams {
     const DMeshlet* meshlets; const uint32_t* meshletData; const float* positions;
     const DMaterial* materials; const uint8_t* texAlpha; const float* texcoords;   // masked materials (texcoords may be null: uv = 0)
     unsigned long long* vis;
+    float* depthOut;                                    // depth-only views: the fused tile-out writes the D32 image itself (row-major floats) instead of the 64-bit words
     float W, H; int32_t Wi, Hi;
     ShardInfo shard;
     TriRec* tris; uint32_t triCap;                      // 48-byte records, capacity per list shard
@@ -1920,6 +1921,17 @@ __device__ __forceinline__ void tile_out_and_hzb_body(const RasterParams& p, con
         const int32_t r0 = min(row, th - 1), r1 = min(row + 1, th - 1), xa = min(x2, tw - 1), xb = min(x2 + 1, tw - 1);
         const unsigned long long v00 = tile[r0 * TPITCH + xa], v01 = tile[r0 * TPITCH + xb];
         const unsigned long long v10 = tile[r1 * TPITCH + xa], v11 = tile[r1 * TPITCH + xb];
+        if (p.depthOut) {
+            // depth-only pass (renderMeshDepth): what leaves the tile is the D32 image -- the high halves of the words, 8 bytes
+            // per lane and row (no 64-bit image, no extract pass afterwards)
+            if (INTERIOR || x2 < tw) {
+                float* dst = p.depthOut + (size_t)(oy + row) * (size_t)p.Wi + ox + x2;
+                const float d00 = __uint_as_float((uint32_t)(v00 >> 32)), d01 = __uint_as_float((uint32_t)(v01 >> 32));
+                const float d10 = __uint_as_float((uint32_t)(v10 >> 32)), d11 = __uint_as_float((uint32_t)(v11 >> 32));
+                if (INTERIOR || row < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<float2*>(dst) = make_float2(d00, d01); else dst[0] = d00; }
+                if (INTERIOR || row + 1 < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<float2*>(dst + p.Wi) = make_float2(d10, d11); else dst[p.Wi] = d10; }
+            }
+        } else
         if (!(p.debug & DBG_NO_VIS_STORE) && (INTERIOR || x2 < tw)) {
             unsigned long long* dst = p.vis + (size_t)(oy + row) * (size_t)p.Wi + ox + x2;
             if (INTERIOR || row < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(v00, v01); else dst[0] = v00; }
@@ -2376,6 +2388,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.meshlets = c->dMeshlets; p.meshletData = c->dMeshletData; p.positions = c->dPositions;
     p.materials = c->dMaterials; p.texAlpha = c->dTexAlpha; p.texcoords = c->dTexcoords;
     p.vis = (unsigned long long*)c->dVis;
+    p.depthOut = (p.hzbFused && clearTiles) ? c->depthOutTarget : nullptr;     // (only the fused first pass writes a whole image)
     p.W = (float)c->width; p.H = (float)c->height; p.Wi = (int32_t)c->width; p.Hi = (int32_t)c->height;
     p.shard = c->shard;
     p.blockPool = c->dBlockPool; p.blockCap = (c->debugFlags & DBG_NO_BLOCKS) ? 0u : c->blockCap;
