@@ -285,7 +285,9 @@ int chordvis_cascade_setup(const ChordCascadeConfig* cfg, const ChordCameraView*
     auto logCascadeSplit = [&](float farDepthPlane, float nearDepthPlane, uint32_t cascadeId, uint32_t count, float lambda) {
         const float range = farDepthPlane - nearDepthPlane, ratio = farDepthPlane / nearDepthPlane;      // :56-74
         const float p = (float)(cascadeId + 1) / (float)count;
-        const float logScale = nearDepthPlane * std::pow(std::fabs(ratio), p);
+        // (pow is the one transcendental of the shader; pinned as the binary64 result rounded once -- tests/spec_np.py
+        // cascade_views_f32 and tests/golden/cascade_setup.json hold this function to the bit)
+        const float logScale = nearDepthPlane * (float)std::pow((double)std::fabs(ratio), (double)p);
         const float uniformScale = nearDepthPlane + range * p;
         const float d = lambda * (logScale - uniformScale) + uniformScale;
         return (d - nearZ) / clipRange;

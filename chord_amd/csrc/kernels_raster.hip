@@ -1221,12 +1221,13 @@ __device__ void bin_record_tiles(const RasterParams& p, const TriSetup& ts, uint
             const int32_t rx0 = max(ts.px0, tx << TILE_SHIFT), rx1 = min(ts.px1, (tx << TILE_SHIFT) + TILE - 1);
             const int32_t ry0 = max(ts.py0, ty << TILE_SHIFT), ry1 = min(ts.py1, (ty << TILE_SHIFT) + TILE - 1);
             bool hit = owns_any_row(p.shard, ry0, ry1);
-            for (int i = 0; i < 3 && hit; i++) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) {                         // (unrolled, no early exit: the vertex arrays stay in registers)
                 const int64_t dxe = (int64_t)(ts.X[eb[i]] - ts.X[ea[i]]), dye = (int64_t)(ts.Y[eb[i]] - ts.Y[ea[i]]);
                 const int64_t a = -(int64_t)ts.s * dye, b = (int64_t)ts.s * dxe;
                 const int64_t bias = (a > 0 || (a == 0 && b > 0)) ? 0 : -1;
                 const int64_t cx = (int64_t)(a > 0 ? rx1 : rx0) * 256 + 128, cy = (int64_t)(b > 0 ? ry1 : ry0) * 256 + 128;
-                hit = !((int64_t)ts.s * (dxe * (cy - ts.Y[ea[i]]) - dye * (cx - ts.X[ea[i]])) + bias < 0);
+                hit = hit && !((int64_t)ts.s * (dxe * (cy - ts.Y[ea[i]]) - dye * (cx - ts.X[ea[i]])) + bias < 0);
             }
             if (!hit) continue;
             const uint32_t tile = (uint32_t)ty * p.tilesX + (uint32_t)tx;
@@ -1259,11 +1260,28 @@ __device__ __forceinline__ f4 clip_intersect(const f4& in, const f4& out, float 
     return r;
 }
 
+// The polygon being clipped (Sutherland-Hodgman ping-pong, <= 3 + 6 vertices) is indexed dynamically, which in registers means
+// scratch memory (round 2: 592 bytes per lane).  It lives in LDS instead, slot-major ([buffer][vertex][thread]: consecutive
+// threads in consecutive banks); one wave per clip block works, which bounds the arrays to 38 KB.
+#define CLIP_MAXV 10
+#define CLIP_THREADS 64u
 __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t blocks)
 {
+    __shared__ float4 sPoly[2 * CLIP_MAXV * CLIP_THREADS];
+    __shared__ float sPU[2 * CLIP_MAXV * CLIP_THREADS], sPV[2 * CLIP_MAXV * CLIP_THREADS];     // texture coordinates ride along (masked materials only)
+    __shared__ int32_t sPX[CLIP_MAXV * CLIP_THREADS], sPY[CLIP_MAXV * CLIP_THREADS];
+    __shared__ float sPD[CLIP_MAXV * CLIP_THREADS];
+    if (threadIdx.x >= CLIP_THREADS) return;
+    const uint32_t tl = threadIdx.x;
+#define POLY(bf, i) sPoly[((bf) * CLIP_MAXV + (i)) * CLIP_THREADS + tl]
+#define PU(bf, i) sPU[((bf) * CLIP_MAXV + (i)) * CLIP_THREADS + tl]
+#define PV(bf, i) sPV[((bf) * CLIP_MAXV + (i)) * CLIP_THREADS + tl]
+#define PX(i) sPX[(i) * CLIP_THREADS + tl]
+#define PY(i) sPY[(i) * CLIP_THREADS + tl]
+#define PD(i) sPD[(i) * CLIP_THREADS + tl]
     const uint32_t n = min(p.counters->clipTriCount[p.pass], p.clipTriCap);
-    const uint32_t listShard = (block * 4u + (threadIdx.x >> 6)) % CHORD_LIST_SHARDS;
-    for (uint32_t k = block * 256u + threadIdx.x; k < n; k += blocks * 256u) {
+    const uint32_t listShard = block % CHORD_LIST_SHARDS;
+    for (uint32_t k = block * CLIP_THREADS + threadIdx.x; k < n; k += blocks * CLIP_THREADS) {
         const ClipTri ct = p.clipTris[k];
         ChordDrawCmd cmd; cmd.objectId = ct.objectId; cmd.meshletId = ct.meshletId; cmd.slot = ct.slot;
         const DMeshlet& m = p.meshlets[cmd.meshletId];
@@ -1275,57 +1293,60 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
         Mat4 mvp;
         for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = mv[r * 4 + cc];
         const uint32_t packedIdx = p.meshletData[m.dataOffset + V + ct.tri];
-        f4 poly[2][12];
-        float pu[2][12], pv[2][12];                               // texture coordinates ride along (masked materials only)
         for (int i = 0; i < 3; i++) {
             const uint32_t li = (packedIdx >> (8 * i)) & 0xFFu;
             const uint32_t vi = p.meshletData[m.dataOffset + li] + m.vertexBase;
             const float* pos = p.positions + (size_t)vi * 3;
-            poly[0][i] = mul_mv(mvp, pos[0], pos[1], pos[2], 1.0f);
-            pu[0][i] = 0.0f; pv[0][i] = 0.0f;
-            if (masked && p.texcoords) { pu[0][i] = p.texcoords[(size_t)vi * 2]; pv[0][i] = p.texcoords[(size_t)vi * 2 + 1]; }
+            const f4 h = mul_mv(mvp, pos[0], pos[1], pos[2], 1.0f);
+            POLY(0, i) = make_float4(h.x, h.y, h.z, h.w);
+            float u = 0.0f, v = 0.0f;
+            if (masked && p.texcoords) { u = p.texcoords[(size_t)vi * 2]; v = p.texcoords[(size_t)vi * 2 + 1]; }
+            PU(0, i) = u; PV(0, i) = v;
         }
         int np = 3, cur = 0;
         for (int pl = p.depthClamp ? 2 : 0; pl < 6 && np >= 3; pl++) {
             int m2 = 0;
             for (int i = 0; i < np; i++) {
                 const int j = (i + 1) % np;
-                const f4 P = poly[cur][i], Q = poly[cur][j];
+                const float4 Pv = POLY(cur, i), Qv = POLY(cur, j);
+                const f4 P = {Pv.x, Pv.y, Pv.z, Pv.w}, Q = {Qv.x, Qv.y, Qv.z, Qv.w};
+                const float pui = PU(cur, i), pvi = PV(cur, i), puj = PU(cur, j), pvj = PV(cur, j);
                 const float dp = clip_dist(P, pl), dq = clip_dist(Q, pl);
                 const bool pin = dp >= 0.0f, qin = dq >= 0.0f;
-                if (pin) { pu[cur ^ 1][m2] = pu[cur][i]; pv[cur ^ 1][m2] = pv[cur][i]; poly[cur ^ 1][m2++] = P; }
-                if (pin && !qin) {
+                if (pin && m2 < CLIP_MAXV) { PU(cur ^ 1, m2) = pui; PV(cur ^ 1, m2) = pvi; POLY(cur ^ 1, m2) = Pv; m2++; }
+                if (pin && !qin && m2 < CLIP_MAXV) {
                     const float t = dp / (dp - dq);
-                    pu[cur ^ 1][m2] = pu[cur][i] + (pu[cur][j] - pu[cur][i]) * t; pv[cur ^ 1][m2] = pv[cur][i] + (pv[cur][j] - pv[cur][i]) * t;
-                    poly[cur ^ 1][m2++] = clip_intersect(P, Q, dp, dq);
-                } else if (!pin && qin) {
+                    PU(cur ^ 1, m2) = pui + (puj - pui) * t; PV(cur ^ 1, m2) = pvi + (pvj - pvi) * t;
+                    const f4 x = clip_intersect(P, Q, dp, dq);
+                    POLY(cur ^ 1, m2) = make_float4(x.x, x.y, x.z, x.w); m2++;
+                } else if (!pin && qin && m2 < CLIP_MAXV) {
                     const float t = dq / (dq - dp);
-                    pu[cur ^ 1][m2] = pu[cur][j] + (pu[cur][i] - pu[cur][j]) * t; pv[cur ^ 1][m2] = pv[cur][j] + (pv[cur][i] - pv[cur][j]) * t;
-                    poly[cur ^ 1][m2++] = clip_intersect(Q, P, dq, dp);
+                    PU(cur ^ 1, m2) = puj + (pui - puj) * t; PV(cur ^ 1, m2) = pvj + (pvi - pvj) * t;
+                    const f4 x = clip_intersect(Q, P, dq, dp);
+                    POLY(cur ^ 1, m2) = make_float4(x.x, x.y, x.z, x.w); m2++;
                 }
             }
             np = m2; cur ^= 1;
         }
         if (np < 3) continue;
         bool ok = true;
-        int32_t PX[12], PY[12]; float PD[12];
         for (int i = 0; i < np; i++) {
-            const f4 h = poly[cur][i];
+            const float4 h = POLY(cur, i);
             if (!(h.w > 0.0f)) { ok = false; break; }
             const float u = h.x / fabsf(h.w) * 0.5f + 0.5f;
             const float v = h.y / fabsf(h.w) * -0.5f + 0.5f;
-            PX[i] = (int32_t)rintf((u * p.W) * 256.0f);
-            PY[i] = (int32_t)rintf((v * p.H) * 256.0f);
-            PD[i] = h.z / h.w;
+            PX(i) = (int32_t)rintf((u * p.W) * 256.0f);
+            PY(i) = (int32_t)rintf((v * p.H) * 256.0f);
+            PD(i) = h.z / h.w;
         }
         if (!ok) continue;
         const uint32_t payload = p.depthOnly ? 0u : encode_triangle_instance(ct.tri, cmd.slot);
         const uint32_t slots = masked ? 2u : 1u;
         for (int i = 1; i + 1 < np; i++) {
             TriSetup ts;
-            ts.X[0] = PX[0]; ts.X[1] = PX[i]; ts.X[2] = PX[i + 1];
-            ts.Y[0] = PY[0]; ts.Y[1] = PY[i]; ts.Y[2] = PY[i + 1];
-            float d[3] = {PD[0], PD[i], PD[i + 1]};
+            ts.X[0] = PX(0); ts.X[1] = PX(i); ts.X[2] = PX(i + 1);
+            ts.Y[0] = PY(0); ts.Y[1] = PY(i); ts.Y[2] = PY(i + 1);
+            float d[3] = {PD(0), PD(i), PD(i + 1)};
             ts.payload = payload;
             if (!tri_setup(ts, twoSided, p.Wi, p.Hi) || !owns_any_row(p.shard, ts.py0, ts.py1)) continue;
             if (p.biasConst != 0.0f || p.biasSlope != 0.0f) { const float o = depth_bias(ts, d, p.biasConst, p.biasSlope); d[0] += o; d[1] += o; d[2] += o; }
@@ -1335,14 +1356,20 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
             write_record(&p.tris[gi], ts, d, twoSided, masked);
             if (masked) {
                 const uint32_t material = CHORD_MATFLAG_MATERIAL(matFlags);
-                const float u3[3] = {pu[cur][0], pu[cur][i], pu[cur][i + 1]}, v3[3] = {pv[cur][0], pv[cur][i], pv[cur][i + 1]};
-                const float w3[3] = {poly[cur][0].w, poly[cur][i].w, poly[cur][i + 1].w};
+                const float u3[3] = {PU(cur, 0), PU(cur, i), PU(cur, i + 1)}, v3[3] = {PV(cur, 0), PV(cur, i), PV(cur, i + 1)};
+                const float w3[3] = {POLY(cur, 0).w, POLY(cur, i).w, POLY(cur, i + 1).w};
                 write_mask_ext(&p.tris[gi + 1u], p.materials[material], material, ts.area, u3, v3, w3);
             }
             // clipped pieces are rare: binned right here, one (scattered) atomic per tile they may touch
             bin_record_tiles(p, ts, gi | CHORD_REC_WIDE);                // clipped pieces take the 48-byte form
         }
     }
+#undef POLY
+#undef PU
+#undef PV
+#undef PX
+#undef PY
+#undef PD
 }
 
 // ---- large triangles: one wave per record, one lane per candidate tile -------------------------

@@ -355,3 +355,174 @@ def cascade_views_f64(cfg, view, light_dir, valid_range=None):
                            np.append(nt, -np.dot(nt, q[4])), np.append(nf, -np.dot(nf, q[0])), np.append(nb, -np.dot(nf, q[6]))])
         out.append(dict(vp=VP, inv=inv, planes=planes, ortho=np.array([P[2, 2], P[2, 3], zbias, radius_scale]), texel=2.0 / dim, radius=R_))
     return out
+
+
+# ---- cascadeComputeCS in float32, operation by operation -----------------------------------------------------------------------
+def cascade_views_f32(cfg, view, light_dir, valid_range=None, tick=0, cache_valid=False):
+    """cascadeComputeCS (cascade_setup.hlsl:79-372, with lookAt_RH / ortho_RH_ZeroOne / matrixInverse of base.hlsli:637-730) in
+    numpy float32 SCALARS, one rounding per source operation in source order: the bit-level statement of what
+    chordvis_cascade_setup must produce (tests/golden/cascade_setup.json is generated from this function).  Canonical choices
+    where the shader leaves the arithmetic to the driver: no FMA contraction; `pow` is evaluated in binary64 and rounded once;
+    `round` is round-half-to-even.  Returns per cascade (or None where the cache keeps the old view) a dict of
+    float32 arrays: translatedWorldToClip / clipToTranslatedWorld as M[r][c], planes[6][4], ortho[4]."""
+    f = np.float32
+    count, realtime, dim = int(cfg["cascadeCount"][0]), int(cfg["realtimeCascadeCount"][0]), int(cfg["cascadeDim"][0])
+    start, end, far_end = f(cfg["cascadeStartDistance"][0]), f(cfg["cascadeEndDistance"][0]), f(cfg["farCascadeEndDistance"][0])
+    lam, far_lam, rs_fixed = f(cfg["splitLambda"][0]), f(cfg["farCascadeSplitLambda"][0]), f(cfg["radiusScaleFixed"][0])
+    near, far = f(view["zNear"][0]), f(view["zFar"][0])
+    clip_range = f(far - near)
+    inv_zfar = np.asarray(view["clipToTranslatedWorldWithZFar_NoJitter"][0], dtype=np.float32).reshape(4, 4).T   # M[r][c]
+
+    def mul_point(M, x, y, z, w):
+        return [f(f(f(f(M[r][0] * x) + f(M[r][1] * y)) + f(M[r][2] * z)) + f(M[r][3] * w)) for r in range(4)]
+
+    def sub(a, b): return [f(a[i] - b[i]) for i in range(3)]
+    def add(a, b): return [f(a[i] + b[i]) for i in range(3)]
+    def mul(a, s): return [f(a[i] * s) for i in range(3)]
+    def dot(a, b): return f(f(f(a[0] * b[0]) + f(a[1] * b[1])) + f(a[2] * b[2]))
+    def cross(a, b): return [f(f(a[1] * b[2]) - f(b[1] * a[2])), f(f(a[2] * b[0]) - f(b[2] * a[0])), f(f(a[0] * b[1]) - f(b[0] * a[1]))]
+    def normalize(a):
+        l = f(np.sqrt(dot(a, a)))
+        return [f(a[0] / l), f(a[1] / l), f(a[2] / l)]
+
+    def matmul(A, B):
+        return [[f(f(f(f(A[r][0] * B[0][c]) + f(A[r][1] * B[1][c])) + f(A[r][2] * B[2][c])) + f(A[r][3] * B[3][c])) for c in range(4)] for r in range(4)]
+
+    def inverse(M):
+        # the cofactor expansion of matrixInverse (base.hlsli:684-730) on the column-major element list m[c * 4 + r]
+        m = [M[i % 4][i // 4] for i in range(16)]
+        def t3(a, b, c): return f(f(m[a] * m[b]) * m[c])
+        def row(s):
+            acc = None
+            for sign, a, b, c in s:
+                v = t3(a, b, c)
+                if acc is None:
+                    acc = v if sign > 0 else f(-v)           # ((-m[a]) * m[b]) * m[c]: the negation is exact
+                else:
+                    acc = f(acc + v) if sign > 0 else f(acc - v)
+            return acc
+        P, N = 1, -1
+        inv = [None] * 16
+        inv[0] = row([(P, 5, 10, 15), (N, 5, 11, 14), (N, 9, 6, 15), (P, 9, 7, 14), (P, 13, 6, 11), (N, 13, 7, 10)])
+        inv[4] = row([(N, 4, 10, 15), (P, 4, 11, 14), (P, 8, 6, 15), (N, 8, 7, 14), (N, 12, 6, 11), (P, 12, 7, 10)])
+        inv[8] = row([(P, 4, 9, 15), (N, 4, 11, 13), (N, 8, 5, 15), (P, 8, 7, 13), (P, 12, 5, 11), (N, 12, 7, 9)])
+        inv[12] = row([(N, 4, 9, 14), (P, 4, 10, 13), (P, 8, 5, 14), (N, 8, 6, 13), (N, 12, 5, 10), (P, 12, 6, 9)])
+        inv[1] = row([(N, 1, 10, 15), (P, 1, 11, 14), (P, 9, 2, 15), (N, 9, 3, 14), (N, 13, 2, 11), (P, 13, 3, 10)])
+        inv[5] = row([(P, 0, 10, 15), (N, 0, 11, 14), (N, 8, 2, 15), (P, 8, 3, 14), (P, 12, 2, 11), (N, 12, 3, 10)])
+        inv[9] = row([(N, 0, 9, 15), (P, 0, 11, 13), (P, 8, 1, 15), (N, 8, 3, 13), (N, 12, 1, 11), (P, 12, 3, 9)])
+        inv[13] = row([(P, 0, 9, 14), (N, 0, 10, 13), (N, 8, 1, 14), (P, 8, 2, 13), (P, 12, 1, 10), (N, 12, 2, 9)])
+        inv[2] = row([(P, 1, 6, 15), (N, 1, 7, 14), (N, 5, 2, 15), (P, 5, 3, 14), (P, 13, 2, 7), (N, 13, 3, 6)])
+        inv[6] = row([(N, 0, 6, 15), (P, 0, 7, 14), (P, 4, 2, 15), (N, 4, 3, 14), (N, 12, 2, 7), (P, 12, 3, 6)])
+        inv[10] = row([(P, 0, 5, 15), (N, 0, 7, 13), (N, 4, 1, 15), (P, 4, 3, 13), (P, 12, 1, 7), (N, 12, 3, 5)])
+        inv[14] = row([(N, 0, 5, 14), (P, 0, 6, 13), (P, 4, 1, 14), (N, 4, 2, 13), (N, 12, 1, 6), (P, 12, 2, 5)])
+        inv[3] = row([(N, 1, 6, 11), (P, 1, 7, 10), (P, 5, 2, 11), (N, 5, 3, 10), (N, 9, 2, 7), (P, 9, 3, 6)])
+        inv[7] = row([(P, 0, 6, 11), (N, 0, 7, 10), (N, 4, 2, 11), (P, 4, 3, 10), (P, 8, 2, 7), (N, 8, 3, 6)])
+        inv[11] = row([(N, 0, 5, 11), (P, 0, 7, 9), (P, 4, 1, 11), (N, 4, 3, 9), (N, 8, 1, 7), (P, 8, 3, 5)])
+        inv[15] = row([(P, 0, 5, 10), (N, 0, 6, 9), (N, 4, 1, 10), (P, 4, 2, 9), (P, 8, 1, 6), (N, 8, 2, 5)])
+        det = f(f(f(f(m[0] * inv[0]) + f(m[1] * inv[4])) + f(m[2] * inv[8])) + f(m[3] * inv[12]))
+        inv_det = f(f(1.0) / det)
+        out = [f(inv[i] * inv_det) for i in range(16)]
+        return [[out[c * 4 + r] for c in range(4)] for r in range(4)]
+
+    def log_split(far_plane, near_plane, cid, n, lam_):
+        rng_, ratio = f(far_plane - near_plane), f(far_plane / near_plane)
+        p = f(f(cid + 1) / f(n))
+        log_scale = f(near_plane * f(np.float64(abs(ratio)) ** np.float64(p)))
+        uniform_scale = f(near_plane + f(rng_ * p))
+        d = f(f(lam_ * f(log_scale - uniform_scale)) + uniform_scale)
+        return f(f(d - near) / clip_range)
+
+    ndc = [(-1, 1, 1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 0), (1, 1, 0), (1, -1, 0), (-1, -1, 0)]
+    cs = []
+    for cid in range(count):
+        if cid < realtime:
+            min_z, max_z, split_lam, n_split, id_split = f(near + start), f(near + end), lam, realtime, cid
+            if valid_range is not None:
+                vmin, vmax = np.asarray(valid_range, np.uint32).view(np.float32)
+                if vmax > 0:
+                    min_z = max(min_z, f(near / vmax))
+                if vmin > 0:
+                    stable = f(end - start)
+                    max_z = max(max_z, f(min_z * f(1.1)))
+                    max_z = min(max_z, f(min_z + stable))
+                    max_z = min(max_z, f(near / vmin))
+            split_start = f(min_z - near)
+        else:
+            max_z, split_lam, min_z, split_start = f(near + far_end), far_lam, f(near + end), end
+            n_split, id_split = count - realtime, cid - realtime
+        split = log_split(max_z, min_z, id_split, n_split, split_lam)
+        prev_split = f(split_start / clip_range) if id_split == 0 else log_split(max_z, min_z, id_split - 1, n_split, split_lam)
+        split0, prev_split0 = log_split(near, f(near + far_end), 0, count, far_lam), f(0.0)            # :163 (argument order as written there)
+        corner = []
+        for x, y, z in ndc:
+            h = mul_point(inv_zfar, f(x), f(y), f(z), f(1.0))
+            corner.append([f(h[0] / h[3]), f(h[1] / h[3]), f(h[2] / h[3])])
+        corner0 = [None] * 8
+        for i in range(4):
+            ray = sub(corner[i + 4], corner[i])
+            corner0[i + 4] = add(corner[i], mul(ray, split0))
+            corner0[i] = add(corner[i], mul(ray, prev_split0))
+        for i in range(4):
+            ray = sub(corner[i + 4], corner[i])
+            near_ray, far_ray = mul(ray, prev_split), mul(ray, split)
+            corner[i + 4] = add(corner[i], far_ray)
+            corner[i] = add(corner[i], near_ray)
+        center, center0 = [f(0), f(0), f(0)], [f(0), f(0), f(0)]
+        for i in range(8):
+            center, center0 = add(center, corner[i]), add(center0, corner0[i])
+        center = [f(c / f(8.0)) for c in center]
+        center0 = [f(c / f(8.0)) for c in center0]
+        radius, radius0 = f(0), f(0)
+        for i in range(8):
+            d, d0 = sub(corner[i], center), sub(corner0[i], center0)
+            radius = max(radius, f(np.sqrt(dot(d, d))))
+            radius0 = max(radius0, f(np.sqrt(dot(d0, d0))))
+        cs.append(dict(radius=radius, snapped=f(f(np.ceil(f(radius * f(16.0)))) / f(16.0)), radius0=radius0, min_z=min_z, center=center))
+    max_snapped = max(c["snapped"] for c in cs)                                                        # WaveActiveMax, :259
+    up = [f(0), f(1), f(0)]
+    L = normalize([f(light_dir[0]), f(light_dir[1]), f(light_dir[2])])
+    out = []
+    for cid in range(count):
+        c = cs[cid]
+        max_e, min_e = c["snapped"], f(-c["snapped"])
+        extent_z = f(max_snapped * f(2.0))
+        if cid >= realtime:
+            radius_scale, z_bias = f(c["radius0"] / c["radius"]), f(1.0)
+        else:
+            radius_scale = f(f(f(10.0) * rs_fixed) / c["radius"])
+            radius_scale = f(radius_scale / f(radius_scale + f(1.0)))
+            z_bias = f(f(0.25) + f(f(c["min_z"] - near) / f(end - start)))
+        radius_scale = min(radius_scale, f(1.0))
+        cam = sub(c["center"], mul(mul(L, extent_z), f(0.5)))
+        fw = normalize(sub(c["center"], cam))
+        s = normalize(cross(fw, up))
+        u = cross(s, fw)
+        V = [[s[0], s[1], s[2], f(-dot(s, cam))], [u[0], u[1], u[2], f(-dot(u, cam))], [f(-fw[0]), f(-fw[1]), f(-fw[2]), dot(fw, cam)], [f(0), f(0), f(0), f(1)]]
+        left, right, bottom, top, zn, zf = min_e, max_e, min_e, max_e, extent_z, f(0.0)
+        P = [[f(0)] * 4 for _ in range(4)]
+        P[0][0] = f(f(2.0) / f(right - left)); P[1][1] = f(f(2.0) / f(top - bottom)); P[2][2] = f(f(-1.0) / f(zf - zn))
+        P[0][3] = f(f(-f(right + left)) / f(right - left)); P[1][3] = f(f(-f(top + bottom)) / f(top - bottom)); P[2][3] = f(f(-zn) / f(zf - zn)); P[3][3] = f(1.0)
+        size = f(dim)
+        origin = mul_point(matmul(P, V), f(0), f(0), f(0), f(1))
+        origin = [f(o * f(size / f(2.0))) for o in origin]
+        P[0][3] = f(P[0][3] + f(f(f(np.rint(origin[0])) - origin[0]) * f(f(2.0) / size)))
+        P[1][3] = f(P[1][3] + f(f(f(np.rint(origin[1])) - origin[1]) * f(f(2.0) / size)))
+        VP = matmul(P, V)
+        IVP = inverse(VP)
+        pts = []
+        for x, y, z in ndc:
+            h = mul_point(IVP, f(x), f(y), f(z), f(1.0))
+            pts.append([f(h[0] / h[3]), f(h[1] / h[3]), f(h[2] / h[3])])
+        planes = []
+        def plane(a, b, o):
+            n = normalize(cross(sub(a, o), sub(b, o)))
+            planes.append([n[0], n[1], n[2], f(-dot(n, o))])
+            return n
+        plane(pts[4], pts[3], pts[7]); plane(pts[6], pts[3], pts[2]); plane(pts[6], pts[1], pts[5]); plane(pts[5], pts[0], pts[4])
+        front_n = plane(pts[1], pts[3], pts[0])
+        plane(pts[5], pts[7], pts[6])
+        planes[5][3] = f(-dot(front_n, pts[6]))                                                        # :365 uses frontN for the back plane's distance
+        keep = cache_valid and cid >= realtime and (tick % (count - realtime)) != (cid - realtime)
+        out.append(None if keep else dict(translatedWorldToClip=np.array(VP, np.float32), clipToTranslatedWorld=np.array(IVP, np.float32),
+                                          planes=np.array(planes, np.float32), ortho=np.array([P[2][2], P[2][3], z_bias, radius_scale], np.float32)))
+    return out

@@ -261,3 +261,39 @@ def test_cascade_setup_agrees_with_a_float64_restatement_of_the_shader(ranged):
             assert np.abs(pl[:, :3] - w["planes"][:, :3]).max() < 1e-4, "cascade %d: plane normals" % k
             assert np.abs(pl[:, 3] - w["planes"][:, 3]).max() < 2e-3 * max(1.0, w["radius"]), "cascade %d: plane distances" % k
             assert np.allclose(g["orthoDepthConvertToView"].astype(np.float64), w["ortho"], rtol=2e-5, atol=1e-6), "cascade %d: orthoDepthConvertToView" % k
+
+
+def test_cascade_setup_matches_the_float32_fixture_bit_for_bit():
+    """chordvis_cascade_setup against tests/golden/cascade_setup.json: the float32 bit patterns of every matrix, plane and
+    orthoDepthConvertToView of every cascade as the float-by-float numpy restatement of cascade_setup.hlsl computes them
+    (spec_np.cascade_views_f32, source order, one rounding per operation) -- no tolerance, no texel-snap allowance; three
+    cases: 5 cascades without SDSM range, the reference's default 8 cascades with one, the same with the cascade cache on tick
+    7 (only the scheduled far cascade is rewritten).  The restatement itself must still reproduce the fixture."""
+    import json
+    import os
+    import spec_np
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cascade_setup.json")))
+    for case in fx["cases"]:
+        cfg = R.default_cascade_config(**case["config"])
+        view = np.zeros(1, dtype=R.CAMERA_VIEW)
+        iv = np.zeros(1, dtype=R.INSTANCE_CULLING_VIEW)
+        view["zNear"], view["zFar"] = case["zNear"], case["zFar"]
+        view["clipToTranslatedWorldWithZFar_NoJitter"][0] = np.asarray(case["clipToTranslatedWorldWithZFar_NoJitter_bits"], np.uint32).view(np.float32)
+        vr = None if case["validDepthMinMax"] is None else np.asarray(case["validDepthMinMax"], np.uint32)
+        marker = np.zeros(int(cfg["cascadeCount"][0]), dtype=R.INSTANCE_CULLING_VIEW)
+        marker["renderDimension"] = -7.0
+        got = L.cascade_setup(cfg, view, iv, case["lightDir"], valid_range=vr, tick=case["tick"], cache_valid=case["cacheValid"], views=marker.copy())
+        again = spec_np.cascade_views_f32(cfg, view, case["lightDir"], valid_range=vr, tick=case["tick"], cache_valid=case["cacheValid"])
+        for k, want in enumerate(case["cascades"]):
+            if want is None:                                          # the cache keeps the view of this cascade: untouched
+                assert again[k] is None and np.all(got[k]["renderDimension"] == -7.0), (case["name"], k)
+                continue
+            u = lambda a: np.asarray(a, np.float32).reshape(-1).view(np.uint32)
+            w2c = np.asarray(got[k]["translatedWorldToClip"], np.float32).reshape(4, 4).T     # M[r][c] of the column-major record
+            c2w = np.asarray(got[k]["clipToTranslatedWorld"], np.float32).reshape(4, 4).T
+            for label, a, b, c in (("translatedWorldToClip", w2c, want["translatedWorldToClip_rc"], again[k]["translatedWorldToClip"]),
+                                   ("clipToTranslatedWorld", c2w, want["clipToTranslatedWorld_rc"], again[k]["clipToTranslatedWorld"]),
+                                   ("frustumPlanesRS", got[k]["frustumPlanesRS"], want["planes"], again[k]["planes"]),
+                                   ("orthoDepthConvertToView", got[k]["orthoDepthConvertToView"], want["orthoDepthConvertToView"], again[k]["ortho"])):
+                assert np.array_equal(u(a), np.asarray(b, np.uint32)), "%s cascade %d: %s differs from the fixture" % (case["name"], k, label)
+                assert np.array_equal(u(c), np.asarray(b, np.uint32)), "%s cascade %d: the restatement no longer reproduces the fixture (%s)" % (case["name"], k, label)
