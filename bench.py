@@ -350,11 +350,13 @@ def main():
     if world == 1 and not args.debug_flags and (not args.no_hzb or wl.startswith("subpixel")) and os.path.isfile(tj):
         try:
             tk = json.load(open(tj))
-            traffic = int(tk["kernels"][dom]["hbm_bytes_per_launch"])
+            # (the setup time covers both setup kernels of a launch: the pixel-block kernel of dense launches and the record kernel)
+            names = [dom] + (["raster_setup_blocks_kernel"] if dom == "raster_setup_kernel" and blocks > 0 else [])
+            traffic = int(sum(tk["kernels"][n]["hbm_bytes_per_launch"] for n in names if n in tk["kernels"]))
             traffic_src = "profiles/" + os.path.basename(tj)
         except (KeyError, ValueError):
             traffic = None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": dom + (" (raster_setup_blocks_kernel + raster_setup_kernel)" if dom == "raster_setup_kernel" and blocks > 0 else ""), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "from_committed_profile": traffic is not None,   # (PMC passes cannot run inside this process: not observed in THIS run)
                 "avg_launch_us": round(dom_ms / launches * 1e3, 2), "launches_per_step": launches,

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(256) void object_cull_kernel(const ChordObject* __r
 // groups span several blocks is done by each of them -- same values), the frame's housekeeping that used to ride on the
 // object kernel (view block published for the later kernels, FrameState zeroed), then the groups.
 // FROM_MASK: the per-group meshlet masks were written by bvh_cull_kernel (hierarchical mode); this kernel only counts them.
-template <bool FROM_MASK>
+// SHARDED: the rank's share of the list is determined too (the unsharded instantiation is the round-2 kernel: the ownership
+// test costs the single-GPU frame nothing)
+template <bool FROM_MASK, bool SHARDED>
 __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p, const DView dv, DView* __restrict__ dviewOut,
                                                                DObjFrame* __restrict__ objFrameOut, uint4* __restrict__ zeroBase, uint32_t zeroVec4,
                                                                uint32_t cullBlocks, FrameTail tail)
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
     }
     __syncthreads();                                       // the object records of this block are written (and visible to it)
     uint32_t mask = 0, tris = 0, mine = 0;
-    const bool sharded = p.shard.ranks > 1u;
+    constexpr bool sharded = SHARDED;
     if (FROM_MASK) {
         if (t < p.groupInstances) mask = p.groupMask[t] & 15u;
         if (mask) {
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
     }
     uint32_t total, blockTris;
     // (counts below 2^12 per block: the visible count in the low half, the rank's in the high half of one scan)
-    (void)block_excl_scan((uint32_t)__popc(mask) | ((uint32_t)__popc(mine) << 16), &total);
+    (void)block_excl_scan(sharded ? (uint32_t)__popc(mask) | ((uint32_t)__popc(mine) << 16) : (uint32_t)__popc(mask), &total);
     (void)block_excl_scan(tris, &blockTris);
     if (threadIdx.x == 0) {
         p.blockCounts[blockIdx.x] = total & 0xFFFFu; p.blockCounts[cullBlocks + blockIdx.x] = blockTris;
@@ -612,25 +614,25 @@ __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DV
 // (Tried in round 2: the phase-0 HZB test of every command inside this kernel for short scenes, to save the launch of
 // hzb_cull_kernel: 23.8 us against 5 + 7 us -- a thread owns a group's up to four commands and tests them one after
 // the other, four dependent chains of loads deep, while the stand-alone kernel has one command per thread.)
-template <bool PREFIXED>
+template <bool PREFIXED, bool SHARDED>
 __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams p, ChordDrawCmd* __restrict__ outCmds,
                                                                  uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters)
 {
-    __shared__ uint32_t red[256], redMine[256];
-    const bool sharded = p.shard.ranks > 1u;
+    __shared__ uint32_t red[256], redMine[SHARDED ? 256 : 1];
+    constexpr bool sharded = SHARDED;
     const uint32_t cullBlocks = gridDim.x;
     uint32_t blockBase, mineBase = 0;
     if (PREFIXED) { blockBase = p.blockCounts[blockIdx.x]; if (sharded) mineBase = p.blockCounts[2u * cullBlocks + blockIdx.x]; }
     else {
         uint32_t part = 0, partMine = 0;
         for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) { part += p.blockCounts[b]; if (sharded) partMine += p.blockCounts[2u * cullBlocks + b]; }
-        red[threadIdx.x] = part; redMine[threadIdx.x] = partMine;
+        red[threadIdx.x] = part; if (sharded) redMine[threadIdx.x] = partMine;
         __syncthreads();
         for (uint32_t s = 128; s > 0; s >>= 1) {
-            if (threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; redMine[threadIdx.x] += redMine[threadIdx.x + s]; }
+            if (threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; if (sharded) redMine[threadIdx.x] += redMine[threadIdx.x + s]; }
             __syncthreads();
         }
-        blockBase = red[0]; mineBase = redMine[0];
+        blockBase = red[0]; if (sharded) mineBase = redMine[0];
         __syncthreads();
     }
 
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
     const uint32_t both = t < p.groupInstances ? p.groupMask[t] : 0u;
     const uint32_t mask = both & 15u, mine = sharded ? both >> 4 : 0u;
     uint32_t total;
-    const uint32_t offs = block_excl_scan((uint32_t)__popc(mask) | ((uint32_t)__popc(mine) << 16), &total);
+    const uint32_t offs = block_excl_scan(sharded ? (uint32_t)__popc(mask) | ((uint32_t)__popc(mine) << 16) : (uint32_t)__popc(mask), &total);
     const uint32_t off = offs & 0xFFFFu;
     uint32_t tris = 0;
     if (mask) {
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
                 cmd.meshletId = prim.meshletBase + p.groupIndices[idxBase + i];
                 cmd.slot = slot;                                            // instance_culling.hlsl:203-206
                 outCmds[slot] = cmd;
-                if (mine & (1u << i)) p.mineCmds[mslot++] = cmd;            // the rank's own list: same order, same slots
+                if (sharded && (mine & (1u << i))) p.mineCmds[mslot++] = cmd;   // the rank's own list: same order, same slots
                 if (!PREFIXED) tris += (p.meshlets[cmd.meshletId].vertexTriangleCount >> 8) & 0xFFu;
                 slot++;
             }
@@ -890,6 +892,9 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     FrameTail none;
     std::memset(&none, 0, sizeof(none));
     const bool hier = c->cullMode == 1 && c->bvhComplete && c->dBvhNodes;
+    const bool sh = p.shard.ranks > 1u;
+#define LAUNCH_COUNT(FM, grid, ...) do { if (sh) hipLaunchKernelGGL((group_cull_count_kernel<FM, true>), grid, dim3(256), 0, c->stream, __VA_ARGS__); \
+                                          else    hipLaunchKernelGGL((group_cull_count_kernel<FM, false>), grid, dim3(256), 0, c->stream, __VA_ARGS__); } while (0)
     if (blocks > 512u || hier) {
         // (the mask array is a multiple of 16 bytes long: dalloc rounds nothing, so the tail is zeroed by the last partial vector
         // only when it exists -- the buffer is allocated with 16 bytes of slack, see upload_scene)
@@ -901,22 +906,22 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
             bp.g = p; bp.nodes = c->dBvhNodes; bp.objectCount = c->objectCount;
             const uint32_t bb = std::min((c->objectCount * 9u + 3u) / 4u, (uint32_t)c->numCUs * 8u);
             hipLaunchKernelGGL(bvh_cull_kernel, dim3(std::max(bb, 1u)), dim3(256), 0, c->stream, bp, c->hView);
-            hipLaunchKernelGGL(group_cull_count_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p, c->hView, (DView*)nullptr,
-                               (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
+            LAUNCH_COUNT(true, dim3(blocks), p, c->hView, (DView*)nullptr, (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
         } else {
-            hipLaunchKernelGGL(group_cull_count_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p, c->hView, (DView*)nullptr,
-                               (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
+            LAUNCH_COUNT(false, dim3(blocks), p, c->hView, (DView*)nullptr, (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
         }
     } else {
-        hipLaunchKernelGGL(group_cull_count_kernel<false>, dim3(blocks + tail.run), dim3(256), 0, c->stream, p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4,
-                           blocks, tail);
+        LAUNCH_COUNT(false, dim3(blocks + tail.run), p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4, blocks, tail);
     }
+#undef LAUNCH_COUNT
     c->viewDirty = false;
     if (blocks > 512u) {
         hipLaunchKernelGGL(group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters, p.mineCount);
-        hipLaunchKernelGGL(group_cull_scatter_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+        if (sh) hipLaunchKernelGGL((group_cull_scatter_kernel<true, true>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+        else    hipLaunchKernelGGL((group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
     } else {
-        hipLaunchKernelGGL(group_cull_scatter_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+        if (sh) hipLaunchKernelGGL((group_cull_scatter_kernel<false, true>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+        else    hipLaunchKernelGGL((group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
     }
 }
 
