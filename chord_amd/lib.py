@@ -65,6 +65,7 @@ class Stats(C.Structure):
         ("pixelBlockBytes", C.c_uint64),
         ("pixelBlocks", C.c_uint64),
         ("msExchangeHzb", C.c_float), ("msExchangeVis", C.c_float),
+        ("rasterSmallPasses", C.c_uint32), ("reserved0", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -248,12 +249,17 @@ def make_views(camera, last_view=None):
     return view, iv
 
 
-def fill_objects(scene, camera, camera_last=None):
-    """SceneNode::getObjectBasicData for every object of a scenes.Scene (static objects)."""
+def fill_objects(scene, camera, camera_last=None, local_to_world_last=None):
+    """SceneNode::getObjectBasicData for every object of a scenes.Scene (static objects unless local_to_world_last -- the
+    objects' transforms of the previous frame, same layout as scene.local_to_world -- says otherwise)."""
     cam = (C.c_double * 3)(*camera.position)
     cam_last = (C.c_double * 3)(*(camera_last or camera).position)
     l2w = scene.local_to_world
-    rc = lib.chordvis_object_basic_data_batch(len(scene.objects), l2w.ctypes.data, None, cam, cam_last,
+    if local_to_world_last is not None:
+        local_to_world_last = np.ascontiguousarray(local_to_world_last, dtype=np.float64)
+        assert local_to_world_last.shape == l2w.shape
+    rc = lib.chordvis_object_basic_data_batch(len(scene.objects), l2w.ctypes.data,
+                                              local_to_world_last.ctypes.data if local_to_world_last is not None else None, cam, cam_last,
                                               scene.objects.ctypes.data)
     if rc != OK:
         raise ChordvisError("chordvis_object_basic_data_batch -> %d" % rc)
