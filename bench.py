@@ -332,17 +332,13 @@ def main():
     block_bytes = sum(pv["pixelBlockBytes"] for pv in per_view) / 2.0
     tiles1 = sum(pv["tilesTouched"][1] for pv in per_view) / 2.0
     launches = max(1, st["rasterLaunches"])
-    # a short second pass takes the bin-less form (raster_small_pass_kernel: its time is in msRasterCluster): no tile kernel
-    # launch, no bins, no read-modify-write of the touched tiles
-    small_passes = sum(pv.get("rasterSmallPasses", 0) for pv in per_view) / 2.0
-    tile_launches = max(1.0, launches - small_passes)
     kernels = {
-        "raster_setup_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame + rec_bytes + block_bytes + 4.0 * bins, launches),
-        "raster_tile_kernel": (st["msRasterChunk"], 4.0 * bins + rec_size * (bins - blocks) + block_bytes + 8.0 * pixels + (tile_launches - 1) * 16.0 * 4096 * tiles1, tile_launches),
+        "raster_setup_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame + rec_bytes + block_bytes + 4.0 * bins),
+        "raster_tile_kernel": (st["msRasterChunk"], 4.0 * bins + rec_size * (bins - blocks) + block_bytes + 8.0 * pixels + (launches - 1) * 16.0 * 4096 * tiles1),
     }
     dom = max(kernels, key=lambda k: kernels[k][0])
-    dom_ms, dom_bytes, dom_launches = kernels[dom]
-    achieved = (dom_bytes / dom_launches) / (dom_ms / dom_launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    dom_ms, dom_bytes = kernels[dom]
+    achieved = (dom_bytes / launches) / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     # HBM traffic of that kernel from the PMC counters: they need their own rocprofv3 passes, so the figure comes from
     # the committed summary of those passes over this same command (profiles/, tools/profile.sh), per launch
     traffic, traffic_src = None, None
@@ -363,9 +359,9 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom + (" (raster_setup_blocks_kernel + raster_setup_kernel)" if dom == "raster_setup_kernel" and blocks > 0 else ""), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "from_committed_profile": traffic is not None,   # (PMC passes cannot run inside this process: not observed in THIS run)
-                "avg_launch_us": round(dom_ms / dom_launches * 1e3, 2), "launches_per_step": dom_launches,
-                "algorithmic_bytes_per_launch": int(dom_bytes / dom_launches),
-                "other_kernel": {k: {"avg_launch_us": round(v[0] / v[2] * 1e3, 2), "algorithmic_bytes_per_launch": int(v[1] / v[2])}
+                "avg_launch_us": round(dom_ms / launches * 1e3, 2), "launches_per_step": launches,
+                "algorithmic_bytes_per_launch": int(dom_bytes / launches),
+                "other_kernel": {k: {"avg_launch_us": round(v[0] / launches * 1e3, 2), "algorithmic_bytes_per_launch": int(v[1] / launches)}
                                  for k, v in kernels.items() if k != dom}}
 
     # ---- N > 1: the same workload unsharded on rank 0's GPU, measured live, so that the line carries its own
@@ -469,7 +465,7 @@ def main():
             "clusters_rastered_per_step": clusters_per_frame, "triangle_records_per_step": recs, "bin_entries_per_step": bins, "pixel_blocks_per_step": blocks, "pixel_block_bytes_per_step": block_bytes,
             "gpu_ms": {k: round(st[k], 4) for k in ("msClear", "msInstanceCulling", "msStage0", "msHzbStage0", "msStage1",
                                                      "msHzbFinal", "msFrame", "msRasterCluster", "msRasterClip", "msRasterChunk")},
-            "small_passes_per_step": small_passes, "tiles_touched_view_a": per_view[0]["tilesTouched"], "tiles_total": ((W + 63) // 64) * ((H + 63) // 64),
+            "tiles_touched_view_a": per_view[0]["tilesTouched"], "tiles_total": ((W + 63) // 64) * ((H + 63) // 64),
             "counts_view_a": {k: per_view[0][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},
             "counts_view_b": {k: per_view[1][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},
             "roofline": roofline,

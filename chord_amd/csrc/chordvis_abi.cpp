@@ -121,15 +121,6 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         CHORD_HIP(c, hipMemset(c->dTileSlabs, 0, tilesN * CHORD_TILE * CHORD_TILE * sizeof(unsigned long long)));
     }
     if ((rc = dalloc(c, &c->dTileRange, (size_t)2 * CHORD_MAX_TILES))) return rc;
-    if ((rc = dalloc(c, &c->dTileDirty, (size_t)CHORD_MAX_TILES))) return rc;
-    CHORD_HIP(c, hipMemset(c->dTileDirty, 0, sizeof(uint32_t) * CHORD_MAX_TILES));
-    if (!c->hPassHint) {
-        void* h = nullptr;
-        CHORD_HIP(c, hipHostMalloc(&h, 64, hipHostMallocMapped));
-        std::memset(h, 0, 64);
-        c->hPassHint = static_cast<volatile uint32_t*>(h);
-    }
-    c->hPassHint[2] = 0u;
     {   // one {min, max} partial per block of the mip-0 kernel (64 x 4 texels per block)
         const uint32_t vw = (c->width + 1) / 2, vh = (c->height + 1) / 2;
         if ((rc = dalloc(c, &c->dRangePartials, (size_t)((vw + 63) / 64) * ((vh + 3) / 4) * 2))) return rc;
@@ -212,7 +203,7 @@ int begin_frame_clear(ChordCtx* c)
     // kernel (object_cull), not by a separate memset
     c->frameStateZeroBytes = offsetof(FrameState, tileCount) + sizeof(uint32_t) * CHORD_TILECOUNT_STRIDE * ((size_t)2 * c->tilesX * c->tilesY);
     c->zeroFrameStateInCull = true;
-    c->rasterCalls = 0; c->smallPasses = 0;
+    c->rasterCalls = 0;
     c->pendingClear = true;
     c->inFrame = true;
     return CHORDVIS_OK;
@@ -339,8 +330,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
-    if (c->hPassHint) { (void)hipHostFree(const_cast<uint32_t*>(c->hPassHint)); c->hPassHint = nullptr; }
-    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dTileDirty); dfree(c->dHzbExchange); dfree(c->dHzbExchangeMax); dfree(c->dRangeExchange); dfree(c->dVisAlt); dfree(c->dVisResolvedAlt); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
+    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dHzbExchangeMax); dfree(c->dRangeExchange); dfree(c->dVisAlt); dfree(c->dVisResolvedAlt); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
     dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -770,7 +760,7 @@ int chordvis_clear_gbuffer(ChordCtx* c)
         CHORD_HIP(c, hipMemsetAsync(c->dVis, 0, c->visWords * 8, c->stream));
     }
     CHORD_HIP(c, hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters), c->stream));
-    c->rasterCalls = 0; c->smallPasses = 0;
+    c->rasterCalls = 0;
     c->pendingClear = false;
     c->inFrame = false;
     return CHORDVIS_OK;
@@ -1349,7 +1339,6 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
     }
     out->overflow = dc.overflow;
     out->rasterLaunches = c->rasterCalls;
-    out->rasterSmallPasses = c->smallPasses;
     for (uint32_t i = 0; i < CHORD_LIST_SHARDS; i++) {
         out->triangleRecords += dc.triCount[i * CHORD_SHARD_STRIDE] + dc.triCountC[i * CHORD_SHARD_STRIDE];
         out->triangleRecordsCompact += dc.triCountC[i * CHORD_SHARD_STRIDE];

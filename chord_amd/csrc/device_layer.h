@@ -292,9 +292,6 @@ struct ChordCtx {
     int pendingTailSlot = 0;          // history chain whose mips 6.. + valid range are still to be reduced (carried by the next frame's first kernel)
     uint32_t* dRangePartials = nullptr;   // per mip-0 block {min, max} of valid depth
     uint32_t* dTileRange = nullptr;       // per 64x64 tile {min, max} of valid depth (fused HZB)
-    uint32_t* dTileDirty = nullptr;       // per tile: a bin-less later pass wrote into it (raster_small_pass_kernel -> hzb_dirty_tiles_kernel)
-    volatile uint32_t* hPassHint = nullptr;   // pinned, device-visible: {clusters, clipped triangles, raster serial} of the last later pass the GPU finished
-    uint32_t smallPasses = 0;             // later passes that took the bin-less form (statistics)
     bool fuseHzb = false;                 // inside render_frame: the tile kernel emits HZB mips 0..5
     bool fuseHzbTemp = false;             // ... also into the temporary chain (slot 0) for stage 1
     int fuseHzbSlot = 1;                  // history slot being produced this frame

@@ -86,8 +86,6 @@ struct RasterParams {
     uint32_t depthOnly, depthClamp;                     // PASS_TYPE_DEPTH (renderMeshDepth, mesh_raster.cpp:159-206): cull NONE, no id; depth clamp: near / far do not clip
     float biasConst, biasSlope;                         // vkCmdSetDepthBias(const, 0, slope), applied to the vertex depths of a depth-pass triangle
     uint32_t clearTiles;                                // first raster pass of a frame: tiles start from 0
-    uint32_t* tileDirty;                                // small later passes (raster_small_pass_kernel): tiles whose words changed, re-reduced by hzb_dirty_tiles_kernel
-    volatile uint32_t* hint;                            // host-visible {clusters, clipped triangles, serial} of a later pass, or NULL (launch_raster reads it a frame later)
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
 #define DBG_NO_PIXELS   1u    // skip every visibility write
@@ -103,8 +101,6 @@ struct RasterParams {
 #define DBG_NO_ENTRY    8192u // tile kernel fetches bin entries and records but does nothing with them
 #define DBG_NO_BATCH    16384u // tile kernel skips the bin altogether (tile in + tile out only)
 #define DBG_NO_UNITS    4096u // tile kernel skips the row units (entries are still fetched, set up, scanned and listed)
-#define DBG_FORCE_DIRECT 524288u // every eligible later pass takes the bin-less form (tests: whatever the hint says)
-#define DBG_NO_DIRECT   1048576u // ... never does (A/B)
 
 __device__ __forceinline__ int32_t bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
@@ -2125,16 +2121,6 @@ __device__ __forceinline__ void merge_blocks(unsigned long long* tile, const uns
     }
 }
 
-// A later pass reports its length to the host (RasterParams::hint, read by launch_raster a frame later).
-__device__ __forceinline__ void write_pass_hint(const RasterParams& p)
-{
-    if (p.hint && blockIdx.x == 0u && threadIdx.x == 0u) {
-        p.hint[0] = *p.count; p.hint[1] = p.counters->clipTriCount[p.pass];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        p.hint[2] = p.binStamp;
-    }
-}
-
 template <bool SH, bool MASKED, bool DEPTH>
 __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
 {
@@ -2146,7 +2132,6 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     __shared__ uint32_t chunkTab[64];                            // the overflow chunks this item's entries live in
     __shared__ uint32_t sTicket;
     if ((p.debug & DBG_TILE_EXIT) && !p.clearTiles) return;
-    write_pass_hint(p);
     // (the item count and the block's first item are fetched together: one round trip, not two dependent ones; the
     // list has an entry for every tile, so slot 1 + blockIdx.x exists whether or not it is active)
     uint2 firstItem = p.tileOrder[1u + min(blockIdx.x, p.tilesX * p.tilesY - 1u)];
@@ -2410,307 +2395,6 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     }
 }
 
-// ---- small later pass: no bins --------------------------------------------------------------------------------------------
-// The second raster pass of a two-pass frame usually holds a few hundred clusters (config 3: ~200 of 8 900, 22 k triangles)
-// and paid five launches near the floor for them: set-up -> records + bins, clipper / large binning, tile order, tile kernel
-// with a read-modify-write of every touched 32-KB tile.  This form needs two: one WORKGROUP per cluster transforms, culls
-// and sets its triangles up (one thread per vertex / per triangle, the same arithmetic as raster_setup_body), keeps them in
-// LDS and scan-converts them straight into the visibility buffer -- a wave takes a triangle's bounding box in 8x8-pixel
-// blocks, one pixel per lane, so the covered lanes of a row are one 64-byte line and the memory-side atomic units see
-// 8-lane requests (214 Gop/s against 26 scattered, tools/microbench/atomics.hip) -- and marks the 64x64 tiles it touched;
-// hzb_dirty_tiles_kernel then re-reduces exactly those tiles to their HZB texels and range with the tile kernel's own
-// reduction.  The image is the same by construction (the 64-bit max is order-free) and the HZB is reduced from it.
-// Clipped triangles (rare) are cut by thread 0 and their pieces join the entry list.  Which form a pass takes is the
-// host's choice from the previous frame's counts (RasterParams::hint): both forms are correct for any list, this one
-// degrades on long lists (a cluster's fragments are global atomics) and on screen-filling triangles (one workgroup each).
-#define SP_THREADS 1024u         // 16 waves per cluster: one workgroup per CU and few of them -- the waves of ONE cluster are the latency hiding there is
-#define SP_WAVES (SP_THREADS / 64u)
-#define SP_ENT_CAP 160u          // entries per round: a cluster's <= 128 triangles, or the pieces of clipped ones (<= 8 each)
-#define SP_SHARE_BLOCKS 8u       // a triangle of more 8x8 blocks than this is shared by the workgroup's waves
-#define SP_TINY_AREA 64          // bbox pixels the triangle's own thread scans (no entry, one lane per triangle)
-#define SP_MAX_CLUSTERS 1024u    // longer lists take the binned form
-
-struct SpEntries {
-    int32_t X[3][SP_ENT_CAP], Y[3][SP_ENT_CAP];
-    float d0[SP_ENT_CAP], e1[SP_ENT_CAP], e2[SP_ENT_CAP], invA[SP_ENT_CAP];
-    uint32_t payload[SP_ENT_CAP], boxX[SP_ENT_CAP], boxY[SP_ENT_CAP];   // px0 | px1 << 16, py0 | py1 << 16
-    uint32_t flags[SP_ENT_CAP];                                         // bit 0: s < 0; bits 1..2: 0 int32 / 1 fp64 / 2 int64 edges
-};
-
-__device__ __forceinline__ void sp_mark_tiles(const RasterParams& p, const TriSetup& ts)
-{
-    for (int32_t ty = ts.py0 >> TILE_SHIFT; ty <= ts.py1 >> TILE_SHIFT; ty++)
-        for (int32_t tx = ts.px0 >> TILE_SHIFT; tx <= ts.px1 >> TILE_SHIFT; tx++) p.tileDirty[(uint32_t)ty * p.tilesX + (uint32_t)tx] = 1u;
-}
-
-// one lane scans its own tiny bbox (tile_raster_narrow's flattened loop, into memory: a covered pixel is one atomic)
-__device__ __forceinline__ void sp_raster_tiny(const RasterParams& p, const TriSetup& ts)
-{
-    const bool neg = ts.s < 0;
-    const int32_t dx0 = ts.X[2] - ts.X[1], dy0 = ts.Y[2] - ts.Y[1];
-    const int32_t dx1 = ts.X[0] - ts.X[2], dy1 = ts.Y[0] - ts.Y[2];
-    const int32_t dx2 = ts.X[1] - ts.X[0], dy2 = ts.Y[1] - ts.Y[0];
-    const int32_t a0 = neg ? dy0 : -dy0, b0 = neg ? -dx0 : dx0;
-    const int32_t a1 = neg ? dy1 : -dy1, b1 = neg ? -dx1 : dx1;
-    const int32_t a2 = neg ? dy2 : -dy2, b2 = neg ? -dx2 : dx2;
-    const int32_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? 0 : -1;
-    const int32_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 0 : -1;
-    const int32_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 0 : -1;
-    const int32_t cx0 = ts.px0 * 256 + 128, cy0 = ts.py0 * 256 + 128;
-    int32_t E0 = __mul24(b0, cy0 - ts.Y[1]) + __mul24(a0, cx0 - ts.X[1]) + bias0;   // bias folded in: inside <=> all >= 0
-    int32_t E1 = __mul24(b1, cy0 - ts.Y[2]) + __mul24(a1, cx0 - ts.X[2]) + bias1;
-    int32_t E2 = __mul24(b2, cy0 - ts.Y[0]) + __mul24(a2, cx0 - ts.X[0]) + bias2;
-    const int32_t w = ts.px1 - ts.px0 + 1, count = __mul24(w, ts.py1 - ts.py0 + 1);
-    const int32_t sx0 = a0 * 256, sx1 = a1 * 256, sx2 = a2 * 256;
-    const int32_t sw0 = b0 * 256 - __mul24(w - 1, sx0), sw1 = b1 * 256 - __mul24(w - 1, sx1), sw2 = b2 * 256 - __mul24(w - 1, sx2);
-    unsigned long long* px = p.vis + (size_t)ts.py0 * (size_t)p.Wi + (size_t)ts.px0;
-    const unsigned long long payload = (unsigned long long)ts.payload;
-    int32_t col = 0;
-    for (int32_t i = 0; i < count; i++) {
-        if ((E0 | E1 | E2) >= 0) {
-            const float l1 = (float)(E1 - bias1) * ts.invA, l2 = (float)(E2 - bias2) * ts.invA;   // exact integers below 2^31: one rounding
-            const float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
-            atomicMax(px, ((unsigned long long)__float_as_uint(z) << 32) | payload);
-        }
-        const bool wrap = col == w - 1;
-        E0 += wrap ? sw0 : sx0; E1 += wrap ? sw1 : sx1; E2 += wrap ? sw2 : sx2;
-        px += wrap ? p.Wi - (w - 1) : 1;
-        col = wrap ? 0 : col + 1;
-    }
-}
-
-__device__ __forceinline__ void sp_store_entry(const RasterParams& p, SpEntries& en, uint32_t k, const TriSetup& ts)
-{
-    int32_t mag = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { en.X[i][k] = ts.X[i]; en.Y[i][k] = ts.Y[i]; mag = max(mag, max(abs(ts.X[i]), abs(ts.Y[i]))); }
-    en.d0[k] = ts.d0; en.e1[k] = ts.e1; en.e2[k] = ts.e2; en.invA[k] = ts.invA; en.payload[k] = ts.payload;
-    en.boxX[k] = (uint32_t)ts.px0 | ((uint32_t)ts.px1 << 16); en.boxY[k] = (uint32_t)ts.py0 | ((uint32_t)ts.py1 << 16);
-    en.flags[k] = (ts.s < 0 ? 1u : 0u) | ((narrow_extent(ts) ? 0u : mag < (1 << 25) ? 1u : 2u) << 1);
-    sp_mark_tiles(p, ts);
-}
-
-// blocks first, first + step, ... of entry e: lane = pixel (lane & 7, lane >> 3) of an 8-aligned 8x8 block
-template <typename E_t>
-__device__ __forceinline__ void sp_raster_entry(const RasterParams& p, const SpEntries& en, uint32_t e, uint32_t first, uint32_t step, uint32_t lane)
-{
-    const uint32_t bX = en.boxX[e], bY = en.boxY[e], fl = en.flags[e];
-    const int32_t px0 = (int32_t)(bX & 0xFFFFu), px1 = (int32_t)(bX >> 16), py0 = (int32_t)(bY & 0xFFFFu), py1 = (int32_t)(bY >> 16);
-    const int32_t bx0 = px0 >> 3, by0 = py0 >> 3, bw = (px1 >> 3) - bx0 + 1, bh = (py1 >> 3) - by0 + 1;
-    const uint32_t nb = (uint32_t)bw * (uint32_t)bh;
-    const int32_t X0 = en.X[0][e], X1 = en.X[1][e], X2 = en.X[2][e], Y0 = en.Y[0][e], Y1 = en.Y[1][e], Y2 = en.Y[2][e];
-    const float d0 = en.d0[e], e1 = en.e1[e], e2 = en.e2[e], invA = en.invA[e];
-    const unsigned long long payload = (unsigned long long)en.payload[e];
-    // the edge functions as scan_row has them: E_i = s * (dx_i * (cy - Y) - dy_i * (cx - X)) + bias_i, inside <=> all >= 0
-    const E_t s = (fl & 1u) ? (E_t)-1 : (E_t)1;
-    const E_t dx0 = (E_t)(X2 - X1), dy0 = (E_t)(Y2 - Y1), dx1 = (E_t)(X0 - X2), dy1 = (E_t)(Y0 - Y2), dx2 = (E_t)(X1 - X0), dy2 = (E_t)(Y1 - Y0);
-    const E_t a0 = -s * dy0, b0 = s * dx0, a1 = -s * dy1, b1 = s * dx1, a2 = -s * dy2, b2 = s * dx2;
-    const E_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? (E_t)0 : (E_t)-1;
-    const E_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? (E_t)0 : (E_t)-1;
-    const E_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? (E_t)0 : (E_t)-1;
-    int32_t bxi = (int32_t)first, byi = 0;
-    while (bxi >= bw) { bxi -= bw; byi++; }
-    for (uint32_t b = first; b < nb; b += step) {
-        const int32_t x = ((bx0 + bxi) << 3) + (int32_t)(lane & 7u), y = ((by0 + byi) << 3) + (int32_t)(lane >> 3);
-        const E_t cx = (E_t)x * (E_t)256 + (E_t)128, cy = (E_t)y * (E_t)256 + (E_t)128;
-        E_t E0, E1, E2;
-        if (std::is_same<E_t, int32_t>::value) {
-            // (vertices at most 64 px apart and a pixel inside their bbox: 24-bit factors, |E| < 2^30; lanes outside the bbox
-            // compute garbage and are masked below)
-            E0 = (E_t)(__mul24((int32_t)b0, (int32_t)cy - Y1) + __mul24((int32_t)a0, (int32_t)cx - X1)) + bias0;
-            E1 = (E_t)(__mul24((int32_t)b1, (int32_t)cy - Y2) + __mul24((int32_t)a1, (int32_t)cx - X2)) + bias1;
-            E2 = (E_t)(__mul24((int32_t)b2, (int32_t)cy - Y0) + __mul24((int32_t)a2, (int32_t)cx - X0)) + bias2;
-        } else {
-            E0 = s * (dx0 * (cy - (E_t)Y1) - dy0 * (cx - (E_t)X1)) + bias0;
-            E1 = s * (dx1 * (cy - (E_t)Y2) - dy1 * (cx - (E_t)X2)) + bias1;
-            E2 = s * (dx2 * (cy - (E_t)Y0) - dy2 * (cx - (E_t)X0)) + bias2;
-        }
-        const bool inside = std::is_floating_point<E_t>::value ? (E0 >= (E_t)0 && E1 >= (E_t)0 && E2 >= (E_t)0)
-                                                              : (((int64_t)E0 | (int64_t)E1 | (int64_t)E2) >= 0);
-        if (inside && x >= px0 && x <= px1 && y >= py0 && y <= py1) {
-            // canonical l_i = float(E_i) * invA with E_i the unbiased integer
-            const float l1 = (float)(double)(E1 - bias1) * invA, l2 = (float)(double)(E2 - bias2) * invA;
-            const float z = (d0 + l1 * e1) + l2 * e2;
-            atomicMax(p.vis + (size_t)y * (size_t)p.Wi + (size_t)x, ((unsigned long long)__float_as_uint(z) << 32) | payload);
-        }
-        bxi += (int32_t)step;
-        while (bxi >= bw) { bxi -= bw; byi++; }
-    }
-}
-
-// entries [0, n) of the workgroup: a short one by the wave its index names, a long one by all of them
-__device__ __forceinline__ void sp_raster_entries(const RasterParams& p, const SpEntries& en, uint32_t n)
-{
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t e = 0; e < n; e++) {
-        const uint32_t bX = en.boxX[e], bY = en.boxY[e];
-        const uint32_t nb = (((bX >> 16) >> 3) - ((bX & 0xFFFFu) >> 3) + 1u) * (((bY >> 16) >> 3) - ((bY & 0xFFFFu) >> 3) + 1u);
-        const bool shared = nb > SP_SHARE_BLOCKS;
-        if ((p.debug & 2097152u) && nb > 32u) continue;              // (ablation: no big triangles)
-        if ((p.debug & 4194304u)) continue;                          // (ablation: no entries at all)
-        if (!shared && (e % SP_WAVES) != wave) continue;
-        const uint32_t first = shared ? wave : 0u, step = shared ? SP_WAVES : 1u;
-        const uint32_t kind = en.flags[e] >> 1;
-        if (kind == 0u) sp_raster_entry<int32_t>(p, en, e, first, step, lane);
-        else if (kind == 1u) sp_raster_entry<double>(p, en, e, first, step, lane);
-        else sp_raster_entry<int64_t>(p, en, e, first, step, lane);
-    }
-}
-
-__global__ __launch_bounds__(SP_THREADS) void raster_small_pass_kernel(RasterParams p)
-{
-    __shared__ float sV[6][256];                                 // x, y, w, u, v, depth of the cluster's vertices
-    __shared__ SpEntries en;
-    __shared__ uint32_t sWaveCnt[2], sClipTri[128], sClipN, sEntN, sClipCursor;              // (triangles live in waves 0 and 1)
-    __shared__ float4 sPoly[2 * CLIP_MAXV];
-    __shared__ float sPU[2 * CLIP_MAXV], sPV[2 * CLIP_MAXV], sPD[CLIP_MAXV];
-    __shared__ int32_t sPX[CLIP_MAXV], sPY[CLIP_MAXV];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, tid = threadIdx.x;
-    float* lX = sV[0]; float* lY = sV[1]; float* lW = sV[2]; float* lU = sV[3]; float* lV = sV[4]; float* lD = sV[5];
-    const uint32_t count = scalar_load(p.count);
-    for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
-        const uint32_t* __restrict__ cw = reinterpret_cast<const uint32_t*>(p.cmds + c);
-        const uint32_t objectId = scalar_load(cw), meshletId = scalar_load(cw + 1), slot = scalar_load(cw + 2);
-        const DMeshlet* __restrict__ mm = &p.meshlets[meshletId];
-        const uint32_t vt = scalar_load(&mm->vertexTriangleCount);
-        const uint32_t V = vt & 0xFFu, dataOffset = scalar_load(&mm->dataOffset), vertexBase = scalar_load(&mm->vertexBase);
-        const uint32_t matFlags = scalar_load(&p.objStatic[objectId].matFlags);
-        const uint32_t T = CHORD_MATFLAG_ALPHA(matFlags) >= CHORD_ALPHA_BLEND ? 0u : (vt >> 8) & 0xFFu;   // blended: in no bucket of renderMesh (mesh_raster.cpp:224)
-        const bool twoSided = (matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u;
-        Mat4 mvp;
-        {
-            const float* __restrict__ mv = p.objFrame[objectId].mvp;
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = scalar_load(mv + r * 4 + cc);
-        }
-        if (tid == 0u) sClipN = 0u;
-        // ---- vertex phase (mesh_raster.hlsl:84-105), one thread per vertex ----
-        bool notFast = false;
-        if (tid < V) {
-            const float* __restrict__ pp = p.positions + (size_t)(p.meshletData[dataOffset + tid] + vertexBase) * 3;
-            const f4 h = mul_mv(mvp, pp[0], pp[1], pp[2], 1.0f);         // :99
-            const float aw = fabsf(h.w);
-            lX[tid] = h.x; lY[tid] = h.y; lW[tid] = h.w;
-            lU[tid] = h.x / aw * 0.5f + 0.5f;                           // :159-161
-            lV[tid] = h.y / aw * -0.5f + 0.5f;
-            const bool fast = in_fast_volume(h);
-            lD[tid] = fast ? h.z / h.w : __builtin_nanf("");
-            notFast = !fast;
-        }
-        const uint32_t packedIdx = tid < T ? p.meshletData[dataOffset + V + tid] : 0u;
-        const bool allFast = __syncthreads_or(notFast ? 1 : 0) == 0;
-        // ---- triangle phase, one thread per triangle: the culls and the set-up of raster_setup_body ----
-        int kind = K_NONE;
-        TriSetup ts;
-        ts.px0 = ts.py0 = ts.px1 = ts.py1 = 0;
-        if (tid < T) {
-            const uint32_t i0 = packedIdx & 0xFFu, i1 = (packedIdx >> 8) & 0xFFu, i2 = (packedIdx >> 16) & 0xFFu;
-            const float x0 = lX[i0], y0 = lY[i0], w0 = lW[i0];
-            const float x1 = lX[i1], y1 = lY[i1], w1 = lW[i1];
-            const float x2 = lX[i2], y2 = lY[i2], w2 = lW[i2];
-            bool culled = false;
-            if (!twoSided) {                                                  // #0 mesh_raster.hlsl:143-149
-                const float det = (x0 * (y1 * w2 - w1 * y2) - y0 * (x1 * w2 - w1 * x2)) + w0 * (x1 * y2 - y1 * x2);
-                culled = det <= 0.0f;
-            }
-            culled = culled || (w0 <= 0.0f && w1 <= 0.0f && w2 <= 0.0f);     // #1 :152-155
-            const float u0 = lU[i0], v0 = lV[i0], u1 = lU[i1], v1 = lV[i1], u2 = lU[i2], v2 = lV[i2];
-            const float maxU = fmaxf(u0, fmaxf(u1, u2)), maxV = fmaxf(v0, fmaxf(v1, v2));
-            const float minU = fminf(u0, fminf(u1, u2)), minV = fminf(v0, fminf(v1, v2));
-            culled = culled || ((minU >= 1.0f || minV >= 1.0f) || (maxU <= 0.0f || maxV <= 0.0f));   // #2 :168-171
-            culled = culled || (rintf(minU * p.W) == rintf(maxU * p.W) || rintf(minV * p.H) == rintf(maxV * p.H)); // #3 :174-179
-            if (!culled) {
-                const float d[3] = {lD[i0], lD[i1], lD[i2]};
-                ts.payload = encode_triangle_instance(tid, slot);
-                if (!allFast && (d[0] != d[0] || d[1] != d[1] || d[2] != d[2])) {
-                    kind = K_CLIP;
-                } else {
-                    ts.X[0] = (int32_t)rintf((u0 * p.W) * 256.0f); ts.Y[0] = (int32_t)rintf((v0 * p.H) * 256.0f);
-                    ts.X[1] = (int32_t)rintf((u1 * p.W) * 256.0f); ts.Y[1] = (int32_t)rintf((v1 * p.H) * 256.0f);
-                    ts.X[2] = (int32_t)rintf((u2 * p.W) * 256.0f); ts.Y[2] = (int32_t)rintf((v2 * p.H) * 256.0f);
-                    if (tri_setup(ts, twoSided, p.Wi, p.Hi)) { kind = K_EMIT; ts.d0 = d[0]; ts.e1 = d[1] - d[0]; ts.e2 = d[2] - d[0]; }
-                }
-            }
-        }
-        // tiny triangles are scanned by their own thread; the others become entries the waves share
-        const bool tiny = kind == K_EMIT && narrow_extent(ts) && (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1) <= SP_TINY_AREA;
-        const unsigned long long em = __ballot(kind == K_EMIT && !tiny);
-        if (lane == 0u && wave < 2u) sWaveCnt[wave] = (uint32_t)__popcll(em);
-        if (kind == K_CLIP) sClipTri[atomicAdd(&sClipN, 1u)] = tid;
-        if (tiny && !(p.debug & 8388608u)) { sp_mark_tiles(p, ts); sp_raster_tiny(p, ts); }
-        __syncthreads();
-        const uint32_t n = sWaveCnt[0] + sWaveCnt[1];
-        if (kind == K_EMIT && !tiny) sp_store_entry(p, en, (wave ? sWaveCnt[0] : 0u) + (uint32_t)__popcll(em & ((1ull << lane) - 1ull)), ts);
-        __syncthreads();
-        sp_raster_entries(p, en, n);
-        // ---- clipped triangles: thread 0 cuts them, their pieces are entries of further rounds ----
-        const uint32_t nclip = sClipN;
-        if (nclip) {
-            if (tid == 0u) atomicAdd(&p.counters->clipTriCount[p.pass], nclip);    // (what the hint reports)
-            uint32_t ci = 0;
-            while (ci < nclip) {
-                __syncthreads();                                              // the entries of the last round are done with
-                if (tid == 0u) {
-                    const ClipLds<1u> L = {sPoly, sPU, sPV, sPX, sPY, sPD, 0u};
-                    uint32_t k = 0;
-                    while (ci < nclip && k + (CLIP_MAXV - 2u) <= SP_ENT_CAP) {
-                        const uint32_t tri = sClipTri[ci++];
-                        int cur;
-                        const int np = clip_triangle(p, L, *mm, V, tri, mvp, false, cur);
-                        for (int i = 1; i + 1 < np; i++) {
-                            TriSetup tc;
-                            tc.X[0] = L.X(0); tc.X[1] = L.X(i); tc.X[2] = L.X(i + 1);
-                            tc.Y[0] = L.Y(0); tc.Y[1] = L.Y(i); tc.Y[2] = L.Y(i + 1);
-                            tc.payload = encode_triangle_instance(tri, slot);
-                            if (!tri_setup(tc, twoSided, p.Wi, p.Hi)) continue;
-                            tc.d0 = L.D(0); tc.e1 = L.D(i) - L.D(0); tc.e2 = L.D(i + 1) - L.D(0);
-                            sp_store_entry(p, en, k++, tc);
-                        }
-                    }
-                    sEntN = k; sClipCursor = ci;
-                }
-                __syncthreads();
-                ci = sClipCursor;
-                sp_raster_entries(p, en, sEntN);
-            }
-        }
-        __syncthreads();                                                      // LDS is rewritten by the next cluster
-    }
-}
-
-// Tiles a small pass marked: their words back into LDS, then the tile kernel's own reduction to HZB mips 0..5 and the tile's
-// depth range (the visibility stores are switched off by the launcher: DBG_NO_VIS_STORE).  Block 0 reports the pass to the
-// host (see RasterParams::hint).
-__global__ __launch_bounds__(TB) void hzb_dirty_tiles_kernel(RasterParams p)
-{
-    __shared__ __align__(16) unsigned long long tile[TILE * TPITCH];
-    __shared__ float sM2[128];
-    __shared__ uint32_t sRange[16];
-    write_pass_hint(p);
-    const uint32_t tiles = p.tilesX * p.tilesY;
-    for (uint32_t tileId = blockIdx.x; tileId < tiles; tileId += gridDim.x) {
-        if (scalar_load(&p.tileDirty[tileId]) == 0u) continue;
-        const int32_t ox = (int32_t)(tileId % p.tilesX) * TILE, oy = (int32_t)(tileId / p.tilesX) * TILE;
-        const int32_t tw = min(TILE, p.Wi - ox), th = min(TILE, p.Hi - oy);
-        for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
-            const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
-            ulonglong2 v = make_ulonglong2(0ull, 0ull);
-            if (ly < th && lx < tw) {
-                const unsigned long long* src = p.vis + (size_t)(oy + ly) * (size_t)p.Wi + ox + lx;
-                if (lx + 1 < tw) v = *reinterpret_cast<const ulonglong2*>(src);
-                else v.x = src[0];
-            }
-            tile[ly * TPITCH + lx] = v.x; tile[ly * TPITCH + lx + 1] = v.y;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0u) p.tileDirty[tileId] = 0u;
-        tile_out_and_hzb(p, tile, sM2, sRange, tileId, ox, oy, tw, th);
-        __syncthreads();
-    }
-}
-
 // ---- launcher ---------------------------------------------------------------------------------
 hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
 {
@@ -2771,32 +2455,6 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.tileClocks = c->dTileClocks + (size_t)pass * CHORD_MAX_TILES;
     p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrder); p.tileSlabs = c->dTileSlabs;
     p.tilePhase = c->dTileClocks + (size_t)2 * CHORD_MAX_TILES + (size_t)pass * CHORD_MAX_TILES * 8;
-
-    // ---- later pass of a fused single-GPU main-view frame: the bin-less form when the previous frame's pass was short --------
-    p.tileDirty = c->dTileDirty; p.hint = nullptr;
-    const bool directEligible = !clearTiles && p.hzbFused && c->shard.ranks == 1 && !c->anyMasked && !c->depthOnly && !c->depthClamp &&
-                                c->hPassHint && !(c->debugFlags & DBG_NO_DIRECT) && !(c->debugFlags & (DBG_TILE_CLOCKS | DBG_SETUP_CLOCKS));
-    if (directEligible) {
-        // (the hint is whatever later pass the GPU finished last: a frame or two old.  Both forms are correct for any list;
-        // a stale hint costs time on one frame, never the image)
-        void* dh = nullptr;
-        LR_HIP(hipHostGetDevicePointer(&dh, const_cast<uint32_t*>(c->hPassHint), 0));
-        p.hint = static_cast<volatile uint32_t*>(dh);
-        const uint32_t hClusters = c->hPassHint[0], hClipped = c->hPassHint[1], hSerial = c->hPassHint[2];
-        const bool fresh = hSerial != 0u && p.binStamp - hSerial < 64u;
-        const bool direct = (c->debugFlags & DBG_FORCE_DIRECT) || (fresh && hClusters <= SP_MAX_CLUSTERS && hClipped == 0u);
-        if (direct) {
-            stamp(c, S_HZBCULL);
-            const uint32_t grid = (fresh && hClusters) ? std::min(std::max(2u * hClusters, 64u), SP_MAX_CLUSTERS) : SP_MAX_CLUSTERS;
-            hipLaunchKernelGGL(raster_small_pass_kernel, dim3(grid), dim3(SP_THREADS), 0, c->stream, p);
-            stamp(c, S_R_CLUSTER);
-            p.debug |= DBG_NO_VIS_STORE;                                 // the words are in place: only the HZB texels and ranges leave
-            hipLaunchKernelGGL(hzb_dirty_tiles_kernel, dim3(tiles), dim3(TB), 0, c->stream, p);
-            stamp(c, S_R_CLIP);
-            c->rasterCalls++; c->smallPasses++;
-            return hipSuccess;
-        }
-    }
 
     // A frame zeroes every count once (begin_frame_clear); outside a frame, or from the third raster
     // call of a frame on, the pass slot is recycled here.

@@ -65,7 +65,6 @@ class Stats(C.Structure):
         ("pixelBlockBytes", C.c_uint64),
         ("pixelBlocks", C.c_uint64),
         ("msExchangeHzb", C.c_float), ("msExchangeVis", C.c_float),
-        ("rasterSmallPasses", C.c_uint32), ("reserved0", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -102,8 +102,8 @@ typedef struct ChordStats {
     float    msStage1;             /* "GLTF Visibility Stage1"           */
     float    msHzbFinal;           /* "BuildHZB"                         */
     float    msFrame;              /* clear .. final HZB                 */
-    float    msRasterCluster;      /* sum over the frame's raster_setup_kernel (per-meshlet setup + binning) / raster_small_pass_kernel launches */
-    float    msRasterClip;         /* ... raster_clip_and_bin_large_kernel + raster_tile_order_kernel / hzb_dirty_tiles_kernel */
+    float    msRasterCluster;      /* sum over the frame's raster_setup_kernel launches (per-meshlet setup + binning) */
+    float    msRasterClip;         /* ... raster_clip_and_bin_large_kernel + raster_tile_order_kernel                 */
     float    msRasterChunk;        /* ... raster_tile_kernel (per-tile resolve in LDS, tile-out, fused HZB mips 0-5)  */
     uint32_t framesTimed;          /* frames the ms* fields are averaged over               */
     uint32_t rasterLaunches;       /* renderMesh calls this frame (1 or 2)                  */
@@ -122,9 +122,6 @@ typedef struct ChordStats {
     uint64_t pixelBlocks;          /* number of those blocks (= their bin entries) */
     float    msExchangeHzb;        /* sharded frames: stream time between phase a and phase b = the all-gather of the HZB mip-0 exchange buffer */
     float    msExchangeVis;        /* ... between phase b and phase c = the all-gather of the visibility words (incl. waiting for the slowest rank) */
-    uint32_t rasterSmallPasses;    /* of rasterLaunches, those that took the bin-less form (raster_small_pass_kernel + hzb_dirty_tiles_kernel:
-                                      their time is in msRasterCluster / msRasterClip, they launch no tile kernel and bin nothing) */
-    uint32_t reserved0;
 } ChordStats;
 
 /* ------------------------------------------------------------------ host-only (no device needed) */
@@ -434,12 +431,10 @@ int chordvis_stats(ChordCtx* ctx, ChordStats* out);
  * triangles, 64 tile kernel of later passes returns at once, 128 no tile-out, 256 tile-out without the HZB
  * reduction, 512 setup-kernel phase clocks (chordvis_debug_setup_profile), 1024 fused tile-out skips the visibility
  * stores, 2048 never split long bins, 4096 / 8192 / 16384 tile kernel skips its row units / entry set-up / the bin
- * altogether.  0 = production; any of those voids parity.  These switches do NOT change results (tests run them): 32768 small
+ * altogether.  0 = production; any of those voids parity.  Two switches do NOT change results (tests run both): 32768 small
  * clusters never leave the setup kernel as pixel blocks, 65536 every launch takes the setup kernel's pixel-block body
  * (by default it does when a launch has more than one cluster per 16 pixels), 131072 chordvis_render_frame launches
- * hzb_tail_kernel between the raster passes instead of letting the phase-1 cull reduce HZB levels 6.. itself, 524288 the
- * second raster pass of chordvis_render_frame always takes the bin-less form (by default it does when the same pass of the
- * previous frames was at most 1024 clusters long and clipped nothing), 1048576 it never does. */
+ * hzb_tail_kernel between the raster passes instead of letting the phase-1 cull reduce HZB levels 6.. itself. */
 int chordvis_set_debug(ChordCtx* ctx, uint32_t flags);
 /* debugging aid: raw read of an internal buffer (0 tile counts, 1 fixed bins, 2 chunk table, 3 bin pool, 4 / 5 32- / 48-byte records) */
 int chordvis_debug_read(ChordCtx* ctx, int which, uint64_t offset, uint64_t bytes, void* host);

@@ -712,27 +712,25 @@ def test_config3_4k_ground_level_views_match_oracle(gpu, pos, front):
     r.close()
 
 
-FORCE_DIRECT, NO_DIRECT = 524288, 1048576
-
-SMALL_PASS = [
+SECOND_PASS = [
     ("small", lambda: scenes.small_test_scene(160, 96)),
     ("small_hd", lambda: scenes.small_test_scene(640, 360, seed=11)),
     ("small_odd", lambda: scenes.small_test_scene(1237, 701, seed=8)),                # edge tiles narrower / shorter than 64 pixels
     ("street_720p", lambda: scenes.config3_street(1280, 720)),
-    # cameras a hand above the ground: triangles through the near plane (thread 0 clips them) and across the screen (shared by the waves)
+    # cameras a hand above the ground: triangles through the near plane and across the screen, in the SECOND pass
     ("street_ground_720p", lambda: (scenes.config3_street(1280, 720)[0], scenes.Camera((-62.0, 0.25, 3.0), (1.0, -0.02, -0.04), 1280, 720))),
     ("street_wall_4k", lambda: (scenes.config3_street()[0], scenes.Camera((-55.0, 1.2, 7.5), (0.9, 0.1, -0.4), 3840, 2160))),
     ("floor", lambda: scenes.floor_under_camera((0.3, 0.25, 0.2), (0.1, -0.6, -1.0), 256, 192)),
 ]
 
 
-@pytest.mark.parametrize("name,builder", SMALL_PASS, ids=[b[0] for b in SMALL_PASS])
-def test_binless_second_pass_matches_oracle(gpu, name, builder):
-    """The bin-less form of a later raster pass (raster_small_pass_kernel + hzb_dirty_tiles_kernel), forced, on a frame whose
-    SECOND pass holds nearly the whole scene: every object 'was' 500 m further down the view direction in the previous frame,
-    so phase 0 (previous transforms against the previous HZB) rejects what that HZB covers and phase 1 brings it back.  Image,
-    HZB chain (re-reduced from the touched tiles only) and counts against the oracle; then static frames without the switch,
-    where the host picks the form from the previous frame's counts."""
+@pytest.mark.parametrize("name,builder", SECOND_PASS, ids=[b[0] for b in SECOND_PASS])
+def test_frame_whose_second_pass_holds_the_scene_matches_oracle(gpu, name, builder):
+    """A frame whose SECOND raster pass holds nearly the whole scene (the usual second pass is a few per cent of it): every
+    object 'was' 500 m further down the view direction in the previous frame, so phase 0 (previous transforms against the
+    previous HZB) rejects what that HZB covers and phase 1 brings it back -- clipped and screen-filling triangles, long bins
+    and the read-modify-write of every tile then happen in the pass that merges into a finished image.  Image, HZB chain and
+    counts against the oracle, then three static frames."""
     from chord_amd import lib as L
     scene, cam = builder()
     W, Hh = cam.width, cam.height
@@ -740,7 +738,7 @@ def test_binless_second_pass_matches_oracle(gpu, name, builder):
     view0, iv0 = L.make_views(cam)
     L.fill_objects(scene, cam)
     want0 = orc.frame(scene, view0, iv0, flags)
-    r = _renderer(gpu, scene, view0, iv0, W, Hh, flags, debug=FORCE_DIRECT)
+    r = _renderer(gpu, scene, view0, iv0, W, Hh, flags)
     r.update_objects(scene.objects)
     r.render_frame()
     H.assert_vis_equal(r.read_visibility(), want0["vis"], W, Hh, name + " frame 0")
@@ -755,33 +753,28 @@ def test_binless_second_pass_matches_oracle(gpu, name, builder):
     r.update_objects(scene.objects)
     r.set_view(view1, iv1, flags)
     r.render_frame()
-    H.assert_vis_equal(r.read_visibility(), want1["vis"], W, Hh, name + " frame 1 (bin-less second pass)")
+    H.assert_vis_equal(r.read_visibility(), want1["vis"], W, Hh, name + " frame 1 (second pass holds the scene)")
     st = r.stats()
-    assert st["rasterSmallPasses"] == 1 and st["rasterLaunches"] == 2 and st["overflow"] == 0
+    assert st["rasterLaunches"] == 2 and st["overflow"] == 0
     assert [st["countInstanceCulled"], st["countStage0Visible"], st["countStage0Rejected"], st["countStage1Visible"]] == list(want1["counts"])
     assert st["trianglesSubmitted"] == want1["stats"].trianglesSubmitted
     mn, mx, rng = r.read_hzb(r.history_hzb())
     assert np.array_equal(mn, want1["hzb_min"]) and np.array_equal(mx, want1["hzb_max"]) and np.array_equal(rng, want1["valid_range"])
 
-    # static frames, no switch: the pass after a short one goes bin-less on the host's own decision
     L.fill_objects(scene, cam, cam)
     view2, iv2 = L.make_views(cam, view1)
-    r.set_debug(0)
     r.update_objects(scene.objects)
     r.set_view(view2, iv2, flags)
-    prev, small = want1["hzb_min"], []
+    prev = want1["hzb_min"]
     for k in range(3):
         want = orc.frame(scene, view2, iv2, flags, prev_hzb_min=prev)
         r.render_frame()
         H.assert_vis_equal(r.read_visibility(), want["vis"], W, Hh, name + " static frame %d" % k)
-        st = r.stats()                                            # (synchronises: the next frame sees this one's report)
-        small.append(st["rasterSmallPasses"])
+        st = r.stats()
         assert st["countStage1Visible"] == want["counts"][3] and st["overflow"] == 0
         mn, mx, rng = r.read_hzb(r.history_hzb())
         assert np.array_equal(mn, want["hzb_min"]) and np.array_equal(mx, want["hzb_max"]) and np.array_equal(rng, want["valid_range"])
         prev = want["hzb_min"]
-    if want["stats"].trianglesClipped == 0 and want["counts"][3] <= 1024:
-        assert small[-1] == 1, small                              # short second pass last frame, nothing clipped: bin-less
     r.close()
 
 
