@@ -434,11 +434,12 @@ def main():
         cpu = {"value": round(tri / (c1 - c0) / 1e9, 6), "unit": "Gtri/s", "cores": 1, "kind": "port",
                "sample": "%d frames of %s (view A, history of view B), oracle/oracle.c single thread, %.1f s"
                          % (args.cpu_baseline_frames, wl, c1 - c0)}
-        # the same frames with the raster legs on every host core (culling and HZB builds stay scalar); the image
-        # must equal the single-thread one
+        # the same frames on every host core (culls over ranges, clusters into per-thread tile-private images merged
+        # by max, HZB levels over row ranges: oracle.c orc_frame_mt); the image must equal the single-thread one
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        threads = min(threads, 32)      # the scalar culling / HZB legs and the shared-buffer CAS stop paying beyond this
+        threads = min(threads, 64)
         if threads > 1:
+            orc.frame_mt(sc_a, view_a, iv_a, flags, prev["hzb_min"], threads)      # (untimed: first touch of the private images)
             m0 = time.perf_counter()
             tri_mt = 0
             for _ in range(args.cpu_baseline_frames):
@@ -447,7 +448,7 @@ def main():
             m1 = time.perf_counter()
             assert np.array_equal(out_mt["vis"], out["vis"]), "multi-threaded CPU replay differs from the scalar one"
             cpu["all_cores"] = {"value": round(tri_mt / (m1 - m0) / 1e9, 6), "unit": "Gtri/s", "cores": threads, "kind": "port",
-                                "sample": "same %d frames, raster legs on %d threads (orc_raster_mt), culling + HZB scalar, %.1f s"
+                                "sample": "same %d frames (after one to map the threads' private images), %d threads: culls over ranges, tile-private images merged by max, HZB over rows (orc_frame_mt), %.1f s"
                                           % (args.cpu_baseline_frames, threads, m1 - m0)}
 
     if rank == 0:

@@ -51,12 +51,14 @@
  *      triangle's depth plane (dz/dx = (float(256 a1) * invA) * e1 + (float(256 a2) * invA) * e2, dz/dy with b) and
  *      r = 2^(exponent(max |d_i|) - 23); fixed here as: the three VERTEX depths are biased by o before interpolation.
  */
+#define _DEFAULT_SOURCE        /* mmap flags (the all-cores replay) under -std=c11 */
 #include "oracle.h"
 
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #define MAT(mat, r, c) ((mat)->m[(c) * 4 + (r)])
 
@@ -278,12 +280,12 @@ int orc_meshlet_visible(uint32_t flags, const ChordInstanceCullingView* iv, cons
     return 1;
 }
 
-uint32_t orc_instance_culling(const ChordSceneDesc* scene, const ChordCameraView* view,
-                              const ChordInstanceCullingView* iv, uint32_t flags,
-                              ChordDrawCmd* outCmds, uint32_t cap)
+/* objects [o0, o1): commands appended at outCmds[n...] (those past `cap` are counted, not stored), slots numbered from n */
+static uint32_t instance_culling_range(const ChordSceneDesc* scene, const ChordCameraView* view,
+                                       const ChordInstanceCullingView* iv, uint32_t flags, uint32_t o0, uint32_t o1,
+                                       ChordDrawCmd* outCmds, uint32_t cap, uint32_t n)
 {
-    uint32_t n = 0;
-    for (uint32_t o = 0; o < scene->objectCount; o++) {
+    for (uint32_t o = o0; o < o1; o++) {
         if (!object_visible(scene, iv, flags, o)) continue;
         const ChordObject* obj = &scene->objects[o];
         const ChordPrimitive* prim = &scene->primitives[obj->GLTFPrimitiveDetail];
@@ -305,6 +307,13 @@ uint32_t orc_instance_culling(const ChordSceneDesc* scene, const ChordCameraView
         }
     }
     return n;
+}
+
+uint32_t orc_instance_culling(const ChordSceneDesc* scene, const ChordCameraView* view,
+                              const ChordInstanceCullingView* iv, uint32_t flags,
+                              ChordDrawCmd* outCmds, uint32_t cap)
+{
+    return instance_culling_range(scene, view, iv, flags, 0, scene->objectCount, outCmds, cap, 0);
 }
 
 /* -------------------------------------------------------------------- HZB -- */
@@ -349,63 +358,72 @@ uint32_t orc_hzb_valid_h(const ChordHZBDesc* d, uint32_t l)
     return v < h ? v : h;
 }
 
+/* hzb_one.hlsl:126-372 / hzb.hlsl:127-389 restated per SURVEY Appendix A4:
+ * texel (x,y) of mip l = reduce over the 2^(l+1) square of edge-clamped
+ * source depth; converted to binary16 on store.  min/max commute with the
+ * monotone f32->f16 rounding, so reducing level by level from the stored
+ * halves (what the shader does from mip 5 up) gives the same bits.  Max
+ * variant: mips >= 5 carry +1 ulp (hzb.hlsl:67-71).  Only the sampled
+ * (valid) extent of each mip is defined; the rest is written as 0.
+ * Rows [y0, y1) of a level (the all-cores replay hands each thread a range; texels do not depend on each other). */
+static void hzb_mip0_rows(const uint64_t* vis, uint32_t W, uint32_t H, const ChordHZBDesc* desc,
+                          uint16_t* hzbMin, uint16_t* hzbMax, uint32_t y0, uint32_t y1, uint32_t* vminIo, uint32_t* vmaxIo)
+{
+    uint32_t vmin = *vminIo, vmax = *vmaxIo;
+    const uint32_t vw = orc_hzb_valid_w(desc, 0), mw = mip_w(desc, 0);
+    for (uint32_t y = y0; y < y1; y++) for (uint32_t x = 0; x < vw; x++) {
+        float mn = 0, mx = 0;
+        for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) {
+            uint32_t sx = 2 * x + i, sy = 2 * y + j;
+            if (sx > W - 1) sx = W - 1;
+            if (sy > H - 1) sy = H - 1;
+            float d = u2f((uint32_t)(vis[(size_t)sy * W + sx] >> 32));
+            if (i == 0 && j == 0) { mn = d; mx = d; } else { mn = fminf(mn, d); mx = fmaxf(mx, d); }
+            if (d > 0.0f) {                      /* hzb.hlsl:163-166 */
+                uint32_t b = f2u(d);
+                if (d < 1.0f && b < vmin) vmin = b;   /* :173 guard, see note in DESIGN.md */
+                if (b > vmax) vmax = b;
+            }
+        }
+        hzbMin[desc->mipOffset[0] + y * mw + x] = orc_f32_to_f16(mn);
+        if (hzbMax) hzbMax[desc->mipOffset[0] + y * mw + x] = orc_f32_to_f16(mx);
+    }
+    *vminIo = vmin; *vmaxIo = vmax;
+}
+
+static void hzb_mip_rows(const ChordHZBDesc* desc, uint32_t l, uint16_t* hzbMin, uint16_t* hzbMax, uint32_t y0, uint32_t y1)
+{
+    const uint32_t vw = orc_hzb_valid_w(desc, l), mw = mip_w(desc, l);
+    const uint32_t pw = orc_hzb_valid_w(desc, l - 1), ph = orc_hzb_valid_h(desc, l - 1), pmw = mip_w(desc, l - 1);
+    for (uint32_t y = y0; y < y1; y++) for (uint32_t x = 0; x < vw; x++) {
+        float mn = 0, mx = 0;
+        for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) {
+            uint32_t cx = 2 * x + i, cy = 2 * y + j;
+            if (cx > pw - 1) cx = pw - 1;        /* children past the valid edge are clamped duplicates */
+            if (cy > ph - 1) cy = ph - 1;
+            size_t idx = desc->mipOffset[l - 1] + (size_t)cy * pmw + cx;
+            float a = orc_f16_to_f32(hzbMin[idx]);
+            float b = hzbMax ? orc_f16_to_f32(hzbMax[idx]) : 0.0f;
+            if (i == 0 && j == 0) { mn = a; mx = b; } else { mn = fminf(mn, a); mx = fmaxf(mx, b); }
+        }
+        size_t o = desc->mipOffset[l] + (size_t)y * mw + x;
+        hzbMin[o] = orc_f32_to_f16(mn);
+        if (hzbMax) {
+            uint16_t h = orc_f32_to_f16(mx);
+            if (l == 5) h = (uint16_t)(h + 1);   /* storeHZBMip5: f32tof16(depth) + 1 */
+            hzbMax[o] = h;
+        }
+    }
+}
+
 void orc_hzb_build(const uint64_t* vis, uint32_t W, uint32_t H, const ChordHZBDesc* desc,
                    uint16_t* hzbMin, uint16_t* hzbMax, uint32_t validRange[2])
 {
-    /* hzb_one.hlsl:126-372 / hzb.hlsl:127-389 restated per SURVEY Appendix A4:
-     * texel (x,y) of mip l = reduce over the 2^(l+1) square of edge-clamped
-     * source depth; converted to binary16 on store.  min/max commute with the
-     * monotone f32->f16 rounding, so reducing level by level from the stored
-     * halves (what the shader does from mip 5 up) gives the same bits.  Max
-     * variant: mips >= 5 carry +1 ulp (hzb.hlsl:67-71).  Only the sampled
-     * (valid) extent of each mip is defined; the rest is written as 0. */
     memset(hzbMin, 0, sizeof(uint16_t) * desc->totalTexels);
     if (hzbMax) memset(hzbMax, 0, sizeof(uint16_t) * desc->totalTexels);
     uint32_t vmin = 0xFFFFFFFFu, vmax = 0u;
-    /* mip 0 from the source */
-    {
-        uint32_t vw = orc_hzb_valid_w(desc, 0), vh = orc_hzb_valid_h(desc, 0), mw = mip_w(desc, 0);
-        for (uint32_t y = 0; y < vh; y++) for (uint32_t x = 0; x < vw; x++) {
-            float mn = 0, mx = 0;
-            for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) {
-                uint32_t sx = 2 * x + i, sy = 2 * y + j;
-                if (sx > W - 1) sx = W - 1;
-                if (sy > H - 1) sy = H - 1;
-                float d = u2f((uint32_t)(vis[(size_t)sy * W + sx] >> 32));
-                if (i == 0 && j == 0) { mn = d; mx = d; } else { mn = fminf(mn, d); mx = fmaxf(mx, d); }
-                if (d > 0.0f) {                      /* hzb.hlsl:163-166 */
-                    uint32_t b = f2u(d);
-                    if (d < 1.0f && b < vmin) vmin = b;   /* :173 guard, see note in DESIGN.md */
-                    if (b > vmax) vmax = b;
-                }
-            }
-            hzbMin[desc->mipOffset[0] + y * mw + x] = orc_f32_to_f16(mn);
-            if (hzbMax) hzbMax[desc->mipOffset[0] + y * mw + x] = orc_f32_to_f16(mx);
-        }
-    }
-    for (uint32_t l = 1; l < desc->mipCount; l++) {
-        uint32_t vw = orc_hzb_valid_w(desc, l), vh = orc_hzb_valid_h(desc, l), mw = mip_w(desc, l);
-        uint32_t pw = orc_hzb_valid_w(desc, l - 1), ph = orc_hzb_valid_h(desc, l - 1), pmw = mip_w(desc, l - 1);
-        for (uint32_t y = 0; y < vh; y++) for (uint32_t x = 0; x < vw; x++) {
-            float mn = 0, mx = 0;
-            for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) {
-                uint32_t cx = 2 * x + i, cy = 2 * y + j;
-                if (cx > pw - 1) cx = pw - 1;        /* children past the valid edge are clamped duplicates */
-                if (cy > ph - 1) cy = ph - 1;
-                size_t idx = desc->mipOffset[l - 1] + (size_t)cy * pmw + cx;
-                float a = orc_f16_to_f32(hzbMin[idx]);
-                float b = hzbMax ? orc_f16_to_f32(hzbMax[idx]) : 0.0f;
-                if (i == 0 && j == 0) { mn = a; mx = b; } else { mn = fminf(mn, a); mx = fmaxf(mx, b); }
-            }
-            size_t o = desc->mipOffset[l] + (size_t)y * mw + x;
-            hzbMin[o] = orc_f32_to_f16(mn);
-            if (hzbMax) {
-                uint16_t h = orc_f32_to_f16(mx);
-                if (l == 5) h = (uint16_t)(h + 1);   /* storeHZBMip5: f32tof16(depth) + 1 */
-                hzbMax[o] = h;
-            }
-        }
-    }
+    hzb_mip0_rows(vis, W, H, desc, hzbMin, hzbMax, 0, orc_hzb_valid_h(desc, 0), &vmin, &vmax);   /* mip 0 from the source */
+    for (uint32_t l = 1; l < desc->mipCount; l++) hzb_mip_rows(desc, l, hzbMin, hzbMax, 0, orc_hzb_valid_h(desc, l));
     if (validRange) { validRange[0] = vmin; validRange[1] = vmax; }
 }
 
@@ -504,9 +522,15 @@ static inline int owns_row(const OrcShard* s, uint32_t y)
     return ((y / s->stripeRows) % s->ranks) == s->rank;
 }
 
+/* `atomic` names how a raster call reaches the image: 0 plain row-major, 1 row-major shared by threads (compare-and-swap),
+ * 2 a thread's PRIVATE image stored tile by tile (64 x 64 words each, so that only the pages of touched tiles are ever
+ * mapped) with the touched tiles recorded in t_dirty -- the all-cores replay merges those by max (orc_frame_mt). */
+#define ORC_PRIV_TILE 64u
+static __thread uint8_t* t_dirty = NULL;
+
 static inline void vis_max(uint64_t* p, uint64_t v, int atomic)
 {
-    if (!atomic) { if (v > *p) *p = v; return; }
+    if (atomic != 1) { if (v > *p) *p = v; return; }
     uint64_t cur = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (v > cur) {
         if (__atomic_compare_exchange_n(p, &cur, v, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
@@ -638,6 +662,10 @@ static void raster_snapped(const int32_t X[3], const int32_t Y[3], const float d
     if (py1 > (int64_t)H - 1) py1 = (int64_t)H - 1;
     if (px1 < px0 || py1 < py0) return;
     if (st) st->trianglesRastered++;
+    const uint32_t tilesX = (W + ORC_PRIV_TILE - 1u) / ORC_PRIV_TILE;
+    if (atomic == 2 && t_dirty)
+        for (int64_t ty = py0 / ORC_PRIV_TILE; ty <= py1 / ORC_PRIV_TILE; ty++)
+            for (int64_t tx = px0 / ORC_PRIV_TILE; tx <= px1 / ORC_PRIV_TILE; tx++) t_dirty[ty * tilesX + tx] = 1;
 
     /* edge i is opposite vertex i: E0 = orient(V1,V2,P), E1 = orient(V2,V0,P), E2 = orient(V0,V1,P) */
     static const int ea[3] = {1, 2, 0}, eb[3] = {2, 0, 1};
@@ -676,7 +704,9 @@ static void raster_snapped(const int32_t X[3], const int32_t Y[3], const float d
             float z = (d[0] + l1 * e1) + l2 * e2;
             if (depthClamp) z = fminf(fmaxf(z, 0.0f), 1.0f);
             uint64_t packed = ((uint64_t)f2u(z) << 32) | payload;
-            vis_max(&vis[(size_t)py * W + (size_t)px], packed, atomic);
+            const size_t at = atomic == 2 ? ((((size_t)(py / ORC_PRIV_TILE) * tilesX + (size_t)(px / ORC_PRIV_TILE)) * ORC_PRIV_TILE + (size_t)(py % ORC_PRIV_TILE)) * ORC_PRIV_TILE + (size_t)(px % ORC_PRIV_TILE))
+                                          : (size_t)py * W + (size_t)px;
+            vis_max(&vis[at], packed, atomic);
             if (st) st->fragments++;
         }
     }
@@ -1045,6 +1075,262 @@ void orc_frame(const ChordSceneDesc* scene, const ChordCameraView* view, const C
         if (counts) counts[1] = n;
     }
     if (outHzbMin) orc_hzb_build(vis, W, H, &hd, outHzbMin, outHzbMax, outValidRange);  /* renderer.cpp:343 */
+}
+
+/* ================================================================================================
+ * All-cores replay of orc_frame (SURVEY 8d "CPU baseline": threads over clusters, per-thread tile-private images merged by
+ * max; culling and the HZB builds over ranges).  Same functions, same results as orc_frame -- the merge is a max, the lists
+ * are concatenated in range order -- checked by tests/test_oracle_kat.py.  Not part of any product path.
+ * ================================================================================================ */
+typedef void (*ParFn)(void* ctx, uint32_t t, uint32_t T);
+typedef struct { ParFn fn; void* ctx; uint32_t t, T; } ParJob;
+static void* par_trampoline(void* p) { ParJob* j = (ParJob*)p; j->fn(j->ctx, j->t, j->T); return NULL; }
+static void par_run(uint32_t T, ParFn fn, void* ctx)
+{
+    pthread_t th[256]; ParJob jobs[256];
+    if (T < 1) T = 1;
+    if (T > 256) T = 256;
+    for (uint32_t t = 1; t < T; t++) { jobs[t].fn = fn; jobs[t].ctx = ctx; jobs[t].t = t; jobs[t].T = T; pthread_create(&th[t], NULL, par_trampoline, &jobs[t]); }
+    fn(ctx, 0, T);
+    for (uint32_t t = 1; t < T; t++) pthread_join(th[t], NULL);
+}
+static inline uint32_t part_lo(uint32_t n, uint32_t t, uint32_t T) { return (uint32_t)((uint64_t)n * t / T); }
+
+/* ---- instance culling over object ranges ---- */
+typedef struct {
+    const ChordSceneDesc* scene; const ChordCameraView* view; const ChordInstanceCullingView* iv; uint32_t flags;
+    ChordDrawCmd** part; uint32_t* partCount; ChordDrawCmd* out; uint32_t cap; uint32_t* base;
+} CullMt;
+static void cull_mt_count(void* c, uint32_t t, uint32_t T)
+{
+    CullMt* m = (CullMt*)c;
+    const uint32_t o0 = part_lo(m->scene->objectCount, t, T), o1 = part_lo(m->scene->objectCount, t + 1, T);
+    /* first the count (nothing stored), then the commands into a buffer of exactly that size */
+    const uint32_t n = instance_culling_range(m->scene, m->view, m->iv, m->flags, o0, o1, NULL, 0, 0);
+    m->part[t] = (ChordDrawCmd*)malloc(sizeof(ChordDrawCmd) * (n ? n : 1));
+    m->partCount[t] = instance_culling_range(m->scene, m->view, m->iv, m->flags, o0, o1, m->part[t], n, 0);
+}
+static void cull_mt_copy(void* c, uint32_t t, uint32_t T)
+{
+    CullMt* m = (CullMt*)c;
+    (void)T;
+    for (uint32_t i = 0; i < m->partCount[t]; i++) {
+        const uint32_t k = m->base[t] + i;
+        if (k >= m->cap) break;
+        m->out[k] = m->part[t][i]; m->out[k].slot = k;                      /* slot = index in the whole list */
+    }
+    free(m->part[t]);
+}
+static uint32_t instance_culling_mt(const ChordSceneDesc* scene, const ChordCameraView* view, const ChordInstanceCullingView* iv,
+                                    uint32_t flags, ChordDrawCmd* outCmds, uint32_t cap, uint32_t T)
+{
+    ChordDrawCmd* part[256]; uint32_t cnt[256], base[257];
+    CullMt m = {scene, view, iv, flags, part, cnt, outCmds, cap, base};
+    par_run(T, cull_mt_count, &m);
+    base[0] = 0;
+    for (uint32_t t = 0; t < T; t++) base[t + 1] = base[t] + cnt[t];
+    par_run(T, cull_mt_copy, &m);
+    return base[T];
+}
+
+/* ---- HZB culling over command ranges ---- */
+typedef struct {
+    const ChordSceneDesc* scene; const ChordCameraView* view; uint32_t flags; int phase; const ChordHZBDesc* hzb; const uint16_t* hzbMin;
+    const ChordDrawCmd* in; uint32_t inCount; uint8_t* verdict; uint32_t* nv; uint32_t* nr; uint32_t* bv; uint32_t* br;
+    ChordDrawCmd* outV; ChordDrawCmd* outR;
+} HzbMt;
+static void hzb_mt_test(void* c, uint32_t t, uint32_t T)
+{
+    HzbMt* m = (HzbMt*)c;
+    const uint32_t i0 = part_lo(m->inCount, t, T), i1 = part_lo(m->inCount, t + 1, T);
+    uint32_t nv = 0, nr = 0;
+    for (uint32_t i = i0; i < i1; i++) {
+        const int v = hzb_visible(m->scene, m->view, m->flags, m->phase, m->hzb, m->hzbMin, &m->in[i]);
+        m->verdict[i] = (uint8_t)v;
+        if (v) nv++; else nr++;
+    }
+    m->nv[t] = nv; m->nr[t] = nr;
+}
+static void hzb_mt_write(void* c, uint32_t t, uint32_t T)
+{
+    HzbMt* m = (HzbMt*)c;
+    const uint32_t i0 = part_lo(m->inCount, t, T), i1 = part_lo(m->inCount, t + 1, T);
+    uint32_t kv = m->bv[t], kr = m->br[t];
+    for (uint32_t i = i0; i < i1; i++) {
+        if (m->verdict[i]) m->outV[kv++] = m->in[i];
+        else if (m->phase == 0 && m->outR) m->outR[kr++] = m->in[i];
+    }
+}
+static void hzb_culling_mt(const ChordSceneDesc* scene, const ChordCameraView* view, uint32_t flags, int phase,
+                           const ChordHZBDesc* hzb, const uint16_t* hzbMin, const ChordDrawCmd* inCmds, uint32_t inCount,
+                           ChordDrawCmd* outVisible, uint32_t* outVisibleCount, ChordDrawCmd* outRejected, uint32_t* outRejectedCount, uint32_t T)
+{
+    uint32_t nv[256], nr[256], bv[257], br[257];
+    uint8_t* verdict = (uint8_t*)malloc(inCount ? inCount : 1);
+    HzbMt m = {scene, view, flags, phase, hzb, hzbMin, inCmds, inCount, verdict, nv, nr, bv, br, outVisible, outRejected};
+    par_run(T, hzb_mt_test, &m);
+    bv[0] = br[0] = 0;
+    for (uint32_t t = 0; t < T; t++) { bv[t + 1] = bv[t] + nv[t]; br[t + 1] = br[t] + nr[t]; }
+    par_run(T, hzb_mt_write, &m);
+    *outVisibleCount = bv[T];
+    if (outRejectedCount) *outRejectedCount = br[T];
+    free(verdict);
+}
+
+/* ---- raster: clusters handed out in chunks, every thread into its own tile-linear image; then the touched tiles are merged
+ *      into the frame's image by max, tile ranges in parallel ---- */
+typedef struct {
+    const ChordSceneDesc* scene; const ChordInstanceCullingView* iv; const ChordDrawCmd* cmds; uint32_t count; uint32_t* next;
+    uint64_t** priv; uint8_t** dirty; OrcRasterStats* stats; uint32_t W, H, tilesX, tilesY; uint64_t* vis;
+} RasterMt;
+static void raster_mt_draw(void* c, uint32_t t, uint32_t T)
+{
+    RasterMt* m = (RasterMt*)c;
+    (void)T;
+    t_dirty = m->dirty[t];
+    for (;;) {
+        /* (8 clusters per grab: a cluster next to the camera can hold more fragments than a thousand distant ones) */
+        uint32_t i = __atomic_fetch_add(m->next, 8u, __ATOMIC_RELAXED);
+        if (i >= m->count) break;
+        const uint32_t e = i + 8u < m->count ? i + 8u : m->count;
+        for (; i < e; i++) raster_cluster(m->scene, m->iv, &m->cmds[i], NULL, m->priv[t], &m->stats[t], 2);
+    }
+    t_dirty = NULL;
+}
+static void raster_mt_merge(void* c, uint32_t t, uint32_t T)
+{
+    RasterMt* m = (RasterMt*)c;
+    const uint32_t tiles = m->tilesX * m->tilesY, k0 = part_lo(tiles, t, T), k1 = part_lo(tiles, t + 1, T);
+    for (uint32_t k = k0; k < k1; k++)
+        for (uint32_t q = 0; q < T; q++) {
+            if (!m->dirty[q][k]) continue;
+            const uint32_t ox = (k % m->tilesX) * ORC_PRIV_TILE, oy = (k / m->tilesX) * ORC_PRIV_TILE;
+            uint64_t* src = m->priv[q] + (size_t)k * ORC_PRIV_TILE * ORC_PRIV_TILE;
+            for (uint32_t y = 0; y < ORC_PRIV_TILE && oy + y < m->H; y++)
+                for (uint32_t x = 0; x < ORC_PRIV_TILE && ox + x < m->W; x++) {
+                    const uint64_t v = src[y * ORC_PRIV_TILE + x];
+                    uint64_t* dst = &m->vis[(size_t)(oy + y) * m->W + ox + x];
+                    if (v > *dst) *dst = v;
+                }
+            /* the private images live across calls (below): a merged tile goes back to all zero */
+            memset(src, 0, sizeof(uint64_t) * ORC_PRIV_TILE * ORC_PRIV_TILE);
+            m->dirty[q][k] = 0;
+        }
+}
+
+/* The threads' private images are kept between calls: mapping and zero-filling them anew for every raster leg costs more than
+ * the leg (page faults of one process serialise), and after a merge they are all zero again.  One replay at a time. */
+static pthread_mutex_t g_privLock = PTHREAD_MUTEX_INITIALIZER;
+static uint64_t* g_priv[256];
+static uint8_t* g_dirty[256];
+static size_t g_privBytes = 0;
+static uint32_t g_privTiles = 0;
+
+static void raster_private_mt(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv, const ChordDrawCmd* cmds, uint32_t count,
+                              uint32_t T, uint32_t W, uint32_t H, uint64_t* vis, OrcRasterStats* stats)
+{
+    OrcRasterStats st[256]; uint32_t next = 0;
+    const uint32_t tilesX = (W + ORC_PRIV_TILE - 1u) / ORC_PRIV_TILE, tilesY = (H + ORC_PRIV_TILE - 1u) / ORC_PRIV_TILE;
+    const size_t bytes = (size_t)tilesX * tilesY * ORC_PRIV_TILE * ORC_PRIV_TILE * sizeof(uint64_t);
+    if (T > 256) T = 256;
+    pthread_mutex_lock(&g_privLock);
+    if (bytes != g_privBytes) {                                   /* another image size: start over */
+        for (uint32_t t = 0; t < 256; t++) {
+            if (g_priv[t]) { munmap(g_priv[t], g_privBytes); g_priv[t] = NULL; }
+            free(g_dirty[t]); g_dirty[t] = NULL;
+        }
+        g_privBytes = bytes; g_privTiles = tilesX * tilesY;
+    }
+    for (uint32_t t = 0; t < T; t++) {
+        /* anonymous mapping: zero pages, mapped on first touch -- a thread pays for the tiles it draws into, not for the screen */
+        if (!g_priv[t]) g_priv[t] = (uint64_t*)mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (!g_dirty[t]) g_dirty[t] = (uint8_t*)calloc(g_privTiles, 1);
+        memset(&st[t], 0, sizeof(OrcRasterStats));
+    }
+    RasterMt m = {scene, iv, cmds, count, &next, g_priv, g_dirty, st, W, H, tilesX, tilesY, vis};
+    par_run(T, raster_mt_draw, &m);
+    par_run(T, raster_mt_merge, &m);
+    pthread_mutex_unlock(&g_privLock);
+    for (uint32_t t = 0; t < T; t++)
+        if (stats) {
+            uint64_t* a = (uint64_t*)stats; const uint64_t* b = (const uint64_t*)&st[t];
+            for (size_t k = 0; k < sizeof(OrcRasterStats) / 8; k++) a[k] += b[k];
+        }
+}
+
+/* ---- HZB build over row ranges ---- */
+typedef struct {
+    const uint64_t* vis; uint32_t W, H; const ChordHZBDesc* desc; uint16_t* hzbMin; uint16_t* hzbMax; uint32_t level; uint32_t* vmin; uint32_t* vmax;
+} HzbBuildMt;
+static void hzb_build_mt_rows(void* c, uint32_t t, uint32_t T)
+{
+    HzbBuildMt* m = (HzbBuildMt*)c;
+    const uint32_t vh = orc_hzb_valid_h(m->desc, m->level), y0 = part_lo(vh, t, T), y1 = part_lo(vh, t + 1, T);
+    if (m->level == 0) { m->vmin[t] = 0xFFFFFFFFu; m->vmax[t] = 0u; hzb_mip0_rows(m->vis, m->W, m->H, m->desc, m->hzbMin, m->hzbMax, y0, y1, &m->vmin[t], &m->vmax[t]); }
+    else hzb_mip_rows(m->desc, m->level, m->hzbMin, m->hzbMax, y0, y1);
+}
+static void hzb_build_mt(const uint64_t* vis, uint32_t W, uint32_t H, const ChordHZBDesc* desc,
+                         uint16_t* hzbMin, uint16_t* hzbMax, uint32_t validRange[2], uint32_t T)
+{
+    uint32_t vmin[256], vmax[256];
+    memset(hzbMin, 0, sizeof(uint16_t) * desc->totalTexels);
+    if (hzbMax) memset(hzbMax, 0, sizeof(uint16_t) * desc->totalTexels);
+    HzbBuildMt m = {vis, W, H, desc, hzbMin, hzbMax, 0, vmin, vmax};
+    for (uint32_t l = 0; l < desc->mipCount; l++) {
+        m.level = l;
+        const uint32_t vh = orc_hzb_valid_h(desc, l);
+        par_run(vh >= 4u * T ? T : 1u, hzb_build_mt_rows, &m);            /* (a level is complete before the next one reads it) */
+        if (l == 0 && validRange) {
+            uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+            for (uint32_t t = 0; t < (vh >= 4u * T ? T : 1u); t++) { if (vmin[t] < lo) lo = vmin[t]; if (vmax[t] > hi) hi = vmax[t]; }
+            validRange[0] = lo; validRange[1] = hi;
+        }
+    }
+}
+
+typedef struct { uint64_t* vis; size_t words; } ClearMt;
+static void clear_mt_part(void* c, uint32_t t, uint32_t T)
+{
+    ClearMt* m = (ClearMt*)c;
+    const size_t a = m->words * t / T, b = m->words * (t + 1) / T;
+    memset(m->vis + a, 0, sizeof(uint64_t) * (b - a));
+}
+
+void orc_frame_mt(const ChordSceneDesc* scene, const ChordCameraView* view, const ChordInstanceCullingView* iv,
+                  uint32_t flags, const uint16_t* prevHzbMin, uint32_t threads,
+                  uint64_t* vis, ChordDrawCmd* outCmds, uint32_t cmdCap, uint32_t counts[4],
+                  uint16_t* outHzbMin, uint16_t* outHzbMax, uint32_t outValidRange[2],
+                  OrcRasterStats* stats)
+{
+    const uint32_t W = (uint32_t)iv->renderDimension[0], H = (uint32_t)iv->renderDimension[1];
+    const uint32_t T = threads < 1 ? 1 : threads > 256 ? 256 : threads;
+    ChordHZBDesc hd;
+    orc_hzb_desc(W, H, &hd);
+    ClearMt cl = {vis, (size_t)W * H};
+    par_run(T, clear_mt_part, &cl);
+    if (counts) memset(counts, 0, sizeof(uint32_t) * 4);
+
+    uint32_t n = instance_culling_mt(scene, view, iv, flags, outCmds, cmdCap, T);
+    if (n > cmdCap) n = cmdCap;
+    if (counts) counts[0] = n;
+
+    if (prevHzbMin && (flags & CHORD_FLAG_HZB_CULL)) {
+        ChordDrawCmd* visL = (ChordDrawCmd*)malloc(sizeof(ChordDrawCmd) * (n ? n : 1));
+        ChordDrawCmd* rejL = (ChordDrawCmd*)malloc(sizeof(ChordDrawCmd) * (n ? n : 1));
+        uint16_t* tmpHzb = (uint16_t*)malloc(sizeof(uint16_t) * hd.totalTexels);
+        uint32_t nv = 0, nr = 0, nv1 = 0;
+        hzb_culling_mt(scene, view, flags, 0, &hd, prevHzbMin, outCmds, n, visL, &nv, rejL, &nr, T);
+        raster_private_mt(scene, iv, visL, nv, T, W, H, vis, stats);
+        hzb_build_mt(vis, W, H, &hd, tmpHzb, NULL, NULL, T);
+        hzb_culling_mt(scene, view, flags, 1, &hd, tmpHzb, rejL, nr, visL, &nv1, NULL, NULL, T);
+        raster_private_mt(scene, iv, visL, nv1, T, W, H, vis, stats);
+        if (counts) { counts[1] = nv; counts[2] = nr; counts[3] = nv1; }
+        free(visL); free(rejL); free(tmpHzb);
+    } else {
+        raster_private_mt(scene, iv, outCmds, n, T, W, H, vis, stats);
+        if (counts) counts[1] = n;
+    }
+    if (outHzbMin) hzb_build_mt(vis, W, H, &hd, outHzbMin, outHzbMax, outValidRange, T);
 }
 
 /* ================================================================================================

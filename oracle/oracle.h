@@ -124,6 +124,15 @@ void orc_frame(const ChordSceneDesc* scene, const ChordCameraView* view, const C
                uint16_t* outHzbMin, uint16_t* outHzbMax, uint32_t outValidRange[2],
                OrcRasterStats* stats);
 
+/* All-cores replay of orc_frame (SURVEY 8d CPU baseline): instance culling over object ranges, HZB culls over command
+ * ranges, clusters rastered by `threads` threads into per-thread tile-private images merged by max, HZB levels over row
+ * ranges.  Identical outputs to orc_frame (unsharded). */
+void orc_frame_mt(const ChordSceneDesc* scene, const ChordCameraView* view, const ChordInstanceCullingView* iv,
+                  uint32_t flags, const uint16_t* prevHzbMin, uint32_t threads,
+                  uint64_t* vis, ChordDrawCmd* outCmds, uint32_t cmdCap, uint32_t counts[4],
+                  uint16_t* outHzbMin, uint16_t* outHzbMax, uint32_t outValidRange[2],
+                  OrcRasterStats* stats);
+
 /* OpenMP-free multi-threaded replay of orc_frame's raster legs (pthread,
  * per-thread row bands merged by max) for the all-cores CPU baseline. */
 void orc_raster_mt(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv,

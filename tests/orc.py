@@ -64,6 +64,8 @@ def _load():
     lib.orc_shading_tiles.restype, lib.orc_shading_tiles.argtypes = u32, [vp, u32, u32, u32, vp, vp]
     lib.orc_raster_mt.restype = None
     lib.orc_raster_mt.argtypes = [P(R.SceneDesc), vp, vp, u32, u32, vp, P(RasterStats)]
+    lib.orc_frame_mt.restype = None
+    lib.orc_frame_mt.argtypes = [P(R.SceneDesc), vp, vp, u32, vp, u32, vp, vp, u32, vp, vp, vp, vp, P(RasterStats)]
     return lib
 
 
@@ -141,25 +143,25 @@ def raster_snapped_triangle(X, Y, d, two_sided, payload, w, h, vis=None, shard=N
 
 
 def frame_mt(scene, view, iv, flags, prev_hzb_min, threads):
-    """orc_frame's sequence (mesh_raster.cpp:269-329, renderer.cpp:319-345) with the two raster legs spread over
-    `threads` host threads (orc_raster_mt); culling and HZB builds stay scalar.  For the all-cores CPU baseline."""
+    """orc_frame_mt: orc_frame's sequence (mesh_raster.cpp:269-329, renderer.cpp:319-345) on `threads` host threads -- culls over
+    ranges, clusters into per-thread tile-private images merged by max, HZB levels over row ranges (SURVEY 8d's all-cores CPU
+    baseline).  Same dictionary as frame()."""
     w, h = int(iv["renderDimension"][0][0]), int(iv["renderDimension"][0][1])
-    cmds = instance_culling(scene, view, iv, flags)
+    d = hzb_desc(w, h)
     vis = np.zeros(w * h, dtype=np.uint64)
-    tris = 0
-    if prev_hzb_min is not None and (flags & R.FLAG_HZB_CULL):
-        d = hzb_desc(w, h)
-        visible, rejected = hzb_culling(scene, view, flags, 0, d, prev_hzb_min, cmds)
-        _, st0 = raster(scene, iv, visible, w, h, vis=vis, threads=threads)
-        _, mn, _, _ = hzb_build(vis, w, h)
-        visible1, _ = hzb_culling(scene, view, flags, 1, d, mn, rejected)
-        _, st1 = raster(scene, iv, visible1, w, h, vis=vis, threads=threads)
-        tris = int(st0.trianglesSubmitted + st1.trianglesSubmitted)
-    else:
-        _, st0 = raster(scene, iv, cmds, w, h, vis=vis, threads=threads)
-        tris = int(st0.trianglesSubmitted)
-    _, mn, mx, rng = hzb_build(vis, w, h, want_max=True, want_range=True)
-    return dict(vis=vis, cmds=cmds, hzb_min=mn, hzb_max=mx, valid_range=rng, triangles_submitted=tris)
+    cap = max(1, scene.lod0_meshlet_instances)
+    cmds = np.zeros(cap, dtype=R.DRAW_CMD)
+    counts = np.zeros(4, dtype=np.uint32)
+    hmin = np.zeros(d.totalTexels, dtype=np.uint16)
+    hmax = np.zeros(d.totalTexels, dtype=np.uint16)
+    rng = np.zeros(2, dtype=np.uint32)
+    st = RasterStats()
+    lib.orc_frame_mt(C.byref(scene.desc), view.ctypes.data, iv.ctypes.data, flags,
+                     prev_hzb_min.ctypes.data if prev_hzb_min is not None else None, int(threads),
+                     vis.ctypes.data, cmds.ctypes.data, cap, counts.ctypes.data,
+                     hmin.ctypes.data, hmax.ctypes.data, rng.ctypes.data, C.byref(st))
+    return dict(vis=vis, cmds=cmds[:counts[0]].copy(), counts=counts, desc=d, hzb_min=hmin, hzb_max=hmax,
+                valid_range=rng, stats=st, triangles_submitted=int(st.trianglesSubmitted))
 
 
 def frame(scene, view, iv, flags, prev_hzb_min=None, shard=None):

@@ -524,18 +524,37 @@ def test_raster_rule_against_exact_rational_reference():
     assert covered > 3000
 
 
-def test_multithreaded_frame_replay_equals_orc_frame():
-    """bench.py's all-cores CPU baseline (orc.frame_mt) is the same frame as orc_frame: image, HZB and counts."""
-    scene, cam = scenes.small_test_scene(320, 200, seed=3)
+def _assert_same_frame(m, f, what):
+    assert np.array_equal(m["vis"], f["vis"]), what
+    assert np.array_equal(m["cmds"], f["cmds"]) and m["counts"].tolist() == f["counts"].tolist(), what
+    assert np.array_equal(m["hzb_min"], f["hzb_min"]) and np.array_equal(m["hzb_max"], f["hzb_max"]), what
+    assert np.array_equal(m["valid_range"], f["valid_range"]), what
+    for k, _ in f["stats"]._fields_:
+        assert getattr(m["stats"], k) == getattr(f["stats"], k), (what, k)
+
+
+@pytest.mark.parametrize("name,builder,threads", [
+    ("small", lambda: scenes.small_test_scene(320, 200, seed=3), 4),
+    ("small_odd", lambda: scenes.small_test_scene(333, 211, seed=8), 7),            # edge tiles, more threads than some ranges hold
+    ("masked", lambda: scenes.masked_test_scene(320, 200), 3),
+    ("street_360p", lambda: scenes.config3_street(640, 360), 8),
+    ("floor", lambda: scenes.floor_under_camera((0.3, 0.25, 0.2), (0.1, -0.6, -1.0), 256, 192), 5),   # clipped triangles
+    ("one_meshlet", scenes.config1_single_meshlet, 16),                              # more threads than objects
+])
+def test_all_cores_frame_replay_equals_orc_frame(name, builder, threads):
+    """bench.py's all-cores CPU baseline (orc_frame_mt: culls over ranges, per-thread tile-private images merged by max, HZB
+    levels over row ranges) is orc_frame: image, command list, counts per stage, HZB chains, valid range, raster statistics --
+    without history, and with it (two-pass)."""
+    scene, cam = builder()
     from chord_amd import lib as L
     L.fill_objects(scene, cam)
     view, iv = L.make_views(cam)
     flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | R.FLAG_HZB_CULL
     f0 = orc.frame(scene, view, iv, flags)
-    f1 = orc.frame(scene, view, iv, flags, prev_hzb_min=f0["hzb_min"])
-    m1 = orc.frame_mt(scene, view, iv, flags, f0["hzb_min"], threads=4)
-    assert np.array_equal(m1["vis"], f1["vis"]) and np.array_equal(m1["hzb_min"], f1["hzb_min"])
-    assert np.array_equal(m1["hzb_max"], f1["hzb_max"]) and np.array_equal(m1["valid_range"], f1["valid_range"])
-    assert m1["triangles_submitted"] == f1["stats"].trianglesSubmitted
-    m0 = orc.frame_mt(scene, view, iv, flags, None, threads=3)
-    assert np.array_equal(m0["vis"], f0["vis"]) and m0["triangles_submitted"] == f0["stats"].trianglesSubmitted
+    _assert_same_frame(orc.frame_mt(scene, view, iv, flags, None, threads), f0, name + " no history")
+    cam1 = cam.moved((0.3, 0.05, -0.2))
+    L.fill_objects(scene, cam1, cam)
+    view1, iv1 = L.make_views(cam1, view)
+    f1 = orc.frame(scene, view1, iv1, flags, prev_hzb_min=f0["hzb_min"])
+    _assert_same_frame(orc.frame_mt(scene, view1, iv1, flags, f0["hzb_min"], threads), f1, name + " two-pass")
+    _assert_same_frame(orc.frame_mt(scene, view1, iv1, flags, f0["hzb_min"], 1), f1, name + " two-pass, one thread")
