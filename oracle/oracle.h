@@ -133,8 +133,8 @@ void orc_frame_mt(const ChordSceneDesc* scene, const ChordCameraView* view, cons
                   uint16_t* outHzbMin, uint16_t* outHzbMax, uint32_t outValidRange[2],
                   OrcRasterStats* stats);
 
-/* OpenMP-free multi-threaded replay of orc_frame's raster legs (pthread,
- * per-thread row bands merged by max) for the all-cores CPU baseline. */
+/* One raster leg on `threads` threads that share the image (compare-and-swap per fragment): the round-2 form, kept for
+ * tests that raster a list of their own. */
 void orc_raster_mt(const ChordSceneDesc* scene, const ChordInstanceCullingView* iv,
                    const ChordDrawCmd* cmds, uint32_t count, uint32_t threads,
                    uint64_t* vis, OrcRasterStats* stats);
