@@ -330,6 +330,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
+    if (c->hBinHint) { (void)hipHostFree(const_cast<uint32_t*>(c->hBinHint)); c->hBinHint = nullptr; }
     dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dHzbExchangeMax); dfree(c->dRangeExchange); dfree(c->dVisAlt); dfree(c->dVisResolvedAlt); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
     dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);

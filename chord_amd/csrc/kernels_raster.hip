@@ -35,6 +35,7 @@
 #include "device_math.h"
 
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 
 namespace chord {
@@ -86,6 +87,8 @@ struct RasterParams {
     uint32_t depthOnly, depthClamp;                     // PASS_TYPE_DEPTH (renderMeshDepth, mesh_raster.cpp:159-206): cull NONE, no id; depth clamp: near / far do not clip
     float biasConst, biasSlope;                         // vkCmdSetDepthBias(const, 0, slope), applied to the vertex depths of a depth-pass triangle
     uint32_t clearTiles;                                // first raster pass of a frame: tiles start from 0
+    uint32_t* binHint;                                  // host-visible word: the longest bin of this pass (tile order kernel -> launch_raster of later frames), or NULL
+    uint32_t slotHot;                                   // bin length from which a tile counts as hot (SLOT_HOT; tests lower it)
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
 #define DBG_NO_PIXELS   1u    // skip every visibility write
@@ -551,6 +554,7 @@ enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
 #define WIN CHORD_BLOCK_WIN
 #define DBG_NO_BLOCKS 32768u     // small clusters take the record path too (A/B of the pixel blocks; results identical)
 #define DBG_FORCE_BLOCKS 65536u  // the setup kernel takes its BLOCKS body whatever the cluster count (tests: small scenes)
+#define DBG_FORCE_HOT 262144u    // the block kernel's hot-tile variant whatever the hint says, tiles hot from 64 entries (tests: small scenes)
 
 template <bool MASKED>
 __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const uint32_t count, float (*sVert)[4][LDS_VERTS])
@@ -928,12 +932,29 @@ __device__ __forceinline__ void resolve_triangle(const RasterParams& p, uint32_t
     tile_raster_narrow<WIN>(win, ts, bx0, by0, ts.px0, ts.py0, ts.px1, ts.py1, false, rowMaskW, p.depthClamp != 0u);
 }
 
+// Hot tiles (BASELINE config 5, variant "hotspot": one screen tile receives 12 % of the frame's 10 M blocks): every bin slot
+// is a returning atomic on the tile's counter line, and a line retires ~88 of them per microsecond -- 1.26 M slots of the
+// hottest tile are 14 ms of a 17.5-ms kernel spent in one queue.  Once a tile's bin holds SLOT_HOT entries, a wave that draws
+// from it takes SLOT_AHEAD slots with one atomic and serves its next clusters in that tile from the reserve (a per-wave,
+// direct-mapped table in LDS); what is left of a reserve when the wave ends is filled with the "no entry" word the tile
+// kernel skips.  Tiles below the threshold -- every tile of every other workload -- never enter the table.
+#define SLOT_CACHE 32u
+#define SLOT_HOT 65536u
+#ifndef SLOT_AHEAD
+#define SLOT_AHEAD 8u
+#endif
+struct SlotCache { uint32_t key[SLOT_CACHE], next[SLOT_CACHE], end[SLOT_CACHE]; uint32_t pend; };   // key = tile + 1 (0: free), slots [next, end) in reserve; pend: lane 0's draw in flight
+
 #ifndef BLOCKS_LDS_VERTS
 #define BLOCKS_LDS_VERTS 128    // vertices per cluster the block kernel takes (larger clusters are left to the record kernel): 12 + 8 KB of LDS per workgroup
 #endif
-__device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, const uint32_t count, float (*sVert)[4][BLOCKS_LDS_VERTS], unsigned long long (*sWin)[WIN * WIN])
+template <bool HOT>
+__device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, const uint32_t count, float (*sVert)[4][BLOCKS_LDS_VERTS], unsigned long long (*sWin)[WIN * WIN],
+                                                         SlotCache* slotCaches)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    SlotCache& sc = slotCaches[HOT ? wave : 0u];
+    if (HOT && lane < SLOT_CACHE) { sc.key[lane] = 0u; sc.next[lane] = 0u; sc.end[lane] = 0u; }
     float* lX = sVert[0][wave]; float* lY = sVert[1][wave]; float* lW = sVert[2][wave];
     float* lU = sVert[3][wave]; float* lV = sVert[4][wave]; float* lD = sVert[5][wave];
     unsigned long long* win = sWin[wave];
@@ -1097,8 +1118,23 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
 #else
                     const BlockEmitParams e = load_block_emit_params();
 #endif
-                    if (lane == 0u && G) gbase = atomicAdd(&e.counters->blockGranules[listShard * CHORD_SHARD_STRIDE], G);
-                    if (has) slot = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&e.tileCount[(size_t)tile * TC_STRIDE]), 0x100000001ull);
+                    // (lane 0's part -- the tile of the window's first pixel -- may be served from this wave's reserve on a hot tile)
+                    // (what lane 0 drew -- 0: from the reserve, else the number of slots -- waits in LDS, not in a register, for the
+                    // resolve to finish)
+                    {
+                        uint32_t ahead = 1u;
+                        if (HOT) {
+                            const uint32_t ci = tile & (SLOT_CACHE - 1u);
+                            if (lane == 0u && has && sc.key[ci] == tile + 1u) {
+                                const uint32_t nx = sc.next[ci];
+                                if (nx < sc.end[ci]) { slot = nx; sc.next[ci] = nx + 1u; ahead = 0u; }
+                                else ahead = SLOT_AHEAD;                         // a hot tile whose reserve is used up: draw ahead again
+                            }
+                            if (lane == 0u) sc.pend = ahead;
+                        }
+                        if (lane == 0u && G) gbase = atomicAdd(&e.counters->blockGranules[listShard * CHORD_SHARD_STRIDE], G);
+                        if (has && ahead) slot = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&e.tileCount[(size_t)tile * TC_STRIDE]), (unsigned long long)ahead * 0x100000001ull);
+                    }
                     // ... and the cluster is resolved while they are in flight
 #pragma unroll
                     for (int k = 0; k < WIN * WIN / 64; k++) win[lane + 64u * k] = 0ull;
@@ -1117,7 +1153,20 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                     const bool fits = gbase + G <= e.blockCap;
                     if (!fits && lane == 0u) atomicOr(&e.counters->overflow, 1u);
                     const uint32_t off = listShard * e.blockCap + gbase + before;              // granule offset of lane r's block
-                    if (has) bin_alloc(e, tile, slot);
+                    uint32_t drew = 1u;
+                    if (HOT) {
+                        if (lane == 0u) drew = sc.pend;
+                        if (lane == 0u && has && drew) {
+                            const uint32_t ci = tile & (SLOT_CACHE - 1u);
+                            if (drew > 1u) {
+                                sc.next[ci] = slot + 1u; sc.end[ci] = slot + drew;
+                                for (uint32_t k = 1u; k < drew; k++) bin_alloc(e, tile, slot + k);   // (every drawn slot, before the first store)
+                            } else if (slot >= scalar_load(&kq()->slotHot) && (sc.key[ci] == 0u || sc.next[ci] >= sc.end[ci])) {
+                                sc.key[ci] = tile + 1u; sc.next[ci] = 0u; sc.end[ci] = 0u;           // hot from now on (an entry with a live reserve is never replaced)
+                            }
+                        }
+                    }
+                    if (has && drew) bin_alloc(e, tile, slot);
                     if (has && fits) bin_put(e, tile, slot, CHORD_REC_BLOCK | off);
                     if (fits) {
                         for (uint32_t q = 0; q < 4u; q++) {                      // (wave-uniform: the parts that exist, one in 4 of 5 clusters)
@@ -1163,6 +1212,12 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
         pax = nax; pay = nay; paz = naz; pbx = nbx; pby = nby; pbz = nbz;
         SPHASE(4);
     }
+    // what is left of the reserves: "no entry" words (the tile kernel skips them; the slots are counted in the bin's length)
+    if (HOT) WAVE_LDS_SYNC();
+    if (HOT && lane < SLOT_CACHE && sc.key[lane] != 0u && sc.next[lane] < sc.end[lane]) {
+        const BlockEmitParams e = load_block_emit_params();
+        for (uint32_t k = sc.next[lane]; k < sc.end[lane]; k++) bin_put(e, sc.key[lane] - 1u, k, 0xFFFFFFFFu);
+    }
     if (sprof && lane == 0u) {
         const uint32_t w = blockIdx.x * 4u + wave;
         if (w < CHORD_MAX_TILES * 8u / 5u) for (int i = 0; i < 5; i++) p.tilePhase[(size_t)w * 5u + i] = sph[i];
@@ -1200,13 +1255,18 @@ __global__ __launch_bounds__(256, SETUP_MIN_WAVES) void raster_setup_kernel(Rast
     raster_setup_body<MASKED>(p, count, sVert);
 }
 
+// HOT: the variant that draws bin slots ahead on hot tiles (above).  It costs the plain kernel's loop 3 % (registers: the loop
+// is at its SGPR limit), so the host launches it only when the previous frames' longest bin says a hot tile exists
+// (RasterParams::binHint, written by the tile order kernel) -- a choice of speed, both variants fill the same bins.
+template <bool HOT>
 __global__ __launch_bounds__(256, BLOCKS_MIN_WAVES) void raster_setup_blocks_kernel(RasterParams p)
 {
     __shared__ float sVert[6][4][BLOCKS_LDS_VERTS];            // x, y, w, u, v, depth of a wave's cluster (12 KB)
     __shared__ unsigned long long sWin[4][WIN * WIN];          // a small cluster's pixel window (8 KB)
+    __shared__ SlotCache sSlots[HOT ? 4 : 1];                  // bin slots drawn ahead on hot tiles (1.5 KB)
     const uint32_t count = *p.count;
     if (!launch_is_dense(p, count)) return;
-    raster_setup_blocks_body(p, count, sVert, sWin);
+    raster_setup_blocks_body<HOT>(p, count, sVert, sWin, sSlots);
 }
 
 // One lane bins one record into every tile its clamped bbox may touch (conservative edge test at the tile
@@ -1470,10 +1530,10 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 template <uint32_t NT>
 __device__ __forceinline__ void tile_order_part(const RasterParams& p)
 {
-    __shared__ uint32_t hist[20], base[20], cursor[20], splitItems;
+    __shared__ uint32_t hist[20], base[20], cursor[20], splitItems, longest;
     const uint32_t tiles = p.tilesX * p.tilesY;
     if (threadIdx.x < 20u) { hist[threadIdx.x] = 0; cursor[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) splitItems = 0;
+    if (threadIdx.x == 0) { splitItems = 0; longest = 0; }
     __syncthreads();
     constexpr uint32_t PER_THREAD = CHORD_MAX_TILES / NT;
     uint32_t myBucket[PER_THREAD], myPos[PER_THREAD], mySlices[PER_THREAD], myCount[PER_THREAD];
@@ -1488,6 +1548,7 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
                 mySlices[k] = min((c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT, CHORD_TILE_MAX_SLICES);
                 myBucket[k] = 18u;
                 myPos[k] = atomicAdd(&splitItems, mySlices[k]);
+                atomicMax(&longest, c);
             } else {
                 // bucket 4 = 2^11.., bucket 16 = count 1, bucket 17 = empty
                 myBucket[k] = c ? 16u - (31u - (uint32_t)__clz(c)) : 17u;
@@ -1500,6 +1561,7 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
         uint32_t acc = splitItems;
         for (int b = 0; b < 18; b++) { base[b] = acc; acc += hist[b]; }
         p.tileOrder[0] = make_uint2(p.clearTiles ? acc : acc - hist[17], 0u);
+        if (p.binHint) *p.binHint = longest;                      // (bins short enough to stay whole report 0)
     }
     __syncthreads();
 #pragma unroll
@@ -2473,7 +2535,17 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     const uint64_t rankPixels = (uint64_t)c->width * c->height / (c->shard.ranks > 1 ? c->shard.ranks : 1u);
     const bool maybeDense = p.blockCap != 0u && (p.blockForce != 0u || (uint64_t)in.capacity * 16ull >= rankPixels);
     p.leftCount = nullptr; p.leftCmds = nullptr;
+    p.binHint = nullptr;
     if (maybeDense) {
+        if (!c->hBinHint) {
+            void* h = nullptr;
+            LR_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped));
+            std::memset(h, 0, 64);
+            c->hBinHint = static_cast<volatile uint32_t*>(h);
+        }
+        void* dh = nullptr;
+        LR_HIP(hipHostGetDevicePointer(&dh, const_cast<uint32_t*>(c->hBinHint), 0));
+        p.binHint = static_cast<uint32_t*>(dh) + pass;
         if (!c->dLeftCmds) LR_HIP(hipMalloc((void**)&c->dLeftCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity));
         p.leftCount = c->dCounts + 6 + pass; p.leftCmds = c->dLeftCmds;
         if (!c->inFrame || c->rasterCalls >= 2) LR_HIP(hipMemsetAsync(p.leftCount, 0, sizeof(uint32_t), c->stream));
@@ -2486,7 +2558,11 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     stamp(c, S_HZBCULL);      // closes whatever preceded the raster (HZB cull / list reset)
     if (maybeDense) {
         const uint32_t bb = std::max(1u, std::min((in.capacity + 3u) / 4u, (uint32_t)c->numCUs * BLOCKS_MIN_WAVES));
-        hipLaunchKernelGGL(raster_setup_blocks_kernel, dim3(bb), dim3(256), 0, c->stream, p);
+        // the longest bin of this pass in the last frame the GPU finished: a hot tile then -> the variant that draws ahead now
+        const bool hot = (c->hBinHint && c->hBinHint[pass] >= SLOT_HOT) || (c->debugFlags & DBG_FORCE_HOT);
+        p.slotHot = (c->debugFlags & DBG_FORCE_HOT) ? 64u : SLOT_HOT;
+        if (hot) hipLaunchKernelGGL(raster_setup_blocks_kernel<true>, dim3(bb), dim3(256), 0, c->stream, p);
+        else     hipLaunchKernelGGL(raster_setup_blocks_kernel<false>, dim3(bb), dim3(256), 0, c->stream, p);
     }
     if (c->anyMasked) hipLaunchKernelGGL(raster_setup_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p);
     else              hipLaunchKernelGGL(raster_setup_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p);

@@ -431,10 +431,12 @@ int chordvis_stats(ChordCtx* ctx, ChordStats* out);
  * triangles, 64 tile kernel of later passes returns at once, 128 no tile-out, 256 tile-out without the HZB
  * reduction, 512 setup-kernel phase clocks (chordvis_debug_setup_profile), 1024 fused tile-out skips the visibility
  * stores, 2048 never split long bins, 4096 / 8192 / 16384 tile kernel skips its row units / entry set-up / the bin
- * altogether.  0 = production; any of those voids parity.  Two switches do NOT change results (tests run both): 32768 small
+ * altogether.  0 = production; any of those voids parity.  These switches do NOT change results (tests run them): 32768 small
  * clusters never leave the setup kernel as pixel blocks, 65536 every launch takes the setup kernel's pixel-block body
  * (by default it does when a launch has more than one cluster per 16 pixels), 131072 chordvis_render_frame launches
- * hzb_tail_kernel between the raster passes instead of letting the phase-1 cull reduce HZB levels 6.. itself. */
+ * hzb_tail_kernel between the raster passes instead of letting the phase-1 cull reduce HZB levels 6.. itself, 262144 the
+ * pixel-block kernel always runs its hot-tile variant and treats a bin of 64 entries as hot (by default the variant is chosen
+ * when the previous frame had a bin of 65536 entries or more). */
 int chordvis_set_debug(ChordCtx* ctx, uint32_t flags);
 /* debugging aid: raw read of an internal buffer (0 tile counts, 1 fixed bins, 2 chunk table, 3 bin pool, 4 / 5 32- / 48-byte records) */
 int chordvis_debug_read(ChordCtx* ctx, int which, uint64_t offset, uint64_t bytes, void* host);

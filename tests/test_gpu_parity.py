@@ -13,6 +13,9 @@ pytestmark = pytest.mark.gpu
 # chordvis_set_debug switches that do not change results: small clusters as pixel blocks never / on every launch
 # (by default the setup kernel decides per launch from the cluster count)
 NO_BLOCKS, FORCE_BLOCKS = 32768, 65536
+# the block kernel's hot-tile variant (bin slots drawn ahead), with tiles hot from 64 entries (by default: chosen from the
+# previous frame's longest bin, hot from 65 536)
+FORCE_HOT = 262144
 
 
 def _renderer(gpu, scene, view, iv, w, h, flags, debug=0, limits=None):
@@ -131,18 +134,20 @@ def test_pixel_blocks_of_small_clusters_are_exact(gpu, name, builder):
     want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want0["hzb_min"])
     rb = _renderer(gpu, scene, view, iv, w, h, H.ALL_FLAGS, FORCE_BLOCKS)
     rr = _renderer(gpu, scene, view, iv, w, h, H.ALL_FLAGS, NO_BLOCKS)
+    rh = _renderer(gpu, scene, view, iv, w, h, H.ALL_FLAGS, FORCE_BLOCKS | FORCE_HOT)     # bin slots drawn ahead: holes in the bins
     for frame, want in enumerate((want0, want1)):
-        rb.render_frame(); rr.render_frame()
+        rb.render_frame(); rr.render_frame(); rh.render_frame()
         got = rb.read_visibility()
         H.assert_vis_equal(got, want["vis"], w, h, "%s frame %d, pixel blocks" % (name, frame))
         assert np.array_equal(got, rr.read_visibility())
+        assert np.array_equal(got, rh.read_visibility()) and rh.stats()["overflow"] == 0
         mn, mx, rng = rb.read_hzb(rb.history_hzb())
         mn2, mx2, rng2 = rr.read_hzb(rr.history_hzb())
         assert np.array_equal(mn, mn2) and np.array_equal(mx, mx2) and np.array_equal(rng, rng2)
         sb, sr = rb.stats(), rr.stats()
         assert sb["overflow"] == 0 and sr["pixelBlockBytes"] == 0
         assert sb["trianglesSubmitted"] == sr["trianglesSubmitted"] and sb["triangleRecords"] <= sr["triangleRecords"]
-    rb.close(); rr.close()
+    rb.close(); rr.close(); rh.close()
 
 
 def test_hzb_culling_lists_match_oracle(gpu):
@@ -319,7 +324,7 @@ def test_config5_hotspot_reduced_matches_oracle(gpu):
     flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL
     want = orc.frame(scene, view, iv, flags)
     from chord_amd.renderer import VisibilityRenderer
-    for mode in (NO_BLOCKS, FORCE_BLOCKS):
+    for mode in (NO_BLOCKS, FORCE_BLOCKS, FORCE_BLOCKS | FORCE_HOT):
         r = VisibilityRenderer(0)
         r.set_limits(max_triangle_records=8 << 20, bin_pool_chunks=16384, bin_max_chunks_per_tile=2048)
         r.upload_scene(scene)
@@ -333,7 +338,7 @@ def test_config5_hotspot_reduced_matches_oracle(gpu):
         assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["stats"].trianglesSubmitted
         # the contention case: most tiles of the screen are empty, the hot ones hold tens of thousands of entries
         assert st["tilesTouched"][0] < 0.5 * ((W + 63) // 64) * ((Hh + 63) // 64)
-        assert st["binEntries"] / max(1, st["tilesTouched"][0]) > (300 if mode == FORCE_BLOCKS else 20000)   # (a block per cluster and tile / a record per triangle)
+        assert st["binEntries"] / max(1, st["tilesTouched"][0]) > (300 if mode & FORCE_BLOCKS else 20000)   # (a block per cluster and tile / a record per triangle)
         r.close()
 
 
@@ -493,7 +498,8 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, r
         r.allocate_gbuffer(w, h)
         r.set_view(view, iv, flags)
         if name.endswith("_blocks"):
-            r.set_debug(FORCE_BLOCKS)
+            # (the hotspot case: odd ranks also draw bin slots ahead on hot tiles, the sharded form of the hot-tile variant)
+            r.set_debug(FORCE_BLOCKS | (FORCE_HOT if name.startswith("hotspot") and rk % 2 else 0))
         ctxs.append(r)
     hip = L._preload_hip_runtime()
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
