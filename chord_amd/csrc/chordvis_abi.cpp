@@ -1205,6 +1205,11 @@ int chordvis_upload_history_hzb(ChordCtx* c, const uint16_t* hostMin)
 int chordvis_set_debug(ChordCtx* c, uint32_t flags)
 {
     if (!c) return CHORDVIS_E_INVALID;
+    // measurement switches the library was not built with would silently measure the product: refuse them
+    if (!RASTER_PROFILE && (flags & CHORD_DEBUG_PROFILE_BITS))
+        return fail(c, CHORDVIS_E_INVALID, "set_debug: the phase clocks (bits 16, 512) need a library built with -DRASTER_PROFILE=1 (chord_amd/build.py --tag prof -DRASTER_PROFILE=1)");
+    if (!RASTER_ABLATION && (flags & CHORD_DEBUG_ABLATION_BITS))
+        return fail(c, CHORDVIS_E_INVALID, "set_debug: the ablation switches need a library built with -DRASTER_ABLATION=1 (chord_amd/build.py --tag abl -DRASTER_ABLATION=1)");
     c->debugFlags = flags;
     if (c->depthCtx) c->depthCtx->debugFlags = flags;      // (the depth views' child context follows)
     return CHORDVIS_OK;

@@ -14,6 +14,18 @@
 
 #include "chordvis.h"
 
+// Build switches of the measurement code in the raster kernels (kernels_raster.hip): per-phase clocks (chordvis_set_debug
+// bits 16 and 512) and ablation switches (bits 1, 2, 32, 64, 128, 256, 1024, 2048, 4096, 8192, 16384).  Off in the product
+// library; python chord_amd/build.py --tag NAME -DRASTER_PROFILE=1 / -DRASTER_ABLATION=1 builds a measuring one.
+#ifndef RASTER_PROFILE
+#define RASTER_PROFILE 0
+#endif
+#ifndef RASTER_ABLATION
+#define RASTER_ABLATION 0
+#endif
+#define CHORD_DEBUG_PROFILE_BITS (16u | 512u)
+#define CHORD_DEBUG_ABLATION_BITS (1u | 2u | 32u | 64u | 128u | 256u | 1024u | 2048u | 4096u | 8192u | 16384u)
+
 namespace chord {
 
 // ---- flattened, pre-resolved scene records (bindless indirections removed at upload) ------

@@ -91,6 +91,15 @@ struct RasterParams {
     uint32_t slotHot;                                   // bin length from which a tile counts as hot (SLOT_HOT; tests lower it)
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
+// The per-phase clocks of the setup kernels (debug bit 512) and of the tile kernel (bit 16) exist only in a build with
+// -DRASTER_PROFILE=1 (python chord_amd/build.py --tag prof -DRASTER_PROFILE=1; the profile tools load that library): their
+// accumulators are 64-bit values held across the kernels' main loops, and those loops are at the 102-SGPR limit -- in the
+// product build they cost the block kernel 90 of its 145 v_readlane / v_writelane and 5 % of its time.
+// The measurement-only ablation switches below (everything but DBG_NO_BLOCKS / DBG_FORCE_BLOCKS / DBG_FORCE_HOT, which tests
+// run because they do not change results) exist only in a build with -DRASTER_ABLATION=1: tested at run time they keep
+// values alive and conditions in the innermost loops of kernels that are register-bound.  chordvis_set_debug refuses a switch
+// the library was not built with (device_layer.h).
+#define ABL(p, flag) (RASTER_ABLATION && ((p).debug & (flag)) != 0u)
 #define DBG_NO_PIXELS   1u    // skip every visibility write
 #define DBG_NO_BIN      2u    // setup only: no records, no bins
 #define DBG_TILE_CLOCKS 16u   // tile kernel writes its elapsed wall-clock ticks per tile
@@ -617,7 +626,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
         const float* __restrict__ pb = p.positions + (size_t)ib * 3;
         pax = pa[0]; pay = pa[1]; paz = pa[2]; pbx = pb[0]; pby = pb[1]; pbz = pb[2];
     }
-    const bool sprof = (p.debug & DBG_SETUP_CLOCKS) != 0;
+    const bool sprof = RASTER_PROFILE && (p.debug & DBG_SETUP_CLOCKS) != 0;
     unsigned long long sph[5] = {0, 0, 0, 0, 0}, stp = sprof ? wall_clock64() : 0ull;
 #define SPHASE(i) do { if (sprof) { const unsigned long long tn = wall_clock64(); sph[i] += tn - stp; stp = tn; } } while (0)
     for (; c < count; c += stride) {
@@ -704,7 +713,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
                     }
                 }
             }
-            if (p.debug & DBG_NO_BIN) kind = K_NONE;
+            if (ABL(p, DBG_NO_BIN)) kind = K_NONE;
             if (half == 0) { kindA = kind; tsA = ts; dA[0] = d[0]; dA[1] = d[1]; dA[2] = d[2]; }
             else           { kindB = kind; tsB = ts; dB[0] = d[0]; dB[1] = d[1]; dB[2] = d[2]; }
         }
@@ -1015,7 +1024,7 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
         const float* __restrict__ pb = ps + (size_t)ib * 3;
         pax = pa[0]; pay = pa[1]; paz = pa[2]; pbx = pb[0]; pby = pb[1]; pbz = pb[2];
     }
-    const bool sprof = (p.debug & DBG_SETUP_CLOCKS) != 0;
+    const bool sprof = RASTER_PROFILE && (p.debug & DBG_SETUP_CLOCKS) != 0;
     unsigned long long sph[5] = {0, 0, 0, 0, 0}, stp = sprof ? wall_clock64() : 0ull;
 #define SPHASE(i) do { if (sprof) { const unsigned long long tn = wall_clock64(); sph[i] += tn - stp; stp = tn; } } while (0)
     for (; c < count; c += stride) {
@@ -1073,7 +1082,7 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
         bool nwA, nwB;
         int kindA = classify_triangle(p, lane, tooBig ? 0u : T, t0, twoSided, allFast, lX, lY, lW, lU, lV, lD, bxA, byA, nwA);
         int kindB = classify_triangle(p, lane + 64u, tooBig ? 0u : T, t1, twoSided, allFast, lX, lY, lW, lU, lV, lD, bxB, byB, nwB);
-        if (p.debug & DBG_NO_BIN) { kindA = K_NONE; kindB = K_NONE; }
+        if (ABL(p, DBG_NO_BIN)) { kindA = K_NONE; kindB = K_NONE; }
         SPHASE(2);
         // next cluster: its positions (the indices have arrived behind the classification)
         const float* __restrict__ ps = scalar_load(&kq()->positions);
@@ -1544,7 +1553,7 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
         if (t < tiles) {
             const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], bin_capacity(p));
             myCount[k] = c;
-            if (c > TILE_SPLIT_MIN && !(p.debug & DBG_NO_SPLIT)) {
+            if (c > TILE_SPLIT_MIN && !ABL(p, DBG_NO_SPLIT)) {
                 mySlices[k] = min((c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT, CHORD_TILE_MAX_SLICES);
                 myBucket[k] = 18u;
                 myPos[k] = atomicAdd(&splitItems, mySlices[k]);
@@ -2035,7 +2044,7 @@ __device__ __forceinline__ void tile_out_and_hzb_body(const RasterParams& p, con
                 if (INTERIOR || row + 1 < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<float2*>(dst + p.Wi) = make_float2(d10, d11); else dst[p.Wi] = d10; }
             }
         } else
-        if (!(p.debug & DBG_NO_VIS_STORE) && (INTERIOR || x2 < tw)) {
+        if (!ABL(p, DBG_NO_VIS_STORE) && (INTERIOR || x2 < tw)) {
             unsigned long long* dst = p.vis + (size_t)(oy + row) * (size_t)p.Wi + ox + x2;
             if (INTERIOR || row < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(v00, v01); else dst[0] = v00; }
             if (INTERIOR || row + 1 < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst + p.Wi) = make_ulonglong2(v10, v11); else dst[p.Wi] = v10; }
@@ -2193,7 +2202,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     __shared__ uint32_t waveSums[2][TB / 64];
     __shared__ uint32_t chunkTab[64];                            // the overflow chunks this item's entries live in
     __shared__ uint32_t sTicket;
-    if ((p.debug & DBG_TILE_EXIT) && !p.clearTiles) return;
+    if (ABL(p, DBG_TILE_EXIT) && !p.clearTiles) return;
     // (the item count and the block's first item are fetched together: one round trip, not two dependent ones; the
     // list has an entry for every tile, so slot 1 + blockIdx.x exists whether or not it is active)
     uint2 firstItem = p.tileOrder[1u + min(blockIdx.x, p.tilesX * p.tilesY - 1u)];
@@ -2208,15 +2217,15 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     // rounded to whole batches)
     const uint32_t per = slices > 1u ? max(TILE_SLICE, ((nAll + slices - 1u) / slices + TB - 1u) & ~(TB - 1u)) : nAll;
     const uint32_t lo = slices > 1u ? min(nAll, slice * per) : 0u;
-    const uint32_t n = (p.debug & DBG_NO_BATCH) ? lo : (slices > 1u ? min(nAll, lo + per) : nAll);
-    const bool prof = (p.debug & DBG_TILE_CLOCKS) != 0;
+    const uint32_t n = ABL(p, DBG_NO_BATCH) ? lo : (slices > 1u ? min(nAll, lo + per) : nAll);
+    const bool prof = RASTER_PROFILE && (p.debug & DBG_TILE_CLOCKS) != 0;
     const unsigned long long t0 = prof ? wall_clock64() : 0ull;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = t0;
     uint32_t cUnits = 0, cUnitIters = 0, cTiny = 0, cTinyIters = 0;      // (profile only)
 #define PHASE(i) do { if (prof) { __syncthreads(); const unsigned long long tn = wall_clock64(); ph[i] += tn - tp; tp = tn; } } while (0)
     const int32_t ox = (int32_t)(tileId % p.tilesX) * TILE, oy = (int32_t)(tileId / p.tilesX) * TILE;
     const int32_t tw = min(TILE, p.Wi - ox), th = min(TILE, p.Hi - oy);
-    const bool noPixels = (p.debug & DBG_NO_PIXELS) != 0;
+    const bool noPixels = ABL(p, DBG_NO_PIXELS);
     // bit ly set <=> this rank owns pixel row oy + ly (all ones when not sharded)
     unsigned long long rowMask = ~0ull;
     if (SH) {
@@ -2316,7 +2325,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         const uint32_t k = base + threadIdx.x;
         const uint4 q0 = nq0, q1 = nq1, q2 = nq2;
         const uint32_t name = nameNext;
-        const bool have = name != 0xFFFFFFFFu && !(p.debug & DBG_NO_ENTRY);
+        const bool have = name != 0xFFFFFFFFu && !ABL(p, DBG_NO_ENTRY);
         nameNext = idxNext;
         if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);         // record of the next batch
         idxNext = k + 2u * TB < n ? binEntry(k + 2u * TB) : 0xFFFFFFFFu;          // bin entry of the batch after
@@ -2349,7 +2358,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                     const bool narrow = narrow_extent(ts);
                     const bool maskedRec = MASKED && (name & CHORD_REC_WIDE) && (q2.z & 4u);   // a TriRecMaskExt follows the record
                     if (narrow && !maskedRec && (x1 - x0 + 1) * (y1 - y0 + 1) <= TINY_AREA) {
-                        if (!(p.debug & DBG_NO_TINY)) tile_raster_narrow<TPITCH>(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask, DEPTH);
+                        if (!ABL(p, DBG_NO_TINY)) tile_raster_narrow<TPITCH>(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask, DEPTH);
                         if (prof) { cTiny++; cTinyIters += (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1)); }
                     } else {
                         rows = entry_store(prm, threadIdx.x, ts, narrow, ox, oy, x0, y0, x1, y1, maskedRec, name & ~CHORD_REC_WIDE);   // (units, not rows)
@@ -2384,7 +2393,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
             const uint32_t nr = min(total - r0, (uint32_t)UNIT_CAP);
             for (uint32_t ui = threadIdx.x; ui < nr; ui += TB) {
                 const uint32_t d = unitList[ui];
-                if (p.debug & DBG_NO_UNITS) continue;
+                if (ABL(p, DBG_NO_UNITS)) continue;
                 const int32_t trips = entry_unit<MASKED, DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, rowMask, noPixels);
                 if (prof) { cUnits++; cUnitIters += (uint32_t)trips; }
             }
@@ -2416,8 +2425,8 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     }
 
     // ---- tile out ------------------------------------------------------------------------------------
-    if (p.debug & DBG_NO_OUT) {
-    } else if (p.hzbFused && !(p.debug & DBG_NO_HZB)) {
+    if (ABL(p, DBG_NO_OUT)) {
+    } else if (p.hzbFused && !ABL(p, DBG_NO_HZB)) {
         // single-GPU frame: the whole tile goes out (first pass: this is the clear; later passes loaded it), and its
         // HZB texels with it; the batch buffers are free now and hold the cross-wave part of the reduction
         tile_out_and_hzb(p, tile, reinterpret_cast<float*>(&prm.w[0][0]), offs, tileId, ox, oy, tw, th);

@@ -426,7 +426,10 @@ int chordvis_upload_history_hzb(ChordCtx* ctx, const uint16_t* hostMin);
  * hipEventRecord between two kernels costs ~5 us of stream idle time on MI355X. */
 int chordvis_enable_timers(ChordCtx* ctx, int mode);
 int chordvis_stats(ChordCtx* ctx, ChordStats* out);
-/* Measurement-only ablation switches of the raster kernels (kernels_raster.hip DBG_*): 1 no pixel writes, 2 setup
+/* Measurement-only switches of the raster kernels (kernels_raster.hip DBG_*).  The clocks (16, 512) and the ablation switches
+ * are compiled into the kernels only with -DRASTER_PROFILE=1 / -DRASTER_ABLATION=1 (python chord_amd/build.py --tag NAME -D...;
+ * load it with CHORDVIS_LIB): the product library REFUSES them (CHORDVIS_E_INVALID), because testing them at run time costs the
+ * register-bound kernels 3-5 %.  1 no pixel writes, 2 setup
  * emits no records / bins, 16 per-tile clocks (chordvis_debug_tile_profile), 32 skip the per-lane scan of tiny
  * triangles, 64 tile kernel of later passes returns at once, 128 no tile-out, 256 tile-out without the HZB
  * reduction, 512 setup-kernel phase clocks (chordvis_debug_setup_profile), 1024 fused tile-out skips the visibility
@@ -444,7 +447,9 @@ int chordvis_debug_read(ChordCtx* ctx, int which, uint64_t offset, uint64_t byte
 int chordvis_debug_slab_nonzero(ChordCtx* ctx, uint64_t* count);
 /* measurement aid: ms per frame of 2*pairs stream-launched frames vs the same frames replayed from a hipGraph */
 int chordvis_debug_graph_frames(ChordCtx* ctx, uint32_t pairs, float* msPerFrameStream, float* msPerFrameGraph);
-/* debug bit 512: per-wave phase ticks (10 ns) of the setup kernel summed over waves: header wait / vertex / triangle / reserve / emit */
+/* debug bit 512: per-wave phase ticks (10 ns) of the setup kernel summed over waves: header wait / vertex / triangle / reserve / emit.
+ * The clocks of bits 16 and 512 are compiled in only with -DRASTER_PROFILE=1 (python chord_amd/build.py --tag prof -DRASTER_PROFILE=1:
+ * their accumulators cost the product kernels scalar registers they do not have); the product library leaves the ticks zero. */
 int chordvis_debug_setup_profile(ChordCtx* ctx, int pass, uint64_t hostTicks[5], uint32_t* waves);
 int chordvis_debug_tile_profile(ChordCtx* ctx, int pass, uint64_t* hostTicks, uint32_t* hostCounts, uint32_t capacity);
 

@@ -1,6 +1,8 @@
 """Error behaviour of the C ABI on the device: a scene the kernels could not index safely is refused at
 upload, a frame that overflowed its work lists says so, and the context stays usable after either.  The reference asserts
 (check() / checkVkResult(), utils.h:57-72); a C ABI that takes caller buffers returns codes instead."""
+import os
+
 import numpy as np
 import pytest
 
@@ -107,4 +109,21 @@ def test_work_list_exhaustion_is_reported_and_recoverable(gpu):
     r.render_frame()
     H.assert_vis_equal(r.read_visibility(), want["vis"], cam.width, cam.height, "after overflowed frames")
     assert r.stats()["overflow"] == 0
+    r.close()
+
+
+def test_measurement_switches_are_refused_by_the_product_library(gpu):
+    """The phase clocks and ablation switches of the raster kernels exist only in libraries built with -DRASTER_PROFILE=1 /
+    -DRASTER_ABLATION=1; the product library says so instead of silently measuring itself.  The switches that do not change
+    results (pixel blocks never / always, hot-tile variant, HZB tail as a launch of its own) stay available."""
+    from chord_amd.renderer import VisibilityRenderer
+    if os.environ.get("CHORDVIS_LIB"):
+        pytest.skip("a variant library is loaded")
+    r = VisibilityRenderer(0)
+    for bit in (1, 2, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
+        with pytest.raises(L.ChordvisError) as e:
+            r.set_debug(bit)
+        assert "(-1)" in str(e.value) and "built with" in str(e.value), str(e.value)        # CHORDVIS_E_INVALID
+    for bits in (32768, 65536, 65536 | 262144, 131072, 0):
+        r.set_debug(bits)
     r.close()

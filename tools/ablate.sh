@@ -5,7 +5,9 @@
 #   -w  workloads (default street_4k_hzb); -f  chordvis_set_debug switch sets (default 0; the switches void parity, HZB is turned
 #       off for them so that culling does not depend on the pixels); -t  variant libraries built with
 #       `python chord_amd/build.py --tag NAME -D...` ("" = the product build, always included first)
-# Stage-by-stage ablation of the tile kernel:   tools/ablate.sh abl -f 0,4096,4128,12320,28704,28832
+# The ablation switches exist only in a library built with -DRASTER_ABLATION=1 (the product library refuses them):
+#   python chord_amd/build.py --tag abl -DRASTER_ABLATION=1   and then   -t abl   (the product build's line is skipped for such flags)
+# Stage-by-stage ablation of the tile kernel:   tools/ablate.sh abl -t abl -f 0,4096,4128,12320,28704,28832
 # Setup kernel without emission on dense geometry:               tools/ablate.sh blk -w subpixel_64m -f 65536,65538
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift; mkdir -p $OUT; cd $GRAFT_REPO_ROOT

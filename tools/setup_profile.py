@@ -1,4 +1,5 @@
-"""Per-phase time of the setup kernel summed over waves (measurement aid; debug bit 512)."""
+"""Per-phase time of the setup kernel summed over waves (measurement aid; debug bit 512).  Needs the profiling build of the
+library:  python chord_amd/build.py --tag prof -DRASTER_PROFILE=1;  CHORDVIS_LIB=chord_amd/_build/libchordvis_prof.so python tools/setup_profile.py"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,4 +1,5 @@
-"""Per-tile timing of the raster tile kernel (measurement aid)."""
+"""Per-tile timing of the raster tile kernel (measurement aid).  Needs the profiling build of the library:
+  python chord_amd/build.py --tag prof -DRASTER_PROFILE=1;  CHORDVIS_LIB=chord_amd/_build/libchordvis_prof.so python tools/tile_profile.py hzb"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
