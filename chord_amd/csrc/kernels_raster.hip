@@ -114,6 +114,25 @@ struct RasterParams {
 #define DBG_NO_BATCH    16384u // tile kernel skips the bin altogether (tile in + tile out only)
 #define DBG_NO_UNITS    4096u // tile kernel skips the row units (entries are still fetched, set up, scanned and listed)
 
+// Scalar loads and the kernel arguments re-read at their point of use.  The raster kernels take ONE by-value RasterParams; the
+// compiler loads every field a kernel touches into scalar registers up front and keeps it there, and the loops of these
+// kernels sit at the 102-SGPR limit: what does not fit lives in VGPR lanes, one v_readlane / v_writelane per use (the record
+// setup kernel: 900 of them, a tenth of its instructions).  Fields needed once per cluster / tile are therefore read again
+// from the kernel-argument segment (scalar cache) where they are used; the pointer goes through an empty asm so that the
+// loads cannot be hoisted back to the top.
+template <typename T>
+__device__ __forceinline__ T scalar_load(const T* ptr)
+{
+    // uniform address, data written by an earlier kernel: the scalar cache is coherent at kernel boundaries
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(ptr));
+}
+__device__ __forceinline__ const RasterParams* kernel_args()
+{
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return reinterpret_cast<const RasterParams*>(kp);
+}
+
 __device__ __forceinline__ int32_t bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 __device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
@@ -281,6 +300,30 @@ __device__ __forceinline__ void tri_setup_from_record(TriSetup& ts, const TriRec
 
 // ---- record + bin emission --------------------------------------------------------------------
 
+// What the record kernel's emission (list and bin reservations, record stores) needs of the kernel arguments, per cluster.
+struct RecordEmitParams {
+    DeviceCounters* counters; ClipTri* clipTris; uint32_t clipTriCap; uint32_t pass;
+    TriRec* tris; uint32_t triCap; TriRecC* trisC; uint32_t triCapC; uint32_t* largeList; uint32_t largeCap;
+    uint32_t* tileCount; uint32_t* tileBins; uint32_t binCap; uint32_t tilesX;
+    uint32_t* binPool; uint32_t binPoolChunks; uint32_t* binPoolCount;
+    unsigned long long* binChunkTab; uint32_t binStamp; uint32_t binMaxChunks;
+    ShardInfo shard;
+};
+__device__ __forceinline__ RecordEmitParams load_record_emit_params()
+{
+    const RasterParams* q = kernel_args();
+    RecordEmitParams e;
+    e.counters = scalar_load(&q->counters); e.clipTris = scalar_load(&q->clipTris); e.clipTriCap = scalar_load(&q->clipTriCap); e.pass = scalar_load(&q->pass);
+    e.tris = scalar_load(&q->tris); e.triCap = scalar_load(&q->triCap); e.trisC = scalar_load(&q->trisC); e.triCapC = scalar_load(&q->triCapC);
+    e.largeList = scalar_load(&q->largeList); e.largeCap = scalar_load(&q->largeCap);
+    e.tileCount = scalar_load(&q->tileCount); e.tileBins = scalar_load(&q->tileBins); e.binCap = scalar_load(&q->binCap); e.tilesX = scalar_load(&q->tilesX);
+    e.binPool = scalar_load(&q->binPool); e.binPoolChunks = scalar_load(&q->binPoolChunks); e.binPoolCount = scalar_load(&q->binPoolCount);
+    e.binChunkTab = scalar_load(&q->binChunkTab); e.binStamp = scalar_load(&q->binStamp); e.binMaxChunks = scalar_load(&q->binMaxChunks);
+    e.shard.stripeRows = scalar_load(&q->shard.stripeRows); e.shard.ranks = scalar_load(&q->shard.ranks); e.shard.rank = scalar_load(&q->shard.rank);
+    e.shard.stripesPerRank = scalar_load(&q->shard.stripesPerRank); e.shard.stripeMagic = scalar_load(&q->shard.stripeMagic); e.shard.rankMagic = scalar_load(&q->shard.rankMagic);
+    return e;
+}
+
 // One bin slot per lane, reserved with ONE atomic per distinct tile in the wave: lanes that target the
 // same tile elect a leader (pure ALU), all leaders issue their atomicAdd in a single wave instruction, and
 // the base is handed back through the lanes.  (64 lanes hitting one counter would serialise at the L2.)
@@ -368,7 +411,8 @@ struct BinTicket {
     BinElect eA, eB;
 };
 
-__device__ __forceinline__ void wave_bin_issue(const RasterParams& p, bool emitA, const TriSetup& tsA, bool emitB, const TriSetup& tsB,
+template <class P>
+__device__ __forceinline__ void wave_bin_issue(const P& p, bool emitA, const TriSetup& tsA, bool emitB, const TriSetup& tsB,
                                                uint32_t lane, BinTicket& k)
 {
     auto tile_of = [&](const TriSetup& ts, int r, bool emit, uint32_t& tile) -> bool {
@@ -399,7 +443,8 @@ __device__ __forceinline__ void wave_bin_issue(const RasterParams& p, bool emitA
 
 // (a record that did not fit its list leaves its reserved bin slots unwritten: the frame is reported incomplete
 // anyway, and a stale entry of an earlier frame is a valid index)
-__device__ __forceinline__ void wave_bin_commit(const RasterParams& p, BinTicket& k, bool okA, uint32_t giA, bool okB, uint32_t giB)
+template <class P>
+__device__ __forceinline__ void wave_bin_commit(const P& p, BinTicket& k, bool okA, uint32_t giA, bool okB, uint32_t giB)
 {
     k.slotA[0] = __shfl(k.slotA[0], k.eA.leader, 64) + k.eA.rank;
     k.slotB[0] = __shfl(k.slotB[0], k.eB.leader, 64) + k.eB.rank;
@@ -565,8 +610,9 @@ enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
 #define DBG_FORCE_BLOCKS 65536u  // the setup kernel takes its BLOCKS body whatever the cluster count (tests: small scenes)
 #define DBG_FORCE_HOT 262144u    // the block kernel's hot-tile variant whatever the hint says, tiles hot from 64 entries (tests: small scenes)
 
+// cmds / count: the list this launch sets up (the input list, or what the block kernel left over: raster_setup_kernel).
 template <bool MASKED>
-__device__ __forceinline__ void raster_setup_body(const RasterParams& p, const uint32_t count, float (*sVert)[4][LDS_VERTS])
+__device__ __forceinline__ void raster_setup_body(const RasterParams& p, const ChordDrawCmd* __restrict__ cmds, const uint32_t count, float (*sVert)[4][LDS_VERTS])
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* lX = sVert[0][wave]; float* lY = sVert[1][wave]; float* lW = sVert[2][wave];
@@ -588,15 +634,16 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
         h.objectId = __builtin_amdgcn_readfirstlane(cmd.objectId);
         h.meshletId = __builtin_amdgcn_readfirstlane(cmd.meshletId);
         h.slot = __builtin_amdgcn_readfirstlane(cmd.slot);
-        const DMeshlet* __restrict__ mm = &p.meshlets[h.meshletId];
+        const RasterParams* q = kernel_args();                  // (scene pointers: read where they are used, not held across the loop)
+        const DMeshlet* __restrict__ mm = &scalar_load(&q->meshlets)[h.meshletId];
         const uint32_t vt = __builtin_amdgcn_readfirstlane(mm->vertexTriangleCount);
         h.V = vt & 0xFFu; h.T = (vt >> 8) & 0xFFu;
         h.dataOffset = __builtin_amdgcn_readfirstlane(mm->dataOffset);
         h.vertexBase = __builtin_amdgcn_readfirstlane(mm->vertexBase);
-        h.matFlags = __builtin_amdgcn_readfirstlane(p.objStatic[h.objectId].matFlags);
+        h.matFlags = __builtin_amdgcn_readfirstlane(scalar_load(&q->objStatic)[h.objectId].matFlags);
         h.twoSided = (h.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u;
         if (CHORD_MATFLAG_ALPHA(h.matFlags) >= CHORD_ALPHA_BLEND) h.T = 0u;   // blended: in no bucket of renderMesh (mesh_raster.cpp:224)
-        const float* __restrict__ mv = p.objFrame[h.objectId].mvp;
+        const float* __restrict__ mv = scalar_load(&q->objFrame)[h.objectId].mvp;
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -611,19 +658,21 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
     const uint32_t stride = gridDim.x * 4u;
     uint32_t c = blockIdx.x * 4u + wave;
     if (c >= count) return;
-    auto cmd_at = [&](uint32_t i) -> ChordDrawCmd { return p.cmds[__builtin_amdgcn_readfirstlane(min(i, count - 1u))]; };
+    auto cmd_at = [&](uint32_t i) -> ChordDrawCmd { return cmds[__builtin_amdgcn_readfirstlane(min(i, count - 1u))]; };
     Header hdr = load_header(cmd_at(c));
     Header hdrN = load_header(cmd_at(c + stride));
     // geometry of the current cluster: vertices lane and lane + 64 (indices, then positions), triangle words
     uint32_t t0 = 0, t1 = 0;
     float pax, pay, paz, pbx, pby, pbz;
     {
-        const uint32_t ia = p.meshletData[hdr.dataOffset + min(lane, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
-        const uint32_t ib = p.meshletData[hdr.dataOffset + min(lane + 64u, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
-        if (lane < hdr.T) t0 = p.meshletData[hdr.dataOffset + hdr.V + lane];
-        if (lane + 64u < hdr.T) t1 = p.meshletData[hdr.dataOffset + hdr.V + 64u + lane];
-        const float* __restrict__ pa = p.positions + (size_t)ia * 3;
-        const float* __restrict__ pb = p.positions + (size_t)ib * 3;
+        const uint32_t* __restrict__ md = scalar_load(&kernel_args()->meshletData);
+        const float* __restrict__ ps = scalar_load(&kernel_args()->positions);
+        const uint32_t ia = md[hdr.dataOffset + min(lane, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
+        const uint32_t ib = md[hdr.dataOffset + min(lane + 64u, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
+        if (lane < hdr.T) t0 = md[hdr.dataOffset + hdr.V + lane];
+        if (lane + 64u < hdr.T) t1 = md[hdr.dataOffset + hdr.V + 64u + lane];
+        const float* __restrict__ pa = ps + (size_t)ia * 3;
+        const float* __restrict__ pb = ps + (size_t)ib * 3;
         pax = pa[0]; pay = pa[1]; paz = pa[2]; pbx = pb[0]; pby = pb[1]; pbz = pb[2];
     }
     const bool sprof = RASTER_PROFILE && (p.debug & DBG_SETUP_CLOCKS) != 0;
@@ -653,7 +702,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
         if (lane < V) vertex(lane, pax, pay, paz);
         if (lane + 64u < V) vertex(lane + 64u, pbx, pby, pbz);
         for (uint32_t i = lane + 128u; i < V; i += 64u) {                        // (meshlets with more than 128 vertices)
-            const float* __restrict__ pp = p.positions + (size_t)(p.meshletData[dataOffset + i] + vertexBase) * 3;
+            const float* __restrict__ pp = scalar_load(&kernel_args()->positions) + (size_t)(scalar_load(&kernel_args()->meshletData)[dataOffset + i] + vertexBase) * 3;
             vertex(i, pp[0], pp[1], pp[2]);
         }
         const bool allFast = __ballot(notFast) == 0ull;
@@ -662,10 +711,11 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         SPHASE(1);
         // next cluster: indices and triangle words now (its header has been resident for an iteration)
-        const uint32_t nia = p.meshletData[hdrN.dataOffset + min(lane, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
-        const uint32_t nib = p.meshletData[hdrN.dataOffset + min(lane + 64u, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
-        const uint32_t nt0 = lane < hdrN.T ? p.meshletData[hdrN.dataOffset + hdrN.V + lane] : 0u;
-        const uint32_t nt1 = lane + 64u < hdrN.T ? p.meshletData[hdrN.dataOffset + hdrN.V + 64u + lane] : 0u;
+        const uint32_t* __restrict__ mdN = scalar_load(&kernel_args()->meshletData);
+        const uint32_t nia = mdN[hdrN.dataOffset + min(lane, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
+        const uint32_t nib = mdN[hdrN.dataOffset + min(lane + 64u, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
+        const uint32_t nt0 = lane < hdrN.T ? mdN[hdrN.dataOffset + hdrN.V + lane] : 0u;
+        const uint32_t nt1 = lane + 64u < hdrN.T ? mdN[hdrN.dataOffset + hdrN.V + 64u + lane] : 0u;
 
         // ---- triangle phase: the (up to) two triangles of a lane are evaluated first, then emitted together so
         //      that every round of list / bin reservations costs ONE atomic round trip for both ------------------
@@ -719,8 +769,9 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
         }
         SPHASE(2);
         // next cluster: its positions now (the indices have arrived behind the triangle arithmetic)
-        const float* __restrict__ npa = p.positions + (size_t)nia * 3;
-        const float* __restrict__ npb = p.positions + (size_t)nib * 3;
+        const float* __restrict__ psN = scalar_load(&kernel_args()->positions);
+        const float* __restrict__ npa = psN + (size_t)nia * 3;
+        const float* __restrict__ npb = psN + (size_t)nib * 3;
         const float nax = npa[0], nay = npa[1], naz = npa[2], nbx = npb[0], nby = npb[1], nbz = npb[2];
         {
             const unsigned long long lt = (1ull << lane) - 1ull;
@@ -738,65 +789,66 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
             const uint32_t nEc = (uint32_t)(__popcll(ecA) + __popcll(ecB)), nEw = (uint32_t)(__popcll(ewA) + __popcll(ewB));
             const uint32_t nLg = (uint32_t)(__popcll(lmA) + __popcll(lmB));
             {
+            const RecordEmitParams e = load_record_emit_params();
             // every reservation of the cluster travels together: the list reservations (lane 0) and the bin
             // reservations; nothing is stored before they are back
             uint32_t cbase = 0, ebaseC = 0, ebaseW = 0, lbase = 0;
             if (lane == 0) {
-                if (nClip) cbase = atomicAdd(&p.counters->clipTriCount[p.pass], nClip);
-                if (nEc) ebaseC = atomicAdd(&p.counters->triCountC[listShard * CHORD_SHARD_STRIDE], nEc);
-                if (nEw) ebaseW = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], nEw * wSlots);
-                if (nLg) lbase = atomicAdd(&p.counters->largeCount[p.pass][listShard * CHORD_SHARD_STRIDE], nLg);
+                if (nClip) cbase = atomicAdd(&e.counters->clipTriCount[p.pass], nClip);
+                if (nEc) ebaseC = atomicAdd(&e.counters->triCountC[listShard * CHORD_SHARD_STRIDE], nEc);
+                if (nEw) ebaseW = atomicAdd(&e.counters->triCount[listShard * CHORD_SHARD_STRIDE], nEw * wSlots);
+                if (nLg) lbase = atomicAdd(&e.counters->largeCount[p.pass][listShard * CHORD_SHARD_STRIDE], nLg);
             }
             BinTicket ticket;
-            if (emA | emB) wave_bin_issue(p, kindA == K_EMIT && !lgA, tsA, kindB == K_EMIT && !lgB, tsB, lane, ticket);
+            if (emA | emB) wave_bin_issue(e, kindA == K_EMIT && !lgA, tsA, kindB == K_EMIT && !lgB, tsB, lane, ticket);
             cbase = bcast(cbase, 0); ebaseC = bcast(ebaseC, 0); ebaseW = bcast(ebaseW, 0); lbase = bcast(lbase, 0);
             SPHASE(3);
             if (kindA == K_CLIP) {
                 const uint32_t k = cbase + (uint32_t)__popcll(cmA & lt);
-                if (k < p.clipTriCap) { ClipTri ct; ct.objectId = hdr.objectId; ct.meshletId = hdr.meshletId; ct.slot = hdr.slot; ct.tri = lane; p.clipTris[k] = ct; }
-                else atomicOr(&p.counters->overflow, 2u);
+                if (k < e.clipTriCap) { ClipTri ct; ct.objectId = hdr.objectId; ct.meshletId = hdr.meshletId; ct.slot = hdr.slot; ct.tri = lane; e.clipTris[k] = ct; }
+                else atomicOr(&e.counters->overflow, 2u);
             }
             if (kindB == K_CLIP) {
                 const uint32_t k = cbase + (uint32_t)__popcll(cmA) + (uint32_t)__popcll(cmB & lt);
-                if (k < p.clipTriCap) { ClipTri ct; ct.objectId = hdr.objectId; ct.meshletId = hdr.meshletId; ct.slot = hdr.slot; ct.tri = lane + 64u; p.clipTris[k] = ct; }
-                else atomicOr(&p.counters->overflow, 2u);
+                if (k < e.clipTriCap) { ClipTri ct; ct.objectId = hdr.objectId; ct.meshletId = hdr.meshletId; ct.slot = hdr.slot; ct.tri = lane + 64u; e.clipTris[k] = ct; }
+                else atomicOr(&e.counters->overflow, 2u);
             }
             // giX names the record in a bin: compact index, or CHORD_REC_WIDE | wide index
             uint32_t giA = 0, giB = 0;
             bool okA = false, okB = false;
             if (cpA) {
                 const uint32_t li = ebaseC + (uint32_t)__popcll(ecA & lt);
-                if (li < p.triCapC) { giA = listShard * p.triCapC + li; write_record_c(&p.trisC[giA], tsA, dA); okA = true; }
-                else atomicOr(&p.counters->overflow, 1u);
+                if (li < e.triCapC) { giA = listShard * e.triCapC + li; write_record_c(&e.trisC[giA], tsA, dA); okA = true; }
+                else atomicOr(&e.counters->overflow, 1u);
             } else if (kindA == K_EMIT) {
                 const uint32_t li = ebaseW + wSlots * (uint32_t)__popcll(ewA & lt);
-                if (li + wSlots <= p.triCap) {
-                    giA = listShard * p.triCap + li; write_record(&p.tris[giA], tsA, dA, twoSided, masked);
-                    if (MASKED && masked) setup_emit_mask_ext(p, &p.tris[giA + 1u], triWord[0], dataOffset, vertexBase, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsA.area);
+                if (li + wSlots <= e.triCap) {
+                    giA = listShard * e.triCap + li; write_record(&e.tris[giA], tsA, dA, twoSided, masked);
+                    if (MASKED && masked) setup_emit_mask_ext(p, &e.tris[giA + 1u], triWord[0], dataOffset, vertexBase, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsA.area);
                     giA |= CHORD_REC_WIDE; okA = true;
-                } else atomicOr(&p.counters->overflow, 1u);
+                } else atomicOr(&e.counters->overflow, 1u);
             }
             if (cpB) {
                 const uint32_t li = ebaseC + (uint32_t)__popcll(ecA) + (uint32_t)__popcll(ecB & lt);
-                if (li < p.triCapC) { giB = listShard * p.triCapC + li; write_record_c(&p.trisC[giB], tsB, dB); okB = true; }
-                else atomicOr(&p.counters->overflow, 1u);
+                if (li < e.triCapC) { giB = listShard * e.triCapC + li; write_record_c(&e.trisC[giB], tsB, dB); okB = true; }
+                else atomicOr(&e.counters->overflow, 1u);
             } else if (kindB == K_EMIT) {
                 const uint32_t li = ebaseW + wSlots * ((uint32_t)__popcll(ewA) + (uint32_t)__popcll(ewB & lt));
-                if (li + wSlots <= p.triCap) {
-                    giB = listShard * p.triCap + li; write_record(&p.tris[giB], tsB, dB, twoSided, masked);
-                    if (MASKED && masked) setup_emit_mask_ext(p, &p.tris[giB + 1u], triWord[1], dataOffset, vertexBase, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsB.area);
+                if (li + wSlots <= e.triCap) {
+                    giB = listShard * e.triCap + li; write_record(&e.tris[giB], tsB, dB, twoSided, masked);
+                    if (MASKED && masked) setup_emit_mask_ext(p, &e.tris[giB + 1u], triWord[1], dataOffset, vertexBase, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsB.area);
                     giB |= CHORD_REC_WIDE; okB = true;
-                } else atomicOr(&p.counters->overflow, 1u);
+                } else atomicOr(&e.counters->overflow, 1u);
             }
             // <= 2x2 tiles: straight into the bins; more: the large list
-            if (emA | emB) wave_bin_commit(p, ticket, okA, giA, okB, giB);
+            if (emA | emB) wave_bin_commit(e, ticket, okA, giA, okB, giB);
             if (lgA && okA) {
                 const uint32_t k = lbase + (uint32_t)__popcll(lmA & lt);
-                if (k < p.largeCap) p.largeList[(size_t)listShard * p.largeCap + k] = giA & ~CHORD_REC_WIDE; else atomicOr(&p.counters->overflow, 1u);
+                if (k < e.largeCap) e.largeList[(size_t)listShard * e.largeCap + k] = giA & ~CHORD_REC_WIDE; else atomicOr(&e.counters->overflow, 1u);
             }
             if (lgB && okB) {
                 const uint32_t k = lbase + (uint32_t)__popcll(lmA) + (uint32_t)__popcll(lmB & lt);
-                if (k < p.largeCap) p.largeList[(size_t)listShard * p.largeCap + k] = giB & ~CHORD_REC_WIDE; else atomicOr(&p.counters->overflow, 1u);
+                if (k < e.largeCap) e.largeList[(size_t)listShard * e.largeCap + k] = giB & ~CHORD_REC_WIDE; else atomicOr(&e.counters->overflow, 1u);
             }
             }
         }
@@ -830,13 +882,6 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const u
 // s_load instead of a vector load + v_readfirstlane per dword), and a block leaves the wave as 16-byte stores of consecutive
 // word pairs (header | word 0, word 1 | word 2, ...): half the store instructions, whole 16-byte granules.
 struct SetupHeader { uint32_t objectId, meshletId, slot, V, T, dataOffset, vertexBase, matFlags; };
-
-template <typename T>
-__device__ __forceinline__ T scalar_load(const T* ptr)
-{
-    // uniform address, data written by an earlier kernel: the scalar cache is coherent at kernel boundaries
-    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(ptr));
-}
 
 // tri_setup without the division: false when the triangle is rejected (zero area, back face after snapping, empty bbox)
 __device__ __forceinline__ bool tri_setup_geom(TriSetup& ts, bool twoSided, int32_t Wi, int32_t Hi, bool& small)
@@ -1260,8 +1305,9 @@ __global__ __launch_bounds__(256, SETUP_MIN_WAVES) void raster_setup_kernel(Rast
 {
     __shared__ float sVert[6][4][LDS_VERTS];                   // x, y, w, u, v, depth of a wave's cluster (24 KB)
     uint32_t count = *p.count;
-    if (launch_is_dense(p, count)) { count = *p.leftCount; p.cmds = p.leftCmds; }
-    raster_setup_body<MASKED>(p, count, sVert);
+    const ChordDrawCmd* cmds = p.cmds;
+    if (launch_is_dense(p, count)) { count = *p.leftCount; cmds = p.leftCmds; }
+    raster_setup_body<MASKED>(p, cmds, count, sVert);
 }
 
 // HOT: the variant that draws bin slots ahead on hot tiles (above).  It costs the plain kernel's loop 3 % (registers: the loop
@@ -1999,8 +2045,32 @@ __device__ __forceinline__ int32_t entry_unit(const RasterParams& p, const Entry
 // 3-5 (8x8 values per tile) cross waves through LDS: one barrier per tile.
 // INTERIOR: every HZB texel of the tile, at every level, lies inside the chain's valid extent (all tiles but those at the
 // right / bottom screen edge): no per-texel bounds arithmetic.
+// What the tile-out needs of the kernel's arguments, read again from the kernel-argument segment (scalar cache) when a tile is
+// finished: held in scalar registers across the scan conversion, these ~30 dwords are spilled to VGPR lanes and back.
+struct TileOutParams {
+    ChordHZBDesc hzbDesc;                                   // (only the fields the reduction uses are loaded)
+    uint16_t* hzbMinA; uint16_t* hzbMinB; uint16_t* hzbMaxB; uint32_t* tileRange;
+    unsigned long long* vis; float* depthOut; int32_t Wi; uint32_t tilesX; uint32_t debug;
+};
+__device__ __forceinline__ TileOutParams load_tile_out_params()
+{
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const RasterParams* q = reinterpret_cast<const RasterParams*>(kp);            // (the kernel's one by-value argument)
+    TileOutParams t;
+    t.hzbDesc.srcWidth = scalar_load(&q->hzbDesc.srcWidth); t.hzbDesc.srcHeight = scalar_load(&q->hzbDesc.srcHeight);
+    t.hzbDesc.width = scalar_load(&q->hzbDesc.width); t.hzbDesc.height = scalar_load(&q->hzbDesc.height);
+    t.hzbDesc.mipCount = scalar_load(&q->hzbDesc.mipCount);
+#pragma unroll
+    for (int l = 0; l < 6; l++) t.hzbDesc.mipOffset[l] = scalar_load(&q->hzbDesc.mipOffset[l]);
+    t.hzbMinA = scalar_load(&q->hzbMinA); t.hzbMinB = scalar_load(&q->hzbMinB); t.hzbMaxB = scalar_load(&q->hzbMaxB);
+    t.tileRange = scalar_load(&q->tileRange); t.vis = scalar_load(&q->vis); t.depthOut = scalar_load(&q->depthOut);
+    t.Wi = scalar_load(&q->Wi); t.tilesX = scalar_load(&q->tilesX); t.debug = scalar_load(&q->debug);
+    return t;
+}
+
 template <bool INTERIOR>
-__device__ __forceinline__ void tile_out_and_hzb_body(const RasterParams& p, const unsigned long long* tile, float* sM2, uint32_t* sRange,
+__device__ __forceinline__ void tile_out_and_hzb_body(const TileOutParams& p, const unsigned long long* tile, float* sM2, uint32_t* sRange,
                                                       uint32_t tileId, int32_t ox, int32_t oy, int32_t tw, int32_t th)
 {
     static_assert(TILE == 64 && TB == 512, "wave w <-> pixel rows 8w..8w+7");
@@ -2098,9 +2168,10 @@ __device__ __forceinline__ void tile_out_and_hzb_body(const RasterParams& p, con
     }
 }
 
-__device__ __forceinline__ void tile_out_and_hzb(const RasterParams& p, const unsigned long long* tile, float* sM2, uint32_t* sRange,
+__device__ __forceinline__ void tile_out_and_hzb(const unsigned long long* tile, float* sM2, uint32_t* sRange,
                                                  uint32_t tileId, int32_t ox, int32_t oy, int32_t tw, int32_t th)
 {
+    const TileOutParams p = load_tile_out_params();
     const ChordHZBDesc& d = p.hzbDesc;
     const uint32_t tX = tileId % p.tilesX, tY = tileId / p.tilesX;
     const uint32_t vw0 = min(max(1u, d.width), ((d.srcWidth - 1u) >> 1) + 1u), vh0 = min(max(1u, d.height), ((d.srcHeight - 1u) >> 1) + 1u);
@@ -2249,7 +2320,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
         ulonglong2 v = make_ulonglong2(0ull, 0ull);
         if (ly < th && lx < tw) {
-            const unsigned long long* src = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
+            const unsigned long long* src = scalar_load(&kernel_args()->vis) + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
             if (lx + 1 < tw) v = *reinterpret_cast<const ulonglong2*>(src);
             else v.x = src[0];
         }
@@ -2269,8 +2340,9 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         chunk0 = lo > p.binCap ? (lo - p.binCap) >> CHORD_BIN_CHUNK_SHIFT : 0u;
         const uint32_t chunks = min(64u, ((n - p.binCap + CHORD_BIN_CHUNK - 1u) >> CHORD_BIN_CHUNK_SHIFT) - chunk0);
         for (uint32_t j = threadIdx.x; j < chunks; j += TB) {
-            const unsigned long long e = p.binChunkTab[(size_t)tileId * p.binMaxChunks + chunk0 + j];
-            chunkTab[j] = (uint32_t)(e >> 32) == p.binStamp ? (uint32_t)e : CHORD_BIN_CHUNK_INVALID;
+            const RasterParams* q = kernel_args();                                // (long bins only: not worth registers across the kernel)
+            const unsigned long long e = scalar_load(&q->binChunkTab)[(size_t)tileId * scalar_load(&q->binMaxChunks) + chunk0 + j];
+            chunkTab[j] = (uint32_t)(e >> 32) == scalar_load(&q->binStamp) ? (uint32_t)e : CHORD_BIN_CHUNK_INVALID;
         }
         __syncthreads();
     }
@@ -2284,8 +2356,12 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     };
     // ---- pixel blocks of small clusters first: their own pass over the item's entries (nothing of the triangle
     //      pipeline below is live here; tiles without blocks -- word 2 of the tile's counter line -- skip it) ----------
-    if (p.blockCap != 0u && !noPixels && p.tileCount[(size_t)tileId * TC_STRIDE + TC_BLOCKS] != 0u) {
-        const uint32_t blockLimit = p.blockCap * CHORD_LIST_SHARDS;
+    // (the block pool and its size are read from the kernel arguments here: frames without blocks -- all but the densest -- do
+    // not hold them in registers)
+    const uint32_t blockCap = scalar_load(&kernel_args()->blockCap);
+    if (blockCap != 0u && !noPixels && scalar_load(&kernel_args()->tileCount)[(size_t)tileId * TC_STRIDE + TC_BLOCKS] != 0u) {
+        const unsigned long long* blockPool = scalar_load(&kernel_args()->blockPool);
+        const uint32_t blockLimit = blockCap * CHORD_LIST_SHARDS;
         uint32_t giNext = lo + threadIdx.x < n ? binWord(lo + threadIdx.x) : 0xFFFFFFFFu;
         for (uint32_t base = lo; base < n; base += TB) {
             const uint32_t gi = giNext;
@@ -2293,8 +2369,8 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
             // (never a block outside the pool: a slot drawn but not written after a reported overflow holds anything)
             const bool isBlock = gi != 0xFFFFFFFFu && gi >= CHORD_REC_BLOCK && (gi & CHORD_REC_INDEX_MASK) < blockLimit;
             uint2 hdr = make_uint2(0u, 0u);
-            if (isBlock) hdr = *reinterpret_cast<const uint2*>(p.blockPool + (size_t)(gi & CHORD_REC_INDEX_MASK) * 2u);
-            merge_blocks(tile, p.blockPool, __ballot(isBlock), gi, hdr.x, hdr.y, threadIdx.x & 63u);
+            if (isBlock) hdr = *reinterpret_cast<const uint2*>(blockPool + (size_t)(gi & CHORD_REC_INDEX_MASK) * 2u);
+            merge_blocks(tile, blockPool, __ballot(isBlock), gi, hdr.x, hdr.y, threadIdx.x & 63u);
         }
     }
     auto binEntry = [&](uint32_t k) -> uint32_t {              // record name of bin entry k, ~0u = none (or a pixel block)
@@ -2410,8 +2486,9 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     //      draws its ticket after every one of its atomics has returned, so no cache-wide release/acquire is
     //      needed (an agent-scope fence writes back the whole L2 of the XCD: measured 2x slower here). ----------
     if (mergeSlices) {
-        if (!merge_slices(tile, p.tileSlabs + (size_t)tileId * (TILE * TILE), &p.tileCount[(size_t)tileId * TC_STRIDE + TC_TICKET],
-                          slices, &sTicket, &p.counters->overflow)) continue;   // not the last slice: done
+        const RasterParams* q = kernel_args();                                    // (split tiles only)
+        if (!merge_slices(tile, scalar_load(&q->tileSlabs) + (size_t)tileId * (TILE * TILE), &scalar_load(&q->tileCount)[(size_t)tileId * TC_STRIDE + TC_TICKET],
+                          slices, &sTicket, &scalar_load(&q->counters)->overflow)) continue;   // not the last slice: done
         if (rmw) {
             for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
                 const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
@@ -2429,7 +2506,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     } else if (p.hzbFused && !ABL(p, DBG_NO_HZB)) {
         // single-GPU frame: the whole tile goes out (first pass: this is the clear; later passes loaded it), and its
         // HZB texels with it; the batch buffers are free now and hold the cross-wave part of the reduction
-        tile_out_and_hzb(p, tile, reinterpret_cast<float*>(&prm.w[0][0]), offs, tileId, ox, oy, tw, th);
+        tile_out_and_hzb(tile, reinterpret_cast<float*>(&prm.w[0][0]), offs, tileId, ox, oy, tw, th);
     } else if (p.clearTiles || p.hzbFused) {
         // first pass of the frame: every word is written (16-byte coalesced stores); this is the clear
         for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
