@@ -13,6 +13,10 @@
 //                         per-triangle culls (mesh_raster.hlsl:143-179) -> snapped setup -> a 32-byte (vertices
 //                         at most 64 px apart) or 48-byte triangle record + one bin entry per 64x64 screen tile
 //                         touched; every reservation of a meshlet in one memory round trip
+//   raster_setup_blocks_kernel  dense launches (a cluster per 16 pixels or more: sub-pixel geometry) run this one first: a
+//                         cluster that fits a 16x16-pixel window is resolved in LDS and leaves as a pixel block per
+//                         touched tile (one bin entry each) instead of a record per triangle; the clusters it cannot
+//                         take go to the record kernel through a leftover list.  <true>: bin slots of hot tiles drawn ahead
 //   raster_clip_and_bin_large_kernel  one launch, two roles: (a) homogeneous Sutherland-Hodgman clipper for
 //                         triangles touching the near / guard planes (rare; emits + bins its pieces itself),
 //                         (b) records touching more than 2x2 tiles: one wave per record, one lane per tile
@@ -919,9 +923,7 @@ struct BlockEmitParams {
 };
 __device__ __forceinline__ BlockEmitParams load_block_emit_params()
 {
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    const RasterParams* q = reinterpret_cast<const RasterParams*>(kp);            // (the kernel's one by-value argument)
+    const RasterParams* q = kernel_args();
     BlockEmitParams e;
     e.tileCount = scalar_load(&q->tileCount); e.tileBins = scalar_load(&q->tileBins); e.binCap = scalar_load(&q->binCap);
     e.binPool = scalar_load(&q->binPool); e.binPoolChunks = scalar_load(&q->binPoolChunks); e.binPoolCount = scalar_load(&q->binPoolCount);
@@ -1014,16 +1016,9 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
     unsigned long long* win = sWin[wave];
     const uint32_t listShard = (blockIdx.x * 4u + wave) % CHORD_LIST_SHARDS;
 
-#ifdef BLK_HOT_PARAMS
-    auto kq = [&]() -> const RasterParams* { return &p; };
-#else
-    // the scene pointers are re-read from the kernel-argument segment where they are used (see BlockEmitParams)
-    auto kq = [&]() -> const RasterParams* {
-        unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(kp));
-        return reinterpret_cast<const RasterParams*>(kp);
-    };
-#endif
+    // the scene pointers are re-read from the kernel-argument segment where they are used (kernel_args; keeping them in
+    // registers -- the "hot parameters" variant of profiles/r03_block_kernel_variants.txt -- cost 3 %)
+    auto kq = [&]() -> const RasterParams* { return kernel_args(); };
     auto header_at = [&](uint32_t i) -> SetupHeader {
         const uint32_t k = __builtin_amdgcn_readfirstlane(min(i, count - 1u));
         SetupHeader h;
@@ -1053,9 +1048,6 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
     if (c >= count) return;
     SetupHeader hdr = header_at(c);
     SetupHeader hdrN = header_at(c + stride);
-#ifdef BLK_MVP_AHEAD
-    Mat4 mvpN = mvp_of(hdr.objectId);
-#endif
     uint32_t t0 = 0, t1 = 0;
     float pax, pay, paz, pbx, pby, pbz;
     {
@@ -1083,13 +1075,9 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
         // ---- vertex phase (mesh_raster.hlsl:84-105), as raster_setup_body -------------------------------------------------
         bool notFast = false;
         if (!tooBig) {
-#ifdef BLK_MVP_AHEAD
-            const Mat4 mvp = mvpN;
-#else
             // (fetched here, not an iteration ahead: sixteen more scalar registers alive across the whole cluster cost more
             // lane spills than the other resident waves cover of this one scalar-cache round trip)
             const Mat4 mvp = mvp_of(hdr.objectId);
-#endif
             auto vertex = [&](uint32_t i, float x, float y, float z) {
                 const f4 h = mul_mv(mvp, x, y, z, 1.0f);
                 const float aw = fabsf(h.w);
@@ -1113,9 +1101,6 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
         WAVE_LDS_SYNC();
         SPHASE(1);
         // next cluster: vertex indices and triangle words
-#ifdef BLK_MVP_AHEAD
-        mvpN = mvp_of(hdrN.objectId);
-#endif
         const uint32_t* __restrict__ md = scalar_load(&kq()->meshletData);
         const uint32_t nia = md[hdrN.dataOffset + min(lane, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
         const uint32_t nib = md[hdrN.dataOffset + min(lane + 64u, max(hdrN.V, 1u) - 1u)] + hdrN.vertexBase;
@@ -1167,11 +1152,7 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                     // one round trip: pool space (lane 0) and, per touched tile, ONE 64-bit add on the tile's counter pair
                     // (low word: bin slot, high word: the tile's block count) ...
                     uint32_t gbase = 0, slot = 0;
-#ifdef BLK_HOT_PARAMS
-                    const RasterParams& e = p;
-#else
                     const BlockEmitParams e = load_block_emit_params();
-#endif
                     // (lane 0's part -- the tile of the window's first pixel -- may be served from this wave's reserve on a hot tile)
                     // (what lane 0 drew -- 0: from the reserve, else the number of slots -- waits in LDS, not in a register, for the
                     // resolve to finish)
@@ -2054,9 +2035,7 @@ struct TileOutParams {
 };
 __device__ __forceinline__ TileOutParams load_tile_out_params()
 {
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    const RasterParams* q = reinterpret_cast<const RasterParams*>(kp);            // (the kernel's one by-value argument)
+    const RasterParams* q = kernel_args();
     TileOutParams t;
     t.hzbDesc.srcWidth = scalar_load(&q->hzbDesc.srcWidth); t.hzbDesc.srcHeight = scalar_load(&q->hzbDesc.srcHeight);
     t.hzbDesc.width = scalar_load(&q->hzbDesc.width); t.hzbDesc.height = scalar_load(&q->hzbDesc.height);
