@@ -249,28 +249,32 @@ __global__ __launch_bounds__(256) void object_cull_kernel(const ChordObject* __r
 // FROM_MASK: the per-group meshlet masks were written by bvh_cull_kernel (hierarchical mode); this kernel only counts them.
 // SHARDED: the rank's share of the list is determined too (the unsharded instantiation is the round-2 kernel: the ownership
 // test costs the single-GPU frame nothing)
-template <bool FROM_MASK, bool SHARDED>
+// FUSED: the short-scene form described above; long scenes run object_cull_kernel first and this kernel without the object
+// pass (its matrices are what set the fused form's register count: 94 VGPRs = 5 waves/SIMD).
+template <bool FROM_MASK, bool SHARDED, bool FUSED>
 __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p, const DView dv, DView* __restrict__ dviewOut,
                                                                DObjFrame* __restrict__ objFrameOut, uint4* __restrict__ zeroBase, uint32_t zeroVec4,
                                                                uint32_t cullBlocks, FrameTail tail)
 {
-    if (tail.run && blockIdx.x == cullBlocks) { hzb_tail_block(tail.p, 1, 1, (uint32_t)CHORD_TILE_SHIFT); return; }
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (dviewOut && blockIdx.x == 0) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
-        for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += 256u) dst[i] = src[i];
-    }
-    for (uint32_t i = t; i < zeroVec4; i += cullBlocks * 256u) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (p.groupInstances && objFrameOut) {
-        const uint32_t first = blockIdx.x * 256u;
-        if (first < p.groupInstances) {
-            const uint32_t oFirst = p.groupOwner[first], oLast = p.groupOwner[min(first + 255u, p.groupInstances - 1u)];
-            // (256 group instances may span more than 256 objects when primitives without groups sit in between)
-            for (uint32_t k = threadIdx.x; k <= oLast - oFirst; k += 256u) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, oFirst + k);
+    if (FUSED) {
+        if (tail.run && blockIdx.x == cullBlocks) { hzb_tail_block(tail.p, 1, 1, (uint32_t)CHORD_TILE_SHIFT); return; }
+        if (dviewOut && blockIdx.x == 0) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
+            for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += 256u) dst[i] = src[i];
         }
+        for (uint32_t i = t; i < zeroVec4; i += cullBlocks * 256u) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (p.groupInstances && objFrameOut) {
+            const uint32_t first = blockIdx.x * 256u;
+            if (first < p.groupInstances) {
+                const uint32_t oFirst = p.groupOwner[first], oLast = p.groupOwner[min(first + 255u, p.groupInstances - 1u)];
+                // (256 group instances may span more than 256 objects when primitives without groups sit in between)
+                for (uint32_t k = threadIdx.x; k <= oLast - oFirst; k += 256u) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, oFirst + k);
+            }
+        }
+        __syncthreads();                                   // the object records of this block are written (and visible to it)
     }
-    __syncthreads();                                       // the object records of this block are written (and visible to it)
     uint32_t mask = 0, tris = 0, mine = 0;
     constexpr bool sharded = SHARDED;
     if (FROM_MASK) {
@@ -893,8 +897,8 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     std::memset(&none, 0, sizeof(none));
     const bool hier = c->cullMode == 1 && c->bvhComplete && c->dBvhNodes;
     const bool sh = p.shard.ranks > 1u;
-#define LAUNCH_COUNT(FM, grid, ...) do { if (sh) hipLaunchKernelGGL((group_cull_count_kernel<FM, true>), grid, dim3(256), 0, c->stream, __VA_ARGS__); \
-                                          else    hipLaunchKernelGGL((group_cull_count_kernel<FM, false>), grid, dim3(256), 0, c->stream, __VA_ARGS__); } while (0)
+#define LAUNCH_COUNT(FM, FUSED, grid, ...) do { if (sh) hipLaunchKernelGGL((group_cull_count_kernel<FM, true, FUSED>), grid, dim3(256), 0, c->stream, __VA_ARGS__); \
+                                                 else    hipLaunchKernelGGL((group_cull_count_kernel<FM, false, FUSED>), grid, dim3(256), 0, c->stream, __VA_ARGS__); } while (0)
     if (blocks > 512u || hier) {
         // (the mask array is a multiple of 16 bytes long: dalloc rounds nothing, so the tail is zeroed by the last partial vector
         // only when it exists -- the buffer is allocated with 16 bytes of slack, see upload_scene)
@@ -906,12 +910,12 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
             bp.g = p; bp.nodes = c->dBvhNodes; bp.objectCount = c->objectCount;
             const uint32_t bb = std::min((c->objectCount * 9u + 3u) / 4u, (uint32_t)c->numCUs * 8u);
             hipLaunchKernelGGL(bvh_cull_kernel, dim3(std::max(bb, 1u)), dim3(256), 0, c->stream, bp, c->hView);
-            LAUNCH_COUNT(true, dim3(blocks), p, c->hView, (DView*)nullptr, (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
+            LAUNCH_COUNT(true, false, dim3(blocks), p, c->hView, (DView*)nullptr, (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
         } else {
-            LAUNCH_COUNT(false, dim3(blocks), p, c->hView, (DView*)nullptr, (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
+            LAUNCH_COUNT(false, false, dim3(blocks), p, c->hView, (DView*)nullptr, (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
         }
     } else {
-        LAUNCH_COUNT(false, dim3(blocks + tail.run), p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4, blocks, tail);
+        LAUNCH_COUNT(false, true, dim3(blocks + tail.run), p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4, blocks, tail);
     }
 #undef LAUNCH_COUNT
     c->viewDirty = false;
