@@ -121,6 +121,14 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         CHORD_HIP(c, hipMemset(c->dTileSlabs, 0, tilesN * CHORD_TILE * CHORD_TILE * sizeof(unsigned long long)));
     }
     if ((rc = dalloc(c, &c->dTileRange, (size_t)2 * CHORD_MAX_TILES))) return rc;
+    if (!c->hBinHint) {     // what the tile order kernel tells the host about a pass (the longest bin): 64 bytes of mapped host memory
+        void* h = nullptr; void* dh = nullptr;
+        CHORD_HIP(c, hipHostMalloc(&h, 64, hipHostMallocMapped));
+        std::memset(h, 0, 64);
+        CHORD_HIP(c, hipHostGetDevicePointer(&dh, h, 0));
+        c->hBinHint = static_cast<volatile uint32_t*>(h); c->dBinHint = static_cast<uint32_t*>(dh);
+    }
+    c->hBinHint[0] = 0u; c->hBinHint[1] = 0u;
     {   // one {min, max} partial per block of the mip-0 kernel (64 x 4 texels per block)
         const uint32_t vw = (c->width + 1) / 2, vh = (c->height + 1) / 2;
         if ((rc = dalloc(c, &c->dRangePartials, (size_t)((vw + 63) / 64) * ((vh + 3) / 4) * 2))) return rc;
@@ -330,7 +338,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
-    if (c->hBinHint) { (void)hipHostFree(const_cast<uint32_t*>(c->hBinHint)); c->hBinHint = nullptr; }
+    if (c->hBinHint) { (void)hipHostFree(const_cast<uint32_t*>(c->hBinHint)); c->hBinHint = nullptr; c->dBinHint = nullptr; }
     dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dHzbExchangeMax); dfree(c->dRangeExchange); dfree(c->dVisAlt); dfree(c->dVisResolvedAlt); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
     dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);

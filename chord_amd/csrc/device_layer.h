@@ -305,6 +305,7 @@ struct ChordCtx {
     uint32_t* dRangePartials = nullptr;   // per mip-0 block {min, max} of valid depth
     uint32_t* dTileRange = nullptr;       // per 64x64 tile {min, max} of valid depth (fused HZB)
     volatile uint32_t* hBinHint = nullptr;    // pinned, device-visible: per raster pass the longest bin of the last frame the GPU finished (hot tiles: launch_raster)
+    uint32_t* dBinHint = nullptr;             // ... its device address
     bool fuseHzb = false;                 // inside render_frame: the tile kernel emits HZB mips 0..5
     bool fuseHzbTemp = false;             // ... also into the temporary chain (slot 0) for stage 1
     int fuseHzbSlot = 1;                  // history slot being produced this frame

@@ -2602,15 +2602,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.leftCount = nullptr; p.leftCmds = nullptr;
     p.binHint = nullptr;
     if (maybeDense) {
-        if (!c->hBinHint) {
-            void* h = nullptr;
-            LR_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped));
-            std::memset(h, 0, 64);
-            c->hBinHint = static_cast<volatile uint32_t*>(h);
-        }
-        void* dh = nullptr;
-        LR_HIP(hipHostGetDevicePointer(&dh, const_cast<uint32_t*>(c->hBinHint), 0));
-        p.binHint = static_cast<uint32_t*>(dh) + pass;
+        if (c->dBinHint) p.binHint = c->dBinHint + pass;          // (host-visible word per pass, allocated with the G-buffer)
         if (!c->dLeftCmds) LR_HIP(hipMalloc((void**)&c->dLeftCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity));
         p.leftCount = c->dCounts + 6 + pass; p.leftCmds = c->dLeftCmds;
         if (!c->inFrame || c->rasterCalls >= 2) LR_HIP(hipMemsetAsync(p.leftCount, 0, sizeof(uint32_t), c->stream));
