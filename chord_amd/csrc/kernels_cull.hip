@@ -506,14 +506,14 @@ struct HzbCullParams {
 // level l, stored at the level's full pitch like the chain in memory.
 #define HZB_TAIL_FIRST 6u
 #define HZB_TAIL_FLOATS 1408u              // a 4096^2 target (the largest): 32^2 + 16^2 + 8^2 + 4^2 + 2^2 + 1 = 1365
-__device__ __forceinline__ void hzb_tail_to_lds(const uint16_t* __restrict__ hzbMin, uint16_t* out, const ChordHZBDesc& d, float* sTail, uint32_t* sOff)
+__device__ __forceinline__ void hzb_tail_to_lds(const uint16_t* __restrict__ hzbMin, uint16_t* out, const ChordHZBDesc& d, float* sTail, uint32_t* sOff, uint32_t threads = 256u)
 {
     uint32_t off = 0, poff = 0;
     for (uint32_t l = HZB_TAIL_FIRST; l < d.mipCount; l++) {
         const uint32_t vw = valid_w(d, l), vh = valid_h(d, l), mw = max(1u, d.width >> l), mh = max(1u, d.height >> l);
         const uint32_t gw = valid_w(d, l - 1), gh = valid_h(d, l - 1), pmw = max(1u, d.width >> (l - 1));
         if (threadIdx.x == 0) sOff[l] = off;
-        for (uint32_t i = threadIdx.x; i < vw * vh; i += 256u) {
+        for (uint32_t i = threadIdx.x; i < vw * vh; i += threads) {
             const uint32_t x = i % vw, y = i / vw;
             float mn = 0.0f;
 #pragma unroll
@@ -683,11 +683,14 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
 // = 92 us on this GPU (~88/us per line, measured); the kernel took 76 us.  List order is free (cmd.z is carried).
 // K = commands per thread: 4 for long lists, 1 for short ones (a short list is latency-bound: one command per thread
 // keeps the dependent chain of loads short and still needs only count/256 reservations).
-template <int PHASE, uint32_t K, bool TAIL>
-__global__ __launch_bounds__(256) void hzb_cull_kernel(HzbCullParams p)
+// THREADS: 256, or 1024 for long lists with K = 1 -- the same one reservation per 1 024 commands, but sixteen waves with one
+// command each instead of four waves with four dependent chains each (config 4: 260 k commands were 254 workgroups, one per
+// CU, i.e. four waves per CU walking 4 x (command -> bounds + matrix -> texels)).
+template <int PHASE, uint32_t K, bool TAIL, uint32_t THREADS = 256u>
+__global__ __launch_bounds__(THREADS) void hzb_cull_kernel(HzbCullParams p)
 {
-    __shared__ uint32_t sWave[4], sBase[2];
-    __shared__ unsigned long long sTris[4];
+    __shared__ uint32_t sWave[THREADS / 64u], sBase[2];
+    __shared__ unsigned long long sTris[THREADS / 64u];
     __shared__ float sTail[TAIL ? HZB_TAIL_FLOATS : 1u];
     __shared__ uint32_t sTailOff[CHORD_HZB_MAX_MIPS];
     const uint32_t count = *p.inCount;
@@ -695,14 +698,14 @@ __global__ __launch_bounds__(256) void hzb_cull_kernel(HzbCullParams p)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // TAIL: the chain this launch culls against has its levels 0..5 in memory; every block with work reduces the rest
     // itself (block 0 also stores them)
-    if (TAIL && (blockIdx.x * (256u * K) < count || blockIdx.x == 0u) && (dv.flags & CHORD_FLAG_HZB_CULL))
-        hzb_tail_to_lds(p.hzbMin, blockIdx.x == 0u ? p.hzbTailOut : nullptr, p.desc, sTail, sTailOff);
-    for (uint32_t base = blockIdx.x * (256u * K); base < count; base += gridDim.x * (256u * K)) {
+    if (TAIL && (blockIdx.x * (THREADS * K) < count || blockIdx.x == 0u) && (dv.flags & CHORD_FLAG_HZB_CULL))
+        hzb_tail_to_lds(p.hzbMin, blockIdx.x == 0u ? p.hzbTailOut : nullptr, p.desc, sTail, sTailOff, THREADS);
+    for (uint32_t base = blockIdx.x * (THREADS * K); base < count; base += gridDim.x * (THREADS * K)) {
         ChordDrawCmd cmd[K];
         uint32_t visBits = 0, rejBits = 0, tris = 0;
 #pragma unroll
         for (uint32_t k = 0; k < K; k++) {
-            const uint32_t i = base + k * 256u + threadIdx.x;
+            const uint32_t i = base + k * THREADS + threadIdx.x;
             cmd[k] = ChordDrawCmd{0, 0, 0};
             if (i < count) {
                 cmd[k] = p.inCmds[i];
@@ -724,12 +727,14 @@ __global__ __launch_bounds__(256) void hzb_cull_kernel(HzbCullParams p)
         __syncthreads();
         uint32_t before = 0, all = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < 4u; w++) { const uint32_t c = sWave[w]; if (w < wave) before += c; all += c; }
+        for (uint32_t w = 0; w < THREADS / 64u; w++) { const uint32_t c = sWave[w]; if (w < wave) before += c; all += c; }
         if (threadIdx.x == 0) {
             const uint32_t nv = all & 0xFFFFu, nr = all >> 16;
             sBase[0] = nv ? atomicAdd(p.visCount, nv) : 0u;
             sBase[1] = (PHASE == 0 && nr) ? atomicAdd(p.rejCount, nr) : 0u;
-            const unsigned long long t = sTris[0] + sTris[1] + sTris[2] + sTris[3];
+            unsigned long long t = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < THREADS / 64u; w++) t += sTris[w];
             if (t) atomicAdd(PHASE == 0 ? &p.counters->trisHzbVisible0 : &p.counters->trisHzbVisible1, t);
         }
         __syncthreads();
@@ -997,18 +1002,20 @@ void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdLis
                      const CmdList* outRejected)
 {
     const HzbCullParams p = make_hzb_cull_params(c, hzb, in, outVisible, outRejected);
+    // long lists: 1 024-thread workgroups, one command per thread, one reservation per workgroup and list
     const bool longList = in.capacity > 65536u;
-    uint32_t blocks = (in.capacity + (longList ? 1023u : 255u)) / (longList ? 1024u : 256u);
-    const uint32_t maxBlocks = (uint32_t)c->numCUs * 8u;
+    const uint32_t threads = longList ? 1024u : 256u;
+    uint32_t blocks = (in.capacity + threads - 1u) / threads;
+    const uint32_t maxBlocks = (uint32_t)c->numCUs * (longList ? 2u : 8u);
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
-    if (phase == 0) { if (longList) hipLaunchKernelGGL((hzb_cull_kernel<0, 4u, false>), dim3(blocks), dim3(256), 0, c->stream, p);
+    if (phase == 0) { if (longList) hipLaunchKernelGGL((hzb_cull_kernel<0, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
                       else          hipLaunchKernelGGL((hzb_cull_kernel<0, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
     else if (c->hzbTailInCull) {
         // (inside chordvis_render_frame: the tile kernel wrote levels 0..5 of this chain; no hzb_tail_kernel ran)
-        if (longList) hipLaunchKernelGGL((hzb_cull_kernel<1, 4u, true>), dim3(blocks), dim3(256), 0, c->stream, p);
+        if (longList) hipLaunchKernelGGL((hzb_cull_kernel<1, 1u, true, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
         else          hipLaunchKernelGGL((hzb_cull_kernel<1, 1u, true>), dim3(blocks), dim3(256), 0, c->stream, p);
-    } else          { if (longList) hipLaunchKernelGGL((hzb_cull_kernel<1, 4u, false>), dim3(blocks), dim3(256), 0, c->stream, p);
+    } else          { if (longList) hipLaunchKernelGGL((hzb_cull_kernel<1, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
                       else          hipLaunchKernelGGL((hzb_cull_kernel<1, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
 }
 
