@@ -633,3 +633,218 @@ int chordvis_load_asset(const char* path, ChordBuiltAsset** out)
 }
 
 } // extern "C"
+
+// ---- the reference's own container for the geometry of an asset: GLTFBinary (asset_gltf.h:260-300) --------------------------
+// saveAsset / loadAsset (serialize.h:217-320): a cereal BinaryOutputArchive of {AssetCompressedMeta, std::string}, the string
+// being the cereal binary archive of the GLTFBinary, LZ4-block-compressed or not.  Both formats are public and small, and both
+// are restated here from their specifications (no cereal, no liblz4 in this library):
+//   cereal binary: arithmetic values little-endian as they stand; std::string / std::vector = uint64 count + elements; a class
+//     registered with CEREAL_CLASS_VERSION writes its uint32 version ONCE per archive, in front of the first instance's members;
+//     members in the order the serialize function names them (serialize.h:47-99: NOT the memory order for GLTFMeshlet and
+//     GLTFBVHNode); glm vectors component by component (pch.h:100-121); enum class as size_t (utils.h:115-118).
+//   LZ4 block: sequences of {token, [literal length bytes], literals, offset16, [match length bytes]}, min match 4, the last
+//     sequence literals only.
+// Pinned by tests/golden/gltf_binary_{raw,lz4}.bin, which the reference's vendored cereal and LZ4 wrote
+// (tests/golden/make_gltf_binary_fixture.{cpp,sh}).  Vertex attributes this path never reads (normals, tangents, second UV set,
+// colours, smooth normals, LOD-0 indices) are skipped on load and written empty.
+
+namespace {
+
+bool lz4_block_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap)
+{
+    size_t i = 0, o = 0;
+    while (i < n) {
+        const uint32_t token = src[i++];
+        size_t lit = token >> 4;
+        if (lit == 15) { uint8_t b; do { if (i >= n) return false; b = src[i++]; lit += b; } while (b == 255); }
+        if (i + lit > n || o + lit > cap) return false;
+        std::memcpy(dst + o, src + i, lit); i += lit; o += lit;
+        if (i >= n) break;                                         // the last sequence has no match
+        if (i + 2 > n) return false;
+        const size_t off = (size_t)src[i] | ((size_t)src[i + 1] << 8); i += 2;
+        if (off == 0 || off > o) return false;
+        size_t len = token & 15u;
+        if (len == 15) { uint8_t b; do { if (i >= n) return false; b = src[i++]; len += b; } while (b == 255); }
+        len += 4;
+        if (o + len > cap) return false;
+        for (size_t k = 0; k < len; k++) dst[o + k] = dst[o + k - off];   // (may overlap: byte by byte)
+        o += len;
+    }
+    return o == cap;
+}
+
+// greedy single-probe matcher (a 4-byte hash of the position, 64 KB window): any valid LZ4 block will do
+void lz4_block_encode(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
+{
+    out.clear();
+    std::vector<uint32_t> table(1u << 16, 0xFFFFFFFFu);
+    auto put_len = [&](size_t v) { while (v >= 255) { out.push_back(255); v -= 255; } out.push_back((uint8_t)v); };
+    auto emit = [&](size_t litStart, size_t litLen, size_t off, size_t matchLen) {      // matchLen 0: last sequence
+        const size_t ml = matchLen ? matchLen - 4 : 0;
+        out.push_back((uint8_t)(((litLen < 15 ? litLen : 15) << 4) | (matchLen ? (ml < 15 ? ml : 15) : 0)));
+        if (litLen >= 15) put_len(litLen - 15);
+        out.insert(out.end(), src + litStart, src + litStart + litLen);
+        if (matchLen) { out.push_back((uint8_t)(off & 255)); out.push_back((uint8_t)(off >> 8)); if (ml >= 15) put_len(ml - 15); }
+    };
+    size_t anchor = 0, i = 0;
+    // (format rules: the last 5 bytes are literals, the last match starts at least 12 bytes before the end)
+    const size_t matchLimit = n > 12 ? n - 12 : 0, endLimit = n > 5 ? n - 5 : 0;
+    while (i < matchLimit) {
+        uint32_t v; std::memcpy(&v, src + i, 4);
+        const uint32_t h = (v * 2654435761u) >> 16;
+        const uint32_t cand = table[h];
+        table[h] = (uint32_t)i;
+        uint32_t w = 0;
+        if (cand != 0xFFFFFFFFu && i - cand <= 65535) std::memcpy(&w, src + cand, 4);
+        if (cand == 0xFFFFFFFFu || i - cand > 65535 || w != v) { i++; continue; }
+        size_t len = 4;
+        while (i + len < endLimit && src[cand + len] == src[i + len]) len++;
+        emit(anchor, i - anchor, i - cand, len);
+        i += len; anchor = i;
+    }
+    emit(anchor, n - anchor, 0, 0);
+}
+
+struct ByteReader {
+    const uint8_t* p; size_t n, i = 0; bool ok = true;
+    template <class T> T get() { T v{}; if (i + sizeof(T) > n) { ok = false; return v; } std::memcpy(&v, p + i, sizeof(T)); i += sizeof(T); return v; }
+    void skip(uint64_t bytes) { if (bytes > n - i) ok = false; else i += (size_t)bytes; }
+    void floats(std::vector<float>& out, uint64_t count) { if (count > (n - i) / 4) { ok = false; return; } out.resize((size_t)count); if (count) std::memcpy(out.data(), p + i, (size_t)count * 4); i += (size_t)count * 4; }
+};
+struct ByteWriter {
+    std::vector<uint8_t> b;
+    template <class T> void put(const T& v) { const uint8_t* q = reinterpret_cast<const uint8_t*>(&v); b.insert(b.end(), q, q + sizeof(T)); }
+    void raw(const void* q, size_t bytes) { const uint8_t* c = static_cast<const uint8_t*>(q); b.insert(b.end(), c, c + bytes); }
+};
+
+} // namespace
+
+extern "C" {
+
+// The reference's GLTFBinary archive of a built asset (compressionMode None / Lz4).
+int chordvis_save_gltf_binary(const ChordBuiltAsset* a, const char* path, int lz4)
+{
+    if (!a || !path) return CHORDVIS_E_INVALID;
+    ByteWriter w;
+    w.put<uint32_t>(0u);                                                             // GLTFBinary: class version (kAssetVersion = 0)
+    const uint64_t nv = a->positions.size() / 3;
+    w.put<uint64_t>(nv); w.raw(a->positions.data(), a->positions.size() * 4);       // positions (vec3 by component = the floats as they stand)
+    w.put<uint64_t>(0);                                                              // normals
+    w.put<uint64_t>(a->texcoords.size() / 2); w.raw(a->texcoords.data(), a->texcoords.size() * 4);   // texcoords0
+    w.put<uint64_t>(0);                                                              // tangents
+    w.put<uint64_t>(0); w.put<uint64_t>(0); w.put<uint64_t>(0);                     // smoothNormals, texcoords1, colors0
+    w.put<uint64_t>(a->meshlets.size());
+    for (size_t i = 0; i < a->meshlets.size(); i++) {                                // serialize.h:64-75 member order
+        const ChordMeshlet& m = a->meshlets[i];
+        if (i == 0) w.put<uint32_t>(0u);
+        w.raw(m.posMin, 12); w.put(m.dataOffset); w.raw(m.posMax, 12); w.put(m.vertexTriangleCount);
+        w.put(m.coneCutOff); w.raw(m.coneAxis, 12); w.raw(m.coneApex, 12); w.put(m.lod);
+    }
+    w.put<uint64_t>(a->meshletData.size()); w.raw(a->meshletData.data(), a->meshletData.size() * 4);
+    w.put<uint64_t>(a->bvh.size());
+    for (size_t i = 0; i < a->bvh.size(); i++) {                                     // serialize.h:47-54
+        const ChordBVHNode& n = a->bvh[i];
+        if (i == 0) w.put<uint32_t>(0u);
+        w.raw(n.sphere, 16); w.raw(n.children, 32); w.put(n.leafMeshletGroupOffset); w.put(n.leafMeshletGroupCount); w.put(n.bvhNodeCount);
+    }
+    w.put<uint64_t>(a->groups.size());
+    for (size_t i = 0; i < a->groups.size(); i++) {                                  // serialize.h:55-63 (= memory order)
+        if (i == 0) w.put<uint32_t>(0u);
+        w.raw(&a->groups[i], sizeof(ChordMeshletGroup));
+    }
+    w.put<uint64_t>(a->groupIndices.size()); w.raw(a->groupIndices.data(), a->groupIndices.size() * 4);
+    w.put<uint64_t>(0);                                                              // lod0Indices
+    if (w.b.size() > 0x7FFFFFFFull) return CHORDVIS_E_INVALID;                       // (AssetCompressedMeta holds int32 sizes)
+    std::vector<uint8_t> packed;
+    if (lz4) lz4_block_encode(w.b.data(), w.b.size(), packed);
+    const std::vector<uint8_t>& body = lz4 ? packed : w.b;
+    ByteWriter f;
+    f.put<int32_t>((int32_t)w.b.size()); f.put<int32_t>((int32_t)body.size()); f.put<uint64_t>(lz4 ? 1u : 0u);   // meta (serialize.h:209-213)
+    f.put<uint64_t>(body.size()); f.raw(body.data(), body.size());                                                // std::string
+    FILE* fp = std::fopen(path, "wb");
+    if (!fp) return CHORDVIS_E_INVALID;
+    bool ok = std::fwrite(f.b.data(), 1, f.b.size(), fp) == f.b.size();
+    ok = std::fclose(fp) == 0 && ok;
+    return ok ? CHORDVIS_OK : CHORDVIS_E_INVALID;
+}
+
+// Reads a GLTFBinary archive into a built asset holding ONE primitive that spans the whole file (the reference keeps the
+// per-primitive offsets in its GLTFAsset, a different archive: a host that has them fills its own ChordPrimitive records and
+// uses only the arrays of chordvis_built_asset_desc).
+int chordvis_load_gltf_binary(const char* path, ChordBuiltAsset** out)
+{
+    if (!path || !out) return CHORDVIS_E_INVALID;
+    *out = nullptr;
+    FILE* fp = std::fopen(path, "rb");
+    if (!fp) return CHORDVIS_E_INVALID;
+    std::vector<uint8_t> file;
+    { uint8_t buf[65536]; size_t k; while ((k = std::fread(buf, 1, sizeof(buf), fp)) > 0) file.insert(file.end(), buf, buf + k); }
+    std::fclose(fp);
+    ByteReader f{file.data(), file.size()};
+    const int32_t rawSize = f.get<int32_t>(), compSize = f.get<int32_t>();
+    const uint64_t mode = f.get<uint64_t>(), strLen = f.get<uint64_t>();
+    if (!f.ok || rawSize < 0 || compSize < 0 || strLen != (uint64_t)compSize || strLen > file.size() - f.i || mode > 1) return CHORDVIS_E_INVALID;
+    std::vector<uint8_t> raw;
+    if (mode == 1) { raw.resize((size_t)rawSize); if (!lz4_block_decode(file.data() + f.i, (size_t)compSize, raw.data(), raw.size())) return CHORDVIS_E_INVALID; }
+    else { if (compSize != rawSize) return CHORDVIS_E_INVALID; raw.assign(file.begin() + (long)f.i, file.begin() + (long)(f.i + strLen)); }
+    ByteReader r{raw.data(), raw.size()};
+    ChordBuiltAsset* a = new ChordBuiltAsset();
+    (void)r.get<uint32_t>();                                                         // GLTFBinary class version
+    r.floats(a->positions, r.get<uint64_t>() * 3);
+    r.skip(r.get<uint64_t>() * 12);                                                  // normals
+    r.floats(a->texcoords, r.get<uint64_t>() * 2);
+    r.skip(r.get<uint64_t>() * 16);                                                  // tangents
+    r.skip(r.get<uint64_t>() * 12); r.skip(r.get<uint64_t>() * 8); r.skip(r.get<uint64_t>() * 16);   // smoothNormals, texcoords1, colors0
+    uint64_t n = r.get<uint64_t>();
+    if (n > (raw.size() - r.i) / 64) r.ok = false;
+    for (uint64_t i = 0; r.ok && i < n; i++) {
+        if (i == 0) (void)r.get<uint32_t>();
+        ChordMeshlet m;
+        for (int k = 0; k < 3; k++) m.posMin[k] = r.get<float>();
+        m.dataOffset = r.get<uint32_t>();
+        for (int k = 0; k < 3; k++) m.posMax[k] = r.get<float>();
+        m.vertexTriangleCount = r.get<uint32_t>(); m.coneCutOff = r.get<float>();
+        for (int k = 0; k < 3; k++) m.coneAxis[k] = r.get<float>();
+        for (int k = 0; k < 3; k++) m.coneApex[k] = r.get<float>();
+        m.lod = r.get<uint32_t>();
+        a->meshlets.push_back(m);
+    }
+    n = r.get<uint64_t>();
+    if (n > (raw.size() - r.i) / 4) r.ok = false; else { a->meshletData.resize((size_t)n); for (uint64_t i = 0; i < n; i++) a->meshletData[(size_t)i] = r.get<uint32_t>(); }
+    n = r.get<uint64_t>();
+    if (n > (raw.size() - r.i) / 60) r.ok = false;
+    for (uint64_t i = 0; r.ok && i < n; i++) {
+        if (i == 0) (void)r.get<uint32_t>();
+        ChordBVHNode b;
+        for (int k = 0; k < 4; k++) b.sphere[k] = r.get<float>();
+        for (int k = 0; k < 8; k++) b.children[k] = r.get<uint32_t>();
+        b.leafMeshletGroupOffset = r.get<uint32_t>(); b.leafMeshletGroupCount = r.get<uint32_t>(); b.bvhNodeCount = r.get<uint32_t>();
+        a->bvh.push_back(b);
+    }
+    n = r.get<uint64_t>();
+    if (n > (raw.size() - r.i) / 40) r.ok = false;
+    for (uint64_t i = 0; r.ok && i < n; i++) {
+        if (i == 0) (void)r.get<uint32_t>();
+        a->groups.push_back(r.get<ChordMeshletGroup>());
+    }
+    n = r.get<uint64_t>();
+    if (n > (raw.size() - r.i) / 4) r.ok = false; else { a->groupIndices.resize((size_t)n); for (uint64_t i = 0; i < n; i++) a->groupIndices[(size_t)i] = r.get<uint32_t>(); }
+    r.skip(r.get<uint64_t>() * 4);                                                   // lod0Indices
+    if (!r.ok || r.i != raw.size() || a->positions.empty()) { delete a; return CHORDVIS_E_INVALID; }
+    // one primitive over everything
+    std::memset(&a->prim, 0, sizeof(a->prim));
+    const size_t nv = a->positions.size() / 3;
+    float mn[3] = {a->positions[0], a->positions[1], a->positions[2]}, mx[3] = {mn[0], mn[1], mn[2]};
+    double sum[3] = {0, 0, 0};
+    for (size_t v = 0; v < nv; v++) for (int k = 0; k < 3; k++) { const float x = a->positions[3 * v + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); sum[k] += x; }
+    for (int k = 0; k < 3; k++) { a->prim.posMin[k] = mn[k]; a->prim.posMax[k] = mx[k]; a->prim.posAverage[k] = (float)(sum[k] / (double)nv); }
+    a->prim.vertexCount = (uint32_t)nv;
+    a->prim.meshletGroupCount = (uint32_t)a->groups.size();
+    uint32_t lods = 0;
+    for (const ChordMeshlet& m : a->meshlets) lods = std::max(lods, m.lod + 1u);
+    a->lodCount = lods;
+    *out = a;
+    return CHORDVIS_OK;
+}
+
+} // extern "C"

@@ -115,6 +115,8 @@ def _load():
         "chordvis_free_built_asset": (None, [vp]),
         "chordvis_save_asset": (i32, [vp, C.c_char_p]),
         "chordvis_load_asset": (i32, [C.c_char_p, P(vp)]),
+        "chordvis_save_gltf_binary": (i32, [vp, C.c_char_p, i32]),
+        "chordvis_load_gltf_binary": (i32, [C.c_char_p, P(vp)]),
         "chordvis_create": (i32, [i32, vp, P(vp)]),
         "chordvis_destroy": (i32, [vp]),
         "chordvis_last_error": (C.c_char_p, [vp]),

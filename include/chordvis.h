@@ -178,6 +178,12 @@ void chordvis_free_built_asset(ChordBuiltAsset* asset);
 /* a flat container for a built asset (the reference: cereal + LZ4 archives, serialize.h:217-320) */
 int chordvis_save_asset(const ChordBuiltAsset* asset, const char* path);
 int chordvis_load_asset(const char* path, ChordBuiltAsset** outAsset);
+/* The reference's own container for an asset's geometry: the GLTFBinary archive (asset_gltf.h:260-300) as saveAsset / loadAsset
+ * write and read it (serialize.h:217-320: cereal binary archive, LZ4 block compression when lz4 != 0).  Load yields ONE
+ * primitive spanning the file (the per-primitive offsets live in the reference's GLTFAsset, another archive); attributes
+ * this path does not read (normals, tangents, ...) are skipped on load and written empty. */
+int chordvis_save_gltf_binary(const ChordBuiltAsset* asset, const char* path, int lz4);
+int chordvis_load_gltf_binary(const char* path, ChordBuiltAsset** outAsset);
 
 /* ------------------------------------------------------------------ context (graphics::Context, graphics.h:88-345) */
 

@@ -1,6 +1,7 @@
 """chordvis_nanite_build: the invariants the runtime relies on (nanite_builder.cpp's own checks and the shape of
 its output), the container, and -- gpu -- frames of built meshes against the oracle in both cull modes."""
 import ctypes as C
+import json
 import os
 
 import numpy as np
@@ -250,3 +251,126 @@ def test_quarter_million_triangle_built_mesh_renders_like_the_oracle(gpu):
             prev = want["hzb_min"]
         assert r.stats()["overflow"] == 0
         r.close()
+
+
+# ---- the reference's own asset container (GLTFBinary: cereal binary archive + LZ4, serialize.h:217-320) -------------------
+GLTF_FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load_gltf_binary(path):
+    h = C.c_void_p()
+    rc = L.lib.chordvis_load_gltf_binary(path.encode(), C.byref(h))
+    assert rc == L.OK, rc
+    try:
+        return L.BuiltAsset(h)
+    finally:
+        L.lib.chordvis_free_built_asset(h)
+
+
+@pytest.mark.parametrize("name", ["gltf_binary_raw.bin", "gltf_binary_lz4.bin"])
+def test_gltf_binary_written_by_the_references_cereal_and_lz4_is_read(name):
+    """tests/golden/gltf_binary_{raw,lz4}.bin were written by the reference's vendored cereal + LZ4 through structs that
+    mirror GLTFBinary / GLTFMeshlet / GLTFMeshletGroup / GLTFBVHNode member by member (make_gltf_binary_fixture.cpp); the
+    library's reader -- its own restatement of both formats -- must find every value the generator put in."""
+    want = json.load(open(os.path.join(GLTF_FIX, "gltf_binary.json")))
+    a = _load_gltf_binary(os.path.join(GLTF_FIX, name))
+    assert np.array_equal(a.positions.reshape(-1), np.array(want["positions"], np.float32))
+    assert np.array_equal(a.texcoord0.reshape(-1), np.array(want["texcoords0"], np.float32))
+    assert np.array_equal(a.meshlet_data, np.array(want["meshletDatas"], np.uint32))
+    assert np.array_equal(a.group_indices, np.array(want["meshletGroupIndices"], np.uint32))
+    assert len(a.meshlets) == len(want["meshlets"]) and len(a.groups) == len(want["meshletGroups"]) and len(a.bvh_nodes) == len(want["bvhNodes"])
+    for m, w in zip(a.meshlets, want["meshlets"]):          # JSON order = MEMORY order of GPUGLTFMeshlet (the archive permutes it)
+        got = list(m["posMin"]) + [m["dataOffset"]] + list(m["posMax"]) + [m["vertexTriangleCount"]] + list(m["coneAxis"]) + [m["coneCutOff"]] + list(m["coneApex"]) + [m["lod"]]
+        assert np.array_equal(np.array(got, np.float64), np.array([np.float32(x) if isinstance(x, float) else x for x in w], np.float64))
+    for g, w in zip(a.groups, want["meshletGroups"]):
+        got = list(g["clusterPosCenter"]) + [g["parentError"]] + list(g["parentPosCenter"]) + [g["error"], g["meshletOffset"], g["meshletCount"]]
+        assert np.array_equal(np.array(got, np.float64), np.array([np.float32(x) if isinstance(x, float) else x for x in w], np.float64))
+    for b, w in zip(a.bvh_nodes, want["bvhNodes"]):
+        got = list(b["sphere"]) + list(b["children"]) + [b["bvhNodeCount"], b["leafMeshletGroupOffset"], b["leafMeshletGroupCount"]]
+        assert np.array_equal(np.array(got, np.float64), np.array([np.float32(x) if isinstance(x, float) else x for x in w], np.float64))
+    assert a.primitive["vertexCount"][0] == want["vertexCount"] and a.primitive["meshletGroupCount"][0] == len(want["meshletGroups"])
+
+
+def test_gltf_binary_round_trip_of_a_built_asset(tmp_path):
+    """A built asset through chordvis_save_gltf_binary (uncompressed and with the library's own LZ4 encoder) and back: the
+    arrays the path reads are identical; truncated and corrupted files are refused."""
+    pos, idx, _ = scenes.bumpy_sphere_mesh(48, 3)
+    h = L.nanite_build(pos, idx, keep_handle=True)
+    ref = L.BuiltAsset(h)
+    sizes = {}
+    for lz4 in (0, 1):
+        path = str(tmp_path / ("a%d.assetbin" % lz4))
+        assert L.lib.chordvis_save_gltf_binary(h, path.encode(), lz4) == L.OK
+        sizes[lz4] = os.path.getsize(path)
+        a = _load_gltf_binary(path)
+        for f in ("meshlets", "groups", "group_indices", "meshlet_data", "positions", "bvh_nodes"):
+            assert np.array_equal(getattr(a, f), getattr(ref, f)), f
+        assert a.lod_count == ref.lod_count and a.primitive["vertexCount"][0] == ref.primitive["vertexCount"][0]
+        assert np.array_equal(a.primitive["posMin"], ref.primitive["posMin"]) and np.array_equal(a.primitive["posMax"], ref.primitive["posMax"])
+    assert sizes[1] < 0.9 * sizes[0]                               # (indices and repeated words compress)
+    L.lib.chordvis_free_built_asset(h)
+    data = open(str(tmp_path / "a1.assetbin"), "rb").read()
+    for bad in (data[:len(data) // 2], data[:40] + bytes([data[40] ^ 0xFF]) + data[41:], b"", data + b"x"):
+        p = str(tmp_path / "bad.assetbin")
+        open(p, "wb").write(bad)
+        h2 = C.c_void_p()
+        rc = L.lib.chordvis_load_gltf_binary(p.encode(), C.byref(h2))
+        if rc == L.OK:                                             # (a flipped literal byte still decodes: then the values differ, nothing crashes)
+            L.lib.chordvis_free_built_asset(h2)
+        else:
+            assert rc == L.E_INVALID
+
+
+def test_gltf_binary_uncompressed_file_is_byte_identical_to_cereals(tmp_path):
+    """Loading the reference-written fixture and saving it again uncompressed reproduces cereal's bytes except for the
+    attributes this path drops (normals / tangents / LOD-0 indices are written empty): checked by re-reading both."""
+    a_path = os.path.join(GLTF_FIX, "gltf_binary_raw.bin")
+    h = C.c_void_p()
+    assert L.lib.chordvis_load_gltf_binary(a_path.encode(), C.byref(h)) == L.OK
+    out = str(tmp_path / "again.bin")
+    assert L.lib.chordvis_save_gltf_binary(h, out.encode(), 0) == L.OK
+    L.lib.chordvis_free_built_asset(h)
+    a, b = _load_gltf_binary(a_path), _load_gltf_binary(out)
+    for f in ("meshlets", "groups", "group_indices", "meshlet_data", "positions", "texcoord0", "bvh_nodes"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    # the sections both files hold are the same bytes: header of the archive + positions
+    ra, rb = open(a_path, "rb").read(), open(out, "rb").read()
+    n = 24 + 4 + 8 + 150 * 12
+    assert ra[16:24] != rb[16:24] and ra[24:n] == rb[24:n]         # (string length differs, version tag + positions identical)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/external/include/cereal"), reason="the reference (vendored cereal + LZ4) exists only in the build container")
+def test_gltf_binary_written_by_the_library_is_read_by_the_references_cereal_and_lz4(tmp_path):
+    """The other direction, where the reference's sources are at hand: files the LIBRARY writes (its own cereal layout, its own
+    LZ4 encoder) through loadAsset's sequence built from the vendored cereal + LZ4 (make_gltf_binary_fixture --check)."""
+    import subprocess
+    exe = str(tmp_path / "check")
+    ref = "/root/reference/external"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", ref + "/include", "-I", ref + "/lz4/lib", os.path.join(GLTF_FIX, "make_gltf_binary_fixture.cpp"),
+                    ref + "/lz4/lib/lz4.c", "-o", exe], check=True)
+    pos, idx, uv = scenes.bumpy_sphere_mesh(48, 3)
+    h = L.nanite_build(pos, idx, uv, keep_handle=True)
+    a = L.BuiltAsset(h)
+    hh = 1469598103934665603
+
+    def mix(v):
+        nonlocal hh
+        hh = ((hh ^ int(v)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    for m in a.meshlets:
+        mix(m["dataOffset"]); mix(m["vertexTriangleCount"]); mix(m["lod"]); mix(np.float32(m["coneCutOff"]).view(np.uint32)); mix(np.float32(m["coneAxis"][0]).view(np.uint32))
+    for v in a.meshlet_data: mix(v)
+    for b in a.bvh_nodes:
+        mix(b["bvhNodeCount"]); mix(b["leafMeshletGroupOffset"]); mix(b["leafMeshletGroupCount"]); mix(b["children"][7])
+    for g in a.groups:
+        mix(g["meshletOffset"]); mix(g["meshletCount"]); mix(np.float32(g["parentError"]).view(np.uint32))
+    for v in a.group_indices: mix(v)
+    for lz4 in (0, 1):
+        path = str(tmp_path / ("w%d.bin" % lz4))
+        assert L.lib.chordvis_save_gltf_binary(h, path.encode(), lz4) == L.OK
+        out = subprocess.run([exe, "--check", path], capture_output=True, text=True, check=True).stdout.split()
+        assert out[0] == "OK" and int(out[2]) == lz4, out
+        kv = dict(zip(out[1::2], out[2::2]))
+        assert int(kv["positions"]) == len(a.positions) and int(kv["texcoords0"]) == len(a.texcoord0) and int(kv["meshlets"]) == len(a.meshlets)
+        assert int(kv["meshletDatas"]) == len(a.meshlet_data) and int(kv["bvhNodes"]) == len(a.bvh_nodes) and int(kv["groups"]) == len(a.groups)
+        assert int(kv["hash"]) == hh, (kv["hash"], hh)
+    L.lib.chordvis_free_built_asset(h)
