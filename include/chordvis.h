@@ -119,7 +119,8 @@ typedef struct ChordStats {
     uint64_t triangleRecordsCompact; /* of triangleRecords, those in the 32-byte form (the rest take 48 bytes) */
     uint64_t pixelBlockBytes;      /* bytes of pixel blocks emitted for small clusters in place of records (this frame); their
                                       triangles are not in triangleRecords, a block counts as one bin entry per tile */
-    uint64_t pixelBlocks;          /* number of those blocks (= their bin entries) */
+    uint64_t pixelBlocks;          /* number of those blocks (= their bin entries; on frames with hot tiles, plus the bin slots the block
+                                      kernel drew ahead and left empty -- a few per wave and hot tile) */
     float    msExchangeHzb;        /* sharded frames: stream time between phase a and phase b = the all-gather of the HZB mip-0 exchange buffer */
     float    msExchangeVis;        /* ... between phase b and phase c = the all-gather of the visibility words (incl. waiting for the slowest rank) */
 } ChordStats;

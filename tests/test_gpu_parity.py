@@ -363,6 +363,16 @@ def test_config5_hotspot_quarter_size_4k_matches_oracle(gpu):
     assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["triangles_submitted"]
     assert st["pixelBlocks"] > 1 << 20                     # the block kernel ran
     H.assert_vis_equal(got, want["vis"], cam.width, cam.height, "config5 hotspot quarter size")
+    # a second frame: the host has now seen the first frame's longest bin (> 65 536 entries) and launches the hot-tile variant of
+    # the block kernel by itself -- bin slots drawn ahead, reserves filled with "no entry" words -- for the same image
+    blocks0 = st["pixelBlocks"]
+    r.render_frame()
+    got2 = r.read_visibility()
+    st2 = r.stats()
+    assert st2["overflow"] == 0
+    assert st2["pixelBlocks"] > blocks0, "the hot-tile variant did not run (no slots drawn ahead): %d vs %d" % (st2["pixelBlocks"], blocks0)
+    assert st2["pixelBlocks"] < blocks0 + (blocks0 >> 2)   # (the unused remainders: at most 7 slots per wave and hot tile; 10 % here, 5 % at full size)
+    H.assert_vis_equal(got2, want["vis"], cam.width, cam.height, "config5 hotspot quarter size, hot-tile variant")
     r.close()
 
 
