@@ -613,6 +613,10 @@ __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DV
     return visible;
 }
 
+// (Round 3: writing the list from the count kernel of short scenes -- every workgroup publishing its counts under a launch
+// serial and adding up its predecessors', 5 us of launch for one memory round trip -- was written and not kept: that kernel
+// also zeroes the frame's counters, among them the list count and the triangle total it would then write itself, and ordering
+// those stores across workgroups needs an agent-scope fence per workgroup that costs what the launch does.)
 // PREFIXED: blockCounts already holds exclusive offsets (group_cull_prefix_kernel ran); otherwise every block sums the
 // preceding blocks' counts itself (a few hundred blocks: cheaper than one more launch).
 // (Tried in round 2: the phase-0 HZB test of every command inside this kernel for short scenes, to save the launch of
