@@ -1083,16 +1083,57 @@ void orc_frame(const ChordSceneDesc* scene, const ChordCameraView* view, const C
  * are concatenated in range order -- checked by tests/test_oracle_kat.py.  Not part of any product path.
  * ================================================================================================ */
 typedef void (*ParFn)(void* ctx, uint32_t t, uint32_t T);
-typedef struct { ParFn fn; void* ctx; uint32_t t, T; } ParJob;
-static void* par_trampoline(void* p) { ParJob* j = (ParJob*)p; j->fn(j->ctx, j->t, j->T); return NULL; }
+
+/* A frame is ~20 parallel sections; creating and joining `threads` threads for each costs more than most of them do (64 threads:
+ * 1 300 pthread_create per frame).  Workers are created once, sleep on a condition variable between sections and are told apart
+ * by a generation counter; worker k takes part in a section iff k < T.  One replay at a time (the callers hold g_privLock or are
+ * single-threaded tests); the workers are never joined -- the process ends with them. */
+static pthread_mutex_t g_poolLock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_poolGo = PTHREAD_COND_INITIALIZER, g_poolDone = PTHREAD_COND_INITIALIZER;
+static pthread_mutex_t g_poolRun = PTHREAD_MUTEX_INITIALIZER;          /* serialises par_run callers */
+static uint32_t g_poolThreads = 0, g_poolGen = 0, g_poolT = 0, g_poolLeft = 0;
+static ParFn g_poolFn = NULL;
+static void* g_poolCtx = NULL;
+
+static void* pool_worker(void* arg)
+{
+    const uint32_t k = (uint32_t)(uintptr_t)arg;
+    uint32_t seen = 0;
+    pthread_mutex_lock(&g_poolLock);
+    for (;;) {
+        while (g_poolGen == seen) pthread_cond_wait(&g_poolGo, &g_poolLock);
+        seen = g_poolGen;
+        if (k >= g_poolT) continue;
+        ParFn fn = g_poolFn; void* ctx = g_poolCtx; const uint32_t T = g_poolT;
+        pthread_mutex_unlock(&g_poolLock);
+        fn(ctx, k, T);
+        pthread_mutex_lock(&g_poolLock);
+        if (--g_poolLeft == 0) pthread_cond_signal(&g_poolDone);
+    }
+    return NULL;
+}
+
 static void par_run(uint32_t T, ParFn fn, void* ctx)
 {
-    pthread_t th[256]; ParJob jobs[256];
     if (T < 1) T = 1;
     if (T > 256) T = 256;
-    for (uint32_t t = 1; t < T; t++) { jobs[t].fn = fn; jobs[t].ctx = ctx; jobs[t].t = t; jobs[t].T = T; pthread_create(&th[t], NULL, par_trampoline, &jobs[t]); }
+    if (T == 1) { fn(ctx, 0, 1); return; }
+    pthread_mutex_lock(&g_poolRun);
+    pthread_mutex_lock(&g_poolLock);
+    while (g_poolThreads + 1 < T) {                                /* workers 1 .. T-1 (the caller is thread 0) */
+        pthread_t th;
+        g_poolThreads++;
+        pthread_create(&th, NULL, pool_worker, (void*)(uintptr_t)g_poolThreads);
+        pthread_detach(th);
+    }
+    g_poolFn = fn; g_poolCtx = ctx; g_poolT = T; g_poolLeft = T - 1; g_poolGen++;
+    pthread_cond_broadcast(&g_poolGo);
+    pthread_mutex_unlock(&g_poolLock);
     fn(ctx, 0, T);
-    for (uint32_t t = 1; t < T; t++) pthread_join(th[t], NULL);
+    pthread_mutex_lock(&g_poolLock);
+    while (g_poolLeft != 0) pthread_cond_wait(&g_poolDone, &g_poolLock);
+    pthread_mutex_unlock(&g_poolLock);
+    pthread_mutex_unlock(&g_poolRun);
 }
 static inline uint32_t part_lo(uint32_t n, uint32_t t, uint32_t T) { return (uint32_t)((uint64_t)n * t / T); }
 
