@@ -439,11 +439,11 @@ def main():
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         threads = min(threads, 64)
         if threads > 1:
-            orc.frame_mt(sc_a, view_a, iv_a, flags, prev["hzb_min"], threads)      # (untimed: first touch of the private images)
+            orc.frame_mt(sc_a, view_a, iv_a, flags, prev["hzb_min"], threads, reuse=True)      # (untimed: first touch of the images)
             m0 = time.perf_counter()
             tri_mt = 0
             for _ in range(args.cpu_baseline_frames):
-                out_mt = orc.frame_mt(sc_a, view_a, iv_a, flags, prev["hzb_min"], threads)
+                out_mt = orc.frame_mt(sc_a, view_a, iv_a, flags, prev["hzb_min"], threads, reuse=True)
                 tri_mt += out_mt["triangles_submitted"]
             m1 = time.perf_counter()
             assert np.array_equal(out_mt["vis"], out["vis"]), "multi-threaded CPU replay differs from the scalar one"

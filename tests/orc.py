@@ -142,19 +142,30 @@ def raster_snapped_triangle(X, Y, d, two_sided, payload, w, h, vis=None, shard=N
     return vis, st
 
 
-def frame_mt(scene, view, iv, flags, prev_hzb_min, threads):
+_mt_buffers = {}
+
+
+def frame_mt(scene, view, iv, flags, prev_hzb_min, threads, reuse=False):
     """orc_frame_mt: orc_frame's sequence (mesh_raster.cpp:269-329, renderer.cpp:319-345) on `threads` host threads -- culls over
     ranges, clusters into per-thread tile-private images merged by max, HZB levels over row ranges (SURVEY 8d's all-cores CPU
-    baseline).  Same dictionary as frame()."""
+    baseline).  Same dictionary as frame().  reuse: the output arrays of the previous call with the same sizes are written again
+    (a timing loop then measures the replay, not 70 MB of first-touch page faults per frame); the caller must be done with them."""
     w, h = int(iv["renderDimension"][0][0]), int(iv["renderDimension"][0][1])
     d = hzb_desc(w, h)
-    vis = np.zeros(w * h, dtype=np.uint64)
     cap = max(1, scene.lod0_meshlet_instances)
-    cmds = np.zeros(cap, dtype=R.DRAW_CMD)
-    counts = np.zeros(4, dtype=np.uint32)
-    hmin = np.zeros(d.totalTexels, dtype=np.uint16)
-    hmax = np.zeros(d.totalTexels, dtype=np.uint16)
-    rng = np.zeros(2, dtype=np.uint32)
+    key = (w, h, cap)
+    if reuse and key in _mt_buffers:
+        vis, cmds, counts, hmin, hmax, rng = _mt_buffers[key]
+    else:
+        vis = np.zeros(w * h, dtype=np.uint64)
+        cmds = np.zeros(cap, dtype=R.DRAW_CMD)
+        counts = np.zeros(4, dtype=np.uint32)
+        hmin = np.zeros(d.totalTexels, dtype=np.uint16)
+        hmax = np.zeros(d.totalTexels, dtype=np.uint16)
+        rng = np.zeros(2, dtype=np.uint32)
+        if reuse:
+            _mt_buffers.clear()
+            _mt_buffers[key] = (vis, cmds, counts, hmin, hmax, rng)
     st = RasterStats()
     lib.orc_frame_mt(C.byref(scene.desc), view.ctypes.data, iv.ctypes.data, flags,
                      prev_hzb_min.ctypes.data if prev_hzb_min is not None else None, int(threads),
