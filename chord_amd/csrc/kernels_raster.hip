@@ -1662,7 +1662,7 @@ __device__ __forceinline__ void lds_write(unsigned long long* tile, int32_t lx, 
 
 // one lane scans its own (tile-clipped) tiny bbox with 32-bit edge functions.  ONE flattened loop over the
 // bbox pixels: with nested row/column loops a wave pays max(rows) x max(cols) over its lanes (a 1x16 and a
-// 16x1 box in the same wave = 256 trips); flattened it pays max(area) <= TINY_AREA.
+// 16x1 box in the same wave = 256 trips); flattened it pays max(area) <= the tile's tiny-area threshold.
 template <int PITCH>
 __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
                                                    int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels,
@@ -1714,15 +1714,26 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
 // completely.  Each batch of 256 bin entries is therefore cut into (triangle, pixel row) units; a
 // block-wide prefix sum over the row counts hands every thread one row at a time, so a lane's loop
 // length is one row span (<= 64 pixels) instead of one bbox area (<= 4096).  Tiny triangles (clipped
-// bbox <= TINY_AREA pixels) are scanned directly by the thread that set them up.
+// bbox <= TINY_AREA / TINY_AREA_DENSE pixels) are scanned directly by the thread that set them up.
 //
 // Edge functions in the row loop are incremental (no multiplies).  Three exact representations:
 //   kind 0  int32   vertices at most 64 px apart (|E| < 2^30)
 //   kind 1  double  |coordinates| < 2^25 sub-pixels: every product and sum below 2^53, so fp64 is exact
 //                   and v_cvt_f32_f64 IS the canonical (float)(double)E
 //   kind 2  int64   anything else (guard-band monsters)
+// The threshold follows the tile: where a bin is long (>= TINY_DENSE_MIN entries: distant instances, a triangle or two per
+// pixel) nearly everything is small and a lane's own loop of up to 48 pixels beats a unit list that is mostly one- and two-row
+// triangles; where it is short the triangles are larger and more varied, and 8 keeps the lanes of a wave alike.  Measured
+// (one threshold 8 / 16 / 32: config 3 0.1882 / 0.1897 / 0.1932 ms, config 4 0.443 / 0.429 / 0.419; 8 | 48 at 1 024 entries:
+// 0.1875 and 0.4194).
 #ifndef TINY_AREA
-#define TINY_AREA 16
+#define TINY_AREA 8
+#endif
+#ifndef TINY_AREA_DENSE
+#define TINY_AREA_DENSE 48
+#endif
+#ifndef TINY_DENSE_MIN
+#define TINY_DENSE_MIN 1024u
 #endif
 
 struct UnitParams {           // one batch entry, as the row loop wants it
@@ -2262,6 +2273,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     const uint32_t item = itemCount.x;
     const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
     const uint32_t nAll = itemCount.y;                            // (already clamped to the bin capacity)
+    const int32_t tinyArea = nAll >= TINY_DENSE_MIN ? TINY_AREA_DENSE : TINY_AREA;
     // entries [lo, n) of the bin are this item's
     // (slices of TILE_SLICE entries; a bin too long for CHORD_TILE_MAX_SLICES of them is cut into that many equal parts,
     // rounded to whole batches)
@@ -2412,7 +2424,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                 if (x1 >= x0 && y1 >= y0) {
                     const bool narrow = narrow_extent(ts);
                     const bool maskedRec = MASKED && (name & CHORD_REC_WIDE) && (q2.z & 4u);   // a TriRecMaskExt follows the record
-                    if (narrow && !maskedRec && (x1 - x0 + 1) * (y1 - y0 + 1) <= TINY_AREA) {
+                    if (narrow && !maskedRec && (x1 - x0 + 1) * (y1 - y0 + 1) <= tinyArea) {
                         if (!ABL(p, DBG_NO_TINY)) tile_raster_narrow<TPITCH>(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask, DEPTH);
                         if (prof) { cTiny++; cTinyIters += (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1)); }
                     } else {
