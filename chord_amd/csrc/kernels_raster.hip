@@ -1562,7 +1562,9 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 // dropped otherwise.  Item = tile | slice << 12 | (slices - 1) << 22.
 #define TILE_SLICE_SHIFT CHORD_TILE_SLICE_SHIFT
 #define TILE_SLICE (1u << TILE_SLICE_SHIFT)
+#ifndef TILE_SPLIT_MIN
 #define TILE_SPLIT_MIN 6144u       // bins up to this many entries stay whole
+#endif
 template <uint32_t NT>
 __device__ __forceinline__ void tile_order_part(const RasterParams& p)
 {
@@ -2620,7 +2622,10 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         if (!c->inFrame || c->rasterCalls >= 2) LR_HIP(hipMemsetAsync(p.leftCount, 0, sizeof(uint32_t), c->stream));
     }
     uint32_t blocks = (in.capacity + 3u) / 4u;
-    const uint32_t maxBlocks = (uint32_t)c->numCUs * SETUP_MIN_WAVES;    // what is resident at SETUP_MIN_WAVES waves per SIMD
+#ifndef SETUP_GRID_MULT
+#define SETUP_GRID_MULT 1u
+#endif
+    const uint32_t maxBlocks = (uint32_t)c->numCUs * SETUP_MIN_WAVES * SETUP_GRID_MULT;    // what is resident at SETUP_MIN_WAVES waves per SIMD
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
     const bool sh = c->shard.ranks > 1;
