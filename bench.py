@@ -8,8 +8,8 @@ apart so that every frame culls against the HZB of a *different* previous frame 
 "two frames, camera advanced 0.5 m").
 
   N = 1   workload "street_4k_hzb"  BASELINE config 3 (Bistro-class, 3840x2160, two-pass HZB)
-  N > 1   workload "subpixel_1g"    BASELINE config 5 (1.07 G sub-pixel triangles per frame), rows sharded in
-          interleaved stripes across the ranks, HZB mip 0 (two-pass workloads) + visibility reassembled with all-gathers
+  N > 1   workload "subpixel_1g"    BASELINE config 5 (1.07 G sub-pixel triangles per frame), the screen sharded by 64 x 64 tiles
+          across the ranks, the tiles' HZB texels (two-pass workloads) + visibility words reassembled with all-gathers
           issued by the library itself over RCCL (chordvis_comm_init_rank: --exchange lib), by torch.distributed on the
           context's stream (--exchange torch), or by ONE process driving all N devices with peer copies (ChordGroup:
           --exchange group).  `auto` tries them in that order, so a node whose RCCL does not come up still yields a curve;
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=("auto", "lib", "torch", "group"),
                     help="N > 1: who issues the all-gathers -- the library over RCCL, torch.distributed, or one process with N devices (ChordGroup, peer copies); auto = the first that works")
     ap.add_argument("--pipelined", action="store_true", help="N > 1, --exchange lib: the visibility all-gather of frame i runs beside frame i + 1 (second RCCL communicator)")
-    ap.add_argument("--stripe-rows", type=int, default=0, help="N > 1: rows per stripe (even); 0 = chordvis_pick_stripe_rows")
+    ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep the default tile map (compact regions of equal area) instead of re-balancing it from the warm-up frames' tile loads")
     ap.add_argument("--cpu-baseline-frames", type=int, default=48, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
     ap.add_argument("--cull", default="flat", choices=("flat", "hierarchical"),
                     help="instanceCulling: the reference's flat group dispatch, or the BVH walk (same command list)")
@@ -144,11 +144,8 @@ def main():
     if args.cull == "hierarchical":
         r.set_cull_mode(1)
     r.upload_scene(scene)
-    stripe_rows = 0
     if world > 1:
-        from chord_amd.sharding import pick_stripe_rows
-        stripe_rows = args.stripe_rows or pick_stripe_rows(H, world)
-        r.set_shard(stripe_rows, world, rank)
+        r.set_shard(world, rank)                         # screen tiles, the default map (re-balanced after the warm-up, below)
     r.allocate_gbuffer(W, H)
     vis_t = vis_mine = None                              # (--exchange torch: a caller-owned visibility buffer, below)
 
@@ -237,8 +234,11 @@ def main():
         words = r.visibility_words()
         vis_t = torch.zeros(words, dtype=torch.int64, device=dev)      # caller-owned visibility (all-gather target)
         r.allocate_gbuffer(W, H, vis_t.data_ptr())
+
+    def vis_views():
+        # (a rank's chunk is as many tile slots as the largest rank owns under the current map)
         chunk = r.visibility_chunk_words()
-        vis_mine = vis_t[rank * chunk:(rank + 1) * chunk]
+        return vis_t[:world * chunk], vis_t[rank * chunk:(rank + 1) * chunk]
 
     def all_gather(full, mine):
         if backend == "nccl":
@@ -259,22 +259,33 @@ def main():
             r.frame_phase_a()
             ex.all_gather_hzb()
             r.frame_phase_b()
-            all_gather(vis_t, vis_mine)
+            ex.all_gather_final()
+            all_gather(*ex.vis)
             r.frame_phase_c()
 
     class Exchange:
-        """all-gather of the context-owned HZB mip-0 exchange buffer (f16, rank-major)."""
+        """all-gathers of the context-owned HZB exchange buffers (per tile slot the tile's HZB texels, rank-major) and of the image."""
         def __init__(self):
-            ptr, halves, chunk_h = r.hzb_exchange()
+            self.remap()
+
+        def remap(self):
             # raw bytes: RCCL has no 16-bit integer type and the payload is opaque f16 bits anyway
-            self.full = _tensor_from_ptr(ptr, halves * 2, torch.uint8, dev)
-            self.mine = self.full[rank * chunk_h * 2:(rank + 1) * chunk_h * 2]
+            ptr, halves, chunk_h = r.hzb_exchange()
+            self.mid = _tensor_from_ptr(ptr, halves * 2, torch.uint8, dev)
+            self.mid_mine = self.mid[rank * chunk_h * 2:(rank + 1) * chunk_h * 2]
+            fptr, fbytes = r.hzb_final_exchange()
+            self.fin = _tensor_from_ptr(fptr, fbytes * world, torch.uint8, dev)
+            self.fin_mine = self.fin[rank * fbytes:(rank + 1) * fbytes]
+            self.vis = vis_views() if vis_t is not None else None
 
         def all_gather_hzb(self):
             if not args.no_hzb:                          # (a frame without stage 1 has nothing to exchange)
-                all_gather(self.full, self.mine)
+                all_gather(self.mid, self.mid_mine)
 
-    ex = Exchange() if world > 1 else None
+        def all_gather_final(self):
+            all_gather(self.fin, self.fin_mine)
+
+    ex = Exchange() if (world > 1 and exchange == "torch") else None
     if args.debug_flags:
         r.set_debug(args.debug_flags)
 
@@ -286,6 +297,24 @@ def main():
         if i >= max(args.warmup, 4) - 2:
             st = r.stats()
             per_view[i & 1] = st
+    # ---- N > 1: the tile map re-balanced from the loads of the last warm-up frame (every rank holds every tile's load after
+    #      the end-of-frame exchange and computes the same map), then two more untimed frames under the new map
+    tile_map = None
+    if world > 1:
+        imb_before = 1.0
+        if not args.no_rebalance:
+            imb_before = r.rebalance()
+            if ex is not None:
+                ex.remap()
+            for i in range(4):
+                frame(i)
+                per_view[i & 1] = r.stats()
+        owners = r.tile_owners()
+        loads = r.read_tile_loads().astype(np.float64)
+        per = np.bincount(owners, weights=loads, minlength=world)
+        tile_map = {"rebalanced": not args.no_rebalance, "entries_max_over_mean_default_map": round(imb_before, 3),
+                    "entries_max_over_mean": round(float(per.max() / max(per.mean(), 1.0)), 3),
+                    "tiles_per_rank": np.bincount(owners, minlength=world).tolist(), "chunk_slots": r.visibility_chunk_words() // 4096}
     tris_per_pair = per_view[0]["trianglesSubmitted"] + per_view[1]["trianglesSubmitted"]
     clusters_per_pair = sum(pv["countStage0Visible"] + pv["countStage1Visible"] for pv in per_view)
 
@@ -459,7 +488,7 @@ def main():
             "dtype": "f32+u64", "data": "synthetic",
             "config": {"workload": wl, **({"ABLATION_debug_flags": args.debug_flags} if args.debug_flags else {}), "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(),
                        "objects": len(scene.objects), "hzb": not args.no_hzb, "cull": args.cull,
-                       "parallelism": "stripes%d" % world if world > 1 else "single"},
+                       "parallelism": "tiles%d" % world if world > 1 else "single"},
             "triangles_submitted_per_step": tris_per_pair / 2.0,
             # end to end over ALL scene triangles (LOD 0), i.e. including what culling removed
             "scene_gtri_per_s": round(scene.triangle_count_lod0() / (ms_per_step * 1e-3) / 1e9, 3),
@@ -475,7 +504,7 @@ def main():
         if world > 1:
             line["exchange"] = exchange
             line["pipelined"] = pipelined
-            line["stripe_rows"] = stripe_rows
+            line["tile_map"] = tile_map
             line["exchange_fallbacks"] = fallbacks
             line["phases_ms"] = phases
             line["rccl_ranks"] = comm["ranks"] if (comm and exchange == "lib") else (dist.get_world_size() if backend == "nccl" else 0)
@@ -503,7 +532,7 @@ def run_group(args, wl, scene, views, objs, flags, W, H, world, rank, dev, strea
             share = max(1, world // 2)
             g.set_limits(max_triangle_records=(1152 << 20) // share, bin_pool_chunks=(1200 << 10) // share, bin_max_chunks_per_tile=2048)
         g.upload_scene(scene)
-        g.allocate_gbuffer(W, H, 0)
+        g.allocate_gbuffer(W, H)
 
         def frame(i):
             g.update_objects(objs[i & 1])                # (host arrays: the group API has no bind_objects; 224 B per object and rank)
@@ -514,6 +543,15 @@ def run_group(args, wl, scene, views, objs, flags, W, H, world, rank, dev, strea
         for i in range(max(args.warmup, 4)):
             frame(i)
         g.sync()
+        imb_before = 1.0
+        if not args.no_rebalance:
+            imb_before = g.rebalance()                   # the tile map from the last warm-up frame's loads
+            for i in range(4):
+                frame(i)
+            g.sync()
+        owners = g.ranks[0].tile_owners()
+        tile_map = {"rebalanced": not args.no_rebalance, "entries_max_over_mean_default_map": round(imb_before, 3),
+                    "tiles_per_rank": np.bincount(owners, minlength=world).tolist()}
         for r_ in g.ranks:
             r_.enable_timers(2, period=8)
         t0 = time.perf_counter()
@@ -557,9 +595,9 @@ def run_group(args, wl, scene, views, objs, flags, W, H, world, rank, dev, strea
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "timed_region_s": round(elapsed, 6),
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
                 "config": {"workload": wl, "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(), "objects": len(scene.objects),
-                           "hzb": not args.no_hzb, "cull": args.cull, "parallelism": "stripes%d" % world},
+                           "hzb": not args.no_hzb, "cull": args.cull, "parallelism": "tiles%d" % world},
                 "triangles_submitted_per_step": tris_per_pair / 2.0,
-                "exchange": "group", "exchange_fallbacks": fallbacks, "collective_backend": "hipMemcpyPeerAsync",
+                "exchange": "group", "exchange_fallbacks": fallbacks, "collective_backend": "hipMemcpyPeerAsync", "tile_map": tile_map,
                 "phases_ms": [{"rank": k, "phase_a_cull": round(st["msClear"] + st["msInstanceCulling"], 4), "phase_a_stage0": round(st["msStage0"], 4),
                                "hzb_mid": round(st["msHzbStage0"], 4), "exchange_hzb": round(st["msExchangeHzb"], 4), "phase_b_stage1": round(st["msStage1"], 4),
                                "exchange_vis": round(st["msExchangeVis"], 4), "phase_c_final_hzb": round(st["msHzbFinal"], 4),

@@ -61,13 +61,6 @@ void begin_frame_stamps(ChordCtx* c)
     chord::stamp(c, S_FRAME_BEGIN);
 }
 
-uint64_t stripes_per_rank(const ChordCtx* c)
-{
-    const uint32_t S = c->shard.stripeRows, N = c->shard.ranks;
-    const uint32_t stripes = (c->height + S - 1) / S;
-    return (stripes + N - 1) / N;
-}
-
 int alloc_hzb(ChordCtx* c, HzbBuffers& h)
 {
     ChordHZBDesc d;
@@ -85,11 +78,13 @@ int alloc_hzb(ChordCtx* c, HzbBuffers& h)
 
 int configure_targets(ChordCtx* c, uint64_t* external)
 {
-    // visibility words (rank-major when sharded: ranks * stripesPerRank * stripeRows rows)
+    // visibility words (sharded: rank-major tile slots, ranks * slotsPerRank * 64 * 64 words)
     const uint32_t N = c->shard.ranks;
-    c->shard.stripesPerRank = (uint32_t)stripes_per_rank(c);
-    const uint64_t rows = N > 1 ? (uint64_t)N * c->shard.stripesPerRank * c->shard.stripeRows : c->height;
-    c->visWords = rows * c->width;
+    c->tilesX = (c->width + CHORD_TILE - 1) >> CHORD_TILE_SHIFT; c->tilesY = (c->height + CHORD_TILE - 1) >> CHORD_TILE_SHIFT;
+    c->shard.tilesX = c->tilesX;
+    // (allocated for the slot capacity; an all-gather moves ranks x shard.slotsPerRank slots, what the current map uses)
+    c->slotCapacity = N > 1 ? chordvis_tile_slot_capacity(c->width, c->height, N) : 0u;
+    c->visWords = N > 1 ? (uint64_t)N * c->slotCapacity * (CHORD_TILE * CHORD_TILE) : (uint64_t)c->width * c->height;
     int rc;
     if (external) {
         dfree(c->dVisOwned);
@@ -104,7 +99,6 @@ int configure_targets(ChordCtx* c, uint64_t* external)
     c->historySlot = 0;
     c->pendingTailSlot = 0;
     {   // per-tile triangle bins of the rasterizer: 64x64-pixel tiles, binCap entries each
-        c->tilesX = (c->width + CHORD_TILE - 1) >> CHORD_TILE_SHIFT; c->tilesY = (c->height + CHORD_TILE - 1) >> CHORD_TILE_SHIFT;
         c->binCap = CHORD_BIN_CAP;              // 4K: 2 passes x 2040 tiles x 16384 x 4 B = 267 MB
         if ((rc = dalloc(c, &c->dTileBins, (size_t)2 * c->tilesX * c->tilesY * c->binCap))) return rc;
         c->binPoolChunks = c->limitPoolChunks;  // default: 2 passes x 32 Ki chunks x 1024 entries x 4 B = 256 MB
@@ -133,20 +127,28 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         const uint32_t vw = (c->width + 1) / 2, vh = (c->height + 1) / 2;
         if ((rc = dalloc(c, &c->dRangePartials, (size_t)((vw + 63) / 64) * ((vh + 3) / 4) * 2))) return rc;
     }
-    // mid-frame HZB mip-0 exchange (sharded only)
+    // sharded: the tile map and the two HZB exchange buffers (one slot per tile slot of the visibility buffer)
     if (N > 1) {
-        c->hzbExchangeChunkHalves = (uint64_t)c->shard.stripesPerRank * (c->shard.stripeRows / 2) * c->hzb[0].desc.width;
-        c->hzbExchangeHalves = c->hzbExchangeChunkHalves * N;
-        if ((rc = dalloc(c, &c->dHzbExchange, c->hzbExchangeHalves))) return rc;
-        CHORD_HIP(c, hipMemsetAsync(c->dHzbExchange, 0, c->hzbExchangeHalves * 2, c->stream));
-        // pipelined frames (chordvis_frame_phase_c_begin / _finish): the max chain's mip 0 and the ranks' valid-range pairs
-        if ((rc = dalloc(c, &c->dHzbExchangeMax, c->hzbExchangeHalves))) return rc;
-        CHORD_HIP(c, hipMemsetAsync(c->dHzbExchangeMax, 0, c->hzbExchangeHalves * 2, c->stream));
-        if ((rc = dalloc(c, &c->dRangeExchange, (size_t)N * 2))) return rc;
-        CHORD_HIP(c, hipMemsetAsync(c->dRangeExchange, 0, (size_t)N * 8, c->stream));
+        const size_t tilesN = (size_t)c->tilesX * c->tilesY;
+        CHORD_HIP(c, hipMemsetAsync(c->dVis, 0, c->visWords * 8, c->stream));   // (slots of edge tiles are partly padding: defined bytes on the wire)
+        if ((rc = dalloc(c, &c->dShardTables, 64 + (tilesN + 1) / 2))) return rc;
+        if ((rc = dalloc(c, &c->dTileLoads, tilesN))) return rc;
+        CHORD_HIP(c, hipMemsetAsync(c->dTileLoads, 0, tilesN * 4, c->stream));
+        if (c->tileOwners.size() != tilesN || !c->tileOwnersExplicit) {
+            c->tileOwners.assign(tilesN, 0);
+            c->tileOwnersExplicit = false;
+            if (tile_layout(c->tilesX, c->tilesY, N, nullptr, 0u, c->tileOwners.data()) != CHORDVIS_OK) return fail(c, CHORDVIS_E_INVALID, "tile layout");
+        }
+        const size_t slots = (size_t)N * c->slotCapacity;
+        if ((rc = dalloc(c, &c->dHzbExchange, slots * CHORD_HZB_SLOT_HALVES))) return rc;
+        CHORD_HIP(c, hipMemsetAsync(c->dHzbExchange, 0, slots * CHORD_HZB_SLOT_HALVES * 2, c->stream));
+        if ((rc = dalloc(c, &c->dHzbFinalExchange, slots * CHORD_HZB_FINAL_SLOT_HALVES))) return rc;
+        CHORD_HIP(c, hipMemsetAsync(c->dHzbFinalExchange, 0, slots * CHORD_HZB_FINAL_SLOT_HALVES * 2, c->stream));
+        if ((rc = install_tile_owners(c))) return rc;
     } else {
-        dfree(c->dHzbExchange); dfree(c->dHzbExchangeMax); dfree(c->dRangeExchange);
-        c->hzbExchangeHalves = c->hzbExchangeChunkHalves = 0;
+        dfree(c->dHzbExchange); dfree(c->dHzbFinalExchange); dfree(c->dShardTables); dfree(c->dTileLoads);
+        c->shard.ownedRows = nullptr; c->shard.tileSlot = nullptr;
+        c->hzbExchangeHalves = c->hzbExchangeChunkHalves = 0; c->hzbFinalExchangeChunkBytes = 0;
     }
     // (a second pair of visibility buffers is made by chordvis_swap_visibility when a pipelined host first asks for it)
     dfree(c->dVisAlt); dfree(c->dVisResolvedAlt);
@@ -247,6 +249,40 @@ void stamp(ChordCtx* c, int tag)
 }
 
 namespace chord {
+// c->tileOwners (host, the same on every rank) -> the two device tables the kernels read: this rank's tiles as one bit mask per
+// tile row, and every tile's slot in the rank-major buffers (owner * slotsPerRank + index among the owner's tiles, by tile index).
+int install_tile_owners(ChordCtx* c)
+{
+    const uint32_t N = c->shard.ranks, tiles = c->tilesX * c->tilesY;
+    if (N <= 1 || !c->dShardTables || c->tileOwners.size() != tiles) return fail(c, CHORDVIS_E_INVALID, "tile owners: no sharded G-buffer");
+    std::vector<uint32_t> used(N, 0);
+    for (uint32_t t = 0; t < tiles; t++) {
+        const uint32_t o = c->tileOwners[t];
+        if (o >= N || ++used[o] > c->slotCapacity) return fail(c, CHORDVIS_E_INVALID, "tile owners: an owner out of range, or a rank with more tiles than chordvis_tile_slot_capacity");
+    }
+    // a rank's chunk: as many slots as the largest rank owns (every all-gather moves ranks x S slots)
+    const uint32_t S = *std::max_element(used.begin(), used.end());
+    std::vector<unsigned long long> tab(64 + (tiles + 1) / 2, 0ull);
+    uint32_t* slot = reinterpret_cast<uint32_t*>(tab.data() + 64);
+    std::fill(used.begin(), used.end(), 0u);
+    for (uint32_t t = 0; t < tiles; t++) {
+        const uint32_t o = c->tileOwners[t];
+        slot[t] = o * S + used[o]++;
+        if (o == c->shard.rank) tab[t / c->tilesX] |= 1ull << (t % c->tilesX);
+    }
+    c->shard.slotsPerRank = S;
+    c->hzbExchangeChunkHalves = (uint64_t)S * CHORD_HZB_SLOT_HALVES;
+    c->hzbExchangeHalves = c->hzbExchangeChunkHalves * N;
+    c->hzbFinalExchangeChunkBytes = (uint64_t)S * CHORD_HZB_FINAL_SLOT_HALVES * 2;
+    // (stream-ordered behind whatever still reads the old tables; the staging vector is pageable, so the call returns after the copy)
+    CHORD_HIP(c, hipMemcpyAsync(c->dShardTables, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    c->shard.ownedRows = c->dShardTables;
+    c->shard.tileSlot = reinterpret_cast<const uint32_t*>(c->dShardTables + 64);
+    c->mineValid = false; c->listMine[1] = c->listMine[2] = false;       // (lists culled for another ownership)
+    return CHORDVIS_OK;
+}
+
 // Per-context work buffers that depend on the scene's counts (object frames, group masks, command lists, raster work
 // lists): the tail of chordvis_upload_scene, shared with the depth-view child context (depth_views.cpp).
 int alloc_scene_work_buffers(ChordCtx* c)
@@ -339,7 +375,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
     if (c->hBinHint) { (void)hipHostFree(const_cast<uint32_t*>(c->hBinHint)); c->hBinHint = nullptr; c->dBinHint = nullptr; }
-    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dHzbExchangeMax); dfree(c->dRangeExchange); dfree(c->dVisAlt); dfree(c->dVisResolvedAlt); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
+    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dHzbFinalExchange); dfree(c->dShardTables); dfree(c->dTileLoads); dfree(c->dVisAlt); dfree(c->dVisResolvedAlt); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
     dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -545,6 +581,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
 
     dfree(c->dRankCmds);                                   // sized by cmdCapacity; re-made by the first sharded raster pass
     dfree(c->dLeftCmds); dfree(c->dMineCmds);
+    c->mineValid = false; c->listMine[1] = c->listMine[2] = false;       // (the rank's lists went with the buffers)
     c->objectCount = s->objectCount; c->primCount = s->primitiveCount; c->materialCount = s->materialCount;
     c->meshletCount = nM; c->groupCount = nG;
     c->groupInstances = (uint32_t)groupInst; c->cmdCapacity = (uint32_t)std::max<uint64_t>(cmdCap, 1);
@@ -701,12 +738,15 @@ int chordvis_set_cull_mode(ChordCtx* c, int hierarchical)
     return CHORDVIS_OK;
 }
 
-int chordvis_set_shard(ChordCtx* c, uint32_t stripeRows, uint32_t ranks, uint32_t rank)
+int chordvis_set_shard(ChordCtx* c, uint32_t ranks, uint32_t rank)
 {
-    if (!c || ranks == 0 || rank >= ranks || stripeRows < 2 || (stripeRows & 1u)) return fail(c, CHORDVIS_E_INVALID, "set_shard: stripeRows must be even, rank < ranks");
-    c->shard.stripeRows = stripeRows; c->shard.ranks = ranks; c->shard.rank = rank;
-    c->shard.stripeMagic = stripeRows > 1 ? (uint32_t)((0x100000000ull + stripeRows - 1) / stripeRows) : 0xFFFFFFFFu;
-    c->shard.rankMagic = ranks > 1 ? (uint32_t)((0x100000000ull + ranks - 1) / ranks) : 0xFFFFFFFFu;
+    if (!c || ranks == 0 || ranks > 255u || rank >= ranks) return fail(c, CHORDVIS_E_INVALID, "set_shard: rank < ranks <= 255");
+#if CHORD_TILE_SHIFT != 6
+    if (ranks > 1) return fail(c, CHORDVIS_E_INVALID, "set_shard: this build's raster tiles are not 64 x 64");
+#endif
+    if (c->inFrame) return fail(c, CHORDVIS_E_INVALID, "set_shard: not inside a frame");
+    if (c->shard.ranks != ranks) { c->tileOwners.clear(); c->tileOwnersExplicit = false; }
+    c->shard.ranks = ranks; c->shard.rank = rank;
     c->mineValid = false; c->listMine[1] = c->listMine[2] = false;       // (lists culled for another ownership)
     if (c->width) {
         if (c->visExternal) { c->dVis = nullptr; return fail(c, CHORDVIS_E_INVALID, "set_shard after allocate_gbuffer with an external buffer: call allocate_gbuffer again"); }
@@ -715,20 +755,82 @@ int chordvis_set_shard(ChordCtx* c, uint32_t stripeRows, uint32_t ranks, uint32_
     return CHORDVIS_OK;
 }
 
+// An explicit tile map (one owner per tile, row-major over the tile grid; the same table on every rank), e.g. from
+// chordvis_tile_layout with the loads of a rendered frame.  Between frames; the history HZB carries over (it is not sharded).
+int chordvis_set_tile_owners(ChordCtx* c, const uint8_t* owners, uint32_t tiles)
+{
+    if (!c || c->shard.ranks <= 1 || !c->width) return fail(c, CHORDVIS_E_INVALID, "set_tile_owners: a sharded context with a G-buffer");
+    std::vector<uint8_t> def;
+    if (!owners) {                                                        // NULL: back to the default map
+        tiles = c->tilesX * c->tilesY;
+        def.assign(tiles, 0);
+        if (tile_layout(c->tilesX, c->tilesY, c->shard.ranks, nullptr, 0u, def.data()) != CHORDVIS_OK) return fail(c, CHORDVIS_E_INVALID, "tile layout");
+        owners = def.data();
+    }
+    if (tiles != c->tilesX * c->tilesY) return fail(c, CHORDVIS_E_INVALID, "set_tile_owners: one owner per tile of the G-buffer");
+    if (c->inFrame) return fail(c, CHORDVIS_E_INVALID, "set_tile_owners: not inside a frame");
+    // frames in flight (pipelined hosts: an image still travelling) were laid out with the old map
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->commResolveStream) CHORD_HIP(c, hipStreamSynchronize(c->commResolveStream));
+    for (int k = 0; k < 2; k++) if (c->visReadyEvent[k]) CHORD_HIP(c, hipEventSynchronize(c->visReadyEvent[k]));
+    std::vector<uint8_t> keep = c->tileOwners;
+    c->tileOwners.assign(owners, owners + tiles);
+    const int rc = install_tile_owners(c);
+    if (rc) { c->tileOwners = keep; if (!keep.empty()) (void)install_tile_owners(c); return rc; }
+    c->tileOwnersExplicit = def.empty();
+    return CHORDVIS_OK;
+}
+
+int chordvis_get_tile_owners(ChordCtx* c, uint8_t* ownersOut, uint32_t tiles)
+{
+    if (!c || !ownersOut || c->shard.ranks <= 1 || c->tileOwners.size() != tiles) return fail(c, CHORDVIS_E_INVALID, "get_tile_owners: a sharded context with a G-buffer, one entry per tile");
+    std::memcpy(ownersOut, c->tileOwners.data(), tiles);
+    return CHORDVIS_OK;
+}
+
+// Bin entries per tile of the last frame this context finished, every rank's tiles (they travel in the end-of-frame exchange).
+// Waits for the context's stream.
+int chordvis_read_tile_loads(ChordCtx* c, uint32_t* loadsOut, uint32_t tiles)
+{
+    if (!c || !loadsOut || c->shard.ranks <= 1 || !c->dTileLoads || tiles != c->tilesX * c->tilesY) return fail(c, CHORDVIS_E_INVALID, "read_tile_loads: a sharded context with a G-buffer, one entry per tile");
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    CHORD_HIP(c, hipMemcpy(loadsOut, c->dTileLoads, sizeof(uint32_t) * tiles, hipMemcpyDeviceToHost));
+    return CHORDVIS_OK;
+}
+
+// Re-balances the tile map from the last frame's loads: chordvis_read_tile_loads -> chordvis_tile_layout -> chordvis_set_tile_owners.
+// Every rank of the frame must call it at the same frame boundary (they hold the same loads, so they compute the same map).
+// imbalance (may be NULL): max over ranks of the OLD map's load / the mean, x 1000.
+int chordvis_rebalance(ChordCtx* c, uint32_t* imbalancePermille)
+{
+    if (!c || c->shard.ranks <= 1 || !c->dTileLoads) return fail(c, CHORDVIS_E_INVALID, "rebalance: a sharded context with a G-buffer");
+    const uint32_t tiles = c->tilesX * c->tilesY, N = c->shard.ranks;
+    std::vector<uint32_t> loads(tiles);
+    int rc = chordvis_read_tile_loads(c, loads.data(), tiles);
+    if (rc) return rc;
+    std::vector<uint64_t> per(N, 0);
+    uint64_t total = 0;
+    for (uint32_t t = 0; t < tiles; t++) { per[c->tileOwners[t]] += loads[t]; total += loads[t]; }
+    if (imbalancePermille) *imbalancePermille = total ? (uint32_t)(*std::max_element(per.begin(), per.end()) * N * 1000u / total) : 1000u;
+    if (total == 0) return CHORDVIS_OK;                                  // (no frame rendered yet: keep the map)
+    std::vector<uint8_t> owners(tiles);
+    if (tile_layout(c->tilesX, c->tilesY, N, loads.data(), c->slotCapacity, owners.data()) != CHORDVIS_OK) return fail(c, CHORDVIS_E_INVALID, "rebalance: tile layout");
+    return chordvis_set_tile_owners(c, owners.data(), tiles);
+}
+
 uint64_t chordvis_visibility_words(ChordCtx* c)
 {
     if (!c) return 0;
     if (c->width == 0) return 0;
     const uint32_t N = c->shard.ranks;
-    const uint64_t rows = N > 1 ? (uint64_t)N * stripes_per_rank(c) * c->shard.stripeRows : c->height;
-    return rows * c->width;
+    return N > 1 ? (uint64_t)N * chordvis_tile_slot_capacity(c->width, c->height, N) * (CHORD_TILE * CHORD_TILE) : (uint64_t)c->width * c->height;
 }
-uint64_t chordvis_visibility_chunk_words(ChordCtx* c) { return c ? chordvis_visibility_words(c) / c->shard.ranks : 0; }
+uint64_t chordvis_visibility_chunk_words(ChordCtx* c) { return !c ? 0 : c->shard.ranks > 1 ? (uint64_t)c->shard.slotsPerRank * (CHORD_TILE * CHORD_TILE) : chordvis_visibility_words(c); }
 uint64_t* chordvis_visibility_ptr(ChordCtx* c) { return c ? c->dVis : nullptr; }
 uint64_t* chordvis_resolved_visibility_ptr(ChordCtx* c) { return c ? (c->shard.ranks > 1 ? c->dVisResolved : c->dVis) : nullptr; }
 uint16_t* chordvis_hzb_exchange_ptr(ChordCtx* c) { return c ? c->dHzbExchange : nullptr; }
-uint16_t* chordvis_hzb_exchange_max_ptr(ChordCtx* c) { return c ? c->dHzbExchangeMax : nullptr; }
-uint32_t* chordvis_range_exchange_ptr(ChordCtx* c) { return c ? c->dRangeExchange : nullptr; }
+uint16_t* chordvis_hzb_final_exchange_ptr(ChordCtx* c) { return c ? c->dHzbFinalExchange : nullptr; }
+uint64_t chordvis_hzb_final_exchange_chunk_bytes(ChordCtx* c) { return c ? c->hzbFinalExchangeChunkBytes : 0; }
 
 // Pipelined sharded frames keep TWO frames' visibility words alive: the one whose all-gather is still travelling and the
 // one being rasterized.  Swaps the roles of the two buffer pairs (the second pair is allocated on first use); call between
@@ -742,7 +844,7 @@ int chordvis_swap_visibility(ChordCtx* c)
     if (!c->dVisAlt) {
         if ((rc = dalloc(c, &c->dVisAlt, c->visWords))) return rc;
         if ((rc = dalloc(c, &c->dVisResolvedAlt, (uint64_t)c->width * c->height))) return rc;
-        CHORD_HIP(c, hipMemsetAsync(c->dVisAlt, 0, c->visWords * 8, c->stream));
+        CHORD_HIP(c, hipMemsetAsync(c->dVisAlt, 0, c->visWords * 8, c->stream));   // (incl. the padding of edge tiles' slots)
         CHORD_HIP(c, hipMemsetAsync(c->dVisResolvedAlt, 0, (uint64_t)c->width * c->height * 8, c->stream));
     }
     std::swap(c->dVisOwned, c->dVisAlt);
@@ -763,7 +865,7 @@ int chordvis_clear_gbuffer(ChordCtx* c)
     // visibility = 0 / depth = 0.0 (render_textures.cpp:81-85,98-100).  Sharded: only the rank's own
     // chunk needs clearing (the all-gather overwrites the rest).
     if (c->shard.ranks > 1) {
-        const uint64_t chunk = c->visWords / c->shard.ranks;
+        const uint64_t chunk = (uint64_t)c->shard.slotsPerRank * (CHORD_TILE * CHORD_TILE);
         CHORD_HIP(c, hipMemsetAsync(c->dVis + chunk * c->shard.rank, 0, chunk * 8, c->stream));
     } else {
         CHORD_HIP(c, hipMemsetAsync(c->dVis, 0, c->visWords * 8, c->stream));
@@ -869,7 +971,8 @@ int chordvis_build_hzb(ChordCtx* c, int bBuildMin, int bBuildMax, int bBuildVali
     if (slot < 0 || slot > 2 || !(bBuildMin || bBuildMax) || (bBuildValidRange && !(bBuildMin && bBuildMax)))   // hzb.cpp:43-47
         return fail(c, CHORDVIS_E_INVALID, "build_hzb: slot in 0..2, at least one channel, valid range needs min and max");
     if ((rc = flush_pending_tail(c))) return rc;
-    launch_hzb_build(c, c->hzb[slot], bBuildMin != 0, bBuildMax != 0, bBuildValidRange != 0, false);
+    // (a sharded context: from the resolved, row-major image -- chordvis_frame_resolve_visibility / phase c)
+    launch_hzb_build(c, c->hzb[slot], bBuildMin != 0, bBuildMax != 0, bBuildValidRange != 0);
     CHORD_HIP(c, hipGetLastError());
     if (out) {
         *out = c->hzb[slot].handle();
@@ -939,94 +1042,100 @@ static int render_frame_impl(ChordCtx* c)
     return CHORDVIS_OK;
 }
 
-// Sharded frame, phase a: everything up to the stage-0 raster + own-stripe HZB mip 0.
+// Sharded frame.  The single-GPU frame with two differences: the tile kernel writes each tile's words to the
+// tile's slot of the rank's chunk and its HZB texels (mips 0..5) to the tile's slots of the two exchange buffers, and after
+// each all-gather a copy kernel (launch_hzb_untile) moves every rank's texels to their places in the chain.
+//   phase a   clear .. stage 0 raster (owned tiles; fused reduction into the exchange slots)
+//   [all-gather of the mid-frame exchange buffer -- only when phase a reported a second stage]
+//   phase b   chain 0 from the exchanged texels, phase-1 cull (reduces mips 6.. itself), stage 1 raster
+//   [all-gather of the end-of-frame exchange buffer (small) and of the visibility words (the image)]
+//   phase c   row-major copy of the image + the history chain from the exchanged texels; ends the frame
+// Hosts that let the image travel beside the next frame call chordvis_frame_phase_c_finish once the small exchange has landed
+// and chordvis_frame_resolve_visibility whenever the image has.
 static int frame_phase_a_impl(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_a");
     if (rc) return rc;
-    if ((rc = flush_pending_tail(c))) return rc;
+    if (c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_phase_a: the context is not sharded");
     begin_frame_stamps(c);
     if ((rc = begin_frame_clear(c))) return rc;
     record(c, S_CLEAR);
     ChordCountAndCmd post;
-    if ((rc = chordvis_instance_culling(c, &post))) return rc;
+    if ((rc = chordvis_instance_culling(c, &post))) return rc;                        // (its first kernel carries the previous frame's HZB tail)
     record(c, S_CULL);
     ChordHZB hist;
     const bool haveHist = c->historySlot != 0;
     if (haveHist) hist = c->hzb[c->historySlot].handle();
+    c->fuseHzb = true;
+    c->fuseHzbSlot = c->historySlot == 1 ? 2 : 1;
+    c->fuseHzbTemp = haveHist && (c->hView.flags & CHORD_FLAG_HZB_CULL);
     ChordCountAndCmd rejected;
     int stage1 = 0;
-    if ((rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1))) return rc;
+    rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1);
+    c->fuseHzb = false;
+    if (rc) return rc;
     c->shouldStage1 = stage1 != 0;
     c->lastRejected = from_handle(rejected);
     record(c, S_STAGE0_END);
-    if (stage1 && c->shard.ranks > 1) { launch_hzb_mip0_exchange(c); CHORD_HIP(c, hipGetLastError()); record(c, S_HZB0); }
     return CHORDVIS_OK;
 }
 
-// phase b: [exchange buffer all-gathered by the caller] -> HZB chain -> stage 1.
+// phase b: [mid-frame exchange buffer all-gathered by the caller] -> HZB chain 0 -> stage 1.
 static int frame_phase_b_impl(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_b");
     if (rc) return rc;
     if (!c->shouldStage1) return CHORDVIS_OK;
-    record(c, S_EXCH_HZB);       // time spent in the all-gather of the HZB mip-0 exchange buffer (the library's or the caller's)
-    if (c->shard.ranks > 1) launch_hzb_build(c, c->hzb[0], true, false, false, true);
-    else launch_hzb_build(c, c->hzb[0], true, false, false, false);
+    record(c, S_EXCH_HZB);       // time spent in the all-gather of the mid-frame exchange buffer (the library's or the caller's)
+    launch_hzb_untile(c, c->hzb[0], false);
     CHORD_HIP(c, hipGetLastError());
+    {   // levels 6.. of the chain: reduced by the blocks of the phase-1 cull themselves when they fit (render_frame_impl)
+        const ChordHZBDesc& hd = c->hzb[0].desc;
+        uint32_t tailFloats = 0;
+        for (uint32_t l = 6; l < hd.mipCount; l++) tailFloats += std::max(1u, hd.width >> l) * std::max(1u, hd.height >> l);
+        c->hzbTailInCull = hd.mipCount > 6u && tailFloats <= 1408u && !(c->debugFlags & 131072u);
+        if (!c->hzbTailInCull) launch_hzb_tail(c, c->hzb[0], false, false);
+    }
     record(c, S_HZB0);
     ChordHZB tmp = c->hzb[0].handle();
-    if ((rc = chordvis_visibility_stage1(c, &tmp, c->lastRejected.handle()))) return rc;
+    c->fuseHzb = true;
+    c->fuseHzbTemp = false;
+    rc = chordvis_visibility_stage1(c, &tmp, c->lastRejected.handle());
+    c->fuseHzb = false;
+    c->hzbTailInCull = false;
+    if (rc) return rc;
     record(c, S_STAGE1_END);
     return CHORDVIS_OK;
 }
 
-// phase c: [visibility buffer all-gathered in place by the caller] -> row-major copy + final HZB.
-static int frame_phase_c_impl(ChordCtx* c)
-{
-    int rc = ready(c, "frame_phase_c");
-    if (rc) return rc;
-    record(c, S_EXCH_VIS);       // time spent in the all-gather of the visibility words
-    if (c->shard.ranks > 1) { launch_detile(c); CHORD_HIP(c, hipGetLastError()); }
-    const int next = c->historySlot == 1 ? 2 : 1;
-    if ((rc = chordvis_build_hzb(c, 1, 1, 1, next, nullptr))) return rc;
-    record(c, S_HZBF);
-    c->historySlot = next;
-    c->inFrame = false;
-    return CHORDVIS_OK;
-}
-
-// Pipelined form of phase c, for hosts that overlap the visibility all-gather of a frame with the next frame: the final HZB
-// does not wait for the gathered image.
-//   phase_c_begin   own-stripe mip 0 of the min and max chains into the exchange buffers, the rank's valid-range pair
-//   [host: all-gather chordvis_hzb_exchange_ptr, chordvis_hzb_exchange_max_ptr (chunk = hzb_exchange_chunk_halves) and
-//          chordvis_range_exchange_ptr (2 words per rank)]
-//   phase_c_finish  the chain from the exchanged mip 0 (identical to buildHZB over the whole image); ends the frame
-//   [host, whenever the visibility all-gather of that frame has landed: chordvis_frame_resolve_visibility]
-static int frame_phase_c_begin_impl(ChordCtx* c)
-{
-    int rc = ready(c, "frame_phase_c_begin");
-    if (rc) return rc;
-    if (c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_phase_c_begin: the context is not sharded");
-    const int next = c->historySlot == 1 ? 2 : 1;
-    launch_hzb_final_exchange(c, c->hzb[next]);
-    CHORD_HIP(c, hipGetLastError());
-    return CHORDVIS_OK;
-}
-
+// [end-of-frame exchange buffer all-gathered by the caller] -> the history chain; the frame is over.  Mips 0..5 are copied
+// from the slots; the one-block tail (mips 6.., valid range from the tiles' pairs) rides on the next frame's first kernel, or
+// is launched by whoever reads the chain first (flush_pending_tail) -- as in the single-GPU frame.
 static int frame_phase_c_finish_impl(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_c_finish");
     if (rc) return rc;
     if (c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_phase_c_finish: the context is not sharded");
-    record(c, S_OTHER);
     const int next = c->historySlot == 1 ? 2 : 1;
-    launch_hzb_build_final_from_exchange(c, c->hzb[next]);
+    launch_hzb_untile(c, c->hzb[next], true);
     CHORD_HIP(c, hipGetLastError());
+    c->pendingTailSlot = next;
     record(c, S_HZBF);
     c->historySlot = next;
     c->inFrame = false;
     return CHORDVIS_OK;
+}
+
+// phase c: [both end-of-frame all-gathers done by the caller] -> row-major copy of the image + the history chain.
+static int frame_phase_c_impl(ChordCtx* c)
+{
+    int rc = ready(c, "frame_phase_c");
+    if (rc) return rc;
+    if (c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_phase_c: the context is not sharded");
+    record(c, S_EXCH_VIS);       // time spent in the end-of-frame all-gathers
+    launch_detile(c);
+    CHORD_HIP(c, hipGetLastError());
+    return frame_phase_c_finish_impl(c);
 }
 
 // A failed frame must not leave frame-scoped state behind (the stand-alone passes that may follow would skip their
@@ -1043,7 +1152,6 @@ int chordvis_render_frame(ChordCtx* c) { return end_failed_frame(c, render_frame
 int chordvis_frame_phase_a(ChordCtx* c) { return end_failed_frame(c, frame_phase_a_impl(c)); }
 int chordvis_frame_phase_b(ChordCtx* c) { return end_failed_frame(c, frame_phase_b_impl(c)); }
 int chordvis_frame_phase_c(ChordCtx* c) { return end_failed_frame(c, frame_phase_c_impl(c)); }
-int chordvis_frame_phase_c_begin(ChordCtx* c) { return end_failed_frame(c, frame_phase_c_begin_impl(c)); }
 int chordvis_frame_phase_c_finish(ChordCtx* c) { return end_failed_frame(c, frame_phase_c_finish_impl(c)); }
 
 // The row-major copy of the (gathered) rank-major visibility words of the CURRENT buffer pair, on `hipStream` (NULL: the

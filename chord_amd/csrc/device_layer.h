@@ -105,16 +105,39 @@ struct DView {                 // constants of one frame
     uint32_t                 pad;
 };
 
+// Multi-GPU screen ownership ("screen tiles (e.g. 64x64) ... visbuffer stored rank-major"): the unit is the rasterizer's
+// 64x64-pixel tile, every tile has one owner, the map is a table (any assignment: compact regions, load-balanced, interleaved).
+// A rank's tiles are stored contiguously, tile-linear (64 rows of 64 words each), in the rank's chunk of the visibility buffer:
+// tile t lives in slot tileSlot[t] = owner * slotsPerRank + (index among the owner's tiles), so ONE in-place all-gather of
+// slotsPerRank * 4096 words per rank reassembles the frame and a de-tile kernel restores row-major.  The HZB texels a tile
+// owns (mips 0..5: one 64x64 tile is exactly one mip-5 texel) travel in slots of the same numbering (below).
 struct ShardInfo {
-    uint32_t stripeRows, ranks, rank, stripesPerRank;
-    // ceil(2^32 / d): (x * magic) >> 32 == x / d for x < 2^16 (rows and stripes of a <= 4096-row frame) -- the GPU has no
-    // integer divide, and the ownership test runs several times per triangle
-    uint32_t stripeMagic, rankMagic;
+    uint32_t ranks, rank, slotsPerRank, tilesX;        // slotsPerRank: slots of one rank's chunk = the largest tile count of the current map
+    const unsigned long long* ownedRows;   // [tilesY] bit tx set <=> this rank owns tile (tx, ty)   (tilesX <= 64: renderer.h:52-53 caps the render size at 4096)
+    const uint32_t* tileSlot;              // [tilesX * tilesY] rank-major slot of every tile
 };
+// Tile slots a context allocates per rank beyond ceil(tiles / ranks), in thousandths: room for a load-balanced map to give a rank
+// of light tiles more of them (tile_layout.cpp).  What an all-gather moves is ranks x slotsPerRank slots, slotsPerRank = the
+// largest tile count of the CURRENT map -- the default map uses none of the slack.
+#define CHORD_TILE_SLACK_PERMILLE 250u
+// HZB texels of one tile, level by level: level l is (32 >> l)^2 texels at offset 1365 - (1365 >> 2l)  (0, 1024, 1280, 1344, 1360, 1364)
+#define CHORD_HZB_TILE_TEXELS 1365u
+#define CHORD_HZB_SLOT_HALVES 1408u          // a tile's slot in the mid-frame exchange buffer: the min chain's texels, padded
+// a tile's slot in the end-of-frame exchange buffer: min texels | max texels | {valid-range min, max, bin entries of the frame, 0} (uint32) | padding
+#define CHORD_HZB_FINAL_SLOT_HALVES 2832u
+#define CHORD_HZB_FINAL_MAX_OFFSET 1408u
+#define CHORD_HZB_FINAL_RANGE_OFFSET 2816u   // (halves; 4-byte aligned)
 #ifdef __HIPCC__
-__device__ __forceinline__ uint32_t shard_stripe_of(const ShardInfo& s, uint32_t y) { return __umulhi(y, s.stripeMagic); }
-__device__ __forceinline__ uint32_t shard_div_ranks(const ShardInfo& s, uint32_t stripe) { return __umulhi(stripe, s.rankMagic); }
-__device__ __forceinline__ uint32_t shard_owner_of_stripe(const ShardInfo& s, uint32_t stripe) { return stripe - shard_div_ranks(s, stripe) * s.ranks; }
+__device__ __forceinline__ uint32_t hzb_slot_level_offset(uint32_t l) { return CHORD_HZB_TILE_TEXELS - (CHORD_HZB_TILE_TEXELS >> (2u * l)); }
+__device__ __forceinline__ bool shard_owns_tile(const ShardInfo& s, uint32_t tx, uint32_t ty) { return (s.ownedRows[ty] >> tx) & 1ull; }
+// does the rank own a tile of the rectangle [tx0, tx1] x [ty0, ty1]?  (small triangles and clusters: one or two rows)
+__device__ __forceinline__ bool shard_owns_any_tile(const ShardInfo& s, uint32_t tx0, uint32_t ty0, uint32_t tx1, uint32_t ty1)
+{
+    const unsigned long long cols = ((2ull << (tx1 - tx0)) - 1ull) << tx0;
+    unsigned long long any = 0ull;
+    for (uint32_t ty = ty0; ty <= ty1; ty++) any |= s.ownedRows[ty] & cols;
+    return any != 0ull;
+}
 #endif
 
 // Work lists between the raster kernels (device memory, counts in DeviceCounters)
@@ -284,7 +307,12 @@ struct ChordCtx {
 
     // gbuffer
     uint32_t width = 0, height = 0;
-    chord::ShardInfo shard{64, 1, 0, 0};
+    chord::ShardInfo shard{1, 0, 0, 0, nullptr, nullptr};
+    uint32_t slotCapacity = 0;            // sharded: tile slots allocated per rank (chordvis_tile_slot_capacity), >= shard.slotsPerRank
+    std::vector<uint8_t> tileOwners;      // sharded: owner of every tile (the same table on every rank); empty = the default layout of configure_targets
+    bool tileOwnersExplicit = false;      // ... set by chordvis_set_tile_owners / chordvis_rebalance (kept across allocate_gbuffer of the same size)
+    unsigned long long* dShardTables = nullptr;   // [64] ownedRows, then [tiles] tileSlot (uint32)
+    uint32_t* dTileLoads = nullptr;       // [tiles] bin entries per tile of the last frame, every rank's tiles (written when the end-of-frame exchange is unpacked)
     void* comm = nullptr;             // ncclComm_t of a one-process-per-GPU host (chordvis_comm_init_rank), or null
     // pipelined frames over RCCL (chordvis_comm_set_pipelined): a second communicator carries the image of frame i beside frame i + 1
     void* commBulk = nullptr;
@@ -309,9 +337,9 @@ struct ChordCtx {
     bool fuseHzb = false;                 // inside render_frame: the tile kernel emits HZB mips 0..5
     bool fuseHzbTemp = false;             // ... also into the temporary chain (slot 0) for stage 1
     int fuseHzbSlot = 1;                  // history slot being produced this frame
-    uint16_t* dHzbExchange = nullptr;
-    uint16_t* dHzbExchangeMax = nullptr;   // pipelined sharded frames: own-stripe mip 0 of the max chain, rank-major like dHzbExchange
-    uint32_t* dRangeExchange = nullptr;    // ... and one valid-range pair per rank
+    uint16_t* dHzbExchange = nullptr;      // sharded frames, mid-frame exchange: per tile slot the min chain's mips 0..5 after the first raster pass (CHORD_HZB_SLOT_HALVES)
+    uint16_t* dHzbFinalExchange = nullptr; // ... end-of-frame exchange: per tile slot min | max | valid range | bin entries (CHORD_HZB_FINAL_SLOT_HALVES)
+    uint64_t hzbFinalExchangeChunkBytes = 0;
     uint64_t* dVisAlt = nullptr;           // ... the visibility words (rank-major) and their row-major copy of the OTHER frame in flight
     uint64_t* dVisResolvedAlt = nullptr;
     hipEvent_t visReadyEvent[2] = {nullptr, nullptr};   // [0]: the resolved image of the last submitted frame is complete, [1]: of the frame before
@@ -390,13 +418,13 @@ void launch_hzb_cull_generic(ChordCtx* c, const HzbBuffers& hzb, const ChordInst
                              bool useLastFrame, const CmdList& in, const CmdList& out);
 void launch_depth_extract(ChordCtx* c, const unsigned long long* vis, float* depth, size_t words);              // high word of every visibility word
 void launch_depth_expand(ChordCtx* c, const float* depth, unsigned long long* vis, size_t words);               // and back: depth << 32
-void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange, bool fromExchange);
-void launch_hzb_mip0_exchange(ChordCtx* c);
+void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange);
 void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange);   // mips 6.. + range from per-tile partials
 void launch_detile(ChordCtx* c, hipStream_t stream = nullptr);
-void launch_hzb_final_exchange(ChordCtx* c, HzbBuffers& out);
-void launch_hzb_build_final_from_exchange(ChordCtx* c, HzbBuffers& out);
-void launch_stripe_filter(ChordCtx* c, const CmdList& in, const CmdList& out);
+void launch_hzb_untile(ChordCtx* c, HzbBuffers& out, bool finalChain);   // exchanged tile slots -> mips 0..5 of the chain (final: min + max + per-tile ranges and loads)
+void launch_rank_filter(ChordCtx* c, const CmdList& in, const CmdList& out);
+int tile_layout(uint32_t tilesX, uint32_t tilesY, uint32_t ranks, const uint32_t* loads, uint32_t cap, uint8_t* owners);   // tile_layout.cpp
+int install_tile_owners(ChordCtx* c);                                     // chordvis_abi.cpp: c->tileOwners -> device tables
 void launch_visibility_mark(ChordCtx* c, const unsigned long long* vis, const ChordDrawCmd* cmds, const uint32_t* cmdCount, uint32_t* marker);
 void launch_shading_tiles(ChordCtx* c, const uint32_t* marker, uint32_t shadingType, uint32_t* tiles, uint32_t* count, uint32_t* args);
 void stamp(ChordCtx* c, int tag);               // no-op when timers are off

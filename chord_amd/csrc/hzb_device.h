@@ -7,13 +7,9 @@
 namespace chord {
 
 struct HzbParams {
-    const unsigned long long* vis; int32_t W, H;
-    ShardInfo shard;
+    const unsigned long long* vis; int32_t W, H;   // row-major visibility words (a sharded context: the resolved copy)
     ChordHZBDesc desc;
     uint16_t* hzbMin; uint16_t* hzbMax; uint32_t* validRange;
-    uint16_t* exchange;           // rank-major mip-0 min rows (sharded only)
-    uint16_t* exchangeMax;        // the same for the max chain (pipelined sharded frames: the history HZB from own-stripe mip 0), or NULL
-    uint32_t exchangePitch;       // halves per exchange row
     uint32_t* rangePartials;      // per mip-0 block {min bits, max bits}; reduced by the tail kernel
     uint32_t rangePartialCount;
 };

@@ -184,43 +184,36 @@ struct GroupCullParams {
     const ChordObject* objects; const DObjStatic* objStatic; const DObjFrame* objFrame; const DPrim* prims;
     const DGroup* groups; const uint32_t* groupIndices; const DMeshlet* meshlets; const uint32_t* groupOwner;
     const DView* dview; uint8_t* groupMask; uint32_t* blockCounts; uint32_t groupInstances;
-    // sharded frames: the commands whose clusters touch one of this rank's pixel rows are ALSO written to the rank's own
+    // sharded frames: the commands whose clusters touch one of this rank's screen tiles are ALSO written to the rank's own
     // list (in the same deterministic order), decided where the meshlet record is already in registers
-    ShardInfo shard; float H; int32_t Hi; ChordDrawCmd* mineCmds; uint32_t* mineCount;
+    ShardInfo shard; float W, H; int32_t Wi, Hi; ChordDrawCmd* mineCmds; uint32_t* mineCount;
 };
 
-// Does the cluster touch one of this rank's pixel rows?  Conservative: the 8 projected AABB corners, one pixel of slack; any
-// corner at or behind the camera plane keeps the cluster.  Dropping a cluster that fails is invisible in the image -- only
-// triangles without an owned row go, exactly as the per-triangle ownership test of the setup kernel would decide.
-__device__ __forceinline__ bool shard_owns_any_row(const ShardInfo& s, int32_t y0, int32_t y1)
-{
-    const uint32_t s0 = shard_stripe_of(s, (uint32_t)y0), s1 = shard_stripe_of(s, (uint32_t)y1);
-    if (s1 - s0 + 1u >= s.ranks) return true;
-    const uint32_t o0 = shard_owner_of_stripe(s, s0);
-    const uint32_t ahead = s.rank >= o0 ? s.rank - o0 : s.rank + s.ranks - o0;
-    return s0 + ahead <= s1;
-}
-
-__device__ __forceinline__ bool cluster_touches_rank(const ShardInfo& shard, const float* __restrict__ mv, const DMeshlet& m, float H, int32_t Hi)
+// Does the cluster touch one of this rank's screen tiles?  Conservative: the pixel rectangle of the 8 projected AABB corners, one
+// pixel of slack; any corner at or behind the camera plane keeps the cluster.  Dropping a cluster that fails is invisible in
+// the image -- only triangles without an owned pixel go, exactly as the per-tile ownership test of the binning would decide.
+__device__ __forceinline__ bool cluster_touches_rank(const ShardInfo& shard, const float* __restrict__ mv, const DMeshlet& m, float W, float H, int32_t Wi, int32_t Hi)
 {
     Mat4 mvp;
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = mv[r * 4 + cc];
-    float ylo = 3.0e38f, yhi = -3.0e38f;
+    float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
     bool unbounded = false;
 #pragma unroll
     for (uint32_t q = 0; q < 8u; q++) {
         const f4 h = mul_mv(mvp, (q & 1u) ? m.posMax[0] : m.posMin[0], (q & 2u) ? m.posMax[1] : m.posMin[1],
                             (q & 4u) ? m.posMax[2] : m.posMin[2], 1.0f);
-        const float y = (h.y / h.w * -0.5f + 0.5f) * H;
-        if (!(h.w > 1.0e-6f) || !(fabsf(y) < 1.0e7f)) unbounded = true;
-        else { ylo = fminf(ylo, y); yhi = fmaxf(yhi, y); }
+        const float x = (h.x / h.w * 0.5f + 0.5f) * W, y = (h.y / h.w * -0.5f + 0.5f) * H;
+        if (!(h.w > 1.0e-6f) || !(fabsf(y) < 1.0e7f) || !(fabsf(x) < 1.0e7f)) unbounded = true;
+        else { xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y); }
     }
     if (unbounded) return true;
+    const int32_t x0 = max((int32_t)floorf(xlo) - 1, 0), x1 = min((int32_t)ceilf(xhi) + 1, Wi - 1);
     const int32_t y0 = max((int32_t)floorf(ylo) - 1, 0), y1 = min((int32_t)ceilf(yhi) + 1, Hi - 1);
-    return y1 >= y0 && shard_owns_any_row(shard, y0, y1);
+    return x1 >= x0 && y1 >= y0 && shard_owns_any_tile(shard, (uint32_t)x0 >> CHORD_TILE_SHIFT, (uint32_t)y0 >> CHORD_TILE_SHIFT,
+                                                       (uint32_t)x1 >> CHORD_TILE_SHIFT, (uint32_t)y1 >> CHORD_TILE_SHIFT);
 }
 
 // The object pass as a kernel of its own: for long scenes (thousands of count blocks) the fused form below makes every count
@@ -289,7 +282,7 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
                 if (mask & (1u << i)) {
                     const DMeshlet& m = p.meshlets[prim.meshletBase + p.groupIndices[idxBase + i]];
                     tris += (m.vertexTriangleCount >> 8) & 0xFFu;
-                    if (sharded && cluster_touches_rank(p.shard, p.objFrame[o].mvp, m, p.H, p.Hi)) mine |= 1u << i;
+                    if (sharded && cluster_touches_rank(p.shard, p.objFrame[o].mvp, m, p.W, p.H, p.Wi, p.Hi)) mine |= 1u << i;
                 }
             if (sharded) p.groupMask[t] = (uint8_t)(mask | (mine << 4));
         }
@@ -316,7 +309,7 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
                     if (i < cnt && meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (st.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, m)) {
                         mask |= 1u << i;
                         tris += (m.vertexTriangleCount >> 8) & 0xFFu;
-                        if (sharded && cluster_touches_rank(p.shard, of.mvp, m, p.H, p.Hi)) mine |= 1u << i;
+                        if (sharded && cluster_touches_rank(p.shard, of.mvp, m, p.W, p.H, p.Wi, p.Hi)) mine |= 1u << i;
                     }
                 }
             }
@@ -878,13 +871,13 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     p.objects = c->dObjects; p.objStatic = c->dObjStatic; p.objFrame = c->dObjFrame; p.prims = c->dPrims;
     p.groups = c->dGroups; p.groupIndices = c->dGroupIndices; p.meshlets = c->dMeshlets; p.groupOwner = c->dGroupOwner;
     p.dview = c->dView; p.groupMask = c->dGroupMask; p.blockCounts = c->dBlockCounts; p.groupInstances = c->groupInstances;
-    p.shard = c->shard; p.H = (float)c->height; p.Hi = (int32_t)c->height; p.mineCmds = nullptr; p.mineCount = nullptr;
+    p.shard = c->shard; p.W = (float)c->width; p.H = (float)c->height; p.Wi = (int32_t)c->width; p.Hi = (int32_t)c->height; p.mineCmds = nullptr; p.mineCount = nullptr;
     c->mineValid = false;
-    if (c->shard.ranks > 1 && c->height) {
+    if (c->shard.ranks > 1 && c->height && c->shard.ownedRows) {
         // sharded frame: the rank's own commands leave the cull as a list of their own (no pass over the full list later)
         if (!c->dMineCmds && hipMalloc((void**)&c->dMineCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity) != hipSuccess) c->dMineCmds = nullptr;
         if (c->dMineCmds) { p.mineCmds = c->dMineCmds; p.mineCount = c->dCounts + 4; c->mineValid = true; }
-        else p.shard.ranks = 1;                              // (allocation failed: launch_raster falls back to the stripe filter)
+        else p.shard.ranks = 1;                              // (allocation failed: launch_raster falls back to the rank filter)
     } else p.shard.ranks = 1;
     const uint32_t blocks = c->cullBlocks;
     uint4* zeroBase = nullptr;
@@ -939,21 +932,18 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
 }
 
 // ---- sharded frames: this rank's clusters of a raster pass -----------------------------------------------------
-// One thread per command: a cluster whose projected bounds touch none of this rank's pixel rows is another rank's
-// work (conservative: 8 AABB corners, one pixel of slack; any corner at or behind the camera plane keeps the
-// cluster).  Dropping it is invisible in the image -- only triangles without an owned row go, exactly as the
-// per-triangle ownership test of the setup kernel would decide -- and makes the setup kernel's work 1/ranks of the
-// frame's.  (Done by one lane per cluster here rather than by the setup kernel's one WAVE per cluster: walking 8.4 M
-// clusters to keep 1 M cost 5 of 10 ms per frame on config 5 at 8 ranks.)  Same block-aggregated compaction as
-// hzb_cull_kernel; order is free (cmd.z is carried).
-struct StripeFilterParams {
+// One thread per command: a cluster whose projected bounds touch none of this rank's screen tiles is another rank's
+// work (cluster_touches_rank).  The lists of a frame never come here -- the group cull writes the rank's share itself and the
+// occlusion culls start from it; this pass is for lists of unknown origin handed to the stand-alone entry points.  Same
+// block-aggregated compaction as hzb_cull_kernel; order is free (cmd.z is carried).
+struct RankFilterParams {
     const DObjFrame* objFrame; const DMeshlet* meshlets;
     const uint32_t* inCount; const ChordDrawCmd* inCmds;
     uint32_t* outCount; ChordDrawCmd* outCmds;
-    ShardInfo shard; float H; int32_t Hi;
+    ShardInfo shard; float W, H; int32_t Wi, Hi;
 };
 
-__global__ __launch_bounds__(256) void stripe_filter_kernel(StripeFilterParams p)
+__global__ __launch_bounds__(256) void rank_filter_kernel(RankFilterParams p)
 {
     __shared__ uint32_t sWave[4], sBase;
     const uint32_t count = *p.inCount;
@@ -967,7 +957,7 @@ __global__ __launch_bounds__(256) void stripe_filter_kernel(StripeFilterParams p
             cmd[k] = ChordDrawCmd{0, 0, 0};
             if (i < count) {
                 cmd[k] = p.inCmds[i];
-                const bool mine = cluster_touches_rank(p.shard, p.objFrame[cmd[k].objectId].mvp, p.meshlets[cmd[k].meshletId], p.H, p.Hi);
+                const bool mine = cluster_touches_rank(p.shard, p.objFrame[cmd[k].objectId].mvp, p.meshlets[cmd[k].meshletId], p.W, p.H, p.Wi, p.Hi);
                 if (mine) keep |= 1u << k;
             }
         }
@@ -989,17 +979,17 @@ __global__ __launch_bounds__(256) void stripe_filter_kernel(StripeFilterParams p
     }
 }
 
-void launch_stripe_filter(ChordCtx* c, const CmdList& in, const CmdList& out)
+void launch_rank_filter(ChordCtx* c, const CmdList& in, const CmdList& out)
 {
-    StripeFilterParams p;
+    RankFilterParams p;
     p.objFrame = c->dObjFrame; p.meshlets = c->dMeshlets;
     p.inCount = in.count; p.inCmds = in.cmds; p.outCount = out.count; p.outCmds = out.cmds;
-    p.shard = c->shard; p.H = (float)c->height; p.Hi = (int32_t)c->height;
+    p.shard = c->shard; p.W = (float)c->width; p.H = (float)c->height; p.Wi = (int32_t)c->width; p.Hi = (int32_t)c->height;
     uint32_t blocks = (in.capacity + 1023u) / 1024u;
     const uint32_t maxBlocks = (uint32_t)c->numCUs * 8u;
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(stripe_filter_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(rank_filter_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
 }
 
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,

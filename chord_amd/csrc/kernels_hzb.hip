@@ -13,9 +13,9 @@
 // edge-clamped source depth, stored as binary16 (RNE); max chain carries +1 ulp from mip 5 up
 // (hzb.hlsl:67-71).  Only the sampled extent of each mip (x <= ((W-1)>>1)>>l) is defined.
 //
-// The sharded (multi-GPU) variant builds mip 0 for the rank's own stripes straight into the
-// rank-major exchange buffer; after the all-gather hzb_mips_kernel reads mip 0 through the
-// stripe map and also writes the canonical mip 0.
+// Sharded (multi-GPU) frames do not come here at all: the tile kernel reduces every owned tile to its HZB texels (mips 0..5)
+// into per-tile slots of an exchange buffer, the slots are all-gathered, and hzb_untile_kernel copies them to the chain
+// (DESIGN.md 6).  chordvis_build_hzb on a sharded context reads the resolved (row-major) image.
 
 #include "hzb_device.h"
 
@@ -23,25 +23,7 @@
 
 namespace chord {
 
-__device__ __forceinline__ size_t vis_row_base(const ShardInfo& s, bool sharded, uint32_t y, uint32_t W)
-{
-    if (!sharded) return (size_t)y * W;
-    const uint32_t stripe = shard_stripe_of(s, y), local = shard_div_ranks(s, stripe);
-    return ((size_t)((stripe - local * s.ranks) * s.stripesPerRank + local) * s.stripeRows + (y - stripe * s.stripeRows)) * (size_t)W;
-}
-
-// exchange-buffer row of mip-0 row y0 (pixel rows 2*y0, 2*y0+1 live in one stripe: stripeRows is even)
-__device__ __forceinline__ size_t exchange_row(const ShardInfo& s, uint32_t y0)
-{
-    const uint32_t half = s.stripeRows >> 1;
-    const uint32_t stripe = y0 / half;
-    return (size_t)((stripe % s.ranks) * s.stripesPerRank + stripe / s.ranks) * half + (y0 % half);
-}
-
-// MODE 0: full frame, row-major vis        -> canonical mip 0 (min, optional max, optional range)
-// MODE 1: own stripes of a rank-major vis  -> exchange buffer (min only)
-// MODE 2: full frame of a rank-major vis   -> canonical mip 0 (after the visibility all-gather)
-template <int MODE>
+// full frame, row-major visibility words -> mip 0 (min, optional max, optional range)
 __global__ __launch_bounds__(256) void hzb_mip0_kernel(HzbParams p, int wantMax, int wantRange)
 {
     const uint32_t vw = valid_w(p.desc, 0), vh = valid_h(p.desc, 0);
@@ -49,24 +31,18 @@ __global__ __launch_bounds__(256) void hzb_mip0_kernel(HzbParams p, int wantMax,
     const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
     float mn = 0.0f, mx = 0.0f;
     uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
-    bool act = x < vw && y < vh;
-    if (MODE == 1 && act) act = shard_owner_of_stripe(p.shard, shard_stripe_of(p.shard, 2u * y)) == p.shard.rank;
+    const bool act = x < vw && y < vh;
     if (act) {
         const uint32_t sx0 = min(2u * x, (uint32_t)p.W - 1u), sx1 = min(2u * x + 1u, (uint32_t)p.W - 1u);
         const uint32_t sy0 = min(2u * y, (uint32_t)p.H - 1u), sy1 = min(2u * y + 1u, (uint32_t)p.H - 1u);
-        const size_t r0 = vis_row_base(p.shard, MODE != 0, sy0, (uint32_t)p.W);
-        const size_t r1 = vis_row_base(p.shard, MODE != 0, sy1, (uint32_t)p.W);
+        const size_t r0 = (size_t)sy0 * (uint32_t)p.W, r1 = (size_t)sy1 * (uint32_t)p.W;
         const float d00 = __uint_as_float((uint32_t)(p.vis[r0 + sx0] >> 32));
         const float d10 = __uint_as_float((uint32_t)(p.vis[r0 + sx1] >> 32));
         const float d01 = __uint_as_float((uint32_t)(p.vis[r1 + sx0] >> 32));
         const float d11 = __uint_as_float((uint32_t)(p.vis[r1 + sx1] >> 32));
         mn = fminf(fminf(fminf(d00, d10), d01), d11);
         mx = fmaxf(fmaxf(fmaxf(d00, d10), d01), d11);
-        if (MODE == 1) {
-            const size_t eo = exchange_row(p.shard, y) * p.exchangePitch + x;
-            p.exchange[eo] = f32_to_f16(mn);
-            if (wantMax && p.exchangeMax) p.exchangeMax[eo] = f32_to_f16(mx);
-        } else {
+        {
             const uint32_t mw = max(1u, p.desc.width);
             p.hzbMin[p.desc.mipOffset[0] + y * mw + x] = f32_to_f16(mn);
             if (wantMax) p.hzbMax[p.desc.mipOffset[0] + y * mw + x] = f32_to_f16(mx);
@@ -83,7 +59,7 @@ __global__ __launch_bounds__(256) void hzb_mip0_kernel(HzbParams p, int wantMax,
             }
         }
     }
-    if (wantRange) {                                             // (MODE 1: of the rank's own stripes; blocks without an owned row write the neutral pair)
+    if (wantRange) {
         // The reference does one InterlockedMin/Max per wave on a single word (hzb.hlsl:168-176); on
         // MI355X one word sustains only ~88 atomics/us (32k waves at 4K = 0.7 ms), so each block
         // writes one partial instead and the single-block tail kernel reduces them.
@@ -103,9 +79,7 @@ __global__ __launch_bounds__(256) void hzb_mip0_kernel(HzbParams p, int wantMax,
     }
 }
 
-// One block per 32x32 mip-0 tile: mips 1..5.  FROM_EXCHANGE: read mip 0 (min) through the
-// stripe map and also emit the canonical mip 0.
-template <bool FROM_EXCHANGE>
+// One block per 32x32 mip-0 tile: mips 1..5.
 __global__ __launch_bounds__(256) void hzb_mips_kernel(HzbParams p, int wantMax)
 {
     __shared__ float sMin[16][17], sMax[16][17];
@@ -123,22 +97,8 @@ __global__ __launch_bounds__(256) void hzb_mips_kernel(HzbParams p, int wantMax)
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 const uint32_t cx = min(2u * X + i, pw - 1u), cy = min(2u * Y + j, ph - 1u);
-                float a, b = 0.0f;
-                if (FROM_EXCHANGE) {
-                    const size_t eo = exchange_row(p.shard, cy) * p.exchangePitch + cx;
-                    const uint16_t h = p.exchange[eo];
-                    a = f16_to_f32(h);
-                    const bool mine = 2u * X + i == cx && 2u * Y + j == cy;     // (not an edge-clamped duplicate)
-                    if (mine) p.hzbMin[d.mipOffset[0] + cy * pmw + cx] = h;
-                    if (wantMax) {
-                        const uint16_t hx = p.exchangeMax[eo];
-                        b = f16_to_f32(hx);
-                        if (mine) p.hzbMax[d.mipOffset[0] + cy * pmw + cx] = hx;
-                    }
-                } else {
-                    a = f16_to_f32(p.hzbMin[d.mipOffset[0] + cy * pmw + cx]);
-                    if (wantMax) b = f16_to_f32(p.hzbMax[d.mipOffset[0] + cy * pmw + cx]);
-                }
+                const float a = f16_to_f32(p.hzbMin[d.mipOffset[0] + cy * pmw + cx]);
+                const float b = wantMax ? f16_to_f32(p.hzbMax[d.mipOffset[0] + cy * pmw + cx]) : 0.0f;
                 if (i == 0 && j == 0) { mn = a; mx = b; } else { mn = fminf(mn, a); mx = fmaxf(mx, b); }
             }
         if (d.mipCount > 1 && X < valid_w(d, 1) && Y < valid_h(d, 1)) {
@@ -191,54 +151,76 @@ __global__ __launch_bounds__(256) void hzb_tail_kernel(HzbParams p, int wantMax,
     hzb_tail_block(p, wantMax, wantRange, firstLevel);
 }
 
-// rank-major (striped) visibility -> row-major
+// rank-major tile slots (64 rows of 64 words per tile) -> row-major: one block per tile, 16-byte loads and stores
 __global__ __launch_bounds__(256) void detile_kernel(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst,
                                                      uint32_t W, uint32_t H, ShardInfo shard)
 {
-    const uint32_t y = blockIdx.y;
-    const size_t sb = vis_row_base(shard, true, y, W);
-    for (uint32_t x = blockIdx.x * 256u + threadIdx.x; x < W; x += gridDim.x * 256u)
-        dst[(size_t)y * W + x] = src[sb + x];
+    const uint32_t tile = blockIdx.y * shard.tilesX + blockIdx.x;
+    const ulonglong2* __restrict__ s2 = reinterpret_cast<const ulonglong2*>(src + (size_t)shard.tileSlot[tile] * (CHORD_TILE * CHORD_TILE));
+    const uint32_t ox = blockIdx.x * CHORD_TILE, oy = blockIdx.y * CHORD_TILE;
+    for (uint32_t i = threadIdx.x; i < CHORD_TILE * CHORD_TILE / 2u; i += 256u) {
+        const uint32_t ly = i >> (CHORD_TILE_SHIFT - 1), lx = (i & (CHORD_TILE / 2u - 1u)) * 2u;
+        if (oy + ly >= H || ox + lx >= W) continue;
+        const ulonglong2 v = s2[i];
+        unsigned long long* d = dst + (size_t)(oy + ly) * W + ox + lx;
+        if (ox + lx + 1u < W) *reinterpret_cast<ulonglong2*>(d) = v;       // (W even or not: 16-byte aligned iff the row start is; checked by the launcher)
+        else d[0] = v.x;
+    }
+}
+__global__ __launch_bounds__(256) void detile_scalar_kernel(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst,
+                                                            uint32_t W, uint32_t H, ShardInfo shard)
+{
+    const uint32_t tile = blockIdx.y * shard.tilesX + blockIdx.x;
+    const unsigned long long* __restrict__ s1 = src + (size_t)shard.tileSlot[tile] * (CHORD_TILE * CHORD_TILE);
+    const uint32_t ox = blockIdx.x * CHORD_TILE, oy = blockIdx.y * CHORD_TILE;
+    for (uint32_t i = threadIdx.x; i < CHORD_TILE * CHORD_TILE; i += 256u) {
+        const uint32_t ly = i >> CHORD_TILE_SHIFT, lx = i & (CHORD_TILE - 1u);
+        if (oy + ly < H && ox + lx < W) dst[(size_t)(oy + ly) * W + ox + lx] = s1[i];
+    }
 }
 
-// One block: a rank's per-block valid-range partials -> its pair in the range exchange buffer (slot = rank).
-__global__ __launch_bounds__(256) void range_reduce_kernel(const uint32_t* __restrict__ partials, uint32_t count, uint32_t* __restrict__ outPair)
+// Exchanged tile slots -> the chain.  The tile kernel of a sharded frame reduces every tile it owns to the HZB texels the tile
+// covers (mips 0..5; tile_out_and_hzb in kernels_raster.hip) and stores them in the tile's slot of an exchange buffer; after the
+// all-gather every rank copies all slots -- its own included -- to their places in the chain.  One block per tile.
+// FINAL: the end-of-frame slots (min | max | valid range | bin entries): both chains, the per-tile range partials the tail
+// reduces, and every tile's load for the next re-balancing of the tile map.
+template <bool FINAL>
+__global__ __launch_bounds__(256) void hzb_untile_kernel(const uint16_t* __restrict__ exchange, ShardInfo shard, ChordHZBDesc d,
+                                                         uint16_t* __restrict__ hzbMin, uint16_t* __restrict__ hzbMax,
+                                                         uint32_t* __restrict__ tileRange, uint32_t* __restrict__ tileLoads)
 {
-    __shared__ uint32_t sMn[4], sMx[4];
-    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    for (uint32_t i = threadIdx.x; i < count; i += 256u) { mn = min(mn, partials[2u * i]); mx = max(mx, partials[2u * i + 1u]); }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = min(mn, (uint32_t)__shfl_down((int)mn, off, 64));
-        mx = max(mx, (uint32_t)__shfl_down((int)mx, off, 64));
+    const uint32_t tX = blockIdx.x, tY = blockIdx.y, tile = tY * shard.tilesX + tX;
+    const uint16_t* __restrict__ slot = exchange + (size_t)shard.tileSlot[tile] * (FINAL ? CHORD_HZB_FINAL_SLOT_HALVES : CHORD_HZB_SLOT_HALVES);
+    for (uint32_t l = 0; l < 6u && l < d.mipCount; l++) {
+        const uint32_t side = 32u >> l, off = hzb_slot_level_offset(l);
+        const uint32_t vw = valid_w(d, l), vh = valid_h(d, l), mw = max(1u, d.width >> l);
+        for (uint32_t i = threadIdx.x; i < side * side; i += 256u) {
+            const uint32_t lx = i & (side - 1u), ly = i >> (5u - l);
+            const uint32_t gx = tX * side + lx, gy = tY * side + ly;
+            if (gx >= vw || gy >= vh) continue;
+            const size_t o = d.mipOffset[l] + (size_t)gy * mw + gx;
+            hzbMin[o] = slot[off + i];
+            if (FINAL) hzbMax[o] = slot[CHORD_HZB_FINAL_MAX_OFFSET + off + i];
+        }
     }
-    if ((threadIdx.x & 63u) == 0u) { sMn[threadIdx.x >> 6] = mn; sMx[threadIdx.x >> 6] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0u) {
-        outPair[0] = min(min(sMn[0], sMn[1]), min(sMn[2], sMn[3]));
-        outPair[1] = max(max(sMx[0], sMx[1]), max(sMx[2], sMx[3]));
+    if (FINAL && threadIdx.x == 0u) {
+        const uint32_t* __restrict__ tail = reinterpret_cast<const uint32_t*>(slot + CHORD_HZB_FINAL_RANGE_OFFSET);
+        tileRange[2u * tile] = tail[0]; tileRange[2u * tile + 1u] = tail[1];
+        tileLoads[tile] = tail[2];
     }
 }
 
 static HzbParams make_params(ChordCtx* c, HzbBuffers& out)
 {
     HzbParams p;
-    p.vis = (const unsigned long long*)c->dVis; p.W = (int32_t)c->width; p.H = (int32_t)c->height;
-    p.shard = c->shard; p.desc = out.desc;
+    p.vis = (const unsigned long long*)(c->shard.ranks > 1 ? c->dVisResolved : c->dVis); p.W = (int32_t)c->width; p.H = (int32_t)c->height;
+    p.desc = out.desc;
     p.hzbMin = out.minTexels; p.hzbMax = out.maxTexels; p.validRange = out.validRange;
-    p.exchange = c->dHzbExchange; p.exchangeMax = nullptr; p.exchangePitch = out.desc.width;
     p.rangePartials = c->dRangePartials; p.rangePartialCount = 0;
     return p;
 }
 
-void launch_hzb_mip0_exchange(ChordCtx* c)
-{
-    HzbParams p = make_params(c, c->hzb[0]);
-    const uint32_t vw = min(p.desc.width, (((uint32_t)p.W - 1u) >> 1) + 1u), vh = min(p.desc.height, (((uint32_t)p.H - 1u) >> 1) + 1u);
-    hipLaunchKernelGGL(hzb_mip0_kernel<1>, dim3((vw + 63u) / 64u, (vh + 3u) / 4u), dim3(256), 0, c->stream, p, 0, 0);
-}
-
-void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange, bool fromExchange)
+void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool bValidRange)
 {
     (void)bMin;
     HzbParams p = make_params(c, out);
@@ -246,42 +228,23 @@ void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool b
     const uint32_t vw = min(p.desc.width, (((uint32_t)p.W - 1u) >> 1) + 1u), vh = min(p.desc.height, (((uint32_t)p.H - 1u) >> 1) + 1u);
     const dim3 g0((vw + 63u) / 64u, (vh + 3u) / 4u);
     p.rangePartialCount = g0.x * g0.y;
-    if (!fromExchange) {
-        if (c->shard.ranks > 1) hipLaunchKernelGGL(hzb_mip0_kernel<2>, g0, dim3(256), 0, c->stream, p, wantMax, wantRange);
-        else                    hipLaunchKernelGGL(hzb_mip0_kernel<0>, g0, dim3(256), 0, c->stream, p, wantMax, wantRange);
-    }
+    hipLaunchKernelGGL(hzb_mip0_kernel, g0, dim3(256), 0, c->stream, p, wantMax, wantRange);
     const dim3 g1((vw + 31u) / 32u, (vh + 31u) / 32u);
-    if (fromExchange) hipLaunchKernelGGL(hzb_mips_kernel<true>, g1, dim3(256), 0, c->stream, p, 0);
-    else              hipLaunchKernelGGL(hzb_mips_kernel<false>, g1, dim3(256), 0, c->stream, p, wantMax);
+    hipLaunchKernelGGL(hzb_mips_kernel, g1, dim3(256), 0, c->stream, p, wantMax);
     if (p.desc.mipCount > 6 || wantRange) hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, wantMax, wantRange, 6u);
     out.valid = true;
 }
 
-// Pipelined sharded frame: the FINAL chain of a frame from the ranks' own-stripe mip 0 instead of from the
-// gathered visibility words.  Step 1, before the exchange: own-stripe mip 0 min + max into the two exchange buffers, the
-// rank's valid-range pair into its slot of the range exchange.
-void launch_hzb_final_exchange(ChordCtx* c, HzbBuffers& out)
+// Sharded frames: the all-gathered tile slots of an exchange buffer -> mips 0..5 of `out` (the tail, mips 6.. and the valid
+// range, is left to whoever needs the chain next: the phase-1 cull reduces it itself, the history chain's rides on the next
+// frame's first kernel -- as in the single-GPU frame, whose tile kernel writes the same texels straight into the chain).
+void launch_hzb_untile(ChordCtx* c, HzbBuffers& out, bool finalChain)
 {
-    HzbParams p = make_params(c, out);
-    p.exchangeMax = c->dHzbExchangeMax;
-    const uint32_t vw = min(p.desc.width, (((uint32_t)p.W - 1u) >> 1) + 1u), vh = min(p.desc.height, (((uint32_t)p.H - 1u) >> 1) + 1u);
-    const dim3 g0((vw + 63u) / 64u, (vh + 3u) / 4u);
-    hipLaunchKernelGGL(hzb_mip0_kernel<1>, g0, dim3(256), 0, c->stream, p, 1, 1);
-    hipLaunchKernelGGL(range_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const uint32_t*)c->dRangePartials, g0.x * g0.y,
-                       c->dRangeExchange + 2u * c->shard.rank);
-}
-
-// Step 2, after the three exchange buffers were all-gathered: mips 0..5 of both chains from the exchanged mip 0, the tail
-// and the valid range from the ranks' pairs -- the chain chordvis_build_hzb(min, max, range) makes from the full image.
-void launch_hzb_build_final_from_exchange(ChordCtx* c, HzbBuffers& out)
-{
-    HzbParams p = make_params(c, out);
-    p.exchangeMax = c->dHzbExchangeMax;
-    const uint32_t vw = min(p.desc.width, (((uint32_t)p.W - 1u) >> 1) + 1u), vh = min(p.desc.height, (((uint32_t)p.H - 1u) >> 1) + 1u);
-    const dim3 g1((vw + 31u) / 32u, (vh + 31u) / 32u);
-    hipLaunchKernelGGL(hzb_mips_kernel<true>, g1, dim3(256), 0, c->stream, p, 1);
-    p.rangePartials = c->dRangeExchange; p.rangePartialCount = c->shard.ranks;
-    hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, 1, 1, 6u);
+    const dim3 g(c->tilesX, c->tilesY);
+    if (finalChain) hipLaunchKernelGGL(hzb_untile_kernel<true>, g, dim3(256), 0, c->stream, (const uint16_t*)c->dHzbFinalExchange, c->shard, out.desc,
+                                       out.minTexels, out.maxTexels, c->dTileRange, c->dTileLoads);
+    else            hipLaunchKernelGGL(hzb_untile_kernel<false>, g, dim3(256), 0, c->stream, (const uint16_t*)c->dHzbExchange, c->shard, out.desc,
+                                       out.minTexels, (uint16_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     out.valid = true;
 }
 
@@ -325,9 +288,12 @@ void launch_depth_expand(ChordCtx* c, const float* depth, unsigned long long* vi
 
 void launch_detile(ChordCtx* c, hipStream_t stream)
 {
-    const dim3 g((c->width + 255u) / 256u > 8u ? 8u : (c->width + 255u) / 256u, c->height);
-    hipLaunchKernelGGL(detile_kernel, g, dim3(256), 0, stream ? stream : c->stream, (const unsigned long long*)c->dVis,
-                       (unsigned long long*)c->dVisResolved, c->width, c->height, c->shard);
+    const dim3 g(c->tilesX, c->tilesY);
+    // (16-byte stores need every row start 16-byte aligned: an even width)
+    if ((c->width & 1u) == 0u) hipLaunchKernelGGL(detile_kernel, g, dim3(256), 0, stream ? stream : c->stream, (const unsigned long long*)c->dVis,
+                                                  (unsigned long long*)c->dVisResolved, c->width, c->height, c->shard);
+    else hipLaunchKernelGGL(detile_scalar_kernel, g, dim3(256), 0, stream ? stream : c->stream, (const unsigned long long*)c->dVis,
+                            (unsigned long long*)c->dVisResolved, c->width, c->height, c->shard);
 }
 
 } // namespace chord

@@ -85,6 +85,9 @@ struct RasterParams {
     ChordHZBDesc hzbDesc;
     uint16_t* hzbMinA;                                  // temporary chain for stage 1 (first pass only) or NULL
     uint16_t* hzbMinB; uint16_t* hzbMaxB;               // chain kept as history
+    // sharded frames: the texels go to the tile's slot of the exchange buffers instead (all-gathered, then hzb_untile_kernel)
+    uint16_t* hzbExA;                                   // mid-frame exchange (min chain after the first pass), or NULL
+    uint16_t* hzbExB;                                   // end-of-frame exchange (min | max | valid range | bin entries)
     uint32_t* tileRange;                                // per tile {min bits, max bits} of valid depth
     unsigned long long* tileClocks;                     // debug: per-tile elapsed wall clock ticks (DBG_TILE_CLOCKS)
     unsigned long long* tilePhase;                      // debug: 8 phase accumulators per tile
@@ -141,33 +144,16 @@ __device__ __forceinline__ int32_t bcast(int32_t v, int src) { return __builtin_
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 __device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
-template <bool SH>
-__device__ __forceinline__ bool owns_row(const ShardInfo& s, int32_t y)
-{
-    if (!SH) return true;
-    return shard_owner_of_stripe(s, shard_stripe_of(s, (uint32_t)y)) == s.rank;
-}
-
-template <bool SH>
-__device__ __forceinline__ size_t row_base(const ShardInfo& s, int32_t y, int32_t Wi)
-{
-    if (!SH) return (size_t)y * (size_t)Wi;
-    const uint32_t stripe = shard_stripe_of(s, (uint32_t)y);
-    const uint32_t local = shard_div_ranks(s, stripe);
-    const uint32_t owner = stripe - local * s.ranks;
-    return ((size_t)(owner * s.stripesPerRank + local) * s.stripeRows + ((uint32_t)y - stripe * s.stripeRows)) * (size_t)Wi;
-}
-
-// does the rank own at least one pixel row in [y0, y1]?  (ranks == 1: always)
-__device__ __forceinline__ bool owns_any_row(const ShardInfo& s, int32_t y0, int32_t y1)
+// Sharded frames: does this rank own tile (tx, ty) / a tile under the pixel rectangle?  (ranks == 1: always)
+__device__ __forceinline__ bool owns_tile(const ShardInfo& s, int32_t tx, int32_t ty)
 {
     if (s.ranks <= 1) return true;
-    const uint32_t s0 = shard_stripe_of(s, (uint32_t)y0), s1 = shard_stripe_of(s, (uint32_t)y1);
-    if (s1 - s0 + 1u >= s.ranks) return true;
-    // the stripes s0..s1 (fewer than `ranks` of them) contain one of this rank's iff the first one at or after s0 is <= s1
-    const uint32_t o0 = shard_owner_of_stripe(s, s0);
-    const uint32_t ahead = s.rank >= o0 ? s.rank - o0 : s.rank + s.ranks - o0;
-    return s0 + ahead <= s1;
+    return shard_owns_tile(s, (uint32_t)tx, (uint32_t)ty);
+}
+__device__ __forceinline__ bool owns_rect(const ShardInfo& s, int32_t px0, int32_t py0, int32_t px1, int32_t py1)
+{
+    if (s.ranks <= 1) return true;
+    return shard_owns_any_tile(s, (uint32_t)px0 >> TILE_SHIFT, (uint32_t)py0 >> TILE_SHIFT, (uint32_t)px1 >> TILE_SHIFT, (uint32_t)py1 >> TILE_SHIFT);
 }
 
 // depth clamp (shadow views): the near / far planes do not clip
@@ -323,8 +309,8 @@ __device__ __forceinline__ RecordEmitParams load_record_emit_params()
     e.tileCount = scalar_load(&q->tileCount); e.tileBins = scalar_load(&q->tileBins); e.binCap = scalar_load(&q->binCap); e.tilesX = scalar_load(&q->tilesX);
     e.binPool = scalar_load(&q->binPool); e.binPoolChunks = scalar_load(&q->binPoolChunks); e.binPoolCount = scalar_load(&q->binPoolCount);
     e.binChunkTab = scalar_load(&q->binChunkTab); e.binStamp = scalar_load(&q->binStamp); e.binMaxChunks = scalar_load(&q->binMaxChunks);
-    e.shard.stripeRows = scalar_load(&q->shard.stripeRows); e.shard.ranks = scalar_load(&q->shard.ranks); e.shard.rank = scalar_load(&q->shard.rank);
-    e.shard.stripesPerRank = scalar_load(&q->shard.stripesPerRank); e.shard.stripeMagic = scalar_load(&q->shard.stripeMagic); e.shard.rankMagic = scalar_load(&q->shard.rankMagic);
+    e.shard.ranks = scalar_load(&q->shard.ranks); e.shard.rank = scalar_load(&q->shard.rank); e.shard.slotsPerRank = 0u; e.shard.tilesX = 0u;
+    e.shard.ownedRows = scalar_load(&q->shard.ownedRows); e.shard.tileSlot = nullptr;
     return e;
 }
 
@@ -423,7 +409,7 @@ __device__ __forceinline__ void wave_bin_issue(const P& p, bool emitA, const Tri
         const int32_t tx0 = ts.px0 >> TILE_SHIFT, tx1 = ts.px1 >> TILE_SHIFT, ty0 = ts.py0 >> TILE_SHIFT, ty1 = ts.py1 >> TILE_SHIFT;
         const int32_t tx = (r & 1) ? tx1 : tx0, ty = (r & 2) ? ty1 : ty0;
         bool has = emit && !((r & 1) && tx1 == tx0) && !((r & 2) && ty1 == ty0);
-        if (has) has = owns_any_row(p.shard, max(ts.py0, ty << TILE_SHIFT), min(ts.py1, (ty << TILE_SHIFT) + TILE - 1));
+        if (has) has = owns_tile(p.shard, tx, ty);
         tile = has ? (uint32_t)ty * p.tilesX + (uint32_t)tx : 0u;
         return has;
     };
@@ -591,8 +577,7 @@ __device__ __forceinline__ void setup_emit_mask_ext(const RasterParams& p, TriRe
 
 template <int PITCH>
 __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
-                                                   int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels,
-                                                   unsigned long long rowMask, const bool clampZ);
+                                                   int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels, const bool clampZ);
 
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v)
 {
@@ -760,7 +745,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
                         ts.X[0] = (int32_t)rintf((u0 * p.W) * 256.0f); ts.Y[0] = (int32_t)rintf((v0 * p.H) * 256.0f);
                         ts.X[1] = (int32_t)rintf((u1 * p.W) * 256.0f); ts.Y[1] = (int32_t)rintf((v1 * p.H) * 256.0f);
                         ts.X[2] = (int32_t)rintf((u2 * p.W) * 256.0f); ts.Y[2] = (int32_t)rintf((v2 * p.H) * 256.0f);
-                        if (tri_setup(ts, twoSided, p.Wi, p.Hi) && owns_any_row(p.shard, ts.py0, ts.py1)) {
+                        if (tri_setup(ts, twoSided, p.Wi, p.Hi) && owns_rect(p.shard, ts.px0, ts.py0, ts.px1, ts.py1)) {
                             kind = K_EMIT;
                             if (p.biasConst != 0.0f || p.biasSlope != 0.0f) { const float o = depth_bias(ts, d, p.biasConst, p.biasSlope); d[0] += o; d[1] += o; d[2] += o; }
                         }
@@ -964,7 +949,8 @@ __device__ __forceinline__ int classify_triangle(const RasterParams& p, uint32_t
     ts.X[1] = (int32_t)rintf((u1 * p.W) * 256.0f); ts.Y[1] = (int32_t)rintf((v1 * p.H) * 256.0f);
     ts.X[2] = (int32_t)rintf((u2 * p.W) * 256.0f); ts.Y[2] = (int32_t)rintf((v2 * p.H) * 256.0f);
     bool small;
-    if (!tri_setup_geom(ts, twoSided, p.Wi, p.Hi, small) || !owns_any_row(p.shard, ts.py0, ts.py1)) return K_NONE;
+    // (sharded frames: ownership is decided per window part, below -- a cluster that straddles two ranks' tiles is small)
+    if (!tri_setup_geom(ts, twoSided, p.Wi, p.Hi, small)) return K_NONE;
     boxX = (uint32_t)ts.px0 | ((uint32_t)ts.px1 << 16); boxY = (uint32_t)ts.py0 | ((uint32_t)ts.py1 << 16);
     narrow = narrow_extent(ts);
     return K_EMIT;
@@ -973,7 +959,7 @@ __device__ __forceinline__ int classify_triangle(const RasterParams& p, uint32_t
 // set-up of an emitted, narrow triangle again from LDS and its scan conversion into the wave's pixel window
 __device__ __forceinline__ void resolve_triangle(const RasterParams& p, uint32_t t, uint32_t slot, uint32_t packedIdx, bool twoSided,
                                                  const float* lU, const float* lV, const float* lD, unsigned long long* win,
-                                                 int32_t bx0, int32_t by0, unsigned long long rowMaskW)
+                                                 int32_t bx0, int32_t by0)
 {
     const uint32_t i0 = packedIdx & 0xFFu, i1 = (packedIdx >> 8) & 0xFFu, i2 = (packedIdx >> 16) & 0xFFu;
     TriSetup ts;
@@ -985,7 +971,7 @@ __device__ __forceinline__ void resolve_triangle(const RasterParams& p, uint32_t
     if (p.biasConst != 0.0f || p.biasSlope != 0.0f) { const float o = depth_bias(ts, d, p.biasConst, p.biasSlope); d[0] += o; d[1] += o; d[2] += o; }
     ts.payload = p.depthOnly ? 0u : encode_triangle_instance(t, slot);
     ts.d0 = d[0]; ts.e1 = d[1] - d[0]; ts.e2 = d[2] - d[0];
-    tile_raster_narrow<WIN>(win, ts, bx0, by0, ts.px0, ts.py0, ts.px1, ts.py1, false, rowMaskW, p.depthClamp != 0u);
+    tile_raster_narrow<WIN>(win, ts, bx0, by0, ts.px0, ts.py0, ts.px1, ts.py1, false, p.depthClamp != 0u);
 }
 
 // Hot tiles (BASELINE config 5, variant "hotspot": one screen tile receives 12 % of the frame's 10 M blocks): every bin slot
@@ -1143,7 +1129,7 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                     const int32_t rx0 = sx ? tx1 << TILE_SHIFT : bx0, rx1 = (sx || tx1 == tx0) ? bx1 : (tx0 << TILE_SHIFT) + TILE - 1;
                     const int32_t ry0 = sy ? ty1 << TILE_SHIFT : by0, ry1 = (sy || ty1 == ty0) ? by1 : (ty0 << TILE_SHIFT) + TILE - 1;
                     const uint32_t rw = (uint32_t)(rx1 - rx0 + 1), rh = (uint32_t)(ry1 - ry0 + 1);
-                    const bool has = lane < 4u && !(sx && tx1 == tx0) && !(sy && ty1 == ty0) && owns_any_row(p.shard, ry0, ry1);
+                    const bool has = lane < 4u && !(sx && tx1 == tx0) && !(sy && ty1 == ty0) && owns_tile(p.shard, sx ? tx1 : tx0, sy ? ty1 : ty0);
                     const uint32_t hasMask = (uint32_t)__ballot(has) & 15u;
                     const uint32_t gran = has ? (rw * rh + 2u) >> 1 : 0u;              // header + w x h words, in 16-byte granules
                     const uint32_t g0 = bcast(gran, 0), g1 = bcast(gran, 1), g2 = bcast(gran, 2), g3 = bcast(gran, 3);
@@ -1173,15 +1159,12 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                     // ... and the cluster is resolved while they are in flight
 #pragma unroll
                     for (int k = 0; k < WIN * WIN / 64; k++) win[lane + 64u * k] = 0ull;
-                    unsigned long long rowMaskW = ~0ull;
-                    if (p.shard.ranks > 1u) {
-                        rowMaskW = 0ull;
-                        for (int32_t ly = 0; ly <= by1 - by0; ly++) if (owns_row<true>(p.shard, by0 + ly)) rowMaskW |= 1ull << ly;
-                    }
                     WAVE_LDS_SYNC();
-                    if (eA) resolve_triangle(p, lane, hdr.slot, t0, twoSided, lU, lV, lD, win, bx0, by0, rowMaskW);
+                    // (a sharded frame's cluster none of whose window parts is this rank's: the conservative cluster test let it through)
+                    const bool anyPart = hasMask != 0u;
+                    if (eA && anyPart) resolve_triangle(p, lane, hdr.slot, t0, twoSided, lU, lV, lD, win, bx0, by0);
                     __builtin_amdgcn_sched_barrier(0);                           // (one triangle's set-up alive at a time)
-                    if (eB) resolve_triangle(p, lane + 64u, hdr.slot, t1, twoSided, lU, lV, lD, win, bx0, by0, rowMaskW);
+                    if (eB && anyPart) resolve_triangle(p, lane + 64u, hdr.slot, t1, twoSided, lU, lV, lD, win, bx0, by0);
                     WAVE_LDS_SYNC();
                     SPHASE(3);
                     gbase = bcast(gbase, 0);
@@ -1316,7 +1299,7 @@ __device__ void bin_record_tiles(const RasterParams& p, const TriSetup& ts, uint
         for (int32_t tx = tx0; tx <= tx1; tx++) {
             const int32_t rx0 = max(ts.px0, tx << TILE_SHIFT), rx1 = min(ts.px1, (tx << TILE_SHIFT) + TILE - 1);
             const int32_t ry0 = max(ts.py0, ty << TILE_SHIFT), ry1 = min(ts.py1, (ty << TILE_SHIFT) + TILE - 1);
-            bool hit = owns_any_row(p.shard, ry0, ry1);
+            bool hit = owns_tile(p.shard, tx, ty);
 #pragma unroll
             for (int i = 0; i < 3; i++) {                         // (unrolled, no early exit: the vertex arrays stay in registers)
                 const int64_t dxe = (int64_t)(ts.X[eb[i]] - ts.X[ea[i]]), dye = (int64_t)(ts.Y[eb[i]] - ts.Y[ea[i]]);
@@ -1464,7 +1447,7 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
             ts.Y[0] = L.Y(0); ts.Y[1] = L.Y(i); ts.Y[2] = L.Y(i + 1);
             float d[3] = {L.D(0), L.D(i), L.D(i + 1)};
             ts.payload = payload;
-            if (!tri_setup(ts, twoSided, p.Wi, p.Hi) || !owns_any_row(p.shard, ts.py0, ts.py1)) continue;
+            if (!tri_setup(ts, twoSided, p.Wi, p.Hi) || !owns_rect(p.shard, ts.px0, ts.py0, ts.px1, ts.py1)) continue;
             if (p.biasConst != 0.0f || p.biasSlope != 0.0f) { const float o = depth_bias(ts, d, p.biasConst, p.biasSlope); d[0] += o; d[1] += o; d[2] += o; }
             const uint32_t li = atomicAdd(&p.counters->triCount[listShard * CHORD_SHARD_STRIDE], slots);
             if (li + slots > p.triCap) { atomicOr(&p.counters->overflow, 1u); continue; }
@@ -1530,7 +1513,7 @@ __device__ void raster_bin_large_part(const RasterParams& p, uint32_t block, uin
             // pixel rectangle of this tile clipped to the triangle's bbox; conservative edge test at its corners
             const int32_t rx0 = max(ts.px0, tx << TILE_SHIFT), rx1 = min(ts.px1, (tx << TILE_SHIFT) + TILE - 1);
             const int32_t ry0 = max(ts.py0, ty << TILE_SHIFT), ry1 = min(ts.py1, (ty << TILE_SHIFT) + TILE - 1);
-            bool hit = owns_any_row(p.shard, ry0, ry1);
+            bool hit = owns_tile(p.shard, tx, ty);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const int64_t cx = (int64_t)(a[i] > 0 ? rx1 : rx0) * 256 + 128, cy = (int64_t)(b[i] > 0 ? ry1 : ry0) * 256 + 128;
@@ -1579,7 +1562,8 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
     for (uint32_t k = 0; k < PER_THREAD; k++) {
         const uint32_t t = threadIdx.x + k * NT;
         myBucket[k] = 0xFFFFFFFFu; myPos[k] = 0; mySlices[k] = 1; myCount[k] = 0;
-        if (t < tiles) {
+        // (sharded frames: another rank's tiles are not work items at all -- their bins are empty, and the clear pass must not touch them)
+        if (t < tiles && owns_tile(p.shard, (int32_t)(t % p.tilesX), (int32_t)(t / p.tilesX))) {
             const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], bin_capacity(p));
             myCount[k] = c;
             if (c > TILE_SPLIT_MIN && !ABL(p, DBG_NO_SPLIT)) {
@@ -1667,8 +1651,7 @@ __device__ __forceinline__ void lds_write(unsigned long long* tile, int32_t lx, 
 // 16x1 box in the same wave = 256 trips); flattened it pays max(area) <= the tile's tiny-area threshold.
 template <int PITCH>
 __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
-                                                   int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels,
-                                                   unsigned long long rowMask, const bool clampZ)
+                                                   int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels, const bool clampZ)
 {
     // (32-bit multiplies are quarter rate on this GPU; every product here has factors below 2^23 -- vertices at most 64 px
     // apart, a pixel centre inside their bbox -- and takes the full-rate 24-bit form; +-s is a select, not a multiply)
@@ -1690,14 +1673,14 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
     int32_t E0 = r0, E1 = r1, E2 = r2;
     const int32_t w = x1 - x0 + 1, count = __mul24(w, y1 - y0 + 1);
     // step to the next pixel / from the last pixel of a row to the first of the next; the body is branch-free:
-    // a pixel outside the triangle (or in a row another rank owns) merges 0, which ds_max ignores
+    // a pixel outside the triangle merges 0, which ds_max ignores
     const int32_t sx0 = a0 * 256, sx1 = a1 * 256, sx2 = a2 * 256;
     const int32_t sw0 = b0 * 256 - __mul24(w - 1, sx0), sw1 = b1 * 256 - __mul24(w - 1, sx1), sw2 = b2 * 256 - __mul24(w - 1, sx2);
-    int32_t ly = y0 - oy, col = 0;
-    unsigned long long* px = tile + ly * PITCH + (x0 - ox);
+    int32_t col = 0;
+    unsigned long long* px = tile + (y0 - oy) * PITCH + (x0 - ox);
     const unsigned long long payload = (unsigned long long)ts.payload;
     for (int32_t i = 0; i < count; i++) {
-        const bool inside = (E0 | E1 | E2) >= 0 && ((rowMask >> ly) & 1ull) && !noPixels;
+        const bool inside = (E0 | E1 | E2) >= 0 && !noPixels;
         const float l1 = (float)(E1 - bias1) * ts.invA, l2 = (float)(E2 - bias2) * ts.invA;
         float z = (ts.d0 + l1 * ts.e1) + l2 * ts.e2;
         if (clampZ) z = fminf(fmaxf(z, 0.0f), 1.0f);
@@ -1706,7 +1689,6 @@ __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, con
         const bool wrap = col == w;
         E0 += wrap ? sw0 : sx0; E1 += wrap ? sw1 : sx1; E2 += wrap ? sw2 : sx2;
         px += wrap ? PITCH - w + 1 : 1;
-        ly += wrap ? 1 : 0;
         col = wrap ? 0 : col;
     }
 }
@@ -1994,12 +1976,11 @@ __device__ __forceinline__ void masked_row(const RasterParams& p, unsigned long 
 // one unit = (entry e, its j-th (row, segment))
 template <bool MASKED, bool DEPTH>
 __device__ __forceinline__ int32_t entry_unit(const RasterParams& p, const EntrySoA& en, unsigned long long* tile, uint32_t e, uint32_t row, uint32_t seg,
-                                           int32_t ox, int32_t oy, unsigned long long rowMask, bool noPixels)
+                                           int32_t ox, int32_t oy, bool noPixels)
 {
     const uint32_t box = en.w[11][e];
     const int32_t bx0 = (int32_t)(box & 63u), bx1 = (int32_t)((box >> 12) & 63u);
     const int32_t ly = (int32_t)row;
-    if (!((rowMask >> ly) & 1ull)) return 0;
     const int32_t lx0 = bx0 + (int32_t)(seg << SEG_SHIFT), lx1 = min(bx1, lx0 + SEG - 1);
     unsigned long long* tileRow = tile + ly * TPITCH;
     const float d0 = __uint_as_float(en.w[6][e]), e1 = __uint_as_float(en.w[7][e]), e2 = __uint_as_float(en.w[8][e]);
@@ -2044,7 +2025,8 @@ __device__ __forceinline__ int32_t entry_unit(const RasterParams& p, const Entry
 struct TileOutParams {
     ChordHZBDesc hzbDesc;                                   // (only the fields the reduction uses are loaded)
     uint16_t* hzbMinA; uint16_t* hzbMinB; uint16_t* hzbMaxB; uint32_t* tileRange;
-    unsigned long long* vis; float* depthOut; int32_t Wi; uint32_t tilesX; uint32_t debug;
+    uint16_t* hzbExA; uint16_t* hzbExB;
+    unsigned long long* vis; float* depthOut; int32_t Wi; uint32_t tilesX; uint32_t debug; uint32_t clearTiles;
 };
 __device__ __forceinline__ TileOutParams load_tile_out_params()
 {
@@ -2056,32 +2038,48 @@ __device__ __forceinline__ TileOutParams load_tile_out_params()
 #pragma unroll
     for (int l = 0; l < 6; l++) t.hzbDesc.mipOffset[l] = scalar_load(&q->hzbDesc.mipOffset[l]);
     t.hzbMinA = scalar_load(&q->hzbMinA); t.hzbMinB = scalar_load(&q->hzbMinB); t.hzbMaxB = scalar_load(&q->hzbMaxB);
+    t.hzbExA = scalar_load(&q->hzbExA); t.hzbExB = scalar_load(&q->hzbExB);
     t.tileRange = scalar_load(&q->tileRange); t.vis = scalar_load(&q->vis); t.depthOut = scalar_load(&q->depthOut);
-    t.Wi = scalar_load(&q->Wi); t.tilesX = scalar_load(&q->tilesX); t.debug = scalar_load(&q->debug);
+    t.Wi = scalar_load(&q->Wi); t.tilesX = scalar_load(&q->tilesX); t.debug = scalar_load(&q->debug); t.clearTiles = scalar_load(&q->clearTiles);
     return t;
 }
 
-template <bool INTERIOR>
+// SH: a tile of a sharded frame -- the words go to the tile's slot of the rank's chunk (tile-linear), the HZB texels, the valid
+// range and the tile's bin length to its slots of the exchange buffers.
+template <bool INTERIOR, bool SH>
 __device__ __forceinline__ void tile_out_and_hzb_body(const TileOutParams& p, const unsigned long long* tile, float* sM2, uint32_t* sRange,
-                                                      uint32_t tileId, int32_t ox, int32_t oy, int32_t tw, int32_t th)
+                                                      uint32_t tileId, uint32_t slotId, uint32_t binLength, int32_t ox, int32_t oy, int32_t tw, int32_t th)
 {
     static_assert(TILE == 64 && TB == 512, "wave w <-> pixel rows 8w..8w+7");
     const ChordHZBDesc& d = p.hzbDesc;
     const uint32_t tX = tileId % p.tilesX, tY = tileId / p.tilesX;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = lane >> 5, l = lane & 31u;
+    uint16_t* exA = SH && p.hzbExA ? p.hzbExA + (size_t)slotId * CHORD_HZB_SLOT_HALVES : nullptr;
+    uint16_t* exB = SH ? p.hzbExB + (size_t)slotId * CHORD_HZB_FINAL_SLOT_HALVES : nullptr;
     auto vw = [&](uint32_t lv) { return min(max(1u, d.width >> lv), (((d.srcWidth - 1u) >> 1) >> lv) + 1u); };
     auto vh = [&](uint32_t lv) { return min(max(1u, d.height >> lv), (((d.srcHeight - 1u) >> 1) >> lv) + 1u); };
-    auto put = [&](uint32_t lv, uint32_t gx, uint32_t gy, float mn, float mx) {
+    // texel (lx, ly) of the tile's (32 >> lv)^2 texels at level lv
+    auto put = [&](uint32_t lv, uint32_t lx, uint32_t ly, float mn, float mx) {
+        const uint32_t side = 32u >> lv, gx = tX * side + lx, gy = tY * side + ly;
         if (INTERIOR || (lv < d.mipCount && gx < vw(lv) && gy < vh(lv))) {
-            const size_t o = d.mipOffset[lv] + (size_t)gy * max(1u, d.width >> lv) + gx;
             const uint16_t hmn = f32_to_f16(mn);
             uint16_t hmx = f32_to_f16(mx);
             if (lv == 5u) hmx = (uint16_t)(hmx + 1u);                       // storeHZBMip5
-            if (p.hzbMinA) p.hzbMinA[o] = hmn;
-            p.hzbMinB[o] = hmn;
-            p.hzbMaxB[o] = hmx;
+            if (SH) {
+                const uint32_t o = hzb_slot_level_offset(lv) + ly * side + lx;
+                if (exA) exA[o] = hmn;
+                exB[o] = hmn;
+                exB[CHORD_HZB_FINAL_MAX_OFFSET + o] = hmx;
+            } else {
+                const size_t o = d.mipOffset[lv] + (size_t)gy * max(1u, d.width >> lv) + gx;
+                if (p.hzbMinA) p.hzbMinA[o] = hmn;
+                p.hzbMinB[o] = hmn;
+                p.hzbMaxB[o] = hmx;
+            }
         }
     };
+    const size_t visBase = SH ? (size_t)slotId * (size_t)(TILE * TILE) : (size_t)oy * (size_t)p.Wi + (size_t)ox;
+    const size_t visPitch = SH ? (size_t)TILE : (size_t)p.Wi;
     // A lane owns 2x2 pixel quads: column pair l, row pairs q = 2 half + rp (rp = 0, 1) of the wave's four.  A mip-0 texel
     // is lane-local, a mip-1 texel is the lane's two iterations and its x neighbour (DPP), a mip-2 texel adds the x
     // neighbour two over and the other half of the wave (the one cross-half exchange per lane); 8-byte LDS reads of
@@ -2095,7 +2093,7 @@ __device__ __forceinline__ void tile_out_and_hzb_body(const TileOutParams& p, co
         const int32_t r0 = min(row, th - 1), r1 = min(row + 1, th - 1), xa = min(x2, tw - 1), xb = min(x2 + 1, tw - 1);
         const unsigned long long v00 = tile[r0 * TPITCH + xa], v01 = tile[r0 * TPITCH + xb];
         const unsigned long long v10 = tile[r1 * TPITCH + xa], v11 = tile[r1 * TPITCH + xb];
-        if (p.depthOut) {
+        if (!SH && p.depthOut) {
             // depth-only pass (renderMeshDepth): what leaves the tile is the D32 image -- the high halves of the words, 8 bytes
             // per lane and row (no 64-bit image, no extract pass afterwards)
             if (INTERIOR || x2 < tw) {
@@ -2107,9 +2105,9 @@ __device__ __forceinline__ void tile_out_and_hzb_body(const TileOutParams& p, co
             }
         } else
         if (!ABL(p, DBG_NO_VIS_STORE) && (INTERIOR || x2 < tw)) {
-            unsigned long long* dst = p.vis + (size_t)(oy + row) * (size_t)p.Wi + ox + x2;
+            unsigned long long* dst = p.vis + visBase + (size_t)row * visPitch + x2;
             if (INTERIOR || row < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(v00, v01); else dst[0] = v00; }
-            if (INTERIOR || row + 1 < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst + p.Wi) = make_ulonglong2(v10, v11); else dst[p.Wi] = v10; }
+            if (INTERIOR || row + 1 < th) { if (INTERIOR || x2 + 1 < tw) *reinterpret_cast<ulonglong2*>(dst + visPitch) = make_ulonglong2(v10, v11); else dst[visPitch] = v10; }
         }
         const float dq[4] = {__uint_as_float((uint32_t)(v00 >> 32)), __uint_as_float((uint32_t)(v01 >> 32)),
                              __uint_as_float((uint32_t)(v10 >> 32)), __uint_as_float((uint32_t)(v11 >> 32))};
@@ -2121,15 +2119,15 @@ __device__ __forceinline__ void tile_out_and_hzb_body(const TileOutParams& p, co
             rmin = min(rmin, (drawn && dq[k] < 1.0f) ? bits : 0xFFFFFFFFu);
         }
         const float mn = fminf(fminf(dq[0], dq[1]), fminf(dq[2], dq[3])), mx = fmaxf(fmaxf(dq[0], dq[1]), fmaxf(dq[2], dq[3]));
-        put(0u, tX * 32u + l, tY * 32u + 4u * wave + q, mn, mx);           // mip 0 texel (l, 4 wave + q)
+        put(0u, l, 4u * wave + q, mn, mx);                                  // mip 0 texel (l, 4 wave + q)
         if (rp == 0u) { m1n = mn; m1x = mx; } else { m1n = fminf(m1n, mn); m1x = fmaxf(m1x, mx); }
     }
     m1n = fminf(m1n, __shfl_xor(m1n, 1, 64)); m1x = fmaxf(m1x, __shfl_xor(m1x, 1, 64));   // mip 1 texel (l/2, 2 wave + half)
-    if ((l & 1u) == 0u) put(1u, tX * 16u + (l >> 1), tY * 16u + 2u * wave + half, m1n, m1x);
+    if ((l & 1u) == 0u) put(1u, l >> 1, 2u * wave + half, m1n, m1x);
     float m2n = fminf(m1n, __shfl_xor(m1n, 2, 64)), m2x = fmaxf(m1x, __shfl_xor(m1x, 2, 64));
     m2n = fminf(m2n, __shfl_xor(m2n, 32, 64)); m2x = fmaxf(m2x, __shfl_xor(m2x, 32, 64));   // mip 2 texel (l/4, wave)
     if (half == 0u && (l & 3u) == 0u) {
-        put(2u, tX * 8u + (l >> 2), tY * 8u + wave, m2n, m2x);
+        put(2u, l >> 2, wave, m2n, m2x);
         sM2[wave * 8u + (l >> 2)] = m2n; sM2[64u + wave * 8u + (l >> 2)] = m2x;
     }
 #pragma unroll
@@ -2144,24 +2142,32 @@ __device__ __forceinline__ void tile_out_and_hzb_body(const TileOutParams& p, co
         float n3 = sM2[lane], x3 = sM2[64u + lane];
         n3 = fminf(n3, __shfl_xor(n3, 1, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 1, 64));
         n3 = fminf(n3, __shfl_xor(n3, 8, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 8, 64));
-        if (!(x & 1u) && !(y & 1u)) put(3u, tX * 4u + (x >> 1), tY * 4u + (y >> 1), n3, x3);
+        if (!(x & 1u) && !(y & 1u)) put(3u, x >> 1, y >> 1, n3, x3);
         n3 = fminf(n3, __shfl_xor(n3, 2, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 2, 64));
         n3 = fminf(n3, __shfl_xor(n3, 16, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 16, 64));
-        if (!(x & 3u) && !(y & 3u)) put(4u, tX * 2u + (x >> 2), tY * 2u + (y >> 2), n3, x3);
+        if (!(x & 3u) && !(y & 3u)) put(4u, x >> 2, y >> 2, n3, x3);
         n3 = fminf(n3, __shfl_xor(n3, 4, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 4, 64));
         n3 = fminf(n3, __shfl_xor(n3, 32, 64)); x3 = fmaxf(x3, __shfl_xor(x3, 32, 64));
         if (lane == 0u) {
-            put(5u, tX, tY, n3, x3);
+            put(5u, 0u, 0u, n3, x3);
             uint32_t lo = 0xFFFFFFFFu, hi = 0u;
 #pragma unroll
             for (uint32_t w = 0; w < TB / 64u; w++) { lo = min(lo, sRange[2u * w]); hi = max(hi, sRange[2u * w + 1u]); }
-            p.tileRange[2u * tileId] = lo; p.tileRange[2u * tileId + 1u] = hi;   // reduced over tiles by hzb_tail_kernel
+            if (SH) {
+                // the slot's tail: valid range of the tile, and its bin entries of the frame so far (what the tile map is balanced by)
+                uint32_t* tail = reinterpret_cast<uint32_t*>(exB + CHORD_HZB_FINAL_RANGE_OFFSET);
+                const uint32_t before = p.clearTiles ? 0u : tail[2];
+                tail[0] = lo; tail[1] = hi; tail[2] = before + binLength; tail[3] = 0u;
+            } else {
+                p.tileRange[2u * tileId] = lo; p.tileRange[2u * tileId + 1u] = hi;   // reduced over tiles by hzb_tail_kernel
+            }
         }
     }
 }
 
+template <bool SH>
 __device__ __forceinline__ void tile_out_and_hzb(const unsigned long long* tile, float* sM2, uint32_t* sRange,
-                                                 uint32_t tileId, int32_t ox, int32_t oy, int32_t tw, int32_t th)
+                                                 uint32_t tileId, uint32_t slotId, uint32_t binLength, int32_t ox, int32_t oy, int32_t tw, int32_t th)
 {
     const TileOutParams p = load_tile_out_params();
     const ChordHZBDesc& d = p.hzbDesc;
@@ -2169,8 +2175,8 @@ __device__ __forceinline__ void tile_out_and_hzb(const unsigned long long* tile,
     const uint32_t vw0 = min(max(1u, d.width), ((d.srcWidth - 1u) >> 1) + 1u), vh0 = min(max(1u, d.height), ((d.srcHeight - 1u) >> 1) + 1u);
     // (valid extents shrink by floor per level, so a tile inside level 0's is inside every level's up to 5)
     const bool interior = tw == TILE && th == TILE && d.mipCount > 5u && (tX + 1u) * 32u <= vw0 && (tY + 1u) * 32u <= vh0;
-    if (interior) tile_out_and_hzb_body<true>(p, tile, sM2, sRange, tileId, ox, oy, tw, th);
-    else tile_out_and_hzb_body<false>(p, tile, sM2, sRange, tileId, ox, oy, tw, th);
+    if (interior) tile_out_and_hzb_body<true, SH>(p, tile, sM2, sRange, tileId, slotId, binLength, ox, oy, tw, th);
+    else tile_out_and_hzb_body<false, SH>(p, tile, sM2, sRange, tileId, slotId, binLength, ox, oy, tw, th);
 }
 
 // Split tiles (see raster_tile_kernel): merges this slice's LDS tile into the tile's accumulation slab and draws a
@@ -2290,13 +2296,11 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     const int32_t ox = (int32_t)(tileId % p.tilesX) * TILE, oy = (int32_t)(tileId / p.tilesX) * TILE;
     const int32_t tw = min(TILE, p.Wi - ox), th = min(TILE, p.Hi - oy);
     const bool noPixels = ABL(p, DBG_NO_PIXELS);
-    // bit ly set <=> this rank owns pixel row oy + ly (all ones when not sharded)
-    unsigned long long rowMask = ~0ull;
-    if (SH) {
-        rowMask = 0ull;
-        for (int32_t ly = 0; ly < th; ly++) if (owns_row<SH>(p.shard, oy + ly)) rowMask |= 1ull << ly;
-        if (rowMask == 0ull) continue;                           // nothing of this tile belongs to the rank
-    }
+    // where the tile's words live: row-major in the image, or (sharded frames: SH) tile-linear in the tile's slot of the rank's
+    // chunk -- 64 rows of 64 words, the whole slot also for a tile cut by the screen edge.  (Only owned tiles are work items.)
+    const uint32_t slotId = SH ? __builtin_amdgcn_readfirstlane(scalar_load(&kernel_args()->shard.tileSlot)[tileId]) : 0u;
+    const size_t visBase = SH ? (size_t)slotId * (size_t)(TILE * TILE) : (size_t)oy * (size_t)p.Wi + (size_t)ox;
+    const size_t visPitch = SH ? (size_t)TILE : (size_t)p.Wi;
 
     // ---- tile in: zero (first pass: this is the clear; un-fused later passes merge by max at tile-out), or the
     //      current words when a later pass must leave the finished tile in LDS for the fused HZB reduction ----
@@ -2313,7 +2317,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
         ulonglong2 v = make_ulonglong2(0ull, 0ull);
         if (ly < th && lx < tw) {
-            const unsigned long long* src = scalar_load(&kernel_args()->vis) + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
+            const unsigned long long* src = scalar_load(&kernel_args()->vis) + visBase + (size_t)ly * visPitch + lx;
             if (lx + 1 < tw) v = *reinterpret_cast<const ulonglong2*>(src);
             else v.x = src[0];
         }
@@ -2427,7 +2431,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                     const bool narrow = narrow_extent(ts);
                     const bool maskedRec = MASKED && (name & CHORD_REC_WIDE) && (q2.z & 4u);   // a TriRecMaskExt follows the record
                     if (narrow && !maskedRec && (x1 - x0 + 1) * (y1 - y0 + 1) <= tinyArea) {
-                        if (!ABL(p, DBG_NO_TINY)) tile_raster_narrow<TPITCH>(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, rowMask, DEPTH);
+                        if (!ABL(p, DBG_NO_TINY)) tile_raster_narrow<TPITCH>(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, DEPTH);
                         if (prof) { cTiny++; cTinyIters += (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1)); }
                     } else {
                         rows = entry_store(prm, threadIdx.x, ts, narrow, ox, oy, x0, y0, x1, y1, maskedRec, name & ~CHORD_REC_WIDE);   // (units, not rows)
@@ -2463,7 +2467,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
             for (uint32_t ui = threadIdx.x; ui < nr; ui += TB) {
                 const uint32_t d = unitList[ui];
                 if (ABL(p, DBG_NO_UNITS)) continue;
-                const int32_t trips = entry_unit<MASKED, DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, rowMask, noPixels);
+                const int32_t trips = entry_unit<MASKED, DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, noPixels);
                 if (prof) { cUnits++; cUnitIters += (uint32_t)trips; }
             }
             if (r0 + UNIT_CAP < total) __syncthreads();           // the list is rewritten by the next round
@@ -2486,7 +2490,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
             for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
                 const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
                 if (ly >= th || lx >= tw) continue;
-                const unsigned long long* src = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
+                const unsigned long long* src = p.vis + visBase + (size_t)ly * visPitch + lx;
                 tile[ly * TPITCH + lx] = max(tile[ly * TPITCH + lx], src[0]);
                 if (lx + 1 < tw) tile[ly * TPITCH + lx + 1] = max(tile[ly * TPITCH + lx + 1], src[1]);
             }
@@ -2499,14 +2503,14 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     } else if (p.hzbFused && !ABL(p, DBG_NO_HZB)) {
         // single-GPU frame: the whole tile goes out (first pass: this is the clear; later passes loaded it), and its
         // HZB texels with it; the batch buffers are free now and hold the cross-wave part of the reduction
-        tile_out_and_hzb(tile, reinterpret_cast<float*>(&prm.w[0][0]), offs, tileId, ox, oy, tw, th);
+        tile_out_and_hzb<SH>(tile, reinterpret_cast<float*>(&prm.w[0][0]), offs, tileId, slotId, nAll, ox, oy, tw, th);
     } else if (p.clearTiles || p.hzbFused) {
         // first pass of the frame: every word is written (16-byte coalesced stores); this is the clear
         for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
             const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
-            if (ly >= th || lx >= tw || !owns_row<SH>(p.shard, oy + ly)) continue;
+            if (ly >= th || lx >= tw) continue;
             const ulonglong2 v = make_ulonglong2(tile[ly * TPITCH + lx], tile[ly * TPITCH + lx + 1]);
-            unsigned long long* dst = p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx;
+            unsigned long long* dst = p.vis + visBase + (size_t)ly * visPitch + lx;
             if (lx + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = v;
             else dst[0] = v.x;
         }
@@ -2516,8 +2520,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         for (uint32_t i = threadIdx.x; i < TILE * TILE; i += TB) {
             const int32_t ly = (int32_t)(i >> TILE_SHIFT), lx = (int32_t)(i & (TILE - 1));
             const unsigned long long v = tile[ly * TPITCH + lx];
-            if (v != 0ull && ly < th && lx < tw && owns_row<SH>(p.shard, oy + ly))
-                atomicMax(p.vis + row_base<SH>(p.shard, oy + ly, p.Wi) + ox + lx, v);
+            if (v != 0ull && ly < th && lx < tw) atomicMax(p.vis + visBase + (size_t)ly * visPitch + lx, v);
         }
     }
     PHASE(5);
@@ -2542,17 +2545,23 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
 #define LR_HIP(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
     RasterParams p;
     p.hzbFused = 0; p.hzbMinA = nullptr; p.hzbMinB = nullptr; p.hzbMaxB = nullptr; p.tileRange = c->dTileRange;
+    p.hzbExA = nullptr; p.hzbExB = nullptr;
     p.hzbDesc = c->hzb[0].desc;
     if (c->fuseHzb && c->shard.ranks == 1) {
         p.hzbFused = 1;
         p.hzbMinA = (clearTiles && c->fuseHzbTemp) ? c->hzb[0].minTexels : nullptr;
         p.hzbMinB = c->hzb[c->fuseHzbSlot].minTexels; p.hzbMaxB = c->hzb[c->fuseHzbSlot].maxTexels;
+    } else if (c->fuseHzb) {
+        // sharded frame: the same reduction, into the owned tiles' slots of the exchange buffers (launch_hzb_untile after the all-gathers)
+        p.hzbFused = 1;
+        p.hzbExA = (clearTiles && c->fuseHzbTemp) ? c->dHzbExchange : nullptr;
+        p.hzbExB = c->dHzbFinalExchange;
     }
     p.count = in.count; p.cmds = in.cmds;
     if (c->shard.ranks > 1) {
-        // sharded frame: only the clusters that touch this rank's pixel rows reach the setup kernel.  The lists of a frame
+        // sharded frame: only the clusters that touch this rank's screen tiles reach the setup kernel.  The lists of a frame
         // are the rank's own already (the group cull writes the rank's share of list 0 beside the full list; the HZB culls
-        // of a sharded frame start from it); a list of unknown origin goes through the stripe filter first.
+        // of a sharded frame start from it); a list of unknown origin goes through the rank filter first.
         bool mine = false;
         if (in.cmds == c->lists[0].cmds && c->mineValid) { p.count = c->dCounts + 4; p.cmds = c->dMineCmds; mine = true; }
         else if (in.cmds == c->dMineCmds && c->mineValid) mine = true;
@@ -2562,7 +2571,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
             CmdList filtered;
             filtered.count = c->dCounts + 5; filtered.cmds = c->dRankCmds; filtered.capacity = in.capacity;
             LR_HIP(hipMemsetAsync(filtered.count, 0, sizeof(uint32_t), c->stream));
-            launch_stripe_filter(c, in, filtered);
+            launch_rank_filter(c, in, filtered);
             p.count = filtered.count; p.cmds = filtered.cmds;
         }
     }
@@ -2650,7 +2659,8 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // start-up round trips paid once, also with a loop-end barrier that does not wait for the visibility stores to drain --
     // was measured: tile kernel +4..6 % on config 3, +11..18 % on config 4; the dispatcher's dynamic hand-out of one item
     // per block balances better than any static split)
-    const uint32_t tileBlocks = clearTiles ? tiles : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
+    // (sharded frames: the work items are the rank's own tiles)
+    const uint32_t tileBlocks = clearTiles ? (sh ? min(tiles, c->shard.slotsPerRank) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
     if (c->depthClamp && !sh) {
         if (c->anyMasked) hipLaunchKernelGGL((raster_tile_kernel<false, true, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
         else              hipLaunchKernelGGL((raster_tile_kernel<false, false, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);

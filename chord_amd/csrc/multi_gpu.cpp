@@ -1,6 +1,6 @@
-// Multi-GPU entry points of the C ABI: the frame sharded by interleaved row stripes, the two
-// exchanges of DESIGN.md 6 (own-stripe HZB mip 0 mid-frame, own-stripe visibility words at the end) issued by the
-// library itself, so that a C++ host calls ONE function per frame like DeferredRenderer::render does
+// Multi-GPU entry points of the C ABI: the frame sharded by 64x64 screen tiles (tile_layout.cpp), the
+// exchanges of DESIGN.md 6 (the owned tiles' HZB texels mid-frame; their HZB texels and visibility words at the end) issued
+// by the library itself, so that a C++ host calls ONE function per frame like DeferredRenderer::render does
 // (renderer.cpp:319-345).  The reference is single-device (graphics.cpp:524-548); nothing here has a counterpart in it.
 //
 // Two forms:
@@ -27,6 +27,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 using namespace chord;
 
@@ -98,25 +99,6 @@ int nccl_fail(ChordCtx* c, const Rccl* r, const char* what, int code)
 // ------------------------------------------------------------------------------------- one process per GPU: RCCL comm
 extern "C" {
 
-uint32_t chordvis_pick_stripe_rows(uint32_t height, uint32_t ranks)
-{
-    // Even stripe height in [32, 256], at least two stripes per rank, minimising  padding / height + 18 / rows : the idle
-    // share of the rank that holds the padded stripe, plus the share of (16-pixel) clusters that straddle two stripes and are
-    // set up by both owners -- measured on BASELINE config 5: 13 % of the per-rank time with 90-row stripes at 8 ranks, 19 % with
-    // 64 rows.  Fewer, taller stripes cost balance on scenes that are uneven from top to bottom, which the interleave over
-    // at least two stripes per rank limits.  Ties towards the taller stripe.  (cost compared as num / (height * rows).)
-    if (ranks == 0) ranks = 1;
-    uint32_t best = 32; uint64_t bestNum = ~0ull;
-    for (uint32_t s = 32; s <= 256; s += 2) {
-        const uint32_t stripes = (height + s - 1) / s, per = (stripes + ranks - 1) / ranks;
-        if (ranks > 1 && per < 2 && s > 32) continue;
-        const uint64_t pad = (uint64_t)per * ranks * s - height;
-        const uint64_t num = pad * s + 18ull * height;
-        if (bestNum == ~0ull || num * best < bestNum * s || (num * best == bestNum * s && s > best)) { bestNum = num; best = s; }
-    }
-    return best;
-}
-
 int chordvis_comm_unique_id(void* out128)
 {
     if (!out128) return CHORDVIS_E_INVALID;
@@ -132,7 +114,7 @@ int chordvis_comm_init_rank(ChordCtx* c, uint32_t nranks, uint32_t rank, const v
 {
     if (!c || !id128 || nranks == 0 || rank >= nranks) return fail(c, CHORDVIS_E_INVALID, "comm_init_rank: bad arguments");
     if (c->shard.ranks != nranks || c->shard.rank != rank)
-        return fail(c, CHORDVIS_E_INVALID, "comm_init_rank: call chordvis_set_shard(stripeRows, nranks, rank) first (same nranks / rank)");
+        return fail(c, CHORDVIS_E_INVALID, "comm_init_rank: call chordvis_set_shard(nranks, rank) first (same nranks / rank)");
     const Rccl* r = rccl();
     if (!r) return fail(c, CHORDVIS_E_COMM, gRcclError.c_str());
     if (c->comm) { (void)r->CommDestroy((NcclComm)c->comm); c->comm = nullptr; }
@@ -223,12 +205,13 @@ namespace chord {
 // ---- pipelined frame of one rank, shared by the two transports ---------------------------------------------------------------
 // (chordvis_comm_set_pipelined over RCCL, chordvis_group_set_pipelined over peer copies)  The image of frame i is
 // gathered on the side -- behind the rank's "phase b done" point, on the resolve stream -- and copied to row-major there, while
-// the compute stream goes on to the history HZB, built from three small exchanges of own-stripe data (mip 0 of the min and max
-// chains, the valid-range pair) instead of from the gathered image, and then to frame i + 1, which rasters into the other
-// buffer pair.  The pair a frame takes over was last used two frames ago; the caller has waited for that frame's "image
-// complete" event (and, in a group, for every rank to have done so) before calling.  ONE body, so that the sequence the
-// one-device group tests exercise with 2..8 ranks is the sequence an RCCL host runs; a transport supplies
-//   small(which, base, chunkBytes)   all-gather of a rank-major buffer of the context, ordered on the compute stream
+// the compute stream goes on to the history HZB, which needs only the small end-of-frame exchange (the tiles' HZB texels, valid
+// ranges and bin lengths), and then to frame i + 1, which rasters into the other buffer pair.  The pair a frame takes over was
+// last used two frames ago; the caller has waited for that frame's "image complete" event (and, in a group, for every rank to
+// have done so) before calling.  ONE body, so that the sequence the one-device group tests exercise with 2..8 ranks is the
+// sequence an RCCL host runs; a transport supplies
+//   small(which, chunkBytes)         all-gather of an exchange buffer of the context (0: mid-frame, 1: end of frame), ordered on the
+//                                    compute stream
 //   image()                          all-gather of the current visibility buffer behind everything enqueued so far on the compute
 //                                    stream, such that `resolveStream` may read the complete buffer afterwards
 // A failing step is remembered; the rank still walks through every exchange (its peers are inside them).
@@ -241,8 +224,7 @@ int pipelined_frame_body(ChordCtx* c, hipEvent_t visReadyThis, hipEvent_t visRea
     c->visReadyEvent[1] = visReadyOther;
     const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
     if (!rc) rc = chordvis_frame_phase_a(c);
-    const size_t hzbBytes = (size_t)c->hzbExchangeChunkHalves * 2;
-    if (stage1) { const int e = tr.small(0, hzbBytes); if (!rc) rc = e; }
+    if (stage1) { const int e = tr.small(0, (size_t)c->hzbExchangeChunkHalves * 2); if (!rc) rc = e; }
     if (!rc) rc = chordvis_frame_phase_b(c);
     {
         int e = tr.image();
@@ -251,16 +233,15 @@ int pipelined_frame_body(ChordCtx* c, hipEvent_t visReadyThis, hipEvent_t visRea
         const hipError_t he = hipEventRecord(visReadyThis, resolveStream);
         if (he != hipSuccess && !rc) rc = fail(c, CHORDVIS_E_HIP, "hipEventRecord(image complete)", he);
     }
-    if (!rc) rc = chordvis_frame_phase_c_begin(c);
-    { int e = tr.small(0, hzbBytes); if (!rc) rc = e; e = tr.small(1, hzbBytes); if (!rc) rc = e; e = tr.small(2, 8); if (!rc) rc = e; }
+    { const int e = tr.small(1, (size_t)c->hzbFinalExchangeChunkBytes); if (!rc) rc = e; }
     if (!rc) rc = chordvis_frame_phase_c_finish(c);
     return rc;
 }
 
-// the rank-major exchange buffers of a context by number: 0 = HZB min mip 0, 1 = HZB max mip 0, 2 = valid-range pairs
+// the rank-major exchange buffers of a context by number: 0 = mid-frame (min chain after stage 0), 1 = end of frame
 static char* exchange_buffer(ChordCtx* c, int which)
 {
-    return which == 0 ? reinterpret_cast<char*>(c->dHzbExchange) : which == 1 ? reinterpret_cast<char*>(c->dHzbExchangeMax) : reinterpret_cast<char*>(c->dRangeExchange);
+    return which == 0 ? reinterpret_cast<char*>(c->dHzbExchange) : reinterpret_cast<char*>(c->dHzbFinalExchange);
 }
 
 struct RcclTransport {
@@ -276,7 +257,7 @@ struct RcclTransport {
         hipError_t he = hipEventRecord(c->commPhaseB, c->stream);
         if (he == hipSuccess) he = hipStreamWaitEvent(c->commResolveStream, c->commPhaseB, 0);
         if (he != hipSuccess) return fail(c, CHORDVIS_E_HIP, "image gather: stream order", he);
-        const size_t words = (size_t)(c->visWords / c->shard.ranks);
+        const size_t words = (size_t)c->shard.slotsPerRank * (CHORD_TILE * CHORD_TILE);
         const int e = r->AllGather(c->dVis + (size_t)c->shard.rank * words, c->dVis, words, kNcclUint64, (NcclComm)c->commBulk, c->commResolveStream);
         return e == kNcclSuccess ? CHORDVIS_OK : nccl_fail(c, r, "ncclAllGather(visibility)", e);
     }
@@ -295,6 +276,17 @@ int comm_render_frame(ChordCtx* c)
 {
     const Rccl* r = rccl();
     if (!r || !c->comm) return fail(c, CHORDVIS_E_COMM, "render_frame: sharded context without a communicator (chordvis_comm_init_rank, or drive chordvis_frame_phase_a/b/c)");
+    if (c->shard.ranks == 1) {
+        // a communicator of one rank: the single-GPU frame (nothing is sharded), then the image through the collective in place --
+        // what a one-GPU box can exercise of this path
+        void* comm = c->comm;
+        c->comm = nullptr;                                                    // (chordvis_render_frame dispatches on it)
+        int rc = chordvis_render_frame(c);
+        c->comm = comm;
+        const int e = r->AllGather(c->dVis, c->dVis, (size_t)c->visWords, kNcclUint64, (NcclComm)comm, c->stream);
+        if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(visibility, one rank)", e);
+        return rc;
+    }
     if (c->commPipelined) return comm_render_frame_pipelined(c, r);
     const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
     int rc = chordvis_frame_phase_a(c);
@@ -303,12 +295,16 @@ int comm_render_frame(ChordCtx* c)
         const size_t bytes = (size_t)c->hzbExchangeChunkHalves * 2;
         char* base = reinterpret_cast<char*>(c->dHzbExchange);
         const int e = r->AllGather(base + (size_t)c->shard.rank * bytes, base, bytes, kNcclUint8, (NcclComm)c->comm, c->stream);
-        if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(hzb mip 0)", e);
+        if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(mid-frame HZB exchange)", e);
     }
     if (!rc) rc = chordvis_frame_phase_b(c);
     {
-        const size_t words = (size_t)(c->visWords / c->shard.ranks);
-        const int e = r->AllGather(c->dVis + (size_t)c->shard.rank * words, c->dVis, words, kNcclUint64, (NcclComm)c->comm, c->stream);
+        const size_t bytes = (size_t)c->hzbFinalExchangeChunkBytes;
+        char* base = reinterpret_cast<char*>(c->dHzbFinalExchange);
+        int e = r->AllGather(base + (size_t)c->shard.rank * bytes, base, bytes, kNcclUint8, (NcclComm)c->comm, c->stream);
+        if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(end-of-frame HZB exchange)", e);
+        const size_t words = (size_t)c->shard.slotsPerRank * (CHORD_TILE * CHORD_TILE);
+        e = r->AllGather(c->dVis + (size_t)c->shard.rank * words, c->dVis, words, kNcclUint64, (NcclComm)c->comm, c->stream);
         if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(visibility)", e);
     }
     if (!rc) rc = chordvis_frame_phase_c(c);
@@ -323,7 +319,6 @@ struct ChordGroup {
     std::vector<ChordCtx*> ctx;
     std::vector<int> device;
     std::string lastError;
-    uint32_t stripeRows = 0;
     // copy streams and events: index [src * n + dst]
     std::vector<hipStream_t> copyStream;
     std::vector<hipEvent_t> evArrived[4];       // per exchange (0 = HZB exchanges, 1 = visibility; 2 / 3 = visibility of a pipelined frame, by parity)
@@ -547,13 +542,11 @@ int chordvis_group_upload_scene(ChordGroup* g, const ChordSceneDesc* scene)
     return run_all(g, [&](uint32_t r) { return chordvis_upload_scene(g->ctx[r], scene); }, "group_upload_scene");   // replicated
 }
 
-int chordvis_group_allocate_gbuffer(ChordGroup* g, uint32_t width, uint32_t height, uint32_t stripeRows)
+int chordvis_group_allocate_gbuffer(ChordGroup* g, uint32_t width, uint32_t height)
 {
     if (!g) return CHORDVIS_E_INVALID;
-    if (stripeRows == 0) stripeRows = chordvis_pick_stripe_rows(height, g->n);
-    g->stripeRows = stripeRows;
     return run_all(g, [&](uint32_t r) {
-        int rc = chordvis_set_shard(g->ctx[r], stripeRows, g->n, r);
+        int rc = chordvis_set_shard(g->ctx[r], g->n, r);
         if (!rc) rc = chordvis_allocate_gbuffer(g->ctx[r], width, height, nullptr);
         return rc;
     }, "group_allocate_gbuffer");
@@ -596,8 +589,10 @@ int chordvis_group_render_frame(ChordGroup* g)
         }
         if (!rc) rc = chordvis_frame_phase_b(c);
         {
-            const int e = group_all_gather(g, r, 1, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dVis); },
-                                           (size_t)(c->visWords / g->n) * 8);
+            int e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dHzbFinalExchange); },
+                                     (size_t)c->hzbFinalExchangeChunkBytes);
+            if (!rc) rc = e;
+            e = group_all_gather(g, r, 1, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dVis); }, (size_t)c->shard.slotsPerRank * (CHORD_TILE * CHORD_TILE) * 8);
             if (!rc) rc = e;
         }
         if (!rc) rc = chordvis_frame_phase_c(c);
@@ -608,9 +603,8 @@ int chordvis_group_render_frame(ChordGroup* g)
 // Pipelined frames (VERDICT r01 item 2 / DESIGN.md 6): the visibility all-gather of frame i -- 58 of 66 MB arriving per rank
 // at 4K -- and its row-major copy leave the frame's critical path and run beside frame i + 1:
 //   * two buffer pairs per rank (chordvis_swap_visibility): frame i + 1 rasters into the other one;
-//   * the history HZB of frame i comes from an exchange of the ranks' own-stripe mip 0 (min, max) and valid-range pairs
-//     (3 small all-gathers, 2 x 4 MB + a few bytes at 4K) instead of from the gathered image: chordvis_frame_phase_c_begin /
-//     _finish -- bit for bit the chain the unpipelined frame builds;
+//   * the history HZB of frame i needs only the small end-of-frame exchange (the tiles' HZB texels out of the tile kernel),
+//     never the gathered image: chordvis_frame_phase_c_finish;
 //   * the gather itself waits on the rank's "phase b done" event, travels on the (source, destination) copy streams, and is
 //     followed by the row-major copy on the rank's resolve stream; "image complete" is an event per buffer pair that
 //     the read-back / consumer entry points of the context wait for.
@@ -635,7 +629,7 @@ struct GroupTransport {
     {
         ChordCtx* c = g->ctx[r];
         const int e = group_all_gather(g, r, 2 + parity, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dVis); },
-                                       (size_t)(c->visWords / g->n) * 8, g->resolveStream[r], true);
+                                       (size_t)c->shard.slotsPerRank * (CHORD_TILE * CHORD_TILE) * 8, g->resolveStream[r], true);
         // (the resolve stream also needs the rank's own chunk: the `ready` event of this exchange was recorded on the compute
         // stream after phase b)
         const hipError_t he = hipStreamWaitEvent(g->resolveStream[r], g->evReady[2 + parity][r], 0);
@@ -660,6 +654,20 @@ static int group_render_frame_pipelined(ChordGroup* g)
         const int rc = chord::pipelined_frame_body(c, g->evVisReady[parity][r], g->evVisReady[parity ^ 1][r], g->resolveStream[r], tr);
         return he != hipSuccess ? fail(c, CHORDVIS_E_HIP, "hipEventSynchronize(image of two frames ago)", he) : rc;
     }, "group_render_frame (pipelined)");
+}
+
+// Re-balances the tile map of every rank from the last frame's loads (chordvis_rebalance on each context: the ranks hold the
+// same loads and compute the same map).  Drains the frames in flight first.
+int chordvis_group_rebalance(ChordGroup* g, uint32_t* imbalancePermille)
+{
+    if (!g) return CHORDVIS_E_INVALID;
+    if (g->n < 2) { if (imbalancePermille) *imbalancePermille = 1000u; return CHORDVIS_OK; }
+    int rc = chordvis_group_sync(g);
+    if (rc) return rc;
+    std::vector<uint32_t> imb(g->n, 1000u);
+    rc = run_all(g, [&](uint32_t r) { return chordvis_rebalance(g->ctx[r], &imb[r]); }, "group_rebalance");
+    if (imbalancePermille) *imbalancePermille = imb[0];
+    return rc;
 }
 
 int chordvis_group_sync(ChordGroup* g)

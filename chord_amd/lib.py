@@ -126,7 +126,15 @@ def _load():
         "chordvis_bind_objects": (i32, [vp, vp, u32]),
         "chordvis_set_view": (i32, [vp, vp, vp, u32]),
         "chordvis_allocate_gbuffer": (i32, [vp, u32, u32, vp]),
-        "chordvis_set_shard": (i32, [vp, u32, u32, u32]),
+        "chordvis_set_shard": (i32, [vp, u32, u32]),
+        "chordvis_tile_count": (u32, [u32, u32]),
+        "chordvis_tile_slots_per_rank": (u32, [u32, u32, u32]),
+        "chordvis_tile_slot_capacity": (u32, [u32, u32, u32]),
+        "chordvis_tile_layout": (i32, [u32, u32, u32, vp, u32, vp]),
+        "chordvis_set_tile_owners": (i32, [vp, vp, u32]),
+        "chordvis_get_tile_owners": (i32, [vp, vp, u32]),
+        "chordvis_read_tile_loads": (i32, [vp, vp, u32]),
+        "chordvis_rebalance": (i32, [vp, vp]),
         "chordvis_set_cull_mode": (i32, [vp, i32]),
         "chordvis_visibility_words": (u64, [vp]),
         "chordvis_visibility_chunk_words": (u64, [vp]),
@@ -142,12 +150,11 @@ def _load():
         "chordvis_frame_phase_a": (i32, [vp]),
         "chordvis_frame_phase_b": (i32, [vp]),
         "chordvis_frame_phase_c": (i32, [vp]),
-        "chordvis_frame_phase_c_begin": (i32, [vp]),
         "chordvis_frame_phase_c_finish": (i32, [vp]),
         "chordvis_frame_resolve_visibility": (i32, [vp, vp]),
         "chordvis_swap_visibility": (i32, [vp]),
-        "chordvis_hzb_exchange_max_ptr": (vp, [vp]),
-        "chordvis_range_exchange_ptr": (vp, [vp]),
+        "chordvis_hzb_final_exchange_ptr": (vp, [vp]),
+        "chordvis_hzb_final_exchange_chunk_bytes": (u64, [vp]),
         "chordvis_reset_history": (i32, [vp]),
         "chordvis_hzb_exchange_ptr": (vp, [vp]),
         "chordvis_hzb_exchange_halves": (u64, [vp]),
@@ -166,7 +173,6 @@ def _load():
         "chordvis_prepare_shading_tile_param": (i32, [vp, u32, P(TileMarker), P(ShadingTiles)]),
         "chordvis_readback_tile_marker": (i32, [vp, P(TileMarker), vp]),
         "chordvis_readback_shading_tiles": (i32, [vp, P(ShadingTiles), vp, u32, P(u32), vp]),
-        "chordvis_pick_stripe_rows": (u32, [u32, u32]),
         "chordvis_comm_unique_id": (i32, [vp]),
         "chordvis_comm_init_rank": (i32, [vp, u32, u32, vp]),
         "chordvis_comm_destroy": (i32, [vp]),
@@ -179,7 +185,8 @@ def _load():
         "chordvis_group_last_error": (C.c_char_p, [vp]),
         "chordvis_group_set_limits": (i32, [vp, P(Limits)]),
         "chordvis_group_upload_scene": (i32, [vp, P(R.SceneDesc)]),
-        "chordvis_group_allocate_gbuffer": (i32, [vp, u32, u32, u32]),
+        "chordvis_group_allocate_gbuffer": (i32, [vp, u32, u32]),
+        "chordvis_group_rebalance": (i32, [vp, vp]),
         "chordvis_group_update_objects": (i32, [vp, vp, u32]),
         "chordvis_group_set_view": (i32, [vp, vp, vp, u32]),
         "chordvis_group_render_frame": (i32, [vp]),

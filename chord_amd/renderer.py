@@ -69,8 +69,34 @@ class VisibilityRenderer:
         """0: flat group cull (the reference's dispatch); 1: walk the primitives' BVHs (same command list)."""
         self._check(L.lib.chordvis_set_cull_mode(self._ctx, int(hierarchical)), "set_cull_mode")
 
-    def set_shard(self, stripe_rows, ranks, rank):
-        self._check(L.lib.chordvis_set_shard(self._ctx, stripe_rows, ranks, rank), "set_shard")
+    def set_shard(self, ranks, rank):
+        """Screen ownership by 64 x 64 tiles: the default map (compact regions along a generalised Hilbert curve)."""
+        self._check(L.lib.chordvis_set_shard(self._ctx, ranks, rank), "set_shard")
+
+    def set_tile_owners(self, owners):
+        """An explicit tile map (one owner per tile); None: the default map."""
+        if owners is None:
+            self._check(L.lib.chordvis_set_tile_owners(self._ctx, None, 0), "set_tile_owners")
+            return
+        owners = np.ascontiguousarray(owners, dtype=np.uint8)
+        self._check(L.lib.chordvis_set_tile_owners(self._ctx, owners.ctypes.data, len(owners)), "set_tile_owners")
+
+    def tile_owners(self):
+        out = np.zeros(int(L.lib.chordvis_tile_count(self.width, self.height)), dtype=np.uint8)
+        self._check(L.lib.chordvis_get_tile_owners(self._ctx, out.ctypes.data, len(out)), "get_tile_owners")
+        return out
+
+    def read_tile_loads(self):
+        """Bin entries per tile of the last frame (every rank's tiles, after the end-of-frame exchange)."""
+        out = np.zeros(int(L.lib.chordvis_tile_count(self.width, self.height)), dtype=np.uint32)
+        self._check(L.lib.chordvis_read_tile_loads(self._ctx, out.ctypes.data, len(out)), "read_tile_loads")
+        return out
+
+    def rebalance(self):
+        """Tile map from the last frame's loads; returns the old map's heaviest rank / mean."""
+        imb = C.c_uint32(0)
+        self._check(L.lib.chordvis_rebalance(self._ctx, C.byref(imb)), "rebalance")
+        return imb.value / 1000.0
 
     def set_view(self, view, instance_view, flags):
         self._views = (view, instance_view)       # keep alive
@@ -90,8 +116,13 @@ class VisibilityRenderer:
         return L.lib.chordvis_resolved_visibility_ptr(self._ctx)
 
     def hzb_exchange(self):
+        """(device pointer, halves, halves per rank) of the mid-frame exchange buffer."""
         return (L.lib.chordvis_hzb_exchange_ptr(self._ctx), int(L.lib.chordvis_hzb_exchange_halves(self._ctx)),
                 int(L.lib.chordvis_hzb_exchange_chunk_halves(self._ctx)))
+
+    def hzb_final_exchange(self):
+        """(device pointer, bytes per rank) of the end-of-frame exchange buffer."""
+        return (L.lib.chordvis_hzb_final_exchange_ptr(self._ctx), int(L.lib.chordvis_hzb_final_exchange_chunk_bytes(self._ctx)))
 
     # -- passes -------------------------------------------------------------------------------------
     def clear_gbuffer(self):
@@ -374,10 +405,16 @@ class VisibilityGroup:
         self.scene = scene
         self._check(L.lib.chordvis_group_upload_scene(self._g, C.byref(scene.desc)), "group_upload_scene")
 
-    def allocate_gbuffer(self, width, height, stripe_rows=0):
-        self._check(L.lib.chordvis_group_allocate_gbuffer(self._g, width, height, stripe_rows), "group_allocate_gbuffer")
+    def allocate_gbuffer(self, width, height):
+        self._check(L.lib.chordvis_group_allocate_gbuffer(self._g, width, height), "group_allocate_gbuffer")
         for r in self.ranks:
             r.width, r.height = width, height
+
+    def rebalance(self):
+        """chordvis_group_rebalance: every rank's tile map from the last frame's loads; returns the old map's heaviest rank / mean."""
+        imb = C.c_uint32(0)
+        self._check(L.lib.chordvis_group_rebalance(self._g, C.byref(imb)), "group_rebalance")
+        return imb.value / 1000.0
 
     def update_objects(self, objects):
         objects = np.ascontiguousarray(objects, dtype=R.OBJECT)

@@ -223,12 +223,39 @@ int chordvis_set_cull_mode(ChordCtx* ctx, int hierarchical);
  * multi-GPU all-gather), or NULL for a context-owned one. */
 int chordvis_allocate_gbuffer(ChordCtx* ctx, uint32_t width, uint32_t height, uint64_t* deviceVisibility);
 
-/* Multi-GPU screen ownership: rows are cut into stripes of stripeRows (even); stripe s belongs
- * to rank (s % ranks).  The visibility buffer is stored rank-major (rank r's stripes
- * contiguous) so one in-place all-gather reassembles it.  ranks == 1: plain row-major. */
 int chordvis_set_limits(ChordCtx* ctx, const ChordLimits* limits);
-int chordvis_set_shard(ChordCtx* ctx, uint32_t stripeRows, uint32_t ranks, uint32_t rank);
-/* Number of uint64 words of the (possibly padded, rank-major) visibility buffer, and of one rank's chunk. */
+/* Multi-GPU screen ownership (the reference is single-device): the screen is cut into the rasterizer's 64 x 64-pixel
+ * tiles and every tile belongs to one rank -- a table tile -> owner, row-major over the tile grid (ceil(W / 64) columns), the
+ * same on every rank of a frame.  The visibility buffer of a sharded context is stored rank-major and tile-linear: a rank's
+ * tiles sit in consecutive slots of 64 x 64 words (64 rows of 64) of the rank's chunk, chunk = ceil(tiles / ranks) slots, so one
+ * in-place all-gather reassembles the frame and a de-tile kernel restores row-major.  ranks == 1: plain row-major.
+ * chordvis_set_shard installs the default map, chordvis_tile_layout(width, height, ranks, NULL, ...): the tile grid is walked
+ * along a generalised Hilbert curve and cut into `ranks` runs of equal length -- compact regions, so that few clusters touch
+ * two ranks' tiles (such a cluster is set up by both). */
+int chordvis_set_shard(ChordCtx* ctx, uint32_t ranks, uint32_t rank);
+uint32_t chordvis_tile_count(uint32_t width, uint32_t height);
+uint32_t chordvis_tile_slots_per_rank(uint32_t width, uint32_t height, uint32_t ranks);   /* ceil(tiles / ranks): a rank's tiles under the default map */
+/* Tile slots a sharded context ALLOCATES per rank: a quarter more than that, room for a load-balanced map to give a rank of
+ * light tiles more of them.  What the all-gathers move is ranks x (the largest tile count of the current map) slots
+ * (chordvis_visibility_chunk_words and the exchange chunk sizes follow the map). */
+uint32_t chordvis_tile_slot_capacity(uint32_t width, uint32_t height, uint32_t ranks);
+/* The map as a function (host only, deterministic: every rank computes the same table from the same inputs).  loads NULL:
+ * the default above.  loads = bin entries per tile of a rendered frame (chordvis_read_tile_loads): regions of equal LOAD along
+ * the same curve; tiles heavier than a quarter of a rank's share are placed one by one (heaviest first, least loaded rank),
+ * near-empty tiles fill every rank up to its tile count.  Never more than maxTilesPerRank tiles per rank (0: ceil(tiles / ranks);
+ * chordvis_rebalance passes chordvis_tile_slot_capacity). */
+int chordvis_tile_layout(uint32_t width, uint32_t height, uint32_t ranks, const uint32_t* loads, uint32_t maxTilesPerRank, uint8_t* ownersOut);
+/* An explicit map, between frames (drains frames in flight; the history HZB carries over: it is not sharded).  owners NULL:
+ * back to the default map. */
+int chordvis_set_tile_owners(ChordCtx* ctx, const uint8_t* owners, uint32_t tiles);
+int chordvis_get_tile_owners(ChordCtx* ctx, uint8_t* ownersOut, uint32_t tiles);
+/* Bin entries per tile of the last frame, EVERY rank's tiles (they travel in the end-of-frame exchange); waits for the stream. */
+int chordvis_read_tile_loads(ChordCtx* ctx, uint32_t* loadsOut, uint32_t tiles);
+/* read_tile_loads -> tile_layout -> set_tile_owners.  Every rank calls it at the same frame boundary (same loads -> same map).
+ * imbalancePermille (may be NULL): the OLD map's heaviest rank / the mean, x 1000. */
+int chordvis_rebalance(ChordCtx* ctx, uint32_t* imbalancePermille);
+/* Number of uint64 words of the (rank-major, tile-linear when sharded) visibility buffer as allocated, and of one rank's chunk
+ * under the current tile map (the all-gather's count; rank r's chunk starts at r x that). */
 uint64_t chordvis_visibility_words(ChordCtx* ctx);
 uint64_t chordvis_visibility_chunk_words(ChordCtx* ctx);
 /* Device pointer of the visibility buffer in use (row-major when ranks == 1). */
@@ -272,31 +299,29 @@ int chordvis_build_hzb(ChordCtx* ctx, int bBuildMin, int bBuildMax, int bBuildVa
  * the next call.  On a sharded context (ranks > 1) this needs a communicator (chordvis_comm_init_rank below) and runs the
  * three phases with the two all-gathers in between; a host that owns its collectives (e.g. torch.distributed) drives
  * the phases itself -- on the context's stream, so that kernels and collectives are ordered:
- *   chordvis_frame_phase_a  clear .. stage 0 raster, own-stripe HZB mip 0 into the exchange buffer
- *   [all-gather exchange buffer]
- *   chordvis_frame_phase_b  assemble HZB, stage 1 cull + raster
- *   [all-gather visibility buffer in place]
- *   chordvis_frame_phase_c  de-stripe into row-major, final HZB, history swap            */
+ *   chordvis_frame_phase_a  clear .. stage 0 raster of the rank's tiles; the tile kernel also reduces every tile to its HZB texels
+ *                           (mips 0..5), into the tile's slots of the two exchange buffers
+ *   [all-gather the mid-frame exchange buffer: chordvis_hzb_exchange_ptr, chunk = chordvis_hzb_exchange_chunk_halves]
+ *   chordvis_frame_phase_b  HZB chain from the exchanged texels, stage 1 cull + raster
+ *   [all-gather the end-of-frame exchange buffer (chordvis_hzb_final_exchange_ptr / _chunk_bytes) and the visibility buffer, in place]
+ *   chordvis_frame_phase_c  row-major copy of the image, history HZB from the exchanged texels, history swap            */
 int chordvis_render_frame(ChordCtx* ctx);
 int chordvis_frame_phase_a(ChordCtx* ctx);
 int chordvis_frame_phase_b(ChordCtx* ctx);
 int chordvis_frame_phase_c(ChordCtx* ctx);
 /* Pipelined form of phase c, for hosts that let the visibility all-gather of frame i travel beside frame i + 1 (two frames'
- * words alive: chordvis_swap_visibility before every phase a).  The frame's final HZB then comes from an exchange of the
- * ranks' own-stripe mip 0 instead of from the gathered image -- the same chain, bit for bit:
- *   chordvis_frame_phase_c_begin    own-stripe mip 0 (min, max) into the two exchange buffers, the rank's valid-range pair
- *   [all-gather chordvis_hzb_exchange_ptr, chordvis_hzb_exchange_max_ptr (chunk = hzb_exchange_chunk_halves) and
- *    chordvis_range_exchange_ptr (two uint32 per rank)]
- *   chordvis_frame_phase_c_finish   the chain from the exchanged mip 0, history swap; the frame is over
+ * words alive: chordvis_swap_visibility before every phase a).  The history HZB needs only the small end-of-frame exchange:
+ *   [all-gather chordvis_hzb_final_exchange_ptr]
+ *   chordvis_frame_phase_c_finish   the history chain from the exchanged texels, history swap; the frame is over
  *   [whenever the visibility all-gather of the frame has landed: chordvis_frame_resolve_visibility, on any stream]   */
-int chordvis_frame_phase_c_begin(ChordCtx* ctx);
 int chordvis_frame_phase_c_finish(ChordCtx* ctx);
 int chordvis_frame_resolve_visibility(ChordCtx* ctx, void* hipStream /* NULL: the context's */);
 int chordvis_swap_visibility(ChordCtx* ctx);
-uint16_t* chordvis_hzb_exchange_max_ptr(ChordCtx* ctx);
-uint32_t* chordvis_range_exchange_ptr(ChordCtx* ctx);
+/* end-of-frame exchange buffer: per tile slot the min and max chains' texels (mips 0..5), the tile's valid range and bin length */
+uint16_t* chordvis_hzb_final_exchange_ptr(ChordCtx* ctx);
+uint64_t chordvis_hzb_final_exchange_chunk_bytes(ChordCtx* ctx);   /* one rank */
 int chordvis_reset_history(ChordCtx* ctx);
-/* exchange buffer for the mid-frame HZB mip-0 all-gather (f16, rank-major) */
+/* mid-frame exchange buffer: per tile slot the min chain's texels (mips 0..5, f16) after the first raster pass, rank-major */
 uint16_t* chordvis_hzb_exchange_ptr(ChordCtx* ctx);
 uint64_t chordvis_hzb_exchange_halves(ChordCtx* ctx);        /* whole buffer */
 uint64_t chordvis_hzb_exchange_chunk_halves(ChordCtx* ctx);  /* one rank     */
@@ -304,18 +329,14 @@ uint64_t chordvis_hzb_exchange_chunk_halves(ChordCtx* ctx);  /* one rank     */
 uint64_t* chordvis_resolved_visibility_ptr(ChordCtx* ctx);
 
 /* ------------------------------------------------------------------ multi-GPU (the reference is single-device,
- * graphics.cpp:524-548).  The frame shards by interleaved row stripes (chordvis_set_shard); the two exchanges of a sharded
- * frame -- own-stripe HZB mip 0 between the raster passes, own-stripe visibility words at the end -- are issued by the library,
+ * graphics.cpp:524-548).  The frame shards by screen tiles (chordvis_set_shard); the exchanges of a sharded frame -- the owned
+ * tiles' HZB texels between the raster passes, their HZB texels and visibility words at the end -- are issued by the library,
  * so the host keeps ONE call per frame, like DeferredRenderer::render (renderer.cpp:319-345). */
-
-/* even stripe height in [32, 256]: the tallest that leaves every rank at least two stripes, weighing the padding of the last
- * stripe against the share of clusters that straddle two stripes (multi_gpu.cpp: it minimises padding / height + 18 / rows) */
-uint32_t chordvis_pick_stripe_rows(uint32_t height, uint32_t ranks);
 
 /* (a) one process per GPU (torch.distributed / MPI hosts): attach an RCCL communicator to a sharded context; from then on
  * chordvis_render_frame(ctx) runs phase a -> ncclAllGather -> phase b -> ncclAllGather -> phase c on the context's stream.
  * Rank 0 makes the id (ncclGetUniqueId), the host distributes the 128 bytes by its own means, every rank calls init_rank
- * after chordvis_set_shard(stripeRows, nranks, rank).  librccl.so is resolved at run time, preferring a copy already loaded
+ * after chordvis_set_shard(nranks, rank).  librccl.so is resolved at run time, preferring a copy already loaded
  * into the process (CHORDVIS_RCCL=<path> overrides). */
 #define CHORDVIS_UNIQUE_ID_BYTES 128
 int chordvis_comm_unique_id(void* out128);
@@ -323,8 +344,7 @@ int chordvis_comm_init_rank(ChordCtx* ctx, uint32_t nranks, uint32_t rank, const
 int chordvis_comm_destroy(ChordCtx* ctx);
 /* Pipelined frames over RCCL (the ChordGroup form: chordvis_group_set_pipelined below).  id128: a SECOND unique id (the same
  * on every rank) for the communicator that carries the image of frame i, on a stream of its own, beside frame i + 1; the
- * history HZB then comes from three small exchanges of own-stripe data instead of from the gathered image (bit for bit the
- * same chain).  chordvis_readback_visibility / chordvis_visibility_mark / chordvis_wait_visibility wait for the image.
+ * history HZB then waits only for the small end-of-frame exchange, not for the image.  chordvis_readback_visibility / chordvis_visibility_mark / chordvis_wait_visibility wait for the image.
  * NULL switches back to the plain protocol.  The context must own its visibility buffer. */
 int chordvis_comm_set_pipelined(ChordCtx* ctx, const void* id128);
 /* NCCL_VERSION_CODE of the loaded library, ranks of ctx's communicator (0 = none; ctx may be NULL), where librccl came from */
@@ -342,8 +362,9 @@ ChordCtx* chordvis_group_ctx(ChordGroup* group, uint32_t rank);
 const char* chordvis_group_last_error(ChordGroup* group);
 int chordvis_group_set_limits(ChordGroup* group, const ChordLimits* limits);
 int chordvis_group_upload_scene(ChordGroup* group, const ChordSceneDesc* scene);
-/* stripeRows 0 = chordvis_pick_stripe_rows(height, n) */
-int chordvis_group_allocate_gbuffer(ChordGroup* group, uint32_t width, uint32_t height, uint32_t stripeRows);
+int chordvis_group_allocate_gbuffer(ChordGroup* group, uint32_t width, uint32_t height);
+/* chordvis_rebalance on every rank (drains the frames in flight first) */
+int chordvis_group_rebalance(ChordGroup* group, uint32_t* imbalancePermille);
 int chordvis_group_update_objects(ChordGroup* group, const ChordObject* hostObjects, uint32_t count);
 int chordvis_group_set_view(ChordGroup* group, const ChordCameraView* view, const ChordInstanceCullingView* instanceView, uint32_t switchFlags);
 /* DeferredRenderer::render hot segment (renderer.cpp:315-345,489) on n devices; returns when the frame is ENQUEUED on every

@@ -516,10 +516,10 @@ void orc_hzb_culling(const ChordSceneDesc* scene, const ChordCameraView* view, u
 
 /* ----------------------------------------------------------------- raster -- */
 
-static inline int owns_row(const OrcShard* s, uint32_t y)
+static inline int owns_pixel(const OrcShard* s, uint32_t x, uint32_t y)
 {
-    if (!s || s->ranks <= 1) return 1;
-    return ((y / s->stripeRows) % s->ranks) == s->rank;
+    if (!s || s->ranks <= 1 || !s->owners) return 1;
+    return s->owners[(size_t)(y / 64u) * s->tilesX + x / 64u] == s->rank;
 }
 
 /* `atomic` names how a raster call reaches the image: 0 plain row-major, 1 row-major shared by threads (compare-and-swap),
@@ -682,8 +682,8 @@ static void raster_snapped(const int32_t X[3], const int32_t Y[3], const float d
     if (mk) mask_setup(mk, scene, mat, A, tu, tv, tw);
 
     for (int64_t py = py0; py <= py1; py++) {
-        if (!owns_row(shard, (uint32_t)py)) continue;
         for (int64_t px = px0; px <= px1; px++) {
+            if (!owns_pixel(shard, (uint32_t)px, (uint32_t)py)) continue;
             int64_t cx = px * 256 + 128, cy = py * 256 + 128;
             int64_t E[3];
             int inside = 1;

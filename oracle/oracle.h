@@ -37,10 +37,11 @@ typedef struct OrcRasterStats {
     uint64_t fragmentsClipped;   /* covered pixel centres a masked material's clip() dropped (not in `fragments`) */
 } OrcRasterStats;
 
-/* Screen ownership for the multi-GPU shard: rows are cut into stripes of
- * `stripeRows`; stripe s belongs to rank (s % ranks).  ranks == 1 => all. */
+/* Screen ownership for the multi-GPU shard: the screen is cut into 64 x 64-pixel tiles, tile (tx, ty) belongs to rank
+ * owners[ty * tilesX + tx]; a rank writes only the pixels of its tiles.  NULL / ranks == 1 => all. */
 typedef struct OrcShard {
-    uint32_t stripeRows;
+    const uint8_t* owners;
+    uint32_t tilesX;
     uint32_t ranks;
     uint32_t rank;
 } OrcShard;

@@ -72,9 +72,9 @@ def tiles_with_type(marker, t):
 
 def assert_rank_counts(rank_stats, single):
     """Counts of a sharded frame against the single-GPU frame's.  The instance cull is replicated (identical list, identical
-    slots: the visibility ids agree); the occlusion culls of a rank run over the clusters that touch ITS pixel rows only, so
+    slots: the visibility ids agree); the occlusion culls of a rank run over the clusters that touch ITS screen tiles only, so
     per stage every rank counts at most the frame's clusters and together they count every one of them at least once
-    (a cluster that straddles two stripes is culled -- identically -- by both owners)."""
+    (a cluster that touches tiles of two ranks is culled -- identically -- by both owners)."""
     assert all(st["overflow"] == 0 for st in rank_stats)
     assert all(st["countInstanceCulled"] == single["countInstanceCulled"] for st in rank_stats)
     for k in ("countStage0Visible", "countStage0Rejected", "countStage1Visible"):

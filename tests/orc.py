@@ -22,7 +22,7 @@ class RasterStats(C.Structure):
 
 
 class Shard(C.Structure):
-    _fields_ = [("stripeRows", C.c_uint32), ("ranks", C.c_uint32), ("rank", C.c_uint32)]
+    _fields_ = [("owners", C.c_void_p), ("tilesX", C.c_uint32), ("ranks", C.c_uint32), ("rank", C.c_uint32)]
 
 
 def build_oracle():
@@ -79,9 +79,14 @@ def hzb_desc(w, h):
 
 
 def _shard(shard):
+    """shard = (owners uint8[tiles], tiles_x, ranks, rank): the screen-tile map of chord_amd.sharding and the rank that renders."""
     if shard is None:
         return None
-    return C.byref(Shard(*shard))
+    owners, tiles_x, ranks, rank = shard
+    owners = np.ascontiguousarray(owners, dtype=np.uint8)
+    s = Shard(owners.ctypes.data, int(tiles_x), int(ranks), int(rank))
+    s._keep = owners
+    return C.byref(s)
 
 
 def instance_culling(scene, view, iv, flags):

@@ -1,4 +1,4 @@
-"""The multi-GPU entry points on ONE device: ranks share device 0, so the protocol (stripes, two exchanges, event
+"""The multi-GPU entry points on ONE device: ranks share device 0, so the protocol (screen tiles, the exchanges, event
 ordering, buffer reuse, one call per frame) is what is tested; xGMI bandwidth is not."""
 import json
 import os
@@ -14,16 +14,17 @@ from chord_amd import scenes
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# (name, scene, ranks, re-balance the tile map from frame 1's loads before frame 2)
 GROUPS = [
-    ("small_2", lambda: scenes.small_test_scene(320, 200, seed=17), 2, 14),
-    ("small_5", lambda: scenes.small_test_scene(320, 200, seed=23), 5, 0),
-    ("street_720p_8", lambda: scenes.config3_street(1280, 720), 8, 0),
-    ("street_x64_360p_4", lambda: scenes.config4_street_x64(640, 360), 4, 0),
+    ("small_2", lambda: scenes.small_test_scene(320, 200, seed=17), 2, False),
+    ("small_5", lambda: scenes.small_test_scene(320, 200, seed=23), 5, True),
+    ("street_720p_8", lambda: scenes.config3_street(1280, 720), 8, True),
+    ("street_x64_360p_4", lambda: scenes.config4_street_x64(640, 360), 4, False),
 ]
 
 
-@pytest.mark.parametrize("name,builder,ranks,stripe", GROUPS, ids=[g[0] for g in GROUPS])
-def test_group_frames_equal_the_single_gpu_frames(gpu, name, builder, ranks, stripe):
+@pytest.mark.parametrize("name,builder,ranks,rebalance", GROUPS, ids=[g[0] for g in GROUPS])
+def test_group_frames_equal_the_single_gpu_frames(gpu, name, builder, ranks, rebalance):
     """chordvis_create_group / chordvis_group_render_frame: one call per frame, the library issues both exchanges
     (direct peer copies ordered by events, no host synchronisation inside a frame); four frames with a moving camera so
     that buffers are reused while copies of the previous frame may still be in flight."""
@@ -39,7 +40,7 @@ def test_group_frames_equal_the_single_gpu_frames(gpu, name, builder, ranks, str
     ref.allocate_gbuffer(w, h)
     g = VisibilityGroup([0] * ranks)
     g.upload_scene(scene)
-    g.allocate_gbuffer(w, h, stripe)
+    g.allocate_gbuffer(w, h)
     wants = []
     last_view = None
     inputs = []
@@ -59,6 +60,13 @@ def test_group_frames_equal_the_single_gpu_frames(gpu, name, builder, ranks, str
         g.render_frame()
     g.sync()
     _check_ranks(g, wants[1], w, h, "frame 1")
+    if rebalance:
+        # chordvis_group_rebalance: every rank re-maps the tiles from the loads of frame 1 (the history HZB carries over)
+        old = g.ranks[0].tile_owners()
+        imb = g.rebalance()
+        maps = [r.tile_owners() for r in g.ranks]
+        assert imb >= 1.0 and all(np.array_equal(maps[0], m) for m in maps[1:])
+        assert not np.array_equal(maps[0], old) or imb < 1.02
     for k, (objs, view, iv) in enumerate(inputs[2:], start=2):   # ... and frame by frame
         g.update_objects(objs)
         g.set_view(view, iv, flags)
@@ -78,18 +86,18 @@ def _check_ranks(g, want, w, h, what):
 
 
 PIPELINED = [
-    ("small_2", lambda: scenes.small_test_scene(320, 200, seed=17), 2, 14),
-    ("small_3", lambda: scenes.small_test_scene(320, 200, seed=23), 3, 0),
+    ("small_2", lambda: scenes.small_test_scene(320, 200, seed=17), 2, 0),
+    ("small_3", lambda: scenes.small_test_scene(320, 200, seed=23), 3, 4),
     ("street_720p_4", lambda: scenes.config3_street(1280, 720), 4, 0),
-    ("street_x64_360p_8", lambda: scenes.config4_street_x64(640, 360), 8, 0),
+    ("street_x64_360p_8", lambda: scenes.config4_street_x64(640, 360), 8, 3),
 ]
 
 
-@pytest.mark.parametrize("name,builder,ranks,stripe", PIPELINED, ids=[g[0] for g in PIPELINED])
-def test_pipelined_group_frames_equal_the_single_gpu_frames(gpu, name, builder, ranks, stripe):
+@pytest.mark.parametrize("name,builder,ranks,rebalance_at", PIPELINED, ids=[g[0] for g in PIPELINED])
+def test_pipelined_group_frames_equal_the_single_gpu_frames(gpu, name, builder, ranks, rebalance_at):
     """chordvis_group_set_pipelined: the visibility all-gather and row-major copy of frame i run beside frame i + 1 (two
-    buffer pairs per rank), and the history HZB comes from an exchange of own-stripe mip 0 (min, max) and valid-range pairs
-    instead of from the gathered image.  Six frames with a moving camera, never synchronised in between: every rank's
+    buffer pairs per rank), and the history HZB waits only for the small end-of-frame exchange (the tiles' HZB texels out of
+    the tile kernel), not for the gathered image.  rebalance_at: the tile map is re-made from the loads before that frame.  Six frames with a moving camera, never synchronised in between: every rank's
     image of every frame (read as 'the frame before' once the next one is submitted, then as the last one), HZB chain and
     counts equal the single-GPU frames."""
     from chord_amd import lib as L
@@ -104,7 +112,7 @@ def test_pipelined_group_frames_equal_the_single_gpu_frames(gpu, name, builder, 
     ref.allocate_gbuffer(w, h)
     g = VisibilityGroup([0] * ranks)
     g.upload_scene(scene)
-    g.allocate_gbuffer(w, h, stripe)
+    g.allocate_gbuffer(w, h)
     g.set_pipelined(True)
     inputs, wants, last_view = [], [], None
     for k, cam in enumerate(cams):
@@ -117,10 +125,12 @@ def test_pipelined_group_frames_equal_the_single_gpu_frames(gpu, name, builder, 
         ref.render_frame()
         wants.append((ref.read_visibility(), ref.read_hzb(ref.history_hzb()), ref.stats()))
     for k, (objs, view, iv) in enumerate(inputs):
+        if rebalance_at and k == rebalance_at:
+            g.rebalance()                                  # (drains the frames in flight: their images were laid out with the old map)
         g.update_objects(objs)
         g.set_view(view, iv, flags)
         g.render_frame()                                   # frame k enqueued; frame k - 1's image may still be travelling
-        if k in (1, 3, 5):
+        if k in (1, 3, 5) and k != rebalance_at:
             for rk, r in enumerate(g.ranks):
                 H.assert_vis_equal(r.read_previous_visibility(), wants[k - 1][0], w, h, "frame %d (as the previous one) rank %d" % (k - 1, rk))
         if k >= 2:
@@ -173,7 +183,7 @@ def test_sharded_render_frame_without_a_communicator_is_refused(gpu):
     scene, cam, view, iv = H.setup_scene(lambda: scenes.small_test_scene(160, 96))
     r = VisibilityRenderer(0)
     r.upload_scene(scene)
-    r.set_shard(16, 2, 1)
+    r.set_shard(2, 1)
     r.allocate_gbuffer(cam.width, cam.height)
     r.set_view(view, iv, H.ALL_FLAGS)
     with pytest.raises(L.ChordvisError):

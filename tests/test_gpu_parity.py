@@ -460,52 +460,56 @@ def test_config3_street_4k_two_pass_matches_oracle_and_properties(gpu):
     r.close()
 
 
+# (name, scene, ranks, tile map): "default" = the library's compact regions, "checker" = every tile border a rank border (an
+# explicit map: chordvis_set_tile_owners), "rebalance" = default on frame 0, then chordvis_rebalance from that frame's loads
 SHARDED = [
-    ("small_3ranks", lambda: scenes.small_test_scene(320, 200, seed=17), 3, 14),
-    # many small clusters per stripe: exercises the cluster-level ownership filter of the setup kernel
-    ("street_720p_4ranks", lambda: scenes.config3_street(1280, 720), 4, None),
+    ("small_3ranks", lambda: scenes.small_test_scene(320, 200, seed=17), 3, "checker"),
+    # many small clusters per tile: exercises the cluster-level ownership filter of the group cull
+    ("street_720p_4ranks", lambda: scenes.config3_street(1280, 720), 4, "default"),
     # config 4 (the N > 1 bench workload) at reduced size: overflow chunks and split tiles in sharded frames
-    ("street_x64_360p_8ranks", lambda: scenes.config4_street_x64(640, 360), 8, None),
+    ("street_x64_360p_8ranks", lambda: scenes.config4_street_x64(640, 360), 8, "rebalance"),
     # config 5 (sub-pixel patches, the other multi-GPU workload) at reduced size
-    ("subpixel_540p_8ranks", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4), 8, None),
+    ("subpixel_540p_8ranks", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4), 8, "default"),
     # full size: long bins, pool chunks and split tiles in both raster passes of a sharded frame
-    ("street_x64_4k_2ranks", scenes.config4_street_x64, 2, None),
-    ("masked_3ranks", lambda: scenes.masked_test_scene(320, 200), 3, 14),
-    # small clusters as pixel blocks on every rank (rows of a block that another rank owns stay empty)
-    ("subpixel_540p_8ranks_blocks", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4), 8, None),
-    # the hotspot variant of config 5: all the work in the few stripes around the screen centre (the imbalance is the point)
-    ("hotspot_540p_8ranks_blocks", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4, hotspot_sigma_px=64.0), 8, None),
-    ("street_x64_360p_3ranks_blocks", lambda: scenes.config4_street_x64(640, 360), 3, 18),
-    ("masked_3ranks_blocks", lambda: scenes.masked_test_scene(320, 200), 3, 14),
+    ("street_x64_4k_2ranks", scenes.config4_street_x64, 2, "default"),
+    ("masked_3ranks", lambda: scenes.masked_test_scene(320, 200), 3, "checker"),
+    # small clusters as pixel blocks on every rank (the parts of a block in another rank's tiles are not emitted)
+    ("subpixel_540p_8ranks_blocks", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4), 8, "checker"),
+    # the hotspot variant of config 5: all the work in a few tiles around the screen centre; the map of frame 1 spreads them
+    ("hotspot_540p_8ranks_blocks", lambda: scenes.config5_subpixel(960, 540, prims=16, patches_per_prim=256, instances=4, hotspot_sigma_px=64.0), 8, "rebalance"),
+    ("street_x64_360p_3ranks_blocks", lambda: scenes.config4_street_x64(640, 360), 3, "default"),
+    ("masked_3ranks_blocks", lambda: scenes.masked_test_scene(320, 200), 3, "default"),
 ]
 
 
-@pytest.mark.parametrize("name,builder,ranks,stripe", SHARDED, ids=[s[0] for s in SHARDED])
-def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, ranks, stripe):
-    """The multi-GPU path on one device: every rank's context runs its phases in turn, the two
-    all-gathers are replaced by device-to-device copies of the rank chunks, and each rank must end up
-    with exactly the single-GPU visibility buffer and HZB."""
+@pytest.mark.parametrize("name,builder,ranks,tile_map", SHARDED, ids=[s[0] for s in SHARDED])
+def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, ranks, tile_map):
+    """The multi-GPU path on one device: every rank's context runs its phases in turn, the three
+    all-gathers (mid-frame HZB texels; end-of-frame HZB texels; visibility words) are replaced by device-to-device
+    copies of the rank chunks, and each rank must end up with exactly the single-GPU visibility buffer and HZB."""
     import ctypes as C
     import torch
     from chord_amd import lib as L
     from chord_amd.renderer import VisibilityRenderer
-    from chord_amd.sharding import pick_stripe_rows
+    from chord_amd.sharding import TileLayout
     scene, cam, view, iv = H.setup_scene(builder)
     w, h, flags = cam.width, cam.height, H.ALL_FLAGS
     # the hotspot scene puts ~300 k records into its hottest tile when rendered unsharded in the record form (the single-GPU
     # reference below): beyond the default 16 Ki + 240 Ki entries per tile, so it runs under the documented raised limit
     limits = dict(bin_max_chunks_per_tile=2048) if name.startswith("hotspot") else None
     ref = _renderer(gpu, scene, view, iv, w, h, flags, limits=limits)
-    if stripe is None:
-        stripe = pick_stripe_rows(h, ranks)
+    lay = TileLayout(w, h, ranks)
     ctxs = []
     for rk in range(ranks):
         r = VisibilityRenderer(0)
         if limits:
             r.set_limits(**limits)
         r.upload_scene(scene)
-        r.set_shard(stripe, ranks, rk)
+        r.set_shard(ranks, rk)
         r.allocate_gbuffer(w, h)
+        assert np.array_equal(r.tile_owners(), lay.owners)
+        if tile_map == "checker":
+            r.set_tile_owners([(t % lay.tiles_x + t // lay.tiles_x) % ranks for t in range(lay.tiles)])
         r.set_view(view, iv, flags)
         if name.endswith("_blocks"):
             # (the hotspot case: odd ranks also draw bin slots ahead on hot tiles, the sharded form of the hot-tile variant)
@@ -526,9 +530,9 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, r
 
     # the small cases are also held against the ORACLE directly (not only against the single-GPU HIP frame: a defect common
     # to both HIP paths would pass the comparison between them)
-    vs_oracle = name in ("small_3ranks", "masked_3ranks", "subpixel_540p_8ranks_blocks", "hotspot_540p_8ranks_blocks")
+    vs_oracle = name in ("small_3ranks", "masked_3ranks", "subpixel_540p_8ranks_blocks", "hotspot_540p_8ranks_blocks", "street_x64_360p_8ranks")
     prev_hzb = None
-    for frame in range(2):                               # frame 0: no history; frame 1: two-pass HZB
+    for frame in range(3 if tile_map == "rebalance" else 2):   # frame 0: no history; frame 1: two-pass HZB (frame 2: again, under the re-balanced map's successor)
         ref.render_frame()
         want = ref.read_visibility()
         wmn, wmx, wrng = ref.read_hzb(ref.history_hzb())
@@ -544,6 +548,8 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, r
         gather([e[0] for e in ex], ex[0][2] * 2)
         for r in ctxs:
             r.frame_phase_b()
+        fin = [r.hzb_final_exchange() for r in ctxs]
+        gather([f[0] for f in fin], fin[0][1])
         gather([r.visibility_ptr() for r in ctxs], ctxs[0].visibility_chunk_words() * 8)
         for r in ctxs:
             r.frame_phase_c()
@@ -552,6 +558,17 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, r
             mn, mx, rng = r.read_hzb(r.history_hzb())
             assert np.array_equal(mn, wmn) and np.array_equal(mx, wmx) and np.array_equal(rng, wrng)
         H.assert_rank_counts([r.stats() for r in ctxs], ref.stats())
+        # every rank holds every tile's load after the end-of-frame exchange; tiles nobody drew into report 0
+        loads = [r.read_tile_loads() for r in ctxs]
+        assert all(np.array_equal(loads[0], x) for x in loads[1:]) and loads[0].sum() > 0
+        if tile_map == "rebalance" and frame < 2:
+            before = [r.rebalance() for r in ctxs]
+            maps = [r.tile_owners() for r in ctxs]
+            assert all(np.array_equal(maps[0], m) for m in maps[1:]) and len(set(before)) == 1
+            per = np.bincount(maps[0], weights=loads[0].astype(np.float64), minlength=ranks)
+            # the new map under the loads it was made from: no rank far above the mean unless a single tile is
+            assert per.max() <= max(1.3 * per.mean(), 1.02 * loads[0].max()), (per.tolist(), before)
+            assert np.bincount(maps[0], minlength=ranks).max() == ctxs[0].visibility_chunk_words() // 4096
     for r in ctxs + [ref]:
         r.close()
 

@@ -117,17 +117,21 @@ def test_larger_packed_word_wins():
     assert len(nz) and (nz == ((np.uint64(np.float32(0.5).view(np.uint32)) << np.uint64(32)) | np.uint64(4))).all()
 
 
-def test_row_sharding_partitions_the_pixels():
-    X, Y = [px(3.3), px(60.1), px(20.7)], [px(2.2), px(30.9), px(61.4)]
-    full, _ = orc.raster_snapped_triangle(X, Y, (0.3, 0.6, 0.9), 1, 11, W, H)
+def test_tile_sharding_partitions_the_pixels():
+    """Screen ownership by 64 x 64 tiles: the ranks' images are disjoint, each inside its own tiles, together the full one."""
+    Wb, Hb = 200, 150                                         # 4 x 3 tiles
+    big = lambda v: int(round(v * 256))
+    X, Y = [big(3.3), big(190.1), big(60.7)], [big(2.2), big(70.9), big(141.4)]
+    full, _ = orc.raster_snapped_triangle(X, Y, (0.3, 0.6, 0.9), 1, 11, Wb, Hb)
+    owners = np.array([0, 1, 2, 3, 3, 2, 1, 0, 1, 1, 0, 2], dtype=np.uint8)
+    own_px = owners[(np.arange(Hb)[:, None] // 64) * 4 + np.arange(Wb)[None, :] // 64]
     acc = np.zeros_like(full)
     for r in range(4):
-        part, _ = orc.raster_snapped_triangle(X, Y, (0.3, 0.6, 0.9), 1, 11, W, H, shard=(6, 4, r))
+        part, _ = orc.raster_snapped_triangle(X, Y, (0.3, 0.6, 0.9), 1, 11, Wb, Hb, shard=(owners, 4, 4, r))
         assert not ((acc != 0) & (part != 0)).any()
-        rows = np.nonzero(part.reshape(H, W).any(axis=1))[0]
-        assert all((y // 6) % 4 == r for y in rows)
+        assert (own_px[part.reshape(Hb, Wb) != 0] == r).all()
         acc |= part
-    assert np.array_equal(acc, full)
+    assert np.array_equal(acc, full) and len(np.unique(own_px[full.reshape(Hb, Wb) != 0])) == 4
 
 
 # ------------------------------------------------------------------------------- id encoding ---
