@@ -44,7 +44,7 @@ def frame(ranks):
 for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
     loads = None
     for which in (maps if ranks > 1 else ["-"]):
-        per_rank, stamps0, owners = [], None, None
+        per_rank, stamps0, owners, detail = [], None, None, []
         if which == "balanced":
             owners = tile_layout(cam.width, cam.height, ranks, loads, int(L.lib.chordvis_tile_slot_capacity(cam.width, cam.height, ranks)))
         acc = None
@@ -69,12 +69,15 @@ for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
             assert st["overflow"] == 0, "work lists overflowed"
             if rk == 0:
                 stamps0 = st
+            detail.append("%.2fM/%.2f/%.2f" % (st["countStage0Visible"] / 1e6, st["msRasterCluster"], st["msRasterChunk"]))
             if ranks > 1:
                 # this rank's own tiles' loads (the other slots of its exchange buffer were never gathered: zero)
                 mine = r.read_tile_loads().astype(np.int64) * (r.tile_owners() == rk)
                 acc = mine if acc is None else acc + mine
         if ranks > 1 and which == "default":
             loads = acc.astype(np.uint32)
+            if os.environ.get("DUMP"):
+                np.save(os.path.join(os.environ["DUMP"], "loads_%s_%d.npy" % (wl, ranks)), loads)
         worst, mean = max(per_rank), sum(per_rank) / len(per_rank)
         if ranks == 1:
             single = worst
@@ -83,7 +86,8 @@ for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
         if ranks > 1:
             own = r.tile_owners()
             per = np.bincount(own, weights=acc.astype(np.float64), minlength=ranks)
-            extra = "; entries max/mean %.3f, tiles per rank %d..%d" % (per.max() / max(per.mean(), 1.0), np.bincount(own, minlength=ranks).min(), np.bincount(own, minlength=ranks).max())
+            extra = "; entries max/mean %.3f, tiles per rank %d..%d; per rank clusters / setup ms / tile ms: %s" % (
+                per.max() / max(per.mean(), 1.0), np.bincount(own, minlength=ranks).min(), np.bincount(own, minlength=ranks).max(), " ".join(detail))
         print("ranks %d (map %s): worst rank %.3f ms/frame, mean %.3f, max/mean %.3f%s%s; per rank %s;  rank-0 GPU stamps (ms): cull %.3f stage0 %.3f hzb0 %.3f stage1 %.3f hzbFinal %.3f | setup %.3f clip+order %.3f tile %.3f"
               % (ranks, which, worst, mean, worst / mean,
                  ("; speed-up with %.2f ms of collectives: %.2fx" % (coll, single / (worst + coll))) if single and ranks > 1 else "", extra,
