@@ -61,6 +61,8 @@ def build_workload(name):
         return scenes.config5_subpixel(3840, 2160, prims=64, hotspot_sigma_px=64.0)
     if name == "street_720p_hzb":        # config 3 at 1280x720: the small two-pass workload of the N > 1 protocol tests
         return scenes.config3_street(1280, 720)
+    if name == "street_x64_720p_hzb":    # config 4 at 1280x720 (the protocol tests' stand-in for the `also` workload)
+        return scenes.config4_street_x64(1280, 720, grid=8)
     if name == "atrium_1080p":
         return scenes.config2_atrium(1920, 1080)
     raise SystemExit("unknown workload %r" % name)
@@ -75,6 +77,7 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=("auto", "lib", "torch", "group"),
                     help="N > 1: who issues the all-gathers -- the library over RCCL, torch.distributed, or one process with N devices (ChordGroup, peer copies); auto = the first that works")
     ap.add_argument("--pipelined", action="store_true", help="N > 1, --exchange lib: the visibility all-gather of frame i runs beside frame i + 1 (second RCCL communicator)")
+    ap.add_argument("--no-also", action="store_true", help="N > 1, default workload: do not also measure BASELINE config 4 (street_x64_4k_hzb) for the line's `also` field")
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep the default tile map (compact regions of equal area) instead of re-balancing it from the warm-up frames' tile loads")
     ap.add_argument("--cpu-baseline-frames", type=int, default=48, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
     ap.add_argument("--cull", default="flat", choices=("flat", "hierarchical"),
@@ -110,7 +113,34 @@ def main():
     from chord_amd import lib as L, records as R
     from chord_amd.renderer import VisibilityRenderer
 
-    wl = args.workload
+    # ---- the workload of the line; N > 1 with the default workload (config 5) also measures BASELINE config 4, the configuration
+    #      BASELINE.json names for 2/4/8 GPUs (a sub-millisecond frame that the exchanges dominate: DESIGN.md 6), in the same line
+    env = dict(world=world, rank=rank, local_rank=local_rank, backend=backend, dev=dev, stream=stream)
+    line = measure(args, args.workload, env)
+    # (CHORDVIS_BENCH_ALSO: test hook -- a small second workload for the one-GPU protocol tests)
+    also_wl = os.environ.get("CHORDVIS_BENCH_ALSO") or ("street_x64_4k_hzb" if args.workload == "auto" else None)
+    if world > 1 and also_wl and not args.no_also:
+        also = measure(args, also_wl, env)
+        if line is not None and also is not None:
+            line["also"] = {k: also[k] for k in ("config", "value", "unit", "ms_per_step", "steps", "timed_region_s", "exchange", "pipelined", "tile_map", "exchange_fallbacks",
+                                                   "phases_ms", "single_gpu_same_workload", "speedup_vs_single", "triangles_submitted_per_step", "gpu_ms") if k in also}
+    if line is not None:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def measure(args, workload, env):
+    """One workload through the whole protocol of the bench (scene, renderer, exchange set-up, warm-up, timed region, roofline, references);
+    returns the JSON line as a dict on rank 0, None on the other ranks."""
+    world, rank, local_rank, backend, dev, stream = (env[k] for k in ("world", "rank", "local_rank", "backend", "dev", "stream"))
+    args = argparse.Namespace(**vars(args))          # (per-workload switches below must not leak into the next measurement)
+    from chord_amd import lib as L, records as R
+    from chord_amd.renderer import VisibilityRenderer
+    line = None
+    wl = workload
     if wl == "auto":
         # N = 1: BASELINE config 3 (the largest single-GPU configuration).  N > 1: config 5, the multi-GPU stress
         # configuration (1 G sub-pixel triangles per frame): a frame long enough (40 ms on one GPU) for the
@@ -513,10 +543,8 @@ def main():
         if single_ref is not None:
             line["single_gpu_same_workload"] = single_ref
             line["speedup_vs_single"] = round(single_ref["ms_per_step"] / ms_per_step, 4)
-        print(json.dumps(line), flush=True)
     r.close()
-    if world > 1:
-        dist.destroy_process_group()
+    return line
 
 
 def run_group(args, wl, scene, views, objs, flags, W, H, world, rank, dev, stream, fallbacks):
@@ -554,11 +582,13 @@ def run_group(args, wl, scene, views, objs, flags, W, H, world, rank, dev, strea
                     "tiles_per_rank": np.bincount(owners, minlength=world).tolist()}
         for r_ in g.ranks:
             r_.enable_timers(2, period=8)
+        g.enqueue_ms()                                   # (reset)
         t0 = time.perf_counter()
         for i in range(args.steps):
             frame(i)
         g.sync()
         elapsed = time.perf_counter() - t0
+        enq = g.enqueue_ms()
         sts = [r_.stats() for r_ in g.ranks]
         g.close()
         r1 = VisibilityRenderer(0, stream.cuda_stream)
@@ -601,14 +631,12 @@ def run_group(args, wl, scene, views, objs, flags, W, H, world, rank, dev, strea
                 "phases_ms": [{"rank": k, "phase_a_cull": round(st["msClear"] + st["msInstanceCulling"], 4), "phase_a_stage0": round(st["msStage0"], 4),
                                "hzb_mid": round(st["msHzbStage0"], 4), "exchange_hzb": round(st["msExchangeHzb"], 4), "phase_b_stage1": round(st["msStage1"], 4),
                                "exchange_vis": round(st["msExchangeVis"], 4), "phase_c_final_hzb": round(st["msHzbFinal"], 4),
-                               "setup_kernels": round(st["msRasterCluster"], 4), "tile_kernels": round(st["msRasterChunk"], 4)} for k, st in enumerate(sts)],
+                               "setup_kernels": round(st["msRasterCluster"], 4), "tile_kernels": round(st["msRasterChunk"], 4),
+                               "host_enqueue_ms": round(enq[k], 4)} for k, st in enumerate(sts)],
                 "roofline": None, "cpu_baseline": None,
                 "single_gpu_same_workload": single, "speedup_vs_single": round(single["ms_per_step"] / ms, 4)}
     dist.barrier()
-    if line is not None:
-        print(json.dumps(line), flush=True)
-    dist.destroy_process_group()
-    return 0
+    return line
 
 
 def _torch_nccl_version():

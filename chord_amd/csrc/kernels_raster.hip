@@ -985,6 +985,14 @@ __device__ __forceinline__ void resolve_triangle(const RasterParams& p, uint32_t
 #ifndef SLOT_AHEAD
 #define SLOT_AHEAD 8u
 #endif
+// ... and four times as many once the bin is a quarter of a million entries long: a rank of a sharded frame that owns such a tile
+// owns little else, every one of its waves draws from that one counter line, and the queue on the line is what the kernel
+// waits for (BASELINE config 5's hotspot at 8 ranks, the rank with the 1.34 M-entry tile: 7.6 -> 6.6 ms per frame; drawing 32
+// ahead everywhere costs the one-GPU frame 4 %: every wave leaves up to 31 unused slots in each of the ~40 hot tiles it touched)
+#ifndef SLOT_AHEAD_VERY_HOT
+#define SLOT_AHEAD_VERY_HOT 32u
+#endif
+#define SLOT_VERY_HOT 262144u
 struct SlotCache { uint32_t key[SLOT_CACHE], next[SLOT_CACHE], end[SLOT_CACHE]; uint32_t pend; };   // key = tile + 1 (0: free), slots [next, end) in reserve; pend: lane 0's draw in flight
 
 #ifndef BLOCKS_LDS_VERTS
@@ -1149,7 +1157,7 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                             if (lane == 0u && has && sc.key[ci] == tile + 1u) {
                                 const uint32_t nx = sc.next[ci];
                                 if (nx < sc.end[ci]) { slot = nx; sc.next[ci] = nx + 1u; ahead = 0u; }
-                                else ahead = SLOT_AHEAD;                         // a hot tile whose reserve is used up: draw ahead again
+                                else ahead = nx >= SLOT_VERY_HOT ? SLOT_AHEAD_VERY_HOT : SLOT_AHEAD;   // a hot tile whose reserve is used up: draw ahead again
                             }
                             if (lane == 0u) sc.pend = ahead;
                         }

@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <cstdio>
@@ -339,6 +340,10 @@ struct ChordGroup {
     uint32_t pending = 0;
     std::vector<int> jobRc;
     bool quit = false;
+    // host time each worker spent inside its chordvis_group_render_frame job (enqueueing kernels, copies, waits for its peers'
+    // generations), accumulated until chordvis_group_enqueue_ms reads it: what the call costs the host, rank by rank
+    std::vector<double> frameJobMs;
+    std::vector<uint32_t> frameJobs;
     // An event must be RECORDED before another thread enqueues a wait on it.  Round 2 put two host barriers (mutex + condition
     // variable over all rank threads) into every exchange; now a rank PUBLISHES what it has recorded as a generation number per
     // event and a peer spins (no sleep: the threads run concurrently and are microseconds apart) until the generation it needs
@@ -452,6 +457,12 @@ int group_all_gather(ChordGroup* g, uint32_t r, int which, const std::function<c
 
 int gfail(ChordGroup* g, int code, const char* what) { if (g) g->lastError = what; return code; }
 
+struct JobClock {      // a worker's time inside one frame job (its own slot: no lock)
+    ChordGroup* g; uint32_t r; std::chrono::steady_clock::time_point t0;
+    JobClock(ChordGroup* g_, uint32_t r_) : g(g_), r(r_), t0(std::chrono::steady_clock::now()) {}
+    ~JobClock() { g->frameJobMs[r] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g->frameJobs[r]++; }
+};
+
 } // namespace
 
 extern "C" {
@@ -466,6 +477,7 @@ int chordvis_create_group(uint32_t n, const int* deviceOrdinals, ChordGroup** ou
     g->device.assign(deviceOrdinals, deviceOrdinals + n);
     g->ctx.assign(n, nullptr);
     g->jobRc.assign(n, 0);
+    g->frameJobMs.assign(n, 0.0); g->frameJobs.assign(n, 0);
     int rc = CHORDVIS_OK;
     for (uint32_t r = 0; r < n && !rc; r++) rc = chordvis_create(g->device[r], nullptr, &g->ctx[r]);
     g->copyStream.assign((size_t)n * n, nullptr);
@@ -578,6 +590,7 @@ int chordvis_group_render_frame(ChordGroup* g)
     // A rank that fails keeps walking through the host barriers (its peers would wait for it forever otherwise).
     return run_all(g, [&](uint32_t r) {
         ChordCtx* c = g->ctx[r];
+        JobClock clock(g, r);
         // the same on every rank (they share the frame history), and taken BEFORE phase a so that a rank whose phase a
         // fails still joins the exchange its peers are about to enter
         const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
@@ -644,6 +657,7 @@ static int group_render_frame_pipelined(ChordGroup* g)
     const int parity = (int)(serial & 1u);
     return run_all(g, [&, parity](uint32_t r) {
         ChordCtx* c = g->ctx[r];
+        JobClock clock(g, r);
         // the buffer pair this frame takes over was last used two frames ago: its gather and copy are complete on every rank
         // once every rank has seen its "image complete" event of that frame (recorded behind the waits for all copies into
         // AND out of the rank's buffer).  NOT a drain of the resolve stream: the previous frame's image is still travelling,
@@ -668,6 +682,16 @@ int chordvis_group_rebalance(ChordGroup* g, uint32_t* imbalancePermille)
     rc = run_all(g, [&](uint32_t r) { return chordvis_rebalance(g->ctx[r], &imb[r]); }, "group_rebalance");
     if (imbalancePermille) *imbalancePermille = imb[0];
     return rc;
+}
+
+// Mean host time per frame each rank's worker thread spent inside chordvis_group_render_frame since the last call (milliseconds,
+// n values; then reset): the launches and copies it enqueued plus its waits for the peers' hand-shakes.
+int chordvis_group_enqueue_ms(ChordGroup* g, double* msPerRank, uint32_t n)
+{
+    if (!g || !msPerRank || n != g->n) return gfail(g, CHORDVIS_E_INVALID, "group_enqueue_ms: one value per rank");
+    std::lock_guard<std::mutex> lk(g->m);                          // (no job is running: run_all returned)
+    for (uint32_t r = 0; r < n; r++) { msPerRank[r] = g->frameJobs[r] ? g->frameJobMs[r] / g->frameJobs[r] : 0.0; g->frameJobMs[r] = 0.0; g->frameJobs[r] = 0; }
+    return CHORDVIS_OK;
 }
 
 int chordvis_group_sync(ChordGroup* g)

@@ -17,9 +17,10 @@
 // compact blobs whatever the grid's aspect), and
 //   * without load figures the curve is cut into `ranks` runs of equal length;
 //   * with them (bin entries per tile of a rendered frame, chordvis_read_tile_loads) tiles heavier than a quarter of a rank's
-//     share are placed one by one, heaviest first, on the least loaded rank; the others are cut into runs of equal load along
-//     the curve (each rank's budget is what it still lacks); tiles with next to nothing in them (a sixteenth of the mean tile
-//     or less) are fillers that bring every rank to its tile count, again in runs along the curve.
+//     share are placed one by one, heaviest first, on the least loaded rank; the others are cut into contiguous runs along the
+//     curve such that the heaviest rank is as light as possible (bisection over the bound); the lightest tiles -- together a
+//     sixteenth of the load at most, each a quarter of the mean tile at most -- are fillers that bring every rank to its tile
+//     count, again in runs along the curve.
 
 #include "device_layer.h"
 
@@ -94,31 +95,56 @@ int tile_layout(uint32_t tilesX, uint32_t tilesY, uint32_t ranks, const uint32_t
         give(t, best);
     }
 
-    // ---- medium tiles: runs of equal load along the curve, a rank's budget being what it lacks of W / N
-    auto is_light = [&](uint32_t t) { return (uint64_t)loads[t] * tiles * 16u <= W; };
+    // ---- medium tiles: contiguous runs along the curve, the heaviest rank as light as possible
+    // fillers: the lightest tiles -- each at most a quarter of the mean tile -- that together hold at most a sixteenth of the load
+    std::vector<uint8_t> isLight(tiles, 0);
+    {
+        std::vector<uint32_t> cand;
+        for (uint32_t t : order) if (own[t] < 0 && (uint64_t)loads[t] * tiles * 4u <= W) cand.push_back(t);
+        std::stable_sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return loads[a] < loads[b]; });   // (stable: ties in curve order)
+        uint64_t cum = 0;
+        for (uint32_t t : cand) { cum += loads[t]; if (cum * 16u > W) break; isLight[t] = 1; }
+    }
     std::vector<uint32_t> medium, light;
     uint64_t Lrem = 0;
     for (uint32_t t : order) {
         if (own[t] >= 0) continue;
-        if (is_light(t)) light.push_back(t); else { medium.push_back(t); Lrem += loads[t]; }
+        if (isLight[t]) light.push_back(t); else { medium.push_back(t); Lrem += loads[t]; }
     }
     {
-        std::vector<uint64_t> lack(N);                                      // N * (W / N - load): scaled by N to stay in integers
-        for (uint32_t r = 0; r < N; r++) lack[r] = W > load[r] * N ? W - load[r] * N : 0u;
-        uint32_t k = 0;
-        uint64_t budget = 0, acc = 0;
-        auto open = [&](uint32_t r) {
-            uint64_t sum = 0;
-            for (uint32_t j = r; j < N; j++) sum += lack[j];
-            budget = sum ? (uint64_t)((unsigned __int128)Lrem * lack[r] / sum) : Lrem / (N - r);
-            acc = 0;
+        // The smallest bound B such that, walking the curve, rank 0, 1, ... each take tiles while their load stays within B
+        // and their tile count within the chunk, and the last rank ends the curve: bisection over B with that greedy walk as the
+        // feasibility test -- the optimal contiguous partition under the count limit (a region of light tiles that fills its
+        // chunk pushes load to ALL the others, not to the ranks that happen to follow it on the curve).
+        auto walk = [&](uint64_t B, bool commit) -> bool {
+            uint32_t k = 0;
+            uint64_t acc = 0;
+            uint32_t cnt = 0;
+            for (uint32_t t : medium) {
+                const uint64_t w = loads[t];
+                while (k < N && (count[k] + cnt >= S || load[k] + acc + w > B)) {
+                    if (commit) { /* (tiles were given as they were taken) */ }
+                    k++; acc = 0; cnt = 0;
+                }
+                if (k == N) return false;
+                if (commit) give(t, k); else { acc += w; cnt++; }
+            }
+            return true;
         };
-        open(0);
-        for (uint32_t t : medium) {
-            const uint64_t w = loads[t];
-            // close the run before this tile when that leaves the rank nearer its budget than taking it (or the rank is full)
-            while (k + 1u < N && (count[k] >= S || acc + w / 2u > budget)) { k++; open(k); }
-            give(t, k); acc += w; Lrem -= w;
+        uint64_t lo = 0, hi = W;
+        for (uint32_t r = 0; r < N; r++) hi = std::max(hi, load[r] + Lrem);
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2u;
+            if (walk(mid, false)) hi = mid; else lo = mid + 1u;
+        }
+        // commit: `give` updates load[] / count[] itself, so the walk's own accumulators stay zero
+        {
+            uint32_t k = 0;
+            for (uint32_t t : medium) {
+                const uint64_t w = loads[t];
+                while (k + 1u < N && (count[k] >= S || load[k] + w > lo)) k++;
+                give(t, k);
+            }
         }
     }
 

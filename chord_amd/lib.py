@@ -191,6 +191,7 @@ def _load():
         "chordvis_group_set_view": (i32, [vp, vp, vp, u32]),
         "chordvis_group_render_frame": (i32, [vp]),
         "chordvis_group_sync": (i32, [vp]),
+        "chordvis_group_enqueue_ms": (i32, [vp, vp, u32]),
         "chordvis_group_set_pipelined": (i32, [vp, i32]),
         "chordvis_allocate_depth_views": (i32, [vp, u32, u32]),
         "chordvis_set_instance_views": (i32, [vp, vp, u32]),

@@ -430,6 +430,12 @@ class VisibilityGroup:
     def sync(self):
         self._check(L.lib.chordvis_group_sync(self._g), "group_sync")
 
+    def enqueue_ms(self):
+        """Mean host time per frame of every rank's worker inside render_frame since the last call."""
+        out = (C.c_double * self.size)()
+        self._check(L.lib.chordvis_group_enqueue_ms(self._g, out, self.size), "group_enqueue_ms")
+        return [float(v) for v in out]
+
     def set_pipelined(self, enable=True):
         """The visibility all-gather of frame i travels beside frame i + 1 (chordvis_group_set_pipelined)."""
         self._check(L.lib.chordvis_group_set_pipelined(self._g, 1 if enable else 0), "group_set_pipelined")

@@ -371,6 +371,8 @@ int chordvis_group_set_view(ChordGroup* group, const ChordCameraView* view, cons
  * device (no host synchronisation; chordvis_group_sync waits) */
 int chordvis_group_render_frame(ChordGroup* group);
 int chordvis_group_sync(ChordGroup* group);
+/* mean host time per frame (ms) each rank's worker spent inside chordvis_group_render_frame since the last call; n = group size */
+int chordvis_group_enqueue_ms(ChordGroup* group, double* msPerRank, uint32_t n);
 /* Pipelined frames: chordvis_group_render_frame returns once frame i is enqueued with its visibility all-gather and row-major
  * copy running beside whatever follows (frame i + 1); every rank's history HZB is complete at the end of the call's work as
  * before.  chordvis_readback_visibility / the consumer entry points of a rank's context wait for ITS image;

@@ -206,8 +206,13 @@ def test_bench_two_ranks_self_spawned_on_one_device(gpu):
     (gloo, host-staged all-gathers: a one-GPU box cannot host two RCCL ranks), the N > 1 control flow of the bench --
     explicit stream, phases, both exchanges, the same-workload single-GPU reference and the speed-up field."""
     line = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "4", "--workload", "street_720p_hzb"],
-                      {"CHORDVIS_BENCH_BACKEND": "gloo", "CHORDVIS_BENCH_ONE_DEVICE": "1"})
+                      {"CHORDVIS_BENCH_BACKEND": "gloo", "CHORDVIS_BENCH_ONE_DEVICE": "1", "CHORDVIS_BENCH_ALSO": "street_x64_720p_hzb"})
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["exchange"] == "torch"
+    # the line explains both multi-GPU configurations: the second workload (on the driver's run: BASELINE config 4) rides in `also`
+    also = line["also"]
+    assert also["config"]["workload"] == "street_x64_720p_hzb" and also["single_gpu_same_workload"]["workload"] == "street_x64_720p_hzb"
+    assert also["value"] > 0 and also["speedup_vs_single"] > 0 and len(also["phases_ms"]) == 2 and also["exchange"] == "torch"
+    assert line["tile_map"]["rebalanced"] and sum(line["tile_map"]["tiles_per_rank"]) == line["tiles_total"]
     assert line["config"]["workload"] == "street_720p_hzb" and line["single_gpu_same_workload"]["workload"] == "street_720p_hzb"
     assert line["speedup_vs_single"] > 0 and line["value"] > 0
     assert line["counts_view_a"]["countInstanceCulled"] > 0
@@ -223,6 +228,8 @@ def test_bench_two_ranks_group_fallback_on_one_device(gpu):
                       {"CHORDVIS_BENCH_BACKEND": "gloo", "CHORDVIS_BENCH_ONE_DEVICE": "1"})
     assert line["n_gpus"] == 2 and line["exchange"] == "group" and line["value"] > 0 and line["speedup_vs_single"] > 0
     assert len(line["phases_ms"]) == 2 and all("exchange_vis" in p for p in line["phases_ms"])
+    # what the one-process transport costs the host, worker by worker
+    assert all(p["host_enqueue_ms"] > 0 for p in line["phases_ms"])
 
 
 def test_bench_single_gpu_line_has_the_contract_fields(gpu):
