@@ -204,7 +204,9 @@ struct DeviceCounters {
 #define CHORD_MAX_TILES ((4096u >> CHORD_TILE_SHIFT) * (4096u >> CHORD_TILE_SHIFT))   // renderer.h:52-53 caps the render size at 4096^2
 #if CHORD_TILE_SHIFT == 6
 #define CHORD_TILECOUNT_STRIDE 16u               // one bin counter per 64-byte line
+#ifndef CHORD_BIN_CAP
 #define CHORD_BIN_CAP 16384u
+#endif
 #else
 #define CHORD_TILECOUNT_STRIDE 4u                // four bin counters per 64-byte line
 #define CHORD_BIN_CAP 8192u
