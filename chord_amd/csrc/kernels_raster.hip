@@ -924,7 +924,7 @@ __device__ __forceinline__ BlockEmitParams load_block_emit_params()
 // and whether it is narrow (fits_compact).  The same culls and the same integers as cluster_records / raster_setup_body.
 __device__ __forceinline__ int classify_triangle(const RasterParams& p, uint32_t t, uint32_t T, uint32_t packedIdx, bool twoSided, bool allFast,
                                                  const float* lX, const float* lY, const float* lW, const float* lU, const float* lV, const float* lD,
-                                                 uint32_t& boxX, uint32_t& boxY, bool& narrow)
+                                                 const int32_t* lSX, const int32_t* lSY, uint32_t& boxX, uint32_t& boxY, bool& narrow)
 {
     boxX = 0u; boxY = 0u; narrow = false;
     if (t >= T) return K_NONE;
@@ -944,10 +944,12 @@ __device__ __forceinline__ int classify_triangle(const RasterParams& p, uint32_t
     culled = culled || (rintf(minU * p.W) == rintf(maxU * p.W) || rintf(minV * p.H) == rintf(maxV * p.H)); // #3 :174-179
     if (culled) return K_NONE;
     if (!allFast) { const float d0 = lD[i0], d1 = lD[i1], d2 = lD[i2]; if (d0 != d0 || d1 != d1 || d2 != d2) return K_CLIP; }
+    // (the snapped 24.8 coordinates are per-vertex values: computed once per vertex in the vertex phase, not once per use --
+    // a cluster's 128 triangles name its 81 vertices 384 times, here and again in the resolve)
     TriSetup ts;
-    ts.X[0] = (int32_t)rintf((u0 * p.W) * 256.0f); ts.Y[0] = (int32_t)rintf((v0 * p.H) * 256.0f);
-    ts.X[1] = (int32_t)rintf((u1 * p.W) * 256.0f); ts.Y[1] = (int32_t)rintf((v1 * p.H) * 256.0f);
-    ts.X[2] = (int32_t)rintf((u2 * p.W) * 256.0f); ts.Y[2] = (int32_t)rintf((v2 * p.H) * 256.0f);
+    ts.X[0] = lSX[i0]; ts.Y[0] = lSY[i0];
+    ts.X[1] = lSX[i1]; ts.Y[1] = lSY[i1];
+    ts.X[2] = lSX[i2]; ts.Y[2] = lSY[i2];
     bool small;
     // (sharded frames: ownership is decided per window part, below -- a cluster that straddles two ranks' tiles is small)
     if (!tri_setup_geom(ts, twoSided, p.Wi, p.Hi, small)) return K_NONE;
@@ -958,14 +960,14 @@ __device__ __forceinline__ int classify_triangle(const RasterParams& p, uint32_t
 
 // set-up of an emitted, narrow triangle again from LDS and its scan conversion into the wave's pixel window
 __device__ __forceinline__ void resolve_triangle(const RasterParams& p, uint32_t t, uint32_t slot, uint32_t packedIdx, bool twoSided,
-                                                 const float* lU, const float* lV, const float* lD, unsigned long long* win,
+                                                 const int32_t* lSX, const int32_t* lSY, const float* lD, unsigned long long* win,
                                                  int32_t bx0, int32_t by0)
 {
     const uint32_t i0 = packedIdx & 0xFFu, i1 = (packedIdx >> 8) & 0xFFu, i2 = (packedIdx >> 16) & 0xFFu;
     TriSetup ts;
-    ts.X[0] = (int32_t)rintf((lU[i0] * p.W) * 256.0f); ts.Y[0] = (int32_t)rintf((lV[i0] * p.H) * 256.0f);
-    ts.X[1] = (int32_t)rintf((lU[i1] * p.W) * 256.0f); ts.Y[1] = (int32_t)rintf((lV[i1] * p.H) * 256.0f);
-    ts.X[2] = (int32_t)rintf((lU[i2] * p.W) * 256.0f); ts.Y[2] = (int32_t)rintf((lV[i2] * p.H) * 256.0f);
+    ts.X[0] = lSX[i0]; ts.Y[0] = lSY[i0];
+    ts.X[1] = lSX[i1]; ts.Y[1] = lSY[i1];
+    ts.X[2] = lSX[i2]; ts.Y[2] = lSY[i2];
     (void)tri_setup(ts, twoSided, p.Wi, p.Hi);                          // (true: the classification accepted exactly these integers)
     float d[3] = {lD[i0], lD[i1], lD[i2]};
     if (p.biasConst != 0.0f || p.biasSlope != 0.0f) { const float o = depth_bias(ts, d, p.biasConst, p.biasSlope); d[0] += o; d[1] += o; d[2] += o; }
@@ -999,14 +1001,15 @@ struct SlotCache { uint32_t key[SLOT_CACHE], next[SLOT_CACHE], end[SLOT_CACHE]; 
 #define BLOCKS_LDS_VERTS 128    // vertices per cluster the block kernel takes (larger clusters are left to the record kernel): 12 + 8 KB of LDS per workgroup
 #endif
 template <bool HOT>
-__device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, const uint32_t count, float (*sVert)[4][BLOCKS_LDS_VERTS], unsigned long long (*sWin)[WIN * WIN],
-                                                         SlotCache* slotCaches)
+__device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, const uint32_t count, float (*sVert)[4][BLOCKS_LDS_VERTS], int32_t (*sSnap)[4][BLOCKS_LDS_VERTS],
+                                                         unsigned long long (*sWin)[WIN * WIN], SlotCache* slotCaches)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     SlotCache& sc = slotCaches[HOT ? wave : 0u];
     if (HOT && lane < SLOT_CACHE) { sc.key[lane] = 0u; sc.next[lane] = 0u; sc.end[lane] = 0u; }
     float* lX = sVert[0][wave]; float* lY = sVert[1][wave]; float* lW = sVert[2][wave];
     float* lU = sVert[3][wave]; float* lV = sVert[4][wave]; float* lD = sVert[5][wave];
+    int32_t* lSX = sSnap[0][wave]; int32_t* lSY = sSnap[1][wave];
     unsigned long long* win = sWin[wave];
     const uint32_t listShard = (blockIdx.x * 4u + wave) % CHORD_LIST_SHARDS;
 
@@ -1076,8 +1079,11 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                 const f4 h = mul_mv(mvp, x, y, z, 1.0f);
                 const float aw = fabsf(h.w);
                 lX[i] = h.x; lY[i] = h.y; lW[i] = h.w;
-                lU[i] = h.x / aw * 0.5f + 0.5f;
-                lV[i] = h.y / aw * -0.5f + 0.5f;
+                const float u = h.x / aw * 0.5f + 0.5f, v = h.y / aw * -0.5f + 0.5f;
+                lU[i] = u; lV[i] = v;
+                // snapped 24.8 coordinates of the vertex (mesh_raster setup: the values every triangle on it uses; a vertex outside
+                // the guard band may overflow the conversion -- its triangles take the clipper and never read them)
+                lSX[i] = (int32_t)rintf((u * p.W) * 256.0f); lSY[i] = (int32_t)rintf((v * p.H) * 256.0f);
                 const bool fast = p.depthClamp ? in_fast_volume_xy(h) : in_fast_volume(h);
                 lD[i] = fast ? h.z / h.w : __builtin_nanf("");
                 notFast = notFast || !fast;
@@ -1104,8 +1110,8 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
         // ---- classification: kind + pixel bounds per triangle, nothing else survives it ----------------------------------
         uint32_t bxA, byA, bxB, byB;
         bool nwA, nwB;
-        int kindA = classify_triangle(p, lane, tooBig ? 0u : T, t0, twoSided, allFast, lX, lY, lW, lU, lV, lD, bxA, byA, nwA);
-        int kindB = classify_triangle(p, lane + 64u, tooBig ? 0u : T, t1, twoSided, allFast, lX, lY, lW, lU, lV, lD, bxB, byB, nwB);
+        int kindA = classify_triangle(p, lane, tooBig ? 0u : T, t0, twoSided, allFast, lX, lY, lW, lU, lV, lD, lSX, lSY, bxA, byA, nwA);
+        int kindB = classify_triangle(p, lane + 64u, tooBig ? 0u : T, t1, twoSided, allFast, lX, lY, lW, lU, lV, lD, lSX, lSY, bxB, byB, nwB);
         if (ABL(p, DBG_NO_BIN)) { kindA = K_NONE; kindB = K_NONE; }
         SPHASE(2);
         // next cluster: its positions (the indices have arrived behind the classification)
@@ -1170,9 +1176,9 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                     WAVE_LDS_SYNC();
                     // (a sharded frame's cluster none of whose window parts is this rank's: the conservative cluster test let it through)
                     const bool anyPart = hasMask != 0u;
-                    if (eA && anyPart) resolve_triangle(p, lane, hdr.slot, t0, twoSided, lU, lV, lD, win, bx0, by0);
+                    if (eA && anyPart) resolve_triangle(p, lane, hdr.slot, t0, twoSided, lSX, lSY, lD, win, bx0, by0);
                     __builtin_amdgcn_sched_barrier(0);                           // (one triangle's set-up alive at a time)
-                    if (eB && anyPart) resolve_triangle(p, lane + 64u, hdr.slot, t1, twoSided, lU, lV, lD, win, bx0, by0);
+                    if (eB && anyPart) resolve_triangle(p, lane + 64u, hdr.slot, t1, twoSided, lSX, lSY, lD, win, bx0, by0);
                     WAVE_LDS_SYNC();
                     SPHASE(3);
                     gbase = bcast(gbase, 0);
@@ -1289,11 +1295,12 @@ template <bool HOT>
 __global__ __launch_bounds__(256, BLOCKS_MIN_WAVES) void raster_setup_blocks_kernel(RasterParams p)
 {
     __shared__ float sVert[6][4][BLOCKS_LDS_VERTS];            // x, y, w, u, v, depth of a wave's cluster (12 KB)
+    __shared__ int32_t sSnap[2][4][BLOCKS_LDS_VERTS];          // ... and its snapped 24.8 screen coordinates (4 KB)
     __shared__ unsigned long long sWin[4][WIN * WIN];          // a small cluster's pixel window (8 KB)
     __shared__ SlotCache sSlots[HOT ? 4 : 1];                  // bin slots drawn ahead on hot tiles (1.5 KB)
     const uint32_t count = *p.count;
     if (!launch_is_dense(p, count)) return;
-    raster_setup_blocks_body<HOT>(p, count, sVert, sWin, sSlots);
+    raster_setup_blocks_body<HOT>(p, count, sVert, sSnap, sWin, sSlots);
 }
 
 // One lane bins one record into every tile its clamped bbox may touch (conservative edge test at the tile
