@@ -47,6 +47,10 @@ def build_workload(name):
     from chord_amd import scenes
     if name == "street_4k_hzb":
         return scenes.config3_street(3840, 2160)
+    if name == "street_4k_masked":       # config 3 with alpha-tested materials on every prop and every other building (same triangles)
+        return scenes.config3_street(3840, 2160, masked=True)
+    if name == "street_4k_masked_twin":  # ... and its opaque twin: the same two-sided materials without the alpha test (equal triangle count)
+        return scenes.config3_street(3840, 2160, masked="twin")
     if name == "street_x64_4k_hzb":
         return scenes.config4_street_x64(3840, 2160, grid=8)
     if name == "street_x16_4k_hzb":
@@ -73,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="auto", help="street_4k_hzb | street_x64_4k_hzb | street_x16_4k_hzb | subpixel_1g | subpixel_64m | atrium_1080p")
+    ap.add_argument("--workload", default="auto", help="street_4k_hzb | street_4k_masked | street_x64_4k_hzb | street_x16_4k_hzb | subpixel_1g | subpixel_1g_hotspot | subpixel_64m | atrium_1080p")
     ap.add_argument("--exchange", default="auto", choices=("auto", "lib", "torch", "group"),
                     help="N > 1: who issues the all-gathers -- the library over RCCL, torch.distributed, or one process with N devices (ChordGroup, peer copies); auto = the first that works")
     ap.add_argument("--pipelined", action="store_true", help="N > 1, --exchange lib: the visibility all-gather of frame i runs beside frame i + 1 (second RCCL communicator)")

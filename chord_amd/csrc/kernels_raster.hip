@@ -513,45 +513,85 @@ __device__ __forceinline__ void write_mask_ext(TriRec* slot, const DMaterial& m,
     *reinterpret_cast<TriRecMaskExt*>(slot) = e;
 }
 
-__device__ __forceinline__ int32_t wrap_index(long long i, long long n, uint32_t mode)
+// Texel indices are 32-bit here: texel_floor maps everything beyond +-1e9 to 0, so an index and its +1 neighbour fit an int32
+// (the oracle's 64-bit arithmetic gives the same values); a 64-bit modulo is ~200 instructions on this GPU and the bilinear
+// fetch of round 2 did eight of them per covered pixel.  Power-of-two sizes (every level of a power-of-two texture) wrap with
+// a mask: i & (n - 1) is the non-negative remainder in two's complement.
+__device__ __forceinline__ int32_t wrap_index(int32_t i, int32_t n, uint32_t mode)
 {
-    if (mode == CHORD_WRAP_CLAMP_TO_EDGE) return (int32_t)(i < 0 ? 0 : (i > n - 1 ? n - 1 : i));
+    if (mode == CHORD_WRAP_CLAMP_TO_EDGE) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    const bool pot = (n & (n - 1)) == 0;
     if (mode == CHORD_WRAP_MIRRORED_REPEAT) {
-        long long m = i % (2 * n);
+        int32_t m = pot ? (i & (2 * n - 1)) : i % (2 * n);
         if (m < 0) m += 2 * n;
-        return (int32_t)(m < n ? m : 2 * n - 1 - m);
+        return m < n ? m : 2 * n - 1 - m;
     }
-    long long m = i % n;
+    int32_t m = pot ? (i & (n - 1)) : i % n;
     if (m < 0) m += n;
-    return (int32_t)m;
+    return m;
 }
 
-__device__ __forceinline__ long long texel_floor(float x)
+// wrap_index(i) and wrap_index(i + 1) with ONE remainder: the neighbour's follows from the remainder's successor
+__device__ __forceinline__ void wrap_pair(int32_t i, int32_t n, uint32_t mode, int32_t& w0, int32_t& w1)
+{
+    if (mode == CHORD_WRAP_CLAMP_TO_EDGE) {
+        w0 = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+        w1 = i + 1 < 0 ? 0 : (i + 1 > n - 1 ? n - 1 : i + 1);
+        return;
+    }
+    const bool mirror = mode == CHORD_WRAP_MIRRORED_REPEAT;
+    const int32_t period = mirror ? 2 * n : n;
+    const bool pot = (period & (period - 1)) == 0;
+    int32_t m = pot ? (i & (period - 1)) : i % period;
+    if (m < 0) m += period;
+    const int32_t m1 = m + 1 == period ? 0 : m + 1;                          // (i + 1) mod period
+    w0 = mirror ? (m < n ? m : 2 * n - 1 - m) : m;
+    w1 = mirror ? (m1 < n ? m1 : 2 * n - 1 - m1) : m1;
+}
+
+__device__ __forceinline__ int32_t texel_floor(float x)
 {
     if (!(fabsf(x) < 1.0e9f)) return 0;
-    return (long long)floorf(x);
+    return (int32_t)floorf(x);
 }
 
-__device__ float sample_alpha(const uint8_t* __restrict__ texAlpha, const DMaterial& m, uint32_t level, bool linear, float u, float v)
+// One level of a material's alpha texture, resolved once per row unit (not once per pixel): base address, size, wraps, filter.
+struct AlphaLevel {
+    const uint8_t* base;            // NULL: no texture (white fallback, alpha 1)
+    int32_t W, H;
+    float fW, fH;
+    uint32_t wrapS, wrapT;
+    bool linear;
+};
+__device__ __forceinline__ AlphaLevel alpha_level(const uint8_t* __restrict__ texAlpha, const DMaterial& m, uint32_t level, bool linear)
 {
-    if (m.texOffset == 0xFFFFFFFFu) return 1.0f;
+    AlphaLevel a;
+    a.base = nullptr; a.W = 1; a.H = 1; a.fW = 1.0f; a.fH = 1.0f; a.wrapS = m.wrapS; a.wrapT = m.wrapT; a.linear = linear;
+    if (m.texOffset == 0xFFFFFFFFu) return a;
     size_t off = m.texOffset;
     for (uint32_t l = 0; l < level; l++) off += (size_t)max(1u, m.texWidth >> l) * max(1u, m.texHeight >> l);
-    const long long W = max(1u, m.texWidth >> level), H = max(1u, m.texHeight >> level);
-    const uint8_t* __restrict__ base = texAlpha + off;
-    if (!linear) {
-        const int32_t ix = wrap_index(texel_floor(u * (float)W), W, m.wrapS), iy = wrap_index(texel_floor(v * (float)H), H, m.wrapT);
-        return (float)base[(size_t)iy * (size_t)W + (size_t)ix] * (1.0f / 255.0f);
+    a.W = (int32_t)max(1u, m.texWidth >> level); a.H = (int32_t)max(1u, m.texHeight >> level);
+    a.fW = (float)a.W; a.fH = (float)a.H;
+    a.base = texAlpha + off;
+    return a;
+}
+__device__ __forceinline__ float sample_alpha(const AlphaLevel& t, float u, float v)
+{
+    if (!t.base) return 1.0f;
+    if (!t.linear) {
+        const int32_t ix = wrap_index(texel_floor(u * t.fW), t.W, t.wrapS), iy = wrap_index(texel_floor(v * t.fH), t.H, t.wrapT);
+        return (float)t.base[iy * t.W + ix] * (1.0f / 255.0f);
     }
-    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
-    const long long x0 = texel_floor(x), y0 = texel_floor(y);
+    const float x = u * t.fW - 0.5f, y = v * t.fH - 0.5f;
+    const int32_t x0 = texel_floor(x), y0 = texel_floor(y);
     float fx = x - (float)x0, fy = y - (float)y0;
     if (!(fabsf(x) < 1.0e9f)) fx = 0.0f;
     if (!(fabsf(y) < 1.0e9f)) fy = 0.0f;
-    const int32_t ix0 = wrap_index(x0, W, m.wrapS), ix1 = wrap_index(x0 + 1, W, m.wrapS);
-    const int32_t iy0 = wrap_index(y0, H, m.wrapT), iy1 = wrap_index(y0 + 1, H, m.wrapT);
-    const float a00 = (float)base[(size_t)iy0 * (size_t)W + (size_t)ix0] * (1.0f / 255.0f), a10 = (float)base[(size_t)iy0 * (size_t)W + (size_t)ix1] * (1.0f / 255.0f);
-    const float a01 = (float)base[(size_t)iy1 * (size_t)W + (size_t)ix0] * (1.0f / 255.0f), a11 = (float)base[(size_t)iy1 * (size_t)W + (size_t)ix1] * (1.0f / 255.0f);
+    int32_t ix0, ix1, iy0, iy1;
+    wrap_pair(x0, t.W, t.wrapS, ix0, ix1);
+    wrap_pair(y0, t.H, t.wrapT, iy0, iy1);
+    const float a00 = (float)t.base[iy0 * t.W + ix0] * (1.0f / 255.0f), a10 = (float)t.base[iy0 * t.W + ix1] * (1.0f / 255.0f);
+    const float a01 = (float)t.base[iy1 * t.W + ix0] * (1.0f / 255.0f), a11 = (float)t.base[iy1 * t.W + ix1] * (1.0f / 255.0f);
     const float top = a00 + (a10 - a00) * fx, bot = a01 + (a11 - a01) * fx;
     return top + (bot - top) * fy;
 }
@@ -1829,6 +1869,22 @@ __device__ __forceinline__ uint32_t block_scan_tb(uint32_t v, uint32_t* waveSums
 #define SEG_SHIFT 6             // 64: one unit per row (16 / 32 were measured 3 % / 1 % slower on config 3: more units, same trips)
 #endif
 #define SEG (1 << SEG_SHIFT)
+// Units of masked (alpha-tested) triangles: MASKED_ROWS pixel rows x segments of MASKED_SEG pixels, MASKED_PIXELS_PER_TRIP pixels
+// per trip of the row loop.  Measured on street_4k_masked (profiles/r04_masked_variants.txt; tile kernel per frame): one row x 64
+// px x 1 pixel per trip 418 us; segments of 32 / 16 / 8 px 419 / 421 / 498; two pixels per trip (taps of both in flight) 488; 16
+// rows per unit (the three dependent fetches a unit starts with -- extension record, material, texels -- paid once per small
+// triangle) 1 012: the pass is bound by the arithmetic of a covered pixel (two divisions, texel indices with a 32-bit modulo per
+// axis, up to four taps: ~300 instruction slots) times its lane occupancy, not by per-unit latency.
+#ifndef MASKED_ROWS
+#define MASKED_ROWS 1
+#endif
+#ifndef MASKED_SEG_SHIFT
+#define MASKED_SEG_SHIFT 6
+#endif
+#define MASKED_SEG (1 << MASKED_SEG_SHIFT)
+#ifndef MASKED_PIXELS_PER_TRIP
+#define MASKED_PIXELS_PER_TRIP 1
+#endif
 #define ENTRY_WORDS 13            // word 12: record index of a masked triangle (its extension follows it)
 struct EntrySoA { uint32_t w[ENTRY_WORDS][TB]; };
 #define EF_KIND_SHIFT 24          // box word: x0 | y0 << 6 | x1 << 12 | y1 << 18 | kind << 24 | bias1 << 26 | bias2 << 27 | sneg << 28
@@ -1917,7 +1973,8 @@ __device__ __forceinline__ uint32_t entry_store(EntrySoA& en, uint32_t t, const 
                                                 int32_t ox, int32_t oy, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
                                                 bool masked = false, uint32_t recIndex = 0u)
 {
-    narrow = narrow && !masked;                                   // masked triangles keep their vertices (kind 3, int64 edges: rare)
+    const bool maskedNarrow = masked && narrow;                   // (bit 29 of the box word: masked_row may use 32-bit edge functions)
+    narrow = narrow && !masked;                                   // masked triangles keep their vertices (kind 3)
     uint32_t box = (uint32_t)(x0 - ox) | ((uint32_t)(y0 - oy) << 6) | ((uint32_t)(x1 - ox) << 12) | ((uint32_t)(y1 - oy) << 18);
     if (narrow) {
         const int32_t s = ts.s;
@@ -1945,46 +2002,93 @@ __device__ __forceinline__ uint32_t entry_store(EntrySoA& en, uint32_t t, const 
         en.w[3][t] = (uint32_t)ts.Y[0]; en.w[4][t] = (uint32_t)ts.Y[1]; en.w[5][t] = (uint32_t)ts.Y[2];
         box |= (masked ? 3u : (mag < (1 << 25) ? 1u : 2u)) << EF_KIND_SHIFT;
         box |= ts.s < 0 ? 1u << 28 : 0u;
+        box |= maskedNarrow ? 1u << 29 : 0u;
         if (masked) en.w[12][t] = recIndex;
     }
     en.w[6][t] = __float_as_uint(ts.d0); en.w[7][t] = __float_as_uint(ts.e1); en.w[8][t] = __float_as_uint(ts.e2);
     en.w[9][t] = __float_as_uint(ts.invA); en.w[10][t] = ts.payload; en.w[11][t] = box;
+    // units: one per (row, segment); a masked triangle's are groups of MASKED_ROWS rows (masked_rows)
+    if (masked) return ((uint32_t)(y1 - y0) / MASKED_ROWS + 1u) * ((uint32_t)((x1 - x0) >> MASKED_SEG_SHIFT) + 1u);
     return (uint32_t)(y1 - y0 + 1) * ((uint32_t)((x1 - x0) >> SEG_SHIFT) + 1u);
 }
 
 // A pixel row of a masked triangle: exact int64 edges, canonical depth, and per covered pixel the perspective-correct
 // texture coordinates, one alpha fetch and the clip() of mesh_raster.hlsl:198-204.
-__device__ __forceinline__ void masked_row(const RasterParams& p, unsigned long long* __restrict__ tileRow, const UnitParams& u, uint32_t recIndex,
-                                        int32_t ox, int32_t py, int32_t lx0, int32_t lx1, bool noPixels, const bool clampZ)
+// E_t: int32_t for triangles whose vertices are at most 64 px apart (|E| < 2^31, as in scan_span_i32; (float)E is then the
+// canonical (float)(double)E), int64_t for the rest.  The span of the row is bounded first (fp32 estimates, one pixel of slack:
+// scan_span), so the loop runs over the covered pixels, not over the bbox row.
+// (A unit of a masked triangle is a GROUP of up to MASKED_ROWS pixel rows, not one: what a unit pays before its first pixel --
+// the triangle's extension record, its material, the texture level, the edge constants: three dependent memory round trips --
+// is then paid once per small triangle instead of once per row.)
+template <typename E_t>
+__device__ __forceinline__ void masked_rows(const RasterParams& p, unsigned long long* __restrict__ tileRow0, const UnitParams& u, uint32_t recIndex,
+                                         int32_t ox, int32_t py0, int32_t nrows, int32_t lx0, int32_t lx1, bool noPixels, const bool clampZ)
 {
     const TriRecMaskExt ext = *reinterpret_cast<const TriRecMaskExt*>(&p.tris[recIndex + 1u]);
     const DMaterial m = p.materials[ext.material];
-    const uint32_t level = ext.levelFilter & 0xFFu;
-    const bool linear = (ext.levelFilter & 256u) != 0u;
-    const int64_t sgn = (u.skind & 1) ? -1 : 1;
-    const int64_t dx0 = u.X[2] - u.X[1], dy0 = u.Y[2] - u.Y[1];
-    const int64_t dx1 = u.X[0] - u.X[2], dy1 = u.Y[0] - u.Y[2];
-    const int64_t dx2 = u.X[1] - u.X[0], dy2 = u.Y[1] - u.Y[0];
-    const int64_t a0 = -sgn * dy0, b0 = sgn * dx0, a1 = -sgn * dy1, b1 = sgn * dx1, a2 = -sgn * dy2, b2 = sgn * dx2;
-    const int64_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? 0 : -1;
-    const int64_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 0 : -1;
-    const int64_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 0 : -1;
-    const int64_t cx = (int64_t)(ox + lx0) * 256 + 128, cy = (int64_t)py * 256 + 128;
-    int64_t E0 = sgn * (dx0 * (cy - u.Y[1]) - dy0 * (cx - u.X[1]));
-    int64_t E1 = sgn * (dx1 * (cy - u.Y[2]) - dy1 * (cx - u.X[2]));
-    int64_t E2 = sgn * (dx2 * (cy - u.Y[0]) - dy2 * (cx - u.X[0]));
-    for (int32_t lx = lx0; lx <= lx1; lx++, E0 += a0 * 256, E1 += a1 * 256, E2 += a2 * 256) {
-        if (E0 + bias0 < 0 || E1 + bias1 < 0 || E2 + bias2 < 0) continue;
-        const float l1 = (float)(double)E1 * u.invA, l2 = (float)(double)E2 * u.invA;
+    const AlphaLevel tex = alpha_level(p.texAlpha, m, ext.levelFilter & 0xFFu, (ext.levelFilter & 256u) != 0u);
+    const E_t sgn = (u.skind & 1) ? (E_t)-1 : (E_t)1;
+    const E_t dx0 = (E_t)(u.X[2] - u.X[1]), dy0 = (E_t)(u.Y[2] - u.Y[1]);
+    const E_t dx1 = (E_t)(u.X[0] - u.X[2]), dy1 = (E_t)(u.Y[0] - u.Y[2]);
+    const E_t dx2 = (E_t)(u.X[1] - u.X[0]), dy2 = (E_t)(u.Y[1] - u.Y[0]);
+    const E_t a0 = -sgn * dy0, b0 = sgn * dx0, a1 = -sgn * dy1, b1 = sgn * dx1, a2 = -sgn * dy2, b2 = sgn * dx2;
+    const E_t bias0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? (E_t)0 : (E_t)-1;
+    const E_t bias1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? (E_t)0 : (E_t)-1;
+    const E_t bias2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? (E_t)0 : (E_t)-1;
+    const E_t cx = (E_t)(ox + lx0) * (E_t)256 + (E_t)128, cy = (E_t)py0 * (E_t)256 + (E_t)128;
+    E_t R0 = sgn * (dx0 * (cy - (E_t)u.Y[1]) - dy0 * (cx - (E_t)u.X[1])) + bias0;       // bias folded in: inside <=> all >= 0
+    E_t R1 = sgn * (dx1 * (cy - (E_t)u.Y[2]) - dy1 * (cx - (E_t)u.X[2])) + bias1;
+    E_t R2 = sgn * (dx2 * (cy - (E_t)u.Y[0]) - dy2 * (cx - (E_t)u.X[0])) + bias2;
+    const E_t st0 = a0 * (E_t)256, st1 = a1 * (E_t)256, st2 = a2 * (E_t)256;
+    const E_t sy0 = b0 * (E_t)256, sy1 = b1 * (E_t)256, sy2 = b2 * (E_t)256;           // one row down
+    for (int32_t r = 0; r < nrows; r++, R0 += sy0, R1 += sy1, R2 += sy2) {
+    E_t E0 = R0, E1 = R1, E2 = R2;
+    unsigned long long* __restrict__ tileRow = tileRow0 + r * TPITCH;
+    float klo = 0.0f, khi = (float)(lx1 - lx0);
+    {
+        const float e[3] = {(float)E0, (float)E1, (float)E2}, t[3] = {(float)st0, (float)st1, (float)st2};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float q = fminf(fmaxf(-e[i] * __builtin_amdgcn_rcpf(t[i]), -4.0f), 4096.0f);   // NaN (0 * inf) -> -4
+            if (t[i] > 0.0f) klo = fmaxf(klo, floorf(q) - 1.0f);
+            else if (t[i] < 0.0f) khi = fminf(khi, floorf(q) + 1.0f);
+            else if (e[i] < 0.0f) khi = -1.0f;
+        }
+    }
+    const int32_t k0 = (int32_t)klo, k1 = (int32_t)khi;
+    E0 += (E_t)k0 * st0; E1 += (E_t)k0 * st1; E2 += (E_t)k0 * st2;
+    // the packed word of the pixel with these (biased) edge values, 0 when it is outside or its alpha fails the cut-off.  No branch:
+    // a pixel outside the triangle evaluates its texture coordinates anyway (whatever they are, texel_floor / wrap_index give an
+    // index inside the level), so that the taps of both pixels of a trip are in flight together -- the loop is bound by the latency
+    // of its dependent byte loads, one round trip per covered pixel before.
+    auto pixel = [&](E_t e0, E_t e1, E_t e2) -> unsigned long long {
+        const bool inside = (e0 | e1 | e2) >= 0;
+        const float l1 = std::is_same<E_t, int32_t>::value ? (float)(e1 - bias1) * u.invA : (float)(double)(e1 - bias1) * u.invA;
+        const float l2 = std::is_same<E_t, int32_t>::value ? (float)(e2 - bias2) * u.invA : (float)(double)(e2 - bias2) * u.invA;
         const float l0 = (1.0f - l1) - l2;
         const float den = (l0 * ext.iw[0] + l1 * ext.iw[1]) + l2 * ext.iw[2];
         const float tu = ((l0 * ext.uw[0] + l1 * ext.uw[1]) + l2 * ext.uw[2]) / den;
         const float tv = ((l0 * ext.vw[0] + l1 * ext.vw[1]) + l2 * ext.vw[2]) / den;
-        const float alpha = sample_alpha(p.texAlpha, m, level, linear, tu, tv);
-        if (alpha * m.alphaFactor - m.alphaCutOff < 0.0f) continue;                  // clip()
+        const float alpha = sample_alpha(tex, tu, tv);
+        const bool keep = inside && !(alpha * m.alphaFactor - m.alphaCutOff < 0.0f) && !noPixels;      // clip()
         float z = (u.d0 + l1 * u.e1) + l2 * u.e2;
         if (clampZ) z = fminf(fmaxf(z, 0.0f), 1.0f);
-        if (!noPixels) atomicMax(tileRow + lx, ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)u.payload);
+        return keep ? (((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)u.payload) : 0ull;
+    };
+    unsigned long long* px = tileRow + lx0 + k0;
+#if MASKED_PIXELS_PER_TRIP == 2
+    for (int32_t k = k0; k <= k1; k += 2, E0 += 2 * st0, E1 += 2 * st1, E2 += 2 * st2, px += 2) {
+        const unsigned long long va = pixel(E0, E1, E2);
+        const unsigned long long vb = k + 1 <= k1 ? pixel(E0 + st0, E1 + st1, E2 + st2) : 0ull;
+        atomicMax(px, va);                                                        // ds_max_u64 (0 changes nothing)
+        atomicMax(px + 1, vb);                                                    // (at most the row's padding word when k + 1 > lx1)
+    }
+#else
+    for (int32_t k = k0; k <= k1; k++, E0 += st0, E1 += st1, E2 += st2, px++) {
+        if ((E0 | E1 | E2) < 0) continue;
+        atomicMax(px, pixel(E0, E1, E2));
+    }
+#endif
     }
 }
 
@@ -2021,9 +2125,32 @@ __device__ __forceinline__ int32_t entry_unit(const RasterParams& p, const Entry
         u.skind = (int32_t)((box >> 28) & 1u) | (int32_t)(kind << 1);
         if (kind == 1u)      scan_row<double>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels, DEPTH);
         else if (kind == 2u) scan_row<int64_t>(tileRow, u, ox, oy + ly, lx0, lx1, noPixels, DEPTH);
-        else if (MASKED)     masked_row(p, tileRow, u, en.w[12][e], ox, oy + ly, lx0, lx1, noPixels, DEPTH);
+        // (kind 3, a masked triangle: entry_unit_masked, in a pass of its own over the round's units)
         return lx1 - lx0 + 1;
     }
+}
+
+// The units of alpha-tested triangles (kind 3) are listed and scanned apart from the others (the block-wide scan counts both
+// kinds): the texture fetch of masked_row (level offsets, wrap modes, four taps, two divisions per pixel) inlined into the loop
+// above put every masked instantiation of the tile kernel 37-54 VGPRs past its 128 -- 144-224 bytes of scratch per lane that
+// every unit of every triangle paid for, masked or not -- and in a list of their own the masked units fill whole waves instead
+// of a lane here and there.  A batch without masked entries skips the pass.
+template <bool DEPTH>
+__device__ __forceinline__ void entry_unit_masked(const RasterParams& p, const EntrySoA& en, unsigned long long* tile, uint32_t e, uint32_t row, uint32_t seg,
+                                                  int32_t ox, int32_t oy, bool noPixels)
+{
+    const uint32_t box = en.w[11][e];
+    const int32_t bx0 = (int32_t)(box & 63u), bx1 = (int32_t)((box >> 12) & 63u), by1 = (int32_t)((box >> 18) & 63u);
+    const int32_t ly = (int32_t)row, nrows = min(MASKED_ROWS, by1 - ly + 1);       // (row: the first row of the group)
+    const int32_t lx0 = bx0 + (int32_t)(seg << MASKED_SEG_SHIFT), lx1 = min(bx1, lx0 + MASKED_SEG - 1);
+    UnitParams u;
+    u.X[0] = (int32_t)en.w[0][e]; u.X[1] = (int32_t)en.w[1][e]; u.X[2] = (int32_t)en.w[2][e];
+    u.Y[0] = (int32_t)en.w[3][e]; u.Y[1] = (int32_t)en.w[4][e]; u.Y[2] = (int32_t)en.w[5][e];
+    u.d0 = __uint_as_float(en.w[6][e]); u.e1 = __uint_as_float(en.w[7][e]); u.e2 = __uint_as_float(en.w[8][e]);
+    u.invA = __uint_as_float(en.w[9][e]); u.payload = en.w[10][e]; u.box = 0;
+    u.skind = (int32_t)((box >> 28) & 1u) | (3 << 1);
+    if ((box >> 29) & 1u) masked_rows<int32_t>(p, tile + ly * TPITCH, u, en.w[12][e], ox, oy + ly, nrows, lx0, lx1, noPixels, DEPTH);   // vertices at most 64 px apart
+    else                  masked_rows<int64_t>(p, tile + ly * TPITCH, u, en.w[12][e], ox, oy + ly, nrows, lx0, lx1, noPixels, DEPTH);
 }
 
 // Tile-out of a finished tile fused with its HZB reduction (single-GPU frames): every word goes to the visibility
@@ -2093,8 +2220,9 @@ __device__ __forceinline__ void tile_out_and_hzb_body(const TileOutParams& p, co
             }
         }
     };
-    const size_t visBase = SH ? (size_t)slotId * (size_t)(TILE * TILE) : (size_t)oy * (size_t)p.Wi + (size_t)ox;
-    const size_t visPitch = SH ? (size_t)TILE : (size_t)p.Wi;
+    // (word index of the tile's first word; 32 bits: a 4096 x 4096 target has 2^24 words, a sharded one at most 1.25 x that)
+    const uint32_t visBase = SH ? slotId << (2 * TILE_SHIFT) : (uint32_t)oy * (uint32_t)p.Wi + (uint32_t)ox;
+    const uint32_t visPitch = SH ? (uint32_t)TILE : (uint32_t)p.Wi;
     // A lane owns 2x2 pixel quads: column pair l, row pairs q = 2 half + rp (rp = 0, 1) of the wave's four.  A mip-0 texel
     // is lane-local, a mip-1 texel is the lane's two iterations and its x neighbour (DPP), a mip-2 texel adds the x
     // neighbour two over and the other half of the wave (the one cross-half exchange per lane); 8-byte LDS reads of
@@ -2313,9 +2441,12 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     const bool noPixels = ABL(p, DBG_NO_PIXELS);
     // where the tile's words live: row-major in the image, or (sharded frames: SH) tile-linear in the tile's slot of the rank's
     // chunk -- 64 rows of 64 words, the whole slot also for a tile cut by the screen edge.  (Only owned tiles are work items.)
-    const uint32_t slotId = SH ? __builtin_amdgcn_readfirstlane(scalar_load(&kernel_args()->shard.tileSlot)[tileId]) : 0u;
-    const size_t visBase = SH ? (size_t)slotId * (size_t)(TILE * TILE) : (size_t)oy * (size_t)p.Wi + (size_t)ox;
-    const size_t visPitch = SH ? (size_t)TILE : (size_t)p.Wi;
+    // (the slot is read again from the tile map where it is needed -- tile-in and tile-out, a scalar-cache hit -- rather than held
+    // across the scan conversion: the kernel sits at its 128 VGPRs / 102 SGPRs)
+    auto slot_of_tile = [&]() -> uint32_t { return SH ? __builtin_amdgcn_readfirstlane(scalar_load(&kernel_args()->shard.tileSlot)[tileId]) : 0u; };
+    // word index of the tile's first word (32 bits: a 4096 x 4096 target has 2^24 words, a sharded one at most 1.25 x that) and its row pitch
+    auto vis_base = [&]() -> uint32_t { return SH ? slot_of_tile() << (2 * TILE_SHIFT) : (uint32_t)oy * (uint32_t)p.Wi + (uint32_t)ox; };
+    const uint32_t visPitch = SH ? (uint32_t)TILE : (uint32_t)p.Wi;
 
     // ---- tile in: zero (first pass: this is the clear; un-fused later passes merge by max at tile-out), or the
     //      current words when a later pass must leave the finished tile in LDS for the fused HZB reduction ----
@@ -2328,11 +2459,11 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         static_assert((TILE * TPITCH) % 2 == 0, "whole 16-byte words");
         for (uint32_t i = threadIdx.x; i < TILE * TPITCH / 2; i += TB) reinterpret_cast<ulonglong2*>(tile)[i] = make_ulonglong2(0ull, 0ull);
     } else
-    for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
+    for (uint32_t i = threadIdx.x, visBase = vis_base(); i < TILE * TILE / 2; i += TB) {
         const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
         ulonglong2 v = make_ulonglong2(0ull, 0ull);
         if (ly < th && lx < tw) {
-            const unsigned long long* src = scalar_load(&kernel_args()->vis) + visBase + (size_t)ly * visPitch + lx;
+            const unsigned long long* src = scalar_load(&kernel_args()->vis) + (size_t)(visBase + (uint32_t)ly * visPitch + (uint32_t)lx);
             if (lx + 1 < tw) v = *reinterpret_cast<const ulonglong2*>(src);
             else v.x = src[0];
         }
@@ -2457,26 +2588,34 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         PHASE(2);
         uint32_t total;
         // (the wave sums alternate between two buffers: a batch without units then needs no barrier but the scan's own)
-        const uint32_t off = block_scan_tb(rows, waveSums[(base >> 9) & 1u], &total);
+        // (MASKED: one scan for both populations -- units of opaque entries in the low half, of masked entries (kind 3) in the high
+        // half: a batch has at most 512 x 64 units)
+        const bool mine3 = MASKED && rows && ((prm.w[11][threadIdx.x] >> EF_KIND_SHIFT) & 3u) == 3u;
+        const uint32_t rowsN = mine3 ? 0u : rows, rowsM = mine3 ? rows : 0u;
+        const uint32_t offAll = block_scan_tb(rowsN | (rowsM << 16), waveSums[(base >> 9) & 1u], &total);
+        const uint32_t offN = offAll & 0xFFFFu, offM = offAll >> 16, totalM = MASKED ? total >> 16 : 0u;
+        total &= 0xFFFFu;
         PHASE(3);
-        // rounds of UNIT_CAP units: every entry thread lists its units of the round (one LDS word each), then every
-        // thread takes units TB apart -- a unit finds its entry with ONE read instead of a 9-step binary search
-        for (uint32_t r0 = 0; r0 < total; r0 += UNIT_CAP) {
-            if (rows) {
-                const uint32_t box = prm.w[11][threadIdx.x];
-                const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> SEG_SHIFT) + 1u, y0l = (box >> 6) & 63u;
-                // my units [off, off + rows) cut to the round's window
-                const uint32_t lo2 = max(off, r0), hi2 = min(off + rows, r0 + UNIT_CAP);
-                if (lo2 < hi2) {
-                    uint32_t j = lo2 - off;
-                    uint32_t row = y0l + (nseg == 1u ? j : nseg == 2u ? j >> 1 : nseg == 4u ? j >> 2 : j / 3u);
-                    uint32_t seg = nseg == 1u ? 0u : nseg == 2u ? (j & 1u) : nseg == 4u ? (j & 3u) : j % 3u;
-                    for (uint32_t u = lo2; u < hi2; u++) {
-                        unitList[u - r0] = threadIdx.x | (row << 9) | (seg << 15);
-                        if (++seg == nseg) { seg = 0u; row++; }
-                    }
+        // my units [off, off + n) of a population, cut to the round's window [r0, r0 + UNIT_CAP): one LDS word each
+        auto list_units = [&](uint32_t off, uint32_t n, uint32_t r0) {
+            if (!n) return;
+            const uint32_t box = prm.w[11][threadIdx.x];
+            const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> SEG_SHIFT) + 1u, y0l = (box >> 6) & 63u;
+            const uint32_t lo2 = max(off, r0), hi2 = min(off + n, r0 + UNIT_CAP);
+            if (lo2 < hi2) {
+                uint32_t j = lo2 - off;
+                uint32_t row = y0l + (nseg == 1u ? j : nseg == 2u ? j >> 1 : nseg == 4u ? j >> 2 : j / 3u);
+                uint32_t seg = nseg == 1u ? 0u : nseg == 2u ? (j & 1u) : nseg == 4u ? (j & 3u) : j % 3u;
+                for (uint32_t u = lo2; u < hi2; u++) {
+                    unitList[u - r0] = threadIdx.x | (row << 9) | (seg << 15);
+                    if (++seg == nseg) { seg = 0u; row++; }
                 }
             }
+        };
+        // rounds of UNIT_CAP units: every entry thread lists its units of the round, then every thread takes units TB apart -- a
+        // unit finds its entry with ONE read instead of a 9-step binary search
+        for (uint32_t r0 = 0; r0 < total; r0 += UNIT_CAP) {
+            list_units(offN, rowsN, r0);
             __syncthreads();
             const uint32_t nr = min(total - r0, (uint32_t)UNIT_CAP);
             for (uint32_t ui = threadIdx.x; ui < nr; ui += TB) {
@@ -2485,8 +2624,31 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                 const int32_t trips = entry_unit<MASKED, DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, noPixels);
                 if (prof) { cUnits++; cUnitIters += (uint32_t)trips; }
             }
-            if (r0 + UNIT_CAP < total) __syncthreads();           // the list is rewritten by the next round
+            if (r0 + UNIT_CAP < total || totalM) __syncthreads(); // the list is rewritten by the next round
         }
+        for (uint32_t r0 = 0; r0 < totalM; r0 += UNIT_CAP) {      // (MASKED only) the alpha-tested triangles' units
+            if (rowsM) {
+                const uint32_t box = prm.w[11][threadIdx.x];
+                const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> MASKED_SEG_SHIFT) + 1u, y0l = (box >> 6) & 63u;
+                const uint32_t lo2 = max(offM, r0), hi2 = min(offM + rowsM, r0 + UNIT_CAP);
+                if (lo2 < hi2) {
+                    const uint32_t j = lo2 - offM, g = j / nseg;
+                    uint32_t row = y0l + g * MASKED_ROWS, seg = j - g * nseg;
+                    for (uint32_t u = lo2; u < hi2; u++) {
+                        unitList[u - r0] = threadIdx.x | (row << 9) | (seg << 15);
+                        if (++seg == nseg) { seg = 0u; row += MASKED_ROWS; }
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nr = min(totalM - r0, (uint32_t)UNIT_CAP);
+            for (uint32_t ui = threadIdx.x; ui < nr; ui += TB) {
+                const uint32_t d = unitList[ui];
+                entry_unit_masked<DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 7u, ox, oy, noPixels);
+            }
+            if (r0 + UNIT_CAP < totalM) __syncthreads();
+        }
+        total |= totalM;
         if (total) __syncthreads();                               // prm / the unit list are rewritten by the next batch
         PHASE(4);
     }
@@ -2502,10 +2664,10 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         if (!merge_slices(tile, scalar_load(&q->tileSlabs) + (size_t)tileId * (TILE * TILE), &scalar_load(&q->tileCount)[(size_t)tileId * TC_STRIDE + TC_TICKET],
                           slices, &sTicket, &scalar_load(&q->counters)->overflow)) continue;   // not the last slice: done
         if (rmw) {
-            for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
+            for (uint32_t i = threadIdx.x, visBase = vis_base(); i < TILE * TILE / 2; i += TB) {
                 const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
                 if (ly >= th || lx >= tw) continue;
-                const unsigned long long* src = p.vis + visBase + (size_t)ly * visPitch + lx;
+                const unsigned long long* src = p.vis + (size_t)(visBase + (uint32_t)ly * visPitch + (uint32_t)lx);
                 tile[ly * TPITCH + lx] = max(tile[ly * TPITCH + lx], src[0]);
                 if (lx + 1 < tw) tile[ly * TPITCH + lx + 1] = max(tile[ly * TPITCH + lx + 1], src[1]);
             }
@@ -2518,24 +2680,24 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     } else if (p.hzbFused && !ABL(p, DBG_NO_HZB)) {
         // single-GPU frame: the whole tile goes out (first pass: this is the clear; later passes loaded it), and its
         // HZB texels with it; the batch buffers are free now and hold the cross-wave part of the reduction
-        tile_out_and_hzb<SH>(tile, reinterpret_cast<float*>(&prm.w[0][0]), offs, tileId, slotId, nAll, ox, oy, tw, th);
+        tile_out_and_hzb<SH>(tile, reinterpret_cast<float*>(&prm.w[0][0]), offs, tileId, slot_of_tile(), nAll, ox, oy, tw, th);
     } else if (p.clearTiles || p.hzbFused) {
         // first pass of the frame: every word is written (16-byte coalesced stores); this is the clear
-        for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
+        for (uint32_t i = threadIdx.x, visBase = vis_base(); i < TILE * TILE / 2; i += TB) {
             const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
             if (ly >= th || lx >= tw) continue;
             const ulonglong2 v = make_ulonglong2(tile[ly * TPITCH + lx], tile[ly * TPITCH + lx + 1]);
-            unsigned long long* dst = p.vis + visBase + (size_t)ly * visPitch + lx;
+            unsigned long long* dst = p.vis + (size_t)(visBase + (uint32_t)ly * visPitch + (uint32_t)lx);
             if (lx + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = v;
             else dst[0] = v.x;
         }
     } else {
         // later passes: only the pixels this pass touched are merged, with a row-coalesced global atomicMax
         // (8 lanes per 64-byte line) — no read-modify-write of the whole tile
-        for (uint32_t i = threadIdx.x; i < TILE * TILE; i += TB) {
+        for (uint32_t i = threadIdx.x, visBase = vis_base(); i < TILE * TILE; i += TB) {
             const int32_t ly = (int32_t)(i >> TILE_SHIFT), lx = (int32_t)(i & (TILE - 1));
             const unsigned long long v = tile[ly * TPITCH + lx];
-            if (v != 0ull && ly < th && lx < tw) atomicMax(p.vis + visBase + (size_t)ly * visPitch + lx, v);
+            if (v != 0ull && ly < th && lx < tw) atomicMax(p.vis + (size_t)(visBase + (uint32_t)ly * visPitch + (uint32_t)lx), v);
         }
     }
     PHASE(5);

@@ -514,8 +514,9 @@ def _building(pb, w, d, h, seed, lods):
     pb.add_surface(plane_surface((-w / 2, h, d / 2), (w, 0, 0), (0, 0, -d), seed + 4, 0.10, 0.5), 8, 8, lods)    # roof
 
 
-def _street_primitives(sb, lods=3):
-    """Unique geometry of one 'street' block: ground + 40 buildings + 311 props. Returns [(prim, l2w)]."""
+def _street_primitives(sb, lods=3, uv_tiles=None):
+    """Unique geometry of one 'street' block: ground + 40 buildings + 311 props. Returns [(prim, l2w)].
+    uv_tiles: (buildings, props) texture repeats per surface for the masked variant (texture coordinates are generated either way)."""
     out = []
     pb = PrimitiveBuilder()
     pb.add_surface(plane_surface((-64, 0, 64), (128, 0, 0), (0, 0, -128), 3000, 0.08, 0.9), 64, 64, lods)
@@ -527,6 +528,8 @@ def _street_primitives(sb, lods=3):
             r = rand01(3100, np.arange(b * 4, b * 4 + 4))
             w, d, h = 9.0 + 2.0 * r[0], 9.0 + 2.0 * r[1], 10.0 + 14.0 * r[2]
             pb = PrimitiveBuilder()
+            if uv_tiles:
+                pb.uv_scale = (uv_tiles[0], uv_tiles[0])
             _building(pb, w, d, h, 3200 + b * 8, lods)
             x = -58.0 + k * 12.8 + (r[3] - 0.5)
             out.append((sb.add_primitive(pb), translate(x, 0.0, z) @ rotate_y((r[3] - 0.5) * 0.2)))
@@ -536,17 +539,35 @@ def _street_primitives(sb, lods=3):
         r = rand01(3900, np.arange(p * 5, p * 5 + 5))
         rad, hgt = 0.15 + 0.5 * r[0], 0.8 + 3.5 * r[1]
         pb = PrimitiveBuilder()
+        if uv_tiles:
+            pb.uv_scale = (uv_tiles[1], uv_tiles[1])
         pb.add_surface(cylinder_surface((0, 0, 0), rad, hgt, 4000 + p, 0.02), 4, 4, lods)
         x, z = -60.0 + 120.0 * r[2], -8.0 + 16.0 * r[3]
         out.append((sb.add_primitive(pb), translate(x, 0.0, z)))
     return out
 
 
-def config3_street(width=3840, height=2160, lods=3):
-    """BASELINE config 3 (Bistro-class): 21 872 LOD0 patches = 2 799 616 triangles, 352 objects, 3 LOD levels."""
-    sb = SceneBuilder("config3_street")
-    for prim, l2w in _street_primitives(sb, lods):
-        sb.add_object(prim, l2w)
+def config3_street(width=3840, height=2160, lods=3, masked=False):
+    """BASELINE config 3 (Bistro-class): 21 872 LOD0 patches = 2 799 616 triangles, 352 objects, 3 LOD levels.
+    masked: the SAME geometry with alpha-tested materials (mesh_raster.hlsl:34-38,107-112,198-204) on every prop and every other
+    building -- two-sided foliage-style cut-outs (a noise and a disc texture, trilinear / nearest samplers): the workload of
+    bench.py --workload street_4k_masked, triangle for triangle the opaque scene."""
+    sb = SceneBuilder("config3_street" + ("_masked" if masked else ""))
+    mats = [0]
+    if masked:
+        tex = [sb.add_texture(t) for t in _alpha_textures(11)]
+        smp = [sb.add_sampler(T.FILTER_LINEAR_MIPMAP_LINEAR, T.FILTER_LINEAR, T.WRAP_REPEAT, T.WRAP_REPEAT),
+               sb.add_sampler(T.FILTER_NEAREST, T.FILTER_NEAREST, T.WRAP_REPEAT, T.WRAP_MIRRORED_REPEAT)]
+        # masked == "twin": the same two-sided materials WITHOUT the alpha test -- the opaque frame of equal triangle count the
+        # masked frame is measured against (two-sided materials skip the cone cull, so the plain scene submits fewer clusters)
+        mode = T.ALPHA_MASK if masked != "twin" else 0
+        mats = [sb.add_material(1, mode, tex[1], smp[0], 0.35, 1.0),    # noise: ~2/3 of the surface survives
+                sb.add_material(1, mode, tex[2], smp[1], 0.30, 1.0),    # discs
+                sb.add_material(1, mode, tex[0], smp[0], 0.5, 1.0)]     # checker
+    for k, (prim, l2w) in enumerate(_street_primitives(sb, lods, uv_tiles=(6.0, 3.0) if masked else None)):
+        # object 0: the ground (opaque); 1..40: buildings (every other one masked); 41..: props (all masked)
+        m = 0 if (not masked or k == 0 or (k <= 40 and k % 2 == 0)) else mats[k % len(mats)]
+        sb.add_object(prim, l2w, material=m)
     # second-floor view down the street: ~8.9k clusters pass LOD/frustum/cone culling, ~3.8k survive the
     # two-pass HZB test (~0.49 M triangles submitted, ~11.7 M fragments at 4K)
     cam = Camera((-62.0, 12.0, 3.0), (1.0, -0.18, -0.04), width, height)
