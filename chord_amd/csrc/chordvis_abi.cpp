@@ -363,11 +363,11 @@ int chordvis_destroy(ChordCtx* c)
     for (float*& d : c->dDepthImages) dfree(d);
     if (c->sharedScene) {       // a depth-view child: the scene buffers are the parent's
         c->dPrims = nullptr; c->dGroups = nullptr; c->dMeshlets = nullptr; c->dGroupIndices = nullptr; c->dMeshletData = nullptr;
-        c->dPositions = nullptr; c->dObjStatic = nullptr; c->dGroupOwner = nullptr; c->dMaterials = nullptr; c->dTexAlpha = nullptr;
+        c->dPositions = nullptr; c->dObjStatic = nullptr; c->dGroupRefs = nullptr; c->dMaterials = nullptr; c->dTexAlpha = nullptr;
         c->dTexcoords = nullptr; c->dBvhNodes = nullptr;
     }
     dfree(c->dPrims); dfree(c->dGroups); dfree(c->dMeshlets); dfree(c->dGroupIndices); dfree(c->dMeshletData);
-    dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dMaterials); dfree(c->dTexAlpha); dfree(c->dTexcoords); dfree(c->dBvhNodes); dfree(c->dGroupOwner); dfree(c->dObjectsOwned);
+    dfree(c->dPositions); dfree(c->dObjStatic); dfree(c->dMaterials); dfree(c->dTexAlpha); dfree(c->dTexcoords); dfree(c->dBvhNodes); dfree(c->dGroupRefs); dfree(c->dObjectsOwned);
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
     dfree(c->dRankCmds); dfree(c->dLeftCmds); dfree(c->dMineCmds);
@@ -573,11 +573,22 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     }
     if (cmdCap >= CHORD_MAX_INSTANCE_ID || groupInst > 0x7FFFFFFFull)
         return fail(c, CHORDVIS_E_CAPACITY, "upload_scene: more than 2^24-2 cluster instances do not fit the 24-bit visibility id (base.h:412)");
-    std::vector<uint32_t> owner((size_t)groupInst);
+    // the flattened (object, group) instances, every indirection of the group cull resolved (DGroupRef)
+    std::vector<DGroupRef> refs((size_t)groupInst);
     for (uint32_t o = 0; o < s->objectCount; o++) {
         const DObjStatic& d = c->hObjStatic[o];
-        std::fill(owner.begin() + d.groupBase, owner.begin() + d.groupBase + c->hPrims[d.prim].groupCount, o);
+        const DPrim& pr = c->hPrims[d.prim];
+        for (uint32_t gl = 0; gl < pr.groupCount; gl++) {
+            const DGroup& g = groups[pr.groupBase + gl];
+            DGroupRef& r = refs[(size_t)d.groupBase + gl];
+            const uint32_t cnt = std::min(g.meshletCount, (uint32_t)CHORD_GROUP_MAX_MESHLETS);
+            r.object = o;
+            r.group = (pr.groupBase + gl) | (cnt << 28);
+            for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++)
+                r.meshlet[i] = cnt ? pr.meshletBase + gidx[pr.groupIndicesBase + g.meshletOffset + (i < cnt ? i : 0u)] : 0u;
+        }
     }
+    if (nG >= (1u << 28)) return fail(c, CHORDVIS_E_CAPACITY, "upload_scene: more than 2^28 cluster groups");
 
     dfree(c->dRankCmds);                                   // sized by cmdCapacity; re-made by the first sharded raster pass
     dfree(c->dLeftCmds); dfree(c->dMineCmds);
@@ -652,7 +663,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     if ((rc = dalloc(c, &dst, vec.size()))) return rc;                                                        \
     if (!vec.empty()) CHORD_HIP(c, hipMemcpy(dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
     UP(c->dMeshlets, meshlets) UP(c->dGroups, groups) UP(c->dGroupIndices, gidx) UP(c->dMeshletData, mdata)
-    UP(c->dPositions, pos) UP(c->dPrims, c->hPrims) UP(c->dObjStatic, c->hObjStatic) UP(c->dGroupOwner, owner)
+    UP(c->dPositions, pos) UP(c->dPrims, c->hPrims) UP(c->dObjStatic, c->hObjStatic) UP(c->dGroupRefs, refs)
     UP(c->dMaterials, dmats)
     if (!bvh.empty()) { UP(c->dBvhNodes, bvh) } else dfree(c->dBvhNodes);
     c->bvhComplete = bvhComplete;

@@ -61,7 +61,7 @@ int chordvis_allocate_depth_views(ChordCtx* c, uint32_t dim, uint32_t viewCount)
     }
     k->sharedScene = true;
     k->dPrims = c->dPrims; k->dGroups = c->dGroups; k->dMeshlets = c->dMeshlets; k->dGroupIndices = c->dGroupIndices;
-    k->dMeshletData = c->dMeshletData; k->dPositions = c->dPositions; k->dObjStatic = c->dObjStatic; k->dGroupOwner = c->dGroupOwner;
+    k->dMeshletData = c->dMeshletData; k->dPositions = c->dPositions; k->dObjStatic = c->dObjStatic; k->dGroupRefs = c->dGroupRefs;
     k->dMaterials = c->dMaterials; k->dTexAlpha = c->dTexAlpha; k->dTexcoords = c->dTexcoords; k->dBvhNodes = c->dBvhNodes;
     k->bvhComplete = c->bvhComplete; k->anyMasked = c->anyMasked; k->hPrims = c->hPrims; k->hObjStatic = c->hObjStatic;
     k->objectCount = c->objectCount; k->primCount = c->primCount; k->materialCount = c->materialCount; k->meshletCount = c->meshletCount;

@@ -86,6 +86,15 @@ struct TriRecMaskExt {         // 48 B
     uint32_t pad;
 };
 
+// One flattened (object, group) instance with everything the group cull needs to START at the records it tests: the reference's
+// thread walks object -> primitive -> group -> group indices -> meshlets (instance_culling.hlsl:133-208: five dependent fetches);
+// the walk is the same for every frame, so it is done once at upload.  24 B.
+struct DGroupRef {
+    uint32_t object;               // owner
+    uint32_t group;                // index into dGroups | meshlet count << 28 (<= 4)
+    uint32_t meshlet[4];           // global meshlet ids of the group's (up to) four meshlets; unused slots repeat the first
+};
+
 struct DObjFrame {             // per object, per frame (written by the object-cull kernel), 208 B
     float    mvp[16];          // row-major VP * M            (mesh_raster.hlsl:90-91)
     float    mvpLast[16];      // row-major VP_last * M_last  (hzb_mainview_culling.hlsl:77-83)
@@ -265,7 +274,7 @@ struct ChordCtx {
     uint8_t* dTexAlpha = nullptr;             // alpha channel of every level of every texture, back to back
     float* dTexcoords = nullptr;              // float2 per vertex (textureCoord0Buffer), or null
     bool anyMasked = false;
-    uint32_t* dGroupOwner = nullptr;  // object id per flattened (object, group)
+    chord::DGroupRef* dGroupRefs = nullptr;   // per flattened (object, group) instance (static: the object -> primitive binding is the scene's)
     chord::DBVHNode* dBvhNodes = nullptr;   // every primitive's tree (or null: the scene came without)
     bool bvhComplete = false;         // every primitive has a validated tree
     int cullMode = 0;                 // 0 flat (the reference's dispatch), 1 hierarchical (chordvis_set_cull_mode)

@@ -182,7 +182,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* blockT
 
 struct GroupCullParams {
     const ChordObject* objects; const DObjStatic* objStatic; const DObjFrame* objFrame; const DPrim* prims;
-    const DGroup* groups; const uint32_t* groupIndices; const DMeshlet* meshlets; const uint32_t* groupOwner;
+    const DGroup* groups; const uint32_t* groupIndices; const DMeshlet* meshlets; const DGroupRef* groupRefs;
     const DView* dview; uint8_t* groupMask; uint32_t* blockCounts; uint32_t groupInstances;
     // sharded frames: the commands whose clusters touch one of this rank's screen tiles are ALSO written to the rank's own
     // list (in the same deterministic order), decided where the meshlet record is already in registers
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
         if (p.groupInstances && objFrameOut) {
             const uint32_t first = blockIdx.x * 256u;
             if (first < p.groupInstances) {
-                const uint32_t oFirst = p.groupOwner[first], oLast = p.groupOwner[min(first + 255u, p.groupInstances - 1u)];
+                const uint32_t oFirst = p.groupRefs[first].object, oLast = p.groupRefs[min(first + 255u, p.groupInstances - 1u)].object;
                 // (256 group instances may span more than 256 objects when primitives without groups sit in between)
                 for (uint32_t k = threadIdx.x; k <= oLast - oFirst; k += 256u) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, oFirst + k);
             }
@@ -273,14 +273,11 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
     if (FROM_MASK) {
         if (t < p.groupInstances) mask = p.groupMask[t] & 15u;
         if (mask) {
-            const uint32_t o = p.groupOwner[t];
-            const DObjStatic st = p.objStatic[o];
-            const DPrim& prim = p.prims[st.prim];
-            const DGroup& g = p.groups[prim.groupBase + (t - st.groupBase)];
-            const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
+            const DGroupRef ref = p.groupRefs[t];
+            const uint32_t o = ref.object;
             for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++)
                 if (mask & (1u << i)) {
-                    const DMeshlet& m = p.meshlets[prim.meshletBase + p.groupIndices[idxBase + i]];
+                    const DMeshlet& m = p.meshlets[ref.meshlet[i]];
                     tris += (m.vertexTriangleCount >> 8) & 0xFFu;
                     if (sharded && cluster_touches_rank(p.shard, p.objFrame[o].mvp, m, p.W, p.H, p.Wi, p.Hi)) mine |= 1u << i;
                 }
@@ -288,25 +285,21 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
         }
     } else
     if (t < p.groupInstances) {
-        const uint32_t o = p.groupOwner[t];
+        // ONE fetch names the owner, the group record and the group's meshlets (DGroupRef, resolved at upload); everything the
+        // tests read -- the object's frame record, the group, its (up to) four meshlets -- is a second, independent round trip
+        const DGroupRef ref = p.groupRefs[t];
+        const uint32_t o = ref.object;
         const DObjFrame& of = p.objFrame[o];
         if (of.visible) {
-            const DObjStatic st = p.objStatic[o];
-            const DPrim& prim = p.prims[st.prim];
-            const DGroup g = p.groups[prim.groupBase + (t - st.groupBase)];
-            if (g.meshletCount != 0u && group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {     // instance_culling.hlsl:174
+            const uint32_t matFlags = p.objStatic[o].matFlags;
+            const DGroup g = p.groups[ref.group & 0x0FFFFFFFu];
+            const uint32_t cnt = ref.group >> 28;
+            if (cnt != 0u && group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {     // instance_culling.hlsl:174
                 const Mat4 M = load_mat(p.objects[o].basicData.localToTranslatedWorld);
-                const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
-                // the (up to) four meshlets of the group: their indices in one round trip, the records in a second one --
-                // not index -> record four times in a row (a slot beyond the group's count re-reads its first meshlet)
-                const uint32_t cnt = min(g.meshletCount, (uint32_t)CHORD_GROUP_MAX_MESHLETS);
-                uint32_t mi[CHORD_GROUP_MAX_MESHLETS];
-#pragma unroll
-                for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) mi[i] = prim.meshletBase + p.groupIndices[idxBase + (i < cnt ? i : 0u)];  // :178-180
 #pragma unroll
                 for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
-                    const DMeshlet m = p.meshlets[mi[i]];
-                    if (i < cnt && meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (st.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, m)) {
+                    const DMeshlet m = p.meshlets[ref.meshlet[i]];                              // :178-180 (a slot beyond the group's count re-reads its first meshlet)
+                    if (i < cnt && meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, m)) {
                         mask |= 1u << i;
                         tris += (m.vertexTriangleCount >> 8) & 0xFFu;
                         if (sharded && cluster_touches_rank(p.shard, of.mvp, m, p.W, p.H, p.Wi, p.Hi)) mine |= 1u << i;
@@ -645,17 +638,13 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
     const uint32_t off = offs & 0xFFFFu;
     uint32_t tris = 0;
     if (mask) {
-        const uint32_t o = p.groupOwner[t];
-        const DObjStatic st = p.objStatic[o];
-        const DPrim& prim = p.prims[st.prim];
-        const DGroup& g = p.groups[prim.groupBase + (t - st.groupBase)];
-        const uint32_t idxBase = prim.groupIndicesBase + g.meshletOffset;
+        const DGroupRef ref = p.groupRefs[t];
         uint32_t slot = blockBase + off, mslot = mineBase + (offs >> 16);
         for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
             if (mask & (1u << i)) {
                 ChordDrawCmd cmd;
-                cmd.objectId = o;
-                cmd.meshletId = prim.meshletBase + p.groupIndices[idxBase + i];
+                cmd.objectId = ref.object;
+                cmd.meshletId = ref.meshlet[i];
                 cmd.slot = slot;                                            // instance_culling.hlsl:203-206
                 outCmds[slot] = cmd;
                 if (sharded && (mine & (1u << i))) p.mineCmds[mslot++] = cmd;   // the rank's own list: same order, same slots
@@ -869,7 +858,7 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
 {
     GroupCullParams p;
     p.objects = c->dObjects; p.objStatic = c->dObjStatic; p.objFrame = c->dObjFrame; p.prims = c->dPrims;
-    p.groups = c->dGroups; p.groupIndices = c->dGroupIndices; p.meshlets = c->dMeshlets; p.groupOwner = c->dGroupOwner;
+    p.groups = c->dGroups; p.groupIndices = c->dGroupIndices; p.meshlets = c->dMeshlets; p.groupRefs = c->dGroupRefs;
     p.dview = c->dView; p.groupMask = c->dGroupMask; p.blockCounts = c->dBlockCounts; p.groupInstances = c->groupInstances;
     p.shard = c->shard; p.W = (float)c->width; p.H = (float)c->height; p.Wi = (int32_t)c->width; p.Hi = (int32_t)c->height; p.mineCmds = nullptr; p.mineCount = nullptr;
     c->mineValid = false;
