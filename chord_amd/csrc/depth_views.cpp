@@ -52,6 +52,7 @@ int chordvis_allocate_depth_views(ChordCtx* c, uint32_t dim, uint32_t viewCount)
     if (c->shard.ranks > 1 || c->sharedScene) return fail(c, CHORDVIS_E_INVALID, "allocate_depth_views: not on a sharded or child context");
     if (c->depthCtx) { chordvis_destroy(c->depthCtx); c->depthCtx = nullptr; }
     for (float*& d : c->dDepthImages) if (d) { (void)hipFree(d); d = nullptr; }
+    c->fusedDepthView = -1;                               // (the child's chain 0 goes with the child: no image of the new views is in it)
     ChordCtx* k = nullptr;
     int rc = chordvis_create(c->device, c->stream, &k);
     if (rc) return fail(c, rc, "allocate_depth_views: child context");
@@ -75,6 +76,7 @@ int chordvis_allocate_depth_views(ChordCtx* c, uint32_t dim, uint32_t viewCount)
         for (float*& d : c->dDepthImages) if (d) { (void)hipFree(d); d = nullptr; }
         c->dDepthImages.clear();
         c->depthDim = 0;
+        c->fusedDepthView = -1;
         if (c->depthCtx) { chordvis_destroy(c->depthCtx); c->depthCtx = nullptr; }
         return code;
     };

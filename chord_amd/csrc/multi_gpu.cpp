@@ -353,6 +353,7 @@ struct ChordGroup {
     std::unique_ptr<std::atomic<uint64_t>[]> readyGen[4];     // [which][rank]
     std::unique_ptr<std::atomic<uint64_t>[]> arrivedGen[4];   // [which][src * n + dst]
     std::vector<uint64_t> useCount[4];                         // [which][rank]: private to the rank's thread
+    std::atomic<bool> abort{false};                            // a hand-shake timed out: every exchange of the group fails from now on
     // one barrier remains, once per pipelined frame (the swap of the buffer pairs)
     std::mutex bm;
     std::condition_variable bcv;
@@ -410,10 +411,23 @@ int run_all(ChordGroup* g, const std::function<int(uint32_t)>& fn, const char* w
     return CHORDVIS_OK;
 }
 
-inline void spin_until(const std::atomic<uint64_t>& a, uint64_t gen)
+// Bounded: a peer that never publishes (its thread died, or it skipped an exchange because a decision every rank must share
+// diverged) must not leave this thread spinning forever.  The first rank to give up raises the group-wide abort flag; every
+// spin of every rank then ends at once, the frame returns CHORDVIS_E_COMM on all of them and the group stays poisoned until it
+// is destroyed (its generation counters no longer agree).
+inline bool spin_until(const std::atomic<uint64_t>& a, uint64_t gen, std::atomic<bool>& abort)
 {
     uint32_t spins = 0;
-    while (a.load(std::memory_order_acquire) < gen) { if (++spins > 4096u) std::this_thread::yield(); }
+    std::chrono::steady_clock::time_point t0;
+    while (a.load(std::memory_order_acquire) < gen) {
+        if (abort.load(std::memory_order_relaxed)) return false;
+        if (++spins > 4096u) {
+            if (spins == 4097u) t0 = std::chrono::steady_clock::now();
+            std::this_thread::yield();
+            if ((spins & 0xFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { abort.store(true); return false; }
+        }
+    }
+    return true;
 }
 
 // Direct all-gather of rank-major buffers, called by every rank's thread: rank r's chunk travels to each peer on the
@@ -435,9 +449,10 @@ int group_all_gather(ChordGroup* g, uint32_t r, int which, const std::function<c
     const uint64_t gen = ++g->useCount[which][r];
     GG_HIP(hipEventRecord(g->evReady[which][r], c->stream));
     g->readyGen[which][r].store(gen, std::memory_order_release);
-    for (uint32_t k = 1; k < n; k++) {
+    bool alive = true;
+    for (uint32_t k = 1; k < n && alive; k++) {
         const uint32_t d = (r + k) % n;                           // (every rank starts with a different peer)
-        spin_until(g->readyGen[which][d], gen);
+        if (!spin_until(g->readyGen[which][d], gen, g->abort)) { alive = false; break; }
         hipStream_t cs = bulk ? g->bulkCopyStream[(size_t)r * n + d] : g->copyStream[(size_t)r * n + d];
         GG_HIP(hipStreamWaitEvent(cs, g->evReady[which][r], 0));
         GG_HIP(hipStreamWaitEvent(cs, g->evReady[which][d], 0));
@@ -445,13 +460,14 @@ int group_all_gather(ChordGroup* g, uint32_t r, int which, const std::function<c
         GG_HIP(hipEventRecord(g->evArrived[which][(size_t)r * n + d], cs));
         g->arrivedGen[which][(size_t)r * n + d].store(gen, std::memory_order_release);
     }
-    for (uint32_t k = 1; k < n; k++) {
+    for (uint32_t k = 1; k < n && alive; k++) {
         const uint32_t o = (r + k) % n;
-        spin_until(g->arrivedGen[which][(size_t)o * n + r], gen);
+        if (!spin_until(g->arrivedGen[which][(size_t)o * n + r], gen, g->abort)) { alive = false; break; }
         GG_HIP(hipStreamWaitEvent(waiter, g->evArrived[which][(size_t)o * n + r], 0));   // into my buffer
         GG_HIP(hipStreamWaitEvent(waiter, g->evArrived[which][(size_t)r * n + o], 0));   // out of my buffer
     }
 #undef GG_HIP
+    if (!alive && !rc) rc = fail(c, CHORDVIS_E_COMM, "group exchange: a peer never reached the hand-shake (timed out or aborted); destroy the group");
     return rc;
 }
 

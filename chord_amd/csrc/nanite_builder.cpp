@@ -31,8 +31,10 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <queue>
 #include <unordered_map>
+#include <exception>
 #include <vector>
 
 namespace {
@@ -771,7 +773,17 @@ int chordvis_save_gltf_binary(const ChordBuiltAsset* a, const char* path, int lz
 // Reads a GLTFBinary archive into a built asset holding ONE primitive that spans the whole file (the reference keeps the
 // per-primitive offsets in its GLTFAsset, a different archive: a host that has them fills its own ChordPrimitive records and
 // uses only the arrays of chordvis_built_asset_desc).
+static int load_gltf_binary_impl(const char* path, ChordBuiltAsset** out);
+
+// (the file's header sizes are not trusted: every element count is checked against the bytes that remain BEFORE it is multiplied,
+// the decompressed size against what an LZ4 block of that length can expand to; allocation failures do not cross the C boundary)
 int chordvis_load_gltf_binary(const char* path, ChordBuiltAsset** out)
+{
+    try { return load_gltf_binary_impl(path, out); }
+    catch (const std::exception&) { if (out) *out = nullptr; return CHORDVIS_E_INVALID; }
+}
+
+static int load_gltf_binary_impl(const char* path, ChordBuiltAsset** out)
 {
     if (!path || !out) return CHORDVIS_E_INVALID;
     *out = nullptr;
@@ -784,17 +796,21 @@ int chordvis_load_gltf_binary(const char* path, ChordBuiltAsset** out)
     const int32_t rawSize = f.get<int32_t>(), compSize = f.get<int32_t>();
     const uint64_t mode = f.get<uint64_t>(), strLen = f.get<uint64_t>();
     if (!f.ok || rawSize < 0 || compSize < 0 || strLen != (uint64_t)compSize || strLen > file.size() - f.i || mode > 1) return CHORDVIS_E_INVALID;
+    if (mode == 1 && (uint64_t)rawSize > (uint64_t)compSize * 255u + 64u) return CHORDVIS_E_INVALID;   // (an LZ4 block expands at most 255 : 1)
     std::vector<uint8_t> raw;
     if (mode == 1) { raw.resize((size_t)rawSize); if (!lz4_block_decode(file.data() + f.i, (size_t)compSize, raw.data(), raw.size())) return CHORDVIS_E_INVALID; }
     else { if (compSize != rawSize) return CHORDVIS_E_INVALID; raw.assign(file.begin() + (long)f.i, file.begin() + (long)(f.i + strLen)); }
     ByteReader r{raw.data(), raw.size()};
-    ChordBuiltAsset* a = new ChordBuiltAsset();
+    std::unique_ptr<ChordBuiltAsset> holder(new ChordBuiltAsset());     // (freed on every early return and on bad_alloc)
+    ChordBuiltAsset* a = holder.get();
     (void)r.get<uint32_t>();                                                         // GLTFBinary class version
-    r.floats(a->positions, r.get<uint64_t>() * 3);
-    r.skip(r.get<uint64_t>() * 12);                                                  // normals
-    r.floats(a->texcoords, r.get<uint64_t>() * 2);
-    r.skip(r.get<uint64_t>() * 16);                                                  // tangents
-    r.skip(r.get<uint64_t>() * 12); r.skip(r.get<uint64_t>() * 8); r.skip(r.get<uint64_t>() * 16);   // smoothNormals, texcoords1, colors0
+    // an element count times its size, refused (reader marked bad) when the product exceeds the bytes that remain
+    auto bytes_of = [&](uint64_t elem) -> uint64_t { const uint64_t n = r.get<uint64_t>(); if (n > (raw.size() - r.i) / elem) { r.ok = false; return 0; } return n * elem; };
+    r.floats(a->positions, bytes_of(12) / 4);
+    r.skip(bytes_of(12));                                                            // normals
+    r.floats(a->texcoords, bytes_of(8) / 4);
+    r.skip(bytes_of(16));                                                            // tangents
+    r.skip(bytes_of(12)); r.skip(bytes_of(8)); r.skip(bytes_of(16));                 // smoothNormals, texcoords1, colors0
     uint64_t n = r.get<uint64_t>();
     if (n > (raw.size() - r.i) / 64) r.ok = false;
     for (uint64_t i = 0; r.ok && i < n; i++) {
@@ -829,8 +845,9 @@ int chordvis_load_gltf_binary(const char* path, ChordBuiltAsset** out)
     }
     n = r.get<uint64_t>();
     if (n > (raw.size() - r.i) / 4) r.ok = false; else { a->groupIndices.resize((size_t)n); for (uint64_t i = 0; i < n; i++) a->groupIndices[(size_t)i] = r.get<uint32_t>(); }
-    r.skip(r.get<uint64_t>() * 4);                                                   // lod0Indices
-    if (!r.ok || r.i != raw.size() || a->positions.empty()) { delete a; return CHORDVIS_E_INVALID; }
+    r.skip(bytes_of(4));                                                             // lod0Indices
+    if (!r.ok || r.i != raw.size() || a->positions.empty()) return CHORDVIS_E_INVALID;
+    if (!a->texcoords.empty() && a->texcoords.size() / 2 != a->positions.size() / 3) return CHORDVIS_E_INVALID;   // one uv per vertex, or none
     // one primitive over everything
     std::memset(&a->prim, 0, sizeof(a->prim));
     const size_t nv = a->positions.size() / 3;
@@ -843,7 +860,7 @@ int chordvis_load_gltf_binary(const char* path, ChordBuiltAsset** out)
     uint32_t lods = 0;
     for (const ChordMeshlet& m : a->meshlets) lods = std::max(lods, m.lod + 1u);
     a->lodCount = lods;
-    *out = a;
+    *out = holder.release();
     return CHORDVIS_OK;
 }
 
