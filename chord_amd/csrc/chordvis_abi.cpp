@@ -1072,7 +1072,12 @@ static int frame_phase_a_impl(ChordCtx* c)
     if ((rc = begin_frame_clear(c))) return rc;
     record(c, S_CLEAR);
     ChordCountAndCmd post;
-    if ((rc = chordvis_instance_culling(c, &post))) return rc;                        // (its first kernel carries the previous frame's HZB tail)
+    // (the post-cull list is not handed out here: a rank writes only its own share of it; chordvis_last_frame_cmds, the read-back
+    // and the tile marker make the full list when they are asked for it -- from the cull's own masks, every rank culled every group)
+    c->lazyFullList = true;
+    rc = chordvis_instance_culling(c, &post);                                        // (its first kernel carries the previous frame's HZB tail)
+    c->lazyFullList = false;
+    if (rc) return rc;
     record(c, S_CULL);
     ChordHZB hist;
     const bool haveHist = c->historySlot != 0;
@@ -1197,6 +1202,8 @@ int chordvis_wait_visibility(ChordCtx* c, void* hipStream)
 int chordvis_last_frame_cmds(ChordCtx* c, ChordCountAndCmd* out)
 {
     if (!c || !out || !c->sceneLoaded) return fail(c, CHORDVIS_E_INVALID, "last_frame_cmds: no scene");
+    launch_full_list(c);                                             // (a sharded frame wrote only the rank's share of it)
+    CHORD_HIP(c, hipGetLastError());
     *out = c->lists[0].handle();
     return CHORDVIS_OK;
 }
@@ -1215,6 +1222,7 @@ int chordvis_visibility_mark(ChordCtx* c, ChordCountAndCmd drawed, ChordTileMark
 {
     if (!c || !out || !c->dVis || !c->sceneLoaded) return fail(c, CHORDVIS_E_INVALID, "visibility_mark: no scene / gbuffer");
     if (!drawed.count || !drawed.cmds) return fail(c, CHORDVIS_E_INVALID, "visibility_mark: null command list");
+    if (drawed.cmds == c->lists[0].cmds) { launch_full_list(c); CHORD_HIP(c, hipGetLastError()); }
     const uint32_t mW = (c->width + 7u) / 8u, mH = (c->height + 7u) / 8u;
     int rc;
     if (!c->dTileMarker) {
@@ -1290,6 +1298,7 @@ int chordvis_readback_previous_visibility(ChordCtx* c, uint64_t* host)
 int chordvis_readback_cmds(ChordCtx* c, ChordCountAndCmd h, ChordDrawCmd* host, uint32_t cap, uint32_t* outCount)
 {
     if (!c || !h.count || !h.cmds || !outCount) return fail(c, CHORDVIS_E_INVALID, "readback_cmds: invalid handle");
+    if (h.cmds == c->lists[0].cmds) { launch_full_list(c); CHORD_HIP(c, hipGetLastError()); }
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
     uint32_t n = 0;
     CHORD_HIP(c, hipMemcpy(&n, h.count, 4, hipMemcpyDeviceToHost));

@@ -312,6 +312,8 @@ struct ChordCtx {
     ChordDrawCmd* dRankCmds = nullptr; // sharded frames: the commands of a raster pass whose clusters touch this rank's rows
     ChordDrawCmd* dMineCmds = nullptr; // sharded frames: the post-instanceCulling commands of THIS rank's clusters, written by the group cull itself (count: listCounts[4])
     bool mineValid = false;            // ... produced by the last chordvis_instance_culling
+    bool lazyFullList = false;         // (set around the cull of a sharded frame inside the library) the group cull writes only the rank's list
+    bool fullListStale = false;        // ... lists[0] has not been written for the last cull: launch_full_list makes it from the cull's masks
     bool listMine[3] = {false, false, false};   // lists[k] currently holds only this rank's clusters (it was culled from the rank's list)
     ChordDrawCmd* dLeftCmds = nullptr; // dense launches: the clusters the block kernel left to the record kernel (kernels_raster.hip)
     uint32_t* dCounts = nullptr;      // 4 x u32 backing the list counts
@@ -422,6 +424,7 @@ int alloc_scene_work_buffers(ChordCtx* c);
 
 // kernel launchers (implemented in the .hip translation units) ---------------------------------
 void launch_group_cull(ChordCtx* c, const CmdList& out);
+void launch_full_list(ChordCtx* c);             // the full post-cull list of a sharded frame, when a consumer asks for it
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
                      const CmdList* outRejected);
 hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles);   // first failing HIP call, or hipSuccess

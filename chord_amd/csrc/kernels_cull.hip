@@ -608,9 +608,11 @@ __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DV
 // (Tried in round 2: the phase-0 HZB test of every command inside this kernel for short scenes, to save the launch of
 // hzb_cull_kernel: 23.8 us against 5 + 7 us -- a thread owns a group's up to four commands and tests them one after
 // the other, four dependent chains of loads deep, while the stand-alone kernel has one command per thread.)
+// outCmds NULL: only the rank's own list is written (sharded frames inside the library: the full list -- 12 bytes per cluster of the
+// whole frame on every rank -- is made when a consumer asks for it, launch_full_list below); countTris 0: a re-run for that purpose.
 template <bool PREFIXED, bool SHARDED>
 __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams p, ChordDrawCmd* __restrict__ outCmds,
-                                                                 uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters)
+                                                                 uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters, uint32_t countTris)
 {
     __shared__ uint32_t red[256], redMine[SHARDED ? 256 : 1];
     constexpr bool sharded = SHARDED;
@@ -646,14 +648,15 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
                 cmd.objectId = ref.object;
                 cmd.meshletId = ref.meshlet[i];
                 cmd.slot = slot;                                            // instance_culling.hlsl:203-206
-                outCmds[slot] = cmd;
-                if (sharded && (mine & (1u << i))) p.mineCmds[mslot++] = cmd;   // the rank's own list: same order, same slots
+                if (outCmds) outCmds[slot] = cmd;
+                if (sharded && p.mineCmds && (mine & (1u << i))) p.mineCmds[mslot++] = cmd;   // the rank's own list: same order, same slots
                 if (!PREFIXED) tris += (p.meshlets[cmd.meshletId].vertexTriangleCount >> 8) & 0xFFu;
                 slot++;
             }
         }
     }
     if (PREFIXED) return;
+    if (!countTris) return;                                         // (a re-run for the full list: counts and totals are the frame's already)
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *outCount = blockBase + (total & 0xFFFFu); if (sharded) *p.mineCount = mineBase + (total >> 16); }
     // triangles this list submits (the Gtri/s unit): one fire-and-forget atomic per block
     uint32_t blockTris;
@@ -854,6 +857,30 @@ static HzbCullParams make_hzb_cull_params(ChordCtx* c, const HzbBuffers& hzb, co
     return p;
 }
 
+static GroupCullParams make_group_cull_params(ChordCtx* c)
+{
+    GroupCullParams p;
+    p.objects = c->dObjects; p.objStatic = c->dObjStatic; p.objFrame = c->dObjFrame; p.prims = c->dPrims;
+    p.groups = c->dGroups; p.groupIndices = c->dGroupIndices; p.meshlets = c->dMeshlets; p.groupRefs = c->dGroupRefs;
+    p.dview = c->dView; p.groupMask = c->dGroupMask; p.blockCounts = c->dBlockCounts; p.groupInstances = c->groupInstances;
+    p.shard = c->shard; p.W = (float)c->width; p.H = (float)c->height; p.Wi = (int32_t)c->width; p.Hi = (int32_t)c->height; p.mineCmds = nullptr; p.mineCount = nullptr;
+    return p;
+}
+
+// The full post-cull list of a frame whose group cull wrote only the rank's own (c->fullListStale): the scatter kernel once
+// more over the masks and block counts the cull left behind -- no other rank is asked, every rank culled every group.
+void launch_full_list(ChordCtx* c)
+{
+    if (!c->fullListStale) return;
+    GroupCullParams p = make_group_cull_params(c);
+    const uint32_t blocks = c->cullBlocks;
+    const CmdList& out = c->lists[0];
+    // (the masks carry the rank's nibble too; the kernel's SHARDED form scans both halves, mineCmds NULL: nothing of the rank's list is rewritten)
+    if (blocks > 512u) hipLaunchKernelGGL((group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, 0u);
+    else               hipLaunchKernelGGL((group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, 0u);
+    c->fullListStale = false;
+}
+
 void launch_group_cull(ChordCtx* c, const CmdList& out)
 {
     GroupCullParams p;
@@ -910,13 +937,17 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     }
 #undef LAUNCH_COUNT
     c->viewDirty = false;
+    // sharded frames inside the library (frame_phase_a): the full list is written when a consumer asks (launch_full_list)
+    ChordDrawCmd* full = out.cmds;
+    c->fullListStale = false;
+    if (sh && c->lazyFullList && out.cmds == c->lists[0].cmds) { full = nullptr; c->fullListStale = true; }
     if (blocks > 512u) {
         hipLaunchKernelGGL(group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters, p.mineCount);
-        if (sh) hipLaunchKernelGGL((group_cull_scatter_kernel<true, true>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
-        else    hipLaunchKernelGGL((group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+        if (sh) hipLaunchKernelGGL((group_cull_scatter_kernel<true, true>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
+        else    hipLaunchKernelGGL((group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
     } else {
-        if (sh) hipLaunchKernelGGL((group_cull_scatter_kernel<false, true>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
-        else    hipLaunchKernelGGL((group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters);
+        if (sh) hipLaunchKernelGGL((group_cull_scatter_kernel<false, true>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
+        else    hipLaunchKernelGGL((group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
     }
 }
 

@@ -587,6 +587,14 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, r
             mn, mx, rng = r.read_hzb(r.history_hzb())
             assert np.array_equal(mn, wmn) and np.array_equal(mx, wmx) and np.array_equal(rng, wrng)
         H.assert_rank_counts([r.stats() for r in ctxs], ref.stats())
+        # the full post-cull list (what the visibility ids index): a rank of a sharded frame writes only its own share during the
+        # frame and makes the whole list when a consumer asks -- identical to the single-GPU list, slots included; the tile marker
+        # of a rank (which reads it) equals the single-GPU marker
+        if frame == 1:
+            want_cmds = ref.read_cmds(ref.last_frame_cmds())
+            for r in (ctxs[0], ctxs[-1]):
+                assert np.array_equal(r.read_cmds(r.last_frame_cmds()), want_cmds)
+            assert np.array_equal(ctxs[1].read_tile_marker(ctxs[1].visibility_mark()), ref.read_tile_marker(ref.visibility_mark()))
         # every rank holds every tile's load after the end-of-frame exchange; tiles nobody drew into report 0
         loads = [r.read_tile_loads() for r in ctxs]
         assert all(np.array_equal(loads[0], x) for x in loads[1:]) and loads[0].sum() > 0
