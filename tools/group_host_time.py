@@ -15,7 +15,7 @@ flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL | R.FLAG_HZB_CULL
 objs = L.fill_objects(scene, cam, cam)
 g = VisibilityGroup([0] * ranks)
 g.upload_scene(scene)
-g.allocate_gbuffer(cam.width, cam.height, 0)
+g.allocate_gbuffer(cam.width, cam.height)
 g.update_objects(objs)
 g.set_view(view, iv, flags)
 for pipelined in (False, True):
@@ -23,6 +23,7 @@ for pipelined in (False, True):
     for _ in range(5):
         g.render_frame()
     g.sync()
+    g.enqueue_ms()               # (reset)
     n, calls = 50, []
     t0 = time.perf_counter()
     for _ in range(n):
@@ -32,6 +33,8 @@ for pipelined in (False, True):
     g.sync()
     total = (time.perf_counter() - t0) / n * 1e3
     calls.sort()
-    print("%d ranks on one device, %s, %s: render_frame call %.1f us median (%.1f min, %.1f p90); %.3f ms per frame end to end (%d ranks' kernels share the one GPU)"
-          % (ranks, wl, "pipelined" if pipelined else "unpipelined", calls[n // 2] * 1e6, calls[0] * 1e6, calls[int(n * 0.9)] * 1e6, total, ranks))
+    enq = g.enqueue_ms()         # per worker thread: its time inside the frame job (launches, copies, waits for the peers' hand-shakes)
+    print("%d ranks on one device, %s, %s: render_frame call %.1f us median (%.1f min, %.1f p90); %.3f ms per frame end to end (%d ranks' kernels share the one GPU); per-worker time inside the call, us: %s"
+          % (ranks, wl, "pipelined" if pipelined else "unpipelined", calls[n // 2] * 1e6, calls[0] * 1e6, calls[int(n * 0.9)] * 1e6, total, ranks,
+             " ".join("%.0f" % (v * 1e3) for v in enq)))
 g.close()

@@ -1,54 +1,56 @@
 #!/bin/bash
-# One GPU-box call that produces everything profiles/rNN_* is built from. Usage: tools/round_profile.sh <round tag, e.g. r03>
-# Counter passes are separate rocprofv3 runs (no tracing alongside --pmc).
+# One GPU-box call that produces everything profiles/rNN_* is built from. Usage: tools/round_profile.sh <round tag, e.g. r04>
+# Counter passes are separate rocprofv3 runs (no tracing alongside --pmc).  FULL=1 adds the microbenchmarks, the counter
+# calibration, the phase clocks and the ablation table (the measuring builds --tag abl -DRASTER_ABLATION=1 / --tag prof
+# -DRASTER_PROFILE=1 must exist then).
 set -u
-R=${1:-r03}
+R=${1:-r04}
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 > gpurun_out/${R}_pytest.txt
-grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl\|amdgpu.ids" gpurun_out/${R}_pytest.txt | tail -8
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/${R}_pytest.txt 2>&1
+grep -a "passed\|failed" gpurun_out/${R}_pytest.txt | tail -3
 tools/profile.sh ${R}_c3 > /dev/null
 tools/profile.sh ${R}_c4 --workload street_x64_4k_hzb > /dev/null
 tools/profile.sh ${R}_c5 --workload subpixel_1g --steps 6 --warmup 2 > /dev/null
 STATS_ONLY=1 tools/profile.sh ${R}_c5hot --workload subpixel_1g_hotspot --steps 6 --warmup 2 > /dev/null
+STATS_ONLY=1 tools/profile.sh ${R}_masked --workload street_4k_masked > /dev/null
 tools/pmc.sh ${R}_sq1 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" > gpurun_out/${R}_sq1.txt 2>&1
 tools/pmc.sh ${R}_sq2 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" > gpurun_out/${R}_sq2.txt 2>&1
 tools/pmc.sh ${R}_sq3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY" > gpurun_out/${R}_sq3.txt 2>&1
-tools/pmc.sh ${R}_tcc "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" > gpurun_out/${R}_tcc.txt 2>&1
 # (the block kernel's SQ counters on the 1/16-size workload with the block kernel forced: same kernel, 5 s of scene generation instead of 70)
 tools/pmc.sh ${R}_sq1_c5 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --workload subpixel_64m --debug-flags 65536 > gpurun_out/${R}_sq1_c5.txt 2>&1
 tools/pmc.sh ${R}_sq2_c5 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA" --workload subpixel_64m --debug-flags 65536 > gpurun_out/${R}_sq2_c5.txt 2>&1
-[ -n "${SKIP_C5_TCC:-}" ] || tools/pmc.sh ${R}_tcc_c5 "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" --workload subpixel_1g --steps 4 --warmup 2 > gpurun_out/${R}_tcc_c5.txt 2>&1
-tools/pmc.sh ${R}_tcc_c5hot "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" --workload subpixel_1g_hotspot --steps 4 --warmup 2 > gpurun_out/${R}_tcc_c5hot.txt 2>&1
+if [ -n "${FULL:-}" ]; then
+tools/pmc.sh ${R}_tcc "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" > gpurun_out/${R}_tcc.txt 2>&1
+tools/pmc.sh ${R}_tcc_c5 "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" --workload subpixel_1g --steps 4 --warmup 2 > gpurun_out/${R}_tcc_c5.txt 2>&1
 cd tools/microbench
 for b in ${MICROBENCH-lds_atomics launch_floor atomics write_size_calib}; do
   [ -x $b ] || hipcc -O3 --offload-arch=gfx950 -o $b $b.hip
   timeout 120 ./$b > $GRAFT_REPO_ROOT/gpurun_out/${R}_microbench_$b.txt 2>&1
 done
-cd /tmp && export TMPDIR=/tmp
-if [ -x $GRAFT_REPO_ROOT/tools/microbench/write_size_calib ]; then
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${R}_calib_w -o r -- $GRAFT_REPO_ROOT/tools/microbench/write_size_calib > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${R}_calib_f -o r -- $GRAFT_REPO_ROOT/tools/microbench/write_size_calib > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+bash tools/ablate.sh ${R}_abl -t abl -f 0,4096,4128,8192,16384,16512,128 > gpurun_out/${R}_ablate_tile.txt 2>&1
+CHORDVIS_LIB=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis_prof.so python tools/tile_profile.py hzb > gpurun_out/${R}_tile_profile.txt 2>&1
+CHORDVIS_LIB=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis_prof.so python tools/setup_profile.py subpixel_64m 65536 > gpurun_out/${R}_setup_profile_64m.txt 2>&1
 fi
 cd $GRAFT_REPO_ROOT
 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
+python bench.py --steps 20 --warmup 5 --cpu-baseline-frames 0 > gpurun_out/${R}_bench_default_20steps.json 2>/dev/null
 python bench.py --workload street_x64_4k_hzb --cpu-baseline-frames 0 > gpurun_out/${R}_bench_c4.json 2>/dev/null
 python bench.py --workload subpixel_1g --steps 10 --warmup 2 --cpu-baseline-frames 0 > gpurun_out/${R}_bench_c5.json 2>/dev/null
 python bench.py --workload subpixel_1g_hotspot --steps 10 --warmup 2 --cpu-baseline-frames 0 > gpurun_out/${R}_bench_c5hot.json 2>/dev/null
 python bench.py --workload subpixel_64m --cpu-baseline-frames 0 --debug-flags 65536 > gpurun_out/${R}_bench_64m.json 2>/dev/null
 python bench.py --workload atrium_1080p --no-hzb --cpu-baseline-frames 0 > gpurun_out/${R}_bench_c2.json 2>/dev/null
 python bench.py --cull hierarchical --cpu-baseline-frames 0 > gpurun_out/${R}_bench_c3_bvh.json 2>/dev/null
-# (the ablation switches and the phase clocks need the measuring builds: python chord_amd/build.py --tag abl -DRASTER_ABLATION=1,
-#  --tag prof -DRASTER_PROFILE=1 -- built before the call, they travel with the snapshot)
-bash tools/ablate.sh ${R}_abl -t abl -f 0,4096,4128,8192,16384,16512,128 > gpurun_out/${R}_ablate_tile.txt 2>&1
+python bench.py --workload street_x64_4k_hzb --cull hierarchical --cpu-baseline-frames 0 > gpurun_out/${R}_bench_c4_bvh.json 2>/dev/null
+python bench.py --workload street_4k_masked --cpu-baseline-frames 0 > gpurun_out/${R}_bench_masked.json 2>/dev/null
+python bench.py --workload street_4k_masked_twin --cpu-baseline-frames 0 > gpurun_out/${R}_bench_masked_twin.json 2>/dev/null
 python tools/shard_time.py subpixel_1g 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c5.txt
-python tools/shard_time.py street_x64_4k_hzb 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c4.txt
-PIPELINED=1 RANKS=2,4,8 python tools/shard_time.py street_x64_4k_hzb 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c4_pipelined.txt
+RANKS=1,8 python tools/shard_time.py street_x64_4k_hzb 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c4.txt
+PIPELINED=1 RANKS=8 python tools/shard_time.py street_x64_4k_hzb 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c4_pipelined.txt
 RANKS=1,8 python tools/shard_time.py subpixel_1g_hotspot 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c5hot.txt
-RANKS=8 STRIPE=32 python tools/shard_time.py subpixel_1g_hotspot 2>&1 | grep "^ranks" >> gpurun_out/${R}_shard_time_c5hot.txt
-python tools/shadow_time.py c3 2>&1 | grep "^c3" > gpurun_out/${R}_shadow_time.txt
 python tools/group_host_time.py 8 2>&1 | grep "ranks on" > gpurun_out/${R}_group_host_time.txt
-CHORDVIS_LIB=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis_prof.so python tools/tile_profile.py hzb > gpurun_out/${R}_tile_profile.txt 2>&1
-CHORDVIS_LIB=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis_prof.so python tools/setup_profile.py subpixel_64m 65536 > gpurun_out/${R}_setup_profile_64m.txt 2>&1
+python tools/shadow_time.py c3 2>&1 | grep "^c3" > gpurun_out/${R}_shadow_time.txt
 bash tools/trace.sh ${R}_trace > gpurun_out/${R}_timeline.txt 2>&1
-cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${R}_shadow -o r -- python $GRAFT_REPO_ROOT/tools/shadow_time.py c3 > /dev/null 2>&1
+bash tools/trace.sh ${R}_trace_c4 --workload street_x64_4k_hzb > gpurun_out/${R}_timeline_c4.txt 2>&1
+find gpurun_out -name "r_kernel_trace.csv" -path "*${R}_trace*" -delete
 cd $GRAFT_REPO_ROOT; ls gpurun_out | grep "^${R}" | head -80
