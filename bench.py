@@ -326,11 +326,21 @@ def measure(args, workload, env):
     # ---- warm-up (untimed): also collects the deterministic per-view counts ---------------------
     r.enable_timers(0)
     per_view = [None, None]
-    for i in range(max(args.warmup, 4)):
+    # (a short warm-up leaves the GPU below its clocks: the W frames asked for, then -- still untimed -- frames until 60 ms of work
+    # have gone through, in pairs so that the timed region starts on view A)
+    warm = max(args.warmup, 4) + (max(args.warmup, 4) & 1)
+    w0 = time.perf_counter()
+    i = 0
+    while i < warm or (world == 1 and time.perf_counter() - w0 < 0.06 and i < 4000):
         frame(i)
-        if i >= max(args.warmup, 4) - 2:
-            st = r.stats()
-            per_view[i & 1] = st
+        frame(i + 1)
+        i += 2
+        if i % 64 == 0 or i >= warm:
+            torch.cuda.synchronize(dev)
+    warm = i
+    for i in range(2):
+        frame(i)
+        per_view[i & 1] = r.stats()
     # ---- N > 1: the tile map re-balanced from the loads of the last warm-up frame (every rank holds every tile's load after
     #      the end-of-frame exchange and computes the same map), then two more untimed frames under the new map
     tile_map = None
@@ -353,9 +363,12 @@ def measure(args, workload, env):
     clusters_per_pair = sum(pv["countStage0Visible"] + pv["countStage1Visible"] for pv in per_view)
 
     # ---- timed region --------------------------------------------------------------------------
-    # GPU timestamps (hipEvent on the launch stream) on every 8th step of the timed region: each event
-    # record costs ~5 us of stream idle time, 15 per frame would inflate the frame by ~20 %
-    r.enable_timers(2, period=8)
+    # GPU timestamps (hipEvent on the launch stream): each event record costs ~5 us of stream idle time, 15 per frame inflate a
+    # frame by ~20 %.  Runs of 64 steps or more stamp every 8th step of the timed region; a shorter run (the driver's 20 steps) would
+    # carry that cost in 15 % of its frames, so its stamped frames -- eight of them -- are rendered right behind the timed region
+    # instead (same frames, same state, same stream): `stamped_inside_timed_region` says which it was.
+    stamp_inside = args.steps >= 64 or world > 1
+    r.enable_timers(2 if stamp_inside else 0, period=8)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -370,7 +383,7 @@ def measure(args, workload, env):
     # The per-kernel averages behind `roofline` come from hipEvent stamps on the launch stream.  Inside the timed region only every
     # 8th step is stamped (a stamped frame is ~20 % longer); a short run (the driver's 20 steps: 2-3 stamped frames) is topped
     # up to at least 8 stamped frames right after it -- same frames, same state, outside the clock.
-    stamped_in_region = (args.steps + 7) // 8
+    stamped_in_region = (args.steps + 7) // 8 if stamp_inside else 0
     extra = 0
     st = r.stats()                                  # per-frame GPU timestamps averaged over the stamped steps of the timed region
     if stamped_in_region < 8 and world == 1:
@@ -383,6 +396,8 @@ def measure(args, workload, env):
         for k in list(st):                          # the ms* fields are means over stamped frames: weighted mean of the two sets
             if k.startswith("ms") and isinstance(st[k], float):
                 st[k] = (st[k] * stamped_in_region + st2[k] * extra) / (stamped_in_region + extra)
+            elif not stamped_in_region:
+                st[k] = st2[k]
     rank_elapsed = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -533,7 +548,7 @@ def measure(args, workload, env):
     if rank == 0:
         line = {
             "metric": "Gtri/s into 4K 64-bit visbuffer", "value": round(value, 4), "unit": "Gtri/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "timed_region_s": round(elapsed, 6),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_frames_run": warm + 2, "ms_per_step": round(ms_per_step, 4), "timed_region_s": round(elapsed, 6),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32+u64", "data": "synthetic",
             "config": {"workload": wl, **({"ABLATION_debug_flags": args.debug_flags} if args.debug_flags else {}), "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(),
