@@ -258,7 +258,7 @@ struct RcclTransport {
         hipError_t he = hipEventRecord(c->commPhaseB, c->stream);
         if (he == hipSuccess) he = hipStreamWaitEvent(c->commResolveStream, c->commPhaseB, 0);
         if (he != hipSuccess) return fail(c, CHORDVIS_E_HIP, "image gather: stream order", he);
-        const size_t words = (size_t)c->shard.slotsPerRank * (CHORD_TILE * CHORD_TILE);
+        const size_t words = c->shard.ranks > 1 ? (size_t)c->shard.slotsPerRank * (CHORD_TILE * CHORD_TILE) : (size_t)c->visWords;
         const int e = r->AllGather(c->dVis + (size_t)c->shard.rank * words, c->dVis, words, kNcclUint64, (NcclComm)c->commBulk, c->commResolveStream);
         return e == kNcclSuccess ? CHORDVIS_OK : nccl_fail(c, r, "ncclAllGather(visibility)", e);
     }
@@ -281,9 +281,29 @@ int comm_render_frame(ChordCtx* c)
         // a communicator of one rank: the single-GPU frame (nothing is sharded), then the image through the collective in place --
         // what a one-GPU box can exercise of this path
         void* comm = c->comm;
+        hipError_t he = hipSuccess;
+        const int parity = (int)(c->commFrameSerial & 1u);
+        if (c->commPipelined) {
+            // (one buffer, not a pair: the frame may not start before the image gather of the frame before has read it)
+            c->commFrameSerial++;
+            he = hipStreamWaitEvent(c->stream, c->commVisReady[parity ^ 1], 0);
+        }
         c->comm = nullptr;                                                    // (chordvis_render_frame dispatches on it)
         int rc = chordvis_render_frame(c);
         c->comm = comm;
+        if (he != hipSuccess && !rc) rc = fail(c, CHORDVIS_E_HIP, "pipelined frame, one rank: stream order", he);
+        if (c->commPipelined) {
+            // the pipelined protocol's image step with the transport a host of N ranks uses: second communicator, resolve
+            // stream behind the compute stream's "phase b done" event, "image complete" event per frame parity
+            RcclTransport tr{c, r};
+            const int e = tr.image();
+            if (!rc) rc = e;
+            he = hipEventRecord(c->commVisReady[parity], c->commResolveStream);
+            if (he != hipSuccess && !rc) rc = fail(c, CHORDVIS_E_HIP, "hipEventRecord(image complete)", he);
+            c->visReadyEvent[0] = c->commVisReady[parity];
+            c->visReadyEvent[1] = c->commVisReady[parity ^ 1];
+            return rc;
+        }
         const int e = r->AllGather(c->dVis, c->dVis, (size_t)c->visWords, kNcclUint64, (NcclComm)comm, c->stream);
         if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(visibility, one rank)", e);
         return rc;

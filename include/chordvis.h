@@ -345,7 +345,20 @@ int chordvis_comm_destroy(ChordCtx* ctx);
 /* Pipelined frames over RCCL (the ChordGroup form: chordvis_group_set_pipelined below).  id128: a SECOND unique id (the same
  * on every rank) for the communicator that carries the image of frame i, on a stream of its own, beside frame i + 1; the
  * history HZB then waits only for the small end-of-frame exchange, not for the image.  chordvis_readback_visibility / chordvis_visibility_mark / chordvis_wait_visibility wait for the image.
- * NULL switches back to the plain protocol.  The context must own its visibility buffer. */
+ * NULL switches back to the plain protocol.  The context must own its visibility buffer.
+ * Two communicators of one process run on two streams of one device, and RCCL orders collectives per communicator only.
+ * What makes that safe here: (1) each communicator is used from exactly one stream, always the same one; (2) every rank
+ * issues the same collectives in the same order on each communicator (frame after frame: small, image, small -- whether the
+ * mid-frame exchange happens is decided from state every rank shares); (3) no collective of one communicator waits, on the
+ * device, for a LATER collective of the other on any rank: the image gather waits for the compute stream's "phase b done"
+ * event, which lies before the next small exchange.  A host that adds collectives of its own must keep (1)-(3), and must not
+ * run a blocking call (hipMalloc, hipFree, a synchronous copy) on one rank between the two enqueues while its peers are
+ * already inside them -- the usual NCCL multi-communicator rule.  With one rank (all a one-GPU box can host) the call sets up
+ * the same second communicator, stream and events; the frame is the unsharded one followed by the image step.
+ * A frame that fails on one rank (capacity, HIP error) still issues every collective of the frame, so its peers do not hang,
+ * returns the first error, and leaves the context outside a frame: the next chordvis_render_frame starts clean (its history is
+ * the last complete frame's only if the host calls chordvis_reset_history on EVERY rank; otherwise that rank culls against a
+ * chain its peers do not share and the images may differ -- treat a failed frame as a reason to reset or to stop). */
 int chordvis_comm_set_pipelined(ChordCtx* ctx, const void* id128);
 /* NCCL_VERSION_CODE of the loaded library, ranks of ctx's communicator (0 = none; ctx may be NULL), where librccl came from */
 int chordvis_comm_info(ChordCtx* ctx, int* ncclVersion, uint32_t* nranks, char* libraryOrigin, uint32_t originBytes);

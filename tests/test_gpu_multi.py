@@ -1,5 +1,6 @@
 """The multi-GPU entry points on ONE device: ranks share device 0, so the protocol (screen tiles, the exchanges, event
 ordering, buffer reuse, one call per frame) is what is tested; xGMI bandwidth is not."""
+import ctypes as C
 import json
 import os
 import subprocess
@@ -172,6 +173,42 @@ def test_library_owned_rccl_exchange_world_size_1(gpu):
         H.assert_vis_equal(r.read_visibility(), ref.read_visibility(), w, h, "frame %d" % frame)
         a, b = r.read_hzb(r.history_hzb()), ref.read_hzb(ref.history_hzb())
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    r.comm_destroy()
+    r.close()
+    ref.close()
+
+
+def test_pipelined_rccl_frames_world_size_1(gpu):
+    """chordvis_comm_set_pipelined on the one rank a one-GPU box can host: a second communicator (its own unique id), the
+    image of every frame gathered on the resolve stream behind the compute stream's "phase b done" event, an "image complete"
+    event per frame parity, consumers ordered by chordvis_wait_visibility (on the context's stream and on a foreign one) --
+    RcclTransport::image and the event plumbing of the N-rank protocol; the frames must equal the fused single-GPU frames."""
+    import torch
+    from chord_amd.renderer import VisibilityRenderer, comm_unique_id
+    scene, cam, view, iv = H.setup_scene(lambda: scenes.small_test_scene(320, 200, seed=32))
+    w, h, flags = cam.width, cam.height, H.ALL_FLAGS
+    ref = VisibilityRenderer(0)
+    r = VisibilityRenderer(0)
+    for x in (ref, r):
+        x.upload_scene(scene)
+        x.allocate_gbuffer(w, h)
+        x.set_view(view, iv, flags)
+    r.comm_init_rank(1, 0, comm_unique_id())
+    r.comm_set_pipelined(comm_unique_id())
+    side = torch.cuda.Stream(device=0)
+    for frame in range(4):
+        ref.render_frame()
+        r.render_frame()
+        r.wait_visibility()
+        r.wait_visibility(C.c_void_p(side.cuda_stream))
+        side.synchronize()
+        H.assert_vis_equal(r.read_visibility(), ref.read_visibility(), w, h, "pipelined frame %d" % frame)
+        a, b = r.read_hzb(r.history_hzb()), ref.read_hzb(ref.history_hzb())
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    r.comm_set_pipelined(None)                       # drains the frames in flight, drops the second communicator
+    ref.render_frame()
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), ref.read_visibility(), w, h, "frame after the pipeline was switched off")
     r.comm_destroy()
     r.close()
     ref.close()
