@@ -90,6 +90,10 @@ def test_weighted_tile_map_balances_hotspots_and_skies(built_lib):
     # everything in two tiles
     two = np.zeros(tiles); two[100] = 7; two[1500] = 9
     check(two, 1.0)
+    # measured loads (chordvis_read_tile_loads on the GPU box, committed): BASELINE config 5's hotspot and config 4 at 4K
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    check(np.load(os.path.join(prof, "r04_tile_loads_config5_hotspot.npy")), 1.06)        # (its heaviest tile alone is a mean rank's load)
+    check(np.load(os.path.join(prof, "r04_tile_loads_config4.npy")), 1.08)
 
 
 def _worker(rank, world, port, tmp):
