@@ -140,6 +140,8 @@ __device__ __forceinline__ const RasterParams* kernel_args()
     return reinterpret_cast<const RasterParams*>(kp);
 }
 
+// number of set bits of a wave mask below this lane
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ int32_t bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 __device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
@@ -998,17 +1000,29 @@ __device__ __forceinline__ int classify_triangle(const RasterParams& p, uint32_t
     return K_EMIT;
 }
 
-// set-up of an emitted, narrow triangle again from LDS and its scan conversion into the wave's pixel window
-__device__ __forceinline__ void resolve_triangle(const RasterParams& p, uint32_t t, uint32_t slot, uint32_t packedIdx, bool twoSided,
-                                                 const int32_t* lSX, const int32_t* lSY, const float* lD, unsigned long long* win,
-                                                 int32_t bx0, int32_t by0)
+// set-up of an emitted, narrow triangle again from LDS and its scan conversion into the wave's pixel window.  `entry` is a word
+// of the cluster's compacted list of emitted triangles (vertex indices in the low 24 bits, triangle number above), boxX / boxY
+// the pixel bounds its classification found: the emitted triangles of a cluster -- 59 of 128 on BASELINE config 5 -- are
+// resolved one per lane in one pass (a second one only when there are more than 64), not in two passes of a lane's own two
+// triangles with half the lanes idle in each.  The classification accepted exactly these integers, and only narrow triangles
+// reach a block: deltas below 2^15, the area from two 24-bit multiplies, its float an int32 conversion.
+__device__ __forceinline__ void resolve_entry(const RasterParams& p, uint32_t entry, uint32_t boxX, uint32_t boxY, uint32_t slot,
+                                              const int32_t* lSX, const int32_t* lSY, const float* lD, unsigned long long* win,
+                                              int32_t bx0, int32_t by0)
 {
-    const uint32_t i0 = packedIdx & 0xFFu, i1 = (packedIdx >> 8) & 0xFFu, i2 = (packedIdx >> 16) & 0xFFu;
+    const uint32_t i0 = entry & 0xFFu, i1 = (entry >> 8) & 0xFFu, i2 = (entry >> 16) & 0xFFu, t = entry >> 24;
     TriSetup ts;
     ts.X[0] = lSX[i0]; ts.Y[0] = lSY[i0];
     ts.X[1] = lSX[i1]; ts.Y[1] = lSY[i1];
     ts.X[2] = lSX[i2]; ts.Y[2] = lSY[i2];
-    (void)tri_setup(ts, twoSided, p.Wi, p.Hi);                          // (true: the classification accepted exactly these integers)
+    const int32_t dx1 = ts.X[1] - ts.X[0], dy1 = ts.Y[1] - ts.Y[0], dx2 = ts.X[2] - ts.X[0], dy2 = ts.Y[2] - ts.Y[0];
+    const int32_t area2 = __mul24(dx1, dy2) - __mul24(dx2, dy1);
+    const int32_t area = area2 < 0 ? -area2 : area2;
+    ts.s = area2 < 0 ? -1 : 1;
+    ts.area = (int64_t)area;
+    ts.invA = 1.0f / (float)area;
+    ts.px0 = (int32_t)(boxX & 0xFFFFu); ts.px1 = (int32_t)(boxX >> 16);
+    ts.py0 = (int32_t)(boxY & 0xFFFFu); ts.py1 = (int32_t)(boxY >> 16);
     float d[3] = {lD[i0], lD[i1], lD[i2]};
     if (p.biasConst != 0.0f || p.biasSlope != 0.0f) { const float o = depth_bias(ts, d, p.biasConst, p.biasSlope); d[0] += o; d[1] += o; d[2] += o; }
     ts.payload = p.depthOnly ? 0u : encode_triangle_instance(t, slot);
@@ -1210,15 +1224,27 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                         if (lane == 0u && G) gbase = atomicAdd(&e.counters->blockGranules[listShard * CHORD_SHARD_STRIDE], G);
                         if (has && ahead) slot = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&e.tileCount[(size_t)tile * TC_STRIDE]), (unsigned long long)ahead * 0x100000001ull);
                     }
-                    // ... and the cluster is resolved while they are in flight
+                    // ... and the cluster is resolved while they are in flight.  The emitted triangles are compacted first (the
+                    // clip-space arrays x, y, w are dead behind the classification: the list and the two bound words take their place)
+                    uint32_t* lList = reinterpret_cast<uint32_t*>(lX);
+                    uint32_t* lBoxX = reinterpret_cast<uint32_t*>(lY);
+                    uint32_t* lBoxY = reinterpret_cast<uint32_t*>(lW);
+                    const uint32_t nA = (uint32_t)__popcll(emA);
+                    WAVE_LDS_SYNC();                                             // (every lane's classification has read them)
+                    if (eA) { const uint32_t k = mbcnt64(emA); lList[k] = (t0 & 0xFFFFFFu) | lane << 24; lBoxX[k] = bxA; lBoxY[k] = byA; }
+                    if (eB) { const uint32_t k = nA + mbcnt64(emB); lList[k] = (t1 & 0xFFFFFFu) | (lane + 64u) << 24; lBoxX[k] = bxB; lBoxY[k] = byB; }
 #pragma unroll
                     for (int k = 0; k < WIN * WIN / 64; k++) win[lane + 64u * k] = 0ull;
                     WAVE_LDS_SYNC();
                     // (a sharded frame's cluster none of whose window parts is this rank's: the conservative cluster test let it through)
                     const bool anyPart = hasMask != 0u;
-                    if (eA && anyPart) resolve_triangle(p, lane, hdr.slot, t0, twoSided, lSX, lSY, lD, win, bx0, by0);
-                    __builtin_amdgcn_sched_barrier(0);                           // (one triangle's set-up alive at a time)
-                    if (eB && anyPart) resolve_triangle(p, lane + 64u, hdr.slot, t1, twoSided, lSX, lSY, lD, win, bx0, by0);
+                    if (anyPart) {
+                        if (lane < nE) resolve_entry(p, lList[lane], lBoxX[lane], lBoxY[lane], hdr.slot, lSX, lSY, lD, win, bx0, by0);
+                        if (nE > 64u) {                                          // (wave-uniform; one triangle's set-up alive at a time)
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (lane + 64u < nE) resolve_entry(p, lList[lane + 64u], lBoxX[lane + 64u], lBoxY[lane + 64u], hdr.slot, lSX, lSY, lD, win, bx0, by0);
+                        }
+                    }
                     WAVE_LDS_SYNC();
                     SPHASE(3);
                     gbase = bcast(gbase, 0);
