@@ -410,6 +410,14 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         mB[a + 1] = mB[a] + as.meshletCount; gB[a + 1] = gB[a] + as.meshletGroupCount;
         iB[a + 1] = iB[a] + as.meshletGroupIndexCount; dB[a + 1] = dB[a] + as.meshletDataCount; vB[a + 1] = vB[a] + as.vertexCount;
     }
+    {
+        // (the raster kernels form vertex index x 3 in 32 bits -- one full-rate instruction instead of a quarter-rate 64-bit
+        // multiply per vertex fetch: 1.43 G vertices = 17 GB of positions per scene; the reference's ByteAddressBuffer offsets
+        // are 32-bit BYTE offsets, a third of that)
+        uint64_t verts = 0;
+        for (uint32_t a = 0; a < s->assetCount; a++) verts += s->assets[a].vertexCount;
+        if (verts > 0x55555555ull) return fail(c, CHORDVIS_E_INVALID, "upload_scene: more than 0x55555555 vertices in one scene");
+    }
     const uint32_t nM = mB.back(), nG = gB.back(), nI = iB.back(), nD = dB.back(), nV = vB.back();
     std::vector<uint32_t> nB(s->assetCount + 1, 0);
     for (uint32_t a = 0; a < s->assetCount; a++) nB[a + 1] = nB[a] + (s->assets[a].bvhNodes ? s->assets[a].bvhNodeCount : 0u);

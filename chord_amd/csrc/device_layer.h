@@ -78,13 +78,19 @@ struct DMaterial {             // 48 B
     float    alphaCutOff;
     uint32_t pad[2];
 };
-// extension of a masked triangle's 48-byte record, in the slot behind it
-struct TriRecMaskExt {         // 48 B
+// extension of a masked triangle's 48-byte record, in the TWO slots behind it.  Everything a row unit of the tile kernel needs to
+// sample the triangle's alpha is in here -- the chosen level's first byte and size, the wraps, the material's factor and cut-off --
+// so a unit's set-up is one round trip (this record), not three dependent ones (extension -> material -> level offsets).
+struct __attribute__((aligned(16))) TriRecMaskExt {         // 96 B, 60 used
     float    uw[3], vw[3], iw[3];   // u / w, v / w, 1 / w per vertex
     uint32_t levelFilter;      // level | linear << 8
-    uint32_t material;
-    uint32_t pad;
+    uint32_t levelBase;        // first alpha byte of that level in dTexAlpha; 0xFFFFFFFF: white fallback (alpha 1)
+    uint32_t dims;             // (width - 1) | (height - 1) << 16 of that level
+    uint32_t wraps;            // wrapS | wrapT << 16 (CHORD_WRAP_*: 16-bit values)
+    float    alphaFactor, alphaCutOff;
+    uint32_t pad[9];
 };
+#define CHORD_MASK_EXT_SLOTS 2u    // record slots an extension takes (a masked triangle: 1 + CHORD_MASK_EXT_SLOTS)
 
 // One flattened (object, group) instance with everything the group cull needs to START at the records it tests: the reference's
 // thread walks object -> primitive -> group -> group indices -> meshlets (instance_culling.hlsl:133-208: five dependent fetches);

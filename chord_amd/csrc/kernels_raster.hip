@@ -480,7 +480,7 @@ __device__ __forceinline__ void write_record(TriRec* dst, const TriSetup& ts, co
 // perspective-correct uv from u/w, v/w, 1/w; ONE level per triangle from the ratio of its doubled uv area (in level-0
 // texels) to its doubled pixel area, level = floor(log2(ratio)) >> 1; nearest or bilinear as the sampler's min / mag
 // filter says; wrap modes on the integer texel index.  A masked triangle takes a 48-byte record (bit 2 of `twoSided`)
-// plus a TriRecMaskExt in the next slot of the same list.
+// plus a TriRecMaskExt in the next two slots of the same list.
 __device__ __forceinline__ bool filter_is_linear(uint32_t f)
 {
     return f == CHORD_FILTER_LINEAR || f == CHORD_FILTER_LINEAR_MIPMAP_NEAREST || f == CHORD_FILTER_LINEAR_MIPMAP_LINEAR;
@@ -511,8 +511,23 @@ __device__ __forceinline__ void write_mask_ext(TriRec* slot, const DMaterial& m,
 #pragma unroll
     for (int i = 0; i < 3; i++) { e.iw[i] = 1.0f / w[i]; e.uw[i] = u[i] * e.iw[i]; e.vw[i] = v[i] * e.iw[i]; }
     e.levelFilter = mask_level_filter(m, absArea2, u, v);
-    e.material = material; e.pad = 0u;
-    *reinterpret_cast<TriRecMaskExt*>(slot) = e;
+    (void)material;
+    const uint32_t level = e.levelFilter & 0xFFu;
+    e.levelBase = 0xFFFFFFFFu; e.dims = 0u;
+    if (m.texOffset != 0xFFFFFFFFu) {
+        uint32_t off = m.texOffset;
+        for (uint32_t l = 0; l < level; l++) off += max(1u, m.texWidth >> l) * max(1u, m.texHeight >> l);
+        e.levelBase = off;
+        e.dims = (max(1u, m.texWidth >> level) - 1u) | (max(1u, m.texHeight >> level) - 1u) << 16;
+    }
+    e.wraps = (m.wrapS & 0xFFFFu) | m.wrapT << 16;
+    e.alphaFactor = m.alphaFactor; e.alphaCutOff = m.alphaCutOff;
+    // (the 60 bytes in use: three 16-byte stores and three dwords; the rest of the second slot is never read)
+    uint4* dst = reinterpret_cast<uint4*>(slot);
+    const uint4* src = reinterpret_cast<const uint4*>(&e);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    reinterpret_cast<uint32_t*>(slot)[12] = e.wraps;
+    reinterpret_cast<float*>(slot)[13] = e.alphaFactor; reinterpret_cast<float*>(slot)[14] = e.alphaCutOff;
 }
 
 // Texel indices are 32-bit here: texel_floor maps everything beyond +-1e9 to 0, so an index and its +1 neighbour fit an int32
@@ -565,16 +580,14 @@ struct AlphaLevel {
     uint32_t wrapS, wrapT;
     bool linear;
 };
-__device__ __forceinline__ AlphaLevel alpha_level(const uint8_t* __restrict__ texAlpha, const DMaterial& m, uint32_t level, bool linear)
+__device__ __forceinline__ AlphaLevel alpha_level(const uint8_t* __restrict__ texAlpha, uint32_t levelBase, uint32_t dims, uint32_t wraps, bool linear)
 {
     AlphaLevel a;
-    a.base = nullptr; a.W = 1; a.H = 1; a.fW = 1.0f; a.fH = 1.0f; a.wrapS = m.wrapS; a.wrapT = m.wrapT; a.linear = linear;
-    if (m.texOffset == 0xFFFFFFFFu) return a;
-    size_t off = m.texOffset;
-    for (uint32_t l = 0; l < level; l++) off += (size_t)max(1u, m.texWidth >> l) * max(1u, m.texHeight >> l);
-    a.W = (int32_t)max(1u, m.texWidth >> level); a.H = (int32_t)max(1u, m.texHeight >> level);
+    a.base = nullptr; a.W = 1; a.H = 1; a.fW = 1.0f; a.fH = 1.0f; a.wrapS = wraps & 0xFFFFu; a.wrapT = wraps >> 16; a.linear = linear;
+    if (levelBase == 0xFFFFFFFFu) return a;
+    a.W = (int32_t)(dims & 0xFFFFu) + 1; a.H = (int32_t)(dims >> 16) + 1;
     a.fW = (float)a.W; a.fH = (float)a.H;
-    a.base = texAlpha + off;
+    a.base = texAlpha + levelBase;
     return a;
 }
 __device__ __forceinline__ float sample_alpha(const AlphaLevel& t, float u, float v)
@@ -621,17 +634,31 @@ template <int PITCH>
 __device__ __forceinline__ void tile_raster_narrow(unsigned long long* tile, const TriSetup& ts, int32_t ox, int32_t oy,
                                                    int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool noPixels, const bool clampZ);
 
-__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+// wave-wide minimum of a and b, maximum of c and d (all 64 lanes active), results wave-uniform.  Each step's operand is a
+// DPP-permuted copy (within quads, within rows of 16, then lane 15 / 31 of a row broadcast to the rows above) folded into the
+// v_min / v_max itself: 24 VALU instructions for the four reductions and no LDS traffic -- the __shfl_xor form was 24
+// ds_bpermute round trips plus ~40 instructions of address arithmetic and min / max.  Written as one asm block because the
+// compiler expands the update_dpp builtin to copy + nop + v_mov_dpp + min; the four chains are interleaved, which also keeps
+// every DPP read two instructions behind the write it depends on (the hazard the leading s_nop covers for the inputs).
+__device__ __forceinline__ void wave_min2_max2(int32_t& a, int32_t& b, int32_t& c, int32_t& d)
 {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = min(v, __shfl_xor(v, m, 64));
-    return v;
-}
-__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
-{
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m, 64));
-    return v;
+#define DPP_STEP(ctrl)                                                \
+    "v_min_i32_dpp %0, %0, %0 " ctrl "\n\t"                           \
+    "v_min_i32_dpp %1, %1, %1 " ctrl "\n\t"                           \
+    "v_max_i32_dpp %2, %2, %2 " ctrl "\n\t"                           \
+    "v_max_i32_dpp %3, %3, %3 " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 DPP_STEP("row_ror:4 row_mask:0xf bank_mask:0xf")
+                 DPP_STEP("row_ror:8 row_mask:0xf bank_mask:0xf")
+                 DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef DPP_STEP
+    a = __builtin_amdgcn_readlane(a, 63); b = __builtin_amdgcn_readlane(b, 63);
+    c = __builtin_amdgcn_readlane(c, 63); d = __builtin_amdgcn_readlane(d, 63);
 }
 
 // ---- the per-cluster setup kernel -------------------------------------------------------------
@@ -702,8 +729,8 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
         const uint32_t ib = md[hdr.dataOffset + min(lane + 64u, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
         if (lane < hdr.T) t0 = md[hdr.dataOffset + hdr.V + lane];
         if (lane + 64u < hdr.T) t1 = md[hdr.dataOffset + hdr.V + 64u + lane];
-        const float* __restrict__ pa = ps + (size_t)ia * 3;
-        const float* __restrict__ pb = ps + (size_t)ib * 3;
+        const float* __restrict__ pa = ps + (size_t)(ia * 3u);      // (32-bit: chordvis_upload_scene refuses scenes whose vertex index x 3 would not fit)
+        const float* __restrict__ pb = ps + (size_t)(ib * 3u);
         pax = pa[0]; pay = pa[1]; paz = pa[2]; pbx = pb[0]; pby = pb[1]; pbz = pb[2];
     }
     const bool sprof = RASTER_PROFILE && (p.debug & DBG_SETUP_CLOCKS) != 0;
@@ -801,17 +828,17 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
         SPHASE(2);
         // next cluster: its positions now (the indices have arrived behind the triangle arithmetic)
         const float* __restrict__ psN = scalar_load(&kernel_args()->positions);
-        const float* __restrict__ npa = psN + (size_t)nia * 3;
-        const float* __restrict__ npb = psN + (size_t)nib * 3;
+        const float* __restrict__ npa = psN + (size_t)(nia * 3u);
+        const float* __restrict__ npb = psN + (size_t)(nib * 3u);
         const float nax = npa[0], nay = npa[1], naz = npa[2], nbx = npb[0], nby = npb[1], nbz = npb[2];
         {
             const unsigned long long lt = (1ull << lane) - 1ull;
             const unsigned long long cmA = __ballot(kindA == K_CLIP), cmB = __ballot(kindB == K_CLIP);
             const unsigned long long emA = __ballot(kindA == K_EMIT), emB = __ballot(kindB == K_EMIT);
             // the 32-byte record form takes every triangle whose vertices are at most 64 px apart; the rest go wide
-            // (a masked triangle takes a 48-byte record and its extension: two slots of the wide list)
+            // (a masked triangle takes a 48-byte record and its extension: three slots of the wide list)
             const bool cpA = kindA == K_EMIT && !masked && fits_compact(tsA), cpB = kindB == K_EMIT && !masked && fits_compact(tsB);
-            const uint32_t wSlots = masked ? 2u : 1u;
+            const uint32_t wSlots = masked ? 1u + CHORD_MASK_EXT_SLOTS : 1u;
             const unsigned long long ecA = __ballot(cpA), ecB = __ballot(cpB);
             const unsigned long long ewA = emA & ~ecA, ewB = emB & ~ecB;
             const bool lgA = kindA == K_EMIT && touches_many_tiles(tsA), lgB = kindB == K_EMIT && touches_many_tiles(tsB);
@@ -914,28 +941,6 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
 // word pairs (header | word 0, word 1 | word 2, ...): half the store instructions, whole 16-byte granules.
 struct SetupHeader { uint32_t objectId, meshletId, slot, V, T, dataOffset, vertexBase, matFlags; };
 
-// tri_setup without the division: false when the triangle is rejected (zero area, back face after snapping, empty bbox)
-__device__ __forceinline__ bool tri_setup_geom(TriSetup& ts, bool twoSided, int32_t Wi, int32_t Hi, bool& small)
-{
-    const int32_t dx1 = ts.X[1] - ts.X[0], dy1 = ts.Y[1] - ts.Y[0], dx2 = ts.X[2] - ts.X[0], dy2 = ts.Y[2] - ts.Y[0];
-    int64_t area2;
-    small = (uint32_t)(dx1 + 32767) < 65535u && (uint32_t)(dy1 + 32767) < 65535u &&
-            (uint32_t)(dx2 + 32767) < 65535u && (uint32_t)(dy2 + 32767) < 65535u;
-    if (small) area2 = (int64_t)(__mul24(dx1, dy2) - __mul24(dx2, dy1));
-    else area2 = (int64_t)dx1 * (int64_t)dy2 - (int64_t)dx2 * (int64_t)dy1;
-    if (area2 == 0) return false;
-    if (!twoSided && area2 > 0) return false;
-    ts.s = area2 < 0 ? -1 : 1;
-    ts.area = area2 < 0 ? -area2 : area2;
-    const int32_t minX = min(ts.X[0], min(ts.X[1], ts.X[2])), maxX = max(ts.X[0], max(ts.X[1], ts.X[2]));
-    const int32_t minY = min(ts.Y[0], min(ts.Y[1], ts.Y[2])), maxY = max(ts.Y[0], max(ts.Y[1], ts.Y[2]));
-    ts.px0 = max(0, (minX + 127) >> 8);
-    ts.py0 = max(0, (minY + 127) >> 8);
-    ts.px1 = min(Wi - 1, (maxX - 128) >> 8);
-    ts.py1 = min(Hi - 1, (maxY - 128) >> 8);
-    return !(ts.px1 < ts.px0 || ts.py1 < ts.py0);
-}
-
 // What the block kernel needs only when a cluster's blocks are written (a few lanes, once per cluster).  Kept in scalar
 // registers across the whole loop these 22 dwords push the kernel past its 102 SGPRs, and every scalar the compiler parks in a
 // VGPR lane costs a VALU instruction each way (~300 v_readlane / v_writelane in the loop body: 15 % of its VALU work).  They
@@ -988,15 +993,22 @@ __device__ __forceinline__ int classify_triangle(const RasterParams& p, uint32_t
     if (!allFast) { const float d0 = lD[i0], d1 = lD[i1], d2 = lD[i2]; if (d0 != d0 || d1 != d1 || d2 != d2) return K_CLIP; }
     // (the snapped 24.8 coordinates are per-vertex values: computed once per vertex in the vertex phase, not once per use --
     // a cluster's 128 triangles name its 81 vertices 384 times, here and again in the resolve)
-    TriSetup ts;
-    ts.X[0] = lSX[i0]; ts.Y[0] = lSY[i0];
-    ts.X[1] = lSX[i1]; ts.Y[1] = lSY[i1];
-    ts.X[2] = lSX[i2]; ts.Y[2] = lSY[i2];
-    bool small;
+    const int32_t X0 = lSX[i0], Y0 = lSY[i0], X1 = lSX[i1], Y1 = lSY[i1], X2 = lSX[i2], Y2 = lSY[i2];
+    const int32_t minX = min(X0, min(X1, X2)), maxX = max(X0, max(X1, X2));
+    const int32_t minY = min(Y0, min(Y1, Y2)), maxY = max(Y0, max(Y1, Y2));
+    // a triangle wider than 64 px is nothing a block holds: the cluster goes to the record kernel whatever else is true of
+    // it (emitted and not narrow; the record kernel culls it or sets it up) -- and what is left here has deltas below 2^15:
+    // the area is two full-rate 24-bit multiplies (the general 64-bit form is four quarter-rate ones, evaluated for every
+    // triangle when it sits behind a select)
+    if (maxX - minX > (1 << 14) || maxY - minY > (1 << 14)) return K_EMIT;
+    narrow = true;
+    const int32_t area2 = __mul24(X1 - X0, Y2 - Y0) - __mul24(X2 - X0, Y1 - Y0);
+    if (area2 == 0 || (!twoSided && area2 > 0)) return K_NONE;
     // (sharded frames: ownership is decided per window part, below -- a cluster that straddles two ranks' tiles is small)
-    if (!tri_setup_geom(ts, twoSided, p.Wi, p.Hi, small)) return K_NONE;
-    boxX = (uint32_t)ts.px0 | ((uint32_t)ts.px1 << 16); boxY = (uint32_t)ts.py0 | ((uint32_t)ts.py1 << 16);
-    narrow = narrow_extent(ts);
+    const int32_t px0 = max(0, (minX + 127) >> 8), py0 = max(0, (minY + 127) >> 8);
+    const int32_t px1 = min(p.Wi - 1, (maxX - 128) >> 8), py1 = min(p.Hi - 1, (maxY - 128) >> 8);
+    if (px1 < px0 || py1 < py0) return K_NONE;
+    boxX = (uint32_t)px0 | ((uint32_t)px1 << 16); boxY = (uint32_t)py0 | ((uint32_t)py1 << 16);
     return K_EMIT;
 }
 
@@ -1027,7 +1039,9 @@ __device__ __forceinline__ void resolve_entry(const RasterParams& p, uint32_t en
     if (p.biasConst != 0.0f || p.biasSlope != 0.0f) { const float o = depth_bias(ts, d, p.biasConst, p.biasSlope); d[0] += o; d[1] += o; d[2] += o; }
     ts.payload = p.depthOnly ? 0u : encode_triangle_instance(t, slot);
     ts.d0 = d[0]; ts.e1 = d[1] - d[0]; ts.e2 = d[2] - d[0];
-    tile_raster_narrow<WIN>(win, ts, bx0, by0, ts.px0, ts.py0, ts.px1, ts.py1, false, p.depthClamp != 0u);
+    // (two copies of the pixel loop rather than a clamp + select per pixel that main-view frames never need)
+    if (p.depthClamp != 0u) tile_raster_narrow<WIN>(win, ts, bx0, by0, ts.px0, ts.py0, ts.px1, ts.py1, false, true);
+    else tile_raster_narrow<WIN>(win, ts, bx0, by0, ts.px0, ts.py0, ts.px1, ts.py1, false, false);
 }
 
 // Hot tiles (BASELINE config 5, variant "hotspot": one screen tile receives 12 % of the frame's 10 M blocks): every bin slot
@@ -1108,8 +1122,8 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
         const uint32_t ib = md[hdr.dataOffset + min(lane + 64u, max(hdr.V, 1u) - 1u)] + hdr.vertexBase;
         if (lane < hdr.T) t0 = md[hdr.dataOffset + hdr.V + lane];
         if (lane + 64u < hdr.T) t1 = md[hdr.dataOffset + hdr.V + 64u + lane];
-        const float* __restrict__ pa = ps + (size_t)ia * 3;
-        const float* __restrict__ pb = ps + (size_t)ib * 3;
+        const float* __restrict__ pa = ps + (size_t)(ia * 3u);      // (32-bit: chordvis_upload_scene refuses scenes whose vertex index x 3 would not fit)
+        const float* __restrict__ pb = ps + (size_t)(ib * 3u);
         pax = pa[0]; pay = pa[1]; paz = pa[2]; pbx = pb[0]; pby = pb[1]; pbz = pb[2];
     }
     const bool sprof = RASTER_PROFILE && (p.debug & DBG_SETUP_CLOCKS) != 0;
@@ -1170,8 +1184,8 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
         SPHASE(2);
         // next cluster: its positions (the indices have arrived behind the classification)
         const float* __restrict__ ps = scalar_load(&kq()->positions);
-        const float* __restrict__ npa = ps + (size_t)nia * 3;
-        const float* __restrict__ npb = ps + (size_t)nib * 3;
+        const float* __restrict__ npa = ps + (size_t)(nia * 3u);
+        const float* __restrict__ npb = ps + (size_t)(nib * 3u);
         const float nax = npa[0], nay = npa[1], naz = npa[2], nbx = npb[0], nby = npb[1], nbz = npb[2];
 
         const bool eA = kindA == K_EMIT, eB = kindB == K_EMIT;
@@ -1184,8 +1198,7 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
             int32_t bx1 = max(eA ? (int32_t)(bxA >> 16) : -1, eB ? (int32_t)(bxB >> 16) : -1);
             int32_t by1 = max(eA ? (int32_t)(byA >> 16) : -1, eB ? (int32_t)(byB >> 16) : -1);
             if (__ballot(bx1 - bx0 >= WIN || by1 - by0 >= WIN) == 0ull) {            // (no single lane is already too wide)
-                bx0 = __builtin_amdgcn_readfirstlane(wave_min_i32(bx0)); by0 = __builtin_amdgcn_readfirstlane(wave_min_i32(by0));
-                bx1 = __builtin_amdgcn_readfirstlane(wave_max_i32(bx1)); by1 = __builtin_amdgcn_readfirstlane(wave_max_i32(by1));
+                wave_min2_max2(bx0, by0, bx1, by1);
                 const int32_t bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
                 const uint32_t nE = (uint32_t)(__popcll(emA) + __popcll(emB));
                 if (bw <= WIN && bh <= WIN && (uint32_t)(bw * bh + 8) * 8u <= nE * 36u) {
@@ -1202,7 +1215,7 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                     const uint32_t gran = has ? (rw * rh + 2u) >> 1 : 0u;              // header + w x h words, in 16-byte granules
                     const uint32_t g0 = bcast(gran, 0), g1 = bcast(gran, 1), g2 = bcast(gran, 2), g3 = bcast(gran, 3);
                     const uint32_t before = (r > 0u ? g0 : 0u) + (r > 1u ? g1 : 0u) + (r > 2u ? g2 : 0u), G = g0 + g1 + g2 + g3;
-                    const uint32_t tile = (uint32_t)(sy ? ty1 : ty0) * p.tilesX + (uint32_t)(sx ? tx1 : tx0);
+                    const uint32_t tile = __umul24((uint32_t)(sy ? ty1 : ty0), p.tilesX) + (uint32_t)(sx ? tx1 : tx0);
                     // one round trip: pool space (lane 0) and, per touched tile, ONE 64-bit add on the tile's counter pair
                     // (low word: bin slot, high word: the tile's block count) ...
                     uint32_t gbase = 0, slot = 0;
@@ -1281,9 +1294,10 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
                             for (uint32_t g = lane; g < gq; g += 64u) {
                                 // granule g = words 2g - 1, 2g of the block (word -1: the header)
                                 const uint32_t j1 = 2u * g, j0 = g == 0u ? 0u : j1 - 1u;
-                                const uint32_t row0 = (j0 * rcp) >> 16, row1 = (j1 * rcp) >> 16;       // exact for j < 256, w <= 16
-                                const unsigned long long w0 = g == 0u ? header : win[(qy + row0) * WIN + qx + (j0 - row0 * qw)];
-                                const unsigned long long w1 = j1 < n ? win[(qy + row1) * WIN + qx + (j1 - row1 * qw)] : 0ull;
+                                // (24-bit multiplies, full rate: j < 512, rcp <= 65536, row < 16, w <= 16)
+                                const uint32_t row0 = __umul24(j0, rcp) >> 16, row1 = __umul24(j1, rcp) >> 16;   // exact for j < 256, w <= 16
+                                const unsigned long long w0 = g == 0u ? header : win[(qy + row0) * WIN + qx + (j0 - __umul24(row0, qw))];
+                                const unsigned long long w1 = j1 < n ? win[(qy + row1) * WIN + qx + (j1 - __umul24(row1, qw))] : 0ull;
                                 dst[g] = make_ulonglong2(w0, w1);
                             }
                         }
@@ -1521,7 +1535,7 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
         const int np = clip_triangle(p, L, m, V, ct.tri, mvp, masked, cur);
         if (np < 3) continue;
         const uint32_t payload = p.depthOnly ? 0u : encode_triangle_instance(ct.tri, cmd.slot);
-        const uint32_t slots = masked ? 2u : 1u;
+        const uint32_t slots = masked ? 1u + CHORD_MASK_EXT_SLOTS : 1u;
         for (int i = 1; i + 1 < np; i++) {
             TriSetup ts;
             ts.X[0] = L.X(0); ts.X[1] = L.X(i); ts.X[2] = L.X(i + 1);
@@ -2050,9 +2064,10 @@ template <typename E_t>
 __device__ __forceinline__ void masked_rows(const RasterParams& p, unsigned long long* __restrict__ tileRow0, const UnitParams& u, uint32_t recIndex,
                                          int32_t ox, int32_t py0, int32_t nrows, int32_t lx0, int32_t lx1, bool noPixels, const bool clampZ)
 {
+    // (60 bytes of the extension, one round trip: nothing here depends on another fetch)
     const TriRecMaskExt ext = *reinterpret_cast<const TriRecMaskExt*>(&p.tris[recIndex + 1u]);
-    const DMaterial m = p.materials[ext.material];
-    const AlphaLevel tex = alpha_level(p.texAlpha, m, ext.levelFilter & 0xFFu, (ext.levelFilter & 256u) != 0u);
+    struct { float alphaFactor, alphaCutOff; } m = {ext.alphaFactor, ext.alphaCutOff};
+    const AlphaLevel tex = alpha_level(p.texAlpha, ext.levelBase, ext.dims, ext.wraps, (ext.levelFilter & 256u) != 0u);
     const E_t sgn = (u.skind & 1) ? (E_t)-1 : (E_t)1;
     const E_t dx0 = (E_t)(u.X[2] - u.X[1]), dy0 = (E_t)(u.Y[2] - u.Y[1]);
     const E_t dx1 = (E_t)(u.X[0] - u.X[2]), dy1 = (E_t)(u.Y[0] - u.Y[2]);
