@@ -647,6 +647,26 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
             d.minFilter = sm.minFilter; d.magFilter = sm.magFilter; d.wrapS = sm.wrapS; d.wrapT = sm.wrapT;
         } else { d.minFilter = d.magFilter = CHORD_FILTER_NEAREST; d.wrapS = d.wrapT = CHORD_WRAP_REPEAT; }
         d.alphaFactor = mat.baseColorFactor[3]; d.alphaCutOff = mat.alphaCutOff;
+        // every level as the tile kernel's row units want it (DMatLevel)
+        if (d.texOffset != 0xFFFFFFFFu) {
+            uint32_t off = d.texOffset;
+            auto wrap_consts = [](uint32_t n, uint32_t mode, uint32_t& magic, uint32_t& bias) {
+                magic = 0u; bias = 0u;
+                if (mode == CHORD_WRAP_CLAMP_TO_EDGE) return;
+                const uint32_t period = mode == CHORD_WRAP_MIRRORED_REPEAT ? 2u * n : n;
+                if ((period & (period - 1u)) == 0u) return;                  // masked, not divided
+                magic = (uint32_t)(0x100000000ull / period);
+                bias = (uint32_t)(((0x40000000ull + period - 1u) / period) * period);
+            };
+            for (uint32_t l = 0; l < d.texMips && l < CHORD_MAX_TEX_LEVELS; l++) {
+                const uint32_t w = std::max(1u, d.texWidth >> l), h = std::max(1u, d.texHeight >> l);
+                chord::DMatLevel& L = d.levels[l];
+                L.base = off; L.dims = (w - 1u) | (h - 1u) << 16;
+                wrap_consts(w, d.wrapS, L.magicS, L.biasS);
+                wrap_consts(h, d.wrapT, L.magicT, L.biasT);
+                off += w * h;
+            }
+        }
     }
     std::vector<float> uvs;
     if (anyMasked) {

@@ -70,25 +70,37 @@ struct DObjStatic {            // per object, derived once per upload, 16 B
 #define CHORD_MATFLAG_MATERIAL(f) ((f) >> 8)
 
 // What the masked buckets read of a material (mesh_raster.hlsl:107-112,198-204), texture and sampler pre-resolved.
-struct DMaterial {             // 48 B
+// One level of a material's alpha texture as the row units of the tile kernel want it (resolved at upload, copied into a masked
+// triangle's extension record by the setup kernel).  A non-power-of-two wrap is a remainder by a divisor known here: magic =
+// floor(2^32 / period) (period = the size, or twice the size for MIRRORED_REPEAT) turns it into one multiply-high and one
+// correction, bias = a multiple of the period >= 2^30 makes the texel index (|i| <= 1e9 + 1) non-negative first.
+struct DMatLevel {             // 24 B
+    uint32_t base;             // first alpha byte of the level in dTexAlpha
+    uint32_t dims;             // (width - 1) | (height - 1) << 16
+    uint32_t magicS, biasS, magicT, biasT;   // 0 for a power-of-two period (wrapped with a mask) and for CLAMP_TO_EDGE
+};
+#define CHORD_MAX_TEX_LEVELS 15u
+struct DMaterial {             // 48 + 15 x 24 B
     uint32_t texOffset;        // first alpha byte of level 0 in dTexAlpha; 0xFFFFFFFF: white fallback (alpha 1)
     uint32_t texWidth, texHeight, texMips;
     uint32_t minFilter, magFilter, wrapS, wrapT;
     float    alphaFactor;      // baseColorFactor.w
     float    alphaCutOff;
     uint32_t pad[2];
+    DMatLevel levels[CHORD_MAX_TEX_LEVELS];
 };
 // extension of a masked triangle's 48-byte record, in the TWO slots behind it.  Everything a row unit of the tile kernel needs to
 // sample the triangle's alpha is in here -- the chosen level's first byte and size, the wraps, the material's factor and cut-off --
 // so a unit's set-up is one round trip (this record), not three dependent ones (extension -> material -> level offsets).
-struct __attribute__((aligned(16))) TriRecMaskExt {         // 96 B, 60 used
+struct __attribute__((aligned(16))) TriRecMaskExt {         // 96 B, 76 used
     float    uw[3], vw[3], iw[3];   // u / w, v / w, 1 / w per vertex
     uint32_t levelFilter;      // level | linear << 8
     uint32_t levelBase;        // first alpha byte of that level in dTexAlpha; 0xFFFFFFFF: white fallback (alpha 1)
     uint32_t dims;             // (width - 1) | (height - 1) << 16 of that level
     uint32_t wraps;            // wrapS | wrapT << 16 (CHORD_WRAP_*: 16-bit values)
     float    alphaFactor, alphaCutOff;
-    uint32_t pad[9];
+    uint32_t magicS, biasS, magicT, biasT;   // DMatLevel's, for the remainders of non-power-of-two sizes
+    uint32_t pad[5];
 };
 #define CHORD_MASK_EXT_SLOTS 2u    // record slots an extension takes (a masked triangle: 1 + CHORD_MASK_EXT_SLOTS)
 

@@ -504,52 +504,65 @@ __device__ __forceinline__ uint32_t mask_level_filter(const DMaterial& m, int64_
     return level | (linear ? 256u : 0u);
 }
 
-__device__ __forceinline__ void write_mask_ext(TriRec* slot, const DMaterial& m, uint32_t material, int64_t absArea2,
+__device__ __forceinline__ void write_mask_ext(TriRec* slot, const DMaterial* mp, uint32_t material, int64_t absArea2,
                                                const float u[3], const float v[3], const float w[3])
 {
+    // (the header fields by value; the one level the triangle samples is read where it is known)
+    DMaterial m;
+    m.texOffset = mp->texOffset; m.texWidth = mp->texWidth; m.texHeight = mp->texHeight; m.texMips = mp->texMips;
+    m.minFilter = mp->minFilter; m.magFilter = mp->magFilter; m.wrapS = mp->wrapS; m.wrapT = mp->wrapT;
+    m.alphaFactor = mp->alphaFactor; m.alphaCutOff = mp->alphaCutOff;
     TriRecMaskExt e;
 #pragma unroll
     for (int i = 0; i < 3; i++) { e.iw[i] = 1.0f / w[i]; e.uw[i] = u[i] * e.iw[i]; e.vw[i] = v[i] * e.iw[i]; }
     e.levelFilter = mask_level_filter(m, absArea2, u, v);
     (void)material;
     const uint32_t level = e.levelFilter & 0xFFu;
-    e.levelBase = 0xFFFFFFFFu; e.dims = 0u;
+    e.levelBase = 0xFFFFFFFFu; e.dims = 0u; e.magicS = e.biasS = e.magicT = e.biasT = 0u;
     if (m.texOffset != 0xFFFFFFFFu) {
-        uint32_t off = m.texOffset;
-        for (uint32_t l = 0; l < level; l++) off += max(1u, m.texWidth >> l) * max(1u, m.texHeight >> l);
-        e.levelBase = off;
-        e.dims = (max(1u, m.texWidth >> level) - 1u) | (max(1u, m.texHeight >> level) - 1u) << 16;
+        const DMatLevel L = mp->levels[level];                  // (resolved at upload: no loop over the levels, no division here)
+        e.levelBase = L.base; e.dims = L.dims;
+        e.magicS = L.magicS; e.biasS = L.biasS; e.magicT = L.magicT; e.biasT = L.biasT;
     }
     e.wraps = (m.wrapS & 0xFFFFu) | m.wrapT << 16;
     e.alphaFactor = m.alphaFactor; e.alphaCutOff = m.alphaCutOff;
-    // (the 60 bytes in use: three 16-byte stores and three dwords; the rest of the second slot is never read)
+    // (the 76 bytes in use: four 16-byte stores and three dwords; the rest of the second slot is never read)
     uint4* dst = reinterpret_cast<uint4*>(slot);
     const uint4* src = reinterpret_cast<const uint4*>(&e);
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
-    reinterpret_cast<uint32_t*>(slot)[12] = e.wraps;
-    reinterpret_cast<float*>(slot)[13] = e.alphaFactor; reinterpret_cast<float*>(slot)[14] = e.alphaCutOff;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    reinterpret_cast<uint32_t*>(slot)[16] = e.biasS; reinterpret_cast<uint32_t*>(slot)[17] = e.magicT; reinterpret_cast<uint32_t*>(slot)[18] = e.biasT;
 }
 
+#ifndef EXP_MASKED
+#define EXP_MASKED 0            // measurement builds only (results differ): 1 no fetch, 2 nearest everywhere, 4 sizes treated as powers of two, 8 unguarded shared-reciprocal divisions
+#endif
 // Texel indices are 32-bit here: texel_floor maps everything beyond +-1e9 to 0, so an index and its +1 neighbour fit an int32
 // (the oracle's 64-bit arithmetic gives the same values); a 64-bit modulo is ~200 instructions on this GPU and the bilinear
-// fetch of round 2 did eight of them per covered pixel.  Power-of-two sizes (every level of a power-of-two texture) wrap with
-// a mask: i & (n - 1) is the non-negative remainder in two's complement.
-__device__ __forceinline__ int32_t wrap_index(int32_t i, int32_t n, uint32_t mode)
+// fetch of round 2 did eight of them per covered pixel.  Power-of-two periods (every level of a power-of-two texture) wrap with
+// a mask: i & (n - 1) is the non-negative remainder in two's complement.  Any other period divides by a constant of the level
+// (DMatLevel: magic = floor(2^32 / period), bias = a multiple of the period >= 2^30): iu = i + bias is in [0, 2^31) and has
+// i's remainder; floor(iu * magic / 2^32) is floor(iu / period) or one less (iu * (2^32 / period - magic) / 2^32 < 1/2), so one
+// multiply-high, one multiply and one conditional subtraction replace the ~50 issue slots of a 32-bit signed remainder.
+__device__ __forceinline__ int32_t period_mod(int32_t i, int32_t period, uint32_t magic, uint32_t bias)
+{
+    if ((EXP_MASKED & 4) || magic == 0u) return i & (period - 1);
+    const uint32_t iu = (uint32_t)i + bias;
+    uint32_t r = iu - __umulhi(iu, magic) * (uint32_t)period;
+    if (r >= (uint32_t)period) r -= (uint32_t)period;
+    return (int32_t)r;
+}
+__device__ __forceinline__ int32_t wrap_index(int32_t i, int32_t n, uint32_t mode, uint32_t magic, uint32_t bias)
 {
     if (mode == CHORD_WRAP_CLAMP_TO_EDGE) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
-    const bool pot = (n & (n - 1)) == 0;
     if (mode == CHORD_WRAP_MIRRORED_REPEAT) {
-        int32_t m = pot ? (i & (2 * n - 1)) : i % (2 * n);
-        if (m < 0) m += 2 * n;
+        const int32_t m = period_mod(i, 2 * n, magic, bias);
         return m < n ? m : 2 * n - 1 - m;
     }
-    int32_t m = pot ? (i & (n - 1)) : i % n;
-    if (m < 0) m += n;
-    return m;
+    return period_mod(i, n, magic, bias);
 }
 
 // wrap_index(i) and wrap_index(i + 1) with ONE remainder: the neighbour's follows from the remainder's successor
-__device__ __forceinline__ void wrap_pair(int32_t i, int32_t n, uint32_t mode, int32_t& w0, int32_t& w1)
+__device__ __forceinline__ void wrap_pair(int32_t i, int32_t n, uint32_t mode, uint32_t magic, uint32_t bias, int32_t& w0, int32_t& w1)
 {
     if (mode == CHORD_WRAP_CLAMP_TO_EDGE) {
         w0 = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
@@ -558,9 +571,7 @@ __device__ __forceinline__ void wrap_pair(int32_t i, int32_t n, uint32_t mode, i
     }
     const bool mirror = mode == CHORD_WRAP_MIRRORED_REPEAT;
     const int32_t period = mirror ? 2 * n : n;
-    const bool pot = (period & (period - 1)) == 0;
-    int32_t m = pot ? (i & (period - 1)) : i % period;
-    if (m < 0) m += period;
+    const int32_t m = period_mod(i, period, magic, bias);
     const int32_t m1 = m + 1 == period ? 0 : m + 1;                          // (i + 1) mod period
     w0 = mirror ? (m < n ? m : 2 * n - 1 - m) : m;
     w1 = mirror ? (m1 < n ? m1 : 2 * n - 1 - m1) : m1;
@@ -578,12 +589,15 @@ struct AlphaLevel {
     int32_t W, H;
     float fW, fH;
     uint32_t wrapS, wrapT;
+    uint32_t magicS, biasS, magicT, biasT;
     bool linear;
 };
-__device__ __forceinline__ AlphaLevel alpha_level(const uint8_t* __restrict__ texAlpha, uint32_t levelBase, uint32_t dims, uint32_t wraps, bool linear)
+__device__ __forceinline__ AlphaLevel alpha_level(const uint8_t* __restrict__ texAlpha, const TriRecMaskExt& e)
 {
+    const uint32_t levelBase = e.levelBase, dims = e.dims;
     AlphaLevel a;
-    a.base = nullptr; a.W = 1; a.H = 1; a.fW = 1.0f; a.fH = 1.0f; a.wrapS = wraps & 0xFFFFu; a.wrapT = wraps >> 16; a.linear = linear;
+    a.base = nullptr; a.W = 1; a.H = 1; a.fW = 1.0f; a.fH = 1.0f; a.wrapS = e.wraps & 0xFFFFu; a.wrapT = e.wraps >> 16; a.linear = (e.levelFilter & 256u) != 0u;
+    a.magicS = e.magicS; a.biasS = e.biasS; a.magicT = e.magicT; a.biasT = e.biasT;
     if (levelBase == 0xFFFFFFFFu) return a;
     a.W = (int32_t)(dims & 0xFFFFu) + 1; a.H = (int32_t)(dims >> 16) + 1;
     a.fW = (float)a.W; a.fH = (float)a.H;
@@ -593,8 +607,9 @@ __device__ __forceinline__ AlphaLevel alpha_level(const uint8_t* __restrict__ te
 __device__ __forceinline__ float sample_alpha(const AlphaLevel& t, float u, float v)
 {
     if (!t.base) return 1.0f;
-    if (!t.linear) {
-        const int32_t ix = wrap_index(texel_floor(u * t.fW), t.W, t.wrapS), iy = wrap_index(texel_floor(v * t.fH), t.H, t.wrapT);
+    if (EXP_MASKED & 1) return 1.0f;
+    if (!t.linear || (EXP_MASKED & 2)) {
+        const int32_t ix = wrap_index(texel_floor(u * t.fW), t.W, t.wrapS, t.magicS, t.biasS), iy = wrap_index(texel_floor(v * t.fH), t.H, t.wrapT, t.magicT, t.biasT);
         return (float)t.base[iy * t.W + ix] * (1.0f / 255.0f);
     }
     const float x = u * t.fW - 0.5f, y = v * t.fH - 0.5f;
@@ -603,8 +618,8 @@ __device__ __forceinline__ float sample_alpha(const AlphaLevel& t, float u, floa
     if (!(fabsf(x) < 1.0e9f)) fx = 0.0f;
     if (!(fabsf(y) < 1.0e9f)) fy = 0.0f;
     int32_t ix0, ix1, iy0, iy1;
-    wrap_pair(x0, t.W, t.wrapS, ix0, ix1);
-    wrap_pair(y0, t.H, t.wrapT, iy0, iy1);
+    wrap_pair(x0, t.W, t.wrapS, t.magicS, t.biasS, ix0, ix1);
+    wrap_pair(y0, t.H, t.wrapT, t.magicT, t.biasT, iy0, iy1);
     const float a00 = (float)t.base[iy0 * t.W + ix0] * (1.0f / 255.0f), a10 = (float)t.base[iy0 * t.W + ix1] * (1.0f / 255.0f);
     const float a01 = (float)t.base[iy1 * t.W + ix0] * (1.0f / 255.0f), a11 = (float)t.base[iy1 * t.W + ix1] * (1.0f / 255.0f);
     const float top = a00 + (a10 - a00) * fx, bot = a01 + (a11 - a01) * fx;
@@ -627,7 +642,7 @@ __device__ __forceinline__ void setup_emit_mask_ext(const RasterParams& p, TriRe
         }
         w[i] = lW[li];
     }
-    write_mask_ext(slot, p.materials[material], material, absArea2, u, v, w);
+    write_mask_ext(slot, &p.materials[material], material, absArea2, u, v, w);
 }
 
 template <int PITCH>
@@ -1552,7 +1567,7 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
                 const uint32_t material = CHORD_MATFLAG_MATERIAL(matFlags);
                 const float u3[3] = {L.U(cur, 0), L.U(cur, i), L.U(cur, i + 1)}, v3[3] = {L.V(cur, 0), L.V(cur, i), L.V(cur, i + 1)};
                 const float w3[3] = {L.P(cur, 0).w, L.P(cur, i).w, L.P(cur, i + 1).w};
-                write_mask_ext(&p.tris[gi + 1u], p.materials[material], material, ts.area, u3, v3, w3);
+                write_mask_ext(&p.tris[gi + 1u], &p.materials[material], material, ts.area, u3, v3, w3);
             }
             // clipped pieces are rare: binned right here, one (scattered) atomic per tile they may touch
             bin_record_tiles(p, ts, gi | CHORD_REC_WIDE);                // clipped pieces take the 48-byte form
@@ -2067,7 +2082,7 @@ __device__ __forceinline__ void masked_rows(const RasterParams& p, unsigned long
     // (60 bytes of the extension, one round trip: nothing here depends on another fetch)
     const TriRecMaskExt ext = *reinterpret_cast<const TriRecMaskExt*>(&p.tris[recIndex + 1u]);
     struct { float alphaFactor, alphaCutOff; } m = {ext.alphaFactor, ext.alphaCutOff};
-    const AlphaLevel tex = alpha_level(p.texAlpha, ext.levelBase, ext.dims, ext.wraps, (ext.levelFilter & 256u) != 0u);
+    const AlphaLevel tex = alpha_level(p.texAlpha, ext);
     const E_t sgn = (u.skind & 1) ? (E_t)-1 : (E_t)1;
     const E_t dx0 = (E_t)(u.X[2] - u.X[1]), dy0 = (E_t)(u.Y[2] - u.Y[1]);
     const E_t dx1 = (E_t)(u.X[0] - u.X[2]), dy1 = (E_t)(u.Y[0] - u.Y[2]);
@@ -2108,8 +2123,14 @@ __device__ __forceinline__ void masked_rows(const RasterParams& p, unsigned long
         const float l2 = std::is_same<E_t, int32_t>::value ? (float)(e2 - bias2) * u.invA : (float)(double)(e2 - bias2) * u.invA;
         const float l0 = (1.0f - l1) - l2;
         const float den = (l0 * ext.iw[0] + l1 * ext.iw[1]) + l2 * ext.iw[2];
-        const float tu = ((l0 * ext.uw[0] + l1 * ext.uw[1]) + l2 * ext.uw[2]) / den;
-        const float tv = ((l0 * ext.vw[0] + l1 * ext.vw[1]) + l2 * ext.vw[2]) / den;
+        float tu = (l0 * ext.uw[0] + l1 * ext.uw[1]) + l2 * ext.uw[2];
+        float tv = (l0 * ext.vw[0] + l1 * ext.vw[1]) + l2 * ext.vw[2];
+        if (EXP_MASKED & 8) {
+            float r = __builtin_amdgcn_rcpf(den);
+            r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
+            float q = tu * r; q = __builtin_fmaf(__builtin_fmaf(-den, q, tu), r, q); tu = __builtin_fmaf(__builtin_fmaf(-den, q, tu), r, q);
+            q = tv * r; q = __builtin_fmaf(__builtin_fmaf(-den, q, tv), r, q); tv = __builtin_fmaf(__builtin_fmaf(-den, q, tv), r, q);
+        } else { tu = tu / den; tv = tv / den; }
         const float alpha = sample_alpha(tex, tu, tv);
         const bool keep = inside && !(alpha * m.alphaFactor - m.alphaCutOff < 0.0f) && !noPixels;      // clip()
         float z = (u.d0 + l1 * u.e1) + l2 * u.e2;
