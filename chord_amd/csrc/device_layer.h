@@ -238,6 +238,7 @@ struct DeviceCounters {
 #define CHORD_TILECOUNT_STRIDE 4u                // four bin counters per 64-byte line
 #define CHORD_BIN_CAP 8192u
 #endif
+static_assert(CHORD_BIN_CAP <= (1u << 20), "tile x bin capacity is formed with a 24-bit multiply in 32 bits (bin_put)");
 struct FrameState {
     DeviceCounters counters;
     uint32_t listCounts[8];        // [0..3] command lists of the frame, [4] this rank's share of list 0 (sharded: written by the group cull), [5] this rank's clusters of a foreign list (stripe filter), [6 + pass] clusters a dense launch's block kernel left over

@@ -213,10 +213,13 @@ __device__ __forceinline__ bool tri_setup(TriSetup& ts, bool twoSided, int32_t W
     const int32_t dx1 = ts.X[1] - ts.X[0], dy1 = ts.Y[1] - ts.Y[0], dx2 = ts.X[2] - ts.X[0], dy2 = ts.Y[2] - ts.Y[0];
     int64_t area2;
     // deltas below 2^15 (vertices within 128 px of vertex 0 -- nearly every triangle): both products fit 2^30 and their
-    // difference an int32, from full-rate 24-bit multiplies; v_mul_lo/hi_u32 of the general form are quarter rate
+    // difference an int32, from full-rate 24-bit multiplies; v_mul_lo/hi_u32 of the general form are quarter rate.  The choice is
+    // made per WAVE (a scalar branch): as a per-lane select the compiler evaluates both forms for every triangle -- four
+    // quarter-rate multiplies here and the int64 -> double -> float conversion below, the price of ~30 plain instructions.
     const bool small = (uint32_t)(dx1 + 32767) < 65535u && (uint32_t)(dy1 + 32767) < 65535u &&
                        (uint32_t)(dx2 + 32767) < 65535u && (uint32_t)(dy2 + 32767) < 65535u;
-    if (small) area2 = (int64_t)(__mul24(dx1, dy2) - __mul24(dx2, dy1));
+    const bool allSmall = __ballot(!small) == 0ull;
+    if (allSmall) area2 = (int64_t)(__mul24(dx1, dy2) - __mul24(dx2, dy1));
     else area2 = (int64_t)dx1 * (int64_t)dy2 - (int64_t)dx2 * (int64_t)dy1;
     if (area2 == 0) return false;
     if (!twoSided && area2 > 0) return false;            // VK_CULL_MODE_BACK_BIT (mesh_raster.cpp:235)
@@ -229,8 +232,9 @@ __device__ __forceinline__ bool tri_setup(TriSetup& ts, bool twoSided, int32_t W
     ts.px1 = min(Wi - 1, (maxX - 128) >> 8);
     ts.py1 = min(Hi - 1, (maxY - 128) >> 8);
     if (ts.px1 < ts.px0 || ts.py1 < ts.py0) return false;
-    // (float)(double)area: one rounding of an exact value either way -- an int32 conversion when the area fits
-    ts.invA = 1.0f / (small ? (float)(int32_t)ts.area : (float)(double)ts.area);
+    // (float)(double)area: one rounding of an exact value either way -- an int32 conversion when the area fits (|2A| < 2^31)
+    if (allSmall) ts.invA = 1.0f / (float)(int32_t)ts.area;
+    else ts.invA = 1.0f / (float)(double)ts.area;
     return true;
 }
 
@@ -354,7 +358,7 @@ __device__ __forceinline__ void bin_alloc(const P& p, uint32_t tile, uint32_t sl
     if (j >= p.binMaxChunks || (o & (CHORD_BIN_CHUNK - 1u)) != 0u) return;
     uint32_t id = atomicAdd(p.binPoolCount, 1u);
     if (id >= p.binPoolChunks) { id = CHORD_BIN_CHUNK_INVALID; atomicOr(&p.counters->overflow, 1u); }
-    __hip_atomic_store(p.binChunkTab + (size_t)tile * p.binMaxChunks + j, ((unsigned long long)p.binStamp << 32) | id,
+    __hip_atomic_store(p.binChunkTab + (__umul24(tile, p.binMaxChunks) + j), ((unsigned long long)p.binStamp << 32) | id,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -365,10 +369,11 @@ __device__ __forceinline__ void bin_alloc(const P& p, uint32_t tile, uint32_t sl
 template <class P>
 __device__ __forceinline__ void bin_put(const P& p, uint32_t tile, uint32_t slot, uint32_t gi)
 {
-    if (slot < p.binCap) { p.tileBins[(size_t)tile * p.binCap + slot] = gi; return; }
+    // (tile < 4096 and the fixed part of a bin at most 2^20 entries: the index is a full-rate 24-bit multiply and fits 32 bits)
+    if (slot < p.binCap) { p.tileBins[__umul24(tile, p.binCap) + slot] = gi; return; }
     const uint32_t o = slot - p.binCap, j = o >> CHORD_BIN_CHUNK_SHIFT;
     if (j >= p.binMaxChunks) { atomicOr(&p.counters->overflow, 1u); return; }
-    const unsigned long long* ent = p.binChunkTab + (size_t)tile * p.binMaxChunks + j;
+    const unsigned long long* ent = p.binChunkTab + (__umul24(tile, p.binMaxChunks) + j);
     const unsigned long long stamp = (unsigned long long)p.binStamp << 32;
     unsigned long long e = 0;
     uint32_t spins = 0;
@@ -379,7 +384,7 @@ __device__ __forceinline__ void bin_put(const P& p, uint32_t tile, uint32_t slot
         __builtin_amdgcn_s_sleep(4);
     }
     const uint32_t id = (uint32_t)e;
-    if (id != CHORD_BIN_CHUNK_INVALID) p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))] = gi;
+    if (id != CHORD_BIN_CHUNK_INVALID) p.binPool[((size_t)id << CHORD_BIN_CHUNK_SHIFT) + (o & (CHORD_BIN_CHUNK - 1u))] = gi;
 }
 
 // one slot drawn, written at once (the looped binners: a slot is drawn, allocated for and stored within one iteration)
@@ -412,7 +417,7 @@ __device__ __forceinline__ void wave_bin_issue(const P& p, bool emitA, const Tri
         const int32_t tx = (r & 1) ? tx1 : tx0, ty = (r & 2) ? ty1 : ty0;
         bool has = emit && !((r & 1) && tx1 == tx0) && !((r & 2) && ty1 == ty0);
         if (has) has = owns_tile(p.shard, tx, ty);
-        tile = has ? (uint32_t)ty * p.tilesX + (uint32_t)tx : 0u;
+        tile = has ? __umul24((uint32_t)ty, p.tilesX) + (uint32_t)tx : 0u;
         return has;
     };
     k.has = 0u;
