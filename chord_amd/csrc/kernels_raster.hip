@@ -1371,7 +1371,7 @@ __device__ __forceinline__ bool launch_is_dense(const RasterParams& p, uint32_t 
 }
 
 #ifndef SETUP_MIN_WAVES
-#define SETUP_MIN_WAVES 4       // waves per SIMD the register allocation of the record kernel aims at
+#define SETUP_MIN_WAVES 5       // waves per SIMD the register allocation of the record kernel aims at (94 VGPRs since the area form is chosen per wave; 4 -> 5: config 4 0.420 -> 0.411 ms)
 #endif
 #ifndef BLOCKS_MIN_WAVES
 #define BLOCKS_MIN_WAVES 6      // ... of the block kernel (80 VGPRs, 20 KB of LDS per 256 threads, 106 SGPRs: 6 workgroups per CU)
