@@ -123,6 +123,7 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         c->hBinHint = static_cast<volatile uint32_t*>(h); c->dBinHint = static_cast<uint32_t*>(dh);
     }
     c->hBinHint[0] = 0u; c->hBinHint[1] = 0u;
+    c->hBinHint[2] = 0xFFFFFFFFu; c->hBinHint[3] = 0xFFFFFFFFu;      // clusters per pass of the last finished frame: none yet
     {   // one {min, max} partial per block of the mip-0 kernel (64 x 4 texels per block)
         const uint32_t vw = (c->width + 1) / 2, vh = (c->height + 1) / 2;
         if ((rc = dalloc(c, &c->dRangePartials, (size_t)((vw + 63) / 64) * ((vh + 3) / 4) * 2))) return rc;

@@ -95,6 +95,7 @@ struct RasterParams {
     float biasConst, biasSlope;                         // vkCmdSetDepthBias(const, 0, slope), applied to the vertex depths of a depth-pass triangle
     uint32_t clearTiles;                                // first raster pass of a frame: tiles start from 0
     uint32_t* binHint;                                  // host-visible word: the longest bin of this pass (tile order kernel -> launch_raster of later frames), or NULL
+    uint32_t* countHint;                                // host-visible word: the number of clusters this pass set up, or NULL
     uint32_t slotHot;                                   // bin length from which a tile counts as hot (SLOT_HOT; tests lower it)
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
@@ -1699,6 +1700,7 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
         for (int b = 0; b < 18; b++) { base[b] = acc; acc += hist[b]; }
         p.tileOrder[0] = make_uint2(p.clearTiles ? acc : acc - hist[17], 0u);
         if (p.binHint) *p.binHint = longest;                      // (bins short enough to stay whole report 0)
+        if (p.countHint) *p.countHint = *p.count;
     }
     __syncthreads();
 #pragma unroll
@@ -2867,8 +2869,19 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     const uint64_t rankPixels = (uint64_t)c->width * c->height / (c->shard.ranks > 1 ? c->shard.ranks : 1u);
     const bool maybeDense = p.blockCap != 0u && (p.blockForce != 0u || (uint64_t)in.capacity * 16ull >= rankPixels);
     p.leftCount = nullptr; p.leftCmds = nullptr;
-    p.binHint = nullptr;
-    if (maybeDense) {
+    p.binHint = nullptr; p.countHint = nullptr;
+    // ... and whether it IS dense the device decides from the list's length (launch_is_dense).  A list that could be dense but was
+    // nowhere near it in the last frame the GPU finished (BASELINE config 4: one cluster per 60 pixels, capacity for one per 30)
+    // gets no block kernel at all -- the launch would find nothing to do and cost its 4.5 us, twice per frame.  Half the device's
+    // threshold, so a list at the threshold keeps its block kernel whichever way the last frame fell; the record kernel then
+    // sets up the input list itself (no leftover list: launch_is_dense is false without one), and either way renders the same image.
+    bool blocksWorthLaunching = maybeDense;
+    if (maybeDense && c->dBinHint) {
+        p.countHint = c->dBinHint + 2 + pass;
+        const uint32_t last = c->hBinHint[2 + pass];              // (0xFFFFFFFF: no frame yet)
+        if (p.blockForce == 0u && last != 0xFFFFFFFFu && (uint64_t)last * 32ull < rankPixels) blocksWorthLaunching = false;
+    }
+    if (blocksWorthLaunching) {
         if (c->dBinHint) p.binHint = c->dBinHint + pass;          // (host-visible word per pass, allocated with the G-buffer)
         if (!c->dLeftCmds) LR_HIP(hipMalloc((void**)&c->dLeftCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity));
         p.leftCount = c->dCounts + 6 + pass; p.leftCmds = c->dLeftCmds;
@@ -2883,7 +2896,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     if (blocks < 1) blocks = 1;
     const bool sh = c->shard.ranks > 1;
     stamp(c, S_HZBCULL);      // closes whatever preceded the raster (HZB cull / list reset)
-    if (maybeDense) {
+    if (blocksWorthLaunching) {
         const uint32_t bb = std::max(1u, std::min((in.capacity + 3u) / 4u, (uint32_t)c->numCUs * BLOCKS_MIN_WAVES));
         // the longest bin of this pass in the last frame the GPU finished: a hot tile then -> the variant that draws ahead now
         const bool hot = (c->hBinHint && c->hBinHint[pass] >= SLOT_HOT) || (c->debugFlags & DBG_FORCE_HOT);
