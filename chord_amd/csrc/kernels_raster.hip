@@ -266,7 +266,7 @@ __device__ __forceinline__ void tri_setup_from_compact(TriSetup& ts, const TriRe
     // the same integers tri_setup reduced: |deltas| <= 2^14, so the 32-bit product is exact
     const int32_t area2 = (int32_t)r.dX1 * (int32_t)r.dY2 - (int32_t)r.dX2 * (int32_t)r.dY1;
     ts.s = area2 < 0 ? -1 : 1;
-    ts.invA = 1.0f / (float)(double)(area2 < 0 ? -(int64_t)area2 : (int64_t)area2);
+    ts.invA = 1.0f / (float)(area2 < 0 ? -area2 : area2);           // (|2A| <= 2^29: the int32 conversion is the canonical (float)(double)|2A|)
     ts.d0 = r.d[0]; ts.e1 = r.d[1] - r.d[0]; ts.e2 = r.d[2] - r.d[0];
     const int32_t minX = min(ts.X[0], min(ts.X[1], ts.X[2])), maxX = max(ts.X[0], max(ts.X[1], ts.X[2]));
     const int32_t minY = min(ts.Y[0], min(ts.Y[1], ts.Y[2])), maxY = max(ts.Y[0], max(ts.Y[1], ts.Y[2]));

@@ -171,3 +171,26 @@ def test_masked_frame_properties():
     slots = ((base["vis"] >> np.uint64(8)) & np.uint64(0xFFFFFF)).astype(np.int64) - 1
     drawn_objs = np.unique(cmds["objectId"][slots[slots >= 0]])
     assert not np.isin(drawn_objs, blend_objs).any()
+
+
+def test_wrap_remainder_by_multiply_high_is_exact():
+    """The tile kernel wraps a texel index of a non-power-of-two level with constants resolved at upload (chordvis_abi.cpp
+    wrap_consts; kernels_raster.hip period_mod): magic = floor(2^32 / period), bias = the first multiple of the period >= 2^30;
+    r = (i + bias) - mulhi(i + bias, magic) * period, minus the period once if r >= period.  Restated here in numpy over every
+    period a level can have (sizes 1..16384, doubled for MIRRORED_REPEAT) at the index range texel_floor produces (|i| <= 1e9,
+    and the +1 neighbour of the bilinear fetch), against the mathematical remainder."""
+    rng = np.random.default_rng(11)
+    periods = np.unique(np.concatenate([np.arange(3, 300), rng.integers(3, 32769, size=4000), [32767, 32766, 24576, 16383, 12289, 3 * 5461]]))
+    periods = periods[(periods & (periods - 1)) != 0].astype(np.uint64)                 # powers of two wrap with a mask
+    edge = np.array([-1000000001, -1000000000, -999999999, -32769, -3, -2, -1, 0, 1, 2, 3, 32767, 999999999, 1000000000, 1000000001], dtype=np.int64)
+    for period in periods:
+        magic = np.uint64(0x100000000) // period
+        bias = ((np.uint64(0x40000000) + period - np.uint64(1)) // period) * period
+        assert magic < 2**32 and bias < 2**31 and bias % period == 0
+        i = np.concatenate([edge, rng.integers(-1000000001, 1000000002, size=256), np.arange(-int(period) - 2, 2 * int(period) + 3)]).astype(np.int64)
+        iu = (i + np.int64(bias)).astype(np.uint64)
+        assert (iu < 2**31).all()
+        q = (iu * magic) >> np.uint64(32)                                                 # v_mul_hi_u32
+        r = (iu - q * period) & np.uint64(0xFFFFFFFF)                                     # 32-bit wrap-around arithmetic
+        r = np.where(r >= period, r - period, r)
+        assert np.array_equal(r.astype(np.int64), np.mod(i, np.int64(period))), int(period)
