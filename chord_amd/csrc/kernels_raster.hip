@@ -2442,35 +2442,53 @@ __device__ __forceinline__ void merge_blocks(unsigned long long* tile, const uns
     // four blocks per step, a 16-byte granule per lane and block: granule g holds the block's words 2g - 1 and 2g (word -1 is
     // the header), so the first 127 words of each of the four are in flight together (a block of sub-pixel geometry has
     // 64..121) -- ~4 KB of loads outstanding per wave instead of one block's worth per memory round trip, in 16-byte
-    // requests (8-byte loads run at 0.54-0.70x their rate, MI355X_MICROARCH.md)
-    while (todo) {
-        uint32_t h[4], r[4], n[4];
-        const ulonglong2* src[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const bool any = todo != 0ull;
-            const int l = any ? __ffsll((long long)todo) - 1 : 0;
-            todo &= todo - 1ull;                                    // (0 stays 0)
-            h[j] = bcast(hdrLo, l); r[j] = bcast(hdrHi, l);
-            src[j] = reinterpret_cast<const ulonglong2*>(pool + (size_t)(bcast(name, l) & CHORD_REC_INDEX_MASK) * 2u);
-            n[j] = any ? (((h[j] >> 12) & 15u) + 1u) * (((h[j] >> 16) & 15u) + 1u) : 0u;
-        }
-        ulonglong2 a[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) a[j] = 2u * lane <= n[j] && n[j] != 0u ? src[j][lane] : make_ulonglong2(0ull, 0ull);   // granule g exists iff 2g - 1 < n
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (lane != 0u) merge_block_word(tile, a[j].x, 2u * lane - 1u, h[j], r[j]);
-            if (2u * lane < n[j]) merge_block_word(tile, a[j].y, 2u * lane, h[j], r[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            for (uint32_t g = lane + 64u; 2u * g <= n[j]; g += 64u) {
-                const ulonglong2 v = src[j][g];
-                merge_block_word(tile, v.x, 2u * g - 1u, h[j], r[j]);
-                if (2u * g < n[j]) merge_block_word(tile, v.y, 2u * g, h[j], r[j]);
-            }
+    // requests (8-byte loads run at 0.54-0.70x their rate, MI355X_MICROARCH.md).  Two groups of four alternate (A, B): the
+    // loads of the next group are issued before the current one is merged, so a step's memory round trip hides behind the
+    // previous step's LDS merges instead of following them -- what a workgroup that is alone on its CU needs (a rank of an
+    // 8-rank frame owns 255 tiles: one workgroup per CU, nothing else to switch to).
+#define MB_PICK(H, R, N, SRC)                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                                       \
+        const bool any = todo != 0ull;                                                                                    \
+        const int l = any ? __ffsll((long long)todo) - 1 : 0;                                                             \
+        todo &= todo - 1ull;                                    /* (0 stays 0) */                                         \
+        H[j] = bcast(hdrLo, l); R[j] = bcast(hdrHi, l);                                                                   \
+        SRC[j] = reinterpret_cast<const ulonglong2*>(pool + (size_t)(bcast(name, l) & CHORD_REC_INDEX_MASK) * 2u);        \
+        N[j] = any ? (((H[j] >> 12) & 15u) + 1u) * (((H[j] >> 16) & 15u) + 1u) : 0u;                                      \
     }
+    // granule g exists iff 2g - 1 < n
+#define MB_LOAD(A, N, SRC)                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) A[j] = 2u * lane <= N[j] && N[j] != 0u ? SRC[j][lane] : make_ulonglong2(0ull, 0ull);
+#define MB_MERGE(A, H, R, N, SRC)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                                       \
+        if (lane != 0u) merge_block_word(tile, A[j].x, 2u * lane - 1u, H[j], R[j]);                                       \
+        if (2u * lane < N[j]) merge_block_word(tile, A[j].y, 2u * lane, H[j], R[j]);                                      \
+    }                                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; j++)                                                                         \
+        for (uint32_t g = lane + 64u; 2u * g <= N[j]; g += 64u) {                                                         \
+            const ulonglong2 v = SRC[j][g];                                                                               \
+            merge_block_word(tile, v.x, 2u * g - 1u, H[j], R[j]);                                                         \
+            if (2u * g < N[j]) merge_block_word(tile, v.y, 2u * g, H[j], R[j]);                                           \
+        }
+    if (!todo) return;
+    uint32_t hA[4], rA[4], nA[4], hB[4], rB[4], nB[4];
+    const ulonglong2* srcA[4];
+    const ulonglong2* srcB[4];
+    ulonglong2 aA[4], aB[4];
+    MB_PICK(hA, rA, nA, srcA)
+    MB_LOAD(aA, nA, srcA)
+    for (;;) {
+        const bool moreB = todo != 0ull;
+        if (moreB) { MB_PICK(hB, rB, nB, srcB) MB_LOAD(aB, nB, srcB) }
+        MB_MERGE(aA, hA, rA, nA, srcA)
+        if (!moreB) break;
+        const bool moreA = todo != 0ull;
+        if (moreA) { MB_PICK(hA, rA, nA, srcA) MB_LOAD(aA, nA, srcA) }
+        MB_MERGE(aB, hB, rB, nB, srcB)
+        if (!moreA) break;
+    }
+#undef MB_PICK
+#undef MB_LOAD
+#undef MB_MERGE
 }
 
 template <bool SH, bool MASKED, bool DEPTH>
