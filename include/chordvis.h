@@ -198,7 +198,10 @@ int chordvis_destroy(ChordCtx* ctx);
 const char* chordvis_last_error(ChordCtx* ctx);
 int chordvis_sync(ChordCtx* ctx);
 
-/* GPUScene / asset upload (gpu_scene.h:20-165, asset_gltf.h:278): copies and flattens. */
+/* GPUScene / asset upload (gpu_scene.h:20-165, asset_gltf.h:278): copies and flattens.  Limits of a scene (CHORDVIS_E_INVALID
+ * beyond them): 0x55555555 vertices over all assets (vertex index x 3 is formed in 32 bits; the reference's ByteAddressBuffer
+ * offsets are 32-bit BYTE offsets, a third of that), meshlets of at most 255 vertices / 128 triangles, groups of at most four
+ * meshlets, alpha-tested textures of at most 16384 x 16384 texels and 15 levels. */
 int chordvis_upload_scene(ChordCtx* ctx, const ChordSceneDesc* scene);
 /* uploadBufferToGPU("GLTFObjectInfo", ...) renderer.cpp:229 — per-frame object records
  * (count must equal the uploaded scene's objectCount; primitive/material ids must not change). */
