@@ -708,25 +708,27 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
         bool twoSided;
         Mat4 mvp;
     };
-    auto load_header = [&](const ChordDrawCmd& cmd) -> Header {
+    // (scalar loads through the constant address space: the addresses are wave-uniform, and a vector load + v_readfirstlane per
+    // dword was 26 VALU instructions per header -- the record kernel is bound by VALU issue on dense scenes like the block kernel)
+    auto load_header = [&](uint32_t i) -> Header {
+        const uint32_t k = __builtin_amdgcn_readfirstlane(min(i, count - 1u));
         Header h;
-        h.objectId = __builtin_amdgcn_readfirstlane(cmd.objectId);
-        h.meshletId = __builtin_amdgcn_readfirstlane(cmd.meshletId);
-        h.slot = __builtin_amdgcn_readfirstlane(cmd.slot);
+        const uint32_t* __restrict__ cw = reinterpret_cast<const uint32_t*>(cmds + k);
+        h.objectId = scalar_load(cw); h.meshletId = scalar_load(cw + 1); h.slot = scalar_load(cw + 2);
         const RasterParams* q = kernel_args();                  // (scene pointers: read where they are used, not held across the loop)
         const DMeshlet* __restrict__ mm = &scalar_load(&q->meshlets)[h.meshletId];
-        const uint32_t vt = __builtin_amdgcn_readfirstlane(mm->vertexTriangleCount);
+        const uint32_t vt = scalar_load(&mm->vertexTriangleCount);
         h.V = vt & 0xFFu; h.T = (vt >> 8) & 0xFFu;
-        h.dataOffset = __builtin_amdgcn_readfirstlane(mm->dataOffset);
-        h.vertexBase = __builtin_amdgcn_readfirstlane(mm->vertexBase);
-        h.matFlags = __builtin_amdgcn_readfirstlane(scalar_load(&q->objStatic)[h.objectId].matFlags);
+        h.dataOffset = scalar_load(&mm->dataOffset);
+        h.vertexBase = scalar_load(&mm->vertexBase);
+        h.matFlags = scalar_load(&scalar_load(&q->objStatic)[h.objectId].matFlags);
         h.twoSided = (h.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u;
         if (CHORD_MATFLAG_ALPHA(h.matFlags) >= CHORD_ALPHA_BLEND) h.T = 0u;   // blended: in no bucket of renderMesh (mesh_raster.cpp:224)
         const float* __restrict__ mv = scalar_load(&q->objFrame)[h.objectId].mvp;
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int cc = 0; cc < 4; cc++) h.mvp.r[r][cc] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mv[r * 4 + cc])));
+            for (int cc = 0; cc < 4; cc++) h.mvp.r[r][cc] = scalar_load(mv + r * 4 + cc);
         return h;
     };
     // Software pipeline over clusters (a wave's clusters k, k+1, ... are `stride` apart in the list).  While cluster k is
@@ -737,9 +739,8 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
     const uint32_t stride = gridDim.x * 4u;
     uint32_t c = blockIdx.x * 4u + wave;
     if (c >= count) return;
-    auto cmd_at = [&](uint32_t i) -> ChordDrawCmd { return cmds[__builtin_amdgcn_readfirstlane(min(i, count - 1u))]; };
-    Header hdr = load_header(cmd_at(c));
-    Header hdrN = load_header(cmd_at(c + stride));
+    Header hdr = load_header(c);
+    Header hdrN = load_header(c + stride);
     // geometry of the current cluster: vertices lane and lane + 64 (indices, then positions), triangle words
     uint32_t t0 = 0, t1 = 0;
     float pax, pay, paz, pbx, pby, pbz;
@@ -832,6 +833,9 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
                     if (!allFast && (d[0] != d[0] || d[1] != d[1] || d[2] != d[2])) {
                         kind = K_CLIP;
                     } else {
+                        // (snapped per use: keeping the snapped pair per vertex in LDS, as the block kernel does, makes the workgroup
+                        // 32 KB -- this kernel holds 256 vertices per wave -- and costs it its fifth wave per SIMD: config 4's set-up
+                        // 154 -> 227 us per frame, measured)
                         ts.X[0] = (int32_t)rintf((u0 * p.W) * 256.0f); ts.Y[0] = (int32_t)rintf((v0 * p.H) * 256.0f);
                         ts.X[1] = (int32_t)rintf((u1 * p.W) * 256.0f); ts.Y[1] = (int32_t)rintf((v1 * p.H) * 256.0f);
                         ts.X[2] = (int32_t)rintf((u2 * p.W) * 256.0f); ts.Y[2] = (int32_t)rintf((v2 * p.H) * 256.0f);
@@ -936,7 +940,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
         __builtin_amdgcn_wave_barrier();
         // rotate the pipeline; the header after next is fetched now and first used after the next vertex phase
         hdr = hdrN;
-        hdrN = load_header(cmd_at(c + 2u * stride));
+        hdrN = load_header(c + 2u * stride);
         t0 = nt0; t1 = nt1;
         pax = nax; pay = nay; paz = naz; pbx = nbx; pby = nby; pbz = nbz;
         SPHASE(4);
