@@ -706,7 +706,6 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
     struct Header {
         uint32_t objectId, meshletId, slot, V, T, dataOffset, vertexBase, matFlags;
         bool twoSided;
-        Mat4 mvp;
     };
     // (scalar loads through the constant address space: the addresses are wave-uniform, and a vector load + v_readfirstlane per
     // dword was 26 VALU instructions per header -- the record kernel is bound by VALU issue on dense scenes like the block kernel)
@@ -724,12 +723,18 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
         h.matFlags = scalar_load(&scalar_load(&q->objStatic)[h.objectId].matFlags);
         h.twoSided = (h.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u;
         if (CHORD_MATFLAG_ALPHA(h.matFlags) >= CHORD_ALPHA_BLEND) h.T = 0u;   // blended: in no bucket of renderMesh (mesh_raster.cpp:224)
-        const float* __restrict__ mv = scalar_load(&q->objFrame)[h.objectId].mvp;
+        return h;
+    };
+    // (the object's matrix is fetched where the cluster's vertex phase starts, not an iteration ahead with the header: sixteen
+    // more scalars alive across a whole cluster are lane spills -- a v_readlane each -- in a loop that sits at its 102 SGPRs)
+    auto mvp_of = [&](uint32_t objectId) -> Mat4 {
+        Mat4 m;
+        const float* __restrict__ mv = scalar_load(&kernel_args()->objFrame)[objectId].mvp;
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int cc = 0; cc < 4; cc++) h.mvp.r[r][cc] = scalar_load(mv + r * 4 + cc);
-        return h;
+            for (int cc = 0; cc < 4; cc++) m.r[r][cc] = scalar_load(mv + r * 4 + cc);
+        return m;
     };
     // Software pipeline over clusters (a wave's clusters k, k+1, ... are `stride` apart in the list).  While cluster k is
     // processed, k+1's header is resident, its vertex indices + triangle words are fetched after k's vertex phase, its
@@ -762,7 +767,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
         const uint32_t slot = hdr.slot, V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
         const bool twoSided = hdr.twoSided || p.depthOnly != 0u;                       // depth passes: cull mode NONE (mesh_raster.cpp:188-190)
         const bool masked = MASKED && CHORD_MATFLAG_ALPHA(hdr.matFlags) == CHORD_ALPHA_MASK;      // (wave-uniform)
-        const Mat4 mvp = hdr.mvp;
+        const Mat4 mvp = mvp_of(hdr.objectId);
         const uint32_t triWord[2] = {t0, t1};
 
         if (sprof) { volatile uint32_t sink = V + T; (void)sink; }
