@@ -1942,10 +1942,10 @@ __device__ __forceinline__ uint32_t block_scan_tb(uint32_t v, uint32_t* waveSums
 #define SEG (1 << SEG_SHIFT)
 // Units of masked (alpha-tested) triangles: MASKED_ROWS pixel rows x segments of MASKED_SEG pixels, MASKED_PIXELS_PER_TRIP pixels
 // per trip of the row loop.  Measured on street_4k_masked (profiles/r04_masked_variants.txt; tile kernel per frame): one row x 64
-// px x 1 pixel per trip 418 us; segments of 32 / 16 / 8 px 419 / 421 / 498; two pixels per trip (taps of both in flight) 488; 16
-// rows per unit (the three dependent fetches a unit starts with -- extension record, material, texels -- paid once per small
-// triangle) 1 012: the pass is bound by the arithmetic of a covered pixel (two divisions, texel indices with a 32-bit modulo per
-// axis, up to four taps: ~300 instruction slots) times its lane occupancy, not by per-unit latency.
+// px x 1 pixel per trip 418 us; segments of 32 / 16 / 8 px 419 / 421 / 498 (and no different once a unit's set-up is one round
+// trip); two pixels per trip (taps of both in flight) 488: the masked instantiation sits at 128 VGPRs with scratch, more live taps
+// move spills into the loop; 16 rows per unit 1 012.  By removal (-DEXP_MASKED): of the pass's ~250 us the bilinear taps are 80,
+// the remainders of non-power-of-two sizes were 45 (period_mod recovered 30), the two divisions 5.
 #ifndef MASKED_ROWS
 #define MASKED_ROWS 1
 #endif
