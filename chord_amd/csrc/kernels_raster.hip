@@ -634,19 +634,14 @@ __device__ __forceinline__ float sample_alpha(const AlphaLevel& t, float u, floa
 
 // extension of a masked triangle of the cluster in flight: texture coordinates from the vertex stream, w from the
 // wave's LDS copy of the clip-space vertices.
-__device__ __forceinline__ void setup_emit_mask_ext(const RasterParams& p, TriRec* slot, uint32_t triWord, uint32_t dataOffset, uint32_t vertexBase,
+__device__ __forceinline__ void setup_emit_mask_ext(const RasterParams& p, TriRec* slot, uint32_t triWord, const float uv[6],
                                                  const float* lW, uint32_t material, int64_t absArea2)
 {
     float u[3], v[3], w[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const uint32_t li = (triWord >> (8 * i)) & 0xFFu;
-        u[i] = 0.0f; v[i] = 0.0f;
-        if (p.texcoords) {
-            const size_t vi = (size_t)(p.meshletData[dataOffset + li] + vertexBase) * 2;
-            u[i] = p.texcoords[vi]; v[i] = p.texcoords[vi + 1];
-        }
-        w[i] = lW[li];
+        u[i] = uv[2 * i]; v[i] = uv[2 * i + 1];               // (fetched at the start of the triangle phase; 0 without texture coordinates)
+        w[i] = lW[(triWord >> (8 * i)) & 0xFFu];
     }
     write_mask_ext(slot, &p.materials[material], material, absArea2, u, v, w);
 }
@@ -804,6 +799,18 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
 
         // ---- triangle phase: the (up to) two triangles of a lane are evaluated first, then emitted together so
         //      that every round of list / bin reservations costs ONE atomic round trip for both ------------------
+        // (masked clusters: the texture coordinates of each lane's two triangles are fetched now -- vertex index, then uv: two
+        // dependent gathers -- so that they arrive behind the culls and the set-up instead of being waited for in the emission)
+        float uvA[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, uvB[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (MASKED && masked && scalar_load(&kernel_args()->texcoords) != nullptr) {
+            const float* __restrict__ tc = scalar_load(&kernel_args()->texcoords);
+            const uint32_t* __restrict__ mdT = scalar_load(&kernel_args()->meshletData);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                if (lane < T) { const size_t vi = (size_t)(mdT[dataOffset + ((t0 >> (8 * i)) & 0xFFu)] + vertexBase) * 2; uvA[2 * i] = tc[vi]; uvA[2 * i + 1] = tc[vi + 1]; }
+                if (lane + 64u < T) { const size_t vi = (size_t)(mdT[dataOffset + ((t1 >> (8 * i)) & 0xFFu)] + vertexBase) * 2; uvB[2 * i] = tc[vi]; uvB[2 * i + 1] = tc[vi + 1]; }
+            }
+        }
         int kindA = K_NONE, kindB = K_NONE;
         TriSetup tsA, tsB;
         float dA[3] = {0.0f, 0.0f, 0.0f}, dB[3] = {0.0f, 0.0f, 0.0f};
@@ -912,7 +919,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
                 const uint32_t li = ebaseW + wSlots * (uint32_t)__popcll(ewA & lt);
                 if (li + wSlots <= e.triCap) {
                     giA = listShard * e.triCap + li; write_record(&e.tris[giA], tsA, dA, twoSided, masked);
-                    if (MASKED && masked) setup_emit_mask_ext(p, &e.tris[giA + 1u], triWord[0], dataOffset, vertexBase, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsA.area);
+                    if (MASKED && masked) setup_emit_mask_ext(p, &e.tris[giA + 1u], triWord[0], uvA, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsA.area);
                     giA |= CHORD_REC_WIDE; okA = true;
                 } else atomicOr(&e.counters->overflow, 1u);
             }
@@ -924,7 +931,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
                 const uint32_t li = ebaseW + wSlots * ((uint32_t)__popcll(ewA) + (uint32_t)__popcll(ewB & lt));
                 if (li + wSlots <= e.triCap) {
                     giB = listShard * e.triCap + li; write_record(&e.tris[giB], tsB, dB, twoSided, masked);
-                    if (MASKED && masked) setup_emit_mask_ext(p, &e.tris[giB + 1u], triWord[1], dataOffset, vertexBase, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsB.area);
+                    if (MASKED && masked) setup_emit_mask_ext(p, &e.tris[giB + 1u], triWord[1], uvB, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsB.area);
                     giB |= CHORD_REC_WIDE; okB = true;
                 } else atomicOr(&e.counters->overflow, 1u);
             }
@@ -1389,7 +1396,7 @@ __device__ __forceinline__ bool launch_is_dense(const RasterParams& p, uint32_t 
 // MASKED: the scene has alpha-tested materials (their clusters emit 48-byte records with a texture-coordinate extension);
 // scenes without any -- every benchmark configuration -- run the instantiation that knows nothing of them.
 template <bool MASKED>
-__global__ __launch_bounds__(256, SETUP_MIN_WAVES) void raster_setup_kernel(RasterParams p)
+__global__ __launch_bounds__(256, MASKED ? 4 : SETUP_MIN_WAVES) void raster_setup_kernel(RasterParams p)   // (masked: twelve more live registers, see uvA)
 {
     __shared__ float sVert[6][4][LDS_VERTS];                   // x, y, w, u, v, depth of a wave's cluster (24 KB)
     uint32_t count = *p.count;
