@@ -107,7 +107,8 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # control plane on gloo (CPU): barriers, the communicator id and the max over ranks work whatever state RCCL is in
-        dist.init_process_group(backend="gloo")
+        import datetime
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=10))
     # Every kernel of the path AND every collective of the frame is enqueued on ONE explicit stream.  (PyTorch's
     # default stream has handle 0; handed to chordvis_create that reads as "no stream given" and the context would run
     # on a private non-blocking stream that nothing orders against the collectives.)
@@ -124,15 +125,24 @@ def main():
     # (CHORDVIS_BENCH_ALSO: test hook -- a small second workload for the one-GPU protocol tests)
     also_wl = os.environ.get("CHORDVIS_BENCH_ALSO") or ("street_x64_4k_hzb" if args.workload == "auto" else None)
     if world > 1 and also_wl and not args.no_also:
-        also = measure(args, also_wl, env)
-        if line is not None and also is not None:
-            line["also"] = {k: also[k] for k in ("config", "value", "unit", "ms_per_step", "steps", "timed_region_s", "exchange", "pipelined", "tile_map", "exchange_fallbacks",
-                                                   "phases_ms", "single_gpu_same_workload", "speedup_vs_single", "triangles_submitted_per_step", "gpu_ms") if k in also}
+        # (the second measurement must not cost the first its line: a failure here -- on any rank; the others leave their
+        # collectives when the control plane times out -- is reported inside `also` instead)
+        try:
+            also = measure(args, also_wl, env)
+            if line is not None and also is not None:
+                line["also"] = {k: also[k] for k in ("config", "value", "unit", "ms_per_step", "steps", "timed_region_s", "exchange", "pipelined", "tile_map", "exchange_fallbacks",
+                                                       "phases_ms", "single_gpu_same_workload", "speedup_vs_single", "triangles_submitted_per_step", "gpu_ms") if k in also}
+        except Exception as e:                      # noqa: BLE001
+            if line is not None:
+                line["also"] = {"config": {"workload": also_wl}, "error": "%s: %s" % (type(e).__name__, e)}
     if line is not None:
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:                           # noqa: BLE001  (the line is out; a peer that failed above cannot meet this barrier)
+            pass
     return 0
 
 
