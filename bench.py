@@ -17,7 +17,12 @@ apart so that every frame culls against the HZB of a *different* previous frame 
           (barriers, the communicator id, the max over ranks) is a gloo group: it does not depend on RCCL.  Every N > 1
           line carries the same workload rendered unsharded on rank 0's GPU (single_gpu_same_workload, speedup_vs_single)
           and, per rank, the GPU time of every phase and exchange of the frame (`phases_ms`).  --workload overrides either
-          default, so the N = 1 point of any curve can be re-run on the N > 1 workload.
+          default, so the N = 1 point of any curve can be re-run on the N > 1 workload.  One N > 1 line holds BOTH protocols -- the top
+          level is the unpipelined frame, `pipelined` the same frames with the image gather beside the next frame (its own ms_per_step,
+          value, speedup_vs_single) --, the figure under the default tile map beside the re-balanced one (`default_map`), the achieved
+          GB/s of every exchange (`exchange_gbs`, `rccl_schedule_ok`; when the image gather over RCCL stays under 250 GB/s per rank the
+          peer-copy transport is measured in the same run: `group_transport`), what bounds the frame (`bound`: launches x launch floor +
+          exchanges), and `also` = BASELINE config 4 with all of the same.
   `python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one process per GPU).
 
 value = triangles of the clusters submitted to the rasterizer per frame (post-cull, the unit of
@@ -80,7 +85,9 @@ def main():
     ap.add_argument("--workload", default="auto", help="street_4k_hzb | street_4k_masked | street_x64_4k_hzb | street_x16_4k_hzb | subpixel_1g | subpixel_1g_hotspot | subpixel_64m | atrium_1080p")
     ap.add_argument("--exchange", default="auto", choices=("auto", "lib", "torch", "group"),
                     help="N > 1: who issues the all-gathers -- the library over RCCL, torch.distributed, or one process with N devices (ChordGroup, peer copies); auto = the first that works")
-    ap.add_argument("--pipelined", action="store_true", help="N > 1, --exchange lib: the visibility all-gather of frame i runs beside frame i + 1 (second RCCL communicator)")
+    ap.add_argument("--pipelined", action="store_true", help="(kept for old command lines: every N > 1 line now carries the pipelined protocol beside the unpipelined one)")
+    ap.add_argument("--no-pipelined", action="store_true", help="N > 1: do not also measure the pipelined protocol")
+    ap.add_argument("--no-group-fallback", action="store_true", help="N > 1, --exchange lib: do not measure the peer-copy transport when the RCCL image gather is slow")
     ap.add_argument("--no-also", action="store_true", help="N > 1, default workload: do not also measure BASELINE config 4 (street_x64_4k_hzb) for the line's `also` field")
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep the default tile map (compact regions of equal area) instead of re-balancing it from the warm-up frames' tile loads")
     ap.add_argument("--cpu-baseline-frames", type=int, default=48, help="oracle frames timed on the host (rank 0, N=1); 0 disables")
@@ -130,7 +137,8 @@ def main():
         try:
             also = measure(args, also_wl, env)
             if line is not None and also is not None:
-                line["also"] = {k: also[k] for k in ("config", "value", "unit", "ms_per_step", "steps", "timed_region_s", "exchange", "pipelined", "tile_map", "exchange_fallbacks",
+                line["also"] = {k: also[k] for k in ("config", "value", "unit", "ms_per_step", "steps", "timed_region_s", "exchange", "pipelined", "tile_map", "exchange_fallbacks", "default_map",
+                                                       "exchange_gbs", "rccl_schedule_ok", "group_transport", "bound", "cull",
                                                        "phases_ms", "single_gpu_same_workload", "speedup_vs_single", "triangles_submitted_per_step", "gpu_ms") if k in also}
         except Exception as e:                      # noqa: BLE001
             if line is not None:
@@ -266,14 +274,6 @@ def measure(args, workload, env):
         r.close()                                        # (the group makes its own contexts, one per device)
         return run_group(args, wl, scene, views, (obj_a, obj_b), flags, W, H, world, rank, dev, stream, fallbacks)
 
-    pipelined = False
-    if exchange == "lib" and args.pipelined:
-        # the image of frame i travels beside frame i + 1 on a second communicator (chordvis_comm_set_pipelined)
-        from chord_amd.renderer import comm_unique_id
-        uid2 = [comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid2, src=0)
-        r.comm_set_pipelined(uid2[0])
-        pipelined = True
     if exchange == "torch":
         words = r.visibility_words()
         vis_t = torch.zeros(words, dtype=torch.int64, device=dev)      # caller-owned visibility (all-gather target)
@@ -300,6 +300,9 @@ def measure(args, workload, env):
         if world == 1 or exchange == "lib":
             r.render_frame()
         else:
+            if ex.cull is not None:                      # the sharded group cull: this rank's share of the tests, then everybody's rank masks
+                r.frame_phase_cull()
+                all_gather(ex.cull, ex.cull_mine)
             r.frame_phase_a()
             ex.all_gather_hzb()
             r.frame_phase_b()
@@ -321,6 +324,11 @@ def measure(args, workload, env):
             self.fin = _tensor_from_ptr(fptr, fbytes * world, torch.uint8, dev)
             self.fin_mine = self.fin[rank * fbytes:(rank + 1) * fbytes]
             self.vis = vis_views() if vis_t is not None else None
+            cptr, cbytes = r.cull_exchange()
+            self.cull = self.cull_mine = None
+            if cptr and cbytes and args.cull == "flat" and not os.environ.get("CHORDVIS_BENCH_REPLICATED_CULL"):
+                self.cull = _tensor_from_ptr(cptr, cbytes * world, torch.uint8, dev)
+                self.cull_mine = self.cull[rank * cbytes:(rank + 1) * cbytes]
 
         def all_gather_hzb(self):
             if not args.no_hzb:                          # (a frame without stage 1 has nothing to exchange)
@@ -332,6 +340,24 @@ def measure(args, workload, env):
     ex = Exchange() if (world > 1 and exchange == "torch") else None
     if args.debug_flags:
         r.set_debug(args.debug_flags)
+
+    def timed(n, first=0):
+        """n frames between barrier + synchronize on both sides; (seconds of this rank, max over ranks)"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        a = time.perf_counter()
+        for k in range(n):
+            frame(first + k)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        mine_s = time.perf_counter() - a
+        if world > 1:
+            t = torch.tensor([mine_s], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return mine_s, float(t.item())
+        return mine_s, mine_s
 
     # ---- warm-up (untimed): also collects the deterministic per-view counts ---------------------
     r.enable_timers(0)
@@ -354,9 +380,15 @@ def measure(args, workload, env):
     # ---- N > 1: the tile map re-balanced from the loads of the last warm-up frame (every rank holds every tile's load after
     #      the end-of-frame exchange and computes the same map), then two more untimed frames under the new map
     tile_map = None
+    default_map = None
     if world > 1:
         imb_before = 1.0
         if not args.no_rebalance:
+            # the same frames under the DEFAULT map first (compact regions of equal area): the re-balanced map below is made from the
+            # loads of exactly the two views the timed region renders, which a moving camera would not grant it
+            nd = max(2, min(args.steps, 20)) & ~1
+            _, dm = timed(nd)
+            default_map = {"steps": nd, "ms_per_step": round(dm / nd * 1e3, 4)}
             imb_before = r.rebalance()
             if ex is not None:
                 ex.remap()
@@ -369,6 +401,10 @@ def measure(args, workload, env):
         tile_map = {"rebalanced": not args.no_rebalance, "entries_max_over_mean_default_map": round(imb_before, 3),
                     "entries_max_over_mean": round(float(per.max() / max(per.mean(), 1.0)), 3),
                     "tiles_per_rank": np.bincount(owners, minlength=world).tolist(), "chunk_slots": r.visibility_chunk_words() // 4096}
+    chunks = None
+    if world > 1:
+        chunks = {"cull": r.cull_exchange()[1] if args.cull == "flat" else 0, "hzb_mid": r.hzb_exchange()[2] * 2,
+                  "final": r.hzb_final_exchange()[1], "image": r.visibility_chunk_words() * 8}
     tris_per_pair = per_view[0]["trianglesSubmitted"] + per_view[1]["trianglesSubmitted"]
     clusters_per_pair = sum(pv["countStage0Visible"] + pv["countStage1Visible"] for pv in per_view)
 
@@ -379,17 +415,7 @@ def measure(args, workload, env):
     # instead (same frames, same state, same stream): `stamped_inside_timed_region` says which it was.
     stamp_inside = args.steps >= 64 or world > 1
     r.enable_timers(2 if stamp_inside else 0, period=8)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        frame(i)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    rank_elapsed, elapsed = timed(args.steps)
     # The per-kernel averages behind `roofline` come from hipEvent stamps on the launch stream.  Inside the timed region only every
     # 8th step is stamped (a stamped frame is ~20 % longer); a short run (the driver's 20 steps: 2-3 stamped frames) is topped
     # up to at least 8 stamped frames right after it -- same frames, same state, outside the clock.
@@ -408,12 +434,27 @@ def measure(args, workload, env):
                 st[k] = (st[k] * stamped_in_region + st2[k] * extra) / (stamped_in_region + extra)
             elif not stamped_in_region:
                 st[k] = st2[k]
-    rank_elapsed = elapsed
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- N > 1, library-run exchange: the PIPELINED protocol on the same frames (second communicator: the image of frame i travels
+    #      beside frame i + 1; the history HZB waits only for the small end-of-frame exchange) -- DESIGN.md 6
+    pipe = None
+    if world > 1 and not args.no_pipelined:
+        if exchange == "lib":
+            from chord_amd.renderer import comm_unique_id
+            try:
+                uid2 = [comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid2, src=0)
+                r.enable_timers(0)
+                r.comm_set_pipelined(uid2[0])
+                timed(4)
+                _, pe = timed(args.steps)
+                r.comm_set_pipelined(None)
+                pipe = {"steps": args.steps, "ms_per_step": round(pe / args.steps * 1e3, 4), "timed_region_s": round(pe, 6)}
+            except Exception as e:                          # noqa: BLE001
+                pipe = {"error": "%s: %s" % (type(e).__name__, e)}
+        else:
+            pipe = {"skipped": "exchange %r drives the phases from the host; the pipelined protocol is the library's (chordvis_comm_set_pipelined / chordvis_group_set_pipelined)" % exchange}
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, inside the timed region)
     # algorithmic bytes per frame (DESIGN.md "Roofline"): setup reads 1884 B per cluster (64 header + 12 cmd +
@@ -517,6 +558,7 @@ def measure(args, workload, env):
                 "phase_a_cull": round(st["msClear"] + st["msInstanceCulling"], 4), "phase_a_stage0": round(st["msStage0"], 4),
                 "hzb_mid": round(st["msHzbStage0"], 4), "exchange_hzb": round(st["msExchangeHzb"], 4),
                 "phase_b_stage1": round(st["msStage1"], 4), "exchange_vis": round(st["msExchangeVis"], 4),
+                "exchange_cull": round(st["msExchangeCull"], 4), "exchange_final": round(st["msExchangeFinal"], 4), "kernel_launches": st["kernelLaunches"],
                 "phase_c_final_hzb": round(st["msHzbFinal"], 4), "setup_kernels": round(st["msRasterCluster"], 4), "tile_kernels": round(st["msRasterChunk"], 4),
                 "clusters": [per_view[0]["countStage0Visible"] + per_view[0]["countStage1Visible"], per_view[1]["countStage0Visible"] + per_view[1]["countStage1Visible"]]}
         allp = [None] * world
@@ -558,7 +600,10 @@ def measure(args, workload, env):
     if rank == 0:
         line = {
             "metric": "Gtri/s into 4K 64-bit visbuffer", "value": round(value, 4), "unit": "Gtri/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_frames_run": warm + 2, "ms_per_step": round(ms_per_step, 4), "timed_region_s": round(elapsed, 6),
+            "n_gpus": world, "steps": args.steps,
+            # (the frames that really ran before the clock: the W asked for, at least 4, plus -- N = 1 -- frames until 60 ms of GPU work
+            # have gone through, because a GPU that has run 5 frames of 0.2 ms has not reached its clocks)
+            "warmup": warm + 2, "warmup_requested": args.warmup, "ms_per_step": round(ms_per_step, 4), "timed_region_s": round(elapsed, 6),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32+u64", "data": "synthetic",
             "config": {"workload": wl, **({"ABLATION_debug_flags": args.debug_flags} if args.debug_flags else {}), "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(),
@@ -578,7 +623,37 @@ def measure(args, workload, env):
         }
         if world > 1:
             line["exchange"] = exchange
-            line["pipelined"] = pipelined
+            one = single_ref["ms_per_step"] if single_ref else None
+            if pipe and "ms_per_step" in pipe:
+                pipe["value"] = round(tris_per_pair / 2.0 / (pipe["ms_per_step"] * 1e-3) / 1e9, 4)
+                pipe["speedup_vs_single"] = round(one / pipe["ms_per_step"], 4) if one else None
+            line["pipelined"] = pipe
+            if default_map:
+                default_map["speedup_vs_single"] = round(one / default_map["ms_per_step"], 4) if one else None
+            line["default_map"] = default_map
+            line["cull"] = "sharded" if phases and any(p["exchange_cull"] > 0 for p in phases) or (ex is not None and ex.cull is not None) else "replicated"
+            # achieved bandwidth of every exchange: bytes ARRIVING at a rank ((N - 1) chunks) / the shortest time any rank spent in it
+            # (the rank that entered last waited least for its peers: the closest a stream stamp gets to the transfer itself)
+            def gbs(key, chunk_bytes):
+                ts = [p[key] for p in phases if p[key] > 0]
+                if not ts or not chunk_bytes:
+                    return None
+                return {"bytes_per_rank_in": int((world - 1) * chunk_bytes), "ms_min_over_ranks": round(min(ts), 4), "ms_max_over_ranks": round(max(ts), 4),
+                        "gbs": round((world - 1) * chunk_bytes / (min(ts) * 1e-3) / 1e9, 2)}
+            both_end = exchange != "lib"                   # (host-driven phases: one stamp covers the small end-of-frame exchange AND the image)
+            line["exchange_gbs"] = {"cull": gbs("exchange_cull", chunks["cull"]), "hzb_mid": gbs("exchange_hzb", chunks["hzb_mid"]),
+                                    "final": gbs("exchange_final", chunks["final"]),
+                                    "image" + ("+final" if both_end else ""): gbs("exchange_vis", chunks["image"] + (chunks["final"] if both_end else 0))}
+            img = line["exchange_gbs"]["image" + ("+final" if both_end else "")]
+            # a ring all-gather of the 66.8 MB image is per-link bound (~0.8 ms), a direct one ~0.13 ms; 250 GB/s into a rank
+            # separates the two.  Below it, the peer-copy transport (ChordGroup) is measured in this same run (main()).
+            line["rccl_schedule_ok"] = (img["gbs"] >= 250.0) if (img and backend == "nccl" and exchange == "lib") else None
+            launches_pf = max(p["kernel_launches"] for p in phases)
+            exch = sum(min([p[k] for p in phases if p[k] > 0] or [0.0]) for k in ("exchange_cull", "exchange_hzb", "exchange_final", "exchange_vis"))
+            # what a short frame cannot go below: its launches x the launch floor (profiles/r03_microbench_launch_floor.txt: 2.6-3 us back to
+            # back, ~5 us with a dependent load in front) + the exchanges at their best rank
+            line["bound"] = {"kernel_launches_per_frame": launches_pf, "launch_floor_us": 5.0, "exchanges_ms": round(exch, 4),
+                             "bound_ms": round(launches_pf * 5.0e-3 + exch, 4), "ms_per_step": round(ms_per_step, 4)}
             line["tile_map"] = tile_map
             line["exchange_fallbacks"] = fallbacks
             line["phases_ms"] = phases
@@ -589,6 +664,18 @@ def measure(args, workload, env):
             line["single_gpu_same_workload"] = single_ref
             line["speedup_vs_single"] = round(single_ref["ms_per_step"] / ms_per_step, 4)
     r.close()
+    # ---- the RCCL image gather stayed under 250 GB/s into a rank (a ring schedule over xGMI: SURVEY 5): the peer-copy transport --
+    #      n - 1 concurrent direct copies per rank -- measured in this same run, its line attached
+    if world > 1 and exchange == "lib" and not args.no_group_fallback:
+        need = [bool(line is not None and line.get("rccl_schedule_ok") is False)]
+        dist.broadcast_object_list(need, src=0)
+        if need[0]:
+            try:
+                gl = run_group(args, wl, scene, views, (obj_a, obj_b), flags, W, H, world, rank, dev, stream, [{"lib": "image gather below 250 GB/s per rank"}])
+            except Exception as e:                          # noqa: BLE001
+                gl = {"error": "%s: %s" % (type(e).__name__, e)}
+            if line is not None and gl is not None:
+                line["group_transport"] = {k: gl[k] for k in ("value", "ms_per_step", "speedup_vs_single", "pipelined", "phases_ms", "collective_backend", "error") if k in gl}
     return line
 
 
@@ -635,6 +722,22 @@ def run_group(args, wl, scene, views, objs, flags, W, H, world, rank, dev, strea
         elapsed = time.perf_counter() - t0
         enq = g.enqueue_ms()
         sts = [r_.stats() for r_ in g.ranks]
+        pipe = None
+        if not args.no_pipelined:
+            # the pipelined protocol on the same frames: the image of frame i travels (on its own copy streams) beside frame i + 1
+            for r_ in g.ranks:
+                r_.enable_timers(0)
+            g.set_pipelined(True)
+            for i in range(4):
+                frame(i)
+            g.sync()
+            p0 = time.perf_counter()
+            for i in range(args.steps):
+                frame(i)
+            g.sync()
+            pe = time.perf_counter() - p0
+            g.set_pipelined(False)
+            pipe = {"steps": args.steps, "ms_per_step": round(pe / args.steps * 1e3, 4), "timed_region_s": round(pe, 6)}
         g.close()
         r1 = VisibilityRenderer(0, stream.cuda_stream)
         if wl.startswith("subpixel_1g"):
@@ -667,15 +770,18 @@ def run_group(args, wl, scene, views, objs, flags, W, H, world, rank, dev, strea
         single = {"workload": wl, "n_gpus": 1, "steps": n1, "ms_per_step": round((s1 - s0) / n1 * 1e3, 4),
                   "value": round(tris_per_pair * (n1 // 2) / (s1 - s0) / 1e9, 4), "unit": "Gtri/s"}
         line = {"metric": "Gtri/s into 4K 64-bit visbuffer", "value": round(tris_total / elapsed / 1e9, 4), "unit": "Gtri/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "timed_region_s": round(elapsed, 6),
+                "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 4) + (0 if args.no_rebalance else 4), "warmup_requested": args.warmup, "ms_per_step": round(ms, 4), "timed_region_s": round(elapsed, 6),
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
                 "config": {"workload": wl, "resolution": [W, H], "scene_triangles_lod0": scene.triangle_count_lod0(), "objects": len(scene.objects),
                            "hzb": not args.no_hzb, "cull": args.cull, "parallelism": "tiles%d" % world},
                 "triangles_submitted_per_step": tris_per_pair / 2.0,
                 "exchange": "group", "exchange_fallbacks": fallbacks, "collective_backend": "hipMemcpyPeerAsync", "tile_map": tile_map,
+                "pipelined": (dict(pipe, value=round(tris_per_pair / 2.0 / (pipe["ms_per_step"] * 1e-3) / 1e9, 4),
+                                   speedup_vs_single=round(single["ms_per_step"] / pipe["ms_per_step"], 4)) if pipe else None),
                 "phases_ms": [{"rank": k, "phase_a_cull": round(st["msClear"] + st["msInstanceCulling"], 4), "phase_a_stage0": round(st["msStage0"], 4),
                                "hzb_mid": round(st["msHzbStage0"], 4), "exchange_hzb": round(st["msExchangeHzb"], 4), "phase_b_stage1": round(st["msStage1"], 4),
                                "exchange_vis": round(st["msExchangeVis"], 4), "phase_c_final_hzb": round(st["msHzbFinal"], 4),
+                               "exchange_cull": round(st["msExchangeCull"], 4), "exchange_final": round(st["msExchangeFinal"], 4), "kernel_launches": st["kernelLaunches"],
                                "setup_kernels": round(st["msRasterCluster"], 4), "tile_kernels": round(st["msRasterChunk"], 4),
                                "host_enqueue_ms": round(enq[k], 4)} for k, st in enumerate(sts)],
                 "roofline": None, "cpu_baseline": None,

@@ -17,7 +17,9 @@ BUILD_DIR = os.path.join(HERE, "_build", "obj")
 LIB = os.path.join(OUT_DIR, "libchordvis.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+# -fvisibility=hidden: the dynamic symbols are the C entry points of include/chordvis.h and nothing else (the header pushes default
+# visibility around its declarations; tests/test_abi.py compares `nm -D` with the header)
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
           "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 # HIP defaults kept on purpose: -fhip-fp32-correctly-rounded-divide-sqrt (IEEE / and sqrt), denormals preserved.
 DEVICE = ["--offload-arch=gfx950"]
@@ -31,7 +33,7 @@ def _headers_digest():
     h = hashlib.sha1()
     for d in (CSRC, os.path.join(ROOT, "include")):
         for f in sorted(os.listdir(d)):
-            if f.endswith((".h", ".hpp", ".hip.h")):
+            if f.endswith((".h", ".hpp", ".hip.h", ".map")):
                 with open(os.path.join(d, f), "rb") as fh:
                     h.update(fh.read())
     h.update(" ".join(COMMON + DEVICE).encode())
@@ -71,7 +73,9 @@ def build(force=False, verbose=True, defines=(), tag=""):
         # exactly one HIP/HSA runtime; PyTorch-ROCm wheels bundle their own (SONAME libamdhip64.so, not
         # libamdhip64.so.7), so the host decides which runtime is live and loads it first (chord_amd/lib.py;
         # a C++ host simply links -lamdhip64 itself).
-        cmd = [HIPCC, "-shared", "-fPIC", "-no-hip-rt", "-o", lib_path] + objs + ["--offload-arch=gfx950"]
+        # the version script makes `chordvis_*` the only dynamic symbols: hipcc keeps the kernels' host-side handles and the implicit
+        # members of types named in the header at default visibility whatever -fvisibility says
+        cmd = [HIPCC, "-shared", "-fPIC", "-no-hip-rt", "-Wl,--version-script=" + os.path.join(CSRC, "chordvis.map"), "-o", lib_path] + objs + ["--offload-arch=gfx950"]
         if verbose:
             print("[chord_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

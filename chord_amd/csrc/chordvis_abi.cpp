@@ -53,6 +53,7 @@ void record(ChordCtx* c, int tag) { chord::stamp(c, tag); }
 
 void begin_frame_stamps(ChordCtx* c)
 {
+    c->frameLaunchBase = c->launchCount;
     c->stampThisFrame = c->timers && (c->frameIndex % c->timerPeriod) == 0;
     c->frameIndex++;
     if (!c->stampThisFrame) return;
@@ -147,7 +148,7 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         CHORD_HIP(c, hipMemsetAsync(c->dHzbFinalExchange, 0, slots * CHORD_HZB_FINAL_SLOT_HALVES * 2, c->stream));
         if ((rc = install_tile_owners(c))) return rc;
     } else {
-        dfree(c->dHzbExchange); dfree(c->dHzbFinalExchange); dfree(c->dShardTables); dfree(c->dTileLoads);
+        dfree(c->dHzbExchange); dfree(c->dHzbFinalExchange); dfree(c->dShardTables); dfree(c->dTileLoads); dfree(c->dTileOwner); dfree(c->dCullExchange);
         c->shard.ownedRows = nullptr; c->shard.tileSlot = nullptr;
         c->hzbExchangeHalves = c->hzbExchangeChunkHalves = 0; c->hzbFinalExchangeChunkBytes = 0;
     }
@@ -280,7 +281,27 @@ int install_tile_owners(ChordCtx* c)
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
     c->shard.ownedRows = c->dShardTables;
     c->shard.tileSlot = reinterpret_cast<const uint32_t*>(c->dShardTables + 64);
+    // the owners themselves, one byte per tile: what the sharded cull makes its rank masks from (kernels_cull.hip cluster_rank_mask)
+    if (c->dTileOwner) { (void)hipFree(c->dTileOwner); c->dTileOwner = nullptr; }
+    CHORD_HIP(c, hipMalloc((void**)&c->dTileOwner, tiles));
+    CHORD_HIP(c, hipMemcpy(c->dTileOwner, c->tileOwners.data(), tiles, hipMemcpyHostToDevice));
     c->mineValid = false; c->listMine[1] = c->listMine[2] = false;       // (lists culled for another ownership)
+    return CHORDVIS_OK;
+}
+
+// The exchange buffer of the sharded group cull: ranks x (chunkBlocks x 256 mask words + chunkBlocks triangle sums), chunkBlocks =
+// ceil(count blocks / ranks) -- the same on every rank of a frame (same scene, same rank count).
+int ensure_cull_exchange(ChordCtx* c)
+{
+    if (!c->sceneLoaded || c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "cull exchange: a scene on a sharded context");
+    const uint32_t N = c->shard.ranks, chunkBlocks = (c->cullBlocks + N - 1u) / N;
+    if (c->dCullExchange && c->cullChunkBlocks == chunkBlocks && c->cullExchangeRanks == N) return CHORDVIS_OK;
+    CHORD_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->dCullExchange) { (void)hipFree(c->dCullExchange); c->dCullExchange = nullptr; }
+    const size_t words = (size_t)N * chunkBlocks * 257u;
+    CHORD_HIP(c, hipMalloc((void**)&c->dCullExchange, words * 4u));
+    CHORD_HIP(c, hipMemsetAsync(c->dCullExchange, 0, words * 4u, c->stream));
+    c->cullChunkBlocks = chunkBlocks; c->cullExchangeRanks = N;
     return CHORDVIS_OK;
 }
 
@@ -294,6 +315,7 @@ int alloc_scene_work_buffers(ChordCtx* c)
     if ((rc = dalloc(c, &c->dObjFrame, (size_t)c->objectCount))) return rc;
     if ((rc = dalloc(c, &c->dGroupMask, (size_t)c->groupInstances + 16))) return rc;   // (+16: zeroed in 16-byte vectors)
     if ((rc = dalloc(c, &c->dBlockCounts, (size_t)c->cullBlocks * 3))) return rc;   // counts, triangles, the rank's own counts (sharded), per count block
+    c->fullListStale = false;          // (no cull of this scene has written the masks / block counts launch_full_list replays)
     for (int i = 0; i < 3; i++) {
         if ((rc = dalloc(c, &c->lists[i].cmds, (size_t)c->cmdCapacity))) return rc;
         c->lists[i].count = c->dCounts + i;
@@ -376,7 +398,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
     if (c->hBinHint) { (void)hipHostFree(const_cast<uint32_t*>(c->hBinHint)); c->hBinHint = nullptr; c->dBinHint = nullptr; }
-    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dHzbFinalExchange); dfree(c->dShardTables); dfree(c->dTileLoads); dfree(c->dVisAlt); dfree(c->dVisResolvedAlt); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
+    dfree(c->dRangePartials); dfree(c->dTileRange); dfree(c->dHzbExchange); dfree(c->dHzbFinalExchange); dfree(c->dShardTables); dfree(c->dTileLoads); dfree(c->dTileOwner); dfree(c->dCullExchange); dfree(c->dVisAlt); dfree(c->dVisResolvedAlt); dfree(c->dTris); dfree(c->dTrisC); dfree(c->dBlockPool); dfree(c->dTileBins); dfree(c->dBinPool); dfree(c->dBinChunkTab);
     dfree(c->dClipTris); dfree(c->dLargeList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -602,6 +624,8 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     dfree(c->dRankCmds);                                   // sized by cmdCapacity; re-made by the first sharded raster pass
     dfree(c->dLeftCmds); dfree(c->dMineCmds);
     c->mineValid = false; c->listMine[1] = c->listMine[2] = false;       // (the rank's lists went with the buffers)
+    c->fullListStale = false; c->cullPhaseDone = false;                    // (the masks of the old scene's last cull are gone: nothing to replay)
+    dfree(c->dCullExchange);                                               // (sized by the scene's count blocks: re-made on demand)
     c->objectCount = s->objectCount; c->primCount = s->primitiveCount; c->materialCount = s->materialCount;
     c->meshletCount = nM; c->groupCount = nG;
     c->groupInstances = (uint32_t)groupInst; c->cmdCapacity = (uint32_t)std::max<uint64_t>(cmdCap, 1);
@@ -894,6 +918,24 @@ int chordvis_swap_visibility(ChordCtx* c)
     return CHORDVIS_OK;
 }
 uint64_t chordvis_hzb_exchange_halves(ChordCtx* c) { return c ? c->hzbExchangeHalves : 0; }
+// the sharded cull's exchange buffer (made on first request, after upload_scene and chordvis_set_shard; NULL / 0 when the sharded
+// cull does not apply: one rank, more than 8, no scene)
+uint32_t* chordvis_cull_exchange_ptr(ChordCtx* c) { return (c && c->sceneLoaded && c->shard.ranks > 1 && c->shard.ranks <= 8u && ensure_cull_exchange(c) == CHORDVIS_OK) ? c->dCullExchange : nullptr; }
+uint64_t chordvis_cull_exchange_chunk_bytes(ChordCtx* c) { return chordvis_cull_exchange_ptr(c) ? (uint64_t)c->cullChunkBlocks * 257u * 4u : 0; }
+// measurement / test aid: fills EVERY rank's chunk of the cull exchange buffer on this context (what the all-gather would deliver),
+// for the current view -- tools/shard_time.py times one rank at a time on one device
+int chordvis_debug_fill_cull_exchange(ChordCtx* c)
+{
+    int rc = ready(c, "debug_fill_cull_exchange");
+    if (rc) return rc;
+    if ((rc = ensure_cull_exchange(c))) return rc;
+    if (!cull_shardable(c)) return fail(c, CHORDVIS_E_INVALID, "debug_fill_cull_exchange: the sharded cull does not apply");
+    if (c->inFrame) return fail(c, CHORDVIS_E_INVALID, "debug_fill_cull_exchange: not inside a frame");
+    if ((rc = flush_view(c))) return rc;
+    launch_cull_masks(c, true);
+    CHORD_HIP(c, hipGetLastError());
+    return CHORDVIS_OK;
+}
 uint64_t chordvis_hzb_exchange_chunk_halves(ChordCtx* c) { return c ? c->hzbExchangeChunkHalves : 0; }
 
 // -------------------------------------------------------------------------------------- passes --
@@ -1079,6 +1121,7 @@ static int render_frame_impl(ChordCtx* c)
     record(c, S_HZBF);
     c->historySlot = next;                                                            // :489
     c->inFrame = false;
+    c->lastFrameLaunches = (uint32_t)(c->launchCount - c->frameLaunchBase);
     return CHORDVIS_OK;
 }
 
@@ -1092,17 +1135,42 @@ static int render_frame_impl(ChordCtx* c)
 //   phase c   row-major copy of the image + the history chain from the exchanged texels; ends the frame
 // Hosts that let the image travel beside the next frame call chordvis_frame_phase_c_finish once the small exchange has landed
 // and chordvis_frame_resolve_visibility whenever the image has.
+// The sharded group cull's first half (optional: a frame that starts at phase a culls every group on every rank, as before).
+//   phase cull   object pass + the group tests of this rank's range of count blocks -> rank-mask words in its chunk of the cull exchange buffer
+//   [all-gather of the cull exchange buffer: chordvis_cull_exchange_ptr, chunk = chordvis_cull_exchange_chunk_bytes]
+//   phase a      masks and block counts from the exchanged words, prefix + scatter (the rank's own list), then as above
+static int frame_phase_cull_impl(ChordCtx* c)
+{
+    int rc = ready(c, "frame_phase_cull");
+    if (rc) return rc;
+    if (c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_phase_cull: the context is not sharded");
+    if (c->cullPhaseDone) return fail(c, CHORDVIS_E_INVALID, "frame_phase_cull: called twice without chordvis_frame_phase_a in between");
+    if ((rc = ensure_cull_exchange(c))) return rc;
+    if (!cull_shardable(c)) return fail(c, CHORDVIS_E_INVALID, "frame_phase_cull: the sharded cull needs 2..8 ranks and the flat cull mode (start the frame at chordvis_frame_phase_a instead)");
+    begin_frame_stamps(c);
+    if ((rc = begin_frame_clear(c))) return rc;
+    record(c, S_CLEAR);
+    launch_cull_masks(c);
+    CHORD_HIP(c, hipGetLastError());
+    c->cullPhaseDone = true;
+    record(c, S_CULL);
+    return CHORDVIS_OK;
+}
+
 static int frame_phase_a_impl(ChordCtx* c)
 {
     int rc = ready(c, "frame_phase_a");
     if (rc) return rc;
     if (c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_phase_a: the context is not sharded");
-    begin_frame_stamps(c);
-    if ((rc = begin_frame_clear(c))) return rc;
-    record(c, S_CLEAR);
+    if (c->cullPhaseDone) record(c, S_EXCH_CULL);       // time spent in the all-gather of the rank masks (the library's or the caller's)
+    else {
+        begin_frame_stamps(c);
+        if ((rc = begin_frame_clear(c))) return rc;
+        record(c, S_CLEAR);
+    }
     ChordCountAndCmd post;
     // (the post-cull list is not handed out here: a rank writes only its own share of it; chordvis_last_frame_cmds, the read-back
-    // and the tile marker make the full list when they are asked for it -- from the cull's own masks, every rank culled every group)
+    // and the tile marker make the full list when they are asked for it -- from the cull's own masks, which every rank holds for every group)
     c->lazyFullList = true;
     rc = chordvis_instance_culling(c, &post);                                        // (its first kernel carries the previous frame's HZB tail)
     c->lazyFullList = false;
@@ -1114,6 +1182,7 @@ static int frame_phase_a_impl(ChordCtx* c)
     c->fuseHzb = true;
     c->fuseHzbSlot = c->historySlot == 1 ? 2 : 1;
     c->fuseHzbTemp = haveHist && (c->hView.flags & CHORD_FLAG_HZB_CULL);
+    c->exchangeSlotsFresh = true;                        // (the fused tile kernel of this frame's passes writes the rank's exchange slots)
     ChordCountAndCmd rejected;
     int stage1 = 0;
     rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1);
@@ -1161,6 +1230,10 @@ static int frame_phase_c_finish_impl(ChordCtx* c)
     int rc = ready(c, "frame_phase_c_finish");
     if (rc) return rc;
     if (c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_phase_c_finish: the context is not sharded");
+    // the history chain, the tiles' valid ranges and their loads come from the end-of-frame exchange slots, which only the fused
+    // tile kernel of chordvis_frame_phase_a / _b writes: a frame rastered with the stand-alone passes has none to unpack
+    if (!c->exchangeSlotsFresh) return fail(c, CHORDVIS_E_INVALID, "frame_phase_c: no chordvis_frame_phase_a in this frame -- the end-of-frame exchange slots are stale (a frame rastered with the stand-alone passes builds its history with chordvis_build_hzb from the resolved image)");
+    c->exchangeSlotsFresh = false;
     const int next = c->historySlot == 1 ? 2 : 1;
     launch_hzb_untile(c, c->hzb[next], true);
     CHORD_HIP(c, hipGetLastError());
@@ -1168,6 +1241,7 @@ static int frame_phase_c_finish_impl(ChordCtx* c)
     record(c, S_HZBF);
     c->historySlot = next;
     c->inFrame = false;
+    c->lastFrameLaunches = (uint32_t)(c->launchCount - c->frameLaunchBase);
     return CHORDVIS_OK;
 }
 
@@ -1189,11 +1263,12 @@ static int end_failed_frame(ChordCtx* c, int rc)
 {
     if (rc && c) {
         if (c->zeroFrameStateInCull) { (void)hipMemsetAsync(c->dFrameState, 0, c->frameStateZeroBytes, c->stream); c->zeroFrameStateInCull = false; }
-        c->inFrame = false; c->fuseHzb = false; c->pendingClear = false; c->shouldStage1 = false;
+        c->inFrame = false; c->fuseHzb = false; c->pendingClear = false; c->shouldStage1 = false; c->cullPhaseDone = false; c->exchangeSlotsFresh = false;
     }
     return rc;
 }
 int chordvis_render_frame(ChordCtx* c) { return end_failed_frame(c, render_frame_impl(c)); }
+int chordvis_frame_phase_cull(ChordCtx* c) { return end_failed_frame(c, frame_phase_cull_impl(c)); }
 int chordvis_frame_phase_a(ChordCtx* c) { return end_failed_frame(c, frame_phase_a_impl(c)); }
 int chordvis_frame_phase_b(ChordCtx* c) { return end_failed_frame(c, frame_phase_b_impl(c)); }
 int chordvis_frame_phase_c(ChordCtx* c) { return end_failed_frame(c, frame_phase_c_impl(c)); }
@@ -1510,6 +1585,7 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
     }
     out->overflow = dc.overflow;
     out->rasterLaunches = c->rasterCalls;
+    out->kernelLaunches = c->lastFrameLaunches;
     for (uint32_t i = 0; i < CHORD_LIST_SHARDS; i++) {
         out->triangleRecords += dc.triCount[i * CHORD_SHARD_STRIDE] + dc.triCountC[i * CHORD_SHARD_STRIDE];
         out->triangleRecordsCompact += dc.triCountC[i * CHORD_SHARD_STRIDE];
@@ -1526,7 +1602,7 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
     }
     if (c->timers && c->framesStamped && c->stampTags.size() > 1) {
         // walk the stamps: the segment ending at stamp i is attributed by its tag and the current stage
-        float clear = 0, cull = 0, st0 = 0, hzb0 = 0, st1 = 0, hzbf = 0, rc_ = 0, rk = 0, rh = 0, other = 0, exh = 0, exv = 0;
+        float clear = 0, cull = 0, st0 = 0, hzb0 = 0, st1 = 0, hzbf = 0, rc_ = 0, rk = 0, rh = 0, other = 0, exh = 0, exv = 0, exc = 0, exf = 0;
         int stage = 0;   // 0 = stage 0, 1 = stage 1
         for (size_t i = 1; i < c->stampTags.size(); i++) {
             const int tag = c->stampTags[i];
@@ -1544,6 +1620,8 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
             case S_HZBF: hzbf += ms; break;
             case S_EXCH_HZB: exh += ms; break;
             case S_EXCH_VIS: exv += ms; break;
+            case S_EXCH_CULL: exc += ms; break;
+            case S_EXCH_FINAL: exf += ms; break;
             default: other += ms; break;
             }
             if (tag == S_STAGE0_END) stage = 1;
@@ -1552,8 +1630,8 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
         out->msClear = clear * inv; out->msInstanceCulling = cull * inv; out->msStage0 = st0 * inv;
         out->msHzbStage0 = hzb0 * inv; out->msStage1 = st1 * inv; out->msHzbFinal = hzbf * inv;
         out->msRasterCluster = rc_ * inv; out->msRasterClip = rk * inv; out->msRasterChunk = rh * inv;
-        out->msExchangeHzb = exh * inv; out->msExchangeVis = exv * inv;
-        out->msFrame = (clear + cull + st0 + hzb0 + st1 + hzbf + other + exh + exv) * inv;
+        out->msExchangeHzb = exh * inv; out->msExchangeVis = exv * inv; out->msExchangeCull = exc * inv; out->msExchangeFinal = exf * inv;
+        out->msFrame = (clear + cull + st0 + hzb0 + st1 + hzbf + other + exh + exv + exc + exf) * inv;
         out->framesTimed = c->framesStamped;
     }
     if (c->timers == 2) { c->stampTags.clear(); c->framesStamped = 0; }

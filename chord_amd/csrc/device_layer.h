@@ -264,7 +264,9 @@ struct HzbBuffers {
 // GPU timestamp tags: a stamp closes the segment that started at the previous stamp.
 enum StampTag { S_FRAME_BEGIN = 0, S_CLEAR, S_CULL, S_HZBCULL, S_R_CLUSTER, S_R_CLIP, S_R_CHUNK, S_STAGE0_END,
                 S_HZB0, S_STAGE1_END, S_HZBF, S_OTHER,
-                S_EXCH_HZB, S_EXCH_VIS };   // sharded frames: the segment is the mid-frame HZB exchange / the visibility all-gather
+                S_EXCH_HZB, S_EXCH_VIS,     // sharded frames: the segment is the mid-frame HZB exchange / the visibility all-gather
+                S_EXCH_CULL,                // ... the all-gather of the group cull's rank masks (sharded cull)
+                S_EXCH_FINAL };             // ... the small end-of-frame exchange (library-run frames stamp it apart from the image gather)
 
 } // namespace chord
 
@@ -334,6 +336,15 @@ struct ChordCtx {
     bool lazyFullList = false;         // (set around the cull of a sharded frame inside the library) the group cull writes only the rank's list
     bool fullListStale = false;        // ... lists[0] has not been written for the last cull: launch_full_list makes it from the cull's masks
     bool listMine[3] = {false, false, false};   // lists[k] currently holds only this rank's clusters (it was culled from the rank's list)
+    // sharded group cull (chordvis_frame_phase_cull): a rank tests only its range of count blocks and writes, per group instance, one
+    // word = for each of the group's <= 4 meshlets the 8-bit set of ranks whose tiles the cluster touches (0: culled); the words of all
+    // ranks are all-gathered, and prefix + scatter run locally from them
+    uint32_t* dCullExchange = nullptr; // [ranks][cullChunkBlocks * 256 words | cullChunkBlocks triangle sums]
+    uint32_t cullChunkBlocks = 0;      // count blocks per rank = ceil(cullBlocks / ranks)
+    uint32_t cullExchangeRanks = 0;    // the rank count the buffer was made for
+    uint8_t* dTileOwner = nullptr;     // sharded: owner of every tile (what the rank masks are made from)
+    bool cullPhaseDone = false;        // this frame's chordvis_frame_phase_cull ran: phase a unpacks the exchanged words instead of culling
+    bool exchangeSlotsFresh = false;   // this frame's fused tile kernel wrote the rank's slots of the end-of-frame exchange buffer (phase c needs them)
     ChordDrawCmd* dLeftCmds = nullptr; // dense launches: the clusters the block kernel left to the record kernel (kernels_raster.hip)
     uint32_t* dCounts = nullptr;      // 4 x u32 backing the list counts
 
@@ -414,6 +425,9 @@ struct ChordCtx {
     bool depthOnly = false, depthClamp = false;
     float depthBiasConst = 0.0f, depthBiasSlope = 0.0f;
 
+    uint64_t launchCount = 0;          // kernel launches since the context was made (CHORD_LAUNCH)
+    uint64_t frameLaunchBase = 0;      // ... at the start of the current frame
+    uint32_t lastFrameLaunches = 0;    // launches of the last finished frame
     // timers: mode 0 off, 1 = last frame only, 2 = accumulate until chordvis_stats
     int timers = 0;
     std::vector<hipEvent_t> evPool;
@@ -430,6 +444,10 @@ struct ChordCtx {
     unsigned long long* dTileClocks = nullptr;   // [2][CHORD_MAX_TILES] per-tile ticks when debug bit 4 is set
 };
 
+// every kernel launch of the library goes through here: the context counts them (ChordStats::kernelLaunches -- what a sub-millisecond
+// frame is bounded by is its launch count x the launch floor)
+#define CHORD_LAUNCH(ctx, ...) do { (ctx)->launchCount++; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 namespace chord {
 
 int fail(ChordCtx* ctx, int code, const char* what, hipError_t e = hipSuccess);
@@ -444,6 +462,9 @@ int alloc_scene_work_buffers(ChordCtx* c);
 // kernel launchers (implemented in the .hip translation units) ---------------------------------
 void launch_group_cull(ChordCtx* c, const CmdList& out);
 void launch_full_list(ChordCtx* c);             // the full post-cull list of a sharded frame, when a consumer asks for it
+void launch_cull_masks(ChordCtx* c, bool wholeRange = false);   // sharded cull: objects + this rank's range of group instances -> rank-mask words (its chunk of dCullExchange)
+bool cull_shardable(const ChordCtx* c);         // the sharded cull applies: 2..8 ranks, flat cull mode, a scene and a sharded G-buffer
+int ensure_cull_exchange(ChordCtx* c);          // chordvis_abi.cpp: (re)allocates dCullExchange for the current scene / rank count
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
                      const CmdList* outRejected);
 hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles);   // first failing HIP call, or hipSuccess

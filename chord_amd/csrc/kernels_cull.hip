@@ -189,10 +189,11 @@ struct GroupCullParams {
     ShardInfo shard; float W, H; int32_t Wi, Hi; ChordDrawCmd* mineCmds; uint32_t* mineCount;
 };
 
-// Does the cluster touch one of this rank's screen tiles?  Conservative: the pixel rectangle of the 8 projected AABB corners, one
-// pixel of slack; any corner at or behind the camera plane keeps the cluster.  Dropping a cluster that fails is invisible in
-// the image -- only triangles without an owned pixel go, exactly as the per-tile ownership test of the binning would decide.
-__device__ __forceinline__ bool cluster_touches_rank(const ShardInfo& shard, const float* __restrict__ mv, const DMeshlet& m, float W, float H, int32_t Wi, int32_t Hi)
+// The screen tiles a cluster may touch.  Conservative: the pixel rectangle of the 8 projected AABB corners, one pixel of slack;
+// any corner at or behind the camera plane makes the cluster "unbounded" (every tile).  Returns 0: no tile (the rectangle lies off
+// screen), 1: the tile rectangle [tx0, tx1] x [ty0, ty1], 2: unbounded.
+__device__ __forceinline__ uint32_t cluster_tile_rect(const float* __restrict__ mv, const DMeshlet& m, float W, float H, int32_t Wi, int32_t Hi,
+                                                      uint32_t& tx0, uint32_t& ty0, uint32_t& tx1, uint32_t& ty1)
 {
     Mat4 mvp;
 #pragma unroll
@@ -209,11 +210,41 @@ __device__ __forceinline__ bool cluster_touches_rank(const ShardInfo& shard, con
         if (!(h.w > 1.0e-6f) || !(fabsf(y) < 1.0e7f) || !(fabsf(x) < 1.0e7f)) unbounded = true;
         else { xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y); }
     }
-    if (unbounded) return true;
+    if (unbounded) return 2u;
     const int32_t x0 = max((int32_t)floorf(xlo) - 1, 0), x1 = min((int32_t)ceilf(xhi) + 1, Wi - 1);
     const int32_t y0 = max((int32_t)floorf(ylo) - 1, 0), y1 = min((int32_t)ceilf(yhi) + 1, Hi - 1);
-    return x1 >= x0 && y1 >= y0 && shard_owns_any_tile(shard, (uint32_t)x0 >> CHORD_TILE_SHIFT, (uint32_t)y0 >> CHORD_TILE_SHIFT,
-                                                       (uint32_t)x1 >> CHORD_TILE_SHIFT, (uint32_t)y1 >> CHORD_TILE_SHIFT);
+    if (x1 < x0 || y1 < y0) return 0u;
+    tx0 = (uint32_t)x0 >> CHORD_TILE_SHIFT; ty0 = (uint32_t)y0 >> CHORD_TILE_SHIFT;
+    tx1 = (uint32_t)x1 >> CHORD_TILE_SHIFT; ty1 = (uint32_t)y1 >> CHORD_TILE_SHIFT;
+    return 1u;
+}
+
+// Does the cluster touch one of this rank's screen tiles?  Dropping a cluster that fails is invisible in
+// the image -- only triangles without an owned pixel go, exactly as the per-tile ownership test of the binning would decide.
+__device__ __forceinline__ bool cluster_touches_rank(const ShardInfo& shard, const float* __restrict__ mv, const DMeshlet& m, float W, float H, int32_t Wi, int32_t Hi)
+{
+    uint32_t tx0, ty0, tx1, ty1;
+    const uint32_t kind = cluster_tile_rect(mv, m, W, H, Wi, Hi, tx0, ty0, tx1, ty1);
+    if (kind != 1u) return kind == 2u;
+    return shard_owns_any_tile(shard, tx0, ty0, tx1, ty1);
+}
+
+// The same for EVERY rank at once (sharded cull): bit r = the cluster touches a tile of rank r.  A rectangle of more than 256 tiles
+// is given to every rank (conservative: the binning decides per tile); a cluster that passed the culls but whose rectangle lies off
+// screen must still be VISIBLE in the exchanged word (it takes a slot of the full list), so it goes to one rank, `nobody`.
+__device__ __forceinline__ uint32_t cluster_rank_mask(const uint8_t* __restrict__ tileOwner, uint32_t tilesX, uint32_t ranks, uint32_t nobody,
+                                                      const float* __restrict__ mv, const DMeshlet& m, float W, float H, int32_t Wi, int32_t Hi)
+{
+    const uint32_t all = (1u << ranks) - 1u;
+    uint32_t tx0, ty0, tx1, ty1;
+    const uint32_t kind = cluster_tile_rect(mv, m, W, H, Wi, Hi, tx0, ty0, tx1, ty1);
+    if (kind == 2u) return all;
+    if (kind == 0u) return 1u << nobody;
+    if ((tx1 - tx0 + 1u) * (ty1 - ty0 + 1u) > 256u) return all;
+    uint32_t mask = 0u;
+    for (uint32_t ty = ty0; ty <= ty1 && mask != all; ty++)
+        for (uint32_t tx = tx0; tx <= tx1; tx++) mask |= 1u << tileOwner[ty * tilesX + tx];
+    return mask;
 }
 
 // The object pass as a kernel of its own: for long scenes (thousands of count blocks) the fused form below makes every count
@@ -316,6 +347,87 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
     if (threadIdx.x == 0) {
         p.blockCounts[blockIdx.x] = total & 0xFFFFu; p.blockCounts[cullBlocks + blockIdx.x] = blockTris;
         if (sharded) p.blockCounts[2u * cullBlocks + blockIdx.x] = total >> 16;
+    }
+}
+
+// ---- sharded group cull (SURVEY 8e "shard by object range"; the shape it replaces: instance_culling.hlsl:133-208, one dispatch over
+// all groups on the one device the reference has) -------------------------------------------------------------------------------
+// Every rank used to read every group and cluster record (config 5: 1.1 GB, 0.22 ms of a 2.4-ms 8-rank frame -- the largest term that
+// did not shrink with the rank count).  Now rank r tests only the count blocks [r * chunkBlocks, (r + 1) * chunkBlocks) and writes, per
+// group instance, ONE WORD: byte i = the set of ranks whose screen tiles meshlet i of the group touches (0 = culled).  What travels
+// is dense and indexable -- groupInstances x 4 bytes over all ranks, one fixed-size all-gather, no counts, no variable-length lists --
+// and everything else is local again: group_mask_unpack_kernel turns the words into the per-group nibbles (visible | this rank's)
+// and the per-block counts the count kernel used to leave behind, the prefix and scatter kernels run unchanged, slots are positions
+// in the full order exactly as before, and the full list can still be made later from the masks (launch_full_list).
+struct CullMaskParams {
+    GroupCullParams g;
+    const uint8_t* tileOwner; uint32_t tilesX, ranks;
+    uint32_t firstBlock, blockCount, chunkBlocks;   // this launch's range of count blocks; blocks per chunk (the triangle sums sit behind chunkBlocks * 256 words)
+    uint32_t* out;                                  // the chunk the range belongs to
+};
+
+__global__ __launch_bounds__(256) void group_cull_masks_kernel(CullMaskParams q, const DView dv)
+{
+    const GroupCullParams& p = q.g;
+    const uint32_t lb = blockIdx.x;                               // block within the chunk
+    const uint32_t t = (q.firstBlock + lb) * 256u + threadIdx.x;
+    uint32_t word = 0, tris = 0;
+    if (lb < q.blockCount && t < p.groupInstances) {
+        const DGroupRef ref = p.groupRefs[t];
+        const uint32_t o = ref.object;
+        const DObjFrame& of = p.objFrame[o];
+        if (of.visible) {
+            const uint32_t matFlags = p.objStatic[o].matFlags;
+            const DGroup g = p.groups[ref.group & 0x0FFFFFFFu];
+            const uint32_t cnt = ref.group >> 28;
+            if (cnt != 0u && group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {     // instance_culling.hlsl:174
+                const Mat4 M = load_mat(p.objects[o].basicData.localToTranslatedWorld);
+#pragma unroll
+                for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
+                    const DMeshlet m = p.meshlets[ref.meshlet[i]];                              // :178-180
+                    if (i < cnt && meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, m)) {
+                        tris += (m.vertexTriangleCount >> 8) & 0xFFu;
+                        word |= cluster_rank_mask(q.tileOwner, q.tilesX, q.ranks, t % q.ranks, of.mvp, m, p.W, p.H, p.Wi, p.Hi) << (8u * i);
+                    }
+                }
+            }
+        }
+    }
+    q.out[lb * 256u + threadIdx.x] = word;                        // (blocks beyond the range: zeros -- defined bytes on the wire)
+    uint32_t blockTris;
+    (void)block_excl_scan(tris, &blockTris);
+    if (threadIdx.x == 0) q.out[q.chunkBlocks * 256u + lb] = blockTris;
+}
+
+// The exchanged words -> what group_cull_count_kernel<., true, .> leaves behind: groupMask (low nibble visible, high nibble this rank's)
+// and the three per-block counts.  4 bytes read + 1 written per group instance.
+struct CullUnpackParams {
+    const uint32_t* words; uint32_t chunkBlocks, rank;
+    uint8_t* groupMask; uint32_t* blockCounts; uint32_t cullBlocks, groupInstances;
+};
+
+__global__ __launch_bounds__(256) void group_mask_unpack_kernel(CullUnpackParams p)
+{
+    const uint32_t b = blockIdx.x, src = b / p.chunkBlocks, lb = b - src * p.chunkBlocks;
+    const uint32_t* __restrict__ chunk = p.words + (size_t)src * (p.chunkBlocks * 257u);
+    const uint32_t t = b * 256u + threadIdx.x;
+    uint32_t vis = 0, mine = 0;
+    if (t < p.groupInstances) {
+        const uint32_t w = chunk[lb * 256u + threadIdx.x];
+#pragma unroll
+        for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
+            const uint32_t byte = (w >> (8u * i)) & 0xFFu;
+            if (byte) vis |= 1u << i;
+            mine |= ((byte >> p.rank) & 1u) << i;
+        }
+        p.groupMask[t] = (uint8_t)(vis | (mine << 4));
+    }
+    uint32_t total;
+    (void)block_excl_scan((uint32_t)__popc(vis) | ((uint32_t)__popc(mine) << 16), &total);
+    if (threadIdx.x == 0) {
+        p.blockCounts[b] = total & 0xFFFFu;
+        p.blockCounts[p.cullBlocks + b] = chunk[p.chunkBlocks * 256u + lb];
+        p.blockCounts[2u * p.cullBlocks + b] = total >> 16;
     }
 }
 
@@ -839,7 +951,7 @@ void launch_hzb_cull_generic(ChordCtx* c, const HzbBuffers& hzb, const ChordInst
     p.inCount = in.count; p.inCmds = in.cmds; p.outCount = out.count; p.outCmds = out.cmds;
     uint32_t blocks = (in.capacity + 255u) / 256u;
     blocks = std::max(1u, std::min(blocks, (uint32_t)c->numCUs * 8u));
-    hipLaunchKernelGGL(hzb_cull_generic_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+    CHORD_LAUNCH(c, hzb_cull_generic_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
 }
 
 // ---------------------------------------------------------------------------------- launchers --
@@ -876,26 +988,35 @@ void launch_full_list(ChordCtx* c)
     const uint32_t blocks = c->cullBlocks;
     const CmdList& out = c->lists[0];
     // (the masks carry the rank's nibble too; the kernel's SHARDED form scans both halves, mineCmds NULL: nothing of the rank's list is rewritten)
-    if (blocks > 512u) hipLaunchKernelGGL((group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, 0u);
-    else               hipLaunchKernelGGL((group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, 0u);
+    if (blocks > 512u) CHORD_LAUNCH(c, (group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, 0u);
+    else               CHORD_LAUNCH(c, (group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, 0u);
     c->fullListStale = false;
 }
 
-void launch_group_cull(ChordCtx* c, const CmdList& out)
+bool cull_shardable(const ChordCtx* c)
 {
-    GroupCullParams p;
-    p.objects = c->dObjects; p.objStatic = c->dObjStatic; p.objFrame = c->dObjFrame; p.prims = c->dPrims;
-    p.groups = c->dGroups; p.groupIndices = c->dGroupIndices; p.meshlets = c->dMeshlets; p.groupRefs = c->dGroupRefs;
-    p.dview = c->dView; p.groupMask = c->dGroupMask; p.blockCounts = c->dBlockCounts; p.groupInstances = c->groupInstances;
-    p.shard = c->shard; p.W = (float)c->width; p.H = (float)c->height; p.Wi = (int32_t)c->width; p.Hi = (int32_t)c->height; p.mineCmds = nullptr; p.mineCount = nullptr;
-    c->mineValid = false;
-    if (c->shard.ranks > 1 && c->height && c->shard.ownedRows) {
-        // sharded frame: the rank's own commands leave the cull as a list of their own (no pass over the full list later)
-        if (!c->dMineCmds && hipMalloc((void**)&c->dMineCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity) != hipSuccess) c->dMineCmds = nullptr;
-        if (c->dMineCmds) { p.mineCmds = c->dMineCmds; p.mineCount = c->dCounts + 4; c->mineValid = true; }
-        else p.shard.ranks = 1;                              // (allocation failed: launch_raster falls back to the rank filter)
-    } else p.shard.ranks = 1;
-    const uint32_t blocks = c->cullBlocks;
+    const bool hier = c->cullMode == 1 && c->bvhComplete && c->dBvhNodes;
+    return c->sceneLoaded && c->shard.ranks > 1u && c->shard.ranks <= 8u && !hier && c->height && c->shard.ownedRows && c->dTileOwner && !(c->debugFlags & 524288u);
+}
+
+static FrameTail take_pending_tail(ChordCtx* c)
+{
+    FrameTail tail;
+    std::memset(&tail, 0, sizeof(tail));
+    if (c->pendingTailSlot) {                              // the previous frame's buildHZB tail: one extra workgroup
+        tail.p = make_hzb_tail_params(c, c->hzb[c->pendingTailSlot]);
+        tail.run = 1u;
+        c->pendingTailSlot = 0;
+    }
+    return tail;
+}
+
+// Sharded cull, first half (chordvis_frame_phase_cull): the object pass (every object on every rank: a rank's clusters may belong to
+// any of them; it also publishes the view, zeroes the frame's counters and carries the previous frame's HZB tail) and the group tests
+// of THIS rank's range of count blocks, into the rank's chunk of the exchange buffer.  wholeRange: every rank's chunk (measurement and
+// tests on one device: tools/shard_time.py fills the peers' chunks once).
+void launch_cull_masks(ChordCtx* c, bool wholeRange)
+{
     uint4* zeroBase = nullptr;
     uint32_t zeroVec4 = 0;
     if (c->zeroFrameStateInCull) {
@@ -904,30 +1025,67 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
         c->zeroFrameStateInCull = false;
     }
     DView* publish = c->viewDirty ? c->dView : (DView*)nullptr;
-    FrameTail tail;
-    std::memset(&tail, 0, sizeof(tail));
-    if (c->pendingTailSlot) {                              // the previous frame's buildHZB tail: one extra workgroup
-        tail.p = make_hzb_tail_params(c, c->hzb[c->pendingTailSlot]);
-        tail.run = 1u;
-        c->pendingTailSlot = 0;
+    const FrameTail tail = take_pending_tail(c);
+    CHORD_LAUNCH(c, object_cull_kernel, dim3((c->objectCount + 255u) / 256u + tail.run), dim3(256), 0, c->stream, c->dObjects, c->dObjStatic,
+                       c->dPrims, c->hView, publish, c->dObjFrame, c->objectCount, zeroBase, zeroVec4, tail, (uint4*)nullptr, 0u);
+    c->viewDirty = false;
+    CullMaskParams q;
+    q.g = make_group_cull_params(c);
+    q.tileOwner = c->dTileOwner; q.tilesX = c->tilesX; q.ranks = c->shard.ranks; q.chunkBlocks = c->cullChunkBlocks;
+    const size_t chunkWords = (size_t)c->cullChunkBlocks * 257u;
+    for (uint32_t r = wholeRange ? 0u : c->shard.rank; r < (wholeRange ? c->shard.ranks : c->shard.rank + 1u); r++) {
+        q.firstBlock = r * c->cullChunkBlocks;
+        q.blockCount = q.firstBlock < c->cullBlocks ? std::min(c->cullChunkBlocks, c->cullBlocks - q.firstBlock) : 0u;
+        q.out = c->dCullExchange + (size_t)r * chunkWords;
+        CHORD_LAUNCH(c, group_cull_masks_kernel, dim3(c->cullChunkBlocks), dim3(256), 0, c->stream, q, c->hView);
     }
+}
+
+void launch_group_cull(ChordCtx* c, const CmdList& out)
+{
+    GroupCullParams p = make_group_cull_params(c);
+    c->mineValid = false;
+    if (c->shard.ranks > 1 && c->height && c->shard.ownedRows) {
+        // sharded frame: the rank's own commands leave the cull as a list of their own (no pass over the full list later)
+        if (!c->dMineCmds && hipMalloc((void**)&c->dMineCmds, sizeof(ChordDrawCmd) * (size_t)c->cmdCapacity) != hipSuccess) c->dMineCmds = nullptr;
+        if (c->dMineCmds) { p.mineCmds = c->dMineCmds; p.mineCount = c->dCounts + 4; c->mineValid = true; }
+        else p.shard.ranks = 1;                              // (allocation failed: launch_raster falls back to the rank filter)
+    } else p.shard.ranks = 1;
+    const uint32_t blocks = c->cullBlocks;
+    const bool sh = p.shard.ranks > 1u;
+    if (c->cullPhaseDone) {
+        // sharded cull, second half: the ranks' words have been all-gathered -- masks and block counts come out of them
+        CullUnpackParams u;
+        u.words = c->dCullExchange; u.chunkBlocks = c->cullChunkBlocks; u.rank = c->shard.rank;
+        u.groupMask = c->dGroupMask; u.blockCounts = c->dBlockCounts; u.cullBlocks = blocks; u.groupInstances = c->groupInstances;
+        CHORD_LAUNCH(c, group_mask_unpack_kernel, dim3(blocks), dim3(256), 0, c->stream, u);
+        c->cullPhaseDone = false;
+    } else {
+    uint4* zeroBase = nullptr;
+    uint32_t zeroVec4 = 0;
+    if (c->zeroFrameStateInCull) {
+        zeroBase = reinterpret_cast<uint4*>(c->dFrameState);
+        zeroVec4 = (uint32_t)((c->frameStateZeroBytes + 15u) / 16u);
+        c->zeroFrameStateInCull = false;
+    }
+    DView* publish = c->viewDirty ? c->dView : (DView*)nullptr;
+    const FrameTail tail = take_pending_tail(c);
     FrameTail none;
     std::memset(&none, 0, sizeof(none));
     const bool hier = c->cullMode == 1 && c->bvhComplete && c->dBvhNodes;
-    const bool sh = p.shard.ranks > 1u;
-#define LAUNCH_COUNT(FM, FUSED, grid, ...) do { if (sh) hipLaunchKernelGGL((group_cull_count_kernel<FM, true, FUSED>), grid, dim3(256), 0, c->stream, __VA_ARGS__); \
-                                                 else    hipLaunchKernelGGL((group_cull_count_kernel<FM, false, FUSED>), grid, dim3(256), 0, c->stream, __VA_ARGS__); } while (0)
+#define LAUNCH_COUNT(FM, FUSED, grid, ...) do { if (sh) CHORD_LAUNCH(c, (group_cull_count_kernel<FM, true, FUSED>), grid, dim3(256), 0, c->stream, __VA_ARGS__); \
+                                                 else    CHORD_LAUNCH(c, (group_cull_count_kernel<FM, false, FUSED>), grid, dim3(256), 0, c->stream, __VA_ARGS__); } while (0)
     if (blocks > 512u || hier) {
         // (the mask array is a multiple of 16 bytes long: dalloc rounds nothing, so the tail is zeroed by the last partial vector
         // only when it exists -- the buffer is allocated with 16 bytes of slack, see upload_scene)
-        hipLaunchKernelGGL(object_cull_kernel, dim3((c->objectCount + 255u) / 256u + tail.run), dim3(256), 0, c->stream, c->dObjects, c->dObjStatic,
+        CHORD_LAUNCH(c, object_cull_kernel, dim3((c->objectCount + 255u) / 256u + tail.run), dim3(256), 0, c->stream, c->dObjects, c->dObjStatic,
                            c->dPrims, c->hView, publish, c->dObjFrame, c->objectCount, zeroBase, zeroVec4, tail,
                            reinterpret_cast<uint4*>(c->dGroupMask), hier ? (c->groupInstances + 15u) / 16u : 0u);
         if (hier) {
             BvhCullParams bp;
             bp.g = p; bp.nodes = c->dBvhNodes; bp.objectCount = c->objectCount;
             const uint32_t bb = std::min((c->objectCount * 9u + 3u) / 4u, (uint32_t)c->numCUs * 8u);
-            hipLaunchKernelGGL(bvh_cull_kernel, dim3(std::max(bb, 1u)), dim3(256), 0, c->stream, bp, c->hView);
+            CHORD_LAUNCH(c, bvh_cull_kernel, dim3(std::max(bb, 1u)), dim3(256), 0, c->stream, bp, c->hView);
             LAUNCH_COUNT(true, false, dim3(blocks), p, c->hView, (DView*)nullptr, (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
         } else {
             LAUNCH_COUNT(false, false, dim3(blocks), p, c->hView, (DView*)nullptr, (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
@@ -937,17 +1095,18 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     }
 #undef LAUNCH_COUNT
     c->viewDirty = false;
+    }
     // sharded frames inside the library (frame_phase_a): the full list is written when a consumer asks (launch_full_list)
     ChordDrawCmd* full = out.cmds;
     c->fullListStale = false;
     if (sh && c->lazyFullList && out.cmds == c->lists[0].cmds) { full = nullptr; c->fullListStale = true; }
     if (blocks > 512u) {
-        hipLaunchKernelGGL(group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters, p.mineCount);
-        if (sh) hipLaunchKernelGGL((group_cull_scatter_kernel<true, true>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
-        else    hipLaunchKernelGGL((group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
+        CHORD_LAUNCH(c, group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters, p.mineCount);
+        if (sh) CHORD_LAUNCH(c, (group_cull_scatter_kernel<true, true>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
+        else    CHORD_LAUNCH(c, (group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
     } else {
-        if (sh) hipLaunchKernelGGL((group_cull_scatter_kernel<false, true>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
-        else    hipLaunchKernelGGL((group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
+        if (sh) CHORD_LAUNCH(c, (group_cull_scatter_kernel<false, true>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
+        else    CHORD_LAUNCH(c, (group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
     }
 }
 
@@ -1009,7 +1168,7 @@ void launch_rank_filter(ChordCtx* c, const CmdList& in, const CmdList& out)
     const uint32_t maxBlocks = (uint32_t)c->numCUs * 8u;
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(rank_filter_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+    CHORD_LAUNCH(c, rank_filter_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
 }
 
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
@@ -1023,14 +1182,14 @@ void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdLis
     const uint32_t maxBlocks = (uint32_t)c->numCUs * (longList ? 2u : 8u);
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
-    if (phase == 0) { if (longList) hipLaunchKernelGGL((hzb_cull_kernel<0, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
-                      else          hipLaunchKernelGGL((hzb_cull_kernel<0, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
+    if (phase == 0) { if (longList) CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
+                      else          CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
     else if (c->hzbTailInCull) {
         // (inside chordvis_render_frame: the tile kernel wrote levels 0..5 of this chain; no hzb_tail_kernel ran)
-        if (longList) hipLaunchKernelGGL((hzb_cull_kernel<1, 1u, true, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
-        else          hipLaunchKernelGGL((hzb_cull_kernel<1, 1u, true>), dim3(blocks), dim3(256), 0, c->stream, p);
-    } else          { if (longList) hipLaunchKernelGGL((hzb_cull_kernel<1, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
-                      else          hipLaunchKernelGGL((hzb_cull_kernel<1, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
+        if (longList) CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
+        else          CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true>), dim3(blocks), dim3(256), 0, c->stream, p);
+    } else          { if (longList) CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
+                      else          CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
 }
 
 } // namespace chord

@@ -228,10 +228,10 @@ void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool b
     const uint32_t vw = min(p.desc.width, (((uint32_t)p.W - 1u) >> 1) + 1u), vh = min(p.desc.height, (((uint32_t)p.H - 1u) >> 1) + 1u);
     const dim3 g0((vw + 63u) / 64u, (vh + 3u) / 4u);
     p.rangePartialCount = g0.x * g0.y;
-    hipLaunchKernelGGL(hzb_mip0_kernel, g0, dim3(256), 0, c->stream, p, wantMax, wantRange);
+    CHORD_LAUNCH(c, hzb_mip0_kernel, g0, dim3(256), 0, c->stream, p, wantMax, wantRange);
     const dim3 g1((vw + 31u) / 32u, (vh + 31u) / 32u);
-    hipLaunchKernelGGL(hzb_mips_kernel, g1, dim3(256), 0, c->stream, p, wantMax);
-    if (p.desc.mipCount > 6 || wantRange) hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, wantMax, wantRange, 6u);
+    CHORD_LAUNCH(c, hzb_mips_kernel, g1, dim3(256), 0, c->stream, p, wantMax);
+    if (p.desc.mipCount > 6 || wantRange) CHORD_LAUNCH(c, hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, wantMax, wantRange, 6u);
     out.valid = true;
 }
 
@@ -241,9 +241,9 @@ void launch_hzb_build(ChordCtx* c, HzbBuffers& out, bool bMin, bool bMax, bool b
 void launch_hzb_untile(ChordCtx* c, HzbBuffers& out, bool finalChain)
 {
     const dim3 g(c->tilesX, c->tilesY);
-    if (finalChain) hipLaunchKernelGGL(hzb_untile_kernel<true>, g, dim3(256), 0, c->stream, (const uint16_t*)c->dHzbFinalExchange, c->shard, out.desc,
+    if (finalChain) CHORD_LAUNCH(c, hzb_untile_kernel<true>, g, dim3(256), 0, c->stream, (const uint16_t*)c->dHzbFinalExchange, c->shard, out.desc,
                                        out.minTexels, out.maxTexels, c->dTileRange, c->dTileLoads);
-    else            hipLaunchKernelGGL(hzb_untile_kernel<false>, g, dim3(256), 0, c->stream, (const uint16_t*)c->dHzbExchange, c->shard, out.desc,
+    else            CHORD_LAUNCH(c, hzb_untile_kernel<false>, g, dim3(256), 0, c->stream, (const uint16_t*)c->dHzbExchange, c->shard, out.desc,
                                        out.minTexels, (uint16_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     out.valid = true;
 }
@@ -261,7 +261,7 @@ void launch_hzb_tail(ChordCtx* c, HzbBuffers& out, bool bMax, bool bValidRange)
 {
     HzbParams p = make_hzb_tail_params(c, out);
     if (p.desc.mipCount > (uint32_t)CHORD_TILE_SHIFT || bValidRange)
-        hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, bMax ? 1 : 0, bValidRange ? 1 : 0, (uint32_t)CHORD_TILE_SHIFT);
+        CHORD_LAUNCH(c, hzb_tail_kernel, dim3(1), dim3(256), 0, c->stream, p, bMax ? 1 : 0, bValidRange ? 1 : 0, (uint32_t)CHORD_TILE_SHIFT);
     out.valid = true;
 }
 
@@ -278,21 +278,21 @@ __global__ __launch_bounds__(256) void depth_expand_kernel(const float* __restri
 void launch_depth_extract(ChordCtx* c, const unsigned long long* vis, float* depth, size_t words)
 {
     const uint32_t blocks = (uint32_t)std::min<size_t>((words + 255u) / 256u, (size_t)c->numCUs * 16u);
-    hipLaunchKernelGGL(depth_extract_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, c->stream, vis, depth, words);
+    CHORD_LAUNCH(c, depth_extract_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, c->stream, vis, depth, words);
 }
 void launch_depth_expand(ChordCtx* c, const float* depth, unsigned long long* vis, size_t words)
 {
     const uint32_t blocks = (uint32_t)std::min<size_t>((words + 255u) / 256u, (size_t)c->numCUs * 16u);
-    hipLaunchKernelGGL(depth_expand_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, c->stream, depth, vis, words);
+    CHORD_LAUNCH(c, depth_expand_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, c->stream, depth, vis, words);
 }
 
 void launch_detile(ChordCtx* c, hipStream_t stream)
 {
     const dim3 g(c->tilesX, c->tilesY);
     // (16-byte stores need every row start 16-byte aligned: an even width)
-    if ((c->width & 1u) == 0u) hipLaunchKernelGGL(detile_kernel, g, dim3(256), 0, stream ? stream : c->stream, (const unsigned long long*)c->dVis,
+    if ((c->width & 1u) == 0u) CHORD_LAUNCH(c, detile_kernel, g, dim3(256), 0, stream ? stream : c->stream, (const unsigned long long*)c->dVis,
                                                   (unsigned long long*)c->dVisResolved, c->width, c->height, c->shard);
-    else hipLaunchKernelGGL(detile_scalar_kernel, g, dim3(256), 0, stream ? stream : c->stream, (const unsigned long long*)c->dVis,
+    else CHORD_LAUNCH(c, detile_scalar_kernel, g, dim3(256), 0, stream ? stream : c->stream, (const unsigned long long*)c->dVis,
                             (unsigned long long*)c->dVisResolved, c->width, c->height, c->shard);
 }
 

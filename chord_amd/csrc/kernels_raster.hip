@@ -2935,14 +2935,14 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         // the longest bin of this pass in the last frame the GPU finished: a hot tile then -> the variant that draws ahead now
         const bool hot = (c->hBinHint && c->hBinHint[pass] >= SLOT_HOT) || (c->debugFlags & DBG_FORCE_HOT);
         p.slotHot = (c->debugFlags & DBG_FORCE_HOT) ? 64u : SLOT_HOT;
-        if (hot) hipLaunchKernelGGL(raster_setup_blocks_kernel<true>, dim3(bb), dim3(256), 0, c->stream, p);
-        else     hipLaunchKernelGGL(raster_setup_blocks_kernel<false>, dim3(bb), dim3(256), 0, c->stream, p);
+        if (hot) CHORD_LAUNCH(c, raster_setup_blocks_kernel<true>, dim3(bb), dim3(256), 0, c->stream, p);
+        else     CHORD_LAUNCH(c, raster_setup_blocks_kernel<false>, dim3(bb), dim3(256), 0, c->stream, p);
     }
-    if (c->anyMasked) hipLaunchKernelGGL(raster_setup_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p);
-    else              hipLaunchKernelGGL(raster_setup_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p);
+    if (c->anyMasked) CHORD_LAUNCH(c, raster_setup_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, p);
+    else              CHORD_LAUNCH(c, raster_setup_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p);
     stamp(c, S_R_CLUSTER);
-    hipLaunchKernelGGL(raster_clip_and_bin_large_kernel, dim3(CLIP_BLOCKS + (uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
-    hipLaunchKernelGGL(raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
+    CHORD_LAUNCH(c, raster_clip_and_bin_large_kernel, dim3(CLIP_BLOCKS + (uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
+    CHORD_LAUNCH(c, raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
     stamp(c, S_R_CLIP);
     // first pass of a frame: every tile is written, one block each, dispatched heaviest first; later passes touch
     // few tiles: one resident wave of blocks strides over the (device-side) active list
@@ -2953,14 +2953,14 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // (sharded frames: the work items are the rank's own tiles)
     const uint32_t tileBlocks = clearTiles ? (sh ? min(tiles, c->shard.slotsPerRank) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
     if (c->depthClamp && !sh) {
-        if (c->anyMasked) hipLaunchKernelGGL((raster_tile_kernel<false, true, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
-        else              hipLaunchKernelGGL((raster_tile_kernel<false, false, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        if (c->anyMasked) CHORD_LAUNCH(c, (raster_tile_kernel<false, true, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        else              CHORD_LAUNCH(c, (raster_tile_kernel<false, false, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
     } else if (c->anyMasked) {
-        if (sh) hipLaunchKernelGGL((raster_tile_kernel<true, true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
-        else    hipLaunchKernelGGL((raster_tile_kernel<false, true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        if (sh) CHORD_LAUNCH(c, (raster_tile_kernel<true, true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        else    CHORD_LAUNCH(c, (raster_tile_kernel<false, true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
     } else {
-        if (sh) hipLaunchKernelGGL((raster_tile_kernel<true, false, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
-        else    hipLaunchKernelGGL((raster_tile_kernel<false, false, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        if (sh) CHORD_LAUNCH(c, (raster_tile_kernel<true, false, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        else    CHORD_LAUNCH(c, (raster_tile_kernel<false, false, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
     }
     stamp(c, S_R_CHUNK);
     c->rasterCalls++;

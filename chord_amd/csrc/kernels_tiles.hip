@@ -130,7 +130,7 @@ void launch_visibility_mark(ChordCtx* c, const unsigned long long* vis, const Ch
     const uint32_t maxBlocks = (uint32_t)c->numCUs * 8u;
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1u) blocks = 1u;
-    hipLaunchKernelGGL(visibility_mark_kernel, dim3(blocks), dim3(256), 0, c->stream, vis, c->width, c->height, cmds, cmdCount,
+    CHORD_LAUNCH(c, visibility_mark_kernel, dim3(blocks), dim3(256), 0, c->stream, vis, c->width, c->height, cmds, cmdCount,
                        c->dObjStatic, reinterpret_cast<uint4*>(marker), mW, mH);
 }
 
@@ -141,9 +141,9 @@ void launch_shading_tiles(ChordCtx* c, const uint32_t* marker, uint32_t shadingT
     uint32_t blocks = (total + 1023u) / 1024u;
     if (blocks > (uint32_t)c->numCUs * 4u) blocks = (uint32_t)c->numCUs * 4u;
     if (blocks < 1u) blocks = 1u;
-    hipLaunchKernelGGL(shading_tiles_kernel, dim3(blocks), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(marker), mW, mH,
+    CHORD_LAUNCH(c, shading_tiles_kernel, dim3(blocks), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(marker), mW, mH,
                        (shadingType >> 5) & 3u, 1u << (shadingType & 31u), reinterpret_cast<uint2*>(tiles), count);
-    hipLaunchKernelGGL(shading_tile_args_kernel, dim3(1), dim3(64), 0, c->stream, count, reinterpret_cast<uint4*>(args));
+    CHORD_LAUNCH(c, shading_tile_args_kernel, dim3(1), dim3(64), 0, c->stream, count, reinterpret_cast<uint4*>(args));
 }
 
 } // namespace chord

@@ -224,6 +224,12 @@ int pipelined_frame_body(ChordCtx* c, hipEvent_t visReadyThis, hipEvent_t visRea
     c->visReadyEvent[0] = visReadyThis;
     c->visReadyEvent[1] = visReadyOther;
     const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
+    // the sharded group cull (2..8 ranks, flat mode: state every rank shares): each rank tests its share of the groups, the rank
+    // masks are all-gathered, phase a goes on from them
+    if (cull_shardable(c) && ensure_cull_exchange(c) == CHORDVIS_OK) {
+        if (!rc) rc = chordvis_frame_phase_cull(c);
+        const int e = tr.small(2, (size_t)c->cullChunkBlocks * 257u * 4u); if (!rc) rc = e;
+    }
     if (!rc) rc = chordvis_frame_phase_a(c);
     if (stage1) { const int e = tr.small(0, (size_t)c->hzbExchangeChunkHalves * 2); if (!rc) rc = e; }
     if (!rc) rc = chordvis_frame_phase_b(c);
@@ -239,10 +245,11 @@ int pipelined_frame_body(ChordCtx* c, hipEvent_t visReadyThis, hipEvent_t visRea
     return rc;
 }
 
-// the rank-major exchange buffers of a context by number: 0 = mid-frame (min chain after stage 0), 1 = end of frame
+// the rank-major exchange buffers of a context by number: 0 = mid-frame (min chain after stage 0), 1 = end of frame, 2 = the
+// sharded cull's rank masks
 static char* exchange_buffer(ChordCtx* c, int which)
 {
-    return which == 0 ? reinterpret_cast<char*>(c->dHzbExchange) : reinterpret_cast<char*>(c->dHzbFinalExchange);
+    return which == 0 ? reinterpret_cast<char*>(c->dHzbExchange) : which == 1 ? reinterpret_cast<char*>(c->dHzbFinalExchange) : reinterpret_cast<char*>(c->dCullExchange);
 }
 
 struct RcclTransport {
@@ -310,7 +317,16 @@ int comm_render_frame(ChordCtx* c)
     }
     if (c->commPipelined) return comm_render_frame_pipelined(c, r);
     const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
-    int rc = chordvis_frame_phase_a(c);
+    int rc = CHORDVIS_OK;
+    if (cull_shardable(c) && ensure_cull_exchange(c) == CHORDVIS_OK) {
+        // the sharded group cull: this rank's share of the group tests, then the rank masks of all ranks
+        rc = chordvis_frame_phase_cull(c);
+        const size_t bytes = (size_t)c->cullChunkBlocks * 257u * 4u;
+        char* base = reinterpret_cast<char*>(c->dCullExchange);
+        const int e = r->AllGather(base + (size_t)c->shard.rank * bytes, base, bytes, kNcclUint8, (NcclComm)c->comm, c->stream);
+        if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(cull exchange)", e);
+    }
+    if (!rc) rc = chordvis_frame_phase_a(c);
     if (stage1) {
         // RCCL has no 16-bit integer type; the payload is opaque f16 bits
         const size_t bytes = (size_t)c->hzbExchangeChunkHalves * 2;
@@ -324,6 +340,7 @@ int comm_render_frame(ChordCtx* c)
         char* base = reinterpret_cast<char*>(c->dHzbFinalExchange);
         int e = r->AllGather(base + (size_t)c->shard.rank * bytes, base, bytes, kNcclUint8, (NcclComm)c->comm, c->stream);
         if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(end-of-frame HZB exchange)", e);
+        stamp(c, S_EXCH_FINAL);                             // (the segment up to phase c's stamp is then the image gather alone)
         const size_t words = (size_t)c->shard.slotsPerRank * (CHORD_TILE * CHORD_TILE);
         e = r->AllGather(c->dVis + (size_t)c->shard.rank * words, c->dVis, words, kNcclUint64, (NcclComm)c->comm, c->stream);
         if (e != kNcclSuccess && !rc) rc = nccl_fail(c, r, "ncclAllGather(visibility)", e);
@@ -435,6 +452,14 @@ int run_all(ChordGroup* g, const std::function<int(uint32_t)>& fn, const char* w
 // diverged) must not leave this thread spinning forever.  The first rank to give up raises the group-wide abort flag; every
 // spin of every rank then ends at once, the frame returns CHORDVIS_E_COMM on all of them and the group stays poisoned until it
 // is destroyed (its generation counters no longer agree).
+// The limit is long on purpose (CHORDVIS_GROUP_TIMEOUT_S, default 300 s): a slow peer is legitimate -- a first frame under a profiler,
+// code-object load, a multi-second frame, N ranks time-sharing one device -- and an abort poisons the group.
+inline double group_timeout_seconds()
+{
+    static const double s = [] { const char* e = getenv("CHORDVIS_GROUP_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 300.0; }();
+    return s;
+}
+
 inline bool spin_until(const std::atomic<uint64_t>& a, uint64_t gen, std::atomic<bool>& abort)
 {
     uint32_t spins = 0;
@@ -444,7 +469,7 @@ inline bool spin_until(const std::atomic<uint64_t>& a, uint64_t gen, std::atomic
         if (++spins > 4096u) {
             if (spins == 4097u) t0 = std::chrono::steady_clock::now();
             std::this_thread::yield();
-            if ((spins & 0xFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { abort.store(true); return false; }
+            if ((spins & 0xFFFu) == 0u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > group_timeout_seconds()) { abort.store(true); return false; }
         }
     }
     return true;
@@ -630,7 +655,14 @@ int chordvis_group_render_frame(ChordGroup* g)
         // the same on every rank (they share the frame history), and taken BEFORE phase a so that a rank whose phase a
         // fails still joins the exchange its peers are about to enter
         const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
-        int rc = chordvis_frame_phase_a(c);
+        int rc = CHORDVIS_OK;
+        if (cull_shardable(c) && ensure_cull_exchange(c) == CHORDVIS_OK) {
+            rc = chordvis_frame_phase_cull(c);
+            const int e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dCullExchange); },
+                                           (size_t)c->cullChunkBlocks * 257u * 4u);
+            if (!rc) rc = e;
+        }
+        if (!rc) rc = chordvis_frame_phase_a(c);
         if (stage1) {
             const int e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dHzbExchange); },
                                            (size_t)c->hzbExchangeChunkHalves * 2);
@@ -641,6 +673,7 @@ int chordvis_group_render_frame(ChordGroup* g)
             int e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dHzbFinalExchange); },
                                      (size_t)c->hzbFinalExchangeChunkBytes);
             if (!rc) rc = e;
+            chord::stamp(c, chord::S_EXCH_FINAL);
             e = group_all_gather(g, r, 1, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dVis); }, (size_t)c->shard.slotsPerRank * (CHORD_TILE * CHORD_TILE) * 8);
             if (!rc) rc = e;
         }

@@ -64,7 +64,8 @@ class Stats(C.Structure):
         ("triangleRecordsCompact", C.c_uint64),
         ("pixelBlockBytes", C.c_uint64),
         ("pixelBlocks", C.c_uint64),
-        ("msExchangeHzb", C.c_float), ("msExchangeVis", C.c_float),
+        ("msExchangeHzb", C.c_float), ("msExchangeVis", C.c_float), ("msExchangeCull", C.c_float), ("msExchangeFinal", C.c_float),
+        ("kernelLaunches", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -147,6 +148,10 @@ def _load():
         "chordvis_visibility_stage1": (i32, [vp, P(HZB), CountAndCmd]),
         "chordvis_build_hzb": (i32, [vp, i32, i32, i32, i32, P(HZB)]),
         "chordvis_render_frame": (i32, [vp]),
+        "chordvis_frame_phase_cull": (i32, [vp]),
+        "chordvis_cull_exchange_ptr": (vp, [vp]),
+        "chordvis_cull_exchange_chunk_bytes": (u64, [vp]),
+        "chordvis_debug_fill_cull_exchange": (i32, [vp]),
         "chordvis_frame_phase_a": (i32, [vp]),
         "chordvis_frame_phase_b": (i32, [vp]),
         "chordvis_frame_phase_c": (i32, [vp]),

@@ -158,6 +158,18 @@ class VisibilityRenderer:
     def render_frame(self):
         self._check(L.lib.chordvis_render_frame(self._ctx), "render_frame")
 
+    def frame_phase_cull(self):
+        """Sharded group cull, first half: this rank's share of the group tests -> rank-mask words (all-gather cull_exchange() next)."""
+        self._check(L.lib.chordvis_frame_phase_cull(self._ctx), "frame_phase_cull")
+
+    def cull_exchange(self):
+        """(device pointer, bytes per rank) of the sharded cull's exchange buffer; (None, 0) when the sharded cull does not apply."""
+        return (L.lib.chordvis_cull_exchange_ptr(self._ctx), int(L.lib.chordvis_cull_exchange_chunk_bytes(self._ctx)))
+
+    def debug_fill_cull_exchange(self):
+        """Measurement aid: every rank's chunk of the cull exchange buffer computed on this context (one rank timed alone)."""
+        self._check(L.lib.chordvis_debug_fill_cull_exchange(self._ctx), "debug_fill_cull_exchange")
+
     def frame_phase_a(self):
         self._check(L.lib.chordvis_frame_phase_a(self._ctx), "frame_phase_a")
 

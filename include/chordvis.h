@@ -30,6 +30,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libchordvis.so is built with -fvisibility=hidden: the entry points declared in this header are its ONLY dynamic symbols (the
+ * library's C++ internals live in a namespace `chord`, which is also the reference's -- a host must never see them). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define CHORDVIS_OK              0
 #define CHORDVIS_E_INVALID      -1   /* bad argument / call order            */
@@ -123,6 +128,10 @@ typedef struct ChordStats {
                                       kernel drew ahead and left empty -- a few per wave and hot tile) */
     float    msExchangeHzb;        /* sharded frames: stream time between phase a and phase b = the all-gather of the HZB mip-0 exchange buffer */
     float    msExchangeVis;        /* ... between phase b and phase c = the all-gather of the visibility words (incl. waiting for the slowest rank) */
+    float    msExchangeCull;       /* ... between phase cull and phase a = the all-gather of the group cull's rank masks (sharded cull) */
+    float    msExchangeFinal;      /* ... library-run frames (chordvis_comm_*, ChordGroup): the small end-of-frame exchange, stamped apart from the image
+                                      gather (msExchangeVis is then the image alone); 0 when the host drives the phases */
+    uint32_t kernelLaunches;       /* kernel launches of the last finished frame (a sub-millisecond frame is bounded by launches x launch floor) */
 } ChordStats;
 
 /* ------------------------------------------------------------------ host-only (no device needed) */
@@ -302,6 +311,11 @@ int chordvis_build_hzb(ChordCtx* ctx, int bBuildMin, int bBuildMax, int bBuildVa
  * the next call.  On a sharded context (ranks > 1) this needs a communicator (chordvis_comm_init_rank below) and runs the
  * three phases with the two all-gathers in between; a host that owns its collectives (e.g. torch.distributed) drives
  * the phases itself -- on the context's stream, so that kernels and collectives are ordered:
+ *   chordvis_frame_phase_cull  (optional; 2..8 ranks, flat cull mode) the sharded group cull (SURVEY 8e "shard by object range"): the
+ *                           object pass + the group / meshlet tests of THIS rank's share of the group instances only, one word per group
+ *                           instance into the rank's chunk of the cull exchange buffer: byte i = the set of ranks whose tiles meshlet i of the
+ *                           group touches, 0 = culled.  A frame that starts at phase a instead tests every group on every rank.
+ *   [all-gather the cull exchange buffer: chordvis_cull_exchange_ptr, chunk = chordvis_cull_exchange_chunk_bytes]
  *   chordvis_frame_phase_a  clear .. stage 0 raster of the rank's tiles; the tile kernel also reduces every tile to its HZB texels
  *                           (mips 0..5), into the tile's slots of the two exchange buffers
  *   [all-gather the mid-frame exchange buffer: chordvis_hzb_exchange_ptr, chunk = chordvis_hzb_exchange_chunk_halves]
@@ -309,6 +323,11 @@ int chordvis_build_hzb(ChordCtx* ctx, int bBuildMin, int bBuildMax, int bBuildVa
  *   [all-gather the end-of-frame exchange buffer (chordvis_hzb_final_exchange_ptr / _chunk_bytes) and the visibility buffer, in place]
  *   chordvis_frame_phase_c  row-major copy of the image, history HZB from the exchanged texels, history swap            */
 int chordvis_render_frame(ChordCtx* ctx);
+int chordvis_frame_phase_cull(ChordCtx* ctx);
+/* cull exchange buffer: ranks x (B x 256 mask words + B triangle sums), B = ceil(count blocks / ranks); made on the first request after
+ * chordvis_upload_scene + chordvis_set_shard (NULL / 0 when the sharded cull does not apply: one rank, more than 8, no scene) */
+uint32_t* chordvis_cull_exchange_ptr(ChordCtx* ctx);
+uint64_t chordvis_cull_exchange_chunk_bytes(ChordCtx* ctx);   /* one rank */
 int chordvis_frame_phase_a(ChordCtx* ctx);
 int chordvis_frame_phase_b(ChordCtx* ctx);
 int chordvis_frame_phase_c(ChordCtx* ctx);
@@ -485,8 +504,12 @@ int chordvis_stats(ChordCtx* ctx, ChordStats* out);
  * (by default it does when a launch has more than one cluster per 16 pixels), 131072 chordvis_render_frame launches
  * hzb_tail_kernel between the raster passes instead of letting the phase-1 cull reduce HZB levels 6.. itself, 262144 the
  * pixel-block kernel always runs its hot-tile variant and treats a bin of 64 entries as hot (by default the variant is chosen
- * when the previous frame had a bin of 65536 entries or more). */
+ * when the previous frame had a bin of 65536 entries or more), 524288 the library's own sharded frames (chordvis_comm_*, ChordGroup)
+ * keep the replicated group cull instead of the sharded one (A / B measurements; every rank of a frame must agree). */
 int chordvis_set_debug(ChordCtx* ctx, uint32_t flags);
+/* measurement / test aid: fills EVERY rank's chunk of the cull exchange buffer on this context for the current view (what the
+ * all-gather would deliver), so that one rank of a sharded frame can be timed alone on one device (tools/shard_time.py) */
+int chordvis_debug_fill_cull_exchange(ChordCtx* ctx);
 /* debugging aid: raw read of an internal buffer (0 tile counts, 1 fixed bins, 2 chunk table, 3 bin pool, 4 / 5 32- / 48-byte records) */
 int chordvis_debug_read(ChordCtx* ctx, int which, uint64_t offset, uint64_t bytes, void* host);
 /* debugging aid: non-zero words in the split-tile accumulation slabs (must be 0 between raster passes) */
@@ -499,6 +522,9 @@ int chordvis_debug_graph_frames(ChordCtx* ctx, uint32_t pairs, float* msPerFrame
 int chordvis_debug_setup_profile(ChordCtx* ctx, int pass, uint64_t hostTicks[5], uint32_t* waves);
 int chordvis_debug_tile_profile(ChordCtx* ctx, int pass, uint64_t* hostTicks, uint32_t* hostCounts, uint32_t capacity);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,12 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert not missing, "declared in include/chordvis.h but not exported: %s" % missing
     assert set(declared) == set(built_lib.EXPORTED), "chord_amd/lib.py prototypes out of sync with the header"
     assert b"gfx950" in built_lib.lib.chordvis_version()
+    # ... and NOTHING else: the library's C++ internals live in a namespace `chord` (the reference's own), kernels have host-side
+    # handles; none of it may be a dynamic symbol of the drop-in (-fvisibility=hidden + csrc/chordvis.map)
+    nm = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True, text=True)
+    assert nm.returncode == 0, nm.stderr
+    exported = sorted(ln.split()[-1] for ln in nm.stdout.splitlines() if ln.strip())
+    assert exported == declared, "dynamic symbols beyond the header's: %s" % sorted(set(exported) - set(declared))[:8]
 
 
 def test_record_layouts_match_the_header():

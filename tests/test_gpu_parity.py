@@ -523,6 +523,7 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, r
     from chord_amd.sharding import TileLayout
     scene, cam, view, iv = H.setup_scene(builder)
     w, h, flags = cam.width, cam.height, H.ALL_FLAGS
+    case_index = [c[0] for c in SHARDED].index(name)
     # the hotspot scene puts ~300 k records into its hottest tile when rendered unsharded in the record form (the single-GPU
     # reference below): beyond the default 16 Ki + 240 Ki entries per tile, so it runs under the documented raised limit
     limits = dict(bin_max_chunks_per_tile=2048) if name.startswith("hotspot") else None
@@ -571,6 +572,14 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, r
             prev_hzb = o["hzb_min"]
             H.assert_vis_equal(want, o["vis"], w, h, "frame %d single-GPU vs oracle" % frame)
             want = o["vis"]                              # the ranks below are compared with the oracle's image
+        # the sharded group cull (every frame but frame 0 of every other case, which starts at phase a: the replicated cull): each
+        # rank tests its share of the group instances, the rank-mask words are all-gathered, phase a goes on from them
+        if frame > 0 or case_index % 2 == 0:
+            for r in ctxs:
+                r.frame_phase_cull()
+            cx = [r.cull_exchange() for r in ctxs]
+            assert all(c[0] and c[1] == cx[0][1] for c in cx)
+            gather([c[0] for c in cx], cx[0][1])
         for r in ctxs:
             r.frame_phase_a()
         ex = [r.hzb_exchange() for r in ctxs]
@@ -591,7 +600,10 @@ def test_sharded_frames_reassemble_to_the_single_gpu_image(gpu, name, builder, r
         # frame and makes the whole list when a consumer asks -- identical to the single-GPU list, slots included; the tile marker
         # of a rank (which reads it) equals the single-GPU marker
         if frame == 1:
-            want_cmds = ref.read_cmds(ref.last_frame_cmds())
+            # (the ORACLE's command array, slots included -- in every case; the single-GPU list must be the same array)
+            import orc
+            want_cmds = orc.instance_culling(scene, view, iv, flags)
+            assert np.array_equal(ref.read_cmds(ref.last_frame_cmds()), want_cmds)
             for r in (ctxs[0], ctxs[-1]):
                 assert np.array_equal(r.read_cmds(r.last_frame_cmds()), want_cmds)
             assert np.array_equal(ctxs[1].read_tile_marker(ctxs[1].visibility_mark()), ref.read_tile_marker(ref.visibility_mark()))

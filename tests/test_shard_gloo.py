@@ -96,6 +96,99 @@ def test_weighted_tile_map_balances_hotspots_and_skies(built_lib):
     check(np.load(os.path.join(prof, "r04_tile_loads_config4.npy")), 1.08)
 
 
+# ---- the sharded group cull's exchange on the host (mirrors kernels_cull.hip: group_cull_masks_kernel / group_mask_unpack_kernel) ----
+def _group_instance_table(scene):
+    """The flattened (object, group) instances in the library's order (DGroupRef, chordvis_upload_scene): (owner object [G], global
+    meshlet ids [G, 4], -1 = no such meshlet)."""
+    O = scene.objects
+    prim = scene.primitives[O["GLTFPrimitiveDetail"]]
+    counts = prim["meshletGroupCount"].astype(np.int64)
+    owner = np.repeat(np.arange(len(O)), counts)
+    gi = np.arange(len(owner)) - np.repeat(np.cumsum(counts) - counts, counts)
+    p = prim[owner]
+    g = scene.groups[p["meshletGroupOffset"].astype(np.int64) + gi]
+    meshlet = np.full((len(owner), 4), -1, dtype=np.int64)
+    for i in range(4):
+        has = g["meshletCount"] > i
+        idx = p["meshletGroupIndicesOffset"][has].astype(np.int64) + g["meshletOffset"][has].astype(np.int64) + i
+        meshlet[has, i] = p["meshletOffset"][has].astype(np.int64) + scene.group_indices[idx]
+    return owner, meshlet
+
+
+def _cluster_rank_mask(scene, iv, lay, obj, mid, nobody):
+    """Bit r = the cluster's pixel rectangle (8 projected AABB corners, one pixel of slack) touches a tile of rank r; a corner at or
+    behind the camera plane: every rank; a rectangle off screen: the one rank `nobody` (the cluster still takes a slot)."""
+    import spec_np as S
+    f32 = np.float32
+    M = S.mat(scene.objects["localToTranslatedWorld"][obj][None])[0]
+    VP = S.mat(iv["translatedWorldToClip"])[0]
+    mvp = S.mul_mm(VP, M)
+    m = scene.meshlets[mid]
+    lo, hi = m["posMin"].astype(f32), m["posMax"].astype(f32)
+    xs, ys = [], []
+    W, H = f32(lay.width), f32(lay.height)
+    with np.errstate(all="ignore"):
+        for q in range(8):
+            c = [hi[k] if (q >> k) & 1 else lo[k] for k in range(3)]
+            h = S.mul_mv(mvp, c[0], c[1], c[2])
+            x = (h[0] / h[3] * f32(0.5) + f32(0.5)) * W
+            y = (h[1] / h[3] * f32(-0.5) + f32(0.5)) * H
+            if not (h[3] > f32(1e-6)) or not (abs(y) < f32(1e7)) or not (abs(x) < f32(1e7)):
+                return (1 << lay.ranks) - 1
+            xs.append(float(x)); ys.append(float(y))
+    x0, x1 = max(int(np.floor(min(xs))) - 1, 0), min(int(np.ceil(max(xs))) + 1, lay.width - 1)
+    y0, y1 = max(int(np.floor(min(ys))) - 1, 0), min(int(np.ceil(max(ys))) + 1, lay.height - 1)
+    if x1 < x0 or y1 < y0:
+        return 1 << nobody
+    mask = 0
+    for ty in range(y0 // 64, y1 // 64 + 1):
+        for tx in range(x0 // 64, x1 // 64 + 1):
+            mask |= 1 << int(lay.owners[ty * lay.tiles_x + tx])
+    return mask
+
+
+def _cull_exchange_chunk(scene, iv, lay, cmds, table, rank, chunk_blocks):
+    """This rank's chunk of the cull exchange buffer: chunk_blocks x 256 words (byte i = the rank set of meshlet i of the group
+    instance, 0 = culled) followed by chunk_blocks triangle sums -- from the commands of the rank's OWN range of group instances."""
+    owner, meshlet = table
+    first, last = rank * chunk_blocks * 256, (rank + 1) * chunk_blocks * 256
+    where = {}
+    for t in range(first, min(last, len(owner))):
+        for i in range(4):
+            if meshlet[t, i] >= 0:
+                assert (int(owner[t]), int(meshlet[t, i])) not in where
+                where[(int(owner[t]), int(meshlet[t, i]))] = (t, i)
+    chunk = np.zeros(chunk_blocks * 257, dtype=np.uint32)
+    for cmd in cmds:
+        key = (int(cmd["objectId"]), int(cmd["meshletId"]))
+        if key in where:
+            t, i = where[key]
+            chunk[t - first] |= np.uint32(_cluster_rank_mask(scene, iv, lay, key[0], key[1], t % lay.ranks) << (8 * i))
+            chunk[chunk_blocks * 256 + (t - first) // 256] += (int(scene.meshlets["vertexTriangleCount"][key[1]]) >> 8) & 0xFF
+    return chunk
+
+
+def _cull_exchange_unpack(words, table, world, chunk_blocks, rank):
+    """All ranks' chunks -> (the full command list in (object, group, meshlet) order with its slots, this rank's own commands, the
+    triangle total): what prefix + scatter make of the exchanged words."""
+    from chord_amd import records as R
+    owner, meshlet = table
+    full, mine, tris = [], [], 0
+    for t in range(len(owner)):
+        src, lb = divmod(t // 256, chunk_blocks)
+        w = int(words[src * chunk_blocks * 257 + lb * 256 + t % 256])
+        for i in range(4):
+            byte = (w >> (8 * i)) & 0xFF
+            if byte:
+                cmd = (int(owner[t]), int(meshlet[t, i]), len(full))
+                full.append(cmd)
+                if (byte >> rank) & 1:
+                    mine.append(cmd)
+    for src in range(world):
+        tris += int(words[src * chunk_blocks * 257 + chunk_blocks * 256: (src + 1) * chunk_blocks * 257].sum())
+    return np.array(full, dtype=R.DRAW_CMD).reshape(-1), np.array(mine, dtype=R.DRAW_CMD).reshape(-1), tris
+
+
 def _worker(rank, world, port, tmp):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -130,13 +223,28 @@ def _worker(rank, world, port, tmp):
         shard = (lay.owners, lay.tiles_x, world, rank)
         own_px = lay.owner_of_pixels() == rank
         want = orc.frame(scene, view, iv, flags, prev_hzb_min=prev_hzb)       # the single-rank frame
-        # ---- phase a: cull (replicated, deterministic), phase-0 HZB cull, raster own tiles --------
-        cmds = orc.instance_culling(scene, view, iv, flags)
+        # ---- phase cull + exchange #0: the group cull sharded by ranges of group instances; what travels is one word per group
+        #      instance (byte i = the set of ranks whose tiles meshlet i touches, 0 = culled), a fixed-size all-gather ----------
+        cmds = orc.instance_culling(scene, view, iv, flags)                  # (what ONE rank culling every group gets: the reference)
+        table = _group_instance_table(scene)
+        chunk_blocks = -(-(-(-len(table[0]) // 256)) // world)
+        ex0 = np.zeros((world, chunk_blocks * 257), dtype=np.uint32)
+        ex0[rank] = _cull_exchange_chunk(scene, iv, lay, cmds, table, rank, chunk_blocks)
+        ex0 = all_gather_rows(ex0)
+        full_cmds, my_cmds, tris = _cull_exchange_unpack(ex0.reshape(-1), table, world, chunk_blocks, rank)
+        assert np.array_equal(full_cmds, cmds), "the list rebuilt from the exchanged rank masks differs from the single-rank cull (slots included)"
+        assert tris == int(((scene.meshlets["vertexTriangleCount"][cmds["meshletId"]] >> 8) & 0xFF).sum())
+        assert 0 < len(my_cmds) <= len(cmds)
+        # ---- phase a: phase-0 HZB cull and raster of the rank's OWN commands (the clusters that touch its tiles) --------
         if prev_hzb is not None:
-            vis_list, rej = orc.hzb_culling(scene, view, flags, 0, desc, prev_hzb, cmds)
+            vis_list, rej = orc.hzb_culling(scene, view, flags, 0, desc, prev_hzb, my_cmds)
+            full_vis_list, _ = orc.hzb_culling(scene, view, flags, 0, desc, prev_hzb, cmds)
         else:
-            vis_list, rej = cmds, cmds[:0]
+            vis_list, rej = my_cmds, my_cmds[:0]
+            full_vis_list = cmds
         mine, _ = orc.raster(scene, iv, vis_list, w, h, shard=shard)
+        # (dropping the clusters that touch none of the rank's tiles changes nothing in its tiles)
+        assert np.array_equal(mine, orc.raster(scene, iv, full_vis_list, w, h, shard=shard)[0])
         mine = mine.reshape(h, w)
         assert not mine[~own_px].any()                                         # only owned tiles written
         if prev_hzb is not None:
@@ -147,7 +255,7 @@ def _worker(rank, world, port, tmp):
             lay.unpack_hzb_slots(desc, slots, chain)
             S.hzb_tail(desc, chain)
             # must equal the HZB of the full stage-0 image, which the single-rank oracle builds internally; rebuild it here to compare
-            full0, _ = orc.raster(scene, iv, vis_list, w, h)
+            full0, _ = orc.raster(scene, iv, full_vis_list, w, h)
             _, want_mn, _, _ = orc.hzb_build(full0, w, h)
             for l in range(desc.mipCount):
                 mw, mh = desc.mip_dims(l); vw, vh = desc.valid_dims(l)

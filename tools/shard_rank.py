@@ -24,6 +24,9 @@ if len(sys.argv) > 4:
     loads = np.load(sys.argv[4])
     r.set_tile_owners(tile_layout(cam.width, cam.height, ranks, loads, int(L.lib.chordvis_tile_slot_capacity(cam.width, cam.height, ranks))))
 r.update_objects(objs); r.set_view(view, iv, flags)
+sharded_cull = ranks > 1 and ranks <= 8 and os.environ.get("CULL", "sharded") != "replicated"
+if sharded_cull:
+    r.debug_fill_cull_exchange()                         # (the peers' chunks of the rank-mask exchange: the view is static)
 r.enable_timers(2)
 n = int(os.environ.get("FRAMES", "10"))
 for i in range(3 + n):
@@ -32,6 +35,8 @@ for i in range(3 + n):
     if ranks == 1:
         r.render_frame()
     else:
+        if sharded_cull:
+            r.frame_phase_cull()
         r.frame_phase_a(); r.frame_phase_b(); r.frame_phase_c()
 r.sync()
 st = r.stats()

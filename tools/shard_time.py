@@ -6,7 +6,11 @@ workloads a rank culls against an HZB that only holds its own tiles: an upper bo
 The tile map: MAP=default (compact regions of equal area), MAP=balanced (chordvis_tile_layout from the loads of a frame rendered
 under the default map -- what chordvis_rebalance installs on every rank after the end-of-frame exchange), MAP=both (default).
 
-  python tools/shard_time.py [workload]      RANKS=1,2,4,8  MAP=both  PIPELINED=1  COLLECTIVES_MS=0.3
+The group cull is the SHARDED one by default (a rank tests its share of the group instances; the peers' chunks of the rank-mask
+exchange are filled once, outside the clock, by chordvis_debug_fill_cull_exchange -- the view is static); CULL=replicated measures the
+round-4 form (every rank tests every group).
+
+  python tools/shard_time.py [workload]      RANKS=1,2,4,8  MAP=both  PIPELINED=1  COLLECTIVES_MS=0.3  CULL=sharded|replicated
 """
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,19 +35,27 @@ r.upload_scene(scene)
 single = None
 
 
+cull_modes = {"sharded": [True], "replicated": [False], "both": [False, True]}[os.environ.get("CULL", "sharded")]
+sharded_cull = cull_modes[0]
+
+
 def frame(ranks):
     if ranks == 1:
         r.render_frame()
-    elif os.environ.get("PIPELINED") == "1":
-        # the pipelined protocol's critical path: no visibility gather, no row-major copy
+        return
+    if os.environ.get("PIPELINED") == "1":
         L.lib.chordvis_swap_visibility(r._ctx)
+    if sharded_cull and ranks <= 8:
+        r.frame_phase_cull()                             # (the peers' chunks are in the buffer already)
+    if os.environ.get("PIPELINED") == "1":
+        # the pipelined protocol's critical path: no visibility gather, no row-major copy
         r.frame_phase_a(); r.frame_phase_b()
         assert L.lib.chordvis_frame_phase_c_finish(r._ctx) == 0
     else:
         r.frame_phase_a(); r.frame_phase_b(); r.frame_phase_c()
 
 
-for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
+for ranks, sharded_cull in [(int(x), m) for x in os.environ.get("RANKS", "1,2,4,8").split(",") for m in (cull_modes if int(x) > 1 else cull_modes[:1])]:
     loads = None
     for which in (maps if ranks > 1 else ["-"]):
         per_rank, stamps0, owners, detail = [], None, None, []
@@ -57,6 +69,8 @@ for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
                 r.set_tile_owners(owners)                   # (None: the default map)
             r.reset_history()
             r.update_objects(objs); r.set_view(view, iv, flags)
+            if ranks > 1 and ranks <= 8 and sharded_cull:
+                r.debug_fill_cull_exchange()
             r.enable_timers(2)
             for _ in range(3):
                 frame(ranks)
@@ -92,9 +106,9 @@ for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8").split(",")]:
                 per.max() / max(per.mean(), 1.0), np.bincount(own, minlength=ranks).min(), np.bincount(own, minlength=ranks).max(), " ".join(detail))
         if only_balanced and which == "default":
             continue
-        print("ranks %d (map %s): worst rank %.3f ms/frame, mean %.3f, max/mean %.3f%s%s; per rank %s;  rank-0 GPU stamps (ms): cull %.3f stage0 %.3f hzb0 %.3f stage1 %.3f hzbFinal %.3f | setup %.3f clip+order %.3f tile %.3f"
+        print("ranks %d (map %s): worst rank %.3f ms/frame, mean %.3f, max/mean %.3f%s%s; per rank %s;  rank-0 GPU stamps (ms): cull %.3f (%s) stage0 %.3f hzb0 %.3f stage1 %.3f hzbFinal %.3f | setup %.3f clip+order %.3f tile %.3f"
               % (ranks, which, worst, mean, worst / mean,
                  ("; speed-up with %.2f ms of collectives: %.2fx" % (coll, single / (worst + coll))) if single and ranks > 1 else "", extra,
-                 " ".join("%.3f" % v for v in per_rank), st["msInstanceCulling"], st["msStage0"], st["msHzbStage0"], st["msStage1"], st["msHzbFinal"],
+                 " ".join("%.3f" % v for v in per_rank), st["msInstanceCulling"], "sharded" if (sharded_cull and 1 < ranks <= 8) else "replicated", st["msStage0"], st["msHzbStage0"], st["msStage1"], st["msHzbFinal"],
                  st["msRasterCluster"], st["msRasterClip"], st["msRasterChunk"]), flush=True)
 r.close()
