@@ -615,6 +615,7 @@ def measure(args, workload, env):
             "clusters_rastered_per_step": clusters_per_frame, "triangle_records_per_step": recs, "bin_entries_per_step": bins, "pixel_blocks_per_step": blocks, "pixel_block_bytes_per_step": block_bytes,
             "gpu_ms": {k: round(st[k], 4) for k in ("msClear", "msInstanceCulling", "msStage0", "msHzbStage0", "msStage1",
                                                      "msHzbFinal", "msFrame", "msRasterCluster", "msRasterClip", "msRasterChunk")},
+            "kernel_launches": st["kernelLaunches"],
             "tiles_touched_view_a": per_view[0]["tilesTouched"], "tiles_total": ((W + 63) // 64) * ((H + 63) // 64),
             "counts_view_a": {k: per_view[0][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},
             "counts_view_b": {k: per_view[1][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},

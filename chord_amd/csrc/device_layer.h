@@ -192,6 +192,11 @@ struct TriRecC {
 // ceil(65536 / w) in the high half), then w x h words, row-major.  Its bin entry is CHORD_REC_BLOCK | granule offset.
 #define CHORD_REC_BLOCK 0xC0000000u
 #define CHORD_REC_INDEX_MASK 0x3FFFFFFFu
+// A bin entry that names the 48-byte record of an alpha-tested (masked) triangle: CHORD_REC_WIDE with bit 29 set.  Such entries are
+// scan-converted by a pass of their own (raster_masked_tile_kernel) and skipped by the tile kernel, which therefore needs to look at
+// nothing but the bin word.  Indices of the 48-byte list stay below 2^29 (chordvis_set_limits caps the list at 0x7FFFFFC0 / 4 records).
+#define CHORD_REC_MASKED 0xA0000000u
+#define CHORD_REC_WIDE_INDEX 0x1FFFFFFFu
 #define CHORD_BLOCK_WIN 16
 struct ClipTri { uint32_t objectId, meshletId, slot, tri; };    // needs the homogeneous clipper (the draw command rides along: the setup kernels read different lists)
 

@@ -751,7 +751,9 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
     const uint32_t offs = block_excl_scan(sharded ? (uint32_t)__popc(mask) | ((uint32_t)__popc(mine) << 16) : (uint32_t)__popc(mask), &total);
     const uint32_t off = offs & 0xFFFFu;
     uint32_t tris = 0;
-    if (mask) {
+    // (a sharded frame that writes only the rank's own list reads the group's reference -- 24 bytes -- only where the rank has a cluster:
+    // an eighth of them on 8 ranks; the slots need nothing but the counts)
+    if (mask && (outCmds || mine || !PREFIXED)) {
         const DGroupRef ref = p.groupRefs[t];
         uint32_t slot = blockBase + off, mslot = mineBase + (offs >> 16);
         for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {

@@ -57,6 +57,13 @@ namespace chord {
 // block path: a block's bin slot and the block count travel in a single atomic), 2 = ticket of the slices of a split tile
 #define TC_BLOCKS 1u
 #define TC_TICKET 2u
+// Where alpha-tested triangles are scan-converted: 0 = in raster_masked_tile_kernel, a pass of their own in front of the tile kernel
+// (whose only instantiations are then the opaque ones); 1 = inside the tile kernel's MASKED instantiations, in a pass of their own
+// over the batch's units (the form of rounds 2-4, kept as a build switch for the A/B: profiles/r05_masked_variants.txt)
+#ifndef CHORD_MASKED_FUSED
+#define CHORD_MASKED_FUSED 1
+#endif
+#define TC_MASKED 3u            // 3 = the bin holds entries of alpha-tested triangles (a flag, plain stores: raster_masked_tile_kernel's work list)
 
 struct RasterParams {
     const uint32_t* count; const ChordDrawCmd* cmds;
@@ -411,7 +418,7 @@ struct BinTicket {
 
 template <class P>
 __device__ __forceinline__ void wave_bin_issue(const P& p, bool emitA, const TriSetup& tsA, bool emitB, const TriSetup& tsB,
-                                               uint32_t lane, BinTicket& k)
+                                               uint32_t lane, BinTicket& k, const bool masked = false)
 {
     auto tile_of = [&](const TriSetup& ts, int r, bool emit, uint32_t& tile) -> bool {
         const int32_t tx0 = ts.px0 >> TILE_SHIFT, tx1 = ts.px1 >> TILE_SHIFT, ty0 = ts.py0 >> TILE_SHIFT, ty1 = ts.py1 >> TILE_SHIFT;
@@ -436,6 +443,17 @@ __device__ __forceinline__ void wave_bin_issue(const P& p, bool emitA, const Tri
     for (int r = 1; r < 4; r++) {
         if (k.has & (1u << r)) k.slotA[r] = atomicAdd(&p.tileCount[(size_t)k.tileA[r] * TC_STRIDE], 1u);
         if (k.has & (16u << r)) k.slotB[r] = atomicAdd(&p.tileCount[(size_t)k.tileB[r] * TC_STRIDE], 1u);
+    }
+    if (masked) {
+        // an alpha-tested cluster: the tiles its triangles are binned into are work items of the masked pass (a flag per tile, plain
+        // stores of the same value: one per distinct primary tile of the wave, one per straddled tile of a lane)
+        if ((k.has & 1u) && (int)lane == k.eA.leader) p.tileCount[(size_t)k.tileA[0] * TC_STRIDE + TC_MASKED] = 1u;
+        if ((k.has & 16u) && (int)lane == k.eB.leader) p.tileCount[(size_t)k.tileB[0] * TC_STRIDE + TC_MASKED] = 1u;
+#pragma unroll
+        for (int r = 1; r < 4; r++) {
+            if (k.has & (1u << r)) p.tileCount[(size_t)k.tileA[r] * TC_STRIDE + TC_MASKED] = 1u;
+            if (k.has & (16u << r)) p.tileCount[(size_t)k.tileB[r] * TC_STRIDE + TC_MASKED] = 1u;
+        }
     }
 }
 
@@ -758,7 +776,12 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
     const bool sprof = RASTER_PROFILE && (p.debug & DBG_SETUP_CLOCKS) != 0;
     unsigned long long sph[5] = {0, 0, 0, 0, 0}, stp = sprof ? wall_clock64() : 0ull;
 #define SPHASE(i) do { if (sprof) { const unsigned long long tn = wall_clock64(); sph[i] += tn - stp; stp = tn; } } while (0)
+    const uint32_t laneTop = lane;
     for (; c < count; c += stride) {
+        // (the lane index of this cluster goes through an empty asm: what the body derives from it is invariant over the cluster
+        // loop and would otherwise be hoisted out of it and held in registers across the whole kernel -- raster_tile_kernel: 25 VGPRs)
+        uint32_t lane = laneTop;
+        asm volatile("" : "+v"(lane));
         const uint32_t slot = hdr.slot, V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
         const bool twoSided = hdr.twoSided || p.depthOnly != 0u;                       // depth passes: cull mode NONE (mesh_raster.cpp:188-190)
         const bool masked = MASKED && CHORD_MATFLAG_ALPHA(hdr.matFlags) == CHORD_ALPHA_MASK;      // (wave-uniform)
@@ -895,7 +918,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
                 if (nLg) lbase = atomicAdd(&e.counters->largeCount[p.pass][listShard * CHORD_SHARD_STRIDE], nLg);
             }
             BinTicket ticket;
-            if (emA | emB) wave_bin_issue(e, kindA == K_EMIT && !lgA, tsA, kindB == K_EMIT && !lgB, tsB, lane, ticket);
+            if (emA | emB) wave_bin_issue(e, kindA == K_EMIT && !lgA, tsA, kindB == K_EMIT && !lgB, tsB, lane, ticket, MASKED && masked);
             cbase = bcast(cbase, 0); ebaseC = bcast(ebaseC, 0); ebaseW = bcast(ebaseW, 0); lbase = bcast(lbase, 0);
             SPHASE(3);
             if (kindA == K_CLIP) {
@@ -920,7 +943,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
                 if (li + wSlots <= e.triCap) {
                     giA = listShard * e.triCap + li; write_record(&e.tris[giA], tsA, dA, twoSided, masked);
                     if (MASKED && masked) setup_emit_mask_ext(p, &e.tris[giA + 1u], triWord[0], uvA, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsA.area);
-                    giA |= CHORD_REC_WIDE; okA = true;
+                    giA |= (MASKED && masked) ? CHORD_REC_MASKED : CHORD_REC_WIDE; okA = true;
                 } else atomicOr(&e.counters->overflow, 1u);
             }
             if (cpB) {
@@ -932,18 +955,18 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
                 if (li + wSlots <= e.triCap) {
                     giB = listShard * e.triCap + li; write_record(&e.tris[giB], tsB, dB, twoSided, masked);
                     if (MASKED && masked) setup_emit_mask_ext(p, &e.tris[giB + 1u], triWord[1], uvB, lW, CHORD_MATFLAG_MATERIAL(hdr.matFlags), tsB.area);
-                    giB |= CHORD_REC_WIDE; okB = true;
+                    giB |= (MASKED && masked) ? CHORD_REC_MASKED : CHORD_REC_WIDE; okB = true;
                 } else atomicOr(&e.counters->overflow, 1u);
             }
             // <= 2x2 tiles: straight into the bins; more: the large list
             if (emA | emB) wave_bin_commit(e, ticket, okA, giA, okB, giB);
             if (lgA && okA) {
                 const uint32_t k = lbase + (uint32_t)__popcll(lmA & lt);
-                if (k < e.largeCap) e.largeList[(size_t)listShard * e.largeCap + k] = giA & ~CHORD_REC_WIDE; else atomicOr(&e.counters->overflow, 1u);
+                if (k < e.largeCap) e.largeList[(size_t)listShard * e.largeCap + k] = giA & CHORD_REC_WIDE_INDEX; else atomicOr(&e.counters->overflow, 1u);
             }
             if (lgB && okB) {
                 const uint32_t k = lbase + (uint32_t)__popcll(lmA) + (uint32_t)__popcll(lmB & lt);
-                if (k < e.largeCap) e.largeList[(size_t)listShard * e.largeCap + k] = giB & ~CHORD_REC_WIDE; else atomicOr(&e.counters->overflow, 1u);
+                if (k < e.largeCap) e.largeList[(size_t)listShard * e.largeCap + k] = giB & CHORD_REC_WIDE_INDEX; else atomicOr(&e.counters->overflow, 1u);
             }
             }
         }
@@ -1166,7 +1189,10 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
     const bool sprof = RASTER_PROFILE && (p.debug & DBG_SETUP_CLOCKS) != 0;
     unsigned long long sph[5] = {0, 0, 0, 0, 0}, stp = sprof ? wall_clock64() : 0ull;
 #define SPHASE(i) do { if (sprof) { const unsigned long long tn = wall_clock64(); sph[i] += tn - stp; stp = tn; } } while (0)
+    const uint32_t laneTop = lane;
     for (; c < count; c += stride) {
+        uint32_t lane = laneTop;                                             // (opaque per cluster: see raster_setup_body)
+        asm volatile("" : "+v"(lane));
         const uint32_t V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
         const bool twoSided = (hdr.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u || p.depthOnly != 0u;
         const bool masked = CHORD_MATFLAG_ALPHA(hdr.matFlags) == CHORD_ALPHA_MASK;
@@ -1395,8 +1421,11 @@ __device__ __forceinline__ bool launch_is_dense(const RasterParams& p, uint32_t 
 #endif
 // MASKED: the scene has alpha-tested materials (their clusters emit 48-byte records with a texture-coordinate extension);
 // scenes without any -- every benchmark configuration -- run the instantiation that knows nothing of them.
+#ifndef SETUP_MASKED_WAVES
+#define SETUP_MASKED_WAVES 4
+#endif
 template <bool MASKED>
-__global__ __launch_bounds__(256, MASKED ? 4 : SETUP_MIN_WAVES) void raster_setup_kernel(RasterParams p)   // (masked: twelve more live registers, see uvA)
+__global__ __launch_bounds__(256, MASKED ? SETUP_MASKED_WAVES : SETUP_MIN_WAVES) void raster_setup_kernel(RasterParams p)   // (masked: twelve more live registers, see uvA)
 {
     __shared__ float sVert[6][4][LDS_VERTS];                   // x, y, w, u, v, depth of a wave's cluster (24 KB)
     uint32_t count = *p.count;
@@ -1444,6 +1473,7 @@ __device__ void bin_record_tiles(const RasterParams& p, const TriSetup& ts, uint
             const uint32_t tile = (uint32_t)ty * p.tilesX + (uint32_t)tx;
             const uint32_t slot = atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE], 1u);
             bin_store(p, tile, slot, gi);
+            if ((gi & 0xE0000000u) == CHORD_REC_MASKED) p.tileCount[(size_t)tile * TC_STRIDE + TC_MASKED] = 1u;
         }
 }
 
@@ -1592,7 +1622,7 @@ __device__ void raster_clip_part(const RasterParams& p, uint32_t block, uint32_t
                 write_mask_ext(&p.tris[gi + 1u], &p.materials[material], material, ts.area, u3, v3, w3);
             }
             // clipped pieces are rare: binned right here, one (scattered) atomic per tile they may touch
-            bin_record_tiles(p, ts, gi | CHORD_REC_WIDE);                // clipped pieces take the 48-byte form
+            bin_record_tiles(p, ts, gi | (masked ? CHORD_REC_MASKED : CHORD_REC_WIDE));   // clipped pieces take the 48-byte form
         }
     }
 }
@@ -1627,6 +1657,7 @@ __device__ void raster_bin_large_part(const RasterParams& p, uint32_t block, uin
         for (int i = 0; i < 3; i++) { ts.X[i] = r->X[i]; ts.Y[i] = r->Y[i]; }
         ts.payload = 0;
         if (!tri_setup(ts, (r->twoSided & 1u) != 0, p.Wi, p.Hi)) continue;
+        const bool maskedRec = (r->twoSided & 4u) != 0u;                 // (wave-uniform: one record per wave)
         const int ea[3] = {1, 2, 0}, eb[3] = {2, 0, 1};
         int64_t a[3], b[3], bias[3], dxe[3], dye[3];
 #pragma unroll
@@ -1655,7 +1686,8 @@ __device__ void raster_bin_large_part(const RasterParams& p, uint32_t block, uin
             if (hit) {
                 const uint32_t tile = (uint32_t)ty * p.tilesX + (uint32_t)tx;
                 const uint32_t slot = atomicAdd(&p.tileCount[(size_t)tile * TC_STRIDE], 1u);   // distinct tiles per lane
-                bin_store(p, tile, slot, gi | CHORD_REC_WIDE);           // (the large list holds 48-byte records)
+                bin_store(p, tile, slot, gi | (maskedRec ? CHORD_REC_MASKED : CHORD_REC_WIDE));   // (the large list holds 48-byte records)
+                if (maskedRec) p.tileCount[(size_t)tile * TC_STRIDE + TC_MASKED] = 1u;
             }
         }
     }
@@ -1696,8 +1728,14 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
         myBucket[k] = 0xFFFFFFFFu; myPos[k] = 0; mySlices[k] = 1; myCount[k] = 0;
         // (sharded frames: another rank's tiles are not work items at all -- their bins are empty, and the clear pass must not touch them)
         if (t < tiles && owns_tile(p.shard, (int32_t)(t % p.tilesX), (int32_t)(t / p.tilesX))) {
-            const uint32_t c = min(p.tileCount[(size_t)t * TC_STRIDE], bin_capacity(p));
-            myCount[k] = c;
+            // (words 0 and 1 of the tile's counter line -- bin entries | of which pixel blocks -- in one 8-byte load)
+            const uint4 cnt = *reinterpret_cast<const uint4*>(&p.tileCount[(size_t)t * TC_STRIDE]);
+            const uint32_t c = min(cnt.x, bin_capacity(p));
+            // bit 31: the bin holds pixel blocks (the tile kernel's block pass; it used to ask the counter line itself, a dependent
+            // round trip per tile in front of its first bin fetch)
+            // bit 30: the bin holds alpha-tested triangles -- on the first pass of a frame the masked pass (raster_masked_tile_kernel)
+            // has written the tile already and the tile kernel starts from those words instead of from zero
+            myCount[k] = c | (cnt.y ? 0x80000000u : 0u) | (cnt.w ? 0x40000000u : 0u);
             if (c > TILE_SPLIT_MIN && !ABL(p, DBG_NO_SPLIT)) {
                 mySlices[k] = min((c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT, CHORD_TILE_MAX_SLICES);
                 myBucket[k] = 18u;
@@ -2226,7 +2264,7 @@ __device__ __forceinline__ void entry_unit_masked(const RasterParams& p, const E
 {
     const uint32_t box = en.w[11][e];
     const int32_t bx0 = (int32_t)(box & 63u), bx1 = (int32_t)((box >> 12) & 63u), by1 = (int32_t)((box >> 18) & 63u);
-    const int32_t ly = (int32_t)row, nrows = min(MASKED_ROWS, by1 - ly + 1);       // (row: the first row of the group)
+    const int32_t ly = (int32_t)row, nrows = MASKED_ROWS == 1 ? 1 : min(MASKED_ROWS, by1 - ly + 1);   // (row: the first row of the group)
     const int32_t lx0 = bx0 + (int32_t)(seg << MASKED_SEG_SHIFT), lx1 = min(bx1, lx0 + MASKED_SEG - 1);
     UnitParams u;
     u.X[0] = (int32_t)en.w[0][e]; u.X[1] = (int32_t)en.w[1][e]; u.X[2] = (int32_t)en.w[2][e];
@@ -2280,7 +2318,12 @@ __device__ __forceinline__ void tile_out_and_hzb_body(const TileOutParams& p, co
     static_assert(TILE == 64 && TB == 512, "wave w <-> pixel rows 8w..8w+7");
     const ChordHZBDesc& d = p.hzbDesc;
     const uint32_t tX = tileId % p.tilesX, tY = tileId / p.tilesX;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = lane >> 5, l = lane & 31u;
+    // (the thread index goes through an empty asm: everything the reduction derives from it -- a dozen texel offsets per lane -- is
+    // loop-invariant over the kernel's work items, and hoisted out of that loop it sat in registers through the whole scan conversion:
+    // 8 of them in scratch in the sharded instantiation)
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const uint32_t lane = tid & 63u, wave = tid >> 6, half = lane >> 5, l = lane & 31u;
     uint16_t* exA = SH && p.hzbExA ? p.hzbExA + (size_t)slotId * CHORD_HZB_SLOT_HALVES : nullptr;
     uint16_t* exB = SH ? p.hzbExB + (size_t)slotId * CHORD_HZB_FINAL_SLOT_HALVES : nullptr;
     auto vw = [&](uint32_t lv) { return min(max(1u, d.width >> lv), (((d.srcWidth - 1u) >> 1) >> lv) + 1u); };
@@ -2486,6 +2529,27 @@ __device__ __forceinline__ void merge_blocks(unsigned long long* tile, const uns
             if (2u * g < N[j]) merge_block_word(tile, v.y, 2u * g, H[j], R[j]);                                           \
         }
     if (!todo) return;
+#ifndef MB_GROUPS
+#define MB_GROUPS 3
+#endif
+#if MB_GROUPS == 3
+    // three groups of four in flight (round 5: the tile kernel has the registers since its per-item invariants are no longer held
+    // across the kernel): a group's loads are covered by the merges of the two groups before it.  An exhausted group picks
+    // nothing (n = 0), loads nothing and merges nothing, so the rotation needs no bookkeeping beyond "is anything left".
+    uint32_t hA[4], rA[4], nA[4], hB[4], rB[4], nB[4], hC[4], rC[4], nC[4];
+    const ulonglong2* srcA[4];
+    const ulonglong2* srcB[4];
+    const ulonglong2* srcC[4];
+    ulonglong2 aA[4], aB[4], aC[4];
+    MB_PICK(hA, rA, nA, srcA) MB_LOAD(aA, nA, srcA)
+    MB_PICK(hB, rB, nB, srcB) MB_LOAD(aB, nB, srcB)
+    MB_PICK(hC, rC, nC, srcC) MB_LOAD(aC, nC, srcC)
+    do {
+        MB_MERGE(aA, hA, rA, nA, srcA) MB_PICK(hA, rA, nA, srcA) MB_LOAD(aA, nA, srcA)
+        MB_MERGE(aB, hB, rB, nB, srcB) MB_PICK(hB, rB, nB, srcB) MB_LOAD(aB, nB, srcB)
+        MB_MERGE(aC, hC, rC, nC, srcC) MB_PICK(hC, rC, nC, srcC) MB_LOAD(aC, nC, srcC)
+    } while ((nA[0] | nB[0] | nC[0]) != 0u);
+#else
     uint32_t hA[4], rA[4], nA[4], hB[4], rB[4], nB[4];
     const ulonglong2* srcA[4];
     const ulonglong2* srcB[4];
@@ -2502,6 +2566,7 @@ __device__ __forceinline__ void merge_blocks(unsigned long long* tile, const uns
         MB_MERGE(aB, hB, rB, nB, srcB)
         if (!moreA) break;
     }
+#endif
 #undef MB_PICK
 #undef MB_LOAD
 #undef MB_MERGE
@@ -2523,10 +2588,16 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     uint2 firstItem = p.tileOrder[1u + min(blockIdx.x, p.tilesX * p.tilesY - 1u)];
     const uint32_t active = p.tileOrder[0].x;
     for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
+    // (the thread index of this work item goes through an empty asm: whatever the body derives from it is invariant over the
+    // item loop, and hoisted out of it those values -- offsets, masks, lane roles -- sat in registers across the whole kernel)
+    uint32_t tix = threadIdx.x;
+    asm volatile("" : "+v"(tix));
     const uint2 itemCount = oi == blockIdx.x ? firstItem : p.tileOrder[1u + oi];
     const uint32_t item = itemCount.x;
     const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
-    const uint32_t nAll = itemCount.y;                            // (already clamped to the bin capacity)
+    const uint32_t nAll = itemCount.y & 0x3FFFFFFFu;              // (already clamped to the bin capacity)
+    const bool hasBlocks = (itemCount.y >> 31) != 0u;             // (the order kernel saw pixel blocks in the tile's bin)
+    const bool preloaded = !CHORD_MASKED_FUSED && p.clearTiles && (itemCount.y & 0x40000000u) != 0u;   // the masked pass wrote this tile (first pass of a frame)
     const int32_t tinyArea = nAll >= TINY_DENSE_MIN ? TINY_AREA_DENSE : TINY_AREA;
     // entries [lo, n) of the bin are this item's
     // (slices of TILE_SLICE entries; a bin too long for CHORD_TILE_MAX_SLICES of them is cut into that many equal parts,
@@ -2551,18 +2622,27 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     auto vis_base = [&]() -> uint32_t { return SH ? slot_of_tile() << (2 * TILE_SHIFT) : (uint32_t)oy * (uint32_t)p.Wi + (uint32_t)ox; };
     const uint32_t visPitch = SH ? (uint32_t)TILE : (uint32_t)p.Wi;
 
+    // The item's first bin entries are requested BEFORE the tile-in, and the records they name before its barrier: the chain
+    // item -> bin entry -> record is what a light tile waits for (profiles/r03_tile_profile_config3.txt: a third of a tile's time),
+    // and the tile-in -- 33 KB of LDS stores, or the tile's words from memory -- depends on none of it.  (Bins that continue in
+    // pool chunks name them through chunkTab, which is filled behind the barrier: they keep the old order.)
+    const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
+    const bool early = n <= p.binCap && !hasBlocks;               // (uniform)
+    const uint32_t k0 = lo + tix;
+    const uint32_t word0 = (early && k0 < n) ? bin[k0] : 0xFFFFFFFFu;
+
     // ---- tile in: zero (first pass: this is the clear; un-fused later passes merge by max at tile-out), or the
     //      current words when a later pass must leave the finished tile in LDS for the fused HZB reduction ----
-    const bool rmw = p.hzbFused && !p.clearTiles;
+    const bool rmw = (p.hzbFused && !p.clearTiles) || preloaded;
     // slices of a split tile start from zero; when the tile must leave this kernel complete (first pass, fused HZB)
     // they meet in memory and the last one to arrive merges them (below)
     const bool mergeSlices = slices > 1u && (p.clearTiles || rmw);
     if (!(rmw && !mergeSlices)) {
         // (the whole array incl. the padding words, 16 bytes per store)
         static_assert((TILE * TPITCH) % 2 == 0, "whole 16-byte words");
-        for (uint32_t i = threadIdx.x; i < TILE * TPITCH / 2; i += TB) reinterpret_cast<ulonglong2*>(tile)[i] = make_ulonglong2(0ull, 0ull);
+        for (uint32_t i = tix; i < TILE * TPITCH / 2; i += TB) reinterpret_cast<ulonglong2*>(tile)[i] = make_ulonglong2(0ull, 0ull);
     } else
-    for (uint32_t i = threadIdx.x, visBase = vis_base(); i < TILE * TILE / 2; i += TB) {
+    for (uint32_t i = tix, visBase = vis_base(); i < TILE * TILE / 2; i += TB) {
         const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
         ulonglong2 v = make_ulonglong2(0ull, 0ull);
         if (ly < th && lx < tw) {
@@ -2572,20 +2652,40 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         }
         tile[ly * TPITCH + lx] = v.x; tile[ly * TPITCH + lx + 1] = v.y;
     }
+    // a record in flight: 32 or 48 raw bytes (which, says bit 31 of its name) in three named registers quads (an
+    // array or a struct passed by reference ends up in scratch memory), expanded when its batch is processed
+#define FETCH_REC(gi, a, b, c)                                                                       \
+    do {                                                                                             \
+        if ((gi) & CHORD_REC_WIDE) {                                                                 \
+            const uint4* src_ = reinterpret_cast<const uint4*>(&p.tris[(gi) & CHORD_REC_WIDE_INDEX]); \
+            a = src_[0]; b = src_[1]; c = src_[2];                                                   \
+        } else {                                                                                     \
+            const uint4* src_ = reinterpret_cast<const uint4*>(&p.trisC[(gi)]);                      \
+            a = src_[0]; b = src_[1];                                                                \
+        }                                                                                            \
+    } while (0)
+    uint32_t idxNext = 0xFFFFFFFFu, nameNext = 0xFFFFFFFFu;
+    uint4 nq0 = make_uint4(0, 0, 0, 0), nq1 = nq0, nq2 = nq0;
+    // (pixel blocks have a pass of their own below, alpha-tested triangles a kernel of their own: neither is a record of this pipeline)
+    auto record_name = [](uint32_t w) -> uint32_t { return (w >= CHORD_REC_BLOCK || (!(MASKED && CHORD_MASKED_FUSED) && (w & 0xE0000000u) == CHORD_REC_MASKED)) ? 0xFFFFFFFFu : w; };
+    if (early) {
+        nameNext = record_name(word0);                                          // (binEntry of an entry of the fixed bin)
+        if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);        // record of batch 0
+        if (k0 + TB < n) idxNext = record_name(bin[k0 + TB]);                   // bin entry of batch 1
+    }
     __syncthreads();
     PHASE(0);
 
     // ---- scan-convert the bin, 256 entries per batch -------------------------------------------
     // Software pipeline over the two dependent fetches of a batch (bin entry -> 48-byte record): the
     // record of batch b+1 and the bin entry of batch b+2 are in flight while batch b is scan-converted.
-    const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
     uint32_t chunk0 = 0;                                          // first overflow chunk of this item's range
     if (n > p.binCap) {
         // overflow chunks the item's entries [lo, n) live in (chunk table -> LDS; an entry of another pass or a failed
         // allocation reads as invalid and its entries are skipped)
         chunk0 = lo > p.binCap ? (lo - p.binCap) >> CHORD_BIN_CHUNK_SHIFT : 0u;
         const uint32_t chunks = min(64u, ((n - p.binCap + CHORD_BIN_CHUNK - 1u) >> CHORD_BIN_CHUNK_SHIFT) - chunk0);
-        for (uint32_t j = threadIdx.x; j < chunks; j += TB) {
+        for (uint32_t j = tix; j < chunks; j += TB) {
             const RasterParams* q = kernel_args();                                // (long bins only: not worth registers across the kernel)
             const unsigned long long e = scalar_load(&q->binChunkTab)[(size_t)tileId * scalar_load(&q->binMaxChunks) + chunk0 + j];
             chunkTab[j] = (uint32_t)(e >> 32) == scalar_load(&q->binStamp) ? (uint32_t)e : CHORD_BIN_CHUNK_INVALID;
@@ -2604,47 +2704,35 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     //      pipeline below is live here; tiles without blocks -- word 2 of the tile's counter line -- skip it) ----------
     // (the block pool and its size are read from the kernel arguments here: frames without blocks -- all but the densest -- do
     // not hold them in registers)
-    const uint32_t blockCap = scalar_load(&kernel_args()->blockCap);
-    if (blockCap != 0u && !noPixels && scalar_load(&kernel_args()->tileCount)[(size_t)tileId * TC_STRIDE + TC_BLOCKS] != 0u) {
+    if (hasBlocks && !noPixels) {
+        const uint32_t blockCap = scalar_load(&kernel_args()->blockCap);
         const unsigned long long* blockPool = scalar_load(&kernel_args()->blockPool);
         const uint32_t blockLimit = blockCap * CHORD_LIST_SHARDS;
-        uint32_t giNext = lo + threadIdx.x < n ? binWord(lo + threadIdx.x) : 0xFFFFFFFFu;
+        uint32_t giNext = lo + tix < n ? binWord(lo + tix) : 0xFFFFFFFFu;
         for (uint32_t base = lo; base < n; base += TB) {
             const uint32_t gi = giNext;
-            giNext = base + TB + threadIdx.x < n ? binWord(base + TB + threadIdx.x) : 0xFFFFFFFFu;
+            giNext = base + TB + tix < n ? binWord(base + TB + tix) : 0xFFFFFFFFu;
             // (never a block outside the pool: a slot drawn but not written after a reported overflow holds anything)
             const bool isBlock = gi != 0xFFFFFFFFu && gi >= CHORD_REC_BLOCK && (gi & CHORD_REC_INDEX_MASK) < blockLimit;
             uint2 hdr = make_uint2(0u, 0u);
             if (isBlock) hdr = *reinterpret_cast<const uint2*>(blockPool + (size_t)(gi & CHORD_REC_INDEX_MASK) * 2u);
-            merge_blocks(tile, blockPool, __ballot(isBlock), gi, hdr.x, hdr.y, threadIdx.x & 63u);
+            merge_blocks(tile, blockPool, __ballot(isBlock), gi, hdr.x, hdr.y, tix & 63u);
         }
     }
     auto binEntry = [&](uint32_t k) -> uint32_t {              // record name of bin entry k, ~0u = none (or a pixel block)
-        const uint32_t gi = binWord(k);
-        if (gi >= CHORD_REC_BLOCK) return 0xFFFFFFFFu;         // (incl. ~0u itself)
-        if (k < p.binCap) return gi;
-        const bool okIdx = (gi & CHORD_REC_WIDE) ? (gi & ~CHORD_REC_WIDE) < wideLimit : gi < compactLimit;
+        const uint32_t gi = record_name(binWord(k));           // (~0u stays ~0u)
+        if (gi == 0xFFFFFFFFu || k < p.binCap) return gi;
+        const bool okIdx = (gi & CHORD_REC_WIDE) ? (gi & CHORD_REC_WIDE_INDEX) < wideLimit : gi < compactLimit;
         return okIdx ? gi : 0xFFFFFFFFu;                       // (only after a reported overflow)
     };
-    // a record in flight: 32 or 48 raw bytes (which, says bit 31 of its name) in three named registers quads (an
-    // array or a struct passed by reference ends up in scratch memory), expanded when its batch is processed
-#define FETCH_REC(gi, a, b, c)                                                                       \
-    do {                                                                                             \
-        if ((gi) & CHORD_REC_WIDE) {                                                                 \
-            const uint4* src_ = reinterpret_cast<const uint4*>(&p.tris[(gi) & ~CHORD_REC_WIDE]);     \
-            a = src_[0]; b = src_[1]; c = src_[2];                                                   \
-        } else {                                                                                     \
-            const uint4* src_ = reinterpret_cast<const uint4*>(&p.trisC[(gi)]);                      \
-            a = src_[0]; b = src_[1];                                                                \
-        }                                                                                            \
-    } while (0)
-    uint32_t idxNext = lo + threadIdx.x < n ? binEntry(lo + threadIdx.x) : 0xFFFFFFFFu;   // bin entry of batch 0
-    uint4 nq0 = make_uint4(0, 0, 0, 0), nq1 = nq0, nq2 = nq0;
-    uint32_t nameNext = idxNext;
-    if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);             // record of batch 0
-    idxNext = lo + TB + threadIdx.x < n ? binEntry(lo + TB + threadIdx.x) : 0xFFFFFFFFu;   // bin entry of batch 1
+    if (!early) {
+        idxNext = k0 < n ? binEntry(k0) : 0xFFFFFFFFu;                           // bin entry of batch 0
+        nameNext = idxNext;
+        if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);         // record of batch 0
+        idxNext = k0 + TB < n ? binEntry(k0 + TB) : 0xFFFFFFFFu;                 // bin entry of batch 1
+    }
     for (uint32_t base = lo; base < n; base += TB) {
-        const uint32_t k = base + threadIdx.x;
+        const uint32_t k = base + tix;
         const uint4 q0 = nq0, q1 = nq1, q2 = nq2;
         const uint32_t name = nameNext;
         const bool have = name != 0xFFFFFFFFu && !ABL(p, DBG_NO_ENTRY);
@@ -2683,7 +2771,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                         if (!ABL(p, DBG_NO_TINY)) tile_raster_narrow<TPITCH>(tile, ts, ox, oy, x0, y0, x1, y1, noPixels, DEPTH);
                         if (prof) { cTiny++; cTinyIters += (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1)); }
                     } else {
-                        rows = entry_store(prm, threadIdx.x, ts, narrow, ox, oy, x0, y0, x1, y1, maskedRec, name & ~CHORD_REC_WIDE);   // (units, not rows)
+                        rows = entry_store(prm, tix, ts, narrow, ox, oy, x0, y0, x1, y1, maskedRec, name & CHORD_REC_WIDE_INDEX);   // (units, not rows)
                     }
                 }
             }
@@ -2693,7 +2781,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         // (the wave sums alternate between two buffers: a batch without units then needs no barrier but the scan's own)
         // (MASKED: one scan for both populations -- units of opaque entries in the low half, of masked entries (kind 3) in the high
         // half: a batch has at most 512 x 64 units)
-        const bool mine3 = MASKED && rows && ((prm.w[11][threadIdx.x] >> EF_KIND_SHIFT) & 3u) == 3u;
+        const bool mine3 = MASKED && rows && ((prm.w[11][tix] >> EF_KIND_SHIFT) & 3u) == 3u;
         const uint32_t rowsN = mine3 ? 0u : rows, rowsM = mine3 ? rows : 0u;
         const uint32_t offAll = block_scan_tb(rowsN | (rowsM << 16), waveSums[(base >> 9) & 1u], &total);
         const uint32_t offN = offAll & 0xFFFFu, offM = offAll >> 16, totalM = MASKED ? total >> 16 : 0u;
@@ -2702,7 +2790,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         // my units [off, off + n) of a population, cut to the round's window [r0, r0 + UNIT_CAP): one LDS word each
         auto list_units = [&](uint32_t off, uint32_t n, uint32_t r0) {
             if (!n) return;
-            const uint32_t box = prm.w[11][threadIdx.x];
+            const uint32_t box = prm.w[11][tix];
             const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> SEG_SHIFT) + 1u, y0l = (box >> 6) & 63u;
             const uint32_t lo2 = max(off, r0), hi2 = min(off + n, r0 + UNIT_CAP);
             if (lo2 < hi2) {
@@ -2710,7 +2798,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                 uint32_t row = y0l + (nseg == 1u ? j : nseg == 2u ? j >> 1 : nseg == 4u ? j >> 2 : j / 3u);
                 uint32_t seg = nseg == 1u ? 0u : nseg == 2u ? (j & 1u) : nseg == 4u ? (j & 3u) : j % 3u;
                 for (uint32_t u = lo2; u < hi2; u++) {
-                    unitList[u - r0] = threadIdx.x | (row << 9) | (seg << 15);
+                    unitList[u - r0] = tix | (row << 9) | (seg << 15);
                     if (++seg == nseg) { seg = 0u; row++; }
                 }
             }
@@ -2721,7 +2809,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
             list_units(offN, rowsN, r0);
             __syncthreads();
             const uint32_t nr = min(total - r0, (uint32_t)UNIT_CAP);
-            for (uint32_t ui = threadIdx.x; ui < nr; ui += TB) {
+            for (uint32_t ui = tix; ui < nr; ui += TB) {
                 const uint32_t d = unitList[ui];
                 if (ABL(p, DBG_NO_UNITS)) continue;
                 const int32_t trips = entry_unit<MASKED, DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, noPixels);
@@ -2731,21 +2819,21 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         }
         for (uint32_t r0 = 0; r0 < totalM; r0 += UNIT_CAP) {      // (MASKED only) the alpha-tested triangles' units
             if (rowsM) {
-                const uint32_t box = prm.w[11][threadIdx.x];
+                const uint32_t box = prm.w[11][tix];
                 const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> MASKED_SEG_SHIFT) + 1u, y0l = (box >> 6) & 63u;
                 const uint32_t lo2 = max(offM, r0), hi2 = min(offM + rowsM, r0 + UNIT_CAP);
                 if (lo2 < hi2) {
                     const uint32_t j = lo2 - offM, g = j / nseg;
                     uint32_t row = y0l + g * MASKED_ROWS, seg = j - g * nseg;
                     for (uint32_t u = lo2; u < hi2; u++) {
-                        unitList[u - r0] = threadIdx.x | (row << 9) | (seg << 15);
+                        unitList[u - r0] = tix | (row << 9) | (seg << 15);
                         if (++seg == nseg) { seg = 0u; row += MASKED_ROWS; }
                     }
                 }
             }
             __syncthreads();
             const uint32_t nr = min(totalM - r0, (uint32_t)UNIT_CAP);
-            for (uint32_t ui = threadIdx.x; ui < nr; ui += TB) {
+            for (uint32_t ui = tix; ui < nr; ui += TB) {
                 const uint32_t d = unitList[ui];
                 entry_unit_masked<DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 7u, ox, oy, noPixels);
             }
@@ -2767,7 +2855,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         if (!merge_slices(tile, scalar_load(&q->tileSlabs) + (size_t)tileId * (TILE * TILE), &scalar_load(&q->tileCount)[(size_t)tileId * TC_STRIDE + TC_TICKET],
                           slices, &sTicket, &scalar_load(&q->counters)->overflow)) continue;   // not the last slice: done
         if (rmw) {
-            for (uint32_t i = threadIdx.x, visBase = vis_base(); i < TILE * TILE / 2; i += TB) {
+            for (uint32_t i = tix, visBase = vis_base(); i < TILE * TILE / 2; i += TB) {
                 const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
                 if (ly >= th || lx >= tw) continue;
                 const unsigned long long* src = p.vis + (size_t)(visBase + (uint32_t)ly * visPitch + (uint32_t)lx);
@@ -2786,7 +2874,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         tile_out_and_hzb<SH>(tile, reinterpret_cast<float*>(&prm.w[0][0]), offs, tileId, slot_of_tile(), nAll, ox, oy, tw, th);
     } else if (p.clearTiles || p.hzbFused) {
         // first pass of the frame: every word is written (16-byte coalesced stores); this is the clear
-        for (uint32_t i = threadIdx.x, visBase = vis_base(); i < TILE * TILE / 2; i += TB) {
+        for (uint32_t i = tix, visBase = vis_base(); i < TILE * TILE / 2; i += TB) {
             const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
             if (ly >= th || lx >= tw) continue;
             const ulonglong2 v = make_ulonglong2(tile[ly * TPITCH + lx], tile[ly * TPITCH + lx + 1]);
@@ -2797,7 +2885,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     } else {
         // later passes: only the pixels this pass touched are merged, with a row-coalesced global atomicMax
         // (8 lanes per 64-byte line) — no read-modify-write of the whole tile
-        for (uint32_t i = threadIdx.x, visBase = vis_base(); i < TILE * TILE; i += TB) {
+        for (uint32_t i = tix, visBase = vis_base(); i < TILE * TILE; i += TB) {
             const int32_t ly = (int32_t)(i >> TILE_SHIFT), lx = (int32_t)(i & (TILE - 1));
             const unsigned long long v = tile[ly * TPITCH + lx];
             if (v != 0ull && ly < th && lx < tw) atomicMax(p.vis + (size_t)(visBase + (uint32_t)ly * visPitch + (uint32_t)lx), v);
@@ -2805,7 +2893,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     }
     PHASE(5);
     if (prof) {
-        if (threadIdx.x == 0) {
+        if (tix == 0) {
             p.tileClocks[tileId] = wall_clock64() - t0;
             for (int i = 0; i < 6; i++) p.tilePhase[(size_t)tileId * 8 + i] = ph[i];
             p.tilePhase[(size_t)tileId * 8 + 6] = 0ull; p.tilePhase[(size_t)tileId * 8 + 7] = 0ull;
@@ -2816,6 +2904,136 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         atomicAdd(&p.tilePhase[(size_t)tileId * 8 + 7], ((unsigned long long)cTiny << 32) | cTinyIters);
     }
     __syncthreads();                                              // the LDS tile is reused by the next iteration
+    }
+}
+
+// ---- alpha-tested (masked) triangles: a pass of their own (mesh_raster.hlsl:34-38,107-112,198-204) ---------------------------------
+// Until round 4 the masked row units ran inside raster_tile_kernel: every masked instantiation of it sat at 128 VGPRs with
+// 144-240 bytes of scratch per lane (the texture fetch next to the whole opaque batch pipeline), the opaque triangles of a masked
+// scene paid for the pass structure (no tiny-triangle path, an extension fetch per unit: 37 us per frame on street_4k_masked), and
+// nothing that keeps a second pixel's taps in flight fitted.  Now a bin entry says by itself that it names an alpha-tested
+// triangle (CHORD_REC_MASKED), the tile kernel skips such entries -- its only instantiations are the opaque ones --, and this
+// kernel, launched between the binning and the tile schedule, scan-converts them: one workgroup per tile whose counter line
+// carries the TC_MASKED flag, the tile in LDS from zero, the entries set up exactly as before (entry_store, masked_rows: the
+// arithmetic is untouched), row units dealt out densely.  On the first pass of a frame the finished tile is WRITTEN (plain
+// 16-byte stores) and the tile kernel, told by the tile schedule (bit 30 of the work item), starts from those words instead of
+// from zero; on later passes the touched pixels are merged with device-scope atomicMax and the tile kernel reads the tile back
+// as it does anyway.  The 64-bit max is order-independent, so which kernel merges a fragment first changes nothing.
+// Price: a masked tile's 32 KB once out and once in on the first pass, and one more launch per pass of a scene with alpha-tested
+// materials; scenes without them launch nothing of this.
+template <bool SH, bool DEPTH>
+__global__ __launch_bounds__(TB, 4) void raster_masked_tile_kernel(RasterParams p)
+{
+    __shared__ __align__(16) unsigned long long tile[TILE * TPITCH];   // 32.5 KB
+    __shared__ EntrySoA prm;                                     // 26 KB
+    __shared__ uint32_t unitList[UNIT_CAP];                      // 16 KB
+    __shared__ uint32_t waveSums[2][TB / 64];
+    __shared__ uint32_t chunkTab[64];
+    // work items: the tile schedule's (heaviest bins first: the masked pass ends with light tiles, like the tile kernel); an item
+    // without the masked flag -- or a further slice of a split tile -- is none of this pass's business
+    // (one workgroup per tile of the target strides over the list: a frame with split tiles has more items than tiles)
+    const uint32_t active = p.tileOrder[0].x;
+    for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
+    const uint2 item = p.tileOrder[1u + oi];
+    if ((item.y & 0x40000000u) == 0u || ((item.x >> 12) & 0x3FFu) != 0u) continue;
+    const uint32_t tileId = item.x & 0xFFFu;
+    const uint32_t n = item.y & 0x3FFFFFFFu;                      // (clamped to the bin capacity by the schedule)
+    const int32_t ox = (int32_t)(tileId % p.tilesX) * TILE, oy = (int32_t)(tileId / p.tilesX) * TILE;
+    const int32_t tw = min(TILE, p.Wi - ox), th = min(TILE, p.Hi - oy);
+    const bool noPixels = ABL(p, DBG_NO_PIXELS);
+    for (uint32_t i = threadIdx.x; i < TILE * TPITCH / 2; i += TB) reinterpret_cast<ulonglong2*>(tile)[i] = make_ulonglong2(0ull, 0ull);
+    const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
+    const uint32_t wideLimit = min(p.triCap * CHORD_LIST_SHARDS, CHORD_REC_WIDE_INDEX);
+    uint32_t batch = 0;
+    // the bin in segments: its fixed part, then windows of 64 pool chunks (their names through chunkTab, as in the tile kernel)
+    for (uint32_t segLo = 0; segLo < n;) {
+        uint32_t segHi, chunk0 = 0;
+        if (segLo < p.binCap) segHi = min(n, p.binCap);
+        else {
+            chunk0 = (segLo - p.binCap) >> CHORD_BIN_CHUNK_SHIFT;
+            segHi = min(n, segLo + 64u * CHORD_BIN_CHUNK);
+            __syncthreads();                                      // (the previous window's readers are done)
+            for (uint32_t j = threadIdx.x; j < 64u; j += TB) {
+                const unsigned long long e = chunk0 + j < p.binMaxChunks ? p.binChunkTab[(size_t)tileId * p.binMaxChunks + chunk0 + j] : 0ull;
+                chunkTab[j] = (uint32_t)(e >> 32) == p.binStamp ? (uint32_t)e : CHORD_BIN_CHUNK_INVALID;
+            }
+        }
+        __syncthreads();                                          // the zeroed tile / the chunk names are visible
+        auto binWord = [&](uint32_t k) -> uint32_t {
+            if (k < p.binCap) return bin[k];
+            const uint32_t o = k - p.binCap, cj = (o >> CHORD_BIN_CHUNK_SHIFT) - chunk0;
+            const uint32_t id = cj < 64u ? chunkTab[cj] : CHORD_BIN_CHUNK_INVALID;
+            return id == CHORD_BIN_CHUNK_INVALID ? 0xFFFFFFFFu : p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))];
+        };
+        uint32_t wNext = segLo + threadIdx.x < segHi ? binWord(segLo + threadIdx.x) : 0xFFFFFFFFu;
+        for (uint32_t base = segLo; base < segHi; base += TB, batch++) {
+            const uint32_t w = wNext;
+            wNext = base + TB + threadIdx.x < segHi ? binWord(base + TB + threadIdx.x) : 0xFFFFFFFFu;
+            const uint32_t idx = w & CHORD_REC_WIDE_INDEX;
+            uint32_t units = 0;
+            if ((w & 0xE0000000u) == CHORD_REC_MASKED && idx < wideLimit) {
+                const uint4* src = reinterpret_cast<const uint4*>(&p.tris[idx]);
+                const uint4 q0 = src[0], q1 = src[1], q2 = src[2];
+                TriRec r;
+                r.X[0] = (int32_t)q0.x; r.X[1] = (int32_t)q0.y; r.X[2] = (int32_t)q0.z; r.Y[0] = (int32_t)q0.w;
+                r.Y[1] = (int32_t)q1.x; r.Y[2] = (int32_t)q1.y;
+                r.d[0] = __uint_as_float(q1.z); r.d[1] = __uint_as_float(q1.w); r.d[2] = __uint_as_float(q2.x);
+                r.payload = q2.y; r.twoSided = q2.z; r.pad = q2.w;
+                TriSetup ts;
+                tri_setup_from_record(ts, r, p.Wi, p.Hi);
+                const int32_t x0 = max(ts.px0, ox), y0 = max(ts.py0, oy);
+                const int32_t x1 = min(ts.px1, ox + tw - 1), y1 = min(ts.py1, oy + th - 1);
+                if (x1 >= x0 && y1 >= y0) units = entry_store(prm, threadIdx.x, ts, narrow_extent(ts), ox, oy, x0, y0, x1, y1, true, idx);
+            }
+            uint32_t total;
+            const uint32_t off = block_scan_tb(units, waveSums[batch & 1u], &total);   // (its barrier also publishes the entries)
+            for (uint32_t r0 = 0; r0 < total; r0 += UNIT_CAP) {
+                if (units) {
+                    const uint32_t box = prm.w[11][threadIdx.x];
+                    const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> MASKED_SEG_SHIFT) + 1u, y0l = (box >> 6) & 63u;
+                    const uint32_t lo2 = max(off, r0), hi2 = min(off + units, r0 + UNIT_CAP);
+                    if (lo2 < hi2) {
+                        const uint32_t j = lo2 - off, g = j / nseg;
+                        uint32_t row = y0l + g * MASKED_ROWS, seg = j - g * nseg;
+                        for (uint32_t u = lo2; u < hi2; u++) {
+                            unitList[u - r0] = threadIdx.x | (row << 9) | (seg << 15);
+                            if (++seg == nseg) { seg = 0u; row += MASKED_ROWS; }
+                        }
+                    }
+                }
+                __syncthreads();
+                const uint32_t nr = min(total - r0, (uint32_t)UNIT_CAP);
+                for (uint32_t ui = threadIdx.x; ui < nr; ui += TB) {
+                    const uint32_t d = unitList[ui];
+                    entry_unit_masked<DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 7u, ox, oy, noPixels);
+                }
+                if (r0 + UNIT_CAP < total) __syncthreads();       // the list is rewritten by the next round
+            }
+            if (total) __syncthreads();                           // prm / the unit list are rewritten by the next batch
+        }
+        segLo = segHi;
+    }
+    __syncthreads();
+    // ---- tile out: the whole tile on the first pass of a frame (the tile kernel starts from it), the touched pixels otherwise ----
+    const uint32_t visBase = SH ? p.shard.tileSlot[tileId] << (2 * TILE_SHIFT) : (uint32_t)oy * (uint32_t)p.Wi + (uint32_t)ox;
+    const uint32_t visPitch = SH ? (uint32_t)TILE : (uint32_t)p.Wi;
+    if (p.clearTiles) {
+        for (uint32_t i = threadIdx.x; i < TILE * TILE / 2; i += TB) {
+            const int32_t ly = (int32_t)(i >> (TILE_SHIFT - 1)), lx = (int32_t)(i & (TILE / 2 - 1)) * 2;
+            if (ly >= th || lx >= tw) continue;
+            const ulonglong2 v = make_ulonglong2(tile[ly * TPITCH + lx], tile[ly * TPITCH + lx + 1]);
+            unsigned long long* dst = p.vis + (size_t)(visBase + (uint32_t)ly * visPitch + (uint32_t)lx);
+            if (lx + 1 < tw) *reinterpret_cast<ulonglong2*>(dst) = v;
+            else dst[0] = v.x;
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < TILE * TILE; i += TB) {
+            const int32_t ly = (int32_t)(i >> TILE_SHIFT), lx = (int32_t)(i & (TILE - 1));
+            const unsigned long long v = tile[ly * TPITCH + lx];
+            if (v != 0ull && ly < th && lx < tw) atomicMax(p.vis + (size_t)(visBase + (uint32_t)ly * visPitch + (uint32_t)lx), v);
+        }
+    }
+    __syncthreads();                                              // the LDS tile is reused by the next item
     }
 }
 
@@ -2943,6 +3161,13 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     stamp(c, S_R_CLUSTER);
     CHORD_LAUNCH(c, raster_clip_and_bin_large_kernel, dim3(CLIP_BLOCKS + (uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
     CHORD_LAUNCH(c, raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
+    if (c->anyMasked && !CHORD_MASKED_FUSED) {
+        // alpha-tested triangles: their own pass over the scheduled tiles whose bins hold any (raster_masked_tile_kernel)
+        const uint32_t items = tiles;                                     // (the workgroups stride over the device-side item list)
+        if (c->depthClamp && !sh) CHORD_LAUNCH(c, (raster_masked_tile_kernel<false, true>), dim3(items), dim3(TB), 0, c->stream, p);
+        else if (sh)              CHORD_LAUNCH(c, (raster_masked_tile_kernel<true, false>), dim3(items), dim3(TB), 0, c->stream, p);
+        else                      CHORD_LAUNCH(c, (raster_masked_tile_kernel<false, false>), dim3(items), dim3(TB), 0, c->stream, p);
+    }
     stamp(c, S_R_CLIP);
     // first pass of a frame: every tile is written, one block each, dispatched heaviest first; later passes touch
     // few tiles: one resident wave of blocks strides over the (device-side) active list
@@ -2952,12 +3177,16 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // per block balances better than any static split)
     // (sharded frames: the work items are the rank's own tiles)
     const uint32_t tileBlocks = clearTiles ? (sh ? min(tiles, c->shard.slotsPerRank) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
+    // (the tile kernel's instantiations are the opaque ones: alpha-tested triangles were scan-converted by the masked pass above)
+#if CHORD_MASKED_FUSED
+    if (c->anyMasked) {
+        if (c->depthClamp && !sh) CHORD_LAUNCH(c, (raster_tile_kernel<false, true, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        else if (sh)              CHORD_LAUNCH(c, (raster_tile_kernel<true, true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        else                      CHORD_LAUNCH(c, (raster_tile_kernel<false, true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+    } else
+#endif
     if (c->depthClamp && !sh) {
-        if (c->anyMasked) CHORD_LAUNCH(c, (raster_tile_kernel<false, true, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
-        else              CHORD_LAUNCH(c, (raster_tile_kernel<false, false, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
-    } else if (c->anyMasked) {
-        if (sh) CHORD_LAUNCH(c, (raster_tile_kernel<true, true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
-        else    CHORD_LAUNCH(c, (raster_tile_kernel<false, true, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
+        CHORD_LAUNCH(c, (raster_tile_kernel<false, false, true>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
     } else {
         if (sh) CHORD_LAUNCH(c, (raster_tile_kernel<true, false, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
         else    CHORD_LAUNCH(c, (raster_tile_kernel<false, false, false>), dim3(tileBlocks), dim3(TB), 0, c->stream, p);
