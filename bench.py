@@ -485,10 +485,11 @@ def measure(args, workload, env):
     achieved = (dom_bytes / launches) / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     # HBM traffic of that kernel from the PMC counters: they need their own rocprofv3 passes, so the figure comes from
     # the committed summary of those passes over this same command (profiles/, tools/profile.sh), per launch
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_head = None, None, None
     prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     tail = {"street_4k_hzb": "config3_4k_hzb_traffic.json", "street_x64_4k_hzb": "config4_x64_4k_hzb_traffic.json",
-            "subpixel_1g": "config5_subpixel_1g_traffic.json"}.get(wl)
+            "subpixel_1g": "config5_subpixel_1g_traffic.json", "subpixel_1g_hotspot": "config5_hotspot_traffic.json",
+            "street_4k_masked": "masked_4k_traffic.json"}.get(wl)
     cands = sorted(f for f in os.listdir(prof_dir) if tail and f.endswith(tail)) if os.path.isdir(prof_dir) else []
     tj = os.path.join(prof_dir, cands[-1]) if cands else ""              # the newest round's
     if world == 1 and not args.debug_flags and (not args.no_hzb or wl.startswith("subpixel")) and os.path.isfile(tj):
@@ -498,10 +499,12 @@ def measure(args, workload, env):
             names = [dom] + (["raster_setup_blocks_kernel"] if dom == "raster_setup_kernel" and blocks > 0 else [])
             traffic = int(sum(tk["kernels"][n]["hbm_bytes_per_launch"] for n in names if n in tk["kernels"]))
             traffic_src = "profiles/" + os.path.basename(tj)
+            traffic_head = tk.get("profile_head")
         except (KeyError, ValueError):
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom + (" (raster_setup_blocks_kernel + raster_setup_kernel)" if dom == "raster_setup_kernel" and blocks > 0 else ""), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_profile_head": traffic_head,          # the commit that profile was taken at: a kernel changed since then leaves `traffic` stale
                 "from_committed_profile": traffic is not None,   # (PMC passes cannot run inside this process: not observed in THIS run)
                 "avg_launch_us": round(dom_ms / launches * 1e3, 2), "launches_per_step": launches,
                 "stamped_frames": stamped_in_region + extra, "stamped_inside_timed_region": stamped_in_region,

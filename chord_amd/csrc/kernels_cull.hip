@@ -548,32 +548,53 @@ __global__ __launch_bounds__(1024) void group_cull_prefix_kernel(uint32_t* __res
                                                                  uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters,
                                                                  uint32_t* __restrict__ mineCount)
 {
-    __shared__ uint32_t sWave[16];
-    __shared__ unsigned long long sTris[16];
+    // A thread owns a contiguous run of `per` blocks (config 5: 8 192 blocks = 8 each): every count it needs is requested before the
+    // first is used, the run is summed in registers, ONE scan over the 1 024 thread totals orders the runs, and the exclusive offsets
+    // go back.  (Round 4's form walked the array in steps of 1 024 -- load, scan, two barriers, store, eight times in a row for config 5,
+    // and a second time for the rank's own counts: 18 us for 16 dependent round trips of a single workgroup.)  The visible counts
+    // and the rank's counts (sharded frames: blockCounts[2 * blocks ..)) are scanned together, packed in one 64-bit value.
+    __shared__ unsigned long long sWave[16], sTris[16];
+    constexpr uint32_t MAXPER = 16u;                               // (up to 16 384 count blocks = 4 Mi group instances in one pass; more: a loop of passes)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    unsigned long long tris = 0;
-    // sharded frames (mineCount != NULL): the same scan once more over the rank's own counts, blockCounts[2 * blocks ..)
-    for (uint32_t which = 0; which < (mineCount ? 2u : 1u); which++) {
-        uint32_t* __restrict__ cnt = blockCounts + (which ? 2u * blocks : 0u);
-        uint32_t carry = 0;
-        for (uint32_t base = 0; base < blocks; base += 1024u) {
-            const uint32_t b = base + threadIdx.x;
-            const uint32_t v = b < blocks ? cnt[b] : 0u;
-            if (which == 0u && b < blocks) tris += blockCounts[blocks + b];
-            uint32_t incl = v;
+    const bool two = mineCount != nullptr;
+    unsigned long long tris = 0, carry = 0;
+    for (uint32_t pass0 = 0; pass0 < blocks; pass0 += 1024u * MAXPER) {
+        const uint32_t nb = min(blocks - pass0, 1024u * MAXPER), per = (nb + 1023u) / 1024u;
+        const uint32_t first = pass0 + threadIdx.x * per;
+        uint32_t v[MAXPER], m[MAXPER];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t nb = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += nb; }
-            if (lane == 63u) sWave[wave] = incl;
-            __syncthreads();
-            uint32_t before = 0, all = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < 16u; w++) { const uint32_t c = sWave[w]; if (w < wave) before += c; all += c; }
-            if (b < blocks) cnt[b] = carry + before + incl - v;
-            carry += all;
-            __syncthreads();
+        for (uint32_t k = 0; k < MAXPER; k++) {
+            const uint32_t b = first + k;
+            const bool in = k < per && b < pass0 + nb;
+            v[k] = in ? blockCounts[b] : 0u;
+            m[k] = (in && two) ? blockCounts[2u * blocks + b] : 0u;
+            if (in) tris += blockCounts[blocks + b];
         }
-        if (threadIdx.x == 0) *(which ? mineCount : outCount) = carry;
+        unsigned long long sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < MAXPER; k++) sum += (unsigned long long)v[k] | ((unsigned long long)m[k] << 32);
+        unsigned long long incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
+        if (lane == 63u) sWave[wave] = incl;
+        __syncthreads();
+        unsigned long long before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16u; w++) { const unsigned long long c = sWave[w]; if (w < wave) before += c; all += c; }
+        unsigned long long run = carry + before + incl - sum;      // exclusive offset of the thread's first block
+#pragma unroll
+        for (uint32_t k = 0; k < MAXPER; k++) {
+            const uint32_t b = first + k;
+            if (k < per && b < pass0 + nb) {
+                blockCounts[b] = (uint32_t)run;
+                if (two) blockCounts[2u * blocks + b] = (uint32_t)(run >> 32);
+            }
+            run += (unsigned long long)v[k] | ((unsigned long long)m[k] << 32);
+        }
+        carry += all;
+        __syncthreads();                                           // sWave is rewritten by the next pass
     }
+    if (threadIdx.x == 0) { *outCount = (uint32_t)carry; if (two) *mineCount = (uint32_t)(carry >> 32); }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tris += __shfl_down(tris, off, 64);
     if (lane == 0u) sTris[wave] = tris;

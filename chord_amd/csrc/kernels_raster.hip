@@ -2530,12 +2530,13 @@ __device__ __forceinline__ void merge_blocks(unsigned long long* tile, const uns
         }
     if (!todo) return;
 #ifndef MB_GROUPS
-#define MB_GROUPS 3
+#define MB_GROUPS 2
 #endif
 #if MB_GROUPS == 3
-    // three groups of four in flight (round 5: the tile kernel has the registers since its per-item invariants are no longer held
-    // across the kernel): a group's loads are covered by the merges of the two groups before it.  An exhausted group picks
-    // nothing (n = 0), loads nothing and merges nothing, so the rotation needs no bookkeeping beyond "is anything left".
+    // three groups of four in flight (a build switch, measured in round 5 once the tile kernel had the registers: a group's loads
+    // covered by the merges of the two groups before it -- the tile kernel of a rank of the 8-rank config-5 frame 0.267 -> 0.291 ms,
+    // one GPU on subpixel_64m 136 -> 147 us: the third group's 20 scalars are lane spills inside the merge loop; not the default).
+    // An exhausted group picks nothing (n = 0), loads nothing and merges nothing, so the rotation needs no bookkeeping.
     uint32_t hA[4], rA[4], nA[4], hB[4], rB[4], nB[4], hC[4], rC[4], nC[4];
     const ulonglong2* srcA[4];
     const ulonglong2* srcB[4];

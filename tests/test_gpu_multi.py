@@ -291,7 +291,19 @@ def test_bench_two_ranks_self_spawned_on_one_device(gpu):
     assert line["counts_view_a"]["countInstanceCulled"] > 0
     # per rank: GPU time of every phase and both exchanges, so that a scaling record explains itself
     assert len(line["phases_ms"]) == 2 and {p["rank"] for p in line["phases_ms"]} == {0, 1}
-    assert all(k in line["phases_ms"][0] for k in ("phase_a_stage0", "exchange_hzb", "phase_b_stage1", "exchange_vis", "phase_c_final_hzb"))
+    assert all(k in line["phases_ms"][0] for k in ("phase_a_stage0", "exchange_hzb", "phase_b_stage1", "exchange_vis", "phase_c_final_hzb", "exchange_cull", "kernel_launches"))
+    # one line holds both protocols (the host-driven exchange of this test hook has no pipelined form: it says so), the figure under
+    # the default tile map beside the re-balanced one, every exchange's achieved bandwidth, what bounds the frame, and the cull's form
+    for ln in (line, also):
+        assert ln["cull"] == "sharded" and all(p_["exchange_cull"] > 0 for p_ in ln["phases_ms"])
+        assert "skipped" in ln["pipelined"]
+        assert ln["default_map"]["ms_per_step"] > 0 and ln["default_map"]["speedup_vs_single"] > 0
+        gb = ln["exchange_gbs"]
+        assert gb["cull"]["gbs"] > 0 and gb["hzb_mid"]["gbs"] > 0 and gb["image+final"]["bytes_per_rank_in"] > 0
+        assert ln["rccl_schedule_ok"] is None                       # (no RCCL in this run)
+        b = ln["bound"]
+        assert 10 <= b["kernel_launches_per_frame"] <= 24 and abs(b["bound_ms"] - (b["kernel_launches_per_frame"] * 5e-3 + b["exchanges_ms"])) < 1e-3
+    assert line["warmup"] >= line["warmup_requested"] == 4
 
 
 def test_bench_two_ranks_group_fallback_on_one_device(gpu):
@@ -303,6 +315,9 @@ def test_bench_two_ranks_group_fallback_on_one_device(gpu):
     assert len(line["phases_ms"]) == 2 and all("exchange_vis" in p for p in line["phases_ms"])
     # what the one-process transport costs the host, worker by worker
     assert all(p["host_enqueue_ms"] > 0 for p in line["phases_ms"])
+    # the group transport measures its pipelined protocol in the same run, and stamps the small end-of-frame exchange apart from the image
+    assert line["pipelined"]["ms_per_step"] > 0 and line["pipelined"]["speedup_vs_single"] > 0
+    assert all(p["exchange_final"] > 0 and p["exchange_cull"] > 0 for p in line["phases_ms"])
 
 
 def test_bench_single_gpu_line_has_the_contract_fields(gpu):

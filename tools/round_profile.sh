@@ -4,15 +4,16 @@
 # calibration, the phase clocks and the ablation table (the measuring builds --tag abl -DRASTER_ABLATION=1 / --tag prof
 # -DRASTER_PROFILE=1 must exist then).
 set -u
-R=${1:-r04}
+R=${1:-r05}
 cd $GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/${R}_pytest.txt 2>&1
 grep -a "passed\|failed" gpurun_out/${R}_pytest.txt | tail -3
 tools/profile.sh ${R}_c3 > /dev/null
 tools/profile.sh ${R}_c4 --workload street_x64_4k_hzb > /dev/null
 tools/profile.sh ${R}_c5 --workload subpixel_1g --steps 6 --warmup 2 > /dev/null
-STATS_ONLY=1 tools/profile.sh ${R}_c5hot --workload subpixel_1g_hotspot --steps 6 --warmup 2 > /dev/null
-STATS_ONLY=1 tools/profile.sh ${R}_masked --workload street_4k_masked > /dev/null
+# (the counter passes of these two as well: round 4 ran them STATS_ONLY and their traffic files came out empty)
+tools/profile.sh ${R}_c5hot --workload subpixel_1g_hotspot --steps 6 --warmup 2 > /dev/null
+tools/profile.sh ${R}_masked --workload street_4k_masked > /dev/null
 tools/pmc.sh ${R}_sq1 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" > gpurun_out/${R}_sq1.txt 2>&1
 tools/pmc.sh ${R}_sq2 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" > gpurun_out/${R}_sq2.txt 2>&1
 tools/pmc.sh ${R}_sq3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY" > gpurun_out/${R}_sq3.txt 2>&1
@@ -44,10 +45,18 @@ python bench.py --cull hierarchical --cpu-baseline-frames 0 > gpurun_out/${R}_be
 python bench.py --workload street_x64_4k_hzb --cull hierarchical --cpu-baseline-frames 0 > gpurun_out/${R}_bench_c4_bvh.json 2>/dev/null
 python bench.py --workload street_4k_masked --cpu-baseline-frames 0 > gpurun_out/${R}_bench_masked.json 2>/dev/null
 python bench.py --workload street_4k_masked_twin --cpu-baseline-frames 0 > gpurun_out/${R}_bench_masked_twin.json 2>/dev/null
-python tools/shard_time.py subpixel_1g 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c5.txt
-RANKS=1,8 python tools/shard_time.py street_x64_4k_hzb 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c4.txt
+# where the alpha-tested triangles are scan-converted: the variant libraries (chord_amd/build.py --tag ...) when they exist
+for v in msep msep2 mf2; do
+  [ -f chord_amd/_build/libchordvis_$v.so ] && CHORDVIS_LIB=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis_$v.so python bench.py --workload street_4k_masked --cpu-baseline-frames 0 > gpurun_out/${R}_bench_masked_$v.json 2>/dev/null
+done
+# every rank of the sharded frames, one at a time: the sharded group cull (default) at 1 / 2 / 4 / 8 ranks, the replicated cull at 8 beside it
+CULL=sharded python tools/shard_time.py subpixel_1g 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c5.txt
+CULL=replicated RANKS=8 python tools/shard_time.py subpixel_1g 2>&1 | grep "^ranks" | sed 's/^/[replicated cull] /' >> gpurun_out/${R}_shard_time_c5.txt
+PIPELINED=1 RANKS=8 python tools/shard_time.py subpixel_1g 2>&1 | grep "^ranks" | sed 's/^/[pipelined protocol] /' >> gpurun_out/${R}_shard_time_c5.txt
+CULL=both RANKS=1,8 python tools/shard_time.py street_x64_4k_hzb 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c4.txt
 PIPELINED=1 RANKS=8 python tools/shard_time.py street_x64_4k_hzb 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c4_pipelined.txt
 RANKS=1,8 python tools/shard_time.py subpixel_1g_hotspot 2>&1 | grep "^ranks" > gpurun_out/${R}_shard_time_c5hot.txt
+( cd /tmp && FRAMES=10 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${R}_rank3 -o r -- python $GRAFT_REPO_ROOT/tools/shard_rank.py subpixel_1g 8 3 > $GRAFT_REPO_ROOT/gpurun_out/${R}_rank3.log 2>&1 ); find gpurun_out/${R}_rank3 -name "*kernel_trace*" -delete
 python tools/group_host_time.py 8 2>&1 | grep "ranks on" > gpurun_out/${R}_group_host_time.txt
 python tools/shadow_time.py c3 2>&1 | grep "^c3" > gpurun_out/${R}_shadow_time.txt
 bash tools/trace.sh ${R}_trace > gpurun_out/${R}_timeline.txt 2>&1

@@ -69,7 +69,13 @@ for r in stats:
     t["launches"] += calls
 for t in traffic.values():
     t["hbm_bytes_per_launch"] = int((2.0 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024)
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --steps 40 --warmup 4` (tools/profile.sh); "
+try:
+    import subprocess
+    head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except OSError:
+    head = ""
+json.dump({"profile_head": head,       # the commit the tree stood at when the profile was summarised (bench.py reports it beside roofline.traffic)
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --steps 40 --warmup 4` (tools/profile.sh); "
                      "bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 per launch", "kernels": traffic},
           open(os.path.join(dst, name + "_traffic.json"), "w"), indent=1)
 print("wrote", os.path.join(dst, name + "_summary.md"))
