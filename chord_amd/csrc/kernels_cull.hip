@@ -548,32 +548,27 @@ __global__ __launch_bounds__(1024) void group_cull_prefix_kernel(uint32_t* __res
                                                                  uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters,
                                                                  uint32_t* __restrict__ mineCount)
 {
-    // A thread owns a contiguous run of `per` blocks (config 5: 8 192 blocks = 8 each): every count it needs is requested before the
-    // first is used, the run is summed in registers, ONE scan over the 1 024 thread totals orders the runs, and the exclusive offsets
-    // go back.  (Round 4's form walked the array in steps of 1 024 -- load, scan, two barriers, store, eight times in a row for config 5,
-    // and a second time for the rank's own counts: 18 us for 16 dependent round trips of a single workgroup.)  The visible counts
-    // and the rank's counts (sharded frames: blockCounts[2 * blocks ..)) are scanned together, packed in one 64-bit value.
+    // One workgroup walks the counts in steps of 1 024 (coalesced), the visible counts and -- sharded frames: blockCounts[2 * blocks ..) --
+    // the rank's own scanned TOGETHER as one 64-bit value (round 4 walked the array twice), and the next step's counts are requested
+    // before this step's scan and barriers, so a step costs the scan, not a memory round trip plus the scan.
+    // (Round 5 also tried a thread per contiguous run of blocks with every load up front: strided 4-byte loads, 15 us where this form
+    // takes 7 on config 4's 3 076 blocks; profiles/r05_config4_x64_4k_hzb_kernel_stats.csv of that run.)
     __shared__ unsigned long long sWave[16], sTris[16];
-    constexpr uint32_t MAXPER = 16u;                               // (up to 16 384 count blocks = 4 Mi group instances in one pass; more: a loop of passes)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool two = mineCount != nullptr;
     unsigned long long tris = 0, carry = 0;
-    for (uint32_t pass0 = 0; pass0 < blocks; pass0 += 1024u * MAXPER) {
-        const uint32_t nb = min(blocks - pass0, 1024u * MAXPER), per = (nb + 1023u) / 1024u;
-        const uint32_t first = pass0 + threadIdx.x * per;
-        uint32_t v[MAXPER], m[MAXPER];
-#pragma unroll
-        for (uint32_t k = 0; k < MAXPER; k++) {
-            const uint32_t b = first + k;
-            const bool in = k < per && b < pass0 + nb;
-            v[k] = in ? blockCounts[b] : 0u;
-            m[k] = (in && two) ? blockCounts[2u * blocks + b] : 0u;
-            if (in) tris += blockCounts[blocks + b];
-        }
-        unsigned long long sum = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < MAXPER; k++) sum += (unsigned long long)v[k] | ((unsigned long long)m[k] << 32);
-        unsigned long long incl = sum;
+    uint32_t nv = threadIdx.x < blocks ? blockCounts[threadIdx.x] : 0u;
+    uint32_t nm = (two && threadIdx.x < blocks) ? blockCounts[2u * blocks + threadIdx.x] : 0u;
+    uint32_t nt = threadIdx.x < blocks ? blockCounts[blocks + threadIdx.x] : 0u;
+    for (uint32_t base = 0; base < blocks; base += 1024u) {
+        const uint32_t b = base + threadIdx.x;
+        const unsigned long long v = (unsigned long long)nv | ((unsigned long long)nm << 32);
+        tris += nt;
+        const uint32_t bn = b + 1024u;
+        nv = bn < blocks ? blockCounts[bn] : 0u;
+        nm = (two && bn < blocks) ? blockCounts[2u * blocks + bn] : 0u;
+        nt = bn < blocks ? blockCounts[blocks + bn] : 0u;
+        unsigned long long incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
         if (lane == 63u) sWave[wave] = incl;
@@ -581,18 +576,10 @@ __global__ __launch_bounds__(1024) void group_cull_prefix_kernel(uint32_t* __res
         unsigned long long before = 0, all = 0;
 #pragma unroll
         for (uint32_t w = 0; w < 16u; w++) { const unsigned long long c = sWave[w]; if (w < wave) before += c; all += c; }
-        unsigned long long run = carry + before + incl - sum;      // exclusive offset of the thread's first block
-#pragma unroll
-        for (uint32_t k = 0; k < MAXPER; k++) {
-            const uint32_t b = first + k;
-            if (k < per && b < pass0 + nb) {
-                blockCounts[b] = (uint32_t)run;
-                if (two) blockCounts[2u * blocks + b] = (uint32_t)(run >> 32);
-            }
-            run += (unsigned long long)v[k] | ((unsigned long long)m[k] << 32);
-        }
+        const unsigned long long excl = carry + before + incl - v;
+        if (b < blocks) { blockCounts[b] = (uint32_t)excl; if (two) blockCounts[2u * blocks + b] = (uint32_t)(excl >> 32); }
         carry += all;
-        __syncthreads();                                           // sWave is rewritten by the next pass
+        __syncthreads();
     }
     if (threadIdx.x == 0) { *outCount = (uint32_t)carry; if (two) *mineCount = (uint32_t)(carry >> 32); }
 #pragma unroll

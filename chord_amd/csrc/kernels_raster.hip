@@ -1189,10 +1189,9 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
     const bool sprof = RASTER_PROFILE && (p.debug & DBG_SETUP_CLOCKS) != 0;
     unsigned long long sph[5] = {0, 0, 0, 0, 0}, stp = sprof ? wall_clock64() : 0ull;
 #define SPHASE(i) do { if (sprof) { const unsigned long long tn = wall_clock64(); sph[i] += tn - stp; stp = tn; } } while (0)
-    const uint32_t laneTop = lane;
+    // (the per-cluster opaque lane index of raster_setup_body was measured here too: 78 -> 76 VGPRs, but 928 -> 946 VALU wave-instructions
+    // per cluster -- this kernel is bound by VALU issue, and what was hoisted out of its loop was arithmetic it now repeats; not kept)
     for (; c < count; c += stride) {
-        uint32_t lane = laneTop;                                             // (opaque per cluster: see raster_setup_body)
-        asm volatile("" : "+v"(lane));
         const uint32_t V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
         const bool twoSided = (hdr.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u || p.depthOnly != 0u;
         const bool masked = CHORD_MATFLAG_ALPHA(hdr.matFlags) == CHORD_ALPHA_MASK;
