@@ -123,6 +123,7 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         CHORD_HIP(c, hipHostGetDevicePointer(&dh, h, 0));
         c->hBinHint = static_cast<volatile uint32_t*>(h); c->dBinHint = static_cast<uint32_t*>(dh);
     }
+    if (c->dHotTiles) CHORD_HIP(c, hipMemsetAsync(c->dHotTiles, 0, sizeof(uint32_t) * 2 * (1 + CHORD_HOT_TILES), c->stream));   // (tile ids of another target size)
     c->hBinHint[0] = 0u; c->hBinHint[1] = 0u;
     c->hBinHint[2] = 0xFFFFFFFFu; c->hBinHint[3] = 0xFFFFFFFFu;      // clusters per pass of the last finished frame: none yet
     {   // one {min, max} partial per block of the mip-0 kernel (64 x 4 texels per block)
@@ -366,6 +367,8 @@ int chordvis_create(int deviceOrdinal, void* hipStream, ChordCtx** outCtx)
         c->ownStream = true;
     }
     bool ok = hipMalloc((void**)&c->dTileClocks, sizeof(unsigned long long) * 18 * CHORD_MAX_TILES) == hipSuccess &&
+              hipMalloc((void**)&c->dHotTiles, sizeof(uint32_t) * 2 * (1 + CHORD_HOT_TILES)) == hipSuccess &&
+              hipMemset(c->dHotTiles, 0, sizeof(uint32_t) * 2 * (1 + CHORD_HOT_TILES)) == hipSuccess &&
               hipMalloc((void**)&c->dView, sizeof(DView)) == hipSuccess &&
               hipMalloc((void**)&c->dFrameState, sizeof(FrameState)) == hipSuccess;
     if (!ok) { chordvis_destroy(c); return CHORDVIS_E_HIP; }
@@ -394,7 +397,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
     dfree(c->dRankCmds); dfree(c->dLeftCmds); dfree(c->dMineCmds);
-    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
+    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dHotTiles); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
     if (c->hBinHint) { (void)hipHostFree(const_cast<uint32_t*>(c->hBinHint)); c->hBinHint = nullptr; c->dBinHint = nullptr; }

@@ -229,6 +229,7 @@ struct DeviceCounters {
 #define CHORD_TILE_MAX_SLICES 64u                    // a long bin is cut into at most this many slices
 #define CHORD_BIN_CHUNK_INVALID 0xFFFFFFFFu
 #define CHORD_TILE_SLICE_SHIFT 11                    // long bins are scan-converted in slices of 2048 entries
+#define CHORD_HOT_TILES 32u                          // hot tiles (bins beyond 65 536 entries) the tile schedule remembers per pass for the next frame's block kernel
 #ifndef CHORD_TILE_SHIFT
 #define CHORD_TILE_SHIFT 6                       // log2 of the raster tile side in pixels (5 or 6)
 #endif
@@ -382,6 +383,7 @@ struct ChordCtx {
     uint32_t* dTileRange = nullptr;       // per 64x64 tile {min, max} of valid depth (fused HZB)
     volatile uint32_t* hBinHint = nullptr;    // pinned, device-visible: per raster pass the longest bin of the last frame the GPU finished (hot tiles: launch_raster)
     uint32_t* dBinHint = nullptr;             // ... its device address
+    uint32_t* dHotTiles = nullptr;            // [2 passes][1 + CHORD_HOT_TILES]: the hot tiles of the last frame (count, tile | very hot << 31), device memory that no frame zeroes
     bool fuseHzb = false;                 // inside render_frame: the tile kernel emits HZB mips 0..5
     bool fuseHzbTemp = false;             // ... also into the temporary chain (slot 0) for stage 1
     int fuseHzbSlot = 1;                  // history slot being produced this frame

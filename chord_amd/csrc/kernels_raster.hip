@@ -104,6 +104,7 @@ struct RasterParams {
     uint32_t* binHint;                                  // host-visible word: the longest bin of this pass (tile order kernel -> launch_raster of later frames), or NULL
     uint32_t* countHint;                                // host-visible word: the number of clusters this pass set up, or NULL
     uint32_t slotHot;                                   // bin length from which a tile counts as hot (SLOT_HOT; tests lower it)
+    uint32_t* hotTiles;                                 // [1 + CHORD_HOT_TILES] this pass's hot tiles of the LAST frame (count, then tile | very hot << 31): written by the tile schedule, read by the block kernel's hot variant
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
 // The per-phase clocks of the setup kernels (debug bit 512) and of the tile kernel (bit 16) exist only in a build with
@@ -361,6 +362,9 @@ __device__ __forceinline__ uint32_t bin_capacity(const RasterParams& p) { return
 template <class P>
 __device__ __forceinline__ void bin_alloc(const P& p, uint32_t tile, uint32_t slot)
 {
+#ifdef EXP_NO_CHUNKS
+    return;
+#endif
     if (slot < p.binCap) return;
     const uint32_t o = slot - p.binCap, j = o >> CHORD_BIN_CHUNK_SHIFT;
     if (j >= p.binMaxChunks || (o & (CHORD_BIN_CHUNK - 1u)) != 0u) return;
@@ -378,6 +382,9 @@ template <class P>
 __device__ __forceinline__ void bin_put(const P& p, uint32_t tile, uint32_t slot, uint32_t gi)
 {
     // (tile < 4096 and the fixed part of a bin at most 2^20 entries: the index is a full-rate 24-bit multiply and fits 32 bits)
+#ifdef EXP_NO_CHUNKS
+    slot &= p.binCap - 1u;                                      // measurement only (wrong image): no entry ever lives in a pool chunk
+#endif
     if (slot < p.binCap) { p.tileBins[__umul24(tile, p.binCap) + slot] = gi; return; }
     const uint32_t o = slot - p.binCap, j = o >> CHORD_BIN_CHUNK_SHIFT;
     if (j >= p.binMaxChunks) { atomicOr(&p.counters->overflow, 1u); return; }
@@ -1135,6 +1142,24 @@ __device__ __forceinline__ void raster_setup_blocks_body(const RasterParams& p, 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     SlotCache& sc = slotCaches[HOT ? wave : 0u];
     if (HOT && lane < SLOT_CACHE) { sc.key[lane] = 0u; sc.next[lane] = 0u; sc.end[lane] = 0u; }
+    if (HOT) {
+        // the tiles that were hot in the last frame are hot from this launch's first cluster on: a tile used to become hot only once its
+        // bin held SLOT_HOT entries IN THIS LAUNCH, i.e. every frame began with 65 536 single draws from one counter line (~0.75 ms
+        // at the ~88 returning atomics per microsecond a line sustains) and 24 k draws of eight before the draws of 32 -- with every wave of
+        // the rank that owns the tile queued on it.  An entry with an empty reserve at position p draws ahead on its first use, 32
+        // slots when p >= SLOT_VERY_HOT; a tile that has cooled down since costs a few "no entry" words at the end of the launch.
+        const uint32_t* __restrict__ hl = scalar_load(&kernel_args()->hotTiles);
+        WAVE_LDS_SYNC();
+        if (hl) {
+            const uint32_t nHot = min(hl[0], (uint32_t)CHORD_HOT_TILES);
+            if (lane < nHot) {
+                const uint32_t e = hl[1u + lane], tile = e & 0xFFFu, ci = tile & (SLOT_CACHE - 1u);
+                const uint32_t pos = (e >> 31) ? SLOT_VERY_HOT : 0u;
+                sc.key[ci] = tile + 1u; sc.next[ci] = pos; sc.end[ci] = pos;           // (two hot tiles on one entry: either wins)
+            }
+        }
+        WAVE_LDS_SYNC();
+    }
     float* lX = sVert[0][wave]; float* lY = sVert[1][wave]; float* lW = sVert[2][wave];
     float* lU = sVert[3][wave]; float* lV = sVert[4][wave]; float* lD = sVert[5][wave];
     int32_t* lSX = sSnap[0][wave]; int32_t* lSY = sSnap[1][wave];
@@ -1714,10 +1739,10 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 template <uint32_t NT>
 __device__ __forceinline__ void tile_order_part(const RasterParams& p)
 {
-    __shared__ uint32_t hist[20], base[20], cursor[20], splitItems, longest;
+    __shared__ uint32_t hist[20], base[20], cursor[20], splitItems, longest, hotCount, hotList[CHORD_HOT_TILES];
     const uint32_t tiles = p.tilesX * p.tilesY;
     if (threadIdx.x < 20u) { hist[threadIdx.x] = 0; cursor[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { splitItems = 0; longest = 0; }
+    if (threadIdx.x == 0) { splitItems = 0; longest = 0; hotCount = 0; }
     __syncthreads();
     constexpr uint32_t PER_THREAD = CHORD_MAX_TILES / NT;
     uint32_t myBucket[PER_THREAD], myPos[PER_THREAD], mySlices[PER_THREAD], myCount[PER_THREAD];
@@ -1735,6 +1760,8 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
             // bit 30: the bin holds alpha-tested triangles -- on the first pass of a frame the masked pass (raster_masked_tile_kernel)
             // has written the tile already and the tile kernel starts from those words instead of from zero
             myCount[k] = c | (cnt.y ? 0x80000000u : 0u) | (cnt.w ? 0x40000000u : 0u);
+            // a bin this long is a hot tile: the next frame's block kernel draws its slots ahead from the first cluster on (hotTiles)
+            if (c >= p.slotHot && p.hotTiles) { const uint32_t h = atomicAdd(&hotCount, 1u); if (h < CHORD_HOT_TILES) hotList[h] = t | (c >= SLOT_VERY_HOT ? 0x80000000u : 0u); }
             if (c > TILE_SPLIT_MIN && !ABL(p, DBG_NO_SPLIT)) {
                 mySlices[k] = min((c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT, CHORD_TILE_MAX_SLICES);
                 myBucket[k] = 18u;
@@ -1754,7 +1781,9 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
         p.tileOrder[0] = make_uint2(p.clearTiles ? acc : acc - hist[17], 0u);
         if (p.binHint) *p.binHint = longest;                      // (bins short enough to stay whole report 0)
         if (p.countHint) *p.countHint = *p.count;
+        if (p.hotTiles) p.hotTiles[0] = min(hotCount, (uint32_t)CHORD_HOT_TILES);
     }
+    if (p.hotTiles && threadIdx.x < min(hotCount, (uint32_t)CHORD_HOT_TILES)) p.hotTiles[1u + threadIdx.x] = hotList[threadIdx.x];
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < PER_THREAD; k++) {
@@ -3122,6 +3151,8 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     const bool maybeDense = p.blockCap != 0u && (p.blockForce != 0u || (uint64_t)in.capacity * 16ull >= rankPixels);
     p.leftCount = nullptr; p.leftCmds = nullptr;
     p.binHint = nullptr; p.countHint = nullptr;
+    p.slotHot = (c->debugFlags & DBG_FORCE_HOT) ? 64u : SLOT_HOT;
+    p.hotTiles = c->dHotTiles ? c->dHotTiles + (size_t)pass * (1u + CHORD_HOT_TILES) : nullptr;
     // ... and whether it IS dense the device decides from the list's length (launch_is_dense).  A list that could be dense but was
     // nowhere near it in the last frame the GPU finished (BASELINE config 4: one cluster per 60 pixels, capacity for one per 30)
     // gets no block kernel at all -- the launch would find nothing to do and cost its 4.5 us, twice per frame.  Half the device's
@@ -3152,7 +3183,6 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         const uint32_t bb = std::max(1u, std::min((in.capacity + 3u) / 4u, (uint32_t)c->numCUs * BLOCKS_MIN_WAVES));
         // the longest bin of this pass in the last frame the GPU finished: a hot tile then -> the variant that draws ahead now
         const bool hot = (c->hBinHint && c->hBinHint[pass] >= SLOT_HOT) || (c->debugFlags & DBG_FORCE_HOT);
-        p.slotHot = (c->debugFlags & DBG_FORCE_HOT) ? 64u : SLOT_HOT;
         if (hot) CHORD_LAUNCH(c, raster_setup_blocks_kernel<true>, dim3(bb), dim3(256), 0, c->stream, p);
         else     CHORD_LAUNCH(c, raster_setup_blocks_kernel<false>, dim3(bb), dim3(256), 0, c->stream, p);
     }
