@@ -2030,7 +2030,16 @@ __device__ __forceinline__ uint32_t block_scan_tb(uint32_t v, uint32_t* waveSums
 #define MASKED_PIXELS_PER_TRIP 1
 #endif
 #define ENTRY_WORDS 13            // word 12: record index of a masked triangle (its extension follows it)
-struct EntrySoA { uint32_t w[ENTRY_WORDS][TB]; };
+// entries per batch of the tile kernel's triangle pipeline (the first TILE_BATCH threads fetch and set up one bin entry each) and units
+// per round of its unit list: 512 / 4096 = 26 + 16 KB of LDS beside the 33-KB tile = two workgroups per CU; 256 / 1536 = 13 + 6 KB =
+// three, if the registers allow it (TILE_MIN_BLOCKS 6: 80 VGPRs) -- a build switch, measured in profiles/r05_tile_kernel_experiments.txt
+#ifndef TILE_BATCH
+#define TILE_BATCH TB
+#endif
+#ifndef TILE_UNIT_CAP
+#define TILE_UNIT_CAP UNIT_CAP
+#endif
+struct EntrySoA { uint32_t w[ENTRY_WORDS][TILE_BATCH]; };
 #define EF_KIND_SHIFT 24          // box word: x0 | y0 << 6 | x1 << 12 | y1 << 18 | kind << 24 | bias1 << 26 | bias2 << 27 | sneg << 28
 
 template <typename E_t>
@@ -2601,12 +2610,15 @@ __device__ __forceinline__ void merge_blocks(unsigned long long* tile, const uns
 #undef MB_MERGE
 }
 
+#ifndef TILE_MIN_BLOCKS
+#define TILE_MIN_BLOCKS 4               // waves per SIMD the register allocation aims at (launch bounds: 4 -> 128 VGPRs, 6 -> 80)
+#endif
 template <bool SH, bool MASKED, bool DEPTH>
-__global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
+__global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(RasterParams p)
 {
     __shared__ __align__(16) unsigned long long tile[TILE * TPITCH];   // 32.5 KB
     __shared__ EntrySoA prm;                                     // 26 KB: the batch's entries that need row units
-    __shared__ uint32_t unitList[UNIT_CAP];                      // 16 KB: (entry | row << 9 | segment << 15) of the units of a round
+    __shared__ uint32_t unitList[TILE_UNIT_CAP];                      // 16 KB: (entry | row << 9 | segment << 15) of the units of a round
     __shared__ uint32_t offs[16];                                // (scratch of the tile-out reduction)
     __shared__ uint32_t waveSums[2][TB / 64];
     __shared__ uint32_t chunkTab[64];                            // the overflow chunks this item's entries live in
@@ -2658,7 +2670,8 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
     const bool early = n <= p.binCap && !hasBlocks;               // (uniform)
     const uint32_t k0 = lo + tix;
-    const uint32_t word0 = (early && k0 < n) ? bin[k0] : 0xFFFFFFFFu;
+    const bool entryThread = TILE_BATCH == TB || tix < TILE_BATCH;   // (a batch is TILE_BATCH bin entries, one per thread of the first waves)
+    const uint32_t word0 = (early && entryThread && k0 < n) ? bin[k0] : 0xFFFFFFFFu;
 
     // ---- tile in: zero (first pass: this is the clear; un-fused later passes merge by max at tile-out), or the
     //      current words when a later pass must leave the finished tile in LDS for the fused HZB reduction ----
@@ -2700,7 +2713,7 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
     if (early) {
         nameNext = record_name(word0);                                          // (binEntry of an entry of the fixed bin)
         if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);        // record of batch 0
-        if (k0 + TB < n) idxNext = record_name(bin[k0 + TB]);                   // bin entry of batch 1
+        if (entryThread && k0 + TILE_BATCH < n) idxNext = record_name(bin[k0 + TILE_BATCH]);   // bin entry of batch 1
     }
     __syncthreads();
     PHASE(0);
@@ -2755,19 +2768,20 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         return okIdx ? gi : 0xFFFFFFFFu;                       // (only after a reported overflow)
     };
     if (!early) {
-        idxNext = k0 < n ? binEntry(k0) : 0xFFFFFFFFu;                           // bin entry of batch 0
+        idxNext = entryThread && k0 < n ? binEntry(k0) : 0xFFFFFFFFu;            // bin entry of batch 0
         nameNext = idxNext;
         if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);         // record of batch 0
-        idxNext = k0 + TB < n ? binEntry(k0 + TB) : 0xFFFFFFFFu;                 // bin entry of batch 1
+        idxNext = entryThread && k0 + TILE_BATCH < n ? binEntry(k0 + TILE_BATCH) : 0xFFFFFFFFu;   // bin entry of batch 1
     }
-    for (uint32_t base = lo; base < n; base += TB) {
+    uint32_t batchNo = 0;
+    for (uint32_t base = lo; base < n; base += TILE_BATCH, batchNo++) {
         const uint32_t k = base + tix;
         const uint4 q0 = nq0, q1 = nq1, q2 = nq2;
         const uint32_t name = nameNext;
         const bool have = name != 0xFFFFFFFFu && !ABL(p, DBG_NO_ENTRY);
         nameNext = idxNext;
         if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);         // record of the next batch
-        idxNext = k + 2u * TB < n ? binEntry(k + 2u * TB) : 0xFFFFFFFFu;          // bin entry of the batch after
+        idxNext = entryThread && k + 2u * TILE_BATCH < n ? binEntry(k + 2u * TILE_BATCH) : 0xFFFFFFFFu;   // bin entry of the batch after
         if (prof) { volatile uint32_t sink = q1.w; (void)sink; }
         PHASE(1);
         uint32_t rows = 0;
@@ -2812,16 +2826,16 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
         // half: a batch has at most 512 x 64 units)
         const bool mine3 = MASKED && rows && ((prm.w[11][tix] >> EF_KIND_SHIFT) & 3u) == 3u;
         const uint32_t rowsN = mine3 ? 0u : rows, rowsM = mine3 ? rows : 0u;
-        const uint32_t offAll = block_scan_tb(rowsN | (rowsM << 16), waveSums[(base >> 9) & 1u], &total);
+        const uint32_t offAll = block_scan_tb(rowsN | (rowsM << 16), waveSums[batchNo & 1u], &total);
         const uint32_t offN = offAll & 0xFFFFu, offM = offAll >> 16, totalM = MASKED ? total >> 16 : 0u;
         total &= 0xFFFFu;
         PHASE(3);
-        // my units [off, off + n) of a population, cut to the round's window [r0, r0 + UNIT_CAP): one LDS word each
+        // my units [off, off + n) of a population, cut to the round's window [r0, r0 + TILE_UNIT_CAP): one LDS word each
         auto list_units = [&](uint32_t off, uint32_t n, uint32_t r0) {
             if (!n) return;
             const uint32_t box = prm.w[11][tix];
             const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> SEG_SHIFT) + 1u, y0l = (box >> 6) & 63u;
-            const uint32_t lo2 = max(off, r0), hi2 = min(off + n, r0 + UNIT_CAP);
+            const uint32_t lo2 = max(off, r0), hi2 = min(off + n, r0 + TILE_UNIT_CAP);
             if (lo2 < hi2) {
                 uint32_t j = lo2 - off;
                 uint32_t row = y0l + (nseg == 1u ? j : nseg == 2u ? j >> 1 : nseg == 4u ? j >> 2 : j / 3u);
@@ -2832,25 +2846,25 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                 }
             }
         };
-        // rounds of UNIT_CAP units: every entry thread lists its units of the round, then every thread takes units TB apart -- a
+        // rounds of TILE_UNIT_CAP units: every entry thread lists its units of the round, then every thread takes units TB apart -- a
         // unit finds its entry with ONE read instead of a 9-step binary search
-        for (uint32_t r0 = 0; r0 < total; r0 += UNIT_CAP) {
+        for (uint32_t r0 = 0; r0 < total; r0 += TILE_UNIT_CAP) {
             list_units(offN, rowsN, r0);
             __syncthreads();
-            const uint32_t nr = min(total - r0, (uint32_t)UNIT_CAP);
+            const uint32_t nr = min(total - r0, (uint32_t)TILE_UNIT_CAP);
             for (uint32_t ui = tix; ui < nr; ui += TB) {
                 const uint32_t d = unitList[ui];
                 if (ABL(p, DBG_NO_UNITS)) continue;
                 const int32_t trips = entry_unit<MASKED, DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 3u, ox, oy, noPixels);
                 if (prof) { cUnits++; cUnitIters += (uint32_t)trips; }
             }
-            if (r0 + UNIT_CAP < total || totalM) __syncthreads(); // the list is rewritten by the next round
+            if (r0 + TILE_UNIT_CAP < total || totalM) __syncthreads(); // the list is rewritten by the next round
         }
-        for (uint32_t r0 = 0; r0 < totalM; r0 += UNIT_CAP) {      // (MASKED only) the alpha-tested triangles' units
+        for (uint32_t r0 = 0; r0 < totalM; r0 += TILE_UNIT_CAP) {      // (MASKED only) the alpha-tested triangles' units
             if (rowsM) {
                 const uint32_t box = prm.w[11][tix];
                 const uint32_t nseg = ((((box >> 12) & 63u) - (box & 63u)) >> MASKED_SEG_SHIFT) + 1u, y0l = (box >> 6) & 63u;
-                const uint32_t lo2 = max(offM, r0), hi2 = min(offM + rowsM, r0 + UNIT_CAP);
+                const uint32_t lo2 = max(offM, r0), hi2 = min(offM + rowsM, r0 + TILE_UNIT_CAP);
                 if (lo2 < hi2) {
                     const uint32_t j = lo2 - offM, g = j / nseg;
                     uint32_t row = y0l + g * MASKED_ROWS, seg = j - g * nseg;
@@ -2861,12 +2875,12 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
                 }
             }
             __syncthreads();
-            const uint32_t nr = min(totalM - r0, (uint32_t)UNIT_CAP);
+            const uint32_t nr = min(totalM - r0, (uint32_t)TILE_UNIT_CAP);
             for (uint32_t ui = tix; ui < nr; ui += TB) {
                 const uint32_t d = unitList[ui];
                 entry_unit_masked<DEPTH>(p, prm, tile, d & 511u, (d >> 9) & 63u, (d >> 15) & 7u, ox, oy, noPixels);
             }
-            if (r0 + UNIT_CAP < totalM) __syncthreads();
+            if (r0 + TILE_UNIT_CAP < totalM) __syncthreads();
         }
         total |= totalM;
         if (total) __syncthreads();                               // prm / the unit list are rewritten by the next batch
@@ -2950,6 +2964,10 @@ __global__ __launch_bounds__(TB, 4) void raster_tile_kernel(RasterParams p)
 // as it does anyway.  The 64-bit max is order-independent, so which kernel merges a fragment first changes nothing.
 // Price: a masked tile's 32 KB once out and once in on the first pass, and one more launch per pass of a scene with alpha-tested
 // materials; scenes without them launch nothing of this.
+#if !CHORD_MASKED_FUSED && TILE_BATCH != TB
+#error "the separate masked pass sets up one entry per thread of its workgroup: TILE_BATCH must be TB"
+#endif
+#if TILE_BATCH == TB
 template <bool SH, bool DEPTH>
 __global__ __launch_bounds__(TB, 4) void raster_masked_tile_kernel(RasterParams p)
 {
@@ -3065,6 +3083,7 @@ __global__ __launch_bounds__(TB, 4) void raster_masked_tile_kernel(RasterParams 
     __syncthreads();                                              // the LDS tile is reused by the next item
     }
 }
+#endif
 
 // ---- launcher ---------------------------------------------------------------------------------
 hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
@@ -3191,13 +3210,15 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     stamp(c, S_R_CLUSTER);
     CHORD_LAUNCH(c, raster_clip_and_bin_large_kernel, dim3(CLIP_BLOCKS + (uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
     CHORD_LAUNCH(c, raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
-    if (c->anyMasked && !CHORD_MASKED_FUSED) {
+#if !CHORD_MASKED_FUSED
+    if (c->anyMasked) {
         // alpha-tested triangles: their own pass over the scheduled tiles whose bins hold any (raster_masked_tile_kernel)
         const uint32_t items = tiles;                                     // (the workgroups stride over the device-side item list)
         if (c->depthClamp && !sh) CHORD_LAUNCH(c, (raster_masked_tile_kernel<false, true>), dim3(items), dim3(TB), 0, c->stream, p);
         else if (sh)              CHORD_LAUNCH(c, (raster_masked_tile_kernel<true, false>), dim3(items), dim3(TB), 0, c->stream, p);
         else                      CHORD_LAUNCH(c, (raster_masked_tile_kernel<false, false>), dim3(items), dim3(TB), 0, c->stream, p);
     }
+#endif
     stamp(c, S_R_CLIP);
     // first pass of a frame: every tile is written, one block each, dispatched heaviest first; later passes touch
     // few tiles: one resident wave of blocks strides over the (device-side) active list
