@@ -1589,6 +1589,10 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
     out->overflow = dc.overflow;
     out->rasterLaunches = c->rasterCalls;
     out->kernelLaunches = c->lastFrameLaunches;
+    for (int pass = 0; pass < 2; pass++) {
+        out->clipTriangles[pass] = dc.clipTriCount[pass];
+        for (uint32_t i = 0; i < CHORD_LIST_SHARDS; i++) out->largeRecords[pass] += dc.largeCount[pass][i * CHORD_SHARD_STRIDE];
+    }
     for (uint32_t i = 0; i < CHORD_LIST_SHARDS; i++) {
         out->triangleRecords += dc.triCount[i * CHORD_SHARD_STRIDE] + dc.triCountC[i * CHORD_SHARD_STRIDE];
         out->triangleRecordsCompact += dc.triCountC[i * CHORD_SHARD_STRIDE];

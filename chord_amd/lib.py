@@ -65,11 +65,11 @@ class Stats(C.Structure):
         ("pixelBlockBytes", C.c_uint64),
         ("pixelBlocks", C.c_uint64),
         ("msExchangeHzb", C.c_float), ("msExchangeVis", C.c_float), ("msExchangeCull", C.c_float), ("msExchangeFinal", C.c_float),
-        ("kernelLaunches", C.c_uint32),
+        ("kernelLaunches", C.c_uint32), ("largeRecords", C.c_uint32 * 2), ("clipTriangles", C.c_uint32 * 2),
     ]
 
     def as_dict(self):
-        return {n: (list(getattr(self, n)) if n == "tilesTouched" else getattr(self, n)) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n in ("tilesTouched", "largeRecords", "clipTriangles") else getattr(self, n)) for n, _ in self._fields_}
 
 
 def _preload_hip_runtime():

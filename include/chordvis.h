@@ -132,6 +132,8 @@ typedef struct ChordStats {
     float    msExchangeFinal;      /* ... library-run frames (chordvis_comm_*, ChordGroup): the small end-of-frame exchange, stamped apart from the image
                                       gather (msExchangeVis is then the image alone); 0 when the host drives the phases */
     uint32_t kernelLaunches;       /* kernel launches of the last finished frame (a sub-millisecond frame is bounded by launches x launch floor) */
+    uint32_t largeRecords[2];      /* per raster pass: records touching more than 2 x 2 tiles (binned by the large-record binner, or tested by the tiles themselves) */
+    uint32_t clipTriangles[2];     /* per raster pass: triangles that went through the homogeneous clipper */
 } ChordStats;
 
 /* ------------------------------------------------------------------ host-only (no device needed) */
