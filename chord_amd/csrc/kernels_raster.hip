@@ -39,6 +39,7 @@
 #include "device_math.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -105,6 +106,7 @@ struct RasterParams {
     uint32_t* countHint;                                // host-visible word: the number of clusters this pass set up, or NULL
     uint32_t slotHot;                                   // bin length from which a tile counts as hot (SLOT_HOT; tests lower it)
     uint32_t* hotTiles;                                 // [1 + CHORD_HOT_TILES] this pass's hot tiles of the LAST frame (count, then tile | very hot << 31): written by the tile schedule, read by the block kernel's hot variant
+    uint32_t tileSlots;                                 // tile workgroups the device holds at once (2 per CU); a pass with fewer non-empty tiles than that cuts its bins finer (tile_order_part), 0: never
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
 // The per-phase clocks of the setup kernels (debug bit 512) and of the tile kernel (bit 16) exist only in a build with
@@ -1736,20 +1738,24 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 #ifndef TILE_SPLIT_MIN
 #define TILE_SPLIT_MIN 6144u       // bins up to this many entries stay whole
 #endif
+#ifndef TILE_SLICE_MIN
+#define TILE_SLICE_MIN 1024u       // the shortest slice of a pass that has fewer tiles than the device has slots
+#endif
 template <uint32_t NT>
 __device__ __forceinline__ void tile_order_part(const RasterParams& p)
 {
-    __shared__ uint32_t hist[20], base[20], cursor[20], splitItems, longest, hotCount, hotList[CHORD_HOT_TILES];
+    __shared__ uint32_t hist[20], base[20], cursor[20], splitItems, longest, hotCount, hotList[CHORD_HOT_TILES], entriesAll, tilesBusy;
     const uint32_t tiles = p.tilesX * p.tilesY;
     if (threadIdx.x < 20u) { hist[threadIdx.x] = 0; cursor[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { splitItems = 0; longest = 0; hotCount = 0; }
+    if (threadIdx.x == 0) { splitItems = 0; longest = 0; hotCount = 0; entriesAll = 0; tilesBusy = 0; }
     __syncthreads();
     constexpr uint32_t PER_THREAD = CHORD_MAX_TILES / NT;
-    uint32_t myBucket[PER_THREAD], myPos[PER_THREAD], mySlices[PER_THREAD], myCount[PER_THREAD];
+    uint32_t myBucket[PER_THREAD], myPos[PER_THREAD], mySlices[PER_THREAD], myCount[PER_THREAD], myHas[PER_THREAD];
+    uint32_t sumMine = 0, tilesMine = 0;
 #pragma unroll
     for (uint32_t k = 0; k < PER_THREAD; k++) {
         const uint32_t t = threadIdx.x + k * NT;
-        myBucket[k] = 0xFFFFFFFFu; myPos[k] = 0; mySlices[k] = 1; myCount[k] = 0;
+        myBucket[k] = 0xFFFFFFFFu; myPos[k] = 0; mySlices[k] = 1; myCount[k] = 0; myHas[k] = 0;
         // (sharded frames: another rank's tiles are not work items at all -- their bins are empty, and the clear pass must not touch them)
         if (t < tiles && owns_tile(p.shard, (int32_t)(t % p.tilesX), (int32_t)(t / p.tilesX))) {
             // (words 0 and 1 of the tile's counter line -- bin entries | of which pixel blocks -- in one 8-byte load)
@@ -1760,13 +1766,35 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
             // bit 30: the bin holds alpha-tested triangles -- on the first pass of a frame the masked pass (raster_masked_tile_kernel)
             // has written the tile already and the tile kernel starts from those words instead of from zero
             myCount[k] = c | (cnt.y ? 0x80000000u : 0u) | (cnt.w ? 0x40000000u : 0u);
+            myHas[k] = 1u;
+            sumMine += c; tilesMine += c ? 1u : 0u;
+        }
+    }
+    // A pass with fewer non-empty tiles than the device holds tile workgroups (a rank of an 8-rank frame owns 255 tiles of a 4K
+    // target, 256 CUs hold 512 workgroups; so does a 1080p target on one GPU) leaves slots idle while every tile is one
+    // workgroup's serial work: its bins are cut finer -- into about as many equal shares as there are slots, never shorter than
+    // TILE_SLICE_MIN entries (a slice pays for a tile of LDS zeroed and its touched words merged through the slab).
+    // The image does not depend on the cut (64-bit max).
+    if (p.tileSlots) { atomicAdd(&entriesAll, sumMine); atomicAdd(&tilesBusy, tilesMine); }
+    __syncthreads();
+    uint32_t splitMin = TILE_SPLIT_MIN, sliceLen = TILE_SLICE;
+    if (p.tileSlots && tilesBusy < p.tileSlots) {
+        const uint32_t share = (entriesAll / p.tileSlots + 511u) & ~511u;   // (whole batches of the tile kernel)
+        sliceLen = min(TILE_SLICE, max(TILE_SLICE_MIN, share));
+        splitMin = min(TILE_SPLIT_MIN, sliceLen + sliceLen / 2u);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER_THREAD; k++) {
+        const uint32_t t = threadIdx.x + k * NT;
+        if (myHas[k]) {
+            const uint32_t c = myCount[k] & 0x3FFFFFFFu;
             // a bin this long is a hot tile: the next frame's block kernel draws its slots ahead from the first cluster on (hotTiles)
             if (c >= p.slotHot && p.hotTiles) { const uint32_t h = atomicAdd(&hotCount, 1u); if (h < CHORD_HOT_TILES) hotList[h] = t | (c >= SLOT_VERY_HOT ? 0x80000000u : 0u); }
-            if (c > TILE_SPLIT_MIN && !ABL(p, DBG_NO_SPLIT)) {
-                mySlices[k] = min((c + TILE_SLICE - 1u) >> TILE_SLICE_SHIFT, CHORD_TILE_MAX_SLICES);
+            if (c > splitMin && !ABL(p, DBG_NO_SPLIT)) {
+                mySlices[k] = min((c + sliceLen - 1u) / sliceLen, CHORD_TILE_MAX_SLICES);
                 myBucket[k] = 18u;
                 myPos[k] = atomicAdd(&splitItems, mySlices[k]);
-                atomicMax(&longest, c);
+                if (c > TILE_SPLIT_MIN) atomicMax(&longest, c);   // (the host's hint keeps its meaning: bins that a full launch would keep whole report 0)
             } else {
                 // bucket 4 = 2^11.., bucket 16 = count 1, bucket 17 = empty
                 myBucket[k] = c ? 16u - (31u - (uint32_t)__clz(c)) : 17u;
@@ -1927,6 +1955,7 @@ struct UnitParams {           // one batch entry, as the row loop wants it
     int32_t skind;            // s in bit 0 (1 = negative), kind << 1
 };
 #define TB 512                  // threads per tile workgroup = entries per batch
+static_assert(TB == 512, "tile_order_part rounds a pass's slice length to batches of 512");
 #define UNIT_CAP 4096           // units per round of a batch
 
 template <typename E_t>
@@ -2641,9 +2670,9 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     const bool preloaded = !CHORD_MASKED_FUSED && p.clearTiles && (itemCount.y & 0x40000000u) != 0u;   // the masked pass wrote this tile (first pass of a frame)
     const int32_t tinyArea = nAll >= TINY_DENSE_MIN ? TINY_AREA_DENSE : TINY_AREA;
     // entries [lo, n) of the bin are this item's
-    // (slices of TILE_SLICE entries; a bin too long for CHORD_TILE_MAX_SLICES of them is cut into that many equal parts,
-    // rounded to whole batches)
-    const uint32_t per = slices > 1u ? max(TILE_SLICE, ((nAll + slices - 1u) / slices + TB - 1u) & ~(TB - 1u)) : nAll;
+    // (equal parts rounded up to whole batches: with the schedule's slice count -- ceil(entries / slice length), slice length
+    // TILE_SLICE, or shorter in a pass with fewer tiles than the device has slots -- that is slices of the schedule's length)
+    const uint32_t per = slices > 1u ? ((nAll + slices - 1u) / slices + TB - 1u) & ~(TB - 1u) : nAll;
     const uint32_t lo = slices > 1u ? min(nAll, slice * per) : 0u;
     const uint32_t n = ABL(p, DBG_NO_BATCH) ? lo : (slices > 1u ? min(nAll, lo + per) : nAll);
     const bool prof = RASTER_PROFILE && (p.debug & DBG_TILE_CLOCKS) != 0;
@@ -3171,6 +3200,10 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.leftCount = nullptr; p.leftCmds = nullptr;
     p.binHint = nullptr; p.countHint = nullptr;
     p.slotHot = (c->debugFlags & DBG_FORCE_HOT) ? 64u : SLOT_HOT;
+    {   // (CHORDVIS_TILE_SLOTS: measurements only -- 0 keeps every bin up to TILE_SPLIT_MIN entries whole, as before round 5)
+        static const int forced = [] { const char* e = getenv("CHORDVIS_TILE_SLOTS"); return e ? atoi(e) : -1; }();
+        p.tileSlots = forced >= 0 ? (uint32_t)forced : (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u);
+    }
     p.hotTiles = c->dHotTiles ? c->dHotTiles + (size_t)pass * (1u + CHORD_HOT_TILES) : nullptr;
     // ... and whether it IS dense the device decides from the list's length (launch_is_dense).  A list that could be dense but was
     // nowhere near it in the last frame the GPU finished (BASELINE config 4: one cluster per 60 pixels, capacity for one per 30)
@@ -3227,7 +3260,8 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // was measured: tile kernel +4..6 % on config 3, +11..18 % on config 4; the dispatcher's dynamic hand-out of one item
     // per block balances better than any static split)
     // (sharded frames: the work items are the rank's own tiles)
-    const uint32_t tileBlocks = clearTiles ? (sh ? min(tiles, c->shard.slotsPerRank) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
+    // (a rank's slices: its bins are cut into about tileSlots shares when it owns fewer tiles than that; blocks beyond the item count leave at once)
+    const uint32_t tileBlocks = clearTiles ? (sh ? min(tiles, max(c->shard.slotsPerRank, p.tileSlots + p.tileSlots / 2u)) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
     // (the tile kernel's instantiations are the opaque ones: alpha-tested triangles were scan-converted by the masked pass above)
 #if CHORD_MASKED_FUSED
     if (c->anyMasked) {

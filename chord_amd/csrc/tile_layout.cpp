@@ -20,7 +20,7 @@
 //     share are placed one by one, heaviest first, on the least loaded rank; the others are cut into contiguous runs along the
 //     curve such that the heaviest rank is as light as possible (bisection over the bound); the lightest tiles -- together a
 //     sixteenth of the load at most, each a quarter of the mean tile at most -- are fillers that bring every rank to its tile
-//     count, again in runs along the curve.
+//     count: each joins the region next to it on the curve while that region is below its count, the rest go out in runs.
 
 #include "device_layer.h"
 
@@ -148,13 +148,28 @@ int tile_layout(uint32_t tilesX, uint32_t tilesY, uint32_t ranks, const uint32_t
         }
     }
 
-    // ---- fillers: every rank to its tile count (tiles / N, the first tiles % N one more), then whatever room is left
+    // ---- fillers: every rank to its tile count (tiles / N, the first tiles % N one more), then whatever room is left.
+    //      A filler goes to the rank that owns the tile next to it ON THE CURVE while that rank is below its count -- a sweep
+    //      forwards (the tile before it), then one backwards (the tile after it), so a run of light tiles between two regions is
+    //      shared by those two regions from both ends and the regions stay compact; what neither neighbour has room for (a sky
+    //      larger than its neighbours' counts) is handed out in curve order, rank by rank, as before.
     {
+        auto quota = [&](uint32_t r) { return tiles / N + (r < tiles % N ? 1u : 0u); };
+        for (int dir = 0; dir < 2; dir++) {
+            int prev = -1;
+            for (uint32_t i = 0; i < tiles; i++) {
+                const uint32_t t = order[dir == 0 ? i : tiles - 1u - i];
+                if (own[t] < 0 && prev >= 0 && count[(uint32_t)prev] < quota((uint32_t)prev)) give(t, (uint32_t)prev);
+                prev = own[t];
+            }
+        }
+        std::vector<uint32_t> rest;
+        for (uint32_t t : light) if (own[t] < 0) rest.push_back(t);
         size_t next = 0;
-        for (int round = 0; round < 2 && next < light.size(); round++)
-            for (uint32_t r = 0; r < N && next < light.size(); r++) {
-                const uint32_t quota = round == 0 ? tiles / N + (r < tiles % N ? 1u : 0u) : S;
-                while (count[r] < quota && next < light.size()) give(light[next++], r);
+        for (int round = 0; round < 2 && next < rest.size(); round++)
+            for (uint32_t r = 0; r < N && next < rest.size(); r++) {
+                const uint32_t q = round == 0 ? quota(r) : S;
+                while (count[r] < q && next < rest.size()) give(rest[next++], r);
             }
     }
 

@@ -241,7 +241,8 @@ int chordvis_set_limits(ChordCtx* ctx, const ChordLimits* limits);
 /* Multi-GPU screen ownership (the reference is single-device): the screen is cut into the rasterizer's 64 x 64-pixel
  * tiles and every tile belongs to one rank -- a table tile -> owner, row-major over the tile grid (ceil(W / 64) columns), the
  * same on every rank of a frame.  The visibility buffer of a sharded context is stored rank-major and tile-linear: a rank's
- * tiles sit in consecutive slots of 64 x 64 words (64 rows of 64) of the rank's chunk, chunk = ceil(tiles / ranks) slots, so one
+ * tiles sit in consecutive slots of 64 x 64 words (64 rows of 64) of the rank's chunk, chunk = the largest tile count of the
+ * current map in slots (ceil(tiles / ranks) under the default map, up to chordvis_tile_slot_capacity under a weighted one), so one
  * in-place all-gather reassembles the frame and a de-tile kernel restores row-major.  ranks == 1: plain row-major.
  * chordvis_set_shard installs the default map, chordvis_tile_layout(width, height, ranks, NULL, ...): the tile grid is walked
  * along a generalised Hilbert curve and cut into `ranks` runs of equal length -- compact regions, so that few clusters touch
@@ -256,7 +257,8 @@ uint32_t chordvis_tile_slot_capacity(uint32_t width, uint32_t height, uint32_t r
 /* The map as a function (host only, deterministic: every rank computes the same table from the same inputs).  loads NULL:
  * the default above.  loads = bin entries per tile of a rendered frame (chordvis_read_tile_loads): regions of equal LOAD along
  * the same curve; tiles heavier than a quarter of a rank's share are placed one by one (heaviest first, least loaded rank),
- * near-empty tiles fill every rank up to its tile count.  Never more than maxTilesPerRank tiles per rank (0: ceil(tiles / ranks);
+ * near-empty tiles fill every rank up to its tile count, each joining the region next to it on the curve while that region has
+ * room.  Never more than maxTilesPerRank tiles per rank (0: ceil(tiles / ranks);
  * chordvis_rebalance passes chordvis_tile_slot_capacity). */
 int chordvis_tile_layout(uint32_t width, uint32_t height, uint32_t ranks, const uint32_t* loads, uint32_t maxTilesPerRank, uint8_t* ownersOut);
 /* An explicit map, between frames (drains frames in flight; the history HZB carries over: it is not sharded).  owners NULL:

@@ -94,6 +94,15 @@ def test_weighted_tile_map_balances_hotspots_and_skies(built_lib):
     prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     check(np.load(os.path.join(prof, "r04_tile_loads_config5_hotspot.npy")), 1.06)        # (its heaviest tile alone is a mean rank's load)
     check(np.load(os.path.join(prof, "r04_tile_loads_config4.npy")), 1.08)
+    # the light tiles (fillers) join the region next to them on the curve instead of going out rank by rank: the border between
+    # ranks -- clusters on it are set up twice -- of the sky frame (378 tile edges when the fillers were dealt in rank order),
+    # of config 4's measured frame (615) and of the hotspot's (275)
+    def border(o):
+        g = o.reshape(ty, tx)
+        return int((g[:, 1:] != g[:, :-1]).sum() + (g[1:] != g[:-1]).sum())
+    assert border(check(sky, 1.05)[0]) <= 340
+    assert border(check(np.load(os.path.join(prof, "r04_tile_loads_config4.npy")), 1.08)[0]) <= 560
+    assert border(check(np.load(os.path.join(prof, "r04_tile_loads_config5_hotspot.npy")), 1.06)[0]) <= 265
 
 
 # ---- the sharded group cull's exchange on the host (mirrors kernels_cull.hip: group_cull_masks_kernel / group_mask_unpack_kernel) ----
