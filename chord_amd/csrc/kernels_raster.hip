@@ -704,6 +704,25 @@ __device__ __forceinline__ void wave_min2_max2(int32_t& a, int32_t& b, int32_t& 
     c = __builtin_amdgcn_readlane(c, 63); d = __builtin_amdgcn_readlane(d, 63);
 }
 
+// wave-wide sums of a and b (all 64 lanes active), results wave-uniform: the same DPP ladder with v_add
+__device__ __forceinline__ void wave_sum2(uint32_t& a, uint32_t& b)
+{
+#define DPP_STEP(ctrl)                                                \
+    "v_add_u32_dpp %0, %0, %0 " ctrl "\n\t"                           \
+    "v_add_u32_dpp %1, %1, %1 " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"
+                 DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"
+                 DPP_STEP("row_ror:4 row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"
+                 DPP_STEP("row_ror:8 row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"
+                 DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0\n\t"
+                 DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(a), "+v"(b));
+#undef DPP_STEP
+    a = (uint32_t)__builtin_amdgcn_readlane((int)a, 63); b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+}
+
 // ---- the per-cluster setup kernel -------------------------------------------------------------
 enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
 #define WIN CHORD_BLOCK_WIN
@@ -1775,7 +1794,12 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
     // workgroup's serial work: its bins are cut finer -- into about as many equal shares as there are slots, never shorter than
     // TILE_SLICE_MIN entries (a slice pays for a tile of LDS zeroed and its touched words merged through the slab).
     // The image does not depend on the cut (64-bit max).
-    if (p.tileSlots) { atomicAdd(&entriesAll, sumMine); atomicAdd(&tilesBusy, tilesMine); }
+    // (a DPP reduction per wave, then one LDS atomic per wave: handed the 1 024 atomics, the compiler's atomic optimizer walks the
+    // lanes of every wave in a scalar loop -- measured +6 us on a 4-us kernel)
+    if (p.tileSlots) {
+        wave_sum2(sumMine, tilesMine);
+        if ((threadIdx.x & 63u) == 0u) { atomicAdd(&entriesAll, sumMine); atomicAdd(&tilesBusy, tilesMine); }
+    }
     __syncthreads();
     uint32_t splitMin = TILE_SPLIT_MIN, sliceLen = TILE_SLICE;
     if (p.tileSlots && tilesBusy < p.tileSlots) {
@@ -3200,9 +3224,12 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.leftCount = nullptr; p.leftCmds = nullptr;
     p.binHint = nullptr; p.countHint = nullptr;
     p.slotHot = (c->debugFlags & DBG_FORCE_HOT) ? 64u : SLOT_HOT;
-    {   // (CHORDVIS_TILE_SLOTS: measurements only -- 0 keeps every bin up to TILE_SPLIT_MIN entries whole, as before round 5)
+    {   // Sharded frames only: a rank of an 8-rank 4K frame owns 255 tiles (config 4: tile kernel 0.088 -> 0.053 ms per rank); the
+        // one single-GPU case with fewer tiles than slots, a 1080p target, measured the same with and without
+        // (profiles/r05_tile_kernel_experiments.txt, item 8).  (CHORDVIS_TILE_SLOTS: measurements only -- 0 keeps every bin up to
+        // TILE_SPLIT_MIN entries whole, a number applies to every frame)
         static const int forced = [] { const char* e = getenv("CHORDVIS_TILE_SLOTS"); return e ? atoi(e) : -1; }();
-        p.tileSlots = forced >= 0 ? (uint32_t)forced : (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u);
+        p.tileSlots = forced >= 0 ? (uint32_t)forced : c->shard.ranks > 1 ? (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u) : 0u;
     }
     p.hotTiles = c->dHotTiles ? c->dHotTiles + (size_t)pass * (1u + CHORD_HOT_TILES) : nullptr;
     // ... and whether it IS dense the device decides from the list's length (launch_is_dense).  A list that could be dense but was
