@@ -705,6 +705,44 @@ def test_moving_camera_sequence_matches_oracle(gpu, name, builder):
     r.close()
 
 
+@pytest.mark.parametrize("w,h", [(400, 240), (1237, 701)])
+def test_frames_with_nothing_in_view_match_oracle(gpu, w, h):
+    """The empty input of this path: a camera that turns its back on the whole scene.  Frame 1 sees the scene, frame 2 nothing
+    (every object fails the frustum test: empty command list, no raster work, an all-zero image and the HZB of one), frame 3 the
+    scene again against that empty history (nothing may be occluded by it), frame 4 as usual -- each against the oracle fed with
+    the oracle's own previous HZB, counts included."""
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam_a = scenes.small_test_scene(w, h, seed=13)
+    away = scenes.Camera((-30.0, 1.6, 30.0), (-0.8, 0.0, 0.6), w, h)            # (outside the scene, looking away from all of it)
+    order = [cam_a, away, cam_a, cam_a]
+    r = VisibilityRenderer(0)
+    r.upload_scene(scene)
+    r.allocate_gbuffer(w, h)
+    prev, prev_view = None, None
+    for i, cam in enumerate(order):
+        last = order[i - 1] if i else cam
+        view0, _ = L.make_views(last)
+        view, iv = L.make_views(cam, view0)
+        objs = L.fill_objects(scene, cam, last).copy()
+        want = orc.frame(scene.with_objects(objs), view, iv, H.ALL_FLAGS, prev_hzb_min=prev)
+        r.update_objects(objs)
+        r.set_view(view, iv, H.ALL_FLAGS)
+        r.render_frame()
+        got = r.read_visibility()
+        H.assert_vis_equal(got, want["vis"], w, h, "frame %d" % i)
+        st = r.stats()
+        assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["stats"].trianglesSubmitted
+        if prev is not None:
+            assert [st["countInstanceCulled"], st["countStage0Visible"], st["countStage0Rejected"], st["countStage1Visible"]] == want["counts"].tolist()
+        if cam is away:
+            assert st["trianglesSubmitted"] == 0 and st["countInstanceCulled"] == 0 and not got.any()
+        else:
+            assert st["trianglesSubmitted"] > 0 and got.any()
+        prev = want["hzb_min"]
+    r.close()
+
+
 @pytest.mark.parametrize("name,builder", [("small", lambda: scenes.small_test_scene(400, 240, seed=31)),
                                           ("config3_1080p", lambda: scenes.config3_street(1920, 1080)),
                                           ("config4_4k", scenes.config4_street_x64)])
