@@ -2663,6 +2663,9 @@ __device__ __forceinline__ void merge_blocks(unsigned long long* tile, const uns
 #undef MB_MERGE
 }
 
+#ifndef TILE_DEEP_FETCH
+#define TILE_DEEP_FETCH 0               // 1: opaque instantiations fetch records two batches ahead (two register sets, batch loop unrolled by two) -- measured in round 5, no gain (profiles/r05_tile_kernel_experiments.txt item 9); 0: the round-2 form
+#endif
 #ifndef TILE_MIN_BLOCKS
 #define TILE_MIN_BLOCKS 4               // waves per SIMD the register allocation aims at (launch bounds: 4 -> 128 VGPRs, 6 -> 80)
 #endif
@@ -2826,15 +2829,12 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);         // record of batch 0
         idxNext = entryThread && k0 + TILE_BATCH < n ? binEntry(k0 + TILE_BATCH) : 0xFFFFFFFFu;   // bin entry of batch 1
     }
-    uint32_t batchNo = 0;
-    for (uint32_t base = lo; base < n; base += TILE_BATCH, batchNo++) {
-        const uint32_t k = base + tix;
-        const uint4 q0 = nq0, q1 = nq1, q2 = nq2;
-        const uint32_t name = nameNext;
+    // One batch in two parts, so that the caller can re-load the record registers in between (by value: a record handed over by
+    // reference ends up in scratch memory).  batch_setup: the records q0..q2 named `name` of the batch's entries (one per entry
+    // thread) are set up -- tiny triangles scanned at once, the others stored as entries; returns the thread's unit count.
+    // batch_units: block-wide scan, unit lists, row units.
+    auto batch_setup = [&](const uint4 q0, const uint4 q1, const uint4 q2, const uint32_t name) -> uint32_t {
         const bool have = name != 0xFFFFFFFFu && !ABL(p, DBG_NO_ENTRY);
-        nameNext = idxNext;
-        if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);         // record of the next batch
-        idxNext = entryThread && k + 2u * TILE_BATCH < n ? binEntry(k + 2u * TILE_BATCH) : 0xFFFFFFFFu;   // bin entry of the batch after
         if (prof) { volatile uint32_t sink = q1.w; (void)sink; }
         PHASE(1);
         uint32_t rows = 0;
@@ -2872,6 +2872,9 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
                 }
             }
         }
+        return rows;
+    };
+    auto batch_units = [&](const uint32_t rows, const uint32_t batchNo) {
         PHASE(2);
         uint32_t total;
         // (the wave sums alternate between two buffers: a batch without units then needs no barrier but the scan's own)
@@ -2938,6 +2941,45 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         total |= totalM;
         if (total) __syncthreads();                               // prm / the unit list are rewritten by the next batch
         PHASE(4);
+    };
+    uint32_t batchNo = 0;
+    if constexpr (TILE_DEEP_FETCH && !MASKED) {
+        // (a build switch, off: measured and not kept)  Records TWO batches ahead (opaque instantiations: 103 VGPRs leave room for a
+        // second set of record registers; the masked ones sit at 128).  The phase clocks of the profiling build put 44 % of the time
+        // of config 4's dense tiles into the wait for a batch's records (profiles/r05_tile_profile_config4.txt) -- with two batches
+        // of cover instead of one the product kernel takes exactly as long (config 4: tile 161.6 vs 161.3 us per frame; config 3
+        // +1 %: 115 VGPRs and 30 % more code), so that wait is the profiling build's own barrier in front of every clock, not latency
+        // the product kernel is exposed to.  Two register sets alternate, unrolled by two: a copy from set to set would make the
+        // compiler wait for the younger load at the copy.  Set A holds the record of batch 0 (fetched above), set B takes batch
+        // 1's, the bin entries run three batches ahead.
+        uint32_t nameA = nameNext, nameB = idxNext;
+        uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0;
+        if (nameB != 0xFFFFFFFFu) FETCH_REC(nameB, b0, b1, b2);                  // record of batch 1
+        uint32_t idx = entryThread && k0 + 2u * TILE_BATCH < n ? binEntry(k0 + 2u * TILE_BATCH) : 0xFFFFFFFFu;   // bin entry of batch 2
+        for (uint32_t base = lo; base < n;) {
+            uint32_t rows = batch_setup(nq0, nq1, nq2, nameA);
+            nameA = idx;
+            if (nameA != 0xFFFFFFFFu) FETCH_REC(nameA, nq0, nq1, nq2);          // record of batch b + 2 into the set just read
+            idx = entryThread && base + tix + 3u * TILE_BATCH < n ? binEntry(base + tix + 3u * TILE_BATCH) : 0xFFFFFFFFu;
+            batch_units(rows, batchNo);
+            base += TILE_BATCH; batchNo++;
+            if (base >= n) break;
+            rows = batch_setup(b0, b1, b2, nameB);
+            nameB = idx;
+            if (nameB != 0xFFFFFFFFu) FETCH_REC(nameB, b0, b1, b2);
+            idx = entryThread && base + tix + 3u * TILE_BATCH < n ? binEntry(base + tix + 3u * TILE_BATCH) : 0xFFFFFFFFu;
+            batch_units(rows, batchNo);
+            base += TILE_BATCH; batchNo++;
+        }
+    } else
+    for (uint32_t base = lo; base < n; base += TILE_BATCH, batchNo++) {
+        const uint32_t k = base + tix;
+        const uint4 q0 = nq0, q1 = nq1, q2 = nq2;
+        const uint32_t name = nameNext;
+        nameNext = idxNext;
+        if (nameNext != 0xFFFFFFFFu) FETCH_REC(nameNext, nq0, nq1, nq2);         // record of the next batch
+        idxNext = entryThread && k + 2u * TILE_BATCH < n ? binEntry(k + 2u * TILE_BATCH) : 0xFFFFFFFFu;   // bin entry of the batch after
+        batch_units(batch_setup(q0, q1, q2, name), batchNo);
     }
     __syncthreads();
 
