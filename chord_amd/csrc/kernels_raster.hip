@@ -107,6 +107,7 @@ struct RasterParams {
     uint32_t slotHot;                                   // bin length from which a tile counts as hot (SLOT_HOT; tests lower it)
     uint32_t* hotTiles;                                 // [1 + CHORD_HOT_TILES] this pass's hot tiles of the LAST frame (count, then tile | very hot << 31): written by the tile schedule, read by the block kernel's hot variant
     uint32_t tileSlots;                                 // tile workgroups the device holds at once (2 per CU); a pass with fewer non-empty tiles than that cuts its bins finer (tile_order_part), 0: never
+    uint32_t tileSplitMin, tileSliceLen;                // bins longer than tileSplitMin entries are cut into slices of tileSliceLen (TILE_SPLIT_MIN, TILE_SLICE)
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
 // The per-phase clocks of the setup kernels (debug bit 512) and of the tile kernel (bit 16) exist only in a build with
@@ -1801,11 +1802,11 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
         if ((threadIdx.x & 63u) == 0u) { atomicAdd(&entriesAll, sumMine); atomicAdd(&tilesBusy, tilesMine); }
     }
     __syncthreads();
-    uint32_t splitMin = TILE_SPLIT_MIN, sliceLen = TILE_SLICE;
+    uint32_t splitMin = p.tileSplitMin, sliceLen = p.tileSliceLen;
     if (p.tileSlots && tilesBusy < p.tileSlots) {
         const uint32_t share = (entriesAll / p.tileSlots + 511u) & ~511u;   // (whole batches of the tile kernel)
-        sliceLen = min(TILE_SLICE, max(TILE_SLICE_MIN, share));
-        splitMin = min(TILE_SPLIT_MIN, sliceLen + sliceLen / 2u);
+        sliceLen = min(p.tileSliceLen, max(TILE_SLICE_MIN, share));
+        splitMin = min(p.tileSplitMin, sliceLen + sliceLen / 2u);
     }
 #pragma unroll
     for (uint32_t k = 0; k < PER_THREAD; k++) {
@@ -3272,6 +3273,11 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         // TILE_SPLIT_MIN entries whole, a number applies to every frame)
         static const int forced = [] { const char* e = getenv("CHORDVIS_TILE_SLOTS"); return e ? atoi(e) : -1; }();
         p.tileSlots = forced >= 0 ? (uint32_t)forced : c->shard.ranks > 1 ? (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u) : 0u;
+        // (CHORDVIS_TILE_SPLIT_MIN / CHORDVIS_TILE_SLICE: measurements only -- the image does not depend on the cut)
+        static const int splitMin = [] { const char* e = getenv("CHORDVIS_TILE_SPLIT_MIN"); return e ? atoi(e) : -1; }();
+        static const int sliceLen = [] { const char* e = getenv("CHORDVIS_TILE_SLICE"); return e ? atoi(e) : -1; }();
+        p.tileSplitMin = splitMin > 0 ? (uint32_t)splitMin : TILE_SPLIT_MIN;
+        p.tileSliceLen = sliceLen >= 512 ? ((uint32_t)sliceLen + 511u) & ~511u : TILE_SLICE;
     }
     p.hotTiles = c->dHotTiles ? c->dHotTiles + (size_t)pass * (1u + CHORD_HOT_TILES) : nullptr;
     // ... and whether it IS dense the device decides from the list's length (launch_is_dense).  A list that could be dense but was
