@@ -180,6 +180,25 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* blockT
     return base + incl - v;
 }
 
+// totals of two values per thread over a block of BT threads (no scan: the group cull only keeps its blocks' totals)
+template <uint32_t BT>
+__device__ __forceinline__ void block_totals2(uint32_t a, uint32_t b, uint32_t* totalA, uint32_t* totalB)
+{
+    __shared__ uint32_t sums[2][BT / 64u];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t ia = wave_incl_scan(a, lane), ib = wave_incl_scan(b, lane);
+    if (lane == 63u) { sums[0][wave] = ia; sums[1][wave] = ib; }
+    __syncthreads();
+    uint32_t ta = 0, tb = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < BT / 64u; w++) { ta += sums[0][w]; tb += sums[1][w]; }
+    *totalA = ta; *totalB = tb;
+}
+
+// the value of lane ^ 1 / lane ^ 2 of the quad (DPP quad_perm [1,0,3,2] / [2,3,0,1]; all lanes active)
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); }
+
 struct GroupCullParams {
     const ChordObject* objects; const DObjStatic* objStatic; const DObjFrame* objFrame; const DPrim* prims;
     const DGroup* groups; const uint32_t* groupIndices; const DMeshlet* meshlets; const DGroupRef* groupRefs;
@@ -275,26 +294,35 @@ __global__ __launch_bounds__(256) void object_cull_kernel(const ChordObject* __r
 // test costs the single-GPU frame nothing)
 // FUSED: the short-scene form described above; long scenes run object_cull_kernel first and this kernel without the object
 // pass (its matrices are what set the fused form's register count: 94 VGPRs = 5 waves/SIMD).
-template <bool FROM_MASK, bool SHARDED, bool FUSED>
-__global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p, const DView dv, DView* __restrict__ dviewOut,
+#ifndef CULL_QUAD
+#define CULL_QUAD 1
+#endif
+template <bool FROM_MASK, bool SHARDED, bool FUSED, bool QUAD = false>
+__global__ __launch_bounds__(QUAD ? 1024 : 256) void group_cull_count_kernel(GroupCullParams p, const DView dv, DView* __restrict__ dviewOut,
                                                                DObjFrame* __restrict__ objFrameOut, uint4* __restrict__ zeroBase, uint32_t zeroVec4,
                                                                uint32_t cullBlocks, FrameTail tail)
 {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    static_assert(!QUAD || (FUSED && !FROM_MASK), "the four-lane form is the short-scene kernel");
+    constexpr uint32_t BT = QUAD ? 1024u : 256u;                    // threads of a block; a block tests 256 group instances either way
+    const uint32_t qi = QUAD ? threadIdx.x & 3u : 0u;               // QUAD: the meshlet of its group this lane tests
+    const uint32_t t = blockIdx.x * 256u + (QUAD ? threadIdx.x >> 2 : threadIdx.x);
     if (FUSED) {
-        if (tail.run && blockIdx.x == cullBlocks) { hzb_tail_block(tail.p, 1, 1, (uint32_t)CHORD_TILE_SHIFT); return; }
+        if (tail.run && blockIdx.x == cullBlocks) {
+            if (QUAD && threadIdx.x >= 256u) return;               // (hzb_tail_block is written for 256 threads; whole waves leave, its barriers count the rest)
+            hzb_tail_block(tail.p, 1, 1, (uint32_t)CHORD_TILE_SHIFT); return;
+        }
         if (dviewOut && blockIdx.x == 0) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
             uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
-            for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += 256u) dst[i] = src[i];
+            for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += BT) dst[i] = src[i];
         }
-        for (uint32_t i = t; i < zeroVec4; i += cullBlocks * 256u) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t i = blockIdx.x * BT + threadIdx.x; i < zeroVec4; i += cullBlocks * BT) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
         if (p.groupInstances && objFrameOut) {
             const uint32_t first = blockIdx.x * 256u;
             if (first < p.groupInstances) {
                 const uint32_t oFirst = p.groupRefs[first].object, oLast = p.groupRefs[min(first + 255u, p.groupInstances - 1u)].object;
                 // (256 group instances may span more than 256 objects when primitives without groups sit in between)
-                for (uint32_t k = threadIdx.x; k <= oLast - oFirst; k += 256u) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, oFirst + k);
+                for (uint32_t k = threadIdx.x; k <= oLast - oFirst; k += BT) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, oFirst + k);
             }
         }
         __syncthreads();                                   // the object records of this block are written (and visible to it)
@@ -327,6 +355,15 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
             const uint32_t cnt = ref.group >> 28;
             if (cnt != 0u && group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {     // instance_culling.hlsl:174
                 const Mat4 M = load_mat(p.objects[o].basicData.localToTranslatedWorld);
+                if (QUAD) {
+                    // one meshlet per lane of the quad (every lane of it has done the group's test): the bits meet below
+                    const DMeshlet m = p.meshlets[qi == 0u ? ref.meshlet[0] : qi == 1u ? ref.meshlet[1] : qi == 2u ? ref.meshlet[2] : ref.meshlet[3]];
+                    if (qi < cnt && meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, m)) {
+                        mask = 1u << qi;
+                        tris = (m.vertexTriangleCount >> 8) & 0xFFu;
+                        if (sharded && cluster_touches_rank(p.shard, of.mvp, m, p.W, p.H, p.Wi, p.Hi)) mine = 1u << qi;
+                    }
+                } else
 #pragma unroll
                 for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
                     const DMeshlet m = p.meshlets[ref.meshlet[i]];                              // :178-180 (a slot beyond the group's count re-reads its first meshlet)
@@ -338,12 +375,20 @@ __global__ __launch_bounds__(256) void group_cull_count_kernel(GroupCullParams p
                 }
             }
         }
-        p.groupMask[t] = (uint8_t)(mask | (mine << 4));                  // low nibble: visible meshlets, high nibble: of which this rank's
+        if (!QUAD) p.groupMask[t] = (uint8_t)(mask | (mine << 4));        // low nibble: visible meshlets, high nibble: of which this rank's
+    }
+    if (QUAD) {
+        // the quad's four lanes hold one bit / one triangle count each (0 where the group or the lane's meshlet failed, or t is past the
+        // list): every lane of the quad ends up with the group's values, lane 0 of it stores and counts them
+        mask |= quad_xor1(mask); mask |= quad_xor2(mask);
+        mine |= quad_xor1(mine); mine |= quad_xor2(mine);
+        tris += quad_xor1(tris); tris += quad_xor2(tris);
+        if (qi != 0u) { mask = 0u; mine = 0u; tris = 0u; }
+        else if (t < p.groupInstances) p.groupMask[t] = (uint8_t)(mask | (mine << 4));
     }
     uint32_t total, blockTris;
-    // (counts below 2^12 per block: the visible count in the low half, the rank's in the high half of one scan)
-    (void)block_excl_scan(sharded ? (uint32_t)__popc(mask) | ((uint32_t)__popc(mine) << 16) : (uint32_t)__popc(mask), &total);
-    (void)block_excl_scan(tris, &blockTris);
+    // (counts below 2^12 per block: the visible count in the low half, the rank's in the high half of one sum)
+    block_totals2<BT>(sharded ? (uint32_t)__popc(mask) | ((uint32_t)__popc(mine) << 16) : (uint32_t)__popc(mask), tris, &total, &blockTris);
     if (threadIdx.x == 0) {
         p.blockCounts[blockIdx.x] = total & 0xFFFFu; p.blockCounts[cullBlocks + blockIdx.x] = blockTris;
         if (sharded) p.blockCounts[2u * cullBlocks + blockIdx.x] = total >> 16;
@@ -1101,7 +1146,12 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
             LAUNCH_COUNT(false, false, dim3(blocks), p, c->hView, (DView*)nullptr, (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
         }
     } else {
-        LAUNCH_COUNT(false, true, dim3(blocks + tail.run), p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4, blocks, tail);
+        // short scenes on one GPU: four lanes per group instance, one meshlet each (CULL_QUAD) -- a list this short leaves most SIMDs
+        // with one wave or none, and a thread that tests a group's four meshlets one after the other is 3 000 dependent VALU
+        // instructions long
+        if (CULL_QUAD && !sh) CHORD_LAUNCH(c, (group_cull_count_kernel<false, false, true, true>), dim3(blocks + tail.run), dim3(1024), 0, c->stream,
+                                            p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4, blocks, tail);
+        else LAUNCH_COUNT(false, true, dim3(blocks + tail.run), p, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4, blocks, tail);
     }
 #undef LAUNCH_COUNT
     c->viewDirty = false;
