@@ -48,6 +48,8 @@ def sq_table(dirs, out, title, note):
     cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_THREAD_CYCLES_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
     cols = [c for c in cols if any(c in v for v in data.values())]
+    if not data:                                   # (a partial call: no counter passes for this table -- the committed one stays)
+        return data
     with open(os.path.join(P, out), "w") as f:
         f.write("# %s\n\n%s\n\n" % (title, note))
         f.write("| kernel | " + " | ".join(c.replace("SQ_", "") for c in cols) + " | wait / wave-cycles | active inst / wave-cycles | VALU lanes active | LDS bank conflicts |\n")
