@@ -306,6 +306,17 @@ __global__ __launch_bounds__(QUAD ? 1024 : 256) void group_cull_count_kernel(Gro
     constexpr uint32_t BT = QUAD ? 1024u : 256u;                    // threads of a block; a block tests 256 group instances either way
     const uint32_t qi = QUAD ? threadIdx.x & 3u : 0u;               // QUAD: the meshlet of its group this lane tests
     const uint32_t t = blockIdx.x * 256u + (QUAD ? threadIdx.x >> 2 : threadIdx.x);
+    // QUAD: what the group's tests read that does not depend on this frame's object records -- the reference, the group, the object's
+    // matrix and flags, the lane's meshlet -- is requested BEFORE the object phase and its barrier: behind the barrier a thread then
+    // waits for the object's frame record alone instead of for three dependent round trips (the compiler moves no load across a barrier)
+    DGroupRef refQ; DGroup gQ; Mat4 MQ; DMeshlet mQ; uint32_t matFlagsQ = 0u;
+    if (QUAD && !(tail.run && blockIdx.x == cullBlocks) && t < p.groupInstances) {
+        refQ = p.groupRefs[t];
+        gQ = p.groups[refQ.group & 0x0FFFFFFFu];
+        MQ = load_mat(p.objects[refQ.object].basicData.localToTranslatedWorld);
+        matFlagsQ = p.objStatic[refQ.object].matFlags;
+        mQ = p.meshlets[qi == 0u ? refQ.meshlet[0] : qi == 1u ? refQ.meshlet[1] : qi == 2u ? refQ.meshlet[2] : refQ.meshlet[3]];
+    }
     if (FUSED) {
         if (tail.run && blockIdx.x == cullBlocks) {
             if (QUAD && threadIdx.x >= 256u) return;               // (hzb_tail_block is written for 256 threads; whole waves leave, its barriers count the rest)
@@ -346,18 +357,18 @@ __global__ __launch_bounds__(QUAD ? 1024 : 256) void group_cull_count_kernel(Gro
     if (t < p.groupInstances) {
         // ONE fetch names the owner, the group record and the group's meshlets (DGroupRef, resolved at upload); everything the
         // tests read -- the object's frame record, the group, its (up to) four meshlets -- is a second, independent round trip
-        const DGroupRef ref = p.groupRefs[t];
+        const DGroupRef ref = QUAD ? refQ : p.groupRefs[t];
         const uint32_t o = ref.object;
         const DObjFrame& of = p.objFrame[o];
         if (of.visible) {
-            const uint32_t matFlags = p.objStatic[o].matFlags;
-            const DGroup g = p.groups[ref.group & 0x0FFFFFFFu];
+            const uint32_t matFlags = QUAD ? matFlagsQ : p.objStatic[o].matFlags;
+            const DGroup g = QUAD ? gQ : p.groups[ref.group & 0x0FFFFFFFu];
             const uint32_t cnt = ref.group >> 28;
             if (cnt != 0u && group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {     // instance_culling.hlsl:174
-                const Mat4 M = load_mat(p.objects[o].basicData.localToTranslatedWorld);
+                const Mat4 M = QUAD ? MQ : load_mat(p.objects[o].basicData.localToTranslatedWorld);
                 if (QUAD) {
                     // one meshlet per lane of the quad (every lane of it has done the group's test): the bits meet below
-                    const DMeshlet m = p.meshlets[qi == 0u ? ref.meshlet[0] : qi == 1u ? ref.meshlet[1] : qi == 2u ? ref.meshlet[2] : ref.meshlet[3]];
+                    const DMeshlet m = mQ;
                     if (qi < cnt && meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, m)) {
                         mask = 1u << qi;
                         tris = (m.vertexTriangleCount >> 8) & 0xFFu;
