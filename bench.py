@@ -619,6 +619,9 @@ def measure(args, workload, env):
             "gpu_ms": {k: round(st[k], 4) for k in ("msClear", "msInstanceCulling", "msStage0", "msHzbStage0", "msStage1",
                                                      "msHzbFinal", "msFrame", "msRasterCluster", "msRasterClip", "msRasterChunk")},
             "kernel_launches": st["kernelLaunches"],
+            # frames the tile schedule of a frame's first raster pass is reused for (chordvis_set_tile_schedule_keep; library default):
+            # `kernel_launches` is a frame between two schedules -- every (this + 1)-th frame has one launch more
+            "tile_schedule_keep_frames": r.tile_schedule_keep(),
             "tiles_touched_view_a": per_view[0]["tilesTouched"], "tiles_total": ((W + 63) // 64) * ((H + 63) // 64),
             "counts_view_a": {k: per_view[0][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},
             "counts_view_b": {k: per_view[1][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},

@@ -112,6 +112,8 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         const size_t tilesN = (size_t)c->tilesX * c->tilesY;
         c->tileItemCap = (uint32_t)(tilesN * (CHORD_TILE_MAX_SLICES + 1u));
         if ((rc = dalloc(c, &c->dTileOrder, ((size_t)1 + c->tileItemCap) * 2))) return rc;   // uint2 per item
+        if ((rc = dalloc(c, &c->dTileOrderKeep, ((size_t)1 + c->tileItemCap) * 2))) return rc;
+        c->orderAge = 0xFFFFFFFFu;
         if ((rc = dalloc(c, &c->dTileSlabs, tilesN * CHORD_TILE * CHORD_TILE))) return rc;
         CHORD_HIP(c, hipMemset(c->dTileSlabs, 0, tilesN * CHORD_TILE * CHORD_TILE * sizeof(unsigned long long)));
     }
@@ -397,7 +399,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
     dfree(c->dRankCmds); dfree(c->dLeftCmds); dfree(c->dMineCmds);
-    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dHotTiles); dfree(c->dTileOrder); dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
+    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dHotTiles); dfree(c->dTileOrder); dfree(c->dTileOrderKeep); c->orderAge = 0xFFFFFFFFu; dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
     if (c->hBinHint) { (void)hipHostFree(const_cast<uint32_t*>(c->hBinHint)); c->hBinHint = nullptr; c->dBinHint = nullptr; }
@@ -423,6 +425,8 @@ int chordvis_sync(ChordCtx* c)
 
 int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
 {
+    if (c) c->orderAge = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
+
     if (!c || !s || !s->objects || !s->primitives || !s->materials || !s->assets || s->objectCount == 0)
         return fail(c, CHORDVIS_E_INVALID, "upload_scene: null or empty scene");
     CHORD_HIP(c, hipSetDevice(c->device));
@@ -779,6 +783,8 @@ int chordvis_allocate_gbuffer(ChordCtx* c, uint32_t width, uint32_t height, uint
 
 int chordvis_set_limits(ChordCtx* c, const ChordLimits* limits)
 {
+    if (c) c->orderAge = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
+
     if (!c || !limits) return fail(c, CHORDVIS_E_INVALID, "set_limits: null argument");
     if (c->sceneLoaded || c->dVis) return fail(c, CHORDVIS_E_INVALID, "set_limits: call before upload_scene / allocate_gbuffer");
     if (limits->maxTriangleRecords) {
@@ -797,6 +803,15 @@ int chordvis_set_limits(ChordCtx* c, const ChordLimits* limits)
     return CHORDVIS_OK;
 }
 
+int chordvis_set_tile_schedule_keep(ChordCtx* c, uint32_t frames)
+{
+    if (!c) return CHORDVIS_E_INVALID;
+    c->orderKeepFrames = frames;
+    c->orderAge = 0xFFFFFFFFu;
+    return CHORDVIS_OK;
+}
+uint32_t chordvis_tile_schedule_keep(ChordCtx* c) { return c ? c->orderKeepFrames : 0u; }
+
 int chordvis_set_cull_mode(ChordCtx* c, int hierarchical)
 {
     if (!c || hierarchical < 0 || hierarchical > 1) return fail(c, CHORDVIS_E_INVALID, "set_cull_mode: 0 (flat) or 1 (hierarchical)");
@@ -807,6 +822,8 @@ int chordvis_set_cull_mode(ChordCtx* c, int hierarchical)
 
 int chordvis_set_shard(ChordCtx* c, uint32_t ranks, uint32_t rank)
 {
+    if (c) c->orderAge = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
+
     if (!c || ranks == 0 || ranks > 255u || rank >= ranks) return fail(c, CHORDVIS_E_INVALID, "set_shard: rank < ranks <= 255");
 #if CHORD_TILE_SHIFT != 6
     if (ranks > 1) return fail(c, CHORDVIS_E_INVALID, "set_shard: this build's raster tiles are not 64 x 64");
@@ -1447,6 +1464,8 @@ int chordvis_upload_history_hzb(ChordCtx* c, const uint16_t* hostMin)
 
 int chordvis_set_debug(ChordCtx* c, uint32_t flags)
 {
+    if (c) c->orderAge = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
+
     if (!c) return CHORDVIS_E_INVALID;
     // measurement switches the library was not built with would silently measure the product: refuse them
     if (!RASTER_PROFILE && (flags & CHORD_DEBUG_PROFILE_BITS))

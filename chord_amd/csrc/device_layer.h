@@ -422,6 +422,9 @@ struct ChordCtx {
     uint32_t* dTileMarker = nullptr;   // [markerDim.y][markerDim.x] uint4: shading types present per 8x8 pixels
     uint32_t* dShadingTiles = nullptr; // [markerDim.x * markerDim.y] uint2 + {count, pad, uint4 dispatch args} behind them
     uint32_t* dTileOrder = nullptr;    // [1 + tileItemCap]: item count, then work items heaviest first
+    uint32_t* dTileOrderKeep = nullptr; // the same for the first pass of main-view frames on one GPU, kept across frames (launch_raster)
+    uint32_t orderAge = 0xFFFFFFFFu;   // frames since dTileOrderKeep was made; 0xFFFFFFFF: not valid (new target, scene, map, switches)
+    uint32_t orderKeepFrames = 7u;     // chordvis_set_tile_schedule_keep: frames a first pass's schedule is kept for (0: never)
     unsigned long long* dTileSlabs = nullptr;   // [tiles][TILE*TILE]: where the slices of a split tile meet (all zero between uses)
     uint32_t tileItemCap = 0;
     uint32_t* dLargeList = nullptr;    // [2 passes][CHORD_LIST_SHARDS][largeCap / 2 / CHORD_LIST_SHARDS] record indices

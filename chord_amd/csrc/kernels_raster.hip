@@ -108,6 +108,7 @@ struct RasterParams {
     uint32_t* hotTiles;                                 // [1 + CHORD_HOT_TILES] this pass's hot tiles of the LAST frame (count, then tile | very hot << 31): written by the tile schedule, read by the block kernel's hot variant
     uint32_t tileSlots;                                 // tile workgroups the device holds at once (2 per CU); a pass with fewer non-empty tiles than that cuts its bins finer (tile_order_part), 0: never
     uint32_t tileSplitMin, tileSliceLen;                // bins longer than tileSplitMin entries are cut into slices of tileSliceLen (TILE_SPLIT_MIN, TILE_SLICE)
+    uint32_t orderKept;                                 // 1: tileOrder is the schedule of an EARLIER frame's first pass (launch_raster: TILE_ORDER_KEEP) -- the items and their order are taken from it, a tile's bin length and flags from the counter line of this pass
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
 // The per-phase clocks of the setup kernels (debug bit 512) and of the tile kernel (bit 16) exist only in a build with
@@ -1758,6 +1759,9 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 #ifndef TILE_SPLIT_MIN
 #define TILE_SPLIT_MIN 6144u       // bins up to this many entries stay whole
 #endif
+#ifndef TILE_ORDER_KEEP
+#define TILE_ORDER_KEEP 1          // 0: the schedule kernel runs in every pass whatever chordvis_set_tile_schedule_keep says (A/B builds)
+#endif
 #ifndef TILE_SLICE_MIN
 #define TILE_SLICE_MIN 1024u       // the shortest slice of a pass that has fewer tiles than the device has slots
 #endif
@@ -2693,9 +2697,19 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     const uint2 itemCount = oi == blockIdx.x ? firstItem : p.tileOrder[1u + oi];
     const uint32_t item = itemCount.x;
     const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
-    const uint32_t nAll = itemCount.y & 0x3FFFFFFFu;              // (already clamped to the bin capacity)
-    const bool hasBlocks = (itemCount.y >> 31) != 0u;             // (the order kernel saw pixel blocks in the tile's bin)
-    const bool preloaded = !CHORD_MASKED_FUSED && p.clearTiles && (itemCount.y & 0x40000000u) != 0u;   // the masked pass wrote this tile (first pass of a frame)
+    // (kept order: the tile's counter line is read here, and -- the address needs the tile only -- a whole tile's first bin entries
+    // beside it, so that the chain item -> bin entry -> record does not grow by the round trip for the length)
+    const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
+    const bool entryThread = TILE_BATCH == TB || tix < TILE_BATCH;   // (a batch is TILE_BATCH bin entries, one per thread of the first waves)
+    uint32_t countWord = itemCount.y, wordSpec = 0xFFFFFFFFu;
+    if (p.orderKept) {
+        const uint4 cnt = *reinterpret_cast<const uint4*>(&p.tileCount[(size_t)tileId * TC_STRIDE]);
+        if (slices == 1u && entryThread) wordSpec = bin[tix];
+        countWord = min(cnt.x, bin_capacity(p)) | (cnt.y ? 0x80000000u : 0u);
+    }
+    const uint32_t nAll = countWord & 0x3FFFFFFFu;                // (already clamped to the bin capacity)
+    const bool hasBlocks = (countWord >> 31) != 0u;               // (the order kernel saw pixel blocks in the tile's bin)
+    const bool preloaded = !CHORD_MASKED_FUSED && p.clearTiles && (countWord & 0x40000000u) != 0u;   // the masked pass wrote this tile (first pass of a frame)
     const int32_t tinyArea = nAll >= TINY_DENSE_MIN ? TINY_AREA_DENSE : TINY_AREA;
     // entries [lo, n) of the bin are this item's
     // (equal parts rounded up to whole batches: with the schedule's slice count -- ceil(entries / slice length), slice length
@@ -2724,11 +2738,9 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     // item -> bin entry -> record is what a light tile waits for (profiles/r03_tile_profile_config3.txt: a third of a tile's time),
     // and the tile-in -- 33 KB of LDS stores, or the tile's words from memory -- depends on none of it.  (Bins that continue in
     // pool chunks name them through chunkTab, which is filled behind the barrier: they keep the old order.)
-    const uint32_t* bin = p.tileBins + (size_t)tileId * p.binCap;
     const bool early = n <= p.binCap && !hasBlocks;               // (uniform)
     const uint32_t k0 = lo + tix;
-    const bool entryThread = TILE_BATCH == TB || tix < TILE_BATCH;   // (a batch is TILE_BATCH bin entries, one per thread of the first waves)
-    const uint32_t word0 = (early && entryThread && k0 < n) ? bin[k0] : 0xFFFFFFFFu;
+    const uint32_t word0 = (early && entryThread && k0 < n) ? ((p.orderKept && slices == 1u) ? wordSpec : bin[k0]) : 0xFFFFFFFFu;
 
     // ---- tile in: zero (first pass: this is the clear; un-fused later passes merge by max at tile-out), or the
     //      current words when a later pass must leave the finished tile in LDS for the fused HZB reduction ----
@@ -3317,7 +3329,20 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     else              CHORD_LAUNCH(c, raster_setup_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, p);
     stamp(c, S_R_CLUSTER);
     CHORD_LAUNCH(c, raster_clip_and_bin_large_kernel, dim3(CLIP_BLOCKS + (uint32_t)c->numCUs * 4u), dim3(256), 0, c->stream, p);
-    CHORD_LAUNCH(c, raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
+    // The first pass of a main-view frame on one GPU writes EVERY tile (it is the clear): its work items are all the tiles whatever
+    // their bins hold, and only their order (heaviest first) and the cut of long bins depend on this frame.  Both change slowly from
+    // frame to frame, so the schedule of such a pass is kept in a buffer of its own and made again only every orderKeepFrames + 1
+    // frames (chordvis_set_tile_schedule_keep, default 7; -DTILE_ORDER_KEEP=0 compiles the path out); in between the tile kernel takes items and order from the kept schedule and a tile's bin length and flags from the
+    // counter line (RasterParams::orderKept) -- one launch less in most frames.  The image does not depend on order or cut.  (The
+    // hints the schedule kernel leaves for the next frame -- longest bin, cluster count, hot tiles -- age with it.)
+    p.orderKept = 0u;
+    bool makeOrder = true;
+    if (TILE_ORDER_KEEP && c->orderKeepFrames && CHORD_MASKED_FUSED && c->inFrame && clearTiles && !sh && !c->depthOnly && pass == 0u && c->dTileOrderKeep && !c->debugFlags) {
+        p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrderKeep);
+        if (c->orderAge < c->orderKeepFrames) { c->orderAge++; p.orderKept = 1u; makeOrder = false; }
+        else c->orderAge = 0u;
+    }
+    if (makeOrder) CHORD_LAUNCH(c, raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
 #if !CHORD_MASKED_FUSED
     if (c->anyMasked) {
         // alpha-tested triangles: their own pass over the scheduled tiles whose bins hold any (raster_masked_tile_kernel)

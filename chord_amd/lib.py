@@ -137,6 +137,8 @@ def _load():
         "chordvis_read_tile_loads": (i32, [vp, vp, u32]),
         "chordvis_rebalance": (i32, [vp, vp]),
         "chordvis_set_cull_mode": (i32, [vp, i32]),
+        "chordvis_set_tile_schedule_keep": (i32, [vp, u32]),
+        "chordvis_tile_schedule_keep": (u32, [vp]),
         "chordvis_visibility_words": (u64, [vp]),
         "chordvis_visibility_chunk_words": (u64, [vp]),
         "chordvis_visibility_ptr": (vp, [vp]),

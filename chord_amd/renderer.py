@@ -69,6 +69,13 @@ class VisibilityRenderer:
         """0: flat group cull (the reference's dispatch); 1: walk the primitives' BVHs (same command list)."""
         self._check(L.lib.chordvis_set_cull_mode(self._ctx, int(hierarchical)), "set_cull_mode")
 
+    def set_tile_schedule_keep(self, frames):
+        """Frames the tile schedule of a frame's first raster pass is kept for (default 7; 0: a fresh schedule every frame)."""
+        self._check(L.lib.chordvis_set_tile_schedule_keep(self._ctx, int(frames)), "set_tile_schedule_keep")
+
+    def tile_schedule_keep(self):
+        return int(L.lib.chordvis_tile_schedule_keep(self._ctx))
+
     def set_shard(self, ranks, rank):
         """Screen ownership by 64 x 64 tiles: the default map (compact regions along a generalised Hilbert curve)."""
         self._check(L.lib.chordvis_set_shard(self._ctx, ranks, rank), "set_shard")

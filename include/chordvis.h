@@ -232,6 +232,15 @@ int chordvis_set_view(ChordCtx* ctx, const ChordCameraView* view, const ChordIns
  * threshold; only the groups of surviving nodes are tested.  The command list is the same array either way. */
 int chordvis_set_cull_mode(ChordCtx* ctx, int hierarchical);
 
+/* Tile schedule of a frame's first raster pass (no counterpart: the reference's hardware rasterizer schedules its own tiles).  That pass
+ * writes every tile of the target, so its work items never change; their order (heaviest bin first) and the cut of long bins are
+ * taken from the schedule of an earlier frame for up to `frames` frames in a row before the schedule kernel runs again (one launch
+ * less in the frames between; single-GPU main-view frames inside chordvis_render_frame).  Order and cut are choices of speed -- the
+ * image is the same with any.  Default 7; 0: a fresh schedule in every frame (a host that knows of a camera cut may set 0 for a frame,
+ * or ignore it: a stale order costs balance for at most `frames` frames). */
+int chordvis_set_tile_schedule_keep(ChordCtx* ctx, uint32_t frames);
+uint32_t chordvis_tile_schedule_keep(ChordCtx* ctx);
+
 /* allocateGBufferTextures (render_textures.cpp:20-45): size the visibility target.  deviceVisibility
  * may be a caller-owned device buffer of chordvis_visibility_words(ctx) uint64 (used for the
  * multi-GPU all-gather), or NULL for a context-owned one. */

@@ -705,6 +705,56 @@ def test_moving_camera_sequence_matches_oracle(gpu, name, builder):
     r.close()
 
 
+def test_kept_tile_schedule_renders_the_same_frames(gpu):
+    """chordvis_set_tile_schedule_keep: the first raster pass of a frame takes its work items, their order and the cut of long bins
+    from the schedule of an earlier frame for up to 7 frames (default).  Ten frames of config 3 at 1080p (bins of several thousand
+    entries: cut tiles) along a camera path with a cut to the opposite direction in the middle, rendered by a context with the default
+    and by one that makes a fresh schedule every frame: both equal the oracle's frames (fed with its own previous HZB), images and
+    counts, frame by frame -- and the context with the default launches one kernel less in the frames between two schedules."""
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityRenderer
+    scene, cam0 = scenes.config3_street(1920, 1080)
+    f = np.array(cam0.front, dtype=np.float64); f /= np.linalg.norm(f)
+    cams = [cam0.moved(tuple(0.5 * i * f)) for i in range(5)]
+    # (the cut: from the far end of the street, looking back along it -- other tiles are the heavy ones, other bins the long ones)
+    back = scenes.Camera(tuple(np.array(cam0.position) + 90.0 * f * np.array([1.0, 0.0, 1.0])), (-cam0.front[0], cam0.front[1], -cam0.front[2]), cam0.width, cam0.height)
+    cams += [back.moved(tuple(-0.5 * i * f)) for i in range(5)]
+    ctx = []
+    for keep in (None, 0):
+        r = VisibilityRenderer(0)
+        r.upload_scene(scene)
+        r.allocate_gbuffer(cam0.width, cam0.height)
+        if keep is not None:
+            r.set_tile_schedule_keep(keep)
+        ctx.append(r)
+    assert ctx[0].tile_schedule_keep() == 7 and ctx[1].tile_schedule_keep() == 0
+    prev = None
+    launches = [[], []]
+    for i, cam in enumerate(cams):
+        last = cams[i - 1] if i else cam
+        view0, _ = L.make_views(last)
+        view, iv = L.make_views(cam, view0)
+        objs = L.fill_objects(scene, cam, last).copy()
+        want = orc.frame(scene.with_objects(objs), view, iv, H.ALL_FLAGS, prev_hzb_min=prev)
+        for k, r in enumerate(ctx):
+            r.update_objects(objs)
+            r.set_view(view, iv, H.ALL_FLAGS)
+            r.render_frame()
+            st = r.stats()
+            launches[k].append(st["kernelLaunches"])
+            H.assert_vis_equal(r.read_visibility(), want["vis"], cam.width, cam.height, "frame %d, schedule kept for %d frames" % (i, r.tile_schedule_keep()))
+            assert st["overflow"] == 0 and st["trianglesSubmitted"] == want["stats"].trianglesSubmitted
+            if prev is not None:
+                assert [st["countInstanceCulled"], st["countStage0Visible"], st["countStage0Rejected"], st["countStage1Visible"]] == want["counts"].tolist()
+        prev = want["hzb_min"]
+    # frame 0 has no history (one raster pass, both contexts alike); from frame 1 on the context with the default runs a frame between
+    # two schedules with one launch less, and its frame 8 -- seven kept frames behind frame 0's schedule -- makes a schedule again
+    assert launches[0][0] == launches[1][0], launches
+    assert all(a == b - 1 for a, b in zip(launches[0][1:8], launches[1][1:8])) and launches[0][8] == launches[1][8], launches
+    for r in ctx:
+        r.close()
+
+
 @pytest.mark.parametrize("w,h", [(400, 240), (1237, 701)])
 def test_frames_with_nothing_in_view_match_oracle(gpu, w, h):
     """The empty input of this path: a camera that turns its back on the whole scene.  Frame 1 sees the scene, frame 2 nothing
