@@ -694,10 +694,30 @@ __device__ __forceinline__ void hzb_tail_to_lds(const uint16_t* __restrict__ hzb
     }
 }
 
+// min / max over the 8 lanes of an octet (lanes 8j .. 8j + 7 of a wave, all of them active): within the quads, then across the two
+// quads of the octet (DPP quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror); every lane ends up with the octet's value
+__device__ __forceinline__ float oct_min(float v)
+{
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+    return fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+}
+__device__ __forceinline__ float oct_max(float v)
+{
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+}
+
 // occlusion test of one command (hzb_mainview_culling.hlsl:60-161)
-template <int PHASE, bool TAIL = false>
+// OCT: the eight lanes of an octet test ONE command together -- lane `sub` projects corner `sub` of the bounds and fetches two of the
+// sixteen texels, the minima / maxima meet by DPP, every lane of the octet returns the same answer.  (Short lists: a handful of waves
+// on the whole chip, each thread a chain of ~700 dependent instructions -- eight projections with three IEEE divisions each.)  The
+// folds are min / max over the same values as the one-thread form's loops: the same result whatever the order (the sign of a zero,
+// which the order could change, decides nothing below).
+template <int PHASE, bool TAIL = false, bool OCT = false>
 __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DView& dv, const ChordDrawCmd& cmd, uint32_t& tris,
-                                                const float* sTail = nullptr, const uint32_t* sTailOff = nullptr)
+                                                const float* sTail = nullptr, const uint32_t* sTailOff = nullptr, const uint32_t sub = 0u)
 {
     bool visible = true;
     {
@@ -716,6 +736,11 @@ __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DV
                     for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = src[r * 4 + cc];
 
                 f3 mx = {-10.0f, -10.0f, -10.0f}, mn = {10.0f, 10.0f, 10.0f};
+                if (OCT) {
+                    const f3 uvz = project_pos_to_uvz(extent_corner(c, e, (int)sub), mvp);
+                    mn.x = fminf(mn.x, oct_min(uvz.x)); mn.y = fminf(mn.y, oct_min(uvz.y)); mn.z = fminf(mn.z, oct_min(uvz.z));
+                    mx.x = fmaxf(mx.x, oct_max(uvz.x)); mx.y = fmaxf(mx.y, oct_max(uvz.y)); mx.z = fmaxf(mx.z, oct_max(uvz.z));
+                } else
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const f3 uvz = project_pos_to_uvz(extent_corner(c, e, k), mvp);
@@ -748,6 +773,19 @@ __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DV
                         const uint32_t mw = max(1u, p.desc.width >> lv);
                         const uint16_t* mip = p.hzbMin + p.desc.mipOffset[lv];
                         float zMin = 10.0f;
+                        if (OCT) {
+                            // texels (x, y) = (sub >> 1, 2 (sub & 1)) and (sub >> 1, 2 (sub & 1) + 1) of the 4 x 4
+                            const int x = (int)(sub >> 1), y0 = (int)((sub & 1u) << 1);
+                            const int sx = min(cz, cx + x), sy0 = min(cw, cy + y0), sy1 = min(cw, cy + y0 + 1);
+                            float a, b;
+                            if (TAIL && lv >= (int)HZB_TAIL_FIRST) {
+                                const float* lmip = sTail + sTailOff[lv];
+                                a = lmip[(uint32_t)sy0 * mw + (uint32_t)sx]; b = lmip[(uint32_t)sy1 * mw + (uint32_t)sx];
+                            } else {
+                                a = f16_to_f32(mip[(uint32_t)sy0 * mw + (uint32_t)sx]); b = f16_to_f32(mip[(uint32_t)sy1 * mw + (uint32_t)sx]);
+                            }
+                            zMin = fminf(zMin, oct_min(fminf(a, b)));
+                        } else
                         if (TAIL && lv >= (int)HZB_TAIL_FIRST) {
                             // levels 6.. were reduced by this block into LDS (hzb_tail_to_lds): same values, no launch for them
                             const float* lmip = sTail + sTailOff[lv];
@@ -853,9 +891,15 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
 // THREADS: 256, or 1024 for long lists with K = 1 -- the same one reservation per 1 024 commands, but sixteen waves with one
 // command each instead of four waves with four dependent chains each (config 4: 260 k commands were 254 workgroups, one per
 // CU, i.e. four waves per CU walking 4 x (command -> bounds + matrix -> texels)).
-template <int PHASE, uint32_t K, bool TAIL, uint32_t THREADS = 256u>
+#ifndef HZB_CULL_OCT
+#define HZB_CULL_OCT 1
+#endif
+// OCT: eight lanes per command (hzb_cmd_visible<., ., OCT>), THREADS / 8 commands per workgroup and step -- the form of short lists.
+template <int PHASE, uint32_t K, bool TAIL, uint32_t THREADS = 256u, bool OCT = false>
 __global__ __launch_bounds__(THREADS) void hzb_cull_kernel(HzbCullParams p)
 {
+    static_assert(!OCT || K == 1u, "eight lanes per command: one command per octet");
+    constexpr uint32_t CPB = OCT ? THREADS / 8u : THREADS * K;      // commands of a workgroup's step
     __shared__ uint32_t sWave[THREADS / 64u], sBase[2];
     __shared__ unsigned long long sTris[THREADS / 64u];
     __shared__ float sTail[TAIL ? HZB_TAIL_FLOATS : 1u];
@@ -865,11 +909,21 @@ __global__ __launch_bounds__(THREADS) void hzb_cull_kernel(HzbCullParams p)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // TAIL: the chain this launch culls against has its levels 0..5 in memory; every block with work reduces the rest
     // itself (block 0 also stores them)
-    if (TAIL && (blockIdx.x * (THREADS * K) < count || blockIdx.x == 0u) && (dv.flags & CHORD_FLAG_HZB_CULL))
+    if (TAIL && (blockIdx.x * CPB < count || blockIdx.x == 0u) && (dv.flags & CHORD_FLAG_HZB_CULL))
         hzb_tail_to_lds(p.hzbMin, blockIdx.x == 0u ? p.hzbTailOut : nullptr, p.desc, sTail, sTailOff, THREADS);
-    for (uint32_t base = blockIdx.x * (THREADS * K); base < count; base += gridDim.x * (THREADS * K)) {
+    for (uint32_t base = blockIdx.x * CPB; base < count; base += gridDim.x * CPB) {
         ChordDrawCmd cmd[K];
         uint32_t visBits = 0, rejBits = 0, tris = 0;
+        if (OCT) {
+            const uint32_t i = base + (threadIdx.x >> 3), sub = threadIdx.x & 7u;
+            cmd[0] = ChordDrawCmd{0, 0, 0};
+            if (i < count) {                                        // (the same for the eight lanes of an octet)
+                cmd[0] = p.inCmds[i];
+                uint32_t t = 0;
+                const bool vis = hzb_cmd_visible<PHASE, TAIL, true>(p, dv, cmd[0], t, sTail, sTailOff, sub);
+                if (sub == 0u) { if (vis) { visBits = 1u; tris = t; } else rejBits = 1u; }   // lane 0 of the octet counts and stores the command
+            }
+        } else
 #pragma unroll
         for (uint32_t k = 0; k < K; k++) {
             const uint32_t i = base + k * THREADS + threadIdx.x;
@@ -1253,14 +1307,19 @@ void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdLis
     const uint32_t maxBlocks = (uint32_t)c->numCUs * (longList ? 2u : 8u);
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
-    if (phase == 0) { if (longList) CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
-                      else          CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
+    // short lists: eight lanes per command, 128 commands per 1 024-thread workgroup (HZB_CULL_OCT)
+    const uint32_t octBlocks = std::max(1u, std::min((in.capacity + 127u) / 128u, (uint32_t)c->numCUs * 8u));
+    if (phase == 0) { if (longList)          CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
+                      else if (HZB_CULL_OCT) CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false, 1024u, true>), dim3(octBlocks), dim3(1024), 0, c->stream, p);
+                      else                   CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
     else if (c->hzbTailInCull) {
         // (inside chordvis_render_frame: the tile kernel wrote levels 0..5 of this chain; no hzb_tail_kernel ran)
-        if (longList) CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
-        else          CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true>), dim3(blocks), dim3(256), 0, c->stream, p);
-    } else          { if (longList) CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
-                      else          CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
+        if (longList)          CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
+        else if (HZB_CULL_OCT) CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true, 1024u, true>), dim3(octBlocks), dim3(1024), 0, c->stream, p);
+        else                   CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true>), dim3(blocks), dim3(256), 0, c->stream, p);
+    } else          { if (longList)          CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
+                      else if (HZB_CULL_OCT) CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false, 1024u, true>), dim3(octBlocks), dim3(1024), 0, c->stream, p);
+                      else                   CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
 }
 
 } // namespace chord
