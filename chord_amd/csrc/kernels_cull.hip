@@ -1301,7 +1301,10 @@ void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdLis
 {
     const HzbCullParams p = make_hzb_cull_params(c, hzb, in, outVisible, outRejected);
     // long lists: 1 024-thread workgroups, one command per thread, one reservation per workgroup and list
-    const bool longList = in.capacity > 65536u;
+#ifndef HZB_CULL_OCT_LONG
+#define HZB_CULL_OCT_LONG 0          // measurement builds: the eight-lane form also for long lists
+#endif
+    const bool longList = in.capacity > 65536u && !HZB_CULL_OCT_LONG;
     const uint32_t threads = longList ? 1024u : 256u;
     uint32_t blocks = (in.capacity + threads - 1u) / threads;
     const uint32_t maxBlocks = (uint32_t)c->numCUs * (longList ? 2u : 8u);
