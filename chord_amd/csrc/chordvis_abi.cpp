@@ -150,6 +150,7 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         if ((rc = dalloc(c, &c->dHzbFinalExchange, slots * CHORD_HZB_FINAL_SLOT_HALVES))) return rc;
         CHORD_HIP(c, hipMemsetAsync(c->dHzbFinalExchange, 0, slots * CHORD_HZB_FINAL_SLOT_HALVES * 2, c->stream));
         if ((rc = install_tile_owners(c))) return rc;
+        if ((rc = prepare_cull_exchange(c))) return rc;
     } else {
         dfree(c->dHzbExchange); dfree(c->dHzbFinalExchange); dfree(c->dShardTables); dfree(c->dTileLoads); dfree(c->dTileOwner); dfree(c->dCullExchange);
         c->shard.ownedRows = nullptr; c->shard.tileSlot = nullptr;
@@ -296,7 +297,7 @@ int install_tile_owners(ChordCtx* c)
 // ceil(count blocks / ranks) -- the same on every rank of a frame (same scene, same rank count).
 int ensure_cull_exchange(ChordCtx* c)
 {
-    if (!c->sceneLoaded || c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "cull exchange: a scene on a sharded context");
+    if (!c->sceneLoaded || c->shard.ranks <= 1 || c->shard.ranks > 8u) return fail(c, CHORDVIS_E_INVALID, "cull exchange: a scene on a context sharded over 2..8 ranks");
     const uint32_t N = c->shard.ranks, chunkBlocks = (c->cullBlocks + N - 1u) / N;
     if (c->dCullExchange && c->cullChunkBlocks == chunkBlocks && c->cullExchangeRanks == N) return CHORDVIS_OK;
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
@@ -306,6 +307,16 @@ int ensure_cull_exchange(ChordCtx* c)
     CHORD_HIP(c, hipMemsetAsync(c->dCullExchange, 0, words * 4u, c->stream));
     c->cullChunkBlocks = chunkBlocks; c->cullExchangeRanks = N;
     return CHORDVIS_OK;
+}
+
+// The exchange buffer is made when the LAST of {upload_scene, set_shard / allocate_gbuffer} has run, not inside a frame: whether a
+// frame starts with the sharded cull -- i.e. whether its first collective happens -- must follow from state every rank shares
+// (cull_shardable), never from an allocation that can fail on one rank while its peers are already inside the all-gather.  A failure
+// here is the failure of a set-up call.
+int prepare_cull_exchange(ChordCtx* c)
+{
+    if (!c->sceneLoaded || c->shard.ranks <= 1 || c->shard.ranks > 8u) return CHORDVIS_OK;
+    return ensure_cull_exchange(c);
 }
 
 // Per-context work buffers that depend on the scene's counts (object frames, group masks, command lists, raster work
@@ -738,6 +749,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
     c->sceneLoaded = true;
     c->historySlot = 0;
     c->pendingTailSlot = 0;
+    if ((rc = chord::prepare_cull_exchange(c))) { c->sceneLoaded = false; return rc; }     // (a sharded context: the rank-mask exchange buffer of this scene)
     if (c->cullMode == 1 && !c->bvhComplete) return fail(c, CHORDVIS_E_INVALID, "upload_scene: hierarchical culling is selected and a primitive has no BVH");
     return CHORDVIS_OK;
 }
@@ -760,6 +772,8 @@ int chordvis_bind_objects(ChordCtx* c, const ChordObject* deviceObjects, uint32_
 int chordvis_set_view(ChordCtx* c, const ChordCameraView* view, const ChordInstanceCullingView* iv, uint32_t switchFlags)
 {
     if (!c || !view || !iv) return fail(c, CHORDVIS_E_INVALID, "set_view: null argument");
+    // (the rank masks on their way through the all-gather were computed with the current view, cull mode and tile map)
+    if (c->cullPhaseDone) return fail(c, CHORDVIS_E_INVALID, "set_view: not between chordvis_frame_phase_cull and chordvis_frame_phase_a");
     c->hView.view = *view; c->hView.iv = *iv; c->hView.flags = switchFlags;
     c->hView.width = (uint32_t)iv->renderDimension[0]; c->hView.height = (uint32_t)iv->renderDimension[1];
     if (c->dVis && (c->hView.width != c->width || c->hView.height != c->height))
@@ -816,6 +830,7 @@ int chordvis_set_cull_mode(ChordCtx* c, int hierarchical)
 {
     if (!c || hierarchical < 0 || hierarchical > 1) return fail(c, CHORDVIS_E_INVALID, "set_cull_mode: 0 (flat) or 1 (hierarchical)");
     if (hierarchical && c->sceneLoaded && !c->bvhComplete) return fail(c, CHORDVIS_E_INVALID, "set_cull_mode: the uploaded scene has primitives without a BVH");
+    if (c->cullPhaseDone) return fail(c, CHORDVIS_E_INVALID, "set_cull_mode: not between chordvis_frame_phase_cull and chordvis_frame_phase_a");
     c->cullMode = hierarchical;
     return CHORDVIS_OK;
 }
@@ -828,7 +843,7 @@ int chordvis_set_shard(ChordCtx* c, uint32_t ranks, uint32_t rank)
 #if CHORD_TILE_SHIFT != 6
     if (ranks > 1) return fail(c, CHORDVIS_E_INVALID, "set_shard: this build's raster tiles are not 64 x 64");
 #endif
-    if (c->inFrame) return fail(c, CHORDVIS_E_INVALID, "set_shard: not inside a frame");
+    if (c->inFrame || c->cullPhaseDone) return fail(c, CHORDVIS_E_INVALID, "set_shard: not inside a frame");
     if (c->shard.ranks != ranks) { c->tileOwners.clear(); c->tileOwnersExplicit = false; }
     c->shard.ranks = ranks; c->shard.rank = rank;
     c->mineValid = false; c->listMine[1] = c->listMine[2] = false;       // (lists culled for another ownership)
@@ -852,7 +867,7 @@ int chordvis_set_tile_owners(ChordCtx* c, const uint8_t* owners, uint32_t tiles)
         owners = def.data();
     }
     if (tiles != c->tilesX * c->tilesY) return fail(c, CHORDVIS_E_INVALID, "set_tile_owners: one owner per tile of the G-buffer");
-    if (c->inFrame) return fail(c, CHORDVIS_E_INVALID, "set_tile_owners: not inside a frame");
+    if (c->inFrame || c->cullPhaseDone) return fail(c, CHORDVIS_E_INVALID, "set_tile_owners: not inside a frame");
     // frames in flight (pipelined hosts: an image still travelling) were laid out with the old map
     CHORD_HIP(c, hipStreamSynchronize(c->stream));
     if (c->commResolveStream) CHORD_HIP(c, hipStreamSynchronize(c->commResolveStream));
@@ -948,8 +963,8 @@ int chordvis_debug_fill_cull_exchange(ChordCtx* c)
 {
     int rc = ready(c, "debug_fill_cull_exchange");
     if (rc) return rc;
+    if (!cull_shardable_config(c)) return fail(c, CHORDVIS_E_INVALID, "debug_fill_cull_exchange: the sharded cull does not apply");
     if ((rc = ensure_cull_exchange(c))) return rc;
-    if (!cull_shardable(c)) return fail(c, CHORDVIS_E_INVALID, "debug_fill_cull_exchange: the sharded cull does not apply");
     if (c->inFrame) return fail(c, CHORDVIS_E_INVALID, "debug_fill_cull_exchange: not inside a frame");
     if ((rc = flush_view(c))) return rc;
     launch_cull_masks(c, true);
@@ -1165,8 +1180,8 @@ static int frame_phase_cull_impl(ChordCtx* c)
     if (rc) return rc;
     if (c->shard.ranks <= 1) return fail(c, CHORDVIS_E_INVALID, "frame_phase_cull: the context is not sharded");
     if (c->cullPhaseDone) return fail(c, CHORDVIS_E_INVALID, "frame_phase_cull: called twice without chordvis_frame_phase_a in between");
-    if ((rc = ensure_cull_exchange(c))) return rc;
-    if (!cull_shardable(c)) return fail(c, CHORDVIS_E_INVALID, "frame_phase_cull: the sharded cull needs 2..8 ranks and the flat cull mode (start the frame at chordvis_frame_phase_a instead)");
+    if (!cull_shardable_config(c)) return fail(c, CHORDVIS_E_INVALID, "frame_phase_cull: the sharded cull needs 2..8 ranks and the flat cull mode (start the frame at chordvis_frame_phase_a instead)");
+    if ((rc = ensure_cull_exchange(c))) return rc;       // (made by upload_scene / set_shard already: a no-op)
     begin_frame_stamps(c);
     if ((rc = begin_frame_clear(c))) return rc;
     record(c, S_CLEAR);
@@ -1495,6 +1510,10 @@ int chordvis_debug_graph_frames(ChordCtx* c, uint32_t pairs, float* msPerFrameSt
     if (!c || !pairs || !msPerFrameStream || !msPerFrameGraph) return fail(c, CHORDVIS_E_INVALID, "debug_graph_frames: bad arguments");
     if (!c->ownStream) return fail(c, CHORDVIS_E_INVALID, "debug_graph_frames: needs a context-owned (capturable) stream");
     int rc;
+    // (the kept tile schedule is off for both measurements: a captured frame either holds the schedule kernel or it does not, whatever the
+    // age of the schedule at replay -- with it in every frame the stream's and the graph's frames are the same eleven + one launches)
+    struct KeepOff { ChordCtx* c; uint32_t keep; ~KeepOff() { c->orderKeepFrames = keep; c->orderAge = 0xFFFFFFFFu; } } keepOff{c, c->orderKeepFrames};
+    c->orderKeepFrames = 0u;
     for (int i = 0; i < 4; i++) if ((rc = chordvis_render_frame(c))) return rc;
     hipEvent_t e0, e1;
     CHORD_HIP(c, hipEventCreate(&e0)); CHORD_HIP(c, hipEventCreate(&e1));

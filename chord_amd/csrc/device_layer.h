@@ -473,8 +473,10 @@ int alloc_scene_work_buffers(ChordCtx* c);
 void launch_group_cull(ChordCtx* c, const CmdList& out);
 void launch_full_list(ChordCtx* c);             // the full post-cull list of a sharded frame, when a consumer asks for it
 void launch_cull_masks(ChordCtx* c, bool wholeRange = false);   // sharded cull: objects + this rank's range of group instances -> rank-mask words (its chunk of dCullExchange)
-bool cull_shardable(const ChordCtx* c);         // the sharded cull applies: 2..8 ranks, flat cull mode, a scene and a sharded G-buffer
+bool cull_shardable_config(const ChordCtx* c);  // the sharded cull applies to this configuration: 2..8 ranks, flat cull mode, a scene and a sharded G-buffer (debug bit 524288 -- set alike on every rank -- turns it off)
+bool cull_shardable(const ChordCtx* c);         // ... and its exchange buffer stands (made at set-up): what a frame decides its first collective by -- state every rank shares
 int ensure_cull_exchange(ChordCtx* c);          // chordvis_abi.cpp: (re)allocates dCullExchange for the current scene / rank count
+int prepare_cull_exchange(ChordCtx* c);         // ... at set-up time (upload_scene, set_shard / allocate_gbuffer), wherever the sharded cull can apply
 void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdList& in, const CmdList& outVisible,
                      const CmdList* outRejected);
 hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles);   // first failing HIP call, or hipSuccess

@@ -1113,10 +1113,17 @@ void launch_full_list(ChordCtx* c)
     c->fullListStale = false;
 }
 
-bool cull_shardable(const ChordCtx* c)
+bool cull_shardable_config(const ChordCtx* c)
 {
     const bool hier = c->cullMode == 1 && c->bvhComplete && c->dBvhNodes;
     return c->sceneLoaded && c->shard.ranks > 1u && c->shard.ranks <= 8u && !hier && c->height && c->shard.ownedRows && c->dTileOwner && !(c->debugFlags & 524288u);
+}
+bool cull_shardable(const ChordCtx* c)
+{
+    // (the buffer is made by the set-up calls -- prepare_cull_exchange --: no frame allocates, so no rank can drop out of the exchange
+    // on its own)
+    const uint32_t N = c->shard.ranks;
+    return cull_shardable_config(c) && c->dCullExchange && c->cullExchangeRanks == N && c->cullChunkBlocks == (c->cullBlocks + N - 1u) / N;
 }
 
 static FrameTail take_pending_tail(ChordCtx* c)

@@ -2790,24 +2790,42 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     // ---- scan-convert the bin, 256 entries per batch -------------------------------------------
     // Software pipeline over the two dependent fetches of a batch (bin entry -> 48-byte record): the
     // record of batch b+1 and the bin entry of batch b+2 are in flight while batch b is scan-converted.
-    uint32_t chunk0 = 0;                                          // first overflow chunk of this item's range
-    if (n > p.binCap) {
-        // overflow chunks the item's entries [lo, n) live in (chunk table -> LDS; an entry of another pass or a failed
-        // allocation reads as invalid and its entries are skipped)
-        chunk0 = lo > p.binCap ? (lo - p.binCap) >> CHORD_BIN_CHUNK_SHIFT : 0u;
-        const uint32_t chunks = min(64u, ((n - p.binCap + CHORD_BIN_CHUNK - 1u) >> CHORD_BIN_CHUNK_SHIFT) - chunk0);
-        for (uint32_t j = tix; j < chunks; j += TB) {
-            const RasterParams* q = kernel_args();                                // (long bins only: not worth registers across the kernel)
-            const unsigned long long e = scalar_load(&q->binChunkTab)[(size_t)tileId * scalar_load(&q->binMaxChunks) + chunk0 + j];
-            chunkTab[j] = (uint32_t)(e >> 32) == scalar_load(&q->binStamp) ? (uint32_t)e : CHORD_BIN_CHUNK_INVALID;
+    // Overflow chunks the item's entries [lo, n) live in: a WINDOW of 64 chunk names in LDS (chunk c at chunkTab[c & 63], names of
+    // chunks [chunk0, chunkEnd); an entry of another pass or a failed allocation reads as invalid and its entries are skipped).
+    // A fresh schedule cuts a bin into slices of at most ~33 chunks, so the window holds a whole item; an item of a KEPT schedule
+    // (orderKept) was cut for an earlier frame's bin and may now span any number of chunks -- a camera cut into a hotspot view --,
+    // so the loops below slide the window along (window_advance): 32 chunks at a time once the loop has passed the window's middle.
+    // Their look-ahead is at most three batches = 1.5 chunks, and names below the current batch's chunk are dead.
+    uint32_t chunk0 = 0, chunkEnd = 0;
+    const uint32_t chunksAll = n > p.binCap ? (n - p.binCap + CHORD_BIN_CHUNK - 1u) >> CHORD_BIN_CHUNK_SHIFT : 0u;   // chunks [0, chunksAll) hold entries below n
+    auto window_load = [&](uint32_t from, uint32_t to) {
+        const RasterParams* q = kernel_args();                                // (long bins only: not worth registers across the kernel)
+        for (uint32_t j = from + tix; j < to; j += TB) {
+            const unsigned long long e = scalar_load(&q->binChunkTab)[(size_t)tileId * scalar_load(&q->binMaxChunks) + j];
+            chunkTab[j & 63u] = (uint32_t)(e >> 32) == scalar_load(&q->binStamp) ? (uint32_t)e : CHORD_BIN_CHUNK_INVALID;
         }
+    };
+    auto window_reset = [&]() {                                  // (callers: n > binCap; every thread of the workgroup)
+        __syncthreads();                                          // (readers of an earlier window are done)
+        chunk0 = lo > p.binCap ? (lo - p.binCap) >> CHORD_BIN_CHUNK_SHIFT : 0u;
+        chunkEnd = min(chunksAll, chunk0 + 64u);
+        window_load(chunk0, chunkEnd);
         __syncthreads();
-    }
+    };
+    auto window_advance = [&](uint32_t base) {                   // top of a loop iteration over entries [base, ...): uniform
+        if (chunkEnd >= chunksAll || base < p.binCap + ((chunk0 + 32u) << CHORD_BIN_CHUNK_SHIFT)) return;
+        __syncthreads();
+        const uint32_t to = min(chunksAll, chunkEnd + 32u);
+        window_load(chunkEnd, to);
+        chunk0 += 32u; chunkEnd = to;
+        __syncthreads();
+    };
+    if (n > p.binCap) window_reset();
     const uint32_t wideLimit = p.triCap * CHORD_LIST_SHARDS, compactLimit = p.triCapC * CHORD_LIST_SHARDS;
     auto binWord = [&](uint32_t k) -> uint32_t {               // bin entry k as stored, ~0u = none
         if (k < p.binCap) return bin[k];
-        const uint32_t o = k - p.binCap, cj = (o >> CHORD_BIN_CHUNK_SHIFT) - chunk0;
-        const uint32_t id = cj < 64u ? chunkTab[cj] : CHORD_BIN_CHUNK_INVALID;
+        const uint32_t o = k - p.binCap, c = o >> CHORD_BIN_CHUNK_SHIFT;
+        const uint32_t id = (c - chunk0) < (chunkEnd - chunk0) ? chunkTab[c & 63u] : CHORD_BIN_CHUNK_INVALID;
         if (id == CHORD_BIN_CHUNK_INVALID) return 0xFFFFFFFFu;
         return p.binPool[(size_t)id * CHORD_BIN_CHUNK + (o & (CHORD_BIN_CHUNK - 1u))];
     };
@@ -2821,6 +2839,7 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         const uint32_t blockLimit = blockCap * CHORD_LIST_SHARDS;
         uint32_t giNext = lo + tix < n ? binWord(lo + tix) : 0xFFFFFFFFu;
         for (uint32_t base = lo; base < n; base += TB) {
+            window_advance(base);
             const uint32_t gi = giNext;
             giNext = base + TB + tix < n ? binWord(base + TB + tix) : 0xFFFFFFFFu;
             // (never a block outside the pool: a slot drawn but not written after a reported overflow holds anything)
@@ -2829,6 +2848,8 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
             if (isBlock) hdr = *reinterpret_cast<const uint2*>(blockPool + (size_t)(gi & CHORD_REC_INDEX_MASK) * 2u);
             merge_blocks(tile, blockPool, __ballot(isBlock), gi, hdr.x, hdr.y, tix & 63u);
         }
+        // (the triangle pass below walks the same entries from `lo` again: a window that was slid along goes back)
+        if (n > p.binCap && chunk0 != (lo > p.binCap ? (lo - p.binCap) >> CHORD_BIN_CHUNK_SHIFT : 0u)) window_reset();
     }
     auto binEntry = [&](uint32_t k) -> uint32_t {              // record name of bin entry k, ~0u = none (or a pixel block)
         const uint32_t gi = record_name(binWord(k));           // (~0u stays ~0u)
@@ -2970,6 +2991,7 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         if (nameB != 0xFFFFFFFFu) FETCH_REC(nameB, b0, b1, b2);                  // record of batch 1
         uint32_t idx = entryThread && k0 + 2u * TILE_BATCH < n ? binEntry(k0 + 2u * TILE_BATCH) : 0xFFFFFFFFu;   // bin entry of batch 2
         for (uint32_t base = lo; base < n;) {
+            window_advance(base);
             uint32_t rows = batch_setup(nq0, nq1, nq2, nameA);
             nameA = idx;
             if (nameA != 0xFFFFFFFFu) FETCH_REC(nameA, nq0, nq1, nq2);          // record of batch b + 2 into the set just read
@@ -2977,6 +2999,7 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
             batch_units(rows, batchNo);
             base += TILE_BATCH; batchNo++;
             if (base >= n) break;
+            window_advance(base);
             rows = batch_setup(b0, b1, b2, nameB);
             nameB = idx;
             if (nameB != 0xFFFFFFFFu) FETCH_REC(nameB, b0, b1, b2);
@@ -2986,6 +3009,7 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         }
     } else
     for (uint32_t base = lo; base < n; base += TILE_BATCH, batchNo++) {
+        window_advance(base);
         const uint32_t k = base + tix;
         const uint4 q0 = nq0, q1 = nq1, q2 = nq2;
         const uint32_t name = nameNext;

@@ -226,7 +226,7 @@ int pipelined_frame_body(ChordCtx* c, hipEvent_t visReadyThis, hipEvent_t visRea
     const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
     // the sharded group cull (2..8 ranks, flat mode: state every rank shares): each rank tests its share of the groups, the rank
     // masks are all-gathered, phase a goes on from them
-    if (cull_shardable(c) && ensure_cull_exchange(c) == CHORDVIS_OK) {
+    if (cull_shardable(c)) {
         if (!rc) rc = chordvis_frame_phase_cull(c);
         const int e = tr.small(2, (size_t)c->cullChunkBlocks * 257u * 4u); if (!rc) rc = e;
     }
@@ -318,8 +318,9 @@ int comm_render_frame(ChordCtx* c)
     if (c->commPipelined) return comm_render_frame_pipelined(c, r);
     const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
     int rc = CHORDVIS_OK;
-    if (cull_shardable(c) && ensure_cull_exchange(c) == CHORDVIS_OK) {
-        // the sharded group cull: this rank's share of the group tests, then the rank masks of all ranks
+    if (cull_shardable(c)) {
+        // the sharded group cull (decided from state every rank shares -- configuration and a buffer made at set-up, never from an
+        // allocation inside the frame): this rank's share of the group tests, then the rank masks of all ranks
         rc = chordvis_frame_phase_cull(c);
         const size_t bytes = (size_t)c->cullChunkBlocks * 257u * 4u;
         char* base = reinterpret_cast<char*>(c->dCullExchange);
@@ -649,6 +650,9 @@ int chordvis_group_render_frame(ChordGroup* g)
     if (g->n == 1) return run_all(g, [&](uint32_t r) { return chordvis_render_frame(g->ctx[r]); }, "group_render_frame");
     if (g->pipelined) return group_render_frame_pipelined(g);
     // A rank that fails keeps walking through the host barriers (its peers would wait for it forever otherwise).
+    // (whether the frame starts with the sharded cull is ONE decision for the group, taken here before any worker runs)
+    bool shardCull = true;
+    for (uint32_t k = 0; k < g->n; k++) shardCull = shardCull && cull_shardable(g->ctx[k]);
     return run_all(g, [&](uint32_t r) {
         ChordCtx* c = g->ctx[r];
         JobClock clock(g, r);
@@ -656,7 +660,7 @@ int chordvis_group_render_frame(ChordGroup* g)
         // fails still joins the exchange its peers are about to enter
         const bool stage1 = c->historySlot != 0 && (c->hView.flags & CHORD_FLAG_HZB_CULL);
         int rc = CHORDVIS_OK;
-        if (cull_shardable(c) && ensure_cull_exchange(c) == CHORDVIS_OK) {
+        if (shardCull) {
             rc = chordvis_frame_phase_cull(c);
             const int e = group_all_gather(g, r, 0, [&](uint32_t k) { return reinterpret_cast<char*>(g->ctx[k]->dCullExchange); },
                                            (size_t)c->cullChunkBlocks * 257u * 4u);

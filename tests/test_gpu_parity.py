@@ -755,6 +755,63 @@ def test_kept_tile_schedule_renders_the_same_frames(gpu):
         r.close()
 
 
+def test_kept_tile_schedule_survives_a_cut_into_a_hotspot(gpu):
+    """The work items of a kept schedule were cut for an EARLIER frame's bins.  A camera that turns from an empty view into config 5's
+    hotspot (reduced, record form: the hottest tile's bin holds some 300 k entries) meets a schedule in which every tile is one whole
+    work item: that item then spans far more overflow chunks than the 64 names the tile kernel holds in LDS at once (16 384 + 64 x
+    1 024 entries), and the kernel must slide its chunk window along the bin -- round 5's kernel read everything past the window as
+    'no entry' and dropped those triangles without a word.  Frames: away (a schedule of empty tiles is made), the
+    hotspot twice under that kept schedule, away, the hotspot again; against the oracle, beside a context that makes a fresh schedule
+    every frame -- which must launch exactly one kernel more in the kept frames."""
+    from chord_amd import lib as L
+    from chord_amd.renderer import VisibilityRenderer
+    W, Hh = 960, 540
+    scene, hot = scenes.config5_subpixel(W, Hh, prims=16, patches_per_prim=256, instances=4, hotspot_sigma_px=64.0)
+    away = scenes.Camera((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), W, Hh)
+    flags = R.FLAG_FRUSTUM_CULL | R.FLAG_CONE_CULL
+    order = [away, hot, hot, away, hot]
+    ctx = []
+    for keep in (None, 0):
+        r = VisibilityRenderer(0)
+        r.set_limits(max_triangle_records=8 << 20, bin_pool_chunks=16384, bin_max_chunks_per_tile=2048)
+        r.upload_scene(scene)
+        r.allocate_gbuffer(W, Hh)
+        if keep is not None:
+            r.set_tile_schedule_keep(keep)
+        ctx.append(r)
+    tiles = ((W + 63) // 64) * ((Hh + 63) // 64)
+    launches = [[], []]
+    want_hot = None
+    for i, cam in enumerate(order):
+        last = order[i - 1] if i else cam
+        view0, _ = L.make_views(last)
+        view, iv = L.make_views(cam, view0)
+        objs = L.fill_objects(scene, cam, last).copy()
+        if cam is hot and want_hot is None:
+            want_hot = orc.frame(scene.with_objects(objs), view, iv, flags)
+        for k, r in enumerate(ctx):
+            r.update_objects(objs)
+            r.set_view(view, iv, flags)
+            r.render_frame()
+            got = r.read_visibility()
+            st = r.stats()
+            launches[k].append(st["kernelLaunches"])
+            assert st["overflow"] == 0
+            if cam is away:
+                assert st["trianglesSubmitted"] == 0 and not got.any(), "frame %d: the empty view drew something" % i
+                continue
+            assert st["trianglesSubmitted"] == want_hot["stats"].trianglesSubmitted
+            cnt = np.zeros(tiles, np.uint32); ticks = np.zeros(tiles * 9, np.uint64)
+            assert L.lib.chordvis_debug_tile_profile(r._ctx, 0, ticks.ctypes.data, cnt.ctypes.data, tiles * 9) == 0
+            assert int(cnt.max()) > 16384 + 64 * 1024 + 4096, "the scene no longer runs a bin past the chunk window: max bin %d" % int(cnt.max())
+            H.assert_vis_equal(got, want_hot["vis"], W, Hh, "frame %d (hotspot), schedule kept for %d frames" % (i, r.tile_schedule_keep()))
+    # frames 1..4 of the default context run under frame 0's schedule (made for an empty view): one launch less than the control
+    assert launches[0][0] == launches[1][0], launches
+    assert all(a == b - 1 for a, b in zip(launches[0][1:], launches[1][1:])), launches
+    for r in ctx:
+        r.close()
+
+
 @pytest.mark.parametrize("w,h", [(400, 240), (1237, 701)])
 def test_frames_with_nothing_in_view_match_oracle(gpu, w, h):
     """The empty input of this path: a camera that turns its back on the whole scene.  Frame 1 sees the scene, frame 2 nothing
