@@ -95,6 +95,9 @@ def main():
                     help="instanceCulling: the reference's flat group dispatch, or the BVH walk (same command list)")
     ap.add_argument("--no-hzb", action="store_true", help="disable HZB occlusion culling (frustum+cone only)")
     ap.add_argument("--debug-flags", type=int, default=0, help="raster ablation switches (measurement only; voids parity)")
+    ap.add_argument("--no-stamps", action="store_true", help="no hipEvent stamps anywhere in the run (kernel traces: every frame of the process is then a product frame; the line's gpu_ms / roofline times are 0)")
+    ap.add_argument("--no-path", action="store_true", help="N = 1: do not also time the moving camera path (`moving_path`)")
+    ap.add_argument("--path-views", type=int, default=64, help="distinct views of the moving camera path (even)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -413,7 +416,7 @@ def measure(args, workload, env):
     # frame by ~20 %.  Runs of 64 steps or more stamp every 8th step of the timed region; a shorter run (the driver's 20 steps) would
     # carry that cost in 15 % of its frames, so its stamped frames -- eight of them -- are rendered right behind the timed region
     # instead (same frames, same state, same stream): `stamped_inside_timed_region` says which it was.
-    stamp_inside = args.steps >= 64 or world > 1
+    stamp_inside = (args.steps >= 64 or world > 1) and not args.no_stamps
     r.enable_timers(2 if stamp_inside else 0, period=8)
     rank_elapsed, elapsed = timed(args.steps)
     # The per-kernel averages behind `roofline` come from hipEvent stamps on the launch stream.  Inside the timed region only every
@@ -422,7 +425,7 @@ def measure(args, workload, env):
     stamped_in_region = (args.steps + 7) // 8 if stamp_inside else 0
     extra = 0
     st = r.stats()                                  # per-frame GPU timestamps averaged over the stamped steps of the timed region
-    if stamped_in_region < 8 and world == 1:
+    if stamped_in_region < 8 and world == 1 and not args.no_stamps:
         r.enable_timers(2, period=1)                # (restarts the accumulation)
         extra = 8 - stamped_in_region
         for i in range(extra):
@@ -430,11 +433,19 @@ def measure(args, workload, env):
         torch.cuda.synchronize(dev)
         st2 = r.stats()
         for k in list(st):                          # the ms* fields are means over stamped frames: weighted mean of the two sets
-            if k.startswith("ms") and isinstance(st[k], float):
+            if (k.startswith("ms") or k == "stampsPerFrame") and isinstance(st[k], float):
                 st[k] = (st[k] * stamped_in_region + st2[k] * extra) / (stamped_in_region + extra)
             elif not stamped_in_region:
                 st[k] = st2[k]
     ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- N = 1: the same metric along a MOVING camera (the two-view loop re-makes the kept tile schedule on the same view every time and
+    #      renders it on views the schedule was made for or next to: as favourable as a kept schedule gets)
+    moving = None
+    if world == 1 and not args.no_path and wl.startswith("street") and not args.debug_flags:
+        moving = moving_path(args, r, scene, cam_a, flags, dev)
+        if moving:
+            moving["ratio_to_two_view"] = round(moving["value"] / (tris_per_pair / 2.0 / (ms_per_step * 1e-3) / 1e9), 4)
 
     # ---- N > 1, library-run exchange: the PIPELINED protocol on the same frames (second communicator: the image of frame i travels
     #      beside frame i + 1; the history HZB waits only for the small end-of-frame exchange) -- DESIGN.md 6
@@ -480,6 +491,22 @@ def measure(args, workload, env):
         "raster_setup_kernel": (st["msRasterCluster"], cluster_bytes * clusters_per_frame + rec_bytes + block_bytes + 4.0 * bins),
         "raster_tile_kernel": (st["msRasterChunk"], 4.0 * bins + rec_size * (bins - blocks) + block_bytes + 8.0 * pixels + (launches - 1) * 16.0 * 4096 * tiles1),
     }
+    # What an event record costs.  A record between two kernels is a barrier packet on the queue: the kernel behind it is not dispatched
+    # under the kernel in front of it, so every stamped interval is a few microseconds longer than its kernels and a stamped frame longer
+    # than a product frame by that x the frame's records (round 5 read that difference as "23 % of the frame idle between kernels"; the
+    # unstamped frames of a kernel trace have first start -> last end = the sum of their kernels' durations).  Measured in this run: the
+    # stamped frame (msFrame: sum of its intervals) against the frame of the timed region, per interval.  The timed region itself holds
+    # stamps in one frame of eight when it is 64 steps or longer: its mean is then U + O / 8 for a stamped frame U + O.
+    stamps_pf = float(st.get("stampsPerFrame") or 0.0)
+    stamp_cost_ms = 0.0
+    if world == 1 and stamps_pf > 1.0 and st["msFrame"] > 0.0:
+        over = st["msFrame"] - ms_per_step
+        if stamp_inside:
+            over *= 8.0 / 7.0
+        stamp_cost_ms = max(0.0, over) / (stamps_pf - 1.0)
+    raw_ms = {k: v[0] for k, v in kernels.items()}
+    # (one interval per launch of the kernel ends in a stamp: the set-up interval of a dense launch holds two kernels and one stamp)
+    kernels = {k: (max(v[0] - launches * stamp_cost_ms, 0.0) if v[0] > 0 else 0.0, v[1]) for k, v in kernels.items()}
     dom = max(kernels, key=lambda k: kernels[k][0])
     dom_ms, dom_bytes = kernels[dom]
     achieved = (dom_bytes / launches) / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -506,7 +533,10 @@ def measure(args, workload, env):
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_profile_head": traffic_head,          # the commit that profile was taken at: a kernel changed since then leaves `traffic` stale
                 "from_committed_profile": traffic is not None,   # (PMC passes cannot run inside this process: not observed in THIS run)
-                "avg_launch_us": round(dom_ms / launches * 1e3, 2), "launches_per_step": launches,
+                # avg_launch_us: the stamped interval less what the stamp itself costs (stamp_cost_us, measured in this run: stamped frame
+                # against the timed region's frame, per interval) -- the figure the rocprofv3 kernel stats of profiles/ must agree with
+                "avg_launch_us": round(dom_ms / launches * 1e3, 2), "avg_launch_us_stamped": round(raw_ms[dom] / launches * 1e3, 2),
+                "stamp_cost_us": round(stamp_cost_ms * 1e3, 2), "stamps_per_frame": round(stamps_pf, 1), "launches_per_step": launches,
                 "stamped_frames": stamped_in_region + extra, "stamped_inside_timed_region": stamped_in_region,
                 "algorithmic_bytes_per_launch": int(dom_bytes / launches),
                 "other_kernel": {k: {"avg_launch_us": round(v[0] / launches * 1e3, 2), "algorithmic_bytes_per_launch": int(v[1] / launches)}
@@ -627,6 +657,9 @@ def measure(args, workload, env):
             "counts_view_b": {k: per_view[1][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            # the same metric over `views` DISTINCT views along the street (0.5 m steps, two 180-degree cuts per loop), every frame culled
+            # against the HZB of the view before it; None where it does not apply (N > 1, the sub-pixel workloads, --no-path)
+            "moving_path": moving,
         }
         if world > 1:
             line["exchange"] = exchange
@@ -684,6 +717,66 @@ def measure(args, workload, env):
             if line is not None and gl is not None:
                 line["group_transport"] = {k: gl[k] for k in ("value", "ms_per_step", "speedup_vs_single", "pipelined", "phases_ms", "collective_backend", "error") if k in gl}
     return line
+
+
+PATH_CUT_AHEAD_M = 90.0
+
+
+def path_cameras(cam_a, n):
+    """n distinct views: n / 2 steps of 0.5 m down the street from the bench camera, a cut to the far end looking back (90 m ahead, the
+    heading reversed: other tiles are the heavy ones, other bins the long ones), n / 2 steps of 0.5 m back; the loop closes with the cut
+    from the last view to the first."""
+    from chord_amd import scenes
+    f = np.array(cam_a.front, dtype=np.float64)
+    f /= np.linalg.norm(f)
+    half = n // 2
+    cams = [cam_a.moved(tuple(0.5 * i * f)) for i in range(half)]
+    b = np.array([-f[0], f[1], -f[2]])
+    p0 = np.array(cam_a.position) + PATH_CUT_AHEAD_M * f * np.array([1.0, 0.0, 1.0])
+    back = scenes.Camera(tuple(p0), tuple(b), cam_a.width, cam_a.height, cam_a.fovy, cam_a.z_near, cam_a.z_far, cam_a.world_up, cam_a.jitter)
+    cams += [back.moved(tuple(0.5 * i * b)) for i in range(n - half)]
+    return cams
+
+
+def moving_path(args, r, scene, cam_a, flags, dev):
+    """The metric of the line over a closed path of distinct views (N = 1): view i culls against the HZB of view i - 1 through the
+    objects' last-frame transforms, exactly as the two-view loop does.  One untimed loop settles the history, a second one reads every
+    view's submitted triangles, then `loops` loops are timed between two synchronisations.  Stamps off."""
+    from chord_amd import lib as L
+    n = max(4, args.path_views & ~1)
+    cams = path_cameras(cam_a, n)
+    base = [L.make_views(c)[0] for c in cams]
+    views, d_obj = [], []
+    for i, c in enumerate(cams):
+        last = cams[i - 1]
+        views.append(L.make_views(c, base[i - 1]))
+        d_obj.append(torch.from_numpy(L.fill_objects(scene, c, last).copy().view(np.uint8).reshape(-1)).to(dev))
+
+    def frame(i):
+        k = i % n
+        r.bind_objects(d_obj[k].data_ptr(), len(scene.objects))
+        r.set_view(views[k][0], views[k][1], flags)
+        r.render_frame()
+    r.enable_timers(0)
+    for i in range(n):
+        frame(i)
+    tris, over = 0, 0
+    for i in range(n):
+        frame(i)
+        st = r.stats()
+        tris += st["trianglesSubmitted"]
+        over |= st["overflow"]
+    loops = max(2, (args.steps + n - 1) // n)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(loops * n):
+        frame(i)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    return {"views": n, "steps": loops * n, "ms_per_step": round(el / (loops * n) * 1e3, 4), "value": round(tris * loops / el / 1e9, 4), "unit": "Gtri/s",
+            "triangles_submitted_per_step": tris / float(n), "overflow": int(over),
+            "path": "%d x 0.5 m down the street, cut to %.0f m ahead looking back, %d x 0.5 m, cut to the start" % (n // 2, PATH_CUT_AHEAD_M, n - n // 2),
+            "tile_schedule_keep_frames": r.tile_schedule_keep()}
 
 
 def run_group(args, wl, scene, views, objs, flags, W, H, world, rank, dev, stream, fallbacks):

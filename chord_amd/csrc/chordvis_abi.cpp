@@ -1678,6 +1678,7 @@ int chordvis_stats(ChordCtx* c, ChordStats* out)
         out->msExchangeHzb = exh * inv; out->msExchangeVis = exv * inv; out->msExchangeCull = exc * inv; out->msExchangeFinal = exf * inv;
         out->msFrame = (clear + cull + st0 + hzb0 + st1 + hzbf + other + exh + exv + exc + exf) * inv;
         out->framesTimed = c->framesStamped;
+        out->stampsPerFrame = (float)c->stampTags.size() * inv;
     }
     if (c->timers == 2) { c->stampTags.clear(); c->framesStamped = 0; }
     if (dc.overflow) return fail(c, CHORDVIS_E_CAPACITY, "a deferred raster list overflowed this frame; the visibility buffer is incomplete");

@@ -66,6 +66,7 @@ class Stats(C.Structure):
         ("pixelBlocks", C.c_uint64),
         ("msExchangeHzb", C.c_float), ("msExchangeVis", C.c_float), ("msExchangeCull", C.c_float), ("msExchangeFinal", C.c_float),
         ("kernelLaunches", C.c_uint32), ("largeRecords", C.c_uint32 * 2), ("clipTriangles", C.c_uint32 * 2),
+        ("stampsPerFrame", C.c_float),
     ]
 
     def as_dict(self):

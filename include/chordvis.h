@@ -134,6 +134,9 @@ typedef struct ChordStats {
     uint32_t kernelLaunches;       /* kernel launches of the last finished frame (a sub-millisecond frame is bounded by launches x launch floor) */
     uint32_t largeRecords[2];      /* per raster pass: records touching more than 2 x 2 tiles (binned by the large-record binner, or tested by the tiles themselves) */
     uint32_t clipTriangles[2];     /* per raster pass: triangles that went through the homogeneous clipper */
+    float    stampsPerFrame;       /* event records per stamped frame behind the ms* fields (0: no timers).  A record between two kernels keeps the
+                                      second from being dispatched under the first: every stamped interval is a few microseconds longer than its
+                                      kernels, a stamped frame that many x this longer than an unstamped one (bench.py: roofline.stamp_cost_us) */
 } ChordStats;
 
 /* ------------------------------------------------------------------ host-only (no device needed) */

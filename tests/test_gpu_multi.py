@@ -321,8 +321,22 @@ def test_bench_two_ranks_group_fallback_on_one_device(gpu):
 
 
 def test_bench_single_gpu_line_has_the_contract_fields(gpu):
-    line = _run_bench(["--steps", "6", "--warmup", "4", "--workload", "street_720p_hzb", "--cpu-baseline-frames", "2"], {})
+    line = _run_bench(["--steps", "6", "--warmup", "4", "--workload", "street_720p_hzb", "--cpu-baseline-frames", "2", "--path-views", "8"], {})
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["roofline"]["frac"] < 1.0 and line["cpu_baseline"]["cores"] == 1
+    # the stamp-corrected per-launch time of the dominant kernel: the stamped interval less what a record costs, measured in the run
+    rf = line["roofline"]
+    assert rf["stamps_per_frame"] >= 10 and 0.0 <= rf["stamp_cost_us"] < 20.0
+    assert 0 < rf["avg_launch_us"] <= rf["avg_launch_us_stamped"]
+    # the same metric along a moving camera (a closed path of distinct views, two cuts per loop)
+    mp = line["moving_path"]
+    assert mp["views"] == 8 and mp["steps"] >= 16 and mp["value"] > 0 and mp["ms_per_step"] > 0 and mp["overflow"] == 0
+    assert 0.2 < mp["ratio_to_two_view"] < 5.0 and mp["tile_schedule_keep_frames"] == line["tile_schedule_keep_frames"]
+
+
+def test_bench_without_stamps_renders_only_product_frames(gpu):
+    """`--no-stamps` (kernel traces: tools/trace.sh): no event record in the whole process -- the line says so and carries no stamped times."""
+    line = _run_bench(["--steps", "6", "--warmup", "4", "--workload", "street_720p_hzb", "--cpu-baseline-frames", "0", "--no-stamps", "--no-path"], {})
+    assert line["roofline"]["stamped_frames"] == 0 and line["gpu_ms"]["msFrame"] == 0.0 and line["value"] > 0 and line["moving_path"] is None

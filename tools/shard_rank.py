@@ -27,7 +27,9 @@ r.update_objects(objs); r.set_view(view, iv, flags)
 sharded_cull = ranks > 1 and ranks <= 8 and os.environ.get("CULL", "sharded") != "replicated"
 if sharded_cull:
     r.debug_fill_cull_exchange()                         # (the peers' chunks of the rank-mask exchange: the view is static)
-r.enable_timers(2)
+# (no event stamps unless STAMPS=1: under a kernel trace the frames are then product frames; the cull / setup / tile split of the printed
+# line needs the stamps and reads 0 without them)
+r.enable_timers(2 if os.environ.get("STAMPS") == "1" else 0)
 n = int(os.environ.get("FRAMES", "10"))
 for i in range(3 + n):
     if i == 3:

@@ -10,7 +10,13 @@ The group cull is the SHARDED one by default (a rank tests its share of the grou
 exchange are filled once, outside the clock, by chordvis_debug_fill_cull_exchange -- the view is static); CULL=replicated measures the
 round-4 form (every rank tests every group).
 
-  python tools/shard_time.py [workload]      RANKS=1,2,4,8  MAP=both  PIPELINED=1  COLLECTIVES_MS=0.3  CULL=sharded|replicated
+WHICH FRAMES: a rank's ms/frame is the wall time of n frames rendered WITHOUT event stamps (chordvis_enable_timers(0)) between two
+stream syncs -- product frames.  The phase breakdown printed behind it (cull / setup / tile ...) comes from a SEPARATE pass of stamped
+frames right after (every frame stamped: each of its ~20 event records is a barrier packet that keeps the next kernel from being
+dispatched under the one in front, a sub-millisecond frame grows by 50-90 us -- round 5 timed those frames and reported them as the
+rank's time); `stamped` is that pass's own ms/frame, for the difference.
+
+  python tools/shard_time.py [workload]      RANKS=1,2,4,8  MAP=both  PIPELINED=1  COLLECTIVES_MS=0.3  CULL=sharded|replicated  FRAMES=20
 """
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -58,7 +64,7 @@ def frame(ranks):
 for ranks, sharded_cull in [(int(x), m) for x in os.environ.get("RANKS", "1,2,4,8").split(",") for m in (cull_modes if int(x) > 1 else cull_modes[:1])]:
     loads = None
     for which in (maps if ranks > 1 else ["-"]):
-        per_rank, stamps0, owners, detail = [], None, None, []
+        per_rank, per_rank_stamped, stamps0, owners, detail = [], [], None, None, []
         if which == "balanced":
             owners = tile_layout(cam.width, cam.height, ranks, loads, int(L.lib.chordvis_tile_slot_capacity(cam.width, cam.height, ranks)))
         acc = None
@@ -71,16 +77,24 @@ for ranks, sharded_cull in [(int(x), m) for x in os.environ.get("RANKS", "1,2,4,
             r.update_objects(objs); r.set_view(view, iv, flags)
             if ranks > 1 and ranks <= 8 and sharded_cull:
                 r.debug_fill_cull_exchange()
-            r.enable_timers(2)
-            for _ in range(3):
+            n = int(os.environ.get("FRAMES", "20"))
+            r.enable_timers(0)                              # the clocked frames carry no event record
+            for _ in range(4):
                 frame(ranks)
             r.sync()
-            n = 10
             t0 = time.perf_counter()
             for _ in range(n):
                 frame(ranks)
             r.sync()
             per_rank.append((time.perf_counter() - t0) / n * 1e3)
+            r.enable_timers(2)                              # a separate pass, every frame stamped: the phase breakdown only
+            frame(ranks)
+            r.sync(); r.stats()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                frame(ranks)
+            r.sync()
+            per_rank_stamped.append((time.perf_counter() - t0) / n * 1e3)
             st = r.stats()
             assert st["overflow"] == 0, "work lists overflowed"
             if rk == 0:
@@ -106,9 +120,9 @@ for ranks, sharded_cull in [(int(x), m) for x in os.environ.get("RANKS", "1,2,4,
                 per.max() / max(per.mean(), 1.0), np.bincount(own, minlength=ranks).min(), np.bincount(own, minlength=ranks).max(), " ".join(detail))
         if only_balanced and which == "default":
             continue
-        print("ranks %d (map %s): worst rank %.3f ms/frame, mean %.3f, max/mean %.3f%s%s; per rank %s;  rank-0 GPU stamps (ms): cull %.3f (%s) stage0 %.3f hzb0 %.3f stage1 %.3f hzbFinal %.3f | setup %.3f clip+order %.3f tile %.3f"
-              % (ranks, which, worst, mean, worst / mean,
+        print("ranks %d (map %s): worst rank %.3f ms/frame unstamped (%d frames; the stamped pass: worst %.3f), mean %.3f, max/mean %.3f%s%s; per rank %s;  rank-0 GPU stamps of the stamped pass (ms, each interval incl. its record's cost): cull %.3f (%s) stage0 %.3f hzb0 %.3f stage1 %.3f hzbFinal %.3f | setup %.3f clip+order %.3f tile %.3f; launches per frame %d"
+              % (ranks, which, worst, n, max(per_rank_stamped), mean, worst / mean,
                  ("; speed-up with %.2f ms of collectives: %.2fx" % (coll, single / (worst + coll))) if single and ranks > 1 else "", extra,
                  " ".join("%.3f" % v for v in per_rank), st["msInstanceCulling"], "sharded" if (sharded_cull and 1 < ranks <= 8) else "replicated", st["msStage0"], st["msHzbStage0"], st["msStage1"], st["msHzbFinal"],
-                 st["msRasterCluster"], st["msRasterClip"], st["msRasterChunk"]), flush=True)
+                 st["msRasterCluster"], st["msRasterClip"], st["msRasterChunk"], st["kernelLaunches"]), flush=True)
 r.close()
