@@ -773,7 +773,22 @@ def moving_path(args, r, scene, cam_a, flags, dev):
         frame(i)
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
-    return {"views": n, "steps": loops * n, "ms_per_step": round(el / (loops * n) * 1e3, 4), "value": round(tris * loops / el / 1e9, 4), "unit": "Gtri/s",
+    # ... and the same loops with a tile schedule made in every frame (chordvis_set_tile_schedule_keep(0)): what keeping the schedule
+    # is worth -- or costs -- where every frame is another view and two of them follow a cut
+    keep = r.tile_schedule_keep()
+    fresh = None
+    if keep:
+        r.set_tile_schedule_keep(0)
+        for i in range(n):
+            frame(i)
+        torch.cuda.synchronize(dev)
+        f0 = time.perf_counter()
+        for i in range(loops * n):
+            frame(i)
+        torch.cuda.synchronize(dev)
+        fresh = round((time.perf_counter() - f0) / (loops * n) * 1e3, 4)
+        r.set_tile_schedule_keep(keep)
+    return {"views": n, "steps": loops * n, "fresh_schedule_ms_per_step": fresh, "ms_per_step": round(el / (loops * n) * 1e3, 4), "value": round(tris * loops / el / 1e9, 4), "unit": "Gtri/s",
             "triangles_submitted_per_step": tris / float(n), "overflow": int(over),
             "path": "%d x 0.5 m down the street, cut to %.0f m ahead looking back, %d x 0.5 m, cut to the start" % (n // 2, PATH_CUT_AHEAD_M, n - n // 2),
             "tile_schedule_keep_frames": r.tile_schedule_keep()}

@@ -109,6 +109,8 @@ struct RasterParams {
     uint32_t tileSlots;                                 // tile workgroups the device holds at once (2 per CU); a pass with fewer non-empty tiles than that cuts its bins finer (tile_order_part), 0: never
     uint32_t tileSplitMin, tileSliceLen;                // bins longer than tileSplitMin entries are cut into slices of tileSliceLen (TILE_SPLIT_MIN, TILE_SLICE)
     uint32_t orderKept;                                 // 1: tileOrder is the schedule of an EARLIER frame's first pass (launch_raster: TILE_ORDER_KEEP) -- the items and their order are taken from it, a tile's bin length and flags from the counter line of this pass
+                                                        // 2: no schedule at all (later passes of a frame: launch_raster TILE_DIRECT) -- work item i is tile i, whole; a tile without entries is left alone
+    uint32_t* heavyHint;                                // host-visible word: this pass's serial (binStamp), stored by whoever meets a bin beyond tileSplitMin entries (launch_raster: such passes get their schedule back), or NULL
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
 // The per-phase clocks of the setup kernels (debug bit 512) and of the tile kernel (bit 16) exist only in a build with
@@ -1762,6 +1764,9 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 #ifndef TILE_ORDER_KEEP
 #define TILE_ORDER_KEEP 1          // 0: the schedule kernel runs in every pass whatever chordvis_set_tile_schedule_keep says (A/B builds)
 #endif
+#ifndef TILE_DIRECT
+#define TILE_DIRECT 1              // 0: later passes of a frame keep their schedule kernel (A/B builds)
+#endif
 #ifndef TILE_SLICE_MIN
 #define TILE_SLICE_MIN 1024u       // the shortest slice of a pass that has fewer tiles than the device has slots
 #endif
@@ -1837,6 +1842,7 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
         for (int b = 0; b < 18; b++) { base[b] = acc; acc += hist[b]; }
         p.tileOrder[0] = make_uint2(p.clearTiles ? acc : acc - hist[17], 0u);
         if (p.binHint) *p.binHint = longest;                      // (bins short enough to stay whole report 0)
+        if (p.heavyHint && splitItems != 0u) *p.heavyHint = p.binStamp;   // (a pass with cut bins keeps its schedule: launch_raster TILE_DIRECT)
         if (p.countHint) *p.countHint = *p.count;
         if (p.hotTiles) p.hotTiles[0] = min(hotCount, (uint32_t)CHORD_HOT_TILES);
     }
@@ -2687,14 +2693,17 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     if (ABL(p, DBG_TILE_EXIT) && !p.clearTiles) return;
     // (the item count and the block's first item are fetched together: one round trip, not two dependent ones; the
     // list has an entry for every tile, so slot 1 + blockIdx.x exists whether or not it is active)
-    uint2 firstItem = p.tileOrder[1u + min(blockIdx.x, p.tilesX * p.tilesY - 1u)];
-    const uint32_t active = p.tileOrder[0].x;
+    // (direct passes -- orderKept 2 -- have no list: item i is tile i, and the first thing a workgroup asks memory for is its tile's counter line)
+    const bool direct = p.orderKept == 2u;
+    uint2 firstItem = make_uint2(blockIdx.x, 0u);
+    uint32_t active = p.tilesX * p.tilesY;
+    if (!direct) { firstItem = p.tileOrder[1u + min(blockIdx.x, p.tilesX * p.tilesY - 1u)]; active = p.tileOrder[0].x; }
     for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
     // (the thread index of this work item goes through an empty asm: whatever the body derives from it is invariant over the
     // item loop, and hoisted out of it those values -- offsets, masks, lane roles -- sat in registers across the whole kernel)
     uint32_t tix = threadIdx.x;
     asm volatile("" : "+v"(tix));
-    const uint2 itemCount = oi == blockIdx.x ? firstItem : p.tileOrder[1u + oi];
+    const uint2 itemCount = oi == blockIdx.x ? firstItem : (direct ? make_uint2(oi, 0u) : p.tileOrder[1u + oi]);
     const uint32_t item = itemCount.x;
     const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
     // (kept order: the tile's counter line is read here, and -- the address needs the tile only -- a whole tile's first bin entries
@@ -2708,6 +2717,14 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         countWord = min(cnt.x, bin_capacity(p)) | (cnt.y ? 0x80000000u : 0u);
     }
     const uint32_t nAll = countWord & 0x3FFFFFFFu;                // (already clamped to the bin capacity)
+    if (direct) {
+        // a later pass of the frame touches a fraction of the tiles (config 3: 436 of 2 040): the others' workgroups end here, one round
+        // trip after their start, and the touched ones have saved the trip to a work list -- what raster_tile_order_kernel cost the
+        // pass was its place in the chain of dependent launches.  No slices, no order: a bin long enough to want them says so to the
+        // host, and the pass gets its schedule back from the next frame on (a choice of speed: this workgroup does the whole bin).
+        if (nAll == 0u) continue;
+        if (nAll > p.tileSplitMin && p.heavyHint && tix == 0u) *p.heavyHint = p.binStamp;
+    }
     const bool hasBlocks = (countWord >> 31) != 0u;               // (the order kernel saw pixel blocks in the tile's bin)
     const bool preloaded = !CHORD_MASKED_FUSED && p.clearTiles && (countWord & 0x40000000u) != 0u;   // the masked pass wrote this tile (first pass of a frame)
     const int32_t tinyArea = nAll >= TINY_DENSE_MIN ? TINY_AREA_DENSE : TINY_AREA;
@@ -3360,7 +3377,21 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // counter line (RasterParams::orderKept) -- one launch less in most frames.  The image does not depend on order or cut.  (The
     // hints the schedule kernel leaves for the next frame -- longest bin, cluster count, hot tiles -- age with it.)
     p.orderKept = 0u;
+    p.heavyHint = nullptr;
     bool makeOrder = true;
+    // Later passes of a frame (the read-modify-write passes behind the first: config 3's second pass touches 436 of its 2 040 tiles with
+    // 60 entries each) run WITHOUT a schedule: one workgroup per tile of the target, tile = workgroup index, a tile whose counter line
+    // says "no entries" ends after that one load.  What such a pass has no use for -- heaviest-first order, bins cut into slices -- is
+    // what the schedule kernel was there for; when a bin does grow long (a camera cut: the scene arrives in the second pass) the tile
+    // kernel or the schedule kernel leaves the pass's serial in a host-visible word and the pass is scheduled again until four frames
+    // have gone by without one (-DTILE_DIRECT=0 compiles the path out; CHORDVIS_TILE_DIRECT=0 turns it off at run time: A/B runs).
+    static const bool directOn = [] { const char* e = getenv("CHORDVIS_TILE_DIRECT"); return !e || atoi(e) != 0; }();
+    if (TILE_DIRECT && directOn && c->inFrame && !clearTiles && p.hzbFused && !c->depthOnly && CHORD_MASKED_FUSED && c->dBinHint && !(c->debugFlags & ~(DBG_NO_BLOCKS | DBG_FORCE_BLOCKS | DBG_FORCE_HOT | 524288u))) {
+        p.heavyHint = c->dBinHint + 4 + pass;
+        const uint32_t seen = c->hBinHint[4 + pass];
+        const bool heavy = seen != 0u && p.binStamp - seen <= 8u;       // (two raster passes per frame draw a serial each)
+        if (!heavy) { p.orderKept = 2u; makeOrder = false; }
+    }
     if (TILE_ORDER_KEEP && c->orderKeepFrames && CHORD_MASKED_FUSED && c->inFrame && clearTiles && !sh && !c->depthOnly && pass == 0u && c->dTileOrderKeep && !c->debugFlags) {
         p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrderKeep);
         if (c->orderAge < c->orderKeepFrames) { c->orderAge++; p.orderKept = 1u; makeOrder = false; }
@@ -3385,7 +3416,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // per block balances better than any static split)
     // (sharded frames: the work items are the rank's own tiles)
     // (a rank's slices: its bins are cut into about tileSlots shares when it owns fewer tiles than that; blocks beyond the item count leave at once)
-    const uint32_t tileBlocks = clearTiles ? (sh ? min(tiles, max(c->shard.slotsPerRank, p.tileSlots + p.tileSlots / 2u)) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
+    const uint32_t tileBlocks = (clearTiles || p.orderKept == 2u) ? ((sh && clearTiles) ? min(tiles, max(c->shard.slotsPerRank, p.tileSlots + p.tileSlots / 2u)) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
     // (the tile kernel's instantiations are the opaque ones: alpha-tested triangles were scan-converted by the masked pass above)
 #if CHORD_MASKED_FUSED
     if (c->anyMasked) {

@@ -7,7 +7,9 @@
 #   micro:NAME[,NAME]   tools/microbench/NAME.hip built and run
 #   trace[:WORKLOAD]    tools/trace.sh (product frames, no stamps) + tools/timeline.py
 #   bench:ARGS          bench.py ARGS (spaces as '+'), compact line;  bench20 / bench200: the default workload in the driver's / the long form
-#   ab:TAGS:WORKLOADS[:STEPS[:REPS]]   product library and the variant libraries TAGS (chord_amd/build.py --tag) on WORKLOADS, interleaved
+#   ab:TAGS:WORKLOADS[:STEPS[:REPS]]   product library and the variant libraries TAGS (chord_amd/build.py --tag; a TAG of the form NAME=VALUE is an
+#                       environment switch of the product library instead) on WORKLOADS, interleaved
+#   rank:WORKLOAD:RANKS:RANK[:ENV+ENV]   kernel trace of ONE rank of a sharded frame (tools/shard_rank.py, no stamps) + tools/timeline.py
 #   shard:WORKLOAD[:ENV+ENV]   tools/shard_time.py WORKLOAD with ENV (e.g. RANKS=1,8+PIPELINED=1)
 #   pmc:NAME:COUNTERS[:ARGS]   one counter pass of bench.py (tools/pmc.sh), COUNTERS space as '+'
 #   profile:NAME[:ARGS] kernel stats + FETCH_SIZE + WRITE_SIZE passes (tools/profile.sh)
@@ -40,9 +42,15 @@ for step in "$@"; do
     bench200) python bench.py > $OUT/bench_default.json 2> $OUT/bench200.err; cat $OUT/bench_default.json | line "default, 200 steps";;
     ab)
       for rep in $(seq 1 ${a4:-2}); do for tag in product ${a1//,/ }; do for wl in ${a2//,/ }; do
-        lib=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis.so; [ $tag != product ] && lib=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis_$tag.so
-        CHORDVIS_LIB=$lib python bench.py --workload $wl --steps ${a3:-200} --cpu-baseline-frames 0 --no-path 2>/dev/null | tee $OUT/ab_${tag}_${wl}_$rep.json | line "[$tag] $wl rep $rep"
+        lib=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis.so; ev=_CALL_NOENV=1
+        case "$tag" in product) ;; *=*) ev=$tag;; *) lib=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis_$tag.so;; esac     # (TAG with '=': an environment switch of the product library)
+        env $ev CHORDVIS_LIB=$lib python bench.py --workload $wl --steps ${a3:-200} --cpu-baseline-frames 0 --no-path 2>/dev/null | tee $OUT/ab_${tag}_${wl}_$rep.json | line "[$tag] $wl rep $rep"
       done; done; done;;
+    rank)
+      ( cd /tmp && export TMPDIR=/tmp && env FRAMES=40 ${a4//+/ } rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/rank_$a1 -o r -- python $GRAFT_REPO_ROOT/tools/shard_rank.py $a1 $a2 $a3 > $GRAFT_REPO_ROOT/$OUT/rank_$a1.log 2>&1 )
+      echo "frames: tools/shard_rank.py $a1 $a2 $a3 (rank $a3 of $a2, collectives skipped, no stamps) ${a4:-}" > $OUT/rank_timeline_$a1.txt
+      python tools/timeline.py $OUT/rank_$a1/r_kernel_trace.csv >> $OUT/rank_timeline_$a1.txt 2>&1; tail -3 $OUT/rank_$a1.log; cat $OUT/rank_timeline_$a1.txt | tail -32
+      find $OUT/rank_$a1 -name "r_kernel_trace.csv" -size +20M -delete;;
     shard)   env ${a2//+/ } python tools/shard_time.py $a1 2>&1 | grep "^ranks" | tee -a $OUT/shard_time_$a1.txt;;
     pmc)     bash tools/pmc.sh $TAG/pmc_$a1 "${a2//+/ }" ${a3//+/ } 2>&1 | tee $OUT/pmc_$a1.txt | grep "raster_tile\|raster_setup\|hzb_cull\|group_cull" ;;
     profile) bash tools/profile.sh $TAG/prof_$a1 ${a2//+/ } > /dev/null 2>&1; ls $OUT/prof_$a1;;

@@ -16,12 +16,13 @@
 #define REP32(X) REP8(X) REP8(X) REP8(X) REP8(X)
 #define REP256(X) REP32(X) REP32(X) REP32(X) REP32(X) REP32(X) REP32(X) REP32(X) REP32(X)
 
-enum { ADD_U32, AND_B32, LSHL_ADD, MUL_F32, FMA_F32, MAD_U24, MUL_LO_U32, CVT_F32_I32, CNDMASK, RCP_F32, MIN_I32, ADD_F32_ALT, NKINDS };
+enum { ADD_U32, AND_B32, LSHL_ADD, MUL_F32, FMA_F32, MAD_U24, MUL_LO_U32, CVT_F32_I32, CNDMASK, RCP_F32, MIN_I32, ADD_F32_ALT, DEP_ADD_U32, DEP_FMA_F32, CMP_CNDMASK, NKINDS };
 static const char* kNames[NKINDS] = {"v_add_u32", "v_and_b32", "v_lshl_add_u32", "v_mul_f32", "v_fma_f32", "v_mad_u32_u24", "v_mul_lo_u32",
-                                     "v_cvt_f32_i32", "v_cndmask_b32", "v_rcp_f32", "v_min_i32", "v_add_f32 / v_add_u32 alternating"};
+                                     "v_cvt_f32_i32", "v_cndmask_b32 (vcc)", "v_rcp_f32", "v_min_i32", "v_add_f32 / v_add_u32 alternating",
+                                     "v_add_u32, ONE dependent chain", "v_fma_f32, ONE dependent chain", "v_cmp_lt_u32 + v_cndmask_b32 pairs"};
 
 template <int KIND>
-__global__ __launch_bounds__(1024, 1) void k_issue(uint32_t loops, unsigned long long* out, uint32_t seed)
+__global__ __launch_bounds__(1024, 2) void k_issue(uint32_t loops, unsigned long long* out, uint32_t seed)
 {
     uint32_t r[8];
 #pragma unroll
@@ -39,7 +40,10 @@ __global__ __launch_bounds__(1024, 1) void k_issue(uint32_t loops, unsigned long
         else if (KIND == MAD_U24) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(r[i]) : "v"(c)); \
         else if (KIND == MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(r[i]) : "v"(c)); \
         else if (KIND == CVT_F32_I32) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(r[i])); \
-        else if (KIND == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(c) : "vcc"); \
+        else if (KIND == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(c)); \
+        else if (KIND == DEP_ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[0]) : "v"(c)); \
+        else if (KIND == DEP_FMA_F32) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(r[0]) : "v"(c)); \
+        else if (KIND == CMP_CNDMASK) { if ((i) & 1) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(c)); else asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(r[i]), "v"(c) : "vcc"); } \
         else if (KIND == RCP_F32) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[i])); \
         else if (KIND == MIN_I32) asm volatile("v_min_i32 %0, %0, %1" : "+v"(r[i]) : "v"(c)); \
         else if (KIND == ADD_F32_ALT) { if ((i) & 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(c)); else asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(c)); }
@@ -60,13 +64,15 @@ template <int KIND>
 static void run(hipStream_t s, unsigned long long* dOut, int cus, double wallHz)
 {
     const uint32_t loops = 400;
-    for (int wavesPerSimd : {1, 2, 4}) {
-        const int threads = 64 * 4 * wavesPerSimd, waves = cus * 4 * wavesPerSimd;
+    for (int wavesPerSimd : {1, 2, 4, 8}) {
+        // (8 waves per SIMD: two 1024-thread blocks per CU -- the dispatcher places one on every CU before it doubles up)
+        const int blocksPerCu = wavesPerSimd == 8 ? 2 : 1;
+        const int threads = 64 * 4 * wavesPerSimd / blocksPerCu, waves = cus * 4 * wavesPerSimd;
         hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-        hipLaunchKernelGGL(k_issue<KIND>, dim3(cus), dim3(threads), 0, s, loops, dOut, 12345u);
+        hipLaunchKernelGGL(k_issue<KIND>, dim3(cus * blocksPerCu), dim3(threads), 0, s, loops, dOut, 12345u);
         (void)hipStreamSynchronize(s);
         (void)hipEventRecord(a, s);
-        hipLaunchKernelGGL(k_issue<KIND>, dim3(cus), dim3(threads), 0, s, loops, dOut, 12345u);
+        hipLaunchKernelGGL(k_issue<KIND>, dim3(cus * blocksPerCu), dim3(threads), 0, s, loops, dOut, 12345u);
         (void)hipEventRecord(b, s); (void)hipEventSynchronize(b);
         float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
         std::vector<unsigned long long> h((size_t)waves * 3);
@@ -88,11 +94,12 @@ int main()
     const int cus = prop.multiProcessorCount;
     std::printf("%s: %d CUs, clockRate %d kHz, wall clock %d kHz\n", prop.name, cus, prop.clockRate, wallKHz);
     hipStream_t s; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    unsigned long long* dOut; (void)hipMalloc(&dOut, (size_t)cus * 16 * 3 * 8);
+    unsigned long long* dOut; (void)hipMalloc(&dOut, (size_t)cus * 32 * 3 * 8);
     const double wallHz = wallKHz > 0 ? wallKHz * 1e3 : 1e8;
     run<ADD_U32>(s, dOut, cus, wallHz); run<AND_B32>(s, dOut, cus, wallHz); run<LSHL_ADD>(s, dOut, cus, wallHz); run<MIN_I32>(s, dOut, cus, wallHz);
     run<MUL_F32>(s, dOut, cus, wallHz); run<FMA_F32>(s, dOut, cus, wallHz); run<ADD_F32_ALT>(s, dOut, cus, wallHz);
     run<MAD_U24>(s, dOut, cus, wallHz); run<CVT_F32_I32>(s, dOut, cus, wallHz); run<CNDMASK>(s, dOut, cus, wallHz);
     run<MUL_LO_U32>(s, dOut, cus, wallHz); run<RCP_F32>(s, dOut, cus, wallHz);
+    run<DEP_ADD_U32>(s, dOut, cus, wallHz); run<DEP_FMA_F32>(s, dOut, cus, wallHz); run<CMP_CNDMASK>(s, dOut, cus, wallHz);
     return 0;
 }
