@@ -128,7 +128,7 @@ int configure_targets(ChordCtx* c, uint64_t* external)
     if (c->dHotTiles) CHORD_HIP(c, hipMemsetAsync(c->dHotTiles, 0, sizeof(uint32_t) * 2 * (1 + CHORD_HOT_TILES), c->stream));   // (tile ids of another target size)
     c->hBinHint[0] = 0u; c->hBinHint[1] = 0u;
     c->hBinHint[2] = 0xFFFFFFFFu; c->hBinHint[3] = 0xFFFFFFFFu;      // clusters per pass of the last finished frame: none yet
-    c->hBinHint[4] = 0u; c->hBinHint[5] = 0u;                        // serial of the last pass that met a bin long enough to want a schedule (launch_raster: TILE_DIRECT): none
+    for (int k = 4; k < 8; k++) c->hBinHint[k] = 0u;                  // serials of the last pass found heavy [4 + pass] / light [6 + pass] (launch_raster: TILE_DIRECT): none
     {   // one {min, max} partial per block of the mip-0 kernel (64 x 4 texels per block)
         const uint32_t vw = (c->width + 1) / 2, vh = (c->height + 1) / 2;
         if ((rc = dalloc(c, &c->dRangePartials, (size_t)((vw + 63) / 64) * ((vh + 3) / 4) * 2))) return rc;

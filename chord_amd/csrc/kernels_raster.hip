@@ -110,7 +110,8 @@ struct RasterParams {
     uint32_t tileSplitMin, tileSliceLen;                // bins longer than tileSplitMin entries are cut into slices of tileSliceLen (TILE_SPLIT_MIN, TILE_SLICE)
     uint32_t orderKept;                                 // 1: tileOrder is the schedule of an EARLIER frame's first pass (launch_raster: TILE_ORDER_KEEP) -- the items and their order are taken from it, a tile's bin length and flags from the counter line of this pass
                                                         // 2: no schedule at all (later passes of a frame: launch_raster TILE_DIRECT) -- work item i is tile i, whole; a tile without entries is left alone
-    uint32_t* heavyHint;                                // host-visible word: this pass's serial (binStamp), stored by whoever meets a bin beyond tileSplitMin entries (launch_raster: such passes get their schedule back), or NULL
+    uint32_t* heavyHint;                                // host-visible words [0] / [2]: this pass's serial (binStamp) stored by whoever finds the pass HEAVY (a bin beyond tileSplitMin entries, more than
+                                                        // TILE_DIRECT_MAX_CLUSTERS clusters) / LIGHT (launch_raster: only a pass that was light a moment ago runs without a schedule), or NULL
     uint32_t debug;                                     // ablation switches (chordvis_set_debug), 0 in production
 };
 // The per-phase clocks of the setup kernels (debug bit 512) and of the tile kernel (bit 16) exist only in a build with
@@ -1767,6 +1768,9 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 #ifndef TILE_DIRECT
 #define TILE_DIRECT 1              // 0: later passes of a frame keep their schedule kernel (A/B builds)
 #endif
+#ifndef TILE_DIRECT_MAX_CLUSTERS
+#define TILE_DIRECT_MAX_CLUSTERS 1024u   // a later pass with more clusters than this keeps its schedule (config 4's second pass, 30 k clusters in every tile of the screen: +15 % per frame without one)
+#endif
 #ifndef TILE_SLICE_MIN
 #define TILE_SLICE_MIN 1024u       // the shortest slice of a pass that has fewer tiles than the device has slots
 #endif
@@ -1842,7 +1846,7 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
         for (int b = 0; b < 18; b++) { base[b] = acc; acc += hist[b]; }
         p.tileOrder[0] = make_uint2(p.clearTiles ? acc : acc - hist[17], 0u);
         if (p.binHint) *p.binHint = longest;                      // (bins short enough to stay whole report 0)
-        if (p.heavyHint && splitItems != 0u) *p.heavyHint = p.binStamp;   // (a pass with cut bins keeps its schedule: launch_raster TILE_DIRECT)
+        if (p.heavyHint) p.heavyHint[(splitItems != 0u || *p.count > TILE_DIRECT_MAX_CLUSTERS) ? 0 : 2] = p.binStamp;   // (launch_raster TILE_DIRECT: heavy / light)
         if (p.countHint) *p.countHint = *p.count;
         if (p.hotTiles) p.hotTiles[0] = min(hotCount, (uint32_t)CHORD_HOT_TILES);
     }
@@ -2722,8 +2726,11 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         // trip after their start, and the touched ones have saved the trip to a work list -- what raster_tile_order_kernel cost the
         // pass was its place in the chain of dependent launches.  No slices, no order: a bin long enough to want them says so to the
         // host, and the pass gets its schedule back from the next frame on (a choice of speed: this workgroup does the whole bin).
+        if (p.heavyHint && tix == 0u) {
+            if (nAll > p.tileSplitMin) p.heavyHint[0] = p.binStamp;
+            if (oi == 0u) p.heavyHint[*p.count > TILE_DIRECT_MAX_CLUSTERS ? 0 : 2] = p.binStamp;     // (the pass's cluster count: one workgroup reports it)
+        }
         if (nAll == 0u) continue;
-        if (nAll > p.tileSplitMin && p.heavyHint && tix == 0u) *p.heavyHint = p.binStamp;
     }
     const bool hasBlocks = (countWord >> 31) != 0u;               // (the order kernel saw pixel blocks in the tile's bin)
     const bool preloaded = !CHORD_MASKED_FUSED && p.clearTiles && (countWord & 0x40000000u) != 0u;   // the masked pass wrote this tile (first pass of a frame)
@@ -3379,18 +3386,23 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.orderKept = 0u;
     p.heavyHint = nullptr;
     bool makeOrder = true;
-    // Later passes of a frame (the read-modify-write passes behind the first: config 3's second pass touches 436 of its 2 040 tiles with
-    // 60 entries each) run WITHOUT a schedule: one workgroup per tile of the target, tile = workgroup index, a tile whose counter line
-    // says "no entries" ends after that one load.  What such a pass has no use for -- heaviest-first order, bins cut into slices -- is
-    // what the schedule kernel was there for; when a bin does grow long (a camera cut: the scene arrives in the second pass) the tile
-    // kernel or the schedule kernel leaves the pass's serial in a host-visible word and the pass is scheduled again until four frames
-    // have gone by without one (-DTILE_DIRECT=0 compiles the path out; CHORDVIS_TILE_DIRECT=0 turns it off at run time: A/B runs).
+    // LIGHT later passes of a frame (the read-modify-write passes behind the first: config 3's second pass is 205 clusters, 436 of its
+    // 2 040 tiles touched with 60 entries each) run WITHOUT a schedule: one workgroup per tile of the target, tile = workgroup index, a
+    // tile whose counter line says "no entries" ends after that one load.  What such a pass has no use for -- heaviest-first order,
+    // bins cut into slices -- is what the schedule kernel was there for (config 3 0.1792 -> 0.1759 ms, a 1080p frame 0.112 -> 0.109).
+    // A pass with work in every tile needs them (config 4's second pass: 57 -> 115 us of tile kernel without), so the pass says what
+    // it is in two host-visible words -- its serial under "heavy" when a bin is longer than tileSplitMin or it set up more than
+    // TILE_DIRECT_MAX_CLUSTERS clusters, under "light" otherwise; written by the schedule kernel, or by the tile kernel of a direct
+    // pass -- and runs direct while the latest report the host has seen says light.  A camera cut that sends the scene
+    // through the second pass costs that frame balance, never a pixel (-DTILE_DIRECT=0 compiles the path out; CHORDVIS_TILE_DIRECT=0
+    // turns it off at run time: A/B runs).
     static const bool directOn = [] { const char* e = getenv("CHORDVIS_TILE_DIRECT"); return !e || atoi(e) != 0; }();
     if (TILE_DIRECT && directOn && c->inFrame && !clearTiles && p.hzbFused && !c->depthOnly && CHORD_MASKED_FUSED && c->dBinHint && !(c->debugFlags & ~(DBG_NO_BLOCKS | DBG_FORCE_BLOCKS | DBG_FORCE_HOT | 524288u))) {
         p.heavyHint = c->dBinHint + 4 + pass;
-        const uint32_t seen = c->hBinHint[4 + pass];
-        const bool heavy = seen != 0u && p.binStamp - seen <= 8u;       // (two raster passes per frame draw a serial each)
-        if (!heavy) { p.orderKept = 2u; makeOrder = false; }
+        const uint32_t heavySeen = c->hBinHint[4 + pass], lightSeen = c->hBinHint[6 + pass];
+        // (the host runs frames ahead of the device -- a bench loop enqueues hundreds: what it reads is the state of a pass long past,
+        // so the rule is "the latest report says light", not "a report of the last few frames"; a pass that reports both is heavy)
+        if (lightSeen != 0u && (heavySeen == 0u || (int32_t)(lightSeen - heavySeen) > 0)) { p.orderKept = 2u; makeOrder = false; }
     }
     if (TILE_ORDER_KEEP && c->orderKeepFrames && CHORD_MASKED_FUSED && c->inFrame && clearTiles && !sh && !c->depthOnly && pass == 0u && c->dTileOrderKeep && !c->debugFlags) {
         p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrderKeep);
