@@ -291,6 +291,7 @@ int install_tile_owners(ChordCtx* c)
     CHORD_HIP(c, hipMalloc((void**)&c->dTileOwner, tiles));
     CHORD_HIP(c, hipMemcpy(c->dTileOwner, c->tileOwners.data(), tiles, hipMemcpyHostToDevice));
     c->mineValid = false; c->listMine[1] = c->listMine[2] = false;       // (lists culled for another ownership)
+    c->orderAge = 0xFFFFFFFFu;                                            // (a kept tile schedule lists the OLD map's tiles)
     return CHORDVIS_OK;
 }
 
@@ -411,6 +412,7 @@ int chordvis_destroy(ChordCtx* c)
     dfree(c->dView); dfree(c->dObjFrame); dfree(c->dGroupMask); dfree(c->dBlockCounts);
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
     dfree(c->dRankCmds); dfree(c->dLeftCmds); dfree(c->dMineCmds);
+    dfree(c->dCullLookback);
     dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dHotTiles); dfree(c->dTileOrder); dfree(c->dTileOrderKeep); c->orderAge = 0xFFFFFFFFu; dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
@@ -1026,9 +1028,14 @@ int chordvis_hzb_culling(ChordCtx* c, const ChordHZB* hzb, int bFirstStage, Chor
     }
     if (bFirstStage) {
         if (inL.cmds == c->lists[1].cmds || inL.cmds == c->lists[2].cmds) return fail(c, CHORDVIS_E_INVALID, "hzb_culling: first stage input must be the instanceCulling list");
+        if (c->fusedCullDone && inL.cmds == c->lists[0].cmds && hzb->minTexels == c->hzb[c->historySlot].minTexels) {
+            // (chordvis_render_frame on a short scene: frame_cull_fused_kernel tested every command it emitted against this chain)
+            c->fusedCullDone = false;
+        } else {
         if (!c->inFrame) CHORD_HIP(c, hipMemsetAsync(c->dCounts + 1, 0, 8, c->stream));
         c->listMine[1] = c->listMine[2] = inMine;
         launch_hzb_cull(c, hb, 0, inL, c->lists[1], &c->lists[2]);
+        }
         if (outVisible) *outVisible = c->lists[1].handle();
         if (outRejected) *outRejected = c->lists[2].handle();
     } else {
@@ -1122,7 +1129,14 @@ static int render_frame_impl(ChordCtx* c)
     if (haveHist) hist = c->hzb[c->historySlot].handle();
     const int next = c->historySlot == 1 ? 2 : 1;
     ChordCountAndCmd post;
-    if ((rc = chordvis_instance_culling(c, &post))) return rc;                        // :321 (its first kernel also carries the previous frame's HZB tail)
+    // (short scenes: instanceCulling and the phase-0 occlusion cull of stage 0 are one kernel -- launch_group_cull is told what stage 0
+    // will cull against, and chordvis_hzb_culling finds its lists made)
+    c->fuseCullFrame = true;
+    c->fuseCullHzb = (haveHist && (c->hView.flags & CHORD_FLAG_HZB_CULL)) ? &c->hzb[c->historySlot] : nullptr;
+    c->fusedCullDone = false;
+    rc = chordvis_instance_culling(c, &post);                                         // :321 (its first kernel also carries the previous frame's HZB tail)
+    c->fuseCullFrame = false; c->fuseCullHzb = nullptr;
+    if (rc) return rc;
     record(c, S_CULL);
     // buildHZB is fused into the raster: the tile kernel reduces every finished 64x64 tile to mips 0..5 of the
     // chain kept as history (and of the temporary chain stage 1 culls against); only the one-block tail remains.
@@ -1132,6 +1146,7 @@ static int render_frame_impl(ChordCtx* c)
     ChordCountAndCmd rejected;
     int stage1 = 0;
     rc = chordvis_visibility_stage0(c, haveHist ? &hist : nullptr, post, &rejected, &stage1);   // :326
+    c->fusedCullDone = false;
     record(c, S_STAGE0_END);
     c->shouldStage1 = stage1 != 0;
     if (!rc && stage1) {

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstddef>
 
 #include <string>
 #include <vector>
@@ -216,6 +217,7 @@ struct DeviceCounters {
     uint32_t binPoolCount[2];                   // per raster pass: overflow chunks handed out
     uint32_t pad;
     uint32_t blockGranules[CHORD_LIST_SHARDS * CHORD_SHARD_STRIDE];   // 16-byte granules of the block pool handed out this frame, per shard
+    uint32_t pad3[10];                          // (the four totals below + FrameState::listCounts are ONE 64-byte line: frame_cull_fused_kernel's last workgroup writes it whole)
     // triangles (meshlet triangle counts) of the commands each list producer emitted this frame
     unsigned long long trisInstanceCulled, trisHzbVisible0, trisHzbVisible1, pad2;
 };
@@ -250,6 +252,9 @@ struct FrameState {
     uint32_t listCounts[8];        // [0..3] command lists of the frame, [4] this rank's share of list 0 (sharded: written by the group cull), [5] this rank's clusters of a foreign list (stripe filter), [6 + pass] clusters a dense launch's block kernel left over
     uint32_t tileCount[2 * CHORD_MAX_TILES * CHORD_TILECOUNT_STRIDE];   // pass p starts at p * tiles * stride
 };
+
+static_assert(offsetof(FrameState, counters.trisInstanceCulled) % 64 == 0 && offsetof(FrameState, listCounts) == offsetof(FrameState, counters.trisInstanceCulled) + 32 &&
+              offsetof(FrameState, tileCount) == offsetof(FrameState, listCounts) + 32, "triangle totals + list counts: one 64-byte line (frame_cull_fused_kernel)");
 
 struct CmdList {
     uint32_t*     count = nullptr;
@@ -450,6 +455,12 @@ struct ChordCtx {
     bool shouldStage1 = false;
     chord::CmdList lastRejected;
     bool hzbTailInCull = false;        // render_frame: the phase-1 HZB cull reduces levels 6.. of the chain itself (no hzb_tail_kernel before it)
+    // short scenes on one GPU: instanceCulling and the phase-0 occlusion cull in one kernel (kernels_cull.hip frame_cull_fused_kernel)
+    bool fuseCullFrame = false;        // render_frame -> launch_group_cull: this instanceCulling opens a frame of chordvis_render_frame (the fused kernel may run)
+    const chord::HzbBuffers* fuseCullHzb = nullptr;   // ... and the history chain the frame's phase-0 cull will test against (NULL: no history / occlusion culling off)
+    bool fusedCullDone = false;        // launch_group_cull took the fused path WITH the phase-0 cull: chordvis_hzb_culling(first stage) of this frame launches nothing
+    uint32_t cullSerial = 0;           // launch serial of the fused kernel's look-back words
+    unsigned long long* dCullLookback = nullptr;   // [numCUs][2]
     uint32_t debugFlags = 0;           // ablation switches for measurements (chordvis_set_debug)
     unsigned long long* dTileClocks = nullptr;   // [2][CHORD_MAX_TILES] per-tile ticks when debug bit 4 is set
 };

@@ -297,6 +297,9 @@ __global__ __launch_bounds__(256) void object_cull_kernel(const ChordObject* __r
 #ifndef CULL_QUAD
 #define CULL_QUAD 1
 #endif
+#ifndef CULL_FUSED
+#define CULL_FUSED 1               // 0: short scenes keep the three launches count / scatter / phase-0 cull (A/B builds)
+#endif
 template <bool FROM_MASK, bool SHARDED, bool FUSED, bool QUAD = false>
 __global__ __launch_bounds__(QUAD ? 1024 : 256) void group_cull_count_kernel(GroupCullParams p, const DView dv, DView* __restrict__ dviewOut,
                                                                DObjFrame* __restrict__ objFrameOut, uint4* __restrict__ zeroBase, uint32_t zeroVec4,
@@ -422,11 +425,17 @@ struct CullMaskParams {
     uint32_t* out;                                  // the chunk the range belongs to
 };
 
-__global__ __launch_bounds__(256) void group_cull_masks_kernel(CullMaskParams q, const DView dv)
+// QUAD: a rank's share of a mid-sized scene is a short list (config 4 at 8 ranks: 98 k group instances, 385 blocks on a chip that holds
+// 1 024 of them at once), and a short list's time is one thread's chain of dependent instructions -- four meshlets tested one after the
+// other.  As in the short-scene count kernel, four lanes share a group instance: every lane does the group's test, lane i the cone /
+// frustum test and the rank mask of meshlet i, the bytes meet by DPP.  The exchanged words are the same.
+template <bool QUAD>
+__global__ __launch_bounds__(QUAD ? 1024 : 256) void group_cull_masks_kernel(CullMaskParams q, const DView dv)
 {
     const GroupCullParams& p = q.g;
     const uint32_t lb = blockIdx.x;                               // block within the chunk
-    const uint32_t t = (q.firstBlock + lb) * 256u + threadIdx.x;
+    const uint32_t qi = QUAD ? threadIdx.x & 3u : 0u, gt = QUAD ? threadIdx.x >> 2 : threadIdx.x;
+    const uint32_t t = (q.firstBlock + lb) * 256u + gt;
     uint32_t word = 0, tris = 0;
     if (lb < q.blockCount && t < p.groupInstances) {
         const DGroupRef ref = p.groupRefs[t];
@@ -438,6 +447,13 @@ __global__ __launch_bounds__(256) void group_cull_masks_kernel(CullMaskParams q,
             const uint32_t cnt = ref.group >> 28;
             if (cnt != 0u && group_visible(dv.view.lodScale, of.localToView, of.maxScale, g)) {     // instance_culling.hlsl:174
                 const Mat4 M = load_mat(p.objects[o].basicData.localToTranslatedWorld);
+                if (QUAD) {
+                    const DMeshlet m = p.meshlets[qi == 0u ? ref.meshlet[0] : qi == 1u ? ref.meshlet[1] : qi == 2u ? ref.meshlet[2] : ref.meshlet[3]];
+                    if (qi < cnt && meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, M, (matFlags & CHORD_MATFLAG_TWO_SIDED) != 0, m)) {
+                        tris = (m.vertexTriangleCount >> 8) & 0xFFu;
+                        word = cluster_rank_mask(q.tileOwner, q.tilesX, q.ranks, t % q.ranks, of.mvp, m, p.W, p.H, p.Wi, p.Hi) << (8u * qi);
+                    }
+                } else
 #pragma unroll
                 for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
                     const DMeshlet m = p.meshlets[ref.meshlet[i]];                              // :178-180
@@ -449,10 +465,21 @@ __global__ __launch_bounds__(256) void group_cull_masks_kernel(CullMaskParams q,
             }
         }
     }
-    q.out[lb * 256u + threadIdx.x] = word;                        // (blocks beyond the range: zeros -- defined bytes on the wire)
-    uint32_t blockTris;
-    (void)block_excl_scan(tris, &blockTris);
-    if (threadIdx.x == 0) q.out[q.chunkBlocks * 256u + lb] = blockTris;
+    if (QUAD) {
+        // (all lanes active: whole quads leave the tests together or hold zeros)
+        word |= quad_xor1(word); word |= quad_xor2(word);
+        tris += quad_xor1(tris); tris += quad_xor2(tris);
+        if (qi != 0u) tris = 0u;
+        else q.out[lb * 256u + gt] = word;                        // (blocks beyond the range: zeros -- defined bytes on the wire)
+        uint32_t none, blockTris;
+        block_totals2<1024u>(0u, tris, &none, &blockTris);
+        if (threadIdx.x == 0) q.out[q.chunkBlocks * 256u + lb] = blockTris;
+    } else {
+        q.out[lb * 256u + threadIdx.x] = word;                    // (blocks beyond the range: zeros -- defined bytes on the wire)
+        uint32_t blockTris;
+        (void)block_excl_scan(tris, &blockTris);
+        if (threadIdx.x == 0) q.out[q.chunkBlocks * 256u + lb] = blockTris;
+    }
 }
 
 // The exchanged words -> what group_cull_count_kernel<., true, .> leaves behind: groupMask (low nibble visible, high nibble this rank's)
@@ -715,17 +742,16 @@ __device__ __forceinline__ float oct_max(float v)
 // on the whole chip, each thread a chain of ~700 dependent instructions -- eight projections with three IEEE divisions each.)  The
 // folds are min / max over the same values as the one-thread form's loops: the same result whatever the order (the sign of a zero,
 // which the order could change, decides nothing below).
+// (hzb_meshlet_visible: the test itself, for a caller that holds the meshlet record and the object's frame record already --
+// frame_cull_fused_kernel; hzb_cmd_visible below: from a draw command)
 template <int PHASE, bool TAIL = false, bool OCT = false>
-__device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DView& dv, const ChordDrawCmd& cmd, uint32_t& tris,
-                                                const float* sTail = nullptr, const uint32_t* sTailOff = nullptr, const uint32_t sub = 0u)
+__device__ __forceinline__ bool hzb_meshlet_visible(const HzbCullParams& p, const DView& dv, const DObjFrame& of, const DMeshlet& m,
+                                                    const float* sTail = nullptr, const uint32_t* sTailOff = nullptr, const uint32_t sub = 0u)
 {
     bool visible = true;
     {
         {
-            const DMeshlet& m = p.meshlets[cmd.meshletId];
-            tris = (m.vertexTriangleCount >> 8) & 0xFFu;
             if (dv.flags & CHORD_FLAG_HZB_CULL) {
-                const DObjFrame& of = p.objFrame[cmd.objectId];
                 f3 c, e;
                 aabb_center_extent(m.posMin, m.posMax, c, e);
                 Mat4 mvp;
@@ -811,6 +837,184 @@ __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DV
         }
     }
     return visible;
+}
+
+template <int PHASE, bool TAIL = false, bool OCT = false>
+__device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DView& dv, const ChordDrawCmd& cmd, uint32_t& tris,
+                                                const float* sTail = nullptr, const uint32_t* sTailOff = nullptr, const uint32_t sub = 0u)
+{
+    const DMeshlet& m = p.meshlets[cmd.meshletId];
+    tris = (m.vertexTriangleCount >> 8) & 0xFFu;
+    return hzb_meshlet_visible<PHASE, TAIL, OCT>(p, dv, p.objFrame[cmd.objectId], m, sTail, sTailOff, sub);
+}
+
+// ---- short scenes on one GPU, frames with a history: instanceCulling AND the phase-0 occlusion cull in ONE kernel -----------------
+// (the shapes it replaces: instance_culling.hlsl:47-208 and hzb_mainview_culling.hlsl:35-213 with bFirstStage, three dispatches in the
+// reference, three launches -- count, scatter, phase-0 cull: 12 + 5 + 7 us of config 3's 175-us frame -- here until round 6.)
+// A short scene's group cull is the four-lane form of group_cull_count_kernel: lane i of a quad holds meshlet i of its group instance,
+// i.e. every lane holds at most ONE command -- so the lane can test that command against last frame's HZB right away (its meshlet
+// record and its object's frame record are in registers), and what is left of the other two launches is where the commands go:
+//   * the full list keeps its deterministic order (slot = position: the visibility ids), so a workgroup needs the number of commands
+//     of the workgroups in front of it.  Every workgroup PUBLISHES its counts under the launch's serial in two 64-bit words
+//     (relaxed agent-scope atomic stores: the payload and its "ready" stamp are one word, no fence) and adds up its predecessors'
+//     words -- thread i polls workgroup i --: one round trip of the memory side instead of a launch.  All workgroups of the grid are
+//     resident at once (the host takes this path only for grids of at most one workgroup per CU), so a predecessor always arrives;
+//     the spin is bounded anyway (overflow bit 4).
+//   * the phase-0 lists (visible / rejected) are placed the same way -- their counts ride in the same words --, which also makes
+//     THEIR order deterministic (the three-launch path reserves their space with one atomic per workgroup).
+//   * round 3 wrote this look-back once and dropped it because the same kernel zeroes the frame's counters -- among them the list
+//     counts and triangle totals it would then write itself, in whatever order the workgroups run.  Those words now sit in ONE 64-byte
+//     line of FrameState (triangle totals + list counts) that the bulk zeroing leaves out and the LAST workgroup writes whole, totals
+//     where there are any, zeros elsewhere.
+//   * levels 6.. of the history chain are the "pending tail" that rides on this very kernel's extra workgroup, so they are not in
+//     memory yet: every workgroup reduces them from level 5 into its LDS first (hzb_tail_to_lds: the phase-1 cull does the same with
+//     the temporary chain), while its first loads are in flight.
+struct FusedCullParams {
+    GroupCullParams g;
+    HzbCullParams h;                       // history chain (min), lists 1 / 2 and their counts; inCount / inCmds unused
+    ChordDrawCmd* outCmds; uint32_t* outCount;      // list 0
+    unsigned long long* lookback;          // [cullBlocks][2]
+    uint32_t* tailLine;                    // the 64-byte line the last workgroup writes: {trisInstanceCulled, trisHzbVisible0, trisHzbVisible1, pad2} (u64) + listCounts[8]
+    uint32_t serial, doHzb, skipVec4First, skipVec4Count;
+};
+#define FUSED_CULL_THREADS 1024u
+
+__global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(FusedCullParams q, const DView dv, DView* __restrict__ dviewOut,
+                                                                            DObjFrame* __restrict__ objFrameOut, uint4* __restrict__ zeroBase, uint32_t zeroVec4,
+                                                                            uint32_t cullBlocks, FrameTail tail)
+{
+    constexpr uint32_t BT = FUSED_CULL_THREADS;
+    __shared__ float sTail[HZB_TAIL_FLOATS];
+    __shared__ uint32_t sTailOff[CHORD_HZB_MAX_MIPS];
+    __shared__ uint32_t sWave[BT / 64u];
+    __shared__ unsigned long long sSumA[BT / 64u], sSumB[BT / 64u];
+    const GroupCullParams& p = q.g;
+    const uint32_t qi = threadIdx.x & 3u;
+    const uint32_t t = blockIdx.x * 256u + (threadIdx.x >> 2);
+    const bool tailBlock = tail.run && blockIdx.x == cullBlocks;
+    // what the tests read that does not depend on this frame's object records, requested before everything else (group_cull_count_kernel)
+    DGroupRef refQ; DGroup gQ; Mat4 MQ; DMeshlet mQ; uint32_t matFlagsQ = 0u;
+    refQ.object = 0u; refQ.group = 0u;
+    if (!tailBlock && t < p.groupInstances) {
+        refQ = p.groupRefs[t];
+        gQ = p.groups[refQ.group & 0x0FFFFFFFu];
+        MQ = load_mat(p.objects[refQ.object].basicData.localToTranslatedWorld);
+        matFlagsQ = p.objStatic[refQ.object].matFlags;
+        mQ = p.meshlets[qi == 0u ? refQ.meshlet[0] : qi == 1u ? refQ.meshlet[1] : qi == 2u ? refQ.meshlet[2] : refQ.meshlet[3]];
+    }
+    if (tailBlock) {
+        if (threadIdx.x >= 256u) return;                   // (hzb_tail_block is written for 256 threads; whole waves leave, its barriers count the rest)
+        hzb_tail_block(tail.p, 1, 1, (uint32_t)CHORD_TILE_SHIFT); return;
+    }
+    if (dviewOut && blockIdx.x == 0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&dv);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(dviewOut);
+        for (uint32_t i = threadIdx.x; i < sizeof(DView) / 4u; i += BT) dst[i] = src[i];
+    }
+    // the frame's counters, bin counts, list counts: zero -- but for the line the last workgroup writes below
+    for (uint32_t i = blockIdx.x * BT + threadIdx.x; i < zeroVec4; i += cullBlocks * BT)
+        if (i - q.skipVec4First >= q.skipVec4Count) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (p.groupInstances && objFrameOut) {
+        const uint32_t first = blockIdx.x * 256u;
+        if (first < p.groupInstances) {
+            const uint32_t oFirst = p.groupRefs[first].object, oLast = p.groupRefs[min(first + 255u, p.groupInstances - 1u)].object;
+            for (uint32_t k = threadIdx.x; k <= oLast - oFirst; k += BT) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, oFirst + k);
+        }
+    }
+    // levels 6.. of the history chain into LDS (its barriers also publish the object records of this block to the block)
+    if (q.doHzb) hzb_tail_to_lds(q.h.hzbMin, nullptr, q.h.desc, sTail, sTailOff, BT);
+    __syncthreads();
+
+    // ---- the tests: group (every lane of the quad), this lane's meshlet, and -- for a meshlet that passed -- last frame's HZB ----
+    bool vis = false, hzbVis = false;
+    uint32_t tris = 0;
+    if (t < p.groupInstances) {
+        const DObjFrame& of = p.objFrame[refQ.object];
+        if (of.visible) {
+            const uint32_t cnt = refQ.group >> 28;
+            if (cnt != 0u && group_visible(dv.view.lodScale, of.localToView, of.maxScale, gQ)) {     // instance_culling.hlsl:174
+                if (qi < cnt && meshlet_visible(dv.flags, &dv.iv.frustumPlanesRS[0][0], of, MQ, (matFlagsQ & CHORD_MATFLAG_TWO_SIDED) != 0, mQ)) {
+                    vis = true;
+                    tris = (mQ.vertexTriangleCount >> 8) & 0xFFu;
+                    hzbVis = !q.doHzb || hzb_meshlet_visible<0, true, false>(q.h, dv, of, mQ, sTail, sTailOff);
+                }
+            }
+        }
+    }
+    {   // the group's 4-bit mask (what the three-launch path leaves behind for whoever replays the scatter)
+        uint32_t mask = vis ? 1u << qi : 0u;
+        mask |= quad_xor1(mask); mask |= quad_xor2(mask);
+        if (qi == 0u && t < p.groupInstances) p.groupMask[t] = (uint8_t)mask;
+    }
+    // ---- positions inside the block: thread order = (group instance, meshlet) order = the order of the list ----
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t mine = (vis ? 1u : 0u) | ((vis && hzbVis) ? 1u << 16 : 0u);
+    const uint32_t incl = wave_incl_scan(mine, lane);
+    unsigned long long ta = ((unsigned long long)(vis ? tris : 0u)) | ((unsigned long long)((vis && hzbVis) ? tris : 0u) << 32);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ta += __shfl_down(ta, off, 64);
+    if (lane == 63u) sWave[wave] = incl;
+    if (lane == 0u) sSumB[wave] = ta;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    unsigned long long trisAll = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < BT / 64u; w++) { const uint32_t c = sWave[w]; if (w < wave) before += c; all += c; trisAll += sSumB[w]; }
+    const uint32_t excl = before + incl - mine;
+    const uint32_t n0 = all & 0xFFFFu, n1 = all >> 16;                      // commands of this block / of which visible in phase 0 (<= 1024)
+    const uint32_t t0 = (uint32_t)trisAll, t1 = (uint32_t)(trisAll >> 32); // their triangles (<= 2^17)
+    __syncthreads();                                                       // (sSumB is reused below)
+    // ---- publish, then add up the workgroups in front of this one ----
+    const unsigned long long stampA = (unsigned long long)q.serial << 32, stampB = (unsigned long long)(q.serial & 0xFFFFFFu) << 40;
+    if (threadIdx.x == 0u) {
+        __hip_atomic_store(q.lookback + 2u * blockIdx.x, stampA | n0 | (n1 << 11), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q.lookback + 2u * blockIdx.x + 1u, stampB | ((unsigned long long)t0 << 20) | t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned long long pa = 0, pb = 0;                                     // (n0 | n1 << 32), (t0 | t1 << 32) of workgroup threadIdx.x
+    if (threadIdx.x < blockIdx.x) {
+        unsigned long long a = 0, b = 0;
+        uint32_t spins = 0;
+        for (;;) {
+            a = __hip_atomic_load(q.lookback + 2u * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = __hip_atomic_load(q.lookback + 2u * threadIdx.x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((a & 0xFFFFFFFF00000000ull) == stampA && (b & 0xFFFFFF0000000000ull) == stampB) break;
+            if (++spins > (1u << 22)) { atomicOr(&q.h.counters->overflow, 16u); a = 0; b = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        pa = (a & 0x7FFull) | (((a >> 11) & 0x7FFull) << 32);
+        pb = ((b >> 20) & 0xFFFFFull) | ((b & 0xFFFFFull) << 32);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { pa += __shfl_down(pa, off, 64); pb += __shfl_down(pb, off, 64); }
+    if (lane == 0u) { sSumA[wave] = pa; sSumB[wave] = pb; }
+    __syncthreads();
+    unsigned long long baseA = 0, baseB = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < BT / 64u; w++) { baseA += sSumA[w]; baseB += sSumB[w]; }
+    const uint32_t base0 = (uint32_t)baseA, base1 = (uint32_t)(baseA >> 32), base2 = base0 - base1;
+    // ---- the commands ----
+    if (vis) {
+        ChordDrawCmd cmd;
+        cmd.objectId = refQ.object;
+        cmd.meshletId = qi == 0u ? refQ.meshlet[0] : qi == 1u ? refQ.meshlet[1] : qi == 2u ? refQ.meshlet[2] : refQ.meshlet[3];
+        const uint32_t i0 = excl & 0xFFFFu, i1 = excl >> 16;
+        cmd.slot = base0 + i0;                                              // instance_culling.hlsl:203-206
+        q.outCmds[cmd.slot] = cmd;
+        if (q.doHzb) {
+            if (hzbVis) q.h.visCmds[base1 + i1] = cmd;
+            else q.h.rejCmds[base2 + (i0 - i1)] = cmd;
+        }
+    }
+    // ---- the last workgroup holds the totals: the line of triangle totals and list counts, whole ----
+    if (blockIdx.x == cullBlocks - 1u && threadIdx.x == 0u) {
+        const uint32_t total0 = base0 + n0, total1 = base1 + n1;
+        const unsigned long long tris0 = (uint32_t)baseB + (unsigned long long)t0, tris1 = (baseB >> 32) + (unsigned long long)t1;
+        uint4* line = reinterpret_cast<uint4*>(q.tailLine);
+        line[0] = make_uint4((uint32_t)tris0, (uint32_t)(tris0 >> 32), q.doHzb ? (uint32_t)tris1 : 0u, q.doHzb ? (uint32_t)(tris1 >> 32) : 0u);   // trisInstanceCulled, trisHzbVisible0
+        line[1] = make_uint4(0u, 0u, 0u, 0u);                                                                                                        // trisHzbVisible1, pad2
+        line[2] = make_uint4(total0, q.doHzb ? total1 : 0u, q.doHzb ? total0 - total1 : 0u, 0u);                                                     // listCounts[0..3]
+        line[3] = make_uint4(0u, 0u, 0u, 0u);                                                                                                        // listCounts[4..7]
+    }
 }
 
 // (Round 3: writing the list from the count kernel of short scenes -- every workgroup publishing its counts under a launch
@@ -1164,7 +1368,9 @@ void launch_cull_masks(ChordCtx* c, bool wholeRange)
         q.firstBlock = r * c->cullChunkBlocks;
         q.blockCount = q.firstBlock < c->cullBlocks ? std::min(c->cullChunkBlocks, c->cullBlocks - q.firstBlock) : 0u;
         q.out = c->dCullExchange + (size_t)r * chunkWords;
-        CHORD_LAUNCH(c, group_cull_masks_kernel, dim3(c->cullChunkBlocks), dim3(256), 0, c->stream, q, c->hView);
+        // (a share of at most 512 count blocks is a short list: four lanes per group instance)
+        if (CULL_QUAD && c->cullChunkBlocks <= 512u) CHORD_LAUNCH(c, group_cull_masks_kernel<true>, dim3(c->cullChunkBlocks), dim3(1024), 0, c->stream, q, c->hView);
+        else                                        CHORD_LAUNCH(c, group_cull_masks_kernel<false>, dim3(c->cullChunkBlocks), dim3(256), 0, c->stream, q, c->hView);
     }
 }
 
@@ -1200,6 +1406,21 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     FrameTail none;
     std::memset(&none, 0, sizeof(none));
     const bool hier = c->cullMode == 1 && c->bvhComplete && c->dBvhNodes;
+    // The fused short-scene kernel (one GPU, flat cull, inside chordvis_render_frame, a grid the device holds at once: its workgroups
+    // wait for each other's counts).  CHORDVIS_CULL_FUSED=0: the three-launch path (A/B runs); the result is the same lists, list 0
+    // in the same order -- the visibility ids do not depend on the path.
+    static const bool fusedOn = [] { const char* e = getenv("CHORDVIS_CULL_FUSED"); return !e || atoi(e) != 0; }();
+    const HzbBuffers* fuseHzb = nullptr;
+    bool fused = false;
+    if (CULL_FUSED && fusedOn && CULL_QUAD && !sh && !hier && c->inFrame && c->fuseCullFrame && out.cmds == c->lists[0].cmds && blocks + 1u <= (uint32_t)c->numCUs && blocks <= 512u &&
+        !(c->debugFlags & ~(32768u | 65536u | 262144u))) {
+        uint32_t tailFloats = 0;
+        const ChordHZBDesc& hd = c->hzb[0].desc;
+        for (uint32_t l = 6; l < hd.mipCount; l++) tailFloats += std::max(1u, hd.width >> l) * std::max(1u, hd.height >> l);
+        if (!c->dCullLookback && hipMalloc((void**)&c->dCullLookback, sizeof(unsigned long long) * 2u * 1024u) == hipSuccess)
+            (void)hipMemsetAsync(c->dCullLookback, 0, sizeof(unsigned long long) * 2u * 1024u, c->stream);
+        if (c->dCullLookback && tailFloats <= HZB_TAIL_FLOATS) { fused = true; fuseHzb = c->fuseCullHzb; }
+    }
 #define LAUNCH_COUNT(FM, FUSED, grid, ...) do { if (sh) CHORD_LAUNCH(c, (group_cull_count_kernel<FM, true, FUSED>), grid, dim3(256), 0, c->stream, __VA_ARGS__); \
                                                  else    CHORD_LAUNCH(c, (group_cull_count_kernel<FM, false, FUSED>), grid, dim3(256), 0, c->stream, __VA_ARGS__); } while (0)
     if (blocks > 512u || hier) {
@@ -1217,6 +1438,24 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
         } else {
             LAUNCH_COUNT(false, false, dim3(blocks), p, c->hView, (DView*)nullptr, (DObjFrame*)nullptr, (uint4*)nullptr, 0u, blocks, none);
         }
+    } else if (fused) {
+        // ... and a grid of at most one workgroup per CU does the whole of instanceCulling -- and, in a frame with a history, the phase-0
+        // occlusion cull -- in ONE kernel (frame_cull_fused_kernel: no scatter launch, no hzb_cull_kernel<0> launch)
+        FusedCullParams q;
+        q.g = p;
+        q.h = make_hzb_cull_params(c, fuseHzb ? *fuseHzb : c->hzb[0], out, c->lists[1], &c->lists[2]);
+        q.outCmds = out.cmds; q.outCount = out.count;
+        q.lookback = c->dCullLookback;
+        q.tailLine = reinterpret_cast<uint32_t*>(&c->dFrameState->counters.trisInstanceCulled);
+        do { ++c->cullSerial; } while ((c->cullSerial & 0xFFFFFFu) == 0u);          // (a stamp of 0 would match words no launch has written)
+        q.serial = c->cullSerial; q.doHzb = fuseHzb ? 1u : 0u;
+        q.skipVec4First = (uint32_t)(offsetof(FrameState, counters.trisInstanceCulled) / 16u); q.skipVec4Count = 4u;
+        CHORD_LAUNCH(c, frame_cull_fused_kernel, dim3(blocks + tail.run), dim3(FUSED_CULL_THREADS), 0, c->stream,
+                     q, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4, blocks, tail);
+        if (fuseHzb) { c->fusedCullDone = true; c->listMine[1] = c->listMine[2] = false; }
+        c->viewDirty = false;
+        c->fullListStale = false;
+        return;
     } else {
         // short scenes on one GPU: four lanes per group instance, one meshlet each (CULL_QUAD) -- a list this short leaves most SIMDs
         // with one wave or none, and a thread that tests a group's four meshlets one after the other is 3 000 dependent VALU

@@ -12,6 +12,7 @@
 #   rank:WORKLOAD:RANKS:RANK[:ENV+ENV]   kernel trace of ONE rank of a sharded frame (tools/shard_rank.py, no stamps) + tools/timeline.py
 #   shard:WORKLOAD[:ENV+ENV]   tools/shard_time.py WORKLOAD with ENV (e.g. RANKS=1,8+PIPELINED=1)
 #   pmc:NAME:COUNTERS[:ARGS]   one counter pass of bench.py (tools/pmc.sh), COUNTERS space as '+'
+#   tileprof[:WORKLOAD] per-tile phase clocks of the tile kernel (tools/tile_profile.py; needs chord_amd/build.py --tag prof -DRASTER_PROFILE=1)
 #   profile:NAME[:ARGS] kernel stats + FETCH_SIZE + WRITE_SIZE passes (tools/profile.sh)
 set -u
 TAG=$1; shift
@@ -51,6 +52,7 @@ for step in "$@"; do
       echo "frames: tools/shard_rank.py $a1 $a2 $a3 (rank $a3 of $a2, collectives skipped, no stamps) ${a4:-}" > $OUT/rank_timeline_$a1.txt
       python tools/timeline.py $OUT/rank_$a1/r_kernel_trace.csv >> $OUT/rank_timeline_$a1.txt 2>&1; tail -3 $OUT/rank_$a1.log; cat $OUT/rank_timeline_$a1.txt | tail -32
       find $OUT/rank_$a1 -name "r_kernel_trace.csv" -size +20M -delete;;
+    tileprof) CHORDVIS_LIB=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis_prof.so WL=${a1:-street_4k_hzb} python tools/tile_profile.py hzb > $OUT/tile_profile_${a1:-street_4k_hzb}.txt 2>&1; grep -a "phase sums\|of which\|^pass\|bins \[" $OUT/tile_profile_${a1:-street_4k_hzb}.txt;;
     shard)   env ${a2//+/ } python tools/shard_time.py $a1 2>&1 | grep "^ranks" | tee -a $OUT/shard_time_$a1.txt;;
     pmc)     bash tools/pmc.sh $TAG/pmc_$a1 "${a2//+/ }" ${a3//+/ } 2>&1 | tee $OUT/pmc_$a1.txt | grep "raster_tile\|raster_setup\|hzb_cull\|group_cull" ;;
     profile) bash tools/profile.sh $TAG/prof_$a1 ${a2//+/ } > /dev/null 2>&1; ls $OUT/prof_$a1;;

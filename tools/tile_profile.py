@@ -24,6 +24,9 @@ for p in (0, 1):
     ticks = np.zeros(tx * ty * 9, np.uint64); cnt = np.zeros(tx * ty, np.uint32)
     assert L.lib.chordvis_debug_tile_profile(r._ctx, p, ticks.ctypes.data, cnt.ctypes.data, tx * ty * 9) == 0
     raw = ticks[tx * ty:].reshape(tx * ty, 8)
+    # phase words: low half = the phase's ticks (10 ns), high half = the eight waves' ticks spent AT the phase's closing barrier (summed)
+    barrier = (raw[:, :6] >> np.uint64(32)).astype(np.float64) / 100.0 / 8.0          # per wave, us
+    raw = raw.copy(); raw[:, :6] &= np.uint64(0xFFFFFFFF)
     phase = raw.astype(np.float64) / 100.0
     ticks = ticks[:tx * ty]
     us = ticks.astype(np.float64) / 100.0
@@ -31,6 +34,8 @@ for p in (0, 1):
     tiny, tinypx = (raw[:, 7] >> np.uint64(32)).astype(np.int64), (raw[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     print("work: entries %d  tiny %d (bbox px %d)  units %d  row-loop trips %d (%.1f per unit)" % (cnt.sum(), tiny.sum(), tinypx.sum(), units.sum(), trips.sum(), trips.sum() / max(1, units.sum())))
     print("phase sums (us) in/load/setup/scan/units/out:", np.round(phase[:, :6].sum(axis=0), 0))
+    print("  of which a wave's mean time at the phase's closing barrier (waiting for the workgroup's slowest wave):", np.round(barrier.sum(axis=0), 0),
+          " = %.1f %% of the phases' time" % (100.0 * barrier.sum() / max(phase[:, :6].sum(), 1e-9)))
     order = np.argsort(-us)[:4]
     print("pass", p, "entries", int(cnt.sum()), "max bin", int(cnt.max()), "tile us: sum %.0f mean %.1f max %.1f" % (us.sum(), us.mean(), us.max()))
     for t in order: print("   tile (%2d,%2d) %7.1f us  bin %5d  phases" % (t % tx, t // tx, us[t], cnt[t]), np.round(phase[t, :6], 1))
