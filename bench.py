@@ -529,7 +529,31 @@ def measure(args, workload, env):
             traffic_head = tk.get("profile_head")
         except (KeyError, ValueError):
             traffic = None
-    roofline = {"bound": "hbm", "kernel": dom + (" (raster_setup_blocks_kernel + raster_setup_kernel)" if dom == "raster_setup_kernel" and blocks > 0 else ""), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # The block kernel of the sub-pixel workloads is bound by instruction issue, not by memory: beside the HBM figure the
+    # line carries its VALU roofline -- wave-instructions per cluster from the committed SQ counter pass (profiles/*_config5_valu.json,
+    # like `traffic`), times the clusters of a launch, over the launch's time, against what the chip's SIMDs can issue: SIMDs x clock /
+    # cycles per wave-instruction, the divisor MEASURED by tools/microbench/valu_issue.hip (profiles/r06_microbench_valu_issue.txt):
+    # 1.31 cycles for two-operand ops at 8 waves per SIMD, 1.64 at 4 waves, 2.1-2.7 for three-operand / multiply ops, 8 cycles between
+    # DEPENDENT instructions of one wave -- not the 4 cycles per instruction rounds 4-5 priced the kernel with.
+    valu = None
+    if dom == "raster_setup_kernel" and blocks > 0 and dom_ms > 0:
+        vj = sorted(f for f in os.listdir(prof_dir) if f.endswith("config5_valu.json")) if os.path.isdir(prof_dir) else []
+        if vj:
+            try:
+                vk = json.load(open(os.path.join(prof_dir, vj[-1])))
+                simds = torch.cuda.get_device_properties(dev).multi_processor_count * 4
+                clock_hz = 2.4e9
+                per = float(vk["valu_per_cluster"])
+                ach = per * clusters_per_frame / (dom_ms * 1e-3)
+                valu = {"insts_per_cluster": per, "salu_per_cluster": vk.get("salu_per_cluster"), "clusters_per_launch": clusters_per_frame / launches,
+                        "achieved_ginst_s": round(ach / 1e9, 1), "simds": simds, "clock_ghz": 2.4,
+                        "cycles_per_inst_measured": {"two_operand_8_waves": 1.31, "two_operand_4_waves": 1.64, "three_operand_8_waves": 2.09, "dependent_chain_one_wave": 8.06},
+                        "peak_ginst_s": round(simds * clock_hz / 1.31 / 1e9, 1), "issue_frac": round(ach / (simds * clock_hz / 1.31), 4),
+                        "issue_frac_three_operand_rate": round(ach / (simds * clock_hz / 2.09), 4),
+                        "source": "profiles/" + vj[-1], "profile_head": vk.get("profile_head"), "from_committed_profile": True}
+            except (KeyError, ValueError):
+                valu = None
+    roofline = {"bound": "hbm", "valu": valu, "kernel": dom + (" (raster_setup_blocks_kernel + raster_setup_kernel)" if dom == "raster_setup_kernel" and blocks > 0 else ""), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_profile_head": traffic_head,          # the commit that profile was taken at: a kernel changed since then leaves `traffic` stale
                 "from_committed_profile": traffic is not None,   # (PMC passes cannot run inside this process: not observed in THIS run)

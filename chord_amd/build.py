@@ -43,10 +43,26 @@ def _headers_digest():
 def build(force=False, verbose=True, defines=(), tag=""):
     """defines / tag: a measurement variant (e.g. defines=("-DCHORD_TILE_V=1",), tag="tile_v1") is built next to the
     product library as _build/libchordvis_<tag>.so; chord_amd/lib.py loads it when CHORDVIS_LIB names it."""
+    # (object trees of measurement variants whose library has been deleted go with it: they only cost pushes to the GPU box)
+    if os.path.isdir(OUT_DIR):
+        import shutil
+        for d in os.listdir(OUT_DIR):
+            if d.startswith("obj_") and not os.path.exists(os.path.join(OUT_DIR, "libchordvis_%s.so" % d[4:])) and d[4:] != tag:
+                shutil.rmtree(os.path.join(OUT_DIR, d), ignore_errors=True)
     build_dir = BUILD_DIR + ("_" + tag if tag else "")
     lib_path = os.path.join(OUT_DIR, "libchordvis%s.so" % ("_" + tag if tag else ""))
-    os.makedirs(build_dir, exist_ok=True)
     hd = _headers_digest() + " ".join(defines)
+    # the library carries a digest of everything it was made from: a tree that holds the library but not its object files (the GPU
+    # box: .gpurunignore leaves chord_amd/_build/obj*/ at home) is up to date without compiling anything
+    whole = hashlib.sha1(hd.encode())
+    for src in _sources():
+        with open(os.path.join(CSRC, src), "rb") as fh:
+            whole.update(fh.read())
+    whole = whole.hexdigest()
+    digest_path = lib_path + ".digest"
+    if not force and os.path.exists(lib_path) and os.path.exists(digest_path) and open(digest_path).read() == whole:
+        return lib_path
+    os.makedirs(build_dir, exist_ok=True)
     objs, rebuilt = [], False
     for src in _sources():
         path = os.path.join(CSRC, src)
@@ -79,6 +95,8 @@ def build(force=False, verbose=True, defines=(), tag=""):
         if verbose:
             print("[chord_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    with open(digest_path, "w") as fh:
+        fh.write(whole)
     return lib_path
 
 

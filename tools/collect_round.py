@@ -46,7 +46,10 @@ def counters(dirs):
 def sq_table(dirs, out, title, note):
     data = counters(dirs)
     cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
-            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_THREAD_CYCLES_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
+            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_MISC",
+            "SQ_INSTS_BRANCH", "SQ_IFETCH", "SQ_IFETCH_LEVEL", "SQ_THREAD_CYCLES_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_CMD_FIFO_FULL",
+            "SQ_INSTS_LDS_ATOMIC", "SQ_INSTS_LDS_LOAD", "SQ_INSTS_LDS_STORE", "SQ_INST_LEVEL_LDS", "SQ_INST_LEVEL_VMEM", "SQ_INST_LEVEL_SMEM",
+            "SQ_VMEM_TA_ADDR_FIFO_FULL", "SQ_VMEM_TA_CMD_FIFO_FULL", "SQ_VMEM_WR_TA_DATA_FIFO_FULL", "SQ_INST_CYCLES_VMEM_RD", "SQ_INST_CYCLES_VMEM_WR", "SQ_BUSY_CU_CYCLES"]
     cols = [c for c in cols if any(c in v for v in data.values())]
     if not data:                                   # (a partial call: no counter passes for this table -- the committed one stays)
         return data
@@ -68,7 +71,7 @@ def sq_table(dirs, out, title, note):
     return data
 
 
-c3 = sq_table(["%s_sq1" % R, "%s_sq2" % R, "%s_sq3" % R], "%s_config3_4k_hzb_sq_counters.md" % R,
+c3 = sq_table(["%s_sq1" % R, "%s_sq2" % R, "%s_sq3" % R, "%s_sq4" % R, "%s_sq5" % R, "%s_sq6" % R], "%s_config3_4k_hzb_sq_counters.md" % R,
               "%s config 3 (street_4k_hzb) -- SQ counters per kernel launch" % R,
               "Averages over `bench.py --steps 12 --warmup 4`, three separate `rocprofv3 --pmc` passes (tools/pmc.sh), the round's final kernels.")
 c5 = sq_table(["%s_sq1_c5" % R, "%s_sq2_c5" % R], "%s_config5_sq_counters.md" % R,
@@ -78,6 +81,14 @@ blk = next((v for k, v in c5.items() if "raster_setup_blocks_kernel" in k), None
 if blk and "SQ_INSTS_VALU" in blk:
     with open(os.path.join(P, "%s_config5_sq_counters.md" % R), "a") as f:
         f.write("\nPer cluster (524 288 per launch): **%.0f VALU + %.0f SALU** wave-instructions.\n" % (blk["SQ_INSTS_VALU"] / 524288.0, blk.get("SQ_INSTS_SALU", 0.0) / 524288.0))
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = ""
+    # what bench.py's roofline.valu reads (like *_traffic.json: a counter pass cannot run inside the bench process)
+    json.dump({"kernel": "raster_setup_blocks_kernel", "workload": "subpixel_64m --debug-flags 65536", "clusters_per_launch": 524288,
+               "valu_per_cluster": round(blk["SQ_INSTS_VALU"] / 524288.0, 1), "salu_per_cluster": round(blk.get("SQ_INSTS_SALU", 0.0) / 524288.0, 1),
+               "profile_head": head}, open(os.path.join(P, "%s_config5_valu.json" % R), "w"), indent=1)
 
 # bench lines, compact
 with open(os.path.join(P, "%s_bench_lines.txt" % R), "w") as f:
@@ -100,7 +111,8 @@ with open(os.path.join(P, "%s_bench_lines.txt" % R), "w") as f:
 
 for src, dst in (("%s_shard_time_c5.txt", "%s_shard_time_config5.txt"), ("%s_shard_time_c4.txt", "%s_shard_time_config4.txt"),
                  ("%s_shard_time_c4_pipelined.txt", "%s_shard_time_config4_pipelined.txt"), ("%s_shard_time_c5hot.txt", "%s_shard_time_config5_hotspot.txt"),
-                 ("%s_timeline.txt", "%s_config3_timeline.txt"), ("%s_timeline_c4.txt", "%s_config4_timeline.txt"),
+                 ("%s_timeline.txt", "%s_config3_timeline.txt"), ("%s_timeline_c4.txt", "%s_config4_timeline.txt"), ("%s_timeline_rank3_c4.txt", "%s_config4_rank3_of_8_timeline.txt"),
+                 ("%s_microbench_valu_issue.txt", "%s_microbench_valu_issue.txt"), ("%s_tile_profile.txt", "%s_tile_profile_config3.txt"), ("%s_ablate_tile.txt", "%s_tile_kernel_ablation.txt"),
                  ("%s_shadow_time.txt", "%s_shadow_time.txt"), ("%s_group_host_time.txt", "%s_group_host_time.txt")):
     s = os.path.join(G, src % R)
     if os.path.exists(s):
