@@ -2745,7 +2745,10 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     const unsigned long long t0 = prof ? wall_clock64() : 0ull;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = t0;
     uint32_t cUnits = 0, cUnitIters = 0, cTiny = 0, cTinyIters = 0;      // (profile only)
-#define PHASE(i) do { if (prof) { __syncthreads(); const unsigned long long tn = wall_clock64(); ph[i] += tn - tp; tp = tn; } } while (0)
+    // (profile build: a phase ends at a barrier of its own, and what a wave spends AT that barrier -- from its arrival to the release, i.e.
+    // waiting for the workgroup's slowest wave -- is summed per phase: bw[])
+    unsigned long long bw[6] = {0, 0, 0, 0, 0, 0};
+#define PHASE(i) do { if (prof) { const unsigned long long ta = wall_clock64(); __syncthreads(); const unsigned long long tn = wall_clock64(); bw[i] += tn - ta; ph[i] += tn - tp; tp = tn; } } while (0)
     const int32_t ox = (int32_t)(tileId % p.tilesX) * TILE, oy = (int32_t)(tileId / p.tilesX) * TILE;
     const int32_t tw = min(TILE, p.Wi - ox), th = min(TILE, p.Hi - oy);
     const bool noPixels = ABL(p, DBG_NO_PIXELS);
@@ -3101,6 +3104,8 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         // work counters of the tile: units << 32 | row-loop trips, tiny triangles << 32 | their bbox pixels
         atomicAdd(&p.tilePhase[(size_t)tileId * 8 + 6], ((unsigned long long)cUnits << 32) | cUnitIters);
         atomicAdd(&p.tilePhase[(size_t)tileId * 8 + 7], ((unsigned long long)cTiny << 32) | cTinyIters);
+        // the eight waves' time at the phase barriers, in the high halves of the phase words (ticks of 10 ns: a phase stays far below 2^32)
+        if ((tix & 63u) == 0u) for (int i = 0; i < 6; i++) atomicAdd(&p.tilePhase[(size_t)tileId * 8 + i], bw[i] << 32);
     }
     __syncthreads();                                              // the LDS tile is reused by the next iteration
     }
@@ -3404,7 +3409,9 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         // so the rule is "the latest report says light", not "a report of the last few frames"; a pass that reports both is heavy)
         if (lightSeen != 0u && (heavySeen == 0u || (int32_t)(lightSeen - heavySeen) > 0)) { p.orderKept = 2u; makeOrder = false; }
     }
-    if (TILE_ORDER_KEEP && c->orderKeepFrames && CHORD_MASKED_FUSED && c->inFrame && clearTiles && !sh && !c->depthOnly && pass == 0u && c->dTileOrderKeep && !c->debugFlags) {
+    // (sharded frames too since round 6: a rank's work items are its own tiles, the map they follow changes only through
+    // install_tile_owners, which ages the schedule out)
+    if (TILE_ORDER_KEEP && c->orderKeepFrames && CHORD_MASKED_FUSED && c->inFrame && clearTiles && !c->depthOnly && pass == 0u && c->dTileOrderKeep && !(c->debugFlags & ~524288u)) {
         p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrderKeep);
         if (c->orderAge < c->orderKeepFrames) { c->orderAge++; p.orderKept = 1u; makeOrder = false; }
         else c->orderAge = 0u;

@@ -7,8 +7,8 @@ microseconds per record -- round 5's timeline showed a stamped frame (eight of t
 "23 % of the frame idle between kernels".  Frames with stamps can still be told from the others in a trace that has both: pass
 --min-gaps to see them apart (a frame counts as stamped when at least that many of its kernel boundaries are wider than 3 us).
 
-A frame starts at its first kernel: group_cull_count_kernel (short scenes: the object pass rides on it) or object_cull_kernel
-(long scenes).  Frames are grouped by their launch sequence (the names in order); the most frequent sequence is printed: per launch
+A frame starts at its first kernel: object_cull_kernel (long scenes), else frame_cull_fused_kernel (short scenes inside
+chordvis_render_frame), else group_cull_count_kernel.  Frames are grouped by their launch sequence (the names in order); the most frequent sequence is printed: per launch
 the median start offset, duration and gap to the launch before, then the frame's span, the sum of its kernels' durations and the
 difference (time the device ran none of the frame's kernels).  Other sequences (a frame that makes its tile schedule again: one
 launch more) are listed with their counts and medians.
@@ -32,7 +32,7 @@ def main(path, min_gaps=None):
         return 1
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     names = [short(r['Kernel_Name']) for r in rows]
-    first = 'object_cull_kernel' if any('object_cull_kernel' in n for n in names) else 'group_cull_count'
+    first = next(k for k in ('object_cull_kernel', 'frame_cull_fused_kernel', 'group_cull_count') if any(k in n for n in names) or k == 'group_cull_count')
     starts = [i for i, n in enumerate(names) if first in n]
     if len(starts) < 3:
         print("fewer than two complete frames in", path)
