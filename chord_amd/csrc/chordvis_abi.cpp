@@ -1562,7 +1562,7 @@ int chordvis_debug_graph_frames(ChordCtx* c, uint32_t pairs, float* msPerFrameSt
 }
 
 // Debugging aid: raw read of an internal buffer.  which: 0 tile counts (FrameState::tileCount), 1 fixed bins, 2 chunk table,
-// 3 bin pool, 4 compact records, 5 wide records.  offset / bytes in bytes.
+// 3 bin pool, 4 compact records, 5 wide records, 6 the fused cull kernel's look-back words.  offset / bytes in bytes.
 int chordvis_debug_read(ChordCtx* c, int which, uint64_t offset, uint64_t bytes, void* host)
 {
     if (!c || !host) return fail(c, CHORDVIS_E_INVALID, "debug_read: null argument");
@@ -1575,6 +1575,7 @@ int chordvis_debug_read(ChordCtx* c, int which, uint64_t offset, uint64_t bytes,
     case 3: base = (const char*)c->dBinPool; break;
     case 4: base = (const char*)c->dTrisC; break;
     case 5: base = (const char*)c->dTris; break;
+    case 6: base = (const char*)c->dCullLookback; break;       // look-back words of frame_cull_fused_kernel (profile build: stage clocks behind them)
     default: return fail(c, CHORDVIS_E_INVALID, "debug_read: unknown buffer");
     }
     CHORD_HIP(c, hipMemcpy(host, base + offset, bytes, hipMemcpyDeviceToHost));

@@ -38,23 +38,33 @@ struct FrameTail { HzbParams p; uint32_t run; };
 // instanceCullingCS (instance_culling.hlsl:47-131) for one object: OBB-vs-frustum and the per-object matrices every
 // later kernel of the frame reads.  Runs inside group_cull_count_kernel (below): a launch of its own cost 8 us of a
 // 216-us frame for 352 objects' worth of work.
+// (in pieces that take the object's matrices by value, so that frame_cull_fused_kernel's lanes can compute the one piece each of them
+// owes its quad with the SAME arithmetic, from records they asked for early)
+__device__ __forceinline__ Mat4 obj_mvp(const Mat4& M, const DView& dv) { return mul_mm(load_mat(dv.iv.translatedWorldToClip), M); }   // instance_culling.hlsl:71
+__device__ __forceinline__ bool obj_visible(const Mat4& M, const float* posMin, const float* posMax, const DView& dv, const Mat4& mvp)
+{
+    if (!(dv.flags & CHORD_FLAG_FRUSTUM_CULL)) return true;                 // instance_culling.hlsl:79-89
+    const bool ortho = mvp.r[3][3] == 1.0f;                                 // base.hlsli:243-246
+    f3 c, e;
+    aabb_center_extent(posMin, posMax, c, e);
+    if (ortho) return !ortho_frustum_culling(c, e, mvp);
+    return !frustum_culling(&dv.iv.frustumPlanesRS[0][0], c, e, M);
+}
+__device__ __forceinline__ Mat4 obj_mvp_last(const Mat4& Ml, const DView& dv) { return mul_mm(load_mat(dv.view.translatedWorldToClipLastFrame), Ml); }   // hzb_mainview_culling.hlsl:77-83
+__device__ __forceinline__ Mat4 obj_local_to_view(const Mat4& M, const DView& dv) { return mul_mm(load_mat(dv.view.translatedWorldToView), M); }        // instance_culling.hlsl:170 -- always the main view
+__device__ __forceinline__ f4 obj_cam_ls(const Mat4& W2L) { return mul_mv(W2L, 0.0f, 0.0f, 0.0f, 1.0f); }                                              // nanite_shared.hlsli:65
+
 __device__ __forceinline__ void object_frame(const ChordObject* __restrict__ objects, const DObjStatic* __restrict__ objStatic,
                                              const DPrim* __restrict__ prims, const DView& dv, DObjFrame* __restrict__ objFrame, uint32_t o)
 {
     const ChordObject& obj = objects[o];
-
     const Mat4 M = load_mat(obj.basicData.localToTranslatedWorld);
-    const Mat4 VP = load_mat(dv.iv.translatedWorldToClip);
-    const Mat4 mvp = mul_mm(VP, M);                                         // instance_culling.hlsl:71
+    const Mat4 mvp = obj_mvp(M, dv);
     const bool ortho = mvp.r[3][3] == 1.0f;                                 // base.hlsli:243-246
-
     bool visible = true;
-    if (dv.flags & CHORD_FLAG_FRUSTUM_CULL) {                               // instance_culling.hlsl:79-89
+    if (dv.flags & CHORD_FLAG_FRUSTUM_CULL) {                               // (the primitive's record is read only then)
         const DPrim& prim = prims[objStatic[o].prim];
-        f3 c, e;
-        aabb_center_extent(prim.posMin, prim.posMax, c, e);
-        if (ortho) visible = !ortho_frustum_culling(c, e, mvp);
-        else       visible = !frustum_culling(&dv.iv.frustumPlanesRS[0][0], c, e, M);
+        visible = obj_visible(M, prim.posMin, prim.posMax, dv, mvp);
     }
 
     DObjFrame& of = objFrame[o];
@@ -62,27 +72,22 @@ __device__ __forceinline__ void object_frame(const ChordObject* __restrict__ obj
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int c = 0; c < 4; c++) of.mvp[r * 4 + c] = mvp.r[r][c];
-
-    {   // hzb_mainview_culling.hlsl:77-83 (phase 0 matrix)
-        const Mat4 Ml = load_mat(obj.basicData.localToTranslatedWorldLastFrame);
-        const Mat4 VPl = load_mat(dv.view.translatedWorldToClipLastFrame);
-        const Mat4 ml = mul_mm(VPl, Ml);
+    {
+        const Mat4 ml = obj_mvp_last(load_mat(obj.basicData.localToTranslatedWorldLastFrame), dv);
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int c = 0; c < 4; c++) of.mvpLast[r * 4 + c] = ml.r[r][c];
     }
-    {   // instance_culling.hlsl:170 — always the main view
-        const Mat4 V = load_mat(dv.view.translatedWorldToView);
-        const Mat4 l2v = mul_mm(V, M);
+    {
+        const Mat4 l2v = obj_local_to_view(M, dv);
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int c = 0; c < 4; c++) of.localToView[r * 4 + c] = l2v.r[r][c];
     }
-    {   // nanite_shared.hlsli:65
-        const Mat4 W2L = load_mat(obj.basicData.translatedWorldToLocal);
-        const f4 cam = mul_mv(W2L, 0.0f, 0.0f, 0.0f, 1.0f);
+    {
+        const f4 cam = obj_cam_ls(load_mat(obj.basicData.translatedWorldToLocal));
         of.camLS[0] = cam.x; of.camLS[1] = cam.y; of.camLS[2] = cam.z;
     }
     of.maxScale = obj.basicData.scaleExtractFromMatrix[3];
@@ -195,6 +200,9 @@ __device__ __forceinline__ void block_totals2(uint32_t a, uint32_t b, uint32_t* 
     *totalA = ta; *totalB = tb;
 }
 
+// the value lane L of the quad holds, in every lane of the quad (DPP quad_perm [L,L,L,L]; all lanes active)
+template <int L> __device__ __forceinline__ uint32_t quad_bcast_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, L | (L << 2) | (L << 4) | (L << 6), 0xF, 0xF, true); }
+template <int L> __device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), L | (L << 2) | (L << 4) | (L << 6), 0xF, 0xF, true)); }
 // the value of lane ^ 1 / lane ^ 2 of the quad (DPP quad_perm [1,0,3,2] / [2,3,0,1]; all lanes active)
 __device__ __forceinline__ uint32_t quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); }
@@ -744,9 +752,11 @@ __device__ __forceinline__ float oct_max(float v)
 // which the order could change, decides nothing below).
 // (hzb_meshlet_visible: the test itself, for a caller that holds the meshlet record and the object's frame record already --
 // frame_cull_fused_kernel; hzb_cmd_visible below: from a draw command)
+// (hzb_bounds_visible: with the projection matrix in registers already -- frame_cull_fused_kernel asks for it beside the object's other
+// fields, one round trip instead of two)
 template <int PHASE, bool TAIL = false, bool OCT = false>
-__device__ __forceinline__ bool hzb_meshlet_visible(const HzbCullParams& p, const DView& dv, const DObjFrame& of, const DMeshlet& m,
-                                                    const float* sTail = nullptr, const uint32_t* sTailOff = nullptr, const uint32_t sub = 0u)
+__device__ __forceinline__ bool hzb_bounds_visible(const HzbCullParams& p, const DView& dv, const Mat4& mvp, const DMeshlet& m,
+                                                   const float* sTail = nullptr, const uint32_t* sTailOff = nullptr, const uint32_t sub = 0u)
 {
     bool visible = true;
     {
@@ -754,12 +764,6 @@ __device__ __forceinline__ bool hzb_meshlet_visible(const HzbCullParams& p, cons
             if (dv.flags & CHORD_FLAG_HZB_CULL) {
                 f3 c, e;
                 aabb_center_extent(m.posMin, m.posMax, c, e);
-                Mat4 mvp;
-                const float* src = PHASE == 0 ? of.mvpLast : of.mvp;         // hzb_mainview_culling.hlsl:77-83
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = src[r * 4 + cc];
 
                 f3 mx = {-10.0f, -10.0f, -10.0f}, mn = {10.0f, 10.0f, 10.0f};
                 if (OCT) {
@@ -840,6 +844,20 @@ __device__ __forceinline__ bool hzb_meshlet_visible(const HzbCullParams& p, cons
 }
 
 template <int PHASE, bool TAIL = false, bool OCT = false>
+__device__ __forceinline__ bool hzb_meshlet_visible(const HzbCullParams& p, const DView& dv, const DObjFrame& of, const DMeshlet& m,
+                                                    const float* sTail = nullptr, const uint32_t* sTailOff = nullptr, const uint32_t sub = 0u)
+{
+    if (!(dv.flags & CHORD_FLAG_HZB_CULL)) return true;
+    Mat4 mvp;
+    const float* src = PHASE == 0 ? of.mvpLast : of.mvp;         // hzb_mainview_culling.hlsl:77-83
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) mvp.r[r][cc] = src[r * 4 + cc];
+    return hzb_bounds_visible<PHASE, TAIL, OCT>(p, dv, mvp, m, sTail, sTailOff, sub);
+}
+
+template <int PHASE, bool TAIL = false, bool OCT = false>
 __device__ __forceinline__ bool hzb_cmd_visible(const HzbCullParams& p, const DView& dv, const ChordDrawCmd& cmd, uint32_t& tris,
                                                 const float* sTail = nullptr, const uint32_t* sTailOff = nullptr, const uint32_t sub = 0u)
 {
@@ -875,7 +893,7 @@ struct FusedCullParams {
     ChordDrawCmd* outCmds; uint32_t* outCount;      // list 0
     unsigned long long* lookback;          // [cullBlocks][2]
     uint32_t* tailLine;                    // the 64-byte line the last workgroup writes: {trisInstanceCulled, trisHzbVisible0, trisHzbVisible1, pad2} (u64) + listCounts[8]
-    uint32_t serial, doHzb, skipVec4First, skipVec4Count;
+    uint32_t serial, doHzb, skipVec4First, skipVec4Count, objectCount;
 };
 #define FUSED_CULL_THREADS 1024u
 
@@ -884,6 +902,14 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
                                                                             uint32_t cullBlocks, FrameTail tail)
 {
     constexpr uint32_t BT = FUSED_CULL_THREADS;
+    // (profile build: wall-clock ticks of this workgroup's stages behind the look-back words -- tools/fused_cull_profile.py)
+#if RASTER_PROFILE
+    unsigned long long fc[7];
+#define FCLOCK(i) do { fc[i] = wall_clock64(); } while (0)
+#else
+#define FCLOCK(i) do { } while (0)
+#endif
+    FCLOCK(0);
     __shared__ float sTail[HZB_TAIL_FLOATS];
     __shared__ uint32_t sTailOff[CHORD_HZB_MAX_MIPS];
     __shared__ uint32_t sWave[BT / 64u];
@@ -891,16 +917,41 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
     const GroupCullParams& p = q.g;
     const uint32_t qi = threadIdx.x & 3u;
     const uint32_t t = blockIdx.x * 256u + (threadIdx.x >> 2);
+    // grid: [0, cullBlocks) the tests; then, when there is one, the workgroup of the previous frame's HZB tail; then the object pass
     const bool tailBlock = tail.run && blockIdx.x == cullBlocks;
-    // what the tests read that does not depend on this frame's object records, requested before everything else (group_cull_count_kernel)
-    DGroupRef refQ; DGroup gQ; Mat4 MQ; DMeshlet mQ; uint32_t matFlagsQ = 0u;
+    if (blockIdx.x >= cullBlocks + tail.run) {
+        // ---- the object pass (instanceCullingCS, instance_culling.hlsl:47-131): the per-object records every LATER kernel of the frame
+        //      reads.  Workgroups of their own, off everybody's path: the tests below do not wait for them (first version: the block's
+        //      objects ahead of its tests, a barrier in between -- 5.8 us of a 20-us workgroup, three dependent round trips and the
+        //      matrix products of seven threads with 1 017 waiting) ----
+        const uint32_t o = (blockIdx.x - cullBlocks - tail.run) * BT + threadIdx.x;
+        if (objFrameOut && o < q.objectCount) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, o);
+        return;
+    }
+    // A quad's four lanes test the four meshlets of ONE group instance of ONE object; what they need of the object -- the rows of V * M
+    // for the LOD cut, the camera in local space for the cone test, whether the object is in the frustum at all, last frame's
+    // projection for the occlusion test -- they work out among themselves, one piece per lane (the pieces of object_frame, the same
+    // arithmetic), and hand round by DPP.  tc: lanes past the list compute on its last entry (all lanes stay active: DPP) and emit nothing.
+    const uint32_t tc = min(t, max(p.groupInstances, 1u) - 1u);
+    DGroupRef refQ; DGroup gQ; Mat4 MQ, roleQ; DMeshlet mQ; uint32_t matFlagsQ = 0u;
+    float scaleQ = 0.0f, pmnQ[3] = {0.0f, 0.0f, 0.0f}, pmxQ[3] = {0.0f, 0.0f, 0.0f};
     refQ.object = 0u; refQ.group = 0u;
-    if (!tailBlock && t < p.groupInstances) {
-        refQ = p.groupRefs[t];
+    const bool live = !tailBlock && p.groupInstances != 0u;
+    if (live) {
+        refQ = p.groupRefs[tc];
         gQ = p.groups[refQ.group & 0x0FFFFFFFu];
-        MQ = load_mat(p.objects[refQ.object].basicData.localToTranslatedWorld);
+        const ChordObject& obj = p.objects[refQ.object];
+        MQ = load_mat(obj.basicData.localToTranslatedWorld);
         matFlagsQ = p.objStatic[refQ.object].matFlags;
         mQ = p.meshlets[qi == 0u ? refQ.meshlet[0] : qi == 1u ? refQ.meshlet[1] : qi == 2u ? refQ.meshlet[2] : refQ.meshlet[3]];
+        // the lane's piece of the object (below): lane 1 the inverse matrix and the scale, lane 3 last frame's matrix, lane 2 the primitive's bounds
+        roleQ = load_mat(qi == 1u ? obj.basicData.translatedWorldToLocal : obj.basicData.localToTranslatedWorldLastFrame);
+        scaleQ = obj.basicData.scaleExtractFromMatrix[3];
+        if (qi == 2u && (dv.flags & CHORD_FLAG_FRUSTUM_CULL)) {
+            const DPrim& prim = p.prims[p.objStatic[refQ.object].prim];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { pmnQ[i] = prim.posMin[i]; pmxQ[i] = prim.posMax[i]; }
+        }
     }
     if (tailBlock) {
         if (threadIdx.x >= 256u) return;                   // (hzb_tail_block is written for 256 threads; whole waves leave, its barriers count the rest)
@@ -914,22 +965,60 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
     // the frame's counters, bin counts, list counts: zero -- but for the line the last workgroup writes below
     for (uint32_t i = blockIdx.x * BT + threadIdx.x; i < zeroVec4; i += cullBlocks * BT)
         if (i - q.skipVec4First >= q.skipVec4Count) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (p.groupInstances && objFrameOut) {
-        const uint32_t first = blockIdx.x * 256u;
-        if (first < p.groupInstances) {
-            const uint32_t oFirst = p.groupRefs[first].object, oLast = p.groupRefs[min(first + 255u, p.groupInstances - 1u)].object;
-            for (uint32_t k = threadIdx.x; k <= oLast - oFirst; k += BT) object_frame(p.objects, p.objStatic, p.prims, dv, objFrameOut, oFirst + k);
-        }
-    }
-    // levels 6.. of the history chain into LDS (its barriers also publish the object records of this block to the block)
+    FCLOCK(1);
+    // levels 6.. of the history chain into LDS, while the records above are on their way
     if (q.doHzb) hzb_tail_to_lds(q.h.hzbMin, nullptr, q.h.desc, sTail, sTailOff, BT);
     __syncthreads();
+    FCLOCK(2);
+
+    // ---- the object's pieces, one per lane of the quad ----
+    DObjFrame of;                                          // (registers: only what the tests read is ever materialised)
+    {
+        float own[16];
+        uint32_t ownFlag = 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) own[i] = 0.0f;
+        if (live) {
+            if (qi == 0u) {                                // rows 0..2 of V * M
+                const Mat4 l2v = obj_local_to_view(MQ, dv);
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) own[r * 4 + cc] = l2v.r[r][cc];
+            } else if (qi == 1u) {                         // camera in local space, largest scale
+                const f4 cam = obj_cam_ls(roleQ);
+                own[0] = cam.x; own[1] = cam.y; own[2] = cam.z; own[3] = scaleQ;
+            } else if (qi == 2u) {                         // VP * M, and the object's own frustum test
+                const Mat4 mvp = obj_mvp(MQ, dv);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) own[r * 4 + cc] = mvp.r[r][cc];
+                ownFlag = (obj_visible(MQ, pmnQ, pmxQ, dv, mvp) ? 1u : 0u) | (mvp.r[3][3] == 1.0f ? 2u : 0u);
+            } else if (q.doHzb) {                          // VP_last * M_last
+                const Mat4 ml = obj_mvp_last(roleQ, dv);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) own[r * 4 + cc] = ml.r[r][cc];
+            }
+        }
+        // (all lanes active here: whole workgroups are live or not)
+#pragma unroll
+        for (int i = 0; i < 12; i++) of.localToView[i] = quad_bcast<0>(own[i]);
+        of.camLS[0] = quad_bcast<1>(own[0]); of.camLS[1] = quad_bcast<1>(own[1]); of.camLS[2] = quad_bcast<1>(own[2]); of.maxScale = quad_bcast<1>(own[3]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) of.mvp[i] = quad_bcast<2>(own[i]);
+        const uint32_t f2 = quad_bcast_u<2>(ownFlag);
+        of.visible = f2 & 1u; of.isOrtho = f2 >> 1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) of.mvpLast[i] = quad_bcast<3>(own[i]);
+    }
 
     // ---- the tests: group (every lane of the quad), this lane's meshlet, and -- for a meshlet that passed -- last frame's HZB ----
     bool vis = false, hzbVis = false;
     uint32_t tris = 0;
     if (t < p.groupInstances) {
-        const DObjFrame& of = p.objFrame[refQ.object];
         if (of.visible) {
             const uint32_t cnt = refQ.group >> 28;
             if (cnt != 0u && group_visible(dv.view.lodScale, of.localToView, of.maxScale, gQ)) {     // instance_culling.hlsl:174
@@ -948,6 +1037,10 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
     }
     // ---- positions inside the block: thread order = (group instance, meshlet) order = the order of the list ----
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#if RASTER_PROFILE
+    __syncthreads();
+#endif
+    FCLOCK(3);
     const uint32_t mine = (vis ? 1u : 0u) | ((vis && hzbVis) ? 1u << 16 : 0u);
     const uint32_t incl = wave_incl_scan(mine, lane);
     unsigned long long ta = ((unsigned long long)(vis ? tris : 0u)) | ((unsigned long long)((vis && hzbVis) ? tris : 0u) << 32);
@@ -966,6 +1059,7 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
     __syncthreads();                                                       // (sSumB is reused below)
     // ---- publish, then add up the workgroups in front of this one ----
     const unsigned long long stampA = (unsigned long long)q.serial << 32, stampB = (unsigned long long)(q.serial & 0xFFFFFFu) << 40;
+    FCLOCK(4);
     if (threadIdx.x == 0u) {
         __hip_atomic_store(q.lookback + 2u * blockIdx.x, stampA | n0 | (n1 << 11), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(q.lookback + 2u * blockIdx.x + 1u, stampB | ((unsigned long long)t0 << 20) | t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -992,6 +1086,7 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
 #pragma unroll
     for (uint32_t w = 0; w < BT / 64u; w++) { baseA += sSumA[w]; baseB += sSumB[w]; }
     const uint32_t base0 = (uint32_t)baseA, base1 = (uint32_t)(baseA >> 32), base2 = base0 - base1;
+    FCLOCK(5);
     // ---- the commands ----
     if (vis) {
         ChordDrawCmd cmd;
@@ -1015,6 +1110,11 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
         line[2] = make_uint4(total0, q.doHzb ? total1 : 0u, q.doHzb ? total0 - total1 : 0u, 0u);                                                     // listCounts[0..3]
         line[3] = make_uint4(0u, 0u, 0u, 0u);                                                                                                        // listCounts[4..7]
     }
+#if RASTER_PROFILE
+    FCLOCK(6);
+    if (threadIdx.x == 0u) for (int i = 0; i < 7; i++) q.lookback[2048u + 8u * blockIdx.x + i] = fc[i];
+#endif
+#undef FCLOCK
 }
 
 // (Round 3: writing the list from the count kernel of short scenes -- every workgroup publishing its counts under a launch
@@ -1412,13 +1512,13 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     static const bool fusedOn = [] { const char* e = getenv("CHORDVIS_CULL_FUSED"); return !e || atoi(e) != 0; }();
     const HzbBuffers* fuseHzb = nullptr;
     bool fused = false;
-    if (CULL_FUSED && fusedOn && CULL_QUAD && !sh && !hier && c->inFrame && c->fuseCullFrame && out.cmds == c->lists[0].cmds && blocks + 1u <= (uint32_t)c->numCUs && blocks <= 512u &&
+    if (CULL_FUSED && fusedOn && CULL_QUAD && !sh && !hier && c->inFrame && c->fuseCullFrame && out.cmds == c->lists[0].cmds && blocks + 1u + (c->objectCount + FUSED_CULL_THREADS - 1u) / FUSED_CULL_THREADS <= (uint32_t)c->numCUs && blocks <= 512u &&
         !(c->debugFlags & ~(32768u | 65536u | 262144u))) {
         uint32_t tailFloats = 0;
         const ChordHZBDesc& hd = c->hzb[0].desc;
         for (uint32_t l = 6; l < hd.mipCount; l++) tailFloats += std::max(1u, hd.width >> l) * std::max(1u, hd.height >> l);
-        if (!c->dCullLookback && hipMalloc((void**)&c->dCullLookback, sizeof(unsigned long long) * 2u * 1024u) == hipSuccess)
-            (void)hipMemsetAsync(c->dCullLookback, 0, sizeof(unsigned long long) * 2u * 1024u, c->stream);
+        if (!c->dCullLookback && hipMalloc((void**)&c->dCullLookback, sizeof(unsigned long long) * (2048u + 8u * 1024u)) == hipSuccess)      // (look-back words; behind them the profile build's stage clocks)
+            (void)hipMemsetAsync(c->dCullLookback, 0, sizeof(unsigned long long) * (2048u + 8u * 1024u), c->stream);
         if (c->dCullLookback && tailFloats <= HZB_TAIL_FLOATS) { fused = true; fuseHzb = c->fuseCullHzb; }
     }
 #define LAUNCH_COUNT(FM, FUSED, grid, ...) do { if (sh) CHORD_LAUNCH(c, (group_cull_count_kernel<FM, true, FUSED>), grid, dim3(256), 0, c->stream, __VA_ARGS__); \
@@ -1450,7 +1550,8 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
         do { ++c->cullSerial; } while ((c->cullSerial & 0xFFFFFFu) == 0u);          // (a stamp of 0 would match words no launch has written)
         q.serial = c->cullSerial; q.doHzb = fuseHzb ? 1u : 0u;
         q.skipVec4First = (uint32_t)(offsetof(FrameState, counters.trisInstanceCulled) / 16u); q.skipVec4Count = 4u;
-        CHORD_LAUNCH(c, frame_cull_fused_kernel, dim3(blocks + tail.run), dim3(FUSED_CULL_THREADS), 0, c->stream,
+        q.objectCount = c->objectCount;
+        CHORD_LAUNCH(c, frame_cull_fused_kernel, dim3(blocks + tail.run + (c->objectCount + FUSED_CULL_THREADS - 1u) / FUSED_CULL_THREADS), dim3(FUSED_CULL_THREADS), 0, c->stream,
                      q, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4, blocks, tail);
         if (fuseHzb) { c->fusedCullDone = true; c->listMine[1] = c->listMine[2] = false; }
         c->viewDirty = false;
