@@ -45,7 +45,7 @@ for step in "$@"; do
       for rep in $(seq 1 ${a4:-2}); do for tag in product ${a1//,/ }; do for wl in ${a2//,/ }; do
         lib=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis.so; ev=_CALL_NOENV=1
         case "$tag" in product) ;; *=*) ev=$tag;; *) lib=$GRAFT_REPO_ROOT/chord_amd/_build/libchordvis_$tag.so;; esac     # (TAG with '=': an environment switch of the product library)
-        env $ev CHORDVIS_LIB=$lib python bench.py --workload $wl --steps ${a3:-200} --cpu-baseline-frames 0 --no-path 2>/dev/null | tee $OUT/ab_${tag}_${wl}_$rep.json | line "[$tag] $wl rep $rep"
+        env $ev CHORDVIS_LIB=$lib python bench.py --workload ${wl//+/ } --steps ${a3:-200} --cpu-baseline-frames 0 --no-path 2>/dev/null | tee $OUT/ab_${tag}_${wl}_$rep.json | line "[$tag] $wl rep $rep"
       done; done; done;;
     rank)
       ( cd /tmp && export TMPDIR=/tmp && env FRAMES=40 ${a4//+/ } rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/rank_$a1 -o r -- python $GRAFT_REPO_ROOT/tools/shard_rank.py $a1 $a2 $a3 > $GRAFT_REPO_ROOT/$OUT/rank_$a1.log 2>&1 )
