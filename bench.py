@@ -412,12 +412,17 @@ def measure(args, workload, env):
     clusters_per_pair = sum(pv["countStage0Visible"] + pv["countStage1Visible"] for pv in per_view)
 
     # ---- timed region --------------------------------------------------------------------------
-    # GPU timestamps (hipEvent on the launch stream): each event record costs ~5 us of stream idle time, 15 per frame inflate a
-    # frame by ~20 %.  Runs of 64 steps or more stamp every 8th step of the timed region; a shorter run (the driver's 20 steps) would
-    # carry that cost in 15 % of its frames, so its stamped frames -- eight of them -- are rendered right behind the timed region
-    # instead (same frames, same state, same stream): `stamped_inside_timed_region` says which it was.
-    stamp_inside = (args.steps >= 64 or world > 1) and not args.no_stamps
+    # GPU timestamps (hipEvent on the launch stream): each event record is a barrier packet that costs 3-5 us (the kernel behind it is
+    # not dispatched under the kernel in front), 15 per frame make a stamped frame ~28 % longer than a product frame.  N = 1: the
+    # stamped frames -- 8, or 16 behind runs of 64 steps or more -- are rendered right behind the timed region (same frames, same
+    # state, same stream); N > 1 (millisecond frames) stamps every 8th step inside it: `stamped_inside_timed_region` says which it was.
+    # (N = 1, round 6: NEVER inside the timed region -- one stamped frame in eight made a 200-step run 3.5 % slower than a 20-step one:
+    # 25 frames x 50 us of records in 35 ms; tools/host_time.py: the same 200 frames without a record run in 166.7 us each)
+    stamp_inside = world > 1 and not args.no_stamps
     r.enable_timers(2 if stamp_inside else 0, period=8)
+    if world == 1:
+        for i in range(16):                          # (the count read-backs above left the device idle: a few more untimed frames ahead of the clock)
+            frame(i)
     rank_elapsed, elapsed = timed(args.steps)
     # The per-kernel averages behind `roofline` come from hipEvent stamps on the launch stream.  Inside the timed region only every
     # 8th step is stamped (a stamped frame is ~20 % longer); a short run (the driver's 20 steps: 2-3 stamped frames) is topped
@@ -427,7 +432,7 @@ def measure(args, workload, env):
     st = r.stats()                                  # per-frame GPU timestamps averaged over the stamped steps of the timed region
     if stamped_in_region < 8 and world == 1 and not args.no_stamps:
         r.enable_timers(2, period=1)                # (restarts the accumulation)
-        extra = 8 - stamped_in_region
+        extra = (16 if args.steps >= 64 else 8) - stamped_in_region
         for i in range(extra):
             frame(args.steps + i)
         torch.cuda.synchronize(dev)
@@ -501,7 +506,7 @@ def measure(args, workload, env):
     stamp_cost_ms = 0.0
     if world == 1 and stamps_pf > 1.0 and st["msFrame"] > 0.0:
         over = st["msFrame"] - ms_per_step
-        if stamp_inside:
+        if stamp_inside:                                # (one frame in eight of the timed region itself was a stamped one)
             over *= 8.0 / 7.0
         stamp_cost_ms = max(0.0, over) / (stamps_pf - 1.0)
     raw_ms = {k: v[0] for k, v in kernels.items()}

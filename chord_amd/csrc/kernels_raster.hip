@@ -68,6 +68,7 @@ namespace chord {
 
 struct RasterParams {
     const uint32_t* count; const ChordDrawCmd* cmds;
+    uint32_t cmdCap;                                    // entries the list `cmds` has room for (>= 1): a wave may read its first command before it knows the count
     uint32_t* leftCount; ChordDrawCmd* leftCmds;         // clusters of a dense launch that do not become pixel blocks (raster_setup_blocks_kernel -> raster_setup_kernel), or NULL
     const DObjFrame* objFrame; const DObjStatic* objStatic;
     const DMeshlet* meshlets; const uint32_t* meshletData; const float* positions;
@@ -427,7 +428,7 @@ __device__ __forceinline__ void bin_store(const RasterParams& p, uint32_t tile, 
 struct BinTicket {
     uint32_t tileA[4], tileB[4], slotA[4], slotB[4];
     uint32_t has;                 // bit r: A has tile r, bit 4 + r: B
-    BinElect eA, eB;
+    uint32_t eA[4], eB[4];        // per tile slot r: leader lane | rank among the wave's lanes with the same tile << 8 (wave_bin_elect)
 };
 
 template <class P>
@@ -449,24 +450,26 @@ __device__ __forceinline__ void wave_bin_issue(const P& p, bool emitA, const Tri
         if (tile_of(tsA, r, emitA, k.tileA[r])) k.has |= 1u << r;
         if (tile_of(tsB, r, emitB, k.tileB[r])) k.has |= 16u << r;
     }
-    k.eA = wave_bin_elect((k.has & 1u) != 0u, k.tileA[0], lane);
-    k.eB = wave_bin_elect((k.has & 16u) != 0u, k.tileB[0], lane);
-    if ((k.has & 1u) && (int)lane == k.eA.leader) k.slotA[0] = atomicAdd(&p.tileCount[(size_t)k.tileA[0] * TC_STRIDE], k.eA.group);
-    if ((k.has & 16u) && (int)lane == k.eB.leader) k.slotB[0] = atomicAdd(&p.tileCount[(size_t)k.tileB[0] * TC_STRIDE], k.eB.group);
+    // ONE atomic per distinct tile of the wave, for the primary tile of a record AND for the up to three further tiles of a record that
+    // straddles a tile boundary.  (Until round 6 the further tiles were reserved by every lane for itself: 18 % of config 3's bin entries,
+    // 85 k returning atomics per frame against 12 k leader atomics, a straddling cluster's 30-60 of them on ONE counter line in one
+    // wave instruction -- a line retires ~88 per microsecond: the reservation round trip was 8 of the 19.5 us a cluster took in config
+    // 3's first pass, tools/setup_profile.py.)
 #pragma unroll
-    for (int r = 1; r < 4; r++) {
-        if (k.has & (1u << r)) k.slotA[r] = atomicAdd(&p.tileCount[(size_t)k.tileA[r] * TC_STRIDE], 1u);
-        if (k.has & (16u << r)) k.slotB[r] = atomicAdd(&p.tileCount[(size_t)k.tileB[r] * TC_STRIDE], 1u);
+    for (int r = 0; r < 4; r++) {
+        const BinElect a = wave_bin_elect((k.has & (1u << r)) != 0u, k.tileA[r], lane);
+        const BinElect b = wave_bin_elect((k.has & (16u << r)) != 0u, k.tileB[r], lane);
+        k.eA[r] = (uint32_t)a.leader | a.rank << 8; k.eB[r] = (uint32_t)b.leader | b.rank << 8;
+        if ((k.has & (1u << r)) && (int)lane == a.leader) k.slotA[r] = atomicAdd(&p.tileCount[(size_t)k.tileA[r] * TC_STRIDE], a.group);
+        if ((k.has & (16u << r)) && (int)lane == b.leader) k.slotB[r] = atomicAdd(&p.tileCount[(size_t)k.tileB[r] * TC_STRIDE], b.group);
     }
     if (masked) {
         // an alpha-tested cluster: the tiles its triangles are binned into are work items of the masked pass (a flag per tile, plain
         // stores of the same value: one per distinct primary tile of the wave, one per straddled tile of a lane)
-        if ((k.has & 1u) && (int)lane == k.eA.leader) p.tileCount[(size_t)k.tileA[0] * TC_STRIDE + TC_MASKED] = 1u;
-        if ((k.has & 16u) && (int)lane == k.eB.leader) p.tileCount[(size_t)k.tileB[0] * TC_STRIDE + TC_MASKED] = 1u;
 #pragma unroll
-        for (int r = 1; r < 4; r++) {
-            if (k.has & (1u << r)) p.tileCount[(size_t)k.tileA[r] * TC_STRIDE + TC_MASKED] = 1u;
-            if (k.has & (16u << r)) p.tileCount[(size_t)k.tileB[r] * TC_STRIDE + TC_MASKED] = 1u;
+        for (int r = 0; r < 4; r++) {
+            if ((k.has & (1u << r)) && lane == (k.eA[r] & 0xFFu)) p.tileCount[(size_t)k.tileA[r] * TC_STRIDE + TC_MASKED] = 1u;
+            if ((k.has & (16u << r)) && lane == (k.eB[r] & 0xFFu)) p.tileCount[(size_t)k.tileB[r] * TC_STRIDE + TC_MASKED] = 1u;
         }
     }
 }
@@ -476,8 +479,11 @@ __device__ __forceinline__ void wave_bin_issue(const P& p, bool emitA, const Tri
 template <class P>
 __device__ __forceinline__ void wave_bin_commit(const P& p, BinTicket& k, bool okA, uint32_t giA, bool okB, uint32_t giB)
 {
-    k.slotA[0] = __shfl(k.slotA[0], k.eA.leader, 64) + k.eA.rank;
-    k.slotB[0] = __shfl(k.slotB[0], k.eB.leader, 64) + k.eB.rank;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        k.slotA[r] = __shfl(k.slotA[r], (int)(k.eA[r] & 0xFFu), 64) + (k.eA[r] >> 8);
+        k.slotB[r] = __shfl(k.slotB[r], (int)(k.eB[r] & 0xFFu), 64) + (k.eB[r] >> 8);
+    }
     // all eight slots of a lane were drawn together (wave_bin_issue): every chunk allocation they owe comes before
     // the first wait -- a wait ahead of a later allocation could close a cycle between two waves (each waiting for a
     // chunk the other allocates in a later step), which costs 2^20 spins and drops entries.  A record that did not fit
@@ -736,8 +742,12 @@ enum { K_NONE = 0, K_EMIT = 1, K_CLIP = 2 };
 #define DBG_FORCE_HOT 262144u    // the block kernel's hot-tile variant whatever the hint says, tiles hot from 64 entries (tests: small scenes)
 
 // cmds / count: the list this launch sets up (the input list, or what the block kernel left over: raster_setup_kernel).
+// firstCmd: the three words of THIS wave's first command (index blockIdx.x * 4 + wave), requested by the caller together with the count
+// -- one round trip instead of two in front of everything else a wave does (a short list is one cluster per wave: the kernel is the
+// chain count -> command -> records -> indices -> positions -> matrix -> reservations, seven dependent round trips until round 6).
 template <bool MASKED>
-__device__ __forceinline__ void raster_setup_body(const RasterParams& p, const ChordDrawCmd* __restrict__ cmds, const uint32_t count, float (*sVert)[4][LDS_VERTS])
+__device__ __forceinline__ void raster_setup_body(const RasterParams& p, const ChordDrawCmd* __restrict__ cmds, const uint32_t count, float (*sVert)[4][LDS_VERTS],
+                                                  const uint32_t firstCmd0, const uint32_t firstCmd1, const uint32_t firstCmd2, const bool firstCmdValid)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* lX = sVert[0][wave]; float* lY = sVert[1][wave]; float* lW = sVert[2][wave];
@@ -755,11 +765,9 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
     };
     // (scalar loads through the constant address space: the addresses are wave-uniform, and a vector load + v_readfirstlane per
     // dword was 26 VALU instructions per header -- the record kernel is bound by VALU issue on dense scenes like the block kernel)
-    auto load_header = [&](uint32_t i) -> Header {
-        const uint32_t k = __builtin_amdgcn_readfirstlane(min(i, count - 1u));
+    auto header_of = [&](uint32_t objectId, uint32_t meshletId, uint32_t slot) -> Header {
         Header h;
-        const uint32_t* __restrict__ cw = reinterpret_cast<const uint32_t*>(cmds + k);
-        h.objectId = scalar_load(cw); h.meshletId = scalar_load(cw + 1); h.slot = scalar_load(cw + 2);
+        h.objectId = objectId; h.meshletId = meshletId; h.slot = slot;
         const RasterParams* q = kernel_args();                  // (scene pointers: read where they are used, not held across the loop)
         const DMeshlet* __restrict__ mm = &scalar_load(&q->meshlets)[h.meshletId];
         const uint32_t vt = scalar_load(&mm->vertexTriangleCount);
@@ -770,6 +778,11 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
         h.twoSided = (h.matFlags & CHORD_MATFLAG_TWO_SIDED) != 0u;
         if (CHORD_MATFLAG_ALPHA(h.matFlags) >= CHORD_ALPHA_BLEND) h.T = 0u;   // blended: in no bucket of renderMesh (mesh_raster.cpp:224)
         return h;
+    };
+    auto load_header = [&](uint32_t i) -> Header {
+        const uint32_t k = __builtin_amdgcn_readfirstlane(min(i, count - 1u));
+        const uint32_t* __restrict__ cw = reinterpret_cast<const uint32_t*>(cmds + k);
+        return header_of(scalar_load(cw), scalar_load(cw + 1), scalar_load(cw + 2));
     };
     // (the object's matrix is fetched where the cluster's vertex phase starts, not an iteration ahead with the header: sixteen
     // more scalars alive across a whole cluster are lane spills -- a v_readlane each -- in a loop that sits at its 102 SGPRs)
@@ -790,8 +803,11 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
     const uint32_t stride = gridDim.x * 4u;
     uint32_t c = blockIdx.x * 4u + wave;
     if (c >= count) return;
-    Header hdr = load_header(c);
+    Header hdr = firstCmdValid ? header_of(firstCmd0, firstCmd1, firstCmd2) : load_header(c);
     Header hdrN = load_header(c + stride);
+    // (the first cluster's matrix travels with its index stream: behind it, a cluster's matrix is asked for while the cluster before it
+    // stores its records -- see the end of the loop)
+    Mat4 mvpNext = mvp_of(hdr.objectId);
     // geometry of the current cluster: vertices lane and lane + 64 (indices, then positions), triangle words
     uint32_t t0 = 0, t1 = 0;
     float pax, pay, paz, pbx, pby, pbz;
@@ -818,7 +834,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
         const uint32_t slot = hdr.slot, V = hdr.V, T = hdr.T, dataOffset = hdr.dataOffset, vertexBase = hdr.vertexBase;
         const bool twoSided = hdr.twoSided || p.depthOnly != 0u;                       // depth passes: cull mode NONE (mesh_raster.cpp:188-190)
         const bool masked = MASKED && CHORD_MATFLAG_ALPHA(hdr.matFlags) == CHORD_ALPHA_MASK;      // (wave-uniform)
-        const Mat4 mvp = mvp_of(hdr.objectId);
+        const Mat4 mvp = mvpNext;
         const uint32_t triWord[2] = {t0, t1};
 
         if (sprof) { volatile uint32_t sink = V + T; (void)sink; }
@@ -954,6 +970,7 @@ __device__ __forceinline__ void raster_setup_body(const RasterParams& p, const C
             if (emA | emB) wave_bin_issue(e, kindA == K_EMIT && !lgA, tsA, kindB == K_EMIT && !lgB, tsB, lane, ticket, MASKED && masked);
             cbase = bcast(cbase, 0); ebaseC = bcast(ebaseC, 0); ebaseW = bcast(ebaseW, 0); lbase = bcast(lbase, 0);
             SPHASE(3);
+            mvpNext = mvp_of(hdrN.objectId);              // (the next cluster's matrix: on its way while this one's records are stored)
             if (kindA == K_CLIP) {
                 const uint32_t k = cbase + (uint32_t)__popcll(cmA & lt);
                 if (k < e.clipTriCap) { ClipTri ct; ct.objectId = hdr.objectId; ct.meshletId = hdr.meshletId; ct.slot = hdr.slot; ct.tri = lane; e.clipTris[k] = ct; }
@@ -1478,10 +1495,15 @@ template <bool MASKED>
 __global__ __launch_bounds__(256, MASKED ? SETUP_MASKED_WAVES : SETUP_MIN_WAVES) void raster_setup_kernel(RasterParams p)   // (masked: twelve more live registers, see uvA)
 {
     __shared__ float sVert[6][4][LDS_VERTS];                   // x, y, w, u, v, depth of a wave's cluster (24 KB)
+    // the wave's first command is asked for TOGETHER with the count (the list has room for the index whatever the count turns out to be)
+    const uint32_t c0 = __builtin_amdgcn_readfirstlane(min(blockIdx.x * 4u + (threadIdx.x >> 6), p.cmdCap - 1u));
+    const uint32_t* __restrict__ cw = reinterpret_cast<const uint32_t*>(p.cmds + c0);
+    const uint32_t f0 = scalar_load(cw), f1 = scalar_load(cw + 1), f2 = scalar_load(cw + 2);
     uint32_t count = *p.count;
     const ChordDrawCmd* cmds = p.cmds;
-    if (launch_is_dense(p, count)) { count = *p.leftCount; cmds = p.leftCmds; }
-    raster_setup_body<MASKED>(p, cmds, count, sVert);
+    bool firstValid = true;
+    if (launch_is_dense(p, count)) { count = *p.leftCount; cmds = p.leftCmds; firstValid = false; }   // (what the block kernel left over: another list)
+    raster_setup_body<MASKED>(p, cmds, count, sVert, f0, f1, f2, firstValid);
 }
 
 // HOT: the variant that draws bin slots ahead on hot tiles (above).  It costs the plain kernel's loop 3 % (registers: the loop
@@ -3264,7 +3286,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         p.hzbExA = (clearTiles && c->fuseHzbTemp) ? c->dHzbExchange : nullptr;
         p.hzbExB = c->dHzbFinalExchange;
     }
-    p.count = in.count; p.cmds = in.cmds;
+    p.count = in.count; p.cmds = in.cmds; p.cmdCap = std::max(in.capacity, 1u);
     if (c->shard.ranks > 1) {
         // sharded frame: only the clusters that touch this rank's screen tiles reach the setup kernel.  The lists of a frame
         // are the rank's own already (the group cull writes the rank's share of list 0 beside the full list; the HZB culls
