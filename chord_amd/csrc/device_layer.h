@@ -25,7 +25,7 @@
 #define RASTER_ABLATION 0
 #endif
 #define CHORD_DEBUG_PROFILE_BITS (16u | 512u)
-#define CHORD_DEBUG_ABLATION_BITS (1u | 2u | 32u | 64u | 128u | 256u | 1024u | 2048u | 4096u | 8192u | 16384u)
+#define CHORD_DEBUG_ABLATION_BITS (1u | 2u | 32u | 64u | 128u | 256u | 1024u | 2048u | 4096u | 8192u | 16384u | 1048576u | 2097152u)
 
 namespace chord {
 

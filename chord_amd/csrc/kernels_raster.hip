@@ -137,6 +137,8 @@ struct RasterParams {
 #define DBG_NO_ENTRY    8192u // tile kernel fetches bin entries and records but does nothing with them
 #define DBG_NO_BATCH    16384u // tile kernel skips the bin altogether (tile in + tile out only)
 #define DBG_NO_UNITS    4096u // tile kernel skips the row units (entries are still fetched, set up, scanned and listed)
+#define DBG_SKIP_LIGHT  1048576u // tile kernel: work items of tiles with fewer than 64 bin entries end at once (what the light tiles cost the pass)
+#define DBG_SKIP_HEAVY  2097152u // ... of tiles with 64 entries or more
 
 // Scalar loads and the kernel arguments re-read at their point of use.  The raster kernels take ONE by-value RasterParams; the
 // compiler loads every field a kernel touches into scalar registers up front and keeps it there, and the loops of these
@@ -2743,6 +2745,8 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         countWord = min(cnt.x, bin_capacity(p)) | (cnt.y ? 0x80000000u : 0u);
     }
     const uint32_t nAll = countWord & 0x3FFFFFFFu;                // (already clamped to the bin capacity)
+    if (ABL(p, DBG_SKIP_LIGHT) && nAll < 64u) continue;
+    if (ABL(p, DBG_SKIP_HEAVY) && nAll >= 64u) continue;
     if (direct) {
         // a later pass of the frame touches a fraction of the tiles (config 3: 436 of 2 040): the others' workgroups end here, one round
         // trip after their start, and the touched ones have saved the trip to a work list -- what raster_tile_order_kernel cost the
