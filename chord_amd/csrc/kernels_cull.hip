@@ -694,6 +694,7 @@ struct HzbCullParams {
     uint32_t* visCount; ChordDrawCmd* visCmds;
     uint32_t* rejCount; ChordDrawCmd* rejCmds;
     DeviceCounters* counters;
+    uint32_t inCapacity;                   // entries the input list has room for (a command may be read ahead of the count)
 };
 
 // The tail of the min chain (levels 6.. from the stored level 5: 60 x 34 texels at 4K) reduced by the calling block into
@@ -895,7 +896,11 @@ struct FusedCullParams {
     uint32_t* tailLine;                    // the 64-byte line the last workgroup writes: {trisInstanceCulled, trisHzbVisible0, trisHzbVisible1, pad2} (u64) + listCounts[8]
     uint32_t serial, doHzb, skipVec4First, skipVec4Count, objectCount;
 };
-#define FUSED_CULL_THREADS 1024u
+#ifndef FUSED_CULL_THREADS
+#define FUSED_CULL_THREADS 256u            // a workgroup = 64 group instances, one wave per SIMD of its CU (1024: sixteen waves on one CU, A/B builds)
+#endif
+#define FUSED_CULL_GROUPS (FUSED_CULL_THREADS / 4u)
+#define FUSED_CULL_MAX_BLOCKS 1024u        // look-back words of the buffer
 
 __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(FusedCullParams q, const DView dv, DView* __restrict__ dviewOut,
                                                                             DObjFrame* __restrict__ objFrameOut, uint4* __restrict__ zeroBase, uint32_t zeroVec4,
@@ -916,7 +921,7 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
     __shared__ unsigned long long sSumA[BT / 64u], sSumB[BT / 64u];
     const GroupCullParams& p = q.g;
     const uint32_t qi = threadIdx.x & 3u;
-    const uint32_t t = blockIdx.x * 256u + (threadIdx.x >> 2);
+    const uint32_t t = blockIdx.x * FUSED_CULL_GROUPS + (threadIdx.x >> 2);
     // grid: [0, cullBlocks) the tests; then, when there is one, the workgroup of the previous frame's HZB tail; then the object pass
     const bool tailBlock = tail.run && blockIdx.x == cullBlocks;
     if (blockIdx.x >= cullBlocks + tail.run) {
@@ -1064,19 +1069,19 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
         __hip_atomic_store(q.lookback + 2u * blockIdx.x, stampA | n0 | (n1 << 11), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(q.lookback + 2u * blockIdx.x + 1u, stampB | ((unsigned long long)t0 << 20) | t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    unsigned long long pa = 0, pb = 0;                                     // (n0 | n1 << 32), (t0 | t1 << 32) of workgroup threadIdx.x
-    if (threadIdx.x < blockIdx.x) {
+    unsigned long long pa = 0, pb = 0;                                     // (n0 | n1 << 32), (t0 | t1 << 32) of the workgroups threadIdx.x, threadIdx.x + BT, ..
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += BT) {
         unsigned long long a = 0, b = 0;
         uint32_t spins = 0;
         for (;;) {
-            a = __hip_atomic_load(q.lookback + 2u * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            b = __hip_atomic_load(q.lookback + 2u * threadIdx.x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a = __hip_atomic_load(q.lookback + 2u * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = __hip_atomic_load(q.lookback + 2u * j + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((a & 0xFFFFFFFF00000000ull) == stampA && (b & 0xFFFFFF0000000000ull) == stampB) break;
             if (++spins > (1u << 22)) { atomicOr(&q.h.counters->overflow, 16u); a = 0; b = 0; break; }
             __builtin_amdgcn_s_sleep(2);
         }
-        pa = (a & 0x7FFull) | (((a >> 11) & 0x7FFull) << 32);
-        pb = ((b >> 20) & 0xFFFFFull) | ((b & 0xFFFFFull) << 32);
+        pa += (a & 0x7FFull) | (((a >> 11) & 0x7FFull) << 32);
+        pb += ((b >> 20) & 0xFFFFFull) | ((b & 0xFFFFFull) << 32);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { pa += __shfl_down(pa, off, 64); pb += __shfl_down(pb, off, 64); }
@@ -1211,6 +1216,24 @@ __global__ __launch_bounds__(THREADS) void hzb_cull_kernel(HzbCullParams p)
     const uint32_t count = *p.inCount;
     const DView& dv = *p.dview;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // OCT (short lists: one step per workgroup): the octet's command is asked for TOGETHER with the count, and the two records it names
+    // -- the meshlet's bounds, the object's projection -- before the tail reduction below: a chain count -> command -> records ->
+    // texels of four dependent round trips behind the reduction's own becomes two beside it.
+    ChordDrawCmd cmdF = ChordDrawCmd{0, 0, 0};
+    DMeshlet mF;
+    Mat4 mvpF;
+    if (OCT) {
+        const uint32_t i = blockIdx.x * CPB + (threadIdx.x >> 3);
+        if (p.inCapacity) cmdF = p.inCmds[min(i, p.inCapacity - 1u)];     // (an entry past the count is whatever an earlier launch left: not used)
+        if (i < count) {
+            mF = p.meshlets[cmdF.meshletId];
+            const float* src = PHASE == 0 ? p.objFrame[cmdF.objectId].mvpLast : p.objFrame[cmdF.objectId].mvp;         // hzb_mainview_culling.hlsl:77-83
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) mvpF.r[r][cc] = src[r * 4 + cc];
+        }
+    }
     // TAIL: the chain this launch culls against has its levels 0..5 in memory; every block with work reduces the rest
     // itself (block 0 also stores them)
     if (TAIL && (blockIdx.x * CPB < count || blockIdx.x == 0u) && (dv.flags & CHORD_FLAG_HZB_CULL))
@@ -1222,9 +1245,18 @@ __global__ __launch_bounds__(THREADS) void hzb_cull_kernel(HzbCullParams p)
             const uint32_t i = base + (threadIdx.x >> 3), sub = threadIdx.x & 7u;
             cmd[0] = ChordDrawCmd{0, 0, 0};
             if (i < count) {                                        // (the same for the eight lanes of an octet)
-                cmd[0] = p.inCmds[i];
-                uint32_t t = 0;
-                const bool vis = hzb_cmd_visible<PHASE, TAIL, true>(p, dv, cmd[0], t, sTail, sTailOff, sub);
+                if (base != blockIdx.x * CPB) {                     // (a later step of a list longer than the grid: its records now)
+                    cmdF = p.inCmds[i];
+                    mF = p.meshlets[cmdF.meshletId];
+                    const float* src = PHASE == 0 ? p.objFrame[cmdF.objectId].mvpLast : p.objFrame[cmdF.objectId].mvp;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int cc = 0; cc < 4; cc++) mvpF.r[r][cc] = src[r * 4 + cc];
+                }
+                cmd[0] = cmdF;
+                const uint32_t t = (mF.vertexTriangleCount >> 8) & 0xFFu;
+                const bool vis = hzb_bounds_visible<PHASE, TAIL, true>(p, dv, mvpF, mF, sTail, sTailOff, sub);
                 if (sub == 0u) { if (vis) { visBits = 1u; tris = t; } else rejBits = 1u; }   // lane 0 of the octet counts and stores the command
             }
         } else
@@ -1385,7 +1417,7 @@ static HzbCullParams make_hzb_cull_params(ChordCtx* c, const HzbBuffers& hzb, co
     HzbCullParams p;
     p.objFrame = c->dObjFrame; p.meshlets = c->dMeshlets; p.dview = c->dView;
     p.hzbMin = hzb.minTexels; p.desc = hzb.desc; p.hzbTailOut = hzb.minTexels;
-    p.inCount = in.count; p.inCmds = in.cmds;
+    p.inCount = in.count; p.inCmds = in.cmds; p.inCapacity = in.capacity;
     p.visCount = outVisible.count; p.visCmds = outVisible.cmds;
     p.rejCount = outRejected ? outRejected->count : nullptr;
     p.rejCmds = outRejected ? outRejected->cmds : nullptr;
@@ -1512,7 +1544,11 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     static const bool fusedOn = [] { const char* e = getenv("CHORDVIS_CULL_FUSED"); return !e || atoi(e) != 0; }();
     const HzbBuffers* fuseHzb = nullptr;
     bool fused = false;
-    if (CULL_FUSED && fusedOn && CULL_QUAD && !sh && !hier && c->inFrame && c->fuseCullFrame && out.cmds == c->lists[0].cmds && blocks + 1u + (c->objectCount + FUSED_CULL_THREADS - 1u) / FUSED_CULL_THREADS <= (uint32_t)c->numCUs && blocks <= 512u &&
+    // (its own workgroup size: fblocks workgroups of FUSED_CULL_GROUPS group instances; a workgroup waits for those in front of it only,
+    // which were dispatched before it -- the bound on the grid is the look-back buffer and what a short scene is, not residency)
+    const uint32_t fblocks = (c->groupInstances + FUSED_CULL_GROUPS - 1u) / FUSED_CULL_GROUPS;
+    const uint32_t fobj = (c->objectCount + FUSED_CULL_THREADS - 1u) / FUSED_CULL_THREADS;
+    if (CULL_FUSED && fusedOn && CULL_QUAD && !sh && !hier && c->inFrame && c->fuseCullFrame && out.cmds == c->lists[0].cmds && fblocks + 1u + fobj <= (uint32_t)c->numCUs * (1024u / FUSED_CULL_THREADS) && fblocks <= FUSED_CULL_MAX_BLOCKS && blocks <= 512u &&
         !(c->debugFlags & ~(32768u | 65536u | 262144u))) {
         uint32_t tailFloats = 0;
         const ChordHZBDesc& hd = c->hzb[0].desc;
@@ -1551,8 +1587,8 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
         q.serial = c->cullSerial; q.doHzb = fuseHzb ? 1u : 0u;
         q.skipVec4First = (uint32_t)(offsetof(FrameState, counters.trisInstanceCulled) / 16u); q.skipVec4Count = 4u;
         q.objectCount = c->objectCount;
-        CHORD_LAUNCH(c, frame_cull_fused_kernel, dim3(blocks + tail.run + (c->objectCount + FUSED_CULL_THREADS - 1u) / FUSED_CULL_THREADS), dim3(FUSED_CULL_THREADS), 0, c->stream,
-                     q, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4, blocks, tail);
+        CHORD_LAUNCH(c, frame_cull_fused_kernel, dim3(fblocks + tail.run + fobj), dim3(FUSED_CULL_THREADS), 0, c->stream,
+                     q, c->hView, publish, c->dObjFrame, zeroBase, zeroVec4, fblocks, tail);
         if (fuseHzb) { c->fusedCullDone = true; c->listMine[1] = c->listMine[2] = false; }
         c->viewDirty = false;
         c->fullListStale = false;
@@ -1657,18 +1693,24 @@ void launch_hzb_cull(ChordCtx* c, const HzbBuffers& hzb, int phase, const CmdLis
     const uint32_t maxBlocks = (uint32_t)c->numCUs * (longList ? 2u : 8u);
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks < 1) blocks = 1;
-    // short lists: eight lanes per command, 128 commands per 1 024-thread workgroup (HZB_CULL_OCT)
-    const uint32_t octBlocks = std::max(1u, std::min((in.capacity + 127u) / 128u, (uint32_t)c->numCUs * 8u));
+    // short lists: eight lanes per command, 32 commands per 256-thread workgroup (HZB_CULL_OCT) -- one wave per SIMD of a CU: a list of
+    // a few thousand commands is a few dozen workgroups, and a wave that shares its SIMD with three others of the same chain issues
+    // every 6.6 cycles instead of every 4.6 (tools/microbench/valu_issue)
+#ifndef HZB_OCT_THREADS
+#define HZB_OCT_THREADS 256u
+#endif
+    constexpr uint32_t OT = HZB_OCT_THREADS;
+    const uint32_t octBlocks = std::max(1u, std::min((in.capacity + OT / 8u - 1u) / (OT / 8u), (uint32_t)c->numCUs * 8u * (1024u / OT)));
     if (phase == 0) { if (longList)          CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
-                      else if (HZB_CULL_OCT) CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false, 1024u, true>), dim3(octBlocks), dim3(1024), 0, c->stream, p);
+                      else if (HZB_CULL_OCT) CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false, OT, true>), dim3(octBlocks), dim3(OT), 0, c->stream, p);
                       else                   CHORD_LAUNCH(c, (hzb_cull_kernel<0, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
     else if (c->hzbTailInCull) {
         // (inside chordvis_render_frame: the tile kernel wrote levels 0..5 of this chain; no hzb_tail_kernel ran)
         if (longList)          CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
-        else if (HZB_CULL_OCT) CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true, 1024u, true>), dim3(octBlocks), dim3(1024), 0, c->stream, p);
+        else if (HZB_CULL_OCT) CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true, OT, true>), dim3(octBlocks), dim3(OT), 0, c->stream, p);
         else                   CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, true>), dim3(blocks), dim3(256), 0, c->stream, p);
     } else          { if (longList)          CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false, 1024u>), dim3(blocks), dim3(1024), 0, c->stream, p);
-                      else if (HZB_CULL_OCT) CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false, 1024u, true>), dim3(octBlocks), dim3(1024), 0, c->stream, p);
+                      else if (HZB_CULL_OCT) CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false, OT, true>), dim3(octBlocks), dim3(OT), 0, c->stream, p);
                       else                   CHORD_LAUNCH(c, (hzb_cull_kernel<1, 1u, false>), dim3(blocks), dim3(256), 0, c->stream, p); }
 }
 
