@@ -619,6 +619,7 @@ int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
         if (ob.GLTFMaterialData >= (1u << 24)) return fail(c, CHORDVIS_E_CAPACITY, "upload_scene: more than 2^24 materials");
         d.shadingType = s->materials[ob.GLTFMaterialData].materialType;
         d.groupBase = (uint32_t)groupInst;
+        for (int i = 0; i < 3; i++) { d.posMin[i] = c->hPrims[d.prim].posMin[i]; d.posMax[i] = c->hPrims[d.prim].posMax[i]; }
         groupInst += c->hPrims[d.prim].groupCount;
         cmdCap += primMeshlets[d.prim];
         instTriangles += primTriangles[d.prim];

@@ -59,12 +59,15 @@ struct DMeshlet {              // GPUGLTFMeshlet with dataOffset globalised and 
     float    coneApex[3]; uint32_t vertexBase;      // asset vertex base + primitive.vertexOffset
 };
 
-struct DObjStatic {            // per object, derived once per upload, 16 B
+struct DObjStatic {            // per object, derived once per upload, 48 B
     uint32_t prim;
     uint32_t matFlags;         // bit 0 bTwoSided, bits 1-2 alphaMode (0 opaque, 1 mask, 2 blend), bits 8.. material index
     uint32_t groupBase;        // first flattened (object, group) index
     uint32_t shadingType;      // materials[object.GLTFMaterialData].materialType (visibility_tile.hlsl:56-60)
+    float    posMin[3]; uint32_t pad0;   // the primitive's bounds (DPrim::posMin / posMax) beside the object: one dependent fetch less for
+    float    posMax[3]; uint32_t pad1;   // whoever tests the object's box with only the object's index in hand (frame_cull_fused_kernel)
 };
+static_assert(sizeof(DObjStatic) == 48, "DObjStatic");
 
 #define CHORD_MATFLAG_TWO_SIDED 1u
 #define CHORD_MATFLAG_ALPHA(f) (((f) >> 1) & 3u)

@@ -704,10 +704,55 @@ struct HzbCullParams {
 // level l, stored at the level's full pitch like the chain in memory.
 #define HZB_TAIL_FIRST 6u
 #define HZB_TAIL_FLOATS 1408u              // a 4096^2 target (the largest): 32^2 + 16^2 + 8^2 + 4^2 + 2^2 + 1 = 1365
-__device__ __forceinline__ void hzb_tail_to_lds(const uint16_t* __restrict__ hzbMin, uint16_t* out, const ChordHZBDesc& d, float* sTail, uint32_t* sOff, uint32_t threads = 256u)
+// (in two parts for callers that have other fetches to wait for: hzb_tail_fetch asks for the level-5 texels of the thread's level-6
+// texels -- at most four of them per thread of a 256-thread workgroup -- and hzb_tail_to_lds takes them when it is handed them)
+struct HzbTailRegs { uint16_t t[4][4]; };
+__device__ __forceinline__ void hzb_tail_fetch(const uint16_t* __restrict__ hzbMin, const ChordHZBDesc& d, uint32_t threads, HzbTailRegs& r)
+{
+    const uint32_t l = HZB_TAIL_FIRST;
+    if (l >= d.mipCount) return;
+    const uint32_t vw = valid_w(d, l), vh = valid_h(d, l);
+    const uint32_t gw = valid_w(d, l - 1), gh = valid_h(d, l - 1), pmw = max(1u, d.width >> (l - 1));
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t i = threadIdx.x + k * threads;
+        if (i < vw * vh) {
+            const uint32_t x = i % vw, y = i / vw;
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                for (int ii = 0; ii < 2; ii++) {
+                    const uint32_t cx = min(2u * x + ii, gw - 1u), cy = min(2u * y + jj, gh - 1u);
+                    r.t[k][jj * 2 + ii] = hzbMin[d.mipOffset[l - 1] + cy * pmw + cx];
+                }
+        }
+    }
+}
+__device__ __forceinline__ void hzb_tail_to_lds(const uint16_t* __restrict__ hzbMin, uint16_t* out, const ChordHZBDesc& d, float* sTail, uint32_t* sOff, uint32_t threads = 256u,
+                                                const HzbTailRegs* fetched = nullptr)
 {
     uint32_t off = 0, poff = 0;
-    for (uint32_t l = HZB_TAIL_FIRST; l < d.mipCount; l++) {
+    uint32_t l0 = HZB_TAIL_FIRST;
+    if (fetched && l0 < d.mipCount && valid_w(d, l0) * valid_h(d, l0) <= 4u * threads) {
+        // level 6 from the texels already in registers (same taps, same order as the loop below)
+        const uint32_t vw = valid_w(d, l0), vh = valid_h(d, l0), mw = max(1u, d.width >> l0), mh = max(1u, d.height >> l0);
+        if (threadIdx.x == 0) sOff[l0] = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t i = threadIdx.x + k * threads;
+            if (i < vw * vh) {
+                const uint32_t x = i % vw, y = i / vw;
+                float mn = f16_to_f32(fetched->t[k][0]);
+                mn = fminf(mn, f16_to_f32(fetched->t[k][1])); mn = fminf(mn, f16_to_f32(fetched->t[k][2])); mn = fminf(mn, f16_to_f32(fetched->t[k][3]));
+                sTail[y * mw + x] = mn;
+                if (out) out[d.mipOffset[l0] + y * mw + x] = f32_to_f16(mn);
+            }
+        }
+        off = mw * mh;
+        l0++;
+        __syncthreads();
+    }
+    for (uint32_t l = l0; l < d.mipCount; l++) {
         const uint32_t vw = valid_w(d, l), vh = valid_h(d, l), mw = max(1u, d.width >> l), mh = max(1u, d.height >> l);
         const uint32_t gw = valid_w(d, l - 1), gh = valid_h(d, l - 1), pmw = max(1u, d.width >> (l - 1));
         if (threadIdx.x == 0) sOff[l] = off;
@@ -938,6 +983,9 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
     // projection for the occlusion test -- they work out among themselves, one piece per lane (the pieces of object_frame, the same
     // arithmetic), and hand round by DPP.  tc: lanes past the list compute on its last entry (all lanes stay active: DPP) and emit nothing.
     const uint32_t tc = min(t, max(p.groupInstances, 1u) - 1u);
+    // (level 5 of the history chain, for the tail reduction below: asked for first, it is there when the group's records are)
+    HzbTailRegs tailRegs;
+    if (q.doHzb && !tailBlock) hzb_tail_fetch(q.h.hzbMin, q.h.desc, BT, tailRegs);
     DGroupRef refQ; DGroup gQ; Mat4 MQ, roleQ; DMeshlet mQ; uint32_t matFlagsQ = 0u;
     float scaleQ = 0.0f, pmnQ[3] = {0.0f, 0.0f, 0.0f}, pmxQ[3] = {0.0f, 0.0f, 0.0f};
     refQ.object = 0u; refQ.group = 0u;
@@ -953,9 +1001,9 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
         roleQ = load_mat(qi == 1u ? obj.basicData.translatedWorldToLocal : obj.basicData.localToTranslatedWorldLastFrame);
         scaleQ = obj.basicData.scaleExtractFromMatrix[3];
         if (qi == 2u && (dv.flags & CHORD_FLAG_FRUSTUM_CULL)) {
-            const DPrim& prim = p.prims[p.objStatic[refQ.object].prim];
+            const DObjStatic& st = p.objStatic[refQ.object];       // (the primitive's bounds, copied beside the object at upload: no third fetch)
 #pragma unroll
-            for (int i = 0; i < 3; i++) { pmnQ[i] = prim.posMin[i]; pmxQ[i] = prim.posMax[i]; }
+            for (int i = 0; i < 3; i++) { pmnQ[i] = st.posMin[i]; pmxQ[i] = st.posMax[i]; }
         }
     }
     if (tailBlock) {
@@ -972,7 +1020,7 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
         if (i - q.skipVec4First >= q.skipVec4Count) zeroBase[i] = make_uint4(0u, 0u, 0u, 0u);
     FCLOCK(1);
     // levels 6.. of the history chain into LDS, while the records above are on their way
-    if (q.doHzb) hzb_tail_to_lds(q.h.hzbMin, nullptr, q.h.desc, sTail, sTailOff, BT);
+    if (q.doHzb) hzb_tail_to_lds(q.h.hzbMin, nullptr, q.h.desc, sTail, sTailOff, BT, &tailRegs);
     __syncthreads();
     FCLOCK(2);
 
@@ -1213,6 +1261,9 @@ __global__ __launch_bounds__(THREADS) void hzb_cull_kernel(HzbCullParams p)
     __shared__ unsigned long long sTris[THREADS / 64u];
     __shared__ float sTail[TAIL ? HZB_TAIL_FLOATS : 1u];
     __shared__ uint32_t sTailOff[CHORD_HZB_MAX_MIPS];
+    // (TAIL: level 5 of the chain for the reduction below, asked for ahead of everything else)
+    HzbTailRegs tailRegs;
+    if (TAIL && OCT) hzb_tail_fetch(p.hzbMin, p.desc, THREADS, tailRegs);
     const uint32_t count = *p.inCount;
     const DView& dv = *p.dview;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1237,7 +1288,7 @@ __global__ __launch_bounds__(THREADS) void hzb_cull_kernel(HzbCullParams p)
     // TAIL: the chain this launch culls against has its levels 0..5 in memory; every block with work reduces the rest
     // itself (block 0 also stores them)
     if (TAIL && (blockIdx.x * CPB < count || blockIdx.x == 0u) && (dv.flags & CHORD_FLAG_HZB_CULL))
-        hzb_tail_to_lds(p.hzbMin, blockIdx.x == 0u ? p.hzbTailOut : nullptr, p.desc, sTail, sTailOff, THREADS);
+        hzb_tail_to_lds(p.hzbMin, blockIdx.x == 0u ? p.hzbTailOut : nullptr, p.desc, sTail, sTailOff, THREADS, (TAIL && OCT) ? &tailRegs : nullptr);
     for (uint32_t base = blockIdx.x * CPB; base < count; base += gridDim.x * CPB) {
         ChordDrawCmd cmd[K];
         uint32_t visBits = 0, rejBits = 0, tris = 0;
