@@ -278,6 +278,30 @@ def test_config4_street_x64_4k_two_frames_match_oracle(gpu):
     r.close()
 
 
+def test_fused_cull_of_a_scene_with_more_workgroups_than_one_poll_covers(gpu):
+    """Four street instances at 1080p: 49 212 group instances = 769 workgroups of the fused short-scene cull (256 threads, 64 group
+    instances each) -- a workgroup polls the look-back words of the workgroups in front of it in a loop of up to four rounds, and
+    the grid is larger than the 256 CUs of the device.  Frame 0 (no history: count + scatter fused) and frame 1 (the phase-0
+    occlusion cull inside the same kernel): lists, counts, image and chain equal the oracle's."""
+    scene, cam, view, iv = H.setup_scene(lambda: scenes.config4_street_x64(1920, 1080, grid=2))
+    W, Hh = cam.width, cam.height
+    want0 = orc.frame(scene, view, iv, H.ALL_FLAGS)
+    want1 = orc.frame(scene, view, iv, H.ALL_FLAGS, prev_hzb_min=want0["hzb_min"])
+    r = _renderer(gpu, scene, view, iv, W, Hh, H.ALL_FLAGS)
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want0["vis"], W, Hh, "street x4 frame 0")
+    st = r.stats()
+    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want0["stats"].trianglesSubmitted
+    r.render_frame()
+    H.assert_vis_equal(r.read_visibility(), want1["vis"], W, Hh, "street x4 frame 1")
+    st = r.stats()
+    assert st["overflow"] == 0 and st["trianglesSubmitted"] == want1["stats"].trianglesSubmitted
+    assert [st["countInstanceCulled"], st["countStage0Visible"], st["countStage0Rejected"], st["countStage1Visible"]] == list(want1["counts"])
+    mn, mx, rng = r.read_hzb(r.history_hzb())
+    assert np.array_equal(mn, want1["hzb_min"]) and np.array_equal(mx, want1["hzb_max"]) and np.array_equal(rng, want1["valid_range"])
+    r.close()
+
+
 def test_config5_subpixel_reduced_matches_oracle(gpu):
     """BASELINE config 5 at reduced size (16 k camera-facing patches of ~8x8 px = 2.1 M triangles of ~0.5 px^2 into
     960x540): nearly every triangle survives the per-triangle culls and about half of them hit a pixel centre --
