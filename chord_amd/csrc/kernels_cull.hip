@@ -1181,39 +1181,48 @@ __global__ __launch_bounds__(FUSED_CULL_THREADS) void frame_cull_fused_kernel(Fu
 // the other, four dependent chains of loads deep, while the stand-alone kernel has one command per thread.)
 // outCmds NULL: only the rank's own list is written (sharded frames inside the library: the full list -- 12 bytes per cluster of the
 // whole frame on every rank -- is made when a consumer asks for it, launch_full_list below); countTris 0: a re-run for that purpose.
+// (not PREFIXED, since round 6 up to CULL_SELFSUM_MAX_BLOCKS count blocks -- config 4 has 3 076: its prefix launch was 8.3 us of one
+// workgroup's work between two kernel boundaries; a block's 12 coalesced loads of counts the L2 holds and one reduction are under a
+// microsecond of every block's start.  The triangle total is the count kernel's per-block sums, added up by the last block.)
+#define CULL_SELFSUM_MAX_BLOCKS 4096u
 template <bool PREFIXED, bool SHARDED>
 __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams p, ChordDrawCmd* __restrict__ outCmds,
                                                                  uint32_t* __restrict__ outCount, DeviceCounters* __restrict__ counters, uint32_t countTris)
 {
-    __shared__ uint32_t red[256], redMine[SHARDED ? 256 : 1];
+    __shared__ unsigned long long red[4], redTris[4];
     constexpr bool sharded = SHARDED;
     const uint32_t cullBlocks = gridDim.x;
-    uint32_t blockBase, mineBase = 0;
-    if (PREFIXED) { blockBase = p.blockCounts[blockIdx.x]; if (sharded) mineBase = p.blockCounts[2u * cullBlocks + blockIdx.x]; }
-    else {
-        uint32_t part = 0, partMine = 0;
-        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) { part += p.blockCounts[b]; if (sharded) partMine += p.blockCounts[2u * cullBlocks + b]; }
-        red[threadIdx.x] = part; if (sharded) redMine[threadIdx.x] = partMine;
-        __syncthreads();
-        for (uint32_t s = 128; s > 0; s >>= 1) {
-            if (threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; if (sharded) redMine[threadIdx.x] += redMine[threadIdx.x + s]; }
-            __syncthreads();
-        }
-        blockBase = red[0]; if (sharded) mineBase = redMine[0];
-        __syncthreads();
-    }
-
+    // (the block's own masks and references are asked for first: the sum of the blocks in front of it is needed last)
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t both = t < p.groupInstances ? p.groupMask[t] : 0u;
     const uint32_t mask = both & 15u, mine = sharded ? both >> 4 : 0u;
+    const bool emit = mask && (outCmds || mine);
+    DGroupRef ref;
+    ref.object = 0u; ref.group = 0u; ref.meshlet[0] = ref.meshlet[1] = ref.meshlet[2] = ref.meshlet[3] = 0u;
+    if (!PREFIXED && emit) ref = p.groupRefs[t];
+    uint32_t blockBase, mineBase = 0;
+    if (PREFIXED) { blockBase = p.blockCounts[blockIdx.x]; if (sharded) mineBase = p.blockCounts[2u * cullBlocks + blockIdx.x]; }
+    else {
+        // (visible counts in the low half, the rank's own in the high half of one 64-bit sum)
+        unsigned long long part = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u)
+            part += (unsigned long long)p.blockCounts[b] | (sharded ? (unsigned long long)p.blockCounts[2u * cullBlocks + b] << 32 : 0ull);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = part;
+        __syncthreads();
+        const unsigned long long all = (red[0] + red[1]) + (red[2] + red[3]);
+        blockBase = (uint32_t)all; if (sharded) mineBase = (uint32_t)(all >> 32);
+        __syncthreads();
+    }
+
     uint32_t total;
     const uint32_t offs = block_excl_scan(sharded ? (uint32_t)__popc(mask) | ((uint32_t)__popc(mine) << 16) : (uint32_t)__popc(mask), &total);
     const uint32_t off = offs & 0xFFFFu;
-    uint32_t tris = 0;
     // (a sharded frame that writes only the rank's own list reads the group's reference -- 24 bytes -- only where the rank has a cluster:
     // an eighth of them on 8 ranks; the slots need nothing but the counts)
-    if (mask && (outCmds || mine || !PREFIXED)) {
-        const DGroupRef ref = p.groupRefs[t];
+    if (emit) {
+        if (PREFIXED) ref = p.groupRefs[t];
         uint32_t slot = blockBase + off, mslot = mineBase + (offs >> 16);
         for (uint32_t i = 0; i < CHORD_GROUP_MAX_MESHLETS; i++) {
             if (mask & (1u << i)) {
@@ -1223,18 +1232,22 @@ __global__ __launch_bounds__(256) void group_cull_scatter_kernel(GroupCullParams
                 cmd.slot = slot;                                            // instance_culling.hlsl:203-206
                 if (outCmds) outCmds[slot] = cmd;
                 if (sharded && p.mineCmds && (mine & (1u << i))) p.mineCmds[mslot++] = cmd;   // the rank's own list: same order, same slots
-                if (!PREFIXED) tris += (p.meshlets[cmd.meshletId].vertexTriangleCount >> 8) & 0xFFu;
                 slot++;
             }
         }
     }
     if (PREFIXED) return;
     if (!countTris) return;                                         // (a re-run for the full list: counts and totals are the frame's already)
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *outCount = blockBase + (total & 0xFFFFu); if (sharded) *p.mineCount = mineBase + (total >> 16); }
-    // triangles this list submits (the Gtri/s unit): one fire-and-forget atomic per block
-    uint32_t blockTris;
-    (void)block_excl_scan(tris, &blockTris);
-    if (threadIdx.x == 0 && blockTris) atomicAdd(&counters->trisInstanceCulled, (unsigned long long)blockTris);
+    if (blockIdx.x != gridDim.x - 1u) return;
+    // the last block: the list's length, and the triangles it submits (the Gtri/s unit) -- the count kernel's per-block sums
+    if (threadIdx.x == 0) { *outCount = blockBase + (total & 0xFFFFu); if (sharded) *p.mineCount = mineBase + (total >> 16); }
+    unsigned long long tris = 0;
+    for (uint32_t b = threadIdx.x; b < cullBlocks; b += 256u) tris += p.blockCounts[cullBlocks + b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tris += __shfl_down(tris, off, 64);
+    if ((threadIdx.x & 63u) == 0u) redTris[threadIdx.x >> 6] = tris;
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned long long t = (redTris[0] + redTris[1]) + (redTris[2] + redTris[3]); if (t) atomicAdd(&counters->trisInstanceCulled, t); }
 }
 
 // -------------------------------------------------------------------------------- HZB stage (kernels) --
@@ -1495,8 +1508,8 @@ void launch_full_list(ChordCtx* c)
     const uint32_t blocks = c->cullBlocks;
     const CmdList& out = c->lists[0];
     // (the masks carry the rank's nibble too; the kernel's SHARDED form scans both halves, mineCmds NULL: nothing of the rank's list is rewritten)
-    if (blocks > 512u) CHORD_LAUNCH(c, (group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, 0u);
-    else               CHORD_LAUNCH(c, (group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, 0u);
+    if (blocks > CULL_SELFSUM_MAX_BLOCKS) CHORD_LAUNCH(c, (group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, 0u);
+    else                                  CHORD_LAUNCH(c, (group_cull_scatter_kernel<false, false>), dim3(blocks), dim3(256), 0, c->stream, p, out.cmds, out.count, c->dCounters, 0u);
     c->fullListStale = false;
 }
 
@@ -1659,7 +1672,7 @@ void launch_group_cull(ChordCtx* c, const CmdList& out)
     ChordDrawCmd* full = out.cmds;
     c->fullListStale = false;
     if (sh && c->lazyFullList && out.cmds == c->lists[0].cmds) { full = nullptr; c->fullListStale = true; }
-    if (blocks > 512u) {
+    if (blocks > CULL_SELFSUM_MAX_BLOCKS) {
         CHORD_LAUNCH(c, group_cull_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, c->dBlockCounts, blocks, out.count, c->dCounters, p.mineCount);
         if (sh) CHORD_LAUNCH(c, (group_cull_scatter_kernel<true, true>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
         else    CHORD_LAUNCH(c, (group_cull_scatter_kernel<true, false>), dim3(blocks), dim3(256), 0, c->stream, p, full, out.count, c->dCounters, 1u);
