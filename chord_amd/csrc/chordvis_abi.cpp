@@ -113,7 +113,8 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         c->tileItemCap = (uint32_t)(tilesN * (CHORD_TILE_MAX_SLICES + 1u));
         if ((rc = dalloc(c, &c->dTileOrder, ((size_t)1 + c->tileItemCap) * 2))) return rc;   // uint2 per item
         if ((rc = dalloc(c, &c->dTileOrderKeep, ((size_t)1 + c->tileItemCap) * 2))) return rc;
-        c->orderAge = 0xFFFFFFFFu;
+        if ((rc = dalloc(c, &c->dTileOrderKeep1, ((size_t)1 + c->tileItemCap) * 2))) return rc;
+        c->orderAge = c->orderAge1 = 0xFFFFFFFFu;
         if ((rc = dalloc(c, &c->dTileSlabs, tilesN * CHORD_TILE * CHORD_TILE))) return rc;
         CHORD_HIP(c, hipMemset(c->dTileSlabs, 0, tilesN * CHORD_TILE * CHORD_TILE * sizeof(unsigned long long)));
     }
@@ -291,7 +292,7 @@ int install_tile_owners(ChordCtx* c)
     CHORD_HIP(c, hipMalloc((void**)&c->dTileOwner, tiles));
     CHORD_HIP(c, hipMemcpy(c->dTileOwner, c->tileOwners.data(), tiles, hipMemcpyHostToDevice));
     c->mineValid = false; c->listMine[1] = c->listMine[2] = false;       // (lists culled for another ownership)
-    c->orderAge = 0xFFFFFFFFu;                                            // (a kept tile schedule lists the OLD map's tiles)
+    c->orderAge = c->orderAge1 = 0xFFFFFFFFu;                                            // (a kept tile schedule lists the OLD map's tiles)
     return CHORDVIS_OK;
 }
 
@@ -413,7 +414,7 @@ int chordvis_destroy(ChordCtx* c)
     for (int i = 0; i < 3; i++) dfree(c->lists[i].cmds);
     dfree(c->dRankCmds); dfree(c->dLeftCmds); dfree(c->dMineCmds);
     dfree(c->dCullLookback);
-    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dHotTiles); dfree(c->dTileOrder); dfree(c->dTileOrderKeep); c->orderAge = 0xFFFFFFFFu; dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
+    dfree(c->dFrameState); c->dCounts = nullptr; c->dCounters = nullptr; dfree(c->dTileClocks); dfree(c->dHotTiles); dfree(c->dTileOrder); dfree(c->dTileOrderKeep); dfree(c->dTileOrderKeep1); c->orderAge = c->orderAge1 = 0xFFFFFFFFu; dfree(c->dTileSlabs); dfree(c->dTileMarker); dfree(c->dShadingTiles);
     dfree(c->dVisOwned); dfree(c->dVisResolved);
     for (int i = 0; i < 3; i++) { dfree(c->hzb[i].minTexels); dfree(c->hzb[i].maxTexels); dfree(c->hzb[i].validRange); }
     if (c->hBinHint) { (void)hipHostFree(const_cast<uint32_t*>(c->hBinHint)); c->hBinHint = nullptr; c->dBinHint = nullptr; }
@@ -439,7 +440,7 @@ int chordvis_sync(ChordCtx* c)
 
 int chordvis_upload_scene(ChordCtx* c, const ChordSceneDesc* s)
 {
-    if (c) c->orderAge = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
+    if (c) c->orderAge = c->orderAge1 = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
 
     if (!c || !s || !s->objects || !s->primitives || !s->materials || !s->assets || s->objectCount == 0)
         return fail(c, CHORDVIS_E_INVALID, "upload_scene: null or empty scene");
@@ -801,7 +802,7 @@ int chordvis_allocate_gbuffer(ChordCtx* c, uint32_t width, uint32_t height, uint
 
 int chordvis_set_limits(ChordCtx* c, const ChordLimits* limits)
 {
-    if (c) c->orderAge = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
+    if (c) c->orderAge = c->orderAge1 = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
 
     if (!c || !limits) return fail(c, CHORDVIS_E_INVALID, "set_limits: null argument");
     if (c->sceneLoaded || c->dVis) return fail(c, CHORDVIS_E_INVALID, "set_limits: call before upload_scene / allocate_gbuffer");
@@ -825,7 +826,7 @@ int chordvis_set_tile_schedule_keep(ChordCtx* c, uint32_t frames)
 {
     if (!c) return CHORDVIS_E_INVALID;
     c->orderKeepFrames = frames;
-    c->orderAge = 0xFFFFFFFFu;
+    c->orderAge = c->orderAge1 = 0xFFFFFFFFu;
     return CHORDVIS_OK;
 }
 uint32_t chordvis_tile_schedule_keep(ChordCtx* c) { return c ? c->orderKeepFrames : 0u; }
@@ -841,7 +842,7 @@ int chordvis_set_cull_mode(ChordCtx* c, int hierarchical)
 
 int chordvis_set_shard(ChordCtx* c, uint32_t ranks, uint32_t rank)
 {
-    if (c) c->orderAge = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
+    if (c) c->orderAge = c->orderAge1 = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
 
     if (!c || ranks == 0 || ranks > 255u || rank >= ranks) return fail(c, CHORDVIS_E_INVALID, "set_shard: rank < ranks <= 255");
 #if CHORD_TILE_SHIFT != 6
@@ -1496,7 +1497,7 @@ int chordvis_upload_history_hzb(ChordCtx* c, const uint16_t* hostMin)
 
 int chordvis_set_debug(ChordCtx* c, uint32_t flags)
 {
-    if (c) c->orderAge = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
+    if (c) c->orderAge = c->orderAge1 = 0xFFFFFFFFu;                    // (the kept tile schedule of launch_raster is made again)
 
     if (!c) return CHORDVIS_E_INVALID;
     // measurement switches the library was not built with would silently measure the product: refuse them
@@ -1529,7 +1530,7 @@ int chordvis_debug_graph_frames(ChordCtx* c, uint32_t pairs, float* msPerFrameSt
     int rc;
     // (the kept tile schedule is off for both measurements: a captured frame either holds the schedule kernel or it does not, whatever the
     // age of the schedule at replay -- with it in every frame the stream's and the graph's frames are the same eleven + one launches)
-    struct KeepOff { ChordCtx* c; uint32_t keep; ~KeepOff() { c->orderKeepFrames = keep; c->orderAge = 0xFFFFFFFFu; } } keepOff{c, c->orderKeepFrames};
+    struct KeepOff { ChordCtx* c; uint32_t keep; ~KeepOff() { c->orderKeepFrames = keep; c->orderAge = c->orderAge1 = 0xFFFFFFFFu; } } keepOff{c, c->orderKeepFrames};
     c->orderKeepFrames = 0u;
     for (int i = 0; i < 4; i++) if ((rc = chordvis_render_frame(c))) return rc;
     hipEvent_t e0, e1;

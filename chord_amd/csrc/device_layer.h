@@ -432,6 +432,8 @@ struct ChordCtx {
     uint32_t* dTileOrder = nullptr;    // [1 + tileItemCap]: item count, then work items heaviest first
     uint32_t* dTileOrderKeep = nullptr; // the same for the first pass of main-view frames on one GPU, kept across frames (launch_raster)
     uint32_t orderAge = 0xFFFFFFFFu;   // frames since dTileOrderKeep was made; 0xFFFFFFFF: not valid (new target, scene, map, switches)
+    uint32_t* dTileOrderKeep1 = nullptr; // ... and of a frame's HEAVY second pass (every tile listed, touched or not: launch_raster)
+    uint32_t orderAge1 = 0xFFFFFFFFu;
     uint32_t orderKeepFrames = 7u;     // chordvis_set_tile_schedule_keep: frames a first pass's schedule is kept for (0: never)
     unsigned long long* dTileSlabs = nullptr;   // [tiles][TILE*TILE]: where the slices of a split tile meet (all zero between uses)
     uint32_t tileItemCap = 0;

@@ -109,6 +109,7 @@ struct RasterParams {
     uint32_t* hotTiles;                                 // [1 + CHORD_HOT_TILES] this pass's hot tiles of the LAST frame (count, then tile | very hot << 31): written by the tile schedule, read by the block kernel's hot variant
     uint32_t tileSlots;                                 // tile workgroups the device holds at once (2 per CU); a pass with fewer non-empty tiles than that cuts its bins finer (tile_order_part), 0: never
     uint32_t tileSplitMin, tileSliceLen;                // bins longer than tileSplitMin entries are cut into slices of tileSliceLen (TILE_SPLIT_MIN, TILE_SLICE)
+    uint32_t orderAll;                                  // the schedule lists every (owned) tile, empty ones last, also in a pass that does not clear: a KEPT schedule of such a pass must name the tiles a later frame touches
     uint32_t orderKept;                                 // 1: tileOrder is the schedule of an EARLIER frame's first pass (launch_raster: TILE_ORDER_KEEP) -- the items and their order are taken from it, a tile's bin length and flags from the counter line of this pass
                                                         // 2: no schedule at all (later passes of a frame: launch_raster TILE_DIRECT) -- work item i is tile i, whole; a tile without entries is left alone
     uint32_t* heavyHint;                                // host-visible words [0] / [2]: this pass's serial (binStamp) stored by whoever finds the pass HEAVY (a bin beyond tileSplitMin entries, more than
@@ -1868,7 +1869,7 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
     if (threadIdx.x == 0) {
         uint32_t acc = splitItems;
         for (int b = 0; b < 18; b++) { base[b] = acc; acc += hist[b]; }
-        p.tileOrder[0] = make_uint2(p.clearTiles ? acc : acc - hist[17], 0u);
+        p.tileOrder[0] = make_uint2((p.clearTiles || p.orderAll) ? acc : acc - hist[17], 0u);
         if (p.binHint) *p.binHint = longest;                      // (bins short enough to stay whole report 0)
         if (p.heavyHint) p.heavyHint[(splitItems != 0u || *p.count > TILE_DIRECT_MAX_CLUSTERS) ? 0 : 2] = p.binStamp;   // (launch_raster TILE_DIRECT: heavy / light)
         if (p.countHint) *p.countHint = *p.count;
@@ -2758,6 +2759,7 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         }
         if (nAll == 0u) continue;
     }
+    if (p.orderAll && !p.clearTiles && nAll == 0u) continue;     // (a later pass's schedule that lists every tile: the untouched ones end here)
     const bool hasBlocks = (countWord >> 31) != 0u;               // (the order kernel saw pixel blocks in the tile's bin)
     const bool preloaded = !CHORD_MASKED_FUSED && p.clearTiles && (countWord & 0x40000000u) != 0u;   // the masked pass wrote this tile (first pass of a frame)
     const int32_t tinyArea = nAll >= TINY_DENSE_MIN ? TINY_AREA_DENSE : TINY_AREA;
@@ -3433,7 +3435,10 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         const uint32_t heavySeen = c->hBinHint[4 + pass], lightSeen = c->hBinHint[6 + pass];
         // (the host runs frames ahead of the device -- a bench loop enqueues hundreds: what it reads is the state of a pass long past,
         // so the rule is "the latest report says light", not "a report of the last few frames"; a pass that reports both is heavy)
-        if (lightSeen != 0u && (heavySeen == 0u || (int32_t)(lightSeen - heavySeen) > 0)) { p.orderKept = 2u; makeOrder = false; }
+        if (lightSeen != 0u && (heavySeen == 0u || (int32_t)(lightSeen - heavySeen) > 0)) {
+            p.orderKept = 2u; makeOrder = false;
+            if (pass == 1u && c->orderAge1 < 0xFFFFFFFEu) c->orderAge1++;      // (a kept schedule of this pass ages through the frames it sits out)
+        }
     }
     // (sharded frames too since round 6: a rank's work items are its own tiles, the map they follow changes only through
     // install_tile_owners, which ages the schedule out)
@@ -3441,6 +3446,19 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrderKeep);
         if (c->orderAge < c->orderKeepFrames) { c->orderAge++; p.orderKept = 1u; makeOrder = false; }
         else c->orderAge = 0u;
+    }
+    // HEAVY later passes keep their schedule too (round 6; config 4's second pass is 30 k clusters with work in every tile: its schedule
+    // kernel was 8.4 us of every frame).  Such a schedule lists EVERY tile of the rank, the empty ones last (orderAll) -- a tile that a
+    // later frame touches must be a work item --, the tile kernel takes a tile's bin length from its counter line as under any kept
+    // schedule, and the untouched tiles' workgroups end after that one load, as in a direct pass.
+    p.orderAll = 0u;
+    static const bool keepLaterOn = [] { const char* e = getenv("CHORDVIS_TILE_KEEP_LATER"); return !e || atoi(e) != 0; }();
+    if (TILE_ORDER_KEEP && keepLaterOn && makeOrder && c->orderKeepFrames && CHORD_MASKED_FUSED && c->inFrame && !clearTiles && p.hzbFused && !c->depthOnly && pass == 1u &&
+        p.heavyHint && c->dTileOrderKeep1 && !(c->debugFlags & ~524288u)) {
+        p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrderKeep1);
+        p.orderAll = 1u;
+        if (c->orderAge1 < c->orderKeepFrames) { c->orderAge1++; p.orderKept = 1u; makeOrder = false; }
+        else c->orderAge1 = 0u;
     }
     if (makeOrder) CHORD_LAUNCH(c, raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
 #if !CHORD_MASKED_FUSED
@@ -3461,7 +3479,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // per block balances better than any static split)
     // (sharded frames: the work items are the rank's own tiles)
     // (a rank's slices: its bins are cut into about tileSlots shares when it owns fewer tiles than that; blocks beyond the item count leave at once)
-    const uint32_t tileBlocks = (clearTiles || p.orderKept == 2u) ? ((sh && clearTiles) ? min(tiles, max(c->shard.slotsPerRank, p.tileSlots + p.tileSlots / 2u)) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
+    const uint32_t tileBlocks = (clearTiles || p.orderKept == 2u || p.orderAll) ? ((sh && clearTiles) ? min(tiles, max(c->shard.slotsPerRank, p.tileSlots + p.tileSlots / 2u)) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
     // (the tile kernel's instantiations are the opaque ones: alpha-tested triangles were scan-converted by the masked pass above)
 #if CHORD_MASKED_FUSED
     if (c->anyMasked) {
