@@ -3430,8 +3430,11 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // through the second pass costs that frame balance, never a pixel (-DTILE_DIRECT=0 compiles the path out; CHORDVIS_TILE_DIRECT=0
     // turns it off at run time: A/B runs).
     static const bool directOn = [] { const char* e = getenv("CHORDVIS_TILE_DIRECT"); return !e || atoi(e) != 0; }();
-    if (TILE_DIRECT && directOn && c->inFrame && !clearTiles && p.hzbFused && !c->depthOnly && CHORD_MASKED_FUSED && c->dBinHint && !(c->debugFlags & ~(DBG_NO_BLOCKS | DBG_FORCE_BLOCKS | DBG_FORCE_HOT | 524288u))) {
-        p.heavyHint = c->dBinHint + 4 + pass;
+    // (laterOk: a read-modify-write pass of a frame with the HZB fused into its tile-out -- what the direct form and the kept schedule of
+    // a later pass are written for)
+    const bool laterOk = c->inFrame && !clearTiles && p.hzbFused && !c->depthOnly && CHORD_MASKED_FUSED && c->dBinHint && !(c->debugFlags & ~(DBG_NO_BLOCKS | DBG_FORCE_BLOCKS | DBG_FORCE_HOT | 524288u));
+    if (laterOk) p.heavyHint = c->dBinHint + 4 + pass;
+    if (TILE_DIRECT && directOn && laterOk) {
         const uint32_t heavySeen = c->hBinHint[4 + pass], lightSeen = c->hBinHint[6 + pass];
         // (the host runs frames ahead of the device -- a bench loop enqueues hundreds: what it reads is the state of a pass long past,
         // so the rule is "the latest report says light", not "a report of the last few frames"; a pass that reports both is heavy)
@@ -3454,7 +3457,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     p.orderAll = 0u;
     static const bool keepLaterOn = [] { const char* e = getenv("CHORDVIS_TILE_KEEP_LATER"); return !e || atoi(e) != 0; }();
     if (TILE_ORDER_KEEP && keepLaterOn && makeOrder && c->orderKeepFrames && CHORD_MASKED_FUSED && c->inFrame && !clearTiles && p.hzbFused && !c->depthOnly && pass == 1u &&
-        p.heavyHint && c->dTileOrderKeep1 && !(c->debugFlags & ~524288u)) {
+        laterOk && c->dTileOrderKeep1 && !(c->debugFlags & ~524288u)) {
         p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrderKeep1);
         p.orderAll = 1u;
         if (c->orderAge1 < c->orderKeepFrames) { c->orderAge1++; p.orderKept = 1u; makeOrder = false; }
