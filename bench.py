@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-stamps", action="store_true", help="no hipEvent stamps anywhere in the run (kernel traces: every frame of the process is then a product frame; the line's gpu_ms / roofline times are 0)")
     ap.add_argument("--no-path", action="store_true", help="N = 1: do not also time the moving camera path (`moving_path`)")
     ap.add_argument("--path-views", type=int, default=64, help="distinct views of the moving camera path (even)")
+    ap.add_argument("--tile-schedule-keep", type=int, default=-1, help="frames a tile schedule is kept for (chordvis_set_tile_schedule_keep; -1: the library's default -- measurement runs only: the line says what ran)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -198,6 +199,8 @@ def measure(args, workload, env):
         r.set_limits(max_triangle_records=(1152 << 20) // share, bin_pool_chunks=(1200 << 10) // share, bin_max_chunks_per_tile=2048)
     if args.cull == "hierarchical":
         r.set_cull_mode(1)
+    if args.tile_schedule_keep >= 0:
+        r.set_tile_schedule_keep(args.tile_schedule_keep)
     r.upload_scene(scene)
     if world > 1:
         r.set_shard(world, rank)                         # screen tiles, the default map (re-balanced after the warm-up, below)
@@ -443,6 +446,15 @@ def measure(args, workload, env):
             elif not stamped_in_region:
                 st[k] = st2[k]
     ms_per_step = elapsed / args.steps * 1e3
+    # launches of a frame between two tile schedules and of a frame that makes them (two consecutive frames, outside the clock)
+    launches_seen = [st["kernelLaunches"]]
+    if world == 1:
+        for i in range(2):
+            frame(args.steps + extra + i)
+            torch.cuda.synchronize(dev)
+            launches_seen.append(r.stats()["kernelLaunches"])
+        launches_seen = launches_seen[1:]
+    st["kernelLaunches"] = min(launches_seen)
 
     # ---- N = 1: the same metric along a MOVING camera (the two-view loop re-makes the kept tile schedule on the same view every time and
     #      renders it on views the schedule was made for or next to: as favourable as a kept schedule gets)
@@ -677,9 +689,9 @@ def measure(args, workload, env):
             "clusters_rastered_per_step": clusters_per_frame, "triangle_records_per_step": recs, "bin_entries_per_step": bins, "pixel_blocks_per_step": blocks, "pixel_block_bytes_per_step": block_bytes,
             "gpu_ms": {k: round(st[k], 4) for k in ("msClear", "msInstanceCulling", "msStage0", "msHzbStage0", "msStage1",
                                                      "msHzbFinal", "msFrame", "msRasterCluster", "msRasterClip", "msRasterChunk")},
-            "kernel_launches": st["kernelLaunches"],
-            # frames the tile schedule of a frame's first raster pass is reused for (chordvis_set_tile_schedule_keep; library default):
-            # `kernel_launches` is a frame between two schedules -- every (this + 1)-th frame has one launch more
+            "kernel_launches": st["kernelLaunches"], "kernel_launches_schedule_frame": max(launches_seen),
+            # frames a pass's tile schedule is reused for (chordvis_set_tile_schedule_keep; the library's default unless --tile-schedule-keep):
+            # `kernel_launches` is a frame between two schedules, `kernel_launches_schedule_frame` one that makes them (every (this + 1)-th)
             "tile_schedule_keep_frames": r.tile_schedule_keep(),
             "tiles_touched_view_a": per_view[0]["tilesTouched"], "tiles_total": ((W + 63) // 64) * ((H + 63) // 64),
             "counts_view_a": {k: per_view[0][k] for k in ("countInstanceCulled", "countStage0Visible", "countStage0Rejected", "countStage1Visible", "trianglesSubmitted", "binEntries")},

@@ -112,8 +112,8 @@ int configure_targets(ChordCtx* c, uint64_t* external)
         const size_t tilesN = (size_t)c->tilesX * c->tilesY;
         c->tileItemCap = (uint32_t)(tilesN * (CHORD_TILE_MAX_SLICES + 1u));
         if ((rc = dalloc(c, &c->dTileOrder, ((size_t)1 + c->tileItemCap) * 2))) return rc;   // uint2 per item
-        if ((rc = dalloc(c, &c->dTileOrderKeep, ((size_t)1 + c->tileItemCap) * 2))) return rc;
-        if ((rc = dalloc(c, &c->dTileOrderKeep1, ((size_t)1 + c->tileItemCap) * 2))) return rc;
+        if ((rc = dalloc(c, &c->dTileOrderKeep, ((size_t)1 + c->tileItemCap) * 4))) return rc;    // (two schedules each: this frame's and the one being made for the next)
+        if ((rc = dalloc(c, &c->dTileOrderKeep1, ((size_t)1 + c->tileItemCap) * 4))) return rc;
         c->orderAge = c->orderAge1 = 0xFFFFFFFFu;
         if ((rc = dalloc(c, &c->dTileSlabs, tilesN * CHORD_TILE * CHORD_TILE))) return rc;
         CHORD_HIP(c, hipMemset(c->dTileSlabs, 0, tilesN * CHORD_TILE * CHORD_TILE * sizeof(unsigned long long)));

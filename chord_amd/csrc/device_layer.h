@@ -434,7 +434,8 @@ struct ChordCtx {
     uint32_t orderAge = 0xFFFFFFFFu;   // frames since dTileOrderKeep was made; 0xFFFFFFFF: not valid (new target, scene, map, switches)
     uint32_t* dTileOrderKeep1 = nullptr; // ... and of a frame's HEAVY second pass (every tile listed, touched or not: launch_raster)
     uint32_t orderAge1 = 0xFFFFFFFFu;
-    uint32_t orderKeepFrames = 7u;     // chordvis_set_tile_schedule_keep: frames a first pass's schedule is kept for (0: never)
+    uint32_t orderFlip[2] = {0u, 0u};  // which half of dTileOrderKeep / dTileOrderKeep1 this frame reads (the other one is being made for the next)
+    uint32_t orderKeepFrames = 1u;     // chordvis_set_tile_schedule_keep: frames a pass's schedule is kept for (0: never; default 1 -- a schedule serves the frame it is made in and the next: along a moving camera path with cuts an older one costs more balance than its launch, profiles/r06_experiments.txt item 15)
     unsigned long long* dTileSlabs = nullptr;   // [tiles][TILE*TILE]: where the slices of a split tile meet (all zero between uses)
     uint32_t tileItemCap = 0;
     uint32_t* dLargeList = nullptr;    // [2 passes][CHORD_LIST_SHARDS][largeCap / 2 / CHORD_LIST_SHARDS] record indices

@@ -109,6 +109,7 @@ struct RasterParams {
     uint32_t* hotTiles;                                 // [1 + CHORD_HOT_TILES] this pass's hot tiles of the LAST frame (count, then tile | very hot << 31): written by the tile schedule, read by the block kernel's hot variant
     uint32_t tileSlots;                                 // tile workgroups the device holds at once (2 per CU); a pass with fewer non-empty tiles than that cuts its bins finer (tile_order_part), 0: never
     uint32_t tileSplitMin, tileSliceLen;                // bins longer than tileSplitMin entries are cut into slices of tileSliceLen (TILE_SPLIT_MIN, TILE_SLICE)
+    uint2* tileOrderNext;                               // non-null: the tile kernel's extra workgroup makes the NEXT frame's schedule of this pass here, from this frame's bin counts (launch_raster)
     uint32_t orderAll;                                  // the schedule lists every (owned) tile, empty ones last, also in a pass that does not clear: a KEPT schedule of such a pass must name the tiles a later frame touches
     uint32_t orderKept;                                 // 1: tileOrder is the schedule of an EARLIER frame's first pass (launch_raster: TILE_ORDER_KEEP) -- the items and their order are taken from it, a tile's bin length and flags from the counter line of this pass
                                                         // 2: no schedule at all (later passes of a frame: launch_raster TILE_DIRECT) -- work item i is tile i, whole; a tile without entries is left alone
@@ -1790,6 +1791,9 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 #ifndef TILE_ORDER_KEEP
 #define TILE_ORDER_KEEP 1          // 0: the schedule kernel runs in every pass whatever chordvis_set_tile_schedule_keep says (A/B builds)
 #endif
+#ifndef TILE_MAKE_NEXT
+#define TILE_MAKE_NEXT 1            // 0: the tile kernel's workgroup 0 does not make the next frame's schedule (compile experiments only: launch_raster still relies on it)
+#endif
 #ifndef TILE_DIRECT
 #define TILE_DIRECT 1              // 0: later passes of a frame keep their schedule kernel (A/B builds)
 #endif
@@ -1800,76 +1804,68 @@ __global__ __launch_bounds__(256) void raster_clip_and_bin_large_kernel(RasterPa
 #define TILE_SLICE_MIN 1024u       // the shortest slice of a pass that has fewer tiles than the device has slots
 #endif
 template <uint32_t NT>
-__device__ __forceinline__ void tile_order_part(const RasterParams& p)
+__device__ __forceinline__ void tile_order_part(const RasterParams& p, uint2* __restrict__ order)
 {
-    __shared__ uint32_t hist[20], base[20], cursor[20], splitItems, longest, hotCount, hotList[CHORD_HOT_TILES], entriesAll, tilesBusy;
+    __shared__ uint32_t hist[20], base[20], cursor[20], splitItems, splitCursor, longest, hotCount, hotList[CHORD_HOT_TILES], entriesAll, tilesBusy;
     const uint32_t tiles = p.tilesX * p.tilesY;
     if (threadIdx.x < 20u) { hist[threadIdx.x] = 0; cursor[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { splitItems = 0; longest = 0; hotCount = 0; entriesAll = 0; tilesBusy = 0; }
+    if (threadIdx.x == 0) { splitItems = 0; splitCursor = 0; longest = 0; hotCount = 0; entriesAll = 0; tilesBusy = 0; }
     __syncthreads();
-    constexpr uint32_t PER_THREAD = CHORD_MAX_TILES / NT;
-    uint32_t myBucket[PER_THREAD], myPos[PER_THREAD], mySlices[PER_THREAD], myCount[PER_THREAD], myHas[PER_THREAD];
+    // A tile's word: bin entries (clamped to the capacity) | bit 31: the bin holds pixel blocks (the tile kernel's block pass; it used to
+    // ask the counter line itself, a dependent round trip per tile in front of its first bin fetch) | bit 30: the bin holds alpha-tested
+    // triangles -- on the first pass of a frame the masked pass (raster_masked_tile_kernel) has written the tile already and the tile
+    // kernel starts from those words instead of from zero.  ~0: not a work item of this rank (sharded frames: another rank's tiles --
+    // their bins are empty, and the clear pass must not touch them).
+    // (The three passes below read the counter lines again -- 16 bytes per tile out of the L2 -- instead of keeping five words per tile
+    // in registers: since round 6 this part also runs as ONE workgroup of the tile kernel, which must not grow by them.)
+    auto tile_word = [&](uint32_t t) -> uint32_t {
+        if (!owns_tile(p.shard, (int32_t)(t % p.tilesX), (int32_t)(t / p.tilesX))) return 0xFFFFFFFFu;
+        const uint32_t* __restrict__ line = &p.tileCount[(size_t)t * TC_STRIDE];
+        const uint32_t n = line[0], nb = line[1], nm = line[3];
+        return min(n, bin_capacity(p)) | (nb ? 0x80000000u : 0u) | (nm ? 0x40000000u : 0u);
+    };
     uint32_t sumMine = 0, tilesMine = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < PER_THREAD; k++) {
-        const uint32_t t = threadIdx.x + k * NT;
-        myBucket[k] = 0xFFFFFFFFu; myPos[k] = 0; mySlices[k] = 1; myCount[k] = 0; myHas[k] = 0;
-        // (sharded frames: another rank's tiles are not work items at all -- their bins are empty, and the clear pass must not touch them)
-        if (t < tiles && owns_tile(p.shard, (int32_t)(t % p.tilesX), (int32_t)(t / p.tilesX))) {
-            // (words 0 and 1 of the tile's counter line -- bin entries | of which pixel blocks -- in one 8-byte load)
-            const uint4 cnt = *reinterpret_cast<const uint4*>(&p.tileCount[(size_t)t * TC_STRIDE]);
-            const uint32_t c = min(cnt.x, bin_capacity(p));
-            // bit 31: the bin holds pixel blocks (the tile kernel's block pass; it used to ask the counter line itself, a dependent
-            // round trip per tile in front of its first bin fetch)
-            // bit 30: the bin holds alpha-tested triangles -- on the first pass of a frame the masked pass (raster_masked_tile_kernel)
-            // has written the tile already and the tile kernel starts from those words instead of from zero
-            myCount[k] = c | (cnt.y ? 0x80000000u : 0u) | (cnt.w ? 0x40000000u : 0u);
-            myHas[k] = 1u;
-            sumMine += c; tilesMine += c ? 1u : 0u;
-        }
-    }
-    // A pass with fewer non-empty tiles than the device holds tile workgroups (a rank of an 8-rank frame owns 255 tiles of a 4K
-    // target, 256 CUs hold 512 workgroups; so does a 1080p target on one GPU) leaves slots idle while every tile is one
-    // workgroup's serial work: its bins are cut finer -- into about as many equal shares as there are slots, never shorter than
-    // TILE_SLICE_MIN entries (a slice pays for a tile of LDS zeroed and its touched words merged through the slab).
-    // The image does not depend on the cut (64-bit max).
-    // (a DPP reduction per wave, then one LDS atomic per wave: handed the 1 024 atomics, the compiler's atomic optimizer walks the
-    // lanes of every wave in a scalar loop -- measured +6 us on a 4-us kernel)
     if (p.tileSlots) {
+        // A pass with fewer non-empty tiles than the device holds tile workgroups (a rank of an 8-rank frame owns 255 tiles of a 4K
+        // target, 256 CUs hold 512 workgroups; so does a 1080p target on one GPU) leaves slots idle while every tile is one
+        // workgroup's serial work: its bins are cut finer -- into about as many equal shares as there are slots, never shorter than
+        // TILE_SLICE_MIN entries (a slice pays for a tile of LDS zeroed and its touched words merged through the slab).
+        // The image does not depend on the cut (64-bit max).
+        // (a DPP reduction per wave, then one LDS atomic per wave: handed the 1 024 atomics, the compiler's atomic optimizer walks the
+        // lanes of every wave in a scalar loop -- measured +6 us on a 4-us kernel)
+        for (uint32_t t = threadIdx.x; t < tiles; t += NT) {
+            const uint32_t w = tile_word(t);
+            if (w != 0xFFFFFFFFu) { const uint32_t c = w & 0x3FFFFFFFu; sumMine += c; tilesMine += c ? 1u : 0u; }
+        }
         wave_sum2(sumMine, tilesMine);
         if ((threadIdx.x & 63u) == 0u) { atomicAdd(&entriesAll, sumMine); atomicAdd(&tilesBusy, tilesMine); }
+        __syncthreads();
     }
-    __syncthreads();
     uint32_t splitMin = p.tileSplitMin, sliceLen = p.tileSliceLen;
     if (p.tileSlots && tilesBusy < p.tileSlots) {
         const uint32_t share = (entriesAll / p.tileSlots + 511u) & ~511u;   // (whole batches of the tile kernel)
         sliceLen = min(p.tileSliceLen, max(TILE_SLICE_MIN, share));
         splitMin = min(p.tileSplitMin, sliceLen + sliceLen / 2u);
     }
-#pragma unroll
-    for (uint32_t k = 0; k < PER_THREAD; k++) {
-        const uint32_t t = threadIdx.x + k * NT;
-        if (myHas[k]) {
-            const uint32_t c = myCount[k] & 0x3FFFFFFFu;
-            // a bin this long is a hot tile: the next frame's block kernel draws its slots ahead from the first cluster on (hotTiles)
-            if (c >= p.slotHot && p.hotTiles) { const uint32_t h = atomicAdd(&hotCount, 1u); if (h < CHORD_HOT_TILES) hotList[h] = t | (c >= SLOT_VERY_HOT ? 0x80000000u : 0u); }
-            if (c > splitMin && !ABL(p, DBG_NO_SPLIT)) {
-                mySlices[k] = min((c + sliceLen - 1u) / sliceLen, CHORD_TILE_MAX_SLICES);
-                myBucket[k] = 18u;
-                myPos[k] = atomicAdd(&splitItems, mySlices[k]);
-                if (c > TILE_SPLIT_MIN) atomicMax(&longest, c);   // (the host's hint keeps its meaning: bins that a full launch would keep whole report 0)
-            } else {
-                // bucket 4 = 2^11.., bucket 16 = count 1, bucket 17 = empty
-                myBucket[k] = c ? 16u - (31u - (uint32_t)__clz(c)) : 17u;
-            }
-            atomicAdd(&hist[myBucket[k]], 1u);
-        }
+    // bucket of a tile: 18 = cut into slices, 4 = 2^11.., 16 = one entry, 17 = empty
+    auto slices_of = [&](uint32_t c) -> uint32_t { return (c > splitMin && !ABL(p, DBG_NO_SPLIT)) ? min((c + sliceLen - 1u) / sliceLen, CHORD_TILE_MAX_SLICES) : 0u; };
+    for (uint32_t t = threadIdx.x; t < tiles; t += NT) {
+        const uint32_t w = tile_word(t);
+        if (w == 0xFFFFFFFFu) continue;
+        const uint32_t c = w & 0x3FFFFFFFu;
+        // a bin this long is a hot tile: the next frame's block kernel draws its slots ahead from the first cluster on (hotTiles)
+        if (c >= p.slotHot && p.hotTiles) { const uint32_t h = atomicAdd(&hotCount, 1u); if (h < CHORD_HOT_TILES) hotList[h] = t | (c >= SLOT_VERY_HOT ? 0x80000000u : 0u); }
+        const uint32_t sl = slices_of(c);
+        if (sl) {
+            atomicAdd(&splitItems, sl);
+            if (c > TILE_SPLIT_MIN) atomicMax(&longest, c);   // (the host's hint keeps its meaning: bins that a full launch would keep whole report 0)
+        } else atomicAdd(&hist[c ? 16u - (31u - (uint32_t)__clz(c)) : 17u], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t acc = splitItems;
         for (int b = 0; b < 18; b++) { base[b] = acc; acc += hist[b]; }
-        p.tileOrder[0] = make_uint2((p.clearTiles || p.orderAll) ? acc : acc - hist[17], 0u);
+        order[0] = make_uint2((p.clearTiles || p.orderAll) ? acc : acc - hist[17], 0u);
         if (p.binHint) *p.binHint = longest;                      // (bins short enough to stay whole report 0)
         if (p.heavyHint) p.heavyHint[(splitItems != 0u || *p.count > TILE_DIRECT_MAX_CLUSTERS) ? 0 : 2] = p.binStamp;   // (launch_raster TILE_DIRECT: heavy / light)
         if (p.countHint) *p.countHint = *p.count;
@@ -1877,16 +1873,27 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
     }
     if (p.hotTiles && threadIdx.x < min(hotCount, (uint32_t)CHORD_HOT_TILES)) p.hotTiles[1u + threadIdx.x] = hotList[threadIdx.x];
     __syncthreads();
-#pragma unroll
-    for (uint32_t k = 0; k < PER_THREAD; k++) {
-        const uint32_t t = threadIdx.x + k * NT;
-        if (myBucket[k] == 0xFFFFFFFFu) continue;
-        if (myBucket[k] == 18u) {
-            for (uint32_t j = 0; j < mySlices[k]; j++) p.tileOrder[1u + myPos[k] + j] = make_uint2(t | (j << 12) | ((mySlices[k] - 1u) << 22), myCount[k]);
+    for (uint32_t t = threadIdx.x; t < tiles; t += NT) {
+        const uint32_t w = tile_word(t);
+        if (w == 0xFFFFFFFFu) continue;
+        const uint32_t c = w & 0x3FFFFFFFu, sl = slices_of(c);
+        if (sl) {
+            const uint32_t pos = atomicAdd(&splitCursor, sl);       // (the slices of a tile side by side, the split tiles in any order: all of them start the pass)
+            for (uint32_t j = 0; j < sl; j++) order[1u + pos + j] = make_uint2(t | (j << 12) | ((sl - 1u) << 22), w);
         } else {
-            p.tileOrder[1u + base[myBucket[k]] + atomicAdd(&cursor[myBucket[k]], 1u)] = make_uint2(t, myCount[k]);   // the count rides along: one round trip less per tile
+            const uint32_t b = c ? 16u - (31u - (uint32_t)__clz(c)) : 17u;
+            order[1u + base[b] + atomicAdd(&cursor[b], 1u)] = make_uint2(t, w);   // the count rides along: one round trip less per tile
         }
     }
+}
+
+// The same part as ONE workgroup of the tile kernel (raster_tile_kernel, workgroup 0 of a launch with tileOrderNext): out of line,
+// and reading the launch's arguments from the kernel-argument segment itself -- inlined, its scalars cost the tile kernel twelve
+// spill slots (48 bytes of scratch in a kernel that has none).  (The KERNEL asks for the segment's address and hands it over: in a
+// function that is not a kernel the compiler folds __builtin_amdgcn_kernarg_segment_ptr() to null -- every load of this part faulted.)
+__device__ __noinline__ void tile_order_next_part(const RasterParams* q)
+{
+    tile_order_part<512u>(*q, q->tileOrderNext);
 }
 
 // (Ordering in the last workgroup of the binning launch was measured twice: with that launch's 1 088 workgroups the ticket
@@ -1894,7 +1901,7 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p)
 // two -- the orderer must read the 2 040 counters with agent-scope loads, past its L2, after a ticket round trip.)
 __global__ __launch_bounds__(1024) void raster_tile_order_kernel(RasterParams p)
 {
-    tile_order_part<1024u>(p);
+    tile_order_part<1024u>(p, p.tileOrder);
 }
 
 // (Tried in round 2: clipper + large-record binning + this schedule in ONE launch of 128 workgroups, the last one --
@@ -2723,16 +2730,30 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     // (the item count and the block's first item are fetched together: one round trip, not two dependent ones; the
     // list has an entry for every tile, so slot 1 + blockIdx.x exists whether or not it is active)
     // (direct passes -- orderKept 2 -- have no list: item i is tile i, and the first thing a workgroup asks memory for is its tile's counter line)
+    // Workgroup 0 of a launch with tileOrderNext makes the NEXT frame's schedule of this pass: the bin counts it orders are final before
+    // this kernel starts, the schedule kernel's work is one workgroup's, and here it costs one of the device's 512 tile slots for the
+    // first microseconds of the launch instead of a launch of its own between the binner and this kernel (launch_raster).
+    // (wg / wgs are worked out where they are used: held in scalar registers across the item loop they were two more to save around
+    // the call of merge_slices -- 48 bytes of scratch in a kernel that had none)
+#define TILE_SKEW (scalar_load(&kernel_args()->tileOrderNext) != nullptr ? 1u : 0u)
+#define wg (blockIdx.x - TILE_SKEW)
+#define wgs (gridDim.x - TILE_SKEW)
+    if (p.tileOrderNext && blockIdx.x == 0u) {
+#if TILE_MAKE_NEXT
+        tile_order_next_part(kernel_args());
+#endif
+        return;
+    }
     const bool direct = p.orderKept == 2u;
-    uint2 firstItem = make_uint2(blockIdx.x, 0u);
+    uint2 firstItem = make_uint2(wg, 0u);
     uint32_t active = p.tilesX * p.tilesY;
-    if (!direct) { firstItem = p.tileOrder[1u + min(blockIdx.x, p.tilesX * p.tilesY - 1u)]; active = p.tileOrder[0].x; }
-    for (uint32_t oi = blockIdx.x; oi < active; oi += gridDim.x) {
+    if (!direct) { firstItem = p.tileOrder[1u + min(wg, p.tilesX * p.tilesY - 1u)]; active = p.tileOrder[0].x; }
+    for (uint32_t oi = wg; oi < active; oi += wgs) {
     // (the thread index of this work item goes through an empty asm: whatever the body derives from it is invariant over the
     // item loop, and hoisted out of it those values -- offsets, masks, lane roles -- sat in registers across the whole kernel)
     uint32_t tix = threadIdx.x;
     asm volatile("" : "+v"(tix));
-    const uint2 itemCount = oi == blockIdx.x ? firstItem : (direct ? make_uint2(oi, 0u) : p.tileOrder[1u + oi]);
+    const uint2 itemCount = oi == wg ? firstItem : (direct ? make_uint2(oi, 0u) : p.tileOrder[1u + oi]);
     const uint32_t item = itemCount.x;
     const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
     // (kept order: the tile's counter line is read here, and -- the address needs the tile only -- a whole tile's first bin entries
@@ -3138,6 +3159,9 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     __syncthreads();                                              // the LDS tile is reused by the next iteration
     }
 }
+#undef wg
+#undef wgs
+#undef TILE_SKEW
 
 // ---- alpha-tested (masked) triangles: a pass of their own (mesh_raster.hlsl:34-38,107-112,198-204) ---------------------------------
 // Until round 4 the masked row units ran inside raster_tile_kernel: every masked instantiation of it sat at 128 VGPRs with
@@ -3440,28 +3464,44 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         // so the rule is "the latest report says light", not "a report of the last few frames"; a pass that reports both is heavy)
         if (lightSeen != 0u && (heavySeen == 0u || (int32_t)(lightSeen - heavySeen) > 0)) {
             p.orderKept = 2u; makeOrder = false;
-            if (pass == 1u && c->orderAge1 < 0xFFFFFFFEu) c->orderAge1++;      // (a kept schedule of this pass ages through the frames it sits out)
         }
     }
-    // (sharded frames too since round 6: a rank's work items are its own tiles, the map they follow changes only through
-    // install_tile_owners, which ages the schedule out)
-    if (TILE_ORDER_KEEP && c->orderKeepFrames && CHORD_MASKED_FUSED && c->inFrame && clearTiles && !c->depthOnly && pass == 0u && c->dTileOrderKeep && !(c->debugFlags & ~524288u)) {
-        p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrderKeep);
-        if (c->orderAge < c->orderKeepFrames) { c->orderAge++; p.orderKept = 1u; makeOrder = false; }
-        else c->orderAge = 0u;
-    }
-    // HEAVY later passes keep their schedule too (round 6; config 4's second pass is 30 k clusters with work in every tile: its schedule
-    // kernel was 8.4 us of every frame).  Such a schedule lists EVERY tile of the rank, the empty ones last (orderAll) -- a tile that a
-    // later frame touches must be a work item --, the tile kernel takes a tile's bin length from its counter line as under any kept
-    // schedule, and the untouched tiles' workgroups end after that one load, as in a direct pass.
-    p.orderAll = 0u;
+    // Kept schedules (chordvis_set_tile_schedule_keep != 0; sharded frames too: a rank's work items are its own tiles, and the map they
+    // follow changes only through install_tile_owners, which invalidates the schedules).  Slot 0: the first pass of a frame, which writes
+    // every tile -- its work items never change, only their order and the cut of long bins.  Slot 1: the second pass; its schedule lists
+    // EVERY tile of the rank, the untouched ones last (orderAll) -- a tile that a later frame touches must be a work item --, and an
+    // untouched tile's workgroup ends after the load of its counter line, as in a direct pass.  Under a kept schedule the tile kernel
+    // takes a tile's bin length and flags from the counter line (orderKept).
+    // WHO MAKES THE SCHEDULE (round 6, end): the tile kernel of the frame before.  Its workgroup 0 orders THIS launch's bin counts --
+    // final before the kernel starts -- into the slot's other buffer (tileOrderNext) while the other workgroups raster; the next frame
+    // reads that buffer.  Every frame then runs under a schedule exactly one frame old and no frame launches a schedule kernel: measured
+    // along a moving camera a one-frame-old schedule is as good as a fresh one, while one kept for 3 / 7 frames costs a config-4 or
+    // masked frame 3 / 7 % of balance (profiles/r06_experiments.txt item 15) -- the launch it saved was 2 %.  CHORDVIS_TILE_NEXT=0: the
+    // form before -- a schedule kernel every (keep + 1)-th frame, the schedule kept in between (A/B runs).
+    p.orderAll = 0u; p.tileOrderNext = nullptr;
     static const bool keepLaterOn = [] { const char* e = getenv("CHORDVIS_TILE_KEEP_LATER"); return !e || atoi(e) != 0; }();
-    if (TILE_ORDER_KEEP && keepLaterOn && makeOrder && c->orderKeepFrames && CHORD_MASKED_FUSED && c->inFrame && !clearTiles && p.hzbFused && !c->depthOnly && pass == 1u &&
-        laterOk && c->dTileOrderKeep1 && !(c->debugFlags & ~524288u)) {
-        p.tileOrder = reinterpret_cast<uint2*>(c->dTileOrderKeep1);
-        p.orderAll = 1u;
-        if (c->orderAge1 < c->orderKeepFrames) { c->orderAge1++; p.orderKept = 1u; makeOrder = false; }
-        else c->orderAge1 = 0u;
+    static const bool nextOn = [] { const char* e = getenv("CHORDVIS_TILE_NEXT"); return !e || atoi(e) != 0; }();
+    const bool keepOk = TILE_ORDER_KEEP && c->orderKeepFrames && CHORD_MASKED_FUSED && c->inFrame && !c->depthOnly && !(c->debugFlags & ~524288u);
+    int slot = -1;
+    if (keepOk && clearTiles && pass == 0u && c->dTileOrderKeep) slot = 0;
+    else if (keepOk && keepLaterOn && laterOk && pass == 1u && c->dTileOrderKeep1) slot = 1;
+    if (slot >= 0) {
+        uint32_t& age = slot ? c->orderAge1 : c->orderAge;
+        uint2* buf = reinterpret_cast<uint2*>(slot ? c->dTileOrderKeep1 : c->dTileOrderKeep);     // two schedules of 1 + tileItemCap items
+        const size_t half = (size_t)1 + c->tileItemCap;
+        p.orderAll = slot ? 1u : 0u;
+        if (nextOn) {
+            uint32_t& flip = c->orderFlip[slot];
+            p.tileOrder = buf + flip * half; p.tileOrderNext = buf + (flip ^ 1u) * half;
+            if (p.orderKept != 2u) {                                              // (a direct pass reads no schedule; its tile kernel still makes the next one)
+                if (age != 0xFFFFFFFFu) { p.orderKept = 1u; makeOrder = false; }  // the schedule the last frame's tile kernel made
+            }
+            age = 0u; flip ^= 1u;
+        } else if (p.orderKept != 2u) {
+            p.tileOrder = buf;
+            if (age < c->orderKeepFrames) { age++; p.orderKept = 1u; makeOrder = false; }
+            else age = 0u;
+        } else p.orderAll = 0u;
     }
     if (makeOrder) CHORD_LAUNCH(c, raster_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, p);
 #if !CHORD_MASKED_FUSED
@@ -3482,7 +3522,7 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
     // per block balances better than any static split)
     // (sharded frames: the work items are the rank's own tiles)
     // (a rank's slices: its bins are cut into about tileSlots shares when it owns fewer tiles than that; blocks beyond the item count leave at once)
-    const uint32_t tileBlocks = (clearTiles || p.orderKept == 2u || p.orderAll) ? ((sh && clearTiles) ? min(tiles, max(c->shard.slotsPerRank, p.tileSlots + p.tileSlots / 2u)) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u));
+    const uint32_t tileBlocks = (p.tileOrderNext ? 1u : 0u) + ((clearTiles || p.orderKept == 2u || p.orderAll) ? ((sh && clearTiles) ? min(tiles, max(c->shard.slotsPerRank, p.tileSlots + p.tileSlots / 2u)) : tiles) : min(tiles, (uint32_t)c->numCUs * (CHORD_TILE_SHIFT == 6 ? 2u : 6u)));
     // (the tile kernel's instantiations are the opaque ones: alpha-tested triangles were scan-converted by the masked pass above)
 #if CHORD_MASKED_FUSED
     if (c->anyMasked) {

@@ -235,12 +235,14 @@ int chordvis_set_view(ChordCtx* ctx, const ChordCameraView* view, const ChordIns
  * threshold; only the groups of surviving nodes are tested.  The command list is the same array either way. */
 int chordvis_set_cull_mode(ChordCtx* ctx, int hierarchical);
 
-/* Tile schedule of a frame's first raster pass (no counterpart: the reference's hardware rasterizer schedules its own tiles).  That pass
- * writes every tile of the target, so its work items never change; their order (heaviest bin first) and the cut of long bins are
+/* Tile schedules of a frame's raster passes (no counterpart: the reference's hardware rasterizer schedules its own tiles).  The first
+ * pass writes every tile of the target, so its work items never change; their order (heaviest bin first) and the cut of long bins are
  * taken from the schedule of an earlier frame for up to `frames` frames in a row before the schedule kernel runs again (one launch
- * less in the frames between; single-GPU main-view frames inside chordvis_render_frame).  Order and cut are choices of speed -- the
- * image is the same with any.  Default 7; 0: a fresh schedule in every frame (a host that knows of a camera cut may set 0 for a frame,
- * or ignore it: a stale order costs balance for at most `frames` frames). */
+ * less in the frames between; frames inside chordvis_render_frame / the frame phases).  A heavy second pass keeps a schedule of its own
+ * the same way (it lists every tile, touched or not).  Order and cut are choices of speed -- the image is the same with any.
+ * Default 1: a schedule serves the frame it is made in and the next (measured: along a moving camera path with cuts an older schedule
+ * costs more balance than its launch -- 7 frames: up to +8 % per frame --, on a static view it is worth its launch); 0: a fresh
+ * schedule in every frame.  A host may ignore camera cuts: a stale order costs balance for at most `frames` frames, never a pixel. */
 int chordvis_set_tile_schedule_keep(ChordCtx* ctx, uint32_t frames);
 uint32_t chordvis_tile_schedule_keep(ChordCtx* ctx);
 

@@ -334,6 +334,8 @@ def test_bench_single_gpu_line_has_the_contract_fields(gpu):
     mp = line["moving_path"]
     assert mp["views"] == 8 and mp["steps"] >= 16 and mp["value"] > 0 and mp["ms_per_step"] > 0 and mp["overflow"] == 0
     assert 0.2 < mp["ratio_to_two_view"] < 5.0 and mp["tile_schedule_keep_frames"] == line["tile_schedule_keep_frames"]
+    # the library's default schedule keep, and the launches of both kinds of frame (between two schedules / making them)
+    assert line["tile_schedule_keep_frames"] == 1 and 4 <= line["kernel_launches"] <= line["kernel_launches_schedule_frame"] <= line["kernel_launches"] + 2
 
 
 def test_bench_without_stamps_renders_only_product_frames(gpu):
