@@ -435,7 +435,7 @@ struct ChordCtx {
     uint32_t* dTileOrderKeep1 = nullptr; // ... and of a frame's HEAVY second pass (every tile listed, touched or not: launch_raster)
     uint32_t orderAge1 = 0xFFFFFFFFu;
     uint32_t orderFlip[2] = {0u, 0u};  // which half of dTileOrderKeep / dTileOrderKeep1 this frame reads (the other one is being made for the next)
-    uint32_t orderKeepFrames = 1u;     // chordvis_set_tile_schedule_keep: frames a pass's schedule is kept for (0: never; default 1 -- a schedule serves the frame it is made in and the next: along a moving camera path with cuts an older one costs more balance than its launch, profiles/r06_experiments.txt item 15)
+    uint32_t orderKeepFrames = 1u;     // chordvis_set_tile_schedule_keep: != 0 -- a pass runs under the schedule the frame before made for it (launch_raster: tileOrderNext); 0: a schedule kernel in every pass.  (CHORDVIS_TILE_NEXT=0, A/B runs: frames a schedule-kernel schedule is reused for)
     unsigned long long* dTileSlabs = nullptr;   // [tiles][TILE*TILE]: where the slices of a split tile meet (all zero between uses)
     uint32_t tileItemCap = 0;
     uint32_t* dLargeList = nullptr;    // [2 passes][CHORD_LIST_SHARDS][largeCap / 2 / CHORD_LIST_SHARDS] record indices

@@ -70,7 +70,7 @@ class VisibilityRenderer:
         self._check(L.lib.chordvis_set_cull_mode(self._ctx, int(hierarchical)), "set_cull_mode")
 
     def set_tile_schedule_keep(self, frames):
-        """Frames the tile schedules of a frame's raster passes are kept for (default 1; 0: a fresh schedule every frame)."""
+        """Non-zero (default 1): a raster pass runs under the tile schedule the frame before made for it; 0: a fresh schedule every pass."""
         self._check(L.lib.chordvis_set_tile_schedule_keep(self._ctx, int(frames)), "set_tile_schedule_keep")
 
     def tile_schedule_keep(self):

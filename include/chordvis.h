@@ -236,13 +236,15 @@ int chordvis_set_view(ChordCtx* ctx, const ChordCameraView* view, const ChordIns
 int chordvis_set_cull_mode(ChordCtx* ctx, int hierarchical);
 
 /* Tile schedules of a frame's raster passes (no counterpart: the reference's hardware rasterizer schedules its own tiles).  The first
- * pass writes every tile of the target, so its work items never change; their order (heaviest bin first) and the cut of long bins are
- * taken from the schedule of an earlier frame for up to `frames` frames in a row before the schedule kernel runs again (one launch
- * less in the frames between; frames inside chordvis_render_frame / the frame phases).  A heavy second pass keeps a schedule of its own
- * the same way (it lists every tile, touched or not).  Order and cut are choices of speed -- the image is the same with any.
- * Default 1: a schedule serves the frame it is made in and the next (measured: along a moving camera path with cuts an older schedule
- * costs more balance than its launch -- 7 frames: up to +8 % per frame --, on a static view it is worth its launch); 0: a fresh
- * schedule in every frame.  A host may ignore camera cuts: a stale order costs balance for at most `frames` frames, never a pixel. */
+ * pass writes every tile of the target, so its work items never change; only their order (heaviest bin first) and the cut of long bins
+ * depend on the frame.  With `frames` != 0 (default 1) a pass runs under the schedule the SAME pass of the frame before left behind:
+ * one workgroup of that frame's tile kernel orders its bin counts for the next frame while the others raster, so no frame launches a
+ * schedule kernel and every schedule is exactly one frame old (frames inside chordvis_render_frame / the frame phases; a heavy second
+ * pass the same way -- its schedule lists every tile, touched or not).  The first frame after a new target, scene, tile map or switch
+ * makes its schedules with the schedule kernel.  0: a fresh schedule from the schedule kernel in every pass.  Order and cut are choices
+ * of speed -- the image is the same with any; a host may ignore camera cuts: a stale order costs balance for one frame, never a pixel.
+ * (Measured: along a moving camera path a one-frame-old schedule is as good as a fresh one; one reused for 3 / 7 frames -- what a
+ * value > 1 meant until round 6 and still means under CHORDVIS_TILE_NEXT=0 -- costs a 30 k-cluster frame 3 / 7 %.) */
 int chordvis_set_tile_schedule_keep(ChordCtx* ctx, uint32_t frames);
 uint32_t chordvis_tile_schedule_keep(ChordCtx* ctx);
 
