@@ -1816,14 +1816,19 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p, uint2* __
     // triangles -- on the first pass of a frame the masked pass (raster_masked_tile_kernel) has written the tile already and the tile
     // kernel starts from those words instead of from zero.  ~0: not a work item of this rank (sharded frames: another rank's tiles --
     // their bins are empty, and the clear pass must not touch them).
-    // (The three passes below read the counter lines again -- 16 bytes per tile out of the L2 -- instead of keeping five words per tile
-    // in registers: since round 6 this part also runs as ONE workgroup of the tile kernel, which must not grow by them.)
+    // (Every thread asks for the lines of all its tiles at once and keeps ONE word per tile -- bucket, slices and position are worked out
+    // again where they are needed: as a workgroup of the tile kernel this part is out of line and its registers are its own, but three
+    // passes of dependent line fetches made it the longest chain of a short launch.)
     auto tile_word = [&](uint32_t t) -> uint32_t {
         if (!owns_tile(p.shard, (int32_t)(t % p.tilesX), (int32_t)(t / p.tilesX))) return 0xFFFFFFFFu;
         const uint32_t* __restrict__ line = &p.tileCount[(size_t)t * TC_STRIDE];
         const uint32_t n = line[0], nb = line[1], nm = line[3];
         return min(n, bin_capacity(p)) | (nb ? 0x80000000u : 0u) | (nm ? 0x40000000u : 0u);
     };
+    constexpr uint32_t PER_THREAD = CHORD_MAX_TILES / NT;
+    uint32_t mine[PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < PER_THREAD; k++) { const uint32_t t = threadIdx.x + k * NT; mine[k] = t < tiles ? tile_word(t) : 0xFFFFFFFFu; }
     uint32_t sumMine = 0, tilesMine = 0;
     if (p.tileSlots) {
         // A pass with fewer non-empty tiles than the device holds tile workgroups (a rank of an 8-rank frame owns 255 tiles of a 4K
@@ -1833,8 +1838,9 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p, uint2* __
         // The image does not depend on the cut (64-bit max).
         // (a DPP reduction per wave, then one LDS atomic per wave: handed the 1 024 atomics, the compiler's atomic optimizer walks the
         // lanes of every wave in a scalar loop -- measured +6 us on a 4-us kernel)
-        for (uint32_t t = threadIdx.x; t < tiles; t += NT) {
-            const uint32_t w = tile_word(t);
+#pragma unroll
+        for (uint32_t k = 0; k < PER_THREAD; k++) {
+            const uint32_t w = mine[k];
             if (w != 0xFFFFFFFFu) { const uint32_t c = w & 0x3FFFFFFFu; sumMine += c; tilesMine += c ? 1u : 0u; }
         }
         wave_sum2(sumMine, tilesMine);
@@ -1849,8 +1855,9 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p, uint2* __
     }
     // bucket of a tile: 18 = cut into slices, 4 = 2^11.., 16 = one entry, 17 = empty
     auto slices_of = [&](uint32_t c) -> uint32_t { return (c > splitMin && !ABL(p, DBG_NO_SPLIT)) ? min((c + sliceLen - 1u) / sliceLen, CHORD_TILE_MAX_SLICES) : 0u; };
-    for (uint32_t t = threadIdx.x; t < tiles; t += NT) {
-        const uint32_t w = tile_word(t);
+#pragma unroll
+    for (uint32_t k = 0; k < PER_THREAD; k++) {
+        const uint32_t t = threadIdx.x + k * NT, w = mine[k];
         if (w == 0xFFFFFFFFu) continue;
         const uint32_t c = w & 0x3FFFFFFFu;
         // a bin this long is a hot tile: the next frame's block kernel draws its slots ahead from the first cluster on (hotTiles)
@@ -1873,8 +1880,9 @@ __device__ __forceinline__ void tile_order_part(const RasterParams& p, uint2* __
     }
     if (p.hotTiles && threadIdx.x < min(hotCount, (uint32_t)CHORD_HOT_TILES)) p.hotTiles[1u + threadIdx.x] = hotList[threadIdx.x];
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < tiles; t += NT) {
-        const uint32_t w = tile_word(t);
+#pragma unroll
+    for (uint32_t k = 0; k < PER_THREAD; k++) {
+        const uint32_t t = threadIdx.x + k * NT, w = mine[k];
         if (w == 0xFFFFFFFFu) continue;
         const uint32_t c = w & 0x3FFFFFFFu, sl = slices_of(c);
         if (sl) {
@@ -3490,12 +3498,15 @@ hipError_t launch_raster(ChordCtx* c, const CmdList& in, bool clearTiles)
         uint2* buf = reinterpret_cast<uint2*>(slot ? c->dTileOrderKeep1 : c->dTileOrderKeep);     // two schedules of 1 + tileItemCap items
         const size_t half = (size_t)1 + c->tileItemCap;
         p.orderAll = slot ? 1u : 0u;
-        if (nextOn) {
+        if (nextOn && p.orderKept == 2u) {
+            // a direct pass reads no schedule and makes none: its tile kernel is as long as its slowest tile's chain of fetches (config 3:
+            // 23 us), and the schedule part -- one workgroup's three dependent passes over the counter lines -- would be the longest
+            // chain of the launch (measured: 23.2 -> 26.4 us).  A pass that turns heavy makes its first schedule with the schedule kernel.
+            age = 0xFFFFFFFFu; p.orderAll = 0u;
+        } else if (nextOn) {
             uint32_t& flip = c->orderFlip[slot];
             p.tileOrder = buf + flip * half; p.tileOrderNext = buf + (flip ^ 1u) * half;
-            if (p.orderKept != 2u) {                                              // (a direct pass reads no schedule; its tile kernel still makes the next one)
-                if (age != 0xFFFFFFFFu) { p.orderKept = 1u; makeOrder = false; }  // the schedule the last frame's tile kernel made
-            }
+            if (age != 0xFFFFFFFFu) { p.orderKept = 1u; makeOrder = false; }      // the schedule the last frame's tile kernel made
             age = 0u; flip ^= 1u;
         } else if (p.orderKept != 2u) {
             p.tileOrder = buf;

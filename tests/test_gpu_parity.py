@@ -837,7 +837,8 @@ def test_kept_schedule_of_a_heavy_second_pass_follows_a_camera_cut(gpu):
     # one -- its schedule kernel reported a light pass --, so the difference there is one launch, not two)
     assert launches[0][0] == launches[1][0] and launches[0][1] == launches[1][1] - 1, launches
     assert launches[0][2] == launches[1][2] - 2 and all(a <= b - 1 for a, b in zip(launches[0][2:], launches[1][2:])), launches
-    assert len(set(launches[0][2:])) == 1, launches
+    # (a second pass that ran direct -- the frame after the empty one -- made no schedule: the next heavy one launches the schedule kernel once)
+    assert max(launches[0][2:]) - min(launches[0][2:]) <= 1, launches
     for r in ctx:
         r.close()
 
