@@ -2741,10 +2741,16 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     // Workgroup 0 of a launch with tileOrderNext makes the NEXT frame's schedule of this pass: the bin counts it orders are final before
     // this kernel starts, the schedule kernel's work is one workgroup's, and here it costs one of the device's 512 tile slots for the
     // first microseconds of the launch instead of a launch of its own between the binner and this kernel (launch_raster).
-    // (wg / wgs are worked out where they are used: held in scalar registers across the item loop they were two more to save around
-    // the call of merge_slices -- 48 bytes of scratch in a kernel that had none)
+    // The kernel sits at its scalar-register limit, so where that skew of the workgroup index is needed decides how it is had:
+    //  * in front of the loop -- the workgroup's first item, on every tile's chain of dependent fetches -- from the argument as the
+    //    launch handed it over (dead once the loop is entered).  Re-read there it was a scalar load and a wait in front of every tile's
+    //    first fetch, and of every untouched tile's workgroup of a direct pass: config 3 0.1597 -> 0.1585 ms, config 4 0.3886 -> 0.3871;
+    //  * at the loop's end -- the stride, off every chain -- re-read from the kernel-argument segment (wgs): held across the body, skew
+    //    or stride is one more scalar to keep through the scan conversion and around the call of merge_slices.  Measured both ways:
+    //    48 bytes of scratch in a kernel that had none; and with a skew of 1 in EVERY launch (a constant: workgroup 0 of a launch without
+    //    a schedule to make just ends) and the stride gridDim.x - 1 held instead, config 3 0.1595 -> 0.1607 ms.  (And the other way --
+    //    item, item count and stride ALL worked out again at the loop's end, only the index carried: 0.1582 -> 0.1591.)
 #define TILE_SKEW (scalar_load(&kernel_args()->tileOrderNext) != nullptr ? 1u : 0u)
-#define wg (blockIdx.x - TILE_SKEW)
 #define wgs (gridDim.x - TILE_SKEW)
     if (p.tileOrderNext && blockIdx.x == 0u) {
 #if TILE_MAKE_NEXT
@@ -2753,15 +2759,18 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         return;
     }
     const bool direct = p.orderKept == 2u;
-    uint2 firstItem = make_uint2(wg, 0u);
+    const uint32_t wg0 = blockIdx.x - (p.tileOrderNext != nullptr ? 1u : 0u);
+    uint2 firstItem = make_uint2(wg0, 0u);
     uint32_t active = p.tilesX * p.tilesY;
-    if (!direct) { firstItem = p.tileOrder[1u + min(wg, p.tilesX * p.tilesY - 1u)]; active = p.tileOrder[0].x; }
-    for (uint32_t oi = wg; oi < active; oi += wgs) {
+    if (!direct) { firstItem = p.tileOrder[1u + min(wg0, p.tilesX * p.tilesY - 1u)]; active = p.tileOrder[0].x; }
+    for (uint32_t oi = wg0; oi < active; oi += wgs) {
     // (the thread index of this work item goes through an empty asm: whatever the body derives from it is invariant over the
     // item loop, and hoisted out of it those values -- offsets, masks, lane roles -- sat in registers across the whole kernel)
     uint32_t tix = threadIdx.x;
     asm volatile("" : "+v"(tix));
-    const uint2 itemCount = oi == wg ? firstItem : (direct ? make_uint2(oi, 0u) : p.tileOrder[1u + oi]);
+    // (the workgroup's first item <=> oi < the launch's tile workgroups = gridDim.x - skew; `oi + 1 < gridDim.x` says so without the
+    // skew, and where it errs -- the last workgroup of a launch without one -- the list holds the same item)
+    const uint2 itemCount = oi + 1u < gridDim.x ? firstItem : (direct ? make_uint2(oi, 0u) : p.tileOrder[1u + oi]);
     const uint32_t item = itemCount.x;
     const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
     // (kept order: the tile's counter line is read here, and -- the address needs the tile only -- a whole tile's first bin entries
@@ -3167,7 +3176,6 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     __syncthreads();                                              // the LDS tile is reused by the next iteration
     }
 }
-#undef wg
 #undef wgs
 #undef TILE_SKEW
 
