@@ -2752,6 +2752,8 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     //    item, item count and stride ALL worked out again at the loop's end, only the index carried: 0.1582 -> 0.1591.)
 #define TILE_SKEW (scalar_load(&kernel_args()->tileOrderNext) != nullptr ? 1u : 0u)
 #define wgs (gridDim.x - TILE_SKEW)
+    const uint32_t tilesAll = p.tilesX * p.tilesY;
+    const uint32_t wg0 = blockIdx.x - (p.tileOrderNext != nullptr ? 1u : 0u);
     if (p.tileOrderNext && blockIdx.x == 0u) {
 #if TILE_MAKE_NEXT
         tile_order_next_part(kernel_args());
@@ -2759,18 +2761,21 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
         return;
     }
     const bool direct = p.orderKept == 2u;
-    const uint32_t wg0 = blockIdx.x - (p.tileOrderNext != nullptr ? 1u : 0u);
+    // (the list is asked under `!direct`: asked for before anything branches -- so that the arguments it needs come in one scalar load
+    // with the others -- a direct pass's workgroups, 1 604 of 2 040 of them with nothing else to do, waited for a fetch they drop:
+    // config 3 0.1581 -> 0.1593 ms, while config 4, which has no direct pass, gained 0.5 %)
     uint2 firstItem = make_uint2(wg0, 0u);
-    uint32_t active = p.tilesX * p.tilesY;
-    if (!direct) { firstItem = p.tileOrder[1u + min(wg0, p.tilesX * p.tilesY - 1u)]; active = p.tileOrder[0].x; }
-    for (uint32_t oi = wg0; oi < active; oi += wgs) {
+    uint32_t active = tilesAll;
+    if (!direct) { firstItem = p.tileOrder[1u + min(wg0, tilesAll - 1u)]; active = p.tileOrder[0].x; }
+    // (bit 31 of the loop's index: not the workgroup's first item -- asked of gridDim.x, "first" was a scalar load from the dispatch
+    // packet and a wait at the top of every item)
+    for (uint32_t oiw = wg0; (oiw & 0x7FFFFFFFu) < active; oiw = ((oiw & 0x7FFFFFFFu) + wgs) | 0x80000000u) {
+    const uint32_t oi = oiw & 0x7FFFFFFFu;
     // (the thread index of this work item goes through an empty asm: whatever the body derives from it is invariant over the
     // item loop, and hoisted out of it those values -- offsets, masks, lane roles -- sat in registers across the whole kernel)
     uint32_t tix = threadIdx.x;
     asm volatile("" : "+v"(tix));
-    // (the workgroup's first item <=> oi < the launch's tile workgroups = gridDim.x - skew; `oi + 1 < gridDim.x` says so without the
-    // skew, and where it errs -- the last workgroup of a launch without one -- the list holds the same item)
-    const uint2 itemCount = oi + 1u < gridDim.x ? firstItem : (direct ? make_uint2(oi, 0u) : p.tileOrder[1u + oi]);
+    const uint2 itemCount = (oiw >> 31) == 0u ? firstItem : (direct ? make_uint2(oi, 0u) : p.tileOrder[1u + oi]);
     const uint32_t item = itemCount.x;
     const uint32_t tileId = item & 0xFFFu, slice = (item >> 12) & 0x3FFu, slices = (item >> 22) + 1u;
     // (kept order: the tile's counter line is read here, and -- the address needs the tile only -- a whole tile's first bin entries
@@ -2779,9 +2784,13 @@ __global__ __launch_bounds__(TB, TILE_MIN_BLOCKS) void raster_tile_kernel(Raster
     const bool entryThread = TILE_BATCH == TB || tix < TILE_BATCH;   // (a batch is TILE_BATCH bin entries, one per thread of the first waves)
     uint32_t countWord = itemCount.y, wordSpec = 0xFFFFFFFFu;
     if (p.orderKept) {
-        const uint4 cnt = *reinterpret_cast<const uint4*>(&p.tileCount[(size_t)tileId * TC_STRIDE]);
-        if (slices == 1u && entryThread) wordSpec = bin[tix];
-        countWord = min(cnt.x, bin_capacity(p)) | (cnt.y ? 0x80000000u : 0u);
+        // (the bin words are asked for whatever the item is -- a slice's first entries are elsewhere and these are dropped --, and the
+        // counter line with a SCALAR load (words 0 and 1: final since the binner ended; the kernel's own atomics touch word 2 only):
+        // under `slices == 1`, and with the line in a vector register the allocator used again for the bin words' address, the compiler
+        // put the fetch it was meant to travel beside behind the wait for the line -- a round trip in front of every tile)
+        if (entryThread) wordSpec = bin[tix];
+        const unsigned long long cnt = scalar_load(reinterpret_cast<const unsigned long long*>(&p.tileCount[(size_t)tileId * TC_STRIDE]));
+        countWord = min((uint32_t)cnt, bin_capacity(p)) | ((uint32_t)(cnt >> 32) ? 0x80000000u : 0u);
     }
     const uint32_t nAll = countWord & 0x3FFFFFFFu;                // (already clamped to the bin capacity)
     if (ABL(p, DBG_SKIP_LIGHT) && nAll < 64u) continue;

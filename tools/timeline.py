@@ -65,10 +65,13 @@ def main(path, min_gaps=None):
         off = statistics.median([iv[k][0] - iv[0][0] for iv in ivs]) / 1e3
         dur = statistics.median([iv[k][1] - iv[k][0] for iv in ivs]) / 1e3
         gap = statistics.median([iv[k][0] - iv[k - 1][1] for iv in ivs]) / 1e3 if k else 0.0
-        print("%8.1f us  dur %7.1f  gap %5.1f  %s" % (off, dur, gap, name))
+        # (the bench alternates two views: a launch whose work differs between them has TWO typical durations and a median that sits on
+        # either -- the second pass's tile kernel read 22.8 us in one trace and 26.2 in the next; mean and quartiles say so)
+        ds = sorted((iv[k][1] - iv[k][0]) / 1e3 for iv in ivs)
+        print("%8.1f us  dur %7.1f  gap %5.1f  %-48s mean %6.1f  quartiles %6.1f .. %6.1f" % (off, dur, gap, name, statistics.fmean(ds), ds[len(ds) // 4], ds[(3 * len(ds)) // 4]))
     span, tot, idle, _ = summary(ivs)
-    print("launches %d: first start to last end %.1f us, sum of kernel durations %.1f us, span - sum %.1f us (medians over %d frames)"
-          % (len(seq), span, tot, idle, len(ivs)))
+    print("launches %d: first start to last end %.1f us, sum of kernel durations %.1f us, span - sum %.1f us (medians over %d frames; mean span %.1f us)"
+          % (len(seq), span, tot, idle, len(ivs), statistics.fmean([iv[-1][1] - iv[0][0] for iv in ivs]) / 1e3))
     # frame to frame: start of a frame to the start of the next (what a timed loop divides by), where consecutive
     per = [(int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp'])) / 1e3 for a, b in zip(starts[:-1], starts[1:])]
     per.sort()
