@@ -122,3 +122,7 @@ for s in glob.glob(os.path.join(G, "%s_rank3" % R, "**", "r_kernel_stats.csv"), 
 md = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--md"], capture_output=True, text=True).stdout
 open(os.path.join(P, "%s_kernel_resources.md" % R), "w").write(md)
 print("collected", R)
+
+# the tile kernel's counters per pass (first passes have one workgroup more: tools/counters_by_pass.py)
+with open(os.path.join(P, "%s_config3_tile_kernel_by_pass.md" % R), "w") as f:
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "counters_by_pass.py"), R], stdout=f)
