@@ -570,6 +570,20 @@ def measure(args, workload, env):
                         "source": "profiles/" + vj[-1], "profile_head": vk.get("profile_head"), "from_committed_profile": True}
             except (KeyError, ValueError):
                 valu = None
+    # The first-pass tile kernel of the 4K street workloads is held to the same lens: its VALU pipes are busy 71 % of the launch (DESIGN 4.2;
+    # per-pass counter rows of the committed passes, tools/counters_by_pass.py -> profiles/*_config3_tile_valu.json).  A committed figure
+    # like `traffic`: counters cannot be read inside this process.
+    if valu is None and dom == "raster_tile_kernel" and wl == "street_4k_hzb" and args.cull != "hierarchical" and not args.debug_flags and not args.no_hzb:
+        vj = sorted(f for f in os.listdir(prof_dir) if f.endswith("config3_tile_valu.json")) if os.path.isdir(prof_dir) else []
+        if vj:
+            try:
+                vk = json.load(open(os.path.join(prof_dir, vj[-1])))
+                valu = {"kernel": vk["kernel"], "insts_per_launch": vk["valu_insts_per_launch"], "busy_cycles_per_launch": vk["busy_cycles_per_launch"],
+                        "clock_ghz_from_busy_cycles": vk["clock_ghz_from_busy_cycles"], "profiled_launch_us": vk["mean_launch_us"],
+                        "issue_frac": vk["valu_busy_frac"], "waves_resident_per_simd": vk["waves_resident_per_simd"], "lanes_active_frac": vk.get("lanes_active_frac"),
+                        "source": "profiles/" + vj[-1], "profile_head": vk.get("profile_head"), "from_committed_profile": True}
+            except (KeyError, ValueError):
+                valu = None
     roofline = {"bound": "hbm", "valu": valu, "kernel": dom + (" (raster_setup_blocks_kernel + raster_setup_kernel)" if dom == "raster_setup_kernel" and blocks > 0 else ""), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_profile_head": traffic_head,          # the commit that profile was taken at: a kernel changed since then leaves `traffic` stale

@@ -30,6 +30,21 @@ print("Source: the per-dispatch rows of the six `rocprofv3 --pmc` passes of `too
 print("2 041 workgroups = a first pass under the schedule the same pass of the frame before made (one workgroup more: it makes the next one);")
 print("2 040 = a direct second pass, or a first pass under a schedule kernel's schedule (the bench's moving-path run with fresh schedules, a context's first frame).\n")
 names = sorted({c for g in agg for c in agg[g]})
+first = max((g for g in agg if len(dur[g]) >= 8), default=None)          # the first passes under a kept schedule: the larger grid
+if first is not None and "SQ_BUSY_CYCLES" in agg[first] and "SQ_INSTS_VALU" in agg[first]:
+    import json
+    import subprocess
+    m = {c: sum(x) / len(x) for c, x in agg[first].items()}
+    cyc = m["SQ_BUSY_CYCLES"] / 32.0
+    head = os.environ.get("PROFILE_HEAD") or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()   # (the commit the counter passes ran at)
+    json.dump({"kernel": "raster_tile_kernel, first pass of a config-3 frame (launches of %d workgroups)" % first, "workload": "street_4k_hzb",
+               "valu_insts_per_launch": round(m["SQ_INSTS_VALU"]), "salu_insts_per_launch": round(m.get("SQ_INSTS_SALU", 0)),
+               "busy_cycles_per_launch": round(cyc), "clock_ghz_from_busy_cycles": round(cyc / (sum(dur[first]) / len(dur[first])) / 1e3, 3),
+               "mean_launch_us": round(sum(dur[first]) / len(dur[first]), 2), "simds": 1024, "cycles_per_wave64_instruction": 4,
+               "valu_busy_frac": round(m["SQ_INSTS_VALU"] / 1024 * 4 / cyc, 4),
+               "waves_resident_per_simd": round(m.get("SQ_WAVE_CYCLES", 0) * 4 / 1024 / cyc, 2),
+               "lanes_active_frac": round(m["SQ_THREAD_CYCLES_VALU"] / (m["SQ_ACTIVE_INST_VALU"] * 64), 4) if "SQ_THREAD_CYCLES_VALU" in m and m.get("SQ_ACTIVE_INST_VALU") else None,
+               "profile_head": head}, open(os.path.join(ROOT, "profiles", "%s_config3_tile_valu.json" % R), "w"), indent=1)
 for g in sorted(agg, reverse=True):
     if len(dur[g]) < 8:
         continue
